@@ -1,0 +1,223 @@
+// oracle/oracle_capi.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// C ABI over the CPU oracle (kb_field.hpp / kb_hash.hpp / kb_pcs.hpp / kb_zerocheck.hpp) so that
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive it through ctypes.
+// Nothing in sp1_amd/ (the product) may link, load or call this library.
+// All field words crossing this ABI are Montgomery u32 (R = 2^32) unless a name says "canonical".
+#include <cstdio>
+#include <cstdlib>
+
+#include "kb_pcs.hpp"
+
+using namespace orc;
+
+static inline const F* FP(const uint32_t* p) { return reinterpret_cast<const F*>(p); }
+static inline F* FP(uint32_t* p) { return reinterpret_cast<F*>(p); }
+static inline E load_e(const uint32_t* p) { E e; memcpy(&e, p, 16); return e; }
+static inline Digest load_d(const uint32_t* p) { Digest d; memcpy(&d, p, 32); return d; }
+
+extern "C" {
+
+// ---- field ----------------------------------------------------------------------------------
+void orc_to_monty(uint32_t* x, size_t n) { for (size_t i = 0; i < n; i++) x[i] = F::from_canonical(x[i]).v; }
+void orc_from_monty(uint32_t* x, size_t n) { for (size_t i = 0; i < n; i++) x[i] = F::raw(x[i]).canonical(); }
+uint32_t orc_two_adic_generator(int bits) { return two_adic_generator(bits).v; }
+void orc_ext_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { E r = load_e(a) * load_e(b); memcpy(out, &r, 16); }
+void orc_ext_inv(const uint32_t* a, uint32_t* out) { E r = einv(load_e(a)); memcpy(out, &r, 16); }
+
+// ---- hash -----------------------------------------------------------------------------------
+void orc_permute(uint32_t* s16) { permute(FP(s16)); }
+void orc_hash(const uint32_t* in, size_t n, uint32_t* out8) { Digest d = hash_slice(FP(in), n); memcpy(out8, &d, 32); }
+void orc_compress(const uint32_t* l, const uint32_t* r, uint32_t* out8) {
+    Digest d = compress(load_d(l), load_d(r));
+    memcpy(out8, &d, 32);
+}
+
+// ---- challenger -----------------------------------------------------------------------------
+void* orc_challenger_new() { return new Challenger(); }
+void* orc_challenger_clone(void* c) { return new Challenger(*static_cast<Challenger*>(c)); }
+void orc_challenger_free(void* c) { delete static_cast<Challenger*>(c); }
+void orc_challenger_observe(void* c, const uint32_t* x, size_t n) {
+    for (size_t i = 0; i < n; i++) static_cast<Challenger*>(c)->observe(F::raw(x[i]));
+}
+uint32_t orc_challenger_sample(void* c) { return static_cast<Challenger*>(c)->sample().v; }
+void orc_challenger_sample_ext(void* c, uint32_t* out4) { E e = static_cast<Challenger*>(c)->sample_ext(); memcpy(out4, &e, 16); }
+uint32_t orc_challenger_sample_bits(void* c, int bits) { return static_cast<Challenger*>(c)->sample_bits(bits); }
+uint32_t orc_challenger_grind(void* c, int bits) { return static_cast<Challenger*>(c)->grind(bits).v; }
+int orc_challenger_check_witness(void* c, int bits, uint32_t w) { return static_cast<Challenger*>(c)->check_witness(bits, F::raw(w)); }
+// state dump: 16 sponge words, n_in, in[8], n_out, out[8]  (34 words)
+void orc_challenger_state(void* c, uint32_t* out34) {
+    Challenger* ch = static_cast<Challenger*>(c);
+    memset(out34, 0, 34 * 4);
+    for (int i = 0; i < 16; i++) out34[i] = ch->state[i].v;
+    out34[16] = (uint32_t)ch->in.size();
+    for (size_t i = 0; i < ch->in.size(); i++) out34[17 + i] = ch->in[i].v;
+    out34[25] = (uint32_t)ch->out.size();
+    for (size_t i = 0; i < ch->out.size(); i++) out34[26 + i] = ch->out[i].v;
+}
+
+// ---- RS encode / folds / multilinear ----------------------------------------------------------
+void orc_rs_encode(const uint32_t* in, int log_n, int w, int log_blowup, uint32_t* out) {
+    rs_encode(FP(in), log_n, w, log_blowup, FP(out));
+}
+void orc_fold_even_odd(const uint32_t* cw, int log_N, const uint32_t* beta, uint32_t* out) {
+    std::vector<E> v((size_t)1 << log_N);
+    memcpy(v.data(), cw, v.size() * 16);
+    std::vector<E> r = fold_even_odd(v, load_e(beta));
+    memcpy(out, r.data(), r.size() * 16);
+}
+void orc_fold_mle(const uint32_t* m, int log_n, const uint32_t* beta, uint32_t* out) {
+    std::vector<E> v((size_t)1 << log_n);
+    memcpy(v.data(), m, v.size() * 16);
+    std::vector<E> r = fold_mle(v, load_e(beta));
+    memcpy(out, r.data(), r.size() * 16);
+}
+void orc_partial_lagrange(const uint32_t* point, int dim, uint32_t* out) {
+    std::vector<E> p(dim);
+    memcpy(p.data(), point, (size_t)dim * 16);
+    std::vector<E> r = partial_lagrange(p);
+    memcpy(out, r.data(), r.size() * 16);
+}
+void orc_eval_mle(const uint32_t* mle, int log_n, int w, const uint32_t* point, uint32_t* out) {
+    std::vector<E> p(log_n);
+    memcpy(p.data(), point, (size_t)log_n * 16);
+    std::vector<E> r = eval_mle_at_point(FP(mle), (size_t)1 << log_n, w, p);
+    memcpy(out, r.data(), r.size() * 16);
+}
+
+// ---- Merkle tensor commitment ---------------------------------------------------------------
+void* orc_merkle_commit(const uint32_t** tensors, const int* widths, int n, size_t height, uint32_t* commit8) {
+    std::vector<TensorRef> ts;
+    for (int i = 0; i < n; i++) ts.push_back({FP(tensors[i]), height, widths[i]});
+    MerkleTree* mt = new MerkleTree(merkle_commit(ts));
+    memcpy(commit8, &mt->commit, 32);
+    return mt;
+}
+void orc_merkle_free(void* t) { delete static_cast<MerkleTree*>(t); }
+// leaf-first concatenated layers: (2*height - 1) digests
+void orc_merkle_layers(void* t, uint32_t* out) {
+    MerkleTree* mt = static_cast<MerkleTree*>(t);
+    size_t o = 0;
+    for (auto& l : mt->layers) { memcpy(out + o * 8, l.data(), l.size() * 32); o += l.size(); }
+}
+void orc_merkle_root(void* t, uint32_t* out8) { memcpy(out8, &static_cast<MerkleTree*>(t)->root, 32); }
+// paths out: [n_idx][log_height][8]
+void orc_merkle_paths(void* t, const uint64_t* idx, size_t n_idx, uint32_t* out) {
+    std::vector<size_t> v(idx, idx + n_idx);
+    TcsProof p = merkle_prove_openings(*static_cast<MerkleTree*>(t), v);
+    memcpy(out, p.paths.data(), p.paths.size() * 32);
+}
+int orc_merkle_verify(const uint32_t* commit8, const uint64_t* idx, size_t n_idx, const uint32_t* values, size_t width,
+                      size_t log_height, const uint32_t* root8, const uint32_t* paths) {
+    TcsProof p;
+    p.merkle_root = load_d(root8);
+    p.log_tensor_height = log_height;
+    p.width = width;
+    p.paths.resize(n_idx * log_height);
+    memcpy(p.paths.data(), paths, p.paths.size() * 32);
+    std::vector<size_t> v(idx, idx + n_idx);
+    return (int)merkle_verify(load_d(commit8), v, FP(values), width, width, log_height, p);
+}
+
+// ---- BaseFold -------------------------------------------------------------------------------
+struct PdHandle { std::shared_ptr<BasefoldProverData> pd; };
+
+void* orc_commit_mles(const uint32_t** mles, const int* widths, int n, int log_n, int log_blowup, uint32_t* commit8) {
+    std::vector<MleRef> ms;
+    for (int i = 0; i < n; i++) ms.push_back({FP(mles[i]), log_n, widths[i]});
+    FriConfig cfg;
+    cfg.log_blowup = log_blowup;
+    PdHandle* h = new PdHandle{commit_mles(ms, cfg)};
+    memcpy(commit8, &h->pd->tree.commit, 32);
+    return h;
+}
+void orc_pd_free(void* h) { delete static_cast<PdHandle*>(h); }
+void orc_pd_codeword(void* h, int k, uint32_t* out) {
+    auto& cw = static_cast<PdHandle*>(h)->pd->codewords[k];
+    memcpy(out, cw.data(), cw.size() * 4);
+}
+void orc_pd_layers(void* h, uint32_t* out) { orc_merkle_layers(&static_cast<PdHandle*>(h)->pd->tree, out); }
+
+// mles / widths / pds are flattened over rounds; mles_per_round[r] gives the split.
+// claims: one ext per column, flattened round -> mle -> column.
+// returns the proof length; writes at most cap bytes (call with cap = 0 to size).
+size_t orc_basefold_prove(const uint32_t* point, int dim, int n_rounds, const int* mles_per_round,
+                          const uint32_t** mles, const int* widths, const uint32_t* claims, void** pds,
+                          int log_blowup, int num_queries, int pow_bits, void* challenger, uint8_t* out, size_t cap) {
+    std::vector<E> pt(dim);
+    memcpy(pt.data(), point, (size_t)dim * 16);
+    std::vector<std::vector<MleRef>> rounds;
+    std::vector<std::vector<std::vector<E>>> cl;
+    std::vector<std::shared_ptr<BasefoldProverData>> pdata;
+    int k = 0;
+    size_t co = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        rounds.emplace_back();
+        cl.emplace_back();
+        for (int m = 0; m < mles_per_round[r]; m++, k++) {
+            rounds.back().push_back({FP(mles[k]), dim, widths[k]});
+            std::vector<E> ev(widths[k]);
+            memcpy(ev.data(), claims + co * 4, ev.size() * 16);
+            co += widths[k];
+            cl.back().push_back(std::move(ev));
+        }
+        pdata.push_back(static_cast<PdHandle*>(pds[r])->pd);
+    }
+    FriConfig cfg{log_blowup, num_queries, pow_bits};
+    BasefoldProof p = basefold_prove(pt, rounds, cl, pdata, cfg, *static_cast<Challenger*>(challenger));
+    std::vector<uint8_t> b = serialize_proof(p);
+    if (b.size() <= cap) memcpy(out, b.data(), b.size());
+    return b.size();
+}
+
+// returns 0 on success, BfError code otherwise, -1 on malformed blob
+int orc_basefold_verify(const uint32_t* commitments, int n_rounds, const uint32_t* point, int dim,
+                        const uint32_t* claims, const int* claims_per_round, const uint8_t* blob, size_t len,
+                        int log_blowup, int num_queries, int pow_bits, void* challenger) {
+    try {
+        BasefoldProof p = deserialize_proof(blob, len);
+        std::vector<Digest> cs(n_rounds);
+        memcpy(cs.data(), commitments, (size_t)n_rounds * 32);
+        std::vector<E> pt(dim);
+        memcpy(pt.data(), point, (size_t)dim * 16);
+        std::vector<std::vector<E>> cl;
+        size_t co = 0;
+        for (int r = 0; r < n_rounds; r++) {
+            std::vector<E> ev(claims_per_round[r]);
+            memcpy(ev.data(), claims + co * 4, ev.size() * 16);
+            co += ev.size();
+            cl.push_back(std::move(ev));
+        }
+        FriConfig cfg{log_blowup, num_queries, pow_bits};
+        return (int)basefold_verify(cs, pt, cl, p, cfg, *static_cast<Challenger*>(challenger));
+    } catch (const std::exception& e) {
+        return -1;
+    }
+}
+
+// ---- stacked interleave + jagged wrapper ------------------------------------------------------
+// returns number of batches; if out != NULL writes batches back-to-back (each [2^lsh][w_b] row-major)
+// and their widths into out_widths.
+size_t orc_interleave(const uint32_t** tables, const uint64_t* rows, const int* cols, int n, size_t batch_size,
+                      int lsh, uint32_t* out, int* out_widths) {
+    std::vector<TensorRef> ts;
+    for (int i = 0; i < n; i++) ts.push_back({FP(tables[i]), (size_t)rows[i], cols[i]});
+    auto bs = interleave_fixed_rate(batch_size, ts, lsh);
+    if (out) {
+        size_t o = 0;
+        for (size_t i = 0; i < bs.size(); i++) {
+            memcpy(out + o, bs[i].data.data(), bs[i].data.size() * 4);
+            o += bs[i].data.size();
+            out_widths[i] = bs[i].width;
+        }
+    }
+    return bs.size();
+}
+void orc_jagged_commit_wrap(const uint32_t* commit8, const uint64_t* rows, const uint64_t* cols, int n,
+                            uint64_t num_added_vals, int max_log_row_count, uint32_t* out8) {
+    Digest d = jagged_commit_wrap(load_d(commit8), std::vector<size_t>(rows, rows + n),
+                                  std::vector<size_t>(cols, cols + n), num_added_vals, max_log_row_count);
+    memcpy(out8, &d, 32);
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+All arrays are numpy uint32 in Montgomery form (R = 2^32) unless a name says canonical.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".hpp", ".cpp", ".inc"))]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_two_adic_generator.restype = C.c_uint32
+        L.orc_challenger_new.restype = C.c_void_p
+        L.orc_challenger_clone.restype = C.c_void_p
+        L.orc_challenger_clone.argtypes = [C.c_void_p]
+        L.orc_challenger_free.argtypes = [C.c_void_p]
+        L.orc_challenger_observe.argtypes = [C.c_void_p, u32p, C.c_size_t]
+        L.orc_challenger_sample.argtypes = [C.c_void_p]
+        L.orc_challenger_sample.restype = C.c_uint32
+        L.orc_challenger_sample_ext.argtypes = [C.c_void_p, u32p]
+        L.orc_challenger_sample_bits.argtypes = [C.c_void_p, C.c_int]
+        L.orc_challenger_sample_bits.restype = C.c_uint32
+        L.orc_challenger_grind.argtypes = [C.c_void_p, C.c_int]
+        L.orc_challenger_grind.restype = C.c_uint32
+        L.orc_challenger_check_witness.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        L.orc_challenger_state.argtypes = [C.c_void_p, u32p]
+        L.orc_merkle_commit.restype = C.c_void_p
+        L.orc_merkle_commit.argtypes = [C.POINTER(u32p), C.POINTER(C.c_int), C.c_int, C.c_size_t, u32p]
+        L.orc_merkle_free.argtypes = [C.c_void_p]
+        L.orc_merkle_layers.argtypes = [C.c_void_p, u32p]
+        L.orc_merkle_root.argtypes = [C.c_void_p, u32p]
+        L.orc_merkle_paths.argtypes = [C.c_void_p, u64p, C.c_size_t, u32p]
+        L.orc_merkle_verify.argtypes = [u32p, u64p, C.c_size_t, u32p, C.c_size_t, C.c_size_t, u32p, u32p]
+        L.orc_commit_mles.restype = C.c_void_p
+        L.orc_commit_mles.argtypes = [C.POINTER(u32p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, u32p]
+        L.orc_pd_free.argtypes = [C.c_void_p]
+        L.orc_pd_codeword.argtypes = [C.c_void_p, C.c_int, u32p]
+        L.orc_pd_layers.argtypes = [C.c_void_p, u32p]
+        L.orc_basefold_prove.restype = C.c_size_t
+        L.orc_basefold_prove.argtypes = [u32p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(u32p),
+                                         C.POINTER(C.c_int), u32p, C.POINTER(C.c_void_p), C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
+        L.orc_basefold_verify.argtypes = [u32p, C.c_int, u32p, C.c_int, u32p, C.POINTER(C.c_int),
+                                          C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_interleave.restype = C.c_size_t
+        L.orc_interleave.argtypes = [C.POINTER(u32p), u64p, C.POINTER(C.c_int), C.c_int, C.c_size_t, C.c_int,
+                                     u32p, C.POINTER(C.c_int)]
+        L.orc_jagged_commit_wrap.argtypes = [u32p, u64p, u64p, C.c_int, C.c_uint64, C.c_int, u32p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def _arr(x):
+    return np.ascontiguousarray(x, dtype=np.uint32)
+
+
+P = 0x7F000001
+
+
+def to_monty(x):
+    a = _arr(x).copy()
+    lib().orc_to_monty(_p(a), C.c_size_t(a.size))
+    return a
+
+
+def from_monty(x):
+    a = _arr(x).copy()
+    lib().orc_from_monty(_p(a), C.c_size_t(a.size))
+    return a
+
+
+def random_felts(shape, seed):
+    """SplitMix64(seed) stream reduced mod p, returned in Montgomery form."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    canon = (z % np.uint64(P)).astype(np.uint32)
+    return to_monty(canon).reshape(shape)
+
+
+def permute(state):
+    s = _arr(state).copy()
+    lib().orc_permute(_p(s))
+    return s
+
+
+def hash_felts(xs):
+    xs = _arr(xs)
+    out = np.zeros(8, np.uint32)
+    lib().orc_hash(_p(xs) if xs.size else None, C.c_size_t(xs.size), _p(out))
+    return out
+
+
+def compress(l, r):
+    out = np.zeros(8, np.uint32)
+    lib().orc_compress(_p(_arr(l)), _p(_arr(r)), _p(out))
+    return out
+
+
+def ext_mul(a, b):
+    out = np.zeros(4, np.uint32)
+    lib().orc_ext_mul(_p(_arr(a)), _p(_arr(b)), _p(out))
+    return out
+
+
+def ext_inv(a):
+    out = np.zeros(4, np.uint32)
+    lib().orc_ext_inv(_p(_arr(a)), _p(out))
+    return out
+
+
+def rs_encode(mle, log_blowup):
+    """mle: [n][w] row-major -> [n << log_blowup][w], rows bit-reversed."""
+    mle = _arr(mle)
+    n, w = mle.shape
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    out = np.zeros((n << log_blowup, w), np.uint32)
+    lib().orc_rs_encode(_p(mle), log_n, w, log_blowup, _p(out))
+    return out
+
+
+def fold_even_odd(cw, beta):
+    cw = _arr(cw)
+    N = cw.shape[0]
+    out = np.zeros((N // 2, 4), np.uint32)
+    lib().orc_fold_even_odd(_p(cw), N.bit_length() - 1, _p(_arr(beta)), _p(out))
+    return out
+
+
+def fold_mle(m, beta):
+    m = _arr(m)
+    n = m.shape[0]
+    out = np.zeros((n // 2, 4), np.uint32)
+    lib().orc_fold_mle(_p(m), n.bit_length() - 1, _p(_arr(beta)), _p(out))
+    return out
+
+
+def partial_lagrange(point):
+    point = _arr(point).reshape(-1, 4)
+    out = np.zeros((1 << point.shape[0], 4), np.uint32)
+    lib().orc_partial_lagrange(_p(point), point.shape[0], _p(out))
+    return out
+
+
+def eval_mle(mle, point):
+    mle = _arr(mle)
+    n, w = mle.shape
+    point = _arr(point).reshape(-1, 4)
+    assert 1 << point.shape[0] == n
+    out = np.zeros((w, 4), np.uint32)
+    lib().orc_eval_mle(_p(mle), point.shape[0], w, _p(point), _p(out))
+    return out
+
+
+def _ptr_array(arrs):
+    return (u32p * len(arrs))(*[_p(a) for a in arrs])
+
+
+class MerkleTree:
+    def __init__(self, tensors):
+        self.tensors = [_arr(t) for t in tensors]
+        self.height = self.tensors[0].shape[0]
+        widths = (C.c_int * len(tensors))(*[t.shape[1] for t in self.tensors])
+        self.commit = np.zeros(8, np.uint32)
+        self.h = lib().orc_merkle_commit(_ptr_array(self.tensors), widths, len(tensors),
+                                         C.c_size_t(self.height), _p(self.commit))
+        self.log_height = self.height.bit_length() - 1
+
+    def layers(self):
+        out = np.zeros((2 * self.height - 1, 8), np.uint32)
+        lib().orc_merkle_layers(self.h, _p(out))
+        return out
+
+    def root(self):
+        out = np.zeros(8, np.uint32)
+        lib().orc_merkle_root(self.h, _p(out))
+        return out
+
+    def paths(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.zeros((len(idx), self.log_height, 8), np.uint32)
+        lib().orc_merkle_paths(self.h, idx.ctypes.data_as(u64p), C.c_size_t(len(idx)), _p(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_merkle_free(self.h)
+            self.h = None
+
+
+def merkle_verify(commit, idx, values, log_height, root, paths):
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    values = _arr(values)
+    return lib().orc_merkle_verify(_p(_arr(commit)), idx.ctypes.data_as(u64p), C.c_size_t(len(idx)), _p(values),
+                                   C.c_size_t(values.shape[1]), C.c_size_t(log_height), _p(_arr(root)),
+                                   _p(_arr(paths)))
+
+
+class Challenger:
+    def __init__(self, h=None):
+        self.h = h if h is not None else lib().orc_challenger_new()
+
+    def clone(self):
+        return Challenger(lib().orc_challenger_clone(self.h))
+
+    def observe(self, xs):
+        xs = _arr(xs).reshape(-1)
+        lib().orc_challenger_observe(self.h, _p(xs), C.c_size_t(xs.size))
+
+    def sample(self):
+        return lib().orc_challenger_sample(self.h)
+
+    def sample_ext(self):
+        out = np.zeros(4, np.uint32)
+        lib().orc_challenger_sample_ext(self.h, _p(out))
+        return out
+
+    def sample_point(self, n):
+        return np.stack([self.sample_ext() for _ in range(n)]) if n else np.zeros((0, 4), np.uint32)
+
+    def sample_bits(self, bits):
+        return lib().orc_challenger_sample_bits(self.h, bits)
+
+    def grind(self, bits):
+        return lib().orc_challenger_grind(self.h, bits)
+
+    def check_witness(self, bits, w):
+        return bool(lib().orc_challenger_check_witness(self.h, bits, C.c_uint32(int(w))))
+
+    def state(self):
+        out = np.zeros(34, np.uint32)
+        lib().orc_challenger_state(self.h, _p(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_challenger_free(self.h)
+            self.h = None
+
+
+class CommittedRound:
+    """BasefoldProver::commit_mles on the CPU oracle for one commitment round."""
+
+    def __init__(self, mles, log_blowup):
+        self.mles = [_arr(m) for m in mles]
+        n = self.mles[0].shape[0]
+        self.log_n = n.bit_length() - 1
+        self.log_blowup = log_blowup
+        widths = (C.c_int * len(mles))(*[m.shape[1] for m in self.mles])
+        self.commit = np.zeros(8, np.uint32)
+        self.h = lib().orc_commit_mles(_ptr_array(self.mles), widths, len(mles), self.log_n, log_blowup,
+                                       _p(self.commit))
+
+    def codeword(self, k):
+        out = np.zeros((1 << (self.log_n + self.log_blowup), self.mles[k].shape[1]), np.uint32)
+        lib().orc_pd_codeword(self.h, k, _p(out))
+        return out
+
+    def layers(self):
+        N = 1 << (self.log_n + self.log_blowup)
+        out = np.zeros((2 * N - 1, 8), np.uint32)
+        lib().orc_pd_layers(self.h, _p(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pd_free(self.h)
+            self.h = None
+
+
+def basefold_prove(point, rounds, claims, challenger, log_blowup=2, num_queries=124, pow_bits=16):
+    """rounds: list[CommittedRound]; claims: list (per round) of list (per mle) of [w][4] arrays."""
+    point = _arr(point).reshape(-1, 4)
+    mles, widths, per_round = [], [], []
+    for r in rounds:
+        per_round.append(len(r.mles))
+        for m in r.mles:
+            mles.append(m)
+            widths.append(m.shape[1])
+    flat_claims = _arr(np.concatenate([np.asarray(c, np.uint32).reshape(-1, 4) for rc in claims for c in rc]))
+    pds = (C.c_void_p * len(rounds))(*[r.h for r in rounds])
+    args = (_p(point), point.shape[0], len(rounds), (C.c_int * len(rounds))(*per_round), _ptr_array(mles),
+            (C.c_int * len(widths))(*widths), _p(flat_claims), pds, log_blowup, num_queries, pow_bits)
+    probe = challenger.clone()
+    size = lib().orc_basefold_prove(*args, probe.h, None, C.c_size_t(0))
+    buf = (C.c_uint8 * size)()
+    got = lib().orc_basefold_prove(*args, challenger.h, buf, C.c_size_t(size))
+    assert got == size
+    return bytes(buf)
+
+
+def basefold_verify(commitments, point, claims_per_round, blob, challenger, log_blowup=2, num_queries=124,
+                    pow_bits=16):
+    """claims_per_round: list (per round) of [total_cols][4] arrays. Returns 0 when the proof verifies."""
+    point = _arr(point).reshape(-1, 4)
+    commitments = _arr(np.stack(commitments))
+    flat = _arr(np.concatenate([np.asarray(c, np.uint32).reshape(-1, 4) for c in claims_per_round]))
+    counts = (C.c_int * len(claims_per_round))(*[np.asarray(c).reshape(-1, 4).shape[0] for c in claims_per_round])
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    return lib().orc_basefold_verify(_p(commitments), commitments.shape[0], _p(point), point.shape[0], _p(flat),
+                                     counts, buf, C.c_size_t(len(blob)), log_blowup, num_queries, pow_bits,
+                                     challenger.h)
+
+
+def interleave(tables, batch_size, lsh):
+    tables = [_arr(t) for t in tables]
+    rows = (C.c_uint64 * len(tables))(*[t.shape[0] for t in tables])
+    cols = (C.c_int * len(tables))(*[t.shape[1] for t in tables])
+    nb = lib().orc_interleave(_ptr_array(tables), rows, cols, len(tables), C.c_size_t(batch_size), lsh, None, None)
+    area = sum(t.size for t in tables)
+    H = 1 << lsh
+    padded = -(-area // H) * H
+    out = np.zeros(max(padded, 1), np.uint32)
+    widths = (C.c_int * nb)()
+    lib().orc_interleave(_ptr_array(tables), rows, cols, len(tables), C.c_size_t(batch_size), lsh, _p(out), widths)
+    res, o = [], 0
+    for w in widths:
+        res.append(out[o:o + H * w].reshape(H, w).copy())
+        o += H * w
+    return res
+
+
+def jagged_commit_wrap(commit, rows, cols, num_added_vals, max_log_row_count):
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    out = np.zeros(8, np.uint32)
+    lib().orc_jagged_commit_wrap(_p(_arr(commit)), rows.ctypes.data_as(u64p), cols.ctypes.data_as(u64p), len(rows),
+                                 C.c_uint64(num_added_vals), max_log_row_count, _p(out))
+    return out

@@ -1,0 +1,137 @@
+"""Pin the C++ oracle against (a) the SURVEY App. A known answers and (b) real reference proof data.
+
+The fixture tests/golden/kb_shrink_basefold.npz was extracted (tests/golden/make_golden.py) from the
+reference's own bincode'd KoalaBear ShardProof; every check below recomputes reference-produced
+values with the oracle, mirroring MerkleTreeTcs::verify_tensor_openings
+(/root/reference/slop/crates/merkle-tree/src/tcs.rs:L102-L188) and BasefoldVerifier::verify_queries
+(/root/reference/slop/crates/basefold/src/verifier.rs:L323-L388).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import kb_py
+import pyoracle as orc
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "kb_shrink_basefold.npz"))
+
+
+def M(x):
+    return orc.to_monty(np.asarray(x, dtype=np.uint32))
+
+
+def C(x):
+    return orc.from_monty(x)
+
+
+def test_perm_known_answers():
+    assert list(C(orc.permute(M([0] * 16)))) == kb_py.KAT_PERM_ZERO
+    assert list(C(orc.permute(M(list(range(16)))))[:4]) == [1028402160, 1336023551, 1247226230, 452505083]
+    assert list(C(orc.hash_felts(M(list(range(25)))))) == [444506572, 1820118882, 1048264750, 1665664460, 60694769,
+                                                           37675321, 1163273259, 1066018793]
+    assert list(C(orc.hash_felts(np.zeros(0, np.uint32)))) == [0] * 8
+    assert list(C(orc.compress(M(list(range(1, 9))), M(list(range(9, 17)))))) == [
+        2115774688, 334764439, 1420131345, 1472047880, 698378043, 636332800, 745080339, 1563288451]
+
+
+def test_field_constants():
+    assert int(C(np.array([orc.lib().orc_two_adic_generator(24)], np.uint32))[0]) == 0x6AC49F88
+    g = kb_py.two_adic_generator(24)
+    assert pow(g, 1 << 23, kb_py.P) == kb_py.P - 1
+
+
+def test_perm_matches_python_random():
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        s = rng.integers(0, kb_py.P, 16).tolist()
+        assert list(C(orc.permute(M(s)))) == kb_py.permute(s)
+    for n in (1, 7, 8, 9, 16, 34, 52):
+        xs = rng.integers(0, kb_py.P, n).tolist()
+        assert list(C(orc.hash_felts(M(xs)))) == kb_py.hash_felts(xs)
+
+
+def test_ext_field_matches_python():
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        a = rng.integers(0, kb_py.P, 4).tolist()
+        b = rng.integers(0, kb_py.P, 4).tolist()
+        assert list(C(orc.ext_mul(M(a), M(b)))) == kb_py.ext_mul(a, b)
+        assert list(C(orc.ext_inv(M(a)))) == kb_py.ext_inv(a)
+
+
+def _openings():
+    for k in range(2):
+        yield ("comp%d" % k, 22, GOLD["comp%d_values" % k], GOLD["comp%d_paths" % k], GOLD["comp%d_root" % k],
+               GOLD["mt_commits"][k], 0)
+    for r in range(20):
+        yield ("round%02d" % r, 21 - r, GOLD["round%02d_values" % r], GOLD["round%02d_paths" % r],
+               GOLD["round%02d_root" % r], GOLD["fri_commitments"][r], r + 1)
+
+
+def test_golden_merkle_openings_verify():
+    """Every kept leaf of the real proof hashes up its path to the stored root and commitment."""
+    q = GOLD["query_indices"].astype(np.uint64)
+    for name, log_h, values, paths, root, commit, shift in _openings():
+        rc = orc.merkle_verify(M(commit), q >> np.uint64(shift), M(values), log_h, M(root), M(paths))
+        assert rc == 0, (name, rc)
+        bad = values.copy()
+        bad[3, 0] = (int(bad[3, 0]) + 1) % kb_py.P
+        assert orc.merkle_verify(M(commit), q >> np.uint64(shift), M(bad), log_h, M(root), M(paths)) == 1  # RootMismatch
+        assert orc.merkle_verify(M(commit), q >> np.uint64(shift), M(values), log_h + 1, M(root), M(paths)) != 0
+
+
+def test_golden_jagged_commitment_chain():
+    """compress(commit, hash([n, rows.., cols..])) — jagged/src/prover.rs:L141-L149."""
+    for k, final in enumerate((GOLD["vk_preprocessed_commit"], GOLD["main_commitment"])):
+        rows = GOLD["row_counts"][k].astype(np.uint64)
+        cols = GOLD["col_counts"][k].astype(np.uint64)
+        # the stored counts already include the two padding tables; undo them to drive the wrapper
+        M_ = 1 << 21
+        assert rows[-2] == M_ and cols[-1] == 1
+        num_added_cols = int(cols[-2]) + 1
+        num_added_vals = int(rows[-1]) + (num_added_cols - 1) * M_
+        got = orc.jagged_commit_wrap(M(GOLD["mt_commits"][k]), rows[:-2], cols[:-2], num_added_vals, 21)
+        assert list(C(got)) == list(final)
+
+
+def test_golden_fold_even_odd_formula():
+    """fold_even_odd on a 2-element slice reproduces the next round's opened value for every kept query."""
+    q = GOLD["query_indices"].astype(np.int64)
+    for r in range(20):
+        lh = 22 - r
+        vals = GOLD["round%02d_values" % r]
+        beta = M(GOLD["betas"][r])
+        for k in range(len(q)):
+            i = int(q[k]) >> r
+            # place the opened pair at its true position of a full-size codeword? Too big; instead use
+            # the oracle's per-pair identity: fold_even_odd of codeword c at pair index j only depends on
+            # (c[2j], c[2j+1], x_j). Build a tiny codeword of the same log size lazily: use kb_py.
+            x0 = pow(kb_py.two_adic_generator(lh), kb_py.reverse_bits_len((i >> 1) << 1, lh), kb_py.P)
+            e0, e1 = [int(v) for v in vals[k][:4]], [int(v) for v in vals[k][4:]]
+            want = kb_py.fold_query(e0, e1, [int(v) for v in GOLD["betas"][r]], x0)
+            if r + 1 < 20:
+                nxt = GOLD["round%02d_values" % (r + 1)][k]
+                j = (int(q[k]) >> (r + 1)) & 1
+                assert want == [int(v) for v in nxt[4 * j:4 * j + 4]]
+            else:
+                assert want == [int(v) for v in GOLD["final_poly"]]
+        # and the C++ oracle's vector fold agrees with that formula on a small synthetic codeword
+    rng = np.random.default_rng(3)
+    for log_n in (1, 2, 5):
+        cw = rng.integers(0, kb_py.P, (1 << log_n, 4)).astype(np.uint32)
+        beta = rng.integers(0, kb_py.P, 4).astype(np.uint32)
+        got = C(orc.fold_even_odd(M(cw), M(beta)))
+        for j in range(1 << (log_n - 1)):
+            x0 = pow(kb_py.two_adic_generator(log_n), kb_py.reverse_bits_len(2 * j, log_n), kb_py.P)
+            want = kb_py.fold_query(cw[2 * j].tolist(), cw[2 * j + 1].tolist(), beta.tolist(), x0)
+            assert got[j].tolist() == want
+
+
+def test_golden_final_poly_consistency():
+    last = GOLD["uni"][-1]
+    beta = GOLD["betas"][-1]
+    got = kb_py.ext_add(last[0].tolist(), kb_py.ext_mul(beta.tolist(), last[1].tolist()))
+    assert got == GOLD["final_poly"].tolist()
+    got_c = C(orc.ext_mul(M(beta), M(last[1])))
+    assert [(int(a) + int(b)) % kb_py.P for a, b in zip(got_c, last[0])] == GOLD["final_poly"].tolist()
