@@ -1,0 +1,197 @@
+/* include/sp1hip.h — C ABI of libsp1hip.so, the MI355X (gfx950) backend for SP1's core-shard
+ * commit/open hot path.
+ *
+ * This is the drop-in boundary: plain `extern "C"` functions, raw device pointers, sizes, no C++ or
+ * torch types. It follows the conventions of the reference's own GPU FFI crate `sp1-gpu-sys`
+ * (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L3-L172): the caller owns every buffer,
+ * every compute call is asynchronous on the given stream, field elements are u32 words in
+ * Montgomery form (R = 2^32) exactly as `KoalaBear` is laid out in Rust memory, extension elements
+ * are 4 consecutive words. A Rust crate wraps these the way `sp1-gpu-cudart` wraps `sp1-gpu-sys`
+ * (see INTEGRATION.md).
+ *
+ * Device layouts:
+ *   base tensor   [height x width]  COLUMN-major: word (row r, col c) at  c*height + r
+ *   ext vector    [len]             4 base columns (SoA): coordinate k of element i at k*len + i
+ *   digest        8 words, array-of-structs
+ *   Merkle tree   leaf-first layers back to back: 2^h leaf digests, 2^(h-1) parents, ..., root;
+ *                 (2^(h+1) - 1) digests in total
+ *
+ * Every function returns SP1HIP_SUCCESS (0) or a negative sp1hip_status; the message for the
+ * calling thread's last failure is sp1hip_last_error(). Nothing throws across this ABI.
+ */
+#ifndef SP1HIP_H
+#define SP1HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SP1HIP_SUCCESS = 0,
+    SP1HIP_ERROR_INVALID_ARGUMENT = -1,
+    SP1HIP_ERROR_OUT_OF_MEMORY = -2,   /* cf. CUDA_OUT_OF_MEMORY,       runtime.rs:L3-L15 */
+    SP1HIP_ERROR_NOT_READY = -3,       /* cf. CUDA_ERROR_NOT_READY_SLOP, runtime.rs:L3-L15 */
+    SP1HIP_ERROR_RUNTIME = -4,         /* any other HIP failure */
+    SP1HIP_ERROR_NO_DEVICE = -5,
+    SP1HIP_ERROR_BUFFER_TOO_SMALL = -6
+} sp1hip_status;
+
+typedef void* sp1hip_stream_t; /* hipStream_t; NULL = the default stream */
+typedef void* sp1hip_event_t;  /* hipEvent_t */
+
+/* Extension-field element passed by value (4 Montgomery words). */
+typedef struct { uint32_t c[4]; } sp1hip_ext_t;
+
+/* One committed tensor of a `Message<Tensor>`: column-major device data, `width` columns. */
+typedef struct {
+    const uint32_t* d_data;
+    uint32_t width;
+} sp1hip_tensor_t;
+
+const char* sp1hip_last_error(void);
+const char* sp1hip_version(void);
+
+/* ---------------------------------------------------------------- runtime
+ * Replaces sp1-gpu-sys `cuda_malloc[_async]`, `cuda_free[_async]`, `cuda_malloc_host`,
+ * `cuda_mem_copy_*`, `cuda_stream_*`, `cuda_event_*`, `cuda_mem_get_info`
+ * (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L16-L172). */
+int sp1hip_device_count(int* count);
+int sp1hip_set_device(int device);
+int sp1hip_get_device(int* device);
+int sp1hip_mem_info(size_t* free_bytes, size_t* total_bytes);
+int sp1hip_malloc(void** d_ptr, size_t bytes);
+int sp1hip_free(void* d_ptr);
+int sp1hip_malloc_async(void** d_ptr, size_t bytes, sp1hip_stream_t stream);
+int sp1hip_free_async(void* d_ptr, sp1hip_stream_t stream);
+int sp1hip_malloc_host(void** h_ptr, size_t bytes);
+int sp1hip_free_host(void* h_ptr);
+int sp1hip_memcpy_h2d_async(void* d_dst, const void* h_src, size_t bytes, sp1hip_stream_t stream);
+int sp1hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, sp1hip_stream_t stream);
+int sp1hip_memcpy_d2d_async(void* d_dst, const void* d_src, size_t bytes, sp1hip_stream_t stream);
+int sp1hip_memset_async(void* d_dst, int value, size_t bytes, sp1hip_stream_t stream);
+int sp1hip_stream_create(sp1hip_stream_t* stream);
+int sp1hip_stream_destroy(sp1hip_stream_t stream);
+int sp1hip_stream_synchronize(sp1hip_stream_t stream);
+int sp1hip_stream_query(sp1hip_stream_t stream); /* SP1HIP_ERROR_NOT_READY while work is pending */
+int sp1hip_event_create(sp1hip_event_t* event);
+int sp1hip_event_destroy(sp1hip_event_t event);
+int sp1hip_event_record(sp1hip_event_t event, sp1hip_stream_t stream);
+int sp1hip_event_synchronize(sp1hip_event_t event);
+int sp1hip_event_elapsed_ms(float* ms, sp1hip_event_t start, sp1hip_event_t stop);
+int sp1hip_stream_wait_event(sp1hip_stream_t stream, sp1hip_event_t event);
+
+/* ---------------------------------------------------------------- layout
+ * Host traces are row-major `[rows][cols]` (`RowMajorMatrix`, slop Tensor); the device wants
+ * column-major. Replaces sp1-gpu's transpose kernels (/root/reference/sp1-gpu/crates/sys/lib/transpose). */
+int sp1hip_transpose_to_col_major(uint32_t* d_out, const uint32_t* d_in_row_major, size_t rows, size_t cols,
+                                  sp1hip_stream_t stream);
+int sp1hip_transpose_to_row_major(uint32_t* d_out, const uint32_t* d_in_col_major, size_t rows, size_t cols,
+                                  sp1hip_stream_t stream);
+/* canonical <-> Montgomery, in place */
+int sp1hip_to_monty(uint32_t* d_data, size_t n, sp1hip_stream_t stream);
+int sp1hip_from_monty(uint32_t* d_data, size_t n, sp1hip_stream_t stream);
+
+/* ---------------------------------------------------------------- Reed–Solomon encode (a4)
+ * Replaces `Dft::dft(src, log_blowup, DftOrdering::BitReversed, dim = 0)` as called by
+ * `CpuDftEncoder::encode_batch` (/root/reference/slop/crates/basefold-prover/src/encoder.rs:L22-L38,
+ * /root/reference/slop/crates/dft/src/lib.rs:L17-L71) and sp1-gpu-sys `batch_coset_dft`
+ * (/root/reference/sp1-gpu/crates/sys/src/dft.rs:L12-L59).
+ * d_in: [2^lg_n x n_cols] column-major coefficients; d_out: [2^(lg_n+lg_blowup) x n_cols]
+ * column-major, row j of a column holds f(w_N^{bitrev(j)}). d_out must not alias d_in. */
+int sp1hip_rs_encode_batch(uint32_t* d_out, const uint32_t* d_in, int lg_n, int lg_blowup, size_t n_cols,
+                           sp1hip_stream_t stream);
+
+/* ---------------------------------------------------------------- Poseidon2 Merkle TCS (a2, a3, a6)
+ * Replaces `TensorCsProver::commit_tensors` / `prove_openings_at_indices` and
+ * `ComputeTcsOpenings::compute_openings_at_indices`
+ * (/root/reference/slop/crates/merkle-tree/src/tcs.rs:L15-L47, p3sync.rs:L40-L238).
+ * d_tree: (2^(lg_height+1) - 1) * 8 words. d_root_and_commit: 16 words — the Merkle root followed by
+ * the commitment compress(root, hash([lg_height, total_width])). */
+int sp1hip_merkle_commit(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, uint32_t* d_tree,
+                         uint32_t* d_root_and_commit, sp1hip_stream_t stream);
+/* d_indices: n_idx row indices. d_values: [n_idx][total_width] row-major (tensor order);
+ * d_paths: [n_idx][lg_height][8]. Either output may be NULL. */
+int sp1hip_merkle_open(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, const uint32_t* d_tree,
+                       const uint32_t* d_indices, size_t n_idx, uint32_t* d_values, uint32_t* d_paths,
+                       sp1hip_stream_t stream);
+/* Batched permutations / hashes for testing and for small host-side uses:
+ * d_states [n][16] permuted in place. */
+int sp1hip_poseidon2_permute(uint32_t* d_states, size_t n, sp1hip_stream_t stream);
+
+/* ---------------------------------------------------------------- BaseFold kernels (a13, a14)
+ * batch: out[r] = sum_c coeff[c] * col_c[r] over all columns of all tensors (message order)
+ *   (`FriCpuProver::batch`, /root/reference/slop/crates/basefold-prover/src/fri.rs:L31-L80).
+ *   d_coeffs: [total_cols] ext, array-of-structs (4 words each). d_out: ext vector [2^lg_height]. */
+int sp1hip_basefold_batch(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height,
+                          const uint32_t* d_coeffs, uint32_t* d_out, sp1hip_stream_t stream);
+/* codeword fold (`p3_fri::fold_even_odd` as called at fri.rs:L118): ext vector 2^lg_n -> 2^(lg_n-1) */
+int sp1hip_fold_even_odd(const uint32_t* d_codeword, int lg_n, sp1hip_ext_t beta, uint32_t* d_out,
+                         sp1hip_stream_t stream);
+/* `Mle::fold` (/root/reference/slop/crates/multilinear/src/fold.rs:L12-L26): out[i] = m[2i] + beta m[2i+1] */
+int sp1hip_fold_mle(const uint32_t* d_mle, int lg_n, sp1hip_ext_t beta, uint32_t* d_out, sp1hip_stream_t stream);
+/* eq(point, .) table (`partial_lagrange`, /root/reference/slop/crates/multilinear/src/lagrange.rs:L19-L45);
+ * h_point: dim ext elements on the host; d_out: ext vector [2^dim]. */
+int sp1hip_partial_lagrange(const sp1hip_ext_t* h_point, int dim, uint32_t* d_out, sp1hip_stream_t stream);
+/* `eval_mle_at_point` for every column (/root/reference/slop/crates/multilinear/src/eval.rs:L9-L21):
+ * d_evals[c] = sum_r d_eq[r] * col_c[r]; d_evals: [total_cols] ext array-of-structs. */
+int sp1hip_mle_eval_columns(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, const uint32_t* d_eq,
+                            uint32_t* d_evals, sp1hip_stream_t stream);
+/* `Mle::fixed_at_zero` for an ext mle (/root/reference/slop/crates/multilinear/src/restrict.rs:L75-L87):
+ * d_out[4] = sum_i d_eq[i] * d_mle[2 i]; d_mle ext vector [2^lg_n], d_eq ext vector [2^(lg_n-1)]. */
+int sp1hip_ext_fixed_at_zero(const uint32_t* d_mle, int lg_n, const uint32_t* d_eq, uint32_t* d_out,
+                             sp1hip_stream_t stream);
+
+/* ---------------------------------------------------------------- transcript (a17)
+ * `DuplexChallenger<KoalaBear, KoalaPerm, 16, 8>` (/root/reference/slop/crates/challenger/src/lib.rs:L25-L87).
+ * Host object; `grind` runs the witness search on the GPU and returns the SMALLEST valid witness. */
+typedef struct sp1hip_challenger_s sp1hip_challenger_t;
+int sp1hip_challenger_new(sp1hip_challenger_t** out);
+int sp1hip_challenger_clone(const sp1hip_challenger_t* ch, sp1hip_challenger_t** out);
+void sp1hip_challenger_free(sp1hip_challenger_t* ch);
+int sp1hip_challenger_observe(sp1hip_challenger_t* ch, const uint32_t* felts, size_t n);
+int sp1hip_challenger_sample(sp1hip_challenger_t* ch, uint32_t* out);
+int sp1hip_challenger_sample_ext(sp1hip_challenger_t* ch, sp1hip_ext_t* out);
+int sp1hip_challenger_sample_bits(sp1hip_challenger_t* ch, int bits, uint32_t* out);
+int sp1hip_challenger_check_witness(sp1hip_challenger_t* ch, int bits, uint32_t witness, int* ok);
+int sp1hip_challenger_grind(sp1hip_challenger_t* ch, int bits, uint32_t* witness, sp1hip_stream_t stream);
+/* 34 words: sponge state[16], n_in, in[8], n_out, out[8] */
+int sp1hip_challenger_state(const sp1hip_challenger_t* ch, uint32_t* out34);
+
+/* ---------------------------------------------------------------- BaseFold prover (a15, a16)
+ * `BasefoldProver::commit_mles` (/root/reference/slop/crates/basefold-prover/src/prover.rs:L78-L99):
+ * RS-encode every mle of one commitment round and Merkle-commit the codewords. The returned
+ * handle owns the device codewords + tree (`BasefoldProverData`); the input mles stay caller-owned
+ * and must outlive the handle (they are read again by `sp1hip_basefold_prove`). */
+typedef struct sp1hip_basefold_data_s sp1hip_basefold_data_t;
+int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg_blowup, uint32_t h_commit[8],
+                       sp1hip_basefold_data_t** out, sp1hip_stream_t stream);
+void sp1hip_basefold_data_free(sp1hip_basefold_data_t* data);
+/* accessors for parity tests */
+int sp1hip_basefold_data_codeword(const sp1hip_basefold_data_t* data, int mle_index, const uint32_t** d_codeword,
+                                  uint32_t* width, int* lg_height);
+int sp1hip_basefold_data_tree(const sp1hip_basefold_data_t* data, const uint32_t** d_tree, int* lg_height);
+
+typedef struct {
+    int log_blowup;          /* core: 2  (/root/reference/crates/primitives/src/fri_params.rs:L5-L15) */
+    int num_queries;         /* core: 124 */
+    int proof_of_work_bits;  /* core: 16 */
+} sp1hip_fri_config_t;
+
+/* `BasefoldProver::prove_trusted_mle_evaluations` (prover.rs:L102-L243). `rounds[r]` are the handles of
+ * the commitment rounds in order; h_claims holds one ext per column flattened round -> mle -> column.
+ * Writes the bincode encoding of `BasefoldProof` (/root/reference/slop/crates/basefold/src/verifier.rs:L94-L116)
+ * into h_proof (capacity *proof_len on entry, size on return; SP1HIP_ERROR_BUFFER_TOO_SMALL sets the needed
+ * size and leaves the challenger untouched). */
+int sp1hip_basefold_prove(const sp1hip_ext_t* h_point, int dim, sp1hip_basefold_data_t* const* rounds, int n_rounds,
+                          const sp1hip_ext_t* h_claims, size_t n_claims, sp1hip_fri_config_t config,
+                          sp1hip_challenger_t* challenger, uint8_t* h_proof, size_t* proof_len,
+                          sp1hip_stream_t stream);
+size_t sp1hip_basefold_proof_size(int dim, const uint32_t* round_widths, int n_rounds, sp1hip_fri_config_t config);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SP1HIP_H */

@@ -1,0 +1,126 @@
+"""ctypes binding of libsp1hip.so (the C-ABI drop-in boundary declared in include/sp1hip.h).
+
+This module only loads the in-tree shared library and declares prototypes. There is NO fallback:
+if the HIP extension is missing or a call fails, an exception is raised (the product path must fail
+loudly, never route through a CPU implementation).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsp1hip.so")
+
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class Ext(C.Structure):
+    _fields_ = [("c", C.c_uint32 * 4)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("d_data", C.c_void_p), ("width", C.c_uint32)]
+
+
+class FriConfig(C.Structure):
+    _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("proof_of_work_bits", C.c_int)]
+
+
+class Sp1HipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("sp1hip status %d: %s" % (status, message))
+        self.status = status
+
+
+# every symbol include/sp1hip.h declares: (name, restype, argtypes); restype None => int status
+_vp = C.c_void_p
+_sz = C.c_size_t
+_int = C.c_int
+PROTOTYPES = [
+    ("sp1hip_last_error", C.c_char_p, []),
+    ("sp1hip_version", C.c_char_p, []),
+    ("sp1hip_device_count", None, [C.POINTER(_int)]),
+    ("sp1hip_set_device", None, [_int]),
+    ("sp1hip_get_device", None, [C.POINTER(_int)]),
+    ("sp1hip_mem_info", None, [C.POINTER(_sz), C.POINTER(_sz)]),
+    ("sp1hip_malloc", None, [C.POINTER(_vp), _sz]),
+    ("sp1hip_free", None, [_vp]),
+    ("sp1hip_malloc_async", None, [C.POINTER(_vp), _sz, _vp]),
+    ("sp1hip_free_async", None, [_vp, _vp]),
+    ("sp1hip_malloc_host", None, [C.POINTER(_vp), _sz]),
+    ("sp1hip_free_host", None, [_vp]),
+    ("sp1hip_memcpy_h2d_async", None, [_vp, _vp, _sz, _vp]),
+    ("sp1hip_memcpy_d2h_async", None, [_vp, _vp, _sz, _vp]),
+    ("sp1hip_memcpy_d2d_async", None, [_vp, _vp, _sz, _vp]),
+    ("sp1hip_memset_async", None, [_vp, _int, _sz, _vp]),
+    ("sp1hip_stream_create", None, [C.POINTER(_vp)]),
+    ("sp1hip_stream_destroy", None, [_vp]),
+    ("sp1hip_stream_synchronize", None, [_vp]),
+    ("sp1hip_stream_query", None, [_vp]),
+    ("sp1hip_event_create", None, [C.POINTER(_vp)]),
+    ("sp1hip_event_destroy", None, [_vp]),
+    ("sp1hip_event_record", None, [_vp, _vp]),
+    ("sp1hip_event_synchronize", None, [_vp]),
+    ("sp1hip_event_elapsed_ms", None, [C.POINTER(C.c_float), _vp, _vp]),
+    ("sp1hip_stream_wait_event", None, [_vp, _vp]),
+    ("sp1hip_transpose_to_col_major", None, [_vp, _vp, _sz, _sz, _vp]),
+    ("sp1hip_transpose_to_row_major", None, [_vp, _vp, _sz, _sz, _vp]),
+    ("sp1hip_to_monty", None, [_vp, _sz, _vp]),
+    ("sp1hip_from_monty", None, [_vp, _sz, _vp]),
+    ("sp1hip_rs_encode_batch", None, [_vp, _vp, _int, _int, _sz, _vp]),
+    ("sp1hip_merkle_commit", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
+    ("sp1hip_merkle_open", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("sp1hip_poseidon2_permute", None, [_vp, _sz, _vp]),
+    ("sp1hip_basefold_batch", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
+    ("sp1hip_fold_even_odd", None, [_vp, _int, Ext, _vp, _vp]),
+    ("sp1hip_fold_mle", None, [_vp, _int, Ext, _vp, _vp]),
+    ("sp1hip_partial_lagrange", None, [C.POINTER(Ext), _int, _vp, _vp]),
+    ("sp1hip_mle_eval_columns", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
+    ("sp1hip_ext_fixed_at_zero", None, [_vp, _int, _vp, _vp, _vp]),
+    ("sp1hip_challenger_new", None, [C.POINTER(_vp)]),
+    ("sp1hip_challenger_clone", None, [_vp, C.POINTER(_vp)]),
+    ("sp1hip_challenger_free", "void", [_vp]),
+    ("sp1hip_challenger_observe", None, [_vp, u32p, _sz]),
+    ("sp1hip_challenger_sample", None, [_vp, u32p]),
+    ("sp1hip_challenger_sample_ext", None, [_vp, C.POINTER(Ext)]),
+    ("sp1hip_challenger_sample_bits", None, [_vp, _int, u32p]),
+    ("sp1hip_challenger_check_witness", None, [_vp, _int, C.c_uint32, C.POINTER(_int)]),
+    ("sp1hip_challenger_grind", None, [_vp, _int, u32p, _vp]),
+    ("sp1hip_challenger_state", None, [_vp, u32p]),
+    ("sp1hip_commit_mles", None, [C.POINTER(Tensor), _int, _int, _int, u32p, C.POINTER(_vp), _vp]),
+    ("sp1hip_basefold_data_free", "void", [_vp]),
+    ("sp1hip_basefold_data_codeword", None, [_vp, _int, C.POINTER(_vp), u32p, C.POINTER(_int)]),
+    ("sp1hip_basefold_data_tree", None, [_vp, C.POINTER(_vp), C.POINTER(_int)]),
+    ("sp1hip_basefold_prove", None, [C.POINTER(Ext), _int, C.POINTER(_vp), _int, C.POINTER(Ext), _sz, FriConfig, _vp,
+                                     u8p, C.POINTER(_sz), _vp]),
+    ("sp1hip_basefold_proof_size", _sz, [_int, u32p, _int, FriConfig]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libsp1hip.so and declare every prototype. Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in PROTOTYPES:
+        fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
+        fn.argtypes = args
+        if res is None:
+            fn.restype = C.c_int
+        elif res == "void":
+            fn.restype = None
+        else:
+            fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise Sp1HipError(status, load().sp1hip_last_error().decode(errors="replace"))

@@ -1,0 +1,286 @@
+"""Thin Python mirror of the reference's operator interfaces for the core-shard commit/open path,
+calling the HIP backend through the C ABI (include/sp1hip.h). PyTorch is used only as the owner of
+device memory (int32 tensors reinterpreted as u32 words) and for streams; every computation is a
+hand-written gfx950 kernel inside libsp1hip.so. There is no CPU fallback.
+
+Names follow the reference:
+  DuplexChallenger                 slop_challenger::DuplexChallenger      (/root/reference/slop/crates/challenger/src/lib.rs:L25-L87)
+  DftEncoder.encode_batch          CpuDftEncoder::encode_batch            (/root/reference/slop/crates/basefold-prover/src/encoder.rs:L22-L38)
+  MerkleTcsProver.commit_tensors / prove_openings_at_indices / compute_openings_at_indices
+                                   TensorCsProver / ComputeTcsOpenings    (/root/reference/slop/crates/merkle-tree/src/tcs.rs:L15-L47)
+  BasefoldProver.commit_mles / prove_trusted_mle_evaluations
+                                   BasefoldProver                         (/root/reference/slop/crates/basefold-prover/src/prover.rs:L78-L243)
+Device layouts: base tensors column-major [height x width]; ext vectors SoA (see include/sp1hip.h).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Ext, FriConfig, Tensor, check
+
+P = 0x7F000001
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream_ptr(stream=None):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _dptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def device_words(n, device=None):
+    """Uninitialised device buffer of n u32 words."""
+    return torch.empty(int(n), dtype=torch.int32, device=device or torch.device("cuda", torch.cuda.current_device()))
+
+
+def to_device(a, device=None):
+    """numpy uint32 array -> flat device word buffer (same memory order)."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    t = torch.from_numpy(a.view(np.int32).reshape(-1))
+    return t.to(device or torch.device("cuda", torch.cuda.current_device()), non_blocking=False)
+
+
+def to_host(t, shape=None):
+    a = t.detach().cpu().numpy().view(np.uint32)
+    return a.reshape(shape) if shape is not None else a
+
+
+def _ext(x):
+    e = Ext()
+    for k in range(4):
+        e.c[k] = int(x[k])
+    return e
+
+
+def _ext_array(xs):
+    xs = np.asarray(xs, dtype=np.uint32).reshape(-1, 4)
+    arr = (Ext * max(len(xs), 1))()
+    for i, x in enumerate(xs):
+        for k in range(4):
+            arr[i].c[k] = int(x[k])
+    return arr
+
+
+class ColMajor:
+    """A column-major [height x width] base-field tensor in device memory (Montgomery words)."""
+
+    def __init__(self, words, height, width):
+        assert words.numel() == height * width and words.dtype == torch.int32
+        self.words, self.height, self.width = words, int(height), int(width)
+
+    @staticmethod
+    def from_row_major_host(a, stream=None):
+        """Upload a row-major numpy [height][width] array and transpose it on the GPU."""
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        h, w = a.shape
+        src = to_device(a)
+        dst = device_words(h * w)
+        check(_L().sp1hip_transpose_to_col_major(_dptr(dst), _dptr(src), h, w, _stream_ptr(stream)))
+        return ColMajor(dst, h, w)
+
+    def to_row_major_host(self, stream=None):
+        dst = device_words(self.height * self.width)
+        check(_L().sp1hip_transpose_to_row_major(_dptr(dst), _dptr(self.words), self.height, self.width,
+                                                 _stream_ptr(stream)))
+        return to_host(dst, (self.height, self.width))
+
+    def as_tensor_struct(self):
+        return Tensor(C.c_void_p(self.words.data_ptr()), self.width)
+
+
+def _tensor_array(tensors):
+    arr = (Tensor * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.as_tensor_struct()
+    return arr
+
+
+class DuplexChallenger:
+    def __init__(self, handle=None):
+        if handle is None:
+            handle = C.c_void_p()
+            check(_L().sp1hip_challenger_new(C.byref(handle)))
+        self.h = handle
+
+    def clone(self):
+        out = C.c_void_p()
+        check(_L().sp1hip_challenger_clone(self.h, C.byref(out)))
+        return DuplexChallenger(out)
+
+    def observe(self, felts):
+        a = np.ascontiguousarray(np.asarray(felts, dtype=np.uint32).reshape(-1))
+        check(_L().sp1hip_challenger_observe(self.h, a.ctypes.data_as(_lib.u32p), a.size))
+
+    def sample(self):
+        out = C.c_uint32()
+        check(_L().sp1hip_challenger_sample(self.h, C.byref(out)))
+        return out.value
+
+    def sample_ext_element(self):
+        e = Ext()
+        check(_L().sp1hip_challenger_sample_ext(self.h, C.byref(e)))
+        return np.array(list(e.c), dtype=np.uint32)
+
+    def sample_point(self, n):
+        return np.stack([self.sample_ext_element() for _ in range(n)]) if n else np.zeros((0, 4), np.uint32)
+
+    def sample_bits(self, bits):
+        out = C.c_uint32()
+        check(_L().sp1hip_challenger_sample_bits(self.h, bits, C.byref(out)))
+        return out.value
+
+    def check_witness(self, bits, witness):
+        ok = C.c_int()
+        check(_L().sp1hip_challenger_check_witness(self.h, bits, C.c_uint32(int(witness)), C.byref(ok)))
+        return bool(ok.value)
+
+    def grind(self, bits, stream=None):
+        out = C.c_uint32()
+        check(_L().sp1hip_challenger_grind(self.h, bits, C.byref(out), _stream_ptr(stream)))
+        return out.value
+
+    def state(self):
+        out = np.zeros(34, np.uint32)
+        check(_L().sp1hip_challenger_state(self.h, out.ctypes.data_as(_lib.u32p)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _L().sp1hip_challenger_free(self.h)
+            self.h = None
+
+
+class DftEncoder:
+    """Reed–Solomon encoder: zero-pad by 2^log_blowup, forward DFT, bit-reversed rows."""
+
+    def __init__(self, log_blowup):
+        self.log_blowup = int(log_blowup)
+
+    def encode_batch(self, mles, stream=None):
+        out = []
+        for m in mles:
+            lg_n = m.height.bit_length() - 1
+            assert 1 << lg_n == m.height
+            cw = device_words((m.height << self.log_blowup) * m.width)
+            check(_L().sp1hip_rs_encode_batch(_dptr(cw), _dptr(m.words), lg_n, self.log_blowup, m.width,
+                                              _stream_ptr(stream)))
+            out.append(ColMajor(cw, m.height << self.log_blowup, m.width))
+        return out
+
+
+class TcsProverData:
+    def __init__(self, tree, root, commit, log_height, total_width):
+        self.tree, self.root, self.commit = tree, root, commit
+        self.log_height, self.total_width = log_height, total_width
+
+
+class MerkleTcsProver:
+    """Poseidon2KoalaBear16Prover: Merkle tensor commitment over rows of column-major tensors."""
+
+    def commit_tensors(self, tensors, stream=None):
+        h = tensors[0].height
+        lg = h.bit_length() - 1
+        assert all(t.height == h for t in tensors) and 1 << lg == h
+        tree = device_words((2 * h - 1) * 8)
+        rc = device_words(16)
+        check(_L().sp1hip_merkle_commit(_tensor_array(tensors), len(tensors), lg, _dptr(tree), _dptr(rc),
+                                        _stream_ptr(stream)))
+        rc_h = to_host(rc)
+        data = TcsProverData(tree, rc_h[:8].copy(), rc_h[8:].copy(), lg, sum(t.width for t in tensors))
+        return data.commit, data
+
+    def _indices(self, indices):
+        return to_device(np.asarray(indices, dtype=np.uint32))
+
+    def prove_openings_at_indices(self, data, indices, stream=None):
+        idx = self._indices(indices)
+        paths = device_words(len(indices) * data.log_height * 8)
+        none = (Tensor * 1)(Tensor(None, 0))
+        check(_L().sp1hip_merkle_open(none, 1, data.log_height, _dptr(data.tree), _dptr(idx), len(indices), None,
+                                      _dptr(paths), _stream_ptr(stream)))
+        return dict(merkle_root=data.root, log_tensor_height=data.log_height, width=data.total_width,
+                    paths=to_host(paths, (len(indices), data.log_height, 8)))
+
+    def compute_openings_at_indices(self, tensors, indices, stream=None):
+        idx = self._indices(indices)
+        tw = sum(t.width for t in tensors)
+        lg = tensors[0].height.bit_length() - 1
+        vals = device_words(len(indices) * tw)
+        check(_L().sp1hip_merkle_open(_tensor_array(tensors), len(tensors), lg, None, _dptr(idx), len(indices),
+                                      _dptr(vals), None, _stream_ptr(stream)))
+        return to_host(vals, (len(indices), tw))
+
+
+class BasefoldProverData:
+    def __init__(self, handle, mles, commit):
+        self.h, self.mles, self.commit = handle, mles, commit
+
+    def codeword(self, k):
+        ptr, width, lg = C.c_void_p(), C.c_uint32(), C.c_int()
+        check(_L().sp1hip_basefold_data_codeword(self.h, k, C.byref(ptr), C.byref(width), C.byref(lg)))
+        n = (1 << lg.value) * width.value
+        out = device_words(n)
+        check(_L().sp1hip_memcpy_d2d_async(_dptr(out), ptr, n * 4, _stream_ptr()))
+        return ColMajor(out, 1 << lg.value, width.value)
+
+    def tree(self):
+        ptr, lg = C.c_void_p(), C.c_int()
+        check(_L().sp1hip_basefold_data_tree(self.h, C.byref(ptr), C.byref(lg)))
+        n = ((2 << lg.value) - 1) * 8
+        out = device_words(n)
+        check(_L().sp1hip_memcpy_d2d_async(_dptr(out), ptr, n * 4, _stream_ptr()))
+        return to_host(out, (n // 8, 8))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _L().sp1hip_basefold_data_free(self.h)
+            self.h = None
+
+
+class BasefoldProver:
+    def __init__(self, log_blowup=2, num_queries=124, proof_of_work_bits=16):
+        self.config = FriConfig(log_blowup, num_queries, proof_of_work_bits)
+
+    def commit_mles(self, mles, stream=None):
+        lg_n = mles[0].height.bit_length() - 1
+        assert all(m.height == 1 << lg_n for m in mles)
+        commit = np.zeros(8, np.uint32)
+        handle = C.c_void_p()
+        check(_L().sp1hip_commit_mles(_tensor_array(mles), len(mles), lg_n, self.config.log_blowup,
+                                      commit.ctypes.data_as(_lib.u32p), C.byref(handle), _stream_ptr(stream)))
+        return commit, BasefoldProverData(handle, list(mles), commit)
+
+    def evaluate_mles(self, mles, point, stream=None):
+        """Claims for `prove_trusted_mle_evaluations`: every column of every mle at `point` ([dim][4])."""
+        point = np.asarray(point, dtype=np.uint32).reshape(-1, 4)
+        dim = point.shape[0]
+        eq = device_words(4 << dim)
+        check(_L().sp1hip_partial_lagrange(_ext_array(point), dim, _dptr(eq), _stream_ptr(stream)))
+        tw = sum(m.width for m in mles)
+        out = device_words(tw * 4)
+        check(_L().sp1hip_mle_eval_columns(_tensor_array(mles), len(mles), dim, _dptr(eq), _dptr(out),
+                                           _stream_ptr(stream)))
+        return to_host(out, (tw, 4))
+
+    def prove_trusted_mle_evaluations(self, eval_point, prover_data, evaluation_claims, challenger, stream=None):
+        """prover_data: list of BasefoldProverData (one per commitment round); evaluation_claims: [total][4]."""
+        point = np.asarray(eval_point, dtype=np.uint32).reshape(-1, 4)
+        claims = np.asarray(evaluation_claims, dtype=np.uint32).reshape(-1, 4)
+        widths = (C.c_uint32 * len(prover_data))(*[sum(m.width for m in pd.mles) for pd in prover_data])
+        size = _L().sp1hip_basefold_proof_size(point.shape[0], widths, len(prover_data), self.config)
+        buf = (C.c_uint8 * size)()
+        n = C.c_size_t(size)
+        handles = (C.c_void_p * len(prover_data))(*[pd.h for pd in prover_data])
+        check(_L().sp1hip_basefold_prove(_ext_array(point), point.shape[0], handles, len(prover_data),
+                                         _ext_array(claims), claims.shape[0], self.config, challenger.h, buf,
+                                         C.byref(n), _stream_ptr(stream)))
+        return bytes(buf[:n.value])

@@ -1,0 +1,469 @@
+// sp1_amd/csrc/basefold.hip — streaming kernels of the BaseFold opening on gfx950: column RLC,
+// codeword / mle folds, eq tables, column evaluations, fold-round leaf hashing and openings, layout
+// helpers.
+//
+//   batch            `FriCpuProver::batch`            /root/reference/slop/crates/basefold-prover/src/fri.rs:L31-L80
+//   fold_even_odd    `p3_fri::fold_even_odd` (fri.rs:L118), formula pinned by
+//                    /root/reference/slop/crates/basefold/src/verifier.rs:L364-L374
+//   fold_mle         /root/reference/slop/crates/multilinear/src/fold.rs:L12-L26
+//   partial_lagrange /root/reference/slop/crates/multilinear/src/lagrange.rs:L19-L45
+//   mle_eval_columns /root/reference/slop/crates/multilinear/src/eval.rs:L9-L21
+//   fixed_at_zero    /root/reference/slop/crates/multilinear/src/restrict.rs:L75-L87
+//   pair leaves      fri.rs:L103-L108 (codeword reshaped [N/2][8]) + p3sync.rs leaf hashing
+//
+// All of these are single-pass streaming kernels: one lane per output row, every column access
+// coalesced, ext vectors in SoA (4 base columns) so a wave reads 4 x 256 B contiguous runs.
+#include "device_ctx.hpp"
+#include "tensor_table.hpp"
+
+namespace sp1hip {
+
+struct ExtArg { uint32_t c[4]; };
+__device__ __forceinline__ kb::Ext E(const ExtArg& a) { return kb::Ext{{a.c[0], a.c[1], a.c[2], a.c[3]}}; }
+
+// ---------------------------------------------------------------- layout helpers
+// 32x32 LDS-tiled transpose, padded against bank conflicts.
+__global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                        size_t in_rows, size_t in_cols) {
+    // in: [in_rows][in_cols] (in_cols fastest) -> out: [in_cols][in_rows]
+    __shared__ uint32_t tile[32][33];
+    const size_t r0 = (size_t)blockIdx.y * 32, c0 = (size_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        size_t r = r0 + k, c = c0 + tx;
+        if (r < in_rows && c < in_cols) tile[k][tx] = in[r * in_cols + c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        size_t c = c0 + k, r = r0 + tx;
+        if (r < in_rows && c < in_cols) out[c * in_rows + r] = tile[tx][k];
+    }
+}
+
+template <bool TO>
+__global__ void monty_convert_kernel(uint32_t* data, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) data[i] = TO ? kb::to_monty(data[i]) : kb::from_monty(data[i]);
+}
+
+// ---------------------------------------------------------------- batch (RLC of all columns)
+// out[r] = sum_g coeff[g] * col_g[r]. Coefficients are wave-uniform (scalar loads); products of
+// two columns share one Montgomery reduction per ext coordinate (2 p^2 < 2^32 p).
+__global__ __launch_bounds__(256) void batch_kernel(const uint32_t* const* __restrict__ cols, uint32_t total_width,
+                                                    uint32_t height, const uint32_t* __restrict__ coeffs,
+                                                    uint32_t* __restrict__ out) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= height) return;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    uint32_t g = 0;
+    for (; g + 1 < total_width; g += 2) {
+        const uint32_t x0 = cols[g][row], x1 = cols[g + 1][row];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint64_t t = (uint64_t)coeffs[4 * g + k] * x0 + (uint64_t)coeffs[4 * g + 4 + k] * x1;
+            acc[k] = kb::add(acc[k], kb::monty_reduce(t));
+        }
+    }
+    if (g < total_width) {
+        const uint32_t x0 = cols[g][row];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = kb::add(acc[k], kb::mul(coeffs[4 * g + k], x0));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[(size_t)k * height + row] = acc[k];
+}
+
+// ---------------------------------------------------------------- folds
+// out[i] = (e0 + e1)/2 + beta * (e0 - e1) / (2 x_i),  x_i = w_N^{bitrev_{lg N}(2 i)}
+__global__ __launch_bounds__(256) void fold_even_odd_kernel(const uint32_t* __restrict__ cw, int lg_n, ExtArg half_beta,
+                                                            const uint32_t* __restrict__ tw_lo,
+                                                            const uint32_t* __restrict__ tw_hi,
+                                                            uint32_t* __restrict__ out) {
+    const uint32_t n = 1u << lg_n, m = n >> 1;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    kb::Ext e0, e1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint2 v = *reinterpret_cast<const uint2*>(cw + (size_t)k * n + 2 * (size_t)i);
+        e0.c[k] = v.x;
+        e1.c[k] = v.y;
+    }
+    // 1 / x_i = w_N^(N - br), br = bitrev_{lg n}(2 i) < N/2
+    const uint32_t br = kb::reverse_bits_len(2 * i, lg_n);
+    const uint32_t ex = ((n - br) & (n - 1)) << (kb::TWO_ADICITY - lg_n);
+    const uint32_t xinv = kb::mul(tw_hi[ex >> TW_LO_BITS], tw_lo[ex & (TW_LO - 1)]);
+    const uint32_t inv2 = 0x00ffffffu;   // to_monty(1/2) = R1 / 2 (R1 = 2^25 - 2 is even)
+    kb::Ext s = kb::ext_mul_base(kb::ext_add(e0, e1), inv2);
+    kb::Ext d = kb::ext_mul_base(kb::ext_sub(e0, e1), xinv);
+    kb::Ext r = kb::ext_add(s, kb::ext_mul(E(half_beta), d));
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[(size_t)k * m + i] = r.c[k];
+}
+
+__global__ __launch_bounds__(256) void fold_mle_kernel(const uint32_t* __restrict__ mle, int lg_n, ExtArg beta,
+                                                       uint32_t* __restrict__ out) {
+    const uint32_t n = 1u << lg_n, m = n >> 1;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    kb::Ext a, b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint2 v = *reinterpret_cast<const uint2*>(mle + (size_t)k * n + 2 * (size_t)i);
+        a.c[k] = v.x;
+        b.c[k] = v.y;
+    }
+    kb::Ext r = kb::ext_add(a, kb::ext_mul(E(beta), b));
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[(size_t)k * m + i] = r.c[k];
+}
+
+// ---------------------------------------------------------------- eq tables
+struct PointArg {
+    uint32_t c[kb::TWO_ADICITY + 8][4];
+};
+
+// small[i] = prod_j (bit_j(i) ? x_j : 1 - x_j) over coordinates [first, first + d), bit_j big-endian.
+// AoS ext output, 2^d entries.
+__global__ void eq_small_kernel(PointArg pt, int first, int d, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << d)) return;
+    kb::Ext acc = kb::ext_one();
+    for (int j = 0; j < d; j++) {
+        kb::Ext x{{pt.c[first + j][0], pt.c[first + j][1], pt.c[first + j][2], pt.c[first + j][3]}};
+        const bool bit = (i >> (d - 1 - j)) & 1u;
+        acc = kb::ext_mul(acc, bit ? x : kb::ext_sub(kb::ext_one(), x));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * (size_t)i + k] = acc.c[k];
+}
+
+// full[i] = hi[i >> d_lo] * lo[i & (2^d_lo - 1)]; SoA output of length 2^dim
+__global__ __launch_bounds__(256) void eq_outer_kernel(const uint32_t* __restrict__ hi, const uint32_t* __restrict__ lo,
+                                                       int d_lo, uint32_t len, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= len) return;
+    const uint32_t ih = i >> d_lo, il = i & ((1u << d_lo) - 1);
+    kb::Ext a{{hi[4 * ih], hi[4 * ih + 1], hi[4 * ih + 2], hi[4 * ih + 3]}};
+    kb::Ext b{{lo[4 * il], lo[4 * il + 1], lo[4 * il + 2], lo[4 * il + 3]}};
+    kb::Ext r = kb::ext_mul(a, b);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[(size_t)k * len + i] = r.c[k];
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = kb::add(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Block-reduces 4 words per lane; lane 0 of wave 0 returns the total (others undefined).
+__device__ __forceinline__ void block_sum4(uint32_t (&v)[4], uint32_t* scratch /* [4][4] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) scratch[wave * 4 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            v[k] = kb::add(kb::add(scratch[k], scratch[4 + k]), kb::add(scratch[8 + k], scratch[12 + k]));
+    }
+    __syncthreads();
+}
+
+constexpr int EVAL_COLS = 8;      // columns per workgroup
+constexpr int EVAL_ROWS = 4096;   // rows per workgroup
+
+// partial[chunk][g] = sum over the chunk's rows of eq[r] * col_g[r]
+__global__ __launch_bounds__(256) void eval_columns_partial_kernel(const uint32_t* const* __restrict__ cols,
+                                                                   uint32_t total_width, uint32_t height,
+                                                                   const uint32_t* __restrict__ eq,
+                                                                   uint32_t* __restrict__ partial) {
+    __shared__ uint32_t scratch[16];
+    const uint32_t g0 = blockIdx.y * EVAL_COLS;
+    const uint32_t r0 = blockIdx.x * EVAL_ROWS;
+    uint32_t acc[EVAL_COLS][4];
+#pragma unroll
+    for (int c = 0; c < EVAL_COLS; c++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[c][k] = 0;
+    for (uint32_t r = r0 + threadIdx.x; r < r0 + EVAL_ROWS && r < height; r += 256) {
+        uint32_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = eq[(size_t)k * height + r];
+#pragma unroll
+        for (int c = 0; c < EVAL_COLS; c++) {
+            if (g0 + c < total_width) {
+                const uint32_t x = cols[g0 + c][r];
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[c][k] = kb::add(acc[c][k], kb::mul(e[k], x));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < EVAL_COLS; c++) {
+        block_sum4(acc[c], scratch);
+        if (threadIdx.x == 0 && g0 + c < total_width) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) partial[((size_t)blockIdx.x * total_width + g0 + c) * 4 + k] = acc[c][k];
+        }
+    }
+}
+
+// out[j] = sum_chunk partial[chunk][j], j over total_width*4 words
+__global__ void sum_partials_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks, uint32_t n_words,
+                                    uint32_t* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_words) return;
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < n_chunks; c++) acc = kb::add(acc, partial[(size_t)c * n_words + j]);
+    out[j] = acc;
+}
+
+// partial[block] = sum_i eq[i] * mle[2 i] over the block's range (ext x ext)
+__global__ __launch_bounds__(256) void fixed_at_zero_partial_kernel(const uint32_t* __restrict__ mle, uint32_t n,
+                                                                    const uint32_t* __restrict__ eq,
+                                                                    uint32_t* __restrict__ partial) {
+    __shared__ uint32_t scratch[16];
+    const uint32_t m = n >> 1;
+    kb::Ext acc = kb::ext_zero();
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < m; i += gridDim.x * 256u) {
+        kb::Ext a, e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            a.c[k] = mle[(size_t)k * n + 2 * (size_t)i];
+            e.c[k] = eq[(size_t)k * m + i];
+        }
+        acc = kb::ext_add(acc, kb::ext_mul(e, a));
+    }
+    block_sum4(acc.c, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) partial[blockIdx.x * 4 + k] = acc.c[k];
+    }
+}
+
+// ---------------------------------------------------------------- fold-round leaves and openings
+// Leaf i of a fold round = (cw[2i], cw[2i+1]) = 8 words = exactly one absorb block.
+__global__ __launch_bounds__(256) void leaf_hash_pairs_kernel(const uint32_t* __restrict__ cw, uint32_t n,
+                                                              const p2::RoundConstants* __restrict__ rc,
+                                                              uint32_t* __restrict__ leaves) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (n >> 1)) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint2 v = *reinterpret_cast<const uint2*>(cw + (size_t)k * n + 2 * (size_t)i);
+        s[k] = v.x;
+        s[4 + k] = v.y;
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) s[k] = 0;
+    p2::permute(s, *rc);
+    uint4* d = reinterpret_cast<uint4*>(leaves + (size_t)i * 8);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+__global__ void open_pairs_kernel(const uint32_t* __restrict__ cw, uint32_t n, const uint32_t* __restrict__ indices,
+                                  size_t n_idx, uint32_t* __restrict__ values) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * 8) return;
+    const size_t q = t >> 3;
+    const uint32_t w = (uint32_t)(t & 7);
+    values[t] = cw[(size_t)(w & 3) * n + 2 * (size_t)indices[q] + (w >> 2)];
+}
+
+__global__ void shift_indices_kernel(uint32_t* idx, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) idx[t] >>= 1;
+}
+
+}  // namespace sp1hip
+
+using namespace sp1hip;
+
+namespace sp1hip {
+// internal entry points shared with prover.hip
+int merkle_finish_tree(uint32_t* d_tree, int lg_height, uint32_t total_width, uint32_t* d_root_and_commit,
+                       const DeviceCtx* ctx, hipStream_t s);
+
+int commit_ext_pairs(const uint32_t* d_cw, int lg_n, uint32_t* d_tree, uint32_t* d_root_and_commit, hipStream_t s) {
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));
+    const uint32_t n = 1u << lg_n, leaves = n >> 1;
+    hipLaunchKernelGGL(leaf_hash_pairs_kernel, dim3((leaves + 255) / 256), dim3(256), 0, s, d_cw, n, ctx->d_rc, d_tree);
+    SP1HIP_LAUNCH_CHECK();
+    return merkle_finish_tree(d_tree, lg_n - 1, 8, d_root_and_commit, ctx, s);
+}
+
+int open_ext_pairs(const uint32_t* d_cw, int lg_n, const uint32_t* d_indices, size_t n_idx, uint32_t* d_values,
+                   hipStream_t s) {
+    if (!n_idx) return SP1HIP_SUCCESS;
+    hipLaunchKernelGGL(open_pairs_kernel, dim3((n_idx * 8 + 255) / 256), dim3(256), 0, s, d_cw, 1u << lg_n, d_indices,
+                       n_idx, d_values);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int shift_indices(uint32_t* d_idx, size_t n, hipStream_t s) {
+    if (!n) return SP1HIP_SUCCESS;
+    hipLaunchKernelGGL(shift_indices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_idx, n);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int ext_fixed_at_zero_async(const uint32_t* d_mle, int lg_n, const uint32_t* d_eq, uint32_t* d_out, hipStream_t s) {
+    const uint32_t n = 1u << lg_n, m = n >> 1;
+    uint32_t blocks = (m + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks == 0) blocks = 1;
+    AsyncScratch part;
+    SP1HIP_TRY(part.alloc((size_t)blocks * 16, s));
+    hipLaunchKernelGGL(fixed_at_zero_partial_kernel, dim3(blocks), dim3(256), 0, s, d_mle, n, d_eq, (uint32_t*)part.p);
+    SP1HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)part.p, blocks, 4u, d_out);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+}  // namespace sp1hip
+
+extern "C" {
+
+int sp1hip_transpose_to_col_major(uint32_t* d_out, const uint32_t* d_in, size_t rows, size_t cols, sp1hip_stream_t stream) {
+    if (rows == 0 || cols == 0) return SP1HIP_SUCCESS;
+    SP1HIP_REQUIRE(d_out && d_in && d_out != d_in, "bad buffers");
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    SP1HIP_REQUIRE(grid.y <= 65535u * 1024u, "too many rows");
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S(stream), d_in, d_out, rows, cols);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_transpose_to_row_major(uint32_t* d_out, const uint32_t* d_in, size_t rows, size_t cols, sp1hip_stream_t stream) {
+    // column-major [rows x cols] is a row-major [cols][rows] array
+    if (rows == 0 || cols == 0) return SP1HIP_SUCCESS;
+    SP1HIP_REQUIRE(d_out && d_in && d_out != d_in, "bad buffers");
+    dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, S(stream), d_in, d_out, cols, rows);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+static int monty_convert(uint32_t* d, size_t n, bool to, sp1hip_stream_t stream) {
+    if (!n) return SP1HIP_SUCCESS;
+    SP1HIP_REQUIRE(d, "null buffer");
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (to) hipLaunchKernelGGL(monty_convert_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, S(stream), d, n);
+    else hipLaunchKernelGGL(monty_convert_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, S(stream), d, n);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_to_monty(uint32_t* d, size_t n, sp1hip_stream_t s) { return monty_convert(d, n, true, s); }
+int sp1hip_from_monty(uint32_t* d, size_t n, sp1hip_stream_t s) { return monty_convert(d, n, false, s); }
+
+int sp1hip_basefold_batch(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, const uint32_t* d_coeffs,
+                          uint32_t* d_out, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(lg_height >= 0 && lg_height <= 30, "lg_height out of range");
+    SP1HIP_REQUIRE(d_coeffs && d_out, "null buffer");
+    TensorTable tab;
+    uint32_t tw;
+    SP1HIP_TRY(make_tensor_table(tensors, n_tensors, &tab, &tw));
+    hipStream_t s = S(stream);
+    const uint32_t height = 1u << lg_height;
+    AsyncScratch cols;
+    SP1HIP_TRY(cols.alloc((size_t)tw * sizeof(uint32_t*), s));
+    SP1HIP_TRY(expand_columns_async(tab, tw, height, (const uint32_t**)cols.p, s));
+    hipLaunchKernelGGL(batch_kernel, dim3((height + 255) / 256), dim3(256), 0, s, (const uint32_t* const*)cols.p, tw,
+                       height, d_coeffs, d_out);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_fold_even_odd(const uint32_t* d_cw, int lg_n, sp1hip_ext_t beta, uint32_t* d_out, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(lg_n >= 1 && lg_n <= kb::TWO_ADICITY, "lg_n out of range");
+    SP1HIP_REQUIRE(d_cw && d_out, "null buffer");
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));
+    ExtArg hb;
+    for (int k = 0; k < 4; k++) hb.c[k] = kb::mul(beta.c[k], 0x00ffffffu);  // beta / 2
+    const uint32_t m = 1u << (lg_n - 1);
+    hipLaunchKernelGGL(fold_even_odd_kernel, dim3((m + 255) / 256), dim3(256), 0, S(stream), d_cw, lg_n, hb,
+                       ctx->d_tw_lo, ctx->d_tw_hi, d_out);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_fold_mle(const uint32_t* d_mle, int lg_n, sp1hip_ext_t beta, uint32_t* d_out, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(lg_n >= 1 && lg_n <= 30, "lg_n out of range");
+    SP1HIP_REQUIRE(d_mle && d_out, "null buffer");
+    ExtArg b;
+    for (int k = 0; k < 4; k++) b.c[k] = beta.c[k];
+    const uint32_t m = 1u << (lg_n - 1);
+    hipLaunchKernelGGL(fold_mle_kernel, dim3((m + 255) / 256), dim3(256), 0, S(stream), d_mle, lg_n, b, d_out);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_partial_lagrange(const sp1hip_ext_t* h_point, int dim, uint32_t* d_out, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(dim >= 0 && dim <= kb::TWO_ADICITY + 6, "dim out of range");
+    SP1HIP_REQUIRE(d_out && (h_point || dim == 0), "null buffer");
+    hipStream_t s = S(stream);
+    PointArg pt;
+    for (int j = 0; j < dim; j++)
+        for (int k = 0; k < 4; k++) pt.c[j][k] = h_point[j].c[k];
+    const int d_hi = dim / 2, d_lo = dim - d_hi;
+    AsyncScratch small;
+    SP1HIP_TRY(small.alloc((((size_t)1 << d_hi) + ((size_t)1 << d_lo)) * 16, s));
+    uint32_t* hi = (uint32_t*)small.p;
+    uint32_t* lo = hi + ((size_t)4 << d_hi);
+    hipLaunchKernelGGL(eq_small_kernel, dim3(((1u << d_hi) + 255) / 256), dim3(256), 0, s, pt, 0, d_hi, hi);
+    SP1HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(eq_small_kernel, dim3(((1u << d_lo) + 255) / 256), dim3(256), 0, s, pt, d_hi, d_lo, lo);
+    SP1HIP_LAUNCH_CHECK();
+    const uint32_t len = 1u << dim;
+    hipLaunchKernelGGL(eq_outer_kernel, dim3((len + 255) / 256), dim3(256), 0, s, hi, lo, d_lo, len, d_out);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_mle_eval_columns(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, const uint32_t* d_eq,
+                            uint32_t* d_evals, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(lg_height >= 0 && lg_height <= 30, "lg_height out of range");
+    SP1HIP_REQUIRE(d_eq && d_evals, "null buffer");
+    TensorTable tab;
+    uint32_t tw;
+    SP1HIP_TRY(make_tensor_table(tensors, n_tensors, &tab, &tw));
+    if (tw == 0) return SP1HIP_SUCCESS;
+    hipStream_t s = S(stream);
+    const uint32_t height = 1u << lg_height;
+    AsyncScratch cols, part;
+    SP1HIP_TRY(cols.alloc((size_t)tw * sizeof(uint32_t*), s));
+    SP1HIP_TRY(expand_columns_async(tab, tw, height, (const uint32_t**)cols.p, s));
+    const uint32_t chunks = (height + EVAL_ROWS - 1) / EVAL_ROWS;
+    SP1HIP_TRY(part.alloc((size_t)chunks * tw * 16, s));
+    dim3 grid(chunks, (tw + EVAL_COLS - 1) / EVAL_COLS);
+    hipLaunchKernelGGL(eval_columns_partial_kernel, grid, dim3(256), 0, s, (const uint32_t* const*)cols.p, tw, height,
+                       d_eq, (uint32_t*)part.p);
+    SP1HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((tw * 4 + 255) / 256), dim3(256), 0, s, (const uint32_t*)part.p, chunks,
+                       tw * 4, d_evals);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_ext_fixed_at_zero(const uint32_t* d_mle, int lg_n, const uint32_t* d_eq, uint32_t* d_out,
+                             sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(lg_n >= 1 && lg_n <= 30, "lg_n out of range");
+    SP1HIP_REQUIRE(d_mle && d_eq && d_out, "null buffer");
+    return ext_fixed_at_zero_async(d_mle, lg_n, d_eq, d_out, S(stream));
+}
+
+}  // extern "C"

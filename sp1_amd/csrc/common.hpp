@@ -1,0 +1,44 @@
+// sp1_amd/csrc/common.hpp — shared host-side plumbing for libsp1hip.so: status codes, the
+// thread-local error message, HIP error mapping, launch helpers, per-device constant upload.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/sp1hip.h"
+
+namespace sp1hip {
+
+void set_error(const char* fmt, ...);
+int map_hip_error(hipError_t e, const char* what);
+
+// Uploads the Poseidon2 round constants and builds the twiddle tables for the current device once.
+int ensure_device_ready();
+
+inline hipStream_t S(sp1hip_stream_t s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace sp1hip
+
+#define SP1HIP_TRY(expr)                                                   \
+    do {                                                                   \
+        int _st = (expr);                                                  \
+        if (_st != SP1HIP_SUCCESS) return _st;                             \
+    } while (0)
+
+#define SP1HIP_HIP(expr)                                                   \
+    do {                                                                   \
+        hipError_t _e = (expr);                                            \
+        if (_e != hipSuccess) return sp1hip::map_hip_error(_e, #expr);     \
+    } while (0)
+
+#define SP1HIP_REQUIRE(cond, msg)                                          \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            sp1hip::set_error("%s: %s", __func__, msg);                    \
+            return SP1HIP_ERROR_INVALID_ARGUMENT;                          \
+        }                                                                  \
+    } while (0)
+
+#define SP1HIP_LAUNCH_CHECK() SP1HIP_HIP(hipGetLastError())

@@ -1,0 +1,129 @@
+// sp1_amd/csrc/kb31.hpp — KoalaBear (p = 2^31 - 2^24 + 1) arithmetic for gfx950 device code and the
+// host-side transcript. Words are Montgomery form, R = 2^32, exactly the in-memory representation of
+// the reference's `SP1Field` (/root/reference/crates/primitives/src/lib.rs:L28-L31; Montgomery
+// conventions as restated in /root/reference/sp1-gpu/crates/sys/include/fields/kb31_t.cuh:L70-L135).
+//
+// gfx950 notes: 32x32 integer multiplies are the scarce resource, so
+//  * the Montgomery quotient digit uses p^-1 = 2^31 + 2^24 + 1 (two shift-adds, no multiply),
+//  * conditional corrections use the unsigned-min idiom (v_min_u32) instead of compare/select,
+//  * extension-field products accumulate in 64 bits and reduce once per output coefficient.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KB_HD __host__ __device__ __forceinline__
+
+namespace kb {
+
+constexpr uint32_t P = 0x7f000001u;
+constexpr uint32_t MU = 0x81000001u;       // p^-1 mod 2^32 = 2^31 + 2^24 + 1
+constexpr uint32_t R1 = 0x01fffffeu;       // 2^32 mod p   (Montgomery one)
+constexpr uint32_t R2 = 0x17f7efe4u;       // 2^64 mod p
+constexpr uint32_t GEN24 = 0x6ac49f88u;    // canonical two_adic_generator(24)
+constexpr int TWO_ADICITY = 24;
+
+KB_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+KB_HD uint32_t mulhi(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// x < 2^32 * p  ->  x * 2^-32 mod p, fully reduced
+KB_HD uint32_t monty_reduce(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    uint32_t t = lo + (lo << 24) + (lo << 31);   // lo * MU mod 2^32
+    uint32_t u = mulhi(t, P);
+    uint32_t r = hi - u;                         // == hi - u (mod 2^32); true value in (-p, p)
+    return umin(r, r + P);
+}
+
+KB_HD uint32_t add(uint32_t a, uint32_t b) { uint32_t s = a + b; return umin(s, s - P); }
+KB_HD uint32_t sub(uint32_t a, uint32_t b) { uint32_t d = a - b; return umin(d, d + P); }
+KB_HD uint32_t neg(uint32_t a) { return sub(0u, a); }
+KB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
+KB_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
+KB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
+KB_HD uint32_t to_monty(uint32_t canonical) { return mul(canonical, R2); }
+KB_HD uint32_t from_monty(uint32_t m) { return monty_reduce((uint64_t)m); }
+
+KB_HD uint32_t pow(uint32_t b, uint64_t e) {
+    uint32_t r = R1;
+    while (e) { if (e & 1) r = mul(r, b); b = sqr(b); e >>= 1; }
+    return r;
+}
+KB_HD uint32_t inv(uint32_t a) { return pow(a, P - 2); }
+
+KB_HD uint32_t two_adic_generator(int bits) {
+    uint32_t g = to_monty(GEN24);
+    for (int i = bits; i < TWO_ADICITY; i++) g = sqr(g);
+    return g;
+}
+
+KB_HD uint32_t reverse_bits_len(uint32_t x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0u;
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+// ---- EF = F[x]/(x^4 - 3); c[0..3] = coefficient order = base-slice order ------------------------
+struct Ext {
+    uint32_t c[4];
+};
+
+KB_HD Ext ext_zero() { return Ext{{0, 0, 0, 0}}; }
+KB_HD Ext ext_one() { return Ext{{R1, 0, 0, 0}}; }
+KB_HD Ext ext_from_base(uint32_t b) { return Ext{{b, 0, 0, 0}}; }
+KB_HD bool ext_eq(const Ext& a, const Ext& b) {
+    return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
+}
+KB_HD Ext ext_add(const Ext& a, const Ext& b) {
+    return Ext{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}};
+}
+KB_HD Ext ext_sub(const Ext& a, const Ext& b) {
+    return Ext{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}};
+}
+KB_HD Ext ext_mul_base(const Ext& a, uint32_t b) {
+    return Ext{{mul(a.c[0], b), mul(a.c[1], b), mul(a.c[2], b), mul(a.c[3], b)}};
+}
+
+// Full product with delayed reduction: monty_reduce accepts x < 2^32 p, and two products of reduced
+// words satisfy 2 p^2 < 2^32 p, so every output coefficient is two 2-product accumulations (the
+// second product rides the multiply-add), two reductions and one add. The x^4 = 3 wrap is applied
+// to b up front with two modular additions per coefficient instead of a multiply.
+KB_HD Ext ext_mul(const Ext& a, const Ext& b) {
+    const uint32_t w1 = add(dbl(b.c[1]), b.c[1]), w2 = add(dbl(b.c[2]), b.c[2]), w3 = add(dbl(b.c[3]), b.c[3]);
+    Ext r;
+    r.c[0] = add(monty_reduce((uint64_t)a.c[0] * b.c[0] + (uint64_t)a.c[1] * w3),
+                 monty_reduce((uint64_t)a.c[2] * w2 + (uint64_t)a.c[3] * w1));
+    r.c[1] = add(monty_reduce((uint64_t)a.c[0] * b.c[1] + (uint64_t)a.c[1] * b.c[0]),
+                 monty_reduce((uint64_t)a.c[2] * w3 + (uint64_t)a.c[3] * w2));
+    r.c[2] = add(monty_reduce((uint64_t)a.c[0] * b.c[2] + (uint64_t)a.c[1] * b.c[1]),
+                 monty_reduce((uint64_t)a.c[2] * b.c[0] + (uint64_t)a.c[3] * w3));
+    r.c[3] = add(monty_reduce((uint64_t)a.c[0] * b.c[3] + (uint64_t)a.c[1] * b.c[2]),
+                 monty_reduce((uint64_t)a.c[2] * b.c[1] + (uint64_t)a.c[3] * b.c[0]));
+    return r;
+}
+
+// Inverse through the tower F < F[y]/(y^2-3) < EF, y = x^2 (host-side transcript use only).
+KB_HD Ext ext_inv(const Ext& a) {
+    const uint32_t W = 0x05fffffau;
+    uint32_t A0 = a.c[0], A1 = a.c[2], B0 = a.c[1], B1 = a.c[3];
+    uint32_t A2_0 = add(sqr(A0), mul(W, sqr(A1))), A2_1 = dbl(mul(A0, A1));
+    uint32_t B2_0 = add(sqr(B0), mul(W, sqr(B1))), B2_1 = dbl(mul(B0, B1));
+    uint32_t D0 = sub(A2_0, mul(W, B2_1)), D1 = sub(A2_1, B2_0);
+    uint32_t n = inv(sub(sqr(D0), mul(W, sqr(D1))));
+    uint32_t I0 = mul(D0, n), I1 = neg(mul(D1, n));
+    uint32_t rA0 = add(mul(A0, I0), mul(W, mul(A1, I1))), rA1 = add(mul(A0, I1), mul(A1, I0));
+    uint32_t rB0 = add(mul(B0, I0), mul(W, mul(B1, I1))), rB1 = add(mul(B0, I1), mul(B1, I0));
+    return Ext{{rA0, neg(rB0), rA1, neg(rB1)}};
+}
+
+}  // namespace kb

@@ -1,0 +1,264 @@
+// sp1_amd/csrc/merkle.hip — Poseidon2 Merkle tensor commitment on gfx950.
+//
+// Replaces `FieldMerkleTreeProver::{commit_tensors, prove_openings_at_indices}` and
+// `compute_openings_at_indices` (/root/reference/slop/crates/merkle-tree/src/p3sync.rs:L40-L238) for
+// `Poseidon2KoalaBear16Prover`; the commitment finalisation compress(root, hash([log_height, width]))
+// is p3sync.rs:L136-L142.
+//
+// Kernel shapes:
+//  * leaf_hash: one lane per row. A lane walks the concatenated row 8 columns at a time; every
+//    column load is coalesced across the wave (consecutive rows of one column-major column), the
+//    16-word sponge state stays in VGPRs across all absorb blocks. ALU-bound (~12k integer op
+//    slots per permutation vs 32 bytes loaded), so no LDS staging: extra waves, not tiling, hide
+//    the load latency.
+//  * compress_layer: one lane per parent, 64 B in (2 x dwordx4 x 2), 32 B out.
+//  * compress_top: the last <= 11 levels in one workgroup (one launch instead of eleven ~2 us ones).
+#include "device_ctx.hpp"
+#include "tensor_table.hpp"
+
+namespace sp1hip {
+
+__global__ void expand_columns_kernel(TensorTable tab, uint32_t total_width, uint64_t height, const uint32_t** out) {
+    for (uint32_t g = threadIdx.x; g < total_width; g += blockDim.x) {
+        int t = 0;
+        while (tab.col_start[t + 1] <= g) t++;
+        out[g] = tab.base[t] + (uint64_t)(g - tab.col_start[t]) * height;
+    }
+}
+
+int make_tensor_table(const sp1hip_tensor_t* tensors, int n_tensors, TensorTable* tab, uint32_t* total_width) {
+    SP1HIP_REQUIRE(tensors && n_tensors > 0, "empty tensor message");
+    SP1HIP_REQUIRE(n_tensors <= MAX_TENSORS, "too many tensors in one message (max 128)");
+    uint32_t w = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        SP1HIP_REQUIRE(tensors[i].d_data != nullptr || tensors[i].width == 0, "null tensor data");
+        tab->base[i] = tensors[i].d_data;
+        tab->col_start[i] = w;
+        w += tensors[i].width;
+    }
+    tab->col_start[n_tensors] = w;
+    tab->n = n_tensors;
+    *total_width = w;
+    return SP1HIP_SUCCESS;
+}
+
+int expand_columns_async(const TensorTable& tab, uint32_t total_width, uint64_t height, const uint32_t** d_cols,
+                         hipStream_t stream) {
+    if (total_width == 0) return SP1HIP_SUCCESS;
+    hipLaunchKernelGGL(expand_columns_kernel, dim3(1), dim3(256), 0, stream, tab, total_width, height, d_cols);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+__device__ __forceinline__ void store_digest(uint32_t* dst, const uint32_t (&s)[16]) {
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+__global__ __launch_bounds__(256) void leaf_hash_kernel(const uint32_t* const* __restrict__ cols, uint32_t total_width,
+                                                        uint32_t height, const p2::RoundConstants* __restrict__ rc,
+                                                        uint32_t* __restrict__ leaves) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= height) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    const uint32_t full = total_width >> 3;
+    for (uint32_t k = 0; k < full; k++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = cols[8 * k + j][row];
+        p2::permute(s, *rc);
+    }
+    const uint32_t rem = total_width & 7u;
+    if (rem) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((uint32_t)j < rem) s[j] = cols[8 * full + j][row];
+        p2::permute(s, *rc);
+    }
+    store_digest(leaves + (size_t)row * 8, s);
+}
+
+__device__ __forceinline__ void load_pair(const uint32_t* src, uint32_t (&s)[16]) {
+    const uint4* p = reinterpret_cast<const uint4*>(src);
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w;
+    s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = c.w;
+    s[12] = d.x; s[13] = d.y; s[14] = d.z; s[15] = d.w;
+}
+
+__global__ __launch_bounds__(256) void compress_layer_kernel(const uint32_t* __restrict__ children, uint32_t n_parents,
+                                                             const p2::RoundConstants* __restrict__ rc,
+                                                             uint32_t* __restrict__ parents) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_parents) return;
+    uint32_t s[16];
+    load_pair(children + (size_t)i * 16, s);
+    p2::permute(s, *rc);
+    store_digest(parents + (size_t)i * 8, s);
+}
+
+// One workgroup finishes the tree: `layer` holds n (<= 2048, power of two) digests and the parents
+// are laid out right behind it, level after level. Also writes root and the finalised commitment.
+__global__ __launch_bounds__(1024) void compress_top_kernel(uint32_t* layer, uint32_t n, uint32_t lg_height,
+                                                            uint32_t total_width,
+                                                            const p2::RoundConstants* __restrict__ rc,
+                                                            uint32_t* __restrict__ root_and_commit) {
+    uint32_t* cur = layer;
+    while (n > 1) {
+        uint32_t* nxt = cur + (size_t)n * 8;
+        const uint32_t np = n >> 1;
+        for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
+            uint32_t s[16];
+            load_pair(cur + (size_t)i * 16, s);
+            p2::permute(s, *rc);
+            store_digest(nxt + (size_t)i * 8, s);
+        }
+        __syncthreads();
+        cur = nxt;
+        n = np;
+    }
+    if (threadIdx.x == 0) {
+        // commitment = compress(root, hash([lg_height, total_width]))
+        uint32_t h[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) h[i] = 0;
+        h[0] = kb::to_monty(lg_height);
+        h[1] = kb::to_monty(total_width);
+        p2::permute(h, *rc);
+        uint32_t s[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { s[i] = cur[i]; s[8 + i] = h[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) root_and_commit[i] = cur[i];
+        p2::permute(s, *rc);
+#pragma unroll
+        for (int i = 0; i < 8; i++) root_and_commit[8 + i] = s[i];
+    }
+}
+
+__global__ void permute_states_kernel(uint32_t* states, size_t n, const p2::RoundConstants* __restrict__ rc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = states[i * 16 + k];
+    p2::permute(s, *rc);
+#pragma unroll
+    for (int k = 0; k < 16; k++) states[i * 16 + k] = s[k];
+}
+
+__global__ void open_values_kernel(const uint32_t* const* __restrict__ cols, uint32_t total_width,
+                                   const uint32_t* __restrict__ indices, size_t n_idx, uint32_t* __restrict__ values) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * total_width) return;
+    size_t q = t / total_width;
+    uint32_t g = (uint32_t)(t % total_width);
+    values[t] = cols[g][indices[q]];
+}
+
+// paths[q][k][0..8] = layer_k[(idx >> k) ^ 1]; one lane per (q, k, half-digest)
+__global__ void open_paths_kernel(const uint32_t* __restrict__ tree, uint32_t lg_height,
+                                  const uint32_t* __restrict__ indices, size_t n_idx, uint32_t* __restrict__ paths) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * lg_height * 2) return;
+    uint32_t half = (uint32_t)(t & 1);
+    size_t qk = t >> 1;
+    uint32_t k = (uint32_t)(qk % lg_height);
+    size_t q = qk / lg_height;
+    // layer k starts at digest offset 2^(h+1) - 2^(h-k+1)
+    uint64_t off = ((uint64_t)2 << lg_height) - ((uint64_t)2 << (lg_height - k));
+    uint64_t node = off + ((indices[q] >> k) ^ 1u);
+    const uint4* src = reinterpret_cast<const uint4*>(tree + node * 8) + half;
+    reinterpret_cast<uint4*>(paths + (qk * 8))[half] = *src;
+}
+
+// Compresses the leaf layer at d_tree up to the root and finalises the commitment.
+int merkle_finish_tree(uint32_t* d_tree, int lg_height, uint32_t total_width, uint32_t* d_root_and_commit,
+                       const DeviceCtx* ctx, hipStream_t s) {
+    uint32_t* cur = d_tree;
+    uint32_t n = 1u << lg_height;
+    while (n > 2048) {
+        uint32_t* nxt = cur + (size_t)n * 8;
+        hipLaunchKernelGGL(compress_layer_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, s, cur, n / 2, ctx->d_rc,
+                           nxt);
+        SP1HIP_LAUNCH_CHECK();
+        cur = nxt;
+        n >>= 1;
+    }
+    hipLaunchKernelGGL(compress_top_kernel, dim3(1), dim3(1024), 0, s, cur, n, (uint32_t)lg_height, total_width,
+                       ctx->d_rc, d_root_and_commit);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+}  // namespace sp1hip
+
+using namespace sp1hip;
+
+extern "C" {
+
+int sp1hip_merkle_commit(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, uint32_t* d_tree,
+                         uint32_t* d_root_and_commit, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(lg_height >= 0 && lg_height <= 30, "lg_height out of range");
+    SP1HIP_REQUIRE(d_tree && d_root_and_commit, "null output");
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));
+    TensorTable tab;
+    uint32_t tw;
+    SP1HIP_TRY(make_tensor_table(tensors, n_tensors, &tab, &tw));
+    const uint32_t height = 1u << lg_height;
+    hipStream_t s = S(stream);
+    AsyncScratch cols;
+    SP1HIP_TRY(cols.alloc((size_t)tw * sizeof(uint32_t*), s));
+    SP1HIP_TRY(expand_columns_async(tab, tw, height, (const uint32_t**)cols.p, s));
+    hipLaunchKernelGGL(leaf_hash_kernel, dim3((height + 255) / 256), dim3(256), 0, s, (const uint32_t* const*)cols.p,
+                       tw, height, ctx->d_rc, d_tree);
+    SP1HIP_LAUNCH_CHECK();
+    return merkle_finish_tree(d_tree, lg_height, tw, d_root_and_commit, ctx, s);
+}
+
+int sp1hip_merkle_open(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, const uint32_t* d_tree,
+                       const uint32_t* d_indices, size_t n_idx, uint32_t* d_values, uint32_t* d_paths,
+                       sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(lg_height >= 0 && lg_height <= 30, "lg_height out of range");
+    SP1HIP_REQUIRE(d_indices || n_idx == 0, "null indices");
+    if (n_idx == 0) return SP1HIP_SUCCESS;
+    hipStream_t s = S(stream);
+    if (d_values) {
+        TensorTable tab;
+        uint32_t tw;
+        SP1HIP_TRY(make_tensor_table(tensors, n_tensors, &tab, &tw));
+        AsyncScratch cols;
+        SP1HIP_TRY(cols.alloc((size_t)tw * sizeof(uint32_t*), s));
+        SP1HIP_TRY(expand_columns_async(tab, tw, (uint64_t)1 << lg_height, (const uint32_t**)cols.p, s));
+        size_t total = n_idx * tw;
+        if (total) {
+            hipLaunchKernelGGL(open_values_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                               (const uint32_t* const*)cols.p, tw, d_indices, n_idx, d_values);
+            SP1HIP_LAUNCH_CHECK();
+        }
+    }
+    if (d_paths && lg_height > 0) {
+        SP1HIP_REQUIRE(d_tree, "null tree");
+        size_t total = n_idx * lg_height * 2;
+        hipLaunchKernelGGL(open_paths_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d_tree, (uint32_t)lg_height,
+                           d_indices, n_idx, d_paths);
+        SP1HIP_LAUNCH_CHECK();
+    }
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_poseidon2_permute(uint32_t* d_states, size_t n, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(d_states || n == 0, "null states");
+    if (!n) return SP1HIP_SUCCESS;
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));
+    hipLaunchKernelGGL(permute_states_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), d_states, n, ctx->d_rc);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+}  // extern "C"

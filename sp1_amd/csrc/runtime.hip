@@ -1,0 +1,164 @@
+// sp1_amd/csrc/runtime.hip — runtime half of the C ABI (memory, streams, events, errors) and the
+// per-device context. HIP-native equivalents of the reference's runtime shims
+// (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L16-L172): hipMallocAsync-backed allocation,
+// streams, events; no globals other than the per-device contexts.
+#include <mutex>
+#include <vector>
+
+#include "device_ctx.hpp"
+
+namespace sp1hip {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int map_hip_error(hipError_t e, const char* what) {
+    set_error("%s failed: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();  // clear the sticky error
+    switch (e) {
+        case hipErrorOutOfMemory: return SP1HIP_ERROR_OUT_OF_MEMORY;
+        case hipErrorNotReady: return SP1HIP_ERROR_NOT_READY;
+        case hipErrorNoDevice:
+        case hipErrorInvalidDevice: return SP1HIP_ERROR_NO_DEVICE;
+        case hipErrorInvalidValue: return SP1HIP_ERROR_INVALID_ARGUMENT;
+        default: return SP1HIP_ERROR_RUNTIME;
+    }
+}
+
+static std::mutex g_ctx_mutex;
+static std::vector<DeviceCtx*> g_ctx;
+
+int get_device_ctx(const DeviceCtx** out) {
+    int dev = -1;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if ((int)g_ctx.size() <= dev) g_ctx.resize(dev + 1, nullptr);
+    if (!g_ctx[dev]) {
+        DeviceCtx* c = new DeviceCtx();
+        c->device = dev;
+        hipDeviceProp_t prop;
+        SP1HIP_HIP(hipGetDeviceProperties(&prop, dev));
+        c->num_cus = prop.multiProcessorCount;
+        p2::RoundConstants rc = p2::make_round_constants();
+        SP1HIP_HIP(hipMalloc((void**)&c->d_rc, sizeof rc));
+        SP1HIP_HIP(hipMemcpy(c->d_rc, &rc, sizeof rc, hipMemcpyHostToDevice));
+        std::vector<uint32_t> lo(TW_LO), hi(TW_HI);
+        uint32_t g = kb::two_adic_generator(kb::TWO_ADICITY), cur = kb::R1;
+        for (int i = 0; i < TW_LO; i++) { lo[i] = cur; cur = kb::mul(cur, g); }
+        uint32_t gh = cur;  // g^4096
+        cur = kb::R1;
+        for (int i = 0; i < TW_HI; i++) { hi[i] = cur; cur = kb::mul(cur, gh); }
+        SP1HIP_HIP(hipMalloc((void**)&c->d_tw_lo, TW_LO * 4));
+        SP1HIP_HIP(hipMalloc((void**)&c->d_tw_hi, TW_HI * 4));
+        SP1HIP_HIP(hipMemcpy(c->d_tw_lo, lo.data(), TW_LO * 4, hipMemcpyHostToDevice));
+        SP1HIP_HIP(hipMemcpy(c->d_tw_hi, hi.data(), TW_HI * 4, hipMemcpyHostToDevice));
+        g_ctx[dev] = c;
+    }
+    *out = g_ctx[dev];
+    return SP1HIP_SUCCESS;
+}
+
+}  // namespace sp1hip
+
+using namespace sp1hip;
+
+extern "C" {
+
+const char* sp1hip_last_error(void) { return g_last_error.c_str(); }
+const char* sp1hip_version(void) { return "sp1hip 0.1.0 (gfx950; KoalaBear; Poseidon2-16)"; }
+
+int sp1hip_device_count(int* count) {
+    SP1HIP_REQUIRE(count, "null count");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e == hipErrorNoDevice) { *count = 0; (void)hipGetLastError(); return SP1HIP_SUCCESS; }
+    SP1HIP_HIP(e);
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_set_device(int device) { SP1HIP_HIP(hipSetDevice(device)); return SP1HIP_SUCCESS; }
+int sp1hip_get_device(int* device) { SP1HIP_REQUIRE(device, "null"); SP1HIP_HIP(hipGetDevice(device)); return SP1HIP_SUCCESS; }
+int sp1hip_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    SP1HIP_REQUIRE(free_bytes && total_bytes, "null output");
+    SP1HIP_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_malloc(void** d_ptr, size_t bytes) {
+    SP1HIP_REQUIRE(d_ptr, "null output");
+    SP1HIP_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_free(void* d_ptr) { SP1HIP_HIP(hipFree(d_ptr)); return SP1HIP_SUCCESS; }
+int sp1hip_malloc_async(void** d_ptr, size_t bytes, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(d_ptr, "null output");
+    SP1HIP_HIP(hipMallocAsync(d_ptr, bytes ? bytes : 1, S(stream)));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_free_async(void* d_ptr, sp1hip_stream_t stream) { SP1HIP_HIP(hipFreeAsync(d_ptr, S(stream))); return SP1HIP_SUCCESS; }
+int sp1hip_malloc_host(void** h_ptr, size_t bytes) {
+    SP1HIP_REQUIRE(h_ptr, "null output");
+    SP1HIP_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_free_host(void* h_ptr) { SP1HIP_HIP(hipHostFree(h_ptr)); return SP1HIP_SUCCESS; }
+int sp1hip_memcpy_h2d_async(void* d, const void* h, size_t n, sp1hip_stream_t s) {
+    SP1HIP_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, S(s)));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_memcpy_d2h_async(void* h, const void* d, size_t n, sp1hip_stream_t s) {
+    SP1HIP_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, S(s)));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_memcpy_d2d_async(void* d, const void* src, size_t n, sp1hip_stream_t s) {
+    SP1HIP_HIP(hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, S(s)));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_memset_async(void* d, int v, size_t n, sp1hip_stream_t s) {
+    SP1HIP_HIP(hipMemsetAsync(d, v, n, S(s)));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_stream_create(sp1hip_stream_t* stream) {
+    SP1HIP_REQUIRE(stream, "null output");
+    hipStream_t s;
+    SP1HIP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_stream_destroy(sp1hip_stream_t stream) { SP1HIP_HIP(hipStreamDestroy(S(stream))); return SP1HIP_SUCCESS; }
+int sp1hip_stream_synchronize(sp1hip_stream_t stream) { SP1HIP_HIP(hipStreamSynchronize(S(stream))); return SP1HIP_SUCCESS; }
+int sp1hip_stream_query(sp1hip_stream_t stream) {
+    hipError_t e = hipStreamQuery(S(stream));
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return SP1HIP_ERROR_NOT_READY; }
+    SP1HIP_HIP(e);
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_event_create(sp1hip_event_t* event) {
+    SP1HIP_REQUIRE(event, "null output");
+    hipEvent_t e;
+    SP1HIP_HIP(hipEventCreate(&e));
+    *event = e;
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_event_destroy(sp1hip_event_t event) { SP1HIP_HIP(hipEventDestroy((hipEvent_t)event)); return SP1HIP_SUCCESS; }
+int sp1hip_event_record(sp1hip_event_t event, sp1hip_stream_t stream) {
+    SP1HIP_HIP(hipEventRecord((hipEvent_t)event, S(stream)));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_event_synchronize(sp1hip_event_t event) { SP1HIP_HIP(hipEventSynchronize((hipEvent_t)event)); return SP1HIP_SUCCESS; }
+int sp1hip_event_elapsed_ms(float* ms, sp1hip_event_t start, sp1hip_event_t stop) {
+    SP1HIP_REQUIRE(ms, "null output");
+    SP1HIP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_stream_wait_event(sp1hip_stream_t stream, sp1hip_event_t event) {
+    SP1HIP_HIP(hipStreamWaitEvent(S(stream), (hipEvent_t)event, 0));
+    return SP1HIP_SUCCESS;
+}
+
+}  // extern "C"

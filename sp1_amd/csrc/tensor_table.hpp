@@ -1,0 +1,38 @@
+// sp1_amd/csrc/tensor_table.hpp — a `Message<Tensor>` (several column-major tensors of equal height)
+// flattened into one device table of column base pointers, so kernels index "column g of the
+// concatenated row" with one wave-uniform (scalar-cache) pointer load.
+#pragma once
+#include "common.hpp"
+
+namespace sp1hip {
+
+constexpr int MAX_TENSORS = 128;
+
+struct TensorTable {
+    const uint32_t* base[MAX_TENSORS];
+    uint32_t col_start[MAX_TENSORS + 1];  // prefix sums of widths
+    int n;
+};
+
+// Validates the message and fills `tab`; returns total width through *total_width.
+int make_tensor_table(const sp1hip_tensor_t* tensors, int n_tensors, TensorTable* tab, uint32_t* total_width);
+
+// Enqueues the expansion of `tab` into d_cols[total_width] (device pointers to each column).
+int expand_columns_async(const TensorTable& tab, uint32_t total_width, uint64_t height, const uint32_t** d_cols,
+                         hipStream_t stream);
+
+// RAII stream-ordered scratch allocation.
+struct AsyncScratch {
+    void* p = nullptr;
+    hipStream_t s = nullptr;
+    int alloc(size_t bytes, hipStream_t stream) {
+        s = stream;
+        SP1HIP_HIP(hipMallocAsync(&p, bytes ? bytes : 1, stream));
+        return SP1HIP_SUCCESS;
+    }
+    ~AsyncScratch() {
+        if (p) (void)hipFreeAsync(p, s);
+    }
+};
+
+}  // namespace sp1hip

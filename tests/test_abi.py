@@ -1,0 +1,109 @@
+"""CPU-side checks of the drop-in boundary: libsp1hip.so builds for gfx950, loads without a GPU, exports
+every function include/sp1hip.h declares, validates arguments before touching a device, and its
+host-side transcript (no kernels involved) matches the oracle."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import pyoracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build_hip()
+    from sp1_amd import _lib
+    return _lib.load()
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "sp1hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(sp1hip_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from sp1_amd import _lib
+    names = _declared()
+    assert len(names) >= 50
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "missing export: " + n
+    assert sorted(n for n, _, _ in _lib.PROTOTYPES) == names, "ctypes prototypes out of sync with the header"
+
+
+def test_header_is_plain_c():
+    import subprocess
+    src = '#include "sp1hip.h"\nint main(void){ sp1hip_fri_config_t c = {2,124,16}; return c.log_blowup - 2; }\n'
+    p = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I",
+                        os.path.join(ROOT, "include"), "-x", "c", "-"], input=src.encode(), capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+
+
+def test_argument_validation_needs_no_device(lib):
+    assert lib.sp1hip_version().startswith(b"sp1hip")
+    n = C.c_int(-1)
+    assert lib.sp1hip_device_count(C.byref(n)) == 0 and n.value >= 0
+    assert lib.sp1hip_rs_encode_batch(None, None, 20, 5, 1, None) == -1
+    assert b"two-adicity" in lib.sp1hip_last_error()
+    assert lib.sp1hip_rs_encode_batch(None, None, 3, 1, 0, None) == 0          # empty batch is a no-op
+    assert lib.sp1hip_merkle_commit(None, 0, 3, None, None, None) == -1
+    from sp1_amd._lib import Ext
+    assert lib.sp1hip_fold_even_odd(None, 0, Ext(), None, None) == -1
+    assert lib.sp1hip_challenger_observe(None, None, 0) == -1
+
+
+def test_host_transcript_matches_oracle(lib):
+    from sp1_amd._lib import Ext
+    h = C.c_void_p()
+    assert lib.sp1hip_challenger_new(C.byref(h)) == 0
+    o = orc.Challenger()
+    rng = np.random.default_rng(4)
+    for step in range(300):
+        op = rng.integers(0, 4)
+        if op == 0:
+            xs = orc.random_felts((int(rng.integers(1, 20)),), step)
+            assert lib.sp1hip_challenger_observe(h, xs.ctypes.data_as(C.POINTER(C.c_uint32)), xs.size) == 0
+            o.observe(xs)
+        elif op == 1:
+            v = C.c_uint32()
+            assert lib.sp1hip_challenger_sample(h, C.byref(v)) == 0
+            assert v.value == o.sample()
+        elif op == 2:
+            e = Ext()
+            assert lib.sp1hip_challenger_sample_ext(h, C.byref(e)) == 0
+            assert list(e.c) == o.sample_ext().tolist()
+        else:
+            bits, v = int(rng.integers(1, 31)), C.c_uint32()
+            assert lib.sp1hip_challenger_sample_bits(h, bits, C.byref(v)) == 0
+            assert v.value == o.sample_bits(bits)
+    st = np.zeros(34, np.uint32)
+    assert lib.sp1hip_challenger_state(h, st.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+    assert np.array_equal(st, o.state())
+    # <= 8-bit grinding runs on the host: smallest witness, same post-state as the oracle
+    w = C.c_uint32()
+    assert lib.sp1hip_challenger_grind(h, 7, C.byref(w), None) == 0
+    assert w.value == o.grind(7)
+    assert lib.sp1hip_challenger_state(h, st.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+    assert np.array_equal(st, o.state())
+    lib.sp1hip_challenger_free(h)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path may never import, link or call anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sp1_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "kb_pcs" not in txt, f
+    from sp1_amd import _lib
+    import subprocess
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True).stdout.decode()
+    assert "oracle" not in out

@@ -1,0 +1,317 @@
+"""GPU parity tests (-m gpu): every HIP entry point of the C ABI against the CPU oracle on the same
+seeded inputs, bit-exact (KoalaBear is integer arithmetic — no tolerance anywhere).
+
+Shapes follow the reference's own tests: Merkle [2^10 x 25] x 10 tensors with 5 openings
+(/root/reference/slop/crates/merkle-tree/src/p3sync.rs:L240-L305), RS encode log sizes 1..15 batch 16
+(/root/reference/sp1-gpu/crates/basefold/src/encoder.rs:L164-L211), BaseFold widths
+[16,10,14],[20,78,34],[10,10] (/root/reference/slop/crates/basefold-prover/src/prover.rs:L288-L361).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import kb_py  # noqa: E402
+import pyoracle as orc  # noqa: E402
+
+P = kb_py.P
+
+
+@pytest.fixture(scope="module")
+def api():
+    from sp1_amd import api as a
+    torch.cuda.set_device(0)
+    return a
+
+
+def col_major_host(t):
+    return t.to_row_major_host()
+
+
+def test_monty_roundtrip_and_permute(api):
+    rng = np.random.default_rng(1)
+    canon = rng.integers(0, P, 4096).astype(np.uint32)
+    d = api.to_device(canon)
+    api.check(api._L().sp1hip_to_monty(api._dptr(d), canon.size, api._stream_ptr()))
+    assert np.array_equal(api.to_host(d), orc.to_monty(canon))
+    api.check(api._L().sp1hip_from_monty(api._dptr(d), canon.size, api._stream_ptr()))
+    assert np.array_equal(api.to_host(d), canon)
+    states = orc.random_felts((1000, 16), 3)
+    d = api.to_device(states)
+    api.check(api._L().sp1hip_poseidon2_permute(api._dptr(d), 1000, api._stream_ptr()))
+    got = api.to_host(d, (1000, 16))
+    for i in (0, 1, 17, 999):
+        assert np.array_equal(got[i], orc.permute(states[i]))
+    zero = api.to_device(np.zeros(16, np.uint32))
+    api.check(api._L().sp1hip_poseidon2_permute(api._dptr(zero), 1, api._stream_ptr()))
+    assert orc.from_monty(api.to_host(zero)).tolist() == kb_py.KAT_PERM_ZERO
+
+
+def test_transpose_roundtrip(api):
+    for shape in ((1, 1), (5, 3), (33, 65), (1000, 25), (4096, 7)):
+        a = orc.random_felts(shape, 5)
+        t = api.ColMajor.from_row_major_host(a)
+        assert np.array_equal(api.to_host(t.words, (shape[1], shape[0])), a.T)
+        assert np.array_equal(t.to_row_major_host(), a)
+
+
+@pytest.mark.parametrize("lg_n", list(range(0, 16)))
+def test_rs_encode_matches_oracle(api, lg_n):
+    """log sizes 0..15, batch 16, blowup 1 and 2 (the reference's GPU-vs-CPU test sweeps 1..15 x 16)."""
+    for lb in (1, 2):
+        if lg_n + lb > 16:
+            continue
+        m = orc.random_felts((1 << lg_n, 16), 100 + lg_n)
+        want = orc.rs_encode(m, lb)
+        got = api.DftEncoder(lb).encode_batch([api.ColMajor.from_row_major_host(m)])[0]
+        assert np.array_equal(got.to_row_major_host(), want), (lg_n, lb)
+
+
+@pytest.mark.parametrize("lg_n,lb,w", [(17, 2, 3), (18, 2, 2), (20, 2, 1), (21, 2, 1), (20, 0, 1), (22, 2, 1), (22, 1, 2)])
+def test_rs_encode_large_multi_pass(api, lg_n, lb, w):
+    """Two- and three-pass plans up to the two-adicity limit 2^24 (core shards encode 2^21 -> 2^23)."""
+    m = orc.random_felts((1 << lg_n, w), 7)
+    want = orc.rs_encode(m, lb)
+    got = api.DftEncoder(lb).encode_batch([api.ColMajor.from_row_major_host(m)])[0]
+    assert np.array_equal(got.to_row_major_host(), want)
+
+
+def test_rs_encode_rejects_bad_sizes(api):
+    m = api.ColMajor(api.device_words(4), 4, 1)
+    with pytest.raises(api._lib.Sp1HipError):
+        api.DftEncoder(23).encode_batch([m])          # exceeds two-adicity
+    out = api.device_words(16)
+    st = api._L().sp1hip_rs_encode_batch(api._dptr(out), api._dptr(out), 2, 2, 1, api._stream_ptr())
+    assert st == -1 and b"alias" in api._L().sp1hip_last_error()
+
+
+@pytest.mark.parametrize("height,widths", [(1 << 10, [25] * 10), (1, [3]), (2, [8]), (256, [1]), (1 << 12, [7, 9, 16, 1]),
+                                            (1 << 13, [32, 32, 32]), (64, [200])])
+def test_merkle_commit_and_openings(api, height, widths):
+    ts = [orc.random_felts((height, w), 40 + i) for i, w in enumerate(widths)]
+    want = orc.MerkleTree(ts)
+    tcs = api.MerkleTcsProver()
+    d_ts = [api.ColMajor.from_row_major_host(t) for t in ts]
+    commit, data = tcs.commit_tensors(d_ts)
+    assert np.array_equal(commit, want.commit)
+    assert np.array_equal(data.root, want.root())
+    assert np.array_equal(api.to_host(data.tree, (2 * height - 1, 8)), want.layers())
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, height, 5).tolist() + [0, height - 1]
+    vals = tcs.compute_openings_at_indices(d_ts, idx)
+    assert np.array_equal(vals, np.concatenate([t[idx] for t in ts], axis=1))
+    proof = tcs.prove_openings_at_indices(data, idx)
+    assert np.array_equal(proof["paths"], want.paths(idx))
+    lg = height.bit_length() - 1
+    assert orc.merkle_verify(commit, idx, vals, lg, proof["merkle_root"], proof["paths"]) == 0
+
+
+def test_golden_leaves_hash_like_the_reference(api):
+    """Rows opened in the reference's real proof, hashed by the HIP leaf kernel, must walk their
+    stored Merkle paths to the stored roots (Poseidon2/sponge on the GPU == reference)."""
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "kb_shrink_basefold.npz"))
+    q = gold["query_indices"].astype(np.uint64)
+    tcs = api.MerkleTcsProver()
+    for name, log_h, shift in (("comp0", 22, 0), ("comp1", 22, 0), ("round00", 21, 1), ("round19", 2, 20)):
+        vals = orc.to_monty(gold[name + "_values"])
+        rows = 16                                         # pad the 12 rows to a power of two
+        padded = np.zeros((rows, vals.shape[1]), np.uint32)
+        padded[:vals.shape[0]] = vals
+        _, data = tcs.commit_tensors([api.ColMajor.from_row_major_host(padded)])
+        leaves = api.to_host(data.tree, (2 * rows - 1, 8))[:vals.shape[0]]
+        paths = orc.to_monty(gold[name + "_paths"])
+        root = orc.to_monty(gold[name + "_root"])
+        for k in range(vals.shape[0]):
+            node, idx = leaves[k], int(q[k]) >> shift
+            for sib in paths[k]:
+                node = orc.compress(node, sib) if idx & 1 == 0 else orc.compress(sib, node)
+                idx >>= 1
+            assert np.array_equal(node, root), (name, k)
+
+
+def _ext_soa(a):
+    return np.ascontiguousarray(a.T)     # [n][4] -> [4][n]
+
+
+def test_basefold_kernels(api):
+    L = api._L()
+    s = api._stream_ptr()
+    rng = np.random.default_rng(21)
+    # partial_lagrange for dims 0..13
+    for dim in (0, 1, 2, 5, 13):
+        pt = orc.random_felts((dim, 4), 60 + dim)
+        out = api.device_words(4 << dim)
+        api.check(L.sp1hip_partial_lagrange(api._ext_array(pt), dim, api._dptr(out), s))
+        assert np.array_equal(api.to_host(out, (4, 1 << dim)).T, orc.partial_lagrange(pt)), dim
+    # batch + column evaluations over a multi-tensor message with ragged widths
+    lg = 11
+    ts = [orc.random_felts((1 << lg, w), 70 + i) for i, w in enumerate((5, 32, 1, 10))]
+    d_ts = [api.ColMajor.from_row_major_host(t) for t in ts]
+    tw = sum(t.shape[1] for t in ts)
+    coeffs = orc.random_felts((tw, 4), 77)
+    out = api.device_words(4 << lg)
+    api.check(L.sp1hip_basefold_batch(api._tensor_array(d_ts), len(d_ts), lg, api._dptr(api.to_device(coeffs)),
+                                      api._dptr(out), s))
+    allcols = np.concatenate(ts, axis=1)
+    want = np.zeros((1 << lg, 4), np.uint32)
+    got = api.to_host(out, (4, 1 << lg)).T
+    for r in (0, 1, 1000, (1 << lg) - 1):
+        acc = [0, 0, 0, 0]
+        for g in range(tw):
+            acc = kb_py.ext_add(acc, kb_py.ext_scale(orc.from_monty(coeffs[g]).tolist(), int(orc.from_monty(allcols[r, g:g + 1])[0])))
+        assert orc.from_monty(got[r]).tolist() == acc
+    pt = orc.random_felts((lg, 4), 78)
+    claims = api.BasefoldProver().evaluate_mles(d_ts, pt)
+    assert np.array_equal(claims, np.concatenate([orc.eval_mle(t, pt) for t in ts]))
+    # folds
+    for lg_n in (1, 2, 3, 10, 15):
+        cw = orc.random_felts((1 << lg_n, 4), 80 + lg_n)
+        beta = orc.random_felts((4,), 81)
+        o1 = api.device_words(2 << lg_n)
+        d_cw = api.to_device(_ext_soa(cw))
+        api.check(L.sp1hip_fold_even_odd(api._dptr(d_cw), lg_n, api._ext(beta), api._dptr(o1), s))
+        assert np.array_equal(api.to_host(o1, (4, 1 << (lg_n - 1))).T, orc.fold_even_odd(cw, beta)), lg_n
+        api.check(L.sp1hip_fold_mle(api._dptr(d_cw), lg_n, api._ext(beta), api._dptr(o1), s))
+        assert np.array_equal(api.to_host(o1, (4, 1 << (lg_n - 1))).T, orc.fold_mle(cw, beta)), lg_n
+        # fixed_at_zero = eval of the even entries at a (lg_n - 1)-point
+        pt = orc.random_felts((lg_n - 1, 4), 82)
+        eq = orc.partial_lagrange(pt)
+        o4 = api.device_words(4)
+        api.check(L.sp1hip_ext_fixed_at_zero(api._dptr(d_cw), lg_n, api._dptr(api.to_device(_ext_soa(eq))), api._dptr(o4), s))
+        acc = [0, 0, 0, 0]
+        ce, cq = orc.from_monty(cw), orc.from_monty(eq)
+        for i in range(1 << (lg_n - 1)):
+            acc = kb_py.ext_add(acc, kb_py.ext_mul(cq[i].tolist(), ce[2 * i].tolist()))
+        assert orc.from_monty(api.to_host(o4)).tolist() == acc, lg_n
+
+
+def test_challenger_matches_oracle(api):
+    rng = np.random.default_rng(33)
+    a, b = api.DuplexChallenger(), orc.Challenger()
+    for step in range(200):
+        op = rng.integers(0, 4)
+        if op == 0:
+            xs = orc.random_felts((int(rng.integers(1, 12)),), 1000 + step)
+            a.observe(xs)
+            b.observe(xs)
+        elif op == 1:
+            assert a.sample() == b.sample()
+        elif op == 2:
+            assert np.array_equal(a.sample_ext_element(), b.sample_ext())
+        else:
+            bits = int(rng.integers(1, 24))
+            assert a.sample_bits(bits) == b.sample_bits(bits)
+        assert np.array_equal(a.state(), b.state())
+    # grinding: host path (<= 8 bits) and GPU path, smallest witness, same post-state
+    for bits in (5, 8, 12, 16):
+        a.observe(orc.random_felts((3,), bits))
+        b.observe(orc.random_felts((3,), bits))
+        assert a.grind(bits) == b.grind(bits), bits
+        assert np.array_equal(a.state(), b.state())
+    with pytest.raises(api._lib.Sp1HipError):
+        a.observe(np.array([P], np.uint32))              # non-reduced word
+
+
+def _prove_both(api, lg_n, widths_per_round, lb, nq, pow_bits, seed):
+    mles = [[orc.random_felts((1 << lg_n, w), seed + 10 * r + i) for i, w in enumerate(ws)]
+            for r, ws in enumerate(widths_per_round)]
+    o_rounds = [orc.CommittedRound(ms, lb) for ms in mles]
+    o_ch = orc.Challenger()
+    for r in o_rounds:
+        o_ch.observe(r.commit)
+    o_pt = o_ch.sample_point(lg_n)
+    o_claims = [[orc.eval_mle(m, o_pt) for m in ms] for ms in mles]
+    o_blob = orc.basefold_prove(o_pt, o_rounds, o_claims, o_ch, lb, nq, pow_bits)
+
+    prover = api.BasefoldProver(lb, nq, pow_bits)
+    d_mles = [[api.ColMajor.from_row_major_host(m) for m in ms] for ms in mles]
+    ch = api.DuplexChallenger()
+    pds = []
+    for r, ms in enumerate(d_mles):
+        commit, pd = prover.commit_mles(ms)
+        assert np.array_equal(commit, o_rounds[r].commit)
+        for k in range(len(ms)):
+            assert np.array_equal(pd.codeword(k).to_row_major_host(), o_rounds[r].codeword(k))
+        assert np.array_equal(pd.tree(), o_rounds[r].layers())
+        ch.observe(commit)
+        pds.append(pd)
+    pt = ch.sample_point(lg_n)
+    assert np.array_equal(pt, o_pt)
+    claims = prover.evaluate_mles([m for ms in d_mles for m in ms], pt)
+    assert np.array_equal(claims, np.concatenate([c for rc in o_claims for c in rc]))
+    v_ch = ch.clone()
+    blob = prover.prove_trusted_mle_evaluations(pt, pds, claims, ch)
+    assert blob == o_blob
+    assert np.array_equal(ch.state(), o_ch.state())
+    # and the oracle's verifier accepts the GPU proof
+    ov = orc.Challenger()
+    for r in o_rounds:
+        ov.observe(r.commit)
+    ov.sample_point(lg_n)
+    per_round, k = [], 0
+    for ws in widths_per_round:
+        per_round.append(claims[k:k + sum(ws)])
+        k += sum(ws)
+    assert orc.basefold_verify([r.commit for r in o_rounds], pt, per_round, blob, ov, lb, nq, pow_bits) == 0
+    return blob
+
+
+@pytest.mark.parametrize("lg_n,widths,lb,nq,pw", [
+    (10, [[16, 10, 14], [20, 78, 34], [10, 10]], 1, 94, 16),      # the reference test's widths + default_fri_config
+    (12, [[32, 32], [7]], 2, 124, 16),                              # core parameters
+    (1, [[2, 1]], 2, 8, 4),                                         # smallest instance
+    (16, [[16, 10, 14]], 2, 124, 16),                               # the reference test's 2^16 variables
+])
+def test_basefold_proof_bytes_match_oracle(api, lg_n, widths, lb, nq, pw):
+    _prove_both(api, lg_n, widths, lb, nq, pw, seed=500 + lg_n)
+
+
+def test_basefold_buffer_too_small_leaves_transcript_untouched(api):
+    import ctypes as C
+    m = api.ColMajor.from_row_major_host(orc.random_felts((16, 2), 1))
+    prover = api.BasefoldProver(2, 4, 2)
+    commit, pd = prover.commit_mles([m])
+    ch = api.DuplexChallenger()
+    before = ch.state()
+    n = C.c_size_t(10)
+    buf = (C.c_uint8 * 10)()
+    handles = (C.c_void_p * 1)(pd.h)
+    st = api._L().sp1hip_basefold_prove(api._ext_array(np.zeros((4, 4))), 4, handles, 1, api._ext_array(np.zeros((2, 4))),
+                                        2, prover.config, ch.h, buf, C.byref(n), api._stream_ptr())
+    assert st == -6 and n.value > 10
+    assert np.array_equal(ch.state(), before)
+
+
+def test_full_size_properties(api):
+    """BASELINE config 2 scale (2^20 rows): size-independent properties instead of the (slow) oracle:
+    linearity of the encoder, fold(encode(m)) == encode(fold(m)), and oracle-verified Merkle paths of
+    the full-size tree."""
+    lg_n, lb = 20, 2
+    L, s = api._L(), api._stream_ptr()
+    a = orc.random_felts((4, 1 << lg_n), 1).T.copy()      # an ext mle [n][4]
+    b = orc.random_felts((4, 1 << lg_n), 2).T.copy()
+    ssum = ((orc.from_monty(a).astype(np.uint64) + orc.from_monty(b)) % P).astype(np.uint32)
+    enc = api.DftEncoder(lb)
+    da, db, dsum = (api.ColMajor(api.to_device(_ext_soa(x)), 1 << lg_n, 4) for x in (a, b, orc.to_monty(ssum)))
+    ea, eb, es = enc.encode_batch([da, db, dsum])
+    ha, hb, hs = (api.to_host(x.words) for x in (ea, eb, es))
+    assert np.array_equal(((orc.from_monty(ha).astype(np.uint64) + orc.from_monty(hb)) % P).astype(np.uint32),
+                          orc.from_monty(hs))
+    beta = orc.random_felts((4,), 3)
+    folded_cw = api.device_words(4 << (lg_n + lb - 1))
+    api.check(L.sp1hip_fold_even_odd(api._dptr(ea.words), lg_n + lb, api._ext(beta), api._dptr(folded_cw), s))
+    folded_m = api.device_words(4 << (lg_n - 1))
+    api.check(L.sp1hip_fold_mle(api._dptr(da.words), lg_n, api._ext(beta), api._dptr(folded_m), s))
+    enc2 = enc.encode_batch([api.ColMajor(folded_m, 1 << (lg_n - 1), 4)])[0]
+    assert torch.equal(enc2.words, folded_cw)
+    # full-size Merkle tree over the 4-column codeword: spot-check paths with the oracle's verifier
+    tcs = api.MerkleTcsProver()
+    commit, data = tcs.commit_tensors([ea])
+    idx = [0, 1, (1 << 22) - 1, 123456, 3999999]
+    vals = tcs.compute_openings_at_indices([ea], idx)
+    proof = tcs.prove_openings_at_indices(data, idx)
+    assert orc.merkle_verify(commit, idx, vals, lg_n + lb, proof["merkle_root"], proof["paths"]) == 0
