@@ -83,6 +83,16 @@ int sp1hip_event_synchronize(sp1hip_event_t event);
 int sp1hip_event_elapsed_ms(float* ms, sp1hip_event_t start, sp1hip_event_t stop);
 int sp1hip_stream_wait_event(sp1hip_stream_t stream, sp1hip_event_t event);
 
+/* ---------------------------------------------------------------- kernel timers (measurement aid)
+ * When enabled, the library brackets its hot kernels with HIP events on the caller's stream
+ * (the equivalent of the reference's NVTX ranges + `SP1_GPU_*_TIMING` switches,
+ * /root/reference/sp1-gpu/crates/tracing/src/tracer.rs). `sp1hip_timers_read` synchronises the recorded
+ * events and returns, for `name` ("leaf_hash", "compress", "ntt_pass", ...), the number of launches and
+ * their summed duration since the last `sp1hip_timers_reset`. */
+int sp1hip_timers_enable(int on);
+int sp1hip_timers_reset(void);
+int sp1hip_timers_read(const char* name, uint64_t* launches, double* total_ms);
+
 /* ---------------------------------------------------------------- layout
  * Host traces are row-major `[rows][cols]` (`RowMajorMatrix`, slop Tensor); the device wants
  * column-major. Replaces sp1-gpu's transpose kernels (/root/reference/sp1-gpu/crates/sys/lib/transpose). */

@@ -63,6 +63,9 @@ PROTOTYPES = [
     ("sp1hip_event_synchronize", None, [_vp]),
     ("sp1hip_event_elapsed_ms", None, [C.POINTER(C.c_float), _vp, _vp]),
     ("sp1hip_stream_wait_event", None, [_vp, _vp]),
+    ("sp1hip_timers_enable", None, [_int]),
+    ("sp1hip_timers_reset", None, []),
+    ("sp1hip_timers_read", None, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     ("sp1hip_transpose_to_col_major", None, [_vp, _vp, _sz, _sz, _vp]),
     ("sp1hip_transpose_to_row_major", None, [_vp, _vp, _sz, _sz, _vp]),
     ("sp1hip_to_monty", None, [_vp, _sz, _vp]),
@@ -104,6 +107,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # If torch is going to be used in this process it must be imported BEFORE libsp1hip.so: torch ships
+    # its own libamdhip64.so and two HIP runtimes in one process do not share devices or streams.
+    # Importing torch first makes the dynamic linker bind this library to the runtime torch loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)

@@ -19,6 +19,17 @@ int ensure_device_ready();
 
 inline hipStream_t S(sp1hip_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// Optional event bracketing of a kernel launch (see sp1hip_timers_* in include/sp1hip.h).
+bool timers_on();
+void timer_begin(const char* name, hipStream_t s);
+void timer_end(hipStream_t s);
+struct ScopedTimer {
+    hipStream_t s;
+    bool on;
+    ScopedTimer(const char* name, hipStream_t stream) : s(stream), on(timers_on()) { if (on) timer_begin(name, s); }
+    ~ScopedTimer() { if (on) timer_end(s); }
+};
+
 }  // namespace sp1hip
 
 #define SP1HIP_TRY(expr)                                                   \

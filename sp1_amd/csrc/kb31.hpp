@@ -3,10 +3,13 @@
 // the reference's `SP1Field` (/root/reference/crates/primitives/src/lib.rs:L28-L31; Montgomery
 // conventions as restated in /root/reference/sp1-gpu/crates/sys/include/fields/kb31_t.cuh:L70-L135).
 //
-// gfx950 notes: 32x32 integer multiplies are the scarce resource, so
-//  * the Montgomery quotient digit uses p^-1 = 2^31 + 2^24 + 1 (two shift-adds, no multiply),
+// gfx950 notes (measured in profiles/r01_ubench.txt): v_mul_lo/hi_u32 issue
+// at about the same rate as other VOP3 integer ops and v_mad_u64_u32 at ~1.3x that, so the kernels are
+// bound by VALU *instruction count*, not by a slow multiplier:
+//  * Montgomery reduction uses the additive form (one v_mul_lo_u32 + one v_mad_u64_u32),
 //  * conditional corrections use the unsigned-min idiom (v_min_u32) instead of compare/select,
-//  * extension-field products accumulate in 64 bits and reduce once per output coefficient.
+//  * corrections are skipped wherever the next consumer tolerates a value in [0, 2p),
+//  * extension-field products accumulate pairs of 64-bit products before reducing.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,6 +20,7 @@ namespace kb {
 
 constexpr uint32_t P = 0x7f000001u;
 constexpr uint32_t MU = 0x81000001u;       // p^-1 mod 2^32 = 2^31 + 2^24 + 1
+constexpr uint32_t NMU = 0x7effffffu;      // -p^-1 mod 2^32
 constexpr uint32_t R1 = 0x01fffffeu;       // 2^32 mod p   (Montgomery one)
 constexpr uint32_t R2 = 0x17f7efe4u;       // 2^64 mod p
 constexpr uint32_t GEN24 = 0x6ac49f88u;    // canonical two_adic_generator(24)
@@ -32,13 +36,19 @@ KB_HD uint32_t mulhi(uint32_t a, uint32_t b) {
 #endif
 }
 
+// Montgomery reduction, "plus" form: with t = x_lo * (-p^-1) mod 2^32 the sum x + t p is a multiple of
+// 2^32, so (x + t p) >> 32 is x * 2^-32 (mod p) and lies in [x / 2^32, x / 2^32 + p). Needs x < 2^63.
+// On gfx950 this is v_mul_lo_u32 + one v_mad_u64_u32 (the multiply-add swallows the accumulation);
+// measured 12-17 % faster than the subtractive form (bench/ubench_*.hip, profiles/r01_ubench.txt).
+KB_HD uint32_t monty_reduce_lazy(uint64_t x) {
+    uint32_t t = (uint32_t)x * NMU;
+    return (uint32_t)(((uint64_t)t * P + x) >> 32);
+}
+
 // x < 2^32 * p  ->  x * 2^-32 mod p, fully reduced
 KB_HD uint32_t monty_reduce(uint64_t x) {
-    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    uint32_t t = lo + (lo << 24) + (lo << 31);   // lo * MU mod 2^32
-    uint32_t u = mulhi(t, P);
-    uint32_t r = hi - u;                         // == hi - u (mod 2^32); true value in (-p, p)
-    return umin(r, r + P);
+    uint32_t r = monty_reduce_lazy(x);   // in [0, 2p)
+    return umin(r, r - P);
 }
 
 KB_HD uint32_t add(uint32_t a, uint32_t b) { uint32_t s = a + b; return umin(s, s - P); }

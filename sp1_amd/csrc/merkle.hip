@@ -178,6 +178,7 @@ __global__ void open_paths_kernel(const uint32_t* __restrict__ tree, uint32_t lg
 // Compresses the leaf layer at d_tree up to the root and finalises the commitment.
 int merkle_finish_tree(uint32_t* d_tree, int lg_height, uint32_t total_width, uint32_t* d_root_and_commit,
                        const DeviceCtx* ctx, hipStream_t s) {
+    ScopedTimer t("compress", s);
     uint32_t* cur = d_tree;
     uint32_t n = 1u << lg_height;
     while (n > 2048) {
@@ -214,8 +215,11 @@ int sp1hip_merkle_commit(const sp1hip_tensor_t* tensors, int n_tensors, int lg_h
     AsyncScratch cols;
     SP1HIP_TRY(cols.alloc((size_t)tw * sizeof(uint32_t*), s));
     SP1HIP_TRY(expand_columns_async(tab, tw, height, (const uint32_t**)cols.p, s));
-    hipLaunchKernelGGL(leaf_hash_kernel, dim3((height + 255) / 256), dim3(256), 0, s, (const uint32_t* const*)cols.p,
-                       tw, height, ctx->d_rc, d_tree);
+    {
+        ScopedTimer t("leaf_hash", s);
+        hipLaunchKernelGGL(leaf_hash_kernel, dim3((height + 255) / 256), dim3(256), 0, s,
+                           (const uint32_t* const*)cols.p, tw, height, ctx->d_rc, d_tree);
+    }
     SP1HIP_LAUNCH_CHECK();
     return merkle_finish_tree(d_tree, lg_height, tw, d_root_and_commit, ctx, s);
 }

@@ -178,6 +178,7 @@ extern "C" int sp1hip_rs_encode_batch(uint32_t* d_out, const uint32_t* d_in, int
     const PassPlan plan = plan_passes(lg_total);
     int lg_seg = lg_total;
     for (int p = 0; p < plan.n_passes; p++) {
+        ScopedTimer t(p == 0 ? "ntt_pass0" : (p == 1 ? "ntt_pass1" : "ntt_pass2"), s);
         const int lg_r = plan.bits[p];
         const bool first = p == 0, last = p == plan.n_passes - 1;
         if (!last) {

@@ -60,23 +60,40 @@ KB_HD void external_linear(uint32_t (&s)[16]) {
     for (int j = 0; j < 16; j++) s[j] = kb::add(s[j], sums[j & 3]);
 }
 
-// new_i = (sum + d_i s_i) * 2^-32 with d = [-2, 1, 2, 4, .., 2^13, 2^15] on Montgomery words: one
-// 64-bit multiply-add builds sum + (s_i << k), one Montgomery reduction divides by 2^32.
-KB_HD void internal_linear(uint32_t (&s)[16]) {
-    uint64_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) sum += s[i];
-    // lane 0: sum - s0 + (p - s0) ... with s0 == 0 the reference adds 0, and (sum - 0 + p) reduces to
-    // the same residue, so no special case is needed: both are == sum - 2 s0 (mod p) and < 2^32 p.
-    uint64_t v0 = sum + kb::P - 2 * (uint64_t)s[0] + kb::P;
-    uint32_t n0 = kb::monty_reduce(v0);
-    constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};
-#pragma unroll
-    for (int i = 1; i < 16; i++) s[i] = kb::monty_reduce(sum + ((uint64_t)s[i] << SH[i - 1]));
-    s[0] = n0;
+// Wave-uniform multiplier 2^k that the optimiser cannot see through (so `s * m + sum` stays one
+// v_mad_u64_u32 instead of a 64-bit shift plus a 64-bit add). Host: plain value.
+KB_HD uint32_t opaque_pow2(int k) {
+    uint32_t m = 1u << k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(m));
+#endif
+    return m;
 }
 
-KB_HD uint32_t cube(uint32_t x) { return kb::mul(kb::sqr(x), x); }
+// Internal rounds keep lanes 1..15 LAZY: unsigned words in [0, p + 2^15) congruent to the true
+// value. new_i = (sum + 2^k s_i) * 2^-32 is one multiply-add (V = s_i * 2^k + sum < 2^48), one
+// v_mul_lo_u32 and one v_mad_u64_u32 (additive Montgomery form, result in [V/2^32, V/2^32 + p), i.e.
+// again < p + 2^15): 3 VALU instructions per lane per round, no correction. Lane 0 (the only lane
+// that feeds an S-box) is kept canonical: V_0 = sum + 2 (p - s_0) >= 0 is == sum - 2 s_0 (mod p).
+// The diagonal is [-2, 1, 2, 4, .., 2^13, 2^15] on Montgomery words and the division by 2^32 is the
+// reference's MONTY_INVERSE factor (/root/reference/sp1-gpu/crates/sys/include/poseidon2/poseidon2_kb31_16.cuh:L118-L140).
+KB_HD void internal_linear_lazy(uint32_t (&s)[16]) {
+    // pair sums fit 32 bits: 2 (p + 2^15) < 2^32
+    uint64_t sum = (uint64_t)(s[0] + s[1]) + (s[2] + s[3]) + (s[4] + s[5]) + (s[6] + s[7]) + (s[8] + s[9]) +
+                   (s[10] + s[11]) + (s[12] + s[13]) + (s[14] + s[15]);
+    const uint64_t v0 = (uint64_t)(kb::P - s[0]) * opaque_pow2(1) + sum;
+    constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};
+#pragma unroll
+    for (int i = 1; i < 16; i++) s[i] = kb::monty_reduce_lazy((uint64_t)s[i] * opaque_pow2(SH[i - 1]) + sum);
+    s[0] = kb::monty_reduce(v0);
+}
+
+// (s + rc)^3: the square is left in [0, 2p) (2p * p < 2^32 p keeps the next reduction valid).
+KB_HD uint32_t sbox(uint32_t s, uint32_t rc) {
+    const uint32_t x = kb::add(s, rc);
+    const uint32_t x2 = kb::monty_reduce_lazy((uint64_t)x * x);
+    return kb::monty_reduce((uint64_t)x2 * x);
+}
 
 template <class RC>
 KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
@@ -84,18 +101,20 @@ KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = cube(kb::add(s[i], rc.ext[r][i]));
+        for (int i = 0; i < 16; i++) s[i] = sbox(s[i], rc.ext[r][i]);
         external_linear(s);
     }
 #pragma unroll 1
     for (int r = 0; r < 20; r++) {
-        s[0] = cube(kb::add(s[0], rc.internal[r]));
-        internal_linear(s);
+        s[0] = sbox(s[0], rc.internal[r]);
+        internal_linear_lazy(s);
     }
+#pragma unroll
+    for (int i = 1; i < 16; i++) s[i] = kb::umin(s[i], s[i] - kb::P);   // lazy -> canonical
 #pragma unroll 1
     for (int r = 4; r < 8; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = cube(kb::add(s[i], rc.ext[r][i]));
+        for (int i = 0; i < 16; i++) s[i] = sbox(s[i], rc.ext[r][i]);
         external_linear(s);
     }
 }

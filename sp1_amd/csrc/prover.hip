@@ -135,10 +135,17 @@ static int grind(DuplexChallenger& ch, int bits, uint32_t* witness_monty, hipStr
 }
 
 // ---------------------------------------------------------------- prover data
+// Stream-ordered allocation from the device's default memory pool (release threshold raised in
+// get_device_ctx, so steady-state proving re-uses the same HBM without touching the driver).
 struct DeviceBuf {
     void* p = nullptr;
-    int alloc(size_t bytes) { SP1HIP_HIP(hipMalloc(&p, bytes ? bytes : 1)); return SP1HIP_SUCCESS; }
-    ~DeviceBuf() { if (p) (void)hipFree(p); }
+    hipStream_t s = nullptr;
+    int alloc(size_t bytes, hipStream_t stream) {
+        s = stream;
+        SP1HIP_HIP(hipMallocAsync(&p, bytes ? bytes : 1, stream));
+        return SP1HIP_SUCCESS;
+    }
+    ~DeviceBuf() { if (p) (void)hipFreeAsync(p, s); }
     DeviceBuf() = default;
     DeviceBuf(const DeviceBuf&) = delete;
     DeviceBuf& operator=(const DeviceBuf&) = delete;
@@ -241,10 +248,10 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
 
     const size_t n = (size_t)1 << dim, N0 = n << lb;
     DeviceBuf d_coeffs, d_mle[2], d_eq;
-    SP1HIP_TRY(d_coeffs.alloc(total_len * 16));
-    SP1HIP_TRY(d_mle[0].alloc(n * 16));
-    SP1HIP_TRY(d_mle[1].alloc(n * 8 + 16));
-    SP1HIP_TRY(d_eq.alloc(n * 8 + 16));
+    SP1HIP_TRY(d_coeffs.alloc(total_len * 16, s));
+    SP1HIP_TRY(d_mle[0].alloc(n * 16, s));
+    SP1HIP_TRY(d_mle[1].alloc(n * 8 + 16, s));
+    SP1HIP_TRY(d_eq.alloc(n * 8 + 16, s));
     SP1HIP_HIP(hipMemcpyAsync(d_coeffs.p, coeffs.data(), total_len * 16, hipMemcpyHostToDevice, s));
     SP1HIP_HIP(hipStreamSynchronize(s));
     SP1HIP_TRY(sp1hip_basefold_batch(mles.data(), (int)mles.size(), dim, d_coeffs.u32(), d_mle[0].u32(), s));
@@ -254,12 +261,12 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     // codewords of every round are kept for the query phase: sizes N0, N0/2, ..., 2 (ext SoA)
     std::vector<std::unique_ptr<DeviceBuf>> cws, trees;
     cws.emplace_back(new DeviceBuf());
-    SP1HIP_TRY(cws.back()->alloc(N0 * 16));
+    SP1HIP_TRY(cws.back()->alloc(N0 * 16, s));
     SP1HIP_TRY(sp1hip_rs_encode_batch(cws.back()->u32(), d_mle[0].u32(), dim, lb, 4, s));
 
     ch.observe(kb::to_monty((uint32_t)dim));
     DeviceBuf d_rb;  // [0..4) zero_val, [4..20) root+commit, [20..24) final poly
-    SP1HIP_TRY(d_rb.alloc(24 * 4));
+    SP1HIP_TRY(d_rb.alloc(24 * 4, s));
     std::vector<std::array<uint32_t, 8>> round_roots;
     std::vector<kb::Ext> uni;
     std::vector<std::array<uint32_t, 8>> fri_commitments;
@@ -274,7 +281,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
         SP1HIP_TRY(ext_fixed_at_zero_async(d_mle[cur].u32(), lg_m, d_eq.u32(), d_rb.u32(), s));
         // commit to the paired leaves of the current codeword
         trees.emplace_back(new DeviceBuf());
-        SP1HIP_TRY(trees.back()->alloc((((size_t)2 << (lg_c - 1)) - 1) * 32));
+        SP1HIP_TRY(trees.back()->alloc((((size_t)2 << (lg_c - 1)) - 1) * 32, s));
         SP1HIP_TRY(commit_ext_pairs(cws.back()->u32(), lg_c, trees.back()->u32(), d_rb.u32() + 4, s));
         uint32_t rb[20];
         SP1HIP_HIP(hipMemcpyAsync(rb, d_rb.p, sizeof rb, hipMemcpyDeviceToHost, s));
@@ -295,7 +302,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
         sp1hip_ext_t b;
         memcpy(b.c, beta.c, 16);
         cws.emplace_back(new DeviceBuf());
-        SP1HIP_TRY(cws.back()->alloc(((size_t)1 << (lg_c - 1)) * 16));
+        SP1HIP_TRY(cws.back()->alloc(((size_t)1 << (lg_c - 1)) * 16, s));
         SP1HIP_TRY(sp1hip_fold_even_odd(cws[cws.size() - 2]->u32(), lg_c, b, cws.back()->u32(), s));
         SP1HIP_TRY(sp1hip_fold_mle(d_mle[cur].u32(), lg_m, b, d_mle[cur ^ 1].u32(), s));
         cur ^= 1;
@@ -326,9 +333,9 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     DeviceBuf d_idx, d_vals, d_paths;
     size_t max_w = 8;
     for (int r = 0; r < n_rounds; r++) max_w = std::max<size_t>(max_w, rounds[r]->total_width);
-    SP1HIP_TRY(d_idx.alloc(nq * 4));
-    SP1HIP_TRY(d_vals.alloc(nq * max_w * 4));
-    SP1HIP_TRY(d_paths.alloc(nq * (size_t)(dim + lb) * 32));
+    SP1HIP_TRY(d_idx.alloc(nq * 4, s));
+    SP1HIP_TRY(d_vals.alloc(nq * max_w * 4, s));
+    SP1HIP_TRY(d_paths.alloc(nq * (size_t)(dim + lb) * 32, s));
     SP1HIP_HIP(hipMemcpyAsync(d_idx.p, q.data(), nq * 4, hipMemcpyHostToDevice, s));
     SP1HIP_HIP(hipStreamSynchronize(s));
     std::vector<uint32_t> vals, paths;
@@ -431,6 +438,8 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
     SP1HIP_REQUIRE(mles && n_mles > 0 && out && h_commit, "bad argument");
     SP1HIP_REQUIRE(lg_n >= 0 && lg_blowup >= 0 && lg_n + lg_blowup <= kb::TWO_ADICITY, "size out of range");
     hipStream_t s = S(stream);
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));   // also configures the memory pool before the first allocation
     std::unique_ptr<sp1hip_basefold_data_s> pd(new sp1hip_basefold_data_s());
     pd->lg_n = lg_n;
     pd->lg_blowup = lg_blowup;
@@ -440,14 +449,14 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
         SP1HIP_REQUIRE(mles[i].d_data || mles[i].width == 0, "null mle");
         pd->mles.push_back(mles[i]);
         pd->cws.emplace_back(new DeviceBuf());
-        SP1HIP_TRY(pd->cws.back()->alloc(N * mles[i].width * 4));
+        SP1HIP_TRY(pd->cws.back()->alloc(N * mles[i].width * 4, s));
         SP1HIP_TRY(sp1hip_rs_encode_batch(pd->cws.back()->u32(), mles[i].d_data, lg_n, lg_blowup, mles[i].width, s));
         pd->cw_tensors.push_back({pd->cws.back()->u32(), mles[i].width});
         pd->total_width += mles[i].width;
     }
-    SP1HIP_TRY(pd->tree.alloc((2 * N - 1) * 32));
+    SP1HIP_TRY(pd->tree.alloc((2 * N - 1) * 32, s));
     DeviceBuf rc;
-    SP1HIP_TRY(rc.alloc(64));
+    SP1HIP_TRY(rc.alloc(64, s));
     SP1HIP_TRY(sp1hip_merkle_commit(pd->cw_tensors.data(), n_mles, lg_h, pd->tree.u32(), rc.u32(), s));
     uint32_t h[16];
     SP1HIP_HIP(hipMemcpyAsync(h, rc.p, 64, hipMemcpyDeviceToHost, s));

@@ -33,6 +33,28 @@ int map_hip_error(hipError_t e, const char* what) {
     }
 }
 
+struct TimerRec { std::string name; hipEvent_t a, b; };
+static std::mutex g_timer_mutex;
+static bool g_timers_on = false;
+static std::vector<TimerRec> g_timer_recs;
+static thread_local TimerRec* g_open_timer = nullptr;
+
+bool timers_on() { return g_timers_on; }
+void timer_begin(const char* name, hipStream_t s) {
+    TimerRec r;
+    r.name = name;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    std::lock_guard<std::mutex> lock(g_timer_mutex);
+    g_timer_recs.push_back(r);
+    g_open_timer = &g_timer_recs.back();
+}
+void timer_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_timer_mutex);
+    if (g_timer_recs.empty()) return;
+    (void)hipEventRecord(g_timer_recs.back().b, s);
+}
+
 static std::mutex g_ctx_mutex;
 static std::vector<DeviceCtx*> g_ctx;
 
@@ -47,6 +69,12 @@ int get_device_ctx(const DeviceCtx** out) {
         hipDeviceProp_t prop;
         SP1HIP_HIP(hipGetDeviceProperties(&prop, dev));
         c->num_cus = prop.multiProcessorCount;
+        // keep freed stream-ordered allocations cached in the pool (hipMallocAsync/hipFreeAsync reuse)
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
         p2::RoundConstants rc = p2::make_round_constants();
         SP1HIP_HIP(hipMalloc((void**)&c->d_rc, sizeof rc));
         SP1HIP_HIP(hipMemcpy(c->d_rc, &rc, sizeof rc, hipMemcpyHostToDevice));
@@ -74,6 +102,29 @@ extern "C" {
 
 const char* sp1hip_last_error(void) { return g_last_error.c_str(); }
 const char* sp1hip_version(void) { return "sp1hip 0.1.0 (gfx950; KoalaBear; Poseidon2-16)"; }
+
+int sp1hip_timers_enable(int on) { g_timers_on = on != 0; return SP1HIP_SUCCESS; }
+int sp1hip_timers_reset(void) {
+    std::lock_guard<std::mutex> lock(g_timer_mutex);
+    for (auto& r : g_timer_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_timer_recs.clear();
+    return SP1HIP_SUCCESS;
+}
+int sp1hip_timers_read(const char* name, uint64_t* launches, double* total_ms) {
+    SP1HIP_REQUIRE(name && launches && total_ms, "null argument");
+    std::lock_guard<std::mutex> lock(g_timer_mutex);
+    *launches = 0;
+    *total_ms = 0;
+    for (auto& r : g_timer_recs) {
+        if (r.name != name) continue;
+        SP1HIP_HIP(hipEventSynchronize(r.b));
+        float ms = 0;
+        SP1HIP_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        *launches += 1;
+        *total_ms += ms;
+    }
+    return SP1HIP_SUCCESS;
+}
 
 int sp1hip_device_count(int* count) {
     SP1HIP_REQUIRE(count, "null count");
