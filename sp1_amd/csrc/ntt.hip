@@ -20,6 +20,8 @@
 // array; all later passes are in place. All columns of the batch go in one launch (grid.y).
 // Algorithmic HBM traffic: 4 n (1 + 2^b) bytes per column; this design moves
 // 4 n (1 + 2^b (2 passes - 1)) bytes (see DESIGN.md §Kernels for the roofline).
+#include <cstdlib>
+
 #include "device_ctx.hpp"
 
 namespace sp1hip {
@@ -159,6 +161,11 @@ static PassPlan plan_passes(int lg_total) {
 
 static inline int ilog2_floor(uint32_t x) { int l = 0; while ((2u << l) <= x) l++; return l; }
 
+// ntt_fast.hip
+bool ntt_fast_plan(int lg_total, int bits[3], int* n_passes);
+int ntt_fast_encode(uint32_t* d_out, const uint32_t* d_in, int lg_n, int lg_blowup, size_t n_cols, const DeviceCtx* ctx,
+                    hipStream_t s);
+
 }  // namespace sp1hip
 
 using namespace sp1hip;
@@ -175,6 +182,14 @@ extern "C" int sp1hip_rs_encode_batch(uint32_t* d_out, const uint32_t* d_in, int
     SP1HIP_TRY(get_device_ctx(&ctx));
     hipStream_t s = S(stream);
     const int lg_total = lg_n + lg_blowup;
+    {
+        // large transforms: register-radix passes (ntt_fast.hip); SP1HIP_NTT_GENERIC=1 forces the
+        // generic LDS kernels below (kept for small sizes and as an A/B reference)
+        static const bool force_generic = getenv("SP1HIP_NTT_GENERIC") != nullptr;
+        int bits[3], np;
+        if (!force_generic && ntt_fast_plan(lg_total, bits, &np))
+            return ntt_fast_encode(d_out, d_in, lg_n, lg_blowup, n_cols, ctx, s);
+    }
     const PassPlan plan = plan_passes(lg_total);
     int lg_seg = lg_total;
     for (int p = 0; p < plan.n_passes; p++) {

@@ -1,0 +1,287 @@
+// sp1_amd/csrc/ntt_fast.hip — register-radix passes of the batched RS-encode NTT for large
+// transforms (2^14 <= N <= 2^24 per column). Same mathematics and output order as ntt.hip (one
+// decimation-in-frequency transform of the zero-padded column, bit-reversed output, split into
+// passes with an inter-pass twiddle); what changes is how a pass is executed on a CU:
+//
+//  * a workgroup (4 waves) owns a tile of 64 independent r-point transforms, r = 2^(A+B) in
+//    {64, 128, 256}; LANE = transform, so every butterfly partner of an element lives in the same
+//    lane and every stage twiddle is WAVE-UNIFORM: twiddles are scalar loads (s_load) into SGPRs,
+//    they cost no VALU issue slots, no LDS traffic and no per-lane address arithmetic;
+//  * the A+B stages run in two register steps (radix 2^A over the 2^B-strided elements, then radix
+//    2^B over consecutive elements) with ONE in-place exchange through LDS between them instead of
+//    one LDS round trip + barrier per stage;
+//  * strided passes read/write 256 B runs (64 adjacent sub-transforms x 4 B); the last pass works
+//    on contiguous runs and is transposed through a padded LDS tile so the lanes still index
+//    independent transforms;
+//  * the inter-pass twiddle w_seg^(i2 k1) is split into a per-workgroup factor (wave-uniform, built
+//    once per workgroup in LDS) and a per-lane factor read from a small cached table with a
+//    coalesced load.
+// VALU work per butterfly is then just the field arithmetic: add (3), sub (2-3), Montgomery
+// multiply (5).
+#include <mutex>
+
+#include "device_ctx.hpp"
+
+namespace sp1hip {
+
+constexpr int FT = 64;  // transforms per tile = lanes per wave
+
+struct FastPassArgs {
+    const uint32_t* in;      // FIRST: [cols][2^lg_n_in]; otherwise unused
+    uint32_t* out;           // [cols][2^lg_total]
+    const uint32_t* tw_r;    // w_r^j, j < r/2 (Montgomery), r = 2^(A+B)
+    const uint32_t* tw_lane; // strided: [r][64] = w_seg^(k1 * c); contiguous: unused
+    const uint32_t* tw_lo;
+    const uint32_t* tw_hi;
+    int lg_total, lg_seg, lg_n_in;
+};
+
+template <int K>
+struct Radix {
+    // In-register DIF over x[0 .. 2^K): element q sits at transform index i = i0 + q * 2^LG_STEP; the
+    // stages handled are s = LG_STEP + K .. LG_STEP + 1 of an r = 2^LG_R point transform. Twiddle for
+    // the butterfly (q, q + hq) at stage s: w_r^(((i0 + (q mod hq) 2^LG_STEP)) << (LG_R - s)).
+    template <int LG_R, int LG_STEP>
+    static __device__ __forceinline__ void run(uint32_t (&x)[1 << K], uint32_t i0, const uint32_t* __restrict__ tw_r) {
+#pragma unroll
+        for (int t = K; t >= 1; t--) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int hq = 1 << (t - 1);
+            const int s = LG_STEP + t;
+#pragma unroll
+            for (int q = 0; q < (1 << K); q++) {
+                if (q & hq) continue;
+                const uint32_t e = (i0 + (uint32_t)((q & (hq - 1)) << LG_STEP)) << (LG_R - s);
+                const uint32_t w = tw_r[e];   // wave-uniform -> scalar load
+                const uint32_t a = x[q], b = x[q + hq];
+                x[q] = kb::add(a, b);
+                x[q + hq] = kb::monty_reduce((uint64_t)(a - b + kb::P) * w);   // a - b + p in (0, 2p)
+            }
+        }
+    }
+};
+
+// Pointers are separate __restrict__ kernel arguments (not a struct) so the compiler knows the
+// twiddle tables cannot alias the output and keeps their wave-uniform loads on the scalar unit.
+template <int A, int B, bool STRIDED, bool FIRST>
+__global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict__ a_in, uint32_t* __restrict__ a_out,
+                                                     const uint32_t* __restrict__ a_tw_r,
+                                                     const uint32_t* __restrict__ a_tw_lane,
+                                                     const uint32_t* __restrict__ a_tw_lo,
+                                                     const uint32_t* __restrict__ a_tw_hi, int a_lg_total, int a_lg_seg,
+                                                     int a_lg_n_in) {
+    struct {
+        const uint32_t* __restrict__ in;
+        uint32_t* __restrict__ out;
+        const uint32_t* __restrict__ tw_r;
+        const uint32_t* __restrict__ tw_lane;
+        const uint32_t* __restrict__ tw_lo;
+        const uint32_t* __restrict__ tw_hi;
+        int lg_total, lg_seg, lg_n_in;
+    } p{a_in, a_out, a_tw_r, a_tw_lane, a_tw_lo, a_tw_hi, a_lg_total, a_lg_seg, a_lg_n_in};
+    constexpr int LG_R = A + B, R = 1 << LG_R;
+    constexpr int PITCH = STRIDED ? FT : R + 1;   // contiguous tiles are [lane][i] with an odd pitch
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* tile = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index is wave-uniform; tell the compiler so (keeps twiddle/table addresses in SGPRs)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t col = blockIdx.y;
+    const uint64_t col_off = (uint64_t)col << p.lg_total;
+    auto addr = [&](uint32_t i, uint32_t l) -> uint32_t { return STRIDED ? i * FT + l : l * PITCH + i; };
+
+    uint32_t i2_0 = 0;
+    uint64_t base = 0;
+    const int lg_st = p.lg_seg - LG_R;
+    if (STRIDED) {
+        const uint32_t tiles_per_seg = 1u << (lg_st - 6);
+        const uint32_t seg = blockIdx.x / tiles_per_seg;
+        i2_0 = (blockIdx.x % tiles_per_seg) << 6;
+        base = col_off + ((uint64_t)seg << p.lg_seg) + i2_0;
+        // global -> LDS: row i is a 256 B run
+        if (FIRST) {
+            const uint32_t n_in = 1u << p.lg_n_in;
+            const uint32_t* src = p.in + ((uint64_t)col << p.lg_n_in);
+#pragma unroll 4
+            for (uint32_t i = wave; i < R; i += 4) {
+                const uint32_t idx = (i << lg_st) + i2_0 + lane;
+                tile[i * FT + lane] = idx < n_in ? src[idx] : 0u;
+            }
+        } else {
+#pragma unroll 4
+            for (uint32_t i = wave; i < R; i += 4) tile[i * FT + lane] = p.out[base + ((uint64_t)i << lg_st) + lane];
+        }
+    } else {
+        // 64 consecutive runs of R words; run `l` goes to LDS row l (pitch R + 1)
+        base = col_off + ((uint64_t)blockIdx.x << (LG_R + 6));
+        if (FIRST) {
+            const uint32_t n_in = 1u << p.lg_n_in;
+            const uint32_t* src = p.in + ((uint64_t)col << p.lg_n_in);
+            const uint64_t off = (uint64_t)blockIdx.x << (LG_R + 6);
+            for (uint32_t e = tid; e < (uint32_t)R * FT; e += 256)
+                tile[(e >> LG_R) * PITCH + (e & (R - 1))] = (off + e) < n_in ? src[off + e] : 0u;
+        } else {
+            for (uint32_t e = tid; e < (uint32_t)R * FT; e += 256)
+                tile[(e >> LG_R) * PITCH + (e & (R - 1))] = p.out[base + e];
+        }
+    }
+    // per-workgroup inter-pass factor U[k1] = w_seg^(i2_0 * k1), kept behind the tile
+    uint32_t* U = lds + (STRIDED ? R * FT : FT * PITCH);
+    if (STRIDED) {
+        const int sh = kb::TWO_ADICITY - p.lg_seg;
+        for (uint32_t k1 = tid; k1 < (uint32_t)R; k1 += 256) {
+            const uint32_t ex = (i2_0 * k1) << sh;
+            U[k1] = kb::mul(p.tw_hi[ex >> TW_LO_BITS], p.tw_lo[ex & (TW_LO - 1)]);
+        }
+    }
+    __syncthreads();
+
+    // ---- step 1: radix 2^A over elements i = i_lo + q 2^B (stages LG_R .. B+1), in place in LDS
+    for (uint32_t i_lo = wave; i_lo < (1u << B); i_lo += 4) {
+        uint32_t x[1 << A];
+#pragma unroll
+        for (int q = 0; q < (1 << A); q++) x[q] = tile[addr(i_lo + ((uint32_t)q << B), lane)];
+        Radix<A>::template run<LG_R, B>(x, i_lo, p.tw_r);
+#pragma unroll
+        for (int q = 0; q < (1 << A); q++) tile[addr(i_lo + ((uint32_t)q << B), lane)] = x[q];
+    }
+    __syncthreads();
+
+    // ---- step 2: radix 2^B over consecutive elements i = i_hi 2^B + q (stages B .. 1)
+    for (uint32_t i_hi = wave; i_hi < (1u << A); i_hi += 4) {
+        uint32_t x[1 << B];
+#pragma unroll
+        for (int q = 0; q < (1 << B); q++) x[q] = tile[addr((i_hi << B) + q, lane)];
+        Radix<B>::template run<LG_R, 0>(x, 0u, p.tw_r);
+        if (STRIDED) {
+#pragma unroll
+            for (int q = 0; q < (1 << B); q++) {
+                const uint32_t i = (i_hi << B) + q;
+                const uint32_t k1 = kb::reverse_bits_len(i, LG_R);      // wave-uniform
+                const uint32_t wl = p.tw_lane[k1 * FT + lane];            // coalesced, L2-resident table
+                const uint32_t w = kb::mul(U[k1], wl);
+                p.out[base + ((uint64_t)i << lg_st) + lane] = kb::mul(x[q], w);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < (1 << B); q++) tile[addr((i_hi << B) + q, lane)] = x[q];
+        }
+    }
+    if (!STRIDED) {
+        __syncthreads();
+        for (uint32_t e = tid; e < (uint32_t)R * FT; e += 256) p.out[base + e] = tile[(e >> LG_R) * PITCH + (e & (R - 1))];
+    }
+}
+
+// tw_r tables (w_r^j, j < r/2) for r = 64, 128, 256 and lane tables per lg_seg, built on first use.
+__global__ void fill_tw_r_kernel(uint32_t* out, int lg_r, const uint32_t* __restrict__ tw_lo,
+                                 const uint32_t* __restrict__ tw_hi) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (1u << lg_r) / 2) return;
+    const uint32_t e = j << (kb::TWO_ADICITY - lg_r);
+    out[j] = kb::mul(tw_hi[e >> TW_LO_BITS], tw_lo[e & (TW_LO - 1)]);
+}
+__global__ void fill_tw_lane_kernel(uint32_t* out, int lg_seg, const uint32_t* __restrict__ tw_lo,
+                                    const uint32_t* __restrict__ tw_hi) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // [256][64]
+    if (t >= 256u * FT) return;
+    const uint32_t k1 = t >> 6, c = t & 63;
+    const uint32_t e = ((k1 * c) & ((1u << lg_seg) - 1)) << (kb::TWO_ADICITY - lg_seg);
+    out[t] = kb::mul(tw_hi[e >> TW_LO_BITS], tw_lo[e & (TW_LO - 1)]);
+}
+
+struct FastTables {
+    uint32_t* tw_r[9] = {nullptr};      // index lg_r (6..8)
+    uint32_t* tw_lane[25] = {nullptr};  // index lg_seg
+};
+static std::mutex g_fast_mutex;
+static FastTables* g_fast_tables[64] = {nullptr};
+
+static int get_fast_tables(const DeviceCtx* ctx, hipStream_t s, int lg_r, int lg_seg, const uint32_t** tw_r,
+                           const uint32_t** tw_lane) {
+    std::lock_guard<std::mutex> lock(g_fast_mutex);
+    SP1HIP_REQUIRE(ctx->device >= 0 && ctx->device < 64, "device index out of range");
+    if (!g_fast_tables[ctx->device]) g_fast_tables[ctx->device] = new FastTables();
+    FastTables* ft = g_fast_tables[ctx->device];
+    if (!ft->tw_r[lg_r]) {
+        SP1HIP_HIP(hipMalloc((void**)&ft->tw_r[lg_r], ((size_t)1 << lg_r) * 2));
+        hipLaunchKernelGGL(fill_tw_r_kernel, dim3(1), dim3(256), 0, s, ft->tw_r[lg_r], lg_r, ctx->d_tw_lo, ctx->d_tw_hi);
+        SP1HIP_LAUNCH_CHECK();
+        SP1HIP_HIP(hipStreamSynchronize(s));   // other streams may use the table next
+    }
+    if (lg_seg >= 0 && !ft->tw_lane[lg_seg]) {
+        SP1HIP_HIP(hipMalloc((void**)&ft->tw_lane[lg_seg], 256 * FT * 4));
+        hipLaunchKernelGGL(fill_tw_lane_kernel, dim3(64), dim3(256), 0, s, ft->tw_lane[lg_seg], lg_seg, ctx->d_tw_lo,
+                           ctx->d_tw_hi);
+        SP1HIP_LAUNCH_CHECK();
+        SP1HIP_HIP(hipStreamSynchronize(s));
+    }
+    *tw_r = ft->tw_r[lg_r];
+    *tw_lane = lg_seg >= 0 ? ft->tw_lane[lg_seg] : nullptr;
+    return SP1HIP_SUCCESS;
+}
+
+template <int A, int B>
+static int launch_pass(FastPassArgs args, bool strided, bool first, uint32_t tiles, uint32_t n_cols, hipStream_t s) {
+    constexpr int R = 1 << (A + B);
+    const size_t lds = strided ? ((size_t)R * FT + R) * 4 : ((size_t)FT * (R + 1)) * 4;
+    dim3 grid(tiles, n_cols);
+    using Kern = void (*)(const uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,
+                          int, int, int);
+    Kern kern = strided ? (first ? ntt_fast_pass<A, B, true, true> : ntt_fast_pass<A, B, true, false>)
+                        : (first ? ntt_fast_pass<A, B, false, true> : ntt_fast_pass<A, B, false, false>);
+    if (lds > 48 * 1024)   // 256-point tiles need ~65 KiB of the CU's 160 KiB LDS
+        SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args.in, args.out, args.tw_r, args.tw_lane, args.tw_lo, args.tw_hi,
+                       args.lg_total, args.lg_seg, args.lg_n_in);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+// Returns false if the size is outside the fast path (caller falls back to the generic kernels).
+bool ntt_fast_plan(int lg_total, int bits[3], int* n_passes) {
+    if (lg_total >= 18 && lg_total <= 24) {
+        const int base = lg_total / 3, rem = lg_total % 3;
+        for (int i = 0; i < 3; i++) bits[i] = base + (i >= 3 - rem ? 1 : 0);
+        *n_passes = 3;
+        return true;
+    }
+    if (lg_total >= 14 && lg_total <= 16) {
+        bits[0] = lg_total - 8;
+        bits[1] = 8;
+        *n_passes = 2;
+        return true;
+    }
+    return false;
+}
+
+int ntt_fast_encode(uint32_t* d_out, const uint32_t* d_in, int lg_n, int lg_blowup, size_t n_cols, const DeviceCtx* ctx,
+                    hipStream_t s) {
+    const int lg_total = lg_n + lg_blowup;
+    int bits[3], n_passes;
+    if (!ntt_fast_plan(lg_total, bits, &n_passes)) return SP1HIP_ERROR_INVALID_ARGUMENT;
+    int lg_seg = lg_total;
+    for (int p = 0; p < n_passes; p++) {
+        const bool first = p == 0, last = p == n_passes - 1;
+        const int lg_r = bits[p];
+        FastPassArgs a{};
+        a.in = d_in;
+        a.out = d_out;
+        a.tw_lo = ctx->d_tw_lo;
+        a.tw_hi = ctx->d_tw_hi;
+        a.lg_total = lg_total;
+        a.lg_seg = lg_seg;
+        a.lg_n_in = lg_n;
+        SP1HIP_TRY(get_fast_tables(ctx, s, lg_r, last ? -1 : lg_seg, &a.tw_r, &a.tw_lane));
+        const uint32_t tiles = 1u << (lg_total - lg_r - 6);
+        ScopedTimer t(p == 0 ? "ntt_pass0" : (p == 1 ? "ntt_pass1" : "ntt_pass2"), s);
+        if (lg_r == 6) SP1HIP_TRY((launch_pass<3, 3>(a, !last, first, tiles, (uint32_t)n_cols, s)));
+        else if (lg_r == 7) SP1HIP_TRY((launch_pass<3, 4>(a, !last, first, tiles, (uint32_t)n_cols, s)));
+        else SP1HIP_TRY((launch_pass<4, 4>(a, !last, first, tiles, (uint32_t)n_cols, s)));
+        lg_seg -= lg_r;
+    }
+    return SP1HIP_SUCCESS;
+}
+
+}  // namespace sp1hip
