@@ -201,6 +201,35 @@ int sp1hip_basefold_prove(const sp1hip_ext_t* h_point, int dim, sp1hip_basefold_
                           sp1hip_stream_t stream);
 size_t sp1hip_basefold_proof_size(int dim, const uint32_t* round_widths, int n_rounds, sp1hip_fri_config_t config);
 
+/* ---------------------------------------------------------------- stacked + jagged commit (a5, a7, a8)
+ * One chip table: column-major [rows x cols] device words (rows = real rows, no padding). */
+typedef struct {
+    const uint32_t* d_data;
+    uint64_t rows;
+    uint32_t cols;
+} sp1hip_table_t;
+typedef struct sp1hip_stacked_data_s sp1hip_stacked_data_t;
+
+/* `StackedPcsProver::commit_multilinears` (/root/reference/slop/crates/stacked/src/prover.rs:L59-L94) with
+ * `interleave_multilinears_with_fixed_rate` (/root/reference/slop/crates/stacked/src/fixed_rate.rs:L6-L47):
+ * dense column-major concatenation of the tables, zero-padded to a multiple of 2^log_stacking_height
+ * (at least one column), cut into batches of `batch_size` stacked columns, BaseFold-committed.
+ * The tables are copied; the returned handle owns the dense buffer and the BaseFold data. */
+int sp1hip_stacked_commit(const sp1hip_table_t* tables, int n_tables, int log_stacking_height, int batch_size,
+                          int lg_blowup, uint32_t h_commit[8], uint64_t* num_added_vals, sp1hip_stacked_data_t** out,
+                          sp1hip_stream_t stream);
+void sp1hip_stacked_data_free(sp1hip_stacked_data_t* data);
+int sp1hip_stacked_data_info(const sp1hip_stacked_data_t* data, sp1hip_basefold_data_t** basefold, int* n_batches,
+                             const uint32_t** d_dense, uint64_t* padded_area);
+int sp1hip_stacked_batch(const sp1hip_stacked_data_t* data, int k, sp1hip_tensor_t* batch);
+/* `JaggedProver::commit_multilinears` (/root/reference/slop/crates/jagged/src/prover.rs:L106-L160), the call made by
+ * `ShardProver::commit_traces` (/root/reference/crates/hypercube/src/prover/shard.rs:L462-L468): tables with zero
+ * rows are counted but not committed; the result is compress(stacked_commit, hash([n + 2, rows.., cols..]))
+ * with the two padding tables appended. */
+int sp1hip_jagged_commit(const sp1hip_table_t* tables, int n_tables, int max_log_row_count, int log_stacking_height,
+                         int batch_size, int lg_blowup, uint32_t h_commit[8], sp1hip_stacked_data_t** out,
+                         sp1hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,10 @@ class Tensor(C.Structure):
     _fields_ = [("d_data", C.c_void_p), ("width", C.c_uint32)]
 
 
+class Table(C.Structure):
+    _fields_ = [("d_data", C.c_void_p), ("rows", C.c_uint64), ("cols", C.c_uint32)]
+
+
 class FriConfig(C.Structure):
     _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("proof_of_work_bits", C.c_int)]
 
@@ -97,6 +101,12 @@ PROTOTYPES = [
     ("sp1hip_basefold_prove", None, [C.POINTER(Ext), _int, C.POINTER(_vp), _int, C.POINTER(Ext), _sz, FriConfig, _vp,
                                      u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_basefold_proof_size", _sz, [_int, u32p, _int, FriConfig]),
+    ("sp1hip_stacked_commit", None, [C.POINTER(Table), _int, _int, _int, _int, u32p, C.POINTER(C.c_uint64),
+                                     C.POINTER(_vp), _vp]),
+    ("sp1hip_stacked_data_free", "void", [_vp]),
+    ("sp1hip_stacked_data_info", None, [_vp, C.POINTER(_vp), C.POINTER(_int), C.POINTER(_vp), C.POINTER(C.c_uint64)]),
+    ("sp1hip_stacked_batch", None, [_vp, _int, C.POINTER(Tensor)]),
+    ("sp1hip_jagged_commit", None, [C.POINTER(Table), _int, _int, _int, _int, _int, u32p, C.POINTER(_vp), _vp]),
 ]
 
 _lib = None

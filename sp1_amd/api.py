@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Ext, FriConfig, Tensor, check
+from ._lib import Ext, FriConfig, Table, Tensor, check
 
 P = 0x7F000001
 
@@ -284,3 +284,83 @@ class BasefoldProver:
                                          _ext_array(claims), claims.shape[0], self.config, challenger.h, buf,
                                          C.byref(n), _stream_ptr(stream)))
         return bytes(buf[:n.value])
+
+
+class _BorrowedBasefoldData:
+    """Non-owning view of the BaseFold data inside a stacked commitment (freed with its owner)."""
+
+    def __init__(self, handle, commit, widths):
+        self.h, self.commit = handle, commit
+        self.mles = [_Width(w) for w in widths]
+
+
+class _Width:
+    def __init__(self, width):
+        self.width = width
+
+
+class _RawColMajor:
+    """A ColMajor-like view over device memory owned elsewhere."""
+
+    def __init__(self, ptr, height, width):
+        self.ptr, self.height, self.width = ptr, height, width
+
+    def as_tensor_struct(self):
+        return Tensor(self.ptr, self.width)
+
+
+class StackedData:
+    """Owns the dense stacked buffer + BaseFold data of one commitment (StackedBasefoldProverData)."""
+
+    def __init__(self, handle, commit, num_added_vals, log_stacking_height):
+        self.h, self.commit, self.num_added_vals, self.lsh = handle, commit, num_added_vals, log_stacking_height
+        bf, nb, dense, padded = C.c_void_p(), C.c_int(), C.c_void_p(), C.c_uint64()
+        check(_L().sp1hip_stacked_data_info(handle, C.byref(bf), C.byref(nb), C.byref(dense), C.byref(padded)))
+        self.padded_area = padded.value
+        self.batches = []
+        for k in range(nb.value):
+            t = Tensor()
+            check(_L().sp1hip_stacked_batch(handle, k, C.byref(t)))
+            self.batches.append(_RawColMajor(t.d_data, 1 << log_stacking_height, t.width))
+        self.basefold = _BorrowedBasefoldData(bf, commit, [t.width for t in self.batches])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _L().sp1hip_stacked_data_free(self.h)
+            self.h = None
+
+
+def _table_array(tables):
+    arr = (Table * max(len(tables), 1))()
+    for i, t in enumerate(tables):
+        arr[i] = Table(C.c_void_p(t.words.data_ptr()) if t.height * t.width else None, t.height, t.width)
+    return arr
+
+
+class StackedPcsProver:
+    def __init__(self, log_stacking_height, batch_size, log_blowup=2):
+        self.lsh, self.batch_size, self.log_blowup = log_stacking_height, batch_size, log_blowup
+
+    def commit_multilinears(self, tables, stream=None):
+        commit = np.zeros(8, np.uint32)
+        added, handle = C.c_uint64(), C.c_void_p()
+        check(_L().sp1hip_stacked_commit(_table_array(tables), len(tables), self.lsh, self.batch_size, self.log_blowup,
+                                         commit.ctypes.data_as(_lib.u32p), C.byref(added), C.byref(handle),
+                                         _stream_ptr(stream)))
+        return commit, StackedData(handle, commit, added.value, self.lsh), added.value
+
+
+class JaggedProver:
+    """JaggedProver::commit_multilinears over chip tables (zero-row tables are counted, not committed)."""
+
+    def __init__(self, max_log_row_count, log_stacking_height, batch_size, log_blowup=2):
+        self.max_log_row_count, self.lsh = max_log_row_count, log_stacking_height
+        self.batch_size, self.log_blowup = batch_size, log_blowup
+
+    def commit_multilinears(self, tables, stream=None):
+        commit = np.zeros(8, np.uint32)
+        handle = C.c_void_p()
+        check(_L().sp1hip_jagged_commit(_table_array(tables), len(tables), self.max_log_row_count, self.lsh,
+                                        self.batch_size, self.log_blowup, commit.ctypes.data_as(_lib.u32p),
+                                        C.byref(handle), _stream_ptr(stream)))
+        return commit, StackedData(handle, commit, None, self.lsh)

@@ -315,3 +315,59 @@ def test_full_size_properties(api):
     vals = tcs.compute_openings_at_indices([ea], idx)
     proof = tcs.prove_openings_at_indices(data, idx)
     assert orc.merkle_verify(commit, idx, vals, lg_n + lb, proof["merkle_root"], proof["paths"]) == 0
+
+
+def _tables(shapes, seed):
+    return [orc.random_felts(s, seed + i) if s[0] * s[1] else np.zeros(s, np.uint32) for i, s in enumerate(shapes)]
+
+
+@pytest.mark.parametrize("shapes,lsh,batch", [
+    ([(96, 3), (32, 1), (160, 2), (64, 5)], 6, 2),          # ragged heights, several batches, zero padding
+    ([(64, 4)], 6, 4),                                       # exactly one full batch, no padding
+    ([(64, 4), (64, 4)], 6, 4),                              # exact multiple of a full batch (overflow-buffer case)
+    ([(40, 1)], 6, 32),                                      # less than one stacked column
+    ([(1 << 12, 7), (3000, 13), (32, 30)], 10, 32),          # core-like: batch 32
+])
+def test_stacked_and_jagged_commit(api, shapes, lsh, batch):
+    """a5/a7/a8: dense stacking of ragged chip tables, BaseFold commit of the batches, jagged wrapper."""
+    lb = 2
+    tables = _tables(shapes, 900)
+    # oracle: interleave -> commit_mles -> wrapper
+    o_batches = orc.interleave(tables, batch, lsh)
+    o_round = orc.CommittedRound(o_batches, lb)
+    area = sum(t.size for t in tables)
+    H = 1 << lsh
+    added = max(-(-area // H) * H, H) - area
+    d_tables = [api.ColMajor.from_row_major_host(t) for t in tables]
+    commit, sd, num_added = api.StackedPcsProver(lsh, batch, lb).commit_multilinears(d_tables)
+    assert num_added == added
+    assert [b.width for b in sd.batches] == [b.shape[1] for b in o_batches]
+    assert np.array_equal(commit, o_round.commit)
+    # jagged wrapper with a zero-row chip in the middle (counted, not committed)
+    max_log_rows = max(lsh, max(int(s[0] - 1).bit_length() for s in shapes))
+    with_empty = d_tables[:1] + [api.ColMajor(api.device_words(0), 0, 9)] + d_tables[1:]
+    jcommit, jsd = api.JaggedProver(max_log_rows, lsh, batch, lb).commit_multilinears(with_empty)
+    rows = [shapes[0][0], 0] + [s[0] for s in shapes[1:]]
+    cols = [shapes[0][1], 9] + [s[1] for s in shapes[1:]]
+    want = orc.jagged_commit_wrap(o_round.commit, rows, cols, added, max_log_rows)
+    assert np.array_equal(jcommit, want)
+    # the stacked batches open like any BaseFold commitment: prove + verify with the oracle
+    prover = api.BasefoldProver(lb, 16, 8)
+    ch = api.DuplexChallenger()
+    ch.observe(commit)
+    pt = ch.sample_point(lsh)
+    claims = prover.evaluate_mles(sd.batches, pt)
+    assert np.array_equal(claims, np.concatenate([orc.eval_mle(b, pt) for b in o_batches]))
+    blob = prover.prove_trusted_mle_evaluations(pt, [sd.basefold], claims, ch)
+    ov = orc.Challenger()
+    ov.observe(commit)
+    ov.sample_point(lsh)
+    assert orc.basefold_verify([commit], pt, [claims], blob, ov, lb, 16, 8) == 0
+
+
+def test_stacked_commit_of_nothing(api):
+    """Empty message: one zero-width batch, padding = one stacked column (reference edge case)."""
+    commit, sd, added = api.StackedPcsProver(4, 2, 1).commit_multilinears([])
+    assert added == 16 and [b.width for b in sd.batches] == [0]
+    o = orc.CommittedRound([np.zeros((16, 0), np.uint32)], 1)
+    assert np.array_equal(commit, o.commit)
