@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "kb_pcs.hpp"
+#include "kb_zerocheck.hpp"
 
 using namespace orc;
 
@@ -218,6 +218,114 @@ void orc_jagged_commit_wrap(const uint32_t* commit8, const uint64_t* rows, const
     Digest d = jagged_commit_wrap(load_d(commit8), std::vector<size_t>(rows, rows + n),
                                   std::vector<size_t>(cols, cols + n), num_added_vals, max_log_row_count);
     memcpy(out8, &d, 32);
+}
+
+// ---- zerocheck ----------------------------------------------------------------------------------
+static std::vector<ZcAir> make_airs(int n, const uint32_t** progs, const int* prog_lens, const int* main_w, const int* prep_w,
+                                    const int* n_constraints) {
+    std::vector<ZcAir> airs(n);
+    for (int i = 0; i < n; i++) {
+        airs[i].main_width = main_w[i];
+        airs[i].prep_width = prep_w[i];
+        airs[i].num_constraints = n_constraints[i];
+        for (int k = 0; k < prog_lens[i]; k++) airs[i].prog.push_back({progs[i][3 * k], progs[i][3 * k + 1], progs[i][3 * k + 2]});
+    }
+    return airs;
+}
+
+// openings: per chip main evals then prep evals (ext), flattened. Returns blob size.
+size_t orc_zerocheck_prove(int n_chips, const uint32_t** progs, const int* prog_lens, const int* main_w, const int* prep_w,
+                           const int* n_constraints, const uint32_t** mains, const uint32_t** preps, const uint64_t* real_rows,
+                           const uint32_t* openings, int max_log_row_count, const uint32_t* zeta, const uint32_t* alpha,
+                           const uint32_t* gkr, const uint32_t* publics, int n_publics, void* challenger, uint8_t* out,
+                           size_t cap) {
+    std::vector<ZcAir> airs = make_airs(n_chips, progs, prog_lens, main_w, prep_w, n_constraints);
+    std::vector<ZcChipInput> chips(n_chips);
+    size_t o = 0;
+    for (int i = 0; i < n_chips; i++) {
+        chips[i].air = &airs[i];
+        chips[i].main = FP(mains[i]);
+        chips[i].prep = preps[i] ? FP(preps[i]) : nullptr;
+        chips[i].real_rows = real_rows[i];
+        for (int c = 0; c < main_w[i]; c++, o++) chips[i].main_opening.push_back(load_e(openings + 4 * o));
+        for (int c = 0; c < prep_w[i]; c++, o++) chips[i].prep_opening.push_back(load_e(openings + 4 * o));
+    }
+    std::vector<E> z(max_log_row_count);
+    memcpy(z.data(), zeta, (size_t)max_log_row_count * 16);
+    std::vector<F> pv(n_publics);
+    memcpy(pv.data(), publics, (size_t)n_publics * 4);
+    ZcProof p = zerocheck_prove(chips, max_log_row_count, z, load_e(alpha), load_e(gkr), pv, *static_cast<Challenger*>(challenger));
+    std::vector<uint8_t> b = serialize_zc_proof(p);
+    if (b.size() <= cap) memcpy(out, b.data(), b.size());
+    return b.size();
+}
+
+int orc_zerocheck_verify(int n_chips, const uint32_t** progs, const int* prog_lens, const int* main_w, const int* prep_w,
+                         const int* n_constraints, const uint64_t* heights, const uint32_t* openings, int max_log_row_count,
+                         const uint32_t* zeta, const uint32_t* alpha, const uint32_t* gkr, const uint32_t* publics,
+                         int n_publics, const uint8_t* blob, size_t len, void* challenger) {
+    try {
+        std::vector<ZcAir> airs = make_airs(n_chips, progs, prog_lens, main_w, prep_w, n_constraints);
+        std::vector<const ZcAir*> ap;
+        std::vector<size_t> hs(heights, heights + n_chips);
+        std::vector<std::vector<E>> mo(n_chips), po(n_chips);
+        size_t o = 0;
+        for (int i = 0; i < n_chips; i++) {
+            ap.push_back(&airs[i]);
+            for (int c = 0; c < main_w[i]; c++, o++) mo[i].push_back(load_e(openings + 4 * o));
+            for (int c = 0; c < prep_w[i]; c++, o++) po[i].push_back(load_e(openings + 4 * o));
+        }
+        ByteReader r{blob, len};
+        ZcProof p;
+        size_t n = r.u64();
+        if (n > len) return -1;
+        for (size_t i = 0; i < n; i++) {
+            size_t k = r.u64();
+            if (k > len) return -1;
+            UniPoly u(k);
+            for (auto& c : u) c = r.e();
+            p.univariate_polys.push_back(u);
+        }
+        p.claimed_sum = r.e();
+        n = r.u64();
+        if (n > len) return -1;
+        p.point.resize(n);
+        for (auto& x : p.point) x = r.e();
+        p.eval = r.e();
+        n = r.u64();
+        if ((int)n != n_chips) return -1;
+        for (size_t i = 0; i < n; i++) {
+            size_t k = r.u64();
+            if ((int)k != main_w[i] + prep_w[i]) return -1;
+            std::vector<E> ev(k);
+            for (auto& x : ev) x = r.e();
+            p.chip_evals.push_back(ev);
+        }
+        if (r.o != len) return -1;
+        std::vector<E> z(max_log_row_count);
+        memcpy(z.data(), zeta, (size_t)max_log_row_count * 16);
+        std::vector<F> pv(n_publics);
+        memcpy(pv.data(), publics, (size_t)n_publics * 4);
+        return zerocheck_verify(ap, hs, mo, po, max_log_row_count, z, load_e(alpha), load_e(gkr), pv, p,
+                                *static_cast<Challenger*>(challenger));
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// round consistency of a PartialSumcheckProof given its own point (no transcript): used on the golden proof
+int orc_sumcheck_rounds_consistent(const uint32_t* polys, int n_rounds, int n_coeffs, const uint32_t* claimed_sum,
+                                   const uint32_t* point, const uint32_t* eval) {
+    std::vector<UniPoly> us(n_rounds, UniPoly(n_coeffs));
+    for (int r = 0; r < n_rounds; r++) memcpy(us[r].data(), polys + (size_t)r * n_coeffs * 4, (size_t)n_coeffs * 16);
+    std::vector<E> pt(n_rounds);
+    memcpy(pt.data(), point, (size_t)n_rounds * 16);
+    if (uni_eval_one_plus_eval_zero(us[0]) != load_e(claimed_sum)) return 1;
+    // proof.point = [alpha_last, ..., alpha_first]
+    for (int r = 1; r < n_rounds; r++)
+        if (uni_eval(us[r - 1], pt[n_rounds - r]) != uni_eval_one_plus_eval_zero(us[r])) return 2 + r;
+    if (uni_eval(us[n_rounds - 1], pt[0]) != load_e(eval)) return 2;
+    return 0;
 }
 
 }  // extern "C"

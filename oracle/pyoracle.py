@@ -360,3 +360,72 @@ def jagged_commit_wrap(commit, rows, cols, num_added_vals, max_log_row_count):
     lib().orc_jagged_commit_wrap(_p(_arr(commit)), rows.ctypes.data_as(u64p), cols.ctypes.data_as(u64p), len(rows),
                                  C.c_uint64(num_added_vals), max_log_row_count, _p(out))
     return out
+
+
+# ---- zerocheck ------------------------------------------------------------------------------------
+class ZcChip:
+    """One chip for the oracle's zerocheck: program ([n][3] u32), widths, traces (row-major, real rows
+    only, Montgomery) and the trace-column evaluations at zeta (main then prep, [w][4])."""
+
+    def __init__(self, prog, main_width, prep_width, num_constraints, main, prep=None, openings=None):
+        self.prog = np.ascontiguousarray(prog, dtype=np.uint32).reshape(-1, 3)
+        self.main_width, self.prep_width, self.num_constraints = main_width, prep_width, num_constraints
+        self.main = _arr(main).reshape(-1, main_width) if main_width else np.zeros((0, 0), np.uint32)
+        self.prep = _arr(prep).reshape(-1, prep_width) if prep_width else None
+        self.real_rows = self.main.shape[0]
+        self.openings = None if openings is None else _arr(openings).reshape(-1, 4)
+
+
+def _zc_common(chips):
+    n = len(chips)
+    progs = _ptr_array([c.prog for c in chips])
+    lens = (C.c_int * n)(*[c.prog.shape[0] for c in chips])
+    mw = (C.c_int * n)(*[c.main_width for c in chips])
+    pw = (C.c_int * n)(*[c.prep_width for c in chips])
+    nc = (C.c_int * n)(*[c.num_constraints for c in chips])
+    return n, progs, lens, mw, pw, nc
+
+
+def zerocheck_prove(chips, max_log_row_count, zeta, alpha, gkr, publics, challenger):
+    L = lib()
+    L.orc_zerocheck_prove.restype = C.c_size_t
+    n, progs, lens, mw, pw, nc = _zc_common(chips)
+    mains = (u32p * n)(*[_p(c.main) if c.main.size else None for c in chips])
+    preps = (u32p * n)(*[_p(c.prep) if c.prep is not None and c.prep.size else None for c in chips])
+    rows = (C.c_uint64 * n)(*[c.real_rows for c in chips])
+    openings = _arr(np.concatenate([c.openings for c in chips]))
+    zeta, alpha, gkr, publics = _arr(zeta).reshape(-1, 4), _arr(alpha), _arr(gkr), _arr(publics).reshape(-1)
+    args = [n, progs, lens, mw, pw, nc, mains, preps, rows, _p(openings), max_log_row_count, _p(zeta), _p(alpha), _p(gkr),
+            _p(publics) if publics.size else None, int(publics.size)]
+    probe = challenger.clone()
+    size = L.orc_zerocheck_prove(*args, C.c_void_p(probe.h), None, C.c_size_t(0))
+    buf = (C.c_uint8 * size)()
+    got = L.orc_zerocheck_prove(*args, C.c_void_p(challenger.h), buf, C.c_size_t(size))
+    assert got == size
+    return bytes(buf)
+
+
+def zerocheck_verify(chips, heights, max_log_row_count, zeta, alpha, gkr, publics, blob, challenger):
+    L = lib()
+    n, progs, lens, mw, pw, nc = _zc_common(chips)
+    hs = (C.c_uint64 * n)(*heights)
+    openings = _arr(np.concatenate([c.openings for c in chips]))
+    zeta, alpha, gkr, publics = _arr(zeta).reshape(-1, 4), _arr(alpha), _arr(gkr), _arr(publics).reshape(-1)
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    return L.orc_zerocheck_verify(n, progs, lens, mw, pw, nc, hs, _p(openings), max_log_row_count, _p(zeta), _p(alpha),
+                                  _p(gkr), _p(publics) if publics.size else None, int(publics.size), buf,
+                                  C.c_size_t(len(blob)), C.c_void_p(challenger.h))
+
+
+def sumcheck_rounds_consistent(polys, claimed_sum, point, eval_):
+    polys = _arr(polys)
+    return lib().orc_sumcheck_rounds_consistent(_p(polys), polys.shape[0], polys.shape[1], _p(_arr(claimed_sum)),
+                                                _p(_arr(point)), _p(_arr(eval_)))
+
+
+def padded_column_openings(table, max_log_row_count, zeta):
+    """Evaluations at zeta of every column of `table` zero-padded to 2^max_log_row_count rows."""
+    t = _arr(table)
+    full = np.zeros((1 << max_log_row_count, t.shape[1]), np.uint32)
+    full[:t.shape[0]] = t
+    return eval_mle(full, zeta) if t.shape[1] else np.zeros((0, 4), np.uint32)

@@ -1,0 +1,123 @@
+"""Constraint programs: AIR constraints as data for the zerocheck kernels.
+
+The reference's chips express constraints as Rust generic code over an `AirBuilder`
+(`Air::eval(&mut ConstraintSumcheckFolder)`, /root/reference/crates/hypercube/src/folder.rs:L276-L323); a GPU
+backend needs them as data, which the reference's own CUDA backend obtains by running `eval` over a
+recording builder (/root/reference/sp1-gpu/crates/air/src/ir/bytecode.rs:L27-L110). The program format here is
+the same operation set in SSA form, one `[op, a, b]` u32 triple per instruction; instruction k defines
+value k:
+
+    0 LOAD_MAIN col | 1 LOAD_PREP col | 2 CONST canonical | 3 PUBLIC idx
+    4 ADD a b | 5 SUB a b | 6 MUL a b | 7 NEG a | 8 ASSERT_ZERO a   (the k-th assert gets alpha-power k)
+
+`AirProgram` is a tiny builder with operator overloading used by the tests; a JSON dump of the
+RISC-V chips from the reference's `crates/core/compiler` maps onto the same triples.
+Single-row constraints only (the zerocheck folder exposes no next-row access), degree <= 3.
+"""
+import numpy as np
+
+LOAD_MAIN, LOAD_PREP, CONST, PUBLIC, ADD, SUB, MUL, NEG, ASSERT_ZERO = range(9)
+P = 0x7F000001
+
+
+class Expr:
+    def __init__(self, prog, idx):
+        self.prog, self.idx = prog, idx
+
+    def _wrap(self, other):
+        return other if isinstance(other, Expr) else self.prog.const(other)
+
+    def __add__(self, o):
+        return self.prog._emit(ADD, self.idx, self._wrap(o).idx)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self.prog._emit(SUB, self.idx, self._wrap(o).idx)
+
+    def __rsub__(self, o):
+        return self.prog._emit(SUB, self._wrap(o).idx, self.idx)
+
+    def __mul__(self, o):
+        return self.prog._emit(MUL, self.idx, self._wrap(o).idx)
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self.prog._emit(NEG, self.idx, 0)
+
+
+class AirProgram:
+    def __init__(self, name, main_width, prep_width=0):
+        self.name, self.main_width, self.prep_width = name, main_width, prep_width
+        self.instrs, self.num_constraints = [], 0
+
+    def _emit(self, op, a, b):
+        self.instrs.append((op, a, b))
+        return Expr(self, len(self.instrs) - 1)
+
+    def main(self, col):
+        assert 0 <= col < self.main_width
+        return self._emit(LOAD_MAIN, col, 0)
+
+    def prep(self, col):
+        assert 0 <= col < self.prep_width
+        return self._emit(LOAD_PREP, col, 0)
+
+    def const(self, v):
+        return self._emit(CONST, int(v) % P, 0)
+
+    def public(self, idx):
+        return self._emit(PUBLIC, idx, 0)
+
+    def assert_zero(self, e):
+        self._emit(ASSERT_ZERO, e.idx, 0)
+        self.num_constraints += 1
+
+    def assert_eq(self, a, b):
+        self.assert_zero(a - b)
+
+    def to_array(self):
+        return np.array(self.instrs, dtype=np.uint32).reshape(-1, 3)
+
+    def max_live_registers(self):
+        """Registers needed after last-use allocation (what the interpreter kernels size their file by)."""
+        return allocate_registers(self.to_array())[1]
+
+
+def allocate_registers(prog):
+    """Linear-scan register allocation for the SSA program. Returns (allocated program, n_registers): an
+    [n, 4] array of [op, dst, a, b] where a/b are register numbers (ASSERT_ZERO has no dst)."""
+    n = len(prog)
+    last_use = [-1] * n
+    for k, (op, a, b) in enumerate(prog.tolist()):
+        if op in (ADD, SUB, MUL):
+            last_use[a] = k
+            last_use[b] = k
+        elif op in (NEG, ASSERT_ZERO):
+            last_use[a] = k
+    free, reg_of, out, n_regs = [], {}, [], 0
+    for k, (op, a, b) in enumerate(prog.tolist()):
+        ra = reg_of.get(a, 0) if op in (ADD, SUB, MUL, NEG, ASSERT_ZERO) else a
+        rb = reg_of.get(b, 0) if op in (ADD, SUB, MUL) else b
+        # operands whose last use is this instruction free their register before dst is chosen
+        if op in (ADD, SUB, MUL, NEG, ASSERT_ZERO):
+            for v in {a, b} if op in (ADD, SUB, MUL) else {a}:
+                if last_use[v] == k and v in reg_of:
+                    free.append(reg_of.pop(v))
+        if op == ASSERT_ZERO:
+            out.append((op, 0, ra, 0))
+            continue
+        if last_use[k] < 0:            # dead value: still needs a slot for the write
+            dst = free[-1] if free else n_regs
+            if not free:
+                n_regs += 1
+        elif free:
+            dst = free.pop()
+            reg_of[k] = dst
+        else:
+            dst = n_regs
+            n_regs += 1
+            reg_of[k] = dst
+        out.append((op, dst, ra, rb))
+    return np.array(out, dtype=np.uint32).reshape(-1, 4), max(n_regs, 1)

@@ -20,7 +20,9 @@ What goes into tests/golden/kb_shrink_basefold.npz (first NQ of the 124 queries 
   * the recovered query indices (the proof does not store them: they come from the Fiat-Shamir
     transcript; they are recovered here by walking each path with both left/right orders),
   * univariate messages, fri commitments, final_poly, the two PoW witnesses,
-  * merkle_tree_commitments, row/column counts, vk.preprocessed_commit, proof.main_commitment.
+  * merkle_tree_commitments, row/column counts, vk.preprocessed_commit, proof.main_commitment,
+  * the three PartialSumcheckProofs of the shard proof (zerocheck: 21 rounds x 5 coefficients; jagged
+    sumcheck; jagged eval) — used to pin the univariate-message conventions of the sumcheck driver.
 
 While extracting, the script *verifies* with oracle/kb_py.py (pure Python) that
   - every kept leaf hashes up its path to the stored root,
@@ -74,11 +76,29 @@ class Reader:
         return dict(values=vals, root=root, log_h=log_h, width=width, paths=paths)
 
     def sumcheck(self):
+        """PartialSumcheckProof<EF> (/root/reference/slop/crates/sumcheck/src/proof.rs:L10-L14)."""
+        polys = []
         for _ in range(self.u64()):
-            self.u32s(4 * self.u64())
-        self.u32s(4)
-        self.u32s(4 * self.u64())
-        self.u32s(4)
+            polys.append(self.u32s(4 * self.u64()))
+        claimed = self.u32s(4)
+        point = self.u32s(4 * self.u64())
+        ev = self.u32s(4)
+        assert len({len(p) for p in polys}) == 1 and len(point) == 4 * len(polys)
+        return dict(polys=np.array(polys, dtype=np.uint32).reshape(len(polys), -1, 4),
+                    claimed_sum=np.array(claimed, dtype=np.uint32), point=np.array(point, dtype=np.uint32).reshape(-1, 4),
+                    eval=np.array(ev, dtype=np.uint32))
+
+
+def find_zerocheck_proof(b, limit):
+    """ShardProof.zerocheck_proof sits before the opened values: max_log_row_count (= 21 here) polys of 5
+    coefficients each (degree 4)."""
+    pat = struct.pack("<Q", 21) + struct.pack("<Q", 5)
+    o = b.find(pat)
+    while 0 <= o < limit:
+        if struct.unpack_from("<Q", b, o + 8 + 88)[0] == 5 and struct.unpack_from("<Q", b, o + 8 + 88 * 20)[0] == 5:
+            return o
+        o = b.find(pat, o + 1)
+    raise RuntimeError("zerocheck proof not found")
 
 
 def find_basefold_start(b):
@@ -109,8 +129,10 @@ def main():
         n = r.u64()
         batch_evals.append(np.array(r.u32s(4 * n), dtype=np.uint32).reshape(n, 4))
         assert [r.u64() for _ in range(r.u64())] == [n]
-    r.sumcheck()
-    r.sumcheck()
+    jagged_sumcheck = r.sumcheck()
+    jagged_eval = r.sumcheck()
+    zc = Reader(b, find_zerocheck_proof(b, r.o)).sumcheck()
+    assert zc["polys"].shape == (21, 5, 4)
     rc = []
     for _ in range(r.u64()):
         rc.append([(r.u64(), r.u64()) for _ in range(r.u64())])
@@ -201,6 +223,9 @@ def main():
         main_commitment=np.array(main_commit, dtype=np.uint32),
         batch_evals0=batch_evals[0], batch_evals1=batch_evals[1],
     )
+    for name, sc in (("zerocheck", zc), ("jagged_sumcheck", jagged_sumcheck), ("jagged_eval", jagged_eval)):
+        for key, val in sc.items():
+            out["%s_%s" % (name, key)] = val
     for k, c in enumerate(comps):
         out["comp%d_values" % k] = c["values"][:NQ]
         out["comp%d_paths" % k] = c["paths"][:NQ]
