@@ -230,6 +230,34 @@ int sp1hip_jagged_commit(const sp1hip_table_t* tables, int n_tables, int max_log
                          int batch_size, int lg_blowup, uint32_t h_commit[8], sp1hip_stacked_data_t** out,
                          sp1hip_stream_t stream);
 
+/* ---------------------------------------------------------------- zerocheck (a9-a12)
+ * One chip of the shard. `program` is a HOST array of n_instr [op, a, b] triples in SSA form
+ * (instruction k defines value k): 0 LOAD_MAIN col, 1 LOAD_PREP col, 2 CONST canonical, 3 PUBLIC idx,
+ * 4 ADD, 5 SUB, 6 MUL, 7 NEG a, 8 ASSERT_ZERO a — the data form of `Air::eval` over
+ * `ConstraintSumcheckFolder` (/root/reference/crates/hypercube/src/folder.rs:L276-L323); single-row constraints.
+ * Traces: column-major device tensors with `real_rows` rows (padding rows are implicit zeros). */
+typedef struct {
+    const uint32_t* program;
+    uint32_t n_instr;
+    uint32_t main_width, prep_width, num_constraints;
+    const uint32_t* d_main;
+    const uint32_t* d_prep;
+    uint64_t real_rows;
+} sp1hip_zc_chip_t;
+
+/* `ShardProver::zerocheck` (/root/reference/crates/hypercube/src/prover/shard.rs:L474-L646): one sumcheck over all
+ * chips (RLC with lambda sampled from the transcript), 2^max_log_row_count rows per chip. h_zeta: the
+ * GKR point (max_log_row_count ext); h_openings: per chip, in order, the main then preprocessed column
+ * evaluations at zeta; alpha / gkr_batch: the two challenges sampled by the caller before the call.
+ * Output: bincode `PartialSumcheckProof<EF>` (/root/reference/slop/crates/sumcheck/src/proof.rs:L10-L14) followed by
+ * u64 n_chips and, per chip, Vec<EF> = preprocessed then main column evaluations at the sumcheck point.
+ * The challenger ends in the state after the openings have been observed (shard.rs:L609-L640). */
+int sp1hip_zerocheck_prove(const sp1hip_zc_chip_t* chips, int n_chips, int max_log_row_count,
+                           const sp1hip_ext_t* h_zeta, const sp1hip_ext_t* h_openings, sp1hip_ext_t alpha,
+                           sp1hip_ext_t gkr_batch, const uint32_t* h_publics, int n_publics,
+                           sp1hip_challenger_t* challenger, uint8_t* h_proof, size_t* proof_len,
+                           sp1hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

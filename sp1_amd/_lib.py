@@ -26,6 +26,12 @@ class Table(C.Structure):
     _fields_ = [("d_data", C.c_void_p), ("rows", C.c_uint64), ("cols", C.c_uint32)]
 
 
+class ZcChip(C.Structure):
+    _fields_ = [("program", C.POINTER(C.c_uint32)), ("n_instr", C.c_uint32), ("main_width", C.c_uint32),
+                ("prep_width", C.c_uint32), ("num_constraints", C.c_uint32), ("d_main", C.c_void_p),
+                ("d_prep", C.c_void_p), ("real_rows", C.c_uint64)]
+
+
 class FriConfig(C.Structure):
     _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("proof_of_work_bits", C.c_int)]
 
@@ -107,6 +113,8 @@ PROTOTYPES = [
     ("sp1hip_stacked_data_info", None, [_vp, C.POINTER(_vp), C.POINTER(_int), C.POINTER(_vp), C.POINTER(C.c_uint64)]),
     ("sp1hip_stacked_batch", None, [_vp, _int, C.POINTER(Tensor)]),
     ("sp1hip_jagged_commit", None, [C.POINTER(Table), _int, _int, _int, _int, _int, u32p, C.POINTER(_vp), _vp]),
+    ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
+                                      _vp, u8p, C.POINTER(_sz), _vp]),
 ]
 
 _lib = None

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Ext, FriConfig, Table, Tensor, check
+from ._lib import Ext, FriConfig, Table, Tensor, ZcChip, check
 
 P = 0x7F000001
 
@@ -364,3 +364,33 @@ class JaggedProver:
                                         self.batch_size, self.log_blowup, commit.ctypes.data_as(_lib.u32p),
                                         C.byref(handle), _stream_ptr(stream)))
         return commit, StackedData(handle, commit, None, self.lsh)
+
+
+class ZerocheckChip:
+    """One chip for `zerocheck`: an `sp1_amd.air.AirProgram`, column-major device traces (real rows only)."""
+
+    def __init__(self, air, main, prep=None):
+        self.air, self.main, self.prep = air, main, prep
+        self.program = np.ascontiguousarray(air.to_array(), dtype=np.uint32)
+        self.real_rows = main.height if main is not None else 0
+
+
+def zerocheck(chips, max_log_row_count, zeta, openings, alpha, gkr_batch, public_values, challenger, stream=None):
+    """ShardProver::zerocheck on the GPU. openings: per chip main then preprocessed column evaluations
+    at zeta, concatenated [total][4]. Returns the proof bytes (layout in include/sp1hip.h)."""
+    arr = (ZcChip * len(chips))()
+    for i, c in enumerate(chips):
+        arr[i] = ZcChip(c.program.ctypes.data_as(_lib.u32p), c.program.shape[0], c.air.main_width, c.air.prep_width,
+                        c.air.num_constraints,
+                        C.c_void_p(c.main.words.data_ptr()) if c.real_rows and c.air.main_width else None,
+                        C.c_void_p(c.prep.words.data_ptr()) if c.real_rows and c.prep is not None else None, c.real_rows)
+    pv = np.ascontiguousarray(np.asarray(public_values, dtype=np.uint32).reshape(-1))
+    zeta = np.asarray(zeta, dtype=np.uint32).reshape(-1, 4)
+    n = C.c_size_t(0)
+    args = [arr, len(chips), max_log_row_count, _ext_array(zeta), _ext_array(openings), _ext(alpha), _ext(gkr_batch),
+            pv.ctypes.data_as(_lib.u32p) if pv.size else None, int(pv.size), challenger.h]
+    st = _L().sp1hip_zerocheck_prove(*args, None, C.byref(n), _stream_ptr(stream))
+    assert st == -6, "size query expected SP1HIP_ERROR_BUFFER_TOO_SMALL"
+    buf = (C.c_uint8 * n.value)()
+    check(_L().sp1hip_zerocheck_prove(*args, buf, C.byref(n), _stream_ptr(stream)))
+    return bytes(buf[:n.value])

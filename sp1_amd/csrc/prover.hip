@@ -168,6 +168,11 @@ struct sp1hip_basefold_data_s {
 
 namespace sp1hip {
 
+// transcript hooks for the other translation units (zerocheck.hip)
+void challenger_observe(sp1hip_challenger_t* ch, uint32_t x) { ch->ch.observe(x); }
+kb::Ext challenger_sample_ext(sp1hip_challenger_t* ch) { return ch->ch.sample_ext(); }
+void challenger_restore(sp1hip_challenger_t* dst, const sp1hip_challenger_t* src) { dst->ch = src->ch; }
+
 struct ByteWriter {
     std::vector<uint8_t> b;
     void u64(uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
