@@ -158,7 +158,11 @@ def main():
                        "cells_per_s": rows_per_s * WIDTH, "commitment_word0": int(last[0])},
             "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel", "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": leaf_bytes / (leaf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": leaf_bytes / (leaf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         # HBM bytes per launch from the committed PMC passes of this kernel on this workload
+                         # (profiles/r01_pmc_summary.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) — equals the
+                         # algorithmic bytes, i.e. no re-reads
+                         "traffic": 4429185024, "traffic_source": "profiles/r01_pmc_summary.md",
                          "avg_launch_ms": leaf_ms, "algorithmic_bytes_per_launch": leaf_bytes,
                          "note": "integer-VALU-bound by construction (Poseidon2: %d permutations per launch, "
                                  "%.3g permutations/s); see DESIGN.md" % (perms, perms / (leaf_ms * 1e-3)),

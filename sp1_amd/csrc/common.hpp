@@ -19,6 +19,11 @@ int ensure_device_ready();
 
 inline hipStream_t S(sp1hip_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// Buffer arena (runtime.hip): stream-keyed free lists; alloc never blocks once the working set is cached.
+int arena_alloc(void** ptr, size_t bytes, hipStream_t stream);
+void arena_free(void* ptr, size_t bytes, hipStream_t stream);
+size_t arena_trim();
+
 // Optional event bracketing of a kernel launch (see sp1hip_timers_* in include/sp1hip.h).
 bool timers_on();
 void timer_begin(const char* name, hipStream_t s);

@@ -135,17 +135,18 @@ static int grind(DuplexChallenger& ch, int bits, uint32_t* witness_monty, hipStr
 }
 
 // ---------------------------------------------------------------- prover data
-// Stream-ordered allocation from the device's default memory pool (release threshold raised in
-// get_device_ctx, so steady-state proving re-uses the same HBM without touching the driver).
+// Buffers come from the stream-keyed arena (runtime.hip): steady-state proving re-uses the same HBM
+// blocks without touching the driver.
 struct DeviceBuf {
     void* p = nullptr;
     hipStream_t s = nullptr;
+    size_t n = 0;
     int alloc(size_t bytes, hipStream_t stream) {
         s = stream;
-        SP1HIP_HIP(hipMallocAsync(&p, bytes ? bytes : 1, stream));
-        return SP1HIP_SUCCESS;
+        n = bytes;
+        return arena_alloc(&p, bytes, stream);
     }
-    ~DeviceBuf() { if (p) (void)hipFreeAsync(p, s); }
+    ~DeviceBuf() { arena_free(p, n, s); }
     DeviceBuf() = default;
     DeviceBuf(const DeviceBuf&) = delete;
     DeviceBuf& operator=(const DeviceBuf&) = delete;

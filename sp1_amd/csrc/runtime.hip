@@ -2,6 +2,7 @@
 // per-device context. HIP-native equivalents of the reference's runtime shims
 // (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L16-L172): hipMallocAsync-backed allocation,
 // streams, events; no globals other than the per-device contexts.
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -53,6 +54,76 @@ void timer_end(hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_timer_mutex);
     if (g_timer_recs.empty()) return;
     (void)hipEventRecord(g_timer_recs.back().b, s);
+}
+
+// ---- stream-keyed buffer arena -------------------------------------------------------------------
+// Steady-state proving allocates the same sizes over and over on one stream (codewords, trees, fold
+// layers). Freed blocks are kept in a per-(device, stream, size) free list and handed back without
+// touching the driver; reuse on the same stream is ordered by the stream itself. hipMallocAsync's own
+// pool was measured to stall 80-120 ms per step on 0.5 GB blocks here (profiles/r01_notes.md).
+struct ArenaKey {
+    int device;
+    hipStream_t stream;
+    size_t bytes;
+    bool operator<(const ArenaKey& o) const {
+        if (device != o.device) return device < o.device;
+        if (stream != o.stream) return stream < o.stream;
+        return bytes < o.bytes;
+    }
+};
+static std::mutex g_arena_mutex;
+static std::map<ArenaKey, std::vector<void*>> g_arena;
+static size_t g_arena_cached_bytes = 0;
+
+static size_t arena_round(size_t bytes) { return bytes < 256 ? 256 : ((bytes + 255) / 256) * 256; }
+
+int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    const size_t sz = arena_round(bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_arena_mutex);
+        auto it = g_arena.find(ArenaKey{dev, stream, sz});
+        if (it != g_arena.end() && !it->second.empty()) {
+            *ptr = it->second.back();
+            it->second.pop_back();
+            g_arena_cached_bytes -= sz;
+            return SP1HIP_SUCCESS;
+        }
+    }
+    hipError_t e = hipMalloc(ptr, sz);
+    if (e == hipErrorOutOfMemory) {       // give cached blocks back to the driver and retry once
+        (void)hipGetLastError();
+        arena_trim();
+        e = hipMalloc(ptr, sz);
+    }
+    SP1HIP_HIP(e);
+    return SP1HIP_SUCCESS;
+}
+
+void arena_free(void* ptr, size_t bytes, hipStream_t stream) {
+    if (!ptr) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const size_t sz = arena_round(bytes);
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    g_arena[ArenaKey{dev, stream, sz}].push_back(ptr);
+    g_arena_cached_bytes += sz;
+}
+
+size_t arena_trim() {
+    std::map<ArenaKey, std::vector<void*>> old;
+    size_t freed;
+    {
+        std::lock_guard<std::mutex> lock(g_arena_mutex);
+        old.swap(g_arena);
+        freed = g_arena_cached_bytes;
+        g_arena_cached_bytes = 0;
+    }
+    (void)hipDeviceSynchronize();
+    for (auto& kv : old)
+        for (void* p : kv.second) (void)hipFree(p);
+    return freed;
 }
 
 static std::mutex g_ctx_mutex;
@@ -123,6 +194,12 @@ int sp1hip_timers_read(const char* name, uint64_t* launches, double* total_ms) {
         *launches += 1;
         *total_ms += ms;
     }
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_mem_trim(size_t* released_bytes) {
+    const size_t n = arena_trim();
+    if (released_bytes) *released_bytes = n;
     return SP1HIP_SUCCESS;
 }
 

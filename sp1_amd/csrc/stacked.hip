@@ -26,7 +26,7 @@ struct sp1hip_stacked_data_s {
     uint32_t commit[8];
     ~sp1hip_stacked_data_s() {
         if (basefold) sp1hip_basefold_data_free(basefold);
-        if (d_dense) (void)hipFreeAsync(d_dense, stream);
+        sp1hip::arena_free(d_dense, padded * 4, stream);
     }
 };
 
@@ -82,7 +82,7 @@ int sp1hip_stacked_commit(const sp1hip_table_t* tables, int n_tables, int log_st
     sd->area = area;
     sd->padded = padded;
     sd->log_stacking_height = log_stacking_height;
-    SP1HIP_HIP(hipMallocAsync(&sd->d_dense, padded * 4, s));
+    SP1HIP_TRY(arena_alloc(&sd->d_dense, padded * 4, s));
     uint64_t off = 0;
     for (int i = 0; i < n_tables; i++) {
         const uint64_t n = tables[i].rows * (uint64_t)tables[i].cols;

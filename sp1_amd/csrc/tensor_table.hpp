@@ -21,18 +21,18 @@ int make_tensor_table(const sp1hip_tensor_t* tensors, int n_tensors, TensorTable
 int expand_columns_async(const TensorTable& tab, uint32_t total_width, uint64_t height, const uint32_t** d_cols,
                          hipStream_t stream);
 
-// RAII stream-ordered scratch allocation.
+// RAII scratch from the stream-keyed arena (the block goes back to the free list when the launch
+// has been enqueued; the next user on the same stream is ordered behind it).
 struct AsyncScratch {
     void* p = nullptr;
     hipStream_t s = nullptr;
+    size_t n = 0;
     int alloc(size_t bytes, hipStream_t stream) {
         s = stream;
-        SP1HIP_HIP(hipMallocAsync(&p, bytes ? bytes : 1, stream));
-        return SP1HIP_SUCCESS;
+        n = bytes;
+        return arena_alloc(&p, bytes, stream);
     }
-    ~AsyncScratch() {
-        if (p) (void)hipFreeAsync(p, s);
-    }
+    ~AsyncScratch() { arena_free(p, n, s); }
 };
 
 }  // namespace sp1hip

@@ -259,12 +259,13 @@ struct VGeq {
 struct DevBuf {
     void* p = nullptr;
     hipStream_t s = nullptr;
+    size_t n = 0;
     int alloc(size_t bytes, hipStream_t stream) {
         s = stream;
-        SP1HIP_HIP(hipMallocAsync(&p, bytes ? bytes : 1, stream));
-        return SP1HIP_SUCCESS;
+        n = bytes;
+        return arena_alloc(&p, bytes, stream);
     }
-    void release() { if (p) { (void)hipFreeAsync(p, s); p = nullptr; } }
+    void release() { arena_free(p, n, s); p = nullptr; }
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
