@@ -33,19 +33,21 @@ namespace sp1hip {
 enum ZcOp : uint32_t { ZC_LOAD_MAIN = 0, ZC_LOAD_PREP = 1, ZC_CONST = 2, ZC_PUBLIC = 3, ZC_ADD = 4, ZC_SUB = 5, ZC_MUL = 6,
                        ZC_NEG = 7, ZC_ASSERT_ZERO = 8 };
 
-struct ZcArgs {
-    const uint32_t* prog;        // [n_instr][4]: op, dst, a, b (register-allocated)
-    uint32_t n_instr;
-    const uint32_t* main;        // column-major; FIRST: [rows x main_w] base, else [rows x 4 main_w]
+// One chip of the current round (device array; every field is wave-uniform in the kernels).
+struct ZcDesc {
+    const uint32_t* prog;        // [n_instr][4]: op | flags, dst, a, b (register-allocated)
+    const uint32_t* main;        // column-major; round 0: [rows x main_w] base words, later [rows x 4 main_w]
     const uint32_t* prep;
-    uint32_t main_w, prep_w;
-    uint32_t rows;               // real rows in the current tables
-    const uint32_t* eq;          // ext vector (SoA) of length eq_len
-    uint32_t eq_len;
     const uint32_t* alpha_pows;  // [num_constraints][4]
     const uint32_t* gkr_pows;    // [main_w + prep_w][4]
-    const uint32_t* publics;     // base words
-    uint32_t* partial;           // [gridDim.x][12]
+    uint32_t n_instr, main_w, prep_w, rows;
+    uint32_t block_start, n_blocks, th, pad;
+};
+
+struct ZcFixDesc {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t rows, width, block_start, n_blocks;
 };
 
 // ---- K = base word (round 0) or extension element (later rounds)
@@ -97,24 +99,78 @@ __device__ __forceinline__ typename KT<FIRST>::T leaf(const uint32_t* tbl, uint3
     return K::add(K::add(s2, s2), r0);
 }
 
+// ---- register files ------------------------------------------------------------------------------
+// The program is wave-uniform, so register numbers are SGPR values. For up to 32 registers the file is
+// kept in VGPRs as 16/32-wide vectors indexed with a uniform index (GPR-index mode, s_set_gpr_idx_on):
+// no memory traffic per interpreted instruction. Larger programs fall back to per-lane scratch.
+typedef uint32_t v32u __attribute__((ext_vector_type(32)));
+typedef uint32_t v16u __attribute__((ext_vector_type(16)));
+
+template <bool FIRST, int MAXR> struct RegFile {
+    typename KT<FIRST>::T r[MAXR];
+    __device__ __forceinline__ typename KT<FIRST>::T get(uint32_t i) const { return r[i]; }
+    __device__ __forceinline__ void set(uint32_t i, const typename KT<FIRST>::T& v) { r[i] = v; }
+};
+#define SP1HIP_VREGFILE(N, V)                                                                                       \
+    template <> struct RegFile<true, N> {                                                                            \
+        V r;                                                                                                         \
+        __device__ __forceinline__ uint32_t get(uint32_t i) const { return r[i]; }                                  \
+        __device__ __forceinline__ void set(uint32_t i, uint32_t v) { r[i] = v; }                                   \
+    };                                                                                                               \
+    template <> struct RegFile<false, N> {                                                                           \
+        V c0, c1, c2, c3;                                                                                            \
+        __device__ __forceinline__ kb::Ext get(uint32_t i) const { return kb::Ext{{c0[i], c1[i], c2[i], c3[i]}}; }   \
+        __device__ __forceinline__ void set(uint32_t i, const kb::Ext& v) {                                          \
+            c0[i] = v.c[0]; c1[i] = v.c[1]; c2[i] = v.c[2]; c3[i] = v.c[3];                                          \
+        }                                                                                                            \
+    };
+SP1HIP_VREGFILE(16, v16u)
+SP1HIP_VREGFILE(32, v32u)
+
+constexpr uint32_t ZC_GKR_FLAG = 0x100u;   // set by the host on the first load of each column
+constexpr uint32_t ZC_TOUCH = 9;           // pseudo-op: column never loaded by the constraints (GKR term only)
+constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB); longer programs read global memory
+
+// One pass of the program at node t. With `gkr`, the first load of every column also accumulates
+// gkr_pow[column] * value into *g (main columns first, then preprocessed): the batching term costs no
+// extra loads. `prog` points to LDS (or global memory for very long programs).
 template <bool FIRST, int MAXR>
-__device__ __forceinline__ kb::Ext run_program(const ZcArgs& a, uint32_t i, int t) {
+__device__ __forceinline__ kb::Ext run_program(const uint4* prog, const ZcDesc& d, const uint32_t* __restrict__ publics,
+                                               uint32_t i, int t, const bool gkr, kb::Ext* g) {
     using K = KT<FIRST>;
-    typename K::T reg[MAXR];
+    RegFile<FIRST, MAXR> reg;
     kb::Ext acc = kb::ext_zero();
     uint32_t ci = 0;
-    for (uint32_t k = 0; k < a.n_instr; k++) {
-        const uint32_t op = a.prog[4 * k], dst = a.prog[4 * k + 1], x = a.prog[4 * k + 2], y = a.prog[4 * k + 3];
-        switch (op) {
-            case ZC_LOAD_MAIN: reg[dst] = leaf<FIRST>(a.main, x, a.rows, i, t); break;
-            case ZC_LOAD_PREP: reg[dst] = leaf<FIRST>(a.prep, x, a.rows, i, t); break;
-            case ZC_CONST: reg[dst] = K::from_f(x); break;               // host pre-converts to Montgomery
-            case ZC_PUBLIC: reg[dst] = K::from_f(a.publics[x]); break;
-            case ZC_ADD: reg[dst] = K::add(reg[x], reg[y]); break;
-            case ZC_SUB: reg[dst] = K::sub(reg[x], reg[y]); break;
-            case ZC_MUL: reg[dst] = K::mul(reg[x], reg[y]); break;
-            case ZC_NEG: reg[dst] = K::sub(K::zero(), reg[x]); break;
-            default: acc = kb::ext_add(acc, K::scale(load_ext_aos(a.alpha_pows, ci++), reg[x])); break;  // ASSERT_ZERO
+    for (uint32_t k = 0; k < d.n_instr; k++) {
+        const uint4 w = prog[k];     // wave-uniform: decode once, keep the fields in SGPRs
+        const uint32_t opw = __builtin_amdgcn_readfirstlane(w.x), dst = __builtin_amdgcn_readfirstlane(w.y);
+        const uint32_t x = __builtin_amdgcn_readfirstlane(w.z), y = __builtin_amdgcn_readfirstlane(w.w);
+        switch (opw & 0xffu) {
+            case ZC_LOAD_MAIN: {
+                typename K::T v = leaf<FIRST>(d.main, x, d.rows, i, t);
+                if (gkr && (opw & ZC_GKR_FLAG)) *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, x), v));
+                reg.set(dst, v);
+                break;
+            }
+            case ZC_LOAD_PREP: {
+                typename K::T v = leaf<FIRST>(d.prep, x, d.rows, i, t);
+                if (gkr && (opw & ZC_GKR_FLAG)) *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, d.main_w + x), v));
+                reg.set(dst, v);
+                break;
+            }
+            case ZC_TOUCH:
+                if (gkr) {
+                    typename K::T v = leaf<FIRST>(y ? d.prep : d.main, x, d.rows, i, t);
+                    *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, (y ? d.main_w : 0u) + x), v));
+                }
+                break;
+            case ZC_CONST: reg.set(dst, K::from_f(x)); break;               // host pre-converts to Montgomery
+            case ZC_PUBLIC: reg.set(dst, K::from_f(publics[x])); break;
+            case ZC_ADD: reg.set(dst, K::add(reg.get(x), reg.get(y))); break;
+            case ZC_SUB: reg.set(dst, K::sub(reg.get(x), reg.get(y))); break;
+            case ZC_MUL: reg.set(dst, K::mul(reg.get(x), reg.get(y))); break;
+            case ZC_NEG: reg.set(dst, K::sub(K::zero(), reg.get(x))); break;
+            default: acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, ci++), reg.get(x))); break;  // ASSERT_ZERO
         }
     }
     return acc;
@@ -126,80 +182,139 @@ __device__ __forceinline__ uint32_t zc_wave_sum(uint32_t v) {
     return v;
 }
 
+__device__ __forceinline__ ZcDesc zc_find_desc(const ZcDesc* __restrict__ descs, int n, uint32_t bid) {
+    int k = 0;
+    for (int i = 1; i < n; i++)
+        if (__builtin_amdgcn_readfirstlane(descs[i].block_start) <= bid) k = i;
+    ZcDesc d = descs[k];
+    return d;
+}
+
+// One launch per sumcheck round covers EVERY chip and the three interpolation nodes:
+//   blockIdx.x -> (chip, block of 256 row pairs), blockIdx.y = pass p (node t = 2p).
+// A pass-p workgroup writes two extension partial sums [A | B] (8 words):
+//   round 0 :  p=0: A = sum eq g(0), B = sum eq g(2)   (GKR batching term only; constraints vanish at 0)
+//              p=1: A = sum eq C(2)                     p=2: A = sum eq C(4)
+//   later   :  p=0: A = sum eq C(0), B = sum eq g(0)    p=1: A = sum eq C(2), B = sum eq g(2)    p=2: A = sum eq C(4)
+// g(4) = 2 g(2) - g(0) is linear, so the three nodes can run in different workgroups and the late, tiny
+// rounds (latency-bound: one wave interprets the whole program serially) run all chips and nodes at once.
 template <bool FIRST, int MAXR>
-__global__ __launch_bounds__(256) void zc_sum_kernel(ZcArgs a) {
+__global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict__ descs, int n_descs,
+                                                       const uint32_t* __restrict__ eq, uint32_t eq_len,
+                                                       const uint32_t* __restrict__ publics, uint32_t* __restrict__ partial) {
     using K = KT<FIRST>;
-    __shared__ uint32_t scratch[4 * 12];
-    const uint32_t terms = (a.rows + 1) / 2;
-    kb::Ext y0 = kb::ext_zero(), y2 = kb::ext_zero(), y4 = kb::ext_zero();
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < terms; i += gridDim.x * 256u) {
-        // GKR-opening batching term: sum_j gkr_pow[j] * value_j(t), main columns then preprocessed
-        kb::Ext g0 = kb::ext_zero(), g2 = kb::ext_zero();
-        for (uint32_t c = 0; c < a.main_w; c++) {
-            const kb::Ext pw = load_ext_aos(a.gkr_pows, c);
-            g0 = kb::ext_add(g0, K::scale(pw, leaf<FIRST>(a.main, c, a.rows, i, 0)));
-            g2 = kb::ext_add(g2, K::scale(pw, leaf<FIRST>(a.main, c, a.rows, i, 2)));
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* red = lds;                                   // [4][8] reduction scratch
+    uint4* lprog = reinterpret_cast<uint4*>(lds + 32);
+    const ZcDesc d = zc_find_desc(descs, n_descs, blockIdx.x);
+    const int pass = blockIdx.y;
+    const bool in_lds = d.n_instr <= ZC_LDS_PROG_MAX;
+    if (in_lds) {
+        const uint4* src = reinterpret_cast<const uint4*>(d.prog);
+        for (uint32_t k = threadIdx.x; k < d.n_instr; k += 256) lprog[k] = src[k];
+        __syncthreads();
+    }
+    const uint4* prog = in_lds ? lprog : reinterpret_cast<const uint4*>(d.prog);
+    const uint32_t terms = (d.rows + 1) / 2;
+    kb::Ext sa = kb::ext_zero(), sb = kb::ext_zero();
+    for (uint32_t i = (blockIdx.x - d.block_start) * 256u + threadIdx.x; i < terms; i += d.n_blocks * 256u) {
+        kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
+        if (FIRST && pass == 0) {
+            for (uint32_t c = 0; c < d.main_w; c++) {
+                const kb::Ext pw = load_ext_aos(d.gkr_pows, c);
+                va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 0)));
+                vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 2)));
+            }
+            for (uint32_t c = 0; c < d.prep_w; c++) {
+                const kb::Ext pw = load_ext_aos(d.gkr_pows, d.main_w + c);
+                va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 0)));
+                vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 2)));
+            }
+        } else {
+            va = run_program<FIRST, MAXR>(prog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
         }
-        for (uint32_t c = 0; c < a.prep_w; c++) {
-            const kb::Ext pw = load_ext_aos(a.gkr_pows, a.main_w + c);
-            g0 = kb::ext_add(g0, K::scale(pw, leaf<FIRST>(a.prep, c, a.rows, i, 0)));
-            g2 = kb::ext_add(g2, K::scale(pw, leaf<FIRST>(a.prep, c, a.rows, i, 2)));
-        }
-        const kb::Ext g4 = kb::ext_sub(kb::ext_add(g2, g2), g0);
-        kb::Ext a0 = g0;
-        if (!FIRST) a0 = kb::ext_add(a0, run_program<FIRST, MAXR>(a, i, 0));   // round 0: constraints vanish at t = 0
-        const kb::Ext a2 = kb::ext_add(run_program<FIRST, MAXR>(a, i, 2), g2);
-        const kb::Ext a4 = kb::ext_add(run_program<FIRST, MAXR>(a, i, 4), g4);
         kb::Ext e;
 #pragma unroll
-        for (int k = 0; k < 4; k++) e.c[k] = a.eq[(size_t)k * a.eq_len + i];
-        y0 = kb::ext_add(y0, kb::ext_mul(a0, e));
-        y2 = kb::ext_add(y2, kb::ext_mul(a2, e));
-        y4 = kb::ext_add(y4, kb::ext_mul(a4, e));
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        sa = kb::ext_add(sa, kb::ext_mul(va, e));
+        sb = kb::ext_add(sb, kb::ext_mul(vb, e));
     }
-    uint32_t v[12];
+    uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = y0.c[k]; v[4 + k] = y2.c[k]; v[8 + k] = y4.c[k]; }
+    for (int k = 0; k < 4; k++) { v[k] = sa.c[k]; v[4 + k] = sb.c[k]; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 12; k++) v[k] = zc_wave_sum(v[k]);
+    for (int k = 0; k < 8; k++) v[k] = zc_wave_sum(v[k]);
+    __syncthreads();
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) scratch[wave * 12 + k] = v[k];
+        for (int k = 0; k < 8; k++) red[wave * 8 + k] = v[k];
     }
     __syncthreads();
-    if (threadIdx.x < 12) {
+    if (threadIdx.x < 8) {
         const uint32_t k = threadIdx.x;
-        a.partial[blockIdx.x * 12 + k] = kb::add(kb::add(scratch[k], scratch[12 + k]), kb::add(scratch[24 + k], scratch[36 + k]));
+        partial[((size_t)blockIdx.x * 3 + pass) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
     }
 }
 
-// out[0..12) = summed partials; out[12..16) = eq[th] (zero if th is outside the table)
-__global__ void zc_sum_partials_kernel(const uint32_t* __restrict__ partial, uint32_t n_blocks,
-                                       const uint32_t* __restrict__ eq, uint32_t eq_len, uint32_t th,
-                                       uint32_t* __restrict__ out) {
-    const uint32_t k = threadIdx.x;
-    if (k >= 16) return;
-    if (k >= 12) { out[k] = th < eq_len ? eq[(size_t)(k - 12) * eq_len + th] : 0u; return; }
-    uint32_t acc = 0;
-    for (uint32_t b = 0; b < n_blocks; b++) acc = kb::add(acc, partial[b * 12 + k]);
-    out[k] = acc;
+// One workgroup per chip: sums its workgroups' partials and forms (y0, y2, y4, eq[th]) -> out[chip][16].
+template <bool FIRST>
+__global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcDesc* __restrict__ descs, const uint32_t* __restrict__ partial,
+                                                        const uint32_t* __restrict__ eq, uint32_t eq_len,
+                                                        uint32_t* __restrict__ out) {
+    __shared__ uint32_t acc[10][24];
+    const ZcDesc d = descs[blockIdx.x];
+    const uint32_t word = threadIdx.x % 24, grp = threadIdx.x / 24;   // 10 groups of 24 words (3 passes x 8)
+    if (grp < 10) {
+        uint32_t a = 0;
+        for (uint32_t b = grp; b < d.n_blocks; b += 10) a = kb::add(a, partial[((size_t)(d.block_start + b)) * 24 + word]);
+        acc[grp][word] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        uint32_t a = 0;
+        for (int g = 0; g < 10; g++) a = kb::add(a, acc[g][threadIdx.x]);
+        acc[0][threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t k = threadIdx.x;
+        // S[p][0..4) = A of pass p, S[p][4..8) = B of pass p
+        const uint32_t A0 = acc[0][k], B0 = acc[0][4 + k], A1 = acc[0][8 + k], B1 = acc[0][12 + k], A2 = acc[0][16 + k];
+        uint32_t y0, y2, y4;
+        if (FIRST) {       // g0 = A0, g2 = B0, C(2) = A1, C(4) = A2
+            y0 = A0;
+            y2 = kb::add(A1, B0);
+            y4 = kb::add(A2, kb::sub(kb::add(B0, B0), A0));
+        } else {           // C(0) = A0, g0 = B0, C(2) = A1, g2 = B1, C(4) = A2
+            y0 = kb::add(A0, B0);
+            y2 = kb::add(A1, B1);
+            y4 = kb::add(A2, kb::sub(kb::add(B1, B1), B0));
+        }
+        uint32_t* o = out + (size_t)blockIdx.x * 16;
+        o[k] = y0; o[4 + k] = y2; o[8 + k] = y4;
+        o[12 + k] = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u;
+    }
 }
 
-// out[i][c] = x + alpha (y - x), x = row 2i, y = row 2i + 1 (zero beyond the real rows); out is an ext table
+// out[i][c] = x + alpha (y - x), x = row 2i, y = row 2i + 1 (zero beyond the real rows); out is an ext table.
+// One launch per round for every table of every chip.
 template <bool FIRST>
-__global__ __launch_bounds__(256) void zc_fix_kernel(const uint32_t* __restrict__ in, uint32_t rows, uint32_t width,
-                                                     kb::Ext alpha, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void zc_fix_kernel(const ZcFixDesc* __restrict__ descs, int n_descs, kb::Ext alpha) {
     using K = KT<FIRST>;
-    const uint32_t out_rows = (rows + 1) / 2;
-    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= (size_t)out_rows * width) return;
+    int k = 0;
+    for (int i = 1; i < n_descs; i++)
+        if (__builtin_amdgcn_readfirstlane(descs[i].block_start) <= blockIdx.x) k = i;
+    const ZcFixDesc d = descs[k];
+    const uint32_t out_rows = (d.rows + 1) / 2;
+    const size_t t = (size_t)(blockIdx.x - d.block_start) * 256u + threadIdx.x;
+    if (t >= (size_t)out_rows * d.width) return;
     const uint32_t c = (uint32_t)(t / out_rows), i = (uint32_t)(t % out_rows);
-    typename K::T x = K::load(in, c, rows, 2 * i);
-    typename K::T y = (2 * i + 1 < rows) ? K::load(in, c, rows, 2 * i + 1) : K::zero();
+    typename K::T x = K::load(d.in, c, d.rows, 2 * i);
+    typename K::T y = (2 * i + 1 < d.rows) ? K::load(d.in, c, d.rows, 2 * i + 1) : K::zero();
     const kb::Ext r = kb::ext_add(K::scale(alpha, K::sub(y, x)), K::to_ext(x));
 #pragma unroll
-    for (int k = 0; k < 4; k++) out[((size_t)c * 4 + k) * out_rows + i] = r.c[k];
+    for (int q = 0; q < 4; q++) d.out[((size_t)c * 4 + q) * out_rows + i] = r.c[q];
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -278,7 +393,7 @@ struct ChipState {
     std::vector<uint32_t> prog;     // allocated [n][4]
     uint32_t n_regs = 1;
     std::vector<Ext> alpha_pows, gkr_pows;
-    DevBuf d_prog, d_alpha, d_gkr, d_partial, d_sums;
+    DevBuf d_prog, d_alpha, d_gkr;
     std::unique_ptr<DevBuf> main_buf, prep_buf;   // ext tables of later rounds
     const uint32_t* d_main = nullptr;
     const uint32_t* d_prep = nullptr;
@@ -332,6 +447,20 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
     return SP1HIP_SUCCESS;
 }
 
+// Marks the first load of every column (GKR flag) and appends a TOUCH pseudo-instruction for each column
+// the constraints never read, so that one pass over the program visits every column exactly once.
+static void add_gkr_visits(std::vector<uint32_t>* prog, uint32_t main_w, uint32_t prep_w) {
+    std::vector<bool> seen_m(main_w, false), seen_p(prep_w, false);
+    const size_t n = prog->size() / 4;
+    for (size_t k = 0; k < n; k++) {
+        uint32_t* o = prog->data() + 4 * k;
+        if (o[0] == ZC_LOAD_MAIN && !seen_m[o[2]]) { seen_m[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
+        if (o[0] == ZC_LOAD_PREP && !seen_p[o[2]]) { seen_p[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
+    }
+    for (uint32_t c = 0; c < main_w; c++) if (!seen_m[c]) { prog->insert(prog->end(), {ZC_TOUCH, 0u, c, 0u}); }
+    for (uint32_t c = 0; c < prep_w; c++) if (!seen_p[c]) { prog->insert(prog->end(), {ZC_TOUCH, 0u, c, 1u}); }
+}
+
 // host evaluation of the program on an all-zero row (padded_row_adjustment, shard.rs:L524-L536)
 static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     const uint32_t n = (uint32_t)(c.prog.size() / 4);
@@ -339,9 +468,10 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     Ext acc = kb::ext_zero();
     uint32_t ci = 0;
     for (uint32_t k = 0; k < n; k++) {
-        const uint32_t op = c.prog[4 * k], dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
+        const uint32_t op = c.prog[4 * k] & 0xffu, dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
         switch (op) {
             case ZC_LOAD_MAIN: case ZC_LOAD_PREP: reg[dst] = 0; break;
+            case ZC_TOUCH: break;
             case ZC_CONST: reg[dst] = x; break;
             case ZC_PUBLIC: reg[dst] = publics[x]; break;
             case ZC_ADD: reg[dst] = kb::add(reg[x], reg[y]); break;
@@ -355,12 +485,16 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
 }
 
 template <bool FIRST>
-static int launch_sum(const ZcArgs& a, uint32_t n_regs, uint32_t blocks, hipStream_t s) {
-    if (n_regs <= 16) hipLaunchKernelGGL((zc_sum_kernel<FIRST, 16>), dim3(blocks), dim3(256), 0, s, a);
-    else if (n_regs <= 64) hipLaunchKernelGGL((zc_sum_kernel<FIRST, 64>), dim3(blocks), dim3(256), 0, s, a);
-    else if (n_regs <= 256) hipLaunchKernelGGL((zc_sum_kernel<FIRST, 256>), dim3(blocks), dim3(256), 0, s, a);
-    else if (n_regs <= 1024) hipLaunchKernelGGL((zc_sum_kernel<FIRST, 1024>), dim3(blocks), dim3(256), 0, s, a);
-    else { set_error("constraint program needs %u live registers (max 1024)", n_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
+static int launch_round(uint32_t max_regs, const ZcDesc* d_descs, int n_descs, uint32_t total_blocks, uint32_t max_instr,
+                        const uint32_t* eq, uint32_t eq_len, const uint32_t* publics, uint32_t* partial, hipStream_t s) {
+    const uint32_t staged = max_instr <= ZC_LDS_PROG_MAX ? max_instr : 0;
+    const size_t lds = 32 * 4 + (size_t)staged * 16;
+    dim3 grid(total_blocks, 3);
+    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
+    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
+    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
+    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
+    else { set_error("constraint program needs %u live registers (max 1024)", max_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }
@@ -439,6 +573,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (op == ZC_PUBLIC) SP1HIP_REQUIRE((int)a < n_publics, "public value index out of range");
         }
         SP1HIP_REQUIRE(asserts == chips[i].num_constraints, "num_constraints does not match the program");
+        add_gkr_visits(&c->prog, chips[i].main_width, chips[i].prep_width);
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
         std::reverse(c->alpha_pows.begin(), c->alpha_pows.end());
@@ -459,8 +594,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         SP1HIP_TRY(c->d_prog.alloc(c->prog.size() * 4, s));
         SP1HIP_TRY(c->d_alpha.alloc(c->alpha_pows.size() * 16, s));
         SP1HIP_TRY(c->d_gkr.alloc(c->gkr_pows.size() * 16, s));
-        SP1HIP_TRY(c->d_partial.alloc(1024 * 12 * 4, s));
-        SP1HIP_TRY(c->d_sums.alloc(16 * 4, s));
         SP1HIP_HIP(hipMemcpyAsync(c->d_prog.p, c->prog.data(), c->prog.size() * 4, hipMemcpyHostToDevice, s));
         if (!c->alpha_pows.empty())
             SP1HIP_HIP(hipMemcpyAsync(c->d_alpha.p, c->alpha_pows.data(), c->alpha_pows.size() * 16, hipMemcpyHostToDevice, s));
@@ -479,30 +612,55 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> point;   // [alpha_last, ..., alpha_first]
     std::vector<Ext> round_claims = claims;
     std::vector<std::array<uint32_t, 16>> sums(n_chips);
+    std::vector<uint32_t> h_sums((size_t)n_chips * 16);
+    DevBuf d_descs, d_fix_descs, d_partial, d_sums;
+    size_t partial_cap = 0;
+    SP1HIP_TRY(d_descs.alloc((size_t)n_chips * sizeof(ZcDesc), s));
+    SP1HIP_TRY(d_fix_descs.alloc((size_t)n_chips * 2 * sizeof(ZcFixDesc), s));
+    SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 64, s));
     for (int r = 0; r < L; r++) {
         const int nv = L - r;                       // variables left
         const Ext last = zeta[nv - 1];
         // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
         SP1HIP_TRY(sp1hip_partial_lagrange(reinterpret_cast<const sp1hip_ext_t*>(zeta.data()), nv - 1, d_eq.u32(), stream));
+        // descriptors of the chips that still have real rows
+        std::vector<ZcDesc> descs;
+        std::vector<int> desc_chip;
+        uint32_t total_blocks = 0, max_regs = 1, max_instr = 1;
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
             if (c.rows == 0) continue;
             const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
             uint32_t blocks = (terms + 255) / 256;
             if (blocks > 1024) blocks = 1024;
-            ZcArgs a{};
-            a.prog = c.d_prog.u32(); a.n_instr = (uint32_t)(c.prog.size() / 4);
-            a.main = c.d_main; a.prep = c.d_prep; a.main_w = c.in->main_width; a.prep_w = c.in->prep_width;
-            a.rows = (uint32_t)c.rows; a.eq = d_eq.u32(); a.eq_len = 1u << (nv - 1);
-            a.alpha_pows = c.d_alpha.u32(); a.gkr_pows = c.d_gkr.u32(); a.publics = d_publics.u32(); a.partial = c.d_partial.u32();
-            if (r == 0) SP1HIP_TRY(launch_sum<true>(a, c.n_regs, blocks, s));
-            else SP1HIP_TRY(launch_sum<false>(a, c.n_regs, blocks, s));
-            hipLaunchKernelGGL(zc_sum_partials_kernel, dim3(1), dim3(64), 0, s, c.d_partial.u32(), blocks, d_eq.u32(),
-                               1u << (nv - 1), terms - 1, c.d_sums.u32());
+            ZcDesc d{};
+            d.prog = c.d_prog.u32(); d.n_instr = (uint32_t)(c.prog.size() / 4);
+            d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+            d.rows = (uint32_t)c.rows; d.alpha_pows = c.d_alpha.u32(); d.gkr_pows = c.d_gkr.u32();
+            d.block_start = total_blocks; d.n_blocks = blocks; d.th = terms - 1;
+            total_blocks += blocks;
+            max_regs = std::max(max_regs, c.n_regs);
+            max_instr = std::max(max_instr, d.n_instr);
+            descs.push_back(d);
+            desc_chip.push_back(i);
+        }
+        const int n_descs = (int)descs.size();
+        if (n_descs) {
+            SP1HIP_HIP(hipMemcpyAsync(d_descs.p, descs.data(), descs.size() * sizeof(ZcDesc), hipMemcpyHostToDevice, s));
+            if (total_blocks * 24 * 4 > partial_cap) {
+                d_partial.release();
+                partial_cap = (size_t)total_blocks * 24 * 4;
+                SP1HIP_TRY(d_partial.alloc(partial_cap, s));
+            }
+            if (r == 0) SP1HIP_TRY(launch_round<true>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+            else SP1HIP_TRY(launch_round<false>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_descs), dim3(256), 0, s, (const ZcDesc*)d_descs.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
+            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_descs), dim3(256), 0, s, (const ZcDesc*)d_descs.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             SP1HIP_LAUNCH_CHECK();
-            SP1HIP_HIP(hipMemcpyAsync(sums[i].data(), c.d_sums.p, 64, hipMemcpyDeviceToHost, s));
+            SP1HIP_HIP(hipMemcpyAsync(h_sums.data(), d_sums.p, (size_t)n_descs * 64, hipMemcpyDeviceToHost, s));
         }
         SP1HIP_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < n_descs; k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + (size_t)k * 16, 64);
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
         std::vector<UniPoly> uni(n_chips);
         for (int i = 0; i < n_chips; i++) {
@@ -536,29 +694,47 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             round_claims[i] = uni_eval(uni[i], a_r);
             st[i]->uni = uni[i];
         }
-        // ---- fix the last variable of every table (fix_last_variable.rs)
+        // ---- fix the last variable of every table (fix_last_variable.rs): one launch for all chips
+        std::vector<ZcFixDesc> fds;
+        std::vector<std::unique_ptr<DevBuf>> fresh;
+        std::vector<std::pair<int, bool>> owner;   // (chip, is_main)
+        uint32_t fix_blocks = 0;
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
             c.vgeq = c.vgeq.fix(a_r);
             if (c.rows == 0) continue;
             const uint64_t out_rows = (c.rows + 1) / 2;
-            auto fix_table = [&](const uint32_t* in, uint32_t width, std::unique_ptr<DevBuf>& holder, const uint32_t** cur) -> int {
-                if (width == 0) return SP1HIP_SUCCESS;
+            for (int which = 0; which < 2; which++) {
+                const uint32_t width = which == 0 ? c.in->main_width : c.in->prep_width;
+                if (width == 0) continue;
                 std::unique_ptr<DevBuf> nb(new DevBuf());
                 SP1HIP_TRY(nb->alloc((size_t)out_rows * width * 16, s));
-                const size_t total = (size_t)out_rows * width;
-                if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, (uint32_t)c.rows, width, a_r, nb->u32());
-                else hipLaunchKernelGGL(zc_fix_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, (uint32_t)c.rows, width, a_r, nb->u32());
-                SP1HIP_LAUNCH_CHECK();
-                holder = std::move(nb);    // the previous round's table is released stream-ordered
-                *cur = holder->u32();
-                return SP1HIP_SUCCESS;
-            };
-            SP1HIP_TRY(fix_table(c.d_main, c.in->main_width, c.main_buf, &c.d_main));
-            SP1HIP_TRY(fix_table(c.d_prep, c.in->prep_width, c.prep_buf, &c.d_prep));
+                ZcFixDesc fd{};
+                fd.in = which == 0 ? c.d_main : c.d_prep;
+                fd.out = nb->u32();
+                fd.rows = (uint32_t)c.rows; fd.width = width; fd.block_start = fix_blocks;
+                fd.n_blocks = (uint32_t)(((size_t)out_rows * width + 255) / 256);
+                fix_blocks += fd.n_blocks;
+                fds.push_back(fd);
+                fresh.push_back(std::move(nb));
+                owner.push_back({i, which == 0});
+            }
             c.eq_adj = c.eq_adj * (a_r * last + (kb::ext_one() - a_r) * (kb::ext_one() - last));
-            c.rows = out_rows;
         }
+        if (!fds.empty()) {
+            SP1HIP_HIP(hipMemcpyAsync(d_fix_descs.p, fds.data(), fds.size() * sizeof(ZcFixDesc), hipMemcpyHostToDevice, s));
+            if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
+            else hipLaunchKernelGGL(zc_fix_kernel<false>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
+            SP1HIP_LAUNCH_CHECK();
+            SP1HIP_HIP(hipStreamSynchronize(s));     // `fds` is a host staging buffer
+            for (size_t k = 0; k < fds.size(); k++) {
+                ChipState& c = *st[owner[k].first];
+                if (owner[k].second) { c.main_buf = std::move(fresh[k]); c.d_main = c.main_buf->u32(); }   // old table released
+                else { c.prep_buf = std::move(fresh[k]); c.d_prep = c.prep_buf->u32(); }
+            }
+        }
+        for (int i = 0; i < n_chips; i++)
+            if (st[i]->rows) st[i]->rows = (st[i]->rows + 1) / 2;
     }
     // ---- proof: PartialSumcheckProof + per-chip component evaluations (prep then main)
     ByteOut w;
