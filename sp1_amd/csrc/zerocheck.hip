@@ -41,6 +41,13 @@ struct ZcDesc {
     const uint32_t* alpha_pows;  // [num_constraints][4]
     const uint32_t* gkr_pows;    // [main_w + prep_w][4]
     uint32_t n_instr, main_w, prep_w, rows;
+    uint32_t block_start, n_blocks;
+    uint32_t alpha_off;          // index of this chunk's first constraint in alpha_pows
+    uint32_t flags;              // bit 0: first chunk of its chip (owns the round-0 GKR-only pass)
+};
+
+// Blocks of one chip (all its chunks are contiguous) for the reduction, plus the eq entry it needs.
+struct ZcChipRange {
     uint32_t block_start, n_blocks, th, pad;
 };
 
@@ -129,6 +136,7 @@ SP1HIP_VREGFILE(32, v32u)
 
 constexpr uint32_t ZC_GKR_FLAG = 0x100u;   // set by the host on the first load of each column
 constexpr uint32_t ZC_TOUCH = 9;           // pseudo-op: column never loaded by the constraints (GKR term only)
+constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
 constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB); longer programs read global memory
 
 // One pass of the program at node t. With `gkr`, the first load of every column also accumulates
@@ -170,7 +178,7 @@ __device__ __forceinline__ kb::Ext run_program(const uint4* prog, const ZcDesc& 
             case ZC_SUB: reg.set(dst, K::sub(reg.get(x), reg.get(y))); break;
             case ZC_MUL: reg.set(dst, K::mul(reg.get(x), reg.get(y))); break;
             case ZC_NEG: reg.set(dst, K::sub(K::zero(), reg.get(x))); break;
-            default: acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, ci++), reg.get(x))); break;  // ASSERT_ZERO
+            default: acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + ci++), reg.get(x))); break;  // ASSERT_ZERO
         }
     }
     return acc;
@@ -182,12 +190,14 @@ __device__ __forceinline__ uint32_t zc_wave_sum(uint32_t v) {
     return v;
 }
 
+// last descriptor whose block_start <= bid (binary search; everything stays wave-uniform)
 __device__ __forceinline__ ZcDesc zc_find_desc(const ZcDesc* __restrict__ descs, int n, uint32_t bid) {
-    int k = 0;
-    for (int i = 1; i < n; i++)
-        if (__builtin_amdgcn_readfirstlane(descs[i].block_start) <= bid) k = i;
-    ZcDesc d = descs[k];
-    return d;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (__builtin_amdgcn_readfirstlane(descs[mid].block_start) <= bid) lo = mid; else hi = mid - 1;
+    }
+    return descs[lo];
 }
 
 // One launch per sumcheck round covers EVERY chip and the three interpolation nodes:
@@ -220,11 +230,13 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
     for (uint32_t i = (blockIdx.x - d.block_start) * 256u + threadIdx.x; i < terms; i += d.n_blocks * 256u) {
         kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
         if (FIRST && pass == 0) {
+            if (d.flags & 1u)
             for (uint32_t c = 0; c < d.main_w; c++) {
                 const kb::Ext pw = load_ext_aos(d.gkr_pows, c);
                 va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 0)));
                 vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 2)));
             }
+            if (d.flags & 1u)
             for (uint32_t c = 0; c < d.prep_w; c++) {
                 const kb::Ext pw = load_ext_aos(d.gkr_pows, d.main_w + c);
                 va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 0)));
@@ -259,11 +271,11 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
 
 // One workgroup per chip: sums its workgroups' partials and forms (y0, y2, y4, eq[th]) -> out[chip][16].
 template <bool FIRST>
-__global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcDesc* __restrict__ descs, const uint32_t* __restrict__ partial,
+__global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __restrict__ ranges, const uint32_t* __restrict__ partial,
                                                         const uint32_t* __restrict__ eq, uint32_t eq_len,
                                                         uint32_t* __restrict__ out) {
     __shared__ uint32_t acc[10][24];
-    const ZcDesc d = descs[blockIdx.x];
+    const ZcChipRange d = ranges[blockIdx.x];
     const uint32_t word = threadIdx.x % 24, grp = threadIdx.x / 24;   // 10 groups of 24 words (3 passes x 8)
     if (grp < 10) {
         uint32_t a = 0;
@@ -388,11 +400,18 @@ struct DevBuf {
     uint32_t* u32() const { return (uint32_t*)p; }
 };
 
+struct Chunk {
+    std::vector<uint32_t> prog;   // allocated [n][4]
+    uint32_t n_regs = 1, alpha_off = 0;
+};
+
 struct ChipState {
     const sp1hip_zc_chip_t* in;
     std::vector<uint32_t> prog;     // allocated [n][4]
     uint32_t n_regs = 1;
     std::vector<Ext> alpha_pows, gkr_pows;
+    std::vector<Chunk> chunks;
+    std::vector<uint32_t> chunk_off;   // offset (in instructions) of each chunk inside d_prog
     DevBuf d_prog, d_alpha, d_gkr;
     std::unique_ptr<DevBuf> main_buf, prep_buf;   // ext tables of later rounds
     const uint32_t* d_main = nullptr;
@@ -444,6 +463,91 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
         if (op == ZC_CONST) o[2] = kb::to_monty(a % kb::P);
     }
     *n_regs = regs ? regs : 1;
+    return SP1HIP_SUCCESS;
+}
+
+// Splits the SSA program into self-contained chunks at assert boundaries (each chunk re-emits the
+// dependency cone of its asserts, at most ~`limit` instructions unless a single cone is larger). Chunks
+// are independent workgroups on the GPU: wide chips get parallelism across constraints, which is what
+// keeps the late, tiny sumcheck rounds from being one wave interpreting thousands of instructions
+// serially (cf. the reference's chunked bytecode, /root/reference/sp1-gpu/crates/air/src/ir/bytecode.rs:L27-L110).
+static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32_t prep_w, uint32_t limit,
+                        std::vector<Chunk>* out) {
+    std::vector<uint32_t> stamp(n, 0xffffffffu);
+    std::vector<uint32_t> members, asserts, stack;
+    uint32_t chunk_id = 0, assert_index = 0, first_assert = 0;
+    auto flush = [&]() -> int {
+        if (asserts.empty()) return SP1HIP_SUCCESS;
+        std::sort(members.begin(), members.end());
+        std::vector<uint32_t> renum(n, 0), sub;
+        // interleave: every member instruction in original order, asserts after their operand exists
+        std::vector<std::pair<uint32_t, bool>> order;   // (ssa index, is_assert)
+        for (uint32_t m : members) order.push_back({m, false});
+        for (uint32_t a : asserts) order.push_back({a, true});
+        std::sort(order.begin(), order.end());
+        uint32_t next = 0;
+        for (auto& o : order) {
+            const uint32_t k = o.first, op = ssa[3 * k];
+            uint32_t a = ssa[3 * k + 1], b = ssa[3 * k + 2];
+            if (op == ZC_ADD || op == ZC_SUB || op == ZC_MUL) { a = renum[a]; b = renum[b]; }
+            else if (op == ZC_NEG || op == ZC_ASSERT_ZERO) a = renum[a];
+            renum[k] = next++;
+            sub.insert(sub.end(), {op, a, b});
+        }
+        Chunk c;
+        c.alpha_off = first_assert;
+        SP1HIP_TRY(allocate_registers(sub.data(), (uint32_t)(sub.size() / 3), &c.prog, &c.n_regs));
+        out->push_back(std::move(c));
+        members.clear();
+        asserts.clear();
+        chunk_id++;
+        return SP1HIP_SUCCESS;
+    };
+    for (uint32_t k = 0; k < n; k++) {
+        if (ssa[3 * k] != ZC_ASSERT_ZERO) continue;
+        // new nodes this assert would add to the current chunk
+        std::vector<uint32_t> fresh;
+        stack.assign(1, ssa[3 * k + 1]);
+        while (!stack.empty()) {
+            const uint32_t v = stack.back();
+            stack.pop_back();
+            if (stamp[v] == chunk_id) continue;
+            stamp[v] = chunk_id;
+            fresh.push_back(v);
+            const uint32_t op = ssa[3 * v];
+            if (op == ZC_ADD || op == ZC_SUB || op == ZC_MUL) { stack.push_back(ssa[3 * v + 1]); stack.push_back(ssa[3 * v + 2]); }
+            else if (op == ZC_NEG) stack.push_back(ssa[3 * v + 1]);
+        }
+        if (!asserts.empty() && members.size() + fresh.size() + asserts.size() + 1 > limit) {
+            for (uint32_t v : fresh) stamp[v] = 0xffffffffu;     // undo, close the chunk, retry in a new one
+            SP1HIP_TRY(flush());
+            k--;
+            continue;
+        }
+        if (asserts.empty()) first_assert = assert_index;
+        members.insert(members.end(), fresh.begin(), fresh.end());
+        asserts.push_back(k);
+        assert_index++;
+    }
+    SP1HIP_TRY(flush());
+    // GKR visits: the first load of each column, in chunk order, carries the flag; columns no constraint
+    // reads get TOUCH pseudo-instructions in extra chunks
+    std::vector<bool> seen_m(main_w, false), seen_p(prep_w, false);
+    for (auto& c : *out)
+        for (size_t k = 0; k < c.prog.size() / 4; k++) {
+            uint32_t* o = c.prog.data() + 4 * k;
+            if (o[0] == ZC_LOAD_MAIN && !seen_m[o[2]]) { seen_m[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
+            if (o[0] == ZC_LOAD_PREP && !seen_p[o[2]]) { seen_p[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
+        }
+    Chunk touch;
+    auto push_touch = [&](uint32_t col, uint32_t is_prep) {
+        touch.prog.insert(touch.prog.end(), {ZC_TOUCH, 0u, col, is_prep});
+        if (touch.prog.size() / 4 >= limit) { out->push_back(touch); touch.prog.clear(); }
+    };
+    for (uint32_t c = 0; c < main_w; c++) if (!seen_m[c]) push_touch(c, 0);
+    for (uint32_t c = 0; c < prep_w; c++) if (!seen_p[c]) push_touch(c, 1);
+    if (!touch.prog.empty()) out->push_back(touch);
+    if (out->empty()) { Chunk e; e.prog = {ZC_TOUCH, 0u, 0u, 2u}; out->push_back(e); }   // no constraints, no columns
     return SP1HIP_SUCCESS;
 }
 
@@ -573,7 +677,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (op == ZC_PUBLIC) SP1HIP_REQUIRE((int)a < n_publics, "public value index out of range");
         }
         SP1HIP_REQUIRE(asserts == chips[i].num_constraints, "num_constraints does not match the program");
-        add_gkr_visits(&c->prog, chips[i].main_width, chips[i].prep_width);
+        SP1HIP_TRY(build_chunks(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT,
+                                &c->chunks));
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
         std::reverse(c->alpha_pows.begin(), c->alpha_pows.end());
@@ -591,10 +696,16 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         c->vgeq = VGeq{(uint32_t)chips[i].real_rows, kb::ext_one(), kb::ext_zero()};
         c->d_main = chips[i].d_main;
         c->d_prep = chips[i].d_prep;
-        SP1HIP_TRY(c->d_prog.alloc(c->prog.size() * 4, s));
+        std::vector<uint32_t> all_prog;
+        for (auto& ck : c->chunks) {
+            c->chunk_off.push_back((uint32_t)(all_prog.size() / 4));
+            all_prog.insert(all_prog.end(), ck.prog.begin(), ck.prog.end());
+        }
+        SP1HIP_TRY(c->d_prog.alloc(all_prog.size() * 4, s));
         SP1HIP_TRY(c->d_alpha.alloc(c->alpha_pows.size() * 16, s));
         SP1HIP_TRY(c->d_gkr.alloc(c->gkr_pows.size() * 16, s));
-        SP1HIP_HIP(hipMemcpyAsync(c->d_prog.p, c->prog.data(), c->prog.size() * 4, hipMemcpyHostToDevice, s));
+        SP1HIP_HIP(hipMemcpyAsync(c->d_prog.p, all_prog.data(), all_prog.size() * 4, hipMemcpyHostToDevice, s));
+        SP1HIP_HIP(hipStreamSynchronize(s));    // all_prog is a per-chip staging vector
         if (!c->alpha_pows.empty())
             SP1HIP_HIP(hipMemcpyAsync(c->d_alpha.p, c->alpha_pows.data(), c->alpha_pows.size() * 16, hipMemcpyHostToDevice, s));
         if (!c->gkr_pows.empty())
@@ -613,9 +724,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> round_claims = claims;
     std::vector<std::array<uint32_t, 16>> sums(n_chips);
     std::vector<uint32_t> h_sums((size_t)n_chips * 16);
-    DevBuf d_descs, d_fix_descs, d_partial, d_sums;
-    size_t partial_cap = 0;
-    SP1HIP_TRY(d_descs.alloc((size_t)n_chips * sizeof(ZcDesc), s));
+    DevBuf d_descs, d_ranges, d_fix_descs, d_partial, d_sums;
+    size_t partial_cap = 0, descs_cap = 0;
+    SP1HIP_TRY(d_ranges.alloc((size_t)n_chips * sizeof(ZcChipRange), s));
     SP1HIP_TRY(d_fix_descs.alloc((size_t)n_chips * 2 * sizeof(ZcFixDesc), s));
     SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 64, s));
     for (int r = 0; r < L; r++) {
@@ -623,8 +734,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         const Ext last = zeta[nv - 1];
         // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
         SP1HIP_TRY(sp1hip_partial_lagrange(reinterpret_cast<const sp1hip_ext_t*>(zeta.data()), nv - 1, d_eq.u32(), stream));
-        // descriptors of the chips that still have real rows
+        // descriptors: one per (chip with real rows, chunk); a chip's blocks are contiguous
         std::vector<ZcDesc> descs;
+        std::vector<ZcChipRange> ranges;
         std::vector<int> desc_chip;
         uint32_t total_blocks = 0, max_regs = 1, max_instr = 1;
         for (int i = 0; i < n_chips; i++) {
@@ -632,35 +744,48 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (c.rows == 0) continue;
             const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
             uint32_t blocks = (terms + 255) / 256;
-            if (blocks > 1024) blocks = 1024;
-            ZcDesc d{};
-            d.prog = c.d_prog.u32(); d.n_instr = (uint32_t)(c.prog.size() / 4);
-            d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
-            d.rows = (uint32_t)c.rows; d.alpha_pows = c.d_alpha.u32(); d.gkr_pows = c.d_gkr.u32();
-            d.block_start = total_blocks; d.n_blocks = blocks; d.th = terms - 1;
-            total_blocks += blocks;
-            max_regs = std::max(max_regs, c.n_regs);
-            max_instr = std::max(max_instr, d.n_instr);
-            descs.push_back(d);
+            if (blocks > 512) blocks = 512;
+            ZcChipRange rg{total_blocks, 0, terms - 1, 0};
+            for (size_t q = 0; q < c.chunks.size(); q++) {
+                ZcDesc d{};
+                d.prog = c.d_prog.u32() + (size_t)c.chunk_off[q] * 4;
+                d.n_instr = (uint32_t)(c.chunks[q].prog.size() / 4);
+                d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+                d.rows = (uint32_t)c.rows; d.alpha_pows = c.d_alpha.u32(); d.gkr_pows = c.d_gkr.u32();
+                d.block_start = total_blocks; d.n_blocks = blocks;
+                d.alpha_off = c.chunks[q].alpha_off; d.flags = q == 0 ? 1u : 0u;
+                total_blocks += blocks;
+                max_regs = std::max(max_regs, c.chunks[q].n_regs);
+                max_instr = std::max(max_instr, d.n_instr);
+                descs.push_back(d);
+            }
+            rg.n_blocks = total_blocks - rg.block_start;
+            ranges.push_back(rg);
             desc_chip.push_back(i);
         }
-        const int n_descs = (int)descs.size();
+        const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
         if (n_descs) {
+            if (descs.size() * sizeof(ZcDesc) > descs_cap) {
+                d_descs.release();
+                descs_cap = descs.size() * sizeof(ZcDesc);
+                SP1HIP_TRY(d_descs.alloc(descs_cap, s));
+            }
             SP1HIP_HIP(hipMemcpyAsync(d_descs.p, descs.data(), descs.size() * sizeof(ZcDesc), hipMemcpyHostToDevice, s));
-            if (total_blocks * 24 * 4 > partial_cap) {
+            SP1HIP_HIP(hipMemcpyAsync(d_ranges.p, ranges.data(), ranges.size() * sizeof(ZcChipRange), hipMemcpyHostToDevice, s));
+            if ((size_t)total_blocks * 24 * 4 > partial_cap) {
                 d_partial.release();
                 partial_cap = (size_t)total_blocks * 24 * 4;
                 SP1HIP_TRY(d_partial.alloc(partial_cap, s));
             }
             if (r == 0) SP1HIP_TRY(launch_round<true>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             else SP1HIP_TRY(launch_round<false>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
-            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_descs), dim3(256), 0, s, (const ZcDesc*)d_descs.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
-            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_descs), dim3(256), 0, s, (const ZcDesc*)d_descs.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
+            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, (const ZcChipRange*)d_ranges.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
+            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, (const ZcChipRange*)d_ranges.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             SP1HIP_LAUNCH_CHECK();
-            SP1HIP_HIP(hipMemcpyAsync(h_sums.data(), d_sums.p, (size_t)n_descs * 64, hipMemcpyDeviceToHost, s));
+            SP1HIP_HIP(hipMemcpyAsync(h_sums.data(), d_sums.p, (size_t)n_ranges * 64, hipMemcpyDeviceToHost, s));
         }
         SP1HIP_HIP(hipStreamSynchronize(s));
-        for (int k = 0; k < n_descs; k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + (size_t)k * 16, 64);
+        for (size_t k = 0; k < desc_chip.size(); k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + k * 16, 64);
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
         std::vector<UniPoly> uni(n_chips);
         for (int i = 0; i < n_chips; i++) {
