@@ -36,6 +36,8 @@ def _gpu_chips(api, chips):
     ({"Affine": 2}, 1),
     ({"Affine": 1000, "Mul": 4096, "Sbox": 2049, "Sbox2": 1}, 12),
     ({"Affine": 70000, "Mul": 1 << 17, "Sbox": 99999}, 17),          # multi-block sums, grid-stride
+    ({"Chain": 300, "Manyregs": 1000, "Mul": 77}, 10),               # chunk-limit overflow, scratch-register tier, TOUCH columns
+    ({"Chain": 1, "Manyregs": 2}, 3),
 ])
 def test_zerocheck_matches_oracle(api, heights, L):
     chips, zc, zeta, alpha, gkr, publics, o_ch = setup(heights, L, 40 + L)

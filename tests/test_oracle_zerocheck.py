@@ -39,6 +39,7 @@ def setup(heights, L, seed):
     ({"Affine": 16, "Mul": 11, "Sbox": 16}, 4),
     ({"Mul": 1}, 1),                                            # one variable
     ({"Affine": 2}, 1),
+    ({"Chain": 6, "Manyregs": 5, "Mul": 3}, 3),                 # big cones, > 32 live registers, untouched columns
 ])
 def test_zerocheck_roundtrip(heights, L):
     chips, zc, zeta, alpha, gkr, publics, ch = setup(heights, L, 5 + L)
