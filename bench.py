@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--cpu-sample-lg-rows", type=int, default=18)
     ap.add_argument("--cpu-baseline-child", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL; gloo lets "
+                         "several ranks share one GPU when testing the N > 1 path on a 1-GPU box)")
     args = ap.parse_args()
     if args.cpu_baseline_child is not None:
         return cpu_baseline_child(args.cpu_baseline_child)
@@ -87,9 +90,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     from sp1_amd import api
     L = api._L()
