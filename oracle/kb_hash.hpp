@@ -13,9 +13,9 @@
 //                                   semantics restated in /root/reference/sp1-gpu/crates/sys/include/challenger/challenger.cuh:L13-L118
 // The permutation/sponge/challenger code itself is in un-vendored Plonky3 (p3-poseidon2,
 // p3-symmetric, p3-challenger =0.4.3-succinct). Permutation, sponge and compressor are pinned by
-// tests/golden (real proof data) and the SURVEY App. A known answers; the challenger is pinned only
-// by the in-tree CUDA restatement + prover/verifier self-consistency ("parity unpinned" for
-// challenger sampling order beyond that).
+// tests/golden (real proof data) and the SURVEY App. A known answers; the challenger is pinned by
+// replaying the reference's real shard-proof transcript (tests/golden/make_transcript.py: grinding
+// witnesses, sumcheck points, fold betas and query indices all reproduce).
 #pragma once
 #include <vector>
 

@@ -167,3 +167,49 @@ def fold_query(e0, e1, beta, x0):
 KAT_PERM_ZERO = [145589356, 1876041682, 1734203622, 499355069, 673349476, 595701365, 270340205,
                  131707822, 1236787881, 1085405948, 2065733208, 1999012278, 2062318124, 1616707536,
                  324813015, 749520722]
+
+
+class Challenger:
+    """DuplexChallenger<KoalaBear, Poseidon2, 16, 8> on canonical ints (pure Python, small cases only).
+    Type: /root/reference/slop/crates/challenger/src/lib.rs:L25-L87; semantics as restated in
+    /root/reference/sp1-gpu/crates/sys/include/challenger/challenger.cuh:L13-L118 (the p3-challenger
+    source is an un-vendored dependency). Pinned by tests/golden/make_transcript.py: replaying the real
+    shard proof's Fiat-Shamir transcript reproduces its sumcheck points, fold betas, grinding witnesses
+    and query indices."""
+
+    def __init__(self):
+        self.state = [0] * 16
+        self.inp = []
+        self.out = []
+
+    def _duplex(self):
+        for i, v in enumerate(self.inp):
+            self.state[i] = v
+        self.inp = []
+        self.state = permute(self.state)
+        self.out = list(self.state[:8])
+
+    def observe(self, x):
+        self.out = []
+        self.inp.append(int(x) % P)
+        if len(self.inp) == 8:
+            self._duplex()
+
+    def observe_many(self, xs):
+        for x in xs:
+            self.observe(x)
+
+    def sample(self):
+        if self.inp or not self.out:
+            self._duplex()
+        return self.out.pop()
+
+    def sample_ext(self):
+        return [self.sample() for _ in range(4)]
+
+    def sample_bits(self, bits):
+        return self.sample() & ((1 << bits) - 1)
+
+    def check_witness(self, bits, w):
+        self.observe(w)
+        return self.sample_bits(bits) == 0

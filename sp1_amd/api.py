@@ -154,7 +154,7 @@ class DuplexChallenger:
         return out
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _L is not None:      # _L is None during interpreter shutdown
             _L().sp1hip_challenger_free(self.h)
             self.h = None
 

@@ -96,6 +96,17 @@ def test_host_transcript_matches_oracle(lib):
     lib.sp1hip_challenger_free(h)
 
 
+def test_library_challenger_replays_reference_transcript(lib):
+    """The product's host DuplexChallenger (behind sp1hip_challenger_*) reproduces the reference's real
+    shard-proof transcript: grinding witnesses accepted, sumcheck points / betas / query indices equal."""
+    import transcript_tape as tt
+    from sp1_amd import api
+    ch = api.DuplexChallenger()
+    n_ops, pinned = tt.replay(ch)
+    assert n_ops == len(tt.TAPE["ops"]) and pinned >= 500
+    assert np.array_equal(orc.from_monty(ch.state()[:16]), tt.TAPE["final_state"])
+
+
 def test_product_does_not_reference_the_oracle():
     """The product path may never import, link or call anything under oracle/."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "sp1_amd")):

@@ -216,6 +216,21 @@ def test_challenger_matches_oracle(api):
         a.observe(np.array([P], np.uint32))              # non-reduced word
 
 
+def test_gpu_grind_at_the_reference_pow_point(api):
+    """Replay the reference's real transcript up to its 16-bit query-phase grind, then grind on the GPU:
+    the kernel's smallest witness is accepted, is <= the reference's (any-valid) witness, and is the
+    oracle's; the reference's own witness is accepted from the same state."""
+    import transcript_tape as tt
+    k = tt.pow_op_index(16)
+    g, o = api.DuplexChallenger(), orc.Challenger()
+    assert tt.replay(g, stop_before_op=k)[0] == k and tt.replay(o, stop_before_op=k)[0] == k
+    ref_w = int(tt.TAPE["data"][tt.TAPE["ops"][k][2]])
+    assert g.clone().check_witness(16, int(orc.to_monty(np.array([ref_w], np.uint32))[0]))
+    w = g.grind(16)
+    assert w == o.grind(16) and np.array_equal(g.state(), o.state())
+    assert int(orc.from_monty(np.array([w], np.uint32))[0]) <= ref_w
+
+
 def _prove_both(api, lg_n, widths_per_round, lb, nq, pow_bits, seed):
     mles = [[orc.random_felts((1 << lg_n, w), seed + 10 * r + i) for i, w in enumerate(ws)]
             for r, ws in enumerate(widths_per_round)]

@@ -135,3 +135,73 @@ def test_golden_final_poly_consistency():
     assert got == GOLD["final_poly"].tolist()
     got_c = C(orc.ext_mul(M(beta), M(last[1])))
     assert [(int(a) + int(b)) % kb_py.P for a, b in zip(got_c, last[0])] == GOLD["final_poly"].tolist()
+
+
+def test_challenger_replays_reference_transcript():
+    """The C++ oracle's DuplexChallenger re-enacts the complete Fiat-Shamir transcript of the reference's
+    real shard proof (vk, public values, LogUp-GKR, zerocheck, jagged sumchecks, BaseFold): all three
+    grinding witnesses are accepted, every sumcheck point, fold beta and query index comes out as stored
+    in / recovered from the proof (tests/golden/make_transcript.py lists the checks)."""
+    import transcript_tape as tt
+    ch = orc.Challenger()
+    n_ops, pinned = tt.replay(ch)
+    assert n_ops == len(tt.TAPE["ops"]) and pinned >= 500
+    assert np.array_equal(C(ch.state()[:16]), tt.TAPE["final_state"])
+    # a transcript that differs in one early word must not reproduce the 16-bit witness + query indices
+    bad = orc.Challenger()
+    bad.observe(M([1]))
+    with pytest.raises(AssertionError):
+        tt.replay(bad)
+
+
+def test_python_challenger_matches_cpp_oracle():
+    a, b = kb_py.Challenger(), orc.Challenger()
+    rng = np.random.default_rng(3)
+    for step in range(40):
+        xs = rng.integers(0, kb_py.P, int(rng.integers(0, 13)), dtype=np.uint32)
+        a.observe_many(int(x) for x in xs)
+        b.observe(M(xs))
+        for _ in range(int(rng.integers(0, 11))):
+            assert a.sample() == int(C(np.array([b.sample()], np.uint32))[0])
+        assert a.sample_bits(9) == b.sample_bits(9)
+
+
+def _reference_basefold_inputs():
+    import transcript_tape as tt
+    k = tt.pow_op_index(5)                         # the batch-grinding check opens verify_mle_evaluations
+    ch = orc.Challenger()
+    assert tt.replay(ch, stop_before_op=k)[0] == k
+    blob = tt.TAPE["basefold_proof_q12"].tobytes()
+    commits = [M(c) for c in GOLD["mt_commits"]]
+    claims = [M(GOLD["batch_evals0"]), M(GOLD["batch_evals1"])]
+    return ch, blob, commits, M(tt.TAPE["stack_point"]), claims
+
+
+def test_oracle_verifier_accepts_the_reference_basefold_proof():
+    """End to end: the oracle's restatement of BasefoldVerifier::verify_mle_evaluations
+    (/root/reference/slop/crates/basefold/src/verifier.rs:L122-L411) parses the reference's own
+    bincode(BasefoldProof) bytes (first 12 queries) and accepts them from the transcript state the real
+    verifier has at that point — batching coefficients, sumcheck messages vs the claims, betas, PoW,
+    query indices, Merkle openings, fold chain, final polynomial. Tampering is rejected."""
+    ch, blob, commits, point, claims = _reference_basefold_inputs()
+    assert orc.basefold_verify(commits, point, claims, blob, ch.clone(), 2, 12, 16) == 0
+    # stacked PCS claim (/root/reference/slop/crates/stacked/src/verifier.rs:L77-L84): the batch
+    # evaluations interpolated at the batch point give JaggedPcsProof.expected_eval
+    import transcript_tape as tt
+    flat = np.concatenate(claims)
+    n = 1 << (len(flat) - 1).bit_length()
+    padded = np.concatenate([flat, np.zeros((n - len(flat), 4), np.uint32)])
+    jp = M(GOLD["jagged_sumcheck_point"])
+    batch_point = jp[:len(jp) - len(point)]
+    eq = C(orc.partial_lagrange(batch_point))
+    acc = [0, 0, 0, 0]
+    for e, v in zip(eq, C(padded)):
+        acc = kb_py.ext_add(acc, kb_py.ext_mul([int(x) for x in e], [int(x) for x in v]))
+    assert acc == [int(x) for x in tt.TAPE["expected_eval"]]
+    # negatives
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 1
+    assert orc.basefold_verify(commits, point, claims, bytes(bad), ch.clone(), 2, 12, 16) != 0
+    claims[1] = claims[1].copy()
+    claims[1][3, 0] = (int(claims[1][3, 0]) + 1) % kb_py.P
+    assert orc.basefold_verify(commits, point, claims, blob, ch.clone(), 2, 12, 16) != 0
