@@ -21,6 +21,7 @@ constexpr int WIDTH = 16, RATE = 8, DIGEST = 8;
 struct RoundConstants {
     uint32_t ext[8][16];   // Montgomery form
     uint32_t internal[20];
+    int32_t ext_c[8][16];  // ext[][] as centred representatives in [-(p-1)/2, (p-1)/2]
 };
 
 // canonical table generated from the reference (oracle/gen_constants.py)
@@ -36,6 +37,9 @@ inline RoundConstants make_round_constants() {
             rc.ext[4 + r][i] = kb::to_monty(RC_CANONICAL[24 + r][i]);
         }
     for (int r = 0; r < 20; r++) rc.internal[r] = kb::to_monty(RC_CANONICAL[4 + r][0]);
+    for (int r = 0; r < 8; r++)
+        for (int i = 0; i < 16; i++)
+            rc.ext_c[r][i] = rc.ext[r][i] > (kb::P - 1) / 2 ? (int32_t)(rc.ext[r][i] - kb::P) : (int32_t)rc.ext[r][i];
     return rc;
 }
 
@@ -95,8 +99,105 @@ KB_HD uint32_t sbox(uint32_t s, uint32_t rc) {
     return kb::monty_reduce((uint64_t)x2 * x);
 }
 
+// ---- external rounds: exact fp64 linear layer + signed, correction-free S-box --------------------
+// gfx950 issues v_add_f64 / v_mul_f64 / v_fma_f64 / v_rndne_f64 / v_cvt_* at the rate of any other
+// VOP3 integer op (profiles/r01_ubench_f64.txt), and a double holds integers up to 2^53 exactly. So
+// the external linear layer is done on doubles WITHOUT any modular reduction: 72 v_add_f64 instead of
+// 72 modular adds (3 VALU each). Inputs are integers |x| < p, every output is a combination with
+// coefficient sum <= 35, i.e. |out| < 2^37: exact.
+// The S-box takes such an unreduced integer v (a Montgomery word up to a multiple of p):
+//   r = v - rndne(v / p) p           (v_mul_f64, v_rndne_f64, v_fma_f64; |r| <= (p-1)/2: the quotient
+//                                     estimate is off by < 2^-46 and p is odd, so the rounding is exact)
+//   y = int(r) + rc_centred          (|y| <= p - 1, fits int32)
+//   s = (y*y + q p) >> 32            q = int32(lo32(y*y) * -p^-1): SIGNED quotient digit, so that
+//   o = (s*y + q' p) >> 32           |s|, |o| < p/2 + p^2/2^32 < p  (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32)
+// and hands back double(o): a signed representative of (v + rc)^3 R^-2, no conditional correction
+// anywhere. Per lane 12 VALU instructions, per external round 16*12 + 72 = 264 against 400 for the
+// all-integer form; the results are the same field elements (the GPU tests compare every digest with
+// the oracle bit for bit).
+constexpr double P_F64 = 2130706433.0;
+constexpr double INV_P_F64 = 1.0 / 2130706433.0;
+
+KB_HD void m4_f64(double& x0, double& x1, double& x2, double& x3) {
+    double t01 = x0 + x1, t23 = x2 + x3;
+    double t0123 = t01 + t23;
+    double t01123 = t0123 + x1, t01233 = t0123 + x3;
+    double n3 = t01233 + (x0 + x0);
+    double n1 = t01123 + (x2 + x2);
+    double n0 = t01123 + t01;
+    double n2 = t01233 + t23;
+    x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+}
+
+KB_HD void external_linear_f64(double (&d)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) m4_f64(d[j], d[j + 1], d[j + 2], d[j + 3]);
+    double sums[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) sums[k] = (d[k] + d[k + 4]) + (d[k + 8] + d[k + 12]);
+#pragma unroll
+    for (int j = 0; j < 16; j++) d[j] = d[j] + sums[j & 3];
+}
+
+// signed Montgomery reduction: (x + q p) / 2^32 with q in [-2^31, 2^31); |x| < 2^62 -> |result| < |x|/2^32 + p/2
+KB_HD int32_t monty_reduce_signed(int64_t x) {
+    const int32_t q = (int32_t)((uint32_t)x * kb::NMU);
+    return (int32_t)((x + (int64_t)q * (int32_t)kb::P) >> 32);
+}
+
+KB_HD double sbox_f64(double v, int32_t rc_centred) {
+    const double q = __builtin_rint(v * INV_P_F64);
+    const int32_t y = (int32_t)__builtin_fma(-q, P_F64, v) + rc_centred;
+    const int32_t y2 = monty_reduce_signed((int64_t)y * y);
+    return (double)monty_reduce_signed((int64_t)y2 * y);
+}
+
+// exact integer v, |v| < 2^37  ->  the word in [0, p] congruent to it (p itself only when p | v)
+KB_HD uint32_t reduce_f64(double v) {
+    const double q = __builtin_floor(v * INV_P_F64);
+    return (uint32_t)__builtin_fma(-q, P_F64, v);
+}
+
 template <class RC>
 KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
+    double d[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) d[i] = (double)s[i];
+    external_linear_f64(d);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_c[r][i]);
+        external_linear_f64(d);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = reduce_f64(d[i]);            // [0, p]: inside the lazy range
+    s[0] = kb::umin(s[0], s[0] - kb::P);                             // the S-box lane is kept canonical
+#pragma unroll 1
+    for (int r = 0; r < 20; r++) {
+        s[0] = sbox(s[0], rc.internal[r]);
+        internal_linear_lazy(s);
+    }
+    // lanes 1..15 are < p + 2^15 (any representative works for the exact layer), lane 0 canonical
+#pragma unroll
+    for (int i = 0; i < 16; i++) d[i] = (double)s[i];
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_c[r][i]);
+        external_linear_f64(d);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t w = reduce_f64(d[i]);
+        s[i] = kb::umin(w, w - kb::P);
+    }
+}
+
+// all-integer form of the same permutation (the previous production path; kept for the A/B
+// micro-benchmark and as an in-library cross-check of the fp64 formulation)
+template <class RC>
+KB_HD void permute_int(uint32_t (&s)[16], const RC& rc) {
     external_linear(s);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
