@@ -21,7 +21,8 @@ constexpr int WIDTH = 16, RATE = 8, DIGEST = 8;
 struct RoundConstants {
     uint32_t ext[8][16];   // Montgomery form
     uint32_t internal[20];
-    int32_t ext_c[8][16];  // ext[][] as centred representatives in [-(p-1)/2, (p-1)/2]
+    double ext_magic[8][16];   // MAGIC + (ext[][] as centred representative in [-(p-1)/2, (p-1)/2])
+    uint32_t internal_neg[20]; // internal[r] - p as a two's-complement word (in [-p, 0))
 };
 
 // canonical table generated from the reference (oracle/gen_constants.py)
@@ -38,8 +39,11 @@ inline RoundConstants make_round_constants() {
         }
     for (int r = 0; r < 20; r++) rc.internal[r] = kb::to_monty(RC_CANONICAL[4 + r][0]);
     for (int r = 0; r < 8; r++)
-        for (int i = 0; i < 16; i++)
-            rc.ext_c[r][i] = rc.ext[r][i] > (kb::P - 1) / 2 ? (int32_t)(rc.ext[r][i] - kb::P) : (int32_t)rc.ext[r][i];
+        for (int i = 0; i < 16; i++) {
+            const int32_t c = rc.ext[r][i] > (kb::P - 1) / 2 ? (int32_t)(rc.ext[r][i] - kb::P) : (int32_t)rc.ext[r][i];
+            rc.ext_magic[r][i] = 6755399441055744.0 + (double)c;
+        }
+    for (int r = 0; r < 20; r++) rc.internal_neg[r] = rc.internal[r] - kb::P;
     return rc;
 }
 
@@ -74,15 +78,54 @@ KB_HD uint32_t opaque_pow2(int k) {
     return m;
 }
 
-// Internal rounds keep lanes 1..15 LAZY: unsigned words in [0, p + 2^15) congruent to the true
-// value. new_i = (sum + 2^k s_i) * 2^-32 is one multiply-add (V = s_i * 2^k + sum < 2^48), one
-// v_mul_lo_u32 and one v_mad_u64_u32 (additive Montgomery form, result in [V/2^32, V/2^32 + p), i.e.
-// again < p + 2^15): 3 VALU instructions per lane per round, no correction. Lane 0 (the only lane
-// that feeds an S-box) is kept canonical: V_0 = sum + 2 (p - s_0) >= 0 is == sum - 2 s_0 (mod p).
-// The diagonal is [-2, 1, 2, 4, .., 2^13, 2^15] on Montgomery words and the division by 2^32 is the
-// reference's MONTY_INVERSE factor (/root/reference/sp1-gpu/crates/sys/include/poseidon2/poseidon2_kb31_16.cuh:L118-L140).
+// Internal rounds keep ALL lanes LAZY: unsigned words congruent to the true value, lanes 1..15 in
+// [0, p + 2^15), lane 0 in [0, p + 8). new_i = (sum + 2^k s_i) * 2^-32 is one multiply-add
+// (V = s_i * 2^k + sum < 2^48), one v_mul_lo_u32 and one v_mad_u64_u32 (additive Montgomery form,
+// result in [V/2^32, V/2^32 + p), i.e. again < p + 2^15): 3 VALU instructions per lane per round, no
+// correction. The diagonal is [-2, 1, 2, 4, .., 2^13, 2^15] on Montgomery words and the division by
+// 2^32 is the reference's MONTY_INVERSE factor
+// (/root/reference/sp1-gpu/crates/sys/include/poseidon2/poseidon2_kb31_16.cuh:L118-L140).
+// Lane 0 goes through the S-box in SIGNED form (see monty_reduce_signed below): y = s_0 + (rc - p)
+// is in [-p, p + 8), its cube comes back as o in (-p, p), and t = o + p in (0, 2p) is the lazy
+// unsigned word that enters the sum; V_0 = sum + 2 (2p - t) >= 0 is == sum - 2 t (mod p) and
+// V_0 < 2^35, so new_0 < p + 8. No conditional correction in the whole round.
+KB_HD int32_t monty_reduce_signed(int64_t x);
+
+// acc + a as ONE v_mad_u64_u32 (a * 1 + acc): a 64-bit add of a 32-bit word without building its
+// zero-extended register pair first
+KB_HD uint64_t acc_u32(uint32_t a, uint64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, 1, %2" : "=v"(r) : "v"(a), "v"(acc) : "vcc");
+    return r;
+#else
+    return acc + a;
+#endif
+}
+
+KB_HD void internal_round_lazy(uint32_t (&s)[16], uint32_t rc_minus_p) {
+    const int32_t y = (int32_t)(s[0] + rc_minus_p);
+    const int32_t y2 = monty_reduce_signed((int64_t)y * y);
+    const uint32_t t = (uint32_t)monty_reduce_signed((int64_t)y2 * y) + kb::P;
+    // pair sums of lanes 1..15 fit 32 bits (2 (p + 2^15) < 2^32; t < 2p must stay alone); the 64-bit
+    // accumulation is a chain of multiply-adds by one (no zero-extension moves)
+    uint64_t sum = acc_u32(s[15], acc_u32(t, 0));
+    sum = acc_u32(s[1] + s[2], sum);
+    sum = acc_u32(s[3] + s[4], sum);
+    sum = acc_u32(s[5] + s[6], sum);
+    sum = acc_u32(s[7] + s[8], sum);
+    sum = acc_u32(s[9] + s[10], sum);
+    sum = acc_u32(s[11] + s[12], sum);
+    sum = acc_u32(s[13] + s[14], sum);
+    const uint64_t v0 = (uint64_t)(2 * kb::P - t) * opaque_pow2(1) + sum;
+    constexpr int SH[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};
+#pragma unroll
+    for (int i = 1; i < 16; i++) s[i] = kb::monty_reduce_lazy((uint64_t)s[i] * opaque_pow2(SH[i - 1]) + sum);
+    s[0] = kb::monty_reduce_lazy(v0);
+}
+
+// all-integer, canonical-lane-0 form of the internal linear layer (used by permute_int)
 KB_HD void internal_linear_lazy(uint32_t (&s)[16]) {
-    // pair sums fit 32 bits: 2 (p + 2^15) < 2^32
     uint64_t sum = (uint64_t)(s[0] + s[1]) + (s[2] + s[3]) + (s[4] + s[5]) + (s[6] + s[7]) + (s[8] + s[9]) +
                    (s[10] + s[11]) + (s[12] + s[13]) + (s[14] + s[15]);
     const uint64_t v0 = (uint64_t)(kb::P - s[0]) * opaque_pow2(1) + sum;
@@ -106,17 +149,22 @@ KB_HD uint32_t sbox(uint32_t s, uint32_t rc) {
 // 72 modular adds (3 VALU each). Inputs are integers |x| < p, every output is a combination with
 // coefficient sum <= 35, i.e. |out| < 2^37: exact.
 // The S-box takes such an unreduced integer v (a Montgomery word up to a multiple of p):
-//   r = v - rndne(v / p) p           (v_mul_f64, v_rndne_f64, v_fma_f64; |r| <= (p-1)/2: the quotient
-//                                     estimate is off by < 2^-46 and p is odd, so the rounding is exact)
-//   y = int(r) + rc_centred          (|y| <= p - 1, fits int32)
+//   q = rndne(v / p)                 (v_mul_f64, v_rndne_f64; the estimate is off by < 2^-41 and p is
+//                                     odd, so q is the exact nearest integer and |v - q p| <= (p-1)/2)
+//   t = fma(-q, p, v + (MAGIC + rc_centred))   MAGIC = 1.5 * 2^52: t is exact, its ulp is 1, and the low
+//                                     32 bits of its mantissa ARE the two's-complement int32
+//   y = lo32(t) = (v - q p) + rc_centred       (|y| <= p - 1; no conversion instruction, no integer add)
 //   s = (y*y + q p) >> 32            q = int32(lo32(y*y) * -p^-1): SIGNED quotient digit, so that
 //   o = (s*y + q' p) >> 32           |s|, |o| < p/2 + p^2/2^32 < p  (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32)
 // and hands back double(o): a signed representative of (v + rc)^3 R^-2, no conditional correction
-// anywhere. Per lane 12 VALU instructions, per external round 16*12 + 72 = 264 against 400 for the
-// all-integer form; the results are the same field elements (the GPU tests compare every digest with
+// anywhere. Per lane 11 VALU instructions, per external round 16*11 + 64 = 240 against 400 for the
+// all-integer form (the compiler turns the x + x terms of the M4 blocks into v_fma_f64); the results are the same field elements (the GPU tests compare every digest with
 // the oracle bit for bit).
 constexpr double P_F64 = 2130706433.0;
 constexpr double INV_P_F64 = 1.0 / 2130706433.0;
+constexpr double MAGIC_F64 = 6755399441055744.0;   // 1.5 * 2^52
+
+KB_HD uint32_t lo32_of(double t) { return (uint32_t)__builtin_bit_cast(uint64_t, t); }
 
 KB_HD void m4_f64(double& x0, double& x1, double& x2, double& x3) {
     double t01 = x0 + x1, t23 = x2 + x3;
@@ -145,17 +193,17 @@ KB_HD int32_t monty_reduce_signed(int64_t x) {
     return (int32_t)((x + (int64_t)q * (int32_t)kb::P) >> 32);
 }
 
-KB_HD double sbox_f64(double v, int32_t rc_centred) {
+KB_HD double sbox_f64(double v, double magic_plus_rc) {
     const double q = __builtin_rint(v * INV_P_F64);
-    const int32_t y = (int32_t)__builtin_fma(-q, P_F64, v) + rc_centred;
+    const int32_t y = (int32_t)lo32_of(__builtin_fma(-q, P_F64, v + magic_plus_rc));
     const int32_t y2 = monty_reduce_signed((int64_t)y * y);
     return (double)monty_reduce_signed((int64_t)y2 * y);
 }
 
-// exact integer v, |v| < 2^37  ->  the word in [0, p] congruent to it (p itself only when p | v)
+// exact integer v, |v| < 2^42  ->  the word in [0, p] congruent to it (p itself only when p | v)
 KB_HD uint32_t reduce_f64(double v) {
     const double q = __builtin_floor(v * INV_P_F64);
-    return (uint32_t)__builtin_fma(-q, P_F64, v);
+    return lo32_of(__builtin_fma(-q, P_F64, v + MAGIC_F64));
 }
 
 template <class RC>
@@ -167,24 +215,20 @@ KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_c[r][i]);
+        for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_magic[r][i]);
         external_linear_f64(d);
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = reduce_f64(d[i]);            // [0, p]: inside the lazy range
-    s[0] = kb::umin(s[0], s[0] - kb::P);                             // the S-box lane is kept canonical
-#pragma unroll 1
-    for (int r = 0; r < 20; r++) {
-        s[0] = sbox(s[0], rc.internal[r]);
-        internal_linear_lazy(s);
-    }
-    // lanes 1..15 are < p + 2^15 (any representative works for the exact layer), lane 0 canonical
+    for (int i = 0; i < 16; i++) s[i] = reduce_f64(d[i]);            // [0, p]: inside the lazy ranges
+#pragma unroll 2
+    for (int r = 0; r < 20; r++) internal_round_lazy(s, rc.internal_neg[r]);
+    // all lanes < p + 2^15: any representative works for the exact layer
 #pragma unroll
     for (int i = 0; i < 16; i++) d[i] = (double)s[i];
 #pragma unroll 1
     for (int r = 4; r < 8; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_c[r][i]);
+        for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_magic[r][i]);
         external_linear_f64(d);
     }
 #pragma unroll
