@@ -567,8 +567,8 @@ static inline OpeningAndProof read_opening(ByteReader& r) {
     return o;
 }
 
-static inline BasefoldProof deserialize_proof(const uint8_t* buf, size_t len) {
-    ByteReader r{buf, len};
+static inline BasefoldProof read_basefold_proof(ByteReader& r) {
+    const size_t len = r.n;
     BasefoldProof p;
     size_t n = r.u64();
     if (n > len) throw std::runtime_error("bad length");
@@ -587,6 +587,12 @@ static inline BasefoldProof deserialize_proof(const uint8_t* buf, size_t len) {
     p.final_poly = r.e();
     p.pow_witness = r.f();
     p.batch_grinding_witness = r.f();
+    return p;
+}
+
+static inline BasefoldProof deserialize_proof(const uint8_t* buf, size_t len) {
+    ByteReader r{buf, len};
+    BasefoldProof p = read_basefold_proof(r);
     if (r.o != len) throw std::runtime_error("trailing bytes");
     return p;
 }

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "kb_zerocheck.hpp"
+#include "kb_jagged.hpp"
 
 using namespace orc;
 
@@ -326,6 +327,88 @@ int orc_sumcheck_rounds_consistent(const uint32_t* polys, int n_rounds, int n_co
         if (uni_eval(us[r - 1], pt[n_rounds - r]) != uni_eval_one_plus_eval_zero(us[r])) return 2 + r;
     if (uni_eval(us[n_rounds - 1], pt[0]) != load_e(eval)) return 2;
     return 0;
+}
+
+// ---- jagged PCS evaluation proof ----------------------------------------------
+struct JaggedRoundHandle { JaggedRoundData d; Digest commit; };
+
+void* orc_jagged_commit(const uint32_t** tables, const uint64_t* rows, const int* cols, int n, int max_log_row_count,
+                        int lsh, size_t batch_size, int log_blowup, uint32_t* commit8) {
+    std::vector<TensorRef> ts;
+    for (int i = 0; i < n; i++) ts.push_back({FP(tables[i]), (size_t)rows[i], cols[i]});
+    FriConfig cfg;
+    cfg.log_blowup = log_blowup;
+    JaggedRoundHandle* h = new JaggedRoundHandle();
+    h->commit = jagged_commit(ts, max_log_row_count, lsh, batch_size, cfg, &h->d);
+    memcpy(commit8, &h->commit, 32);
+    return h;
+}
+void orc_jagged_round_free(void* h) { delete static_cast<JaggedRoundHandle*>(h); }
+
+static std::vector<std::vector<E>> split_claims(const uint32_t* claims, const int* per_round, int n_rounds) {
+    std::vector<std::vector<E>> cl;
+    size_t co = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        std::vector<E> ev(per_round[r]);
+        memcpy(ev.data(), claims + co * 4, ev.size() * 16);
+        co += ev.size();
+        cl.push_back(std::move(ev));
+    }
+    return cl;
+}
+
+size_t orc_jagged_prove(const uint32_t* z_row, int max_log_row_count, int n_rounds, void** rounds, const uint32_t* claims,
+                        const int* claims_per_round, int lsh, int log_blowup, int num_queries, int pow_bits,
+                        void* challenger, uint8_t* out, size_t cap) {
+    std::vector<E> zr(max_log_row_count);
+    memcpy(zr.data(), z_row, (size_t)max_log_row_count * 16);
+    std::vector<JaggedRoundData> rd;
+    for (int r = 0; r < n_rounds; r++) rd.push_back(static_cast<JaggedRoundHandle*>(rounds[r])->d);
+    FriConfig cfg{log_blowup, num_queries, pow_bits};
+    JaggedProof p = jagged_prove(zr, split_claims(claims, claims_per_round, n_rounds), rd, max_log_row_count, lsh, cfg,
+                                 *static_cast<Challenger*>(challenger));
+    std::vector<uint8_t> b = serialize_jagged_proof(p);
+    if (b.size() <= cap) memcpy(out, b.data(), b.size());
+    return b.size();
+}
+
+// 0 = accepted, > 0 = the restated verifier's error code, -1 = malformed blob
+int orc_jagged_verify(const uint32_t* commitments, int n_rounds, const uint32_t* z_row, int max_log_row_count,
+                      const uint32_t* claims, const int* claims_per_round, const uint8_t* blob, size_t len, int lsh,
+                      int log_blowup, int num_queries, int pow_bits, void* challenger) {
+    try {
+        JaggedProof p = deserialize_jagged_proof(blob, len);
+        std::vector<Digest> cs(n_rounds);
+        memcpy(cs.data(), commitments, (size_t)n_rounds * 32);
+        std::vector<E> zr(max_log_row_count);
+        memcpy(zr.data(), z_row, (size_t)max_log_row_count * 16);
+        FriConfig cfg{log_blowup, num_queries, pow_bits};
+        return jagged_verify(cs, zr, split_claims(claims, claims_per_round, n_rounds), p, max_log_row_count, lsh, cfg,
+                             *static_cast<Challenger*>(challenger));
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// pieces, for kernel-level parity tests
+void orc_partial_jagged_table(const uint64_t* heights, size_t n_cols, int max_log_row_count, const uint32_t* z_row,
+                              const uint32_t* z_col, int z_col_dim, uint32_t* out) {
+    JaggedParams pp = JaggedParams::from_column_heights(std::vector<size_t>(heights, heights + n_cols), max_log_row_count);
+    std::vector<E> zr(max_log_row_count), zc(z_col_dim);
+    memcpy(zr.data(), z_row, zr.size() * 16);
+    memcpy(zc.data(), z_col, zc.size() * 16);
+    std::vector<E> t = partial_jagged_table(pp, zr, zc);
+    memcpy(out, t.data(), t.size() * 16);
+}
+void orc_full_jagged_eval(const uint64_t* heights, size_t n_cols, const uint32_t* z_row, int z_row_dim, const uint32_t* z_col,
+                          int z_col_dim, const uint32_t* z_index, int z_index_dim, uint32_t* out4) {
+    JaggedParams pp = JaggedParams::from_column_heights(std::vector<size_t>(heights, heights + n_cols), z_row_dim);
+    std::vector<E> zr(z_row_dim), zc(z_col_dim), zi(z_index_dim);
+    memcpy(zr.data(), z_row, zr.size() * 16);
+    memcpy(zc.data(), z_col, zc.size() * 16);
+    memcpy(zi.data(), z_index, zi.size() * 16);
+    E r = full_jagged_little_polynomial_evaluation(pp.prefix, zr, zc, zi);
+    memcpy(out4, &r, 16);
 }
 
 }  // extern "C"

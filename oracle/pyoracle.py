@@ -69,6 +69,17 @@ def lib():
         L.orc_interleave.argtypes = [C.POINTER(u32p), u64p, C.POINTER(C.c_int), C.c_int, C.c_size_t, C.c_int,
                                      u32p, C.POINTER(C.c_int)]
         L.orc_jagged_commit_wrap.argtypes = [u32p, u64p, u64p, C.c_int, C.c_uint64, C.c_int, u32p]
+        L.orc_jagged_commit.restype = C.c_void_p
+        L.orc_jagged_commit.argtypes = [C.POINTER(u32p), u64p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                        C.c_int, u32p]
+        L.orc_jagged_round_free.argtypes = [C.c_void_p]
+        L.orc_jagged_prove.restype = C.c_size_t
+        L.orc_jagged_prove.argtypes = [u32p, C.c_int, C.c_int, C.POINTER(C.c_void_p), u32p, C.POINTER(C.c_int), C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
+        L.orc_jagged_verify.argtypes = [u32p, C.c_int, u32p, C.c_int, u32p, C.POINTER(C.c_int), C.POINTER(C.c_uint8),
+                                        C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_partial_jagged_table.argtypes = [u64p, C.c_size_t, C.c_int, u32p, u32p, C.c_int, u32p]
+        L.orc_full_jagged_eval.argtypes = [u64p, C.c_size_t, u32p, C.c_int, u32p, C.c_int, u32p, C.c_int, u32p]
         _lib = L
     return _lib
 
@@ -429,3 +440,71 @@ def padded_column_openings(table, max_log_row_count, zeta):
     full = np.zeros((1 << max_log_row_count, t.shape[1]), np.uint32)
     full[:t.shape[0]] = t
     return eval_mle(full, zeta) if t.shape[1] else np.zeros((0, 4), np.uint32)
+
+
+# ---- jagged PCS evaluation proof -------------------------------------------------
+class JaggedRound:
+    """JaggedProver::commit_multilinears on the CPU oracle: tables = list of [rows_k][cols_k] row-major arrays
+    (rows_k may be 0). Keeps the stacked batches + BaseFold data for the evaluation proof."""
+
+    def __init__(self, tables, max_log_row_count, lsh, batch_size, log_blowup):
+        self.tables = [_arr(t) for t in tables]
+        rows = (C.c_uint64 * len(tables))(*[t.shape[0] for t in self.tables])
+        cols = (C.c_int * len(tables))(*[t.shape[1] for t in self.tables])
+        self.commit = np.zeros(8, np.uint32)
+        self.h = lib().orc_jagged_commit(_ptr_array(self.tables), rows, cols, len(tables), max_log_row_count, lsh,
+                                         C.c_size_t(batch_size), log_blowup, _p(self.commit))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_jagged_round_free(self.h)
+            self.h = None
+
+
+def _claims_args(claims_per_round):
+    flat = _arr(np.concatenate([np.asarray(c, np.uint32).reshape(-1, 4) for c in claims_per_round]))
+    counts = (C.c_int * len(claims_per_round))(*[np.asarray(c).reshape(-1, 4).shape[0] for c in claims_per_round])
+    return flat, counts
+
+
+def jagged_prove(z_row, claims_per_round, rounds, lsh, challenger, log_blowup=2, num_queries=124, pow_bits=16):
+    """JaggedProver::prove_trusted_evaluations -> bincode(JaggedPcsProof)."""
+    z_row = _arr(z_row).reshape(-1, 4)
+    flat, counts = _claims_args(claims_per_round)
+    hs = (C.c_void_p * len(rounds))(*[r.h for r in rounds])
+    args = (_p(z_row), z_row.shape[0], len(rounds), hs, _p(flat), counts, lsh, log_blowup, num_queries, pow_bits)
+    scratch = challenger.clone()                      # sizing pass on a copy of the transcript
+    n = lib().orc_jagged_prove(*args, scratch.h, None, 0)
+    buf = (C.c_uint8 * n)()
+    lib().orc_jagged_prove(*args, challenger.h, buf, n)
+    return bytes(buf)
+
+
+def jagged_verify(commitments, z_row, claims_per_round, blob, lsh, challenger, log_blowup=2, num_queries=124, pow_bits=16):
+    """JaggedPcsVerifier::verify_trusted_evaluations; 0 = accepted."""
+    z_row = _arr(z_row).reshape(-1, 4)
+    commitments = _arr(np.stack(commitments))
+    flat, counts = _claims_args(claims_per_round)
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    return lib().orc_jagged_verify(_p(commitments), commitments.shape[0], _p(z_row), z_row.shape[0], _p(flat), counts, buf,
+                                   C.c_size_t(len(blob)), lsh, log_blowup, num_queries, pow_bits, challenger.h)
+
+
+def partial_jagged_table(heights, max_log_row_count, z_row, z_col):
+    heights = np.ascontiguousarray(heights, dtype=np.uint64)
+    z_row, z_col = _arr(z_row).reshape(-1, 4), _arr(z_col).reshape(-1, 4)
+    total = int(heights.sum())
+    log_m = max(total - 1, 0).bit_length()
+    out = np.zeros((1 << log_m, 4), np.uint32)
+    lib().orc_partial_jagged_table(heights.ctypes.data_as(u64p), C.c_size_t(len(heights)), max_log_row_count, _p(z_row),
+                                   _p(z_col), z_col.shape[0], _p(out))
+    return out
+
+
+def full_jagged_eval(heights, z_row, z_col, z_index):
+    heights = np.ascontiguousarray(heights, dtype=np.uint64)
+    z_row, z_col, z_index = (_arr(z).reshape(-1, 4) for z in (z_row, z_col, z_index))
+    out = np.zeros(4, np.uint32)
+    lib().orc_full_jagged_eval(heights.ctypes.data_as(u64p), C.c_size_t(len(heights)), _p(z_row), z_row.shape[0], _p(z_col),
+                               z_col.shape[0], _p(z_index), z_index.shape[0], _p(out))
+    return out

@@ -38,6 +38,11 @@ Output tests/golden/kb_shrink_transcript.npz:
     reference's own bytes (univariate messages, commitments, openings, Merkle paths, final_poly, both
     witnesses) with only the per-opening counts rewritten — what the oracle's BaseFold verifier is run
     on in tests/test_oracle_golden.py (num_queries = 12; the query indices are the first 12 sampled).
+  jagged_tail = the reference's bytes of the rest of JaggedPcsProof (batch evaluations, jagged sumcheck,
+    jagged-eval sumcheck, row/column counts, commitments, expected_eval, max_log_row_count, log_m);
+    basefold_proof_q12 + jagged_tail is a complete JaggedPcsProof. jagged_start_op = tape index where
+    JaggedPcsVerifier::verify_trusted_evaluations starts (first z_col sample); jagged_z_row = the
+    zerocheck point; jagged_claims0/1 = the preprocessed / main column openings it is given.
   stack_point = the evaluation point of the stacked PCS (last log_stacking_height coordinates of the
     jagged sumcheck point), expected_eval = JaggedPcsProof.expected_eval.
   pinned = 1 when the expected value is read from / checked against the proof itself, 0 when it is
@@ -266,6 +271,7 @@ def main():
     final_poly = r.ext()
     pow_witness, batch_witness = r.felts(1)[0], r.felts(1)[0]
     blob += b[tail:r.o]
+    jagged_tail_start = r.o
     batch_evals = [r.tensor_ext(1)[0] for _ in range(r.u64())]
     jagged_sc = r.sumcheck()
     jagged_eval_sc = r.sumcheck()
@@ -274,6 +280,7 @@ def main():
     expected_eval = r.ext()
     assert r.u64() == max_log_row_count
     log_m = r.u64()
+    jagged_tail = b[jagged_tail_start:r.o]
     print("parsed shard proof: %d bytes, log_m %d" % (r.o, log_m))
     assert pow_witness == int(gold["pow_witness"]) and batch_witness == int(gold["batch_witness"])
 
@@ -359,6 +366,7 @@ def main():
     col_counts = [[c for _, c in rnd] for rnd in rc]
     n_prefix = sum(sum(c) for c in col_counts) + 1          # usize_prefix_sums.len()
     num_col_variables = (n_prefix - 1 - 1).bit_length() if n_prefix > 2 else 0
+    jagged_start_op = len(t.ops)
     z_col = [t.sample_ext() for _ in range(num_col_variables)]
     t.sumcheck(jagged_sc, 2)
     t.observe_exts([jagged_eval_sc["claimed_sum"]])
@@ -392,7 +400,12 @@ def main():
                         beta_seed_dim=np.int32(found), z_col_dim=np.int32(num_col_variables),
                         basefold_proof_q12=np.frombuffer(bytes(blob), dtype=np.uint8),
                         stack_point=np.array(stack_point, dtype=np.uint32),
-                        expected_eval=np.array(expected_eval, dtype=np.uint32))
+                        expected_eval=np.array(expected_eval, dtype=np.uint32),
+                        jagged_tail=np.frombuffer(bytes(jagged_tail), dtype=np.uint8),
+                        jagged_start_op=np.int32(jagged_start_op),
+                        jagged_z_row=np.array(zerocheck["point"], dtype=np.uint32),
+                        jagged_claims0=np.array([e for _, prep, _, _ in opened for e in prep], dtype=np.uint32).reshape(-1, 4),
+                        jagged_claims1=np.array([e for _, _, mainv, _ in opened for e in mainv], dtype=np.uint32).reshape(-1, 4))
     print("wrote", path, os.path.getsize(path), "bytes;", len(ops), "ops,", len(data), "words,",
           int((ops[:, 3] == 1).sum()), "pinned ops")
 

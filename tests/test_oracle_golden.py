@@ -205,3 +205,30 @@ def test_oracle_verifier_accepts_the_reference_basefold_proof():
     claims[1] = claims[1].copy()
     claims[1][3, 0] = (int(claims[1][3, 0]) + 1) % kb_py.P
     assert orc.basefold_verify(commits, point, claims, blob, ch.clone(), 2, 12, 16) != 0
+
+
+def test_oracle_jagged_verifier_accepts_the_reference_jagged_proof():
+    """The oracle's restatement of JaggedPcsVerifier::verify_trusted_evaluations
+    (/root/reference/slop/crates/jagged/src/verifier.rs:L109-L383) on the reference's REAL JaggedPcsProof
+    (its own bytes; BaseFold part = first 12 queries), from the transcript state the real verifier has
+    after the zerocheck openings: z_col sampling, claim insertion, both sumchecks, the branching-program
+    closing check of the jagged-eval proof, expected_eval * J(z) = sumcheck eval, stacked interpolation,
+    BaseFold opening — all accept; tampering is rejected."""
+    import transcript_tape as tt
+    T = tt.TAPE
+    k = int(T["jagged_start_op"])
+    ch = orc.Challenger()
+    assert tt.replay(ch, stop_before_op=k)[0] == k
+    blob = T["basefold_proof_q12"].tobytes() + T["jagged_tail"].tobytes()
+    commits = [M(GOLD["vk_preprocessed_commit"]), M(GOLD["main_commitment"])]
+    claims = [M(T["jagged_claims0"]), M(T["jagged_claims1"])]
+    z_row = M(T["jagged_z_row"])
+    lsh = len(T["stack_point"])
+    end = ch.clone()
+    assert orc.jagged_verify(commits, z_row, claims, blob, lsh, end, 2, 12, 16) == 0
+    bad = bytearray(blob)
+    bad[-200] ^= 1                                   # inside the row/column counts or commitments
+    assert orc.jagged_verify(commits, z_row, claims, bytes(bad), lsh, ch.clone(), 2, 12, 16) != 0
+    claims[0] = claims[0].copy()
+    claims[0][5, 1] ^= 1
+    assert orc.jagged_verify(commits, z_row, claims, blob, lsh, ch.clone(), 2, 12, 16) != 0
