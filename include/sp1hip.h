@@ -233,6 +233,22 @@ int sp1hip_jagged_commit(const sp1hip_table_t* tables, int n_tables, int max_log
                          int batch_size, int lg_blowup, uint32_t h_commit[8], sp1hip_stacked_data_t** out,
                          sp1hip_stream_t stream);
 
+/* ---------------------------------------------------------------- jagged PCS evaluation proof
+ * `JaggedProver::prove_trusted_evaluations` (/root/reference/slop/crates/jagged/src/prover.rs:L162-L328): the jagged
+ * sumcheck over the dense vector (`HadamardProduct`, hadamard.rs:L52-L146), the jagged-eval sumcheck
+ * (jagged_eval/sumcheck_eval.rs:L185-L243) and the stacked / BaseFold opening of the dense commitments
+ * (stacked/src/prover.rs:L107-L152) — everything between the zerocheck point and the end of the shard proof's
+ * `evaluation_proof`. rounds[r]: handles returned by sp1hip_jagged_commit, in commitment order (SP1:
+ * preprocessed, main); h_z_row: the zerocheck point (max_log_row_count ext); h_claims: the evaluations at z_row
+ * of every column of every table of every round (round -> table -> column; no padding columns),
+ * claims_per_round[r] of them for round r. Writes bincode(JaggedPcsProof)
+ * (/root/reference/slop/crates/jagged/src/verifier.rs:L17-L26) into h_proof (capacity *proof_len on entry, size on
+ * return; SP1HIP_ERROR_BUFFER_TOO_SMALL sets the needed size). The challenger is advanced only on success. */
+int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1hip_stacked_data_t* const* rounds,
+                        int n_rounds, const sp1hip_ext_t* h_claims, const size_t* claims_per_round,
+                        sp1hip_fri_config_t config, sp1hip_challenger_t* challenger, uint8_t* h_proof,
+                        size_t* proof_len, sp1hip_stream_t stream);
+
 /* ---------------------------------------------------------------- zerocheck (a9-a12)
  * One chip of the shard. `program` is a HOST array of n_instr [op, a, b] triples in SSA form
  * (instruction k defines value k): 0 LOAD_MAIN col, 1 LOAD_PREP col, 2 CONST canonical, 3 PUBLIC idx,

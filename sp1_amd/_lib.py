@@ -114,6 +114,8 @@ PROTOTYPES = [
     ("sp1hip_stacked_data_info", None, [_vp, C.POINTER(_vp), C.POINTER(_int), C.POINTER(_vp), C.POINTER(C.c_uint64)]),
     ("sp1hip_stacked_batch", None, [_vp, _int, C.POINTER(Tensor)]),
     ("sp1hip_jagged_commit", None, [C.POINTER(Table), _int, _int, _int, _int, _int, u32p, C.POINTER(_vp), _vp]),
+    ("sp1hip_jagged_prove", None, [C.POINTER(Ext), _int, C.POINTER(_vp), _int, C.POINTER(Ext), C.POINTER(_sz), FriConfig, _vp,
+                                   u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
                                       _vp, u8p, C.POINTER(_sz), _vp]),
 ]

@@ -365,6 +365,29 @@ class JaggedProver:
                                         C.byref(handle), _stream_ptr(stream)))
         return commit, StackedData(handle, commit, None, self.lsh)
 
+    def prove_trusted_evaluations(self, z_row, claims_per_round, rounds, challenger, num_queries=124, pow_bits=16,
+                                  stream=None):
+        """JaggedProver::prove_trusted_evaluations (/root/reference/slop/crates/jagged/src/prover.rs:L162-L328).
+        rounds: the StackedData of every commitment round, in order; claims_per_round[r]: [n_cols_r][4] column
+        evaluations at z_row of round r's tables. Returns bincode(JaggedPcsProof); advances the challenger."""
+        z_row = np.ascontiguousarray(np.asarray(z_row, dtype=np.uint32).reshape(-1, 4))
+        assert z_row.shape[0] == self.max_log_row_count
+        cl = [np.asarray(c, dtype=np.uint32).reshape(-1, 4) for c in claims_per_round]
+        flat = np.ascontiguousarray(np.concatenate(cl)) if cl else np.zeros((0, 4), np.uint32)
+        counts = (C.c_size_t * len(rounds))(*[c.shape[0] for c in cl])
+        hs = (C.c_void_p * len(rounds))(*[r.h for r in rounds])
+        cfg = FriConfig(self.log_blowup, num_queries, pow_bits)
+        n = C.c_size_t(0)
+        args = [_ext_array(z_row), self.max_log_row_count, hs, len(rounds), _ext_array(flat) if flat.size else None, counts,
+                cfg, challenger.h]
+        st = _L().sp1hip_jagged_prove(*args, None, C.byref(n), _stream_ptr(stream))
+        if st != -6:                                   # anything but BUFFER_TOO_SMALL is a real error
+            check(st)
+            raise RuntimeError("size query unexpectedly succeeded")
+        buf = (C.c_uint8 * n.value)()
+        check(_L().sp1hip_jagged_prove(*args, buf, C.byref(n), _stream_ptr(stream)))
+        return bytes(buf[:n.value])
+
 
 class ZerocheckChip:
     """One chip for `zerocheck`: an `sp1_amd.air.AirProgram`, column-major device traces (real rows only)."""

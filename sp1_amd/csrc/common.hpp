@@ -14,9 +14,6 @@ namespace sp1hip {
 void set_error(const char* fmt, ...);
 int map_hip_error(hipError_t e, const char* what);
 
-// Uploads the Poseidon2 round constants and builds the twiddle tables for the current device once.
-int ensure_device_ready();
-
 inline hipStream_t S(sp1hip_stream_t s) { return static_cast<hipStream_t>(s); }
 
 // Buffer arena (runtime.hip): stream-keyed free lists; alloc never blocks once the working set is cached.

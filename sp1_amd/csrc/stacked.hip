@@ -15,20 +15,7 @@
 #include <vector>
 
 #include "device_ctx.hpp"
-
-struct sp1hip_stacked_data_s {
-    void* d_dense = nullptr;
-    hipStream_t stream = nullptr;
-    sp1hip_basefold_data_t* basefold = nullptr;
-    std::vector<sp1hip_tensor_t> batches;
-    uint64_t area = 0, padded = 0;
-    int log_stacking_height = 0;
-    uint32_t commit[8];
-    ~sp1hip_stacked_data_s() {
-        if (basefold) sp1hip_basefold_data_free(basefold);
-        sp1hip::arena_free(d_dense, padded * 4, stream);
-    }
-};
+#include "stacked_data.hpp"
 
 using namespace sp1hip;
 
@@ -157,6 +144,13 @@ int sp1hip_jagged_commit(const sp1hip_table_t* tables, int n_tables, int max_log
     uint32_t h[8];
     host_hash(meta, h);
     host_compress(inner, h, h_commit);
+    // what the evaluation proof (jagged.hip) needs later: JaggedProverData (prover.rs:L150-L156)
+    (*out)->jagged = true;
+    (*out)->max_log_row_count = max_log_row_count;
+    (*out)->row_counts = rows;
+    (*out)->column_counts = cols;
+    (*out)->padding_column_count = added_cols;
+    memcpy((*out)->jagged_commit, h_commit, 32);
     return SP1HIP_SUCCESS;
 }
 
