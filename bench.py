@@ -171,6 +171,12 @@ def main():
                          # algorithmic bytes, i.e. no re-reads
                          "traffic": 4429185024, "traffic_source": "profiles/r01_pmc_summary.md",
                          "avg_launch_ms": leaf_ms, "algorithmic_bytes_per_launch": leaf_bytes,
+                         # the bound that actually binds: VALU issue. 3722 = dynamic VALU instructions per
+                         # permutation counted in the gfx950 ISA of this build (profiles/r01_pmc_summary.md, SQ pass:
+                         # SQ_INSTS_VALU agrees); peak = 256 CUs x 64 lanes x 2.4 GHz, one instruction per lane-clock
+                         "valu": {"insts_per_permutation": 3722, "achieved_lane_insts_per_s": 3722 * perms / (leaf_ms * 1e-3),
+                                  "peak_lane_insts_per_s": 256 * 64 * 2.4e9,
+                                  "frac": 3722 * perms / (leaf_ms * 1e-3) / (256 * 64 * 2.4e9)},
                          "note": "integer-VALU-bound by construction (Poseidon2: %d permutations per launch, "
                                  "%.3g permutations/s); see DESIGN.md" % (perms, perms / (leaf_ms * 1e-3)),
                          "rs_encode": {"bound": "hbm", "ms_per_step": ntt_ms, "algorithmic_bytes_per_step": ntt_bytes,

@@ -11,6 +11,7 @@ this is NOT a complete shard proof.
   python bench/bench_shard.py [--scale-log2 K]   (area = (2^28 + 2^27) >> K; default K = 0)
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -120,12 +121,21 @@ def main():
         ops, t_open_evals = timed(openings)
         chips = [api.ZerocheckChip(a, t) for a, t in zip(airs, tables)]
         blob, t_zc = timed(lambda: api.zerocheck(chips, L, zeta, np.concatenate(ops), alpha, gkr, [], ch))
-        # BaseFold opening of the stacked commitment at a fresh point
-        pt = ch.sample_point(lsh)
-        claims, t_claims = timed(lambda: prover.evaluate_mles(sd.batches, pt))
-        proof, t_open = timed(lambda: prover.prove_trusted_mle_evaluations(pt, [sd.basefold], claims, ch))
-        res = dict(res, commit_ms=t_commit, zerocheck_ms=t_zc, stacked_claims_ms=t_claims, basefold_open_ms=t_open,
-                   zerocheck_proof_bytes=len(blob), basefold_proof_bytes=len(proof), trace_openings_ms=t_open_evals)
+        # jagged PCS evaluation proof at the zerocheck point: jagged sumcheck + jagged-eval sumcheck + stacked
+        # batch evaluations + BaseFold opening (= ShardProof.evaluation_proof)
+        z_row, chip_evals = api.parse_zerocheck_proof(blob)
+        main_claims = np.concatenate(chip_evals)         # no preprocessed columns here
+        api.check(api._L().sp1hip_timers_enable(1))
+        api.check(api._L().sp1hip_timers_reset())
+        proof, t_jag = timed(lambda: jp.prove_trusted_evaluations(z_row, [main_claims], [sd], ch))
+        stages = {}
+        for name in ("jagged_round0_sum", "jagged_fold0_sum", "jagged_fold_sum", "jagged_batch_evals"):
+            cnt, ms = C.c_uint64(), C.c_double()
+            api.check(api._L().sp1hip_timers_read(name.encode(), C.byref(cnt), C.byref(ms)))
+            stages[name + "_ms"] = round(ms.value, 3)
+        api.check(api._L().sp1hip_timers_enable(0))
+        res = dict(res, commit_ms=t_commit, zerocheck_ms=t_zc, jagged_eval_proof_ms=t_jag, jagged_kernels=stages,
+                   zerocheck_proof_bytes=len(blob), jagged_proof_bytes=len(proof), trace_openings_ms=t_open_evals)
         print(json.dumps(res), flush=True)
         del sd
 

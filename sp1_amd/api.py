@@ -413,7 +413,41 @@ def zerocheck(chips, max_log_row_count, zeta, openings, alpha, gkr_batch, public
     args = [arr, len(chips), max_log_row_count, _ext_array(zeta), _ext_array(openings), _ext(alpha), _ext(gkr_batch),
             pv.ctypes.data_as(_lib.u32p) if pv.size else None, int(pv.size), challenger.h]
     st = _L().sp1hip_zerocheck_prove(*args, None, C.byref(n), _stream_ptr(stream))
-    assert st == -6, "size query expected SP1HIP_ERROR_BUFFER_TOO_SMALL"
+    if st != -6:                                       # anything but BUFFER_TOO_SMALL is a real error
+        check(st)
+        raise RuntimeError("size query unexpectedly succeeded")
     buf = (C.c_uint8 * n.value)()
     check(_L().sp1hip_zerocheck_prove(*args, buf, C.byref(n), _stream_ptr(stream)))
     return bytes(buf[:n.value])
+
+
+def parse_zerocheck_proof(blob):
+    """Split the zerocheck output (layout in include/sp1hip.h) into the sumcheck point (Montgomery words,
+    [dim][4]) and the per-chip opened values (one [w_prep + w_main][4] array per chip: preprocessed columns
+    first, then main) — what the jagged evaluation proof takes as z_row and as its column claims."""
+    import struct
+    P_ = P
+    o = 0
+
+    def u64():
+        nonlocal o
+        v = struct.unpack_from("<Q", blob, o)[0]
+        o += 8
+        return v
+
+    def exts(k):
+        nonlocal o
+        a = np.frombuffer(blob, dtype="<u4", count=4 * k, offset=o).astype(np.uint64)
+        o += 16 * k
+        return ((a << np.uint64(32)) % np.uint64(P_)).astype(np.uint32).reshape(k, 4)    # canonical -> Montgomery
+
+    for _ in range(u64()):
+        exts(u64())
+    exts(1)
+    point = exts(u64())
+    exts(1)
+    chips = []
+    for _ in range(u64()):
+        chips.append(exts(u64()))
+    assert o == len(blob)
+    return point, chips
