@@ -9,6 +9,7 @@
 
 #include "kb_zerocheck.hpp"
 #include "kb_jagged.hpp"
+#include "kb_gkr.hpp"
 
 using namespace orc;
 
@@ -409,6 +410,72 @@ void orc_full_jagged_eval(const uint64_t* heights, size_t n_cols, const uint32_t
     memcpy(zi.data(), z_index, zi.size() * 16);
     E r = full_jagged_little_polynomial_evaluation(pp.prefix, zr, zc, zi);
     memcpy(out4, &r, 16);
+}
+
+// ---- LogUp-GKR -------------------------------------------------------------------
+// Interaction program of one chip (uint32 words): [n_interactions, then per interaction: is_send, kind, n_values,
+// vcol(multiplicity), vcol(value 0), ...]; vcol = [n_terms, constant (canonical), then n_terms x (is_main, column,
+// weight (canonical))].
+static VCol parse_vcol(const uint32_t*& p) {
+    VCol v;
+    const uint32_t nt = *p++;
+    v.constant = F::from_canonical(*p++);
+    for (uint32_t t = 0; t < nt; t++) { v.terms.push_back({(int)p[0], (int)p[1], F::from_canonical(p[2])}); p += 3; }
+    return v;
+}
+static std::vector<GkrChip> make_gkr_chips(int n, const char** names, const uint32_t** progs, const int* main_w, const int* prep_w,
+                                           const uint32_t** mains, const uint32_t** preps, const uint64_t* rows) {
+    std::vector<GkrChip> chips(n);
+    for (int k = 0; k < n; k++) {
+        GkrChip& c = chips[k];
+        c.name = names[k];
+        c.main_width = main_w[k]; c.prep_width = prep_w[k];
+        c.main = mains ? FP(mains[k]) : nullptr;
+        c.prep = (preps && preps[k]) ? FP(preps[k]) : nullptr;
+        c.real_rows = rows ? (size_t)rows[k] : 0;
+        const uint32_t* p = progs[k];
+        const uint32_t ni = *p++;
+        for (uint32_t i = 0; i < ni; i++) {
+            GkrInteraction in;
+            in.is_send = *p++ != 0;
+            in.kind = *p++;
+            const uint32_t nv = *p++;
+            in.multiplicity = parse_vcol(p);
+            for (uint32_t j = 0; j < nv; j++) in.values.push_back(parse_vcol(p));
+            c.interactions.push_back(std::move(in));
+        }
+    }
+    return chips;
+}
+
+size_t orc_gkr_prove(int n_chips, const char** names, const uint32_t** progs, const int* main_w, const int* prep_w,
+                     const uint32_t** mains, const uint32_t** preps, const uint64_t* rows, int L, void* challenger, uint8_t* out,
+                     size_t cap) {
+    std::vector<GkrChip> chips = make_gkr_chips(n_chips, names, progs, main_w, prep_w, mains, preps, rows);
+    GkrProof p = gkr_prove(chips, L, *static_cast<Challenger*>(challenger));
+    std::vector<uint8_t> b = serialize_gkr_proof(p);
+    if (b.size() <= cap) memcpy(out, b.data(), b.size());
+    return b.size();
+}
+
+// 0 = accepted; > 0 = error code of the restated verifier; -1 = malformed blob. With check_interactions == 0 the
+// chips are ignored (n_chips may be 0) and beta_seed_dim must be given.
+int orc_gkr_verify(int n_chips, const char** names, const uint32_t** progs, const int* main_w, const int* prep_w,
+                   const uint64_t* heights, int L, const uint8_t* blob, size_t len, int check_interactions, int beta_seed_dim,
+                   void* challenger) {
+    try {
+        GkrProof p = deserialize_gkr_proof(blob, len);
+        std::vector<GkrChip> chips;
+        std::vector<size_t> hs;
+        if (check_interactions) {
+            chips = make_gkr_chips(n_chips, names, progs, main_w, prep_w, nullptr, nullptr, nullptr);
+            hs.assign(heights, heights + n_chips);
+        }
+        return gkr_verify(chips, hs, L, p, check_interactions != 0, check_interactions ? -1 : beta_seed_dim,
+                          *static_cast<Challenger*>(challenger));
+    } catch (const std::exception&) {
+        return -1;
+    }
 }
 
 }  // extern "C"

@@ -80,6 +80,12 @@ def lib():
                                         C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_partial_jagged_table.argtypes = [u64p, C.c_size_t, C.c_int, u32p, u32p, C.c_int, u32p]
         L.orc_full_jagged_eval.argtypes = [u64p, C.c_size_t, u32p, C.c_int, u32p, C.c_int, u32p, C.c_int, u32p]
+        cpp = C.POINTER(C.c_char_p)
+        L.orc_gkr_prove.restype = C.c_size_t
+        L.orc_gkr_prove.argtypes = [C.c_int, cpp, C.POINTER(u32p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(u32p),
+                                    C.POINTER(u32p), u64p, C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
+        L.orc_gkr_verify.argtypes = [C.c_int, cpp, C.POINTER(u32p), C.POINTER(C.c_int), C.POINTER(C.c_int), u64p, C.c_int,
+                                     C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -508,3 +514,46 @@ def full_jagged_eval(heights, z_row, z_col, z_index):
     lib().orc_full_jagged_eval(heights.ctypes.data_as(u64p), C.c_size_t(len(heights)), _p(z_row), z_row.shape[0], _p(z_col),
                                z_col.shape[0], _p(z_index), z_index.shape[0], _p(out))
     return out
+
+
+# ---- LogUp-GKR -------------------------------------------------------------------
+def _gkr_chip_args(chips):
+    """chips: [(InteractionProgram-like with .name/.main_width/.prep_width/.to_array(), main, prep or None)]."""
+    n = len(chips)
+    names = (C.c_char_p * n)(*[c[0].name.encode() for c in chips])
+    progs = [np.ascontiguousarray(c[0].to_array(), dtype=np.uint32) for c in chips]
+    mains = [_arr(c[1]) for c in chips]
+    preps = [None if c[2] is None else _arr(c[2]) for c in chips]
+    prog_ptrs = (u32p * n)(*[_p(a) for a in progs])
+    main_ptrs = (u32p * n)(*[_p(a) if a.size else None for a in mains])
+    prep_ptrs = (u32p * n)(*[None if a is None or not a.size else _p(a) for a in preps])
+    mw = (C.c_int * n)(*[c[0].main_width for c in chips])
+    pw = (C.c_int * n)(*[c[0].prep_width for c in chips])
+    rows = (C.c_uint64 * n)(*[m.shape[0] for m in mains])
+    keep = (progs, mains, preps)
+    return n, names, prog_ptrs, mw, pw, main_ptrs, prep_ptrs, rows, keep
+
+
+def gkr_prove(chips, max_log_row_count, challenger):
+    """GkrProverImpl::prove_logup_gkr -> bincode(LogupGkrProof). Chips in name order."""
+    n, names, progs, mw, pw, mains, preps, rows, keep = _gkr_chip_args(chips)
+    scratch = challenger.clone()
+    size = lib().orc_gkr_prove(n, names, progs, mw, pw, mains, preps, rows, max_log_row_count, scratch.h, None, 0)
+    buf = (C.c_uint8 * size)()
+    lib().orc_gkr_prove(n, names, progs, mw, pw, mains, preps, rows, max_log_row_count, challenger.h, buf, size)
+    return bytes(buf)
+
+
+def gkr_verify(chips, heights, max_log_row_count, blob, challenger):
+    """LogUpGkrVerifier::verify_logup_gkr with the final interaction check; 0 = accepted."""
+    n, names, progs, mw, pw, _, _, _, keep = _gkr_chip_args(chips)
+    hs = (C.c_uint64 * n)(*heights)
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    return lib().orc_gkr_verify(n, names, progs, mw, pw, hs, max_log_row_count, buf, C.c_size_t(len(blob)), 1, -1, challenger.h)
+
+
+def gkr_verify_transcript_only(max_log_row_count, blob, beta_seed_dim, challenger):
+    """Everything of verify_logup_gkr that does not need the machine's chips (used on the reference's real proof)."""
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    return lib().orc_gkr_verify(0, None, None, None, None, None, max_log_row_count, buf, C.c_size_t(len(blob)), 0,
+                                beta_seed_dim, challenger.h)

@@ -121,3 +121,85 @@ def allocate_registers(prog):
             reg_of[k] = dst
         out.append((op, dst, ra, rb))
     return np.array(out, dtype=np.uint32).reshape(-1, 4), max(n_regs, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Interaction programs: the sends / receives of a chip as data for LogUp-GKR.
+#
+# The reference stores them as `Interaction { values: Vec<VirtualPairCol>, multiplicity: VirtualPairCol, kind }`
+# (/root/reference/crates/hypercube/src/lookup/interaction.rs:L11-L24), a `VirtualPairCol` being
+# `sum_k weight_k * column_k + constant` over the preprocessed / main columns of the row. Encoding (u32 words,
+# the layout `sp1hip_gkr_chip_t.interactions` expects):
+#
+#   [n_interactions, then per interaction: is_send, kind, n_values, vcol(multiplicity), vcol(value_0), ...]
+#   vcol = [n_terms, constant (canonical), then n_terms x (is_main, column, weight (canonical))]
+#
+# Order inside a chip: all sends, then all receives (cpu.rs:L86-L92).
+class VCol:
+    """sum weight * column + constant; columns are ("main", i) or ("prep", i)."""
+
+    def __init__(self, terms=(), constant=0):
+        self.terms = [(kind, int(col), int(w) % P) for kind, col, w in terms]
+        self.constant = int(constant) % P
+
+    @staticmethod
+    def main(col, weight=1):
+        return VCol([("main", col, weight)])
+
+    @staticmethod
+    def prep(col, weight=1):
+        return VCol([("prep", col, weight)])
+
+    @staticmethod
+    def const(c):
+        return VCol([], c)
+
+    def __add__(self, o):
+        o = o if isinstance(o, VCol) else VCol([], o)
+        return VCol(self.terms + o.terms, self.constant + o.constant)
+
+    __radd__ = __add__
+
+    def __mul__(self, k):
+        return VCol([(a, b, w * int(k)) for a, b, w in self.terms], self.constant * int(k))
+
+    __rmul__ = __mul__
+
+    def words(self):
+        out = [len(self.terms), self.constant]
+        for kind, col, w in self.terms:
+            out += [1 if kind == "main" else 0, col, w]
+        return out
+
+    def apply(self, prep_row, main_row):
+        acc = self.constant
+        for kind, col, w in self.terms:
+            acc += w * int((main_row if kind == "main" else prep_row)[col])
+        return acc % P
+
+
+class InteractionProgram:
+    """The interactions of one chip (name order across chips is the caller's job: BTreeSet<Chip>)."""
+
+    def __init__(self, name, main_width, prep_width=0):
+        self.name, self.main_width, self.prep_width = name, main_width, prep_width
+        self.sends, self.receives = [], []
+
+    def send(self, kind, values, multiplicity):
+        self.sends.append((int(kind), list(values), multiplicity))
+
+    def receive(self, kind, values, multiplicity):
+        self.receives.append((int(kind), list(values), multiplicity))
+
+    @property
+    def num_interactions(self):
+        return len(self.sends) + len(self.receives)
+
+    def to_array(self):
+        out = [self.num_interactions]
+        for is_send, lst in ((1, self.sends), (0, self.receives)):
+            for kind, values, mult in lst:
+                out += [is_send, kind, len(values)] + mult.words()
+                for v in values:
+                    out += v.words()
+        return np.array(out, dtype=np.uint32)

@@ -43,6 +43,8 @@ Output tests/golden/kb_shrink_transcript.npz:
     basefold_proof_q12 + jagged_tail is a complete JaggedPcsProof. jagged_start_op = tape index where
     JaggedPcsVerifier::verify_trusted_evaluations starts (first z_col sample); jagged_z_row = the
     zerocheck point; jagged_claims0/1 = the preprocessed / main column openings it is given.
+  gkr_proof = the reference's bytes of ShardProof.logup_gkr_proof (bincode(LogupGkrProof)); gkr_start_op =
+    tape index of its 12-bit grinding check (the first op of verify_logup_gkr).
   stack_point = the evaluation point of the stacked PCS (last log_stacking_height coordinates of the
     jagged sumcheck point), expected_eval = JaggedPcsProof.expected_eval.
   pinned = 1 when the expected value is read from / checked against the proof itself, 0 when it is
@@ -229,6 +231,7 @@ def main():
     assert len(public_values) == 187 and r.o == 900
 
     # ---- LogupGkrProof --------------------------------------------------------------------------
+    gkr_start = r.o
     numer, nd = r.tensor_ext(2)
     denom, dd = r.tensor_ext(2)
     assert nd == dd and nd[1] == 1
@@ -244,6 +247,7 @@ def main():
         prep_ev = r.tensor_ext(1)[0] if r.u8() else None
         gkr_openings.append((name, prep_ev, main_ev))
     gkr_witness = r.felts(1)[0]
+    gkr_bytes = b[gkr_start:r.o]
     zerocheck = r.sumcheck()
     opened = []
     for _ in range(r.u64()):
@@ -305,7 +309,8 @@ def main():
     head = (list(t.ops), list(t.data), t.ch.__dict__.copy())
 
     # verify_logup_gkr: beta_seed_dim depends on the machine's widest interaction, which the proof
-    # does not store — find it as the unique value that makes the first GKR sumcheck point come out.
+    # does not store — find it as the smallest value that makes the first GKR sumcheck point come out
+    # (2; 3 draws the same number of sponge permutations before the next absorb and is indistinguishable).
     niv = (len(numer).bit_length() - 1) - 1                 # number_of_interaction_variables
     found = None
     for beta_seed_dim in range(1, 9):
@@ -352,6 +357,7 @@ def main():
         t.observe_var_exts(main_ev)
 
     # verify_zerocheck
+    zerocheck_start_op = len(t.ops)
     t.sample_ext()                                          # alpha
     t.sample_ext()                                          # gkr_batch_open_challenge
     t.sample_ext()                                          # lambda
@@ -402,6 +408,8 @@ def main():
                         stack_point=np.array(stack_point, dtype=np.uint32),
                         expected_eval=np.array(expected_eval, dtype=np.uint32),
                         jagged_tail=np.frombuffer(bytes(jagged_tail), dtype=np.uint8),
+                        gkr_proof=np.frombuffer(bytes(gkr_bytes), dtype=np.uint8),
+                        gkr_start_op=np.int32(len(head[0])), zerocheck_start_op=np.int32(zerocheck_start_op),
                         jagged_start_op=np.int32(jagged_start_op),
                         jagged_z_row=np.array(zerocheck["point"], dtype=np.uint32),
                         jagged_claims0=np.array([e for _, prep, _, _ in opened for e in prep], dtype=np.uint32).reshape(-1, 4),

@@ -232,3 +232,33 @@ def test_oracle_jagged_verifier_accepts_the_reference_jagged_proof():
     claims[0] = claims[0].copy()
     claims[0][5, 1] ^= 1
     assert orc.jagged_verify(commits, z_row, claims, blob, lsh, ch.clone(), 2, 12, 16) != 0
+
+
+def test_oracle_gkr_verifier_accepts_the_reference_gkr_proof():
+    """The oracle's restatement of LogUpGkrVerifier::verify_logup_gkr
+    (/root/reference/crates/hypercube/src/logup_gkr/verifier.rs:L102-L285) parses the reference's own
+    bincode(LogupGkrProof) and accepts everything that does not need the recursion machine's chips: the 12-bit
+    witness, the output shapes and non-zero denominators, every round's claim / sumcheck / eq-weighted closing
+    equation with the challenges it samples itself, the trace point, and it leaves the transcript exactly where
+    the zerocheck starts."""
+    import transcript_tape as tt
+    T = tt.TAPE
+    k = int(T["gkr_start_op"])
+    ch = orc.Challenger()
+    assert tt.replay(ch, stop_before_op=k)[0] == k
+    blob = T["gkr_proof"].tobytes()
+    L = len(T["jagged_z_row"])
+    v = ch.clone()
+    assert orc.gkr_verify_transcript_only(L, blob, int(T["beta_seed_dim"]), v) == 0
+    # the verifier's transcript must now be where the tape says the zerocheck begins: replay the tape to the
+    # first zerocheck sample and compare states
+    zc = int(T["zerocheck_start_op"])
+    ref = orc.Challenger()
+    assert tt.replay(ref, stop_before_op=zc)[0] == zc
+    assert np.array_equal(ref.state(), v.state())
+    # (beta_seed_dim 2 and 3 draw the same number of sponge permutations before the next absorb, so the proof
+    # cannot tell them apart; 4 can)
+    assert orc.gkr_verify_transcript_only(L, blob, int(T["beta_seed_dim"]) + 2, ch.clone()) != 0
+    bad = bytearray(blob)
+    bad[5000] ^= 1
+    assert orc.gkr_verify_transcript_only(L, bytes(bad), int(T["beta_seed_dim"]), ch.clone()) != 0
