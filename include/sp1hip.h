@@ -249,6 +249,33 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                         sp1hip_fri_config_t config, sp1hip_challenger_t* challenger, uint8_t* h_proof,
                         size_t* proof_len, sp1hip_stream_t stream);
 
+/* ---------------------------------------------------------------- LogUp-GKR
+ * One chip of the shard for the lookup argument. `interactions`: HOST words describing its sends (first) and
+ * receives, the data form of `Interaction { values: Vec<VirtualPairCol>, multiplicity, kind }`
+ * (/root/reference/crates/hypercube/src/lookup/interaction.rs:L11-L24):
+ *   [n_interactions, then per interaction: is_send, kind, n_values, vcol(multiplicity), vcol(value_0), ...]
+ *   vcol = [n_terms, constant (canonical), then n_terms x (is_main, column, weight (canonical))]
+ * Traces: column-major device tensors with `real_rows` rows. Chips must be passed in name order (BTreeSet<Chip>). */
+typedef struct {
+    const char* name;
+    const uint32_t* interactions;
+    uint32_t n_words;
+    uint32_t main_width, prep_width;
+    const uint32_t* d_main;
+    const uint32_t* d_prep;
+    uint64_t real_rows;
+} sp1hip_gkr_chip_t;
+
+/* `GkrProverImpl::prove_logup_gkr` (/root/reference/crates/hypercube/src/logup_gkr/prover.rs:L70-L215): 12-bit grind,
+ * alpha / beta challenges, the fraction circuit over every (row, interaction) (execution.rs:L112-L382), one degree-3
+ * sumcheck per circuit layer (cpu.rs:L146-L226, logup_poly.rs:L70-L553) and the trace-column openings at the
+ * final point. Writes bincode(LogupGkrProof) (/root/reference/crates/hypercube/src/logup_gkr/proof.rs:L32-L62): its
+ * `logup_evaluations` (point + per-chip openings) are the `h_zeta` / `h_openings` inputs of
+ * sp1hip_zerocheck_prove. The challenger is advanced only on success. */
+int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_log_row_count,
+                           sp1hip_challenger_t* challenger, uint8_t* h_proof, size_t* proof_len,
+                           sp1hip_stream_t stream);
+
 /* ---------------------------------------------------------------- zerocheck (a9-a12)
  * One chip of the shard. `program` is a HOST array of n_instr [op, a, b] triples in SSA form
  * (instruction k defines value k): 0 LOAD_MAIN col, 1 LOAD_PREP col, 2 CONST canonical, 3 PUBLIC idx,

@@ -32,6 +32,12 @@ class ZcChip(C.Structure):
                 ("d_prep", C.c_void_p), ("real_rows", C.c_uint64)]
 
 
+class GkrChip(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("interactions", C.POINTER(C.c_uint32)), ("n_words", C.c_uint32),
+                ("main_width", C.c_uint32), ("prep_width", C.c_uint32), ("d_main", C.c_void_p), ("d_prep", C.c_void_p),
+                ("real_rows", C.c_uint64)]
+
+
 class FriConfig(C.Structure):
     _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("proof_of_work_bits", C.c_int)]
 
@@ -116,6 +122,7 @@ PROTOTYPES = [
     ("sp1hip_jagged_commit", None, [C.POINTER(Table), _int, _int, _int, _int, _int, u32p, C.POINTER(_vp), _vp]),
     ("sp1hip_jagged_prove", None, [C.POINTER(Ext), _int, C.POINTER(_vp), _int, C.POINTER(Ext), C.POINTER(_sz), FriConfig, _vp,
                                    u8p, C.POINTER(_sz), _vp]),
+    ("sp1hip_logup_gkr_prove", None, [C.POINTER(GkrChip), _int, _int, _vp, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
                                       _vp, u8p, C.POINTER(_sz), _vp]),
 ]

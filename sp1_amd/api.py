@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Ext, FriConfig, Table, Tensor, ZcChip, check
+from ._lib import Ext, FriConfig, GkrChip, Table, Tensor, ZcChip, check
 
 P = 0x7F000001
 
@@ -419,6 +419,74 @@ def zerocheck(chips, max_log_row_count, zeta, openings, alpha, gkr_batch, public
     buf = (C.c_uint8 * n.value)()
     check(_L().sp1hip_zerocheck_prove(*args, buf, C.byref(n), _stream_ptr(stream)))
     return bytes(buf[:n.value])
+
+
+def logup_gkr(chips, max_log_row_count, challenger, stream=None):
+    """GkrProverImpl::prove_logup_gkr on the GPU. chips: [(sp1_amd.air.InteractionProgram, main ColMajor or None,
+    prep ColMajor or None)] in name order. Returns bincode(LogupGkrProof); advances the challenger."""
+    arr = (GkrChip * len(chips))()
+    keep = []
+    for i, (prog, main, prep) in enumerate(chips):
+        words = np.ascontiguousarray(prog.to_array(), dtype=np.uint32)
+        keep.append(words)
+        rows = main.height if main is not None else (prep.height if prep is not None else 0)
+        arr[i] = GkrChip(prog.name.encode(), words.ctypes.data_as(_lib.u32p), words.size, prog.main_width, prog.prep_width,
+                         C.c_void_p(main.words.data_ptr()) if main is not None and rows and prog.main_width else None,
+                         C.c_void_p(prep.words.data_ptr()) if prep is not None and rows and prog.prep_width else None, rows)
+    n = C.c_size_t(0)
+    st = _L().sp1hip_logup_gkr_prove(arr, len(chips), max_log_row_count, challenger.h, None, C.byref(n), _stream_ptr(stream))
+    if st != -6:
+        check(st)
+        raise RuntimeError("size query unexpectedly succeeded")
+    buf = (C.c_uint8 * n.value)()
+    check(_L().sp1hip_logup_gkr_prove(arr, len(chips), max_log_row_count, challenger.h, buf, C.byref(n), _stream_ptr(stream)))
+    return bytes(buf[:n.value])
+
+
+def parse_logup_gkr_proof(blob):
+    """The `logup_evaluations` of a bincode(LogupGkrProof): (point [L][4], [(name, main [w][4], prep [w][4] or None)])
+    in Montgomery words — the zeta / openings that zerocheck consumes."""
+    import struct
+    o = 0
+
+    def u64():
+        nonlocal o
+        v = struct.unpack_from("<Q", blob, o)[0]
+        o += 8
+        return v
+
+    def exts(k):
+        nonlocal o
+        a = np.frombuffer(blob, dtype="<u4", count=4 * k, offset=o).astype(np.uint64)
+        o += 16 * k
+        return ((a << np.uint64(32)) % np.uint64(P)).astype(np.uint32).reshape(k, 4)
+
+    for _ in range(2):                                     # circuit output
+        exts(u64())
+        o += 24
+    for _ in range(u64()):                                 # round proofs
+        exts(4)
+        for _ in range(u64()):
+            exts(u64())
+        exts(1)
+        exts(u64())
+        exts(1)
+    point = exts(u64())
+    chips = []
+    for _ in range(u64()):
+        n = u64()
+        name = blob[o:o + n].decode()
+        o += n
+        main = exts(u64())
+        o += 16
+        prep = None
+        o += 1
+        if blob[o - 1]:
+            prep = exts(u64())
+            o += 16
+        chips.append((name, main, prep))
+    assert o + 4 == len(blob)
+    return point, chips
 
 
 def parse_zerocheck_proof(blob):

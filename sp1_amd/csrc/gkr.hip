@@ -1,0 +1,850 @@
+// sp1_amd/csrc/gkr.hip — LogUp-GKR on the device: the lookup argument that sits between
+// `commit_traces` and zerocheck in a shard proof.
+//
+//   sp1hip_logup_gkr_prove  `GkrProverImpl::prove_logup_gkr`   /root/reference/crates/hypercube/src/logup_gkr/prover.rs:L70-L215
+//     first layer           `generate_interaction_vals` / `generate_first_layer`   execution.rs:L13-L36, L112-L252
+//     circuit               `layer_transition`, `extract_outputs`                 execution.rs:L38-L110, L254-L382
+//     per-layer sumcheck    `prove_gkr_round` + `LogupRoundPolynomial`            cpu.rs:L146-L226, logup_poly.rs:L70-L553
+//                           driven as `reduce_sumcheck_to_evaluation`             /root/reference/slop/crates/sumcheck/src/prover.rs:L13-L96
+//   Output: bincode(LogupGkrProof) (/root/reference/crates/hypercube/src/logup_gkr/proof.rs:L32-L62).
+//
+// MI355X shape
+//  * Layout: every (chip, interaction) owns contiguous per-row vectors `N[level][i][row]`, `D[level][i][row]`
+//    over the chip's REAL rows only (padding rows are the constants (0, 1) and are never stored): a wave
+//    walks consecutive rows of one interaction, so all loads are unit-stride (4 B lanes for the base-field
+//    first-layer numerators, 16 B lanes for ext), and the interaction's program / eq weight are wave-uniform.
+//  * The fraction tree (level L -> 1) is built once and kept: level l has ceil(h / 2^(L-l)) rows per chip.
+//    The GKR layer with v row variables reads level v+1 in place (numerator_0/1 = even/odd rows).
+//  * One fused kernel per sumcheck round over a row variable: fold the previous round's four tables with
+//    alpha and accumulate the next round's three sums (y(0), 8 y(1/2), eq mass of the real entries) from
+//    the folded values in registers. The padding rows enter in closed form on the host, exactly as the
+//    reference does it (`eq_correction_term`, logup_poly.rs:L521-L530).
+//  * eq over the row variables is never folded: the per-round tables are the partial-Lagrange tables of
+//    the remaining prefix of the point, built for all prefix lengths by one launch per layer; the factor
+//    of the already-bound variables is a host scalar.
+//  * Once the row variables are bound, a layer is 2^niv x 4 values: the interaction-variable rounds run on
+//    the host (a few hundred ext products).
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_ctx.hpp"
+#include "tensor_table.hpp"
+
+namespace sp1hip {
+
+void challenger_observe(sp1hip_challenger_t* ch, uint32_t x);
+kb::Ext challenger_sample_ext(sp1hip_challenger_t* ch);
+void challenger_restore(sp1hip_challenger_t* dst, const sp1hip_challenger_t* src);
+
+namespace gkr {
+
+using Ext = kb::Ext;
+struct DeviceBuf : AsyncScratch {
+    uint32_t* u32() const { return (uint32_t*)p; }
+    Ext* ext() const { return (Ext*)p; }
+};
+
+__device__ __forceinline__ Ext ld_ext(const Ext* p, uint32_t i) {
+    const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+    return Ext{{v.x, v.y, v.z, v.w}};
+}
+__device__ __forceinline__ void st_ext(Ext* p, uint32_t i, const Ext& e) {
+    reinterpret_cast<uint4*>(p)[i] = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]);
+}
+
+// ---- block reduction of NS ext accumulators -> partials[block][4 NS]
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = kb::add(v, __shfl_down(v, off, 64));
+    return v;
+}
+template <int NS>
+__device__ __forceinline__ void block_reduce_store(const Ext (&acc)[NS], uint32_t* out) {
+    __shared__ uint32_t sm[4][4 * NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = wave_sum(acc[s].c[k]);
+            if (lane == 0) sm[wave][4 * s + k] = w;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * NS) {
+        uint32_t a = 0;
+        for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
+        out[threadIdx.x] = a;
+    }
+}
+template <int NS>
+__global__ __launch_bounds__(256) void reduce_partials(const uint32_t* __restrict__ partials, uint32_t n, uint32_t* out) {
+    Ext acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) acc[s] = kb::ext_zero();
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const uint32_t* q = partials + ((size_t)i * NS + s) * 4;
+            acc[s] = kb::ext_add(acc[s], Ext{{q[0], q[1], q[2], q[3]}});
+        }
+    block_reduce_store<NS>(acc, out);
+}
+
+// ================================================================ first layer
+// Per (chip, interaction): program words in device memory (layout of sp1_amd/air.py InteractionProgram, one
+// interaction: is_send, kind, n_values, vcol(multiplicity), vcol(values..)), column-major traces.
+struct IntDesc {
+    const uint32_t* prog;      // this interaction's words
+    const uint32_t* main;      // column-major [main_w][rows]
+    const uint32_t* prep;
+    uint32_t rows;
+    uint32_t* n_out;           // base numerators [rows]
+    Ext* d_out;                // ext denominators [rows]
+};
+
+__device__ __forceinline__ uint32_t vcol_apply(const uint32_t*& p, const IntDesc& d, uint32_t r) {
+    const uint32_t nt = p[0];
+    uint32_t acc = p[1];                                   // constant (Montgomery)
+    p += 2;
+    for (uint32_t t = 0; t < nt; t++, p += 3) {
+        const uint32_t* col = (p[0] ? d.main : d.prep) + (size_t)p[1] * d.rows;
+        acc = kb::add(acc, kb::mul(col[r], p[2]));
+    }
+    return acc;
+}
+
+// betas: [n_betas] ext (partial Lagrange of beta_seed)
+__global__ __launch_bounds__(256) void first_layer_kernel(const IntDesc* __restrict__ descs, Ext alpha, const Ext* __restrict__ betas) {
+    const IntDesc d = descs[blockIdx.y];
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < d.rows; r += gridDim.x * blockDim.x) {
+        const uint32_t* p = d.prog;
+        const bool is_send = p[0] != 0;
+        const uint32_t kind = p[1], nv = p[2];            // kind: Montgomery form
+        p += 3;
+        uint32_t m = vcol_apply(p, d, r);
+        if (!is_send) m = kb::sub(0u, m);
+        Ext den = kb::ext_add(alpha, kb::ext_mul_base(ld_ext(betas, 0), kind));
+        for (uint32_t j = 0; j < nv; j++) den = kb::ext_add(den, kb::ext_mul_base(ld_ext(betas, 1 + j), vcol_apply(p, d, r)));
+        d.n_out[r] = m;
+        st_ext(d.d_out, r, den);
+    }
+}
+
+// ================================================================ fraction tree
+struct TransDesc {
+    const void* n_in;          // base (level L) or ext
+    const Ext* d_in;
+    Ext* n_out;
+    Ext* d_out;
+    uint32_t rows_in;
+};
+
+template <bool NBASE>
+__device__ __forceinline__ Ext load_n(const void* p, uint32_t i) {
+    if (NBASE) return kb::ext_from_base(((const uint32_t*)p)[i]);
+    return ld_ext((const Ext*)p, i);
+}
+
+template <bool NBASE>
+__global__ __launch_bounds__(256) void transition_kernel(const TransDesc* __restrict__ descs) {
+    const TransDesc d = descs[blockIdx.y];
+    const uint32_t rows_out = (d.rows_in + 1) / 2;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows_out; r += gridDim.x * blockDim.x) {
+        const Ext da = ld_ext(d.d_in, 2 * r);
+        if (2 * r + 1 < d.rows_in) {
+            const Ext db = ld_ext(d.d_in, 2 * r + 1);
+            Ext n;
+            if (NBASE) {
+                const uint32_t na = ((const uint32_t*)d.n_in)[2 * r], nb = ((const uint32_t*)d.n_in)[2 * r + 1];
+                n = kb::ext_add(kb::ext_mul_base(db, na), kb::ext_mul_base(da, nb));
+            } else {
+                n = kb::ext_add(kb::ext_mul(db, load_n<false>(d.n_in, 2 * r)), kb::ext_mul(da, load_n<false>(d.n_in, 2 * r + 1)));
+            }
+            st_ext(d.n_out, r, n);
+            st_ext(d.d_out, r, kb::ext_mul(da, db));
+        } else {                                           // partner is a padding row: (0, 1)
+            st_ext(d.n_out, r, load_n<NBASE>(d.n_in, 2 * r));
+            st_ext(d.d_out, r, da);
+        }
+    }
+}
+
+// ================================================================ eq tables of one layer
+// out holds, for t = 0 .. v, the partial-Lagrange table of the first t coordinates of `pt` at offset 2^t - 1... i.e.
+// table t occupies [2^t - 1, 2^(t+1) - 1). Thread g -> (t, i).
+struct PointArg { Ext c[32]; };
+__global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int v, Ext* __restrict__ out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x + 1;       // 1 .. 2^(v+1) - 1
+    if (g >= (2u << v)) return;
+    const int t = 31 - __clz(g);
+    const uint32_t i = g - (1u << t);
+    Ext acc = kb::ext_one();
+    for (int j = 0; j < t; j++) {
+        const bool bit = (i >> (t - 1 - j)) & 1u;
+        acc = kb::ext_mul(acc, bit ? pt.c[j] : kb::ext_sub(kb::ext_one(), pt.c[j]));
+    }
+    st_ext(out, g - 1, acc);
+}
+
+// ================================================================ sumcheck rounds over a row variable
+// Per (chip, interaction): the sources of one round.
+//  FIRST (interleaved): x_n / x_d = level v+1 vectors (rows_x real entries); row r of the layer is the pair
+//                       (entry 2r = "0" half, entry 2r+1 = "1" half).
+//  later: four separate vectors n0, d0, n1, d1 with `rows` real entries each.
+struct RoundDesc {
+    const void* src[4];        // FIRST: {x_n, x_d, -, -}; later: {n0, d0, n1, d1}
+    Ext* dst[4];               // folded n0, d0, n1, d1
+    uint32_t rows;             // real rows r of the layer at this round (FIRST: ceil(rows_x / 2))
+    uint32_t rows_x;           // FIRST only
+    uint32_t eq_int_index;     // global interaction index
+};
+
+struct Quad { Ext n0, d0, n1, d1; };
+
+template <bool FIRST, bool NBASE>
+__device__ __forceinline__ Quad load_quad(const RoundDesc& d, uint32_t r) {
+    Quad q;
+    if (r >= d.rows) { q.n0 = q.n1 = kb::ext_zero(); q.d0 = q.d1 = kb::ext_one(); return q; }
+    if (FIRST) {
+        q.n0 = load_n<NBASE>(d.src[0], 2 * r);
+        q.d0 = ld_ext((const Ext*)d.src[1], 2 * r);
+        if (2 * r + 1 < d.rows_x) { q.n1 = load_n<NBASE>(d.src[0], 2 * r + 1); q.d1 = ld_ext((const Ext*)d.src[1], 2 * r + 1); }
+        else { q.n1 = kb::ext_zero(); q.d1 = kb::ext_one(); }
+    } else {
+        q.n0 = ld_ext((const Ext*)d.src[0], r); q.d0 = ld_ext((const Ext*)d.src[1], r);
+        q.n1 = ld_ext((const Ext*)d.src[2], r); q.d1 = ld_ext((const Ext*)d.src[3], r);
+    }
+    return q;
+}
+
+__device__ __forceinline__ Ext lerp(const Ext& a, const Ext& b, const Ext& t) { return kb::ext_add(a, kb::ext_mul(t, kb::ext_sub(b, a))); }
+
+// accumulate the three sums of one row pair (a = row 2k, b = row 2k+1) weighted by w = eq_int: S0 += w T[2k] F(a),
+// Sh += w (T[2k] + T[2k+1]) Fh(a + b), Seq += w (T[2k] + T[2k+1])
+__device__ __forceinline__ void accumulate_pair(const Quad& a, const Quad& b, const Ext& lambda, const Ext& ta, const Ext& tb,
+                                                Ext (&acc)[3]) {
+    const Ext f0 = kb::ext_add(kb::ext_mul(lambda, kb::ext_add(kb::ext_mul(a.n0, a.d1), kb::ext_mul(a.n1, a.d0))), kb::ext_mul(a.d0, a.d1));
+    const Ext sn0 = kb::ext_add(a.n0, b.n0), sn1 = kb::ext_add(a.n1, b.n1), sd0 = kb::ext_add(a.d0, b.d0), sd1 = kb::ext_add(a.d1, b.d1);
+    const Ext fh = kb::ext_add(kb::ext_mul(lambda, kb::ext_add(kb::ext_mul(sn0, sd1), kb::ext_mul(sn1, sd0))), kb::ext_mul(sd0, sd1));
+    const Ext ts = kb::ext_add(ta, tb);
+    acc[0] = kb::ext_add(acc[0], kb::ext_mul(ta, f0));
+    acc[1] = kb::ext_add(acc[1], kb::ext_mul(ts, fh));
+    acc[2] = kb::ext_add(acc[2], ts);
+}
+
+// round 0 of a layer: sums only. T = partial-Lagrange table of the layer's row point (2^v entries)
+template <bool NBASE>
+__global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
+                                                       const Ext* __restrict__ T, Ext lambda, uint32_t* __restrict__ partials) {
+    const RoundDesc d = descs[blockIdx.y];
+    Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+    const uint32_t pairs = (d.rows + 1) / 2;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < pairs; k += gridDim.x * blockDim.x) {
+        const Quad a = load_quad<true, NBASE>(d, 2 * k), b = load_quad<true, NBASE>(d, 2 * k + 1);
+        accumulate_pair(a, b, lambda, ld_ext(T, 2 * k), ld_ext(T, 2 * k + 1), acc);
+    }
+    const Ext w = ld_ext(eq_int, d.eq_int_index);
+#pragma unroll
+    for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+    block_reduce_store<3>(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12);
+}
+
+// fold rows (2r', 2r'+1) -> r' with alpha for r' = 2k, 2k+1, store, and (if SUM) accumulate the next round's sums
+// from the folded pair. T_next = table of the remaining row variables (half the size).
+template <bool FIRST, bool NBASE, bool SUM>
+__global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
+                                                      const Ext* __restrict__ T_next, Ext lambda, Ext alpha,
+                                                      uint32_t* __restrict__ partials) {
+    const RoundDesc d = descs[blockIdx.y];
+    Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+    const uint32_t rows_out = (d.rows + 1) / 2;
+    const uint32_t pairs = (rows_out + 1) / 2;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < pairs; k += gridDim.x * blockDim.x) {
+        Quad o[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t ro = 2 * k + h;
+            const Quad a = load_quad<FIRST, NBASE>(d, 2 * ro), b = load_quad<FIRST, NBASE>(d, 2 * ro + 1);
+            o[h].n0 = lerp(a.n0, b.n0, alpha); o[h].d0 = lerp(a.d0, b.d0, alpha);
+            o[h].n1 = lerp(a.n1, b.n1, alpha); o[h].d1 = lerp(a.d1, b.d1, alpha);
+            if (ro < rows_out) { st_ext(d.dst[0], ro, o[h].n0); st_ext(d.dst[1], ro, o[h].d0); st_ext(d.dst[2], ro, o[h].n1); st_ext(d.dst[3], ro, o[h].d1); }
+        }
+        if (SUM) accumulate_pair(o[0], o[1], lambda, ld_ext(T_next, 2 * k), ld_ext(T_next, 2 * k + 1), acc);
+    }
+    if (SUM) {
+        const Ext w = ld_ext(eq_int, d.eq_int_index);
+#pragma unroll
+        for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+        block_reduce_store<3>(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12);
+    }
+}
+
+// ================================================================ trace openings at the final point
+struct OpenDesc { const uint32_t* cols; uint32_t rows, width, col0, out0; };   // one group of <= 8 columns of one chip
+constexpr int OPEN_COLS = 8, OPEN_ROWS = 4096;
+__global__ __launch_bounds__(256) void open_columns_kernel(const OpenDesc* __restrict__ descs, const uint32_t* __restrict__ eq,
+                                                           uint32_t eq_len, uint32_t* __restrict__ partials, uint32_t total_cols) {
+    const OpenDesc d = descs[blockIdx.y];
+    const uint32_t r0 = blockIdx.x * OPEN_ROWS;
+    Ext acc[OPEN_COLS];
+#pragma unroll
+    for (int c = 0; c < OPEN_COLS; c++) acc[c] = kb::ext_zero();
+    if (r0 < d.rows) {
+        for (uint32_t r = r0 + threadIdx.x; r < r0 + OPEN_ROWS && r < d.rows; r += 256) {
+            const Ext e{{eq[r], eq[eq_len + r], eq[2 * (size_t)eq_len + r], eq[3 * (size_t)eq_len + r]}};
+#pragma unroll
+            for (int c = 0; c < OPEN_COLS; c++)
+                if (d.col0 + c < d.width) acc[c] = kb::ext_add(acc[c], kb::ext_mul_base(e, d.cols[(size_t)(d.col0 + c) * d.rows + r]));
+        }
+    }
+    __shared__ uint32_t sm[4][4 * OPEN_COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < OPEN_COLS; c++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = wave_sum(acc[c].c[k]);
+            if (lane == 0) sm[wave][4 * c + k] = w;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * OPEN_COLS) {
+        const int c = threadIdx.x / 4;
+        if (d.col0 + c < d.width) {
+            uint32_t a = 0;
+            for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
+            partials[((size_t)blockIdx.x * total_cols + d.out0 + c) * 4 + (threadIdx.x & 3)] = a;
+        }
+    }
+}
+__global__ void open_sum_kernel(const uint32_t* __restrict__ partials, uint32_t n_chunks, uint32_t n_words, uint32_t* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_words) return;
+    uint32_t acc = 0;
+    for (uint32_t c = 0; c < n_chunks; c++) acc = kb::add(acc, partials[(size_t)c * n_words + j]);
+    out[j] = acc;
+}
+
+// ================================================================ host side
+Ext operator+(const Ext& a, const Ext& b) { return kb::ext_add(a, b); }
+Ext operator-(const Ext& a, const Ext& b) { return kb::ext_sub(a, b); }
+Ext operator*(const Ext& a, const Ext& b) { return kb::ext_mul(a, b); }
+Ext ext_c(uint32_t canonical) { return kb::ext_from_base(kb::to_monty(canonical)); }
+int log2_ceil(uint64_t x) { int l = 0; while (((uint64_t)1 << l) < x) l++; return l; }
+
+std::vector<Ext> partial_lagrange_host(const std::vector<Ext>& pt) {
+    std::vector<Ext> ev{kb::ext_one()};
+    for (const Ext& x : pt) {
+        std::vector<Ext> nx(ev.size() * 2);
+        for (size_t i = 0; i < ev.size(); i++) { const Ext pr = ev[i] * x; nx[2 * i] = ev[i] - pr; nx[2 * i + 1] = pr; }
+        ev.swap(nx);
+    }
+    return ev;
+}
+Ext eval_mle_host(const std::vector<Ext>& vals, const std::vector<Ext>& pt) {
+    const std::vector<Ext> eq = partial_lagrange_host(pt);
+    Ext acc = kb::ext_zero();
+    for (size_t i = 0; i < vals.size(); i++) acc = acc + eq[i] * vals[i];
+    return acc;
+}
+
+using Poly4 = std::array<Ext, 4>;
+Ext poly_eval(const Poly4& c, const Ext& x) { return ((c[3] * x + c[2]) * x + c[1]) * x + c[0]; }
+
+// the cubic through (0, y0), (1, y1), (1/2, yh), (b, 0): Lagrange interpolation as the reference's
+// interpolate_univariate_polynomial (univariate.rs:L85-L97) — any exact method gives the same coefficients
+Poly4 interpolate4(const Ext (&xs)[4], const Ext (&ys)[4]) {
+    Poly4 res{kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+    for (int i = 0; i < 4; i++) {
+        Ext den = kb::ext_one();
+        Ext num[4] = {ys[i], kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+        int deg = 0;
+        for (int j = 0; j < 4; j++) {
+            if (j == i) continue;
+            den = den * (xs[i] - xs[j]);
+            Ext nxt[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+            for (int k = 0; k <= deg; k++) { nxt[k + 1] = nxt[k + 1] + num[k]; nxt[k] = nxt[k] - num[k] * xs[j]; }
+            deg++;
+            for (int k = 0; k < 4; k++) num[k] = nxt[k];
+        }
+        const Ext inv = kb::ext_inv(den);
+        for (int k = 0; k < 4; k++) res[k] = res[k] + num[k] * inv;
+    }
+    return res;
+}
+
+struct Bytes {
+    std::vector<uint8_t> b;
+    void u64(uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+    void felt(uint32_t m) { const uint32_t v = kb::from_monty(m); for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+    void ext(const Ext& e) { for (int k = 0; k < 4; k++) felt(e.c[k]); }
+};
+
+void observe_ext(sp1hip_challenger_t* ch, const Ext& e) { for (int k = 0; k < 4; k++) challenger_observe(ch, e.c[k]); }
+
+int upload(DeviceBuf& buf, const void* src, size_t bytes, hipStream_t s) {
+    SP1HIP_TRY(buf.alloc(std::max<size_t>(bytes, 16), s));
+    if (bytes) SP1HIP_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s));
+    return SP1HIP_SUCCESS;
+}
+
+struct ChipInfo {
+    std::string name;
+    uint32_t rows, k, main_w, prep_w, int0;                 // k interactions, int0 = first global interaction index
+    const uint32_t* d_main;
+    const uint32_t* d_prep;
+};
+
+constexpr uint32_t MAX_TILES = 512;
+uint32_t tiles_for(uint64_t threads) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), MAX_TILES); }
+
+}  // namespace gkr
+}  // namespace sp1hip
+
+using namespace sp1hip;
+using namespace sp1hip::gkr;
+
+extern "C" {
+
+int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_log_row_count, sp1hip_challenger_t* challenger,
+                           uint8_t* h_proof, size_t* proof_len, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(chips && n_chips > 0 && challenger && proof_len, "bad argument");
+    const int L = max_log_row_count;
+    SP1HIP_REQUIRE(L >= 1 && L <= 30, "max_log_row_count out of range");
+    hipStream_t s = S(stream);
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));
+
+    // ---- parse the interaction programs (host words -> Montgomery device words), gather shapes
+    std::vector<ChipInfo> info(n_chips);
+    std::vector<std::vector<uint32_t>> progs;               // per global interaction: device-form words
+    size_t max_arity = 0, total_cols = 0;
+    for (int c = 0; c < n_chips; c++) {
+        const sp1hip_gkr_chip_t& ci = chips[c];
+        SP1HIP_REQUIRE(ci.name && ci.interactions, "null chip field");
+        SP1HIP_REQUIRE(ci.real_rows <= ((uint64_t)1 << L), "chip taller than 2^max_log_row_count");
+        SP1HIP_REQUIRE(ci.real_rows == 0 || ci.main_width == 0 || ci.d_main, "null main trace");
+        SP1HIP_REQUIRE(ci.real_rows == 0 || ci.prep_width == 0 || ci.d_prep, "null preprocessed trace");
+        if (c) SP1HIP_REQUIRE(strcmp(chips[c - 1].name, ci.name) < 0, "chips must be sorted by name (BTreeSet order)");
+        info[c] = ChipInfo{ci.name, (uint32_t)ci.real_rows, 0, ci.main_width, ci.prep_width, (uint32_t)progs.size(), ci.d_main, ci.d_prep};
+        const uint32_t* p = ci.interactions;
+        const uint32_t* end = p + ci.n_words;
+        SP1HIP_REQUIRE(ci.n_words >= 1, "empty interaction program");
+        const uint32_t ni = *p++;
+        info[c].k = ni;
+        auto vcol = [&](std::vector<uint32_t>& out) -> bool {
+            if (p + 2 > end) return false;
+            const uint32_t nt = p[0];
+            if (p[1] >= kb::P || p + 2 + 3 * (size_t)nt > end) return false;
+            out.push_back(nt);
+            out.push_back(kb::to_monty(p[1]));
+            p += 2;
+            for (uint32_t t = 0; t < nt; t++, p += 3) {
+                if (p[0] > 1 || p[2] >= kb::P) return false;
+                if (p[1] >= (p[0] ? ci.main_width : ci.prep_width)) return false;
+                out.push_back(p[0]); out.push_back(p[1]); out.push_back(kb::to_monty(p[2]));
+            }
+            return true;
+        };
+        for (uint32_t i = 0; i < ni; i++) {
+            SP1HIP_REQUIRE(p + 3 <= end, "truncated interaction program");
+            std::vector<uint32_t> w{p[0], kb::to_monty(p[1] % kb::P), p[2]};
+            const uint32_t nv = p[2];
+            SP1HIP_REQUIRE(p[0] <= 1 && p[1] < kb::P && nv < 64, "bad interaction header");
+            p += 3;
+            SP1HIP_REQUIRE(vcol(w), "bad multiplicity column");
+            for (uint32_t j = 0; j < nv; j++) SP1HIP_REQUIRE(vcol(w), "bad value column (index or weight out of range)");
+            max_arity = std::max<size_t>(max_arity, nv + 1);
+            progs.push_back(std::move(w));
+        }
+        SP1HIP_REQUIRE(p == end, "trailing words in interaction program");
+        total_cols += (size_t)ci.main_width + ci.prep_width;
+    }
+    const uint32_t K = (uint32_t)progs.size();
+    SP1HIP_REQUIRE(K >= 1, "no interactions in the shard");
+    const int niv = log2_ceil(K), beta_seed_dim = log2_ceil(max_arity);
+    const uint32_t W = 1u << niv;
+
+    // ---- proof size (everything is determined by the shapes)
+    size_t need = 2 * (8 + (size_t)2 * W * 16 + 24) + 8;
+    for (int v = 1; v <= L - 1; v++) need += 64 + 8 + (size_t)(niv + v) * (8 + 64) + 16 + 8 + (size_t)(niv + v) * 16 + 16;
+    need += 8 + (size_t)L * 16 + 8;
+    for (int c = 0; c < n_chips; c++) {
+        need += 8 + info[c].name.size() + 8 + (size_t)info[c].main_w * 16 + 16 + 1;
+        if (info[c].prep_w) need += 8 + (size_t)info[c].prep_w * 16 + 16;
+    }
+    need += 4;
+    if (!h_proof || *proof_len < need) {
+        *proof_len = need;
+        set_error("sp1hip_logup_gkr_prove: proof buffer too small, need %zu bytes", need);
+        return SP1HIP_ERROR_BUFFER_TOO_SMALL;
+    }
+
+    sp1hip_challenger_t* ch = nullptr;
+    SP1HIP_TRY(sp1hip_challenger_clone(challenger, &ch));
+    struct ChGuard { sp1hip_challenger_t* c; ~ChGuard() { sp1hip_challenger_free(c); } } guard{ch};
+
+    // ---- transcript head (prover.rs:L86-L95)
+    uint32_t witness = 0;
+    SP1HIP_TRY(sp1hip_challenger_grind(ch, 12, &witness, stream));
+    const Ext alpha = challenger_sample_ext(ch);
+    std::vector<Ext> beta_seed(beta_seed_dim);
+    for (auto& b : beta_seed) b = challenger_sample_ext(ch);
+    (void)challenger_sample_ext(ch);                         // _pv_challenge
+    const std::vector<Ext> betas = partial_lagrange_host(beta_seed);
+
+    // ---- device storage: levels L .. 1 of the fraction tree, per interaction
+    // rows at level l of chip c: ceil(h / 2^(L - l))
+    auto rows_at = [&](uint32_t h, int l) -> uint32_t { return (uint32_t)(((uint64_t)h + (((uint64_t)1 << (L - l)) - 1)) >> (L - l)); };
+    std::vector<uint32_t> int_chip(K);
+    for (int c = 0; c < n_chips; c++) for (uint32_t i = 0; i < info[c].k; i++) int_chip[info[c].int0 + i] = c;
+    std::vector<size_t> level_entries(L + 2, 0);            // total entries of level l over all interactions
+    for (int l = 1; l <= L; l++) for (uint32_t i = 0; i < K; i++) level_entries[l] += rows_at(info[int_chip[i]].rows, l);
+    std::vector<DeviceBuf> lvN(L + 1), lvD(L + 1);
+    for (int l = 1; l <= L; l++) {
+        SP1HIP_TRY(lvN[l].alloc(std::max<size_t>(level_entries[l], 1) * (l == L ? 4 : 16), s));
+        SP1HIP_TRY(lvD[l].alloc(std::max<size_t>(level_entries[l], 1) * 16, s));
+    }
+    // offsets of interaction i inside level l
+    std::vector<std::vector<size_t>> off(L + 1, std::vector<size_t>(K + 1, 0));
+    for (int l = 1; l <= L; l++) for (uint32_t i = 0; i < K; i++) off[l][i + 1] = off[l][i] + rows_at(info[int_chip[i]].rows, l);
+    auto n_ptr = [&](int l, uint32_t i) -> void* { return (char*)lvN[l].p + off[l][i] * (l == L ? 4 : 16); };
+    auto d_ptr = [&](int l, uint32_t i) -> Ext* { return lvD[l].ext() + off[l][i]; };
+
+    // ---- first layer
+    DeviceBuf d_progs, d_betas, d_descs;
+    uint32_t max_rows = 0;
+    {
+        std::vector<uint32_t> flat;
+        std::vector<size_t> poff(K);
+        for (uint32_t i = 0; i < K; i++) { poff[i] = flat.size(); flat.insert(flat.end(), progs[i].begin(), progs[i].end()); }
+        SP1HIP_TRY(upload(d_progs, flat.data(), flat.size() * 4, s));
+        SP1HIP_TRY(upload(d_betas, betas.data(), betas.size() * 16, s));
+        std::vector<IntDesc> descs(K);
+        for (uint32_t i = 0; i < K; i++) {
+            const ChipInfo& c = info[int_chip[i]];
+            descs[i] = IntDesc{d_progs.u32() + poff[i], c.d_main, c.d_prep, c.rows, (uint32_t*)n_ptr(L, i), d_ptr(L, i)};
+            max_rows = std::max(max_rows, c.rows);
+        }
+        SP1HIP_TRY(upload(d_descs, descs.data(), descs.size() * sizeof(IntDesc), s));
+        if (max_rows) {
+            ScopedTimer t("gkr_first_layer", s);
+            hipLaunchKernelGGL(first_layer_kernel, dim3(tiles_for(max_rows), K), dim3(256), 0, s, (const IntDesc*)d_descs.p, alpha,
+                               (const Ext*)d_betas.p);
+            SP1HIP_LAUNCH_CHECK();
+        }
+    }
+    // ---- fraction tree
+    DeviceBuf d_trans;
+    SP1HIP_TRY(d_trans.alloc((size_t)K * sizeof(TransDesc), s));
+    std::vector<TransDesc> tdesc(K);
+    for (int l = L; l >= 2; l--) {
+        uint32_t mr = 0;
+        for (uint32_t i = 0; i < K; i++) {
+            const uint32_t rin = rows_at(info[int_chip[i]].rows, l);
+            tdesc[i] = TransDesc{n_ptr(l, i), d_ptr(l, i), (Ext*)n_ptr(l - 1, i), d_ptr(l - 1, i), rin};
+            mr = std::max(mr, (rin + 1) / 2);
+        }
+        if (!mr) continue;
+        SP1HIP_HIP(hipMemcpyAsync(d_trans.p, tdesc.data(), (size_t)K * sizeof(TransDesc), hipMemcpyHostToDevice, s));
+        ScopedTimer t("gkr_transition", s);
+        if (l == L) hipLaunchKernelGGL(transition_kernel<true>, dim3(tiles_for(mr), K), dim3(256), 0, s, (const TransDesc*)d_trans.p);
+        else hipLaunchKernelGGL(transition_kernel<false>, dim3(tiles_for(mr), K), dim3(256), 0, s, (const TransDesc*)d_trans.p);
+        SP1HIP_LAUNCH_CHECK();
+        SP1HIP_HIP(hipStreamSynchronize(s));                 // tdesc is reused by the next level
+    }
+    // ---- circuit output = level 1 (<= 2 rows per interaction): index 2 i + r, padding (0, 1)
+    std::vector<Ext> out_n(2 * (size_t)W, kb::ext_zero()), out_d(2 * (size_t)W, kb::ext_one());
+    {
+        std::vector<Ext> hn(std::max<size_t>(level_entries[1], 1)), hd(std::max<size_t>(level_entries[1], 1));
+        if (L >= 2) {
+            SP1HIP_HIP(hipMemcpyAsync(hn.data(), lvN[1].p, level_entries[1] * 16, hipMemcpyDeviceToHost, s));
+        } else {                                             // L == 1: level 1 is the first layer itself (base numerators)
+            std::vector<uint32_t> hb(std::max<size_t>(level_entries[1], 1));
+            SP1HIP_HIP(hipMemcpyAsync(hb.data(), lvN[1].p, level_entries[1] * 4, hipMemcpyDeviceToHost, s));
+            SP1HIP_HIP(hipStreamSynchronize(s));
+            for (size_t e = 0; e < level_entries[1]; e++) hn[e] = kb::ext_from_base(hb[e]);
+        }
+        SP1HIP_HIP(hipMemcpyAsync(hd.data(), lvD[1].p, level_entries[1] * 16, hipMemcpyDeviceToHost, s));
+        SP1HIP_HIP(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < K; i++)
+            for (uint32_t r = 0; r < rows_at(info[int_chip[i]].rows, 1); r++) { out_n[2 * i + r] = hn[off[1][i] + r]; out_d[2 * i + r] = hd[off[1][i] + r]; }
+    }
+    challenger_observe(ch, kb::to_monty(2 * W));
+    for (auto& e : out_n) observe_ext(ch, e);
+    challenger_observe(ch, kb::to_monty(2 * W));
+    for (auto& e : out_d) observe_ext(ch, e);
+    std::vector<Ext> eval_point(niv + 1);
+    for (auto& z : eval_point) z = challenger_sample_ext(ch);
+    Ext num_eval = eval_mle_host(out_n, eval_point), den_eval = eval_mle_host(out_d, eval_point);
+
+    // ---- GKR rounds, layer v = 1 .. L-1 (reads level v + 1)
+    struct RoundOut { Ext n0, n1, d0, d1; std::vector<Poly4> polys; Ext claimed_sum, eval; std::vector<Ext> point; };
+    std::vector<RoundOut> rounds;
+    DeviceBuf d_rdesc, d_eq_int, d_T, d_partials, d_out, scratch[2];
+    SP1HIP_TRY(d_rdesc.alloc((size_t)K * sizeof(RoundDesc), s));
+    SP1HIP_TRY(d_eq_int.alloc((size_t)W * 16, s));
+    SP1HIP_TRY(d_T.alloc(((size_t)2 << std::max(L - 1, 1)) * 16, s));
+    SP1HIP_TRY(d_partials.alloc((size_t)K * MAX_TILES * 48, s));
+    SP1HIP_TRY(d_out.alloc(48, s));
+    // folded tables: 4 vectors per interaction, at most ceil(rows(level v+1) / 4) entries each after the first fold
+    size_t scratch_entries = 0;
+    for (uint32_t i = 0; i < K; i++) scratch_entries += (rows_at(info[int_chip[i]].rows, L) + 3) / 4 + 1;
+    for (int b = 0; b < 2; b++) SP1HIP_TRY(scratch[b].alloc(std::max<size_t>(scratch_entries, 1) * 64, s));
+    std::vector<RoundDesc> rdesc(K);
+    const Ext one = kb::ext_one(), inv8 = kb::ext_inv(ext_c(8)), inv2 = kb::ext_inv(ext_c(2)), four = ext_c(4);
+    uint32_t h_sums[12];
+
+    for (int v = 1; v <= L - 1; v++) {
+        const Ext lambda = challenger_sample_ext(ch);
+        RoundOut ro;
+        Ext claim = num_eval * lambda + den_eval;
+        ro.claimed_sum = claim;
+        const std::vector<Ext> int_point(eval_point.begin(), eval_point.begin() + niv), row_point(eval_point.begin() + niv, eval_point.end());
+        const std::vector<Ext> eq_int = partial_lagrange_host(int_point);
+        SP1HIP_HIP(hipMemcpyAsync(d_eq_int.p, eq_int.data(), (size_t)W * 16, hipMemcpyHostToDevice, s));
+        PointArg pa{};
+        for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
+        hipLaunchKernelGGL(eq_prefix_tables_kernel, dim3(((2u << v) + 255) / 256), dim3(256), 0, s, pa, v, d_T.ext());
+        SP1HIP_LAUNCH_CHECK();
+        auto T_of = [&](int t) -> const Ext* { return d_T.ext() + (((size_t)1 << t) - 1); };
+
+        std::vector<Ext> alphas;
+        Ext PA = one;                                        // eq factor of the row variables bound so far
+        Poly4 poly{};
+        Ext alpha_r = kb::ext_zero();
+        // per-interaction live row counts of the current round
+        std::vector<uint32_t> live(K);
+        uint32_t max_live = 0;
+        for (uint32_t i = 0; i < K; i++) { live[i] = (rows_at(info[int_chip[i]].rows, v + 1) + 1) / 2; max_live = std::max(max_live, live[i]); }
+        int cur = 0;
+        auto scratch_ptr = [&](int b, uint32_t i, int which, const std::vector<size_t>& so) -> Ext* { return scratch[b].ext() + 4 * so[i] + (size_t)which * (so[i + 1] - so[i]); };
+        std::vector<size_t> so_prev, so_next;
+        for (int j = 0; j < v; j++) {                        // row-variable rounds
+            const int t = v - j;                             // remaining row variables
+            uint32_t tiles;
+            if (j == 0) {
+                for (uint32_t i = 0; i < K; i++) {
+                    rdesc[i] = RoundDesc{};
+                    rdesc[i].src[0] = n_ptr(v + 1, i); rdesc[i].src[1] = d_ptr(v + 1, i);
+                    rdesc[i].rows = live[i]; rdesc[i].rows_x = rows_at(info[int_chip[i]].rows, v + 1); rdesc[i].eq_int_index = i;
+                }
+                SP1HIP_HIP(hipMemcpyAsync(d_rdesc.p, rdesc.data(), (size_t)K * sizeof(RoundDesc), hipMemcpyHostToDevice, s));
+                tiles = tiles_for((max_live + 1) / 2);
+                ScopedTimer tm("gkr_round_sum_first", s);
+                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32());
+                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32());
+            } else {
+                // fold round j-1 with alpha_r into scratch[cur], summing round j
+                so_next.assign(K + 1, 0);
+                uint32_t max_out = 0;
+                for (uint32_t i = 0; i < K; i++) { const uint32_t o = (live[i] + 1) / 2; so_next[i + 1] = so_next[i] + o; max_out = std::max(max_out, o); }
+                for (uint32_t i = 0; i < K; i++) {
+                    RoundDesc& d = rdesc[i];
+                    d = RoundDesc{};
+                    if (j == 1) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
+                    else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
+                    for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
+                    d.rows = live[i]; d.eq_int_index = i;
+                }
+                SP1HIP_HIP(hipMemcpyAsync(d_rdesc.p, rdesc.data(), (size_t)K * sizeof(RoundDesc), hipMemcpyHostToDevice, s));
+                tiles = tiles_for((max_out + 1) / 2);
+                ScopedTimer tm("gkr_round_fold_sum", s);
+                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32());
+                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32());
+                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32());
+                for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2;
+                so_prev = so_next;
+                cur ^= 1;
+            }
+            SP1HIP_LAUNCH_CHECK();
+            hipLaunchKernelGGL(reduce_partials<3>, dim3(1), dim3(256), 0, s, d_partials.u32(), K * tiles, d_out.u32());
+            SP1HIP_LAUNCH_CHECK();
+            SP1HIP_HIP(hipMemcpyAsync(h_sums, d_out.p, 48, hipMemcpyDeviceToHost, s));
+            SP1HIP_HIP(hipStreamSynchronize(s));
+            Ext S0, Sh, Seq;
+            memcpy(&S0, h_sums, 16); memcpy(&Sh, h_sums + 4, 16); memcpy(&Seq, h_sums + 8, 16);
+            const Ext pt = row_point[t - 1];
+            const Ext corr = one - Seq;                      // eq mass of the padding entries (before the PA factor)
+            const Ext p0 = PA * (S0 + corr * (one - pt));
+            const Ext ph = PA * (Sh + corr * four) * inv8;
+            const Ext xs[4] = {kb::ext_zero(), one, inv2, (one - pt) * kb::ext_inv(one - (pt + pt))};
+            const Ext ys[4] = {p0, claim - p0, ph, kb::ext_zero()};
+            poly = interpolate4(xs, ys);
+            ro.polys.push_back(poly);
+            for (auto& c : poly) observe_ext(ch, c);
+            alpha_r = challenger_sample_ext(ch);
+            alphas.push_back(alpha_r);
+            claim = poly_eval(poly, alpha_r);
+            PA = PA * (pt * alpha_r + (one - pt) * (one - alpha_r));
+        }
+        // bind the last row variable: one value per (interaction, table), dense over 2^niv on the host
+        std::vector<Ext> tn0(W, kb::ext_zero()), td0(W, one), tn1(W, kb::ext_zero()), td1(W, one);
+        {
+            so_next.assign(K + 1, 0);
+            for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + (live[i] + 1) / 2;
+            uint32_t max_out = 0;
+            for (uint32_t i = 0; i < K; i++) {
+                RoundDesc& d = rdesc[i];
+                d = RoundDesc{};
+                if (v == 1) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
+                else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
+                for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
+                d.rows = live[i]; d.eq_int_index = i;
+                max_out = std::max<uint32_t>(max_out, (live[i] + 1) / 2);
+            }
+            SP1HIP_HIP(hipMemcpyAsync(d_rdesc.p, rdesc.data(), (size_t)K * sizeof(RoundDesc), hipMemcpyHostToDevice, s));
+            const uint32_t tiles = tiles_for((max_out + 1) / 2);
+            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32());
+            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32());
+            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32());
+            SP1HIP_LAUNCH_CHECK();
+            std::vector<Ext> host(std::max<size_t>(so_next[K], 1) * 4);
+            SP1HIP_HIP(hipMemcpyAsync(host.data(), scratch[cur].p, so_next[K] * 64, hipMemcpyDeviceToHost, s));
+            SP1HIP_HIP(hipStreamSynchronize(s));
+            for (uint32_t i = 0; i < K; i++) {
+                if (so_next[i + 1] == so_next[i]) continue;   // chip without rows: stays (0, 1)
+                const size_t base = 4 * so_next[i], len = so_next[i + 1] - so_next[i];
+                tn0[i] = host[base]; td0[i] = host[base + len]; tn1[i] = host[base + 2 * len]; td1[i] = host[base + 3 * len];
+            }
+        }
+        // interaction-variable rounds on the host (InteractionLayer, logup_poly.rs:L240-L316); eq_adjustment = PA
+        std::vector<Ext> eqi = eq_int;
+        for (int j = 0; j < niv; j++) {
+            const size_t half = eqi.size() / 2;
+            Ext s0 = kb::ext_zero(), sh = kb::ext_zero();
+            for (size_t k = 0; k < half; k++) {
+                const size_t a = 2 * k, b = 2 * k + 1;
+                s0 = s0 + eqi[a] * (lambda * (td0[a] * tn1[a] + td1[a] * tn0[a]) + td0[a] * td1[a]);
+                const Ext sn0 = tn0[a] + tn0[b], sn1 = tn1[a] + tn1[b], sd0 = td0[a] + td0[b], sd1 = td1[a] + td1[b];
+                sh = sh + (eqi[a] + eqi[b]) * (lambda * (sd0 * sn1 + sd1 * sn0) + sd0 * sd1);
+            }
+            const Ext pt = int_point[niv - 1 - j];
+            const Ext p0 = PA * s0, ph = PA * sh * inv8;
+            const Ext xs[4] = {kb::ext_zero(), one, inv2, (one - pt) * kb::ext_inv(one - (pt + pt))};
+            const Ext ys[4] = {p0, claim - p0, ph, kb::ext_zero()};
+            poly = interpolate4(xs, ys);
+            ro.polys.push_back(poly);
+            for (auto& c : poly) observe_ext(ch, c);
+            alpha_r = challenger_sample_ext(ch);
+            alphas.push_back(alpha_r);
+            claim = poly_eval(poly, alpha_r);
+            for (size_t k = 0; k < half; k++) {
+                tn0[k] = tn0[2 * k] + alpha_r * (tn0[2 * k + 1] - tn0[2 * k]); td0[k] = td0[2 * k] + alpha_r * (td0[2 * k + 1] - td0[2 * k]);
+                tn1[k] = tn1[2 * k] + alpha_r * (tn1[2 * k + 1] - tn1[2 * k]); td1[k] = td1[2 * k] + alpha_r * (td1[2 * k + 1] - td1[2 * k]);
+                eqi[k] = eqi[2 * k] + alpha_r * (eqi[2 * k + 1] - eqi[2 * k]);
+            }
+            tn0.resize(half); td0.resize(half); tn1.resize(half); td1.resize(half); eqi.resize(half);
+        }
+        ro.eval = claim;
+        ro.point.assign(alphas.rbegin(), alphas.rend());
+        ro.n0 = tn0[0]; ro.d0 = td0[0]; ro.n1 = tn1[0]; ro.d1 = td1[0];
+        observe_ext(ch, ro.n0); observe_ext(ch, ro.n1); observe_ext(ch, ro.d0); observe_ext(ch, ro.d1);
+        eval_point = ro.point;
+        const Ext lc = challenger_sample_ext(ch);
+        num_eval = ro.n0 + (ro.n1 - ro.n0) * lc;
+        den_eval = ro.d0 + (ro.d1 - ro.d0) * lc;
+        eval_point.push_back(lc);
+        rounds.push_back(std::move(ro));
+    }
+
+    // ---- trace openings at the last L coordinates
+    const std::vector<Ext> trace_point(eval_point.end() - L, eval_point.end());
+    std::vector<Ext> openings(std::max<size_t>(total_cols, 1), kb::ext_zero());
+    if (total_cols) {
+        DeviceBuf d_eq, d_od, d_part, d_res;
+        SP1HIP_TRY(d_eq.alloc(((size_t)16) << L, s));
+        SP1HIP_TRY(sp1hip_partial_lagrange(reinterpret_cast<const sp1hip_ext_t*>(trace_point.data()), L, d_eq.u32(), stream));
+        std::vector<OpenDesc> od;
+        uint32_t out0 = 0, max_rows_open = 0;
+        for (int c = 0; c < n_chips; c++) {
+            // proof order per chip: main evaluations, then preprocessed; opening slots: [main | prep]
+            for (uint32_t g = 0; g < info[c].main_w; g += OPEN_COLS) od.push_back(OpenDesc{info[c].d_main, info[c].rows, info[c].main_w, g, out0 + g});
+            out0 += info[c].main_w;
+            for (uint32_t g = 0; g < info[c].prep_w; g += OPEN_COLS) od.push_back(OpenDesc{info[c].d_prep, info[c].rows, info[c].prep_w, g, out0 + g});
+            out0 += info[c].prep_w;
+            max_rows_open = std::max(max_rows_open, info[c].rows);
+        }
+        const uint32_t chunks = std::max<uint32_t>((max_rows_open + OPEN_ROWS - 1) / OPEN_ROWS, 1);
+        SP1HIP_TRY(upload(d_od, od.data(), od.size() * sizeof(OpenDesc), s));
+        SP1HIP_TRY(d_part.alloc((size_t)chunks * total_cols * 16, s));
+        SP1HIP_TRY(d_res.alloc(total_cols * 16, s));
+        SP1HIP_HIP(hipMemsetAsync(d_part.p, 0, (size_t)chunks * total_cols * 16, s));
+        ScopedTimer t("gkr_openings", s);
+        hipLaunchKernelGGL(open_columns_kernel, dim3(chunks, (uint32_t)od.size()), dim3(256), 0, s, (const OpenDesc*)d_od.p, d_eq.u32(),
+                           1u << L, d_part.u32(), (uint32_t)total_cols);
+        SP1HIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(open_sum_kernel, dim3(((uint32_t)total_cols * 4 + 255) / 256), dim3(256), 0, s, d_part.u32(), chunks,
+                           (uint32_t)total_cols * 4, d_res.u32());
+        SP1HIP_LAUNCH_CHECK();
+        SP1HIP_HIP(hipMemcpyAsync(openings.data(), d_res.p, total_cols * 16, hipMemcpyDeviceToHost, s));
+        SP1HIP_HIP(hipStreamSynchronize(s));
+    }
+    challenger_observe(ch, kb::to_monty((uint32_t)n_chips));
+    {
+        size_t o = 0;
+        for (int c = 0; c < n_chips; c++) {
+            const Ext* main = openings.data() + o;
+            const Ext* prep = main + info[c].main_w;
+            if (info[c].prep_w) {
+                challenger_observe(ch, kb::to_monty(info[c].prep_w));
+                for (uint32_t k = 0; k < info[c].prep_w; k++) observe_ext(ch, prep[k]);
+            }
+            challenger_observe(ch, kb::to_monty(info[c].main_w));
+            for (uint32_t k = 0; k < info[c].main_w; k++) observe_ext(ch, main[k]);
+            o += info[c].main_w + info[c].prep_w;
+        }
+    }
+
+    // ---- bincode(LogupGkrProof)
+    Bytes w;
+    for (const std::vector<Ext>* vv : {&out_n, &out_d}) {
+        w.u64(vv->size());
+        for (auto& e : *vv) w.ext(e);
+        w.u64(2); w.u64(vv->size()); w.u64(1);
+    }
+    w.u64(rounds.size());
+    for (auto& r : rounds) {
+        w.ext(r.n0); w.ext(r.n1); w.ext(r.d0); w.ext(r.d1);
+        w.u64(r.polys.size());
+        for (auto& p : r.polys) { w.u64(4); for (auto& c : p) w.ext(c); }
+        w.ext(r.claimed_sum);
+        w.u64(r.point.size());
+        for (auto& x : r.point) w.ext(x);
+        w.ext(r.eval);
+    }
+    w.u64(trace_point.size());
+    for (auto& x : trace_point) w.ext(x);
+    w.u64(n_chips);
+    {
+        size_t o = 0;
+        for (int c = 0; c < n_chips; c++) {
+            w.u64(info[c].name.size());
+            for (char chr : info[c].name) w.b.push_back((uint8_t)chr);
+            w.u64(info[c].main_w);
+            for (uint32_t k = 0; k < info[c].main_w; k++) w.ext(openings[o + k]);
+            w.u64(1); w.u64(info[c].main_w);
+            w.b.push_back(info[c].prep_w ? 1 : 0);
+            if (info[c].prep_w) {
+                w.u64(info[c].prep_w);
+                for (uint32_t k = 0; k < info[c].prep_w; k++) w.ext(openings[o + info[c].main_w + k]);
+                w.u64(1); w.u64(info[c].prep_w);
+            }
+            o += info[c].main_w + info[c].prep_w;
+        }
+    }
+    w.felt(witness);
+    if (w.b.size() != need) {
+        set_error("internal error: GKR proof size %zu != expected %zu", w.b.size(), need);
+        return SP1HIP_ERROR_RUNTIME;
+    }
+    memcpy(h_proof, w.b.data(), w.b.size());
+    *proof_len = w.b.size();
+    challenger_restore(challenger, ch);
+    return SP1HIP_SUCCESS;
+}
+
+}  // extern "C"
