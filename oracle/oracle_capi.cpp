@@ -10,6 +10,7 @@
 #include "kb_zerocheck.hpp"
 #include "kb_jagged.hpp"
 #include "kb_gkr.hpp"
+#include "kb_shard.hpp"
 
 using namespace orc;
 
@@ -473,6 +474,54 @@ int orc_gkr_verify(int n_chips, const char** names, const uint32_t** progs, cons
         }
         return gkr_verify(chips, hs, L, p, check_interactions != 0, check_interactions ? -1 : beta_seed_dim,
                           *static_cast<Challenger*>(challenger));
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// ---- whole shard proof ------------------------------------------------------------------------------------
+static std::vector<ShardChip> make_shard_chips(int n, const char** names, const uint32_t** zc_progs, const int* zc_lens,
+                                               const int* main_w, const int* prep_w, const int* n_constraints,
+                                               const uint32_t** gkr_progs, const uint32_t** mains, const uint32_t** preps,
+                                               const uint64_t* rows) {
+    std::vector<ShardChip> chips(n);
+    if (n == 0) return chips;
+    std::vector<ZcAir> airs = make_airs(n, zc_progs, zc_lens, main_w, prep_w, n_constraints);
+    std::vector<GkrChip> g = make_gkr_chips(n, names, gkr_progs, main_w, prep_w, mains, preps, rows);
+    for (int k = 0; k < n; k++) {
+        chips[k].name = names[k];
+        chips[k].air = airs[k];
+        chips[k].interactions = g[k].interactions;
+        chips[k].main = g[k].main; chips[k].prep = g[k].prep; chips[k].real_rows = g[k].real_rows;
+    }
+    return chips;
+}
+
+size_t orc_shard_prove(int n, const char** names, const uint32_t** zc_progs, const int* zc_lens, const int* main_w, const int* prep_w,
+                       const int* n_constraints, const uint32_t** gkr_progs, const uint32_t** mains, const uint32_t** preps,
+                       const uint64_t* rows, const uint32_t* publics, int n_publics, void* prep_round, int L, int lsh,
+                       size_t batch, int log_blowup, int num_queries, int pow_bits, void* challenger, uint8_t* out, size_t cap) {
+    std::vector<ShardChip> chips = make_shard_chips(n, names, zc_progs, zc_lens, main_w, prep_w, n_constraints, gkr_progs, mains, preps, rows);
+    std::vector<F> pv(n_publics);
+    memcpy(pv.data(), publics, (size_t)n_publics * 4);
+    ShardParams sp{L, lsh, batch, FriConfig{log_blowup, num_queries, pow_bits}};
+    ShardProof p = shard_prove(chips, pv, static_cast<JaggedRoundHandle*>(prep_round)->d, sp, *static_cast<Challenger*>(challenger));
+    std::vector<uint8_t> b = serialize_shard_proof(p);
+    if (b.size() <= cap) memcpy(out, b.data(), b.size());
+    return b.size();
+}
+
+// with_chips == 0: n may be 0; everything chip-independent is checked (the reference's real proof)
+int orc_shard_verify(int n, const char** names, const uint32_t** zc_progs, const int* zc_lens, const int* main_w, const int* prep_w,
+                     const int* n_constraints, const uint32_t** gkr_progs, const uint32_t* prep_commit8, const uint8_t* blob,
+                     size_t len, int L, int lsh, int log_blowup, int num_queries, int pow_bits, int with_chips, int beta_seed_dim,
+                     void* challenger) {
+    try {
+        ShardProof p = deserialize_shard_proof(blob, len);
+        std::vector<ShardChip> chips;
+        if (with_chips) chips = make_shard_chips(n, names, zc_progs, zc_lens, main_w, prep_w, n_constraints, gkr_progs, nullptr, nullptr, nullptr);
+        ShardParams sp{L, lsh, 0, FriConfig{log_blowup, num_queries, pow_bits}};
+        return shard_verify(chips, load_d(prep_commit8), p, sp, with_chips != 0, beta_seed_dim, *static_cast<Challenger*>(challenger));
     } catch (const std::exception&) {
         return -1;
     }

@@ -86,6 +86,13 @@ def lib():
                                     C.POINTER(u32p), u64p, C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
         L.orc_gkr_verify.argtypes = [C.c_int, cpp, C.POINTER(u32p), C.POINTER(C.c_int), C.POINTER(C.c_int), u64p, C.c_int,
                                      C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        ip = C.POINTER(C.c_int)
+        L.orc_shard_prove.restype = C.c_size_t
+        L.orc_shard_prove.argtypes = [C.c_int, cpp, C.POINTER(u32p), ip, ip, ip, ip, C.POINTER(u32p), C.POINTER(u32p),
+                                      C.POINTER(u32p), u64p, u32p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
+        L.orc_shard_verify.argtypes = [C.c_int, cpp, C.POINTER(u32p), ip, ip, ip, ip, C.POINTER(u32p), u32p, C.POINTER(C.c_uint8),
+                                       C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -557,3 +564,42 @@ def gkr_verify_transcript_only(max_log_row_count, blob, beta_seed_dim, challenge
     buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
     return lib().orc_gkr_verify(0, None, None, None, None, None, max_log_row_count, buf, C.c_size_t(len(blob)), 0,
                                 beta_seed_dim, challenger.h)
+
+
+# ---- whole shard proof ---------------------------------------------------------------------------------
+def _shard_chip_args(chips):
+    """chips: [(AirProgram, InteractionProgram, main row-major, prep row-major or None)] in name order."""
+    n = len(chips)
+    airs = [np.ascontiguousarray(c[0].to_array(), dtype=np.uint32) for c in chips]
+    zc_ptrs = (u32p * n)(*[_p(a) for a in airs])
+    zc_lens = (C.c_int * n)(*[a.shape[0] for a in airs])
+    nc = (C.c_int * n)(*[c[0].num_constraints for c in chips])
+    g = _gkr_chip_args([(c[1], c[2], c[3]) for c in chips])
+    return n, g[1], zc_ptrs, zc_lens, g[3], g[4], nc, g[2], g[5], g[6], g[7], (airs, g[8])
+
+
+def shard_prove(chips, publics, prep_round, L, lsh, batch, challenger, log_blowup=2, num_queries=124, pow_bits=16):
+    """ShardProver::prove_shard_with_data -> bincode(ShardProof). prep_round: JaggedRound of the preprocessed traces."""
+    n, names, zc, zl, mw, pw, nc, gk, mains, preps, rows, keep = _shard_chip_args(chips)
+    pv = _arr(publics).reshape(-1)
+    args = (n, names, zc, zl, mw, pw, nc, gk, mains, preps, rows, _p(pv) if pv.size else None, int(pv.size), prep_round.h, L,
+            lsh, C.c_size_t(batch), log_blowup, num_queries, pow_bits)
+    scratch = challenger.clone()
+    size = lib().orc_shard_prove(*args, scratch.h, None, 0)
+    buf = (C.c_uint8 * size)()
+    lib().orc_shard_prove(*args, challenger.h, buf, size)
+    return bytes(buf)
+
+
+def shard_verify(chips, prep_commit, blob, L, lsh, challenger, log_blowup=2, num_queries=124, pow_bits=16):
+    """ShardVerifier::verify_shard with every chip-dependent check; 0 = accepted."""
+    n, names, zc, zl, mw, pw, nc, gk, _, _, _, keep = _shard_chip_args(chips)
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    return lib().orc_shard_verify(n, names, zc, zl, mw, pw, nc, gk, _p(_arr(prep_commit)), buf, C.c_size_t(len(blob)), L, lsh,
+                                  log_blowup, num_queries, pow_bits, 1, -1, challenger.h)
+
+
+def shard_verify_transcript_only(prep_commit, blob, L, lsh, beta_seed_dim, challenger, log_blowup=2, num_queries=124, pow_bits=16):
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    return lib().orc_shard_verify(0, None, None, None, None, None, None, None, _p(_arr(prep_commit)), buf, C.c_size_t(len(blob)),
+                                  L, lsh, log_blowup, num_queries, pow_bits, 0, beta_seed_dim, challenger.h)

@@ -43,8 +43,11 @@ Output tests/golden/kb_shrink_transcript.npz:
     basefold_proof_q12 + jagged_tail is a complete JaggedPcsProof. jagged_start_op = tape index where
     JaggedPcsVerifier::verify_trusted_evaluations starts (first z_col sample); jagged_z_row = the
     zerocheck point; jagged_claims0/1 = the preprocessed / main column openings it is given.
-  gkr_proof = the reference's bytes of ShardProof.logup_gkr_proof (bincode(LogupGkrProof)); gkr_start_op =
-    tape index of its 12-bit grinding check (the first op of verify_logup_gkr).
+  shard_head = the reference's bytes of the ShardProof from its first byte (public_values) up to the BasefoldProof:
+    shard_head + basefold_proof_q12 + jagged_tail is a complete bincode(ShardProof) with 12 queries;
+    shard_head[gkr_range[0]:gkr_range[1]] is bincode(LogupGkrProof). shard_start_op = tape index right after
+    vk.observe_into (where verify_shard starts); gkr_start_op = tape index of the 12-bit grinding check (the
+    first op of verify_logup_gkr).
   stack_point = the evaluation point of the stacked PCS (last log_stacking_height coordinates of the
     jagged sumcheck point), expected_eval = JaggedPcsProof.expected_eval.
   pinned = 1 when the expected value is read from / checked against the proof itself, 0 when it is
@@ -155,6 +158,10 @@ class Tape:
         else:
             self._push(0, len(words), words, 1)
         self.ch.observe_many(words)
+
+    def barrier(self):
+        """Do not merge the next observe into the previous one (so that a replay can stop exactly here)."""
+        self.ops.append((0, 0, len(self.data), 1))
 
     def observe_exts(self, es):
         self.observe([w for e in es for w in e])
@@ -297,6 +304,8 @@ def main():
     t.observe(gcs_y)
     t.observe([enable_untrusted])
     t.observe([0] * 6)
+    t.barrier()
+    shard_start_op = len(t.ops) - 1
     # verify_shard head
     t.observe(public_values)
     t.observe(main_commit)
@@ -408,7 +417,9 @@ def main():
                         stack_point=np.array(stack_point, dtype=np.uint32),
                         expected_eval=np.array(expected_eval, dtype=np.uint32),
                         jagged_tail=np.frombuffer(bytes(jagged_tail), dtype=np.uint8),
-                        gkr_proof=np.frombuffer(bytes(gkr_bytes), dtype=np.uint8),
+                        shard_head=np.frombuffer(bytes(b[112:bf_start]), dtype=np.uint8),
+                        gkr_range=np.array([gkr_start - 112, gkr_start - 112 + len(gkr_bytes)], dtype=np.int64),
+                        shard_start_op=np.int32(shard_start_op),
                         gkr_start_op=np.int32(len(head[0])), zerocheck_start_op=np.int32(zerocheck_start_op),
                         jagged_start_op=np.int32(jagged_start_op),
                         jagged_z_row=np.array(zerocheck["point"], dtype=np.uint32),

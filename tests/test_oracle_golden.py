@@ -246,7 +246,7 @@ def test_oracle_gkr_verifier_accepts_the_reference_gkr_proof():
     k = int(T["gkr_start_op"])
     ch = orc.Challenger()
     assert tt.replay(ch, stop_before_op=k)[0] == k
-    blob = T["gkr_proof"].tobytes()
+    blob = tt.gkr_proof_bytes()
     L = len(T["jagged_z_row"])
     v = ch.clone()
     assert orc.gkr_verify_transcript_only(L, blob, int(T["beta_seed_dim"]), v) == 0
@@ -262,3 +262,30 @@ def test_oracle_gkr_verifier_accepts_the_reference_gkr_proof():
     bad = bytearray(blob)
     bad[5000] ^= 1
     assert orc.gkr_verify_transcript_only(L, bytes(bad), int(T["beta_seed_dim"]), ch.clone()) != 0
+
+
+def test_oracle_shard_verifier_accepts_the_reference_shard_proof():
+    """End to end on the reference's REAL ShardProof (its own bytes, 12 BaseFold queries): the oracle's restatement
+    of ShardVerifier::verify_shard (/root/reference/crates/hypercube/src/verifier/shard.rs:L437-L742) parses the whole
+    bincode(ShardProof) and, from the transcript state after vk.observe_into, accepts every check that does not
+    need the recursion machine's chip definitions: transcript head, LogUp-GKR rounds, zerocheck sumcheck,
+    the complete jagged evaluation proof, and the row/column-count consistency with the opened values. It must end
+    in the tape's final transcript state."""
+    import transcript_tape as tt
+    T = tt.TAPE
+    k = int(T["shard_start_op"])
+    ch = orc.Challenger()
+    assert tt.replay(ch, stop_before_op=k)[0] == k
+    blob = tt.shard_proof_bytes()
+    L, lsh = len(T["jagged_z_row"]), len(T["stack_point"])
+    v = ch.clone()
+    assert orc.shard_verify_transcript_only(M(GOLD["vk_preprocessed_commit"]), blob, L, lsh, int(T["beta_seed_dim"]), v, 2, 12, 16) == 0
+    # the tape samples all 124 query indices, this run only the 12 kept ones: compare at that point of the tape
+    ref = orc.Challenger()
+    stop = len(T["ops"]) - 124 + 12
+    assert tt.replay(ref, stop_before_op=stop)[0] == stop
+    assert np.array_equal(ref.state(), v.state())
+    bad = bytearray(blob)
+    bad[900] ^= 1                                    # inside the public values
+    assert orc.shard_verify_transcript_only(M(GOLD["vk_preprocessed_commit"]), bytes(bad), L, lsh, int(T["beta_seed_dim"]),
+                                            ch.clone(), 2, 12, 16) != 0

@@ -19,7 +19,8 @@ def replay(ch, stop_before_op=None):
         if stop_before_op is not None and k == stop_before_op:
             return k, pinned
         if op == 0:
-            ch.observe(data_m[off:off + arg])
+            if arg:                                          # arg == 0: a barrier between two absorbs
+                ch.observe(data_m[off:off + arg])
         elif op == 1:
             got = orc.from_monty(np.array([ch.sample() for _ in range(arg)], dtype=np.uint32))
             assert np.array_equal(got, data[off:off + arg]), ("sample", k)
@@ -39,3 +40,13 @@ def pow_op_index(bits=16):
     idx = [k for k, (op, arg, _, _) in enumerate(ops) if op == 3 and arg == bits]
     assert len(idx) == 1
     return idx[0]
+
+
+def gkr_proof_bytes():
+    a, b = (int(x) for x in TAPE["gkr_range"])
+    return TAPE["shard_head"].tobytes()[a:b]
+
+
+def shard_proof_bytes():
+    """bincode(ShardProof) of the reference's real proof with the BaseFold openings restricted to 12 queries."""
+    return TAPE["shard_head"].tobytes() + TAPE["basefold_proof_q12"].tobytes() + TAPE["jagged_tail"].tobytes()
