@@ -304,6 +304,40 @@ int sp1hip_zerocheck_prove(const sp1hip_zc_chip_t* chips, int n_chips, int max_l
                            sp1hip_challenger_t* challenger, uint8_t* h_proof, size_t* proof_len,
                            sp1hip_stream_t stream);
 
+/* ---------------------------------------------------------------- one whole shard proof
+ * A chip of the shard with everything the stages need: constraint program (zerocheck, see sp1hip_zc_chip_t),
+ * interaction program (LogUp-GKR, see sp1hip_gkr_chip_t) and its device traces. Chips in name order. */
+typedef struct {
+    const char* name;
+    const uint32_t* program;        /* [n_instr][3] constraint program (host) */
+    uint32_t n_instr, num_constraints;
+    const uint32_t* interactions;   /* interaction program words (host) */
+    uint32_t n_words;
+    uint32_t main_width, prep_width;
+    const uint32_t* d_main;
+    const uint32_t* d_prep;
+    uint64_t real_rows;
+} sp1hip_shard_chip_t;
+
+typedef struct {
+    int max_log_row_count;          /* core: 22 */
+    int log_stacking_height;        /* core: 21 */
+    int batch_size;                 /* stacked columns per BaseFold batch */
+    sp1hip_fri_config_t fri;
+} sp1hip_shard_params_t;
+
+/* `ShardProver::prove_shard_with_data` (/root/reference/crates/hypercube/src/prover/shard.rs:L650-L792) — the body of
+ * `AirProver::prove_shard_with_pk`, the seam a proving backend plugs into. `preprocessed`: the proving key's
+ * preprocessed commitment round (sp1hip_jagged_commit over the preprocessed traces of the chips that have one, in
+ * chip order, done once at setup). The challenger must already have absorbed the verifying key
+ * (`vk.observe_into`). Commits the main traces, runs LogUp-GKR, zerocheck and the jagged evaluation proof in the
+ * reference's transcript order and writes bincode(ShardProof)
+ * (/root/reference/crates/hypercube/src/verifier/proof.rs:L47-L94). Size protocol and transcript commit-on-success as
+ * for the stage entry points. */
+int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint32_t* h_publics, int n_publics,
+                       sp1hip_stacked_data_t* preprocessed, sp1hip_shard_params_t params, sp1hip_challenger_t* challenger,
+                       uint8_t* h_proof, size_t* proof_len, sp1hip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

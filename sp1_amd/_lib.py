@@ -42,6 +42,18 @@ class FriConfig(C.Structure):
     _fields_ = [("log_blowup", C.c_int), ("num_queries", C.c_int), ("proof_of_work_bits", C.c_int)]
 
 
+class ShardChip(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("program", C.POINTER(C.c_uint32)), ("n_instr", C.c_uint32),
+                ("num_constraints", C.c_uint32), ("interactions", C.POINTER(C.c_uint32)), ("n_words", C.c_uint32),
+                ("main_width", C.c_uint32), ("prep_width", C.c_uint32), ("d_main", C.c_void_p), ("d_prep", C.c_void_p),
+                ("real_rows", C.c_uint64)]
+
+
+class ShardParams(C.Structure):
+    _fields_ = [("max_log_row_count", C.c_int), ("log_stacking_height", C.c_int), ("batch_size", C.c_int),
+                ("fri", FriConfig)]
+
+
 class Sp1HipError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("sp1hip status %d: %s" % (status, message))
@@ -123,6 +135,7 @@ PROTOTYPES = [
     ("sp1hip_jagged_prove", None, [C.POINTER(Ext), _int, C.POINTER(_vp), _int, C.POINTER(Ext), C.POINTER(_sz), FriConfig, _vp,
                                    u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_logup_gkr_prove", None, [C.POINTER(GkrChip), _int, _int, _vp, u8p, C.POINTER(_sz), _vp]),
+    ("sp1hip_prove_shard", None, [C.POINTER(ShardChip), _int, u32p, _int, _vp, ShardParams, _vp, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
                                       _vp, u8p, C.POINTER(_sz), _vp]),
 ]

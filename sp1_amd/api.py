@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Ext, FriConfig, GkrChip, Table, Tensor, ZcChip, check
+from ._lib import Ext, FriConfig, GkrChip, ShardChip, ShardParams, Table, Tensor, ZcChip, check
 
 P = 0x7F000001
 
@@ -440,6 +440,35 @@ def logup_gkr(chips, max_log_row_count, challenger, stream=None):
         raise RuntimeError("size query unexpectedly succeeded")
     buf = (C.c_uint8 * n.value)()
     check(_L().sp1hip_logup_gkr_prove(arr, len(chips), max_log_row_count, challenger.h, buf, C.byref(n), _stream_ptr(stream)))
+    return bytes(buf[:n.value])
+
+
+def prove_shard(chips, public_values, preprocessed, max_log_row_count, log_stacking_height, batch_size, challenger,
+                log_blowup=2, num_queries=124, pow_bits=16, stream=None):
+    """ShardProver::prove_shard_with_data on the GPU (sp1hip_prove_shard). chips: [(AirProgram, InteractionProgram, main
+    ColMajor or None, prep ColMajor or None)] in name order; preprocessed: the StackedData of the preprocessed round
+    (JaggedProver.commit_multilinears over the preprocessed traces). Returns bincode(ShardProof)."""
+    arr = (ShardChip * len(chips))()
+    keep = []
+    for i, (air, inter, main, prep) in enumerate(chips):
+        prog = np.ascontiguousarray(air.to_array(), dtype=np.uint32)
+        words = np.ascontiguousarray(inter.to_array(), dtype=np.uint32)
+        keep += [prog, words]
+        rows = main.height if main is not None else 0
+        arr[i] = ShardChip(inter.name.encode(), prog.ctypes.data_as(_lib.u32p), prog.shape[0], air.num_constraints,
+                           words.ctypes.data_as(_lib.u32p), words.size, air.main_width, air.prep_width,
+                           C.c_void_p(main.words.data_ptr()) if rows else None,
+                           C.c_void_p(prep.words.data_ptr()) if prep is not None and rows and air.prep_width else None, rows)
+    pv = np.ascontiguousarray(np.asarray(public_values, dtype=np.uint32).reshape(-1))
+    params = ShardParams(max_log_row_count, log_stacking_height, batch_size, FriConfig(log_blowup, num_queries, pow_bits))
+    n = C.c_size_t(0)
+    args = [arr, len(chips), pv.ctypes.data_as(_lib.u32p) if pv.size else None, int(pv.size), preprocessed.h, params, challenger.h]
+    st = _L().sp1hip_prove_shard(*args, None, C.byref(n), _stream_ptr(stream))
+    if st != -6:
+        check(st)
+        raise RuntimeError("size query unexpectedly succeeded")
+    buf = (C.c_uint8 * n.value)()
+    check(_L().sp1hip_prove_shard(*args, buf, C.byref(n), _stream_ptr(stream)))
     return bytes(buf[:n.value])
 
 

@@ -542,6 +542,22 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
 }
 
 }  // namespace
+
+// bincode(JaggedPcsProof) size: BaseFold proof + batch evaluations + two sumchecks + counts + commitments + tail
+size_t jagged_proof_size(int lsh, const std::vector<uint32_t>& round_widths, const std::vector<size_t>& tables_per_round,
+                         uint64_t total_area, sp1hip_fri_config_t config) {
+    const int n_rounds = (int)round_widths.size();
+    const int log_m = log2_ceil(total_area), D = log_m + 1;
+    size_t need = sp1hip_basefold_proof_size(lsh, round_widths.data(), n_rounds, config);
+    need += 8;
+    for (uint32_t w : round_widths) need += 8 + (size_t)w * 16 + 16;
+    need += 8 + (size_t)log_m * (8 + 48) + 16 + 8 + (size_t)log_m * 16 + 16;
+    need += 8 + (size_t)2 * D * (8 + 48) + 16 + 8 + (size_t)2 * D * 16 + 16;
+    need += 8;
+    for (size_t t : tables_per_round) need += 8 + t * 16;
+    need += 8 + (size_t)n_rounds * 32 + 16 + 8 + 8;
+    return need;
+}
 }  // namespace sp1hip
 
 using namespace sp1hip;
@@ -576,16 +592,9 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     const int log_m = log2_ceil(total_area);
     SP1HIP_REQUIRE(log_m >= lsh, "internal: area smaller than one stacked column");
     const int num_col_variables = log2_ceil(total_cols);
-    const int D = log_m + 1;
-    // size: BaseFold proof + batch evaluations + two sumchecks + counts + commitments + tail
-    size_t need = sp1hip_basefold_proof_size(lsh, round_widths.data(), n_rounds, config);
-    need += 8;
-    for (uint32_t w : round_widths) need += 8 + (size_t)w * 16 + 16;
-    need += 8 + (size_t)log_m * (8 + 48) + 16 + 8 + (size_t)log_m * 16 + 16;
-    need += 8 + (size_t)2 * D * (8 + 48) + 16 + 8 + (size_t)2 * D * 16 + 16;
-    need += 8;
-    for (int r = 0; r < n_rounds; r++) need += 8 + rounds[r]->row_counts.size() * 16;
-    need += 8 + (size_t)n_rounds * 32 + 16 + 8 + 8;
+    std::vector<size_t> tables_per_round;
+    for (int r = 0; r < n_rounds; r++) tables_per_round.push_back(rounds[r]->row_counts.size());
+    const size_t need = jagged_proof_size(lsh, round_widths, tables_per_round, total_area, config);
     if (!h_proof || *proof_len < need) {
         *proof_len = need;
         set_error("sp1hip_jagged_prove: proof buffer too small, need %zu bytes", need);

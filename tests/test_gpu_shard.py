@@ -1,0 +1,49 @@
+"""GPU parity (-m gpu) of one whole shard proof: sp1hip_prove_shard's bincode(ShardProof) and final transcript state
+equal the oracle's prove_shard_with_data byte for byte, and the oracle's restated verify_shard — with every
+chip-dependent check — accepts it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import pyoracle as orc  # noqa: E402
+from shard_chips import make_shard_chips, preprocessed_round  # noqa: E402
+
+LB, NQ, PW = 1, 5, 4
+
+
+@pytest.fixture(scope="module")
+def api():
+    from sp1_amd import api as a
+    torch.cuda.set_device(0)
+    return a
+
+
+@pytest.mark.parametrize("n_tuples,L,lsh,batch,with_empty,dup", [
+    (4, 3, 2, 2, False, 2),
+    (5, 4, 3, 3, True, 3),
+    (3, 5, 2, 4, False, 1),
+    (200, 10, 6, 4, True, 3),
+])
+def test_shard_proof_matches_oracle(api, n_tuples, L, lsh, batch, with_empty, dup):
+    chips, publics = make_shard_chips(n_tuples, 20 + L, with_empty, dup)
+    o_prep = preprocessed_round(chips, L, lsh, batch, LB)
+    jp = api.JaggedProver(L, lsh, batch, LB)
+    dev = []
+    for air, inter, main, prep in chips:
+        d_main = api.ColMajor.from_row_major_host(main) if main.shape[0] else None
+        d_prep = api.ColMajor.from_row_major_host(prep) if prep is not None and prep.shape[0] else None
+        dev.append((air, inter, d_main, d_prep))
+    g_commit, g_prep = jp.commit_multilinears([d[3] for d in dev if d[3] is not None])
+    assert np.array_equal(g_commit, o_prep.commit)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    o_ch.observe(o_prep.commit)
+    g_ch.observe(g_commit)
+    v_ch = o_ch.clone()
+    want = orc.shard_prove(chips, publics, o_prep, L, lsh, batch, o_ch, LB, NQ, PW)
+    got = api.prove_shard(dev, publics, g_prep, L, lsh, batch, g_ch, LB, NQ, PW)
+    assert len(got) == len(want)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+    assert orc.shard_verify(chips, g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
