@@ -2,11 +2,10 @@
 """Stage timings of the implemented hot path at CORE-shard scale (A = 2^28 + 2^27 cells,
 stacking height 2^21, 32 columns per batch, log_blowup 2, 124 queries, 16 PoW bits).
 
-Not the driver's bench (that is ../bench.py, BASELINE config 2). This script reports, for one
-synthetic shard resident in HBM: jagged commit (stack + RS encode + Merkle), zerocheck over synthetic
-chips covering the same area, and the BaseFold opening, so that the per-stage numbers in DESIGN.md /
-profiles come from a measured run. LogUp-GKR and the jagged sumchecks are not implemented (§8f), so
-this is NOT a complete shard proof.
+Not the driver's bench (that is ../bench.py, BASELINE config 2). This script proves one synthetic shard
+resident in HBM end to end with sp1hip_prove_shard (commit -> LogUp-GKR -> zerocheck -> jagged evaluation
+proof = a complete bincode(ShardProof); the chips have degree-3 constraints and balanced lookups, so the
+proof is a valid one) and then times the four stages separately on the same inputs.
 
   python bench/bench_shard.py [--scale-log2 K]   (area = (2^28 + 2^27) >> K; default K = 0)
 """
@@ -66,6 +65,26 @@ def timed(fn):
     return out, (time.perf_counter() - t0) * 1e3
 
 
+def wide_interactions(name, width, send):
+    """One lookup per 16 columns: the tuple (a, b, c) of the group's first quad with multiplicity d (boolean)."""
+    from sp1_amd.air import InteractionProgram, VCol
+    p = InteractionProgram(name, width, 2 if name == "Prep" else 0)
+    for g in range(0, width // 4, 4):
+        vals = [VCol.main(4 * g), VCol.main(4 * g + 1), VCol.main(4 * g + 2)]
+        (p.send if send else p.receive)(5, vals, VCol.main(4 * g + 3))
+    return p
+
+
+def read_timers(names):
+    out = {}
+    for name in names:
+        cnt, ms = C.c_uint64(), C.c_double()
+        api.check(api._L().sp1hip_timers_read(name.encode(), C.byref(cnt), C.byref(ms)))
+        if cnt.value:
+            out[name + "_ms"] = round(ms.value, 3)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale-log2", type=int, default=0)
@@ -77,67 +96,76 @@ def main():
     area_target = ((1 << 28) + (1 << 27)) >> (2 * args.scale_log2) if args.scale_log2 else (1 << 28) + (1 << 27)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(42)
-    # chips: widths like real ones (narrow & tall ... wide & short), heights multiples of 32, <= 2^L
+    # chips: widths like real ones (narrow & tall ... wide & short); every shape appears twice, as a sender and as a
+    # receiver of the same tuples (same device trace), so the lookup argument balances and the proof is valid
     shapes, area = [], 0
     widths = [8, 16, 32, 64, 100, 200, 400]
     k = 0
-    while area < area_target:                      # power-of-two heights (the column-eval kernel needs them)
+    while area < area_target:
         w = widths[k % len(widths)] // 4 * 4
-        rows = (1 << L) >> (k % 4)
-        while rows * w > area_target - area and rows > 32:
+        rows = (1 << (L - 1)) >> (k % 4)
+        while 2 * rows * w > area_target - area and rows > 32:
             rows >>= 1
         shapes.append((rows, w))
-        area += rows * w
+        area += 2 * rows * w
         k += 1
-    tables = [wide_trace(r, w, gen) for r, w in shapes]
-    airs = [wide_air(w) for _, w in shapes]
-    print("chips:", shapes, "area = %.3e cells" % area, file=sys.stderr)
+    traces = [wide_trace(r, w, gen) for r, w in shapes]
+    chips = []
+    for i, ((r, w), t) in enumerate(zip(shapes, traces)):
+        chips.append((wide_air(w), wide_interactions("R%02d" % i, w, False), t, None))
+        chips.append((wide_air(w), wide_interactions("S%02d" % i, w, True), t, None))
+    # one chip with preprocessed columns (the proving key's commitment round)
+    prep_rows = 1 << max(L - 6, 5)
+    prep_air = AirProgram("Prep", 4, prep_width=2)
+    prep_air.assert_zero(prep_air.prep(0) * (prep_air.main(3) * (prep_air.main(3) - 1)))
+    prep_air.assert_eq(prep_air.main(2), prep_air.main(0) * prep_air.main(1))
+    prep_main = wide_trace(prep_rows, 4, gen)
+    prep_prep = api.ColMajor(torch.randint(0, api.P, (2 * prep_rows,), dtype=torch.int32, device="cuda", generator=gen), prep_rows, 2)
+    chips.append((prep_air, wide_interactions("Prep", 0, True), prep_main, prep_prep))
+    for c in chips:
+        c[0].name = c[1].name
+    chips.sort(key=lambda c: c[1].name)
+    n_int = sum(c[1].num_interactions for c in chips)
+    print("chips: %d (%d interactions), shapes %s, area = %.3e cells" % (len(chips), n_int, shapes, area), file=sys.stderr)
 
-    res = {"area_cells": area, "max_log_row_count": L, "log_stacking_height": lsh, "chips": len(shapes)}
     jp = api.JaggedProver(L, lsh, 32, 2)
-    prover = api.BasefoldProver(2, 124, 16)
+    prep_commit, prep_data = jp.commit_multilinears([prep_prep])
+    res = {"area_cells": area, "max_log_row_count": L, "log_stacking_height": lsh, "chips": len(chips), "interactions": n_int}
+    stage_timers = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition",
+                    "gkr_round_sum_first", "gkr_round_fold_sum", "gkr_openings", "jagged_round0_sum", "jagged_fold0_sum",
+                    "jagged_fold_sum", "jagged_batch_evals")
     for rep in range(args.repeat):
-        (commit, sd), t_commit = timed(lambda: jp.commit_multilinears(tables))
         ch = api.DuplexChallenger()
-        ch.observe(commit)
-        zeta = ch.sample_point(L)
-        alpha, gkr = ch.sample_ext_element(), ch.sample_ext_element()
-        # trace-column evaluations at zeta (what LogUp-GKR hands to zerocheck): eval of zero-padded columns
-        def openings():
-            eq = api.device_words(4 << L)
-            api.check(api._L().sp1hip_partial_lagrange(api._ext_array(zeta), L, api._dptr(eq), api._stream_ptr()))
-            outs = []
-            for t in tables:
-                # columns are shorter than 2^L: evaluate against the first `rows` entries of eq == zero padding
-                o = api.device_words(t.width * 4)
-                # build an eq table truncated to t.height (SoA): 4 slices
-                eq_t = torch.cat([eq[kk << L:(kk << L) + t.height] for kk in range(4)])
-                lg = t.height.bit_length() - 1
-                assert 1 << lg == t.height
-                api.check(api._L().sp1hip_mle_eval_columns(api._tensor_array([t]), 1, lg, api._dptr(eq_t), api._dptr(o),
-                                                           api._stream_ptr()))
-                outs.append(api.to_host(o, (t.width, 4)))
-            return outs
-        ops, t_open_evals = timed(openings)
-        chips = [api.ZerocheckChip(a, t) for a, t in zip(airs, tables)]
-        blob, t_zc = timed(lambda: api.zerocheck(chips, L, zeta, np.concatenate(ops), alpha, gkr, [], ch))
-        # jagged PCS evaluation proof at the zerocheck point: jagged sumcheck + jagged-eval sumcheck + stacked
-        # batch evaluations + BaseFold opening (= ShardProof.evaluation_proof)
-        z_row, chip_evals = api.parse_zerocheck_proof(blob)
-        main_claims = np.concatenate(chip_evals)         # no preprocessed columns here
-        api.check(api._L().sp1hip_timers_enable(1))
+        ch.observe(prep_commit)
+        api.check(api._L().sp1hip_timers_enable(1 if rep == args.repeat - 1 else 0))
         api.check(api._L().sp1hip_timers_reset())
-        proof, t_jag = timed(lambda: jp.prove_trusted_evaluations(z_row, [main_claims], [sd], ch))
-        stages = {}
-        for name in ("jagged_round0_sum", "jagged_fold0_sum", "jagged_fold_sum", "jagged_batch_evals"):
-            cnt, ms = C.c_uint64(), C.c_double()
-            api.check(api._L().sp1hip_timers_read(name.encode(), C.byref(cnt), C.byref(ms)))
-            stages[name + "_ms"] = round(ms.value, 3)
-        api.check(api._L().sp1hip_timers_enable(0))
-        res = dict(res, commit_ms=t_commit, zerocheck_ms=t_zc, jagged_eval_proof_ms=t_jag, jagged_kernels=stages,
-                   zerocheck_proof_bytes=len(blob), jagged_proof_bytes=len(proof), trace_openings_ms=t_open_evals)
-        print(json.dumps(res), flush=True)
-        del sd
+        proof, t_total = timed(lambda: api.prove_shard(chips, [], prep_data, L, lsh, 32, ch))
+        out = dict(res, prove_shard_ms=round(t_total, 2), shard_proof_bytes=len(proof),
+                   cells_per_s=round(area / (t_total * 1e-3)))
+        if rep == args.repeat - 1:
+            out["kernel_ms_with_timers_on"] = read_timers(stage_timers)
+        print(json.dumps(out), flush=True)
+    api.check(api._L().sp1hip_timers_enable(0))
+
+    # stage by stage (same inputs), for the per-stage table in DESIGN.md
+    ch = api.DuplexChallenger()
+    ch.observe(prep_commit)
+    (commit, sd), t_commit = timed(lambda: jp.commit_multilinears([c[2] for c in chips]))
+    ch.observe(commit)
+    gk = [(c[1], c[2], c[3]) for c in chips]
+    gblob, t_gkr = timed(lambda: api.logup_gkr(gk, L, ch))
+    zeta, opened = api.parse_logup_gkr_proof(gblob)
+    alpha, gkr_b = ch.sample_ext_element(), ch.sample_ext_element()
+    ops = np.concatenate([np.concatenate([m] + ([p] if p is not None else [])) for _, m, p in opened])
+    zchips = [api.ZerocheckChip(c[0], c[2], c[3]) for c in chips]
+    zblob, t_zc = timed(lambda: api.zerocheck(zchips, L, zeta, ops, alpha, gkr_b, [], ch))
+    z_row, chip_evals = api.parse_zerocheck_proof(zblob)
+    prep_claims = np.concatenate([e[:c[0].prep_width] for e, c in zip(chip_evals, chips)])
+    main_claims = np.concatenate([e[c[0].prep_width:] for e, c in zip(chip_evals, chips)])
+    jblob, t_jag = timed(lambda: jp.prove_trusted_evaluations(z_row, [prep_claims, main_claims], [prep_data, sd], ch))
+    print(json.dumps(dict(res, stages_ms={"commit": round(t_commit, 2), "logup_gkr": round(t_gkr, 2), "zerocheck": round(t_zc, 2),
+                                          "jagged_evaluation_proof": round(t_jag, 2)},
+                          proof_bytes={"logup_gkr": len(gblob), "zerocheck": len(zblob), "evaluation_proof": len(jblob)})), flush=True)
 
 
 if __name__ == "__main__":
