@@ -574,6 +574,8 @@ def _shard_chip_args(chips):
     zc_ptrs = (u32p * n)(*[_p(a) for a in airs])
     zc_lens = (C.c_int * n)(*[a.shape[0] for a in airs])
     nc = (C.c_int * n)(*[c[0].num_constraints for c in chips])
+    for c in chips:
+        assert (c[0].main_width, c[0].prep_width) == (c[1].main_width, c[1].prep_width), "AIR / interaction widths differ"
     g = _gkr_chip_args([(c[1], c[2], c[3]) for c in chips])
     return n, g[1], zc_ptrs, zc_lens, g[3], g[4], nc, g[2], g[5], g[6], g[7], (airs, g[8])
 
