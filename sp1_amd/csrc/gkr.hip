@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "round_sync.hpp"
 #include "tensor_table.hpp"
 
 namespace sp1hip {
@@ -239,7 +240,8 @@ __device__ __forceinline__ void accumulate_pair(const Quad& a, const Quad& b, co
 // round 0 of a layer: sums only. T = partial-Lagrange table of the layer's row point (2^v entries)
 template <bool NBASE>
 __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
-                                                       const Ext* __restrict__ T, Ext lambda, uint32_t* __restrict__ partials) {
+                                                       const Ext* __restrict__ T, Ext lambda, uint32_t* __restrict__ partials,
+                                                       RoundSync rs, uint32_t seq) {
     const RoundDesc d = descs[blockIdx.y];
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
     const uint32_t pairs = (d.rows + 1) / 2;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restri
     const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
     for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-    block_reduce_store<3>(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12);
+    rs_finish<3>(acc, partials, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, rs, seq);
 }
 
 // fold rows (2r', 2r'+1) -> r' with alpha for r' = 2k, 2k+1, store, and (if SUM) accumulate the next round's sums
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restri
 template <bool FIRST, bool NBASE, bool SUM>
 __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
                                                       const Ext* __restrict__ T_next, Ext lambda, Ext alpha,
-                                                      uint32_t* __restrict__ partials) {
+                                                      uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq) {
     const RoundDesc d = descs[blockIdx.y];
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
     const uint32_t rows_out = (d.rows + 1) / 2;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restric
         const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
         for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-        block_reduce_store<3>(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12);
+        rs_finish<3>(acc, partials, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, rs, seq);
     }
 }
 
@@ -400,6 +402,12 @@ struct ChipInfo {
 
 constexpr uint32_t MAX_TILES = 512;
 uint32_t tiles_for(uint64_t threads) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), MAX_TILES); }
+// sumcheck-round launches: every workgroup ends with one agent-scope atomic and one partial-sum slot, so keep the
+// grid at a few workgroups per CU (the kernels are grid-stride)
+uint32_t round_tiles(uint64_t threads, uint32_t K) {
+    const uint64_t cap = std::max<uint64_t>(4096 / std::max<uint32_t>(K, 1), 1);
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), cap);
+}
 
 }  // namespace gkr
 }  // namespace sp1hip
@@ -584,8 +592,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     // ---- GKR rounds, layer v = 1 .. L-1 (reads level v + 1)
     struct RoundOut { Ext n0, n1, d0, d1; std::vector<Poly4> polys; Ext claimed_sum, eval; std::vector<Ext> point; };
     std::vector<RoundOut> rounds;
-    DeviceBuf d_rdesc, d_eq_int, d_T, d_partials, d_out, scratch[2];
-    SP1HIP_TRY(d_rdesc.alloc((size_t)K * sizeof(RoundDesc), s));
+    DeviceBuf d_eq_int, d_T, d_partials, d_out, scratch[2];
     SP1HIP_TRY(d_eq_int.alloc((size_t)W * 16, s));
     SP1HIP_TRY(d_T.alloc(((size_t)2 << std::max(L - 1, 1)) * 16, s));
     SP1HIP_TRY(d_partials.alloc((size_t)K * MAX_TILES * 48, s));
@@ -594,7 +601,43 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     size_t scratch_entries = 0;
     for (uint32_t i = 0; i < K; i++) scratch_entries += (rows_at(info[int_chip[i]].rows, L) + 3) / 4 + 1;
     for (int b = 0; b < 2; b++) SP1HIP_TRY(scratch[b].alloc(std::max<size_t>(scratch_entries, 1) * 64, s));
-    std::vector<RoundDesc> rdesc(K);
+    // The descriptors of EVERY round of EVERY layer depend on shapes only: plan them all, upload once, and let each
+    // launch index the table — no per-round host-to-device copy on the critical path.
+    auto scratch_ptr = [&](int b, uint32_t i, int which, const std::vector<size_t>& so) -> Ext* { return scratch[b].ext() + 4 * so[i] + (size_t)which * (so[i + 1] - so[i]); };
+    // fills K descriptors of one launch. j = round index inside the layer (0 = sums only, >= 1 fold of round j-1),
+    // last = the fold that binds the last row variable
+    auto fill_descs = [&](RoundDesc* out, int v, int j, bool last, const std::vector<uint32_t>& live, int cur,
+                          const std::vector<size_t>& so_prev, const std::vector<size_t>& so_next) {
+        for (uint32_t i = 0; i < K; i++) {
+            RoundDesc& d = out[i];
+            d = RoundDesc{};
+            d.rows = live[i]; d.eq_int_index = i;
+            const bool from_level = j == 0 || (last ? v == 1 : j == 1);
+            if (from_level) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
+            else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
+            if (j > 0 || last) for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
+        }
+    };
+    std::vector<RoundDesc> all_descs;
+    for (int v = 1; v <= L - 1; v++) {
+        std::vector<uint32_t> live(K);
+        for (uint32_t i = 0; i < K; i++) live[i] = (rows_at(info[int_chip[i]].rows, v + 1) + 1) / 2;
+        int cur = 0;
+        std::vector<size_t> so_prev, so_next;
+        for (int j = 0; j <= v; j++) {
+            const bool last = j == v;
+            if (j > 0) { so_next.assign(K + 1, 0); for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + (live[i] + 1) / 2; }
+            all_descs.resize(all_descs.size() + K);
+            fill_descs(all_descs.data() + all_descs.size() - K, v, j, last, live, cur, so_prev, so_next);
+            if (j > 0 && !last) { for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2; so_prev = so_next; cur ^= 1; }
+        }
+    }
+    DeviceBuf d_all;
+    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s));
+    SP1HIP_HIP(hipStreamSynchronize(s));
+    size_t launch_idx = 0;                                   // next K descriptors of d_all
+    RoundSyncHost rsync;
+    SP1HIP_TRY(rsync.init(s));
     const Ext one = kb::ext_one(), inv8 = kb::ext_inv(ext_c(8)), inv2 = kb::ext_inv(ext_c(2)), four = ext_c(4);
     uint32_t h_sums[12];
 
@@ -621,50 +664,35 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         uint32_t max_live = 0;
         for (uint32_t i = 0; i < K; i++) { live[i] = (rows_at(info[int_chip[i]].rows, v + 1) + 1) / 2; max_live = std::max(max_live, live[i]); }
         int cur = 0;
-        auto scratch_ptr = [&](int b, uint32_t i, int which, const std::vector<size_t>& so) -> Ext* { return scratch[b].ext() + 4 * so[i] + (size_t)which * (so[i + 1] - so[i]); };
         std::vector<size_t> so_prev, so_next;
         for (int j = 0; j < v; j++) {                        // row-variable rounds
             const int t = v - j;                             // remaining row variables
             uint32_t tiles;
+            const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
             if (j == 0) {
-                for (uint32_t i = 0; i < K; i++) {
-                    rdesc[i] = RoundDesc{};
-                    rdesc[i].src[0] = n_ptr(v + 1, i); rdesc[i].src[1] = d_ptr(v + 1, i);
-                    rdesc[i].rows = live[i]; rdesc[i].rows_x = rows_at(info[int_chip[i]].rows, v + 1); rdesc[i].eq_int_index = i;
-                }
-                SP1HIP_HIP(hipMemcpyAsync(d_rdesc.p, rdesc.data(), (size_t)K * sizeof(RoundDesc), hipMemcpyHostToDevice, s));
-                tiles = tiles_for((max_live + 1) / 2);
+                tiles = round_tiles((max_live + 1) / 2, K);
                 ScopedTimer tm("gkr_round_sum_first", s);
-                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32());
-                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32());
+                const RoundSync rs = rsync.next();
+                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq);
+                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq);
             } else {
                 // fold round j-1 with alpha_r into scratch[cur], summing round j
                 so_next.assign(K + 1, 0);
                 uint32_t max_out = 0;
                 for (uint32_t i = 0; i < K; i++) { const uint32_t o = (live[i] + 1) / 2; so_next[i + 1] = so_next[i] + o; max_out = std::max(max_out, o); }
-                for (uint32_t i = 0; i < K; i++) {
-                    RoundDesc& d = rdesc[i];
-                    d = RoundDesc{};
-                    if (j == 1) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
-                    else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
-                    for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
-                    d.rows = live[i]; d.eq_int_index = i;
-                }
-                SP1HIP_HIP(hipMemcpyAsync(d_rdesc.p, rdesc.data(), (size_t)K * sizeof(RoundDesc), hipMemcpyHostToDevice, s));
-                tiles = tiles_for((max_out + 1) / 2);
+                tiles = round_tiles((max_out + 1) / 2, K);
                 ScopedTimer tm("gkr_round_fold_sum", s);
-                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32());
-                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32());
-                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32());
+                const RoundSync rs = rsync.next();
+                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq);
+                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq);
+                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq);
                 for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2;
                 so_prev = so_next;
                 cur ^= 1;
             }
             SP1HIP_LAUNCH_CHECK();
-            hipLaunchKernelGGL(reduce_partials<3>, dim3(1), dim3(256), 0, s, d_partials.u32(), K * tiles, d_out.u32());
-            SP1HIP_LAUNCH_CHECK();
-            SP1HIP_HIP(hipMemcpyAsync(h_sums, d_out.p, 48, hipMemcpyDeviceToHost, s));
-            SP1HIP_HIP(hipStreamSynchronize(s));
+            (void)tiles;
+            SP1HIP_TRY(rsync.wait(h_sums, 12));
             Ext S0, Sh, Seq;
             memcpy(&S0, h_sums, 16); memcpy(&Sh, h_sums + 4, 16); memcpy(&Seq, h_sums + 8, 16);
             const Ext pt = row_point[t - 1];
@@ -687,20 +715,12 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             so_next.assign(K + 1, 0);
             for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + (live[i] + 1) / 2;
             uint32_t max_out = 0;
-            for (uint32_t i = 0; i < K; i++) {
-                RoundDesc& d = rdesc[i];
-                d = RoundDesc{};
-                if (v == 1) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
-                else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
-                for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
-                d.rows = live[i]; d.eq_int_index = i;
-                max_out = std::max<uint32_t>(max_out, (live[i] + 1) / 2);
-            }
-            SP1HIP_HIP(hipMemcpyAsync(d_rdesc.p, rdesc.data(), (size_t)K * sizeof(RoundDesc), hipMemcpyHostToDevice, s));
+            for (uint32_t i = 0; i < K; i++) max_out = std::max<uint32_t>(max_out, (live[i] + 1) / 2);
+            const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
             const uint32_t tiles = tiles_for((max_out + 1) / 2);
-            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32());
-            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32());
-            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles, K), dim3(256), 0, s, (const RoundDesc*)d_rdesc.p, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32());
+            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u);
+            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u);
+            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u);
             SP1HIP_LAUNCH_CHECK();
             std::vector<Ext> host(std::max<size_t>(so_next[K], 1) * 4);
             SP1HIP_HIP(hipMemcpyAsync(host.data(), scratch[cur].p, so_next[K] * 64, hipMemcpyDeviceToHost, s));

@@ -1,0 +1,133 @@
+// sp1_amd/csrc/round_sync.hpp — hand a few words from the LAST workgroup of a kernel to the host without a
+// second launch, a copy or a stream synchronise.
+//
+// Every sumcheck round of this library ends with "reduce the per-workgroup partial sums, give the host NS
+// extension elements, let the host run the transcript". Done with a reduce kernel + hipMemcpyAsync +
+// hipStreamSynchronize that is ~40 us of launch / copy / wake-up latency per round, and a shard proof has
+// ~370 rounds. Here the workgroup that arrives last at an agent-scope counter reduces the partials and
+// stores the sums plus a sequence number into mapped pinned host memory; the host spins on the sequence
+// number (bounded). Inter-workgroup visibility follows the placement-independent protocol of the CDNA
+// guide (§6 G16): drain stores, workgroup barrier, one-lane agent-scope release, counter; consumer one-lane
+// agent-scope acquire, barrier, plain loads.
+#pragma once
+#include <chrono>
+
+#include "common.hpp"
+#include "kb31.hpp"
+
+namespace sp1hip {
+
+struct RoundSync {                       // device-visible handles
+    uint32_t* counter;                   // device word, zero between uses
+    volatile uint32_t* host_slot;        // mapped pinned: [0] = sequence number, [1 ..] = the sums
+};
+
+__device__ __forceinline__ uint32_t rs_wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = kb::add(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// Call from EVERY thread of EVERY workgroup of a 256-thread launch, once, at the end. acc: this thread's NS
+// accumulators. partials: [total_blocks][4 NS] scratch. block_linear: this workgroup's index in [0, total_blocks).
+template <int NS>
+__device__ __forceinline__ void rs_finish(const kb::Ext (&acc)[NS], uint32_t* __restrict__ partials, uint32_t block_linear,
+                                          uint32_t total_blocks, RoundSync rs, uint32_t seq) {
+    __shared__ uint32_t sm[4][4 * NS];
+    __shared__ uint32_t last_flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = rs_wave_sum(acc[s].c[k]);
+            if (lane == 0) sm[wave][4 * s + k] = w;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * NS) {
+        uint32_t a = 0;
+        for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
+        partials[(size_t)block_linear * 4 * NS + threadIdx.x] = a;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t ticket = __hip_atomic_fetch_add(rs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = ticket == total_blocks - 1;
+        if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // the last workgroup: total over all partials
+    kb::Ext tot[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) tot[s] = kb::ext_zero();
+    for (uint32_t i = threadIdx.x; i < total_blocks; i += 256)
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const uint32_t* q = partials + ((size_t)i * NS + s) * 4;
+            tot[s] = kb::ext_add(tot[s], kb::Ext{{q[0], q[1], q[2], q[3]}});
+        }
+    __syncthreads();                       // sm is reused
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = rs_wave_sum(tot[s].c[k]);
+            if (lane == 0) sm[wave][4 * s + k] = w;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * NS) {
+        uint32_t a = 0;
+        for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
+        rs.host_slot[1 + threadIdx.x] = a;
+    }
+    if (threadIdx.x == 0) *rs.counter = 0;     // ready for the next launch on this stream
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) rs.host_slot[0] = seq;
+}
+
+// Host side: owns the counter word and the pinned slot; wait() spins until the kernel that was given `seq` has
+// published (bounded; also notices a failed launch).
+struct RoundSyncHost {
+    uint32_t* d_counter = nullptr;
+    uint32_t* h_slot = nullptr;            // pinned + mapped, 32 words
+    uint32_t seq = 0;
+    hipStream_t s = nullptr;
+    int init(hipStream_t stream) {
+        s = stream;
+        SP1HIP_HIP(hipMalloc((void**)&d_counter, 4));
+        SP1HIP_HIP(hipMemsetAsync(d_counter, 0, 4, s));
+        SP1HIP_HIP(hipHostMalloc((void**)&h_slot, 32 * 4, hipHostMallocMapped));
+        memset(h_slot, 0, 32 * 4);
+        return SP1HIP_SUCCESS;
+    }
+    ~RoundSyncHost() {
+        if (d_counter) (void)hipFree(d_counter);
+        if (h_slot) (void)hipHostFree(h_slot);
+    }
+    RoundSync next() { seq++; return RoundSync{d_counter, (volatile uint32_t*)h_slot}; }
+    // copies n_words sums (from slot[1..]) into out
+    int wait(uint32_t* out, int n_words) {
+        volatile uint32_t* slot = h_slot;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t spins = 0;
+        while (slot[0] != seq) {
+            if ((++spins & 0xffff) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) return map_hip_error(q, "kernel failed while the host waited for a round result");
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                    set_error("timed out waiting for a sumcheck round result");
+                    return SP1HIP_ERROR_RUNTIME;
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int k = 0; k < n_words; k++) out[k] = slot[1 + k];
+        return SP1HIP_SUCCESS;
+    }
+};
+
+}  // namespace sp1hip

@@ -60,7 +60,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     std::vector<sp1hip_zc_chip_t> zc(n_chips);
     std::vector<sp1hip_table_t> tables(n_chips);
     uint64_t main_area = 0;
-    size_t total_w = 0, prep_cols = 0, main_cols = 0, opened_bytes = 8;
+    size_t total_w = 0, prep_cols = 0, opened_bytes = 8;
     for (int c = 0; c < n_chips; c++) {
         const sp1hip_shard_chip_t& ci = chips[c];
         SP1HIP_REQUIRE(ci.name && ci.program && ci.interactions, "null chip field");
@@ -71,7 +71,6 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         main_area += ci.real_rows * (uint64_t)ci.main_width;
         total_w += ci.main_width + ci.prep_width;
         prep_cols += ci.prep_width;
-        main_cols += ci.main_width;
         opened_bytes += 8 + strlen(ci.name) + 8 + (size_t)ci.prep_width * 16 + 8 + (size_t)ci.main_width * 16 + 8 + (size_t)(L + 1) * 4;
     }
     SP1HIP_REQUIRE(prep_cols > 0, "a shard needs at least one preprocessed column (two commitment rounds)");
