@@ -140,14 +140,54 @@ __global__ __launch_bounds__(256) void jg_reduce_partials(const uint32_t* __rest
 }
 
 // ---- round 0: y(0) = sum J[2i] q[2i], H = sum (J[2i] + J[2i+1]) (q[2i] + q[2i+1])   (hadamard.rs:L100-L135)
+// J(x) = eq_col[c] * eq_row[row] and a column is a long run of consecutive x, so eq_col[c] is factored out of
+// the run: per element only ext x base products (4 multiplies) remain, and the column search is done once per
+// thread. A thread owns RUN consecutive dense indices; when its run crosses into another column the partial
+// sums are flushed through that column's eq_col. A pair that straddles two columns takes the unfactored formula.
+constexpr int JG_ITERS = 16;     // pairs per thread; a workgroup covers 256 * JG_ITERS consecutive pairs
+__device__ __forceinline__ Ext jg_row_eq(const JgJ& J, uint32_t row) {
+    return Ext{{J.row_eq[row], J.row_eq[J.row_len + row], J.row_eq[2 * J.row_len + row], J.row_eq[3 * J.row_len + row]}};
+}
+// Lanes take CONSECUTIVE pairs (coalesced 8 B of q and 2 x 4 planes of eq_row per lane) and step by 256 pairs,
+// so a lane stays inside one column for many steps and keeps that column's sums un-multiplied.
 __global__ __launch_bounds__(256) void jg_round0_sum(JgSegs S, JgJ J, uint32_t n_pairs, uint32_t* __restrict__ partials) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += gridDim.x * blockDim.x) {
-        uint32_t q[2];
-        Ext j[2];
-        jg_load_base<2>(S, J, 2 * i, q, j);
-        e0 = kb::ext_add(e0, kb::ext_mul_base(j[0], q[0]));
-        eh = kb::ext_add(eh, kb::ext_mul_base(kb::ext_add(j[0], j[1]), kb::add(q[0], q[1])));
+    for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 256 * JG_ITERS < n_pairs; chunk += gridDim.x) {
+        uint32_t c = 0, col_end = 0;
+        bool have = false;
+        Ext a0 = kb::ext_zero(), ah = kb::ext_zero();     // sums of the current column, without eq_col[c]
+#pragma unroll 1
+        for (int it = 0; it < JG_ITERS; it++) {
+            const uint32_t pair = chunk * 256 * JG_ITERS + it * 256 + threadIdx.x;
+            if (pair >= n_pairs) break;
+            const uint32_t x = 2 * pair;
+            if (!have) { c = jg_find_col(J, x); col_end = J.prefix[c + 1]; have = true; }
+            else if (x >= col_end) {                      // entered a later column: flush
+                const Ext w = ld_ext(J.col_eq, c);
+                e0 = kb::ext_add(e0, kb::ext_mul(w, a0));
+                eh = kb::ext_add(eh, kb::ext_mul(w, ah));
+                a0 = ah = kb::ext_zero();
+                while (J.prefix[c + 1] <= x) c++;
+                col_end = J.prefix[c + 1];
+            }
+            const uint32_t q0 = jg_q(S, x), q1 = jg_q(S, x + 1);
+            const uint32_t row = x - J.prefix[c];
+            const Ext r0 = jg_row_eq(J, row);
+            a0 = kb::ext_add(a0, kb::ext_mul_base(r0, q0));
+            if (x + 1 < col_end) {
+                ah = kb::ext_add(ah, kb::ext_mul_base(kb::ext_add(r0, jg_row_eq(J, row + 1)), kb::add(q0, q1)));
+            } else {                                      // x + 1 opens the next non-empty column (at its row 0)
+                uint32_t c1 = c + 1;
+                while (J.prefix[c1 + 1] <= x + 1) c1++;
+                const Ext j0 = kb::ext_mul(ld_ext(J.col_eq, c), r0), j1 = kb::ext_mul(ld_ext(J.col_eq, c1), jg_row_eq(J, x + 1 - J.prefix[c1]));
+                eh = kb::ext_add(eh, kb::ext_mul_base(kb::ext_add(j0, j1), kb::add(q0, q1)));
+            }
+        }
+        if (have) {
+            const Ext w = ld_ext(J.col_eq, c);
+            e0 = kb::ext_add(e0, kb::ext_mul(w, a0));
+            eh = kb::ext_add(eh, kb::ext_mul(w, ah));
+        }
     }
     block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
 }
@@ -156,25 +196,53 @@ __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& a
     return kb::ext_add(a, kb::ext_mul(alpha, kb::ext_sub(b, a)));
 }
 
-// ---- first fold (base q, recomputed J) fused with the next round's sums. Thread k: inputs 4k..4k+3,
-// outputs 2k, 2k+1 of the round-1 tables (n_out entries).
+// ---- first fold (base q, recomputed J) fused with the next round's sums. One step of a thread: inputs 4k..4k+3,
+// outputs 2k, 2k+1 of the round-1 tables (n_out entries). Lanes take consecutive k (16 B of q per lane) and step by
+// 256, tracking their column like jg_round0_sum; inside one column J folds as eq_col[c] * lerp(eq_row[r], eq_row[r+1]).
 __global__ __launch_bounds__(256) void jg_fold0_sum(JgSegs S, JgJ J, Ext alpha, uint32_t n_out, Ext* __restrict__ q_out,
                                                     Ext* __restrict__ j_out, uint32_t* __restrict__ partials) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     const uint32_t n_thr = (n_out + 1) / 2;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_thr; k += gridDim.x * blockDim.x) {
-        uint32_t q[4];
-        Ext j[4];
-        jg_load_base<4>(S, J, 4 * k, q, j);
-        Ext qo[2], jo[2];
+    for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 256 * JG_ITERS < n_thr; chunk += gridDim.x) {
+        uint32_t c = 0, col_end = 0;
+        bool have = false;
+#pragma unroll 1
+        for (int it = 0; it < JG_ITERS; it++) {
+            const uint32_t k = chunk * 256 * JG_ITERS + it * 256 + threadIdx.x;
+            if (k >= n_thr) break;
+            const uint32_t x0 = 4 * k;
+            Ext qo[2], jo[2];
+            if (x0 + 3 < S.total) {
+                if (!have) { c = jg_find_col(J, x0); col_end = J.prefix[c + 1]; have = true; }
+                else if (x0 >= col_end) { while (J.prefix[c + 1] <= x0) c++; col_end = J.prefix[c + 1]; }
+            }
+            if (x0 + 3 < S.total && x0 + 3 < col_end) {       // all four inputs in column c
+                const uint32_t row = x0 - J.prefix[c];
+                const Ext w = ld_ext(J.col_eq, c);
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            qo[h] = kb::ext_add(kb::ext_from_base(q[2 * h]), kb::ext_mul_base(alpha, kb::sub(q[2 * h + 1], q[2 * h])));
-            jo[h] = fold_ext(j[2 * h], j[2 * h + 1], alpha);
-            if (2 * k + h < n_out) { st_ext(q_out, 2 * k + h, qo[h]); st_ext(j_out, 2 * k + h, jo[h]); }
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t qa = jg_q(S, x0 + 2 * h), qb = jg_q(S, x0 + 2 * h + 1);
+                    qo[h] = kb::ext_add(kb::ext_from_base(qa), kb::ext_mul_base(alpha, kb::sub(qb, qa)));
+                    const Ext ra = jg_row_eq(J, row + 2 * h), rb = jg_row_eq(J, row + 2 * h + 1);
+                    jo[h] = kb::ext_mul(w, kb::ext_add(ra, kb::ext_mul(alpha, kb::ext_sub(rb, ra))));
+                }
+            } else {                                          // column boundary or the zero tail: element by element
+                uint32_t q[4];
+                Ext j[4];
+                jg_load_base<4>(S, J, x0, q, j);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    qo[h] = kb::ext_add(kb::ext_from_base(q[2 * h]), kb::ext_mul_base(alpha, kb::sub(q[2 * h + 1], q[2 * h])));
+                    jo[h] = fold_ext(j[2 * h], j[2 * h + 1], alpha);
+                }
+                have = false;                                 // re-search next time (cheap: boundaries are rare)
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (2 * k + h < n_out) { st_ext(q_out, 2 * k + h, qo[h]); st_ext(j_out, 2 * k + h, jo[h]); }
+            e0 = kb::ext_add(e0, kb::ext_mul(jo[0], qo[0]));
+            eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(jo[0], jo[1]), kb::ext_add(qo[0], qo[1])));
         }
-        e0 = kb::ext_add(e0, kb::ext_mul(jo[0], qo[0]));
-        eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(jo[0], jo[1]), kb::ext_add(qo[0], qo[1])));
     }
     block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
 }
@@ -673,12 +741,12 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
         uint32_t nb;
         if (round == 0) {
             ScopedTimer t("jagged_round0_sum", s);
-            nb = Scratch::blocks_for(T / 2);
+            nb = Scratch::blocks_for((T / 2 + JG_ITERS - 1) / JG_ITERS);
             hipLaunchKernelGGL(jg_round0_sum, dim3(nb), dim3(256), 0, s, segs, J, T / 2, sc.partials.u32());
         } else if (round == 1) {
             ScopedTimer t("jagged_fold0_sum", s);
             const uint32_t n_out = (n_live + 1) / 2;
-            nb = Scratch::blocks_for((n_out + 1) / 2);
+            nb = Scratch::blocks_for(((n_out + 1) / 2 + JG_ITERS - 1) / JG_ITERS);
             hipLaunchKernelGGL(jg_fold0_sum, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)tabs[1].p,
                                sc.partials.u32());
             n_live = n_out;
