@@ -423,8 +423,6 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     const int L = max_log_row_count;
     SP1HIP_REQUIRE(L >= 1 && L <= 30, "max_log_row_count out of range");
     hipStream_t s = S(stream);
-    const DeviceCtx* ctx;
-    SP1HIP_TRY(get_device_ctx(&ctx));
 
     // ---- parse the interaction programs (host words -> Montgomery device words), gather shapes
     std::vector<ChipInfo> info(n_chips);
@@ -491,6 +489,8 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         return SP1HIP_ERROR_BUFFER_TOO_SMALL;
     }
 
+    const DeviceCtx* ctx;                                    // (validation and the size query above need no device)
+    SP1HIP_TRY(get_device_ctx(&ctx));
     sp1hip_challenger_t* ch = nullptr;
     SP1HIP_TRY(sp1hip_challenger_clone(challenger, &ch));
     struct ChGuard { sp1hip_challenger_t* c; ~ChGuard() { sp1hip_challenger_free(c); } } guard{ch};

@@ -58,6 +58,23 @@ def test_argument_validation_needs_no_device(lib):
     from sp1_amd._lib import Ext
     assert lib.sp1hip_fold_even_odd(None, 0, Ext(), None, None) == -1
     assert lib.sp1hip_challenger_observe(None, None, 0) == -1
+    # the prover-level entry points reject malformed input before touching a device
+    from sp1_amd._lib import FriConfig, GkrChip, ShardParams
+    n = C.c_size_t(0)
+    assert lib.sp1hip_jagged_prove(None, 3, None, 0, None, None, FriConfig(2, 124, 16), None, None, C.byref(n), None) == -1
+    assert lib.sp1hip_logup_gkr_prove(None, 0, 3, None, None, C.byref(n), None) == -1
+    assert lib.sp1hip_prove_shard(None, 0, None, 0, None, ShardParams(3, 2, 2, FriConfig(2, 124, 16)), None, None, C.byref(n), None) == -1
+    h = C.c_void_p()
+    assert lib.sp1hip_challenger_new(C.byref(h)) == 0
+    words = np.array([1, 1, 5, 1, 0, 0, 1, 0, 7, 1], np.uint32)            # a value column index 7 in a 2-column chip
+    bad = (GkrChip * 1)(GkrChip(b"X", words.ctypes.data_as(C.POINTER(C.c_uint32)), words.size, 2, 0, None, None, 0))
+    assert lib.sp1hip_logup_gkr_prove(bad, 1, 3, h, None, C.byref(n), None) == -1
+    assert b"value column" in lib.sp1hip_last_error() or b"multiplicity" in lib.sp1hip_last_error()
+    none = np.array([0], np.uint32)                                      # a chip without interactions
+    two = (GkrChip * 2)(GkrChip(b"B", none.ctypes.data_as(C.POINTER(C.c_uint32)), 1, 2, 0, None, None, 0),
+                        GkrChip(b"A", none.ctypes.data_as(C.POINTER(C.c_uint32)), 1, 2, 0, None, None, 0))
+    assert lib.sp1hip_logup_gkr_prove(two, 2, 3, h, None, C.byref(n), None) == -1 and b"sorted" in lib.sp1hip_last_error()
+    lib.sp1hip_challenger_free(h)
 
 
 def test_host_transcript_matches_oracle(lib):
