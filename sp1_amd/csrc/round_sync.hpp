@@ -90,7 +90,13 @@ __device__ __forceinline__ void rs_finish(const kb::Ext (&acc)[NS], uint32_t* __
 }
 
 // Host side: owns the counter word and the pinned slot; wait() spins until the kernel that was given `seq` has
-// published (bounded; also notices a failed launch).
+// published (bounded; also notices a failed launch). The pair (device counter, pinned slot) comes from a process-wide
+// free list: hipMalloc / hipFree / hipHostMalloc synchronise the device and would serialise provers that run
+// concurrently on other streams.
+struct RoundSyncSlot { uint32_t* d_counter; uint32_t* h_slot; };
+int round_sync_acquire(RoundSyncSlot* out);        // runtime.hip
+void round_sync_release(RoundSyncSlot slot);
+
 struct RoundSyncHost {
     uint32_t* d_counter = nullptr;
     uint32_t* h_slot = nullptr;            // pinned + mapped, 32 words
@@ -98,15 +104,15 @@ struct RoundSyncHost {
     hipStream_t s = nullptr;
     int init(hipStream_t stream) {
         s = stream;
-        SP1HIP_HIP(hipMalloc((void**)&d_counter, 4));
-        SP1HIP_HIP(hipMemsetAsync(d_counter, 0, 4, s));
-        SP1HIP_HIP(hipHostMalloc((void**)&h_slot, 32 * 4, hipHostMallocMapped));
-        memset(h_slot, 0, 32 * 4);
+        RoundSyncSlot slot;
+        SP1HIP_TRY(round_sync_acquire(&slot));
+        d_counter = slot.d_counter;
+        h_slot = slot.h_slot;
+        seq = h_slot[0];                   // continue the slot's sequence (its counter is zero between uses)
         return SP1HIP_SUCCESS;
     }
     ~RoundSyncHost() {
-        if (d_counter) (void)hipFree(d_counter);
-        if (h_slot) (void)hipHostFree(h_slot);
+        if (d_counter) round_sync_release(RoundSyncSlot{d_counter, h_slot});
     }
     RoundSync next() { seq++; return RoundSync{d_counter, (volatile uint32_t*)h_slot}; }
     // copies n_words sums (from slot[1..]) into out

@@ -2,11 +2,13 @@
 // per-device context. HIP-native equivalents of the reference's runtime shims
 // (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L16-L172): hipMallocAsync-backed allocation,
 // streams, events; no globals other than the per-device contexts.
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "round_sync.hpp"
 
 namespace sp1hip {
 
@@ -163,6 +165,34 @@ int get_device_ctx(const DeviceCtx** out) {
     }
     *out = g_ctx[dev];
     return SP1HIP_SUCCESS;
+}
+
+// ---- round-sync slots (round_sync.hpp): (device counter, mapped pinned host words) pairs, recycled
+static std::mutex g_rs_mutex;
+static std::vector<RoundSyncSlot> g_rs_free[64];
+
+int round_sync_acquire(RoundSyncSlot* out) {
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    SP1HIP_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lock(g_rs_mutex);
+        if (!g_rs_free[dev].empty()) { *out = g_rs_free[dev].back(); g_rs_free[dev].pop_back(); return SP1HIP_SUCCESS; }
+    }
+    RoundSyncSlot slot{nullptr, nullptr};
+    SP1HIP_HIP(hipMalloc((void**)&slot.d_counter, 4));
+    SP1HIP_HIP(hipMemset(slot.d_counter, 0, 4));
+    SP1HIP_HIP(hipHostMalloc((void**)&slot.h_slot, 32 * 4, hipHostMallocMapped));
+    memset(slot.h_slot, 0, 32 * 4);
+    *out = slot;
+    return SP1HIP_SUCCESS;
+}
+
+void round_sync_release(RoundSyncSlot slot) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lock(g_rs_mutex);
+    g_rs_free[dev].push_back(slot);
 }
 
 }  // namespace sp1hip
