@@ -202,8 +202,19 @@ struct RoundDesc {
     uint32_t rows;             // real rows r of the layer at this round (FIRST: ceil(rows_x / 2))
     uint32_t rows_x;           // FIRST only
     uint32_t eq_int_index;     // global interaction index
+    uint32_t tile0;            // first workgroup of this interaction in the launch (work is split by size, not per interaction)
 };
 
+// workgroup -> (interaction, range of its pairs): the interactions differ by orders of magnitude in height, so the
+// launch is a flat list of equally sized tiles; descs[].tile0 is ascending
+__device__ __forceinline__ uint32_t find_desc(const RoundDesc* __restrict__ descs, uint32_t K, uint32_t b) {
+    uint32_t lo = 0, hi = K;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (descs[mid].tile0 <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 struct Quad { Ext n0, d0, n1, d1; };
 
 template <bool FIRST, bool NBASE>
@@ -241,18 +252,19 @@ __device__ __forceinline__ void accumulate_pair(const Quad& a, const Quad& b, co
 template <bool NBASE>
 __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
                                                        const Ext* __restrict__ T, Ext lambda, uint32_t* __restrict__ partials,
-                                                       RoundSync rs, uint32_t seq) {
-    const RoundDesc d = descs[blockIdx.y];
+                                                       RoundSync rs, uint32_t seq, uint32_t K, uint32_t tile_size) {
+    const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
     const uint32_t pairs = (d.rows + 1) / 2;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < pairs; k += gridDim.x * blockDim.x) {
+    const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
         const Quad a = load_quad<true, NBASE>(d, 2 * k), b = load_quad<true, NBASE>(d, 2 * k + 1);
         accumulate_pair(a, b, lambda, ld_ext(T, 2 * k), ld_ext(T, 2 * k + 1), acc);
     }
     const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
     for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-    rs_finish<3>(acc, partials, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, rs, seq);
+    rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
 }
 
 // fold rows (2r', 2r'+1) -> r' with alpha for r' = 2k, 2k+1, store, and (if SUM) accumulate the next round's sums
@@ -260,12 +272,14 @@ __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restri
 template <bool FIRST, bool NBASE, bool SUM>
 __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
                                                       const Ext* __restrict__ T_next, Ext lambda, Ext alpha,
-                                                      uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq) {
-    const RoundDesc d = descs[blockIdx.y];
+                                                      uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq, uint32_t K,
+                                                      uint32_t tile_size) {
+    const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
     const uint32_t rows_out = (d.rows + 1) / 2;
     const uint32_t pairs = (rows_out + 1) / 2;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < pairs; k += gridDim.x * blockDim.x) {
+    const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
         Quad o[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restric
         const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
         for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-        rs_finish<3>(acc, partials, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, rs, seq);
+        rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
     }
 }
 
@@ -402,13 +416,6 @@ struct ChipInfo {
 
 constexpr uint32_t MAX_TILES = 512;
 uint32_t tiles_for(uint64_t threads) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), MAX_TILES); }
-// sumcheck-round launches: every workgroup ends with one agent-scope atomic and one partial-sum slot, so keep the
-// grid at a few workgroups per CU (the kernels are grid-stride)
-uint32_t round_tiles(uint64_t threads, uint32_t K) {
-    const uint64_t cap = std::max<uint64_t>(4096 / std::max<uint32_t>(K, 1), 1);
-    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), cap);
-}
-
 }  // namespace gkr
 }  // namespace sp1hip
 
@@ -595,7 +602,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     DeviceBuf d_eq_int, d_T, d_partials, d_out, scratch[2];
     SP1HIP_TRY(d_eq_int.alloc((size_t)W * 16, s));
     SP1HIP_TRY(d_T.alloc(((size_t)2 << std::max(L - 1, 1)) * 16, s));
-    SP1HIP_TRY(d_partials.alloc((size_t)K * MAX_TILES * 48, s));
+    SP1HIP_TRY(d_partials.alloc((size_t)(4096 + 2 * K) * 48, s));
     SP1HIP_TRY(d_out.alloc(48, s));
     // folded tables: 4 vectors per interaction, at most ceil(rows(level v+1) / 4) entries each after the first fold
     size_t scratch_entries = 0;
@@ -606,8 +613,17 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     auto scratch_ptr = [&](int b, uint32_t i, int which, const std::vector<size_t>& so) -> Ext* { return scratch[b].ext() + 4 * so[i] + (size_t)which * (so[i + 1] - so[i]); };
     // fills K descriptors of one launch. j = round index inside the layer (0 = sums only, >= 1 fold of round j-1),
     // last = the fold that binds the last row variable
+    struct LaunchShape { uint32_t tiles, tile_size; };
+    std::vector<LaunchShape> shapes;
+    constexpr uint32_t TARGET_TILES = 3072;
     auto fill_descs = [&](RoundDesc* out, int v, int j, bool last, const std::vector<uint32_t>& live, int cur,
                           const std::vector<size_t>& so_prev, const std::vector<size_t>& so_next) {
+        // pairs handled per interaction: sums-only launch: ceil(rows / 2); fold launches: ceil(ceil(rows / 2) / 2)
+        uint64_t total_pairs = 0;
+        auto pairs_of = [&](uint32_t rows) -> uint32_t { const uint32_t p = (rows + 1) / 2; return j == 0 ? p : (p + 1) / 2; };
+        for (uint32_t i = 0; i < K; i++) total_pairs += pairs_of(live[i]);
+        const uint32_t tile_size = (uint32_t)std::max<uint64_t>(256, ((total_pairs + TARGET_TILES - 1) / TARGET_TILES + 255) / 256 * 256);
+        uint32_t tile0 = 0;
         for (uint32_t i = 0; i < K; i++) {
             RoundDesc& d = out[i];
             d = RoundDesc{};
@@ -616,7 +632,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             if (from_level) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
             else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
             if (j > 0 || last) for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
+            d.tile0 = tile0;
+            tile0 += (pairs_of(live[i]) + tile_size - 1) / tile_size;
         }
+        shapes.push_back(LaunchShape{std::max<uint32_t>(tile0, 1), tile_size});
     };
     std::vector<RoundDesc> all_descs;
     for (int v = 1; v <= L - 1; v++) {
@@ -668,24 +687,25 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         for (int j = 0; j < v; j++) {                        // row-variable rounds
             const int t = v - j;                             // remaining row variables
             uint32_t tiles;
+            const LaunchShape shape = shapes[launch_idx];
             const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
             if (j == 0) {
-                tiles = round_tiles((max_live + 1) / 2, K);
+                tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_sum_first", s);
                 const RoundSync rs = rsync.next();
-                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq);
-                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq);
+                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
+                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
             } else {
                 // fold round j-1 with alpha_r into scratch[cur], summing round j
                 so_next.assign(K + 1, 0);
                 uint32_t max_out = 0;
                 for (uint32_t i = 0; i < K; i++) { const uint32_t o = (live[i] + 1) / 2; so_next[i + 1] = so_next[i] + o; max_out = std::max(max_out, o); }
-                tiles = round_tiles((max_out + 1) / 2, K);
+                tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_fold_sum", s);
                 const RoundSync rs = rsync.next();
-                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq);
-                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq);
-                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq);
+                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
+                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
+                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
                 for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2;
                 so_prev = so_next;
                 cur ^= 1;
@@ -716,11 +736,13 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + (live[i] + 1) / 2;
             uint32_t max_out = 0;
             for (uint32_t i = 0; i < K; i++) max_out = std::max<uint32_t>(max_out, (live[i] + 1) / 2);
+            const LaunchShape shape = shapes[launch_idx];
             const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
-            const uint32_t tiles = tiles_for((max_out + 1) / 2);
-            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u);
-            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u);
-            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles, K), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u);
+            const uint32_t tiles = shape.tiles;
+            (void)max_out;
+            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size);
+            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size);
+            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size);
             SP1HIP_LAUNCH_CHECK();
             std::vector<Ext> host(std::max<size_t>(so_next[K], 1) * 4);
             SP1HIP_HIP(hipMemcpyAsync(host.data(), scratch[cur].p, so_next[K] * 64, hipMemcpyDeviceToHost, s));
