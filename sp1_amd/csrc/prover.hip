@@ -336,42 +336,57 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     w.u64((uint64_t)dim);
     for (auto& c : fri_commitments) w.felts(c.data(), 8);
 
-    DeviceBuf d_idx, d_vals, d_paths;
-    size_t max_w = 8;
-    for (int r = 0; r < n_rounds; r++) max_w = std::max<size_t>(max_w, rounds[r]->total_width);
+    // Query phase: every opening (component rounds, then the dim fold rounds) is produced into ONE device buffer and
+    // brought back with one copy and one synchronise instead of one round trip per opening.
+    DeviceBuf d_idx, d_open;
+    struct Slot { size_t vals_off, n_vals, paths_off, n_paths; };
+    std::vector<Slot> slots;
+    size_t words = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        const size_t nv = nq * rounds[r]->total_width, np = nq * (size_t)(dim + lb) * 8;
+        slots.push_back(Slot{words, nv, words + nv, np});
+        words += nv + np;
+    }
+    for (int r = 0; r < dim; r++) {
+        const size_t lg_h = (size_t)(dim + lb - r - 1);
+        const size_t nv = nq * 8, np = nq * lg_h * 8;
+        slots.push_back(Slot{words, nv, words + nv, np});
+        words += nv + np;
+    }
     SP1HIP_TRY(d_idx.alloc(nq * 4, s));
-    SP1HIP_TRY(d_vals.alloc(nq * max_w * 4, s));
-    SP1HIP_TRY(d_paths.alloc(nq * (size_t)(dim + lb) * 32, s));
+    SP1HIP_TRY(d_open.alloc(std::max<size_t>(words, 1) * 4, s));
     SP1HIP_HIP(hipMemcpyAsync(d_idx.p, q.data(), nq * 4, hipMemcpyHostToDevice, s));
-    SP1HIP_HIP(hipStreamSynchronize(s));
+    for (int r = 0; r < n_rounds; r++) {
+        sp1hip_basefold_data_s* pd = rounds[r];
+        const Slot& sl = slots[r];
+        SP1HIP_TRY(sp1hip_merkle_open(pd->cw_tensors.data(), (int)pd->cw_tensors.size(), dim + lb, pd->tree.u32(), d_idx.u32(),
+                                      nq, d_open.u32() + sl.vals_off, d_open.u32() + sl.paths_off, s));
+    }
+    for (int r = 0; r < dim; r++) {
+        const int lg_c = dim + lb - r, lg_h = lg_c - 1;
+        const Slot& sl = slots[n_rounds + r];
+        SP1HIP_TRY(shift_indices(d_idx.u32(), nq, s));
+        SP1HIP_TRY(open_ext_pairs(cws[r]->u32(), lg_c, d_idx.u32(), nq, d_open.u32() + sl.vals_off, s));
+        sp1hip_tensor_t none{nullptr, 0};
+        SP1HIP_TRY(sp1hip_merkle_open(&none, 1, lg_h, trees[r]->u32(), d_idx.u32(), nq, nullptr, d_open.u32() + sl.paths_off, s));
+    }
+    std::vector<uint32_t> opened(std::max<size_t>(words, 1));
+    SP1HIP_HIP(hipMemcpyAsync(opened.data(), d_open.p, words * 4, hipMemcpyDeviceToHost, s));
+    SP1HIP_HIP(hipStreamSynchronize(s));            // (also covers the q upload above)
     std::vector<uint32_t> vals, paths;
     w.u64((uint64_t)n_rounds);
     for (int r = 0; r < n_rounds; r++) {
-        sp1hip_basefold_data_s* pd = rounds[r];
-        const int lg_h = dim + lb;
-        SP1HIP_TRY(sp1hip_merkle_open(pd->cw_tensors.data(), (int)pd->cw_tensors.size(), lg_h, pd->tree.u32(), d_idx.u32(),
-                                      nq, d_vals.u32(), d_paths.u32(), s));
-        vals.resize(nq * pd->total_width);
-        paths.resize(nq * lg_h * 8);
-        SP1HIP_HIP(hipMemcpyAsync(vals.data(), d_vals.p, vals.size() * 4, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipMemcpyAsync(paths.data(), d_paths.p, paths.size() * 4, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
-        write_opening(w, vals, nq, pd->total_width, pd->root, lg_h, paths);
+        const Slot& sl = slots[r];
+        vals.assign(opened.begin() + sl.vals_off, opened.begin() + sl.vals_off + sl.n_vals);
+        paths.assign(opened.begin() + sl.paths_off, opened.begin() + sl.paths_off + sl.n_paths);
+        write_opening(w, vals, nq, rounds[r]->total_width, rounds[r]->root, (size_t)(dim + lb), paths);
     }
     w.u64((uint64_t)dim);
     for (int r = 0; r < dim; r++) {
-        const int lg_c = dim + lb - r, lg_h = lg_c - 1;
-        SP1HIP_TRY(shift_indices(d_idx.u32(), nq, s));
-        SP1HIP_TRY(open_ext_pairs(cws[r]->u32(), lg_c, d_idx.u32(), nq, d_vals.u32(), s));
-        sp1hip_tensor_t none{nullptr, 0};
-        SP1HIP_TRY(sp1hip_merkle_open(&none, 1, lg_h, trees[r]->u32(), d_idx.u32(), nq, nullptr, d_paths.u32(), s));
-        vals.resize(nq * 8);
-        paths.resize(nq * (size_t)lg_h * 8);
-        SP1HIP_HIP(hipMemcpyAsync(vals.data(), d_vals.p, vals.size() * 4, hipMemcpyDeviceToHost, s));
-        if (!paths.empty())
-            SP1HIP_HIP(hipMemcpyAsync(paths.data(), d_paths.p, paths.size() * 4, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
-        write_opening(w, vals, nq, 8, round_roots[r].data(), (size_t)lg_h, paths);
+        const Slot& sl = slots[n_rounds + r];
+        vals.assign(opened.begin() + sl.vals_off, opened.begin() + sl.vals_off + sl.n_vals);
+        paths.assign(opened.begin() + sl.paths_off, opened.begin() + sl.paths_off + sl.n_paths);
+        write_opening(w, vals, nq, 8, round_roots[r].data(), (size_t)(dim + lb - r - 1), paths);
     }
     w.ext(final_poly);
     w.felt(pow_witness);
