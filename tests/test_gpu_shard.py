@@ -78,3 +78,61 @@ def test_large_shard_proof_is_accepted_by_the_pinned_verifier(api, scale_log2):
     v2 = orc.Challenger()
     v2.observe(prep_commit)
     assert orc.shard_verify(shapes_only, prep_commit, bytes(bad), L, lsh, v2, 2, 124, 16) != 0
+
+
+def test_concurrent_shard_provers_give_identical_proofs(api):
+    """The library is re-entrant per stream: three host threads proving the same shard on three streams at once
+    (their kernels interleave on the GPU) each return the bytes of the sequential proof."""
+    import os
+    import sys
+    import threading
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "bench"))
+    from synthetic_shard import build_shard
+    L, lsh = 18, 17
+    chips, prep_prep, shapes, area = build_shard(L, lsh, ((1 << 28) + (1 << 27)) >> 8)
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    prep_commit, prep_data = jp.commit_multilinears([prep_prep])
+
+    def prove(stream):
+        ch = api.DuplexChallenger()
+        ch.observe(prep_commit)
+        with torch.cuda.stream(stream):
+            return api.prove_shard(chips, [], prep_data, L, lsh, 32, ch, stream=stream)
+
+    ref = prove(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    out = {}
+
+    def worker(k, s):
+        out[k] = [prove(s) for _ in range(3)]
+
+    threads = [threading.Thread(target=worker, args=(k, torch.cuda.Stream())) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert all(p == ref for k in out for p in out[k]) and len(out) == 3
+
+
+def test_prove_shard_size_protocol_and_transcript_rollback(api):
+    chips, publics = make_shard_chips(4, 23)
+    L, lsh, batch = 3, 2, 2
+    jp = api.JaggedProver(L, lsh, batch, LB)
+    dev = [(a, i, api.ColMajor.from_row_major_host(m) if m.shape[0] else None,
+            api.ColMajor.from_row_major_host(p) if p is not None and p.shape[0] else None) for a, i, m, p in chips]
+    _, g_prep = jp.commit_multilinears([d[3] for d in dev if d[3] is not None])
+    ch = api.DuplexChallenger()
+    before = ch.state()
+    # a corrupted constraint program is rejected by the zerocheck stage: the caller's transcript must be untouched
+    bad = list(dev)
+    air = bad[0][0]
+    import copy
+    air2 = copy.deepcopy(air)
+    air2.instrs[0] = (0, 99, 0)                      # LOAD_MAIN column 99
+    bad[0] = (air2, bad[0][1], bad[0][2], bad[0][3])
+    with pytest.raises(api._lib.Sp1HipError):
+        api.prove_shard(bad, publics, g_prep, L, lsh, batch, ch, LB, NQ, PW)
+    assert np.array_equal(ch.state(), before)
+    good = api.prove_shard(dev, publics, g_prep, L, lsh, batch, ch, LB, NQ, PW)
+    assert len(good) > 1000 and not np.array_equal(ch.state(), before)
