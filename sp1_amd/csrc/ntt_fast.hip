@@ -18,6 +18,8 @@
 //    coalesced load.
 // VALU work per butterfly is then just the field arithmetic: add (3), sub (2-3), Montgomery
 // multiply (5).
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "device_ctx.hpp"
@@ -64,8 +66,10 @@ struct Radix {
 
 // Pointers are separate __restrict__ kernel arguments (not a struct) so the compiler knows the
 // twiddle tables cannot alias the output and keeps their wave-uniform loads on the scalar unit.
-template <int A, int B, bool STRIDED, bool FIRST>
-__global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict__ a_in, uint32_t* __restrict__ a_out,
+// WAVES: waves per workgroup. The 256-point tiles take ~65 KiB of LDS (two workgroups per CU), so they run with 8
+// waves per workgroup to keep 16 waves per CU in flight; the 64/128-point tiles use 4.
+template <int A, int B, bool STRIDED, bool FIRST, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __restrict__ a_in, uint32_t* __restrict__ a_out,
                                                      const uint32_t* __restrict__ a_tw_r,
                                                      const uint32_t* __restrict__ a_tw_lane,
                                                      const uint32_t* __restrict__ a_tw_lo,
@@ -104,13 +108,13 @@ __global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict_
             const uint32_t n_in = 1u << p.lg_n_in;
             const uint32_t* src = p.in + ((uint64_t)col << p.lg_n_in);
 #pragma unroll 4
-            for (uint32_t i = wave; i < R; i += 4) {
+            for (uint32_t i = wave; i < R; i += WAVES) {
                 const uint32_t idx = (i << lg_st) + i2_0 + lane;
                 tile[i * FT + lane] = idx < n_in ? src[idx] : 0u;
             }
         } else {
 #pragma unroll 4
-            for (uint32_t i = wave; i < R; i += 4) tile[i * FT + lane] = p.out[base + ((uint64_t)i << lg_st) + lane];
+            for (uint32_t i = wave; i < R; i += WAVES) tile[i * FT + lane] = p.out[base + ((uint64_t)i << lg_st) + lane];
         }
     } else {
         // 64 consecutive runs of R words; run `l` goes to LDS row l (pitch R + 1)
@@ -119,10 +123,10 @@ __global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict_
             const uint32_t n_in = 1u << p.lg_n_in;
             const uint32_t* src = p.in + ((uint64_t)col << p.lg_n_in);
             const uint64_t off = (uint64_t)blockIdx.x << (LG_R + 6);
-            for (uint32_t e = tid; e < (uint32_t)R * FT; e += 256)
+            for (uint32_t e = tid; e < (uint32_t)R * FT; e += 64 * WAVES)
                 tile[(e >> LG_R) * PITCH + (e & (R - 1))] = (off + e) < n_in ? src[off + e] : 0u;
         } else {
-            for (uint32_t e = tid; e < (uint32_t)R * FT; e += 256)
+            for (uint32_t e = tid; e < (uint32_t)R * FT; e += 64 * WAVES)
                 tile[(e >> LG_R) * PITCH + (e & (R - 1))] = p.out[base + e];
         }
     }
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict_
     uint32_t* U = lds + (STRIDED ? R * FT : FT * PITCH);
     if (STRIDED) {
         const int sh = kb::TWO_ADICITY - p.lg_seg;
-        for (uint32_t k1 = tid; k1 < (uint32_t)R; k1 += 256) {
+        for (uint32_t k1 = tid; k1 < (uint32_t)R; k1 += 64 * WAVES) {
             const uint32_t ex = (i2_0 * k1) << sh;
             U[k1] = kb::mul(p.tw_hi[ex >> TW_LO_BITS], p.tw_lo[ex & (TW_LO - 1)]);
         }
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict_
     __syncthreads();
 
     // ---- step 1: radix 2^A over elements i = i_lo + q 2^B (stages LG_R .. B+1), in place in LDS
-    for (uint32_t i_lo = wave; i_lo < (1u << B); i_lo += 4) {
+    for (uint32_t i_lo = wave; i_lo < (1u << B); i_lo += WAVES) {
         uint32_t x[1 << A];
 #pragma unroll
         for (int q = 0; q < (1 << A); q++) x[q] = tile[addr(i_lo + ((uint32_t)q << B), lane)];
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict_
     __syncthreads();
 
     // ---- step 2: radix 2^B over consecutive elements i = i_hi 2^B + q (stages B .. 1)
-    for (uint32_t i_hi = wave; i_hi < (1u << A); i_hi += 4) {
+    for (uint32_t i_hi = wave; i_hi < (1u << A); i_hi += WAVES) {
         uint32_t x[1 << B];
 #pragma unroll
         for (int q = 0; q < (1 << B); q++) x[q] = tile[addr((i_hi << B) + q, lane)];
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void ntt_fast_pass(const uint32_t* __restrict_
     }
     if (!STRIDED) {
         __syncthreads();
-        for (uint32_t e = tid; e < (uint32_t)R * FT; e += 256) p.out[base + e] = tile[(e >> LG_R) * PITCH + (e & (R - 1))];
+        for (uint32_t e = tid; e < (uint32_t)R * FT; e += 64 * WAVES) p.out[base + e] = tile[(e >> LG_R) * PITCH + (e & (R - 1))];
     }
 }
 
@@ -229,11 +233,12 @@ static int launch_pass(FastPassArgs args, bool strided, bool first, uint32_t til
     dim3 grid(tiles, n_cols);
     using Kern = void (*)(const uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,
                           int, int, int);
-    Kern kern = strided ? (first ? ntt_fast_pass<A, B, true, true> : ntt_fast_pass<A, B, true, false>)
-                        : (first ? ntt_fast_pass<A, B, false, true> : ntt_fast_pass<A, B, false, false>);
+    constexpr int WAVES = (A + B == 8) ? 8 : 4;
+    Kern kern = strided ? (first ? ntt_fast_pass<A, B, true, true, WAVES> : ntt_fast_pass<A, B, true, false, WAVES>)
+                        : (first ? ntt_fast_pass<A, B, false, true, WAVES> : ntt_fast_pass<A, B, false, false, WAVES>);
     if (lds > 48 * 1024)   // 256-point tiles need ~65 KiB of the CU's 160 KiB LDS
         SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args.in, args.out, args.tw_r, args.tw_lane, args.tw_lo, args.tw_hi,
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, s, args.in, args.out, args.tw_r, args.tw_lane, args.tw_lo, args.tw_hi,
                        args.lg_total, args.lg_seg, args.lg_n_in);
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
@@ -244,6 +249,9 @@ bool ntt_fast_plan(int lg_total, int bits[3], int* n_passes) {
     if (lg_total >= 18 && lg_total <= 24) {
         const int base = lg_total / 3, rem = lg_total % 3;
         for (int i = 0; i < 3; i++) bits[i] = base + (i >= 3 - rem ? 1 : 0);
+        if (const char* e = getenv("SP1HIP_NTT_PLAN")) {      // experiment: "877" etc.
+            if (strlen(e) == 3 && (e[0] - '0') + (e[1] - '0') + (e[2] - '0') == lg_total) for (int i = 0; i < 3; i++) bits[i] = e[i] - '0';
+        }
         *n_passes = 3;
         return true;
     }
