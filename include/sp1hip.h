@@ -133,6 +133,10 @@ int sp1hip_merkle_open(const sp1hip_tensor_t* tensors, int n_tensors, int lg_hei
 /* Batched permutations / hashes for testing and for small host-side uses:
  * d_states [n][16] permuted in place. */
 int sp1hip_poseidon2_permute(uint32_t* d_states, size_t n, sp1hip_stream_t stream);
+/* The same permutation in its all-integer formulation (modular-add linear layers, unsigned Montgomery S-box). The
+ * production kernels use the exact-fp64 linear layer + signed S-box of sp1_amd/csrc/poseidon2.hpp; this entry point
+ * exists so that the two independent formulations can be compared on hundreds of millions of states. */
+int sp1hip_poseidon2_permute_integer_form(uint32_t* d_states, size_t n, sp1hip_stream_t stream);
 
 /* ---------------------------------------------------------------- BaseFold kernels (a13, a14)
  * batch: out[r] = sum_c coeff[c] * col_c[r] over all columns of all tensors (message order)

@@ -139,13 +139,14 @@ __global__ __launch_bounds__(1024) void compress_top_kernel(uint32_t* layer, uin
     }
 }
 
+template <bool INTEGER_FORM>
 __global__ void permute_states_kernel(uint32_t* states, size_t n, const p2::RoundConstants* __restrict__ rc) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) s[k] = states[i * 16 + k];
-    p2::permute(s, *rc);
+    if (INTEGER_FORM) p2::permute_int(s, *rc); else p2::permute(s, *rc);
 #pragma unroll
     for (int k = 0; k < 16; k++) states[i * 16 + k] = s[k];
 }
@@ -260,7 +261,17 @@ int sp1hip_poseidon2_permute(uint32_t* d_states, size_t n, sp1hip_stream_t strea
     if (!n) return SP1HIP_SUCCESS;
     const DeviceCtx* ctx;
     SP1HIP_TRY(get_device_ctx(&ctx));
-    hipLaunchKernelGGL(permute_states_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), d_states, n, ctx->d_rc);
+    hipLaunchKernelGGL(permute_states_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, S(stream), d_states, n, ctx->d_rc);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_poseidon2_permute_integer_form(uint32_t* d_states, size_t n, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(d_states || n == 0, "null states");
+    if (n == 0) return SP1HIP_SUCCESS;
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));
+    hipLaunchKernelGGL(permute_states_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, S(stream), d_states, n, ctx->d_rc);
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }

@@ -51,6 +51,37 @@ def test_monty_roundtrip_and_permute(api):
     assert orc.from_monty(api.to_host(zero)).tolist() == kb_py.KAT_PERM_ZERO
 
 
+def test_poseidon2_formulations_agree_on_a_quarter_billion_states(api):
+    """The production permutation (exact fp64 linear layer + signed, correction-free S-boxes) against the all-integer
+    formulation on 2^28 states = as many permutations as two BASELINE commit steps: random words, plus the edge
+    patterns that stress the lazy ranges (all zero, all p - 1, single non-zero lanes, alternating 0 / p - 1).
+    Both are also pinned to the oracle on the first states."""
+    L = api._L()
+    n = 1 << 24
+    edge = np.zeros((64, 16), np.uint32)
+    edge[1] = P - 1
+    for k in range(16):
+        edge[2 + k, k] = P - 1
+        edge[18 + k, k] = 1
+    edge[34, ::2] = P - 1
+    edge[35, 1::2] = P - 1
+    edge[36:] = np.random.default_rng(7).integers(P - 64, P, (28, 16))
+    gen = torch.Generator(device="cuda")
+    for rep in range(16):                                   # 16 x 2^24 states
+        gen.manual_seed(100 + rep)
+        a = torch.randint(0, P, (n * 16,), dtype=torch.int32, device="cuda", generator=gen)
+        a[:edge.size] = torch.from_numpy(edge.astype(np.int32).reshape(-1)).cuda()
+        b = a.clone()
+        api.check(L.sp1hip_poseidon2_permute(api._dptr(a), n, api._stream_ptr()))
+        api.check(L.sp1hip_poseidon2_permute_integer_form(api._dptr(b), n, api._stream_ptr()))
+        assert torch.equal(a, b), "formulations differ (rep %d)" % rep
+        if rep == 0:
+            got = a[:edge.size].cpu().numpy().astype(np.uint32).reshape(64, 16)
+            for i in range(64):
+                assert np.array_equal(got[i], orc.permute(edge[i])), i
+        assert int(a.max()) < P and int(a.min()) >= 0
+
+
 def test_transpose_roundtrip(api):
     for shape in ((1, 1), (5, 3), (33, 65), (1000, 25), (4096, 7)):
         a = orc.random_felts(shape, 5)
