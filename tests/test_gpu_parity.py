@@ -363,6 +363,40 @@ def test_full_size_properties(api):
     assert orc.merkle_verify(commit, idx, vals, lg_n + lb, proof["merkle_root"], proof["paths"]) == 0
 
 
+def test_baseline_config2_commit_properties(api):
+    """The bench workload itself (2^20 x 256 KoalaBear trace as 8 batches of 32, blowup 4): checksums of the full
+    codeword that do not need the (slow) oracle — row 0 of the bit-reversed DFT is the evaluation at 1 = the column
+    sum, row 1 the evaluation at -1 = the alternating sum, over all 256 columns; and oracle-verified Merkle openings
+    (all 256 values of a row + 22-digest paths) of the full-size 8-tensor tree against the commitment."""
+    lg_n, lb, W, B = 20, 2, 32, 8
+    n = 1 << lg_n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42)
+    mles = [api.ColMajor(torch.randint(0, P, (W * n,), dtype=torch.int32, device="cuda", generator=gen), n, W) for _ in range(B)]
+    enc = api.DftEncoder(lb)
+    cws = enc.encode_batch(mles)
+    Lf = api._L()
+    for m, cw in zip(mles, cws):
+        canon = m.words.clone()
+        api.check(Lf.sp1hip_from_monty(api._dptr(canon), canon.numel(), api._stream_ptr()))
+        cols = canon.view(W, n).to(torch.int64)
+        total = cols.sum(dim=1) % P
+        alt = (cols[:, 0::2].sum(dim=1) - cols[:, 1::2].sum(dim=1)) % P
+        out = cw.words.view(W, n << lb)[:, :2].clone().contiguous()
+        api.check(Lf.sp1hip_from_monty(api._dptr(out), out.numel(), api._stream_ptr()))
+        assert torch.equal(out[:, 0].to(torch.int64), total) and torch.equal(out[:, 1].to(torch.int64), alt)
+    tcs = api.MerkleTcsProver()
+    commit, data = tcs.commit_tensors(cws)
+    idx = [0, 1, (1 << 22) - 1, 2718281, 3141592]
+    vals = tcs.compute_openings_at_indices(cws, idx)
+    proof = tcs.prove_openings_at_indices(data, idx)
+    assert vals.shape[-1] == W * B
+    assert orc.merkle_verify(commit, idx, vals, lg_n + lb, proof["merkle_root"], proof["paths"]) == 0
+    # the same commitment through the prover entry point the bench times
+    commit2, _ = api.BasefoldProver(lb, 124, 16).commit_mles(mles)
+    assert np.array_equal(commit, commit2)
+
+
 def _tables(shapes, seed):
     return [orc.random_felts(s, seed + i) if s[0] * s[1] else np.zeros(s, np.uint32) for i, s in enumerate(shapes)]
 
