@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 LG_N, WIDTH, LOG_BLOWUP, BATCH = 20, 256, 2, 32        # 8 stacked batches of 32 columns
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_TRAFFIC_PER_LAUNCH = 788688051                      # profiles/r01_pmc_summary.md: HBM bytes per leaf-hash launch (1/8 step)
 
 
 def timers_read(api, name):
@@ -135,25 +136,55 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     api.check(L.sp1hip_timers_enable(0))
+    tl = {name: timers_read(api, name) for name in ("leaf_hash", "ntt_pass0", "ntt_pass1", "ntt_pass2", "compress")}
     from sp1_amd import shards
     dt = shards.max_over_ranks(dt)      # shards are striped one per rank: no data-path collective
+
+    # the same kernels once more with the encode/hash overlap switched off (not timed into `value`): isolated
+    # launch durations, so the roofline object can show both what a launch achieves alone and inside the step
+    iso = {}
+    if rank == 0:
+        os.environ["SP1HIP_COMMIT_OVERLAP"] = "0"
+        api.check(L.sp1hip_timers_reset())
+        api.check(L.sp1hip_timers_enable(1))
+        t1 = time.perf_counter()
+        iso_steps = max(2, min(5, args.steps))
+        for _ in range(iso_steps):
+            _, pd = step()
+            del pd
+        torch.cuda.synchronize()
+        iso["ms_per_step"] = 1e3 * (time.perf_counter() - t1) / iso_steps
+        api.check(L.sp1hip_timers_enable(0))
+        for name in ("leaf_hash", "ntt_pass0", "ntt_pass1", "ntt_pass2"):
+            k, m = timers_read(api, name)
+            iso[name + "_ms_per_step"] = m / iso_steps
+        del os.environ["SP1HIP_COMMIT_OVERLAP"]
+        api.check(L.sp1hip_timers_reset())
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         N = n << LOG_BLOWUP
         rows_per_s = world * args.steps * n / dt
-        # dominant kernel: leaf_hash (one launch per step). Algorithmic bytes per launch
-        # (SURVEY §8d): leaf read 4*N*W + digest write 32*N.
-        launches, ms = timers_read(api, "leaf_hash")
-        leaf_ms = ms / max(launches, 1)
+        # dominant kernel: leaf hashing (one launch per stacked batch, 8 per step, overlapped with the encodes
+        # of the following batches). Algorithmic bytes per step: leaf read 4*N*W + digest write 32*N;
+        # per launch = 1/8 of that. The split adds 2 x 32 B of sponge-capacity carry per row per boundary.
+        leaf_launches, leaf_ms_total = tl["leaf_hash"]
+        per_step = leaf_launches // args.steps
+        leaf_ms = leaf_ms_total / args.steps            # all leaf-hash launches of one step
         leaf_bytes = 4 * N * WIDTH + 32 * N
+        carry_bytes = 64 * N * (per_step - 1)
         perms = N * (WIDTH // 8)
         ntt = {}
         for name in ("ntt_pass0", "ntt_pass1", "ntt_pass2", "compress"):
-            k, m = timers_read(api, name)
+            k, m = tl[name]
             if k:
                 ntt[name + "_ms_per_step"] = round(m / args.steps, 4)
         ntt_ms = sum(v for k, v in ntt.items() if k.startswith("ntt"))
         ntt_bytes = 4 * n * WIDTH * (1 + (1 << LOG_BLOWUP))
+        valu_peak = 256 * 64 * 2.4e9
+        iso_leaf = iso["leaf_hash_ms_per_step"]
+        iso_ntt = sum(iso[k] for k in iso if k.startswith("ntt"))
         out = {
             "metric": "RISC-V cycles proved/sec (core shard prove; synthetic config 2: commit phase, 1 trace row = 1 cycle)",
             "value": rows_per_s, "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,26 +194,33 @@ def main():
                                    "log_blowup 2: RS-encode NTT + Poseidon2 Merkle commit, bit-exact vs CPU oracle",
                        "rows": n, "cols": WIDTH, "log_blowup": LOG_BLOWUP, "parallelism": "independent shards, one per GPU",
                        "cells_per_s": rows_per_s * WIDTH, "commitment_word0": int(last[0])},
-            "roofline": {"bound": "hbm", "kernel": "leaf_hash_kernel", "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "leaf_hash_part_kernel", "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": leaf_bytes / (leaf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         # HBM bytes per launch from the committed PMC passes of this kernel on this workload
-                         # (profiles/r01_pmc_summary.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) — equals the
-                         # algorithmic bytes, i.e. no re-reads
-                         "traffic": 4429185024, "traffic_source": "profiles/r01_pmc_summary.md",
-                         "avg_launch_ms": leaf_ms, "algorithmic_bytes_per_launch": leaf_bytes,
+                         # HBM bytes per step of this kernel from the committed PMC passes
+                         # (profiles/r01_pmc_summary.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+                         "traffic": PMC_TRAFFIC_PER_LAUNCH, "traffic_source": "profiles/r01_pmc_summary.md",
+                         "launches_per_step": per_step, "avg_launch_ms": leaf_ms / max(per_step, 1),
+                         "algorithmic_bytes_per_launch": leaf_bytes // max(per_step, 1),
+                         "sponge_carry_bytes_per_step": carry_bytes,
                          # the bound that actually binds: VALU issue. 3722 = dynamic VALU instructions per
                          # permutation counted in the gfx950 ISA of this build (profiles/r01_pmc_summary.md, SQ pass:
-                         # SQ_INSTS_VALU agrees); peak = 256 CUs x 64 lanes x 2.4 GHz, one instruction per lane-clock
+                         # SQ_INSTS_VALU agrees); peak = 256 CUs x 64 lanes x 2.4 GHz, one instruction per lane-clock.
+                         # `frac` is measured inside the timed steps, where the launches share the chip with the
+                         # encode passes of the following batches; `frac_isolated` is the same launch with the overlap
+                         # switched off (SP1HIP_COMMIT_OVERLAP=0), measured right after the timed region.
                          "valu": {"insts_per_permutation": 3722, "achieved_lane_insts_per_s": 3722 * perms / (leaf_ms * 1e-3),
-                                  "peak_lane_insts_per_s": 256 * 64 * 2.4e9,
-                                  "frac": 3722 * perms / (leaf_ms * 1e-3) / (256 * 64 * 2.4e9)},
-                         "note": "integer-VALU-bound by construction (Poseidon2: %d permutations per launch, "
+                                  "peak_lane_insts_per_s": valu_peak, "frac": 3722 * perms / (leaf_ms * 1e-3) / valu_peak,
+                                  "frac_isolated": 3722 * perms / (iso_leaf * 1e-3) / valu_peak if iso_leaf else None},
+                         "note": "integer-VALU-bound by construction (Poseidon2: %d permutations per step, "
                                  "%.3g permutations/s); see DESIGN.md" % (perms, perms / (leaf_ms * 1e-3)),
                          "rs_encode": {"bound": "hbm", "ms_per_step": ntt_ms, "algorithmic_bytes_per_step": ntt_bytes,
                                        "achieved": ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
                                        "frac": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ntt_ms else None},
-                         "per_step_ms": ntt},
+                         "per_step_ms": ntt,
+                         "isolated": {"note": "same workload, encode/hash overlap off, %d steps after the timed region" % iso_steps,
+                                      "ms_per_step": round(iso["ms_per_step"], 4), "leaf_hash_ms_per_step": round(iso_leaf, 4),
+                                      "rs_encode_ms_per_step": round(iso_ntt, 4)}},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_lg_rows)

@@ -23,14 +23,17 @@ size_t arena_trim();
 
 // Optional event bracketing of a kernel launch (see sp1hip_timers_* in include/sp1hip.h).
 bool timers_on();
-void timer_begin(const char* name, hipStream_t s);
-void timer_end(hipStream_t s);
+int timer_begin(const char* name, hipStream_t s);      // index of the record, -1 if none
+void timer_end(int idx, hipStream_t s);
 struct ScopedTimer {
     hipStream_t s;
-    bool on;
-    ScopedTimer(const char* name, hipStream_t stream) : s(stream), on(timers_on()) { if (on) timer_begin(name, s); }
-    ~ScopedTimer() { if (on) timer_end(s); }
+    int idx;
+    ScopedTimer(const char* name, hipStream_t stream) : s(stream), idx(timers_on() ? timer_begin(name, stream) : -1) {}
+    ~ScopedTimer() { if (idx >= 0) timer_end(idx, s); }
 };
+
+// A side stream (and n_events reusable events) paired with the caller's stream (runtime.hip).
+int aux_stream_for(hipStream_t main, int n_events, hipStream_t* aux, hipEvent_t** events);
 
 }  // namespace sp1hip
 

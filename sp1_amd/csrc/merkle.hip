@@ -80,6 +80,82 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const uint32_t* const* _
     store_digest(leaves + (size_t)row * 8, s);
 }
 
+// The same sponge split at tensor boundaries: part k absorbs columns [c0, c0 + width) of the concatenated row.
+// Valid when every boundary falls on a multiple of the rate (8) and every part but the first starts with a
+// full block, so only the 8 capacity words cross a boundary (`carry`, column-major [8][height]): the rate
+// words are overwritten by the next block anyway (PaddingFreeSponge overwrite mode). Lets commit_mles hash
+// tensor k while tensor k + 1 is still being encoded on another stream.
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void leaf_hash_part_kernel(const uint32_t* const* __restrict__ cols, uint32_t width,
+                                                             uint32_t height, const p2::RoundConstants* __restrict__ rc,
+                                                             uint32_t* __restrict__ carry, uint32_t* __restrict__ leaves) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= height) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[8 + i] = FIRST ? 0u : carry[(size_t)i * height + row];
+    const uint32_t full = width >> 3;
+    for (uint32_t k = 0; k < full; k++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = cols[8 * k + j][row];
+        p2::permute(s, *rc);
+    }
+    if (LAST) {
+        const uint32_t rem = width & 7u;
+        if (rem) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((uint32_t)j < rem) s[j] = cols[8 * full + j][row];
+            p2::permute(s, *rc);
+        }
+        store_digest(leaves + (size_t)row * 8, s);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) carry[(size_t)i * height + row] = s[8 + i];
+    }
+}
+
+// Groups consecutive tensors into parts that leaf_hash_part_kernel can hash one after the other: a part is
+// closed as soon as the concatenated row so far is a whole number of blocks; a trailing remainder narrower
+// than one block joins the part before it. parts[k] = {last tensor of part k, first column, width}.
+// Fewer than two parts: hash in one launch instead.
+void leaf_hash_plan(const sp1hip_tensor_t* tensors, int n_tensors, std::vector<LeafPart>* parts) {
+    parts->clear();
+    uint32_t c0 = 0, c = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        c += tensors[i].width;
+        if (c > c0 && ((c - c0) & 7u) == 0) {
+            parts->push_back({i, c0, c - c0});
+            c0 = c;
+        }
+    }
+    if (c > c0) {
+        if (c - c0 >= 8 || parts->empty()) parts->push_back({n_tensors - 1, c0, c - c0});
+        else { parts->back().last_tensor = n_tensors - 1; parts->back().width += c - c0; }
+    } else if (!parts->empty()) {
+        parts->back().last_tensor = n_tensors - 1;      // zero-width tensors at the end
+    }
+}
+
+// Enqueues part `k` of `n_parts`: d_cols points at the column table entry of the part's first column.
+int leaf_hash_part(const uint32_t* const* d_cols, uint32_t width, int k, int n_parts, uint32_t height, uint32_t* d_carry,
+                   uint32_t* d_tree, const DeviceCtx* ctx, hipStream_t s) {
+    ScopedTimer t("leaf_hash", s);
+    const dim3 grid((height + 255) / 256), block(256);
+    const bool first = k == 0, last = k == n_parts - 1;
+    if (first && last) return SP1HIP_ERROR_INVALID_ARGUMENT;
+    if (first)
+        hipLaunchKernelGGL((leaf_hash_part_kernel<true, false>), grid, block, 0, s, d_cols, width, height, ctx->d_rc, d_carry, d_tree);
+    else if (last)
+        hipLaunchKernelGGL((leaf_hash_part_kernel<false, true>), grid, block, 0, s, d_cols, width, height, ctx->d_rc, d_carry, d_tree);
+    else
+        hipLaunchKernelGGL((leaf_hash_part_kernel<false, false>), grid, block, 0, s, d_cols, width, height, ctx->d_rc, d_carry, d_tree);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
 __device__ __forceinline__ void load_pair(const uint32_t* src, uint32_t (&s)[16]) {
     const uint4* p = reinterpret_cast<const uint4*>(src);
     uint4 a = p[0], b = p[1], c = p[2], d = p[3];

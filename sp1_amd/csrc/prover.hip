@@ -27,6 +27,9 @@
 namespace sp1hip {
 
 int merkle_finish_tree(uint32_t*, int, uint32_t, uint32_t*, const DeviceCtx*, hipStream_t);
+void leaf_hash_plan(const sp1hip_tensor_t* tensors, int n_tensors, std::vector<LeafPart>* parts);
+int leaf_hash_part(const uint32_t* const* d_cols, uint32_t width, int k, int n_parts, uint32_t height, uint32_t* d_carry,
+                   uint32_t* d_tree, const DeviceCtx* ctx, hipStream_t s);
 int commit_ext_pairs(const uint32_t* d_cw, int lg_n, uint32_t* d_tree, uint32_t* d_root_and_commit, hipStream_t s);
 int open_ext_pairs(const uint32_t* d_cw, int lg_n, const uint32_t* d_indices, size_t n_idx, uint32_t* d_values, hipStream_t s);
 int shift_indices(uint32_t* d_idx, size_t n, hipStream_t s);
@@ -471,13 +474,60 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
         pd->mles.push_back(mles[i]);
         pd->cws.emplace_back(new DeviceBuf());
         SP1HIP_TRY(pd->cws.back()->alloc(N * mles[i].width * 4, s));
-        SP1HIP_TRY(sp1hip_rs_encode_batch(pd->cws.back()->u32(), mles[i].d_data, lg_n, lg_blowup, mles[i].width, s));
         pd->cw_tensors.push_back({pd->cws.back()->u32(), mles[i].width});
         pd->total_width += mles[i].width;
     }
     SP1HIP_TRY(pd->tree.alloc((2 * N - 1) * 32, s));
     DeviceBuf rc;
     SP1HIP_TRY(rc.alloc(64, s));
+    const char* ov = getenv("SP1HIP_COMMIT_OVERLAP");
+    // default: overlap when the codeword is large enough to fill the chip; "0" never, "1" always (tests)
+    const bool overlap = ov ? ov[0] != '0' : N * (size_t)pd->total_width >= ((size_t)1 << 24);
+    std::vector<LeafPart> parts;
+    if (overlap) leaf_hash_plan(pd->cw_tensors.data(), n_mles, &parts);
+    if (parts.size() >= 2) {
+        // Leaf hashing is VALU-issue bound, the encode passes wait on HBM a quarter of their time: encode tensor
+        // k + 1 on the side stream while this stream absorbs tensor k into the per-row sponge states.
+        hipStream_t aux;
+        hipEvent_t* ev;
+        SP1HIP_TRY(aux_stream_for(s, n_mles + 1, &aux, &ev));
+        struct Join {                      // an early return must not hand buffers back while `aux` still writes them
+            hipStream_t aux;
+            ~Join() { (void)hipStreamSynchronize(aux); }
+        };
+        TensorTable tab;
+        uint32_t tw;
+        SP1HIP_TRY(make_tensor_table(pd->cw_tensors.data(), n_mles, &tab, &tw));
+        DeviceBuf cols, carry;
+        SP1HIP_TRY(cols.alloc((size_t)tw * sizeof(uint32_t*), s));
+        SP1HIP_TRY(carry.alloc(N * 8 * 4, s));
+        SP1HIP_TRY(expand_columns_async(tab, tw, N, (const uint32_t**)cols.p, s));
+        SP1HIP_HIP(hipEventRecord(ev[n_mles], s));            // inputs and recycled buffers are ordered on `s`
+        SP1HIP_HIP(hipStreamWaitEvent(aux, ev[n_mles], 0));
+        {
+            Join join{aux};
+            for (int i = 0; i < n_mles; i++) {
+                SP1HIP_TRY(sp1hip_rs_encode_batch(pd->cws[i]->u32(), mles[i].d_data, lg_n, lg_blowup, mles[i].width, aux));
+                SP1HIP_HIP(hipEventRecord(ev[i], aux));
+            }
+            for (int k = 0; k < (int)parts.size(); k++) {
+                SP1HIP_HIP(hipStreamWaitEvent(s, ev[parts[k].last_tensor], 0));
+                SP1HIP_TRY(leaf_hash_part((const uint32_t* const*)cols.p + parts[k].c0, parts[k].width, k, (int)parts.size(),
+                                          (uint32_t)N, carry.u32(), pd->tree.u32(), ctx, s));
+            }
+            SP1HIP_TRY(merkle_finish_tree(pd->tree.u32(), lg_h, tw, rc.u32(), ctx, s));
+            uint32_t h[16];
+            SP1HIP_HIP(hipMemcpyAsync(h, rc.p, 64, hipMemcpyDeviceToHost, s));
+            SP1HIP_HIP(hipStreamSynchronize(s));            // `s` waited for every encode: `aux` is idle here
+            memcpy(pd->root, h, 32);
+            memcpy(pd->commit, h + 8, 32);
+        }
+        memcpy(h_commit, pd->commit, 32);
+        *out = pd.release();
+        return SP1HIP_SUCCESS;
+    }
+    for (int i = 0; i < n_mles; i++)
+        SP1HIP_TRY(sp1hip_rs_encode_batch(pd->cws[i]->u32(), mles[i].d_data, lg_n, lg_blowup, mles[i].width, s));
     SP1HIP_TRY(sp1hip_merkle_commit(pd->cw_tensors.data(), n_mles, lg_h, pd->tree.u32(), rc.u32(), s));
     uint32_t h[16];
     SP1HIP_HIP(hipMemcpyAsync(h, rc.p, 64, hipMemcpyDeviceToHost, s));

@@ -40,22 +40,48 @@ struct TimerRec { std::string name; hipEvent_t a, b; };
 static std::mutex g_timer_mutex;
 static bool g_timers_on = false;
 static std::vector<TimerRec> g_timer_recs;
-static thread_local TimerRec* g_open_timer = nullptr;
 
 bool timers_on() { return g_timers_on; }
-void timer_begin(const char* name, hipStream_t s) {
+int timer_begin(const char* name, hipStream_t s) {
     TimerRec r;
     r.name = name;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
     (void)hipEventRecord(r.a, s);
     std::lock_guard<std::mutex> lock(g_timer_mutex);
     g_timer_recs.push_back(r);
-    g_open_timer = &g_timer_recs.back();
+    return (int)g_timer_recs.size() - 1;
 }
-void timer_end(hipStream_t s) {
+void timer_end(int idx, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_timer_mutex);
-    if (g_timer_recs.empty()) return;
-    (void)hipEventRecord(g_timer_recs.back().b, s);
+    if (idx < 0 || idx >= (int)g_timer_recs.size()) return;   // reset in between: drop the sample
+    (void)hipEventRecord(g_timer_recs[idx].b, s);
+}
+
+// ---- helper streams ------------------------------------------------------------------------------
+// One high-priority side stream per (device, caller stream), created on first use and kept: commit_mles
+// runs the Reed-Solomon encodes there while the caller's stream hashes the batches already encoded.
+struct AuxRec { hipStream_t aux; std::vector<hipEvent_t> events; };
+static std::mutex g_aux_mutex;
+static std::map<std::pair<int, hipStream_t>, AuxRec> g_aux;
+
+int aux_stream_for(hipStream_t main, int n_events, hipStream_t* aux, hipEvent_t** events) {
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    AuxRec& r = g_aux[{dev, main}];
+    if (!r.aux) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+        SP1HIP_HIP(hipStreamCreateWithPriority(&r.aux, hipStreamNonBlocking, hi));
+    }
+    while ((int)r.events.size() < n_events) {
+        hipEvent_t e;
+        SP1HIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        r.events.push_back(e);
+    }
+    *aux = r.aux;
+    *events = r.events.data();   // stable until the next call for this stream (one host thread per stream)
+    return SP1HIP_SUCCESS;
 }
 
 // ---- stream-keyed buffer arena -------------------------------------------------------------------

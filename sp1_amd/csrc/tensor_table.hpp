@@ -2,6 +2,8 @@
 // flattened into one device table of column base pointers, so kernels index "column g of the
 // concatenated row" with one wave-uniform (scalar-cache) pointer load.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 
 namespace sp1hip {
@@ -20,6 +22,10 @@ int make_tensor_table(const sp1hip_tensor_t* tensors, int n_tensors, TensorTable
 // Enqueues the expansion of `tab` into d_cols[total_width] (device pointers to each column).
 int expand_columns_async(const TensorTable& tab, uint32_t total_width, uint64_t height, const uint32_t** d_cols,
                          hipStream_t stream);
+
+// One launch of the split leaf hash (merkle.hip): columns [c0, c0 + width) of the concatenated row, ready
+// once tensors 0 .. last_tensor are encoded.
+struct LeafPart { int last_tensor; uint32_t c0, width; };
 
 // RAII scratch from the stream-keyed arena (the block goes back to the free list when the launch
 // has been enqueued; the next user on the same stream is ordered behind it).

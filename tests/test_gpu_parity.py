@@ -397,6 +397,35 @@ def test_baseline_config2_commit_properties(api):
     assert np.array_equal(commit, commit2)
 
 
+@pytest.mark.parametrize("mode", ["1", "0"])
+@pytest.mark.parametrize("lg_n,lb,widths", [
+    (10, 2, [16, 8, 24]),          # splittable: every boundary on a multiple of the sponge rate
+    (12, 1, [8, 8, 13]),           # ragged tail in the last tensor
+    (9, 2, [32, 32, 32, 32, 32, 32]),
+    (11, 2, [16, 10, 14]),         # parts {16}, {10 + 14}: a part closes where the row is a whole number of blocks
+    (10, 2, [32, 32, 3]),          # a tail narrower than one block joins the part before it
+    (8, 2, [8, 4]),                # ... which leaves a single part here -> single-launch path
+    (9, 1, [5, 6, 7]),             # never block-aligned -> single-launch path
+    (0, 2, [8, 8]),                # one-row tensors
+])
+def test_commit_mles_overlapped_encode_and_hash(api, monkeypatch, mode, lg_n, lb, widths):
+    """commit_mles hashes tensor k on the caller's stream while tensor k + 1 is encoded on a side stream, carrying
+    the 8 capacity words of every row's sponge across tensor boundaries (leaf_hash_part_kernel). Forced on ("1")
+    and off ("0") at sizes the oracle handles: commitment, every codeword and the whole tree are the oracle's."""
+    monkeypatch.setenv("SP1HIP_COMMIT_OVERLAP", mode)
+    ms = [orc.random_felts((1 << lg_n, w), 900 + 7 * i + lg_n) for i, w in enumerate(widths)]
+    o = orc.CommittedRound(ms, lb)
+    prover = api.BasefoldProver(lb, 124, 16)
+    d = [api.ColMajor.from_row_major_host(m) for m in ms]
+    for _ in range(2):             # second pass re-uses the side stream, its events and recycled buffers
+        commit, pd = prover.commit_mles(d)
+        assert np.array_equal(commit, o.commit)
+        for k in range(len(ms)):
+            assert np.array_equal(pd.codeword(k).to_row_major_host(), o.codeword(k))
+        assert np.array_equal(pd.tree(), o.layers())
+        del pd
+
+
 def _tables(shapes, seed):
     return [orc.random_felts(s, seed + i) if s[0] * s[1] else np.zeros(s, np.uint32) for i, s in enumerate(shapes)]
 
