@@ -16,8 +16,8 @@
 //  * the inter-pass twiddle w_seg^(i2 k1) is split into a per-workgroup factor (wave-uniform, built
 //    once per workgroup in LDS) and a per-lane factor read from a small cached table with a
 //    coalesced load.
-// VALU work per butterfly is then just the field arithmetic: add (3), sub (2-3), Montgomery
-// multiply (5).
+// VALU work per butterfly is then just the field arithmetic: add (3) and the signed Montgomery product of
+// the difference (7, sub_mul_tw); the radix steps whose base index is 0 skip the multiplications by 1.
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -38,27 +38,42 @@ struct FastPassArgs {
     int lg_total, lg_seg, lg_n_in;
 };
 
+// (a - b) * w for canonical a, b and a wave-uniform twiddle given as the pair (w, w' = w p^-1 mod 2^32): the
+// signed Montgomery product hi(d w) - hi((d w' mod 2^32) p) of d = a - b in (-p, p) is exact (both 64-bit
+// products share their low word), lies in (-p, p), and takes v_sub + v_mul_lo + 2 v_mul_hi_i32 + v_sub;
+// one add + unsigned-min brings it back to [0, p). One VALU slot less than widening a - b + p, multiplying
+// 32 x 32 -> 64 and reducing with v_mul_lo + v_mad_u64 + correction.
+__device__ __forceinline__ uint32_t sub_mul_tw(uint32_t a, uint32_t b, uint32_t w, uint32_t wm) {
+    const int32_t d = (int32_t)(a - b);
+    const int32_t q = (int32_t)((uint32_t)d * wm);
+    const uint32_t r = (uint32_t)(__mulhi(d, (int32_t)w) - __mulhi(q, (int32_t)kb::P));
+    return kb::umin(r, r + kb::P);
+}
+
 template <int K>
 struct Radix {
     // In-register DIF over x[0 .. 2^K): element q sits at transform index i = i0 + q * 2^LG_STEP; the
     // stages handled are s = LG_STEP + K .. LG_STEP + 1 of an r = 2^LG_R point transform. Twiddle for
-    // the butterfly (q, q + hq) at stage s: w_r^(((i0 + (q mod hq) 2^LG_STEP)) << (LG_R - s)).
-    template <int LG_R, int LG_STEP>
+    // the butterfly (q, q + hq) at stage s: w_r^(((i0 + (q mod hq) 2^LG_STEP)) << (LG_R - s)); tw_r holds
+    // w_r^j for j < r/2 followed by the matching w' words. ZERO_BASE: i0 is known to be 0, so the butterflies
+    // with q mod hq == 0 have twiddle 1 (47 % of a radix-16 step) and skip the multiplication.
+    template <int LG_R, int LG_STEP, bool ZERO_BASE>
     static __device__ __forceinline__ void run(uint32_t (&x)[1 << K], uint32_t i0, const uint32_t* __restrict__ tw_r) {
 #pragma unroll
         for (int t = K; t >= 1; t--) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int hq = 1 << (t - 1);
             const int s = LG_STEP + t;
 #pragma unroll
             for (int q = 0; q < (1 << K); q++) {
                 if (q & hq) continue;
-                const uint32_t e = (i0 + (uint32_t)((q & (hq - 1)) << LG_STEP)) << (LG_R - s);
-                const uint32_t w = tw_r[e];   // wave-uniform -> scalar load
                 const uint32_t a = x[q], b = x[q + hq];
                 x[q] = kb::add(a, b);
-                x[q + hq] = kb::monty_reduce((uint64_t)(a - b + kb::P) * w);   // a - b + p in (0, 2p)
+                if (ZERO_BASE && (q & (hq - 1)) == 0) {
+                    x[q + hq] = kb::sub(a, b);
+                } else {
+                    const uint32_t e = (i0 + (uint32_t)((q & (hq - 1)) << LG_STEP)) << (LG_R - s);
+                    x[q + hq] = sub_mul_tw(a, b, tw_r[e], tw_r[e + (1u << (LG_R - 1))]);   // wave-uniform -> scalar loads
+                }
             }
         }
     }
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
         uint32_t x[1 << A];
 #pragma unroll
         for (int q = 0; q < (1 << A); q++) x[q] = tile[addr(i_lo + ((uint32_t)q << B), lane)];
-        Radix<A>::template run<LG_R, B>(x, i_lo, p.tw_r);
+        Radix<A>::template run<LG_R, B, false>(x, i_lo, p.tw_r);
 #pragma unroll
         for (int q = 0; q < (1 << A); q++) tile[addr(i_lo + ((uint32_t)q << B), lane)] = x[q];
     }
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
         uint32_t x[1 << B];
 #pragma unroll
         for (int q = 0; q < (1 << B); q++) x[q] = tile[addr((i_hi << B) + q, lane)];
-        Radix<B>::template run<LG_R, 0>(x, 0u, p.tw_r);
+        Radix<B>::template run<LG_R, 0, true>(x, 0u, p.tw_r);
         if (STRIDED) {
 #pragma unroll
             for (int q = 0; q < (1 << B); q++) {
@@ -178,13 +193,16 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
     }
 }
 
-// tw_r tables (w_r^j, j < r/2) for r = 64, 128, 256 and lane tables per lg_seg, built on first use.
+// tw_r tables (w_r^j, j < r/2, then the same entries times p^-1 mod 2^32) for r = 64, 128, 256 and lane tables per lg_seg, built on first use.
 __global__ void fill_tw_r_kernel(uint32_t* out, int lg_r, const uint32_t* __restrict__ tw_lo,
                                  const uint32_t* __restrict__ tw_hi) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (1u << lg_r) / 2) return;
+    const uint32_t half = (1u << lg_r) / 2;
+    if (j >= half) return;
     const uint32_t e = j << (kb::TWO_ADICITY - lg_r);
-    out[j] = kb::mul(tw_hi[e >> TW_LO_BITS], tw_lo[e & (TW_LO - 1)]);
+    const uint32_t w = kb::mul(tw_hi[e >> TW_LO_BITS], tw_lo[e & (TW_LO - 1)]);
+    out[j] = w;
+    out[half + j] = w * kb::MU;      // w p^-1 mod 2^32 for the signed Montgomery product (sub_mul_tw)
 }
 __global__ void fill_tw_lane_kernel(uint32_t* out, int lg_seg, const uint32_t* __restrict__ tw_lo,
                                     const uint32_t* __restrict__ tw_hi) {
@@ -209,7 +227,7 @@ static int get_fast_tables(const DeviceCtx* ctx, hipStream_t s, int lg_r, int lg
     if (!g_fast_tables[ctx->device]) g_fast_tables[ctx->device] = new FastTables();
     FastTables* ft = g_fast_tables[ctx->device];
     if (!ft->tw_r[lg_r]) {
-        SP1HIP_HIP(hipMalloc((void**)&ft->tw_r[lg_r], ((size_t)1 << lg_r) * 2));
+        SP1HIP_HIP(hipMalloc((void**)&ft->tw_r[lg_r], ((size_t)1 << lg_r) * 4));
         hipLaunchKernelGGL(fill_tw_r_kernel, dim3(1), dim3(256), 0, s, ft->tw_r[lg_r], lg_r, ctx->d_tw_lo, ctx->d_tw_hi);
         SP1HIP_LAUNCH_CHECK();
         SP1HIP_HIP(hipStreamSynchronize(s));   // other streams may use the table next
