@@ -103,6 +103,24 @@ int sp1hip_transpose_to_col_major(uint32_t* d_out, const uint32_t* d_in_row_majo
                                   sp1hip_stream_t stream);
 int sp1hip_transpose_to_row_major(uint32_t* d_out, const uint32_t* d_in_col_major, size_t rows, size_t cols,
                                   sp1hip_stream_t stream);
+/* Host traces -> device tables in one call (staging half). Replaces the per-chip
+ * "copy host trace to device" + `DeviceTensor::transpose` of `device_main_tracegen`
+ * (/root/reference/sp1-gpu/crates/jagged_tracegen/src/lib.rs:L819-L835). Table i is `rows x cols` Montgomery
+ * words, row-major, at h_data (pinned memory — `sp1hip_malloc_host` / `sp1hip_host_register` — for an
+ * asynchronous copy at full PCIe rate; pageable memory works but is copied through the runtime's bounce
+ * buffers); d_out[i] receives it column-major (`cols` columns of `rows` words). Chunked copies on a side
+ * stream overlap the transposes on `stream`; returns after enqueueing. The host buffers must stay untouched
+ * until `stream` has passed this call. */
+typedef struct {
+    const uint32_t* h_data;
+    uint64_t rows;
+    uint32_t cols;
+} sp1hip_host_table_t;
+int sp1hip_stage_tables(const sp1hip_host_table_t* tables, int n_tables, uint32_t* const* d_out, sp1hip_stream_t stream);
+/* hipHostRegister / hipHostUnregister on caller-owned memory (the reference's `cuda_host_register`,
+ * /root/reference/sp1-gpu/crates/sys/src/runtime.rs:L75-L172). */
+int sp1hip_host_register(void* h_ptr, size_t bytes);
+int sp1hip_host_unregister(void* h_ptr);
 /* canonical <-> Montgomery, in place */
 int sp1hip_to_monty(uint32_t* d_data, size_t n, sp1hip_stream_t stream);
 int sp1hip_from_monty(uint32_t* d_data, size_t n, sp1hip_stream_t stream);

@@ -26,6 +26,10 @@ class Table(C.Structure):
     _fields_ = [("d_data", C.c_void_p), ("rows", C.c_uint64), ("cols", C.c_uint32)]
 
 
+class HostTable(C.Structure):
+    _fields_ = [("h_data", C.c_void_p), ("rows", C.c_uint64), ("cols", C.c_uint32)]
+
+
 class ZcChip(C.Structure):
     _fields_ = [("program", C.POINTER(C.c_uint32)), ("n_instr", C.c_uint32), ("main_width", C.c_uint32),
                 ("prep_width", C.c_uint32), ("num_constraints", C.c_uint32), ("d_main", C.c_void_p),
@@ -97,6 +101,9 @@ PROTOTYPES = [
     ("sp1hip_timers_read", None, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     ("sp1hip_transpose_to_col_major", None, [_vp, _vp, _sz, _sz, _vp]),
     ("sp1hip_transpose_to_row_major", None, [_vp, _vp, _sz, _sz, _vp]),
+    ("sp1hip_stage_tables", None, [C.POINTER(HostTable), _int, C.POINTER(_vp), _vp]),
+    ("sp1hip_host_register", None, [_vp, _sz]),
+    ("sp1hip_host_unregister", None, [_vp]),
     ("sp1hip_to_monty", None, [_vp, _sz, _vp]),
     ("sp1hip_from_monty", None, [_vp, _sz, _vp]),
     ("sp1hip_rs_encode_batch", None, [_vp, _vp, _int, _int, _sz, _vp]),

@@ -97,6 +97,34 @@ class ColMajor:
         return Tensor(C.c_void_p(self.words.data_ptr()), self.width)
 
 
+def stage_tables(host_tables, stream=None):
+    """Row-major host traces -> column-major device tables, one call for the whole shard (sp1hip_stage_tables:
+    chunked PCIe copies on a side stream overlapped with the on-GPU transposes; mirrors `device_main_tracegen`'s
+    "copy host trace to device", /root/reference/sp1-gpu/crates/jagged_tracegen/src/lib.rs:L819-L835).
+    `host_tables`: 2-D numpy uint32 arrays or CPU torch int32 tensors (pinned for the asynchronous path), Montgomery
+    words. Returns a list of ColMajor; each keeps its host source alive (the copies are asynchronous)."""
+    from ._lib import HostTable
+    n = len(host_tables)
+    arr = (HostTable * max(n, 1))()
+    outs = (C.c_void_p * max(n, 1))()
+    result = []
+    for i, a in enumerate(host_tables):
+        if isinstance(a, np.ndarray):
+            assert a.dtype == np.uint32 and a.ndim == 2 and a.flags["C_CONTIGUOUS"], "row-major uint32 [rows][cols]"
+            ptr, (h, w) = a.ctypes.data, a.shape
+        else:
+            assert a.dtype == torch.int32 and a.dim() == 2 and a.is_contiguous() and not a.is_cuda
+            ptr, (h, w) = a.data_ptr(), a.shape
+        dst = device_words(h * w)
+        cm = ColMajor(dst, h, w)
+        cm._host_source = a
+        arr[i] = HostTable(C.c_void_p(ptr), h, w)
+        outs[i] = C.c_void_p(dst.data_ptr())
+        result.append(cm)
+    check(_L().sp1hip_stage_tables(arr, n, outs, _stream_ptr(stream)))
+    return result
+
+
 def _tensor_array(tensors):
     arr = (Tensor * len(tensors))()
     for i, t in enumerate(tensors):

@@ -75,6 +75,15 @@ def test_argument_validation_needs_no_device(lib):
                         GkrChip(b"A", none.ctypes.data_as(C.POINTER(C.c_uint32)), 1, 2, 0, None, None, 0))
     assert lib.sp1hip_logup_gkr_prove(two, 2, 3, h, None, C.byref(n), None) == -1 and b"sorted" in lib.sp1hip_last_error()
     lib.sp1hip_challenger_free(h)
+    # staging: nothing to do is fine, missing buffers and over-wide tables are rejected up front
+    from sp1_amd._lib import HostTable
+    assert lib.sp1hip_stage_tables(None, 0, None, None) == 0
+    outs = (C.c_void_p * 1)(None)
+    assert lib.sp1hip_stage_tables((HostTable * 1)(HostTable(None, 0, 7)), 1, outs, None) == 0     # an empty trace
+    assert lib.sp1hip_stage_tables((HostTable * 1)(HostTable(None, 4, 7)), 1, outs, None) == -1
+    assert b"null table data" in lib.sp1hip_last_error()
+    assert lib.sp1hip_stage_tables((HostTable * 1)(HostTable(words.ctypes.data, 1, 1 << 20)), 1, outs, None) == -1
+    assert lib.sp1hip_host_register(None, 16) == -1 and lib.sp1hip_host_unregister(None) == -1
 
 
 def test_host_transcript_matches_oracle(lib):
