@@ -532,13 +532,13 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     // ---- first layer
     DeviceBuf d_progs, d_betas, d_descs;
     uint32_t max_rows = 0;
+    std::vector<uint32_t> flat;                              // upload sources live to the end of the call
+    std::vector<IntDesc> descs(K);
     {
-        std::vector<uint32_t> flat;
         std::vector<size_t> poff(K);
         for (uint32_t i = 0; i < K; i++) { poff[i] = flat.size(); flat.insert(flat.end(), progs[i].begin(), progs[i].end()); }
         SP1HIP_TRY(upload(d_progs, flat.data(), flat.size() * 4, s));
         SP1HIP_TRY(upload(d_betas, betas.data(), betas.size() * 16, s));
-        std::vector<IntDesc> descs(K);
         for (uint32_t i = 0; i < K; i++) {
             const ChipInfo& c = info[int_chip[i]];
             descs[i] = IntDesc{d_progs.u32() + poff[i], c.d_main, c.d_prep, c.rows, (uint32_t*)n_ptr(L, i), d_ptr(L, i)};
@@ -553,38 +553,40 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         }
     }
     // ---- fraction tree
+    // every level's descriptors are planned and uploaded once: the tree is built by L - 1 back-to-back launches
     DeviceBuf d_trans;
-    SP1HIP_TRY(d_trans.alloc((size_t)K * sizeof(TransDesc), s));
-    std::vector<TransDesc> tdesc(K);
-    for (int l = L; l >= 2; l--) {
-        uint32_t mr = 0;
+    std::vector<TransDesc> tdesc((size_t)K * (L >= 2 ? L - 1 : 0));
+    std::vector<uint32_t> level_mr(L + 1, 0);
+    for (int l = L; l >= 2; l--)
         for (uint32_t i = 0; i < K; i++) {
             const uint32_t rin = rows_at(info[int_chip[i]].rows, l);
-            tdesc[i] = TransDesc{n_ptr(l, i), d_ptr(l, i), (Ext*)n_ptr(l - 1, i), d_ptr(l - 1, i), rin};
-            mr = std::max(mr, (rin + 1) / 2);
+            tdesc[(size_t)(L - l) * K + i] = TransDesc{n_ptr(l, i), d_ptr(l, i), (Ext*)n_ptr(l - 1, i), d_ptr(l - 1, i), rin};
+            level_mr[l] = std::max(level_mr[l], (rin + 1) / 2);
         }
+    SP1HIP_TRY(upload(d_trans, tdesc.data(), tdesc.size() * sizeof(TransDesc), s));
+    for (int l = L; l >= 2; l--) {
+        const uint32_t mr = level_mr[l];
         if (!mr) continue;
-        SP1HIP_HIP(hipMemcpyAsync(d_trans.p, tdesc.data(), (size_t)K * sizeof(TransDesc), hipMemcpyHostToDevice, s));
+        const TransDesc* d_t = (const TransDesc*)d_trans.p + (size_t)(L - l) * K;
         ScopedTimer t("gkr_transition", s);
-        if (l == L) hipLaunchKernelGGL(transition_kernel<true>, dim3(tiles_for(mr), K), dim3(256), 0, s, (const TransDesc*)d_trans.p);
-        else hipLaunchKernelGGL(transition_kernel<false>, dim3(tiles_for(mr), K), dim3(256), 0, s, (const TransDesc*)d_trans.p);
+        if (l == L) hipLaunchKernelGGL(transition_kernel<true>, dim3(tiles_for(mr), K), dim3(256), 0, s, d_t);
+        else hipLaunchKernelGGL(transition_kernel<false>, dim3(tiles_for(mr), K), dim3(256), 0, s, d_t);
         SP1HIP_LAUNCH_CHECK();
-        SP1HIP_HIP(hipStreamSynchronize(s));                 // tdesc is reused by the next level
     }
+    Mailbox mb;                                              // device -> host hand-overs outside the sumcheck rounds
+    SP1HIP_TRY(mb.init(s));
     // ---- circuit output = level 1 (<= 2 rows per interaction): index 2 i + r, padding (0, 1)
     std::vector<Ext> out_n(2 * (size_t)W, kb::ext_zero()), out_d(2 * (size_t)W, kb::ext_one());
     {
         std::vector<Ext> hn(std::max<size_t>(level_entries[1], 1)), hd(std::max<size_t>(level_entries[1], 1));
         if (L >= 2) {
-            SP1HIP_HIP(hipMemcpyAsync(hn.data(), lvN[1].p, level_entries[1] * 16, hipMemcpyDeviceToHost, s));
+            SP1HIP_TRY(mb.fetch(lvN[1].p, level_entries[1] * 4, hn.data()));
         } else {                                             // L == 1: level 1 is the first layer itself (base numerators)
             std::vector<uint32_t> hb(std::max<size_t>(level_entries[1], 1));
-            SP1HIP_HIP(hipMemcpyAsync(hb.data(), lvN[1].p, level_entries[1] * 4, hipMemcpyDeviceToHost, s));
-            SP1HIP_HIP(hipStreamSynchronize(s));
+            SP1HIP_TRY(mb.fetch(lvN[1].p, level_entries[1], hb.data()));
             for (size_t e = 0; e < level_entries[1]; e++) hn[e] = kb::ext_from_base(hb[e]);
         }
-        SP1HIP_HIP(hipMemcpyAsync(hd.data(), lvD[1].p, level_entries[1] * 16, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
+        SP1HIP_TRY(mb.fetch(lvD[1].p, level_entries[1] * 4, hd.data()));
         for (uint32_t i = 0; i < K; i++)
             for (uint32_t r = 0; r < rows_at(info[int_chip[i]].rows, 1); r++) { out_n[2 * i + r] = hn[off[1][i] + r]; out_d[2 * i + r] = hd[off[1][i] + r]; }
     }
@@ -652,8 +654,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         }
     }
     DeviceBuf d_all;
-    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s));
-    SP1HIP_HIP(hipStreamSynchronize(s));
+    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s));     // all_descs outlives the copy
     size_t launch_idx = 0;                                   // next K descriptors of d_all
     RoundSyncHost rsync;
     SP1HIP_TRY(rsync.init(s));
@@ -745,8 +746,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size);
             SP1HIP_LAUNCH_CHECK();
             std::vector<Ext> host(std::max<size_t>(so_next[K], 1) * 4);
-            SP1HIP_HIP(hipMemcpyAsync(host.data(), scratch[cur].p, so_next[K] * 64, hipMemcpyDeviceToHost, s));
-            SP1HIP_HIP(hipStreamSynchronize(s));
+            SP1HIP_TRY(mb.fetch(scratch[cur].p, so_next[K] * 16, host.data()));
             for (uint32_t i = 0; i < K; i++) {
                 if (so_next[i + 1] == so_next[i]) continue;   // chip without rows: stays (0, 1)
                 const size_t base = 4 * so_next[i], len = so_next[i + 1] - so_next[i];
@@ -822,8 +822,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         hipLaunchKernelGGL(open_sum_kernel, dim3(((uint32_t)total_cols * 4 + 255) / 256), dim3(256), 0, s, d_part.u32(), chunks,
                            (uint32_t)total_cols * 4, d_res.u32());
         SP1HIP_LAUNCH_CHECK();
-        SP1HIP_HIP(hipMemcpyAsync(openings.data(), d_res.p, total_cols * 16, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
+        SP1HIP_TRY(mb.fetch(d_res.p, total_cols * 4, openings.data()));
     }
     challenger_observe(ch, kb::to_monty((uint32_t)n_chips));
     {

@@ -35,6 +35,7 @@
 #include <array>
 
 #include "device_ctx.hpp"
+#include "round_sync.hpp"
 #include "stacked_data.hpp"
 #include "tensor_table.hpp"
 
@@ -130,13 +131,21 @@ __device__ __forceinline__ void block_reduce_store(const Ext& a, const Ext& b, u
     }
 }
 
-__global__ __launch_bounds__(256) void jg_reduce_partials(const uint32_t* __restrict__ partials, uint32_t n, uint32_t* out8) {
+// Sums the block partials and hands the two ext sums to the host through the mailbox slot (round_sync.hpp): payload
+// words [1..8], then the sequence number — no copy, no stream synchronise.
+__global__ __launch_bounds__(256) void jg_reduce_partials(const uint32_t* __restrict__ partials, uint32_t n,
+                                                          volatile uint32_t* slot, uint32_t seq) {
+    __shared__ uint32_t out8[8];
     Ext a = kb::ext_zero(), b = kb::ext_zero();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         a = kb::ext_add(a, Ext{{partials[8 * i], partials[8 * i + 1], partials[8 * i + 2], partials[8 * i + 3]}});
         b = kb::ext_add(b, Ext{{partials[8 * i + 4], partials[8 * i + 5], partials[8 * i + 6], partials[8 * i + 7]}});
     }
     block_reduce_store(a, b, out8);
+    if (threadIdx.x < 8) slot[1 + threadIdx.x] = out8[threadIdx.x];     // the same lanes wrote out8
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) slot[0] = seq;
 }
 
 // ---- round 0: y(0) = sum J[2i] q[2i], H = sum (J[2i] + J[2i+1]) (q[2i] + q[2i+1])   (hadamard.rs:L100-L135)
@@ -374,14 +383,15 @@ __global__ __launch_bounds__(256) void je_phase1_round(JeCols C, const Ext* __re
 // One round of the second half (variable = bit rp of t_c; every bit of t_{c+1} is bound). V0 / V1: the
 // column-independent bound part times the two lambda-endpoint matrices (host). prev_bit_of_u: the
 // previously bound variable was bit D-1 of u (rp == 0) or bit rp-1 of t.
+struct JeV { Ext v[8]; };          // the two prefix row vectors of a phase-2 round, passed by value (128 B of kernarg)
 __global__ __launch_bounds__(256) void je_phase2_round(JeCols C, const Ext* __restrict__ suffix2, int D, int rp, Ext alpha_prev,
-                                                       Ext half, const Ext* __restrict__ V, Ext* __restrict__ inter,
+                                                       Ext half, JeV V, Ext* __restrict__ inter,
                                                        uint32_t* __restrict__ partials) {
     Ext y0 = kb::ext_zero(), yh = kb::ext_zero();
     const Ext one = kb::ext_one();
     Ext v0[4], v1[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++) { v0[m] = ld_ext(V, m); v1[m] = ld_ext(V, 4 + m); }
+    for (int m = 0; m < 4; m++) { v0[m] = V.v[m]; v1[m] = V.v[4 + m]; }
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < C.n; k += gridDim.x * blockDim.x) {
         const uint32_t t = C.t[k], u = C.u[k];
         const bool x = rp == 0 ? ((u >> (D - 1)) & 1u) : ((t >> (rp - 1)) & 1u);
@@ -463,22 +473,22 @@ Ext observe_and_sample(sp1hip_challenger_t* ch, const std::array<Ext, 3>& poly) 
 }
 
 struct Scratch {                    // device scratch shared by all rounds of one proof
-    DeviceBuf partials, out8;
+    DeviceBuf partials;
+    Mailbox mb;
     uint32_t h_out[8];
     hipStream_t s;
     static constexpr uint32_t MAX_BLOCKS = 2048;
     int init(hipStream_t stream) {
         s = stream;
         SP1HIP_TRY(partials.alloc((size_t)MAX_BLOCKS * 32, s));
-        return out8.alloc(32, s);
+        return mb.init(s);
     }
     static uint32_t blocks_for(uint64_t threads) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), MAX_BLOCKS); }
     // reduce `nb` block partials and bring the two ext sums to the host
     int finish(uint32_t nb, Ext* a, Ext* b) {
-        hipLaunchKernelGGL(jg_reduce_partials, dim3(1), dim3(256), 0, s, partials.u32(), nb, out8.u32());
+        hipLaunchKernelGGL(jg_reduce_partials, dim3(1), dim3(256), 0, s, partials.u32(), nb, (volatile uint32_t*)mb.h_slot, mb.seq + 1);
         SP1HIP_LAUNCH_CHECK();
-        SP1HIP_HIP(hipMemcpyAsync(h_out, out8.p, 32, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
+        SP1HIP_TRY(mb.wait_next(h_out, 8));
         memcpy(a, h_out, 16);
         memcpy(b, h_out + 4, 16);
         return SP1HIP_SUCCESS;
@@ -530,7 +540,7 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
         else { ts.push_back(prefix[c]); us.push_back(prefix[c + 1]); zc.push_back(col_eq[c]); }
     }
     const uint32_t n = (uint32_t)ts.size();
-    DeviceBuf d_t, d_u, d_zc, d_mats, d_suffix, d_state, d_inter, d_V;
+    DeviceBuf d_t, d_u, d_zc, d_mats, d_suffix, d_state, d_inter;
     SP1HIP_TRY(upload(d_t, ts.data(), n * 4, s));
     SP1HIP_TRY(upload(d_u, us.data(), n * 4, s));
     SP1HIP_TRY(upload(d_zc, zc.data(), (size_t)n * 16, s));
@@ -540,7 +550,6 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
     SP1HIP_TRY(d_suffix.alloc((size_t)D * n * 64, s));
     SP1HIP_TRY(d_state.alloc((size_t)n * 128, s));
     SP1HIP_TRY(d_inter.alloc((size_t)n * 16, s));
-    SP1HIP_TRY(d_V.alloc(128, s));
     const JeCols C{d_t.u32(), d_u.u32(), (const Ext*)d_zc.p, n};
     const uint32_t nb = Scratch::blocks_for(n);
 
@@ -590,12 +599,13 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
                 for (int m = 0; m < 4; m++) acc = acc + W[m] * B[((size_t)rp * 2 + b) * 16 + 4 * m + k];
                 V[4 * b + k] = acc;
             }
-        SP1HIP_HIP(hipMemcpyAsync(d_V.p, V, 128, hipMemcpyHostToDevice, s));
+        JeV Varg;
+        memcpy(Varg.v, V, sizeof V);
         hipLaunchKernelGGL(je_phase2_round, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_suffix2.p, D, rp, alpha, half,
-                           (const Ext*)d_V.p, (Ext*)d_inter.p, sc.partials.u32());
+                           Varg, (Ext*)d_inter.p, sc.partials.u32());
         SP1HIP_LAUNCH_CHECK();
         Ext y0, yh;
-        SP1HIP_TRY(sc.finish(nb, &y0, &yh));            // (synchronises: V may be reused next iteration)
+        SP1HIP_TRY(sc.finish(nb, &y0, &yh));
         poly = interpolate(y0, yh + yh + yh + yh, claim - y0);
         proof->polys.push_back(poly);
         alpha = observe_and_sample(ch, poly);
@@ -779,14 +789,12 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
         // tables were never materialised: T == 2, fold straight from the base data (cannot happen with lsh >= 1 and
         // two-padding-table rounds unless the area is exactly 2; handled for completeness)
         uint32_t hq[2];
-        SP1HIP_HIP(hipMemcpyAsync(hq, rounds[0]->d_dense, 8, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
+        SP1HIP_TRY(sc.mb.fetch(rounds[0]->d_dense, 2, hq));
         q_eval = kb::ext_from_base(hq[0]) + kb::ext_mul_base(alpha, kb::sub(hq[1], hq[0]));
     } else {
         Ext hq[2] = {kb::ext_zero(), kb::ext_zero()}, hj[2] = {kb::ext_zero(), kb::ext_zero()};
-        SP1HIP_HIP(hipMemcpyAsync(hq, tabs[cur].p, (size_t)n_live * 16, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipMemcpyAsync(hj, tabs[cur + 1].p, (size_t)n_live * 16, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
+        SP1HIP_TRY(sc.mb.fetch(tabs[cur].p, (size_t)n_live * 4, hq));
+        SP1HIP_TRY(sc.mb.fetch(tabs[cur + 1].p, (size_t)n_live * 4, hj));
         q_eval = hq[0] + alpha * (hq[1] - hq[0]);
         j_eval = hj[0] + alpha * (hj[1] - hj[0]);
     }
@@ -812,8 +820,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
         batch_evals[r].resize(w);
         ScopedTimer t("jagged_batch_evals", s);
         SP1HIP_TRY(sp1hip_mle_eval_columns(rounds[r]->batches.data(), (int)rounds[r]->batches.size(), lsh, d_eq.u32(), d_evals.u32(), stream));
-        SP1HIP_HIP(hipMemcpyAsync(batch_evals[r].data(), d_evals.p, (size_t)w * 16, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
+        SP1HIP_TRY(sc.mb.fetch(d_evals.p, (size_t)w * 4, batch_evals[r].data()));
         flat_claims.insert(flat_claims.end(), batch_evals[r].begin(), batch_evals[r].end());
         bf.push_back(rounds[r]->basefold);
     }

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "round_sync.hpp"
 #include "tensor_table.hpp"
 
 namespace sp1hip {
@@ -73,7 +74,8 @@ struct DuplexChallenger {
 
 // Each lane tests one candidate witness: overwrite slot `pos` of the pre-loaded sponge state, permute,
 // look at state[7] (the first word `sample` pops). atomicMin keeps the smallest hit.
-__global__ __launch_bounds__(256) void grind_kernel(const uint32_t* __restrict__ base_state, int pos, uint32_t mask,
+struct GrindBase { uint32_t w[16]; };       // the sponge state the candidates are written into, passed by value
+__global__ __launch_bounds__(256) void grind_kernel(GrindBase base_state, int pos, uint32_t mask,
                                                     uint32_t first, uint32_t count,
                                                     const p2::RoundConstants* __restrict__ rc, uint32_t* result) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void grind_kernel(const uint32_t* __restrict__
     const uint32_t wm = kb::to_monty(w);
     uint32_t s[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = base_state[i];
+    for (int i = 0; i < 16; i++) s[i] = base_state.w[i];
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = (i == pos) ? wm : s[i];
     p2::permute(s, *rc);
@@ -112,22 +114,20 @@ static int grind(DuplexChallenger& ch, int bits, uint32_t* witness_monty, hipStr
         const DeviceCtx* ctx;
         SP1HIP_TRY(get_device_ctx(&ctx));
         AsyncScratch buf;
-        SP1HIP_TRY(buf.alloc(17 * 4, s));
-        uint32_t* d_base = (uint32_t*)buf.p;
-        uint32_t* d_res = d_base + 16;
-        uint32_t init[17];
-        memcpy(init, base, sizeof base);
-        init[16] = 0xffffffffu;
-        SP1HIP_HIP(hipMemcpyAsync(d_base, init, sizeof init, hipMemcpyHostToDevice, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));   // `init` is a stack buffer
+        SP1HIP_TRY(buf.alloc(4, s));
+        uint32_t* d_res = (uint32_t*)buf.p;
+        GrindBase gb;
+        memcpy(gb.w, base, sizeof base);
+        Mailbox mb;
+        SP1HIP_TRY(mb.init(s));
+        SP1HIP_HIP(hipMemsetAsync(d_res, 0xff, 4, s));
         uint32_t batch = 1u << std::min(22, bits + 3);
         for (uint64_t first = 0; first < kb::P && found == 0xffffffffu; first += batch) {
             const uint32_t cnt = (uint32_t)std::min<uint64_t>(batch, kb::P - first);
-            hipLaunchKernelGGL(grind_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, d_base, pos, mask, (uint32_t)first,
+            hipLaunchKernelGGL(grind_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, gb, pos, mask, (uint32_t)first,
                                cnt, ctx->d_rc, d_res);
             SP1HIP_LAUNCH_CHECK();
-            SP1HIP_HIP(hipMemcpyAsync(&found, d_res, 4, hipMemcpyDeviceToHost, s));
-            SP1HIP_HIP(hipStreamSynchronize(s));
+            SP1HIP_TRY(mb.fetch(d_res, 1, &found));
         }
     }
     if (found == 0xffffffffu) { set_error("grind: no witness found"); return SP1HIP_ERROR_RUNTIME; }
@@ -261,8 +261,9 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     SP1HIP_TRY(d_mle[0].alloc(n * 16, s));
     SP1HIP_TRY(d_mle[1].alloc(n * 8 + 16, s));
     SP1HIP_TRY(d_eq.alloc(n * 8 + 16, s));
-    SP1HIP_HIP(hipMemcpyAsync(d_coeffs.p, coeffs.data(), total_len * 16, hipMemcpyHostToDevice, s));
-    SP1HIP_HIP(hipStreamSynchronize(s));
+    SP1HIP_HIP(hipMemcpyAsync(d_coeffs.p, coeffs.data(), total_len * 16, hipMemcpyHostToDevice, s));   // `coeffs` outlives the copy
+    Mailbox mb;                                   // every device -> host hand-over below goes through it (round_sync.hpp)
+    SP1HIP_TRY(mb.init(s));
     SP1HIP_TRY(sp1hip_basefold_batch(mles.data(), (int)mles.size(), dim, d_coeffs.u32(), d_mle[0].u32(), s));
     kb::Ext cur_claim = kb::ext_zero();
     for (size_t i = 0; i < n_claims; i++) cur_claim = kb::ext_add(cur_claim, kb::ext_mul(claims[i], coeffs[i]));
@@ -293,8 +294,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
         SP1HIP_TRY(trees.back()->alloc((((size_t)2 << (lg_c - 1)) - 1) * 32, s));
         SP1HIP_TRY(commit_ext_pairs(cws.back()->u32(), lg_c, trees.back()->u32(), d_rb.u32() + 4, s));
         uint32_t rb[20];
-        SP1HIP_HIP(hipMemcpyAsync(rb, d_rb.p, sizeof rb, hipMemcpyDeviceToHost, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));
+        SP1HIP_TRY(mb.fetch(d_rb.p, 20, rb));
         kb::Ext zero_val{{rb[0], rb[1], rb[2], rb[3]}};
         kb::Ext one_val = kb::ext_add(kb::ext_mul(kb::ext_sub(cur_claim, zero_val), kb::ext_inv(last)), zero_val);
         uni.push_back(zero_val);
@@ -324,8 +324,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
             SP1HIP_HIP(hipMemcpyAsync(d_rb.u32() + 20 + k, cws.back()->u32() + (size_t)k * len, 4, hipMemcpyDeviceToDevice, s));
     }
     uint32_t fp[4];
-    SP1HIP_HIP(hipMemcpyAsync(fp, d_rb.u32() + 20, 16, hipMemcpyDeviceToHost, s));
-    SP1HIP_HIP(hipStreamSynchronize(s));
+    SP1HIP_TRY(mb.fetch(d_rb.u32() + 20, 4, fp));
     kb::Ext final_poly{{fp[0], fp[1], fp[2], fp[3]}};
     ch.observe_ext(final_poly);
     uint32_t pow_witness;
@@ -374,8 +373,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
         SP1HIP_TRY(sp1hip_merkle_open(&none, 1, lg_h, trees[r]->u32(), d_idx.u32(), nq, nullptr, d_open.u32() + sl.paths_off, s));
     }
     std::vector<uint32_t> opened(std::max<size_t>(words, 1));
-    SP1HIP_HIP(hipMemcpyAsync(opened.data(), d_open.p, words * 4, hipMemcpyDeviceToHost, s));
-    SP1HIP_HIP(hipStreamSynchronize(s));            // (also covers the q upload above)
+    SP1HIP_TRY(mb.fetch(d_open.p, words, opened.data()));      // (its completion also covers the q upload above)
     std::vector<uint32_t> vals, paths;
     w.u64((uint64_t)n_rounds);
     for (int r = 0; r < n_rounds; r++) {
@@ -517,8 +515,9 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
             }
             SP1HIP_TRY(merkle_finish_tree(pd->tree.u32(), lg_h, tw, rc.u32(), ctx, s));
             uint32_t h[16];
-            SP1HIP_HIP(hipMemcpyAsync(h, rc.p, 64, hipMemcpyDeviceToHost, s));
-            SP1HIP_HIP(hipStreamSynchronize(s));            // `s` waited for every encode: `aux` is idle here
+            Mailbox mb;
+            SP1HIP_TRY(mb.init(s));
+            SP1HIP_TRY(mb.fetch(rc.p, 16, h));              // `s` waited for every encode: `aux` is idle here
             memcpy(pd->root, h, 32);
             memcpy(pd->commit, h + 8, 32);
         }
@@ -530,8 +529,9 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
         SP1HIP_TRY(sp1hip_rs_encode_batch(pd->cws[i]->u32(), mles[i].d_data, lg_n, lg_blowup, mles[i].width, s));
     SP1HIP_TRY(sp1hip_merkle_commit(pd->cw_tensors.data(), n_mles, lg_h, pd->tree.u32(), rc.u32(), s));
     uint32_t h[16];
-    SP1HIP_HIP(hipMemcpyAsync(h, rc.p, 64, hipMemcpyDeviceToHost, s));
-    SP1HIP_HIP(hipStreamSynchronize(s));
+    Mailbox mb;
+    SP1HIP_TRY(mb.init(s));
+    SP1HIP_TRY(mb.fetch(rc.p, 16, h));
     memcpy(pd->root, h, 32);
     memcpy(pd->commit, h + 8, 32);
     memcpy(h_commit, pd->commit, 32);

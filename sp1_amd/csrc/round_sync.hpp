@@ -136,4 +136,65 @@ struct RoundSyncHost {
     }
 };
 
+// ---- Mailbox: "copy these few device words to the host and wait for them" without hipMemcpyAsync + hipStreamSynchronize.
+// A one-workgroup kernel, ordered on the stream behind the producer, stores the words into mapped pinned memory and
+// then a sequence number; the host spins on the sequence number. Seeing it also means everything enqueued on the
+// stream before the fetch has completed (in-order stream), so host staging buffers handed to earlier
+// hipMemcpyAsync calls may be reused. Measured against the copy + synchronise pair this saves ~30-50 us per
+// round trip (no blit dispatch on completion, no interrupt wake-up); a shard proof has ~170 of them outside GKR.
+constexpr uint32_t MAILBOX_WORDS = 16384;       // payload capacity (64 KiB)
+
+int mailbox_publish(const uint32_t* d_src, uint32_t n_words, uint32_t* h_slot, uint32_t seq, hipStream_t s);   // runtime.hip
+
+struct MailboxSlot { uint32_t* h_slot; };       // [0] = sequence number, [1 .. MAILBOX_WORDS] payload
+int mailbox_acquire(MailboxSlot* out);          // runtime.hip (process-wide free list, like the round-sync slots)
+void mailbox_release(MailboxSlot slot);
+
+struct Mailbox {
+    uint32_t* h_slot = nullptr;
+    uint32_t seq = 0;
+    hipStream_t s = nullptr;
+    int init(hipStream_t stream) {
+        s = stream;
+        MailboxSlot slot;
+        SP1HIP_TRY(mailbox_acquire(&slot));
+        h_slot = slot.h_slot;
+        seq = h_slot[0];
+        return SP1HIP_SUCCESS;
+    }
+    ~Mailbox() { if (h_slot) mailbox_release(MailboxSlot{h_slot}); }
+    // d_src[0 .. n_words) -> out, after everything already enqueued on the stream. n_words == 0: a pure fence.
+    int fetch(const void* d_src, size_t n_words, void* out) {
+        if (n_words > MAILBOX_WORDS) {           // too large for the slot: the classic pair
+            SP1HIP_HIP(hipMemcpyAsync(out, d_src, n_words * 4, hipMemcpyDeviceToHost, s));
+            SP1HIP_HIP(hipStreamSynchronize(s));
+            return SP1HIP_SUCCESS;
+        }
+        SP1HIP_TRY(mailbox_publish((const uint32_t*)d_src, (uint32_t)n_words, h_slot, seq + 1, s));
+        return wait_next(out, n_words);
+    }
+    // For kernels that write the slot themselves (payload words [1 ..], then `seq + 1` into word 0): waits for
+    // that sequence number and copies the payload out.
+    int wait_next(void* out, size_t n_words) {
+        seq++;
+        volatile uint32_t* slot = h_slot;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t spins = 0;
+        while (slot[0] != seq) {
+            if ((++spins & 0xffff) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) return map_hip_error(q, "kernel failed while the host waited for a result");
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                    set_error("timed out waiting for a device result");
+                    return SP1HIP_ERROR_RUNTIME;
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        uint32_t* o = (uint32_t*)out;
+        for (size_t k = 0; k < n_words; k++) o[k] = slot[1 + k];
+        return SP1HIP_SUCCESS;
+    }
+};
+
 }  // namespace sp1hip

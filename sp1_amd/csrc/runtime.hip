@@ -221,6 +221,44 @@ void round_sync_release(RoundSyncSlot slot) {
     g_rs_free[dev].push_back(slot);
 }
 
+__global__ __launch_bounds__(256) void mailbox_publish_kernel(const uint32_t* __restrict__ src, uint32_t n,
+                                                              volatile uint32_t* slot, uint32_t seq) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256) slot[1 + i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) slot[0] = seq;
+}
+
+int mailbox_publish(const uint32_t* d_src, uint32_t n_words, uint32_t* h_slot, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(mailbox_publish_kernel, dim3(1), dim3(256), 0, s, d_src, n_words, (volatile uint32_t*)h_slot, seq);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+static std::vector<MailboxSlot> g_mb_free[64];
+
+int mailbox_acquire(MailboxSlot* out) {
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    SP1HIP_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lock(g_rs_mutex);
+        if (!g_mb_free[dev].empty()) { *out = g_mb_free[dev].back(); g_mb_free[dev].pop_back(); return SP1HIP_SUCCESS; }
+    }
+    MailboxSlot slot{nullptr};
+    SP1HIP_HIP(hipHostMalloc((void**)&slot.h_slot, (size_t)(MAILBOX_WORDS + 1) * 4, hipHostMallocMapped));
+    memset(slot.h_slot, 0, (size_t)(MAILBOX_WORDS + 1) * 4);
+    *out = slot;
+    return SP1HIP_SUCCESS;
+}
+
+void mailbox_release(MailboxSlot slot) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lock(g_rs_mutex);
+    g_mb_free[dev].push_back(slot);
+}
+
 }  // namespace sp1hip
 
 using namespace sp1hip;

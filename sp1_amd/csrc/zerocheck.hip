@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "round_sync.hpp"
 
 namespace sp1hip {
 
@@ -327,6 +328,12 @@ __global__ __launch_bounds__(256) void zc_fix_kernel(const ZcFixDesc* __restrict
     const kb::Ext r = kb::ext_add(K::scale(alpha, K::sub(y, x)), K::to_ext(x));
 #pragma unroll
     for (int q = 0; q < 4; q++) d.out[((size_t)c * 4 + q) * out_rows + i] = r.c[q];
+}
+
+struct ZcGatherDesc { const uint32_t* src; uint32_t n_words, dst_off; };
+__global__ __launch_bounds__(256) void zc_gather_kernel(const ZcGatherDesc* __restrict__ descs, uint32_t* __restrict__ out) {
+    const ZcGatherDesc d = descs[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < d.n_words; i += 256) out[d.dst_off + i] = d.src[i];
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -661,6 +668,12 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> pows(max_constraints);
     { Ext cur = kb::ext_one(); for (auto& x : pows) { x = cur; cur = cur * alpha; } }
 
+    // Host staging vectors handed to hipMemcpyAsync live until the end of the call (`staging`, the ChipStates, the
+    // per-round `keep_*` lists below): no synchronisation is needed just to keep a source buffer valid, and every
+    // device->host hand-over goes through the mailbox (round_sync.hpp), so the stream is never drained mid-proof.
+    Mailbox mb;
+    SP1HIP_TRY(mb.init(s));
+    std::vector<std::vector<uint32_t>> staging;
     std::vector<std::unique_ptr<ChipState>> st;
     std::vector<Ext> claims;
     size_t oo = 0;
@@ -696,7 +709,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         c->vgeq = VGeq{(uint32_t)chips[i].real_rows, kb::ext_one(), kb::ext_zero()};
         c->d_main = chips[i].d_main;
         c->d_prep = chips[i].d_prep;
-        std::vector<uint32_t> all_prog;
+        staging.emplace_back();
+        std::vector<uint32_t>& all_prog = staging.back();
         for (auto& ck : c->chunks) {
             c->chunk_off.push_back((uint32_t)(all_prog.size() / 4));
             all_prog.insert(all_prog.end(), ck.prog.begin(), ck.prog.end());
@@ -705,14 +719,12 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         SP1HIP_TRY(c->d_alpha.alloc(c->alpha_pows.size() * 16, s));
         SP1HIP_TRY(c->d_gkr.alloc(c->gkr_pows.size() * 16, s));
         SP1HIP_HIP(hipMemcpyAsync(c->d_prog.p, all_prog.data(), all_prog.size() * 4, hipMemcpyHostToDevice, s));
-        SP1HIP_HIP(hipStreamSynchronize(s));    // all_prog is a per-chip staging vector
         if (!c->alpha_pows.empty())
             SP1HIP_HIP(hipMemcpyAsync(c->d_alpha.p, c->alpha_pows.data(), c->alpha_pows.size() * 16, hipMemcpyHostToDevice, s));
         if (!c->gkr_pows.empty())
             SP1HIP_HIP(hipMemcpyAsync(c->d_gkr.p, c->gkr_pows.data(), c->gkr_pows.size() * 16, hipMemcpyHostToDevice, s));
         st.push_back(std::move(c));
     }
-    SP1HIP_HIP(hipStreamSynchronize(s));   // host staging vectors above may now be reused
 
     std::vector<Ext> zeta(L);
     memcpy(zeta.data(), h_zeta, (size_t)L * 16);
@@ -726,6 +738,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<uint32_t> h_sums((size_t)n_chips * 16);
     DevBuf d_descs, d_ranges, d_fix_descs, d_partial, d_sums;
     size_t partial_cap = 0, descs_cap = 0;
+    std::vector<std::unique_ptr<std::vector<ZcDesc>>> keep_descs;
+    std::vector<std::unique_ptr<std::vector<ZcChipRange>>> keep_ranges;
+    std::vector<std::unique_ptr<std::vector<ZcFixDesc>>> keep_fds;
     SP1HIP_TRY(d_ranges.alloc((size_t)n_chips * sizeof(ZcChipRange), s));
     SP1HIP_TRY(d_fix_descs.alloc((size_t)n_chips * 2 * sizeof(ZcFixDesc), s));
     SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 64, s));
@@ -735,8 +750,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
         SP1HIP_TRY(sp1hip_partial_lagrange(reinterpret_cast<const sp1hip_ext_t*>(zeta.data()), nv - 1, d_eq.u32(), stream));
         // descriptors: one per (chip with real rows, chunk); a chip's blocks are contiguous
-        std::vector<ZcDesc> descs;
-        std::vector<ZcChipRange> ranges;
+        keep_descs.emplace_back(new std::vector<ZcDesc>());
+        keep_ranges.emplace_back(new std::vector<ZcChipRange>());
+        std::vector<ZcDesc>& descs = *keep_descs.back();
+        std::vector<ZcChipRange>& ranges = *keep_ranges.back();
         std::vector<int> desc_chip;
         uint32_t total_blocks = 0, max_regs = 1, max_instr = 1;
         for (int i = 0; i < n_chips; i++) {
@@ -782,9 +799,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, (const ZcChipRange*)d_ranges.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, (const ZcChipRange*)d_ranges.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             SP1HIP_LAUNCH_CHECK();
-            SP1HIP_HIP(hipMemcpyAsync(h_sums.data(), d_sums.p, (size_t)n_ranges * 64, hipMemcpyDeviceToHost, s));
+            SP1HIP_TRY(mb.fetch(d_sums.p, (size_t)n_ranges * 16, h_sums.data()));
         }
-        SP1HIP_HIP(hipStreamSynchronize(s));
         for (size_t k = 0; k < desc_chip.size(); k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + k * 16, 64);
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
         std::vector<UniPoly> uni(n_chips);
@@ -820,7 +836,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             st[i]->uni = uni[i];
         }
         // ---- fix the last variable of every table (fix_last_variable.rs): one launch for all chips
-        std::vector<ZcFixDesc> fds;
+        keep_fds.emplace_back(new std::vector<ZcFixDesc>());
+        std::vector<ZcFixDesc>& fds = *keep_fds.back();
         std::vector<std::unique_ptr<DevBuf>> fresh;
         std::vector<std::pair<int, bool>> owner;   // (chip, is_main)
         uint32_t fix_blocks = 0;
@@ -851,8 +868,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
             else hipLaunchKernelGGL(zc_fix_kernel<false>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
             SP1HIP_LAUNCH_CHECK();
-            SP1HIP_HIP(hipStreamSynchronize(s));     // `fds` is a host staging buffer
-            for (size_t k = 0; k < fds.size(); k++) {
+            for (size_t k = 0; k < fds.size(); k++) {     // the arena is stream-ordered: the old table is recycled behind this launch
                 ChipState& c = *st[owner[k].first];
                 if (owner[k].second) { c.main_buf = std::move(fresh[k]); c.d_main = c.main_buf->u32(); }   // old table released
                 else { c.prep_buf = std::move(fresh[k]); c.d_prep = c.prep_buf->u32(); }
@@ -874,19 +890,36 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     w.ext(final_eval);
     w.u64((uint64_t)n_chips);
     std::vector<std::vector<Ext>> chip_evals(n_chips);
-    for (int i = 0; i < n_chips; i++) {
-        ChipState& c = *st[i];
-        const uint32_t wp = c.in->prep_width, wm = c.in->main_width;
-        std::vector<uint32_t> hp((size_t)wp * 4, 0), hm((size_t)wm * 4, 0);
-        if (c.rows) {   // one row left: ext table [1 x w] = w*4 words, column-major == (col, coord)
-            if (wp) SP1HIP_HIP(hipMemcpyAsync(hp.data(), c.d_prep, hp.size() * 4, hipMemcpyDeviceToHost, s));
-            if (wm) SP1HIP_HIP(hipMemcpyAsync(hm.data(), c.d_main, hm.size() * 4, hipMemcpyDeviceToHost, s));
-            SP1HIP_HIP(hipStreamSynchronize(s));
+    {   // one row is left of every table: ext [1 x w] = w*4 words (col, coord). Gather them all, one hand-over.
+        std::vector<ZcGatherDesc> gd;
+        size_t total_words = 0;
+        for (int i = 0; i < n_chips; i++) {
+            ChipState& c = *st[i];
+            const uint32_t wp = c.in->prep_width, wm = c.in->main_width;
+            if (c.rows && wp) gd.push_back({c.d_prep, wp * 4, (uint32_t)total_words});
+            total_words += (size_t)wp * 4;
+            if (c.rows && wm) gd.push_back({c.d_main, wm * 4, (uint32_t)total_words});
+            total_words += (size_t)wm * 4;
         }
-        for (uint32_t k = 0; k < wp; k++) chip_evals[i].push_back(Ext{{hp[4 * k], hp[4 * k + 1], hp[4 * k + 2], hp[4 * k + 3]}});
-        for (uint32_t k = 0; k < wm; k++) chip_evals[i].push_back(Ext{{hm[4 * k], hm[4 * k + 1], hm[4 * k + 2], hm[4 * k + 3]}});
-        w.u64(chip_evals[i].size());
-        for (auto& e : chip_evals[i]) w.ext(e);
+        std::vector<uint32_t> flat(total_words, 0);
+        if (!gd.empty()) {
+            DevBuf d_gd, d_flat;
+            SP1HIP_TRY(d_gd.alloc(gd.size() * sizeof(ZcGatherDesc), s));
+            SP1HIP_TRY(d_flat.alloc(total_words * 4, s));
+            SP1HIP_HIP(hipMemsetAsync(d_flat.p, 0, total_words * 4, s));
+            SP1HIP_HIP(hipMemcpyAsync(d_gd.p, gd.data(), gd.size() * sizeof(ZcGatherDesc), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(zc_gather_kernel, dim3((unsigned)gd.size()), dim3(256), 0, s, (const ZcGatherDesc*)d_gd.p, d_flat.u32());
+            SP1HIP_LAUNCH_CHECK();
+            SP1HIP_TRY(mb.fetch(d_flat.p, total_words, flat.data()));     // also keeps `gd` valid long enough
+        }
+        size_t off = 0;
+        for (int i = 0; i < n_chips; i++) {
+            const uint32_t wtot = st[i]->in->prep_width + st[i]->in->main_width;
+            for (uint32_t k = 0; k < wtot; k++, off += 4)
+                chip_evals[i].push_back(Ext{{flat[off], flat[off + 1], flat[off + 2], flat[off + 3]}});
+            w.u64(chip_evals[i].size());
+            for (auto& e : chip_evals[i]) w.ext(e);
+        }
     }
     // observe the openings (shard.rs:L609-L640)
     challenger_observe(challenger, kb::to_monty((uint32_t)n_chips));
