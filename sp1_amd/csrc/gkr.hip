@@ -401,10 +401,9 @@ struct Bytes {
 
 void observe_ext(sp1hip_challenger_t* ch, const Ext& e) { for (int k = 0; k < 4; k++) challenger_observe(ch, e.c[k]); }
 
-int upload(DeviceBuf& buf, const void* src, size_t bytes, hipStream_t s) {
+int upload(DeviceBuf& buf, const void* src, size_t bytes, hipStream_t s, PinnedStage& stage) {
     SP1HIP_TRY(buf.alloc(std::max<size_t>(bytes, 16), s));
-    if (bytes) SP1HIP_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s));
-    return SP1HIP_SUCCESS;
+    return stage.upload(buf.p, src, bytes);
 }
 
 struct ChipInfo {
@@ -530,6 +529,8 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     auto d_ptr = [&](int l, uint32_t i) -> Ext* { return lvD[l].ext() + off[l][i]; };
 
     // ---- first layer
+    PinnedStage stage;                                       // small uploads (round_sync.hpp)
+    SP1HIP_TRY(stage.init(s));
     DeviceBuf d_progs, d_betas, d_descs;
     uint32_t max_rows = 0;
     std::vector<uint32_t> flat;                              // upload sources live to the end of the call
@@ -537,14 +538,14 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     {
         std::vector<size_t> poff(K);
         for (uint32_t i = 0; i < K; i++) { poff[i] = flat.size(); flat.insert(flat.end(), progs[i].begin(), progs[i].end()); }
-        SP1HIP_TRY(upload(d_progs, flat.data(), flat.size() * 4, s));
-        SP1HIP_TRY(upload(d_betas, betas.data(), betas.size() * 16, s));
+        SP1HIP_TRY(upload(d_progs, flat.data(), flat.size() * 4, s, stage));
+        SP1HIP_TRY(upload(d_betas, betas.data(), betas.size() * 16, s, stage));
         for (uint32_t i = 0; i < K; i++) {
             const ChipInfo& c = info[int_chip[i]];
             descs[i] = IntDesc{d_progs.u32() + poff[i], c.d_main, c.d_prep, c.rows, (uint32_t*)n_ptr(L, i), d_ptr(L, i)};
             max_rows = std::max(max_rows, c.rows);
         }
-        SP1HIP_TRY(upload(d_descs, descs.data(), descs.size() * sizeof(IntDesc), s));
+        SP1HIP_TRY(upload(d_descs, descs.data(), descs.size() * sizeof(IntDesc), s, stage));
         if (max_rows) {
             ScopedTimer t("gkr_first_layer", s);
             hipLaunchKernelGGL(first_layer_kernel, dim3(tiles_for(max_rows), K), dim3(256), 0, s, (const IntDesc*)d_descs.p, alpha,
@@ -563,7 +564,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             tdesc[(size_t)(L - l) * K + i] = TransDesc{n_ptr(l, i), d_ptr(l, i), (Ext*)n_ptr(l - 1, i), d_ptr(l - 1, i), rin};
             level_mr[l] = std::max(level_mr[l], (rin + 1) / 2);
         }
-    SP1HIP_TRY(upload(d_trans, tdesc.data(), tdesc.size() * sizeof(TransDesc), s));
+    SP1HIP_TRY(upload(d_trans, tdesc.data(), tdesc.size() * sizeof(TransDesc), s, stage));
     for (int l = L; l >= 2; l--) {
         const uint32_t mr = level_mr[l];
         if (!mr) continue;
@@ -654,7 +655,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         }
     }
     DeviceBuf d_all;
-    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s));     // all_descs outlives the copy
+    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s, stage));     // all_descs outlives the copy
     size_t launch_idx = 0;                                   // next K descriptors of d_all
     RoundSyncHost rsync;
     SP1HIP_TRY(rsync.init(s));
@@ -668,7 +669,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         ro.claimed_sum = claim;
         const std::vector<Ext> int_point(eval_point.begin(), eval_point.begin() + niv), row_point(eval_point.begin() + niv, eval_point.end());
         const std::vector<Ext> eq_int = partial_lagrange_host(int_point);
-        SP1HIP_HIP(hipMemcpyAsync(d_eq_int.p, eq_int.data(), (size_t)W * 16, hipMemcpyHostToDevice, s));
+        SP1HIP_TRY(stage.upload(d_eq_int.p, eq_int.data(), (size_t)W * 16));
         PointArg pa{};
         for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
         hipLaunchKernelGGL(eq_prefix_tables_kernel, dim3(((2u << v) + 255) / 256), dim3(256), 0, s, pa, v, d_T.ext());
@@ -811,7 +812,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             max_rows_open = std::max(max_rows_open, info[c].rows);
         }
         const uint32_t chunks = std::max<uint32_t>((max_rows_open + OPEN_ROWS - 1) / OPEN_ROWS, 1);
-        SP1HIP_TRY(upload(d_od, od.data(), od.size() * sizeof(OpenDesc), s));
+        SP1HIP_TRY(upload(d_od, od.data(), od.size() * sizeof(OpenDesc), s, stage));
         SP1HIP_TRY(d_part.alloc((size_t)chunks * total_cols * 16, s));
         SP1HIP_TRY(d_res.alloc(total_cols * 16, s));
         SP1HIP_HIP(hipMemsetAsync(d_part.p, 0, (size_t)chunks * total_cols * 16, s));

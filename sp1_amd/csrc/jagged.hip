@@ -475,12 +475,14 @@ Ext observe_and_sample(sp1hip_challenger_t* ch, const std::array<Ext, 3>& poly) 
 struct Scratch {                    // device scratch shared by all rounds of one proof
     DeviceBuf partials;
     Mailbox mb;
+    PinnedStage stage;
     uint32_t h_out[8];
     hipStream_t s;
     static constexpr uint32_t MAX_BLOCKS = 2048;
     int init(hipStream_t stream) {
         s = stream;
         SP1HIP_TRY(partials.alloc((size_t)MAX_BLOCKS * 32, s));
+        SP1HIP_TRY(stage.init(s));
         return mb.init(s);
     }
     static uint32_t blocks_for(uint64_t threads) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), MAX_BLOCKS); }
@@ -520,10 +522,9 @@ void build_layer_matrices(const std::vector<Ext>& z_row, const std::vector<Ext>&
     }
 }
 
-int upload(DeviceBuf& buf, const void* src, size_t bytes, hipStream_t s) {
+int upload(DeviceBuf& buf, const void* src, size_t bytes, hipStream_t s, PinnedStage& stage) {
     SP1HIP_TRY(buf.alloc(std::max<size_t>(bytes, 16), s));
-    if (bytes) SP1HIP_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s));
-    return SP1HIP_SUCCESS;
+    return stage.upload(buf.p, src, bytes);
 }
 
 // JaggedEvalSumcheckProver::prove_jagged_evaluation. prefix: #columns + 1 dense prefix sums.
@@ -541,12 +542,12 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
     }
     const uint32_t n = (uint32_t)ts.size();
     DeviceBuf d_t, d_u, d_zc, d_mats, d_suffix, d_state, d_inter;
-    SP1HIP_TRY(upload(d_t, ts.data(), n * 4, s));
-    SP1HIP_TRY(upload(d_u, us.data(), n * 4, s));
-    SP1HIP_TRY(upload(d_zc, zc.data(), (size_t)n * 16, s));
+    SP1HIP_TRY(upload(d_t, ts.data(), n * 4, s, sc.stage));
+    SP1HIP_TRY(upload(d_u, us.data(), n * 4, s, sc.stage));
+    SP1HIP_TRY(upload(d_zc, zc.data(), (size_t)n * 16, s, sc.stage));
     std::vector<Ext> mats;
     build_layer_matrices(z_row, z_trace, D, &mats);
-    SP1HIP_TRY(upload(d_mats, mats.data(), mats.size() * 16, s));
+    SP1HIP_TRY(upload(d_mats, mats.data(), mats.size() * 16, s, sc.stage));
     SP1HIP_TRY(d_suffix.alloc((size_t)D * n * 64, s));
     SP1HIP_TRY(d_state.alloc((size_t)n * 128, s));
     SP1HIP_TRY(d_inter.alloc((size_t)n * 16, s));
@@ -586,7 +587,7 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
                 B[((size_t)layer * 2 + cb) * 16 + e] = a0 + alphas[layer] * (a1 - a0);
             }
     DeviceBuf d_B, d_suffix2;
-    SP1HIP_TRY(upload(d_B, B.data(), B.size() * 16, s));
+    SP1HIP_TRY(upload(d_B, B.data(), B.size() * 16, s, sc.stage));
     SP1HIP_TRY(d_suffix2.alloc((size_t)D * n * 64, s));
     hipLaunchKernelGGL(je_suffix_kernel<false>, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_B.p, D, (Ext*)d_suffix2.p, sc.partials.u32());
     SP1HIP_LAUNCH_CHECK();
@@ -719,8 +720,8 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     Scratch sc;
     SP1HIP_TRY(sc.init(s));
     DeviceBuf d_prefix, d_col_eq, d_row_eq;
-    SP1HIP_TRY(upload(d_prefix, prefix.data(), prefix.size() * 4, s));
-    SP1HIP_TRY(upload(d_col_eq, col_eq.data(), col_eq.size() * 16, s));
+    SP1HIP_TRY(upload(d_prefix, prefix.data(), prefix.size() * 4, s, sc.stage));
+    SP1HIP_TRY(upload(d_col_eq, col_eq.data(), col_eq.size() * 16, s, sc.stage));
     SP1HIP_TRY(d_row_eq.alloc(((size_t)16) << max_log_row_count, s));
     SP1HIP_TRY(sp1hip_partial_lagrange(h_z_row, max_log_row_count, d_row_eq.u32(), stream));
     JgSegs segs{};

@@ -261,9 +261,11 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     SP1HIP_TRY(d_mle[0].alloc(n * 16, s));
     SP1HIP_TRY(d_mle[1].alloc(n * 8 + 16, s));
     SP1HIP_TRY(d_eq.alloc(n * 8 + 16, s));
-    SP1HIP_HIP(hipMemcpyAsync(d_coeffs.p, coeffs.data(), total_len * 16, hipMemcpyHostToDevice, s));   // `coeffs` outlives the copy
     Mailbox mb;                                   // every device -> host hand-over below goes through it (round_sync.hpp)
     SP1HIP_TRY(mb.init(s));
+    PinnedStage stage;
+    SP1HIP_TRY(stage.init(s));
+    SP1HIP_TRY(stage.upload(d_coeffs.p, coeffs.data(), total_len * 16));
     SP1HIP_TRY(sp1hip_basefold_batch(mles.data(), (int)mles.size(), dim, d_coeffs.u32(), d_mle[0].u32(), s));
     kb::Ext cur_claim = kb::ext_zero();
     for (size_t i = 0; i < n_claims; i++) cur_claim = kb::ext_add(cur_claim, kb::ext_mul(claims[i], coeffs[i]));
@@ -357,7 +359,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     }
     SP1HIP_TRY(d_idx.alloc(nq * 4, s));
     SP1HIP_TRY(d_open.alloc(std::max<size_t>(words, 1) * 4, s));
-    SP1HIP_HIP(hipMemcpyAsync(d_idx.p, q.data(), nq * 4, hipMemcpyHostToDevice, s));
+    SP1HIP_TRY(stage.upload(d_idx.p, q.data(), nq * 4));
     for (int r = 0; r < n_rounds; r++) {
         sp1hip_basefold_data_s* pd = rounds[r];
         const Slot& sl = slots[r];

@@ -259,6 +259,29 @@ void mailbox_release(MailboxSlot slot) {
     g_mb_free[dev].push_back(slot);
 }
 
+static std::vector<PinnedBlock> g_pin_free[64];
+
+int pinned_stage_acquire(PinnedBlock* out) {
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    SP1HIP_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lock(g_rs_mutex);
+        if (!g_pin_free[dev].empty()) { *out = g_pin_free[dev].back(); g_pin_free[dev].pop_back(); return SP1HIP_SUCCESS; }
+    }
+    PinnedBlock b{nullptr};
+    SP1HIP_HIP(hipHostMalloc((void**)&b.h, PINNED_STAGE_BYTES, hipHostMallocDefault));
+    *out = b;
+    return SP1HIP_SUCCESS;
+}
+
+void pinned_stage_release(PinnedBlock b) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lock(g_rs_mutex);
+    g_pin_free[dev].push_back(b);
+}
+
 }  // namespace sp1hip
 
 using namespace sp1hip;

@@ -661,7 +661,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<uint32_t> publics(h_publics, h_publics + n_publics);
     DevBuf d_publics;
     SP1HIP_TRY(d_publics.alloc((size_t)n_publics * 4, s));
-    if (n_publics) SP1HIP_HIP(hipMemcpyAsync(d_publics.p, publics.data(), (size_t)n_publics * 4, hipMemcpyHostToDevice, s));
 
     int max_constraints = 0;
     for (int i = 0; i < n_chips; i++) max_constraints = std::max<int>(max_constraints, chips[i].num_constraints);
@@ -673,6 +672,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     // device->host hand-over goes through the mailbox (round_sync.hpp), so the stream is never drained mid-proof.
     Mailbox mb;
     SP1HIP_TRY(mb.init(s));
+    PinnedStage stage;                            // small uploads go through a pinned block (round_sync.hpp)
+    SP1HIP_TRY(stage.init(s));
+    if (n_publics) SP1HIP_TRY(stage.upload(d_publics.p, publics.data(), (size_t)n_publics * 4));
     std::vector<std::vector<uint32_t>> staging;
     std::vector<std::unique_ptr<ChipState>> st;
     std::vector<Ext> claims;
@@ -718,11 +720,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         SP1HIP_TRY(c->d_prog.alloc(all_prog.size() * 4, s));
         SP1HIP_TRY(c->d_alpha.alloc(c->alpha_pows.size() * 16, s));
         SP1HIP_TRY(c->d_gkr.alloc(c->gkr_pows.size() * 16, s));
-        SP1HIP_HIP(hipMemcpyAsync(c->d_prog.p, all_prog.data(), all_prog.size() * 4, hipMemcpyHostToDevice, s));
+        SP1HIP_TRY(stage.upload(c->d_prog.p, all_prog.data(), all_prog.size() * 4));
         if (!c->alpha_pows.empty())
-            SP1HIP_HIP(hipMemcpyAsync(c->d_alpha.p, c->alpha_pows.data(), c->alpha_pows.size() * 16, hipMemcpyHostToDevice, s));
+            SP1HIP_TRY(stage.upload(c->d_alpha.p, c->alpha_pows.data(), c->alpha_pows.size() * 16));
         if (!c->gkr_pows.empty())
-            SP1HIP_HIP(hipMemcpyAsync(c->d_gkr.p, c->gkr_pows.data(), c->gkr_pows.size() * 16, hipMemcpyHostToDevice, s));
+            SP1HIP_TRY(stage.upload(c->d_gkr.p, c->gkr_pows.data(), c->gkr_pows.size() * 16));
         st.push_back(std::move(c));
     }
 
@@ -787,8 +789,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 descs_cap = descs.size() * sizeof(ZcDesc);
                 SP1HIP_TRY(d_descs.alloc(descs_cap, s));
             }
-            SP1HIP_HIP(hipMemcpyAsync(d_descs.p, descs.data(), descs.size() * sizeof(ZcDesc), hipMemcpyHostToDevice, s));
-            SP1HIP_HIP(hipMemcpyAsync(d_ranges.p, ranges.data(), ranges.size() * sizeof(ZcChipRange), hipMemcpyHostToDevice, s));
+            SP1HIP_TRY(stage.upload(d_descs.p, descs.data(), descs.size() * sizeof(ZcDesc)));
+            SP1HIP_TRY(stage.upload(d_ranges.p, ranges.data(), ranges.size() * sizeof(ZcChipRange)));
             if ((size_t)total_blocks * 24 * 4 > partial_cap) {
                 d_partial.release();
                 partial_cap = (size_t)total_blocks * 24 * 4;
@@ -803,6 +805,19 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         for (size_t k = 0; k < desc_chip.size(); k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + k * 16, 64);
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
+        // the interpolation nodes {0, 1, 2, 4, b} are the same for every chip of a round: build the five Lagrange
+        // basis polynomials once (exact field arithmetic: the result is the reference's interpolation, whatever the
+        // operation order) and combine them per chip — 25 extension products instead of a full interpolation each
+        const Ext two_c = ext_c(2), four_c = ext_c(4);
+        const Ext b_node = (kb::ext_one() - last) * kb::ext_inv(kb::ext_one() - (last + last));
+        const std::vector<Ext> nodes{kb::ext_zero(), kb::ext_one(), two_c, four_c, b_node};
+        UniPoly basis[5];
+        for (int k = 0; k < 5; k++) {
+            std::vector<Ext> e(5, kb::ext_zero());
+            e[k] = kb::ext_one();
+            basis[k] = interpolate(nodes, e);
+            basis[k].resize(5, kb::ext_zero());
+        }
         std::vector<UniPoly> uni(n_chips);
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
@@ -820,9 +835,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             const Ext y2 = y2s * (f2 * c.eq_adj) - c.pad_adj * v2 * msb * f2;
             const Ext f4 = last * seven - three;
             const Ext y4 = y4s * (f4 * c.eq_adj) - c.pad_adj * v4 * msb * f4;
-            const Ext b = (kb::ext_one() - last) * kb::ext_inv(kb::ext_one() - (last + last));
-            uni[i] = interpolate({kb::ext_zero(), kb::ext_one(), two, four, b},
-                                 {y0, round_claims[i] - y0, y2, y4, kb::ext_zero()});
+            const Ext ys[4] = {y0, round_claims[i] - y0, y2, y4};          // the fifth value, at b, is zero
+            uni[i].assign(5, kb::ext_zero());
+            for (int d = 0; d < 5; d++)
+                for (int k = 0; k < 4; k++) uni[i][d] = uni[i][d] + ys[k] * basis[k][d];
         }
         UniPoly rlc{kb::ext_zero()};
         for (auto& u : uni) rlc = uni_add(uni_scale(rlc, lambda), u);
@@ -864,7 +880,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             c.eq_adj = c.eq_adj * (a_r * last + (kb::ext_one() - a_r) * (kb::ext_one() - last));
         }
         if (!fds.empty()) {
-            SP1HIP_HIP(hipMemcpyAsync(d_fix_descs.p, fds.data(), fds.size() * sizeof(ZcFixDesc), hipMemcpyHostToDevice, s));
+            SP1HIP_TRY(stage.upload(d_fix_descs.p, fds.data(), fds.size() * sizeof(ZcFixDesc)));
             if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
             else hipLaunchKernelGGL(zc_fix_kernel<false>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
             SP1HIP_LAUNCH_CHECK();
@@ -907,7 +923,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             SP1HIP_TRY(d_gd.alloc(gd.size() * sizeof(ZcGatherDesc), s));
             SP1HIP_TRY(d_flat.alloc(total_words * 4, s));
             SP1HIP_HIP(hipMemsetAsync(d_flat.p, 0, total_words * 4, s));
-            SP1HIP_HIP(hipMemcpyAsync(d_gd.p, gd.data(), gd.size() * sizeof(ZcGatherDesc), hipMemcpyHostToDevice, s));
+            SP1HIP_TRY(stage.upload(d_gd.p, gd.data(), gd.size() * sizeof(ZcGatherDesc)));
             hipLaunchKernelGGL(zc_gather_kernel, dim3((unsigned)gd.size()), dim3(256), 0, s, (const ZcGatherDesc*)d_gd.p, d_flat.u32());
             SP1HIP_LAUNCH_CHECK();
             SP1HIP_TRY(mb.fetch(d_flat.p, total_words, flat.data()));     // also keeps `gd` valid long enough
