@@ -264,4 +264,59 @@ KB_HD void permute_int(uint32_t (&s)[16], const RC& rc) {
     }
 }
 
+// ---- cooperative form: ONE permutation per 16 lanes (a DPP row), lane r holds state word r --------------------------
+// For the latency-bound places (the top of a Merkle tree: a chain of dependent compressions with fewer nodes than
+// lanes). The per-lane form above issues ~3.7k dependent-ish VALU instructions per permutation from one wave; here
+// the linear layers become wavefront shuffles — quad_perm for the 4x4 MDS blocks, row_ror for the column sums and
+// the internal layer's 16-term sum — and a permutation is ~1.3k instructions per wave, i.e. ~2.8x less latency.
+// All lanes of the row must be active. Words are canonical ([0, p)) throughout.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+#else
+    return v;       // device-only; the host pass just needs the declaration
+#endif
+}
+constexpr int DPP_QUAD_SWAP1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_SWAP2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int DPP_QUAD_NEXT = 0x39;    // quad_perm [1,2,3,0]: lane i reads lane i+1 of its quad
+constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+
+// y_i = 2 x_i + 3 x_{i+1} + x_{i+2} + x_{i+3} inside each quad (the circulant the m4() sequence computes), then every
+// word gets the sum of the four quads' words at its position.
+__device__ __forceinline__ uint32_t external_linear_coop(uint32_t x) {
+    const uint32_t a = kb::add(x, dpp_mov<DPP_QUAD_SWAP1>(x));
+    const uint32_t quad_sum = kb::add(a, dpp_mov<DPP_QUAD_SWAP2>(a));
+    const uint32_t x1 = dpp_mov<DPP_QUAD_NEXT>(x);
+    const uint32_t y = kb::add(kb::add(quad_sum, x), kb::add(x1, x1));
+    const uint32_t u = kb::add(y, dpp_mov<DPP_ROW_ROR8>(y));
+    const uint32_t v = kb::add(u, dpp_mov<DPP_ROW_ROR4>(u));
+    return kb::add(y, v);
+}
+
+// lane = index of this lane in its row (0..15)
+template <class RC>
+__device__ __forceinline__ uint32_t permute_coop16(uint32_t x, uint32_t lane, const RC& rc) {
+    // internal diagonal on Montgomery words: [-2, 1, 2, 4, ..., 2^13, 2^15] (lane 0 enters as p - s_0 with shift 1)
+    const uint32_t shift = lane == 0 ? 1u : (lane == 15 ? 15u : lane - 1);
+    x = external_linear_coop(x);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) x = external_linear_coop(sbox(x, rc.ext[r][lane]));
+#pragma unroll 1
+    for (int r = 0; r < 20; r++) {
+        const uint32_t cubed = sbox(x, rc.internal[r]);
+        x = lane == 0 ? cubed : x;
+        uint32_t t = kb::add(x, dpp_mov<DPP_ROW_ROR8>(x));
+        t = kb::add(t, dpp_mov<DPP_ROW_ROR4>(t));
+        t = kb::add(t, dpp_mov<DPP_ROW_ROR2>(t));
+        t = kb::add(t, dpp_mov<DPP_ROW_ROR1>(t));            // sum of the 16 words mod p, in every lane
+        const uint32_t in = lane == 0 ? kb::P - x : x;
+        x = kb::monty_reduce(((uint64_t)in << shift) + t);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) x = external_linear_coop(sbox(x, rc.ext[r][lane]));
+    return x;
+}
+
 }  // namespace p2
