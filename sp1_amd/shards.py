@@ -62,3 +62,64 @@ def gather_blobs(blobs):
             if idx >= 0:
                 out[idx] = bytes(p[k, :ln].numpy().tobytes())
     return out
+
+
+def reduce_tree(leaf_blobs, n_leaves, combine, arity=2):
+    """The recursion compress tree across ranks (`CompressTree::reduce_proofs`,
+    /root/reference/crates/prover/src/worker/controller/compress.rs:L234-L420): adjacent ranges of proofs are batched
+    `arity` at a time into a parent node until one proof is left. Nodes of every level are striped over the ranks like
+    the leaves (node j of a level belongs to rank j mod W); a child that lives on another rank is SENT to the parent's
+    rank — point-to-point (`batch_isend_irecv`: RCCL send/recv over xGMI under the "nccl" backend, gloo in the CPU
+    tests), nothing is broadcast, and nothing moves while a node is being proven. This is the only inter-GPU traffic of
+    the whole proving pipeline; it is latency-bound (~1.5 MB per proof).
+
+    leaf_blobs: {leaf index: bytes} for the leaves THIS rank proved (`stripe`); n_leaves: global leaf count;
+    combine(list_of_child_blobs) -> bytes proves a parent (a RecursionAir shard whose witness is the child proofs —
+    the same `sp1hip_prove_shard` hot path with another machine description). A node with a single child is carried
+    up unchanged. Returns the root blob on rank 0 and None elsewhere."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    level = dict(leaf_blobs)
+    n = int(n_leaves)
+    if n == 0:
+        return None
+    while n > 1:
+        n_parents = (n + arity - 1) // arity
+        have = {}                       # child index -> blob, for the parents this rank owns
+        if world == 1:
+            have = level
+        else:
+            dev = _device()
+            # lengths of every node of the level: one small fixed-shape collective
+            lens = torch.zeros(n, dtype=torch.int64, device=dev)
+            for i, b in level.items():
+                lens[i] = len(b)
+            dist.all_reduce(lens, op=dist.ReduceOp.SUM)
+            lens = lens.cpu().tolist()
+            ops, recv_bufs, keep = [], {}, []
+            for j in range(n_parents):
+                owner = j % world
+                for c in range(j * arity, min((j + 1) * arity, n)):
+                    src = c % world
+                    if src == owner:
+                        if rank == owner:
+                            have[c] = level[c]
+                    elif rank == src:
+                        t = torch.frombuffer(bytearray(level[c]), dtype=torch.uint8).to(dev)
+                        keep.append(t)
+                        ops.append(dist.P2POp(dist.isend, t, owner))
+                    elif rank == owner:
+                        t = torch.empty(lens[c], dtype=torch.uint8, device=dev)
+                        recv_bufs[c] = t
+                        ops.append(dist.P2POp(dist.irecv, t, src))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for c, t in recv_bufs.items():
+                have[c] = bytes(t.cpu().numpy().tobytes())
+        nxt = {}
+        for j in range(rank, n_parents, world):
+            kids = [have[c] for c in range(j * arity, min((j + 1) * arity, n))]
+            nxt[j] = kids[0] if len(kids) == 1 else combine(kids)
+        level, n = nxt, n_parents
+    return level.get(0) if rank == 0 else None

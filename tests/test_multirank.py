@@ -69,6 +69,44 @@ def test_striping_and_blob_exchange_gloo(n_shards):
         assert t == 2.0                                            # max over ranks
 
 
+def _combine(kids):
+    """Stand-in for proving a parent node: an order-sensitive digest of the children's bytes."""
+    import hashlib
+    return hashlib.sha256(b"|".join(kids)).digest() + bytes([len(kids)])
+
+
+def _tree_worker(rank, world, port, n_shards, arity, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sp1_amd import shards
+    blobs = {i: _shard_blob(i) for i in shards.stripe(n_shards, world, rank)}
+    root = shards.reduce_tree(blobs, n_shards, _combine, arity)
+    dist.barrier()
+    q.put((rank, root))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_shards,arity", [(2, 7, 2), (2, 8, 3), (3, 5, 2), (2, 1, 2)])
+def test_compress_tree_over_ranks_gloo(world, n_shards, arity):
+    """The recursion-tree reduce step: point-to-point proof movement to the parent's rank, same root as one process."""
+    import __graft_entry__ as g
+    g.build_hip()
+    from sp1_amd import shards
+    want = shards.reduce_tree({i: _shard_blob(i) for i in range(n_shards)}, n_shards, _combine, arity)
+    port = 31500 + (os.getpid() % 2000) + 10 * n_shards + arity + world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tree_worker, args=(r, world, port, n_shards, arity, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0] == want and want is not None
+    assert all(results[r] is None for r in range(1, world))
+
+
 def test_single_process_helpers():
     from sp1_amd import shards
     assert shards.stripe(5, 1, 0) == [0, 1, 2, 3, 4]
