@@ -56,27 +56,33 @@ __device__ __forceinline__ void store_digest(uint32_t* dst, const uint32_t (&s)[
     d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// The sponge state lives in VGPRs as doubles across all absorb blocks of a row (poseidon2.hpp permute_f64): the
+// capacity lanes are never reduced between permutations and the rate lanes a block overwrites are never reduced at
+// all; only the 8 digest words are brought back to canonical form at the end.
 __global__ __launch_bounds__(256) void leaf_hash_kernel(const uint32_t* const* __restrict__ cols, uint32_t total_width,
                                                         uint32_t height, const p2::RoundConstants* __restrict__ rc,
                                                         uint32_t* __restrict__ leaves) {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     if (row >= height) return;
-    uint32_t s[16];
+    double d[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = 0;
+    for (int i = 0; i < 16; i++) d[i] = 0.0;
     const uint32_t full = total_width >> 3;
     for (uint32_t k = 0; k < full; k++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = cols[8 * k + j][row];
-        p2::permute(s, *rc);
+        for (int j = 0; j < 8; j++) d[j] = (double)cols[8 * k + j][row];
+        p2::permute_f64(d, *rc);
     }
     const uint32_t rem = total_width & 7u;
     if (rem) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if ((uint32_t)j < rem) s[j] = cols[8 * full + j][row];
-        p2::permute(s, *rc);
+            if ((uint32_t)j < rem) d[j] = (double)cols[8 * full + j][row];
+        p2::permute_f64(d, *rc);
     }
+    uint32_t s[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = p2::canonical_f64(d[j]);
     store_digest(leaves + (size_t)row * 8, s);
 }
 
@@ -91,29 +97,32 @@ __global__ __launch_bounds__(256) void leaf_hash_part_kernel(const uint32_t* con
                                                              uint32_t* __restrict__ carry, uint32_t* __restrict__ leaves) {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     if (row >= height) return;
-    uint32_t s[16];
+    double d[16];
 #pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = 0;
+    for (int i = 0; i < 8; i++) d[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s[8 + i] = FIRST ? 0u : carry[(size_t)i * height + row];
+    for (int i = 0; i < 8; i++) d[8 + i] = FIRST ? 0.0 : (double)carry[(size_t)i * height + row];
     const uint32_t full = width >> 3;
     for (uint32_t k = 0; k < full; k++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = cols[8 * k + j][row];
-        p2::permute(s, *rc);
+        for (int j = 0; j < 8; j++) d[j] = (double)cols[8 * k + j][row];
+        p2::permute_f64(d, *rc);
     }
     if (LAST) {
         const uint32_t rem = width & 7u;
         if (rem) {
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if ((uint32_t)j < rem) s[j] = cols[8 * full + j][row];
-            p2::permute(s, *rc);
+                if ((uint32_t)j < rem) d[j] = (double)cols[8 * full + j][row];
+            p2::permute_f64(d, *rc);
         }
+        uint32_t s[16];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = p2::canonical_f64(d[j]);
         store_digest(leaves + (size_t)row * 8, s);
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) carry[(size_t)i * height + row] = s[8 + i];
+        for (int i = 0; i < 8; i++) carry[(size_t)i * height + row] = p2::canonical_f64(d[8 + i]);
     }
 }
 

@@ -200,17 +200,19 @@ KB_HD double sbox_f64(double v, double magic_plus_rc) {
     return (double)monty_reduce_signed((int64_t)y2 * y);
 }
 
-// exact integer v, |v| < 2^42  ->  the word in [0, p] congruent to it (p itself only when p | v)
+// exact integer v, |v| < 2^44  ->  the word in [0, p] congruent to it (p itself only when p | v)
 KB_HD uint32_t reduce_f64(double v) {
     const double q = __builtin_floor(v * INV_P_F64);
     return lo32_of(__builtin_fma(-q, P_F64, v + MAGIC_F64));
 }
 
+// The permutation on a state held as doubles. In: exact integers |d_i| < 2^38 congruent to the state words (fresh
+// Montgomery words, or the UNREDUCED outputs of a previous call: the first linear layer then yields < 35 * 2^38 <
+// 2^44, which the S-box's reduction takes). Out: exact integers |d_i| < 35 p < 2^37, unreduced. A sponge that
+// absorbs block after block keeps its capacity lanes in this form and never pays for reducing / re-converting them,
+// and the rate lanes it is about to overwrite are never reduced at all (permute() below reduces all 16).
 template <class RC>
-KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
-    double d[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) d[i] = (double)s[i];
+KB_HD void permute_f64(double (&d)[16], const RC& rc) {
     external_linear_f64(d);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
@@ -218,6 +220,7 @@ KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
         for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_magic[r][i]);
         external_linear_f64(d);
     }
+    uint32_t s[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = reduce_f64(d[i]);            // [0, p]: inside the lazy ranges
 #pragma unroll 2
@@ -231,11 +234,22 @@ KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
         for (int i = 0; i < 16; i++) d[i] = sbox_f64(d[i], rc.ext_magic[r][i]);
         external_linear_f64(d);
     }
+}
+
+// unreduced output lane of permute_f64 -> canonical word
+KB_HD uint32_t canonical_f64(double v) {
+    const uint32_t w = reduce_f64(v);
+    return kb::umin(w, w - kb::P);
+}
+
+template <class RC>
+KB_HD void permute(uint32_t (&s)[16], const RC& rc) {
+    double d[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t w = reduce_f64(d[i]);
-        s[i] = kb::umin(w, w - kb::P);
-    }
+    for (int i = 0; i < 16; i++) d[i] = (double)s[i];
+    permute_f64(d, rc);
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = canonical_f64(d[i]);
 }
 
 // all-integer form of the same permutation (the previous production path; kept for the A/B
