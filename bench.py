@@ -203,15 +203,16 @@ def main():
                          "launches_per_step": per_step, "avg_launch_ms": leaf_ms / max(per_step, 1),
                          "algorithmic_bytes_per_launch": leaf_bytes // max(per_step, 1),
                          "sponge_carry_bytes_per_step": carry_bytes,
-                         # the bound that actually binds: VALU issue. 3722 = dynamic VALU instructions per
-                         # permutation counted in the gfx950 ISA of this build (profiles/r01_pmc_summary.md, SQ pass:
-                         # SQ_INSTS_VALU agrees); peak = 256 CUs x 64 lanes x 2.4 GHz, one instruction per lane-clock.
+                         # the bound that actually binds: VALU issue. 3573 = SQ_INSTS_VALU per permutation of a
+                         # leaf_hash_part_kernel launch (profiles/r01_pmc_summary.md, last SQ pass; 3556 in the steady-state
+                         # loop of the ISA listing + the carry load/store of the launch; the single-launch kernel of the
+                         # isolated pass: 3558); peak = 256 CUs x 64 lanes x 2.4 GHz, one instruction per lane-clock.
                          # `frac` is measured inside the timed steps, where the launches share the chip with the
                          # encode passes of the following batches; `frac_isolated` is the same launch with the overlap
                          # switched off (SP1HIP_COMMIT_OVERLAP=0), measured right after the timed region.
-                         "valu": {"insts_per_permutation": 3722, "achieved_lane_insts_per_s": 3722 * perms / (leaf_ms * 1e-3),
-                                  "peak_lane_insts_per_s": valu_peak, "frac": 3722 * perms / (leaf_ms * 1e-3) / valu_peak,
-                                  "frac_isolated": 3722 * perms / (iso_leaf * 1e-3) / valu_peak if iso_leaf else None},
+                         "valu": {"insts_per_permutation": 3573, "achieved_lane_insts_per_s": 3573 * perms / (leaf_ms * 1e-3),
+                                  "peak_lane_insts_per_s": valu_peak, "frac": 3573 * perms / (leaf_ms * 1e-3) / valu_peak,
+                                  "frac_isolated": 3558 * perms / (iso_leaf * 1e-3) / valu_peak if iso_leaf else None},
                          "note": "integer-VALU-bound by construction (Poseidon2: %d permutations per step, "
                                  "%.3g permutations/s); see DESIGN.md" % (perms, perms / (leaf_ms * 1e-3)),
                          "rs_encode": {"bound": "hbm", "ms_per_step": ntt_ms, "algorithmic_bytes_per_step": ntt_bytes,
