@@ -57,24 +57,33 @@ struct Radix {
     // the butterfly (q, q + hq) at stage s: w_r^(((i0 + (q mod hq) 2^LG_STEP)) << (LG_R - s)); tw_r holds
     // w_r^j for j < r/2 followed by the matching w' words. ZERO_BASE: i0 is known to be 0, so the butterflies
     // with q mod hq == 0 have twiddle 1 (47 % of a radix-16 step) and skip the multiplication.
-    template <int LG_R, int LG_STEP, bool ZERO_BASE>
+    // ZB: the upper (1 - 2^-ZB) of x[] is known to be zero (first pass of a zero-padded encode, blowup >= 2^ZB):
+    // a butterfly whose partner is zero is a copy and one multiplication, one with both inputs zero vanishes. The
+    // zero pattern is a compile-time bitmask that the fully unrolled loops fold away.
+    template <int LG_R, int LG_STEP, bool ZERO_BASE, int ZB = 0>
     static __device__ __forceinline__ void run(uint32_t (&x)[1 << K], uint32_t i0, const uint32_t* __restrict__ tw_r) {
+        uint32_t nz = (ZB > 0 && ZB <= K) ? ((1u << (1 << (K - ZB))) - 1u) : ((1 << K) == 32 ? ~0u : (1u << (1 << K)) - 1u);
 #pragma unroll
         for (int t = K; t >= 1; t--) {
             const int hq = 1 << (t - 1);
             const int s = LG_STEP + t;
+            uint32_t nz_next = nz;
 #pragma unroll
             for (int q = 0; q < (1 << K); q++) {
                 if (q & hq) continue;
+                const bool a_nz = (nz >> q) & 1u, b_nz = (nz >> (q + hq)) & 1u;
+                if (!a_nz && !b_nz) continue;
                 const uint32_t a = x[q], b = x[q + hq];
-                x[q] = kb::add(a, b);
+                if (b_nz) x[q] = kb::add(a, b);
                 if (ZERO_BASE && (q & (hq - 1)) == 0) {
-                    x[q + hq] = kb::sub(a, b);
+                    x[q + hq] = b_nz ? kb::sub(a, b) : a;
                 } else {
                     const uint32_t e = (i0 + (uint32_t)((q & (hq - 1)) << LG_STEP)) << (LG_R - s);
-                    x[q + hq] = sub_mul_tw(a, b, tw_r[e], tw_r[e + (1u << (LG_R - 1))]);   // wave-uniform -> scalar loads
+                    x[q + hq] = sub_mul_tw(a, b_nz ? b : 0u, tw_r[e], tw_r[e + (1u << (LG_R - 1))]);   // wave-uniform -> scalar loads
                 }
+                nz_next |= (1u << q) | (1u << (q + hq));
             }
+            nz = nz_next;
         }
     }
 };
@@ -83,7 +92,8 @@ struct Radix {
 // twiddle tables cannot alias the output and keeps their wave-uniform loads on the scalar unit.
 // WAVES: waves per workgroup. The 256-point tiles take ~65 KiB of LDS (two workgroups per CU), so they run with 8
 // waves per workgroup to keep 16 waves per CU in flight; the 64/128-point tiles use 4.
-template <int A, int B, bool STRIDED, bool FIRST, int WAVES>
+// ZB (FIRST passes only): log2 of the zero-padding factor the radix step may rely on (0 or 2).
+template <int A, int B, bool STRIDED, bool FIRST, int WAVES, int ZB = 0>
 __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __restrict__ a_in, uint32_t* __restrict__ a_out,
                                                      const uint32_t* __restrict__ a_tw_r,
                                                      const uint32_t* __restrict__ a_tw_lane,
@@ -160,8 +170,8 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
     for (uint32_t i_lo = wave; i_lo < (1u << B); i_lo += WAVES) {
         uint32_t x[1 << A];
 #pragma unroll
-        for (int q = 0; q < (1 << A); q++) x[q] = tile[addr(i_lo + ((uint32_t)q << B), lane)];
-        Radix<A>::template run<LG_R, B, false>(x, i_lo, p.tw_r);
+        for (int q = 0; q < (1 << A); q++) x[q] = (ZB > 0 && q >= (1 << (A - ZB))) ? 0u : tile[addr(i_lo + ((uint32_t)q << B), lane)];
+        Radix<A>::template run<LG_R, B, false, ZB>(x, i_lo, p.tw_r);
 #pragma unroll
         for (int q = 0; q < (1 << A); q++) tile[addr(i_lo + ((uint32_t)q << B), lane)] = x[q];
     }
@@ -245,14 +255,15 @@ static int get_fast_tables(const DeviceCtx* ctx, hipStream_t s, int lg_r, int lg
 }
 
 template <int A, int B>
-static int launch_pass(FastPassArgs args, bool strided, bool first, uint32_t tiles, uint32_t n_cols, hipStream_t s) {
+static int launch_pass(FastPassArgs args, bool strided, bool first, bool zero_quarters, uint32_t tiles, uint32_t n_cols, hipStream_t s) {
     constexpr int R = 1 << (A + B);
     const size_t lds = strided ? ((size_t)R * FT + R) * 4 : ((size_t)FT * (R + 1)) * 4;
     dim3 grid(tiles, n_cols);
     using Kern = void (*)(const uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,
                           int, int, int);
     constexpr int WAVES = (A + B == 8) ? 8 : 4;
-    Kern kern = strided ? (first ? ntt_fast_pass<A, B, true, true, WAVES> : ntt_fast_pass<A, B, true, false, WAVES>)
+    Kern kern = strided ? (first ? (zero_quarters ? ntt_fast_pass<A, B, true, true, WAVES, 2> : ntt_fast_pass<A, B, true, true, WAVES>)
+                                 : ntt_fast_pass<A, B, true, false, WAVES>)
                         : (first ? ntt_fast_pass<A, B, false, true, WAVES> : ntt_fast_pass<A, B, false, false, WAVES>);
     if (lds > 48 * 1024)   // 256-point tiles need ~65 KiB of the CU's 160 KiB LDS
         SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -302,9 +313,10 @@ int ntt_fast_encode(uint32_t* d_out, const uint32_t* d_in, int lg_n, int lg_blow
         SP1HIP_TRY(get_fast_tables(ctx, s, lg_r, last ? -1 : lg_seg, &a.tw_r, &a.tw_lane));
         const uint32_t tiles = 1u << (lg_total - lg_r - 6);
         ScopedTimer t(p == 0 ? "ntt_pass0" : (p == 1 ? "ntt_pass1" : "ntt_pass2"), s);
-        if (lg_r == 6) SP1HIP_TRY((launch_pass<3, 3>(a, !last, first, tiles, (uint32_t)n_cols, s)));
-        else if (lg_r == 7) SP1HIP_TRY((launch_pass<3, 4>(a, !last, first, tiles, (uint32_t)n_cols, s)));
-        else SP1HIP_TRY((launch_pass<4, 4>(a, !last, first, tiles, (uint32_t)n_cols, s)));
+        const bool zq = first && lg_blowup >= 2;       // three quarters of the first pass's input are padding zeros
+        if (lg_r == 6) SP1HIP_TRY((launch_pass<3, 3>(a, !last, first, zq, tiles, (uint32_t)n_cols, s)));
+        else if (lg_r == 7) SP1HIP_TRY((launch_pass<3, 4>(a, !last, first, zq, tiles, (uint32_t)n_cols, s)));
+        else SP1HIP_TRY((launch_pass<4, 4>(a, !last, first, zq, tiles, (uint32_t)n_cols, s)));
         lg_seg -= lg_r;
     }
     return SP1HIP_SUCCESS;
