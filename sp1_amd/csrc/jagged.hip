@@ -208,6 +208,8 @@ __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& a
 // ---- first fold (base q, recomputed J) fused with the next round's sums. One step of a thread: inputs 4k..4k+3,
 // outputs 2k, 2k+1 of the round-1 tables (n_out entries). Lanes take consecutive k (16 B of q per lane) and step by
 // 256, tracking their column like jg_round0_sum; inside one column J folds as eq_col[c] * lerp(eq_row[r], eq_row[r+1]).
+// WRITE_J = false when the next level keeps J factored (jg_foldf_sum): the 16 B/entry j table is never materialised.
+template <bool WRITE_J>
 __global__ __launch_bounds__(256) void jg_fold0_sum(JgSegs S, JgJ J, Ext alpha, uint32_t n_out, Ext* __restrict__ q_out,
                                                     Ext* __restrict__ j_out, uint32_t* __restrict__ partials) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
@@ -248,12 +250,90 @@ __global__ __launch_bounds__(256) void jg_fold0_sum(JgSegs S, JgJ J, Ext alpha, 
             }
 #pragma unroll
             for (int h = 0; h < 2; h++)
-                if (2 * k + h < n_out) { st_ext(q_out, 2 * k + h, qo[h]); st_ext(j_out, 2 * k + h, jo[h]); }
+                if (2 * k + h < n_out) { st_ext(q_out, 2 * k + h, qo[h]); if (WRITE_J) st_ext(j_out, 2 * k + h, jo[h]); }
             e0 = kb::ext_add(e0, kb::ext_mul(jo[0], qo[0]));
             eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(jo[0], jo[1]), kb::ext_add(qo[0], qo[1])));
         }
     }
     block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+}
+
+// ---- folds that keep J factored. While every column starts at a multiple of 2^r in the dense order (chip heights
+// are multiples of 32 in the reference's shards, powers of two in the synthetic ones), folding the r lowest dense
+// variables never mixes two columns, so J_r(x) = eq_col[c] * eq_row_r[x - (prefix[c] >> r)] with eq_row_r the row
+// table folded r times (a 2^(L-r)-entry table that lives in L2 / MALL). The j tables of these levels — 32 B/entry
+// written and read back, 12 GB over levels 1..5 at core scale — are never materialised: a fold reads q_{r-1}, writes
+// q_r and sums against the factored J_r, with eq_col[c] pulled out of each column run as in round 0.
+__global__ __launch_bounds__(256) void jg_fold_row_eq(const uint32_t* __restrict__ in, uint32_t len_in, Ext alpha,
+                                                      uint32_t* __restrict__ out) {
+    const uint32_t len_out = len_in >> 1;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= len_out) return;
+    const Ext a{{in[2 * i], in[len_in + 2 * i], in[2 * len_in + 2 * i], in[3 * len_in + 2 * i]}};
+    const Ext b{{in[2 * i + 1], in[len_in + 2 * i + 1], in[2 * len_in + 2 * i + 1], in[3 * len_in + 2 * i + 1]}};
+    const Ext r = fold_ext(a, b, alpha);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[(size_t)k * len_out + i] = r.c[k];
+}
+
+// q_in: level r-1 (n_in live entries); J: level r (prefix >> r, eq_row_r); writes q_out = level r (n_out entries)
+__global__ __launch_bounds__(256) void jg_foldf_sum(const Ext* __restrict__ q_in, uint32_t n_in, JgJ J, Ext alpha, uint32_t n_out,
+                                                    Ext* __restrict__ q_out, uint32_t* __restrict__ partials) {
+    Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
+    const uint32_t n_pairs = (n_out + 1) / 2;
+    for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 256 * JG_ITERS < n_pairs; chunk += gridDim.x) {
+        uint32_t c = 0, col_end = 0;
+        bool have = false;
+        Ext a0 = kb::ext_zero(), ah = kb::ext_zero();     // sums of the current column, without eq_col[c]
+#pragma unroll 1
+        for (int it = 0; it < JG_ITERS; it++) {
+            const uint32_t pair = chunk * 256 * JG_ITERS + it * 256 + threadIdx.x;
+            if (pair >= n_pairs) break;
+            const uint32_t x = 2 * pair;                  // level-r index of the first output
+            Ext q[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) q[v] = 2 * x + v < n_in ? ld_ext(q_in, 2 * x + v) : kb::ext_zero();
+            const Ext q0 = fold_ext(q[0], q[1], alpha), q1 = fold_ext(q[2], q[3], alpha);
+            st_ext(q_out, x, q0);
+            if (x + 1 < n_out) st_ext(q_out, x + 1, q1);
+            if (!have) { c = jg_find_col(J, x); col_end = J.prefix[c + 1]; have = true; }
+            else if (x >= col_end) {                      // entered a later column: flush
+                const Ext w = ld_ext(J.col_eq, c);
+                e0 = kb::ext_add(e0, kb::ext_mul(w, a0));
+                eh = kb::ext_add(eh, kb::ext_mul(w, ah));
+                a0 = ah = kb::ext_zero();
+                while (J.prefix[c + 1] <= x) c++;
+                col_end = J.prefix[c + 1];
+            }
+            const Ext r0 = jg_row_eq(J, x - J.prefix[c]);
+            a0 = kb::ext_add(a0, kb::ext_mul(r0, q0));
+            if (x + 1 < col_end) {
+                ah = kb::ext_add(ah, kb::ext_mul(kb::ext_add(r0, jg_row_eq(J, x + 1 - J.prefix[c])), kb::ext_add(q0, q1)));
+            } else {
+                Ext jsum = kb::ext_mul(ld_ext(J.col_eq, c), r0);
+                if (x + 1 < n_out) {                      // x + 1 opens a later non-empty column
+                    uint32_t c1 = c + 1;
+                    while (J.prefix[c1 + 1] <= x + 1) c1++;
+                    jsum = kb::ext_add(jsum, kb::ext_mul(ld_ext(J.col_eq, c1), jg_row_eq(J, x + 1 - J.prefix[c1])));
+                }
+                eh = kb::ext_add(eh, kb::ext_mul(jsum, kb::ext_add(q0, q1)));
+            }
+        }
+        if (have) {
+            const Ext w = ld_ext(J.col_eq, c);
+            e0 = kb::ext_add(e0, kb::ext_mul(w, a0));
+            eh = kb::ext_add(eh, kb::ext_mul(w, ah));
+        }
+    }
+    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+}
+
+// j_out[x] = eq_col[c] * eq_row_r[x - prefix_r[c]] for the n entries of level r (leaving the factored form)
+__global__ __launch_bounds__(256) void jg_materialize_j(JgJ J, uint32_t n, Ext* __restrict__ j_out) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= n) return;
+    const uint32_t c = jg_find_col(J, x);
+    st_ext(j_out, x, jg_j_at(J, c, x - J.prefix[c]));
 }
 
 // ---- later folds: ext tables with n_in live entries -> n_out = ceil(n_in / 2), fused with the sums
@@ -743,11 +823,49 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     std::vector<Ext> alphas;
     Ext claim = sumcheck_claim, alpha = kb::ext_zero(), q_eval = kb::ext_zero(), j_eval = kb::ext_zero();
     std::array<Ext, 3> poly{};
-    DeviceBuf tabs[4];                 // q/j ping-pong
+    DeviceBuf tabs[4];                 // q/j ping-pong: q of odd levels in tabs[0], of even levels in tabs[2]; j behind each
     const uint32_t n1 = (T + 1) / 2;
-    for (int k = 0; k < 4; k++) SP1HIP_TRY(tabs[k].alloc((size_t)std::max<uint32_t>(k < 2 ? n1 : (n1 + 1) / 2, 1) * 16, s));
+    SP1HIP_TRY(tabs[0].alloc((size_t)std::max<uint32_t>(n1, 1) * 16, s));
+    SP1HIP_TRY(tabs[2].alloc((size_t)std::max<uint32_t>((n1 + 1) / 2, 1) * 16, s));
+    // levels 1 .. rf keep J factored (see jg_foldf_sum): every column must start at a multiple of 2^level
+    int rf = 0;
+    {
+        uint32_t g = T;
+        for (uint32_t pfx : prefix) g |= pfx;
+        rf = g ? __builtin_ctz(g) : 0;
+        rf = std::min(rf, std::min(log_m - 2, max_log_row_count - 1));
+        if (const char* e = getenv("SP1HIP_JAGGED_FACTORED")) if (e[0] == '0') rf = 0;     // A/B switch
+        if (rf < 2) rf = 0;            // a single factored level is not worth the extra table
+    }
+    bool j_materialised = rf == 0;     // does tabs[cur + 1] hold the j table of the current level?
+    if (rf == 0) {
+        SP1HIP_TRY(tabs[1].alloc((size_t)std::max<uint32_t>(n1, 1) * 16, s));
+        SP1HIP_TRY(tabs[3].alloc((size_t)std::max<uint32_t>((n1 + 1) / 2, 1) * 16, s));
+    }
+    DeviceBuf row_eq_lv[2], d_prefix_lv;       // folded row tables (ping-pong) and the shifted prefix sums of a level
+    const uint32_t* row_eq_cur = d_row_eq.u32();
+    uint32_t row_len_cur = 1u << max_log_row_count;
+    std::vector<uint32_t> prefix_lv(prefix.size());
+    if (rf) {
+        SP1HIP_TRY(row_eq_lv[0].alloc(((size_t)16) << (max_log_row_count - 1), s));
+        SP1HIP_TRY(row_eq_lv[1].alloc(((size_t)16) << (max_log_row_count - 1), s));
+        SP1HIP_TRY(d_prefix_lv.alloc(prefix.size() * 4 * (size_t)(rf + 1), s));
+    }
+    // J of level `lv` (1 <= lv <= rf): folds the row table once more with the challenge that produced the level
+    auto level_J = [&](int lv, const Ext& a_prev, JgJ* out) -> int {
+        uint32_t* dst = row_eq_lv[lv & 1].u32();
+        hipLaunchKernelGGL(jg_fold_row_eq, dim3((row_len_cur / 2 + 255) / 256), dim3(256), 0, s, row_eq_cur, row_len_cur, a_prev, dst);
+        SP1HIP_LAUNCH_CHECK();
+        row_eq_cur = dst;
+        row_len_cur >>= 1;
+        for (size_t c = 0; c < prefix.size(); c++) prefix_lv[c] = prefix[c] >> lv;
+        uint32_t* d_pl = d_prefix_lv.u32() + (size_t)lv * prefix.size();
+        SP1HIP_TRY(sc.stage.upload(d_pl, prefix_lv.data(), prefix.size() * 4));
+        *out = JgJ{d_pl, ncols, (const Ext*)d_col_eq.p, row_eq_cur, row_len_cur};
+        return SP1HIP_SUCCESS;
+    };
     uint32_t n_live = T;               // live entries of the current round's tables
-    int cur = 0;                       // tabs[cur], tabs[cur + 1] hold (q, j) of the current round when round >= 1
+    int cur = 0;                       // tabs[cur] (and tabs[cur + 1] once materialised) hold (q, j) of the current level
     for (int round = 0; round < log_m; round++) {
         uint32_t nb;
         if (round == 0) {
@@ -758,17 +876,40 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
             ScopedTimer t("jagged_fold0_sum", s);
             const uint32_t n_out = (n_live + 1) / 2;
             nb = Scratch::blocks_for(((n_out + 1) / 2 + JG_ITERS - 1) / JG_ITERS);
-            hipLaunchKernelGGL(jg_fold0_sum, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)tabs[1].p,
-                               sc.partials.u32());
+            if (rf) {
+                JgJ J1;                                    // keeps eq_row_1 in step for level 2
+                SP1HIP_TRY(level_J(1, alpha, &J1));
+                hipLaunchKernelGGL(jg_fold0_sum<false>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)nullptr,
+                                   sc.partials.u32());
+            } else {
+                hipLaunchKernelGGL(jg_fold0_sum<true>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)tabs[1].p,
+                                   sc.partials.u32());
+            }
             n_live = n_out;
             cur = 0;
         } else {
             ScopedTimer t("jagged_fold_sum", s);
             const uint32_t n_out = (n_live + 1) / 2;
-            nb = Scratch::blocks_for((n_out + 1) / 2);
             const int nxt = cur ^ 2;
-            hipLaunchKernelGGL(jg_fold_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, (const Ext*)tabs[cur + 1].p, n_live,
-                               alpha, n_out, (Ext*)tabs[nxt].p, (Ext*)tabs[nxt + 1].p, sc.partials.u32());
+            if (round <= rf) {                             // factored: level `round` from level `round - 1`
+                JgJ Jl;
+                SP1HIP_TRY(level_J(round, alpha, &Jl));
+                nb = Scratch::blocks_for(((n_out + 1) / 2 + JG_ITERS - 1) / JG_ITERS);
+                hipLaunchKernelGGL(jg_foldf_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, n_live, Jl, alpha, n_out,
+                                   (Ext*)tabs[nxt].p, sc.partials.u32());
+            } else {
+                if (!j_materialised) {                     // leave the factored form: j of level round - 1
+                    const JgJ Jp{d_prefix_lv.u32() + (size_t)(round - 1) * prefix.size(), ncols, (const Ext*)d_col_eq.p, row_eq_cur, row_len_cur};
+                    SP1HIP_TRY(tabs[cur + 1].alloc((size_t)std::max<uint32_t>(n_live, 1) * 16, s));
+                    SP1HIP_TRY(tabs[nxt + 1].alloc((size_t)std::max<uint32_t>(n_out, 1) * 16, s));
+                    hipLaunchKernelGGL(jg_materialize_j, dim3((n_live + 255) / 256), dim3(256), 0, s, Jp, n_live, (Ext*)tabs[cur + 1].p);
+                    SP1HIP_LAUNCH_CHECK();
+                    j_materialised = true;
+                }
+                nb = Scratch::blocks_for((n_out + 1) / 2);
+                hipLaunchKernelGGL(jg_fold_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, (const Ext*)tabs[cur + 1].p, n_live,
+                                   alpha, n_out, (Ext*)tabs[nxt].p, (Ext*)tabs[nxt + 1].p, sc.partials.u32());
+            }
             n_live = n_out;
             cur = nxt;
         }

@@ -21,11 +21,18 @@ def api():
 BIG = [
     ([[(1 << 10, 3), (777, 5), (0, 2), (33, 7)], [(1 << 12, 9), (4095, 2), (1, 1), (2048, 30)]], 12, 8, 4),
     ([[(70000, 3)], [(1 << 17, 5), (99999, 4), (123, 40)]], 17, 12, 8),       # multi-block sums, odd areas
+    # every column starts at a multiple of 64 / 32 / 4 in the dense order: the first 6 / 5 / 2 folds keep J factored
+    # (jg_foldf_sum), then the prover leaves the factored form (jg_materialize_j)
+    ([[(1 << 10, 3), (768, 5), (0, 2), (64, 7)], [(1 << 12, 9), (4032, 2), (128, 1), (2048, 30)]], 12, 8, 4),
+    ([[(32, 3), (96, 1)], [(1 << 15, 5), (65504, 4), (160, 40)]], 16, 10, 8),
+    ([[(1 << 10, 3), (772, 5), (12, 7)]], 10, 6, 4),
 ]
 
 
+@pytest.mark.parametrize("factored", ["1", "0"])
 @pytest.mark.parametrize("shapes,L,lsh,batch", CASES + BIG)
-def test_jagged_proof_matches_oracle(api, shapes, L, lsh, batch):
+def test_jagged_proof_matches_oracle(api, monkeypatch, shapes, L, lsh, batch, factored):
+    monkeypatch.setenv("SP1HIP_JAGGED_FACTORED", factored)       # "0": always materialise the j tables
     lb, nq, pw = 1, 6, 4
     rounds, tabs = make_rounds(shapes, L, lsh, batch, 7 + L, lb)
     jp = api.JaggedProver(L, lsh, batch, lb)
