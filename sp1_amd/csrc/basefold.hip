@@ -48,30 +48,22 @@ __global__ void monty_convert_kernel(uint32_t* data, size_t n) {
 }
 
 // ---------------------------------------------------------------- batch (RLC of all columns)
-// out[r] = sum_g coeff[g] * col_g[r]. Coefficients are wave-uniform (scalar loads); products of
-// two columns share one Montgomery reduction per ext coordinate (2 p^2 < 2^32 p).
+// out[r] = sum_g coeff[g] * col_g[r]. Coefficients are wave-uniform (scalar loads); the sum over the columns is
+// accumulated unreduced (kb::DotAcc, total_width <= 2^16).
 __global__ __launch_bounds__(256) void batch_kernel(const uint32_t* const* __restrict__ cols, uint32_t total_width,
                                                     uint32_t height, const uint32_t* __restrict__ coeffs,
                                                     uint32_t* __restrict__ out) {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     if (row >= height) return;
-    uint32_t acc[4] = {0, 0, 0, 0};
-    uint32_t g = 0;
-    for (; g + 1 < total_width; g += 2) {
-        const uint32_t x0 = cols[g][row], x1 = cols[g + 1][row];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint64_t t = (uint64_t)coeffs[4 * g + k] * x0 + (uint64_t)coeffs[4 * g + 4 + k] * x1;
-            acc[k] = kb::add(acc[k], kb::monty_reduce(t));
-        }
+    kb::DotAcc acc;                   // delayed reduction: one Montgomery reduction per coordinate for the whole row
+    kb::dot_init(acc);
+    for (uint32_t g = 0; g < total_width; g++) {
+        const kb::Ext c{{coeffs[4 * g], coeffs[4 * g + 1], coeffs[4 * g + 2], coeffs[4 * g + 3]}};   // wave-uniform
+        kb::dot_add(acc, c, cols[g][row]);
     }
-    if (g < total_width) {
-        const uint32_t x0 = cols[g][row];
+    const kb::Ext r = kb::dot_finish(acc);
 #pragma unroll
-        for (int k = 0; k < 4; k++) acc[k] = kb::add(acc[k], kb::mul(coeffs[4 * g + k], x0));
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) out[(size_t)k * height + row] = acc[k];
+    for (int k = 0; k < 4; k++) out[(size_t)k * height + row] = r.c[k];
 }
 
 // ---------------------------------------------------------------- folds
@@ -177,8 +169,8 @@ __device__ __forceinline__ void block_sum4(uint32_t (&v)[4], uint32_t* scratch /
     __syncthreads();
 }
 
-constexpr int EVAL_COLS = 8;      // columns per workgroup
-constexpr int EVAL_ROWS = 4096;   // rows per workgroup
+constexpr int EVAL_COLS = 4;      // columns per workgroup (4 x 16 VGPRs of unreduced accumulators)
+constexpr int EVAL_ROWS = 16384;  // rows per workgroup
 
 // partial[chunk][g] = sum over the chunk's rows of eq[r] * col_g[r]
 __global__ __launch_bounds__(256) void eval_columns_partial_kernel(const uint32_t* const* __restrict__ cols,
@@ -188,23 +180,23 @@ __global__ __launch_bounds__(256) void eval_columns_partial_kernel(const uint32_
     __shared__ uint32_t scratch[16];
     const uint32_t g0 = blockIdx.y * EVAL_COLS;
     const uint32_t r0 = blockIdx.x * EVAL_ROWS;
+    kb::DotAcc dacc[EVAL_COLS];       // delayed reduction: EVAL_ROWS / 256 terms per lane, one reduction per column
+#pragma unroll
+    for (int c = 0; c < EVAL_COLS; c++) kb::dot_init(dacc[c]);
+    for (uint32_t r = r0 + threadIdx.x; r < r0 + EVAL_ROWS && r < height; r += 256) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * height + r];
+#pragma unroll
+        for (int c = 0; c < EVAL_COLS; c++)
+            if (g0 + c < total_width) kb::dot_add(dacc[c], e, cols[g0 + c][r]);
+    }
     uint32_t acc[EVAL_COLS][4];
 #pragma unroll
-    for (int c = 0; c < EVAL_COLS; c++)
+    for (int c = 0; c < EVAL_COLS; c++) {
+        const kb::Ext v = kb::dot_finish(dacc[c]);
 #pragma unroll
-        for (int k = 0; k < 4; k++) acc[c][k] = 0;
-    for (uint32_t r = r0 + threadIdx.x; r < r0 + EVAL_ROWS && r < height; r += 256) {
-        uint32_t e[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) e[k] = eq[(size_t)k * height + r];
-#pragma unroll
-        for (int c = 0; c < EVAL_COLS; c++) {
-            if (g0 + c < total_width) {
-                const uint32_t x = cols[g0 + c][r];
-#pragma unroll
-                for (int k = 0; k < 4; k++) acc[c][k] = kb::add(acc[c][k], kb::mul(e[k], x));
-            }
-        }
+        for (int k = 0; k < 4; k++) acc[c][k] = v.c[k];
     }
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) {

@@ -300,32 +300,34 @@ __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restric
 }
 
 // ================================================================ trace openings at the final point
-struct OpenDesc { const uint32_t* cols; uint32_t rows, width, col0, out0; };   // one group of <= 8 columns of one chip
-constexpr int OPEN_COLS = 8, OPEN_ROWS = 4096;
+struct OpenDesc { const uint32_t* cols; uint32_t rows, width, col0, out0; };   // one group of <= OPEN_COLS columns of one chip
+constexpr int OPEN_COLS = 4, OPEN_ROWS = 16384;
+// Column sums against eq with delayed reduction (kb::DotAcc): 64 terms per lane, one reduction per column and lane.
 __global__ __launch_bounds__(256) void open_columns_kernel(const OpenDesc* __restrict__ descs, const uint32_t* __restrict__ eq,
                                                            uint32_t eq_len, uint32_t* __restrict__ partials, uint32_t total_cols) {
     const OpenDesc d = descs[blockIdx.y];
     const uint32_t r0 = blockIdx.x * OPEN_ROWS;
-    Ext acc[OPEN_COLS];
+    if (r0 >= d.rows) return;                             // partials are zero-initialised
+    kb::DotAcc acc[OPEN_COLS];
 #pragma unroll
-    for (int c = 0; c < OPEN_COLS; c++) acc[c] = kb::ext_zero();
-    if (r0 < d.rows) {
-        for (uint32_t r = r0 + threadIdx.x; r < r0 + OPEN_ROWS && r < d.rows; r += 256) {
-            const Ext e{{eq[r], eq[eq_len + r], eq[2 * (size_t)eq_len + r], eq[3 * (size_t)eq_len + r]}};
+    for (int c = 0; c < OPEN_COLS; c++) kb::dot_init(acc[c]);
+    for (uint32_t r = r0 + threadIdx.x; r < r0 + OPEN_ROWS && r < d.rows; r += 256) {
+        const Ext e{{eq[r], eq[eq_len + r], eq[2 * (size_t)eq_len + r], eq[3 * (size_t)eq_len + r]}};
 #pragma unroll
-            for (int c = 0; c < OPEN_COLS; c++)
-                if (d.col0 + c < d.width) acc[c] = kb::ext_add(acc[c], kb::ext_mul_base(e, d.cols[(size_t)(d.col0 + c) * d.rows + r]));
-        }
+        for (int c = 0; c < OPEN_COLS; c++)
+            if (d.col0 + c < d.width) kb::dot_add(acc[c], e, d.cols[(size_t)(d.col0 + c) * d.rows + r]);
     }
     __shared__ uint32_t sm[4][4 * OPEN_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < OPEN_COLS; c++)
+    for (int c = 0; c < OPEN_COLS; c++) {
+        const Ext v = kb::dot_finish(acc[c]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t w = wave_sum(acc[c].c[k]);
+            const uint32_t w = wave_sum(v.c[k]);
             if (lane == 0) sm[wave][4 * c + k] = w;
         }
+    }
     __syncthreads();
     if (threadIdx.x < 4 * OPEN_COLS) {
         const int c = threadIdx.x / 4;

@@ -122,6 +122,34 @@ KB_HD Ext ext_mul(const Ext& a, const Ext& b) {
     return r;
 }
 
+// ---- long dot products sum_r e_r * v_r (e extension, v base) with ONE reduction at the end ------------------------
+// v is split into 16-bit halves so that a partial product e_k * half fits 47 bits and 2^16 of them fit a 64-bit
+// accumulator: per term and coordinate two v_mad_u64_u32 and no reduction, instead of a 64-bit product, a Montgomery
+// reduction and a modular add (~15 VALU slots per term against ~38). Used by the evaluation kernels (columns at a
+// point, batching): their inner loops are exactly this shape.
+struct DotAcc { uint64_t lo[4], hi[4]; };
+KB_HD void dot_init(DotAcc& a) {
+    for (int k = 0; k < 4; k++) { a.lo[k] = 0; a.hi[k] = 0; }
+}
+KB_HD void dot_add(DotAcc& a, const Ext& e, uint32_t v) {      // at most 2^16 calls between dot_init and dot_finish
+    const uint32_t vl = v & 0xffffu, vh = v >> 16;
+    for (int k = 0; k < 4; k++) {
+        a.lo[k] += (uint64_t)e.c[k] * vl;
+        a.hi[k] += (uint64_t)e.c[k] * vh;
+    }
+}
+// S < 2^63 -> S * 2^-32 mod p (Montgomery reduction of the low word; the high word is already "times 2^32")
+KB_HD uint32_t dot_reduce64(uint64_t s) {
+    const uint32_t h = (uint32_t)(s >> 32);                     // < 2^31 < 2p
+    return add(monty_reduce((uint64_t)(uint32_t)s), umin(h, h - P));
+}
+KB_HD Ext dot_finish(const DotAcc& a) {
+    constexpr uint32_t M16 = (uint32_t)(((uint64_t)1 << 48) % P);   // to_monty(2^16)
+    Ext r;
+    for (int k = 0; k < 4; k++) r.c[k] = add(dot_reduce64(a.lo[k]), mul(dot_reduce64(a.hi[k]), M16));
+    return r;
+}
+
 // Inverse through the tower F < F[y]/(y^2-3) < EF, y = x^2 (host-side transcript use only).
 KB_HD Ext ext_inv(const Ext& a) {
     const uint32_t W = 0x05fffffau;
