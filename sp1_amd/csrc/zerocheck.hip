@@ -558,20 +558,6 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
     return SP1HIP_SUCCESS;
 }
 
-// Marks the first load of every column (GKR flag) and appends a TOUCH pseudo-instruction for each column
-// the constraints never read, so that one pass over the program visits every column exactly once.
-static void add_gkr_visits(std::vector<uint32_t>* prog, uint32_t main_w, uint32_t prep_w) {
-    std::vector<bool> seen_m(main_w, false), seen_p(prep_w, false);
-    const size_t n = prog->size() / 4;
-    for (size_t k = 0; k < n; k++) {
-        uint32_t* o = prog->data() + 4 * k;
-        if (o[0] == ZC_LOAD_MAIN && !seen_m[o[2]]) { seen_m[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
-        if (o[0] == ZC_LOAD_PREP && !seen_p[o[2]]) { seen_p[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
-    }
-    for (uint32_t c = 0; c < main_w; c++) if (!seen_m[c]) { prog->insert(prog->end(), {ZC_TOUCH, 0u, c, 0u}); }
-    for (uint32_t c = 0; c < prep_w; c++) if (!seen_p[c]) { prog->insert(prog->end(), {ZC_TOUCH, 0u, c, 1u}); }
-}
-
 // host evaluation of the program on an all-zero row (padded_row_adjustment, shard.rs:L524-L536)
 static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     const uint32_t n = (uint32_t)(c.prog.size() / 4);
