@@ -143,7 +143,7 @@ def main():
     # the same kernels once more with the encode/hash overlap switched off (not timed into `value`): isolated
     # launch durations, so the roofline object can show both what a launch achieves alone and inside the step
     iso = {}
-    if rank == 0:
+    if rank == 0 and world == 1:      # (N > 1 runs measure scaling only: no after-pass, no CPU baseline)
         os.environ["SP1HIP_COMMIT_OVERLAP"] = "0"
         api.check(L.sp1hip_timers_reset())
         api.check(L.sp1hip_timers_enable(1))
@@ -183,7 +183,7 @@ def main():
         ntt_ms = sum(v for k, v in ntt.items() if k.startswith("ntt"))
         ntt_bytes = 4 * n * WIDTH * (1 + (1 << LOG_BLOWUP))
         valu_peak = 256 * 64 * 2.4e9
-        iso_leaf = iso["leaf_hash_ms_per_step"]
+        iso_leaf = iso.get("leaf_hash_ms_per_step")
         iso_ntt = sum(iso[k] for k in iso if k.startswith("ntt"))
         out = {
             "metric": "RISC-V cycles proved/sec (core shard prove; synthetic config 2: commit phase, 1 trace row = 1 cycle)",
@@ -219,12 +219,11 @@ def main():
                                        "achieved": ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
                                        "frac": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ntt_ms else None},
                          "per_step_ms": ntt,
-                         "isolated": {"note": "same workload, encode/hash overlap off, %d steps after the timed region" % iso_steps,
-                                      "ms_per_step": round(iso["ms_per_step"], 4), "leaf_hash_ms_per_step": round(iso_leaf, 4),
-                                      "rs_encode_ms_per_step": round(iso_ntt, 4)}},
+                         "isolated": ({"note": "same workload, encode/hash overlap off, %d steps after the timed region" % iso_steps,
+                                       "ms_per_step": round(iso["ms_per_step"], 4), "leaf_hash_ms_per_step": round(iso_leaf, 4),
+                                       "rs_encode_ms_per_step": round(iso_ntt, 4)} if iso else None)},
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_lg_rows)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_lg_rows) if (world == 1 and not args.no_cpu_baseline) else None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
