@@ -66,6 +66,8 @@ def main():
     stage_timers = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition",
                     "gkr_round_sum_first", "gkr_round_fold_sum", "gkr_openings", "jagged_round0_sum", "jagged_fold0_sum",
                     "jagged_fold_sum", "jagged_batch_evals")
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
     for rep in range(args.repeat):
         ch = api.DuplexChallenger()
         ch.observe(prep_commit)
@@ -74,6 +76,8 @@ def main():
         proof, t_total = timed(lambda: api.prove_shard(chips, [], prep_data, L, lsh, 32, ch))
         out = dict(res, prove_shard_ms=round(t_total, 2), shard_proof_bytes=len(proof),
                    cells_per_s=round(area / (t_total * 1e-3)))
+        if rep == 0:      # what one in-flight proof holds on top of its inputs (the arena keeps it cached afterwards)
+            out["hbm_working_set_gb"] = round((free0 - torch.cuda.mem_get_info()[0]) / 1e9, 2)
         if rep == args.repeat - 1:
             out["kernel_ms_with_timers_on"] = read_timers(stage_timers)
         print(json.dumps(out), flush=True)
