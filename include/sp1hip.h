@@ -179,6 +179,16 @@ int sp1hip_mle_eval_columns(const sp1hip_tensor_t* tensors, int n_tensors, int l
 int sp1hip_ext_fixed_at_zero(const uint32_t* d_mle, int lg_n, const uint32_t* d_eq, uint32_t* d_out,
                              sp1hip_stream_t stream);
 
+/* `mle_fix_last_variable` for a whole table (/root/reference/slop/crates/multilinear/src/restrict.rs:L10-L72; the
+ * zerocheck prover's per-round table update, /root/reference/crates/hypercube/src/prover/zerocheck/mod.rs:L156-L171):
+ * out[i][c] = x + alpha (y - x), x = row 2i, y = row 2i + 1, or the column's padding value when 2i + 1 == rows.
+ * d_in: column-major, `rows x width` base words (in_is_ext == 0) or the extension layout below (in_is_ext != 0).
+ * d_out: extension table of ceil(rows / 2) rows in the layout the sumcheck kernels use: word q of column c, row i at
+ * d_out[(4 c + q) * out_rows + i]. d_padding: `width` base words (or 4 width words, (c, q) order, for an extension
+ * input) in DEVICE memory, or NULL for zero padding. */
+int sp1hip_fix_last_variable(const uint32_t* d_in, uint64_t rows, uint32_t width, int in_is_ext, sp1hip_ext_t alpha,
+                             const uint32_t* d_padding, uint32_t* d_out, sp1hip_stream_t stream);
+
 /* ---------------------------------------------------------------- transcript (a17)
  * `DuplexChallenger<KoalaBear, KoalaPerm, 16, 8>` (/root/reference/slop/crates/challenger/src/lib.rs:L25-L87).
  * Host object; `grind` runs the witness search on the GPU and returns the SMALLEST valid witness. */

@@ -116,6 +116,7 @@ PROTOTYPES = [
     ("sp1hip_fold_mle", None, [_vp, _int, Ext, _vp, _vp]),
     ("sp1hip_partial_lagrange", None, [C.POINTER(Ext), _int, _vp, _vp]),
     ("sp1hip_mle_eval_columns", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
+    ("sp1hip_fix_last_variable", None, [_vp, C.c_uint64, C.c_uint32, _int, Ext, _vp, _vp, _vp]),
     ("sp1hip_ext_fixed_at_zero", None, [_vp, _int, _vp, _vp, _vp]),
     ("sp1hip_challenger_new", None, [C.POINTER(_vp)]),
     ("sp1hip_challenger_clone", None, [_vp, C.POINTER(_vp)]),

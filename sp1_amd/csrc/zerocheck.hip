@@ -938,6 +938,42 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     return SP1HIP_SUCCESS;
 }
 
+namespace sp1hip {
+// standalone form of the per-round table update, with the reference's per-column padding value
+template <bool FIRST>
+__global__ __launch_bounds__(256) void fix_last_variable_kernel(const uint32_t* __restrict__ in, uint32_t rows, uint32_t width,
+                                                                kb::Ext alpha, const uint32_t* __restrict__ padding,
+                                                                uint32_t* __restrict__ out) {
+    using K = KT<FIRST>;
+    const uint32_t out_rows = (rows + 1) / 2;
+    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= (size_t)out_rows * width) return;
+    const uint32_t c = (uint32_t)(t / out_rows), i = (uint32_t)(t % out_rows);
+    typename K::T x = K::load(in, c, rows, 2 * i), y;
+    if (2 * i + 1 < rows) y = K::load(in, c, rows, 2 * i + 1);
+    else if (!padding) y = K::zero();
+    else y = K::load(padding, c, 1, 0);                   // a one-row table in the same layout
+    const kb::Ext r = kb::ext_add(K::scale(alpha, K::sub(y, x)), K::to_ext(x));
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[((size_t)c * 4 + q) * out_rows + i] = r.c[q];
+}
+}  // namespace sp1hip
+
+extern "C" int sp1hip_fix_last_variable(const uint32_t* d_in, uint64_t rows, uint32_t width, int in_is_ext, sp1hip_ext_t alpha,
+                                        const uint32_t* d_padding, uint32_t* d_out, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(rows < ((uint64_t)1 << 32), "too many rows");
+    if (rows == 0 || width == 0) return SP1HIP_SUCCESS;
+    SP1HIP_REQUIRE(d_in && d_out && d_in != d_out, "bad buffers");
+    const kb::Ext a{{alpha.c[0], alpha.c[1], alpha.c[2], alpha.c[3]}};
+    const uint64_t total = ((rows + 1) / 2) * width;
+    SP1HIP_REQUIRE((total + 255) / 256 < ((uint64_t)1 << 31), "table too large for one launch");
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (in_is_ext) hipLaunchKernelGGL(fix_last_variable_kernel<false>, grid, dim3(256), 0, S(stream), d_in, (uint32_t)rows, width, a, d_padding, d_out);
+    else hipLaunchKernelGGL(fix_last_variable_kernel<true>, grid, dim3(256), 0, S(stream), d_in, (uint32_t)rows, width, a, d_padding, d_out);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
 extern "C" int sp1hip_zerocheck_prove(const sp1hip_zc_chip_t* chips, int n_chips, int max_log_row_count,
                                       const sp1hip_ext_t* h_zeta, const sp1hip_ext_t* h_openings, sp1hip_ext_t alpha,
                                       sp1hip_ext_t gkr_batch, const uint32_t* h_publics, int n_publics,

@@ -64,3 +64,57 @@ def test_zerocheck_rejects_bad_programs_and_keeps_transcript(api):
     with pytest.raises(api._lib.Sp1HipError):
         api.zerocheck(g, 2, zeta, np.concatenate([c.openings for c in zc]), alpha, gkr, publics, ch)
     assert np.array_equal(ch.state(), before)
+
+
+@pytest.mark.parametrize("rows,width,pad", [(1000, 5, True), (1001, 3, True), (1, 2, True), (777, 4, False), (2, 1, False)])
+def test_fix_last_variable_export(api, rows, width, pad):
+    """sp1hip_fix_last_variable (restrict.rs mle_fix_last_variable): out[i][c] = x + alpha (y - x) with the column's
+    padding value for a missing last row; base input, then the extension output fed back in (extension padding).
+    Checked against the pure-Python extension arithmetic of oracle/kb_py.py in the canonical domain."""
+    import ctypes as C
+    import kb_py
+    from sp1_amd._lib import Ext
+    L = api._L()
+    tab = orc.random_felts((rows, width), 31 + rows)               # row-major host, Montgomery
+    alpha_m = orc.random_felts((4,), 5)
+    padding_m = orc.random_felts((width,), 9) if pad else None
+    d_in = api.ColMajor.from_row_major_host(tab)
+    out_rows = (rows + 1) // 2
+    d_out = api.device_words(out_rows * width * 4)
+    d_pad = api.to_device(padding_m) if pad else None
+    a = Ext()
+    for k in range(4):
+        a.c[k] = int(alpha_m[k])
+    api.check(L.sp1hip_fix_last_variable(api._dptr(d_in.words), rows, width, 0, a, api._dptr(d_pad) if pad else None,
+                                         api._dptr(d_out), api._stream_ptr()))
+    got = orc.from_monty(api.to_host(d_out)).reshape(width, 4, out_rows)
+    t, al = orc.from_monty(tab).astype(object), [int(v) for v in orc.from_monty(alpha_m)]
+    pv = [int(v) for v in orc.from_monty(padding_m)] if pad else [0] * width
+    want = np.zeros((width, 4, out_rows), dtype=object)
+    for c in range(width):
+        for i in range(out_rows):
+            x = int(t[2 * i, c])
+            y = int(t[2 * i + 1, c]) if 2 * i + 1 < rows else pv[c]
+            want[c, :, i] = kb_py.ext_add(kb_py.ext_scale(al, (y - x) % kb_py.P), kb_py.ext_from_base(x))
+    assert np.array_equal(got.astype(object), want)
+    # second application on the extension table, extension padding values
+    rows2, out2 = out_rows, (out_rows + 1) // 2
+    beta_m = orc.random_felts((4,), 6)
+    pad2_m = orc.random_felts((width * 4,), 10) if pad else None
+    d_pad2 = api.to_device(pad2_m) if pad else None
+    d_out2 = api.device_words(out2 * width * 4)
+    b = Ext()
+    for k in range(4):
+        b.c[k] = int(beta_m[k])
+    api.check(L.sp1hip_fix_last_variable(api._dptr(d_out), rows2, width, 1, b, api._dptr(d_pad2) if pad else None,
+                                         api._dptr(d_out2), api._stream_ptr()))
+    got2 = orc.from_monty(api.to_host(d_out2)).reshape(width, 4, out2)
+    be = [int(v) for v in orc.from_monty(beta_m)]
+    p2 = orc.from_monty(pad2_m).reshape(width, 4) if pad else np.zeros((width, 4), np.uint32)
+    want2 = np.zeros((width, 4, out2), dtype=object)
+    for c in range(width):
+        for i in range(out2):
+            x = [int(v) for v in want[c, :, 2 * i]]
+            y = [int(v) for v in want[c, :, 2 * i + 1]] if 2 * i + 1 < rows2 else [int(v) for v in p2[c]]
+            want2[c, :, i] = kb_py.ext_add(kb_py.ext_mul(be, kb_py.ext_sub(y, x)), x)
+    assert np.array_equal(got2.astype(object), want2)
