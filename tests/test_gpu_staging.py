@@ -74,3 +74,18 @@ def test_staged_shard_commits_like_the_oracle(api):
     staged = api.stage_tables([np.ascontiguousarray(t) for t in tabs[0]])
     commit, sd = api.JaggedProver(L, lsh, batch, lb).commit_multilinears(staged)
     assert np.array_equal(commit, rounds[0].commit)
+
+
+def test_host_register_then_stage(api):
+    """Caller-owned memory pinned in place (sp1hip_host_register, the reference's cuda_host_register) feeds the staging
+    path like a pinned allocation does; unregistering afterwards leaves the array usable."""
+    a = orc.random_felts((50000, 33), 77)
+    L = api._L()
+    api.check(L.sp1hip_host_register(a.ctypes.data, a.nbytes))
+    try:
+        (cm,) = api.stage_tables([a])
+        torch.cuda.synchronize()
+        assert np.array_equal(col_major_words(cm), a.T)
+    finally:
+        api.check(L.sp1hip_host_unregister(a.ctypes.data))
+    assert int(a[0, 0]) == int(orc.random_felts((50000, 33), 77)[0, 0])
