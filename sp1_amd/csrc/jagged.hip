@@ -201,8 +201,99 @@ __global__ __launch_bounds__(256) void jg_round0_sum(JgSegs S, JgJ J, uint32_t n
     block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
 }
 
+// ---- round 0, table-major form (every table height even, so dense pairs are row pairs (2k, 2k+1) of one column).
+// sum_x J(x) q(x) = sum_tables sum_rows eq_row[r] * (sum_c eq_col[c] q[c, r]): a lane owns one row pair of a table
+// and walks the table's columns — consecutive lanes read consecutive 8-byte pairs of a column — accumulating
+// sum_c eq_col[c] q unreduced (kb::DotAcc, wave-uniform coefficients), and multiplies by eq_row ONCE per row pair.
+// The generic kernel above re-reads the 16 B/row eq_row table for every column (6.4 GB at core scale against the
+// 1.6 GB of q) and spends an ext x base product plus a table walk per element.
+struct JgTab { const uint32_t* q; uint32_t height, col0, ncols, tile0, x0, tile1; };   // q: the table's first column in the dense buffer; x0: its dense index; tile1: first tile of the first-fold launch
+constexpr uint32_t JG_TAB_PAIRS = 256;                                       // row pairs per tile
+__global__ __launch_bounds__(256) void jg_round0_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles,
+                                                        JgJ J, uint32_t* __restrict__ partials) {
+    Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint32_t lo = 0, hi = n_tabs;                     // last table with tile0 <= tile
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (__builtin_amdgcn_readfirstlane(tabs[mid].tile0) <= tile) lo = mid; else hi = mid;
+        }
+        const JgTab t = tabs[lo];
+        const uint32_t k = (tile - t.tile0) * JG_TAB_PAIRS + threadIdx.x;     // row pair of this lane
+        if (2 * k >= t.height) continue;
+        kb::DotAcc u0, us;
+        kb::dot_init(u0);
+        kb::dot_init(us);
+        const uint32_t* col = t.q + 2 * (size_t)k;
+        for (uint32_t c = 0; c < t.ncols; c++, col += t.height) {
+            if ((c & 0x3fffu) == 0x3fffu) {               // 2^14 columns per accumulator window (never in practice)
+                const Ext r0 = jg_row_eq(J, 2 * k), r1 = jg_row_eq(J, 2 * k + 1);
+                e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
+                eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
+                kb::dot_init(u0);
+                kb::dot_init(us);
+            }
+            const uint2 v = *reinterpret_cast<const uint2*>(col);
+            const Ext w = ld_ext(J.col_eq, t.col0 + c);   // wave-uniform
+            kb::dot_add(u0, w, v.x);
+            kb::dot_add(us, w, kb::add(v.x, v.y));
+        }
+        const Ext r0 = jg_row_eq(J, 2 * k), r1 = jg_row_eq(J, 2 * k + 1);
+        e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
+        eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
+    }
+    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+}
+
 __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& alpha) {   // a + alpha (b - a)
     return kb::ext_add(a, kb::ext_mul(alpha, kb::ext_sub(b, a)));
+}
+
+// ---- first fold, table-major form (every table height a multiple of 4; J stays factored): a lane owns the level-1 row
+// pair (2k', 2k'+1) of a table = rows 4k' .. 4k'+3 of every column. q1 = lerp of the base pair (stored as the level-1
+// q table), and the next round's sums use sum_c eq_col[c] q1[c, r] accumulated unreduced (kb::edot_add with the
+// (eq_col, 3 eq_col) pairs), times eq_row_1 once per row.
+__global__ __launch_bounds__(256) void jg_fold0_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles, JgJ J1,
+                                                       const Ext* __restrict__ col_eq3, Ext alpha, Ext* __restrict__ q_out,
+                                                       uint32_t* __restrict__ partials) {
+    Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint32_t lo = 0, hi = n_tabs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (__builtin_amdgcn_readfirstlane(tabs[mid].tile1) <= tile) lo = mid; else hi = mid;
+        }
+        const JgTab t = tabs[lo];
+        const uint32_t k = (tile - t.tile1) * JG_TAB_PAIRS + threadIdx.x;     // level-1 row pair of this lane
+        if (4 * k >= t.height) continue;
+        kb::DotAcc u0, us;
+        kb::dot_init(u0);
+        kb::dot_init(us);
+        const uint32_t* col = t.q + 4 * (size_t)k;
+        const uint32_t h1 = t.height >> 1;
+        Ext* out = q_out + (t.x0 >> 1) + 2 * (size_t)k;
+        for (uint32_t c = 0; c < t.ncols; c++, col += t.height, out += h1) {
+            if ((c & 0xfffu) == 0xfffu) {                 // 2^12 columns per accumulator window (never in practice)
+                const Ext r0 = jg_row_eq(J1, 2 * k), r1 = jg_row_eq(J1, 2 * k + 1);
+                e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
+                eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
+                kb::dot_init(u0);
+                kb::dot_init(us);
+            }
+            const uint4 v = *reinterpret_cast<const uint4*>(col);
+            const Ext qa = kb::ext_add(kb::ext_from_base(v.x), kb::ext_mul_base(alpha, kb::sub(v.y, v.x)));
+            const Ext qb = kb::ext_add(kb::ext_from_base(v.z), kb::ext_mul_base(alpha, kb::sub(v.w, v.z)));
+            st_ext(out, 0, qa);
+            st_ext(out, 1, qb);
+            const Ext w = ld_ext(J1.col_eq, t.col0 + c), w3 = ld_ext(col_eq3, t.col0 + c);     // wave-uniform
+            kb::edot_add(u0, w, w3, qa);
+            kb::edot_add(us, w, w3, kb::ext_add(qa, qb));
+        }
+        const Ext r0 = jg_row_eq(J1, 2 * k), r1 = jg_row_eq(J1, 2 * k + 1);
+        e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
+        eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
+    }
+    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
 }
 
 // ---- first fold (base q, recomputed J) fused with the next round's sums. One step of a thread: inputs 4k..4k+3,
@@ -864,23 +955,79 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
         *out = JgJ{d_pl, ncols, (const Ext*)d_col_eq.p, row_eq_cur, row_len_cur};
         return SP1HIP_SUCCESS;
     };
+    // table-major descriptors for round 0 (only when every column start is even, i.e. dense pairs never straddle columns)
+    std::vector<JgTab> tabs0;
+    uint32_t n_tiles0 = 0, n_tiles1 = 0;
+    bool tables_mult4 = false;         // every table height a multiple of 4: the first fold can go table-major too
+    std::vector<std::pair<uint64_t, uint64_t>> zero_tails;      // dense index ranges holding only padding zeros
+    DeviceBuf d_tabs0, d_col_eq3;
+    {
+        uint32_t g = T;
+        for (uint32_t pfx : prefix) g |= pfx;
+        const char* e = getenv("SP1HIP_JAGGED_FACTORED");
+        if ((g & 1u) == 0 && !(e && e[0] == '0')) {
+            uint64_t seg_start = 0;
+            uint32_t col = 0;
+            for (int r = 0; r < n_rounds; r++) {
+                const sp1hip_stacked_data_s* d = rounds[r];
+                uint64_t off = 0;
+                const size_t n_real = d->row_counts.size() - 2;           // the two padding tables hold zeros only
+                for (size_t t = 0; t < d->row_counts.size(); t++) {
+                    const uint32_t h = (uint32_t)d->row_counts[t], w = (uint32_t)d->column_counts[t];
+                    if (t < n_real && h && w) {
+                        tabs0.push_back(JgTab{(const uint32_t*)d->d_dense + off, h, col, w, n_tiles0, (uint32_t)(seg_start + off), n_tiles1});
+                        n_tiles0 += (h / 2 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
+                        n_tiles1 += ((h + 3) / 4 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
+                    }
+                    if (t == n_real) zero_tails.push_back({seg_start + off, seg_start + d->padded});
+                    off += (uint64_t)h * w;
+                    col += w;
+                }
+                seg_start += d->padded;
+            }
+            if (!tabs0.empty()) {
+                SP1HIP_TRY(upload(d_tabs0, tabs0.data(), tabs0.size() * sizeof(JgTab), s, sc.stage));
+                tables_mult4 = (g & 3u) == 0;
+                std::vector<Ext> col_eq3(col_eq.size());
+                for (size_t c = 0; c < col_eq.size(); c++)
+                    for (int q = 0; q < 4; q++) col_eq3[c].c[q] = kb::add(kb::dbl(col_eq[c].c[q]), col_eq[c].c[q]);
+                SP1HIP_TRY(upload(d_col_eq3, col_eq3.data(), col_eq3.size() * 16, s, sc.stage));
+            }
+        }
+    }
     uint32_t n_live = T;               // live entries of the current round's tables
     int cur = 0;                       // tabs[cur] (and tabs[cur + 1] once materialised) hold (q, j) of the current level
     for (int round = 0; round < log_m; round++) {
         uint32_t nb;
         if (round == 0) {
             ScopedTimer t("jagged_round0_sum", s);
-            nb = Scratch::blocks_for((T / 2 + JG_ITERS - 1) / JG_ITERS);
-            hipLaunchKernelGGL(jg_round0_sum, dim3(nb), dim3(256), 0, s, segs, J, T / 2, sc.partials.u32());
+            if (!tabs0.empty()) {
+                nb = Scratch::blocks_for((uint64_t)n_tiles0 * 256);
+                hipLaunchKernelGGL(jg_round0_tables, dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(), n_tiles0, J,
+                                   sc.partials.u32());
+            } else {
+                nb = Scratch::blocks_for((T / 2 + JG_ITERS - 1) / JG_ITERS);
+                hipLaunchKernelGGL(jg_round0_sum, dim3(nb), dim3(256), 0, s, segs, J, T / 2, sc.partials.u32());
+            }
         } else if (round == 1) {
             ScopedTimer t("jagged_fold0_sum", s);
             const uint32_t n_out = (n_live + 1) / 2;
             nb = Scratch::blocks_for(((n_out + 1) / 2 + JG_ITERS - 1) / JG_ITERS);
             if (rf) {
-                JgJ J1;                                    // keeps eq_row_1 in step for level 2
+                JgJ J1;                                    // eq_row_1 for this round's sums and for level 2
                 SP1HIP_TRY(level_J(1, alpha, &J1));
-                hipLaunchKernelGGL(jg_fold0_sum<false>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)nullptr,
-                                   sc.partials.u32());
+                if (tables_mult4) {
+                    // the kernel writes the real tables only: the zero tail of every round (its padding tables) must
+                    // read as zero in the next fold
+                    for (auto& z : zero_tails)
+                        if (z.second > z.first) SP1HIP_HIP(hipMemsetAsync((Ext*)tabs[0].p + z.first / 2, 0, (size_t)((z.second - z.first) / 2) * 16, s));
+                    nb = Scratch::blocks_for((uint64_t)n_tiles1 * 256);
+                    hipLaunchKernelGGL(jg_fold0_tables, dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(), n_tiles1,
+                                       J1, (const Ext*)d_col_eq3.p, alpha, (Ext*)tabs[0].p, sc.partials.u32());
+                } else {
+                    hipLaunchKernelGGL(jg_fold0_sum<false>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)nullptr,
+                                       sc.partials.u32());
+                }
             } else {
                 hipLaunchKernelGGL(jg_fold0_sum<true>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)tabs[1].p,
                                    sc.partials.u32());
