@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void jg_round0_sum(JgSegs S, JgJ J, uint32_t n
 // sum_c eq_col[c] q unreduced (kb::DotAcc, wave-uniform coefficients), and multiplies by eq_row ONCE per row pair.
 // The generic kernel above re-reads the 16 B/row eq_row table for every column (6.4 GB at core scale against the
 // 1.6 GB of q) and spends an ext x base product plus a table walk per element.
-struct JgTab { const uint32_t* q; uint32_t height, col0, ncols, tile0, x0, tile1; };   // q: the table's first column in the dense buffer; x0: its dense index; tile1: first tile of the first-fold launch
+struct JgTab { const uint32_t* q; uint32_t height, col0, ncols, tile0, x0, tile1, tile2; };   // q: the table's first column in the dense buffer; x0: its dense index; tile0/1/2: first tile in the round-0 / one-level / two-level fold launches
 constexpr uint32_t JG_TAB_PAIRS = 256;                                       // row pairs per tile
 __global__ __launch_bounds__(256) void jg_round0_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles,
                                                         JgJ J, uint32_t* __restrict__ partials) {
@@ -249,47 +249,61 @@ __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& a
     return kb::ext_add(a, kb::ext_mul(alpha, kb::ext_sub(b, a)));
 }
 
-// ---- first fold, table-major form (every table height a multiple of 4; J stays factored): a lane owns the level-1 row
-// pair (2k', 2k'+1) of a table = rows 4k' .. 4k'+3 of every column. q1 = lerp of the base pair (stored as the level-1
-// q table), and the next round's sums use sum_c eq_col[c] q1[c, r] accumulated unreduced (kb::edot_add with the
-// (eq_col, 3 eq_col) pairs), times eq_row_1 once per row.
-__global__ __launch_bounds__(256) void jg_fold0_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles, JgJ J1,
-                                                       const Ext* __restrict__ col_eq3, Ext alpha, Ext* __restrict__ q_out,
-                                                       uint32_t* __restrict__ partials) {
+// ---- first fold(s), table-major form (J stays factored). LEVELS = 1 (heights % 4 == 0): a lane owns the level-1 row
+// pair (2k, 2k+1) of a table = base rows 4k .. 4k+3 of every column; q1 = lerp of the base pairs with alpha0.
+// LEVELS = 2 (heights % 8 == 0): the level-2 row pair = base rows 8k .. 8k+7; level 1 is recomputed in registers and
+// folded again with alpha1, so the level-1 table (16 B per entry written, then read) never exists: round 1 runs
+// with STORE = false (sums only, 4 B/element read), round 2 reads the base words again and writes level 2.
+// The next round's sums use sum_c eq_col[c] q[c, r] accumulated unreduced (kb::edot_add with the (eq_col, 3 eq_col)
+// pairs), times the level's eq_row once per row.
+template <int LEVELS, bool STORE>
+__global__ __launch_bounds__(256) void jg_fold_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles, JgJ Jl,
+                                                      const Ext* __restrict__ col_eq3, Ext alpha0, Ext alpha1, Ext* __restrict__ q_out,
+                                                      uint32_t* __restrict__ partials) {
+    constexpr uint32_t SPAN = 2u << LEVELS;               // base rows per lane and column
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         uint32_t lo = 0, hi = n_tabs;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (__builtin_amdgcn_readfirstlane(tabs[mid].tile1) <= tile) lo = mid; else hi = mid;
+            const uint32_t t0 = __builtin_amdgcn_readfirstlane(LEVELS == 1 ? tabs[mid].tile1 : tabs[mid].tile2);
+            if (t0 <= tile) lo = mid; else hi = mid;
         }
         const JgTab t = tabs[lo];
-        const uint32_t k = (tile - t.tile1) * JG_TAB_PAIRS + threadIdx.x;     // level-1 row pair of this lane
-        if (4 * k >= t.height) continue;
+        const uint32_t k = (tile - (LEVELS == 1 ? t.tile1 : t.tile2)) * JG_TAB_PAIRS + threadIdx.x;   // row pair of this lane
+        if (SPAN * k >= t.height) continue;
         kb::DotAcc u0, us;
         kb::dot_init(u0);
         kb::dot_init(us);
-        const uint32_t* col = t.q + 4 * (size_t)k;
-        const uint32_t h1 = t.height >> 1;
-        Ext* out = q_out + (t.x0 >> 1) + 2 * (size_t)k;
-        for (uint32_t c = 0; c < t.ncols; c++, col += t.height, out += h1) {
+        const uint32_t* col = t.q + SPAN * (size_t)k;
+        const uint32_t hl = t.height >> LEVELS;
+        Ext* out = q_out + (t.x0 >> LEVELS) + 2 * (size_t)k;
+        for (uint32_t c = 0; c < t.ncols; c++, col += t.height, out += hl) {
             if ((c & 0xfffu) == 0xfffu) {                 // 2^12 columns per accumulator window (never in practice)
-                const Ext r0 = jg_row_eq(J1, 2 * k), r1 = jg_row_eq(J1, 2 * k + 1);
+                const Ext r0 = jg_row_eq(Jl, 2 * k), r1 = jg_row_eq(Jl, 2 * k + 1);
                 e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
                 eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
                 kb::dot_init(u0);
                 kb::dot_init(us);
             }
+            Ext qa, qb;
             const uint4 v = *reinterpret_cast<const uint4*>(col);
-            const Ext qa = kb::ext_add(kb::ext_from_base(v.x), kb::ext_mul_base(alpha, kb::sub(v.y, v.x)));
-            const Ext qb = kb::ext_add(kb::ext_from_base(v.z), kb::ext_mul_base(alpha, kb::sub(v.w, v.z)));
-            st_ext(out, 0, qa);
-            st_ext(out, 1, qb);
-            const Ext w = ld_ext(J1.col_eq, t.col0 + c), w3 = ld_ext(col_eq3, t.col0 + c);     // wave-uniform
+            const Ext l0 = kb::ext_add(kb::ext_from_base(v.x), kb::ext_mul_base(alpha0, kb::sub(v.y, v.x)));
+            const Ext l1 = kb::ext_add(kb::ext_from_base(v.z), kb::ext_mul_base(alpha0, kb::sub(v.w, v.z)));
+            if (LEVELS == 1) { qa = l0; qb = l1; }
+            else {
+                const uint4 v2 = *reinterpret_cast<const uint4*>(col + 4);
+                const Ext l2 = kb::ext_add(kb::ext_from_base(v2.x), kb::ext_mul_base(alpha0, kb::sub(v2.y, v2.x)));
+                const Ext l3 = kb::ext_add(kb::ext_from_base(v2.z), kb::ext_mul_base(alpha0, kb::sub(v2.w, v2.z)));
+                qa = kb::ext_add(l0, kb::ext_mul(alpha1, kb::ext_sub(l1, l0)));
+                qb = kb::ext_add(l2, kb::ext_mul(alpha1, kb::ext_sub(l3, l2)));
+            }
+            if (STORE) { st_ext(out, 0, qa); st_ext(out, 1, qb); }
+            const Ext w = ld_ext(Jl.col_eq, t.col0 + c), w3 = ld_ext(col_eq3, t.col0 + c);     // wave-uniform
             kb::edot_add(u0, w, w3, qa);
             kb::edot_add(us, w, w3, kb::ext_add(qa, qb));
         }
-        const Ext r0 = jg_row_eq(J1, 2 * k), r1 = jg_row_eq(J1, 2 * k + 1);
+        const Ext r0 = jg_row_eq(Jl, 2 * k), r1 = jg_row_eq(Jl, 2 * k + 1);
         e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
         eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
     }
@@ -916,8 +930,6 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     std::array<Ext, 3> poly{};
     DeviceBuf tabs[4];                 // q/j ping-pong: q of odd levels in tabs[0], of even levels in tabs[2]; j behind each
     const uint32_t n1 = (T + 1) / 2;
-    SP1HIP_TRY(tabs[0].alloc((size_t)std::max<uint32_t>(n1, 1) * 16, s));
-    SP1HIP_TRY(tabs[2].alloc((size_t)std::max<uint32_t>((n1 + 1) / 2, 1) * 16, s));
     // levels 1 .. rf keep J factored (see jg_foldf_sum): every column must start at a multiple of 2^level
     int rf = 0;
     {
@@ -957,8 +969,9 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     };
     // table-major descriptors for round 0 (only when every column start is even, i.e. dense pairs never straddle columns)
     std::vector<JgTab> tabs0;
-    uint32_t n_tiles0 = 0, n_tiles1 = 0;
+    uint32_t n_tiles0 = 0, n_tiles1 = 0, n_tiles2 = 0;
     bool tables_mult4 = false;         // every table height a multiple of 4: the first fold can go table-major too
+    bool skip_level1 = false;          // ... of 8: rounds 1 and 2 both fold from the base words, level 1 is never stored
     std::vector<std::pair<uint64_t, uint64_t>> zero_tails;      // dense index ranges holding only padding zeros
     DeviceBuf d_tabs0, d_col_eq3;
     {
@@ -975,9 +988,10 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                 for (size_t t = 0; t < d->row_counts.size(); t++) {
                     const uint32_t h = (uint32_t)d->row_counts[t], w = (uint32_t)d->column_counts[t];
                     if (t < n_real && h && w) {
-                        tabs0.push_back(JgTab{(const uint32_t*)d->d_dense + off, h, col, w, n_tiles0, (uint32_t)(seg_start + off), n_tiles1});
+                        tabs0.push_back(JgTab{(const uint32_t*)d->d_dense + off, h, col, w, n_tiles0, (uint32_t)(seg_start + off), n_tiles1, n_tiles2});
                         n_tiles0 += (h / 2 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
                         n_tiles1 += ((h + 3) / 4 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
+                        n_tiles2 += ((h + 7) / 8 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
                     }
                     if (t == n_real) zero_tails.push_back({seg_start + off, seg_start + d->padded});
                     off += (uint64_t)h * w;
@@ -988,6 +1002,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
             if (!tabs0.empty()) {
                 SP1HIP_TRY(upload(d_tabs0, tabs0.data(), tabs0.size() * sizeof(JgTab), s, sc.stage));
                 tables_mult4 = (g & 3u) == 0;
+                skip_level1 = (g & 7u) == 0 && rf >= 2 && log_m >= 4;
                 std::vector<Ext> col_eq3(col_eq.size());
                 for (size_t c = 0; c < col_eq.size(); c++)
                     for (int q = 0; q < 4; q++) col_eq3[c].c[q] = kb::add(kb::dbl(col_eq[c].c[q]), col_eq[c].c[q]);
@@ -995,6 +1010,9 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
             }
         }
     }
+    // q of odd levels lives in tabs[0]: level 1 (T/2 entries), or level 3 when level 1 is never stored
+    SP1HIP_TRY(tabs[0].alloc((size_t)std::max<uint32_t>(skip_level1 ? (T + 7) / 8 : n1, 1) * 16, s));
+    SP1HIP_TRY(tabs[2].alloc((size_t)std::max<uint32_t>((n1 + 1) / 2, 1) * 16, s));
     uint32_t n_live = T;               // live entries of the current round's tables
     int cur = 0;                       // tabs[cur] (and tabs[cur + 1] once materialised) hold (q, j) of the current level
     for (int round = 0; round < log_m; round++) {
@@ -1016,14 +1034,18 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
             if (rf) {
                 JgJ J1;                                    // eq_row_1 for this round's sums and for level 2
                 SP1HIP_TRY(level_J(1, alpha, &J1));
-                if (tables_mult4) {
+                if (skip_level1) {                         // sums only; round 2 folds from the base words again
+                    nb = Scratch::blocks_for((uint64_t)n_tiles1 * 256);
+                    hipLaunchKernelGGL((jg_fold_tables<1, false>), dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(),
+                                       n_tiles1, J1, (const Ext*)d_col_eq3.p, alpha, alpha, (Ext*)nullptr, sc.partials.u32());
+                } else if (tables_mult4) {
                     // the kernel writes the real tables only: the zero tail of every round (its padding tables) must
                     // read as zero in the next fold
                     for (auto& z : zero_tails)
                         if (z.second > z.first) SP1HIP_HIP(hipMemsetAsync((Ext*)tabs[0].p + z.first / 2, 0, (size_t)((z.second - z.first) / 2) * 16, s));
                     nb = Scratch::blocks_for((uint64_t)n_tiles1 * 256);
-                    hipLaunchKernelGGL(jg_fold0_tables, dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(), n_tiles1,
-                                       J1, (const Ext*)d_col_eq3.p, alpha, (Ext*)tabs[0].p, sc.partials.u32());
+                    hipLaunchKernelGGL((jg_fold_tables<1, true>), dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(),
+                                       n_tiles1, J1, (const Ext*)d_col_eq3.p, alpha, alpha, (Ext*)tabs[0].p, sc.partials.u32());
                 } else {
                     hipLaunchKernelGGL(jg_fold0_sum<false>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)nullptr,
                                        sc.partials.u32());
@@ -1038,7 +1060,15 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
             ScopedTimer t("jagged_fold_sum", s);
             const uint32_t n_out = (n_live + 1) / 2;
             const int nxt = cur ^ 2;
-            if (round <= rf) {                             // factored: level `round` from level `round - 1`
+            if (round == 2 && skip_level1) {               // level 2 straight from the base words (alpha0, alpha1)
+                JgJ Jl;
+                SP1HIP_TRY(level_J(2, alpha, &Jl));
+                for (auto& z : zero_tails)
+                    if (z.second > z.first) SP1HIP_HIP(hipMemsetAsync((Ext*)tabs[nxt].p + z.first / 4, 0, (size_t)((z.second - z.first) / 4) * 16, s));
+                nb = Scratch::blocks_for((uint64_t)n_tiles2 * 256);
+                hipLaunchKernelGGL((jg_fold_tables<2, true>), dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(),
+                                   n_tiles2, Jl, (const Ext*)d_col_eq3.p, alphas[0], alpha, (Ext*)tabs[nxt].p, sc.partials.u32());
+            } else if (round <= rf) {                      // factored: level `round` from level `round - 1`
                 JgJ Jl;
                 SP1HIP_TRY(level_J(round, alpha, &Jl));
                 nb = Scratch::blocks_for(((n_out + 1) / 2 + JG_ITERS - 1) / JG_ITERS);
