@@ -182,7 +182,15 @@ struct ByteWriter {
     void u64(uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
     void u32(uint32_t v) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); }
     void felt(uint32_t monty) { u32(kb::from_monty(monty)); }
-    void felts(const uint32_t* m, size_t n) { for (size_t i = 0; i < n; i++) felt(m[i]); }
+    void felts(const uint32_t* m, size_t n) {            // bulk: the openings are ~340k words of a core-scale proof
+        const size_t o = b.size();
+        b.resize(o + 4 * n);
+        uint8_t* p = b.data() + o;
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t c = kb::from_monty(m[i]);     // little-endian host: canonical word == its four bytes
+            memcpy(p + 4 * i, &c, 4);
+        }
+    }
     void ext(const kb::Ext& e) { felts(e.c, 4); }
 };
 
@@ -248,6 +256,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     SP1HIP_REQUIRE(dim + lb <= kb::TWO_ADICITY, "instance exceeds two-adicity");
 
     ByteWriter w;
+    w.b.reserve(proof_size(dim, [&] { std::vector<uint32_t> ws; for (int r = 0; r < n_rounds; r++) ws.push_back(rounds[r]->total_width); return ws; }(), cfg));
     // Grind for batch randomness, then the batching coefficients.
     uint32_t batch_witness;
     SP1HIP_TRY(grind(ch, 5, &batch_witness, s));
