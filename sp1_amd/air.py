@@ -78,7 +78,13 @@ class AirProgram:
         self.assert_zero(a - b)
 
     def to_array(self):
-        return np.array(self.instrs, dtype=np.uint32).reshape(-1, 3)
+        # memoised per instruction count: a prover builds the same program for every shard
+        n = len(self.instrs)
+        cached = getattr(self, "_array_cache", None)
+        if cached is None or cached[0] != n:
+            cached = (n, np.array(self.instrs, dtype=np.uint32).reshape(-1, 3))
+            self._array_cache = cached
+        return cached[1]
 
     def max_live_registers(self):
         """Registers needed after last-use allocation (what the interpreter kernels size their file by)."""
@@ -196,10 +202,16 @@ class InteractionProgram:
         return len(self.sends) + len(self.receives)
 
     def to_array(self):
+        key = (len(self.sends), len(self.receives))      # memoised: the same description is sent with every shard
+        cached = getattr(self, "_array_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
         out = [self.num_interactions]
         for is_send, lst in ((1, self.sends), (0, self.receives)):
             for kind, values, mult in lst:
                 out += [is_send, kind, len(values)] + mult.words()
                 for v in values:
                     out += v.words()
-        return np.array(out, dtype=np.uint32)
+        arr = np.array(out, dtype=np.uint32)
+        self._array_cache = (key, arr)
+        return arr
