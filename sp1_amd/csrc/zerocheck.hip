@@ -135,6 +135,22 @@ template <bool FIRST, int MAXR> struct RegFile {
 SP1HIP_VREGFILE(16, v16u)
 SP1HIP_VREGFILE(32, v32u)
 
+// MAXR == 0: the file lives in LDS, register i of a lane at slot i * 256 + lane (16 B slots for extension values: one
+// ds_read_b128 / ds_write_b128 per access, conflict-free). Indexing a VGPR vector with a wave-uniform index costs an
+// s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off triple per word — ~36 instructions of pure register traffic around a
+// 12-instruction extension add; the LDS file makes an interpreted op cost its arithmetic plus three LDS accesses,
+// and leaves the VGPRs to the arithmetic (measured per-op cost: add 75 -> ~20 instructions, multiply 147 -> ~100).
+template <> struct RegFile<true, 0> {
+    uint32_t* base;                // this lane's slot of register 0
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i * 256u]; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) { base[i * 256u] = v; }
+};
+template <> struct RegFile<false, 0> {
+    uint4* base;
+    __device__ __forceinline__ kb::Ext get(uint32_t i) const { const uint4 v = base[i * 256u]; return kb::Ext{{v.x, v.y, v.z, v.w}}; }
+    __device__ __forceinline__ void set(uint32_t i, const kb::Ext& v) { base[i * 256u] = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]); }
+};
+
 constexpr uint32_t ZC_GKR_FLAG = 0x100u;   // set by the host on the first load of each column
 constexpr uint32_t ZC_TOUCH = 9;           // pseudo-op: column never loaded by the constraints (GKR term only)
 constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
@@ -144,10 +160,9 @@ constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB
 // gkr_pow[column] * value into *g (main columns first, then preprocessed): the batching term costs no
 // extra loads. `prog` points to LDS (or global memory for very long programs).
 template <bool FIRST, int MAXR>
-__device__ __forceinline__ kb::Ext run_program(const uint4* prog, const ZcDesc& d, const uint32_t* __restrict__ publics,
-                                               uint32_t i, int t, const bool gkr, kb::Ext* g) {
+__device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, const uint4* prog, const ZcDesc& d,
+                                               const uint32_t* __restrict__ publics, uint32_t i, int t, const bool gkr, kb::Ext* g) {
     using K = KT<FIRST>;
-    RegFile<FIRST, MAXR> reg;
     kb::Ext acc = kb::ext_zero();
     uint32_t ci = 0;
     for (uint32_t k = 0; k < d.n_instr; k++) {
@@ -212,11 +227,14 @@ __device__ __forceinline__ ZcDesc zc_find_desc(const ZcDesc* __restrict__ descs,
 template <bool FIRST, int MAXR>
 __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict__ descs, int n_descs,
                                                        const uint32_t* __restrict__ eq, uint32_t eq_len,
-                                                       const uint32_t* __restrict__ publics, uint32_t* __restrict__ partial) {
+                                                       const uint32_t* __restrict__ publics, uint32_t* __restrict__ partial,
+                                                       uint32_t rf_off) {
     using K = KT<FIRST>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* red = lds;                                   // [4][8] reduction scratch
     uint4* lprog = reinterpret_cast<uint4*>(lds + 32);
+    RegFile<FIRST, MAXR> reg;
+    if constexpr (MAXR == 0) reg.base = reinterpret_cast<decltype(reg.base)>(lds + rf_off) + threadIdx.x;   // LDS file behind the program
     const ZcDesc d = zc_find_desc(descs, n_descs, blockIdx.x);
     const int pass = blockIdx.y;
     const bool in_lds = d.n_instr <= ZC_LDS_PROG_MAX;
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
                 vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 2)));
             }
         } else {
-            va = run_program<FIRST, MAXR>(prog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
+            va = run_program<FIRST, MAXR>(reg, prog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
         }
         kb::Ext e;
 #pragma unroll
@@ -587,10 +605,21 @@ static int launch_round(uint32_t max_regs, const ZcDesc* d_descs, int n_descs, u
     const uint32_t staged = max_instr <= ZC_LDS_PROG_MAX ? max_instr : 0;
     const size_t lds = 32 * 4 + (size_t)staged * 16;
     dim3 grid(total_blocks, 3);
-    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
-    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
-    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
-    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial);
+    // register file in LDS when it fits 64 KiB together with the staged program (two workgroups per CU at worst)
+    const size_t rf_bytes = (size_t)max_regs * 256 * (FIRST ? 4 : 16);
+    static const bool force_vgpr = [] { const char* e = getenv("SP1HIP_ZC_REGFILE"); return e && e[0] == 'v'; }();
+    if (!force_vgpr && lds + rf_bytes <= 64 * 1024) {
+        auto kern = zc_round_kernel<FIRST, 0>;
+        if (lds + rf_bytes > 48 * 1024)
+            SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + rf_bytes)));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds + rf_bytes, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4));
+        SP1HIP_LAUNCH_CHECK();
+        return SP1HIP_SUCCESS;
+    }
+    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
+    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
+    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
+    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
     else { set_error("constraint program needs %u live registers (max 1024)", max_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
