@@ -948,11 +948,14 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     DeviceBuf row_eq_lv[2], d_prefix_lv;       // folded row tables (ping-pong) and the shifted prefix sums of a level
     const uint32_t* row_eq_cur = d_row_eq.u32();
     uint32_t row_len_cur = 1u << max_log_row_count;
-    std::vector<uint32_t> prefix_lv(prefix.size());
     if (rf) {
         SP1HIP_TRY(row_eq_lv[0].alloc(((size_t)16) << (max_log_row_count - 1), s));
         SP1HIP_TRY(row_eq_lv[1].alloc(((size_t)16) << (max_log_row_count - 1), s));
         SP1HIP_TRY(d_prefix_lv.alloc(prefix.size() * 4 * (size_t)(rf + 1), s));
+        std::vector<uint32_t> all_lv(prefix.size() * (size_t)(rf + 1));      // the shifted prefix sums of every level: one upload
+        for (int lv = 0; lv <= rf; lv++)
+            for (size_t c = 0; c < prefix.size(); c++) all_lv[(size_t)lv * prefix.size() + c] = prefix[c] >> lv;
+        SP1HIP_TRY(sc.stage.upload(d_prefix_lv.p, all_lv.data(), all_lv.size() * 4));
     }
     // J of level `lv` (1 <= lv <= rf): folds the row table once more with the challenge that produced the level
     auto level_J = [&](int lv, const Ext& a_prev, JgJ* out) -> int {
@@ -961,9 +964,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
         SP1HIP_LAUNCH_CHECK();
         row_eq_cur = dst;
         row_len_cur >>= 1;
-        for (size_t c = 0; c < prefix.size(); c++) prefix_lv[c] = prefix[c] >> lv;
         uint32_t* d_pl = d_prefix_lv.u32() + (size_t)lv * prefix.size();
-        SP1HIP_TRY(sc.stage.upload(d_pl, prefix_lv.data(), prefix.size() * 4));
         *out = JgJ{d_pl, ncols, (const Ext*)d_col_eq.p, row_eq_cur, row_len_cur};
         return SP1HIP_SUCCESS;
     };

@@ -437,7 +437,10 @@ struct ChipState {
     std::vector<Ext> alpha_pows, gkr_pows;
     std::vector<Chunk> chunks;
     std::vector<uint32_t> chunk_off;   // offset (in instructions) of each chunk inside d_prog
-    DevBuf d_prog, d_alpha, d_gkr;
+    size_t off_prog = 0, off_alpha = 0, off_gkr = 0;     // word offsets into the call's single constant blob
+    const uint32_t* p_prog = nullptr;
+    const uint32_t* p_alpha = nullptr;
+    const uint32_t* p_gkr = nullptr;
     std::unique_ptr<DevBuf> main_buf, prep_buf;   // ext tables of later rounds
     const uint32_t* d_main = nullptr;
     const uint32_t* d_prep = nullptr;
@@ -682,7 +685,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> pows(max_constraints);
     { Ext cur = kb::ext_one(); for (auto& x : pows) { x = cur; cur = cur * alpha; } }
 
-    // Host staging vectors handed to hipMemcpyAsync live until the end of the call (`staging`, the ChipStates, the
+    // Host staging vectors handed to hipMemcpyAsync live until the end of the call (`blob`, the ChipStates, the
     // per-round `keep_*` lists below): no synchronisation is needed just to keep a source buffer valid, and every
     // device->host hand-over goes through the mailbox (round_sync.hpp), so the stream is never drained mid-proof.
     Mailbox mb;
@@ -690,7 +693,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     PinnedStage stage;                            // small uploads go through a pinned block (round_sync.hpp)
     SP1HIP_TRY(stage.init(s));
     if (n_publics) SP1HIP_TRY(stage.upload(d_publics.p, publics.data(), (size_t)n_publics * 4));
-    std::vector<std::vector<uint32_t>> staging;
+    std::vector<uint32_t> blob;
     std::vector<std::unique_ptr<ChipState>> st;
     std::vector<Ext> claims;
     size_t oo = 0;
@@ -726,21 +729,28 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         c->vgeq = VGeq{(uint32_t)chips[i].real_rows, kb::ext_one(), kb::ext_zero()};
         c->d_main = chips[i].d_main;
         c->d_prep = chips[i].d_prep;
-        staging.emplace_back();
-        std::vector<uint32_t>& all_prog = staging.back();
+        // programs and power tables of every chip go into ONE blob: one upload for the whole call
+        auto pad4 = [&]() { while (blob.size() & 3) blob.push_back(0); };
+        pad4();
+        c->off_prog = blob.size();
         for (auto& ck : c->chunks) {
-            c->chunk_off.push_back((uint32_t)(all_prog.size() / 4));
-            all_prog.insert(all_prog.end(), ck.prog.begin(), ck.prog.end());
+            c->chunk_off.push_back((uint32_t)((blob.size() - c->off_prog) / 4));
+            blob.insert(blob.end(), ck.prog.begin(), ck.prog.end());
         }
-        SP1HIP_TRY(c->d_prog.alloc(all_prog.size() * 4, s));
-        SP1HIP_TRY(c->d_alpha.alloc(c->alpha_pows.size() * 16, s));
-        SP1HIP_TRY(c->d_gkr.alloc(c->gkr_pows.size() * 16, s));
-        SP1HIP_TRY(stage.upload(c->d_prog.p, all_prog.data(), all_prog.size() * 4));
-        if (!c->alpha_pows.empty())
-            SP1HIP_TRY(stage.upload(c->d_alpha.p, c->alpha_pows.data(), c->alpha_pows.size() * 16));
-        if (!c->gkr_pows.empty())
-            SP1HIP_TRY(stage.upload(c->d_gkr.p, c->gkr_pows.data(), c->gkr_pows.size() * 16));
+        pad4();
+        c->off_alpha = blob.size();
+        for (const Ext& e : c->alpha_pows) blob.insert(blob.end(), e.c, e.c + 4);
+        c->off_gkr = blob.size();
+        for (const Ext& e : c->gkr_pows) blob.insert(blob.end(), e.c, e.c + 4);
         st.push_back(std::move(c));
+    }
+    DevBuf d_blob;
+    SP1HIP_TRY(d_blob.alloc(std::max<size_t>(blob.size(), 4) * 4, s));
+    SP1HIP_TRY(stage.upload(d_blob.p, blob.data(), blob.size() * 4));
+    for (auto& c : st) {
+        c->p_prog = d_blob.u32() + c->off_prog;
+        c->p_alpha = d_blob.u32() + c->off_alpha;
+        c->p_gkr = d_blob.u32() + c->off_gkr;
     }
 
     std::vector<Ext> zeta(L);
@@ -753,13 +763,12 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> round_claims = claims;
     std::vector<std::array<uint32_t, 16>> sums(n_chips);
     std::vector<uint32_t> h_sums((size_t)n_chips * 16);
-    DevBuf d_descs, d_ranges, d_fix_descs, d_partial, d_sums;
+    DevBuf d_descs, d_partial, d_sums;       // d_descs: the round's descriptors [ZcDesc.. | ZcChipRange.. | ZcFixDesc..]
     size_t partial_cap = 0, descs_cap = 0;
     std::vector<std::unique_ptr<std::vector<ZcDesc>>> keep_descs;
     std::vector<std::unique_ptr<std::vector<ZcChipRange>>> keep_ranges;
     std::vector<std::unique_ptr<std::vector<ZcFixDesc>>> keep_fds;
-    SP1HIP_TRY(d_ranges.alloc((size_t)n_chips * sizeof(ZcChipRange), s));
-    SP1HIP_TRY(d_fix_descs.alloc((size_t)n_chips * 2 * sizeof(ZcFixDesc), s));
+    std::vector<std::unique_ptr<std::vector<uint8_t>>> keep_packs;
     SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 64, s));
     for (int r = 0; r < L; r++) {
         const int nv = L - r;                       // variables left
@@ -782,10 +791,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             ZcChipRange rg{total_blocks, 0, terms - 1, 0};
             for (size_t q = 0; q < c.chunks.size(); q++) {
                 ZcDesc d{};
-                d.prog = c.d_prog.u32() + (size_t)c.chunk_off[q] * 4;
+                d.prog = c.p_prog + (size_t)c.chunk_off[q] * 4;
                 d.n_instr = (uint32_t)(c.chunks[q].prog.size() / 4);
                 d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
-                d.rows = (uint32_t)c.rows; d.alpha_pows = c.d_alpha.u32(); d.gkr_pows = c.d_gkr.u32();
+                d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
                 d.block_start = total_blocks; d.n_blocks = blocks;
                 d.alpha_off = c.chunks[q].alpha_off; d.flags = q == 0 ? 1u : 0u;
                 total_blocks += blocks;
@@ -798,14 +807,50 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             desc_chip.push_back(i);
         }
         const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
-        if (n_descs) {
-            if (descs.size() * sizeof(ZcDesc) > descs_cap) {
-                d_descs.release();
-                descs_cap = descs.size() * sizeof(ZcDesc);
-                SP1HIP_TRY(d_descs.alloc(descs_cap, s));
+        // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
+        // it now, so that every descriptor of the round goes up in ONE copy
+        keep_fds.emplace_back(new std::vector<ZcFixDesc>());
+        std::vector<ZcFixDesc>& fds = *keep_fds.back();
+        std::vector<std::unique_ptr<DevBuf>> fresh;
+        std::vector<std::pair<int, bool>> owner;   // (chip, is_main)
+        uint32_t fix_blocks = 0;
+        for (int i = 0; i < n_chips; i++) {
+            ChipState& c = *st[i];
+            if (c.rows == 0) continue;
+            const uint64_t out_rows = (c.rows + 1) / 2;
+            for (int which = 0; which < 2; which++) {
+                const uint32_t width = which == 0 ? c.in->main_width : c.in->prep_width;
+                if (width == 0) continue;
+                std::unique_ptr<DevBuf> nb(new DevBuf());
+                SP1HIP_TRY(nb->alloc((size_t)out_rows * width * 16, s));
+                ZcFixDesc fd{};
+                fd.in = which == 0 ? c.d_main : c.d_prep;
+                fd.out = nb->u32();
+                fd.rows = (uint32_t)c.rows; fd.width = width; fd.block_start = fix_blocks;
+                fd.n_blocks = (uint32_t)(((size_t)out_rows * width + 255) / 256);
+                fix_blocks += fd.n_blocks;
+                fds.push_back(fd);
+                fresh.push_back(std::move(nb));
+                owner.push_back({i, which == 0});
             }
-            SP1HIP_TRY(stage.upload(d_descs.p, descs.data(), descs.size() * sizeof(ZcDesc)));
-            SP1HIP_TRY(stage.upload(d_ranges.p, ranges.data(), ranges.size() * sizeof(ZcChipRange)));
+        }
+        const size_t off_ranges = (descs.size() * sizeof(ZcDesc) + 15) & ~(size_t)15;
+        const size_t off_fds = (off_ranges + ranges.size() * sizeof(ZcChipRange) + 15) & ~(size_t)15;
+        const size_t pack_bytes = off_fds + fds.size() * sizeof(ZcFixDesc);
+        keep_packs.emplace_back(new std::vector<uint8_t>(std::max<size_t>(pack_bytes, 16), 0));
+        std::vector<uint8_t>& pack = *keep_packs.back();
+        if (!descs.empty()) memcpy(pack.data(), descs.data(), descs.size() * sizeof(ZcDesc));
+        if (!ranges.empty()) memcpy(pack.data() + off_ranges, ranges.data(), ranges.size() * sizeof(ZcChipRange));
+        if (!fds.empty()) memcpy(pack.data() + off_fds, fds.data(), fds.size() * sizeof(ZcFixDesc));
+        if (pack.size() > descs_cap) {
+            d_descs.release();
+            descs_cap = pack.size();
+            SP1HIP_TRY(d_descs.alloc(descs_cap, s));
+        }
+        SP1HIP_TRY(stage.upload(d_descs.p, pack.data(), pack_bytes));
+        const ZcChipRange* d_ranges_p = (const ZcChipRange*)((const uint8_t*)d_descs.p + off_ranges);
+        const ZcFixDesc* d_fix_p = (const ZcFixDesc*)((const uint8_t*)d_descs.p + off_fds);
+        if (n_descs) {
             if ((size_t)total_blocks * 24 * 4 > partial_cap) {
                 d_partial.release();
                 partial_cap = (size_t)total_blocks * 24 * 4;
@@ -813,8 +858,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             if (r == 0) SP1HIP_TRY(launch_round<true>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             else SP1HIP_TRY(launch_round<false>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
-            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, (const ZcChipRange*)d_ranges.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
-            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, (const ZcChipRange*)d_ranges.p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
+            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
+            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             SP1HIP_LAUNCH_CHECK();
             SP1HIP_TRY(mb.fetch(d_sums.p, (size_t)n_ranges * 16, h_sums.data()));
         }
@@ -866,38 +911,16 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             round_claims[i] = uni_eval(uni[i], a_r);
             st[i]->uni = uni[i];
         }
-        // ---- fix the last variable of every table (fix_last_variable.rs): one launch for all chips
-        keep_fds.emplace_back(new std::vector<ZcFixDesc>());
-        std::vector<ZcFixDesc>& fds = *keep_fds.back();
-        std::vector<std::unique_ptr<DevBuf>> fresh;
-        std::vector<std::pair<int, bool>> owner;   // (chip, is_main)
-        uint32_t fix_blocks = 0;
+        // ---- fix the last variable of every table (fix_last_variable.rs): one launch for all chips (planned above)
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
             c.vgeq = c.vgeq.fix(a_r);
             if (c.rows == 0) continue;
-            const uint64_t out_rows = (c.rows + 1) / 2;
-            for (int which = 0; which < 2; which++) {
-                const uint32_t width = which == 0 ? c.in->main_width : c.in->prep_width;
-                if (width == 0) continue;
-                std::unique_ptr<DevBuf> nb(new DevBuf());
-                SP1HIP_TRY(nb->alloc((size_t)out_rows * width * 16, s));
-                ZcFixDesc fd{};
-                fd.in = which == 0 ? c.d_main : c.d_prep;
-                fd.out = nb->u32();
-                fd.rows = (uint32_t)c.rows; fd.width = width; fd.block_start = fix_blocks;
-                fd.n_blocks = (uint32_t)(((size_t)out_rows * width + 255) / 256);
-                fix_blocks += fd.n_blocks;
-                fds.push_back(fd);
-                fresh.push_back(std::move(nb));
-                owner.push_back({i, which == 0});
-            }
             c.eq_adj = c.eq_adj * (a_r * last + (kb::ext_one() - a_r) * (kb::ext_one() - last));
         }
         if (!fds.empty()) {
-            SP1HIP_TRY(stage.upload(d_fix_descs.p, fds.data(), fds.size() * sizeof(ZcFixDesc)));
-            if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
-            else hipLaunchKernelGGL(zc_fix_kernel<false>, dim3(fix_blocks), dim3(256), 0, s, (const ZcFixDesc*)d_fix_descs.p, (int)fds.size(), a_r);
+            if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3(fix_blocks), dim3(256), 0, s, d_fix_p, (int)fds.size(), a_r);
+            else hipLaunchKernelGGL(zc_fix_kernel<false>, dim3(fix_blocks), dim3(256), 0, s, d_fix_p, (int)fds.size(), a_r);
             SP1HIP_LAUNCH_CHECK();
             for (size_t k = 0; k < fds.size(); k++) {     // the arena is stream-ordered: the old table is recycled behind this launch
                 ChipState& c = *st[owner[k].first];
