@@ -217,7 +217,7 @@ __device__ __forceinline__ ZcDesc zc_find_desc(const ZcDesc* __restrict__ descs,
 }
 
 // One launch per sumcheck round covers EVERY chip and the three interpolation nodes:
-//   blockIdx.x -> (chip, block of 256 row pairs), blockIdx.y = pass p (node t = 2p).
+//   blockIdx.x = 3 b + p -> (chip, block b of 256 row pairs), pass p (node t = 2p).
 // A pass-p workgroup writes two extension partial sums [A | B] (8 words):
 //   round 0 :  p=0: A = sum eq g(0), B = sum eq g(2)   (GKR batching term only; constraints vanish at 0)
 //              p=1: A = sum eq C(2)                     p=2: A = sum eq C(4)
@@ -235,8 +235,11 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
     uint4* lprog = reinterpret_cast<uint4*>(lds + 32);
     RegFile<FIRST, MAXR> reg;
     if constexpr (MAXR == 0) reg.base = reinterpret_cast<decltype(reg.base)>(lds + rf_off) + threadIdx.x;   // LDS file behind the program
-    const ZcDesc d = zc_find_desc(descs, n_descs, blockIdx.x);
-    const int pass = blockIdx.y;
+    // the three nodes of one block of row pairs are CONSECUTIVE workgroups: they are dispatched together (to
+    // different XCDs), so the second and third read of the same table rows hit the memory-side cache instead of HBM
+    const uint32_t bid = blockIdx.x / 3u;
+    const int pass = (int)(blockIdx.x - 3u * bid);
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
     const bool in_lds = d.n_instr <= ZC_LDS_PROG_MAX;
     if (in_lds) {
         const uint4* src = reinterpret_cast<const uint4*>(d.prog);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
     const uint4* prog = in_lds ? lprog : reinterpret_cast<const uint4*>(d.prog);
     const uint32_t terms = (d.rows + 1) / 2;
     kb::Ext sa = kb::ext_zero(), sb = kb::ext_zero();
-    for (uint32_t i = (blockIdx.x - d.block_start) * 256u + threadIdx.x; i < terms; i += d.n_blocks * 256u) {
+    for (uint32_t i = (bid - d.block_start) * 256u + threadIdx.x; i < terms; i += d.n_blocks * 256u) {
         kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
         if (FIRST && pass == 0) {
             if (d.flags & 1u)
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
     __syncthreads();
     if (threadIdx.x < 8) {
         const uint32_t k = threadIdx.x;
-        partial[((size_t)blockIdx.x * 3 + pass) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
+        partial[((size_t)bid * 3 + pass) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
     }
 }
 
@@ -607,7 +610,7 @@ static int launch_round(uint32_t max_regs, const ZcDesc* d_descs, int n_descs, u
                         const uint32_t* eq, uint32_t eq_len, const uint32_t* publics, uint32_t* partial, hipStream_t s) {
     const uint32_t staged = max_instr <= ZC_LDS_PROG_MAX ? max_instr : 0;
     const size_t lds = 32 * 4 + (size_t)staged * 16;
-    dim3 grid(total_blocks, 3);
+    dim3 grid(total_blocks * 3);          // workgroup 3 b + p = node p of block b
     // register file in LDS when it fits 64 KiB together with the staged program (two workgroups per CU at worst)
     const size_t rf_bytes = (size_t)max_regs * 256 * (FIRST ? 4 : 16);
     static const bool force_vgpr = [] { const char* e = getenv("SP1HIP_ZC_REGFILE"); return e && e[0] == 'v'; }();
