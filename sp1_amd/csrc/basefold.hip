@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void eval_columns_partial_kernel(const uint32_
                                                                    const uint32_t* __restrict__ eq,
                                                                    uint32_t* __restrict__ partial) {
     __shared__ uint32_t scratch[16];
-    const uint32_t g0 = blockIdx.y * EVAL_COLS;
-    const uint32_t r0 = blockIdx.x * EVAL_ROWS;
+    const uint32_t g0 = blockIdx.x * EVAL_COLS;      // consecutive workgroups share the rows (and their eq slice)
+    const uint32_t r0 = blockIdx.y * EVAL_ROWS;
     kb::DotAcc dacc[EVAL_COLS];       // delayed reduction: EVAL_ROWS / 256 terms per lane, one reduction per column
 #pragma unroll
     for (int c = 0; c < EVAL_COLS; c++) kb::dot_init(dacc[c]);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void eval_columns_partial_kernel(const uint32_
         block_sum4(acc[c], scratch);
         if (threadIdx.x == 0 && g0 + c < total_width) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) partial[((size_t)blockIdx.x * total_width + g0 + c) * 4 + k] = acc[c][k];
+            for (int k = 0; k < 4; k++) partial[((size_t)blockIdx.y * total_width + g0 + c) * 4 + k] = acc[c][k];
         }
     }
 }
@@ -441,7 +441,7 @@ int sp1hip_mle_eval_columns(const sp1hip_tensor_t* tensors, int n_tensors, int l
     SP1HIP_TRY(expand_columns_async(tab, tw, height, (const uint32_t**)cols.p, s));
     const uint32_t chunks = (height + EVAL_ROWS - 1) / EVAL_ROWS;
     SP1HIP_TRY(part.alloc((size_t)chunks * tw * 16, s));
-    dim3 grid(chunks, (tw + EVAL_COLS - 1) / EVAL_COLS);
+    dim3 grid((tw + EVAL_COLS - 1) / EVAL_COLS, chunks);
     hipLaunchKernelGGL(eval_columns_partial_kernel, grid, dim3(256), 0, s, (const uint32_t* const*)cols.p, tw, height,
                        d_eq, (uint32_t*)part.p);
     SP1HIP_LAUNCH_CHECK();

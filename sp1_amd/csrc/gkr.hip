@@ -305,8 +305,10 @@ constexpr int OPEN_COLS = 4, OPEN_ROWS = 16384;
 // Column sums against eq with delayed reduction (kb::DotAcc): 64 terms per lane, one reduction per column and lane.
 __global__ __launch_bounds__(256) void open_columns_kernel(const OpenDesc* __restrict__ descs, const uint32_t* __restrict__ eq,
                                                            uint32_t eq_len, uint32_t* __restrict__ partials, uint32_t total_cols) {
-    const OpenDesc d = descs[blockIdx.y];
-    const uint32_t r0 = blockIdx.x * OPEN_ROWS;
+    // consecutive workgroups = the column groups of one table over the SAME rows: their eq slice is re-read from the
+    // caches, not from HBM
+    const OpenDesc d = descs[blockIdx.x];
+    const uint32_t r0 = blockIdx.y * OPEN_ROWS;
     if (r0 >= d.rows) return;                             // partials are zero-initialised
     kb::DotAcc acc[OPEN_COLS];
 #pragma unroll
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void open_columns_kernel(const OpenDesc* __res
         if (d.col0 + c < d.width) {
             uint32_t a = 0;
             for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
-            partials[((size_t)blockIdx.x * total_cols + d.out0 + c) * 4 + (threadIdx.x & 3)] = a;
+            partials[((size_t)blockIdx.y * total_cols + d.out0 + c) * 4 + (threadIdx.x & 3)] = a;
         }
     }
 }
@@ -819,7 +821,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         SP1HIP_TRY(d_res.alloc(total_cols * 16, s));
         SP1HIP_HIP(hipMemsetAsync(d_part.p, 0, (size_t)chunks * total_cols * 16, s));
         ScopedTimer t("gkr_openings", s);
-        hipLaunchKernelGGL(open_columns_kernel, dim3(chunks, (uint32_t)od.size()), dim3(256), 0, s, (const OpenDesc*)d_od.p, d_eq.u32(),
+        hipLaunchKernelGGL(open_columns_kernel, dim3((uint32_t)od.size(), chunks), dim3(256), 0, s, (const OpenDesc*)d_od.p, d_eq.u32(),
                            1u << L, d_part.u32(), (uint32_t)total_cols);
         SP1HIP_LAUNCH_CHECK();
         hipLaunchKernelGGL(open_sum_kernel, dim3(((uint32_t)total_cols * 4 + 255) / 256), dim3(256), 0, s, d_part.u32(), chunks,
