@@ -144,3 +144,39 @@ def test_product_does_not_reference_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True).stdout.decode()
     assert "oracle" not in out
+
+
+def test_ffi_struct_layouts_match_the_header(tmp_path):
+    """The reference keeps an FFI struct-layout test next to its kernels (sp1-gpu/crates/zerocheck/tests/ffi_layout.rs);
+    here: every struct of include/sp1hip.h, compiled by the C compiler, has the size and field offsets of its ctypes
+    mirror in sp1_amd/_lib.py (the same check a Rust `#[repr(C)]` binding would need)."""
+    import re
+    import subprocess
+    from sp1_amd import _lib
+    pairs = {"sp1hip_ext_t": _lib.Ext, "sp1hip_tensor_t": _lib.Tensor, "sp1hip_table_t": _lib.Table,
+             "sp1hip_host_table_t": _lib.HostTable, "sp1hip_fri_config_t": _lib.FriConfig, "sp1hip_zc_chip_t": _lib.ZcChip,
+             "sp1hip_gkr_chip_t": _lib.GkrChip, "sp1hip_shard_chip_t": _lib.ShardChip, "sp1hip_shard_params_t": _lib.ShardParams}
+    header = open(os.path.join(ROOT, "include", "sp1hip.h")).read()
+    declared = set(re.findall(r"}\s*(sp1hip_\w+_t)\s*;", header))
+    assert declared == set(pairs), "a struct of the header has no ctypes mirror (or the other way round): %s" % (declared ^ set(pairs))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sp1hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append('return 0; }')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    seen = 0
+    for line in out:
+        if not line:
+            continue
+        cname, field, value = line.split()
+        cls = pairs[cname]
+        want = C.sizeof(cls) if field == "size" else getattr(cls, field).offset
+        assert int(value) == want, (cname, field, value, want)
+        seen += 1
+    assert seen == sum(1 + len(c._fields_) for c in pairs.values())
