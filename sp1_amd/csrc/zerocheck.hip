@@ -859,6 +859,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 partial_cap = (size_t)total_blocks * 24 * 4;
                 SP1HIP_TRY(d_partial.alloc(partial_cap, s));
             }
+            ScopedTimer tm("zerocheck_round", s);      // (the reference's SP1_GPU_ZEROCHECK_ROUND_TIMING switch)
             if (r == 0) SP1HIP_TRY(launch_round<true>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             else SP1HIP_TRY(launch_round<false>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
@@ -922,6 +923,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             c.eq_adj = c.eq_adj * (a_r * last + (kb::ext_one() - a_r) * (kb::ext_one() - last));
         }
         if (!fds.empty()) {
+            ScopedTimer tm("zerocheck_fix", s);
             if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3(fix_blocks), dim3(256), 0, s, d_fix_p, (int)fds.size(), a_r);
             else hipLaunchKernelGGL(zc_fix_kernel<false>, dim3(fix_blocks), dim3(256), 0, s, d_fix_p, (int)fds.size(), a_r);
             SP1HIP_LAUNCH_CHECK();
