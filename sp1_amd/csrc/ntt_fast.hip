@@ -13,9 +13,9 @@
 //  * strided passes read/write 256 B runs (64 adjacent sub-transforms x 4 B); the last pass works
 //    on contiguous runs and is transposed through a padded LDS tile so the lanes still index
 //    independent transforms;
-//  * the inter-pass twiddle w_seg^(i2 k1) is split into a per-workgroup factor (wave-uniform, built
-//    once per workgroup in LDS) and a per-lane factor read from a small cached table with a
-//    coalesced load.
+//  * the inter-pass twiddle w_seg^(i2 k1) comes from a precomputed table laid out like the segment itself (one
+//    coalesced load next to the store; shared by all columns, so it is served by L2 / MALL): one multiplication per
+//    element instead of building the twiddle from a per-workgroup and a per-lane factor (two).
 // VALU work per butterfly is then just the field arithmetic: add (3) and the signed Montgomery product of
 // the difference (7, sub_mul_tw); the radix steps whose base index is 0 skip the multiplications by 1.
 #include <cstdlib>
@@ -155,15 +155,6 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
                 tile[(e >> LG_R) * PITCH + (e & (R - 1))] = p.out[base + e];
         }
     }
-    // per-workgroup inter-pass factor U[k1] = w_seg^(i2_0 * k1), kept behind the tile
-    uint32_t* U = lds + (STRIDED ? R * FT : FT * PITCH);
-    if (STRIDED) {
-        const int sh = kb::TWO_ADICITY - p.lg_seg;
-        for (uint32_t k1 = tid; k1 < (uint32_t)R; k1 += 64 * WAVES) {
-            const uint32_t ex = (i2_0 * k1) << sh;
-            U[k1] = kb::mul(p.tw_hi[ex >> TW_LO_BITS], p.tw_lo[ex & (TW_LO - 1)]);
-        }
-    }
     __syncthreads();
 
     // ---- step 1: radix 2^A over elements i = i_lo + q 2^B (stages LG_R .. B+1), in place in LDS
@@ -187,10 +178,10 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
 #pragma unroll
             for (int q = 0; q < (1 << B); q++) {
                 const uint32_t i = (i_hi << B) + q;
-                const uint32_t k1 = kb::reverse_bits_len(i, LG_R);      // wave-uniform
-                const uint32_t wl = p.tw_lane[k1 * FT + lane];            // coalesced, L2-resident table
-                const uint32_t w = kb::mul(U[k1], wl);
-                p.out[base + ((uint64_t)i << lg_st) + lane] = kb::mul(x[q], w);
+                // inter-pass twiddle w_seg^(i2 * bitrev(i)) from a table laid out like the segment itself (same
+                // coalesced 256 B run as the store; shared by every column, so it lives in L2 / MALL)
+                const uint64_t off = ((uint64_t)i << lg_st) + i2_0 + lane;
+                p.out[base + ((uint64_t)i << lg_st) + lane] = kb::mul(x[q], p.tw_lane[off]);
             }
         } else {
 #pragma unroll
@@ -214,18 +205,21 @@ __global__ void fill_tw_r_kernel(uint32_t* out, int lg_r, const uint32_t* __rest
     out[j] = w;
     out[half + j] = w * kb::MU;      // w p^-1 mod 2^32 for the signed Montgomery product (sub_mul_tw)
 }
-__global__ void fill_tw_lane_kernel(uint32_t* out, int lg_seg, const uint32_t* __restrict__ tw_lo,
+// out[(i << lg_st) + i2] = w_seg^(i2 * bitrev_{lg_r}(i)): the inter-pass twiddle of every element of a segment
+__global__ void fill_tw_lane_kernel(uint32_t* out, int lg_seg, int lg_r, const uint32_t* __restrict__ tw_lo,
                                     const uint32_t* __restrict__ tw_hi) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // [256][64]
-    if (t >= 256u * FT) return;
-    const uint32_t k1 = t >> 6, c = t & 63;
-    const uint32_t e = ((k1 * c) & ((1u << lg_seg) - 1)) << (kb::TWO_ADICITY - lg_seg);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (1u << lg_seg)) return;
+    const int lg_st = lg_seg - lg_r;
+    const uint32_t i = t >> lg_st, i2 = t & ((1u << lg_st) - 1);
+    const uint32_t k1 = kb::reverse_bits_len(i, lg_r);
+    const uint32_t e = (uint32_t)(((uint64_t)i2 * k1) & ((1u << lg_seg) - 1)) << (kb::TWO_ADICITY - lg_seg);
     out[t] = kb::mul(tw_hi[e >> TW_LO_BITS], tw_lo[e & (TW_LO - 1)]);
 }
 
 struct FastTables {
     uint32_t* tw_r[9] = {nullptr};      // index lg_r (6..8)
-    uint32_t* tw_lane[25] = {nullptr};  // index lg_seg
+    uint32_t* tw_lane[25][9] = {{nullptr}};  // index [lg_seg][lg_r]: full inter-pass twiddle table of a segment (2^lg_seg words)
 };
 static std::mutex g_fast_mutex;
 static FastTables* g_fast_tables[64] = {nullptr};
@@ -242,22 +236,22 @@ static int get_fast_tables(const DeviceCtx* ctx, hipStream_t s, int lg_r, int lg
         SP1HIP_LAUNCH_CHECK();
         SP1HIP_HIP(hipStreamSynchronize(s));   // other streams may use the table next
     }
-    if (lg_seg >= 0 && !ft->tw_lane[lg_seg]) {
-        SP1HIP_HIP(hipMalloc((void**)&ft->tw_lane[lg_seg], 256 * FT * 4));
-        hipLaunchKernelGGL(fill_tw_lane_kernel, dim3(64), dim3(256), 0, s, ft->tw_lane[lg_seg], lg_seg, ctx->d_tw_lo,
-                           ctx->d_tw_hi);
+    if (lg_seg >= 0 && !ft->tw_lane[lg_seg][lg_r]) {
+        SP1HIP_HIP(hipMalloc((void**)&ft->tw_lane[lg_seg][lg_r], ((size_t)4) << lg_seg));
+        hipLaunchKernelGGL(fill_tw_lane_kernel, dim3(((1u << lg_seg) + 255) / 256), dim3(256), 0, s, ft->tw_lane[lg_seg][lg_r], lg_seg,
+                           lg_r, ctx->d_tw_lo, ctx->d_tw_hi);
         SP1HIP_LAUNCH_CHECK();
         SP1HIP_HIP(hipStreamSynchronize(s));
     }
     *tw_r = ft->tw_r[lg_r];
-    *tw_lane = lg_seg >= 0 ? ft->tw_lane[lg_seg] : nullptr;
+    *tw_lane = lg_seg >= 0 ? ft->tw_lane[lg_seg][lg_r] : nullptr;
     return SP1HIP_SUCCESS;
 }
 
 template <int A, int B>
 static int launch_pass(FastPassArgs args, bool strided, bool first, bool zero_quarters, uint32_t tiles, uint32_t n_cols, hipStream_t s) {
     constexpr int R = 1 << (A + B);
-    const size_t lds = strided ? ((size_t)R * FT + R) * 4 : ((size_t)FT * (R + 1)) * 4;
+    const size_t lds = strided ? ((size_t)R * FT) * 4 : ((size_t)FT * (R + 1)) * 4;
     dim3 grid(tiles, n_cols);
     using Kern = void (*)(const uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,
                           int, int, int);
