@@ -116,7 +116,11 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is wave-uniform; tell the compiler so (keeps twiddle/table addresses in SGPRs)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t col = blockIdx.y;
+    // strided passes: the COLUMN is the fast grid index, so consecutive workgroups work on the same tile position of
+    // different columns and share that tile's slice of the inter-pass twiddle table in their XCD's L2 (with 8 XCDs
+    // taking workgroups round-robin, every XCD sees n_cols / 8 of them back to back)
+    const uint32_t col = STRIDED ? blockIdx.x : blockIdx.y;
+    const uint32_t tile_idx = STRIDED ? blockIdx.y : blockIdx.x;
     const uint64_t col_off = (uint64_t)col << p.lg_total;
     auto addr = [&](uint32_t i, uint32_t l) -> uint32_t { return STRIDED ? i * FT + l : l * PITCH + i; };
 
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
     const int lg_st = p.lg_seg - LG_R;
     if (STRIDED) {
         const uint32_t tiles_per_seg = 1u << (lg_st - 6);
-        const uint32_t seg = blockIdx.x / tiles_per_seg;
-        i2_0 = (blockIdx.x % tiles_per_seg) << 6;
+        const uint32_t seg = tile_idx / tiles_per_seg;
+        i2_0 = (tile_idx % tiles_per_seg) << 6;
         base = col_off + ((uint64_t)seg << p.lg_seg) + i2_0;
         // global -> LDS: row i is a 256 B run
         if (FIRST) {
@@ -143,11 +147,11 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fast_pass(const uint32_t* __re
         }
     } else {
         // 64 consecutive runs of R words; run `l` goes to LDS row l (pitch R + 1)
-        base = col_off + ((uint64_t)blockIdx.x << (LG_R + 6));
+        base = col_off + ((uint64_t)tile_idx << (LG_R + 6));
         if (FIRST) {
             const uint32_t n_in = 1u << p.lg_n_in;
             const uint32_t* src = p.in + ((uint64_t)col << p.lg_n_in);
-            const uint64_t off = (uint64_t)blockIdx.x << (LG_R + 6);
+            const uint64_t off = (uint64_t)tile_idx << (LG_R + 6);
             for (uint32_t e = tid; e < (uint32_t)R * FT; e += 64 * WAVES)
                 tile[(e >> LG_R) * PITCH + (e & (R - 1))] = (off + e) < n_in ? src[off + e] : 0u;
         } else {
@@ -252,7 +256,7 @@ template <int A, int B>
 static int launch_pass(FastPassArgs args, bool strided, bool first, bool zero_quarters, uint32_t tiles, uint32_t n_cols, hipStream_t s) {
     constexpr int R = 1 << (A + B);
     const size_t lds = strided ? ((size_t)R * FT) * 4 : ((size_t)FT * (R + 1)) * 4;
-    dim3 grid(tiles, n_cols);
+    const dim3 grid = strided ? dim3(n_cols, tiles) : dim3(tiles, n_cols);
     using Kern = void (*)(const uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,
                           int, int, int);
     constexpr int WAVES = (A + B == 8) ? 8 : 4;
