@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void fold_even_odd_kernel(const uint32_t* __re
     const uint32_t inv2 = 0x00ffffffu;   // to_monty(1/2) = R1 / 2 (R1 = 2^25 - 2 is even)
     kb::Ext s = kb::ext_mul_base(kb::ext_add(e0, e1), inv2);
     kb::Ext d = kb::ext_mul_base(kb::ext_sub(e0, e1), xinv);
-    kb::Ext r = kb::ext_add(s, kb::ext_mul(E(half_beta), d));
+    kb::Ext r = kb::ext_add(s, kb::ext_mul(d, E(half_beta)));      // the challenge is wave-uniform: second operand
 #pragma unroll
     for (int k = 0; k < 4; k++) out[(size_t)k * m + i] = r.c[k];
 }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void fold_mle_kernel(const uint32_t* __restric
         a.c[k] = v.x;
         b.c[k] = v.y;
     }
-    kb::Ext r = kb::ext_add(a, kb::ext_mul(E(beta), b));
+    kb::Ext r = kb::ext_add(a, kb::ext_mul(b, E(beta)));
 #pragma unroll
     for (int k = 0; k < 4; k++) out[(size_t)k * m + i] = r.c[k];
 }

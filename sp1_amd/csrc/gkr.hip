@@ -233,15 +233,15 @@ __device__ __forceinline__ Quad load_quad(const RoundDesc& d, uint32_t r) {
     return q;
 }
 
-__device__ __forceinline__ Ext lerp(const Ext& a, const Ext& b, const Ext& t) { return kb::ext_add(a, kb::ext_mul(t, kb::ext_sub(b, a))); }
+__device__ __forceinline__ Ext lerp(const Ext& a, const Ext& b, const Ext& t) { return kb::ext_add(a, kb::ext_mul(kb::ext_sub(b, a), t)); }   // t: the round's challenge (wave-uniform, second)
 
 // accumulate the three sums of one row pair (a = row 2k, b = row 2k+1) weighted by w = eq_int: S0 += w T[2k] F(a),
 // Sh += w (T[2k] + T[2k+1]) Fh(a + b), Seq += w (T[2k] + T[2k+1])
 __device__ __forceinline__ void accumulate_pair(const Quad& a, const Quad& b, const Ext& lambda, const Ext& ta, const Ext& tb,
                                                 Ext (&acc)[3]) {
-    const Ext f0 = kb::ext_add(kb::ext_mul(lambda, kb::ext_add(kb::ext_mul(a.n0, a.d1), kb::ext_mul(a.n1, a.d0))), kb::ext_mul(a.d0, a.d1));
+    const Ext f0 = kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(a.n0, a.d1), kb::ext_mul(a.n1, a.d0)), lambda), kb::ext_mul(a.d0, a.d1));
     const Ext sn0 = kb::ext_add(a.n0, b.n0), sn1 = kb::ext_add(a.n1, b.n1), sd0 = kb::ext_add(a.d0, b.d0), sd1 = kb::ext_add(a.d1, b.d1);
-    const Ext fh = kb::ext_add(kb::ext_mul(lambda, kb::ext_add(kb::ext_mul(sn0, sd1), kb::ext_mul(sn1, sd0))), kb::ext_mul(sd0, sd1));
+    const Ext fh = kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(sn0, sd1), kb::ext_mul(sn1, sd0)), lambda), kb::ext_mul(sd0, sd1));
     const Ext ts = kb::ext_add(ta, tb);
     acc[0] = kb::ext_add(acc[0], kb::ext_mul(ta, f0));
     acc[1] = kb::ext_add(acc[1], kb::ext_mul(ts, fh));

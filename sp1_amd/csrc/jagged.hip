@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void jg_round0_tables(const JgTab* __restrict_
 }
 
 __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& alpha) {   // a + alpha (b - a)
-    return kb::ext_add(a, kb::ext_mul(alpha, kb::ext_sub(b, a)));
+    return kb::ext_add(a, kb::ext_mul(kb::ext_sub(b, a), alpha));      // alpha: wave-uniform, second
 }
 
 // ---- first fold(s), table-major form (J stays factored). LEVELS = 1 (heights % 4 == 0): a lane owns the level-1 row
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void jg_fold_tables(const JgTab* __restrict__ 
                 const uint4 v2 = *reinterpret_cast<const uint4*>(col + 4);
                 const Ext l2 = kb::ext_add(kb::ext_from_base(v2.x), kb::ext_mul_base(alpha0, kb::sub(v2.y, v2.x)));
                 const Ext l3 = kb::ext_add(kb::ext_from_base(v2.z), kb::ext_mul_base(alpha0, kb::sub(v2.w, v2.z)));
-                qa = kb::ext_add(l0, kb::ext_mul(alpha1, kb::ext_sub(l1, l0)));
-                qb = kb::ext_add(l2, kb::ext_mul(alpha1, kb::ext_sub(l3, l2)));
+                qa = kb::ext_add(l0, kb::ext_mul(kb::ext_sub(l1, l0), alpha1));
+                qb = kb::ext_add(l2, kb::ext_mul(kb::ext_sub(l3, l2), alpha1));
             }
             if (STORE) { st_ext(out, 0, qa); st_ext(out, 1, qb); }
             const Ext w = ld_ext(Jl.col_eq, t.col0 + c), w3 = ld_ext(col_eq3, t.col0 + c);     // wave-uniform
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void jg_fold0_sum(JgSegs S, JgJ J, Ext alpha, 
                     const uint32_t qa = jg_q(S, x0 + 2 * h), qb = jg_q(S, x0 + 2 * h + 1);
                     qo[h] = kb::ext_add(kb::ext_from_base(qa), kb::ext_mul_base(alpha, kb::sub(qb, qa)));
                     const Ext ra = jg_row_eq(J, row + 2 * h), rb = jg_row_eq(J, row + 2 * h + 1);
-                    jo[h] = kb::ext_mul(w, kb::ext_add(ra, kb::ext_mul(alpha, kb::ext_sub(rb, ra))));
+                    jo[h] = kb::ext_mul(w, kb::ext_add(ra, kb::ext_mul(kb::ext_sub(rb, ra), alpha)));
                 }
             } else {                                          // column boundary or the zero tail: element by element
                 uint32_t q[4];

@@ -80,7 +80,7 @@ template <> struct KT<false> {
     static __device__ __forceinline__ T add(const T& a, const T& b) { return kb::ext_add(a, b); }
     static __device__ __forceinline__ T sub(const T& a, const T& b) { return kb::ext_sub(a, b); }
     static __device__ __forceinline__ T mul(const T& a, const T& b) { return kb::ext_mul(a, b); }
-    static __device__ __forceinline__ kb::Ext scale(const kb::Ext& e, const T& k) { return kb::ext_mul(e, k); }
+    static __device__ __forceinline__ kb::Ext scale(const kb::Ext& e, const T& k) { return kb::ext_mul(k, e); }   // e is wave-uniform
     static __device__ __forceinline__ kb::Ext to_ext(const T& k) { return k; }
     static __device__ __forceinline__ T load(const uint32_t* tbl, uint32_t col, uint32_t rows, uint32_t r) {
         T v;
