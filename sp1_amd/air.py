@@ -48,11 +48,21 @@ class Expr:
 
 
 class AirProgram:
-    def __init__(self, name, main_width, prep_width=0):
+    def __init__(self, name, main_width, prep_width=0, cse=False):
+        """cse=True hash-conses the instructions (a repeated load / constant / operation reuses the earlier value,
+        ADD and MUL are commutative) — what a recording builder does for the wide chips (Poseidon2: thousands of
+        repeated sub-expressions); the value of every constraint is unchanged."""
         self.name, self.main_width, self.prep_width = name, main_width, prep_width
         self.instrs, self.num_constraints = [], 0
+        self._seen = {} if cse else None
 
     def _emit(self, op, a, b):
+        if self._seen is not None and op != ASSERT_ZERO:
+            key = (op, min(a, b), max(a, b)) if op in (ADD, MUL) else (op, a, b)
+            k = self._seen.get(key)
+            if k is not None:
+                return Expr(self, k)
+            self._seen[key] = len(self.instrs)
         self.instrs.append((op, a, b))
         return Expr(self, len(self.instrs) - 1)
 

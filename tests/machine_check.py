@@ -1,0 +1,67 @@
+"""Row-by-row checks of a machine description against concrete tables (numpy, canonical integers): every constraint
+program evaluates to zero on every real row, and the interactions balance as a multiset (LogUp's claim). Independent
+of both provers: it is how the trace generator and the hand transcription of the recursion machine are cross-checked
+before any proof is made."""
+import numpy as np
+
+from sp1_amd.air import ADD, ASSERT_ZERO, CONST, LOAD_MAIN, LOAD_PREP, MUL, NEG, PUBLIC, SUB
+
+P = 0x7F000001
+U = np.uint64
+PP = U(P)
+R_INV = pow(1 << 32, -1, P)
+
+
+def from_monty(x):
+    return (np.asarray(x, dtype=U) * U(R_INV)) % PP
+
+
+def constraint_values(air, prep, main, publics):
+    """prep/main: canonical [rows, w] uint64; returns [rows, num_constraints] canonical."""
+    rows = main.shape[0]
+    vals, out = [], []
+    for op, a, b in air.instrs:
+        if op == LOAD_MAIN:
+            v = main[:, a]
+        elif op == LOAD_PREP:
+            v = prep[:, a]
+        elif op == CONST:
+            v = np.full(rows, a, dtype=U)
+        elif op == PUBLIC:
+            v = np.full(rows, int(publics[a]), dtype=U)
+        elif op == ADD:
+            v = (vals[a] + vals[b]) % PP
+        elif op == SUB:
+            v = (vals[a] + PP - vals[b]) % PP
+        elif op == MUL:
+            v = (vals[a] * vals[b]) % PP
+        elif op == NEG:
+            v = (PP - vals[a]) % PP
+        elif op == ASSERT_ZERO:
+            out.append(vals[a])
+            v = None
+        vals.append(v)
+    return np.stack(out, axis=1) if out else np.zeros((rows, 0), dtype=U)
+
+
+def _vcol(v, prep, main):
+    acc = np.full(main.shape[0], v.constant, dtype=U)
+    for kind, col, w in v.terms:
+        acc = (acc + (main if kind == "main" else prep)[:, col] * U(w)) % PP
+    return acc
+
+
+def bus_imbalance(chips):
+    """chips: [(InteractionProgram, prep canonical, main canonical)]. Returns the messages whose signed multiplicity
+    sum is non-zero mod p (empty dict = balanced)."""
+    tally = {}
+    for it, prep, main in chips:
+        for sign, lst in ((1, it.sends), (-1, it.receives)):
+            for kind, values, mult in lst:
+                m = _vcol(mult, prep, main)
+                cols = np.stack([_vcol(v, prep, main) for v in values], axis=1)
+                live = np.nonzero(m)[0]
+                for r in live:
+                    key = (kind,) + tuple(int(x) for x in cols[r])
+                    tally[key] = (tally.get(key, 0) + sign * int(m[r])) % P
+    return {k: v for k, v in tally.items() if v}

@@ -1,0 +1,84 @@
+"""GPU parity (-m gpu) on the REAL machine: `sp1hip_prove_shard` proves satisfying traces of the reference's recursion
+compress machine (sp1_amd/machines/recursion.py — the transcription that the reference's own ShardProof pins in
+tests/test_recursion_machine.py): bytes equal the oracle prover's, and the oracle's full verify_shard (zerocheck closing
+equation + LogUp-GKR interaction check with the real chips) accepts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import pyoracle as orc  # noqa: E402
+from sp1_amd.machines import recursion as R, recursion_trace as RT  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def api():
+    from sp1_amd import api as a
+    torch.cuda.set_device(0)
+    return a
+
+
+def _shapes_only(machine):
+    return [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
+            for a, i in machine]
+
+
+def _device_chips(api, machine, tabs):
+    return [(a, i, api.ColMajor.from_row_major_host(tabs[a.name][1]), api.ColMajor.from_row_major_host(tabs[a.name][0]))
+            for a, i in machine]
+
+
+@pytest.mark.parametrize("counts,seed,L,lsh,batch", [
+    ({"BaseAlu": 70, "ExtAlu": 90, "MemoryConst": 50, "MemoryVar": 40, "Poseidon2WideDeg3": 20, "PrefixSumChecks": 33, "Select": 100},
+     1, 8, 7, 4),
+    ({"BaseAlu": 600, "ExtAlu": 800, "MemoryConst": 500, "MemoryVar": 650, "Poseidon2WideDeg3": 150, "PrefixSumChecks": 220,
+      "Select": 1100}, 2, 11, 9, 32),
+])
+def test_recursion_shard_proof_matches_oracle(api, counts, seed, L, lsh, batch):
+    LB, NQ, PW = 1, 5, 4
+    tabs, pv = RT.generate(counts, seed=seed)
+    m = R.compress_machine()
+    chips = [(a, i, tabs[a.name][1], tabs[a.name][0]) for a, i in m]
+    o_prep = orc.JaggedRound([c[3] for c in chips], L, lsh, batch, LB)
+    jp = api.JaggedProver(L, lsh, batch, LB)
+    dev = _device_chips(api, m, tabs)
+    g_commit, g_prep = jp.commit_multilinears([d[3] for d in dev])
+    assert np.array_equal(g_commit, o_prep.commit)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    o_ch.observe(o_prep.commit)
+    g_ch.observe(g_commit)
+    v_ch = o_ch.clone()
+    want = orc.shard_prove(chips, pv, o_prep, L, lsh, batch, o_ch, LB, NQ, PW)
+    got = api.prove_shard(dev, pv, g_prep, L, lsh, batch, g_ch, LB, NQ, PW)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+    assert orc.shard_verify(_shapes_only(m), g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
+
+
+def test_recursion_shard_at_a_sixteenth_of_the_reference_shape_verifies(api):
+    """Production parameters (blowup 4, 124 queries, 16-bit PoW, stacking height as in the recursion prover scaled with
+    the shape): 1/16 of the table heights of the reference's real compress proof (5.6e6 cells). The succinct verifier —
+    the one that accepts that real proof with these same chip programs — accepts the GPU proof."""
+    counts = {k: max(v // 16, 8) for k, v in RT.REFERENCE_COMPRESS_HEIGHTS.items()}
+    tabs, pv = RT.generate(counts, seed=11)
+    m = R.compress_machine()
+    L, lsh = 17, 16
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    dev = _device_chips(api, m, tabs)
+    commit, prep = jp.commit_multilinears([d[3] for d in dev])
+    ch, v = api.DuplexChallenger(), orc.Challenger()
+    ch.observe(commit)
+    v.observe(commit)
+    proof = api.prove_shard(dev, pv, prep, L, lsh, 32, ch)
+    assert orc.shard_verify(_shapes_only(m), commit, proof, L, lsh, v, 2, 124, 16) == 0
+    assert np.array_equal(v.state(), ch.state())
+    # a proof of a trace with one wrong Poseidon2 cell is rejected
+    bad = tabs["Poseidon2WideDeg3"][1].copy()
+    bad[77, 140] ^= 1
+    dev2 = [(a, i, api.ColMajor.from_row_major_host(bad) if a.name == "Poseidon2WideDeg3" else mm, p) for a, i, mm, p in dev]
+    ch, v = api.DuplexChallenger(), orc.Challenger()
+    ch.observe(commit)
+    v.observe(commit)
+    proof = api.prove_shard(dev2, pv, prep, L, lsh, 32, ch)
+    assert orc.shard_verify(_shapes_only(m), commit, proof, L, lsh, v, 2, 124, 16) != 0
