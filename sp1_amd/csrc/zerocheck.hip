@@ -28,84 +28,9 @@
 
 #include "device_ctx.hpp"
 #include "round_sync.hpp"
+#include "zc_device.hpp"
 
 namespace sp1hip {
-
-enum ZcOp : uint32_t { ZC_LOAD_MAIN = 0, ZC_LOAD_PREP = 1, ZC_CONST = 2, ZC_PUBLIC = 3, ZC_ADD = 4, ZC_SUB = 5, ZC_MUL = 6,
-                       ZC_NEG = 7, ZC_ASSERT_ZERO = 8 };
-
-// One chip of the current round (device array; every field is wave-uniform in the kernels).
-struct ZcDesc {
-    const uint32_t* prog;        // [n_instr][4]: op | flags, dst, a, b (register-allocated)
-    const uint32_t* main;        // column-major; round 0: [rows x main_w] base words, later [rows x 4 main_w]
-    const uint32_t* prep;
-    const uint32_t* alpha_pows;  // [num_constraints][4]
-    const uint32_t* gkr_pows;    // [main_w + prep_w][4]
-    uint32_t n_instr, main_w, prep_w, rows;
-    uint32_t block_start, n_blocks;
-    uint32_t alpha_off;          // index of this chunk's first constraint in alpha_pows
-    uint32_t flags;              // bit 0: first chunk of its chip (owns the round-0 GKR-only pass)
-};
-
-// Blocks of one chip (all its chunks are contiguous) for the reduction, plus the eq entry it needs.
-struct ZcChipRange {
-    uint32_t block_start, n_blocks, th, pad;
-};
-
-struct ZcFixDesc {
-    const uint32_t* in;
-    uint32_t* out;
-    uint32_t rows, width, block_start, n_blocks;
-};
-
-// ---- K = base word (round 0) or extension element (later rounds)
-template <bool FIRST> struct KT;
-template <> struct KT<true> {
-    using T = uint32_t;
-    static __device__ __forceinline__ T zero() { return 0u; }
-    static __device__ __forceinline__ T from_f(uint32_t x) { return x; }
-    static __device__ __forceinline__ T add(T a, T b) { return kb::add(a, b); }
-    static __device__ __forceinline__ T sub(T a, T b) { return kb::sub(a, b); }
-    static __device__ __forceinline__ T mul(T a, T b) { return kb::mul(a, b); }
-    static __device__ __forceinline__ kb::Ext scale(const kb::Ext& e, T k) { return kb::ext_mul_base(e, k); }
-    static __device__ __forceinline__ kb::Ext to_ext(T k) { return kb::ext_from_base(k); }
-    static __device__ __forceinline__ T load(const uint32_t* tbl, uint32_t col, uint32_t rows, uint32_t r) {
-        return tbl[(size_t)col * rows + r];
-    }
-};
-template <> struct KT<false> {
-    using T = kb::Ext;
-    static __device__ __forceinline__ T zero() { return kb::ext_zero(); }
-    static __device__ __forceinline__ T from_f(uint32_t x) { return kb::ext_from_base(x); }
-    static __device__ __forceinline__ T add(const T& a, const T& b) { return kb::ext_add(a, b); }
-    static __device__ __forceinline__ T sub(const T& a, const T& b) { return kb::ext_sub(a, b); }
-    static __device__ __forceinline__ T mul(const T& a, const T& b) { return kb::ext_mul(a, b); }
-    static __device__ __forceinline__ kb::Ext scale(const kb::Ext& e, const T& k) { return kb::ext_mul(k, e); }   // e is wave-uniform
-    static __device__ __forceinline__ kb::Ext to_ext(const T& k) { return k; }
-    static __device__ __forceinline__ T load(const uint32_t* tbl, uint32_t col, uint32_t rows, uint32_t r) {
-        T v;
-#pragma unroll
-        for (int k = 0; k < 4; k++) v.c[k] = tbl[((size_t)col * 4 + k) * rows + r];
-        return v;
-    }
-};
-
-__device__ __forceinline__ kb::Ext load_ext_aos(const uint32_t* p, uint32_t i) {
-    return kb::Ext{{p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]}};
-}
-
-// value of column `col` at node t in {0, 2, 4} for row pair i
-template <bool FIRST>
-__device__ __forceinline__ typename KT<FIRST>::T leaf(const uint32_t* tbl, uint32_t col, uint32_t rows, uint32_t i, int t) {
-    using K = KT<FIRST>;
-    typename K::T r0 = K::load(tbl, col, rows, 2 * i);
-    if (t == 0) return r0;
-    typename K::T r1 = (2 * i + 1 < rows) ? K::load(tbl, col, rows, 2 * i + 1) : K::zero();
-    typename K::T slope = K::sub(r1, r0);
-    typename K::T s2 = K::add(slope, slope);
-    if (t == 2) return K::add(s2, r0);
-    return K::add(K::add(s2, s2), r0);
-}
 
 // ---- register files ------------------------------------------------------------------------------
 // The program is wave-uniform, so register numbers are SGPR values. For up to 32 registers the file is
@@ -140,70 +65,114 @@ SP1HIP_VREGFILE(32, v32u)
 // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off triple per word — ~36 instructions of pure register traffic around a
 // 12-instruction extension add; the LDS file makes an interpreted op cost its arithmetic plus three LDS accesses,
 // and leaves the VGPRs to the arithmetic (measured per-op cost: add 75 -> ~20 instructions, multiply 147 -> ~100).
+// The slot stride is the workgroup size: programs with many live values run in narrower workgroups (128 / 64 lanes) so
+// that the file still fits the LDS budget (launch_round).
+// (pointers carry the LDS address space explicitly: a generic pointer here turns every access into a FLAT instruction)
+typedef uint32_t zc_lds_word_t __attribute__((address_space(3)));
+typedef uint32_t zc_lds_quad_t __attribute__((ext_vector_type(4), address_space(3)));
+typedef uint32_t zc_quad_t __attribute__((ext_vector_type(4)));
 template <> struct RegFile<true, 0> {
-    uint32_t* base;                // this lane's slot of register 0
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i * 256u]; }
-    __device__ __forceinline__ void set(uint32_t i, uint32_t v) { base[i * 256u] = v; }
+    zc_lds_word_t* base;           // this lane's slot of register 0
+    uint32_t stride;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i * stride]; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) { base[i * stride] = v; }
 };
 template <> struct RegFile<false, 0> {
-    uint4* base;
-    __device__ __forceinline__ kb::Ext get(uint32_t i) const { const uint4 v = base[i * 256u]; return kb::Ext{{v.x, v.y, v.z, v.w}}; }
-    __device__ __forceinline__ void set(uint32_t i, const kb::Ext& v) { base[i * 256u] = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]); }
+    zc_lds_quad_t* base;
+    uint32_t stride;
+    __device__ __forceinline__ kb::Ext get(uint32_t i) const { const zc_quad_t v = base[i * stride]; return kb::Ext{{v.x, v.y, v.z, v.w}}; }
+    __device__ __forceinline__ void set(uint32_t i, const kb::Ext& v) { zc_quad_t q = {v.c[0], v.c[1], v.c[2], v.c[3]}; base[i * stride] = q; }
 };
 
-constexpr uint32_t ZC_GKR_FLAG = 0x100u;   // set by the host on the first load of each column
+constexpr uint32_t ZC_GKR_FLAG = 0x100u;   // bits 8..11: column j of this load is the first load of that column (host)
+constexpr uint32_t ZC_A_PREV = 0x1000u, ZC_B_PREV = 0x2000u;   // operand = the value the previous instruction produced
+constexpr uint32_t ZC_DST_TEMP = 0x4000u;  // the result is only forwarded, never stored in the register file
+                                           // bits 16..17: (number of consecutive columns of a LOAD) - 1
 constexpr uint32_t ZC_TOUCH = 9;           // pseudo-op: column never loaded by the constraints (GKR term only)
+// internal forms with an immediate operand (host peephole `fold_immediates`: an ADD / SUB / MUL one of whose operands is
+// a CONST): the constant travels in the instruction word — no register, no LDS access, and in the extension rounds a
+// constant factor is 4 base products instead of a full 16-product extension multiply
+constexpr uint32_t ZC_ADDC = 10, ZC_SUBC = 11, ZC_CSUB = 12, ZC_MULC = 13;
+constexpr uint32_t ZC_MONO_MIN_TERMS = 1024; // rounds with at least this many row pairs run a chip's program in ONE piece
 constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
 constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB); longer programs read global memory
+
+typedef uint32_t zc_word_t __attribute__((ext_vector_type(4)));       // one instruction: op | flags, dst, a, b
+typedef const zc_word_t __attribute__((address_space(4)))* zc_const_prog_t;
 
 // One pass of the program at node t. With `gkr`, the first load of every column also accumulates
 // gkr_pow[column] * value into *g (main columns first, then preprocessed): the batching term costs no
 // extra loads. `prog` points to LDS (or global memory for very long programs).
-template <bool FIRST, int MAXR>
-__device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, const uint4* prog, const ZcDesc& d,
+template <bool FIRST, int MAXR, typename PROG>
+__device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG prog, const ZcDesc& d,
                                                const uint32_t* __restrict__ publics, uint32_t i, int t, const bool gkr, kb::Ext* g) {
     using K = KT<FIRST>;
+    using T = typename K::T;
     kb::Ext acc = kb::ext_zero();
     uint32_t ci = 0;
+    T prev = K::zero();                   // the value the last value-producing instruction produced (operand forwarding)
+    auto next = prog[0];                  // instruction words are fetched one instruction ahead of their use
     for (uint32_t k = 0; k < d.n_instr; k++) {
-        const uint4 w = prog[k];     // wave-uniform: decode once, keep the fields in SGPRs
+        const auto w = next;              // wave-uniform: decode once, keep the fields in SGPRs
+        if (k + 1 < d.n_instr) next = prog[k + 1];
         const uint32_t opw = __builtin_amdgcn_readfirstlane(w.x), dst = __builtin_amdgcn_readfirstlane(w.y);
         const uint32_t x = __builtin_amdgcn_readfirstlane(w.z), y = __builtin_amdgcn_readfirstlane(w.w);
-        switch (opw & 0xffu) {
-            case ZC_LOAD_MAIN: {
-                typename K::T v = leaf<FIRST>(d.main, x, d.rows, i, t);
-                if (gkr && (opw & ZC_GKR_FLAG)) *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, x), v));
-                reg.set(dst, v);
-                break;
-            }
-            case ZC_LOAD_PREP: {
-                typename K::T v = leaf<FIRST>(d.prep, x, d.rows, i, t);
-                if (gkr && (opw & ZC_GKR_FLAG)) *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, d.main_w + x), v));
-                reg.set(dst, v);
-                break;
-            }
-            case ZC_TOUCH:
-                if (gkr) {
-                    typename K::T v = leaf<FIRST>(y ? d.prep : d.main, x, d.rows, i, t);
-                    *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, (y ? d.main_w : 0u) + x), v));
+        const uint32_t op = opw & 0xffu;
+        if (op <= ZC_LOAD_PREP) {         // 1..4 consecutive columns: every global load is in flight before the first use
+            const uint32_t cnt = ((opw >> 16) & 3u) + 1;
+            const uint32_t* tbl = op == ZC_LOAD_MAIN ? d.main : d.prep;
+            const uint32_t gbase = op == ZC_LOAD_MAIN ? 0u : d.main_w;
+            T r0[4], r1[4];
+            const bool odd = 2 * i + 1 < d.rows;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (j < cnt) {
+                    r0[j] = K::load(tbl, x + j, d.rows, 2 * i);
+                    r1[j] = (t != 0 && odd) ? K::load(tbl, x + j, d.rows, 2 * i + 1) : K::zero();
                 }
-                break;
-            case ZC_CONST: reg.set(dst, K::from_f(x)); break;               // host pre-converts to Montgomery
-            case ZC_PUBLIC: reg.set(dst, K::from_f(publics[x])); break;
-            case ZC_ADD: reg.set(dst, K::add(reg.get(x), reg.get(y))); break;
-            case ZC_SUB: reg.set(dst, K::sub(reg.get(x), reg.get(y))); break;
-            case ZC_MUL: reg.set(dst, K::mul(reg.get(x), reg.get(y))); break;
-            case ZC_NEG: reg.set(dst, K::sub(K::zero(), reg.get(x))); break;
-            default: acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + ci++), reg.get(x))); break;  // ASSERT_ZERO
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (j < cnt) {
+                    T v = r0[j];
+                    if (t != 0) {
+                        const T s2 = K::add(K::sub(r1[j], r0[j]), K::sub(r1[j], r0[j]));
+                        v = t == 2 ? K::add(s2, r0[j]) : K::add(K::add(s2, s2), r0[j]);
+                    }
+                    if (gkr && (opw & (ZC_GKR_FLAG << j))) *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, gbase + x + j), v));
+                    if (!(opw & ZC_DST_TEMP)) reg.set(dst + j, v);
+                    prev = v;
+                }
+            continue;
         }
+        if (op == ZC_TOUCH) {
+            if (gkr) {
+                T v = leaf<FIRST>(y ? d.prep : d.main, x, d.rows, i, t);
+                *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, (y ? d.main_w : 0u) + x), v));
+            }
+            continue;
+        }
+        T a = prev, b = prev, res;
+        if (op >= ZC_ADD && !(opw & ZC_A_PREV)) a = reg.get(x);
+        if (op >= ZC_ADD && op <= ZC_MUL && !(opw & ZC_B_PREV)) b = reg.get(y);
+        switch (op) {
+            case ZC_CONST: res = K::from_f(x); break;               // host pre-converts to Montgomery
+            case ZC_PUBLIC: res = K::from_f(publics[x]); break;
+            case ZC_ADD: res = K::add(a, b); break;
+            case ZC_SUB: res = K::sub(a, b); break;
+            case ZC_MUL: res = K::mul(a, b); break;
+            case ZC_NEG: res = K::sub(K::zero(), a); break;
+            case ZC_ADDC: res = KC<FIRST>::addc(a, y); break;
+            case ZC_SUBC: res = KC<FIRST>::subc(a, y); break;
+            case ZC_CSUB: res = KC<FIRST>::csub(y, a); break;
+            case ZC_MULC: res = KC<FIRST>::mulc(a, y); break;
+            default:                                                  // ASSERT_ZERO
+                acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + ci++), a));
+                continue;
+        }
+        prev = res;
+        if (!(opw & ZC_DST_TEMP)) reg.set(dst, res);
     }
     return acc;
-}
-
-__device__ __forceinline__ uint32_t zc_wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = kb::add(v, __shfl_xor(v, off));
-    return v;
 }
 
 // last descriptor whose block_start <= bid (binary search; everything stays wave-uniform)
@@ -224,32 +193,41 @@ __device__ __forceinline__ ZcDesc zc_find_desc(const ZcDesc* __restrict__ descs,
 //   later   :  p=0: A = sum eq C(0), B = sum eq g(0)    p=1: A = sum eq C(2), B = sum eq g(2)    p=2: A = sum eq C(4)
 // g(4) = 2 g(2) - g(0) is linear, so the three nodes can run in different workgroups and the late, tiny
 // rounds (latency-bound: one wave interprets the whole program serially) run all chips and nodes at once.
-template <bool FIRST, int MAXR>
+// STAGED: the program is copied to LDS once per workgroup (short chunked programs); otherwise every wave streams it
+// from global memory through the scalar cache (constant address space: wave-uniform s_load_dwordx4), which leaves the
+// whole LDS budget to the register file — the form used for a chip's undivided program in the large rounds.
+
+template <bool FIRST, int MAXR, bool STAGED>
 __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict__ descs, int n_descs,
                                                        const uint32_t* __restrict__ eq, uint32_t eq_len,
                                                        const uint32_t* __restrict__ publics, uint32_t* __restrict__ partial,
-                                                       uint32_t rf_off) {
+                                                       uint32_t rf_off, uint32_t block_base) {
     using K = KT<FIRST>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* red = lds;                                   // [4][8] reduction scratch
     uint4* lprog = reinterpret_cast<uint4*>(lds + 32);
     RegFile<FIRST, MAXR> reg;
-    if constexpr (MAXR == 0) reg.base = reinterpret_cast<decltype(reg.base)>(lds + rf_off) + threadIdx.x;   // LDS file behind the program
+    if constexpr (MAXR == 0) {                             // LDS file behind the (staged) program
+        reg.base = (decltype(reg.base))(lds + rf_off) + threadIdx.x;
+        reg.stride = blockDim.x;
+    }
+    if (threadIdx.x < 32) red[threadIdx.x] = 0;            // workgroups narrower than 4 waves leave slots untouched
     // the three nodes of one block of row pairs are CONSECUTIVE workgroups: they are dispatched together (to
     // different XCDs), so the second and third read of the same table rows hit the memory-side cache instead of HBM
-    const uint32_t bid = blockIdx.x / 3u;
-    const int pass = (int)(blockIdx.x - 3u * bid);
+    const uint32_t bid = block_base + blockIdx.x / 3u;
+    const int pass = (int)(blockIdx.x % 3u);
     const ZcDesc d = zc_find_desc(descs, n_descs, bid);
-    const bool in_lds = d.n_instr <= ZC_LDS_PROG_MAX;
-    if (in_lds) {
+    if constexpr (STAGED) {
         const uint4* src = reinterpret_cast<const uint4*>(d.prog);
-        for (uint32_t k = threadIdx.x; k < d.n_instr; k += 256) lprog[k] = src[k];
-        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < d.n_instr; k += blockDim.x) lprog[k] = src[k];
     }
-    const uint4* prog = in_lds ? lprog : reinterpret_cast<const uint4*>(d.prog);
+    __syncthreads();
     const uint32_t terms = (d.rows + 1) / 2;
     kb::Ext sa = kb::ext_zero(), sb = kb::ext_zero();
-    for (uint32_t i = (bid - d.block_start) * 256u + threadIdx.x; i < terms; i += d.n_blocks * 256u) {
+    // a block is d.block_pairs row pairs (= the workgroup width of the chip's launch group: one pass of the program
+    // per workgroup while the round is large; the partial-sum layout only knows blocks)
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < terms; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, terms); i += blockDim.x) {
         kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
         if (FIRST && pass == 0) {
             if (d.flags & 1u)
@@ -264,8 +242,10 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
                 va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 0)));
                 vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 2)));
             }
+        } else if constexpr (STAGED) {
+            va = run_program<FIRST, MAXR>(reg, (const zc_word_t*)lprog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
         } else {
-            va = run_program<FIRST, MAXR>(reg, prog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
+            va = run_program<FIRST, MAXR>(reg, (zc_const_prog_t)(uintptr_t)d.prog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
         }
         kb::Ext e;
 #pragma unroll
@@ -438,8 +418,10 @@ struct ChipState {
     std::vector<uint32_t> prog;     // allocated [n][4]
     uint32_t n_regs = 1;
     std::vector<Ext> alpha_pows, gkr_pows;
-    std::vector<Chunk> chunks;
+    std::vector<Chunk> chunks;         // split at assert boundaries (parallel across constraints: the small rounds)
     std::vector<uint32_t> chunk_off;   // offset (in instructions) of each chunk inside d_prog
+    std::vector<Chunk> mono;           // the undivided program (+ a TOUCH chunk): no recomputation (the large rounds)
+    std::vector<uint32_t> mono_off;
     size_t off_prog = 0, off_alpha = 0, off_gkr = 0;     // word offsets into the call's single constant blob
     const uint32_t* p_prog = nullptr;
     const uint32_t* p_alpha = nullptr;
@@ -455,45 +437,122 @@ struct ChipState {
 };
 
 // linear-scan register allocation of the SSA program (host)
-static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint32_t>* out, uint32_t* n_regs) {
-    std::vector<int> last_use(n, -1);
+static inline bool zc_is_imm(uint32_t op) { return op >= ZC_ADDC && op <= ZC_MULC; }
+
+// ADD / SUB / MUL with a CONST operand -> the immediate forms (same instruction indices; the CONST instructions stay
+// behind and drop out when the chunks collect the cones of the asserts).
+static void fold_immediates(const uint32_t* ssa, uint32_t n, std::vector<uint32_t>* out) {
+    out->assign(ssa, ssa + (size_t)n * 3);
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t op = ssa[3 * k], a = ssa[3 * k + 1], b = ssa[3 * k + 2];
-        SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO, "bad opcode in constraint program");
-        if (op == ZC_ADD || op == ZC_SUB || op == ZC_MUL) {
+        if (op != ZC_ADD && op != ZC_SUB && op != ZC_MUL) continue;
+        const bool ca = ssa[3 * a] == ZC_CONST, cb = ssa[3 * b] == ZC_CONST;
+        if (ca == cb) continue;                                 // none (or both: left to the generic path)
+        uint32_t* o = out->data() + 3 * (size_t)k;
+        const uint32_t var = ca ? b : a, c = ssa[3 * (ca ? a : b) + 1];
+        o[1] = var; o[2] = c;
+        o[0] = op == ZC_ADD ? ZC_ADDC : op == ZC_MUL ? ZC_MULC : (cb ? ZC_SUBC : ZC_CSUB);
+    }
+}
+
+// Register allocation of an SSA program (host) -> the interpreter's [op | flags, dst, a, b] words.
+//  * last-use allocation into the lowest free register (the LDS file is sized by the highest one used);
+//  * operand forwarding: the interpreter keeps the value of the last value-producing instruction in VGPRs (`prev`);
+//    an operand that is that value is flagged ZC_A_PREV / ZC_B_PREV (no LDS read), and a value whose every use
+//    happens before the next value is produced is flagged ZC_DST_TEMP: it never touches the register file — in the
+//    constraint programs of real chips about half of all values are consumed by the very next instruction;
+//  * runs of up to 4 LOADs of consecutive columns of one table become ONE instruction (count in bits 16-17) with
+//    consecutive destination registers: the kernel issues all their global loads before waiting once, so a row
+//    of a wide chip costs a quarter of the memory round trips.
+static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint32_t>* out, uint32_t* n_regs) {
+    auto is_bin = [](uint32_t op) { return op == ZC_ADD || op == ZC_SUB || op == ZC_MUL; };
+    auto is_un = [](uint32_t op) { return op == ZC_NEG || op == ZC_ASSERT_ZERO || zc_is_imm(op); };
+    std::vector<int> last_use(n, -1), next_val(n, -1);
+    std::vector<uint32_t> n_uses(n, 0);
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t op = ssa[3 * k], a = ssa[3 * k + 1], b = ssa[3 * k + 2];
+        SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO || zc_is_imm(op), "bad opcode in constraint program");
+        if (is_bin(op)) {
             SP1HIP_REQUIRE(a < k && b < k, "constraint program is not in SSA order");
-            last_use[a] = (int)k;
-            last_use[b] = (int)k;
-        } else if (op == ZC_NEG || op == ZC_ASSERT_ZERO) {
+            last_use[a] = (int)k; last_use[b] = (int)k;
+            n_uses[a]++; n_uses[b]++;
+        } else if (is_un(op)) {
             SP1HIP_REQUIRE(a < k, "constraint program is not in SSA order");
             last_use[a] = (int)k;
+            n_uses[a]++;
         }
     }
-    std::vector<uint32_t> free_regs, reg_of(n, 0xffffffffu);
-    uint32_t regs = 0;
-    out->assign((size_t)n * 4, 0);
+    {   // next_val[k]: the first value-producing instruction after k
+        int nv = -1;
+        for (uint32_t k = n; k-- > 0;) { next_val[k] = nv; if (ssa[3 * k] != ZC_ASSERT_ZERO) nv = (int)k; }
+    }
+    // load groups: group_len[k] > 0 on the first LOAD of a run, 0 on the merged followers
+    std::vector<uint32_t> group_len(n, 1);
+    for (uint32_t k = 0; k < n;) {
+        const uint32_t op = ssa[3 * k];
+        uint32_t m = 1;
+        if (op == ZC_LOAD_MAIN || op == ZC_LOAD_PREP)
+            while (m < 4 && k + m < n && ssa[3 * (k + m)] == op && ssa[3 * (k + m) + 1] == ssa[3 * k + 1] + m) m++;
+        group_len[k] = m;
+        for (uint32_t j = 1; j < m; j++) group_len[k + j] = 0;
+        k += m;
+    }
+    // a value is a temporary when it dies before the next value is produced (and it is not inside a load group,
+    // whose members all go to the file except that the LAST column stays forwardable)
+    auto is_temp = [&](uint32_t k) {
+        if (ssa[3 * k] == ZC_ASSERT_ZERO || n_uses[k] == 0) return false;
+        if ((ssa[3 * k] == ZC_LOAD_MAIN || ssa[3 * k] == ZC_LOAD_PREP) && !(group_len[k] == 1)) return false;
+        return next_val[k] < 0 ? true : last_use[k] <= next_val[k];
+    };
+    std::vector<char> busy;
+    auto take = [&](uint32_t m) {            // lowest run of m free registers
+        uint32_t run = 0;
+        for (uint32_t r = 0; r < busy.size(); r++) {
+            run = busy[r] ? 0 : run + 1;
+            if (run == m) { for (uint32_t j = 0; j < m; j++) busy[r - j] = 1; return r + 1 - m; }
+        }
+        const uint32_t tail = run;             // free registers at the top can be extended
+        const uint32_t start = (uint32_t)busy.size() - tail;
+        busy.resize(start + m, 1);
+        for (uint32_t j = 0; j < m; j++) busy[start + j] = 1;
+        return start;
+    };
+    std::vector<uint32_t> reg_of(n, 0xffffffffu);
+    out->clear();
+    int last_value = -1;                       // SSA index held in `prev` when the next instruction runs
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t op = ssa[3 * k], a = ssa[3 * k + 1], b = ssa[3 * k + 2];
-        const bool bin = op == ZC_ADD || op == ZC_SUB || op == ZC_MUL, un = op == ZC_NEG || op == ZC_ASSERT_ZERO;
-        uint32_t ra = a, rb = b;
-        if (bin || un) ra = reg_of[a];
-        if (bin) rb = reg_of[b];
-        if (bin || un) {
-            if (last_use[a] == (int)k && reg_of[a] != 0xffffffffu) { free_regs.push_back(reg_of[a]); reg_of[a] = 0xffffffffu; }
-            if (bin && b != a && last_use[b] == (int)k && reg_of[b] != 0xffffffffu) { free_regs.push_back(reg_of[b]); reg_of[b] = 0xffffffffu; }
+        if (group_len[k] == 0) continue;       // merged into the group's first LOAD
+        uint32_t word = op, ra = a, rb = b;
+        if (is_bin(op) || is_un(op)) {
+            if ((int)a == last_value) word |= ZC_A_PREV; else ra = reg_of[a];
+            if (is_bin(op)) { if ((int)b == last_value) word |= ZC_B_PREV; else rb = reg_of[b]; }
+            if ((!(word & ZC_A_PREV) && ra == 0xffffffffu) || (is_bin(op) && !(word & ZC_B_PREV) && rb == 0xffffffffu)) {
+                set_error("internal: operand of instruction %u has no register", k);
+                return SP1HIP_ERROR_RUNTIME;
+            }
+            if (last_use[a] == (int)k && reg_of[a] != 0xffffffffu) { busy[reg_of[a]] = 0; reg_of[a] = 0xffffffffu; }
+            if (is_bin(op) && b != a && last_use[b] == (int)k && reg_of[b] != 0xffffffffu) { busy[reg_of[b]] = 0; reg_of[b] = 0xffffffffu; }
         }
         uint32_t dst = 0;
         if (op != ZC_ASSERT_ZERO) {
-            if (!free_regs.empty()) { dst = free_regs.back(); free_regs.pop_back(); }
-            else dst = regs++;
-            if (last_use[k] >= 0) reg_of[k] = dst;
-            else free_regs.push_back(dst);      // dead value
+            const uint32_t m = group_len[k];
+            if (m == 1 && (is_temp(k) || n_uses[k] == 0)) {
+                word |= ZC_DST_TEMP;           // lives in `prev` only (or is dead)
+            } else {
+                dst = take(m);
+                for (uint32_t j = 0; j < m; j++) {
+                    if (n_uses[k + j]) reg_of[k + j] = dst + j; else busy[dst + j] = 0;
+                }
+            }
+            word |= (m - 1) << 16;
+            last_value = (int)(k + m - 1);
         }
-        uint32_t* o = out->data() + (size_t)k * 4;
-        o[0] = op; o[1] = dst; o[2] = ra; o[3] = rb;
-        if (op == ZC_CONST) o[2] = kb::to_monty(a % kb::P);
+        if (op == ZC_CONST) ra = kb::to_monty(a % kb::P);
+        if (zc_is_imm(op)) rb = kb::to_monty(b % kb::P);
+        out->insert(out->end(), {word, dst, ra, rb});
     }
-    *n_regs = regs ? regs : 1;
+    *n_regs = busy.empty() ? 1u : (uint32_t)busy.size();
     return SP1HIP_SUCCESS;
 }
 
@@ -521,7 +580,7 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
             const uint32_t k = o.first, op = ssa[3 * k];
             uint32_t a = ssa[3 * k + 1], b = ssa[3 * k + 2];
             if (op == ZC_ADD || op == ZC_SUB || op == ZC_MUL) { a = renum[a]; b = renum[b]; }
-            else if (op == ZC_NEG || op == ZC_ASSERT_ZERO) a = renum[a];
+            else if (op == ZC_NEG || op == ZC_ASSERT_ZERO || zc_is_imm(op)) a = renum[a];
             renum[k] = next++;
             sub.insert(sub.end(), {op, a, b});
         }
@@ -547,7 +606,7 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
             fresh.push_back(v);
             const uint32_t op = ssa[3 * v];
             if (op == ZC_ADD || op == ZC_SUB || op == ZC_MUL) { stack.push_back(ssa[3 * v + 1]); stack.push_back(ssa[3 * v + 2]); }
-            else if (op == ZC_NEG) stack.push_back(ssa[3 * v + 1]);
+            else if (op == ZC_NEG || zc_is_imm(op)) stack.push_back(ssa[3 * v + 1]);
         }
         if (!asserts.empty() && members.size() + fresh.size() + asserts.size() + 1 > limit) {
             for (uint32_t v : fresh) stamp[v] = 0xffffffffu;     // undo, close the chunk, retry in a new one
@@ -567,8 +626,11 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
     for (auto& c : *out)
         for (size_t k = 0; k < c.prog.size() / 4; k++) {
             uint32_t* o = c.prog.data() + 4 * k;
-            if (o[0] == ZC_LOAD_MAIN && !seen_m[o[2]]) { seen_m[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
-            if (o[0] == ZC_LOAD_PREP && !seen_p[o[2]]) { seen_p[o[2]] = true; o[0] |= ZC_GKR_FLAG; }
+            const uint32_t op = o[0] & 0xffu, cnt = ((o[0] >> 16) & 3u) + 1;
+            if (op != ZC_LOAD_MAIN && op != ZC_LOAD_PREP) continue;
+            std::vector<bool>& seen = op == ZC_LOAD_MAIN ? seen_m : seen_p;
+            for (uint32_t j = 0; j < cnt; j++)
+                if (!seen[o[2] + j]) { seen[o[2] + j] = true; o[0] |= ZC_GKR_FLAG << j; }
         }
     Chunk touch;
     auto push_touch = [&](uint32_t col, uint32_t is_prep) {
@@ -585,47 +647,77 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
 // host evaluation of the program on an all-zero row (padded_row_adjustment, shard.rs:L524-L536)
 static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     const uint32_t n = (uint32_t)(c.prog.size() / 4);
-    std::vector<uint32_t> reg(c.n_regs, 0);
+    std::vector<uint32_t> reg(c.n_regs + 4, 0);
     Ext acc = kb::ext_zero();
-    uint32_t ci = 0;
+    uint32_t ci = 0, prev = 0;
     for (uint32_t k = 0; k < n; k++) {
-        const uint32_t op = c.prog[4 * k] & 0xffu, dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
+        const uint32_t opw = c.prog[4 * k], op = opw & 0xffu, dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
+        const uint32_t A = (opw & ZC_A_PREV) ? prev : (op >= ZC_ADD && op != ZC_TOUCH ? reg[x] : 0u);
+        const uint32_t B = (opw & ZC_B_PREV) ? prev : (op >= ZC_ADD && op <= ZC_MUL ? reg[y] : 0u);
+        uint32_t res = 0;
         switch (op) {
-            case ZC_LOAD_MAIN: case ZC_LOAD_PREP: reg[dst] = 0; break;
-            case ZC_TOUCH: break;
-            case ZC_CONST: reg[dst] = x; break;
-            case ZC_PUBLIC: reg[dst] = publics[x]; break;
-            case ZC_ADD: reg[dst] = kb::add(reg[x], reg[y]); break;
-            case ZC_SUB: reg[dst] = kb::sub(reg[x], reg[y]); break;
-            case ZC_MUL: reg[dst] = kb::mul(reg[x], reg[y]); break;
-            case ZC_NEG: reg[dst] = kb::neg(reg[x]); break;
-            default: acc = acc + kb::ext_mul_base(c.alpha_pows[ci++], reg[x]); break;
+            case ZC_LOAD_MAIN: case ZC_LOAD_PREP:
+                if (!(opw & ZC_DST_TEMP)) for (uint32_t j = 0; j <= ((opw >> 16) & 3u); j++) reg[dst + j] = 0;
+                prev = 0;
+                continue;
+            case ZC_TOUCH: continue;
+            case ZC_CONST: res = x; break;
+            case ZC_PUBLIC: res = publics[x]; break;
+            case ZC_ADD: res = kb::add(A, B); break;
+            case ZC_SUB: res = kb::sub(A, B); break;
+            case ZC_MUL: res = kb::mul(A, B); break;
+            case ZC_NEG: res = kb::neg(A); break;
+            case ZC_ADDC: res = kb::add(A, y); break;
+            case ZC_SUBC: res = kb::sub(A, y); break;
+            case ZC_CSUB: res = kb::sub(y, A); break;
+            case ZC_MULC: res = kb::mul(A, y); break;
+            default: acc = acc + kb::ext_mul_base(c.alpha_pows[ci++], A); continue;
         }
+        prev = res;
+        if (!(opw & ZC_DST_TEMP)) reg[dst] = res;
     }
     return acc;
 }
 
+// register-file bytes one lane needs in LDS
+template <bool FIRST> static inline size_t zc_rf_lane_bytes(uint32_t n_regs) { return (size_t)n_regs * (FIRST ? 4 : 16); }
+constexpr size_t ZC_LDS_BUDGET = 64 * 1024;
+
+// widest workgroup (256 / 128 / 64 lanes) whose LDS register file fits the budget; 0 if even one wave does not
+template <bool FIRST> static inline uint32_t zc_wg_for(uint32_t n_regs, size_t other_lds) {
+    for (uint32_t wg = 256; wg >= 64; wg >>= 1)
+        if (other_lds + zc_rf_lane_bytes<FIRST>(n_regs) * wg <= ZC_LDS_BUDGET) return wg;
+    return 0;
+}
+
+// One group of descriptors = a contiguous block range [block_lo, block_lo + n_blocks) launched together.
 template <bool FIRST>
-static int launch_round(uint32_t max_regs, const ZcDesc* d_descs, int n_descs, uint32_t total_blocks, uint32_t max_instr,
-                        const uint32_t* eq, uint32_t eq_len, const uint32_t* publics, uint32_t* partial, hipStream_t s) {
-    const uint32_t staged = max_instr <= ZC_LDS_PROG_MAX ? max_instr : 0;
-    const size_t lds = 32 * 4 + (size_t)staged * 16;
-    dim3 grid(total_blocks * 3);          // workgroup 3 b + p = node p of block b
-    // register file in LDS when it fits 64 KiB together with the staged program (two workgroups per CU at worst)
-    const size_t rf_bytes = (size_t)max_regs * 256 * (FIRST ? 4 : 16);
+static int launch_round(uint32_t max_regs, bool staged, const ZcDesc* d_descs, int n_descs, uint32_t block_lo, uint32_t n_blocks,
+                        uint32_t max_instr, const uint32_t* eq, uint32_t eq_len, const uint32_t* publics, uint32_t* partial, hipStream_t s) {
+    const size_t lds = 32 * 4 + (staged ? (size_t)max_instr * 16 : 0);
+    dim3 grid(n_blocks * 3);              // workgroup 3 b + p = node p of block b
     static const bool force_vgpr = [] { const char* e = getenv("SP1HIP_ZC_REGFILE"); return e && e[0] == 'v'; }();
-    if (!force_vgpr && lds + rf_bytes <= 64 * 1024) {
-        auto kern = zc_round_kernel<FIRST, 0>;
-        if (lds + rf_bytes > 48 * 1024)
-            SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + rf_bytes)));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds + rf_bytes, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4));
+    const uint32_t wg = force_vgpr ? 0 : zc_wg_for<FIRST>(max_regs, lds);
+    if (wg) {
+        const size_t total = lds + zc_rf_lane_bytes<FIRST>(max_regs) * wg;
+        if (staged) {
+            auto kern = zc_round_kernel<FIRST, 0, true>;
+            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
+        } else {
+            auto kern = zc_round_kernel<FIRST, 0, false>;
+            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
+        }
         SP1HIP_LAUNCH_CHECK();
         return SP1HIP_SUCCESS;
     }
-    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
-    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
-    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
-    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u);
+    // register file in VGPRs / scratch (programs whose file does not fit LDS, or SP1HIP_ZC_REGFILE=vgpr for A/B runs)
+    SP1HIP_REQUIRE(staged, "internal: unstaged program without an LDS register file");
+    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
     else { set_error("constraint program needs %u live registers (max 1024)", max_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
@@ -705,18 +797,21 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     for (int i = 0; i < n_chips; i++) {
         std::unique_ptr<ChipState> c(new ChipState());
         c->in = &chips[i];
-        SP1HIP_TRY(allocate_registers(chips[i].program, chips[i].n_instr, &c->prog, &c->n_regs));
         uint32_t asserts = 0;
         for (uint32_t k = 0; k < chips[i].n_instr; k++) {
             const uint32_t op = chips[i].program[3 * k], a = chips[i].program[3 * k + 1];
+            SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO, "bad opcode in constraint program");
             if (op == ZC_ASSERT_ZERO) asserts++;
             if (op == ZC_LOAD_MAIN) SP1HIP_REQUIRE(a < chips[i].main_width, "main column out of range");
             if (op == ZC_LOAD_PREP) SP1HIP_REQUIRE(a < chips[i].prep_width, "preprocessed column out of range");
             if (op == ZC_PUBLIC) SP1HIP_REQUIRE((int)a < n_publics, "public value index out of range");
         }
         SP1HIP_REQUIRE(asserts == chips[i].num_constraints, "num_constraints does not match the program");
-        SP1HIP_TRY(build_chunks(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT,
-                                &c->chunks));
+        std::vector<uint32_t> folded;
+        fold_immediates(chips[i].program, chips[i].n_instr, &folded);
+        SP1HIP_TRY(allocate_registers(folded.data(), chips[i].n_instr, &c->prog, &c->n_regs));
+        SP1HIP_TRY(build_chunks(folded.data(), chips[i].n_instr, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT, &c->chunks));
+        SP1HIP_TRY(build_chunks(folded.data(), chips[i].n_instr, chips[i].main_width, chips[i].prep_width, 0xffffffffu, &c->mono));
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
         std::reverse(c->alpha_pows.begin(), c->alpha_pows.end());
@@ -740,6 +835,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         c->off_prog = blob.size();
         for (auto& ck : c->chunks) {
             c->chunk_off.push_back((uint32_t)((blob.size() - c->off_prog) / 4));
+            blob.insert(blob.end(), ck.prog.begin(), ck.prog.end());
+        }
+        for (auto& ck : c->mono) {
+            c->mono_off.push_back((uint32_t)((blob.size() - c->off_prog) / 4));
             blob.insert(blob.end(), ck.prog.begin(), ck.prog.end());
         }
         pad4();
@@ -780,36 +879,73 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         const Ext last = zeta[nv - 1];
         // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
         SP1HIP_TRY(sp1hip_partial_lagrange(reinterpret_cast<const sp1hip_ext_t*>(zeta.data()), nv - 1, d_eq.u32(), stream));
-        // descriptors: one per (chip with real rows, chunk); a chip's blocks are contiguous
+        // descriptors: one per (chip with real rows, chunk); a chip's blocks are contiguous. Chips are grouped by how
+        // their programs run this round — (program staged in LDS?, workgroup width the LDS register file allows) — and
+        // every group is one launch over its contiguous block range.
         keep_descs.emplace_back(new std::vector<ZcDesc>());
         keep_ranges.emplace_back(new std::vector<ZcChipRange>());
         std::vector<ZcDesc>& descs = *keep_descs.back();
         std::vector<ZcChipRange>& ranges = *keep_ranges.back();
         std::vector<int> desc_chip;
-        uint32_t total_blocks = 0, max_regs = 1, max_instr = 1;
+        struct Group { bool staged; uint32_t wg, max_regs, max_instr, block_lo, n_blocks; std::vector<int> chips; };
+        std::vector<Group> groups;
+        static const bool mono_enabled = [] { const char* e = getenv("SP1HIP_ZC_MONO"); return !(e && e[0] == '0'); }();
+        std::vector<char> use_mono(n_chips, 0);
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
             if (c.rows == 0) continue;
             const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
-            uint32_t blocks = (terms + 255) / 256;
-            if (blocks > 512) blocks = 512;
-            ZcChipRange rg{total_blocks, 0, terms - 1, 0};
-            for (size_t q = 0; q < c.chunks.size(); q++) {
-                ZcDesc d{};
-                d.prog = c.p_prog + (size_t)c.chunk_off[q] * 4;
-                d.n_instr = (uint32_t)(c.chunks[q].prog.size() / 4);
-                d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
-                d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
-                d.block_start = total_blocks; d.n_blocks = blocks;
-                d.alpha_off = c.chunks[q].alpha_off; d.flags = q == 0 ? 1u : 0u;
-                total_blocks += blocks;
-                max_regs = std::max(max_regs, c.chunks[q].n_regs);
-                max_instr = std::max(max_instr, d.n_instr);
-                descs.push_back(d);
+            uint32_t mono_regs = 1;
+            for (auto& ck : c.mono) mono_regs = std::max(mono_regs, ck.n_regs);
+            const uint32_t mono_wg = r == 0 ? zc_wg_for<true>(mono_regs, 128) : zc_wg_for<false>(mono_regs, 128);
+            use_mono[i] = mono_enabled && c.chunks.size() > 1 && terms >= ZC_MONO_MIN_TERMS && mono_wg != 0;
+            const std::vector<Chunk>& cks = use_mono[i] ? c.mono : c.chunks;
+            uint32_t regs = 1, instr = 1;
+            for (auto& ck : cks) { regs = std::max(regs, ck.n_regs); instr = std::max<uint32_t>(instr, (uint32_t)(ck.prog.size() / 4)); }
+            // short programs are staged in LDS (<= 16 KiB, read by every wave of the workgroup); long ones stream
+            // through the scalar cache and leave the LDS to the register file
+            bool staged = instr <= 1024;
+            uint32_t wg = r == 0 ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
+            if (wg == 0) {                  // the file does not fit LDS: VGPR / scratch tier, program staged
+                SP1HIP_REQUIRE(instr <= ZC_LDS_PROG_MAX, "constraint program too large (one constraint with too many live values)");
+                staged = true;
             }
-            rg.n_blocks = total_blocks - rg.block_start;
-            ranges.push_back(rg);
-            desc_chip.push_back(i);
+            size_t g = 0;
+            for (; g < groups.size(); g++) if (groups[g].staged == staged && groups[g].wg == wg) break;
+            if (g == groups.size()) groups.push_back(Group{staged, wg, 1, 1, 0, 0, {}});
+            groups[g].max_regs = std::max(groups[g].max_regs, regs);
+            groups[g].max_instr = std::max(groups[g].max_instr, instr);
+            groups[g].chips.push_back(i);
+        }
+        uint32_t total_blocks = 0;
+        for (auto& g : groups) {
+            g.block_lo = total_blocks;
+            for (int i : g.chips) {
+                ChipState& c = *st[i];
+                const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
+                const uint32_t bp = g.wg ? g.wg : 256u;
+                uint32_t blocks = (terms + bp - 1) / bp;
+                if (blocks > 131072u / bp) blocks = 131072u / bp;
+                const std::vector<Chunk>& cks = use_mono[i] ? c.mono : c.chunks;
+                const std::vector<uint32_t>& offs = use_mono[i] ? c.mono_off : c.chunk_off;
+                ZcChipRange rg{total_blocks, 0, terms - 1, 0};
+                for (size_t q = 0; q < cks.size(); q++) {
+                    ZcDesc d{};
+                    d.prog = c.p_prog + (size_t)offs[q] * 4;
+                    d.n_instr = (uint32_t)(cks[q].prog.size() / 4);
+                    d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+                    d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
+                    d.block_start = total_blocks; d.n_blocks = blocks;
+                    d.alpha_off = cks[q].alpha_off; d.flags = q == 0 ? 1u : 0u;
+                    d.block_pairs = bp;
+                    total_blocks += blocks;
+                    descs.push_back(d);
+                }
+                rg.n_blocks = total_blocks - rg.block_start;
+                ranges.push_back(rg);
+                desc_chip.push_back(i);
+            }
+            g.n_blocks = total_blocks - g.block_lo;
         }
         const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
         // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
@@ -862,8 +998,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_TRY(d_partial.alloc(partial_cap, s));
             }
             ScopedTimer tm("zerocheck_round", s);      // (the reference's SP1_GPU_ZEROCHECK_ROUND_TIMING switch)
-            if (r == 0) SP1HIP_TRY(launch_round<true>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
-            else SP1HIP_TRY(launch_round<false>(max_regs, (const ZcDesc*)d_descs.p, n_descs, total_blocks, max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+            for (auto& g : groups) {
+                if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+                else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+            }
             if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             SP1HIP_LAUNCH_CHECK();
