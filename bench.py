@@ -1,29 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py — core-shard commit hot path on MI355X, BASELINE.json config 2.
+"""bench.py — one WHOLE core-shard proof per step on MI355X (BASELINE.json metric: core shard prove).
 
-One "step" = BasefoldProver::commit_mles on one synthetic trace already resident in HBM
-(column-major): Reed–Solomon encode (zero-padded NTT, log_blowup 2, bit-reversed) of a
-2^20-row x 256-column KoalaBear trace + Poseidon2 Merkle commitment of the 2^22 x 256 codeword.
-Metric: RISC-V cycles proved/sec — for the synthetic fixed-height trace one trace row stands for one
-cycle (cycles only exist for real programs; the synthetic configs report rows/cells), so
-value = rows committed per second summed over all GPUs. `config` also carries cells/s.
+One "step" = `sp1hip_prove_shard` = `ShardProver::prove_shard_with_data`
+(/root/reference/crates/hypercube/src/prover/shard.rs:L650-L792) on one synthetic core shard already resident in HBM
+(column-major traces): jagged commit of the main traces (RS-encode NTT, blowup 4 + Poseidon2 Merkle) -> LogUp-GKR ->
+zerocheck -> jagged evaluation proof (jagged sumcheck, jagged-eval, stacked BaseFold opening, 124 queries, 16-bit PoW);
+the output is a complete bincode(ShardProof) that the pinned verifier accepts (tests/test_gpu_shard.py).
 
-Usage: python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run)
-Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for `roofline` and `cpu_baseline`).
+Workload (`config.workload`): the core-SHAPED synthetic shard of bench/core_shard.py at CORE size (area 2^28 + 2^27
+trace cells, max_log_row_count 22, stacking height 2^21): 33 chips with the widths / constraint counts of RISC-V chips
+and the 730 interactions and row proportions of a recorded core shard (bench/core_shape.json, from data in the
+reference tree). The reference defines its headline "Core kHz" as cycles / core-proving seconds
+(/root/reference/sp1-gpu/crates/perf/src/report.rs:L52-L60); cycles exist only for real programs (they need the Rust
+executor), so for this synthetic shard `value` is trace CELLS proved per second and `proofs_per_s` rides
+along; nothing is converted to cycles.
+
+Usage: python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, shards striped
+one per rank, no data-path collective). Prints ONE JSON line on rank 0; see DESIGN.md §8 for every field.
 """
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bench"))
 
-LG_N, WIDTH, LOG_BLOWUP, BATCH = 20, 256, 2, 32        # 8 stacked batches of 32 columns
-HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC_PER_LAUNCH = 788688051                      # profiles/r01_pmc_summary.md: HBM bytes per leaf-hash launch (1/8 step)
+CORE_AREA = (1 << 28) + (1 << 27)
+HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_GUIDE = 256 * 4 * 32 * 2.4e9   # guide: 4 SIMD-32 per CU, a wave64 instruction issues in 2 cycles -> 78.6 T lane-inst/s
+VALU_PEAK_MEASURED = 256 * 64 * 2.4e9    # measured VOP3-integer / f64 rate (profiles/r01_ubench*.txt): one lane-inst per lane-clock
+TIMERS = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition", "gkr_round_sum_first",
+          "gkr_round_fold_sum", "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",
+          "jagged_fold_sum", "jagged_batch_evals")
 
 
 def timers_read(api, name):
@@ -44,39 +57,67 @@ def effective_cores():
     return n
 
 
-def cpu_baseline_child(lg_rows):
+# ---- CPU baseline: the oracle's prove_shard_with_data on a scaled-down copy of the same shard -------------------------
+def cpu_baseline_child(path):
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as orc
-    mles = [orc.random_felts((1 << lg_rows, BATCH), 42 + i) for i in range(WIDTH // BATCH)]
-    orc.CommittedRound([m[:256] for m in mles], LOG_BLOWUP)          # warm-up / first touch
+    from core_shard import chip_programs, load_shape
+    z = np.load(path)
+    L, lsh = int(z["L"]), int(z["lsh"])
+    chips = []
+    for k, c in enumerate(sorted(load_shape()["chips"], key=lambda c: c["name"])):
+        air, inter = chip_programs(c["name"], c["width"], c["prep_width"], c["constraints"], c["interactions"])
+        chips.append((air, inter, z["main%d" % k], z["prep%d" % k] if c["prep_width"] else None))
     t0 = time.perf_counter()
-    orc.CommittedRound(mles, LOG_BLOWUP)
-    print(json.dumps({"seconds": time.perf_counter() - t0}))
+    prep = orc.JaggedRound([c[3] for c in chips if c[3] is not None], L, lsh, 32, 2)
+    t_setup = time.perf_counter() - t0
+    ch = orc.Challenger()
+    ch.observe(prep.commit)
+    t0 = time.perf_counter()
+    blob = orc.shard_prove(chips, np.zeros(0, np.uint32), prep, L, lsh, 32, ch, 2, 124, 16)
+    print(json.dumps({"seconds": time.perf_counter() - t0, "setup_seconds": t_setup, "proof_bytes": len(blob)}))
 
 
-def cpu_baseline(lg_rows):
-    """The CPU oracle (a port, NOT the reference binary) on a bounded sample of the same workload, in a
-    child process so OpenMP is sized to the cores this container may use."""
+def cpu_baseline(api, scale_log2):
+    """The CPU oracle (a C++17/OpenMP restatement of the reference's prover, NOT the reference binary) proving the same
+    shard shape scaled down by 4^scale_log2, in a child process so OpenMP is sized to the cores this container may use."""
     import subprocess
+    import tempfile
+
+    import numpy as np
+    from core_shard import build_core_shard
+    L, lsh = 22 - scale_log2, 21 - scale_log2
+    chips, meta = build_core_shard(CORE_AREA >> (2 * scale_log2), L)
+    arrays = {"L": L, "lsh": lsh}
+    for k, (_, _, main, prep) in enumerate(chips):
+        arrays["main%d" % k] = main.to_row_major_host()
+        if prep is not None:
+            arrays["prep%d" % k] = prep.to_row_major_host()
     cores = effective_cores()
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="false")
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(lg_rows)], env=env,
-                         capture_output=True, text=True, check=True).stdout
-    dt = json.loads(out.strip().splitlines()[-1])["seconds"]
-    return {"value": (1 << lg_rows) / dt, "unit": "cycles/s", "cores": cores, "kind": "port",
-            "sample": "oracle commit_mles (RS encode + Poseidon2 Merkle) of 2^%d x %d rows = 1/%d of one step; "
-                      "C++17 + OpenMP, %d threads (cgroup quota); %.2f s wall" % (lg_rows, WIDTH, 1 << (LG_N - lg_rows),
-                                                                                 cores, dt)}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "shard.npz")
+        np.savez(path, **arrays)
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="false")
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", path], env=env,
+                             capture_output=True, text=True, check=True).stdout
+    r = json.loads(out.strip().splitlines()[-1])
+    return {"value": meta["area_cells"] / r["seconds"], "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": "oracle prove_shard_with_data (commit + LogUp-GKR + zerocheck + jagged evaluation proof, 124 queries, 16-bit PoW) "
+                      "of the same core-shaped shard at 1/%d of the area (%d cells, max_log_row_count %d); C++17 + OpenMP, %d threads "
+                      "(cgroup quota); %.2f s wall" % (1 << (2 * scale_log2), meta["area_cells"], L, cores, r["seconds"])}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-sample-lg-rows", type=int, default=18)
-    ap.add_argument("--cpu-baseline-child", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--scale-log2", type=int, default=0, help="prove a shard of area CORE >> 2k (testing aid; the bench line is k = 0)")
+    ap.add_argument("--cpu-sample-scale-log2", type=int, default=3)
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (2-in-flight, commit-only, CPU baseline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL; gloo lets "
                          "several ranks share one GPU when testing the N > 1 path on a 1-GPU box)")
@@ -99,131 +140,150 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from sp1_amd import api
-    L = api._L()
+    from core_shard import build_core_shard
+    from sp1_amd import api, shards
+    lib = api._L()
+    k = args.scale_log2
+    L, lsh = 22 - k, 21 - k
+    chips, meta = build_core_shard(CORE_AREA >> (2 * k), L, seed=42 + rank)       # every rank proves its own shard
+    area = meta["area_cells"]
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    prep_commit, prep_data = jp.commit_multilinears([c[3] for c in chips if c[3] is not None])   # setup (the proving key)
+    torch.cuda.synchronize()
 
-    # synthetic trace, resident in HBM, column-major: SplitMix64-style words < p, generated on device
-    n = 1 << LG_N
-    g = torch.Generator(device="cuda")
-    g.manual_seed(42 + rank)
-    mles = []
-    for b in range(WIDTH // BATCH):
-        words = torch.randint(0, api.P, (BATCH * n,), dtype=torch.int32, device="cuda", generator=g)
-        mles.append(api.ColMajor(words, n, BATCH))
-    prover = api.BasefoldProver(LOG_BLOWUP, 124, 16)
-
-    def step():
-        commit, pd = prover.commit_mles(mles)
-        return commit, pd
+    def step(stream=None):
+        ch = api.DuplexChallenger()
+        ch.observe(prep_commit)                                              # stands for vk.observe_into
+        return api.prove_shard(chips, [], prep_data, L, lsh, 32, ch, stream=stream)
 
     for _ in range(args.warmup):
-        _, pd = step()
-        del pd
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    api.check(L.sp1hip_timers_reset())
-    api.check(L.sp1hip_timers_enable(1))
+    api.check(lib.sp1hip_timers_reset())
+    api.check(lib.sp1hip_timers_enable(1))
     t0 = time.perf_counter()
-    last = None
+    proof = None
     for _ in range(args.steps):
-        last, pd = step()
-        del pd
+        proof = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    api.check(L.sp1hip_timers_enable(0))
-    tl = {name: timers_read(api, name) for name in ("leaf_hash", "ntt_pass0", "ntt_pass1", "ntt_pass2", "compress")}
-    from sp1_amd import shards
-    dt = shards.max_over_ranks(dt)      # shards are striped one per rank: no data-path collective
+    api.check(lib.sp1hip_timers_enable(0))
+    tl = {name: timers_read(api, name) for name in TIMERS}
+    dt = shards.max_over_ranks(dt)                 # shards are striped one per rank: no data-path collective
 
-    # the same kernels once more with the encode/hash overlap switched off (not timed into `value`): isolated
-    # launch durations, so the roofline object can show both what a launch achieves alone and inside the step
-    iso = {}
-    if rank == 0 and world == 1:      # (N > 1 runs measure scaling only: no after-pass, no CPU baseline)
-        os.environ["SP1HIP_COMMIT_OVERLAP"] = "0"
-        api.check(L.sp1hip_timers_reset())
-        api.check(L.sp1hip_timers_enable(1))
-        t1 = time.perf_counter()
-        iso_steps = max(2, min(5, args.steps))
-        for _ in range(iso_steps):
-            _, pd = step()
-            del pd
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:      # untimed extras; N > 1 runs measure scaling only
+        # (a) two provers in flight on one GPU (two host threads, two streams): the sumcheck rounds of one proof fill the
+        #     transcript round trips of the other; same inputs, byte-identical proofs
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for s in streams:
+            with torch.cuda.stream(s):
+                step(s)                                                          # fill each stream's arena
         torch.cuda.synchronize()
-        iso["ms_per_step"] = 1e3 * (time.perf_counter() - t1) / iso_steps
-        api.check(L.sp1hip_timers_enable(0))
-        for name in ("leaf_hash", "ntt_pass0", "ntt_pass1", "ntt_pass2"):
-            k, m = timers_read(api, name)
-            iso[name + "_ms_per_step"] = m / iso_steps
-        del os.environ["SP1HIP_COMMIT_OVERLAP"]
-        api.check(L.sp1hip_timers_reset())
+        n_each = max(2, args.steps // 2)
+        bad = []
+
+        def worker(s):
+            for _ in range(n_each):
+                with torch.cuda.stream(s):
+                    if step(s) != proof:
+                        bad.append(1)
+
+        t1 = time.perf_counter()
+        threads = [threading.Thread(target=worker, args=(s,)) for s in streams]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        assert not bad, "a concurrently produced proof differs from the sequential one"
+        extras["two_in_flight"] = {"proofs": 2 * n_each, "ms_per_proof": 1e3 * dt2 / (2 * n_each), "cells_per_s": 2 * n_each * area / dt2,
+                                   "proofs_per_s": 2 * n_each / dt2}
+        # (b) the commit phase alone (BASELINE config 2's stage: RS encode + Poseidon2 Merkle of the main traces)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            _, sd = jp.commit_multilinears([c[2] for c in chips])
+            del sd
+        torch.cuda.synchronize()
+        extras["commit_only"] = {"ms": 1e3 * (time.perf_counter() - t1) / 3, "cells": sum(c[2].height * c[2].width for c in chips)}
+        if not args.no_cpu_baseline:
+            extras["cpu_baseline"] = cpu_baseline(api, max(args.cpu_sample_scale_log2, k))
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        N = n << LOG_BLOWUP
-        rows_per_s = world * args.steps * n / dt
-        # dominant kernel: leaf hashing (one launch per stacked batch, 8 per step, overlapped with the encodes
-        # of the following batches). Algorithmic bytes per step: leaf read 4*N*W + digest write 32*N;
-        # per launch = 1/8 of that. The split adds 2 x 32 B of sponge-capacity carry per row per boundary.
-        leaf_launches, leaf_ms_total = tl["leaf_hash"]
-        per_step = leaf_launches // args.steps
-        leaf_ms = leaf_ms_total / args.steps            # all leaf-hash launches of one step
-        leaf_bytes = 4 * N * WIDTH + 32 * N
-        carry_bytes = 64 * N * (per_step - 1)
-        perms = N * (WIDTH // 8)
-        ntt = {}
-        for name in ("ntt_pass0", "ntt_pass1", "ntt_pass2", "compress"):
-            k, m = tl[name]
-            if k:
-                ntt[name + "_ms_per_step"] = round(m / args.steps, 4)
-        ntt_ms = sum(v for k, v in ntt.items() if k.startswith("ntt"))
-        ntt_bytes = 4 * n * WIDTH * (1 + (1 << LOG_BLOWUP))
-        valu_peak = 256 * 64 * 2.4e9
-        iso_leaf = iso.get("leaf_hash_ms_per_step")
-        iso_ntt = sum(iso[k] for k in iso if k.startswith("ntt"))
-        out = {
-            "metric": "RISC-V cycles proved/sec (core shard prove; synthetic config 2: commit phase, 1 trace row = 1 cycle)",
-            "value": rows_per_s, "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: synthetic 2^20-row x 256-col KoalaBear trace (8 stacked batches of 32), "
-                                   "log_blowup 2: RS-encode NTT + Poseidon2 Merkle commit, bit-exact vs CPU oracle",
-                       "rows": n, "cols": WIDTH, "log_blowup": LOG_BLOWUP, "parallelism": "independent shards, one per GPU",
-                       "cells_per_s": rows_per_s * WIDTH, "commitment_word0": int(last[0])},
-            "roofline": {"bound": "hbm", "kernel": "leaf_hash_part_kernel", "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": leaf_bytes / (leaf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         # HBM bytes per step of this kernel from the committed PMC passes
-                         # (profiles/r01_pmc_summary.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-                         "traffic": PMC_TRAFFIC_PER_LAUNCH, "traffic_source": "profiles/r01_pmc_summary.md",
-                         "launches_per_step": per_step, "avg_launch_ms": leaf_ms / max(per_step, 1),
-                         "algorithmic_bytes_per_launch": leaf_bytes // max(per_step, 1),
-                         "sponge_carry_bytes_per_step": carry_bytes,
-                         # the bound that actually binds: VALU issue. 3573 = SQ_INSTS_VALU per permutation of a
-                         # leaf_hash_part_kernel launch (profiles/r01_pmc_summary.md, last SQ pass; 3556 in the steady-state
-                         # loop of the ISA listing + the carry load/store of the launch; the single-launch kernel of the
-                         # isolated pass: 3558); peak = 256 CUs x 64 lanes x 2.4 GHz, one instruction per lane-clock.
-                         # `frac` is measured inside the timed steps, where the launches share the chip with the
-                         # encode passes of the following batches; `frac_isolated` is the same launch with the overlap
-                         # switched off (SP1HIP_COMMIT_OVERLAP=0), measured right after the timed region.
-                         "valu": {"insts_per_permutation": 3573, "achieved_lane_insts_per_s": 3573 * perms / (leaf_ms * 1e-3),
-                                  "peak_lane_insts_per_s": valu_peak, "frac": 3573 * perms / (leaf_ms * 1e-3) / valu_peak,
-                                  "frac_isolated": 3558 * perms / (iso_leaf * 1e-3) / valu_peak if iso_leaf else None},
-                         "note": "integer-VALU-bound by construction (Poseidon2: %d permutations per step, "
-                                 "%.3g permutations/s); see DESIGN.md" % (perms, perms / (leaf_ms * 1e-3)),
-                         "rs_encode": {"bound": "hbm", "ms_per_step": ntt_ms, "algorithmic_bytes_per_step": ntt_bytes,
-                                       "achieved": ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None,
-                                       "frac": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ntt_ms else None},
-                         "per_step_ms": ntt,
-                         "isolated": ({"note": "same workload, encode/hash overlap off, %d steps after the timed region" % iso_steps,
-                                       "ms_per_step": round(iso["ms_per_step"], 4), "leaf_hash_ms_per_step": round(iso_leaf, 4),
-                                       "rs_encode_ms_per_step": round(iso_ntt, 4)} if iso else None)},
+        ms = {name: m / args.steps for name, (cnt, m) in tl.items() if cnt}
+        launches = {name: cnt // args.steps for name, (cnt, m) in tl.items() if cnt}
+        # algorithmic bytes per proof of the streaming kernels: S stacked columns of height
+        # h = 2^lsh, codeword height N = 4 h
+        h, A_main = 1 << lsh, sum(c[2].height * c[2].width for c in chips)
+        S_cols = -(-A_main // h) + 1
+        N = 4 * h
+        alg = {
+            "leaf_hash": 4 * N * S_cols + 32 * N,
+            "ntt": 4 * h * S_cols * 5,
+            "zerocheck_round": 20 * area,            # round 0 reads 4A, rounds >= 1 read 16A of extension tables in total
+            "zerocheck_fix": 36 * area,              # reads 4A + 16A, writes 8A + 8A
         }
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_lg_rows) if (world == 1 and not args.no_cpu_baseline) else None
+        perms = N * (-(-S_cols // 8)) if S_cols else 0
+        ntt_ms = sum(v for n, v in ms.items() if n.startswith("ntt_pass"))
+        stages = {
+            "leaf_hash": {"ms": ms.get("leaf_hash"), "launches": launches.get("leaf_hash"), "bound": "valu",
+                          "algorithmic_bytes": alg["leaf_hash"], "hbm_frac": alg["leaf_hash"] / (ms["leaf_hash"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                          "permutations": perms,
+                          # 3573 VALU instructions per permutation: SQ_INSTS_VALU of this kernel, profiles/r01_pmc_summary.md
+                          "valu_frac_vs_guide_issue_rate": 3573 * perms / (ms["leaf_hash"] * 1e-3) / VALU_PEAK_GUIDE,
+                          "valu_frac_vs_measured_int_rate": 3573 * perms / (ms["leaf_hash"] * 1e-3) / VALU_PEAK_MEASURED},
+            "rs_encode": {"ms": ntt_ms, "bound": "hbm", "algorithmic_bytes": alg["ntt"],
+                          "hbm_frac": alg["ntt"] / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ntt_ms else None},
+            "zerocheck_round": {"ms": ms.get("zerocheck_round"), "launches": launches.get("zerocheck_round"), "bound": "valu (interpreted constraints)",
+                                "algorithmic_bytes": alg["zerocheck_round"],
+                                "hbm_frac": alg["zerocheck_round"] / (ms["zerocheck_round"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "zerocheck_fix": {"ms": ms.get("zerocheck_fix"), "bound": "hbm", "algorithmic_bytes": alg["zerocheck_fix"],
+                              "hbm_frac": alg["zerocheck_fix"] / (ms["zerocheck_fix"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "logup_gkr_kernels_ms": sum(v for n, v in ms.items() if n.startswith("gkr_")),
+            "jagged_kernels_ms": sum(v for n, v in ms.items() if n.startswith("jagged_")),
+            "timed_kernels_ms": sum(ms.values()),
+        }
+        # the dominant kernel of the step, by live-measured launch time (HIP events recorded by the library on the
+        # launch stream, sp1hip_timers_*)
+        dom = max(("leaf_hash", "zerocheck_round", "zerocheck_fix"), key=lambda n: ms.get(n, 0.0))
+        dom_ms, dom_launches = ms[dom], launches[dom]
+        achieved = alg[dom] / dom_launches / (dom_ms / dom_launches * 1e-3) / 1e9
+        ms_per_step = 1e3 * dt / args.steps
+        out = {
+            "metric": "core shard prove throughput: trace cells proved/sec (whole ShardProof; synthetic core-shaped shard, see config)",
+            "value": world * args.steps * area / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": "synthetic",
+            "proofs_per_s": world * args.steps / dt,
+            "config": {"workload": "one whole core-shard proof (sp1hip_prove_shard = prove_shard_with_data): core-shaped synthetic shard, "
+                                   "%d chips / %d interactions / %d constraints (widths, constraint counts, interaction counts and row "
+                                   "proportions from the reference's rv64im_costs.json, rv64im_complexity.json, layer_workloads.json), "
+                                   "area %d cells%s, max_log_row_count %d, stacking height 2^%d, log_blowup 2, 124 queries, 16-bit PoW; "
+                                   "traces resident in HBM" % (meta["chips"], meta["interactions"], meta["constraints"], area,
+                                                               " (CORE = 2^28 + 2^27)" if k == 0 else " (CORE >> %d)" % (2 * k), L, lsh),
+                       "area_cells": area, "first_layer_entries": meta["first_layer_entries"], "proof_bytes": len(proof),
+                       "parallelism": "independent shards, one per GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "avg_launch_ms": dom_ms / dom_launches, "launches_per_step": dom_launches,
+                         "algorithmic_bytes_per_launch": alg[dom] // dom_launches,
+                         "note": "dominant kernel of the step by measured launch time; it is VALU-bound, not HBM-bound (see stages."
+                                 + dom + "); traffic: PMC passes are collected offline (profiles/), not inside this run",
+                         "stages": stages},
+            "cpu_baseline": extras.get("cpu_baseline"),
+            "two_in_flight": extras.get("two_in_flight"),
+            "commit_only": extras.get("commit_only"),
+        }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
