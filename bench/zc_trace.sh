@@ -1,10 +1,12 @@
 #!/bin/bash
 # per-launch durations of the zerocheck round kernels for one recursion shard proof (run on the GPU box)
-# usage: bench/zc_trace.sh <out-file> [bench args]
+# usage: bench/zc_trace.sh <out-file> [script relative to the repo root, default bench/bench_recursion.py --repeat 1] [args]
 out=$1; shift
+if [ $# -eq 0 ]; then set -- bench/bench_recursion.py --repeat 1; fi
+script=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_zc
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_zc -o rec -- python $GRAFT_REPO_ROOT/bench/bench_recursion.py --repeat 1 "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_zc -o rec -- python $GRAFT_REPO_ROOT/$script "$@" > /dev/null 2>&1
 python - "$out" <<PY
 import csv, glob, sys
 f = glob.glob("/tmp/prof_zc/**/*kernel_trace.csv", recursive=True)[0]

@@ -109,7 +109,6 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
     using K = KT<FIRST>;
     using T = typename K::T;
     kb::Ext acc = kb::ext_zero();
-    uint32_t ci = 0;
     T prev = K::zero();                   // the value the last value-producing instruction produced (operand forwarding)
     auto next = prog[0];                  // instruction words are fetched one instruction ahead of their use
     for (uint32_t k = 0; k < d.n_instr; k++) {
@@ -166,7 +165,7 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
             case ZC_CSUB: res = KC<FIRST>::csub(y, a); break;
             case ZC_MULC: res = KC<FIRST>::mulc(a, y); break;
             default:                                                  // ASSERT_ZERO
-                acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + ci++), a));
+                acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, y), a));     // y: the constraint's index
                 continue;
         }
         prev = res;
@@ -455,6 +454,85 @@ static void fold_immediates(const uint32_t* ssa, uint32_t n, std::vector<uint32_
     }
 }
 
+// Instruction scheduling (host). The k-th ASSERT_ZERO of the caller's program is constraint k; here every assert gets
+// its index as an explicit operand, which frees the ORDER: asserts are sorted by the last (or first) trace column their
+// cone touches, and every value is emitted right before its first use (depth-first from the asserts), the columns an
+// assert needs first, in ascending order (so that runs of them merge into one load instruction). Constraints of real
+// chips are local in the column layout (an operation's columns are contiguous), so this keeps few values alive at a
+// time: the register file of a 250-column chip shrinks from "every shared sub-expression of the chip" to the handful
+// one operation needs, which is what decides the workgroup width / occupancy of the interpreter (launch_round).
+// mode 0: original order (asserts tagged only); 1: by last column; 2: by first column.
+static void schedule_program(const uint32_t* ssa, uint32_t n, uint32_t main_w, int mode, std::vector<uint32_t>* out) {
+    auto is_bin = [](uint32_t op) { return op == ZC_ADD || op == ZC_SUB || op == ZC_MUL; };
+    auto is_un = [](uint32_t op) { return op == ZC_NEG || op == ZC_ASSERT_ZERO || zc_is_imm(op); };
+    std::vector<uint32_t> asserts, idx_of(n, 0);
+    for (uint32_t k = 0; k < n; k++)
+        if (ssa[3 * k] == ZC_ASSERT_ZERO) { idx_of[k] = (uint32_t)asserts.size(); asserts.push_back(k); }
+    out->clear();
+    if (mode == 0) {
+        out->assign(ssa, ssa + (size_t)n * 3);
+        for (uint32_t k : asserts) (*out)[3 * (size_t)k + 2] = idx_of[k];
+        return;
+    }
+    // first / last column a value depends on (main columns first, then preprocessed)
+    std::vector<uint32_t> lo(n, 0xffffffffu), hi(n, 0);
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t op = ssa[3 * k], a = ssa[3 * k + 1], b = ssa[3 * k + 2];
+        if (op == ZC_LOAD_MAIN) lo[k] = hi[k] = a + 1;
+        else if (op == ZC_LOAD_PREP) lo[k] = hi[k] = main_w + a + 1;
+        else if (is_bin(op)) { lo[k] = std::min(lo[a], lo[b]); hi[k] = std::max(hi[a], hi[b]); }
+        else if (is_un(op)) { lo[k] = lo[a]; hi[k] = hi[a]; }
+    }
+    std::vector<uint32_t> order = asserts;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return mode == 1 ? hi[x] < hi[y] : lo[x] < lo[y]; });
+    std::vector<uint32_t> renum(n, 0xffffffffu), stack, loads;
+    auto emit = [&](uint32_t k) {
+        const uint32_t op = ssa[3 * k];
+        uint32_t a = ssa[3 * k + 1], b = ssa[3 * k + 2];
+        if (is_bin(op)) { a = renum[a]; b = renum[b]; }
+        else if (is_un(op)) a = renum[a];
+        if (op == ZC_ASSERT_ZERO) b = idx_of[k];
+        renum[k] = (uint32_t)(out->size() / 3);
+        out->insert(out->end(), {op, a, b});
+    };
+    std::vector<uint8_t> visited(n, 0);
+    for (uint32_t as : order) {
+        // 1. the columns this assert still needs, ascending
+        loads.clear();
+        stack.assign(1, ssa[3 * as + 1]);
+        std::vector<uint32_t> seen_here;
+        while (!stack.empty()) {
+            const uint32_t v = stack.back();
+            stack.pop_back();
+            if (renum[v] != 0xffffffffu || visited[v]) continue;
+            visited[v] = 1;
+            seen_here.push_back(v);
+            const uint32_t op = ssa[3 * v];
+            if (op == ZC_LOAD_MAIN || op == ZC_LOAD_PREP) loads.push_back(v);
+            else if (is_bin(op)) { stack.push_back(ssa[3 * v + 1]); stack.push_back(ssa[3 * v + 2]); }
+            else if (is_un(op)) stack.push_back(ssa[3 * v + 1]);
+        }
+        for (uint32_t v : seen_here) visited[v] = 0;
+        std::sort(loads.begin(), loads.end(), [&](uint32_t x, uint32_t y) { return lo[x] < lo[y]; });
+        for (uint32_t v : loads) emit(v);
+        // 2. the rest of the cone, operands before users (iterative post-order)
+        stack.assign(1, ssa[3 * as + 1]);
+        while (!stack.empty()) {
+            const uint32_t v = stack.back();
+            if (renum[v] != 0xffffffffu) { stack.pop_back(); continue; }
+            const uint32_t op = ssa[3 * v];
+            uint32_t need[2], nn = 0;
+            if (is_bin(op)) { need[nn++] = ssa[3 * v + 1]; need[nn++] = ssa[3 * v + 2]; }
+            else if (is_un(op)) need[nn++] = ssa[3 * v + 1];
+            bool ready = true;
+            for (uint32_t j = nn; j-- > 0;)
+                if (renum[need[j]] == 0xffffffffu) { stack.push_back(need[j]); ready = false; }
+            if (ready) { emit(v); stack.pop_back(); }
+        }
+        emit(as);
+    }
+}
+
 // Register allocation of an SSA program (host) -> the interpreter's [op | flags, dst, a, b] words.
 //  * last-use allocation into the lowest free register (the LDS file is sized by the highest one used);
 //  * operand forwarding: the interpreter keeps the value of the last value-producing instruction in VGPRs (`prev`);
@@ -550,6 +628,7 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
         }
         if (op == ZC_CONST) ra = kb::to_monty(a % kb::P);
         if (zc_is_imm(op)) rb = kb::to_monty(b % kb::P);
+        if (op == ZC_ASSERT_ZERO) rb = b;         // the constraint's index (schedule_program)
         out->insert(out->end(), {word, dst, ra, rb});
     }
     *n_regs = busy.empty() ? 1u : (uint32_t)busy.size();
@@ -649,7 +728,7 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     const uint32_t n = (uint32_t)(c.prog.size() / 4);
     std::vector<uint32_t> reg(c.n_regs + 4, 0);
     Ext acc = kb::ext_zero();
-    uint32_t ci = 0, prev = 0;
+    uint32_t prev = 0;
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t opw = c.prog[4 * k], op = opw & 0xffu, dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
         const uint32_t A = (opw & ZC_A_PREV) ? prev : (op >= ZC_ADD && op != ZC_TOUCH ? reg[x] : 0u);
@@ -671,7 +750,7 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
             case ZC_SUBC: res = kb::sub(A, y); break;
             case ZC_CSUB: res = kb::sub(y, A); break;
             case ZC_MULC: res = kb::mul(A, y); break;
-            default: acc = acc + kb::ext_mul_base(c.alpha_pows[ci++], A); continue;
+            default: acc = acc + kb::ext_mul_base(c.alpha_pows[y], A); continue;
         }
         prev = res;
         if (!(opw & ZC_DST_TEMP)) reg[dst] = res;
@@ -807,11 +886,31 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (op == ZC_PUBLIC) SP1HIP_REQUIRE((int)a < n_publics, "public value index out of range");
         }
         SP1HIP_REQUIRE(asserts == chips[i].num_constraints, "num_constraints does not match the program");
-        std::vector<uint32_t> folded;
+        // fold constants into immediates, then pick the instruction order with the smallest register file
+        std::vector<uint32_t> folded, sched;
         fold_immediates(chips[i].program, chips[i].n_instr, &folded);
-        SP1HIP_TRY(allocate_registers(folded.data(), chips[i].n_instr, &c->prog, &c->n_regs));
-        SP1HIP_TRY(build_chunks(folded.data(), chips[i].n_instr, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT, &c->chunks));
-        SP1HIP_TRY(build_chunks(folded.data(), chips[i].n_instr, chips[i].main_width, chips[i].prep_width, 0xffffffffu, &c->mono));
+        static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
+        uint32_t best_regs = 0xffffffffu;
+        for (int mode = 0; mode < 3; mode++) {
+            if (forced_mode >= 0 && mode != forced_mode) continue;
+            std::vector<uint32_t> cand;
+            std::vector<Chunk> mono;
+            schedule_program(folded.data(), chips[i].n_instr, chips[i].main_width, mode, &cand);
+            SP1HIP_TRY(build_chunks(cand.data(), (uint32_t)(cand.size() / 3), chips[i].main_width, chips[i].prep_width, 0xffffffffu, &mono));
+            uint32_t regs = 0;
+            for (auto& ck : mono) regs = std::max(regs, ck.n_regs);
+            if (regs < best_regs) { best_regs = regs; sched.swap(cand); c->mono.swap(mono); }
+        }
+        const uint32_t n_sched = (uint32_t)(sched.size() / 3);
+        static const bool zc_debug = getenv("SP1HIP_ZC_DEBUG") != nullptr;
+        if (zc_debug) {
+            size_t mono_instr = 0;
+            for (auto& ck : c->mono) mono_instr += ck.prog.size() / 4;
+            fprintf(stderr, "[sp1hip zc] chip %d: %u ssa instrs, %u constraints, %u+%u cols -> undivided program %zu words, %u registers\n",
+                    i, chips[i].n_instr, chips[i].num_constraints, chips[i].main_width, chips[i].prep_width, mono_instr, best_regs);
+        }
+        SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &c->prog, &c->n_regs));
+        SP1HIP_TRY(build_chunks(sched.data(), n_sched, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT, &c->chunks));
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
         std::reverse(c->alpha_pows.begin(), c->alpha_pows.end());
