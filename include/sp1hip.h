@@ -202,6 +202,12 @@ int sp1hip_challenger_sample_ext(sp1hip_challenger_t* ch, sp1hip_ext_t* out);
 int sp1hip_challenger_sample_bits(sp1hip_challenger_t* ch, int bits, uint32_t* out);
 int sp1hip_challenger_check_witness(sp1hip_challenger_t* ch, int bits, uint32_t witness, int* ok);
 int sp1hip_challenger_grind(sp1hip_challenger_t* ch, int bits, uint32_t* witness, sp1hip_stream_t stream);
+/* Proof-of-work witnesses to USE instead of searching, in the order the proof grinds (a shard proof: LogUp-GKR 12 bits,
+ * BaseFold batching 5 bits, BaseFold queries `proof_of_work_bits`); canonical words, at most 4. The reference's rayon
+ * `find_any` (and its CUDA grind) return ANY valid witness, this library's search the smallest: a caller that replays a
+ * Rust-made proof injects that proof's witnesses and gets the same bytes. An injected witness the transcript rejects
+ * is an error (SP1HIP_ERROR_INVALID_ARGUMENT). Consumed by grind; cleared with n = 0. */
+int sp1hip_challenger_inject_pow_witnesses(sp1hip_challenger_t* ch, const uint32_t* witnesses, int n);
 /* 34 words: sponge state[16], n_in, in[8], n_out, out[8] */
 int sp1hip_challenger_state(const sp1hip_challenger_t* ch, uint32_t* out34);
 
@@ -369,6 +375,36 @@ typedef struct {
 int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint32_t* h_publics, int n_publics,
                        sp1hip_stacked_data_t* preprocessed, sp1hip_shard_params_t params, sp1hip_challenger_t* challenger,
                        uint8_t* h_proof, size_t* proof_len, sp1hip_stream_t stream);
+
+/* ---------------------------------------------------------------- the AirProver slot: setup / proving key
+ * `MachineVerifyingKey` (/root/reference/crates/hypercube/src/verifier/config.rs:L71-L81), Montgomery words. The
+ * septic digest is x[7] then y[7]. */
+typedef struct {
+    uint32_t pc_start[3];
+    uint32_t initial_global_cumulative_sum[14];
+    uint32_t preprocessed_commit[8];
+    uint32_t enable_untrusted_programs;
+} sp1hip_vk_t;
+typedef struct sp1hip_pk_s sp1hip_pk_t;
+
+/* `ShardProver::setup_from_preprocessed_data_and_traces` (/root/reference/crates/hypercube/src/prover/shard.rs:L406-L429),
+ * the body of `AirProver::setup_from_vk` once the preprocessed traces exist: commits them (one jagged round) and returns
+ * the proving key = that commitment round (`PreprocessedData`) + the verifying key it defines. `preprocessed_tables`:
+ * the column-major device tables of the chips that have preprocessed columns, in chip (name) order; they stay
+ * caller-owned and must outlive the key. */
+int sp1hip_setup(const sp1hip_table_t* preprocessed_tables, int n_tables, const uint32_t pc_start[3],
+                 const uint32_t initial_global_cumulative_sum[14], uint32_t enable_untrusted_programs,
+                 sp1hip_shard_params_t params, sp1hip_pk_t** out, sp1hip_stream_t stream);
+void sp1hip_pk_free(sp1hip_pk_t* pk);
+int sp1hip_pk_vk(const sp1hip_pk_t* pk, sp1hip_vk_t* out);
+/* `MachineVerifyingKey::observe_into` (config.rs:L97-L112): commit, pc_start, septic x / y, untrusted flag, 6 zeros. */
+int sp1hip_vk_observe_into(const sp1hip_vk_t* vk, sp1hip_challenger_t* challenger);
+/* `AirProver::prove_shard_with_pk` (shard.rs:L321-L345) from the generated traces on: a default challenger absorbs the
+ * verifying key, then `sp1hip_prove_shard`. `pow_witnesses` (canonical words, may be NULL / 0): see
+ * sp1hip_challenger_inject_pow_witnesses. */
+int sp1hip_prove_shard_with_pk(const sp1hip_pk_t* pk, const sp1hip_shard_chip_t* chips, int n_chips, const uint32_t* h_publics,
+                               int n_publics, const uint32_t* pow_witnesses, int n_pow_witnesses, uint8_t* h_proof, size_t* proof_len,
+                               sp1hip_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,15 @@ class ShardParams(C.Structure):
                 ("fri", FriConfig)]
 
 
+class Vk(C.Structure):
+    _fields_ = [("pc_start", C.c_uint32 * 3), ("initial_global_cumulative_sum", C.c_uint32 * 14),
+                ("preprocessed_commit", C.c_uint32 * 8), ("enable_untrusted_programs", C.c_uint32)]
+
+
+# status codes of include/sp1hip.h
+SUCCESS, ERROR_INVALID_ARGUMENT, ERROR_BUFFER_TOO_SMALL = 0, -1, -6
+
+
 class Sp1HipError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("sp1hip status %d: %s" % (status, message))
@@ -127,6 +136,7 @@ PROTOTYPES = [
     ("sp1hip_challenger_sample_bits", None, [_vp, _int, u32p]),
     ("sp1hip_challenger_check_witness", None, [_vp, _int, C.c_uint32, C.POINTER(_int)]),
     ("sp1hip_challenger_grind", None, [_vp, _int, u32p, _vp]),
+    ("sp1hip_challenger_inject_pow_witnesses", None, [_vp, u32p, _int]),
     ("sp1hip_challenger_state", None, [_vp, u32p]),
     ("sp1hip_commit_mles", None, [C.POINTER(Tensor), _int, _int, _int, u32p, C.POINTER(_vp), _vp]),
     ("sp1hip_basefold_data_free", "void", [_vp]),
@@ -145,6 +155,11 @@ PROTOTYPES = [
                                    u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_logup_gkr_prove", None, [C.POINTER(GkrChip), _int, _int, _vp, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_prove_shard", None, [C.POINTER(ShardChip), _int, u32p, _int, _vp, ShardParams, _vp, u8p, C.POINTER(_sz), _vp]),
+    ("sp1hip_setup", None, [C.POINTER(Table), _int, u32p, u32p, C.c_uint32, ShardParams, C.POINTER(_vp), _vp]),
+    ("sp1hip_pk_free", "void", [_vp]),
+    ("sp1hip_pk_vk", None, [_vp, C.POINTER(Vk)]),
+    ("sp1hip_vk_observe_into", None, [C.POINTER(Vk), _vp]),
+    ("sp1hip_prove_shard_with_pk", None, [_vp, C.POINTER(ShardChip), _int, u32p, _int, u32p, _int, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
                                       _vp, u8p, C.POINTER(_sz), _vp]),
 ]

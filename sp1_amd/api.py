@@ -171,6 +171,11 @@ class DuplexChallenger:
         check(_L().sp1hip_challenger_check_witness(self.h, bits, C.c_uint32(int(witness)), C.byref(ok)))
         return bool(ok.value)
 
+    def inject_pow_witnesses(self, witnesses):
+        """Canonical proof-of-work witnesses for the next grinds, in order (sp1hip_challenger_inject_pow_witnesses)."""
+        w = (C.c_uint32 * max(len(witnesses), 1))(*[int(x) for x in witnesses])
+        check(_L().sp1hip_challenger_inject_pow_witnesses(self.h, w, len(witnesses)))
+
     def grind(self, bits, stream=None):
         out = C.c_uint32()
         check(_L().sp1hip_challenger_grind(self.h, bits, C.byref(out), _stream_ptr(stream)))
@@ -409,7 +414,7 @@ class JaggedProver:
         args = [_ext_array(z_row), self.max_log_row_count, hs, len(rounds), _ext_array(flat) if flat.size else None, counts,
                 cfg, challenger.h]
         st = _L().sp1hip_jagged_prove(*args, None, C.byref(n), _stream_ptr(stream))
-        if st != -6:                                   # anything but BUFFER_TOO_SMALL is a real error
+        if st != _lib.ERROR_BUFFER_TOO_SMALL:                                   # anything but BUFFER_TOO_SMALL is a real error
             check(st)
             raise RuntimeError("size query unexpectedly succeeded")
         buf = (C.c_uint8 * n.value)()
@@ -441,7 +446,7 @@ def zerocheck(chips, max_log_row_count, zeta, openings, alpha, gkr_batch, public
     args = [arr, len(chips), max_log_row_count, _ext_array(zeta), _ext_array(openings), _ext(alpha), _ext(gkr_batch),
             pv.ctypes.data_as(_lib.u32p) if pv.size else None, int(pv.size), challenger.h]
     st = _L().sp1hip_zerocheck_prove(*args, None, C.byref(n), _stream_ptr(stream))
-    if st != -6:                                       # anything but BUFFER_TOO_SMALL is a real error
+    if st != _lib.ERROR_BUFFER_TOO_SMALL:                                       # anything but BUFFER_TOO_SMALL is a real error
         check(st)
         raise RuntimeError("size query unexpectedly succeeded")
     buf = (C.c_uint8 * n.value)()
@@ -463,7 +468,7 @@ def logup_gkr(chips, max_log_row_count, challenger, stream=None):
                          C.c_void_p(prep.words.data_ptr()) if prep is not None and rows and prog.prep_width else None, rows)
     n = C.c_size_t(0)
     st = _L().sp1hip_logup_gkr_prove(arr, len(chips), max_log_row_count, challenger.h, None, C.byref(n), _stream_ptr(stream))
-    if st != -6:
+    if st != _lib.ERROR_BUFFER_TOO_SMALL:
         check(st)
         raise RuntimeError("size query unexpectedly succeeded")
     buf = (C.c_uint8 * n.value)()
@@ -471,11 +476,7 @@ def logup_gkr(chips, max_log_row_count, challenger, stream=None):
     return C.string_at(buf, n.value)        # (slicing a c_uint8 array would build a list of ints first: ~20 ms per MB)
 
 
-def prove_shard(chips, public_values, preprocessed, max_log_row_count, log_stacking_height, batch_size, challenger,
-                log_blowup=2, num_queries=124, pow_bits=16, stream=None):
-    """ShardProver::prove_shard_with_data on the GPU (sp1hip_prove_shard). chips: [(AirProgram, InteractionProgram, main
-    ColMajor or None, prep ColMajor or None)] in name order; preprocessed: the StackedData of the preprocessed round
-    (JaggedProver.commit_multilinears over the preprocessed traces). Returns bincode(ShardProof)."""
+def _shard_chip_array(chips):
     arr = (ShardChip * len(chips))()
     keep = []
     for i, (air, inter, main, prep) in enumerate(chips):
@@ -487,17 +488,72 @@ def prove_shard(chips, public_values, preprocessed, max_log_row_count, log_stack
                            words.ctypes.data_as(_lib.u32p), words.size, air.main_width, air.prep_width,
                            C.c_void_p(main.words.data_ptr()) if rows else None,
                            C.c_void_p(prep.words.data_ptr()) if prep is not None and rows and air.prep_width else None, rows)
+    return arr, keep
+
+
+def prove_shard(chips, public_values, preprocessed, max_log_row_count, log_stacking_height, batch_size, challenger,
+                log_blowup=2, num_queries=124, pow_bits=16, stream=None):
+    """ShardProver::prove_shard_with_data on the GPU (sp1hip_prove_shard). chips: [(AirProgram, InteractionProgram, main
+    ColMajor or None, prep ColMajor or None)] in name order; preprocessed: the StackedData of the preprocessed round
+    (JaggedProver.commit_multilinears over the preprocessed traces). Returns bincode(ShardProof)."""
+    arr, keep = _shard_chip_array(chips)
     pv = np.ascontiguousarray(np.asarray(public_values, dtype=np.uint32).reshape(-1))
     params = ShardParams(max_log_row_count, log_stacking_height, batch_size, FriConfig(log_blowup, num_queries, pow_bits))
     n = C.c_size_t(0)
     args = [arr, len(chips), pv.ctypes.data_as(_lib.u32p) if pv.size else None, int(pv.size), preprocessed.h, params, challenger.h]
     st = _L().sp1hip_prove_shard(*args, None, C.byref(n), _stream_ptr(stream))
-    if st != -6:
+    if st != _lib.ERROR_BUFFER_TOO_SMALL:
         check(st)
         raise RuntimeError("size query unexpectedly succeeded")
     buf = (C.c_uint8 * n.value)()
     check(_L().sp1hip_prove_shard(*args, buf, C.byref(n), _stream_ptr(stream)))
     return C.string_at(buf, n.value)        # (slicing a c_uint8 array would build a list of ints first: ~20 ms per MB)
+
+
+class ProvingKey:
+    """`ProvingKey` of the AirProver slot: the preprocessed commitment round + the verifying key (sp1hip_setup).
+    Keeps the preprocessed device tables alive."""
+
+    def __init__(self, prep_tables, max_log_row_count, log_stacking_height, batch_size, pc_start=(0, 0, 0),
+                 initial_global_cumulative_sum=(0,) * 14, enable_untrusted_programs=0, log_blowup=2, num_queries=124, pow_bits=16,
+                 stream=None):
+        self.tables = list(prep_tables)
+        self.params = ShardParams(max_log_row_count, log_stacking_height, batch_size, FriConfig(log_blowup, num_queries, pow_bits))
+        arr = _table_array(self.tables)
+        pc = (C.c_uint32 * 3)(*[int(x) for x in pc_start])
+        cum = (C.c_uint32 * 14)(*[int(x) for x in initial_global_cumulative_sum])
+        h = C.c_void_p()
+        check(_L().sp1hip_setup(arr, len(self.tables), pc, cum, int(enable_untrusted_programs), self.params, C.byref(h),
+                                _stream_ptr(stream)))
+        self.h = h
+        vk = _lib.Vk()
+        check(_L().sp1hip_pk_vk(self.h, C.byref(vk)))
+        self.vk = vk
+        self.preprocessed_commit = np.array(list(vk.preprocessed_commit), dtype=np.uint32)
+
+    def observe_into(self, challenger):
+        """MachineVerifyingKey::observe_into."""
+        check(_L().sp1hip_vk_observe_into(C.byref(self.vk), challenger.h))
+
+    def prove_shard(self, chips, public_values, pow_witnesses=(), stream=None):
+        """AirProver::prove_shard_with_pk from the generated traces on -> bincode(ShardProof)."""
+        arr, keep = _shard_chip_array(chips)
+        pv = np.ascontiguousarray(np.asarray(public_values, dtype=np.uint32).reshape(-1))
+        w = (C.c_uint32 * max(len(pow_witnesses), 1))(*[int(x) for x in pow_witnesses])
+        n = C.c_size_t(0)
+        args = [self.h, arr, len(chips), pv.ctypes.data_as(_lib.u32p) if pv.size else None, int(pv.size), w, len(pow_witnesses)]
+        st = _L().sp1hip_prove_shard_with_pk(*args, None, C.byref(n), _stream_ptr(stream))
+        if st != _lib.ERROR_BUFFER_TOO_SMALL:
+            check(st)
+            raise RuntimeError("size query unexpectedly succeeded")
+        buf = (C.c_uint8 * n.value)()
+        check(_L().sp1hip_prove_shard_with_pk(*args, buf, C.byref(n), _stream_ptr(stream)))
+        return C.string_at(buf, n.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _L().sp1hip_pk_free(self.h)
+            self.h = None
 
 
 def parse_logup_gkr_proof(blob):

@@ -368,6 +368,7 @@ int sp1hip_basefold_batch(const sp1hip_tensor_t* tensors, int n_tensors, int lg_
     TensorTable tab;
     uint32_t tw;
     SP1HIP_TRY(make_tensor_table(tensors, n_tensors, &tab, &tw));
+    SP1HIP_REQUIRE(tw <= 65536, "more than 2^16 columns in one message (batch_kernel's unreduced accumulators hold 2^16 terms)");
     hipStream_t s = S(stream);
     const uint32_t height = 1u << lg_height;
     AsyncScratch cols;
@@ -434,6 +435,7 @@ int sp1hip_mle_eval_columns(const sp1hip_tensor_t* tensors, int n_tensors, int l
     uint32_t tw;
     SP1HIP_TRY(make_tensor_table(tensors, n_tensors, &tab, &tw));
     if (tw == 0) return SP1HIP_SUCCESS;
+    SP1HIP_REQUIRE(tw <= 65536, "more than 2^16 columns in one message (the unreduced accumulators hold 2^16 terms)");
     hipStream_t s = S(stream);
     const uint32_t height = 1u << lg_height;
     AsyncScratch cols, part;

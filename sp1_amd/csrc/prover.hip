@@ -48,6 +48,8 @@ struct DuplexChallenger {
     int n_in = 0;
     uint32_t out[8];
     int n_out = 0;
+    uint32_t injected[4];            // proof-of-work witnesses to use instead of searching (canonical), see grind()
+    int n_injected = 0, next_injected = 0;
 
     void duplexing() {
         for (int i = 0; i < n_in; i++) state[i] = in[i];
@@ -101,6 +103,15 @@ static int grind(DuplexChallenger& ch, int bits, uint32_t* witness_monty, hipStr
     const int pos = ch.n_in;
     const uint32_t mask = (1u << bits) - 1;
     uint32_t found = 0xffffffffu;
+    if (ch.next_injected < ch.n_injected) {       // the caller's witness (sp1hip_challenger_inject_pow_witnesses)
+        found = ch.injected[ch.next_injected++];
+        *witness_monty = kb::to_monty(found);
+        if (!ch.check_witness(bits, *witness_monty)) {
+            set_error("grind: the injected %d-bit proof-of-work witness %u is not valid at this point of the transcript", bits, found);
+            return SP1HIP_ERROR_INVALID_ARGUMENT;
+        }
+        return SP1HIP_SUCCESS;
+    }
     if (bits <= 8) {
         // expected <= 256 candidates: cheaper on the host than a launch + sync
         for (uint32_t w = 0; w < kb::P; w++) {
@@ -454,6 +465,14 @@ int sp1hip_challenger_check_witness(sp1hip_challenger_t* ch, int bits, uint32_t 
 int sp1hip_challenger_grind(sp1hip_challenger_t* ch, int bits, uint32_t* witness, sp1hip_stream_t stream) {
     SP1HIP_REQUIRE(ch && witness, "null argument");
     return grind(ch->ch, bits, witness, S(stream));
+}
+int sp1hip_challenger_inject_pow_witnesses(sp1hip_challenger_t* ch, const uint32_t* witnesses, int n) {
+    SP1HIP_REQUIRE(ch && n >= 0 && n <= 4 && (witnesses || n == 0), "bad argument");
+    for (int i = 0; i < n; i++) SP1HIP_REQUIRE(witnesses[i] < kb::P, "witness not a canonical field element");
+    for (int i = 0; i < n; i++) ch->ch.injected[i] = witnesses[i];
+    ch->ch.n_injected = n;
+    ch->ch.next_injected = 0;
+    return SP1HIP_SUCCESS;
 }
 int sp1hip_challenger_state(const sp1hip_challenger_t* ch, uint32_t* out34) {
     SP1HIP_REQUIRE(ch && out34, "null argument");

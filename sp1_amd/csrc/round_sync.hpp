@@ -112,10 +112,14 @@ struct RoundSyncHost {
         seq = h_slot[0];                   // continue the slot's sequence (its counter is zero between uses)
         return SP1HIP_SUCCESS;
     }
+    bool pending = false;                  // a kernel that will write this slot may still be in flight
     ~RoundSyncHost() {
+        // an early exit (error return, timeout) can leave a round kernel queued that still increments the counter and
+        // writes the sequence number: drain the stream before another prover may acquire the slot
+        if (d_counter && pending) (void)hipStreamSynchronize(s);
         if (d_counter) round_sync_release(RoundSyncSlot{d_counter, h_slot});
     }
-    RoundSync next() { seq++; return RoundSync{d_counter, (volatile uint32_t*)h_slot}; }
+    RoundSync next() { seq++; pending = true; return RoundSync{d_counter, (volatile uint32_t*)h_slot}; }
     // copies n_words sums (from slot[1..]) into out
     int wait(uint32_t* out, int n_words) {
         volatile uint32_t* slot = h_slot;
@@ -132,6 +136,7 @@ struct RoundSyncHost {
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        pending = false;
         for (int k = 0; k < n_words; k++) out[k] = slot[1 + k];
         return SP1HIP_SUCCESS;
     }
@@ -163,7 +168,11 @@ struct Mailbox {
         seq = h_slot[0];
         return SP1HIP_SUCCESS;
     }
-    ~Mailbox() { if (h_slot) mailbox_release(MailboxSlot{h_slot}); }
+    bool pending = false;
+    ~Mailbox() {
+        if (h_slot && pending) (void)hipStreamSynchronize(s);      // see ~RoundSyncHost
+        if (h_slot) mailbox_release(MailboxSlot{h_slot});
+    }
     // d_src[0 .. n_words) -> out, after everything already enqueued on the stream. n_words == 0: a pure fence.
     int fetch(const void* d_src, size_t n_words, void* out) {
         if (n_words > MAILBOX_WORDS) {           // too large for the slot: the classic pair
@@ -178,6 +187,7 @@ struct Mailbox {
     // that sequence number and copies the payload out.
     int wait_next(void* out, size_t n_words) {
         seq++;
+        pending = true;
         volatile uint32_t* slot = h_slot;
         const auto t0 = std::chrono::steady_clock::now();
         uint64_t spins = 0;
@@ -192,6 +202,7 @@ struct Mailbox {
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        pending = false;
         uint32_t* o = (uint32_t*)out;
         for (size_t k = 0; k < n_words; k++) o[k] = slot[1 + k];
         return SP1HIP_SUCCESS;
@@ -220,7 +231,12 @@ struct PinnedStage {
         h = b.h;
         return SP1HIP_SUCCESS;
     }
-    ~PinnedStage() { if (h) pinned_stage_release(PinnedBlock{h}); }
+    ~PinnedStage() {
+        // a DMA that still reads the block must finish before the block is handed to another prover; on the normal path
+        // the stream is already idle here (the caller has just received its last result), so the query is all it costs
+        if (h && used && hipStreamQuery(s) != hipSuccess) (void)hipStreamSynchronize(s);
+        if (h) pinned_stage_release(PinnedBlock{h});
+    }
     int upload(void* d_dst, const void* src, size_t bytes) {
         if (bytes == 0) return SP1HIP_SUCCESS;
         const size_t at = (used + 63) & ~(size_t)63;

@@ -228,4 +228,66 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     return SP1HIP_SUCCESS;
 }
 
+
+// ------------------------------------------------------------------------------------------- the AirProver slot
+// `setup_from_preprocessed_data_and_traces` (shard.rs:L406-L429): commit the preprocessed traces, keep the commitment
+// round (the proving key's PreprocessedData) next to the verifying key it defines.
+struct sp1hip_pk_s {
+    sp1hip_stacked_data_t* preprocessed = nullptr;
+    sp1hip_vk_t vk{};
+    sp1hip_shard_params_t params{};
+    ~sp1hip_pk_s() { if (preprocessed) sp1hip_stacked_data_free(preprocessed); }
+};
+
+int sp1hip_setup(const sp1hip_table_t* preprocessed_tables, int n_tables, const uint32_t pc_start[3],
+                 const uint32_t initial_global_cumulative_sum[14], uint32_t enable_untrusted_programs,
+                 sp1hip_shard_params_t params, sp1hip_pk_t** out, sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(preprocessed_tables && n_tables > 0 && pc_start && initial_global_cumulative_sum && out, "null argument");
+    for (int i = 0; i < 3; i++) SP1HIP_REQUIRE(pc_start[i] < kb::P, "pc_start not reduced");
+    for (int i = 0; i < 14; i++) SP1HIP_REQUIRE(initial_global_cumulative_sum[i] < kb::P, "cumulative sum not reduced");
+    SP1HIP_REQUIRE(enable_untrusted_programs < kb::P, "flag not reduced");
+    std::unique_ptr<sp1hip_pk_s> pk(new sp1hip_pk_s());
+    SP1HIP_TRY(sp1hip_jagged_commit(preprocessed_tables, n_tables, params.max_log_row_count, params.log_stacking_height,
+                                    params.batch_size, params.fri.log_blowup, pk->vk.preprocessed_commit, &pk->preprocessed, stream));
+    memcpy(pk->vk.pc_start, pc_start, 12);
+    memcpy(pk->vk.initial_global_cumulative_sum, initial_global_cumulative_sum, 56);
+    pk->vk.enable_untrusted_programs = enable_untrusted_programs;
+    pk->params = params;
+    *out = pk.release();
+    return SP1HIP_SUCCESS;
+}
+
+void sp1hip_pk_free(sp1hip_pk_t* pk) { delete pk; }
+
+int sp1hip_pk_vk(const sp1hip_pk_t* pk, sp1hip_vk_t* out) {
+    SP1HIP_REQUIRE(pk && out, "null argument");
+    *out = pk->vk;
+    return SP1HIP_SUCCESS;
+}
+
+// `MachineVerifyingKey::observe_into` (/root/reference/crates/hypercube/src/verifier/config.rs:L97-L112)
+int sp1hip_vk_observe_into(const sp1hip_vk_t* vk, sp1hip_challenger_t* challenger) {
+    SP1HIP_REQUIRE(vk && challenger, "null argument");
+    for (int k = 0; k < 8; k++) challenger_observe(challenger, vk->preprocessed_commit[k]);
+    for (int k = 0; k < 3; k++) challenger_observe(challenger, vk->pc_start[k]);
+    for (int k = 0; k < 14; k++) challenger_observe(challenger, vk->initial_global_cumulative_sum[k]);     // x[7] then y[7]
+    challenger_observe(challenger, vk->enable_untrusted_programs);
+    for (int k = 0; k < 6; k++) challenger_observe(challenger, 0u);                                        // the padding
+    return SP1HIP_SUCCESS;
+}
+
+// `AirProver::prove_shard_with_pk` (shard.rs:L321-L345) after trace generation: default challenger, vk.observe_into,
+// prove_shard_with_data.
+int sp1hip_prove_shard_with_pk(const sp1hip_pk_t* pk, const sp1hip_shard_chip_t* chips, int n_chips, const uint32_t* h_publics,
+                               int n_publics, const uint32_t* pow_witnesses, int n_pow_witnesses, uint8_t* h_proof, size_t* proof_len,
+                               sp1hip_stream_t stream) {
+    SP1HIP_REQUIRE(pk && proof_len, "null argument");
+    sp1hip_challenger_t* ch = nullptr;
+    SP1HIP_TRY(sp1hip_challenger_new(&ch));
+    struct ChGuard { sp1hip_challenger_t* c; ~ChGuard() { sp1hip_challenger_free(c); } } guard{ch};
+    SP1HIP_TRY(sp1hip_vk_observe_into(&pk->vk, ch));
+    if (n_pow_witnesses) SP1HIP_TRY(sp1hip_challenger_inject_pow_witnesses(ch, pow_witnesses, n_pow_witnesses));
+    return sp1hip_prove_shard(chips, n_chips, h_publics, n_publics, pk->preprocessed, pk->params, ch, h_proof, proof_len, stream);
+}
+
 }  // extern "C"

@@ -145,10 +145,11 @@ class _Memory:
         return addrs
 
 
-def generate(counts, seed=0):
+def generate(counts, seed=0, digest=None):
     """counts: {chip name: number of real rows} (MemoryVar rows hold 2 events each; PublicValues is always 16 rows
-    with 8 real ones). Returns ({name: (prep, main)} row-major Montgomery uint32 tables padded like the reference,
-    public values [187] Montgomery)."""
+    with 8 real ones). digest: 8 canonical field elements the shard commits as its public-values digest (written by 8
+    extra MemoryConst rows and read by the PublicValues chip); random memory cells by default. Returns
+    ({name: (prep, main)} row-major Montgomery uint32 tables padded like the reference, public values [187] Montgomery)."""
     rng = np.random.default_rng(seed)
     mem = _Memory(rng)
     rnd = lambda *shape: rng.integers(0, P, size=shape, dtype=np.int64).astype(U)
@@ -177,6 +178,12 @@ def generate(counts, seed=0):
     # MemoryConst: prep = value[4], addr, mult
     k = n["MemoryConst"]
     addrs, b = write_mixed(k)
+    digest_addrs = None
+    if digest is not None:
+        db = np.zeros((8, 4), dtype=U)
+        db[:, 0] = np.asarray(digest, dtype=U) % PP
+        digest_addrs = mem.write(db, felt=True)
+        addrs, b, k = np.concatenate([addrs, digest_addrs]), np.concatenate([b, db]), k + 8
     prep = np.zeros((_pad32(k), 6), dtype=U)
     prep[:k, 0:4], prep[:k, 4] = b, addrs + A0
     T["MemoryConst"] = [prep, np.zeros((_pad32(k), 1), dtype=U)]
@@ -285,7 +292,11 @@ def generate(counts, seed=0):
     prep_x[:k, 6] = addrs + A0
     writers.append(("PrefixSumChecks", 7, np.arange(k), addrs))
     # PublicValues: 16 rows, the first 8 commit digest word i: prep = pv_idx[8], addr, mult; main = the element
-    apv = mem.pick(8, mem.felt)
+    if digest_addrs is None:
+        apv = mem.pick(8, mem.felt)
+    else:
+        apv = digest_addrs
+        np.add.at(mem.reads, apv, 1)
     prep_v, main_v = np.zeros((16, 10), dtype=U), np.zeros((16, 1), dtype=U)
     prep_v[np.arange(8), np.arange(8)] = 1
     prep_v[:8, 8], prep_v[:8, 9], main_v[:8, 0] = apv + A0, 1, felt_of(apv)

@@ -51,7 +51,8 @@ def gather_blobs(blobs):
     max_len = max([int(m[:, 1].max().item()) for m in metas] + [1])
     payload = torch.zeros((max(max_n, 1), max_len), dtype=torch.uint8, device=dev)
     for k, (_, b) in enumerate(items):
-        payload[k, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        if len(b):                       # (torch.frombuffer rejects an empty buffer)
+            payload[k, :len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     payloads = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(payloads, payload)
     out = {}
@@ -104,6 +105,9 @@ def reduce_tree(leaf_blobs, n_leaves, combine, arity=2):
                     if src == owner:
                         if rank == owner:
                             have[c] = level[c]
+                    elif lens[c] == 0:           # an empty blob needs no message
+                        if rank == owner:
+                            have[c] = b""
                     elif rank == src:
                         t = torch.frombuffer(bytearray(level[c]), dtype=torch.uint8).to(dev)
                         keep.append(t)
@@ -123,3 +127,30 @@ def reduce_tree(leaf_blobs, n_leaves, combine, arity=2):
             nxt[j] = kids[0] if len(kids) == 1 else combine(kids)
         level, n = nxt, n_parents
     return level.get(0) if rank == 0 else None
+
+
+def recursion_combine(prove, counts, seed=0):
+    """A real `combine` for `reduce_tree`: the parent of a list of child proofs is a shard proof over the reference's
+    recursion compress machine (sp1_amd/machines/recursion.py) that COMMITS to its children — the eight words of its
+    public-values digest (RecursionPublicValues::digest, constrained by the PublicValues chip) are derived from the
+    children's bytes. The recursion *verifier program* that would check the children inside the VM is Rust and out of
+    scope; what travels through the tree and gets proven at every node is a genuine ShardProof of that
+    machine, produced by `prove(tables, public_values) -> bytes` (sp1hip_prove_shard behind `ProvingKey.prove_shard`
+    on a GPU rank; the CPU tests plug the oracle prover in).
+
+    counts: rows per chip of the parent's (random straight-line) recursion program, see recursion_trace.generate."""
+    import hashlib
+
+    from .machines import recursion_trace
+
+    def combine(children):
+        h = hashlib.sha256()
+        for c in children:
+            h.update(len(c).to_bytes(8, "little"))
+            h.update(c)
+        d = h.digest()
+        digest = [int.from_bytes(d[4 * i:4 * i + 4], "little") % recursion_trace.P for i in range(8)]
+        tables, publics = recursion_trace.generate(counts, seed=seed + len(children), digest=digest)
+        return prove(tables, publics)
+
+    return combine

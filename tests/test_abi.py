@@ -155,7 +155,8 @@ def test_ffi_struct_layouts_match_the_header(tmp_path):
     from sp1_amd import _lib
     pairs = {"sp1hip_ext_t": _lib.Ext, "sp1hip_tensor_t": _lib.Tensor, "sp1hip_table_t": _lib.Table,
              "sp1hip_host_table_t": _lib.HostTable, "sp1hip_fri_config_t": _lib.FriConfig, "sp1hip_zc_chip_t": _lib.ZcChip,
-             "sp1hip_gkr_chip_t": _lib.GkrChip, "sp1hip_shard_chip_t": _lib.ShardChip, "sp1hip_shard_params_t": _lib.ShardParams}
+             "sp1hip_gkr_chip_t": _lib.GkrChip, "sp1hip_shard_chip_t": _lib.ShardChip, "sp1hip_shard_params_t": _lib.ShardParams,
+             "sp1hip_vk_t": _lib.Vk}
     header = open(os.path.join(ROOT, "include", "sp1hip.h")).read()
     declared = set(re.findall(r"}\s*(sp1hip_\w+_t)\s*;", header))
     assert declared == set(pairs), "a struct of the header has no ctypes mirror (or the other way round): %s" % (declared ^ set(pairs))
@@ -180,3 +181,67 @@ def test_ffi_struct_layouts_match_the_header(tmp_path):
         assert int(value) == want, (cname, field, value, want)
         seen += 1
     assert seen == sum(1 + len(c._fields_) for c in pairs.values())
+
+
+def test_status_constants_match_the_header():
+    from sp1_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "sp1hip.h")).read()
+    codes = dict((k, int(v)) for k, v in re.findall(r"SP1HIP_(\w+)\s*=\s*(-?\d+)", hdr))
+    assert codes["SUCCESS"] == _lib.SUCCESS and codes["ERROR_INVALID_ARGUMENT"] == _lib.ERROR_INVALID_ARGUMENT
+    assert codes["ERROR_BUFFER_TOO_SMALL"] == _lib.ERROR_BUFFER_TOO_SMALL
+
+
+def test_vk_observe_into_replays_the_head_of_the_reference_transcript(lib):
+    """`sp1hip_vk_observe_into` = MachineVerifyingKey::observe_into (/root/reference/crates/hypercube/src/verifier/config.rs:L97-L112).
+    The reference's real (vk, proof) pair starts its transcript with exactly that call: feeding the real vk's fields through
+    the entry point must land in the state the tape has when the shard proof starts."""
+    import transcript_tape as tt
+    from sp1_amd import _lib, api
+    T = tt.TAPE
+    k = int(T["shard_start_op"])
+    ref = orc.Challenger()
+    assert tt.replay(ref, stop_before_op=k)[0] == k
+    words = []
+    for op, arg, off, _ in T["ops"][:k]:
+        assert op == 0                                            # the head of the transcript only observes
+        words += list(orc.to_monty(T["data"][off:off + arg]))
+    assert len(words) == 8 + 3 + 14 + 1 + 6 and not any(words[-6:])
+    vk = _lib.Vk()
+    vk.preprocessed_commit[:] = words[0:8]
+    vk.pc_start[:] = words[8:11]
+    vk.initial_global_cumulative_sum[:] = words[11:25]
+    vk.enable_untrusted_programs = words[25]
+    ch = api.DuplexChallenger()
+    assert lib.sp1hip_vk_observe_into(C.byref(vk), ch.h) == 0
+    assert np.array_equal(ch.state(), ref.state())
+
+
+def test_injected_pow_witness_is_used_and_checked(lib):
+    """The witness-injection knob: grind returns the SMALLEST witness by default, the caller's when
+    one is injected (so a Rust-made proof's `find_any` witness can be replayed), and refuses an invalid one."""
+    from sp1_amd import _lib, api
+    base = api.DuplexChallenger()
+    base.observe(orc.to_monty(np.arange(1, 12, dtype=np.uint32)))
+    bits = 6
+    valid = []
+    w = 0
+    while len(valid) < 3:                                         # host path (bits <= 8): no device needed
+        if base.clone().check_witness(bits, int(orc.to_monty(np.array([w], np.uint32))[0])):
+            valid.append(w)
+        w += 1
+    def grind(ch):                                                # (api.grind takes a torch stream; no device here)
+        out = C.c_uint32()
+        st = lib.sp1hip_challenger_grind(ch.h, bits, C.byref(out), None)
+        return st, int(orc.from_monty(np.array([out.value], np.uint32))[0])
+
+    a = base.clone()
+    assert grind(a) == (0, valid[0])
+    b = base.clone()
+    b.inject_pow_witnesses([valid[2]])
+    assert grind(b) == (0, valid[2])
+    assert not np.array_equal(a.state(), b.state())
+    assert grind(b)[0] == 0                                       # queue consumed: back to searching
+    c = base.clone()
+    invalid = next(x for x in range(valid[2]) if x not in valid)
+    c.inject_pow_witnesses([invalid])
+    assert grind(c)[0] == _lib.ERROR_INVALID_ARGUMENT and b"injected" in lib.sp1hip_last_error()

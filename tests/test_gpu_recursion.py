@@ -82,3 +82,50 @@ def test_recursion_shard_at_a_sixteenth_of_the_reference_shape_verifies(api):
     v.observe(commit)
     proof = api.prove_shard(dev2, pv, prep, L, lsh, 32, ch)
     assert orc.shard_verify(_shapes_only(m), commit, proof, L, lsh, v, 2, 124, 16) != 0
+
+
+def test_proving_key_slot_and_pow_witness_injection(api):
+    """The AirProver-shaped entry points: sp1hip_setup (commit the preprocessed traces -> pk + vk), sp1hip_vk_observe_into,
+    sp1hip_prove_shard_with_pk. Same bytes as the stage-by-stage path; and a caller-supplied proof-of-work witness is used
+    (the reference's `find_any` returns any valid one, this library the smallest): the proof changes, still verifies."""
+    import struct
+    counts = {"BaseAlu": 70, "ExtAlu": 90, "MemoryConst": 50, "MemoryVar": 40, "Poseidon2WideDeg3": 20, "PrefixSumChecks": 33, "Select": 100}
+    L, lsh, batch, fri = 8, 7, 4, (1, 5, 4)
+    tabs, pv = RT.generate(counts, seed=21)
+    m = R.compress_machine()
+    dev = _device_chips(api, m, tabs)
+    pc_start = orc.to_monty(np.array([3, 1, 4], np.uint32))
+    cum = orc.to_monty(np.arange(100, 114, dtype=np.uint32))
+    pk = api.ProvingKey([d[3] for d in dev], L, lsh, batch, pc_start, cum, 0, *fri)
+    got = pk.prove_shard(dev, pv)
+    # the same through the stage-level API
+    jp = api.JaggedProver(L, lsh, batch, fri[0])
+    commit, prep = jp.commit_multilinears([d[3] for d in dev])
+    assert np.array_equal(commit, pk.preprocessed_commit)
+    ch = api.DuplexChallenger()
+    pk.observe_into(ch)
+    head = ch.clone()
+    assert api.prove_shard(dev, pv, prep, L, lsh, batch, ch, *fri) == got
+    # oracle verifier from the same transcript head: vk.observe_into = commit, pc_start, septic x/y, flag, 6 zeros
+    v = orc.Challenger()
+    v.observe(np.concatenate([commit, pc_start, cum, np.zeros(7, np.uint32)]))
+    assert np.array_equal(v.state(), head.state())
+    assert orc.shard_verify(_shapes_only(m), commit, got, L, lsh, v.clone(), *fri) == 0
+    # an alternative witness for the first grind (LogUp-GKR, 12 bits): rebuild the transcript up to that point
+    t = head.clone()
+    t.observe(pv)
+    n_pv = struct.unpack_from("<Q", got, 0)[0]
+    main_commit = orc.to_monty(np.frombuffer(got, dtype=np.uint32, count=8, offset=8 + 4 * n_pv))
+    t.observe(main_commit)
+    t.observe(orc.to_monty(np.array([len(m)], np.uint32)))
+    for a, _ in m:
+        name = a.name.encode()
+        t.observe(orc.to_monty(np.array([tabs[a.name][1].shape[0], len(name)] + list(name), np.uint32)))
+    valid = [w for w in range(40000) if t.clone().check_witness(12, int(orc.to_monty(np.array([w], np.uint32))[0]))][:2]
+    assert len(valid) == 2
+    other = pk.prove_shard(dev, pv, pow_witnesses=[valid[1]])
+    assert other != got and len(other) == len(got)
+    assert orc.shard_verify(_shapes_only(m), commit, other, L, lsh, v.clone(), *fri) == 0
+    assert pk.prove_shard(dev, pv, pow_witnesses=[valid[0]]) == got           # the smallest one is the default
+    with pytest.raises(api._lib.Sp1HipError):
+        pk.prove_shard(dev, pv, pow_witnesses=[valid[0] + 1 if valid[0] + 1 != valid[1] else valid[0] + 2])

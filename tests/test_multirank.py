@@ -112,3 +112,93 @@ def test_single_process_helpers():
     assert shards.stripe(5, 1, 0) == [0, 1, 2, 3, 4]
     assert shards.max_over_ranks(3.5) == 3.5
     assert shards.gather_blobs({2: b"ab"}) == {2: b"ab"}
+
+
+# ---- the compress tree with REAL proofs: every node is a ShardProof of the reference's recursion machine ------------------
+_COUNTS = {"BaseAlu": 20, "ExtAlu": 20, "MemoryConst": 30, "MemoryVar": 10, "Poseidon2WideDeg3": 4, "PrefixSumChecks": 8, "Select": 20}
+_L, _LSH, _BATCH, _FRI = 7, 6, 4, (1, 5, 4)
+
+
+def _oracle_prove(tables, publics):
+    """prove(tables, publics) for shards.recursion_combine on a rank without a GPU: the CPU oracle (tests may use it). The blob
+    that travels is the node's preprocessed commitment (its verifying key) followed by bincode(ShardProof)."""
+    import pyoracle as orc
+    from sp1_amd.machines import recursion as R
+    chips = [(a, i, tables[a.name][1], tables[a.name][0]) for a, i in R.compress_machine()]
+    prep = orc.JaggedRound([c[3] for c in chips], _L, _LSH, _BATCH, _FRI[0])
+    ch = orc.Challenger()
+    ch.observe(prep.commit)
+    return prep.commit.tobytes() + orc.shard_prove(chips, publics, prep, _L, _LSH, _BATCH, ch, *_FRI)
+
+
+def _verify_node(blob):
+    import numpy as np
+    import pyoracle as orc
+    from sp1_amd.machines import recursion as R
+    commit = np.frombuffer(blob[:32], dtype=np.uint32).copy()
+    shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32)) for a, i in R.compress_machine()]
+    ch = orc.Challenger()
+    ch.observe(commit)
+    return orc.shard_verify(shapes, commit, blob[32:], _L, _LSH, ch, *_FRI)
+
+
+def _leaf_proof(i):
+    from sp1_amd.machines import recursion_trace as RT
+    tables, publics = RT.generate(_COUNTS, seed=100 + i)
+    return _oracle_prove(tables, publics)
+
+
+def _real_tree_worker(rank, world, port, n_leaves, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sp1_amd import shards
+    leaves = {i: _leaf_proof(i) for i in shards.stripe(n_leaves, world, rank)}
+    root = shards.reduce_tree(leaves, n_leaves, shards.recursion_combine(_oracle_prove, _COUNTS, seed=7), 2)
+    dist.barrier()
+    q.put((rank, root))
+    dist.destroy_process_group()
+
+
+def test_compress_tree_moves_and_verifies_real_recursion_proofs_gloo():
+    """world 2, 3 leaves: every leaf and every parent is a real ShardProof over the reference's recursion compress machine
+    (the transcription the reference's own proof pins); parents commit to their children through the public-values digest
+    (`shards.recursion_combine`). The root that arrives on rank 0 is byte-identical to the single-process tree, the full
+    verifier accepts it, and its committed digest is the hash of the two blobs that were sent to its rank."""
+    import hashlib
+    import struct
+
+    import __graft_entry__ as g
+    g.build_hip()
+    g.build_oracle()
+    from sp1_amd import shards
+    from sp1_amd.machines import recursion as R
+    n_leaves, world = 3, 2
+    combine = shards.recursion_combine(_oracle_prove, _COUNTS, seed=7)
+    leaves = {i: _leaf_proof(i) for i in range(n_leaves)}
+    want = shards.reduce_tree(leaves, n_leaves, combine, 2)
+    assert all(_verify_node(b) == 0 for b in leaves.values()) and _verify_node(want) == 0
+    # the root's committed digest = sha256 of its children [parent(leaf0, leaf1), leaf2]
+    kids = [combine([leaves[0], leaves[1]]), leaves[2]]
+    h = hashlib.sha256()
+    for c in kids:
+        h.update(len(c).to_bytes(8, "little"))
+        h.update(c)
+    d = h.digest()
+    digest = [int.from_bytes(d[4 * i:4 * i + 4], "little") % 0x7F000001 for i in range(8)]
+    proof = want[32:]
+    assert struct.unpack_from("<Q", proof, 0)[0] == R.NUM_PUBLIC_VALUES
+    assert list(struct.unpack_from("<8I", proof, 8 + 4 * R.PV_DIGEST_OFFSET)) == digest
+    port = 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_real_tree_worker, args=(r, world, port, n_leaves, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0] == want and results[1] is None
+    bad = bytearray(want)
+    bad[32 + 8 + 4 * R.PV_DIGEST_OFFSET] ^= 1                      # a parent that lies about its children is rejected
+    assert _verify_node(bytes(bad)) != 0
