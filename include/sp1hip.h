@@ -376,6 +376,27 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
                        sp1hip_stacked_data_t* preprocessed, sp1hip_shard_params_t params, sp1hip_challenger_t* challenger,
                        uint8_t* h_proof, size_t* proof_len, sp1hip_stream_t stream);
 
+/* ---------------------------------------------------------------- device trace generation (recursion machine)
+ * `CudaTracegenAir::generate_trace_device` of the recursion chips
+ * (/root/reference/sp1-gpu/crates/tracegen/src/recursion/{alu_base,alu_ext,select,poseidon2_wide,prefix_sum_checks}.rs, mod.rs):
+ * d_events = the execution record's event array copied to the device as is (Montgomery words in the `#[repr(C)]` layout
+ * of /root/reference/crates/recursion/executor/src/lib.rs: BaseAluIo 3 words, ExtAluIo<Block> 12, SelectIo 5, MemEvent 4,
+ * PrefixSumChecksEvent 20, Poseidon2Event 32 = input[16] | output[16]); d_trace = the chip's main trace, column-major
+ * [width][height] (widths 3, 12, 5, 8, 15, 179), rows past the events are the reference's padding rows (zeros; for
+ * Poseidon2 the permutation trace of the zero state). height >= the number of event rows (MemoryVar: 2 events per row). */
+int sp1hip_tracegen_recursion_base_alu(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
+                                       sp1hip_stream_t stream);
+int sp1hip_tracegen_recursion_ext_alu(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
+                                      sp1hip_stream_t stream);
+int sp1hip_tracegen_recursion_select(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
+                                     sp1hip_stream_t stream);
+int sp1hip_tracegen_recursion_memory_var(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
+                                         sp1hip_stream_t stream);
+int sp1hip_tracegen_recursion_prefix_sum_checks(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
+                                                sp1hip_stream_t stream);
+int sp1hip_tracegen_recursion_poseidon2_wide(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
+                                             sp1hip_stream_t stream);
+
 /* ---------------------------------------------------------------- the AirProver slot: setup / proving key
  * `MachineVerifyingKey` (/root/reference/crates/hypercube/src/verifier/config.rs:L71-L81), Montgomery words. The
  * septic digest is x[7] then y[7]. */

@@ -155,6 +155,12 @@ PROTOTYPES = [
                                    u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_logup_gkr_prove", None, [C.POINTER(GkrChip), _int, _int, _vp, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_prove_shard", None, [C.POINTER(ShardChip), _int, u32p, _int, _vp, ShardParams, _vp, u8p, C.POINTER(_sz), _vp]),
+    ("sp1hip_tracegen_recursion_base_alu", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_tracegen_recursion_ext_alu", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_tracegen_recursion_select", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_tracegen_recursion_memory_var", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_tracegen_recursion_prefix_sum_checks", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_tracegen_recursion_poseidon2_wide", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_setup", None, [C.POINTER(Table), _int, u32p, u32p, C.c_uint32, ShardParams, C.POINTER(_vp), _vp]),
     ("sp1hip_pk_free", "void", [_vp]),
     ("sp1hip_pk_vk", None, [_vp, C.POINTER(Vk)]),

@@ -510,6 +510,24 @@ def prove_shard(chips, public_values, preprocessed, max_log_row_count, log_stack
     return C.string_at(buf, n.value)        # (slicing a c_uint8 array would build a list of ints first: ~20 ms per MB)
 
 
+# main-trace widths and events per row of the recursion chips with device trace generation (sp1hip_tracegen_recursion_*)
+RECURSION_TRACEGEN = {"BaseAlu": ("base_alu", 3, 3, 1), "ExtAlu": ("ext_alu", 12, 12, 1), "Select": ("select", 5, 5, 1),
+                      "MemoryVar": ("memory_var", 8, 4, 2), "PrefixSumChecks": ("prefix_sum_checks", 15, 20, 1),
+                      "Poseidon2WideDeg3": ("poseidon2_wide", 179, 32, 1)}
+
+
+def tracegen_recursion(chip, events, height, stream=None):
+    """Main trace of a recursion chip generated on the device from its event array (`generate_trace_device`).
+    events: [n_events][event_words] uint32 Montgomery words (numpy, or an int32 device tensor). Returns a ColMajor."""
+    fn, width, event_words, _ = RECURSION_TRACEGEN[chip]
+    if isinstance(events, np.ndarray):
+        events = to_device(np.ascontiguousarray(events, dtype=np.uint32).reshape(-1, event_words))
+    n = events.numel() // event_words
+    out = device_words(int(height) * width)
+    check(getattr(_L(), "sp1hip_tracegen_recursion_" + fn)(_dptr(out), int(height), _dptr(events) if n else None, n, _stream_ptr(stream)))
+    return ColMajor(out, int(height), width)
+
+
 class ProvingKey:
     """`ProvingKey` of the AirProver slot: the preprocessed commitment round + the verifying key (sp1hip_setup).
     Keeps the preprocessed device tables alive."""
