@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void batch_kernel(const uint32_t* const* __res
     kb::dot_init(acc);
     for (uint32_t g = 0; g < total_width; g++) {
         const kb::Ext c{{coeffs[4 * g], coeffs[4 * g + 1], coeffs[4 * g + 2], coeffs[4 * g + 3]}};   // wave-uniform
-        kb::dot_add(acc, c, cols[g][row]);
+        kb::dot_add(acc, c, gptr(cols[g])[row]);
     }
     const kb::Ext r = kb::dot_finish(acc);
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void eval_columns_partial_kernel(const uint32_
         for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * height + r];
 #pragma unroll
         for (int c = 0; c < EVAL_COLS; c++)
-            if (g0 + c < total_width) kb::dot_add(dacc[c], e, cols[g0 + c][r]);
+            if (g0 + c < total_width) kb::dot_add(dacc[c], e, gptr(cols[g0 + c])[r]);
     }
     uint32_t acc[EVAL_COLS][4];
 #pragma unroll

@@ -11,6 +11,17 @@
 
 namespace sp1hip {
 
+// Pointers that reach a kernel INSIDE a descriptor / pointer table read from memory are generic pointers to the compiler,
+// which then emits FLAT loads and stores (address-space check per lane, both memory counters, no scalar base). gptr()
+// restores the global address space at the access site; q4 is the 16-byte word extension elements travel as.
+typedef uint32_t q4_t __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ const __attribute__((address_space(1))) T* gptr(const T* p) {
+    return (const __attribute__((address_space(1))) T*)p;
+}
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T* gptr(T* p) {
+    return (__attribute__((address_space(1))) T*)p;
+}
+
 void set_error(const char* fmt, ...);
 int map_hip_error(hipError_t e, const char* what);
 

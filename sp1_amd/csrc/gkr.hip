@@ -50,11 +50,12 @@ struct DeviceBuf : AsyncScratch {
 };
 
 __device__ __forceinline__ Ext ld_ext(const Ext* p, uint32_t i) {
-    const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+    const q4_t v = gptr(reinterpret_cast<const q4_t*>(p))[i];
     return Ext{{v.x, v.y, v.z, v.w}};
 }
 __device__ __forceinline__ void st_ext(Ext* p, uint32_t i, const Ext& e) {
-    reinterpret_cast<uint4*>(p)[i] = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]);
+    const q4_t v = {e.c[0], e.c[1], e.c[2], e.c[3]};
+    gptr(reinterpret_cast<q4_t*>(p))[i] = v;
 }
 
 // ---- block reduction of NS ext accumulators -> partials[block][4 NS]
@@ -107,13 +108,14 @@ struct IntDesc {
     Ext* d_out;                // ext denominators [rows]
 };
 
-__device__ __forceinline__ uint32_t vcol_apply(const uint32_t*& p, const IntDesc& d, uint32_t r) {
+typedef const uint32_t __attribute__((address_space(4)))* prog_words_t;      // interaction programs: wave-uniform, read-only -> scalar loads
+__device__ __forceinline__ uint32_t vcol_apply(prog_words_t& p, const IntDesc& d, uint32_t r) {
     const uint32_t nt = p[0];
     uint32_t acc = p[1];                                   // constant (Montgomery)
     p += 2;
     for (uint32_t t = 0; t < nt; t++, p += 3) {
         const uint32_t* col = (p[0] ? d.main : d.prep) + (size_t)p[1] * d.rows;
-        acc = kb::add(acc, kb::mul(col[r], p[2]));
+        acc = kb::add(acc, kb::mul(gptr(col)[r], p[2]));
     }
     return acc;
 }
@@ -122,7 +124,7 @@ __device__ __forceinline__ uint32_t vcol_apply(const uint32_t*& p, const IntDesc
 __global__ __launch_bounds__(256) void first_layer_kernel(const IntDesc* __restrict__ descs, Ext alpha, const Ext* __restrict__ betas) {
     const IntDesc d = descs[blockIdx.y];
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < d.rows; r += gridDim.x * blockDim.x) {
-        const uint32_t* p = d.prog;
+        prog_words_t p = (prog_words_t)(uintptr_t)d.prog;
         const bool is_send = p[0] != 0;
         const uint32_t kind = p[1], nv = p[2];            // kind: Montgomery form
         p += 3;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const IntDesc* __restr
         if (!is_send) m = kb::sub(0u, m);
         Ext den = kb::ext_add(alpha, kb::ext_mul_base(ld_ext(betas, 0), kind));
         for (uint32_t j = 0; j < nv; j++) den = kb::ext_add(den, kb::ext_mul_base(ld_ext(betas, 1 + j), vcol_apply(p, d, r)));
-        d.n_out[r] = m;
+        gptr(d.n_out)[r] = m;
         st_ext(d.d_out, r, den);
     }
 }
@@ -146,7 +148,7 @@ struct TransDesc {
 
 template <bool NBASE>
 __device__ __forceinline__ Ext load_n(const void* p, uint32_t i) {
-    if (NBASE) return kb::ext_from_base(((const uint32_t*)p)[i]);
+    if (NBASE) return kb::ext_from_base(gptr((const uint32_t*)p)[i]);
     return ld_ext((const Ext*)p, i);
 }
 
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void transition_kernel(const TransDesc* __rest
             const Ext db = ld_ext(d.d_in, 2 * r + 1);
             Ext n;
             if (NBASE) {
-                const uint32_t na = ((const uint32_t*)d.n_in)[2 * r], nb = ((const uint32_t*)d.n_in)[2 * r + 1];
+                const uint32_t na = gptr((const uint32_t*)d.n_in)[2 * r], nb = gptr((const uint32_t*)d.n_in)[2 * r + 1];
                 n = kb::ext_add(kb::ext_mul_base(db, na), kb::ext_mul_base(da, nb));
             } else {
                 n = kb::ext_add(kb::ext_mul(db, load_n<false>(d.n_in, 2 * r)), kb::ext_mul(da, load_n<false>(d.n_in, 2 * r + 1)));
@@ -280,16 +282,24 @@ __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restric
     const uint32_t pairs = (rows_out + 1) / 2;
     const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
     for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        // every load of the iteration is issued before the first use: one exposed memory latency per iteration instead
+        // of three (rows of h = 0, rows of h = 1, eq table), at the price of ~40 more live VGPRs
+        Quad in[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) in[q] = load_quad<FIRST, NBASE>(d, 4 * k + q);
+        Ext ta, tb;
+        if (SUM) { ta = ld_ext(T_next, 2 * k); tb = ld_ext(T_next, 2 * k + 1); }
         Quad o[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t ro = 2 * k + h;
-            const Quad a = load_quad<FIRST, NBASE>(d, 2 * ro), b = load_quad<FIRST, NBASE>(d, 2 * ro + 1);
+            const Quad& a = in[2 * h];
+            const Quad& b = in[2 * h + 1];
             o[h].n0 = lerp(a.n0, b.n0, alpha); o[h].d0 = lerp(a.d0, b.d0, alpha);
             o[h].n1 = lerp(a.n1, b.n1, alpha); o[h].d1 = lerp(a.d1, b.d1, alpha);
             if (ro < rows_out) { st_ext(d.dst[0], ro, o[h].n0); st_ext(d.dst[1], ro, o[h].d0); st_ext(d.dst[2], ro, o[h].n1); st_ext(d.dst[3], ro, o[h].d1); }
         }
-        if (SUM) accumulate_pair(o[0], o[1], lambda, ld_ext(T_next, 2 * k), ld_ext(T_next, 2 * k + 1), acc);
+        if (SUM) accumulate_pair(o[0], o[1], lambda, ta, tb, acc);
     }
     if (SUM) {
         const Ext w = ld_ext(eq_int, d.eq_int_index);
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(256) void open_columns_kernel(const OpenDesc* __res
         const Ext e{{eq[r], eq[eq_len + r], eq[2 * (size_t)eq_len + r], eq[3 * (size_t)eq_len + r]}};
 #pragma unroll
         for (int c = 0; c < OPEN_COLS; c++)
-            if (d.col0 + c < d.width) kb::dot_add(acc[c], e, d.cols[(size_t)(d.col0 + c) * d.rows + r]);
+            if (d.col0 + c < d.width) kb::dot_add(acc[c], e, gptr(d.cols)[(size_t)(d.col0 + c) * d.rows + r]);
     }
     __shared__ uint32_t sm[4][4 * OPEN_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

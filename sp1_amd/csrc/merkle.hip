@@ -70,14 +70,14 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const uint32_t* const* _
     const uint32_t full = total_width >> 3;
     for (uint32_t k = 0; k < full; k++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) d[j] = (double)cols[8 * k + j][row];
+        for (int j = 0; j < 8; j++) d[j] = (double)gptr(cols[8 * k + j])[row];
         p2::permute_f64(d, *rc);
     }
     const uint32_t rem = total_width & 7u;
     if (rem) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if ((uint32_t)j < rem) d[j] = (double)cols[8 * full + j][row];
+            if ((uint32_t)j < rem) d[j] = (double)gptr(cols[8 * full + j])[row];
         p2::permute_f64(d, *rc);
     }
     uint32_t s[16];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void leaf_hash_part_kernel(const uint32_t* con
     const uint32_t full = width >> 3;
     for (uint32_t k = 0; k < full; k++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) d[j] = (double)cols[8 * k + j][row];
+        for (int j = 0; j < 8; j++) d[j] = (double)gptr(cols[8 * k + j])[row];
         p2::permute_f64(d, *rc);
     }
     if (LAST) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void leaf_hash_part_kernel(const uint32_t* con
         if (rem) {
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if ((uint32_t)j < rem) d[j] = (double)cols[8 * full + j][row];
+                if ((uint32_t)j < rem) d[j] = (double)gptr(cols[8 * full + j])[row];
             p2::permute_f64(d, *rc);
         }
         uint32_t s[16];
@@ -250,7 +250,7 @@ __global__ void open_values_kernel(const uint32_t* const* __restrict__ cols, uin
     if (t >= n_idx * total_width) return;
     size_t q = t / total_width;
     uint32_t g = (uint32_t)(t % total_width);
-    values[t] = cols[g][indices[q]];
+    values[t] = gptr(cols[g])[indices[q]];
 }
 
 // paths[q][k][0..8] = layer_k[(idx >> k) ^ 1]; one lane per (q, k, half-digest)

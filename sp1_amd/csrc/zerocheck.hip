@@ -327,13 +327,13 @@ __global__ __launch_bounds__(256) void zc_fix_kernel(const ZcFixDesc* __restrict
     typename K::T y = (2 * i + 1 < d.rows) ? K::load(d.in, c, d.rows, 2 * i + 1) : K::zero();
     const kb::Ext r = kb::ext_add(K::scale(alpha, K::sub(y, x)), K::to_ext(x));
 #pragma unroll
-    for (int q = 0; q < 4; q++) d.out[((size_t)c * 4 + q) * out_rows + i] = r.c[q];
+    for (int q = 0; q < 4; q++) gptr(d.out)[((size_t)c * 4 + q) * out_rows + i] = r.c[q];
 }
 
 struct ZcGatherDesc { const uint32_t* src; uint32_t n_words, dst_off; };
 __global__ __launch_bounds__(256) void zc_gather_kernel(const ZcGatherDesc* __restrict__ descs, uint32_t* __restrict__ out) {
     const ZcGatherDesc d = descs[blockIdx.x];
-    for (uint32_t i = threadIdx.x; i < d.n_words; i += 256) out[d.dst_off + i] = d.src[i];
+    for (uint32_t i = threadIdx.x; i < d.n_words; i += 256) out[d.dst_off + i] = gptr(d.src)[i];
 }
 
 // ------------------------------------------------------------------------------------------ host side
