@@ -200,7 +200,7 @@ template <bool FIRST, int MAXR, bool STAGED>
 __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict__ descs, int n_descs,
                                                        const uint32_t* __restrict__ eq, uint32_t eq_len,
                                                        const uint32_t* __restrict__ publics, uint32_t* __restrict__ partial,
-                                                       uint32_t rf_off, uint32_t block_base) {
+                                                       uint32_t rf_off, uint32_t block_base, uint32_t fused_flag) {
     using K = KT<FIRST>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* red = lds;                                   // [4][8] reduction scratch
@@ -211,10 +211,12 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
         reg.stride = blockDim.x;
     }
     if (threadIdx.x < 32) red[threadIdx.x] = 0;            // workgroups narrower than 4 waves leave slots untouched
-    // the three nodes of one block of row pairs are CONSECUTIVE workgroups: they are dispatched together (to
-    // different XCDs), so the second and third read of the same table rows hit the memory-side cache instead of HBM
-    const uint32_t bid = block_base + blockIdx.x / 3u;
-    const int pass = (int)(blockIdx.x % 3u);
+    // The three nodes of a block of row pairs are three CONSECUTIVE workgroups: dispatched together (to different XCDs),
+    // their re-reads of the same table rows meet in the memory-side cache instead of HBM. `fused` (A/B knob
+    // SP1HIP_ZC_FUSE_NODES=1) makes one workgroup evaluate all three nodes instead; measured slower, see the host side.
+    const bool fused = (fused_flag != 0);
+    const uint32_t bid = block_base + (fused ? blockIdx.x : blockIdx.x / 3u);
+    const int only_pass = fused ? -1 : (int)(blockIdx.x % 3u);
     const ZcDesc d = zc_find_desc(descs, n_descs, bid);
     if constexpr (STAGED) {
         const uint4* src = reinterpret_cast<const uint4*>(d.prog);
@@ -222,51 +224,61 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
     }
     __syncthreads();
     const uint32_t terms = (d.rows + 1) / 2;
-    kb::Ext sa = kb::ext_zero(), sb = kb::ext_zero();
+    kb::Ext sa[3], sb[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) { sa[p] = kb::ext_zero(); sb[p] = kb::ext_zero(); }
     // a block is d.block_pairs row pairs (= the workgroup width of the chip's launch group: one pass of the program
     // per workgroup while the round is large; the partial-sum layout only knows blocks)
     for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < terms; base += d.n_blocks * d.block_pairs)
     for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, terms); i += blockDim.x) {
-        kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
-        if (FIRST && pass == 0) {
-            if (d.flags & 1u)
-            for (uint32_t c = 0; c < d.main_w; c++) {
-                const kb::Ext pw = load_ext_aos(d.gkr_pows, c);
-                va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 0)));
-                vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 2)));
-            }
-            if (d.flags & 1u)
-            for (uint32_t c = 0; c < d.prep_w; c++) {
-                const kb::Ext pw = load_ext_aos(d.gkr_pows, d.main_w + c);
-                va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 0)));
-                vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 2)));
-            }
-        } else if constexpr (STAGED) {
-            va = run_program<FIRST, MAXR>(reg, (const zc_word_t*)lprog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
-        } else {
-            va = run_program<FIRST, MAXR>(reg, (zc_const_prog_t)(uintptr_t)d.prog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
-        }
         kb::Ext e;
 #pragma unroll
         for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
-        sa = kb::ext_add(sa, kb::ext_mul(va, e));
-        sb = kb::ext_add(sb, kb::ext_mul(vb, e));
-    }
-    uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = sa.c[k]; v[4 + k] = sb.c[k]; }
+        for (int pass = 0; pass < 3; pass++) {
+            if (only_pass >= 0 && pass != only_pass) continue;
+            kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
+            if (FIRST && pass == 0) {
+                if (d.flags & 1u)
+                for (uint32_t c = 0; c < d.main_w; c++) {
+                    const kb::Ext pw = load_ext_aos(d.gkr_pows, c);
+                    va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 0)));
+                    vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.main, c, d.rows, i, 2)));
+                }
+                if (d.flags & 1u)
+                for (uint32_t c = 0; c < d.prep_w; c++) {
+                    const kb::Ext pw = load_ext_aos(d.gkr_pows, d.main_w + c);
+                    va = kb::ext_add(va, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 0)));
+                    vb = kb::ext_add(vb, K::scale(pw, leaf<FIRST>(d.prep, c, d.rows, i, 2)));
+                }
+            } else if constexpr (STAGED) {
+                va = run_program<FIRST, MAXR>(reg, (const zc_word_t*)lprog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
+            } else {
+                va = run_program<FIRST, MAXR>(reg, (zc_const_prog_t)(uintptr_t)d.prog, d, publics, i, 2 * pass, !FIRST && pass < 2, &vb);
+            }
+            sa[pass] = kb::ext_add(sa[pass], kb::ext_mul(va, e));
+            sb[pass] = kb::ext_add(sb[pass], kb::ext_mul(vb, e));
+        }
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = zc_wave_sum(v[k]);
-    __syncthreads();
-    if (lane == 0) {
+    for (int pass = 0; pass < 3; pass++) {
+        if (only_pass >= 0 && pass != only_pass) continue;
+        uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) red[wave * 8 + k] = v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const uint32_t k = threadIdx.x;
-        partial[((size_t)bid * 3 + pass) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
+        for (int k = 0; k < 4; k++) { v[k] = sa[pass].c[k]; v[4 + k] = sb[pass].c[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = zc_wave_sum(v[k]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) red[wave * 8 + k] = v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const uint32_t k = threadIdx.x;
+            partial[((size_t)bid * 3 + pass) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
+        }
     }
 }
 
@@ -771,10 +783,11 @@ template <bool FIRST> static inline uint32_t zc_wg_for(uint32_t n_regs, size_t o
 
 // One group of descriptors = a contiguous block range [block_lo, block_lo + n_blocks) launched together.
 template <bool FIRST>
-static int launch_round(uint32_t max_regs, bool staged, const ZcDesc* d_descs, int n_descs, uint32_t block_lo, uint32_t n_blocks,
+static int launch_round(uint32_t max_regs, bool staged, bool fused, const ZcDesc* d_descs, int n_descs, uint32_t block_lo, uint32_t n_blocks,
                         uint32_t max_instr, const uint32_t* eq, uint32_t eq_len, const uint32_t* publics, uint32_t* partial, hipStream_t s) {
     const size_t lds = 32 * 4 + (staged ? (size_t)max_instr * 16 : 0);
-    dim3 grid(n_blocks * 3);              // workgroup 3 b + p = node p of block b
+    dim3 grid(fused ? n_blocks : n_blocks * 3);      // unfused: workgroup 3 b + p = node p of block b
+    const uint32_t ff = fused ? 1u : 0u;
     static const bool force_vgpr = [] { const char* e = getenv("SP1HIP_ZC_REGFILE"); return e && e[0] == 'v'; }();
     const uint32_t wg = force_vgpr ? 0 : zc_wg_for<FIRST>(max_regs, lds);
     if (wg) {
@@ -782,21 +795,21 @@ static int launch_round(uint32_t max_regs, bool staged, const ZcDesc* d_descs, i
         if (staged) {
             auto kern = zc_round_kernel<FIRST, 0, true>;
             if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
-            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
+            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
         } else {
             auto kern = zc_round_kernel<FIRST, 0, false>;
             if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
-            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
+            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
         }
         SP1HIP_LAUNCH_CHECK();
         return SP1HIP_SUCCESS;
     }
     // register file in VGPRs / scratch (programs whose file does not fit LDS, or SP1HIP_ZC_REGFILE=vgpr for A/B runs)
     SP1HIP_REQUIRE(staged, "internal: unstaged program without an LDS register file");
-    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
-    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
-    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
-    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
+    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
+    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
+    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
     else { set_error("constraint program needs %u live registers (max 1024)", max_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
@@ -1098,8 +1111,14 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             ScopedTimer tm("zerocheck_round", s);      // (the reference's SP1_GPU_ZEROCHECK_ROUND_TIMING switch)
             for (auto& g : groups) {
-                if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
-                else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+                // SP1HIP_ZC_FUSE_NODES=1: one workgroup evaluates the three nodes of its rows (rows leave HBM once). Measured
+                // on the core-shaped shard: 12.5 ms of round kernels against 11.0 ms unfused — the re-reads of the unfused
+                // form already meet in the memory-side cache (FETCH_SIZE counts those hits), and fusing costs a third of
+                // the parallelism. Off by default; kept for A/B runs.
+                static const bool fuse_enabled = [] { const char* e = getenv("SP1HIP_ZC_FUSE_NODES"); return e && e[0] == '1'; }();
+                const bool fused = fuse_enabled && g.n_blocks >= 4096;
+                if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+                else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             }
             if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
