@@ -51,17 +51,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale-log2", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--core-shaped", action="store_true", help="the bench.py workload (bench/core_shard.py) instead of the round-1 one")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     L = 22 - args.scale_log2            # max_log_row_count
     lsh = 21 - args.scale_log2          # log stacking height
     area_target = ((1 << 28) + (1 << 27)) >> (2 * args.scale_log2) if args.scale_log2 else (1 << 28) + (1 << 27)
-    chips, prep_prep, shapes, area = build_shard(L, lsh, area_target)
+    if args.core_shaped:
+        from core_shard import build_core_shard
+        chips, meta = build_core_shard(area_target, L)
+        area, shapes = meta["area_cells"], "core-shaped"
+        prep_tables = [c[3] for c in chips if c[3] is not None]
+    else:
+        chips, prep_prep, shapes, area = build_shard(L, lsh, area_target)
+        prep_tables = [prep_prep]
     n_int = sum(c[1].num_interactions for c in chips)
     print("chips: %d (%d interactions), shapes %s, area = %.3e cells" % (len(chips), n_int, shapes, area), file=sys.stderr)
 
     jp = api.JaggedProver(L, lsh, 32, 2)
-    prep_commit, prep_data = jp.commit_multilinears([prep_prep])
+    prep_commit, prep_data = jp.commit_multilinears(prep_tables)
     res = {"area_cells": area, "max_log_row_count": L, "log_stacking_height": lsh, "chips": len(chips), "interactions": n_int}
     stage_timers = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition",
                     "gkr_round_sum_first", "gkr_round_fold_sum", "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",

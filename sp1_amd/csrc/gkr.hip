@@ -26,6 +26,7 @@
 //    the host (a few hundred ext products).
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -40,6 +41,8 @@ namespace sp1hip {
 void challenger_observe(sp1hip_challenger_t* ch, uint32_t x);
 kb::Ext challenger_sample_ext(sp1hip_challenger_t* ch);
 void challenger_restore(sp1hip_challenger_t* dst, const sp1hip_challenger_t* src);
+void challenger_export(const sp1hip_challenger_t* ch, uint32_t* w34);
+void challenger_import(sp1hip_challenger_t* ch, const uint32_t* w34);
 
 namespace gkr {
 
@@ -250,11 +253,162 @@ __device__ __forceinline__ void accumulate_pair(const Quad& a, const Quad& b, co
     acc[2] = kb::ext_add(acc[2], ts);
 }
 
+// ---------------------------------------------------------------- device-resident transcript for the row rounds
+// The v row-variable rounds of a layer used to return to the host after every launch (three sums -> the round polynomial
+// -> observe -> sample alpha -> next launch): ~56 us of host round trip around a ~26 us kernel, 231 times per proof. With
+// `GkrChainArgs` the LAST workgroup of a round (the one that already reduces the partial sums) finishes the round itself:
+// it forms the cubic from the sums (the Lagrange basis of the nodes {0, 1, 1/2, b} only depends on the layer's point:
+// the host precomputes it per round), runs the DuplexChallenger on 16 lanes (`permute_coop16`: one state word per lane),
+// and leaves alpha / claim / eq factor for the next launch, which the host has already enqueued. The host sees a layer's
+// messages, challenges and the sponge once, at the end of the layer.
+// (the reference's CUDA path keeps a device challenger for the same reason:
+//  /root/reference/sp1-gpu/crates/sys/include/challenger/challenger.cuh:L13-L170)
+struct GkrChain {                          // device memory, one per proof
+    uint32_t ch_state[16], ch_in[8], ch_out[8];
+    uint32_t ch_n_in, ch_n_out, pad0, pad1;
+    Ext claim, PA, alpha;
+};
+struct GkrRoundConst { Ext pt; Ext basis[3][4]; };     // basis[k] = the cubic that is 1 at node k and 0 at the other three
+struct GkrRoundOut { Ext poly[4]; Ext alpha; };
+struct GkrChainArgs { GkrChain* st; const GkrRoundConst* rc; GkrRoundOut* out; const p2::RoundConstants* p2rc; };
+
+// DuplexChallenger<KoalaBear, 16, 8> spread over the first 16 lanes of a wave (lane r = state word r; lanes 0..7 also
+// hold the input / output buffers). Same semantics as the host object in prover.hip.
+struct CoopChallenger {
+    uint32_t x, in_w, out_w;
+    int n_in, n_out;
+    uint32_t lane;
+    const p2::RoundConstants* rc;
+    __device__ __forceinline__ void duplexing() {
+        if ((int)lane < n_in) x = in_w;
+        n_in = 0;
+        x = p2::permute_coop16(x, lane, *rc);
+        out_w = x;
+        n_out = 8;
+    }
+    __device__ __forceinline__ void observe(uint32_t v) {      // v is the same in every lane
+        n_out = 0;
+        if ((int)lane == n_in) in_w = v;
+        if (++n_in == 8) duplexing();
+    }
+    __device__ __forceinline__ uint32_t sample() {
+        if (n_in != 0 || n_out == 0) duplexing();
+        --n_out;
+        return __shfl(out_w, n_out, 16);
+    }
+};
+
+// Runs in lanes 0..15 of the last workgroup. sums: S0, Sh, Seq (12 words, LDS).
+__device__ __forceinline__ void gkr_round_tail(const uint32_t* sums, const GkrChainArgs& ca) {
+    const uint32_t lane = threadIdx.x;
+    GkrChain* st = ca.st;
+    const Ext S0{{sums[0], sums[1], sums[2], sums[3]}}, Sh{{sums[4], sums[5], sums[6], sums[7]}}, Seq{{sums[8], sums[9], sums[10], sums[11]}};
+    const Ext claim = ld_ext(&st->claim, 0), PA = ld_ext(&st->PA, 0), pt = ld_ext(&ca.rc->pt, 0);
+    const Ext one = kb::ext_one();
+    const uint32_t inv8 = kb::inv(kb::to_monty(8u)), four = kb::to_monty(4u);
+    const Ext corr = kb::ext_sub(one, Seq);
+    const Ext p0 = kb::ext_mul(PA, kb::ext_add(S0, kb::ext_mul(corr, kb::ext_sub(one, pt))));
+    const Ext ph = kb::ext_mul_base(kb::ext_mul(PA, kb::ext_add(Sh, kb::ext_mul_base(corr, four))), inv8);
+    const Ext ys[3] = {p0, kb::ext_sub(claim, p0), ph};
+    Ext poly[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        Ext a = kb::ext_zero();
+#pragma unroll
+        for (int k = 0; k < 3; k++) a = kb::ext_add(a, kb::ext_mul(ys[k], ld_ext(&ca.rc->basis[k][d], 0)));
+        poly[d] = a;
+    }
+    CoopChallenger ch;
+    ch.lane = lane; ch.rc = ca.p2rc;
+    ch.x = st->ch_state[lane];
+    ch.in_w = lane < 8 ? st->ch_in[lane] : 0u;
+    ch.out_w = lane < 8 ? st->ch_out[lane] : 0u;
+    ch.n_in = (int)st->ch_n_in; ch.n_out = (int)st->ch_n_out;
+#pragma unroll 1
+    for (int d = 0; d < 4; d++)
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) ch.observe(poly[d].c[k]);
+    Ext alpha;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) alpha.c[k] = ch.sample();
+    const Ext next_claim = kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(poly[3], alpha), poly[2]), alpha), poly[1]), alpha), poly[0]);
+    const Ext next_PA = kb::ext_mul(PA, kb::ext_add(kb::ext_mul(pt, alpha), kb::ext_mul(kb::ext_sub(one, pt), kb::ext_sub(one, alpha))));
+    st->ch_state[lane] = ch.x;
+    if (lane < 8) { st->ch_in[lane] = ch.in_w; st->ch_out[lane] = ch.out_w; }
+    if (lane == 0) {
+        st->ch_n_in = (uint32_t)ch.n_in; st->ch_n_out = (uint32_t)ch.n_out;
+        st_ext(&st->claim, 0, next_claim); st_ext(&st->PA, 0, next_PA); st_ext(&st->alpha, 0, alpha);
+#pragma unroll
+        for (int d = 0; d < 4; d++) st_ext(&ca.out->poly[d], 0, poly[d]);
+        st_ext(&ca.out->alpha, 0, alpha);
+    }
+}
+
+// rs_finish (round_sync.hpp) with the round finished on the device instead of published to the host
+template <int NS>
+__device__ __forceinline__ void rs_finish_chain(const Ext (&acc)[NS], uint32_t* __restrict__ partials, uint32_t block_linear,
+                                                uint32_t total_blocks, uint32_t* counter, const GkrChainArgs& ca) {
+    static_assert(NS == 3, "the GKR rounds publish three sums");
+    __shared__ uint32_t sm[4][4 * NS];
+    __shared__ uint32_t fin[4 * NS];
+    __shared__ uint32_t last_flag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = wave_sum(acc[s].c[k]);
+            if (lane == 0) sm[wave][4 * s + k] = w;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * NS) {
+        uint32_t a = 0;
+        for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
+        partials[(size_t)block_linear * 4 * NS + threadIdx.x] = a;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = ticket == total_blocks - 1;
+        if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    Ext tot[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) tot[s] = kb::ext_zero();
+    for (uint32_t i = threadIdx.x; i < total_blocks; i += 256)
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const uint32_t* q = partials + ((size_t)i * NS + s) * 4;
+            tot[s] = kb::ext_add(tot[s], Ext{{q[0], q[1], q[2], q[3]}});
+        }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = wave_sum(tot[s].c[k]);
+            if (lane == 0) sm[wave][4 * s + k] = w;
+        }
+    __syncthreads();
+    if (threadIdx.x < 4 * NS) {
+        uint32_t a = 0;
+        for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
+        fin[threadIdx.x] = a;
+    }
+    if (threadIdx.x == 0) *counter = 0;        // ready for the next launch on this stream
+    __syncthreads();
+    if (threadIdx.x < 16) gkr_round_tail(fin, ca);
+}
+
 // round 0 of a layer: sums only. T = partial-Lagrange table of the layer's row point (2^v entries)
 template <bool NBASE>
 __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
                                                        const Ext* __restrict__ T, Ext lambda, uint32_t* __restrict__ partials,
-                                                       RoundSync rs, uint32_t seq, uint32_t K, uint32_t tile_size) {
+                                                       RoundSync rs, uint32_t seq, uint32_t K, uint32_t tile_size, GkrChainArgs ca) {
     const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
     const uint32_t pairs = (d.rows + 1) / 2;
@@ -266,17 +420,19 @@ __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restri
     const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
     for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-    rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
+    if (ca.st) rs_finish_chain<3>(acc, partials, blockIdx.x, gridDim.x, rs.counter, ca);
+    else rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
 }
 
 // fold rows (2r', 2r'+1) -> r' with alpha for r' = 2k, 2k+1, store, and (if SUM) accumulate the next round's sums
 // from the folded pair. T_next = table of the remaining row variables (half the size).
 template <bool FIRST, bool NBASE, bool SUM>
 __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
-                                                      const Ext* __restrict__ T_next, Ext lambda, Ext alpha,
+                                                      const Ext* __restrict__ T_next, Ext lambda, Ext alpha_arg,
                                                       uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq, uint32_t K,
-                                                      uint32_t tile_size) {
+                                                      uint32_t tile_size, GkrChainArgs ca) {
     const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
+    const Ext alpha = ca.st ? ld_ext(&ca.st->alpha, 0) : alpha_arg;      // chained: left by the previous round's last workgroup
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
     const uint32_t rows_out = (d.rows + 1) / 2;
     const uint32_t pairs = (rows_out + 1) / 2;
@@ -305,7 +461,8 @@ __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restric
         const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
         for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-        rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
+        if (ca.st) rs_finish_chain<3>(acc, partials, blockIdx.x, gridDim.x, rs.counter, ca);
+        else rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
     }
 }
 
@@ -443,6 +600,15 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     const int L = max_log_row_count;
     SP1HIP_REQUIRE(L >= 1 && L <= 30, "max_log_row_count out of range");
     hipStream_t s = S(stream);
+    // SP1HIP_GKR_DEBUG=1: host-side phase times on stderr (where a stage's non-kernel time goes)
+    static const bool gkr_debug = getenv("SP1HIP_GKR_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!gkr_debug) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sp1hip gkr] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
 
     // ---- parse the interaction programs (host words -> Montgomery device words), gather shapes
     std::vector<ChipInfo> info(n_chips);
@@ -542,6 +708,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     auto n_ptr = [&](int l, uint32_t i) -> void* { return (char*)lvN[l].p + off[l][i] * (l == L ? 4 : 16); };
     auto d_ptr = [&](int l, uint32_t i) -> Ext* { return lvD[l].ext() + off[l][i]; };
 
+    mark("parse + level buffers");
     // ---- first layer
     PinnedStage stage;                                       // small uploads (round_sync.hpp)
     SP1HIP_TRY(stage.init(s));
@@ -567,6 +734,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             SP1HIP_LAUNCH_CHECK();
         }
     }
+    mark("first layer enqueued");
     // ---- fraction tree
     // every level's descriptors are planned and uploaded once: the tree is built by L - 1 back-to-back launches
     DeviceBuf d_trans;
@@ -588,31 +756,12 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         else hipLaunchKernelGGL(transition_kernel<false>, dim3(tiles_for(mr), K), dim3(256), 0, s, d_t);
         SP1HIP_LAUNCH_CHECK();
     }
+    mark("tree enqueued");
     Mailbox mb;                                              // device -> host hand-overs outside the sumcheck rounds
     SP1HIP_TRY(mb.init(s));
-    // ---- circuit output = level 1 (<= 2 rows per interaction): index 2 i + r, padding (0, 1)
-    std::vector<Ext> out_n(2 * (size_t)W, kb::ext_zero()), out_d(2 * (size_t)W, kb::ext_one());
-    {
-        std::vector<Ext> hn(std::max<size_t>(level_entries[1], 1)), hd(std::max<size_t>(level_entries[1], 1));
-        if (L >= 2) {
-            SP1HIP_TRY(mb.fetch(lvN[1].p, level_entries[1] * 4, hn.data()));
-        } else {                                             // L == 1: level 1 is the first layer itself (base numerators)
-            std::vector<uint32_t> hb(std::max<size_t>(level_entries[1], 1));
-            SP1HIP_TRY(mb.fetch(lvN[1].p, level_entries[1], hb.data()));
-            for (size_t e = 0; e < level_entries[1]; e++) hn[e] = kb::ext_from_base(hb[e]);
-        }
-        SP1HIP_TRY(mb.fetch(lvD[1].p, level_entries[1] * 4, hd.data()));
-        for (uint32_t i = 0; i < K; i++)
-            for (uint32_t r = 0; r < rows_at(info[int_chip[i]].rows, 1); r++) { out_n[2 * i + r] = hn[off[1][i] + r]; out_d[2 * i + r] = hd[off[1][i] + r]; }
-    }
-    challenger_observe(ch, kb::to_monty(2 * W));
-    for (auto& e : out_n) observe_ext(ch, e);
-    challenger_observe(ch, kb::to_monty(2 * W));
-    for (auto& e : out_d) observe_ext(ch, e);
-    std::vector<Ext> eval_point(niv + 1);
-    for (auto& z : eval_point) z = challenger_sample_ext(ch);
-    Ext num_eval = eval_mle_host(out_n, eval_point), den_eval = eval_mle_host(out_d, eval_point);
-
+    // (the descriptors of every round depend on shapes only: they are planned and uploaded WHILE the GPU builds the first
+    // layer and the fraction tree — 3.9 ms of host work at 730 interactions x 231 rounds that used to sit on the critical
+    // path behind the first hand-over)
     // ---- GKR rounds, layer v = 1 .. L-1 (reads level v + 1)
     struct RoundOut { Ext n0, n1, d0, d1; std::vector<Poly4> polys; Ext claimed_sum, eval; std::vector<Ext> point; };
     std::vector<RoundOut> rounds;
@@ -668,15 +817,61 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             if (j > 0 && !last) { for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2; so_prev = so_next; cur ^= 1; }
         }
     }
+    mark("round descriptors planned");
     DeviceBuf d_all;
     SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s, stage));     // all_descs outlives the copy
+    mark("round descriptors uploaded");
+    // ---- circuit output = level 1 (<= 2 rows per interaction): index 2 i + r, padding (0, 1)
+    std::vector<Ext> out_n(2 * (size_t)W, kb::ext_zero()), out_d(2 * (size_t)W, kb::ext_one());
+    {
+        std::vector<Ext> hn(std::max<size_t>(level_entries[1], 1)), hd(std::max<size_t>(level_entries[1], 1));
+        if (L >= 2) {
+            SP1HIP_TRY(mb.fetch(lvN[1].p, level_entries[1] * 4, hn.data()));
+        } else {                                             // L == 1: level 1 is the first layer itself (base numerators)
+            std::vector<uint32_t> hb(std::max<size_t>(level_entries[1], 1));
+            SP1HIP_TRY(mb.fetch(lvN[1].p, level_entries[1], hb.data()));
+            for (size_t e = 0; e < level_entries[1]; e++) hn[e] = kb::ext_from_base(hb[e]);
+        }
+        SP1HIP_TRY(mb.fetch(lvD[1].p, level_entries[1] * 4, hd.data()));
+        for (uint32_t i = 0; i < K; i++)
+            for (uint32_t r = 0; r < rows_at(info[int_chip[i]].rows, 1); r++) { out_n[2 * i + r] = hn[off[1][i] + r]; out_d[2 * i + r] = hd[off[1][i] + r]; }
+    }
+    mark("circuit output fetched");
+    challenger_observe(ch, kb::to_monty(2 * W));
+    for (auto& e : out_n) observe_ext(ch, e);
+    challenger_observe(ch, kb::to_monty(2 * W));
+    for (auto& e : out_d) observe_ext(ch, e);
+    std::vector<Ext> eval_point(niv + 1);
+    for (auto& z : eval_point) z = challenger_sample_ext(ch);
+    Ext num_eval = eval_mle_host(out_n, eval_point), den_eval = eval_mle_host(out_d, eval_point);
+
     size_t launch_idx = 0;                                   // next K descriptors of d_all
     RoundSyncHost rsync;
     SP1HIP_TRY(rsync.init(s));
     const Ext one = kb::ext_one(), inv8 = kb::ext_inv(ext_c(8)), inv2 = kb::ext_inv(ext_c(2)), four = ext_c(4);
     uint32_t h_sums[12];
+    // device-resident transcript for the row rounds: SP1HIP_GKR_CHAIN=1. Byte-identical proofs (the GPU tests run both),
+    // but OFF by default: measured on MI355X the round finished by one wave of the last workgroup (three cooperative
+    // Poseidon2 permutations + the cubic: ~18 us of dependent instructions) costs what it saves — the host round trip
+    // through mapped pinned memory is ~19 us per round (core-shaped shard: row rounds 32.3 ms chained vs 29.0 ms).
+    const bool chain_enabled = [] { const char* e = getenv("SP1HIP_GKR_CHAIN"); return e && e[0] == '1'; }();   // read per call
+    DeviceBuf d_chain, d_rconst, d_rout;
+    std::vector<std::unique_ptr<std::vector<GkrRoundConst>>> keep_rconst;       // upload sources live to the end of the call
+    std::vector<std::unique_ptr<GkrChain>> keep_chain;
+    const p2::RoundConstants* d_p2rc = nullptr;
+    if (chain_enabled) {
+        const DeviceCtx* ctx;
+        SP1HIP_TRY(get_device_ctx(&ctx));
+        d_p2rc = ctx->d_rc;
+        SP1HIP_TRY(d_chain.alloc(sizeof(GkrChain), s));
+        SP1HIP_TRY(d_rconst.alloc(sizeof(GkrRoundConst) * (size_t)std::max(L, 1), s));
+        SP1HIP_TRY(d_rout.alloc(sizeof(GkrRoundOut) * (size_t)std::max(L, 1), s));
+    }
 
+    double dbg_rows = 0, dbg_int = 0, dbg_head = 0;
+    auto dbg_t = std::chrono::steady_clock::now();
     for (int v = 1; v <= L - 1; v++) {
+        if (gkr_debug) dbg_t = std::chrono::steady_clock::now();
         const Ext lambda = challenger_sample_ext(ch);
         RoundOut ro;
         Ext claim = num_eval * lambda + den_eval;
@@ -694,6 +889,34 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         Ext PA = one;                                        // eq factor of the row variables bound so far
         Poly4 poly{};
         Ext alpha_r = kb::ext_zero();
+        const bool chain = chain_enabled;
+        if (chain) {
+            // what the device needs to finish a round by itself: the sponge, the running claim, and per round the point
+            // coordinate and the Lagrange basis of the nodes {0, 1, 1/2, (1 - pt) / (1 - 2 pt)} (they depend on the layer's
+            // point only; the fourth node's value is zero, so three basis cubics suffice)
+            keep_rconst.emplace_back(new std::vector<GkrRoundConst>(v));
+            std::vector<GkrRoundConst>& rcs = *keep_rconst.back();
+            for (int j = 0; j < v; j++) {
+                const Ext pt = row_point[v - j - 1];
+                const Ext xs[4] = {kb::ext_zero(), one, inv2, (one - pt) * kb::ext_inv(one - (pt + pt))};
+                rcs[j].pt = pt;
+                for (int k = 0; k < 3; k++) {
+                    Ext ys[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+                    ys[k] = one;
+                    const Poly4 b = interpolate4(xs, ys);
+                    for (int d = 0; d < 4; d++) rcs[j].basis[k][d] = b[d];
+                }
+            }
+            keep_chain.emplace_back(new GkrChain());
+            GkrChain& hc = *keep_chain.back();
+            uint32_t w34[34];
+            challenger_export(ch, w34);
+            memcpy(hc.ch_state, w34, 64); memcpy(hc.ch_in, w34 + 16, 32); memcpy(hc.ch_out, w34 + 25, 32);
+            hc.ch_n_in = w34[24]; hc.ch_n_out = w34[33]; hc.pad0 = hc.pad1 = 0;
+            hc.claim = claim; hc.PA = one; hc.alpha = kb::ext_zero();
+            SP1HIP_TRY(stage.upload(d_chain.p, &hc, sizeof hc));
+            SP1HIP_TRY(stage.upload(d_rconst.p, rcs.data(), sizeof(GkrRoundConst) * (size_t)v));
+        }
         // per-interaction live row counts of the current round
         std::vector<uint32_t> live(K);
         uint32_t max_live = 0;
@@ -705,12 +928,14 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             uint32_t tiles;
             const LaunchShape shape = shapes[launch_idx];
             const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
+            const GkrChainArgs ca = chain ? GkrChainArgs{(GkrChain*)d_chain.p, (const GkrRoundConst*)d_rconst.p + j, (GkrRoundOut*)d_rout.p + j, d_p2rc}
+                                          : GkrChainArgs{nullptr, nullptr, nullptr, nullptr};
             if (j == 0) {
                 tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_sum_first", s);
-                const RoundSync rs = rsync.next();
-                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
-                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
+                const RoundSync rs = chain ? RoundSync{rsync.d_counter, nullptr} : rsync.next();
+                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
+                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
             } else {
                 // fold round j-1 with alpha_r into scratch[cur], summing round j
                 so_next.assign(K + 1, 0);
@@ -718,16 +943,17 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 for (uint32_t i = 0; i < K; i++) { const uint32_t o = (live[i] + 1) / 2; so_next[i + 1] = so_next[i] + o; max_out = std::max(max_out, o); }
                 tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_fold_sum", s);
-                const RoundSync rs = rsync.next();
-                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
-                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
-                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size);
+                const RoundSync rs = chain ? RoundSync{rsync.d_counter, nullptr} : rsync.next();
+                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
+                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
+                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
                 for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2;
                 so_prev = so_next;
                 cur ^= 1;
             }
             SP1HIP_LAUNCH_CHECK();
             (void)tiles;
+            if (chain) continue;                             // the round finishes itself on the device; the next launch follows
             SP1HIP_TRY(rsync.wait(h_sums, 12));
             Ext S0, Sh, Seq;
             memcpy(&S0, h_sums, 16); memcpy(&Sh, h_sums + 4, 16); memcpy(&Seq, h_sums + 8, 16);
@@ -756,10 +982,29 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
             const uint32_t tiles = shape.tiles;
             (void)max_out;
-            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size);
-            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size);
-            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size);
+            const GkrChainArgs ca = chain ? GkrChainArgs{(GkrChain*)d_chain.p, nullptr, nullptr, nullptr} : GkrChainArgs{nullptr, nullptr, nullptr, nullptr};
+            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca);
+            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca);
+            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca);
             SP1HIP_LAUNCH_CHECK();
+            if (chain) {
+                // ONE hand-over for the layer's v rounds: the messages, the challenges, the running values and the sponge
+                std::vector<GkrRoundOut> outs(v);
+                GkrChain hc;
+                SP1HIP_TRY(mb.fetch(d_rout.p, sizeof(GkrRoundOut) / 4 * (size_t)v, outs.data()));
+                SP1HIP_TRY(mb.fetch(d_chain.p, sizeof(GkrChain) / 4, &hc));
+                for (int j = 0; j < v; j++) {
+                    Poly4 pj;
+                    for (int d = 0; d < 4; d++) pj[d] = outs[j].poly[d];
+                    ro.polys.push_back(pj);
+                    alphas.push_back(outs[j].alpha);
+                }
+                uint32_t w34[34];
+                memcpy(w34, hc.ch_state, 64); memcpy(w34 + 16, hc.ch_in, 32); w34[24] = hc.ch_n_in;
+                memcpy(w34 + 25, hc.ch_out, 32); w34[33] = hc.ch_n_out;
+                challenger_import(ch, w34);
+                claim = hc.claim; PA = hc.PA; alpha_r = hc.alpha;
+            }
             std::vector<Ext> host(std::max<size_t>(so_next[K], 1) * 4);
             SP1HIP_TRY(mb.fetch(scratch[cur].p, so_next[K] * 16, host.data()));
             for (uint32_t i = 0; i < K; i++) {
@@ -768,6 +1013,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 tn0[i] = host[base]; td0[i] = host[base + len]; tn1[i] = host[base + 2 * len]; td1[i] = host[base + 3 * len];
             }
         }
+        if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_rows += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
         // interaction-variable rounds on the host (InteractionLayer, logup_poly.rs:L240-L316); eq_adjustment = PA
         std::vector<Ext> eqi = eq_int;
         for (int j = 0; j < niv; j++) {
@@ -796,6 +1042,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             }
             tn0.resize(half); td0.resize(half); tn1.resize(half); td1.resize(half); eqi.resize(half);
         }
+        if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_int += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
         ro.eval = claim;
         ro.point.assign(alphas.rbegin(), alphas.rend());
         ro.n0 = tn0[0]; ro.d0 = td0[0]; ro.n1 = tn1[0]; ro.d1 = td1[0];
@@ -808,6 +1055,9 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         rounds.push_back(std::move(ro));
     }
 
+    if (gkr_debug) fprintf(stderr, "[sp1hip gkr]   of which row-variable rounds %.3f ms, interaction-variable rounds (host) %.3f ms\n", dbg_rows, dbg_int);
+    (void)dbg_head;
+    mark("all layers");
     // ---- trace openings at the last L coordinates
     const std::vector<Ext> trace_point(eval_point.end() - L, eval_point.end());
     std::vector<Ext> openings(std::max<size_t>(total_cols, 1), kb::ext_zero());
@@ -855,6 +1105,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         }
     }
 
+    mark("openings");
     // ---- bincode(LogupGkrProof)
     Bytes w;
     for (const std::vector<Ext>* vv : {&out_n, &out_d}) {

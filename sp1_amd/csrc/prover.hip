@@ -187,6 +187,22 @@ namespace sp1hip {
 void challenger_observe(sp1hip_challenger_t* ch, uint32_t x) { ch->ch.observe(x); }
 kb::Ext challenger_sample_ext(sp1hip_challenger_t* ch) { return ch->ch.sample_ext(); }
 void challenger_restore(sp1hip_challenger_t* dst, const sp1hip_challenger_t* src) { dst->ch = src->ch; }
+// the sponge as 34 words (state[16], in[8], n_in, out[8], n_out): the image a device-resident transcript starts from /
+// hands back (gkr.hip: a layer's sumcheck rounds chain on the GPU)
+void challenger_export(const sp1hip_challenger_t* ch, uint32_t* w) {
+    memcpy(w, ch->ch.state, 64);
+    memcpy(w + 16, ch->ch.in, 32);
+    w[24] = (uint32_t)ch->ch.n_in;
+    memcpy(w + 25, ch->ch.out, 32);
+    w[33] = (uint32_t)ch->ch.n_out;
+}
+void challenger_import(sp1hip_challenger_t* ch, const uint32_t* w) {
+    memcpy(ch->ch.state, w, 64);
+    memcpy(ch->ch.in, w + 16, 32);
+    ch->ch.n_in = (int)w[24];
+    memcpy(ch->ch.out, w + 25, 32);
+    ch->ch.n_out = (int)w[33];
+}
 
 struct ByteWriter {
     std::vector<uint8_t> b;

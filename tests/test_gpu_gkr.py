@@ -27,6 +27,7 @@ def _dev(api, chips):
     return out
 
 
+@pytest.mark.parametrize("chain", ["0", "1"])      # 1: the row rounds finish on the device (device-resident DuplexChallenger)
 @pytest.mark.parametrize("n_tuples,L,with_empty,dup", [
     (4, 3, False, 2),
     (5, 4, True, 3),
@@ -35,7 +36,8 @@ def _dev(api, chips):
     (37, 7, True, 3),          # odd live counts at several levels
     (300, 10, True, 3),        # multi-tile rows
 ])
-def test_gkr_proof_matches_oracle(api, n_tuples, L, with_empty, dup):
+def test_gkr_proof_matches_oracle(api, monkeypatch, n_tuples, L, with_empty, dup, chain):
+    monkeypatch.setenv("SP1HIP_GKR_CHAIN", chain)
     chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
     o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
     seed = orc.random_felts((9,), L)
