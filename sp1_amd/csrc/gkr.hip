@@ -768,7 +768,6 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     DeviceBuf d_eq_int, d_T, d_partials, d_out, scratch[2];
     SP1HIP_TRY(d_eq_int.alloc((size_t)W * 16, s));
     SP1HIP_TRY(d_T.alloc(((size_t)2 << std::max(L - 1, 1)) * 16, s));
-    SP1HIP_TRY(d_partials.alloc((size_t)(4096 + 2 * K) * 48, s));
     SP1HIP_TRY(d_out.alloc(48, s));
     // folded tables: 4 vectors per interaction, at most ceil(rows(level v+1) / 4) entries each after the first fold
     size_t scratch_entries = 0;
@@ -781,7 +780,9 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     // last = the fold that binds the last row variable
     struct LaunchShape { uint32_t tiles, tile_size; };
     std::vector<LaunchShape> shapes;
-    constexpr uint32_t TARGET_TILES = 3072;
+    // workgroups of a large round: one resident set (256 CUs x 4 workgroups), no tail wave — measured on the core-shaped
+    // shard (GKR kernels, ms): 512: 32.2, 768: 30.1, 1024: 29.2, 1536: 29.7, 3072: 31.3, 6144: 34.3 (SP1HIP_GKR_TILES)
+    static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? (uint32_t)atoi(e) : 1024u; }();
     auto fill_descs = [&](RoundDesc* out, int v, int j, bool last, const std::vector<uint32_t>& live, int cur,
                           const std::vector<size_t>& so_prev, const std::vector<size_t>& so_next) {
         // pairs handled per interaction: sums-only launch: ceil(rows / 2); fold launches: ceil(ceil(rows / 2) / 2)
@@ -816,6 +817,11 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             fill_descs(all_descs.data() + all_descs.size() - K, v, j, last, live, cur, so_prev, so_next);
             if (j > 0 && !last) { for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2; so_prev = so_next; cur ^= 1; }
         }
+    }
+    {   // partial sums: one slot per workgroup of the largest launch
+        uint32_t max_tiles = 1;
+        for (auto& sh : shapes) max_tiles = std::max(max_tiles, sh.tiles);
+        SP1HIP_TRY(d_partials.alloc((size_t)max_tiles * 48, s));
     }
     mark("round descriptors planned");
     DeviceBuf d_all;

@@ -986,6 +986,24 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<std::unique_ptr<std::vector<ZcFixDesc>>> keep_fds;
     std::vector<std::unique_ptr<std::vector<uint8_t>>> keep_packs;
     SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 64, s));
+    // The folded extension tables of all chips live in two ping-pong buffers sized once (round r writes half r & 1;
+    // every round's tables are half the size of the previous round's): no allocation inside the round loop — it used to
+    // be ~66 arena calls per round.
+    DevBuf d_fold[2];
+    {
+        size_t words[2] = {4, 4};
+        for (int half = 0; half < 2; half++)
+            for (int i = 0; i < n_chips; i++) {
+                uint64_t rows = chips[i].real_rows;
+                for (int k = 0; k < half && rows; k++) rows = (rows + 1) / 2;
+                if (rows == 0) continue;
+                const uint64_t out_rows = (rows + 1) / 2;
+                for (uint32_t width : {chips[i].main_width, chips[i].prep_width})
+                    if (width) words[half] += (((size_t)out_rows * width * 4 + 3) & ~(size_t)3);
+            }
+        SP1HIP_TRY(d_fold[0].alloc(words[0] * 4, s));
+        SP1HIP_TRY(d_fold[1].alloc(words[1] * 4, s));
+    }
     for (int r = 0; r < L; r++) {
         const int nv = L - r;                       // variables left
         const Ext last = zeta[nv - 1];
@@ -1037,7 +1055,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
                 const uint32_t bp = g.wg ? g.wg : 256u;
                 uint32_t blocks = (terms + bp - 1) / bp;
-                if (blocks > 131072u / bp) blocks = 131072u / bp;
+                static const uint32_t max_pairs = [] { const char* e = getenv("SP1HIP_ZC_MAX_PAIRS"); return e ? (uint32_t)atoi(e) : 131072u; }();
+                if (blocks > max_pairs / bp) blocks = std::max(1u, max_pairs / bp);
                 const std::vector<Chunk>& cks = use_mono[i] ? c.mono : c.chunks;
                 const std::vector<uint32_t>& offs = use_mono[i] ? c.mono_off : c.chunk_off;
                 ZcChipRange rg{total_blocks, 0, terms - 1, 0};
@@ -1064,9 +1083,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         // it now, so that every descriptor of the round goes up in ONE copy
         keep_fds.emplace_back(new std::vector<ZcFixDesc>());
         std::vector<ZcFixDesc>& fds = *keep_fds.back();
-        std::vector<std::unique_ptr<DevBuf>> fresh;
+        std::vector<uint32_t*> fresh;              // the folded tables: slices of the round's half of the ping-pong buffer
         std::vector<std::pair<int, bool>> owner;   // (chip, is_main)
         uint32_t fix_blocks = 0;
+        size_t fold_words = 0;
+        uint32_t* const fold_base = (uint32_t*)d_fold[r & 1].p;
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
             if (c.rows == 0) continue;
@@ -1074,16 +1095,16 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             for (int which = 0; which < 2; which++) {
                 const uint32_t width = which == 0 ? c.in->main_width : c.in->prep_width;
                 if (width == 0) continue;
-                std::unique_ptr<DevBuf> nb(new DevBuf());
-                SP1HIP_TRY(nb->alloc((size_t)out_rows * width * 16, s));
+                uint32_t* const nb = fold_base + fold_words;
+                fold_words += ((size_t)out_rows * width * 4 + 3) & ~(size_t)3;
                 ZcFixDesc fd{};
                 fd.in = which == 0 ? c.d_main : c.d_prep;
-                fd.out = nb->u32();
+                fd.out = nb;
                 fd.rows = (uint32_t)c.rows; fd.width = width; fd.block_start = fix_blocks;
                 fd.n_blocks = (uint32_t)(((size_t)out_rows * width + 255) / 256);
                 fix_blocks += fd.n_blocks;
                 fds.push_back(fd);
-                fresh.push_back(std::move(nb));
+                fresh.push_back(nb);
                 owner.push_back({i, which == 0});
             }
         }
@@ -1187,8 +1208,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             SP1HIP_LAUNCH_CHECK();
             for (size_t k = 0; k < fds.size(); k++) {     // the arena is stream-ordered: the old table is recycled behind this launch
                 ChipState& c = *st[owner[k].first];
-                if (owner[k].second) { c.main_buf = std::move(fresh[k]); c.d_main = c.main_buf->u32(); }   // old table released
-                else { c.prep_buf = std::move(fresh[k]); c.d_prep = c.prep_buf->u32(); }
+                if (owner[k].second) c.d_main = fresh[k]; else c.d_prep = fresh[k];
             }
         }
         for (int i = 0; i < n_chips; i++)
