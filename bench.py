@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale-log2", type=int, default=0, help="prove a shard of area CORE >> 2k (testing aid; the bench line is k = 0)")
-    ap.add_argument("--cpu-sample-scale-log2", type=int, default=5)
+    ap.add_argument("--cpu-sample-scale-log2", type=int, default=6)
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (2-in-flight, commit-only, CPU baseline)")

@@ -1022,15 +1022,21 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_rows += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
         // interaction-variable rounds on the host (InteractionLayer, logup_poly.rs:L240-L316); eq_adjustment = PA
         std::vector<Ext> eqi = eq_int;
+        size_t real = K;                                     // entries >= real are the padding fraction (0, 1) in all four tables
         for (int j = 0; j < niv; j++) {
             const size_t half = eqi.size() / 2;
-            Ext s0 = kb::ext_zero(), sh = kb::ext_zero();
-            for (size_t k = 0; k < half; k++) {
+            const size_t real_pairs = (real + 1) / 2;
+            Ext s0 = kb::ext_zero(), sh = kb::ext_zero(), pad0 = kb::ext_zero(), padh = kb::ext_zero();
+            for (size_t k = 0; k < real_pairs; k++) {
                 const size_t a = 2 * k, b = 2 * k + 1;
                 s0 = s0 + eqi[a] * (lambda * (td0[a] * tn1[a] + td1[a] * tn0[a]) + td0[a] * td1[a]);
                 const Ext sn0 = tn0[a] + tn0[b], sn1 = tn1[a] + tn1[b], sd0 = td0[a] + td0[b], sd1 = td1[a] + td1[b];
                 sh = sh + (eqi[a] + eqi[b]) * (lambda * (sd0 * sn1 + sd1 * sn0) + sd0 * sd1);
             }
+            // a pair of padding entries contributes eq[a] * 1 to the first sum and (eq[a] + eq[b]) * (1 + 1)(1 + 1) to the second
+            for (size_t k = real_pairs; k < half; k++) { pad0 = pad0 + eqi[2 * k]; padh = padh + eqi[2 * k] + eqi[2 * k + 1]; }
+            s0 = s0 + pad0;
+            sh = sh + padh * four;
             const Ext pt = int_point[niv - 1 - j];
             const Ext p0 = PA * s0, ph = PA * sh * inv8;
             const Ext xs[4] = {kb::ext_zero(), one, inv2, (one - pt) * kb::ext_inv(one - (pt + pt))};
@@ -1042,10 +1048,15 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             alphas.push_back(alpha_r);
             claim = poly_eval(poly, alpha_r);
             for (size_t k = 0; k < half; k++) {
-                tn0[k] = tn0[2 * k] + alpha_r * (tn0[2 * k + 1] - tn0[2 * k]); td0[k] = td0[2 * k] + alpha_r * (td0[2 * k + 1] - td0[2 * k]);
-                tn1[k] = tn1[2 * k] + alpha_r * (tn1[2 * k + 1] - tn1[2 * k]); td1[k] = td1[2 * k] + alpha_r * (td1[2 * k + 1] - td1[2 * k]);
+                if (k < real_pairs) {
+                    tn0[k] = tn0[2 * k] + alpha_r * (tn0[2 * k + 1] - tn0[2 * k]); td0[k] = td0[2 * k] + alpha_r * (td0[2 * k + 1] - td0[2 * k]);
+                    tn1[k] = tn1[2 * k] + alpha_r * (tn1[2 * k + 1] - tn1[2 * k]); td1[k] = td1[2 * k] + alpha_r * (td1[2 * k + 1] - td1[2 * k]);
+                } else {
+                    tn0[k] = kb::ext_zero(); td0[k] = one; tn1[k] = kb::ext_zero(); td1[k] = one;
+                }
                 eqi[k] = eqi[2 * k] + alpha_r * (eqi[2 * k + 1] - eqi[2 * k]);
             }
+            real = real_pairs;
             tn0.resize(half); td0.resize(half); tn1.resize(half); td1.resize(half); eqi.resize(half);
         }
         if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_int += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }

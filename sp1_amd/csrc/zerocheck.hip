@@ -24,6 +24,8 @@
 #include <array>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "device_ctx.hpp"
@@ -422,6 +424,14 @@ struct DevBuf {
 struct Chunk {
     std::vector<uint32_t> prog;   // allocated [n][4]
     uint32_t n_regs = 1, alpha_off = 0;
+};
+
+struct ZcPlan {                      // everything that depends on a chip's program only (cached per process)
+    uint32_t n_instr = 0, main_w = 0, prep_w = 0;
+    std::vector<uint32_t> source;    // the caller's [n][3] program (collision check)
+    std::vector<uint32_t> prog;      // allocated [n][4], whole program (padded-row evaluation)
+    uint32_t n_regs = 1;
+    std::vector<Chunk> chunks, mono;
 };
 
 struct ChipState {
@@ -899,31 +909,61 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (op == ZC_PUBLIC) SP1HIP_REQUIRE((int)a < n_publics, "public value index out of range");
         }
         SP1HIP_REQUIRE(asserts == chips[i].num_constraints, "num_constraints does not match the program");
-        // fold constants into immediates, then pick the instruction order with the smallest register file
-        std::vector<uint32_t> folded, sched;
-        fold_immediates(chips[i].program, chips[i].n_instr, &folded);
-        static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
-        uint32_t best_regs = 0xffffffffu;
-        for (int mode = 0; mode < 3; mode++) {
-            if (forced_mode >= 0 && mode != forced_mode) continue;
-            std::vector<uint32_t> cand;
-            std::vector<Chunk> mono;
-            schedule_program(folded.data(), chips[i].n_instr, chips[i].main_width, mode, &cand);
-            SP1HIP_TRY(build_chunks(cand.data(), (uint32_t)(cand.size() / 3), chips[i].main_width, chips[i].prep_width, 0xffffffffu, &mono));
-            uint32_t regs = 0;
-            for (auto& ck : mono) regs = std::max(regs, ck.n_regs);
-            if (regs < best_regs) { best_regs = regs; sched.swap(cand); c->mono.swap(mono); }
+        // The plan of a program (immediates folded, instruction order chosen, registers allocated, chunked and undivided
+        // forms) depends on the program alone: a machine's chips are planned once per process and looked up afterwards
+        // (a prover proves the same machine shard after shard; planning 33 chips costs ~1.3 ms of host time per proof).
+        {
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
+            mix(chips[i].main_width); mix(chips[i].prep_width); mix(chips[i].n_instr);
+            for (size_t k = 0; k < (size_t)chips[i].n_instr * 3; k++) mix(chips[i].program[k]);
+            static std::mutex plan_mutex;
+            static std::unordered_map<uint64_t, std::shared_ptr<const ZcPlan>> plan_cache;
+            std::shared_ptr<const ZcPlan> plan;
+            {
+                std::lock_guard<std::mutex> lk(plan_mutex);
+                auto it = plan_cache.find(h);
+                if (it != plan_cache.end() && it->second->n_instr == chips[i].n_instr && it->second->main_w == chips[i].main_width &&
+                    it->second->prep_w == chips[i].prep_width &&
+                    (chips[i].n_instr == 0 || memcmp(it->second->source.data(), chips[i].program, (size_t)chips[i].n_instr * 12) == 0))
+                    plan = it->second;
+            }
+            if (!plan) {
+                std::shared_ptr<ZcPlan> np(new ZcPlan());
+                np->n_instr = chips[i].n_instr; np->main_w = chips[i].main_width; np->prep_w = chips[i].prep_width;
+                np->source.assign(chips[i].program, chips[i].program + (size_t)chips[i].n_instr * 3);
+                // fold constants into immediates, then pick the instruction order with the smallest register file
+                std::vector<uint32_t> folded, sched;
+                fold_immediates(chips[i].program, chips[i].n_instr, &folded);
+                static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
+                uint32_t best_regs = 0xffffffffu;
+                for (int mode = 0; mode < 3; mode++) {
+                    if (forced_mode >= 0 && mode != forced_mode) continue;
+                    std::vector<uint32_t> cand;
+                    std::vector<Chunk> mono;
+                    schedule_program(folded.data(), chips[i].n_instr, chips[i].main_width, mode, &cand);
+                    SP1HIP_TRY(build_chunks(cand.data(), (uint32_t)(cand.size() / 3), chips[i].main_width, chips[i].prep_width, 0xffffffffu, &mono));
+                    uint32_t regs = 0;
+                    for (auto& ck : mono) regs = std::max(regs, ck.n_regs);
+                    if (regs < best_regs) { best_regs = regs; sched.swap(cand); np->mono.swap(mono); }
+                }
+                const uint32_t n_sched = (uint32_t)(sched.size() / 3);
+                static const bool zc_debug = getenv("SP1HIP_ZC_DEBUG") != nullptr;
+                if (zc_debug) {
+                    size_t mono_instr = 0;
+                    for (auto& ck : np->mono) mono_instr += ck.prog.size() / 4;
+                    fprintf(stderr, "[sp1hip zc] chip %d: %u ssa instrs, %u constraints, %u+%u cols -> undivided program %zu words, %u registers\n",
+                            i, chips[i].n_instr, chips[i].num_constraints, chips[i].main_width, chips[i].prep_width, mono_instr, best_regs);
+                }
+                SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &np->prog, &np->n_regs));
+                SP1HIP_TRY(build_chunks(sched.data(), n_sched, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT, &np->chunks));
+                plan = np;
+                std::lock_guard<std::mutex> lk(plan_mutex);
+                if (plan_cache.size() > 4096) plan_cache.clear();
+                plan_cache[h] = plan;
+            }
+            c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono;
         }
-        const uint32_t n_sched = (uint32_t)(sched.size() / 3);
-        static const bool zc_debug = getenv("SP1HIP_ZC_DEBUG") != nullptr;
-        if (zc_debug) {
-            size_t mono_instr = 0;
-            for (auto& ck : c->mono) mono_instr += ck.prog.size() / 4;
-            fprintf(stderr, "[sp1hip zc] chip %d: %u ssa instrs, %u constraints, %u+%u cols -> undivided program %zu words, %u registers\n",
-                    i, chips[i].n_instr, chips[i].num_constraints, chips[i].main_width, chips[i].prep_width, mono_instr, best_regs);
-        }
-        SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &c->prog, &c->n_regs));
-        SP1HIP_TRY(build_chunks(sched.data(), n_sched, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT, &c->chunks));
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
         std::reverse(c->alpha_pows.begin(), c->alpha_pows.end());
