@@ -3,6 +3,8 @@
 // (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L16-L172): hipMallocAsync-backed allocation,
 // streams, events; no globals other than the per-device contexts.
 #include <cstring>
+#include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -103,7 +105,19 @@ static std::mutex g_arena_mutex;
 static std::map<ArenaKey, std::vector<void*>> g_arena;
 static size_t g_arena_cached_bytes = 0;
 
-static size_t arena_round(size_t bytes) { return bytes < 256 ? 256 : ((bytes + 255) / 256) * 256; }
+// Size classes in steps of 1/8 of a power of two (<= 12.5 % internal slack): real shards have varying table heights,
+// and exact-size keys would cache a new block for nearly every proof and never reuse it.
+static size_t arena_round(size_t bytes) {
+    if (bytes <= 4096) return bytes < 256 ? 256 : ((bytes + 255) / 256) * 256;
+    int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (lg - 3);
+    return ((bytes + step - 1) / step) * step;
+}
+// cached (free-listed) bytes above this are handed back to the driver, largest blocks first (SP1HIP_ARENA_CAP_GB, default 64)
+static size_t arena_cap_bytes() {
+    static const size_t cap = [] { const char* e = getenv("SP1HIP_ARENA_CAP_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
+    return cap;
+}
 
 int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
     int dev = 0;
@@ -134,9 +148,27 @@ void arena_free(void* ptr, size_t bytes, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     const size_t sz = arena_round(bytes);
-    std::lock_guard<std::mutex> lock(g_arena_mutex);
-    g_arena[ArenaKey{dev, stream, sz}].push_back(ptr);
-    g_arena_cached_bytes += sz;
+    std::vector<void*> evict;
+    {
+        std::lock_guard<std::mutex> lock(g_arena_mutex);
+        g_arena[ArenaKey{dev, stream, sz}].push_back(ptr);
+        g_arena_cached_bytes += sz;
+        // over the cap: drop this device's largest cached blocks (never the one just returned: it may still be in use by
+        // work queued on its stream; the others were free-listed earlier, and hipFree waits for the device anyway)
+        while (g_arena_cached_bytes > arena_cap_bytes()) {
+            auto best = g_arena.end();
+            for (auto it = g_arena.begin(); it != g_arena.end(); ++it)
+                if (it->first.device == dev && !it->second.empty() && !(it->second.size() == 1 && it->second.back() == ptr) &&
+                    (best == g_arena.end() || it->first.bytes > best->first.bytes))
+                    best = it;
+            if (best == g_arena.end()) break;
+            void* victim = best->second.front() == ptr ? best->second.back() : best->second.front();
+            best->second.erase(std::find(best->second.begin(), best->second.end(), victim));
+            g_arena_cached_bytes -= best->first.bytes;
+            evict.push_back(victim);
+        }
+    }
+    for (void* p : evict) (void)hipFree(p);
 }
 
 size_t arena_trim() {
