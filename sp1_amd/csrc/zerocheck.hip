@@ -97,6 +97,7 @@ constexpr uint32_t ZC_TOUCH = 9;           // pseudo-op: column never loaded by 
 constexpr uint32_t ZC_ADDC = 10, ZC_SUBC = 11, ZC_CSUB = 12, ZC_MULC = 13;
 constexpr uint32_t ZC_MONO_MIN_TERMS = 1024; // rounds with at least this many row pairs run a chip's program in ONE piece
 constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
+constexpr uint32_t ZC_CHUNK_HARD_MAX = 320; // a chunk may grow to this while its asserts share most of their cones
 constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB); longer programs read global memory
 
 typedef uint32_t zc_word_t __attribute__((ext_vector_type(4)));       // one instruction: op | flags, dst, a, b
@@ -665,6 +666,7 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
 static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32_t prep_w, uint32_t limit,
                         std::vector<Chunk>* out) {
     std::vector<uint32_t> stamp(n, 0xffffffffu);
+    std::vector<uint8_t> cone_seen(n, 0);
     std::vector<uint32_t> members, asserts, stack;
     uint32_t chunk_id = 0, assert_index = 0, first_assert = 0;
     auto flush = [&]() -> int {
@@ -710,10 +712,33 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
             else if (op == ZC_NEG || zc_is_imm(op)) stack.push_back(ssa[3 * v + 1]);
         }
         if (!asserts.empty() && members.size() + fresh.size() + asserts.size() + 1 > limit) {
-            for (uint32_t v : fresh) stamp[v] = 0xffffffffu;     // undo, close the chunk, retry in a new one
-            SP1HIP_TRY(flush());
-            k--;
-            continue;
+            // over the target size. If most of this assert's cone is ALREADY in the chunk (it shares the chunk's
+            // intermediate values: the 16 constraints of a Poseidon2 external round share one S-box / linear layer), closing
+            // the chunk here would recompute all of it in the next one: keep it, up to a hard cap.
+            bool keep = false;
+            if (limit != 0xffffffffu && members.size() + fresh.size() + asserts.size() + 1 <= ZC_CHUNK_HARD_MAX) {
+                size_t cone = 0;
+                std::vector<uint32_t> st2(1, ssa[3 * k + 1]);
+                std::vector<uint8_t>& seen = cone_seen;
+                std::vector<uint32_t> touched;
+                while (!st2.empty()) {
+                    const uint32_t v = st2.back();
+                    st2.pop_back();
+                    if (seen[v]) continue;
+                    seen[v] = 1; touched.push_back(v); cone++;
+                    const uint32_t op = ssa[3 * v];
+                    if (op == ZC_ADD || op == ZC_SUB || op == ZC_MUL) { st2.push_back(ssa[3 * v + 1]); st2.push_back(ssa[3 * v + 2]); }
+                    else if (op == ZC_NEG || zc_is_imm(op)) st2.push_back(ssa[3 * v + 1]);
+                }
+                for (uint32_t v : touched) seen[v] = 0;
+                keep = 2 * fresh.size() <= cone;
+            }
+            if (!keep) {
+                for (uint32_t v : fresh) stamp[v] = 0xffffffffu;     // undo, close the chunk, retry in a new one
+                SP1HIP_TRY(flush());
+                k--;
+                continue;
+            }
         }
         if (asserts.empty()) first_assert = assert_index;
         members.insert(members.end(), fresh.begin(), fresh.end());
@@ -1068,7 +1093,13 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             uint32_t mono_regs = 1;
             for (auto& ck : c.mono) mono_regs = std::max(mono_regs, ck.n_regs);
             const uint32_t mono_wg = r == 0 ? zc_wg_for<true>(mono_regs, 128) : zc_wg_for<false>(mono_regs, 128);
-            use_mono[i] = mono_enabled && c.chunks.size() > 1 && terms >= ZC_MONO_MIN_TERMS && mono_wg != 0;
+            // the undivided program pays off when chunking recomputes a lot (long dependency chains shared by many
+            // constraints); a program of self-contained constraints runs as chunks in every round: same work, small
+            // register files, and as many workgroups as there are constraints
+            size_t chunk_words = 0, mono_words = 0;
+            for (auto& ck : c.chunks) chunk_words += ck.prog.size();
+            for (auto& ck : c.mono) mono_words += ck.prog.size();
+            use_mono[i] = mono_enabled && c.chunks.size() > 1 && terms >= ZC_MONO_MIN_TERMS && mono_wg != 0 && 2 * chunk_words > 3 * mono_words;
             const std::vector<Chunk>& cks = use_mono[i] ? c.mono : c.chunks;
             uint32_t regs = 1, instr = 1;
             for (auto& ck : cks) { regs = std::max(regs, ck.n_regs); instr = std::max<uint32_t>(instr, (uint32_t)(ck.prog.size() / 4)); }
