@@ -364,16 +364,11 @@ __device__ __forceinline__ void rs_finish_chain(const Ext (&acc)[NS], uint32_t* 
     if (threadIdx.x < 4 * NS) {
         uint32_t a = 0;
         for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
-        partials[(size_t)block_linear * 4 * NS + threadIdx.x] = a;
+        rs_store_partial(&partials[(size_t)block_linear * 4 * NS + threadIdx.x], a);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const uint32_t ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = ticket == total_blocks - 1;
-        if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (threadIdx.x == 0) last_flag = rs_ticket_is_last(counter, block_linear, total_blocks);
     __syncthreads();
     if (!last_flag) return;
     Ext tot[NS];
@@ -381,10 +376,7 @@ __device__ __forceinline__ void rs_finish_chain(const Ext (&acc)[NS], uint32_t* 
     for (int s = 0; s < NS; s++) tot[s] = kb::ext_zero();
     for (uint32_t i = threadIdx.x; i < total_blocks; i += 256)
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const uint32_t* q = partials + ((size_t)i * NS + s) * 4;
-            tot[s] = kb::ext_add(tot[s], Ext{{q[0], q[1], q[2], q[3]}});
-        }
+        for (int s = 0; s < NS; s++) tot[s] = kb::ext_add(tot[s], rs_load_partial(partials + ((size_t)i * NS + s) * 4));
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < NS; s++)
@@ -399,7 +391,6 @@ __device__ __forceinline__ void rs_finish_chain(const Ext (&acc)[NS], uint32_t* 
         for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
         fin[threadIdx.x] = a;
     }
-    if (threadIdx.x == 0) *counter = 0;        // ready for the next launch on this stream
     __syncthreads();
     if (threadIdx.x < 16) gkr_round_tail(fin, ca);
 }

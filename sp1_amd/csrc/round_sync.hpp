@@ -6,9 +6,17 @@
 // hipStreamSynchronize that is ~40 us of launch / copy / wake-up latency per round, and a shard proof has
 // ~370 rounds. Here the workgroup that arrives last at an agent-scope counter reduces the partials and
 // stores the sums plus a sequence number into mapped pinned host memory; the host spins on the sequence
-// number (bounded). Inter-workgroup visibility follows the placement-independent protocol of the CDNA
-// guide (§6 G16): drain stores, workgroup barrier, one-lane agent-scope release, counter; consumer one-lane
-// agent-scope acquire, barrier, plain loads.
+// number (bounded).
+//
+// Inter-workgroup visibility WITHOUT fences (measured with bench/ubench_rs_finish.hip, profiles/r02_ubench_rs_finish.txt):
+// the textbook protocol (plain stores, agent-scope release fence, counter; acquire fence, plain loads) makes every
+// workgroup write back its XCD's whole L2 (`buffer_wbl2 sc1`) — in a fold round that is the freshly written half-size
+// tables: 33 us instead of 16 for 730 workgroups with 64 KiB of output each, 176 instead of 60 for 4096. Only the
+// 4 NS partial words per workgroup cross workgroups, so those are stored and loaded coherently (sc1: through to memory
+// past the non-coherent L2s) and ordered by `s_waitcnt vmcnt(0)` + the workgroup barrier before the ticket; everything
+// else a round writes becomes visible at the kernel boundary as usual. And the ticket is two-level (RS_GROUPS group
+// counters on separate lines, then one): same-address agent-scope atomics serialise at ~17 ns each — 12 us for 730
+// workgroups on a single counter.
 #pragma once
 #include <chrono>
 #include <cstring>
@@ -22,6 +30,29 @@ struct RoundSync {                       // device-visible handles
     uint32_t* counter;                   // device word, zero between uses
     volatile uint32_t* host_slot;        // mapped pinned: [0] = sequence number, [1 ..] = the sums
 };
+
+constexpr uint32_t RS_GROUPS = 32, RS_GROUP_STRIDE = 64;             // counter words: group g at g * STRIDE, level 2 at GROUPS * STRIDE
+constexpr size_t RS_COUNTER_BYTES = (size_t)(RS_GROUPS + 1) * RS_GROUP_STRIDE * 4;
+
+// one lane per workgroup: true for the workgroup that arrives last; leaves every counter zero for the next launch
+__device__ __forceinline__ bool rs_ticket_is_last(uint32_t* counter, uint32_t block_linear, uint32_t total_blocks) {
+    const uint32_t g = block_linear % RS_GROUPS, members = (total_blocks - g + RS_GROUPS - 1) / RS_GROUPS;
+    uint32_t* cg = counter + g * RS_GROUP_STRIDE;
+    if (__hip_atomic_fetch_add(cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+    __hip_atomic_store(cg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* c2 = counter + RS_GROUPS * RS_GROUP_STRIDE;
+    const uint32_t groups = total_blocks < RS_GROUPS ? total_blocks : RS_GROUPS;
+    if (__hip_atomic_fetch_add(c2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != groups - 1) return false;
+    __hip_atomic_store(c2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+__device__ __forceinline__ void rs_store_partial(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ kb::Ext rs_load_partial(const uint32_t* q) {
+    kb::Ext e;
+#pragma unroll
+    for (int k = 0; k < 4; k++) e.c[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return e;
+}
 
 __device__ __forceinline__ uint32_t rs_wave_sum(uint32_t v) {
 #pragma unroll
@@ -48,16 +79,11 @@ __device__ __forceinline__ void rs_finish(const kb::Ext (&acc)[NS], uint32_t* __
     if (threadIdx.x < 4 * NS) {
         uint32_t a = 0;
         for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
-        partials[(size_t)block_linear * 4 * NS + threadIdx.x] = a;
+        rs_store_partial(&partials[(size_t)block_linear * 4 * NS + threadIdx.x], a);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const uint32_t ticket = __hip_atomic_fetch_add(rs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = ticket == total_blocks - 1;
-        if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (threadIdx.x == 0) last_flag = rs_ticket_is_last(rs.counter, block_linear, total_blocks);
     __syncthreads();
     if (!last_flag) return;
     // the last workgroup: total over all partials
@@ -66,10 +92,8 @@ __device__ __forceinline__ void rs_finish(const kb::Ext (&acc)[NS], uint32_t* __
     for (int s = 0; s < NS; s++) tot[s] = kb::ext_zero();
     for (uint32_t i = threadIdx.x; i < total_blocks; i += 256)
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const uint32_t* q = partials + ((size_t)i * NS + s) * 4;
-            tot[s] = kb::ext_add(tot[s], kb::Ext{{q[0], q[1], q[2], q[3]}});
-        }
+        for (int s = 0; s < NS; s++)
+            tot[s] = kb::ext_add(tot[s], rs_load_partial(partials + ((size_t)i * NS + s) * 4));
     __syncthreads();                       // sm is reused
 #pragma unroll
     for (int s = 0; s < NS; s++)
@@ -84,8 +108,7 @@ __device__ __forceinline__ void rs_finish(const kb::Ext (&acc)[NS], uint32_t* __
         for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
         rs.host_slot[1 + threadIdx.x] = a;
     }
-    if (threadIdx.x == 0) *rs.counter = 0;     // ready for the next launch on this stream
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slot is uncached host memory: acknowledged stores are ordered before seq
     __syncthreads();
     if (threadIdx.x == 0) rs.host_slot[0] = seq;
 }

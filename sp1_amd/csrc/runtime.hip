@@ -238,8 +238,8 @@ int round_sync_acquire(RoundSyncSlot* out) {
         if (!g_rs_free[dev].empty()) { *out = g_rs_free[dev].back(); g_rs_free[dev].pop_back(); return SP1HIP_SUCCESS; }
     }
     RoundSyncSlot slot{nullptr, nullptr};
-    SP1HIP_HIP(hipMalloc((void**)&slot.d_counter, 4));
-    SP1HIP_HIP(hipMemset(slot.d_counter, 0, 4));
+    SP1HIP_HIP(hipMalloc((void**)&slot.d_counter, RS_COUNTER_BYTES));
+    SP1HIP_HIP(hipMemset(slot.d_counter, 0, RS_COUNTER_BYTES));
     SP1HIP_HIP(hipHostMalloc((void**)&slot.h_slot, 32 * 4, hipHostMallocMapped));
     memset(slot.h_slot, 0, 32 * 4);
     *out = slot;
