@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "host_par.hpp"
 #include "round_sync.hpp"
 #include "tensor_table.hpp"
 
@@ -865,6 +866,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         SP1HIP_TRY(d_rout.alloc(sizeof(GkrRoundOut) * (size_t)std::max(L, 1), s));
     }
 
+    HostPar::Scope par;                                      // helper threads for the host loops between hand-overs
     double dbg_rows = 0, dbg_int = 0, dbg_head = 0;
     auto dbg_t = std::chrono::steady_clock::now();
     for (int v = 1; v <= L - 1; v++) {
@@ -874,7 +876,19 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         Ext claim = num_eval * lambda + den_eval;
         ro.claimed_sum = claim;
         const std::vector<Ext> int_point(eval_point.begin(), eval_point.begin() + niv), row_point(eval_point.begin() + niv, eval_point.end());
-        const std::vector<Ext> eq_int = partial_lagrange_host(int_point);
+        // Lagrange tables of every prefix of the interaction point (eq_tabs[m]: the first m coordinates, 2^m entries)
+        std::vector<std::vector<Ext>> eq_tabs(niv + 1);
+        eq_tabs[0] = {one};
+        for (int m = 0; m < niv; m++) {
+            const std::vector<Ext>& ev = eq_tabs[m];
+            std::vector<Ext>& nx = eq_tabs[m + 1];
+            nx.resize(ev.size() * 2);
+            const Ext x = int_point[m];
+            par.run(ev.size(), 64, [&](int, size_t b, size_t e) {
+                for (size_t i = b; i < e; i++) { const Ext pr = ev[i] * x; nx[2 * i] = ev[i] - pr; nx[2 * i + 1] = pr; }
+            });
+        }
+        const std::vector<Ext>& eq_int = eq_tabs[niv];
         SP1HIP_TRY(stage.upload(d_eq_int.p, eq_int.data(), (size_t)W * 16));
         PointArg pa{};
         for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
@@ -1011,25 +1025,53 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             }
         }
         if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_rows += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
-        // interaction-variable rounds on the host (InteractionLayer, logup_poly.rs:L240-L316); eq_adjustment = PA
-        std::vector<Ext> eqi = eq_int;
+        // interaction-variable rounds on the host (InteractionLayer, logup_poly.rs:L240-L316); eq_adjustment = PA.
+        // The eq table is never folded: after binding the last j variables it is eq_scale x the Lagrange table of the
+        // first niv - j coordinates (an intermediate table of the construction above), and a Lagrange table sums to one,
+        // which gives the padding entries' share of both sums without visiting them. The sums and the folds of a round
+        // run on the helper threads (host_par.hpp); the tables ping-pong because a parallel fold cannot be in place.
+        Ext eq_scale = one;
         size_t real = K;                                     // entries >= real are the padding fraction (0, 1) in all four tables
+        std::vector<Ext> un0(W / 2 + 1), ud0(W / 2 + 1), un1(W / 2 + 1), ud1(W / 2 + 1);
+        std::vector<Ext>*tab[2][4] = {{&tn0, &td0, &tn1, &td1}, {&un0, &ud0, &un1, &ud1}};
+        int side = 0;
         for (int j = 0; j < niv; j++) {
+            const std::vector<Ext>& eqi = eq_tabs[niv - j];
             const size_t half = eqi.size() / 2;
             const size_t real_pairs = (real + 1) / 2;
-            Ext s0 = kb::ext_zero(), sh = kb::ext_zero(), pad0 = kb::ext_zero(), padh = kb::ext_zero();
-            for (size_t k = 0; k < real_pairs; k++) {
-                const size_t a = 2 * k, b = 2 * k + 1;
-                s0 = s0 + eqi[a] * (lambda * (td0[a] * tn1[a] + td1[a] * tn0[a]) + td0[a] * td1[a]);
-                const Ext sn0 = tn0[a] + tn0[b], sn1 = tn1[a] + tn1[b], sd0 = td0[a] + td0[b], sd1 = td1[a] + td1[b];
-                sh = sh + (eqi[a] + eqi[b]) * (lambda * (sd0 * sn1 + sd1 * sn0) + sd0 * sd1);
+            const Ext *n0 = tab[side][0]->data(), *d0 = tab[side][1]->data(), *n1 = tab[side][2]->data(), *d1 = tab[side][3]->data();
+            struct alignas(64) Part { Ext x0, y0, xh, yh, e0, es; };
+            Part parts[HostPar::Scope::MAX_THREADS];
+            const int nparts_max = par.threads();
+            for (int q = 0; q < nparts_max; q++) parts[q] = Part{kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+            par.run(real_pairs, 24, [&](int part, size_t kb0, size_t ke) {
+                Part acc = parts[part];
+                for (size_t k = kb0; k < ke; k++) {
+                    const size_t a = 2 * k, b = 2 * k + 1;
+                    // lambda is factored out of the sums: sum eq (lambda X + Y) = lambda sum eq X + sum eq Y
+                    acc.x0 = acc.x0 + eqi[a] * (d0[a] * n1[a] + d1[a] * n0[a]);
+                    acc.y0 = acc.y0 + eqi[a] * (d0[a] * d1[a]);
+                    const Ext sn0 = n0[a] + n0[b], sn1 = n1[a] + n1[b], sd0 = d0[a] + d0[b], sd1 = d1[a] + d1[b];
+                    const Ext es = eqi[a] + eqi[b];
+                    acc.xh = acc.xh + es * (sd0 * sn1 + sd1 * sn0);
+                    acc.yh = acc.yh + es * (sd0 * sd1);
+                    acc.e0 = acc.e0 + eqi[a];
+                    acc.es = acc.es + es;
+                }
+                parts[part] = acc;
+            });
+            Part t = parts[0];
+            for (int q = 1; q < nparts_max; q++) {
+                t.x0 = t.x0 + parts[q].x0; t.y0 = t.y0 + parts[q].y0; t.xh = t.xh + parts[q].xh; t.yh = t.yh + parts[q].yh;
+                t.e0 = t.e0 + parts[q].e0; t.es = t.es + parts[q].es;
             }
-            // a pair of padding entries contributes eq[a] * 1 to the first sum and (eq[a] + eq[b]) * (1 + 1)(1 + 1) to the second
-            for (size_t k = real_pairs; k < half; k++) { pad0 = pad0 + eqi[2 * k]; padh = padh + eqi[2 * k] + eqi[2 * k + 1]; }
-            s0 = s0 + pad0;
-            sh = sh + padh * four;
             const Ext pt = int_point[niv - 1 - j];
-            const Ext p0 = PA * s0, ph = PA * sh * inv8;
+            // a pair of padding entries contributes eq[a] * 1 to the first sum and (eq[a] + eq[b]) * (1 + 1)(1 + 1) to the
+            // second; over ALL pairs sum eq[a] = 1 - pt and sum (eq[a] + eq[b]) = 1
+            const Ext s0 = lambda * t.x0 + t.y0 + ((one - pt) - t.e0);
+            const Ext sh = lambda * t.xh + t.yh + (one - t.es) * four;
+            const Ext PAe = PA * eq_scale;
+            const Ext p0 = PAe * s0, ph = PAe * sh * inv8;
             const Ext xs[4] = {kb::ext_zero(), one, inv2, (one - pt) * kb::ext_inv(one - (pt + pt))};
             const Ext ys[4] = {p0, claim - p0, ph, kb::ext_zero()};
             poly = interpolate4(xs, ys);
@@ -1038,22 +1080,23 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             alpha_r = challenger_sample_ext(ch);
             alphas.push_back(alpha_r);
             claim = poly_eval(poly, alpha_r);
-            for (size_t k = 0; k < half; k++) {
-                if (k < real_pairs) {
-                    tn0[k] = tn0[2 * k] + alpha_r * (tn0[2 * k + 1] - tn0[2 * k]); td0[k] = td0[2 * k] + alpha_r * (td0[2 * k + 1] - td0[2 * k]);
-                    tn1[k] = tn1[2 * k] + alpha_r * (tn1[2 * k + 1] - tn1[2 * k]); td1[k] = td1[2 * k] + alpha_r * (td1[2 * k + 1] - td1[2 * k]);
-                } else {
-                    tn0[k] = kb::ext_zero(); td0[k] = one; tn1[k] = kb::ext_zero(); td1[k] = one;
+            eq_scale = eq_scale * (pt * alpha_r + (one - pt) * (one - alpha_r));
+            Ext *o0 = tab[side ^ 1][0]->data(), *o1 = tab[side ^ 1][1]->data(), *o2 = tab[side ^ 1][2]->data(), *o3 = tab[side ^ 1][3]->data();
+            par.run(real_pairs, 48, [&](int, size_t kb0, size_t ke) {
+                for (size_t k = kb0; k < ke; k++) {
+                    o0[k] = n0[2 * k] + alpha_r * (n0[2 * k + 1] - n0[2 * k]); o1[k] = d0[2 * k] + alpha_r * (d0[2 * k + 1] - d0[2 * k]);
+                    o2[k] = n1[2 * k] + alpha_r * (n1[2 * k + 1] - n1[2 * k]); o3[k] = d1[2 * k] + alpha_r * (d1[2 * k + 1] - d1[2 * k]);
                 }
-                eqi[k] = eqi[2 * k] + alpha_r * (eqi[2 * k + 1] - eqi[2 * k]);
-            }
+            });
+            if (real_pairs < half) { o0[real_pairs] = kb::ext_zero(); o1[real_pairs] = one; o2[real_pairs] = kb::ext_zero(); o3[real_pairs] = one; }
             real = real_pairs;
-            tn0.resize(half); td0.resize(half); tn1.resize(half); td1.resize(half); eqi.resize(half);
+            side ^= 1;
         }
+        const Ext fin_n0 = (*tab[side][0])[0], fin_d0 = (*tab[side][1])[0], fin_n1 = (*tab[side][2])[0], fin_d1 = (*tab[side][3])[0];
         if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_int += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
         ro.eval = claim;
         ro.point.assign(alphas.rbegin(), alphas.rend());
-        ro.n0 = tn0[0]; ro.d0 = td0[0]; ro.n1 = tn1[0]; ro.d1 = td1[0];
+        ro.n0 = fin_n0; ro.d0 = fin_d0; ro.n1 = fin_n1; ro.d1 = fin_d1;
         observe_ext(ch, ro.n0); observe_ext(ch, ro.n1); observe_ext(ch, ro.d0); observe_ext(ch, ro.d1);
         eval_point = ro.point;
         const Ext lc = challenger_sample_ext(ch);
