@@ -100,6 +100,16 @@ __global__ __launch_bounds__(256) void reduce_partials(const uint32_t* __restric
     block_reduce_store<NS>(acc, out);
 }
 
+// Layout of the circuit levels (numerators / denominators per interaction): a fold kernel's lane wants 8 consecutive
+// entries (two row pairs), a sums-only kernel's 4, the fraction tree's 2 — 128 / 64 / 32 B at that lane stride. Inside every
+// complete block of 512 entries, entry e lives at (e mod 8) * 64 + (e div 8) mod 64: the fold's loads are contiguous 1 KiB
+// runs, the sums-only loads two 512 B runs, the tree's four 256 B runs, and the writers (one entry per lane) fill whole
+// 128 B lines. The last, incomplete block keeps the natural order (nothing grows; the <= 2-entry level the host reads is
+// untouched). Same idea as folded_pos below.
+__device__ __forceinline__ uint32_t level_pos(uint32_t e, uint32_t len) {
+    return (e | 511u) < len ? ((e & ~511u) | ((e & 7u) << 6) | ((e >> 3) & 63u)) : e;
+}
+
 // ================================================================ first layer
 // Per (chip, interaction): program words in device memory (layout of sp1_amd/air.py InteractionProgram, one
 // interaction: is_send, kind, n_values, vcol(multiplicity), vcol(values..)), column-major traces.
@@ -136,8 +146,9 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const IntDesc* __restr
         if (!is_send) m = kb::sub(0u, m);
         Ext den = kb::ext_add(alpha, kb::ext_mul_base(ld_ext(betas, 0), kind));
         for (uint32_t j = 0; j < nv; j++) den = kb::ext_add(den, kb::ext_mul_base(ld_ext(betas, 1 + j), vcol_apply(p, d, r)));
-        gptr(d.n_out)[r] = m;
-        st_ext(d.d_out, r, den);
+        const uint32_t rp = level_pos(r, d.rows);
+        gptr(d.n_out)[rp] = m;
+        st_ext(d.d_out, rp, den);
     }
 }
 
@@ -161,21 +172,22 @@ __global__ __launch_bounds__(256) void transition_kernel(const TransDesc* __rest
     const TransDesc d = descs[blockIdx.y];
     const uint32_t rows_out = (d.rows_in + 1) / 2;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows_out; r += gridDim.x * blockDim.x) {
-        const Ext da = ld_ext(d.d_in, 2 * r);
+        const uint32_t ia = level_pos(2 * r, d.rows_in), ib = level_pos(2 * r + 1, d.rows_in), io = level_pos(r, rows_out);
+        const Ext da = ld_ext(d.d_in, ia);
         if (2 * r + 1 < d.rows_in) {
-            const Ext db = ld_ext(d.d_in, 2 * r + 1);
+            const Ext db = ld_ext(d.d_in, ib);
             Ext n;
             if (NBASE) {
-                const uint32_t na = gptr((const uint32_t*)d.n_in)[2 * r], nb = gptr((const uint32_t*)d.n_in)[2 * r + 1];
+                const uint32_t na = gptr((const uint32_t*)d.n_in)[ia], nb = gptr((const uint32_t*)d.n_in)[ib];
                 n = kb::ext_add(kb::ext_mul_base(db, na), kb::ext_mul_base(da, nb));
             } else {
-                n = kb::ext_add(kb::ext_mul(db, load_n<false>(d.n_in, 2 * r)), kb::ext_mul(da, load_n<false>(d.n_in, 2 * r + 1)));
+                n = kb::ext_add(kb::ext_mul(db, load_n<false>(d.n_in, ia)), kb::ext_mul(da, load_n<false>(d.n_in, ib)));
             }
-            st_ext(d.n_out, r, n);
-            st_ext(d.d_out, r, kb::ext_mul(da, db));
+            st_ext(d.n_out, io, n);
+            st_ext(d.d_out, io, kb::ext_mul(da, db));
         } else {                                           // partner is a padding row: (0, 1)
-            st_ext(d.n_out, r, load_n<NBASE>(d.n_in, 2 * r));
-            st_ext(d.d_out, r, da);
+            st_ext(d.n_out, io, load_n<NBASE>(d.n_in, ia));
+            st_ext(d.d_out, io, da);
         }
     }
 }
@@ -239,9 +251,10 @@ __device__ __forceinline__ Quad load_quad(const RoundDesc& d, uint32_t r) {
     Quad q;
     if (r >= d.rows) { q.n0 = q.n1 = kb::ext_zero(); q.d0 = q.d1 = kb::ext_one(); return q; }
     if (FIRST) {
-        q.n0 = load_n<NBASE>(d.src[0], 2 * r);
-        q.d0 = ld_ext((const Ext*)d.src[1], 2 * r);
-        if (2 * r + 1 < d.rows_x) { q.n1 = load_n<NBASE>(d.src[0], 2 * r + 1); q.d1 = ld_ext((const Ext*)d.src[1], 2 * r + 1); }
+        const uint32_t ea = level_pos(2 * r, d.rows_x), eb = level_pos(2 * r + 1, d.rows_x);
+        q.n0 = load_n<NBASE>(d.src[0], ea);
+        q.d0 = ld_ext((const Ext*)d.src[1], ea);
+        if (2 * r + 1 < d.rows_x) { q.n1 = load_n<NBASE>(d.src[0], eb); q.d1 = ld_ext((const Ext*)d.src[1], eb); }
         else { q.n1 = kb::ext_zero(); q.d1 = kb::ext_one(); }
     } else {
         const uint32_t rp = folded_pos(r, d.rows);
