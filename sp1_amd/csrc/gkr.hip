@@ -421,65 +421,105 @@ __device__ __forceinline__ void rs_finish_chain(const Ext (&acc)[NS], uint32_t* 
     if (threadIdx.x < 16) gkr_round_tail(fin, ca);
 }
 
+// Small rounds (FLAT): most of a proof's ~230 row rounds have a handful of pairs per interaction — one workgroup per
+// interaction is then 730 workgroups of one busy lane each, and what the launch costs is the 730 tickets and partial sums of
+// its tail. FLAT launches give every LANE one pair instead: lane p of the launch looks its descriptor up in a host-built
+// table (flat_index[p]; descs[].tile0 = first pair of the interaction), weighs its own sums with its interaction's eq
+// factor, and the launch is total_pairs / 256 workgroups.
+struct FlatArgs { const uint16_t* index; uint32_t total_pairs; };
+
 // round 0 of a layer: sums only. T = partial-Lagrange table of the layer's row point (2^v entries)
-template <bool NBASE>
+template <bool NBASE, bool FLAT>
 __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
                                                        const Ext* __restrict__ T, Ext lambda, uint32_t* __restrict__ partials,
-                                                       RoundSync rs, uint32_t seq, uint32_t K, uint32_t tile_size, GkrChainArgs ca) {
-    const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
+                                                       RoundSync rs, uint32_t seq, uint32_t K, uint32_t tile_size, GkrChainArgs ca, FlatArgs fa) {
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
-    const uint32_t pairs = (d.rows + 1) / 2;
-    const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
-    for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-        const Quad a = load_quad<true, NBASE>(d, 2 * k), b = load_quad<true, NBASE>(d, 2 * k + 1);
-        accumulate_pair(a, b, lambda, ld_ext(T, 2 * k), ld_ext(T, 2 * k + 1), acc);
-    }
-    const Ext w = ld_ext(eq_int, d.eq_int_index);
+    if (FLAT) {
+        const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+        if (p < fa.total_pairs) {
+            const RoundDesc d = descs[fa.index[p]];
+            const uint32_t k = p - d.tile0;
+            const Quad a = load_quad<true, NBASE>(d, 2 * k), b = load_quad<true, NBASE>(d, 2 * k + 1);
+            accumulate_pair(a, b, lambda, ld_ext(T, 2 * k), ld_ext(T, 2 * k + 1), acc);
+            const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
-    for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+            for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+        }
+    } else {
+        const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
+        const uint32_t pairs = (d.rows + 1) / 2;
+        const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
+        for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+            const Quad a = load_quad<true, NBASE>(d, 2 * k), b = load_quad<true, NBASE>(d, 2 * k + 1);
+            accumulate_pair(a, b, lambda, ld_ext(T, 2 * k), ld_ext(T, 2 * k + 1), acc);
+        }
+        const Ext w = ld_ext(eq_int, d.eq_int_index);
+#pragma unroll
+        for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+    }
     if (ca.st) rs_finish_chain<3>(acc, partials, blockIdx.x, gridDim.x, rs.counter, ca);
     else rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
 }
 
+// rows (4k .. 4k+3) -> folded rows (2k, 2k+1), stored; and (if SUM) the next round's sums from the folded pair
+template <bool FIRST, bool NBASE, bool SUM>
+__device__ __forceinline__ void fold_sum_pair(const RoundDesc& d, uint32_t k, uint32_t rows_out, const Ext& alpha, const Ext& lambda,
+                                              const Ext* __restrict__ T_next, Ext (&acc)[3]) {
+    // every load of the iteration is issued before the first use: one exposed memory latency per iteration instead
+    // of three (rows of h = 0, rows of h = 1, eq table), at the price of ~40 more live VGPRs
+    Quad in[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) in[q] = load_quad<FIRST, NBASE>(d, 4 * k + q);
+    Ext ta, tb;
+    if (SUM) { ta = ld_ext(T_next, 2 * k); tb = ld_ext(T_next, 2 * k + 1); }
+    Quad o[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t ro = 2 * k + h;
+        const Quad& a = in[2 * h];
+        const Quad& b = in[2 * h + 1];
+        o[h].n0 = lerp(a.n0, b.n0, alpha); o[h].d0 = lerp(a.d0, b.d0, alpha);
+        o[h].n1 = lerp(a.n1, b.n1, alpha); o[h].d1 = lerp(a.d1, b.d1, alpha);
+        // (the fold that binds the last row variable, SUM = false, leaves one row per table for the host: natural order)
+        const uint32_t rq = SUM ? folded_pos(ro, rows_out) : ro;
+        if (ro < rows_out) { st_ext(d.dst[0], rq, o[h].n0); st_ext(d.dst[1], rq, o[h].d0); st_ext(d.dst[2], rq, o[h].n1); st_ext(d.dst[3], rq, o[h].d1); }
+    }
+    if (SUM) accumulate_pair(o[0], o[1], lambda, ta, tb, acc);
+}
+
 // fold rows (2r', 2r'+1) -> r' with alpha for r' = 2k, 2k+1, store, and (if SUM) accumulate the next round's sums
 // from the folded pair. T_next = table of the remaining row variables (half the size).
-template <bool FIRST, bool NBASE, bool SUM>
+template <bool FIRST, bool NBASE, bool SUM, bool FLAT>
 __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
                                                       const Ext* __restrict__ T_next, Ext lambda, Ext alpha_arg,
                                                       uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq, uint32_t K,
-                                                      uint32_t tile_size, GkrChainArgs ca) {
-    const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
+                                                      uint32_t tile_size, GkrChainArgs ca, FlatArgs fa) {
     const Ext alpha = ca.st ? ld_ext(&ca.st->alpha, 0) : alpha_arg;      // chained: left by the previous round's last workgroup
     Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
-    const uint32_t rows_out = (d.rows + 1) / 2;
-    const uint32_t pairs = (rows_out + 1) / 2;
-    const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
-    for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-        // every load of the iteration is issued before the first use: one exposed memory latency per iteration instead
-        // of three (rows of h = 0, rows of h = 1, eq table), at the price of ~40 more live VGPRs
-        Quad in[4];
+    if (FLAT) {
+        const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+        if (p < fa.total_pairs) {
+            const RoundDesc d = descs[fa.index[p]];
+            fold_sum_pair<FIRST, NBASE, SUM>(d, p - d.tile0, (d.rows + 1) / 2, alpha, lambda, T_next, acc);
+            if (SUM) {
+                const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
-        for (int q = 0; q < 4; q++) in[q] = load_quad<FIRST, NBASE>(d, 4 * k + q);
-        Ext ta, tb;
-        if (SUM) { ta = ld_ext(T_next, 2 * k); tb = ld_ext(T_next, 2 * k + 1); }
-        Quad o[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t ro = 2 * k + h;
-            const Quad& a = in[2 * h];
-            const Quad& b = in[2 * h + 1];
-            o[h].n0 = lerp(a.n0, b.n0, alpha); o[h].d0 = lerp(a.d0, b.d0, alpha);
-            o[h].n1 = lerp(a.n1, b.n1, alpha); o[h].d1 = lerp(a.d1, b.d1, alpha);
-            // (the fold that binds the last row variable, SUM = false, leaves one row per table for the host: natural order)
-            const uint32_t rq = SUM ? folded_pos(ro, rows_out) : ro;
-            if (ro < rows_out) { st_ext(d.dst[0], rq, o[h].n0); st_ext(d.dst[1], rq, o[h].d0); st_ext(d.dst[2], rq, o[h].n1); st_ext(d.dst[3], rq, o[h].d1); }
+                for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+            }
         }
-        if (SUM) accumulate_pair(o[0], o[1], lambda, ta, tb, acc);
+    } else {
+        const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
+        const uint32_t rows_out = (d.rows + 1) / 2;
+        const uint32_t pairs = (rows_out + 1) / 2;
+        const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
+        for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) fold_sum_pair<FIRST, NBASE, SUM>(d, k, rows_out, alpha, lambda, T_next, acc);
+        if (SUM) {
+            const Ext w = ld_ext(eq_int, d.eq_int_index);
+#pragma unroll
+            for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+        }
     }
     if (SUM) {
-        const Ext w = ld_ext(eq_int, d.eq_int_index);
-#pragma unroll
-        for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
         if (ca.st) rs_finish_chain<3>(acc, partials, blockIdx.x, gridDim.x, rs.counter, ca);
         else rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
     }
@@ -797,8 +837,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     auto scratch_ptr = [&](int b, uint32_t i, int which, const std::vector<size_t>& so) -> Ext* { return scratch[b].ext() + 4 * so[i] + (size_t)which * (so[i + 1] - so[i]); };
     // fills K descriptors of one launch. j = round index inside the layer (0 = sums only, >= 1 fold of round j-1),
     // last = the fold that binds the last row variable
-    struct LaunchShape { uint32_t tiles, tile_size; };
+    struct LaunchShape { uint32_t tiles, tile_size, total_pairs; size_t flat_off; bool flat; };
     std::vector<LaunchShape> shapes;
+    std::vector<uint16_t> flat_index;                        // FLAT launches: pair -> descriptor, all launches back to back
+    static const uint32_t FLAT_MAX_PAIRS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_PAIRS"); return e ? (uint32_t)atoi(e) : 16384u; }();
     // workgroups of a large round: one resident set (256 CUs x 4 workgroups), no tail wave — measured on the core-shaped
     // shard (GKR kernels, ms): 512: 32.2, 768: 30.1, 1024: 29.2, 1536: 29.7, 3072: 31.3, 6144: 34.3 (SP1HIP_GKR_TILES)
     static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? (uint32_t)atoi(e) : 1024u; }();
@@ -808,7 +850,9 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         uint64_t total_pairs = 0;
         auto pairs_of = [&](uint32_t rows) -> uint32_t { const uint32_t p = (rows + 1) / 2; return j == 0 ? p : (p + 1) / 2; };
         for (uint32_t i = 0; i < K; i++) total_pairs += pairs_of(live[i]);
-        const uint32_t tile_size = (uint32_t)std::max<uint64_t>(256, ((total_pairs + TARGET_TILES - 1) / TARGET_TILES + 255) / 256 * 256);
+        const bool flat = total_pairs <= FLAT_MAX_PAIRS && K <= 65536 && !last;
+        const uint32_t tile_size = flat ? 1u : (uint32_t)std::max<uint64_t>(256, ((total_pairs + TARGET_TILES - 1) / TARGET_TILES + 255) / 256 * 256);
+        const size_t flat_off = flat_index.size();
         uint32_t tile0 = 0;
         for (uint32_t i = 0; i < K; i++) {
             RoundDesc& d = out[i];
@@ -819,9 +863,12 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
             if (j > 0 || last) for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
             d.tile0 = tile0;
-            tile0 += (pairs_of(live[i]) + tile_size - 1) / tile_size;
+            const uint32_t n_tiles = (pairs_of(live[i]) + tile_size - 1) / tile_size;
+            if (flat) flat_index.insert(flat_index.end(), n_tiles, (uint16_t)i);
+            tile0 += n_tiles;
         }
-        shapes.push_back(LaunchShape{std::max<uint32_t>(tile0, 1), tile_size});
+        if (flat) shapes.push_back(LaunchShape{std::max<uint32_t>((tile0 + 255) / 256, 1), tile_size, tile0, flat_off, true});
+        else shapes.push_back(LaunchShape{std::max<uint32_t>(tile0, 1), tile_size, tile0, 0, false});
     };
     std::vector<RoundDesc> all_descs;
     for (int v = 1; v <= L - 1; v++) {
@@ -845,6 +892,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     mark("round descriptors planned");
     DeviceBuf d_all;
     SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s, stage));     // all_descs outlives the copy
+    DeviceBuf d_flat;
+    if (flat_index.empty()) flat_index.push_back(0);
+    flat_index.resize((flat_index.size() + 1) / 2 * 2);
+    SP1HIP_TRY(upload(d_flat, flat_index.data(), flat_index.size() * sizeof(uint16_t), s, stage));
     mark("round descriptors uploaded");
     // ---- circuit output = level 1 (<= 2 rows per interaction): index 2 i + r, padding (0, 1)
     std::vector<Ext> out_n(2 * (size_t)W, kb::ext_zero()), out_d(2 * (size_t)W, kb::ext_one());
@@ -968,12 +1019,15 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
             const GkrChainArgs ca = chain ? GkrChainArgs{(GkrChain*)d_chain.p, (const GkrRoundConst*)d_rconst.p + j, (GkrRoundOut*)d_rout.p + j, d_p2rc}
                                           : GkrChainArgs{nullptr, nullptr, nullptr, nullptr};
+            const FlatArgs fa{(const uint16_t*)d_flat.p + shape.flat_off, shape.total_pairs};
             if (j == 0) {
                 tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_sum_first", s);
                 const RoundSync rs = chain ? RoundSync{rsync.d_counter, nullptr} : rsync.next();
-                if (v + 1 == L) hipLaunchKernelGGL(round_sum_first<true>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
-                else hipLaunchKernelGGL(round_sum_first<false>, dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
+#define SP1HIP_GKR_SUM_FIRST(NB, FL) hipLaunchKernelGGL((round_sum_first<NB, FL>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca, fa)
+                if (v + 1 == L) { if (shape.flat) SP1HIP_GKR_SUM_FIRST(true, true); else SP1HIP_GKR_SUM_FIRST(true, false); }
+                else { if (shape.flat) SP1HIP_GKR_SUM_FIRST(false, true); else SP1HIP_GKR_SUM_FIRST(false, false); }
+#undef SP1HIP_GKR_SUM_FIRST
             } else {
                 // fold round j-1 with alpha_r into scratch[cur], summing round j
                 so_next.assign(K + 1, 0);
@@ -982,9 +1036,11 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_fold_sum", s);
                 const RoundSync rs = chain ? RoundSync{rsync.d_counter, nullptr} : rsync.next();
-                if (j == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
-                else if (j == 1) hipLaunchKernelGGL((round_fold_sum<true, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
-                else hipLaunchKernelGGL((round_fold_sum<false, false, true>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca);
+#define SP1HIP_GKR_FOLD_SUM(F, NB, FL) hipLaunchKernelGGL((round_fold_sum<F, NB, true, FL>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca, fa)
+                if (j == 1 && v + 1 == L) { if (shape.flat) SP1HIP_GKR_FOLD_SUM(true, true, true); else SP1HIP_GKR_FOLD_SUM(true, true, false); }
+                else if (j == 1) { if (shape.flat) SP1HIP_GKR_FOLD_SUM(true, false, true); else SP1HIP_GKR_FOLD_SUM(true, false, false); }
+                else { if (shape.flat) SP1HIP_GKR_FOLD_SUM(false, false, true); else SP1HIP_GKR_FOLD_SUM(false, false, false); }
+#undef SP1HIP_GKR_FOLD_SUM
                 for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2;
                 so_prev = so_next;
                 cur ^= 1;
@@ -1021,9 +1077,9 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             const uint32_t tiles = shape.tiles;
             (void)max_out;
             const GkrChainArgs ca = chain ? GkrChainArgs{(GkrChain*)d_chain.p, nullptr, nullptr, nullptr} : GkrChainArgs{nullptr, nullptr, nullptr, nullptr};
-            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca);
-            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca);
-            else hipLaunchKernelGGL((round_fold_sum<false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca);
+            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca, FlatArgs{nullptr, 0u});
+            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca, FlatArgs{nullptr, 0u});
+            else hipLaunchKernelGGL((round_fold_sum<false, false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca, FlatArgs{nullptr, 0u});
             SP1HIP_LAUNCH_CHECK();
             if (chain) {
                 // ONE hand-over for the layer's v rounds: the messages, the challenges, the running values and the sponge

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void tracegen_copy_kernel(uint32_t* __restrict
 }
 
 // Poseidon2Wide (degree 3): 179 columns per row
-constexpr int P2_COLS = 8 * 16 + 16 + 19 + 16;
+// (8 * 16 + 16 + 19 + 16 = 179 columns)
 __global__ __launch_bounds__(256) void tracegen_poseidon2_wide_kernel(uint32_t* __restrict__ trace, uint64_t height,
                                                                      const uint32_t* __restrict__ events, uint64_t n_events,
                                                                      const p2::RoundConstants* __restrict__ rc) {
