@@ -95,6 +95,12 @@ constexpr uint32_t ZC_TOUCH = 9;           // pseudo-op: column never loaded by 
 // a CONST): the constant travels in the instruction word — no register, no LDS access, and in the extension rounds a
 // constant factor is 4 base products instead of a full 16-product extension multiply
 constexpr uint32_t ZC_ADDC = 10, ZC_SUBC = 11, ZC_CSUB = 12, ZC_MULC = 13;
+// fused multiply-add by a constant (register allocation, host): acc + term * c for a MULC whose only use is the ADD / SUB
+// (as subtrahend, c negated) that follows it — the linear combinations real chips are full of (limb recompositions, the
+// closed-form Poseidon2 rounds) become ONE dispatch per term, and the running sum is forwarded from instruction to
+// instruction in VGPRs instead of going through the register file. Word: op | flags, dst | (acc register << 16), term
+// register, c; ZC_A_PREV: term = previous value, ZC_B_PREV: acc = previous value.
+constexpr uint32_t ZC_MADC = 14;
 constexpr uint32_t ZC_MONO_MIN_TERMS = 1024; // rounds with at least this many row pairs run a chip's program in ONE piece
 constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
 constexpr uint32_t ZC_CHUNK_HARD_MAX = 320; // a chunk may grow to this while its asserts share most of their cones
@@ -167,12 +173,13 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
             case ZC_SUBC: res = KC<FIRST>::subc(a, y); break;
             case ZC_CSUB: res = KC<FIRST>::csub(y, a); break;
             case ZC_MULC: res = KC<FIRST>::mulc(a, y); break;
+            case ZC_MADC: res = K::add((opw & ZC_B_PREV) ? prev : reg.get(dst >> 16), KC<FIRST>::mulc(a, y)); break;
             default:                                                  // ASSERT_ZERO
                 acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, y), a));     // y: the constraint's index
                 continue;
         }
         prev = res;
-        if (!(opw & ZC_DST_TEMP)) reg.set(dst, res);
+        if (!(opw & ZC_DST_TEMP)) reg.set(dst & 0xffffu, res);
     }
     return acc;
 }
@@ -583,9 +590,24 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
             n_uses[a]++;
         }
     }
-    {   // next_val[k]: the first value-producing instruction after k
+    // fused[k]: a MULC whose single use is the ADD / SUB (as subtrahend) that is the next value-producing instruction:
+    // it is not emitted, its user becomes a MADC
+    std::vector<char> fused(n, 0);
+    std::vector<int> fused_src(n, -1);         // for the user: the MULC it absorbs
+    static const bool madc_enabled = [] { const char* e = getenv("SP1HIP_ZC_MADC"); return !(e && e[0] == '0'); }();
+    if (madc_enabled)
+        for (uint32_t k = 0; k + 1 < n; k++) {
+            if (ssa[3 * k] != ZC_MULC || n_uses[k] != 1) continue;
+            uint32_t u = k + 1;
+            while (u < n && ssa[3 * u] == ZC_ASSERT_ZERO) u++;
+            if (u >= n || fused_src[u] >= 0) continue;
+            const uint32_t uop = ssa[3 * u], ua = ssa[3 * u + 1], ub = ssa[3 * u + 2];
+            if (ua == ub) continue;
+            if ((uop == ZC_ADD && (ua == k || ub == k)) || (uop == ZC_SUB && ub == k)) { fused[k] = 1; fused_src[u] = (int)k; }
+        }
+    {   // next_val[k]: the first value-producing (emitted) instruction after k
         int nv = -1;
-        for (uint32_t k = n; k-- > 0;) { next_val[k] = nv; if (ssa[3 * k] != ZC_ASSERT_ZERO) nv = (int)k; }
+        for (uint32_t k = n; k-- > 0;) { next_val[k] = nv; if (ssa[3 * k] != ZC_ASSERT_ZERO && !fused[k]) nv = (int)k; }
     }
     // load groups: group_len[k] > 0 on the first LOAD of a run, 0 on the merged followers
     std::vector<uint32_t> group_len(n, 1);
@@ -624,7 +646,30 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t op = ssa[3 * k], a = ssa[3 * k + 1], b = ssa[3 * k + 2];
         if (group_len[k] == 0) continue;       // merged into the group's first LOAD
+        if (fused[k]) continue;                // emitted with its user
         uint32_t word = op, ra = a, rb = b;
+        if (fused_src[k] >= 0) {               // acc +- (term * c)  ->  MADC
+            const uint32_t m = (uint32_t)fused_src[k], term = ssa[3 * m + 1], acc = a == m ? b : a;
+            const uint32_t c = kb::to_monty(ssa[3 * m + 2] % kb::P);
+            uint32_t racc = 0;
+            word = ZC_MADC;
+            if ((int)term == last_value) word |= ZC_A_PREV; else ra = reg_of[term];
+            if ((int)acc == last_value) word |= ZC_B_PREV; else racc = reg_of[acc];
+            if ((!(word & ZC_A_PREV) && ra == 0xffffffffu) || (!(word & ZC_B_PREV) && racc == 0xffffffffu)) {
+                set_error("internal: operand of fused instruction %u has no register", k);
+                return SP1HIP_ERROR_RUNTIME;
+            }
+            if (word & ZC_A_PREV) ra = 0;
+            if (last_use[term] == (int)m && reg_of[term] != 0xffffffffu) { busy[reg_of[term]] = 0; reg_of[term] = 0xffffffffu; }
+            if (acc != term && last_use[acc] == (int)k && reg_of[acc] != 0xffffffffu) { busy[reg_of[acc]] = 0; reg_of[acc] = 0xffffffffu; }
+            uint32_t dst = 0;
+            if (is_temp(k) || n_uses[k] == 0) word |= ZC_DST_TEMP;
+            else { dst = take(1); reg_of[k] = dst; }
+            if (dst > 0xffffu || racc > 0xffffu) { set_error("constraint program needs more than 65536 registers"); return SP1HIP_ERROR_RUNTIME; }
+            last_value = (int)k;
+            out->insert(out->end(), {word, dst | (racc << 16), ra, op == ZC_SUB ? kb::neg(c) : c});
+            continue;
+        }
         if (is_bin(op) || is_un(op)) {
             if ((int)a == last_value) word |= ZC_A_PREV; else ra = reg_of[a];
             if (is_bin(op)) { if ((int)b == last_value) word |= ZC_B_PREV; else rb = reg_of[b]; }
@@ -779,7 +824,7 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t opw = c.prog[4 * k], op = opw & 0xffu, dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
         const uint32_t A = (opw & ZC_A_PREV) ? prev : (op >= ZC_ADD && op != ZC_TOUCH ? reg[x] : 0u);
-        const uint32_t B = (opw & ZC_B_PREV) ? prev : (op >= ZC_ADD && op <= ZC_MUL ? reg[y] : 0u);
+        const uint32_t B = (op <= ZC_MUL && (opw & ZC_B_PREV)) ? prev : (op >= ZC_ADD && op <= ZC_MUL ? reg[y] : 0u);
         uint32_t res = 0;
         switch (op) {
             case ZC_LOAD_MAIN: case ZC_LOAD_PREP:
@@ -797,10 +842,11 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
             case ZC_SUBC: res = kb::sub(A, y); break;
             case ZC_CSUB: res = kb::sub(y, A); break;
             case ZC_MULC: res = kb::mul(A, y); break;
+            case ZC_MADC: res = kb::add((opw & ZC_B_PREV) ? prev : reg[dst >> 16], kb::mul(A, y)); break;
             default: acc = acc + kb::ext_mul_base(c.alpha_pows[y], A); continue;
         }
         prev = res;
-        if (!(opw & ZC_DST_TEMP)) reg[dst] = res;
+        if (!(opw & ZC_DST_TEMP)) reg[dst & 0xffffu] = res;
     }
     return acc;
 }
