@@ -461,30 +461,46 @@ __global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restri
     else rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
 }
 
-// rows (4k .. 4k+3) -> folded rows (2k, 2k+1), stored; and (if SUM) the next round's sums from the folded pair
+// rows (4k .. 4k+3) -> folded rows (2k, 2k+1), stored; and (if SUM) the next round's sums from the folded pair.
+// Split in two so that the tiled loop can issue the loads of iteration i + 1 before the arithmetic of iteration i.
+// Software-pipelined variant of the tiled loop (loads of iteration i + 1 in flight during the arithmetic of iteration i):
+// 182 VGPRs -> 2 waves per SIMD instead of 4. Measured on the core-shaped shard: later folds -4 %, a layer's first fold -9 %,
+// the top layer's first fold (base-field numerators) +7 %: no net gain — with the lane-blocked layouts the large rounds
+// are bound by VALU issue (2,400 instructions per iteration, a third of them half-rate 64-bit multiply-adds: ~87 % of that
+// bound), not by exposed latency. Off; kept for A/B runs.
+constexpr bool PREFETCH_FOLDS = false;
+struct FoldIn { Quad in[4]; Ext ta, tb; };
 template <bool FIRST, bool NBASE, bool SUM>
-__device__ __forceinline__ void fold_sum_pair(const RoundDesc& d, uint32_t k, uint32_t rows_out, const Ext& alpha, const Ext& lambda,
-                                              const Ext* __restrict__ T_next, Ext (&acc)[3]) {
+__device__ __forceinline__ void fold_load(const RoundDesc& d, uint32_t k, const Ext* __restrict__ T_next, FoldIn& f) {
     // every load of the iteration is issued before the first use: one exposed memory latency per iteration instead
-    // of three (rows of h = 0, rows of h = 1, eq table), at the price of ~40 more live VGPRs
-    Quad in[4];
+    // of three (rows of h = 0, rows of h = 1, eq table)
 #pragma unroll
-    for (int q = 0; q < 4; q++) in[q] = load_quad<FIRST, NBASE>(d, 4 * k + q);
-    Ext ta, tb;
-    if (SUM) { ta = ld_ext(T_next, 2 * k); tb = ld_ext(T_next, 2 * k + 1); }
+    for (int q = 0; q < 4; q++) f.in[q] = load_quad<FIRST, NBASE>(d, 4 * k + q);
+    if (SUM) { f.ta = ld_ext(T_next, 2 * k); f.tb = ld_ext(T_next, 2 * k + 1); }
+}
+template <bool SUM>
+__device__ __forceinline__ void fold_compute(const RoundDesc& d, uint32_t k, uint32_t rows_out, const Ext& alpha, const Ext& lambda,
+                                             const FoldIn& f, Ext (&acc)[3]) {
     Quad o[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t ro = 2 * k + h;
-        const Quad& a = in[2 * h];
-        const Quad& b = in[2 * h + 1];
+        const Quad& a = f.in[2 * h];
+        const Quad& b = f.in[2 * h + 1];
         o[h].n0 = lerp(a.n0, b.n0, alpha); o[h].d0 = lerp(a.d0, b.d0, alpha);
         o[h].n1 = lerp(a.n1, b.n1, alpha); o[h].d1 = lerp(a.d1, b.d1, alpha);
         // (the fold that binds the last row variable, SUM = false, leaves one row per table for the host: natural order)
         const uint32_t rq = SUM ? folded_pos(ro, rows_out) : ro;
         if (ro < rows_out) { st_ext(d.dst[0], rq, o[h].n0); st_ext(d.dst[1], rq, o[h].d0); st_ext(d.dst[2], rq, o[h].n1); st_ext(d.dst[3], rq, o[h].d1); }
     }
-    if (SUM) accumulate_pair(o[0], o[1], lambda, ta, tb, acc);
+    if (SUM) accumulate_pair(o[0], o[1], lambda, f.ta, f.tb, acc);
+}
+template <bool FIRST, bool NBASE, bool SUM>
+__device__ __forceinline__ void fold_sum_pair(const RoundDesc& d, uint32_t k, uint32_t rows_out, const Ext& alpha, const Ext& lambda,
+                                              const Ext* __restrict__ T_next, Ext (&acc)[3]) {
+    FoldIn f;
+    fold_load<FIRST, NBASE, SUM>(d, k, T_next, f);
+    fold_compute<SUM>(d, k, rows_out, alpha, lambda, f, acc);
 }
 
 // fold rows (2r', 2r'+1) -> r' with alpha for r' = 2k, 2k+1, store, and (if SUM) accumulate the next round's sums
@@ -512,7 +528,22 @@ __global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restric
         const uint32_t rows_out = (d.rows + 1) / 2;
         const uint32_t pairs = (rows_out + 1) / 2;
         const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
-        for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) fold_sum_pair<FIRST, NBASE, SUM>(d, k, rows_out, alpha, lambda, T_next, acc);
+        if (PREFETCH_FOLDS && SUM) {
+            // software pipeline: the loads of iteration i + 1 are in flight during the arithmetic of iteration i
+            uint32_t k = k0 + threadIdx.x;
+            FoldIn cur;
+            if (k < k1) fold_load<FIRST, NBASE, SUM>(d, k, T_next, cur);
+            while (k < k1) {
+                const uint32_t kn = k + blockDim.x;
+                FoldIn nxt;
+                if (kn < k1) fold_load<FIRST, NBASE, SUM>(d, kn, T_next, nxt);
+                fold_compute<SUM>(d, k, rows_out, alpha, lambda, cur, acc);
+                if (kn < k1) cur = nxt;
+                k = kn;
+            }
+        } else {
+            for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) fold_sum_pair<FIRST, NBASE, SUM>(d, k, rows_out, alpha, lambda, T_next, acc);
+        }
         if (SUM) {
             const Ext w = ld_ext(eq_int, d.eq_int_index);
 #pragma unroll
