@@ -219,6 +219,9 @@ int sp1hip_challenger_state(const sp1hip_challenger_t* ch, uint32_t* out34);
 typedef struct sp1hip_basefold_data_s sp1hip_basefold_data_t;
 int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg_blowup, uint32_t h_commit[8],
                        sp1hip_basefold_data_t** out, sp1hip_stream_t stream);
+/* Prover data is scratch of the stream it was committed on: freeing it orders the reuse of its blocks behind THAT stream's
+ * work. A handle that was also opened on another stream (a proving key shared by provers on their own streams) waits for
+ * the device when it is freed; do not free a handle while a prove call that uses it is still running on another thread. */
 void sp1hip_basefold_data_free(sp1hip_basefold_data_t* data);
 /* accessors for parity tests */
 int sp1hip_basefold_data_codeword(const sp1hip_basefold_data_t* data, int mle_index, const uint32_t** d_codeword,

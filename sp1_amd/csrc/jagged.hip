@@ -841,6 +841,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     for (int r = 0; r < n_rounds; r++) {
         const sp1hip_stacked_data_s* d = rounds[r];
         SP1HIP_REQUIRE(d && d->jagged, "round data did not come from sp1hip_jagged_commit");
+        if (d->stream != s) rounds[r]->foreign_use = true;
         SP1HIP_REQUIRE(d->log_stacking_height == lsh && d->max_log_row_count == max_log_row_count, "rounds disagree on parameters");
         SP1HIP_REQUIRE(d->area > 0, "a commitment round without any table data cannot be opened");
         uint64_t expect = 0;

@@ -179,6 +179,11 @@ struct sp1hip_basefold_data_s {
     sp1hip::DeviceBuf tree;
     uint32_t root[8], commit[8];
     uint32_t total_width = 0;
+    // The blocks go back to the free list of the stream that created them, which orders their reuse behind that stream's
+    // work only. A handle that was also read on ANOTHER stream (a proving key's preprocessed commitment is opened by every
+    // prover, each on its own stream) waits for the device before it lets go.
+    bool foreign_use = false;
+    ~sp1hip_basefold_data_s() { if (foreign_use) (void)hipDeviceSynchronize(); }
 };
 
 namespace sp1hip {
@@ -617,6 +622,7 @@ int sp1hip_basefold_prove(const sp1hip_ext_t* h_point, int dim, sp1hip_basefold_
     for (int r = 0; r < n_rounds; r++) {
         SP1HIP_REQUIRE(rounds[r], "null round");
         widths.push_back(rounds[r]->total_width);
+        if (rounds[r]->tree.s != S(stream)) rounds[r]->foreign_use = true;
     }
     const size_t need = proof_size(dim, widths, config);
     if (!h_proof || *proof_len < need) {

@@ -21,7 +21,9 @@ struct sp1hip_stacked_data_s {
     std::vector<uint64_t> row_counts, column_counts;   // per table, the two padding tables appended
     uint64_t padding_column_count = 0;
     uint32_t jagged_commit[8];
+    bool foreign_use = false;            // read on a stream other than `stream` (see sp1hip_basefold_data_s)
     ~sp1hip_stacked_data_s() {
+        if (foreign_use) (void)hipDeviceSynchronize();
         if (basefold) sp1hip_basefold_data_free(basefold);
         sp1hip::arena_free(d_dense, padded * 4, stream);
     }
