@@ -1149,9 +1149,12 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             const std::vector<Chunk>& cks = use_mono[i] ? c.mono : c.chunks;
             uint32_t regs = 1, instr = 1;
             for (auto& ck : cks) { regs = std::max(regs, ck.n_regs); instr = std::max<uint32_t>(instr, (uint32_t)(ck.prog.size() / 4)); }
-            // short programs are staged in LDS (<= 16 KiB, read by every wave of the workgroup); long ones stream
-            // through the scalar cache and leave the LDS to the register file
-            bool staged = instr <= 1024;
+            // programs stream through the scalar cache (wave-uniform s_load_dwordx4 straight into SGPRs: no LDS read and no
+            // v_readfirstlane per instruction word, and the whole LDS budget goes to the register file). Staging programs
+            // of up to SP1HIP_ZC_STAGE_MAX instructions in LDS instead was the default until it was measured 3-5 % slower
+            // (recursion shard 14.6 vs 13.8 ms of round kernels, core-shaped 10.4 vs 10.1); the VGPR / scratch tier still stages.
+            static const uint32_t stage_max = [] { const char* e = getenv("SP1HIP_ZC_STAGE_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
+            bool staged = instr <= stage_max;
             uint32_t wg = r == 0 ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
             if (wg == 0) {                  // the file does not fit LDS: VGPR / scratch tier, program staged
                 SP1HIP_REQUIRE(instr <= ZC_LDS_PROG_MAX, "constraint program too large (one constraint with too many live values)");
