@@ -101,6 +101,7 @@ constexpr uint32_t ZC_ADDC = 10, ZC_SUBC = 11, ZC_CSUB = 12, ZC_MULC = 13;
 // instruction in VGPRs instead of going through the register file. Word: op | flags, dst | (acc register << 16), term
 // register, c; ZC_A_PREV: term = previous value, ZC_B_PREV: acc = previous value.
 constexpr uint32_t ZC_MADC = 14;
+constexpr uint32_t ZC_RSUB = 15;           // b - a: a SUB whose forwarded operand is the subtrahend (register allocation, host)
 constexpr uint32_t ZC_MONO_MIN_TERMS = 1024; // rounds with at least this many row pairs run a chip's program in ONE piece
 constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
 constexpr uint32_t ZC_CHUNK_HARD_MAX = 320; // a chunk may grow to this while its asserts share most of their cones
@@ -159,24 +160,42 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
             }
             continue;
         }
-        T a = prev, b = prev, res;
-        if (op >= ZC_ADD && !(opw & ZC_A_PREV)) a = reg.get(x);
-        if (op >= ZC_ADD && op <= ZC_MUL && !(opw & ZC_B_PREV)) b = reg.get(y);
-        switch (op) {
-            case ZC_CONST: res = K::from_f(x); break;               // host pre-converts to Montgomery
-            case ZC_PUBLIC: res = K::from_f(publics[x]); break;
-            case ZC_ADD: res = K::add(a, b); break;
-            case ZC_SUB: res = K::sub(a, b); break;
-            case ZC_MUL: res = K::mul(a, b); break;
-            case ZC_NEG: res = K::sub(K::zero(), a); break;
-            case ZC_ADDC: res = KC<FIRST>::addc(a, y); break;
-            case ZC_SUBC: res = KC<FIRST>::subc(a, y); break;
-            case ZC_CSUB: res = KC<FIRST>::csub(y, a); break;
-            case ZC_MULC: res = KC<FIRST>::mulc(a, y); break;
-            case ZC_MADC: res = K::add((opw & ZC_B_PREV) ? prev : reg.get(dst >> 16), KC<FIRST>::mulc(a, y)); break;
-            default:                                                  // ASSERT_ZERO
-                acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, y), a));     // y: the constraint's index
-                continue;
+        if (op == ZC_ASSERT_ZERO) {                                   // y: the constraint's index; `prev` stays what it was
+            const T a = (opw & ZC_A_PREV) ? prev : reg.get(x);
+            acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, y), a));
+            continue;
+        }
+        // The forwarded value `prev` is dead once this instruction has read it, so the A operand is loaded INTO it when it
+        // is not the forwarded value itself: no operand copies at the merge of the "forwarded" and "register file" paths
+        // (they were 8 v_mov per extension-field instruction). The host puts the forwarded operand of a binary
+        // instruction first (ADD / MUL commute, SUB becomes RSUB); ZC_B_PREV then means "b is the same value as a".
+        T res;
+        if (op == ZC_MADC) {
+            if (opw & ZC_B_PREV) {                                    // the running sum is the forwarded value
+                const T term = (opw & ZC_A_PREV) ? prev : reg.get(x);
+                res = K::add(prev, KC<FIRST>::mulc(term, y));
+            } else {
+                const T accv = reg.get(dst >> 16);
+                if (!(opw & ZC_A_PREV)) prev = reg.get(x);
+                res = K::add(accv, KC<FIRST>::mulc(prev, y));
+            }
+        } else if (op == ZC_CONST) {
+            res = K::from_f(x);                                       // host pre-converts to Montgomery
+        } else if (op == ZC_PUBLIC) {
+            res = K::from_f(publics[x]);
+        } else {
+            if (!(opw & ZC_A_PREV)) prev = reg.get(x);
+            switch (op) {
+                case ZC_ADD: res = K::add(prev, (opw & ZC_B_PREV) ? prev : reg.get(y)); break;
+                case ZC_SUB: res = K::sub(prev, (opw & ZC_B_PREV) ? prev : reg.get(y)); break;
+                case ZC_RSUB: res = K::sub(reg.get(y), prev); break;
+                case ZC_MUL: res = K::mul(prev, (opw & ZC_B_PREV) ? prev : reg.get(y)); break;
+                case ZC_NEG: res = K::sub(K::zero(), prev); break;
+                case ZC_ADDC: res = KC<FIRST>::addc(prev, y); break;
+                case ZC_SUBC: res = KC<FIRST>::subc(prev, y); break;
+                case ZC_CSUB: res = KC<FIRST>::csub(y, prev); break;
+                default: res = KC<FIRST>::mulc(prev, y); break;      // ZC_MULC
+            }
         }
         prev = res;
         if (!(opw & ZC_DST_TEMP)) reg.set(dst & 0xffffu, res);
@@ -671,8 +690,15 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
             continue;
         }
         if (is_bin(op) || is_un(op)) {
-            if ((int)a == last_value) word |= ZC_A_PREV; else ra = reg_of[a];
-            if (is_bin(op)) { if ((int)b == last_value) word |= ZC_B_PREV; else rb = reg_of[b]; }
+            // the interpreter loads operand A into the forwarded value's registers: a forwarded operand must BE operand A
+            uint32_t oa = a, ob = b;
+            if (is_bin(op) && (int)ob == last_value && (int)oa != last_value) {
+                std::swap(oa, ob);
+                if (op == ZC_SUB) word = ZC_RSUB;
+            }
+            ra = oa; rb = ob;
+            if ((int)oa == last_value) word |= ZC_A_PREV; else ra = reg_of[oa];
+            if (is_bin(op)) { if ((int)ob == last_value) word |= ZC_B_PREV; else rb = reg_of[ob]; }
             if ((!(word & ZC_A_PREV) && ra == 0xffffffffu) || (is_bin(op) && !(word & ZC_B_PREV) && rb == 0xffffffffu)) {
                 set_error("internal: operand of instruction %u has no register", k);
                 return SP1HIP_ERROR_RUNTIME;
@@ -824,7 +850,8 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t opw = c.prog[4 * k], op = opw & 0xffu, dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
         const uint32_t A = (opw & ZC_A_PREV) ? prev : (op >= ZC_ADD && op != ZC_TOUCH ? reg[x] : 0u);
-        const uint32_t B = (op <= ZC_MUL && (opw & ZC_B_PREV)) ? prev : (op >= ZC_ADD && op <= ZC_MUL ? reg[y] : 0u);
+        const bool bin = (op >= ZC_ADD && op <= ZC_MUL) || op == ZC_RSUB;
+        const uint32_t B = (bin && (opw & ZC_B_PREV)) ? prev : (bin ? reg[y] : 0u);
         uint32_t res = 0;
         switch (op) {
             case ZC_LOAD_MAIN: case ZC_LOAD_PREP:
@@ -837,6 +864,7 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
             case ZC_ADD: res = kb::add(A, B); break;
             case ZC_SUB: res = kb::sub(A, B); break;
             case ZC_MUL: res = kb::mul(A, B); break;
+            case ZC_RSUB: res = kb::sub(B, A); break;
             case ZC_NEG: res = kb::neg(A); break;
             case ZC_ADDC: res = kb::add(A, y); break;
             case ZC_SUBC: res = kb::sub(A, y); break;
