@@ -871,7 +871,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     struct LaunchShape { uint32_t tiles, tile_size, total_pairs; size_t flat_off; bool flat; };
     std::vector<LaunchShape> shapes;
     std::vector<uint16_t> flat_index;                        // FLAT launches: pair -> descriptor, all launches back to back
-    static const uint32_t FLAT_MAX_PAIRS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_PAIRS"); return e ? (uint32_t)atoi(e) : 16384u; }();
+    const uint32_t FLAT_MAX_PAIRS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_PAIRS"); return e ? (uint32_t)atoi(e) : 16384u; }();   // read per call (tests)
     // workgroups of a large round: one resident set (256 CUs x 4 workgroups), no tail wave — measured on the core-shaped
     // shard (GKR kernels, ms): 512: 32.2, 768: 30.1, 1024: 29.2, 1536: 29.7, 3072: 31.3, 6144: 34.3 (SP1HIP_GKR_TILES)
     static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? (uint32_t)atoi(e) : 1024u; }();

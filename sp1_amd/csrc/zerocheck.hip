@@ -1181,7 +1181,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             // v_readfirstlane per instruction word, and the whole LDS budget goes to the register file). Staging programs
             // of up to SP1HIP_ZC_STAGE_MAX instructions in LDS instead was the default until it was measured 3-5 % slower
             // (recursion shard 14.6 vs 13.8 ms of round kernels, core-shaped 10.4 vs 10.1); the VGPR / scratch tier still stages.
-            static const uint32_t stage_max = [] { const char* e = getenv("SP1HIP_ZC_STAGE_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();
+            const uint32_t stage_max = [] { const char* e = getenv("SP1HIP_ZC_STAGE_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();   // read per call (tests)
             bool staged = instr <= stage_max;
             uint32_t wg = r == 0 ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
             if (wg == 0) {                  // the file does not fit LDS: VGPR / scratch tier, program staged

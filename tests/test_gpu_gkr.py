@@ -54,6 +54,23 @@ def test_gkr_proof_matches_oracle(api, monkeypatch, n_tuples, L, with_empty, dup
     assert point.shape == (L, 4) and [o[0] for o in opened] == [c[0].name for c in chips]
 
 
+@pytest.mark.parametrize("flat_pairs", ["0", "64"])     # 0: every round one workgroup per tile; 64: both forms inside one layer
+@pytest.mark.parametrize("n_tuples,L,with_empty,dup", [(37, 7, True, 3), (300, 10, True, 3)])
+def test_gkr_small_round_forms_give_the_same_bytes(api, monkeypatch, n_tuples, L, with_empty, dup, flat_pairs):
+    """Rounds with few pairs run one pair per lane (SP1HIP_GKR_FLAT_PAIRS, default 16384 — every round of these sizes);
+    forcing the tiled form, or a mix, must not change a byte."""
+    monkeypatch.setenv("SP1HIP_GKR_FLAT_PAIRS", flat_pairs)
+    chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    seed = orc.random_felts((9,), L)
+    o_ch.observe(seed)
+    g_ch.observe(seed)
+    want = orc.gkr_prove(chips, L, o_ch)
+    got = api.logup_gkr(_dev(api, chips), L, g_ch)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_gkr_rejects_unsorted_chips_and_keeps_transcript(api):
     chips = make_gkr_chips(4, 3)
     dev = _dev(api, chips)

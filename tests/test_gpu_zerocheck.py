@@ -54,6 +54,24 @@ def test_zerocheck_matches_oracle(api, heights, L):
     assert orc.zerocheck_verify(zc, [c.real_rows for c in zc], L, zeta, alpha, gkr, publics, got, v_ch) == 0
 
 
+@pytest.mark.parametrize("heights,L", [
+    ({"Affine": 1000, "Mul": 4096, "Sbox": 2049, "Sbox2": 1}, 12),
+    ({"Chain": 300, "Manyregs": 1000, "Mul": 77}, 10),
+])
+def test_zerocheck_programs_staged_in_lds_give_the_same_bytes(api, monkeypatch, heights, L):
+    """Constraint programs stream through the scalar cache by default; SP1HIP_ZC_STAGE_MAX stages the short ones in LDS
+    (the other instruction-fetch path of the interpreter)."""
+    monkeypatch.setenv("SP1HIP_ZC_STAGE_MAX", "1024")
+    chips, zc, zeta, alpha, gkr, publics, o_ch = setup(heights, L, 40 + L)
+    g_ch = api.DuplexChallenger()
+    g_ch.observe(orc.random_felts((8,), 40 + L))
+    g_ch.sample_point(L); g_ch.sample_ext_element(); g_ch.sample_ext_element()
+    want = orc.zerocheck_prove(zc, L, zeta, alpha, gkr, publics, o_ch)
+    got = api.zerocheck(_gpu_chips(api, chips), L, zeta, np.concatenate([c.openings for c in zc]), alpha, gkr, publics, g_ch)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_zerocheck_rejects_bad_programs_and_keeps_transcript(api):
     chips, zc, zeta, alpha, gkr, publics, _ = setup({"Mul": 4}, 2, 3)
     g = _gpu_chips(api, chips)
