@@ -188,12 +188,15 @@ def main():
         torch.cuda.synchronize()
         n_each = max(2, args.steps // 2)
         bad = []
+        per_proof = {id(s): [] for s in streams}
 
         def worker(s):
             for _ in range(n_each):
+                tp = time.perf_counter()
                 with torch.cuda.stream(s):
                     if step(s) != proof:
                         bad.append(1)
+                per_proof[id(s)].append(round(1e3 * (time.perf_counter() - tp), 1))
 
         t1 = time.perf_counter()
         threads = [threading.Thread(target=worker, args=(s,)) for s in streams]
@@ -204,6 +207,8 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
         assert not bad, "a concurrently produced proof differs from the sequential one"
+        if os.environ.get("SP1HIP_BENCH_DEBUG"):
+            print("two_in_flight per-proof ms:", list(per_proof.values()), file=sys.stderr)
         extras["two_in_flight"] = {"proofs": 2 * n_each, "ms_per_proof": 1e3 * dt2 / (2 * n_each), "cells_per_s": 2 * n_each * area / dt2,
                                    "proofs_per_s": 2 * n_each / dt2}
         # (b) the commit phase alone (BASELINE config 2's stage: RS encode + Poseidon2 Merkle of the main traces)
