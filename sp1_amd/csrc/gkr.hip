@@ -129,7 +129,8 @@ __device__ __forceinline__ uint32_t vcol_apply(prog_words_t& p, const IntDesc& d
     p += 2;
     for (uint32_t t = 0; t < nt; t++, p += 3) {
         const uint32_t* col = (p[0] ? d.main : d.prep) + (size_t)p[1] * d.rows;
-        acc = kb::add(acc, kb::mul(gptr(col)[r], p[2]));
+        const uint32_t v = gptr(col)[r], wgt = p[2];             // most weights are one (a wave-uniform test): no product then
+        acc = kb::add(acc, wgt == kb::R1 ? v : kb::mul(v, wgt));
     }
     return acc;
 }
@@ -635,20 +636,36 @@ Ext poly_eval(const Poly4& c, const Ext& x) { return ((c[3] * x + c[2]) * x + c[
 // interpolate_univariate_polynomial (univariate.rs:L85-L97) — any exact method gives the same coefficients
 Poly4 interpolate4(const Ext (&xs)[4], const Ext (&ys)[4]) {
     Poly4 res{kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+    // a node whose value is zero contributes nothing (every caller's fourth value is the root of the eq factor), and
+    // the remaining denominators are inverted together (one inversion + 3 products per extra denominator): this runs
+    // once per sumcheck round on the host, between two device hand-overs
+    Ext num[4][4], den[4];
+    bool live[4];
     for (int i = 0; i < 4; i++) {
-        Ext den = kb::ext_one();
-        Ext num[4] = {ys[i], kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+        live[i] = !kb::ext_eq(ys[i], kb::ext_zero());
+        if (!live[i]) continue;
+        den[i] = kb::ext_one();
+        Ext cur[4] = {ys[i], kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
         int deg = 0;
         for (int j = 0; j < 4; j++) {
             if (j == i) continue;
-            den = den * (xs[i] - xs[j]);
+            den[i] = den[i] * (xs[i] - xs[j]);
             Ext nxt[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
-            for (int k = 0; k <= deg; k++) { nxt[k + 1] = nxt[k + 1] + num[k]; nxt[k] = nxt[k] - num[k] * xs[j]; }
+            for (int k = 0; k <= deg; k++) { nxt[k + 1] = nxt[k + 1] + cur[k]; nxt[k] = nxt[k] - cur[k] * xs[j]; }
             deg++;
-            for (int k = 0; k < 4; k++) num[k] = nxt[k];
+            for (int k = 0; k < 4; k++) cur[k] = nxt[k];
         }
-        const Ext inv = kb::ext_inv(den);
-        for (int k = 0; k < 4; k++) res[k] = res[k] + num[k] * inv;
+        for (int k = 0; k < 4; k++) num[i][k] = cur[k];
+    }
+    // batch inversion of the live denominators
+    Ext prefix[4], running = kb::ext_one();
+    for (int i = 0; i < 4; i++) if (live[i]) { prefix[i] = running; running = running * den[i]; }
+    Ext inv_all = kb::ext_inv(running);
+    for (int i = 3; i >= 0; i--) {
+        if (!live[i]) continue;
+        const Ext inv = inv_all * prefix[i];
+        inv_all = inv_all * den[i];
+        for (int k = 0; k < 4; k++) res[k] = res[k] + num[i][k] * inv;
     }
     return res;
 }
