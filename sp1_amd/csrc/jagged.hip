@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) void jg_reduce_partials(const uint32_t* __rest
     }
     block_reduce_store(a, b, out8);
     if (threadIdx.x < 8) slot[1 + threadIdx.x] = out8[threadIdx.x];     // the same lanes wrote out8
-    __threadfence_system();
+    // the slot is uncached host memory: acknowledged stores are ordered before the sequence number; a system-scope fence
+    // would also write back this XCD's whole L2 (round_sync.hpp)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) slot[0] = seq;
 }

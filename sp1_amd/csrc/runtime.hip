@@ -265,7 +265,9 @@ void round_sync_release(RoundSyncSlot slot) {
 __global__ __launch_bounds__(256) void mailbox_publish_kernel(const uint32_t* __restrict__ src, uint32_t n,
                                                               volatile uint32_t* slot, uint32_t seq) {
     for (uint32_t i = threadIdx.x; i < n; i += 256) slot[1 + i] = src[i];
-    __threadfence_system();
+    // the slot is uncached host memory: acknowledged stores are ordered before the sequence number; a system-scope fence
+    // would also write back this XCD's whole L2 (round_sync.hpp)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) slot[0] = seq;
 }
