@@ -67,7 +67,11 @@ Pool* pool() {
                     cpus = std::min<unsigned>(cpus, (unsigned)std::max<long long>(1, quota / period));
                 fclose(f);
             }
-            n = (int)std::min<unsigned>(8u, std::max(1u, cpus / 2));
+            // one prover process per GPU (torchrun exports LOCAL_WORLD_SIZE): the processes of a node share the CPUs, and every
+            // prover also has a thread that polls for device hand-overs
+            unsigned procs = 1;
+            if (const char* lw = getenv("LOCAL_WORLD_SIZE")) procs = (unsigned)std::max(1, atoi(lw));
+            n = (int)std::min<unsigned>(8u, std::max(1u, cpus / (2 * procs)));
         }
         n = std::max(1, std::min(n, HostPar::Scope::MAX_THREADS));
         q->helpers = n - 1;

@@ -8,7 +8,8 @@
 // of that scope, and go back to sleep when the scope ends. One set of helpers per process: a second prover that is in
 // flight on another stream finds them taken and simply runs its loops inline (`threads() == 1`).
 // Field arithmetic is exact, so splitting a sum over threads and adding the parts in order gives the same words.
-// SP1HIP_HOST_THREADS=<n> overrides the thread count (1 = never use helpers); default min(8, hardware threads / 2).
+// SP1HIP_HOST_THREADS=<n> overrides the thread count (1 = never use helpers); default min(8, CPUs / (2 x processes of the
+// node)), CPUs honouring the cgroup quota, processes = LOCAL_WORLD_SIZE (one prover process per GPU).
 #pragma once
 #include <cstddef>
 
