@@ -105,6 +105,10 @@ constexpr uint32_t ZC_RSUB = 15;           // b - a: a SUB whose forwarded opera
 constexpr uint32_t ZC_MONO_MIN_TERMS = 1024; // rounds with at least this many row pairs run a chip's program in ONE piece
 constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
 constexpr uint32_t ZC_CHUNK_HARD_MAX = 320; // a chunk may grow to this while its asserts share most of their cones
+// the last rounds (at most ZC_FINE_MAX_TERMS row pairs per chip: one wave, mostly idle lanes) are pure latency — one wave
+// interprets a chunk serially at ~0.35 us per instruction — so they run a third form of the program, cut into pieces of
+// ~ZC_FINE_LIMIT instructions with no regard for recomputation: more workgroups, each a third as long
+constexpr uint32_t ZC_FINE_LIMIT = 32, ZC_FINE_MAX_TERMS = 64;
 constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB); longer programs read global memory
 
 typedef uint32_t zc_word_t __attribute__((ext_vector_type(4)));       // one instruction: op | flags, dst, a, b
@@ -458,7 +462,7 @@ struct ZcPlan {                      // everything that depends on a chip's prog
     std::vector<uint32_t> source;    // the caller's [n][3] program (collision check)
     std::vector<uint32_t> prog;      // allocated [n][4], whole program (padded-row evaluation)
     uint32_t n_regs = 1;
-    std::vector<Chunk> chunks, mono;
+    std::vector<Chunk> chunks, mono, fine;
 };
 
 struct ChipState {
@@ -470,6 +474,8 @@ struct ChipState {
     std::vector<uint32_t> chunk_off;   // offset (in instructions) of each chunk inside d_prog
     std::vector<Chunk> mono;           // the undivided program (+ a TOUCH chunk): no recomputation (the large rounds)
     std::vector<uint32_t> mono_off;
+    std::vector<Chunk> fine;           // short pieces for the last, latency-bound rounds
+    std::vector<uint32_t> fine_off;
     size_t off_prog = 0, off_alpha = 0, off_gkr = 0;     // word offsets into the call's single constant blob
     const uint32_t* p_prog = nullptr;
     const uint32_t* p_alpha = nullptr;
@@ -735,7 +741,7 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
 // keeps the late, tiny sumcheck rounds from being one wave interpreting thousands of instructions
 // serially (cf. the reference's chunked bytecode, /root/reference/sp1-gpu/crates/air/src/ir/bytecode.rs:L27-L110).
 static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32_t prep_w, uint32_t limit,
-                        std::vector<Chunk>* out) {
+                        std::vector<Chunk>* out, uint32_t hard_max = ZC_CHUNK_HARD_MAX) {
     std::vector<uint32_t> stamp(n, 0xffffffffu);
     std::vector<uint8_t> cone_seen(n, 0);
     std::vector<uint32_t> members, asserts, stack;
@@ -787,7 +793,7 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
             // intermediate values: the 16 constraints of a Poseidon2 external round share one S-box / linear layer), closing
             // the chunk here would recompute all of it in the next one: keep it, up to a hard cap.
             bool keep = false;
-            if (limit != 0xffffffffu && members.size() + fresh.size() + asserts.size() + 1 <= ZC_CHUNK_HARD_MAX) {
+            if (limit != 0xffffffffu && members.size() + fresh.size() + asserts.size() + 1 <= hard_max) {
                 size_t cone = 0;
                 std::vector<uint32_t> st2(1, ssa[3 * k + 1]);
                 std::vector<uint8_t>& seen = cone_seen;
@@ -1056,12 +1062,13 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 }
                 SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &np->prog, &np->n_regs));
                 SP1HIP_TRY(build_chunks(sched.data(), n_sched, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT, &np->chunks));
+                SP1HIP_TRY(build_chunks(sched.data(), n_sched, chips[i].main_width, chips[i].prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT));
                 plan = np;
                 std::lock_guard<std::mutex> lk(plan_mutex);
                 if (plan_cache.size() > 4096) plan_cache.clear();
                 plan_cache[h] = plan;
             }
-            c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono;
+            c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono; c->fine = plan->fine;
         }
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
@@ -1090,6 +1097,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         for (auto& ck : c->mono) {
             c->mono_off.push_back((uint32_t)((blob.size() - c->off_prog) / 4));
+            blob.insert(blob.end(), ck.prog.begin(), ck.prog.end());
+        }
+        for (auto& ck : c->fine) {
+            c->fine_off.push_back((uint32_t)((blob.size() - c->off_prog) / 4));
             blob.insert(blob.end(), ck.prog.begin(), ck.prog.end());
         }
         pad4();
@@ -1174,7 +1185,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             for (auto& ck : c.chunks) chunk_words += ck.prog.size();
             for (auto& ck : c.mono) mono_words += ck.prog.size();
             use_mono[i] = mono_enabled && c.chunks.size() > 1 && terms >= ZC_MONO_MIN_TERMS && mono_wg != 0 && 2 * chunk_words > 3 * mono_words;
-            const std::vector<Chunk>& cks = use_mono[i] ? c.mono : c.chunks;
+            static const bool fine_enabled = [] { const char* e = getenv("SP1HIP_ZC_FINE"); return !(e && e[0] == '0'); }();
+            if (!use_mono[i] && fine_enabled && terms <= ZC_FINE_MAX_TERMS && c.fine.size() > c.chunks.size()) use_mono[i] = 2;
+            const std::vector<Chunk>& cks = use_mono[i] == 1 ? c.mono : use_mono[i] == 2 ? c.fine : c.chunks;
             uint32_t regs = 1, instr = 1;
             for (auto& ck : cks) { regs = std::max(regs, ck.n_regs); instr = std::max<uint32_t>(instr, (uint32_t)(ck.prog.size() / 4)); }
             // programs stream through the scalar cache (wave-uniform s_load_dwordx4 straight into SGPRs: no LDS read and no
@@ -1205,8 +1218,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 uint32_t blocks = (terms + bp - 1) / bp;
                 static const uint32_t max_pairs = [] { const char* e = getenv("SP1HIP_ZC_MAX_PAIRS"); return e ? (uint32_t)atoi(e) : 131072u; }();
                 if (blocks > max_pairs / bp) blocks = std::max(1u, max_pairs / bp);
-                const std::vector<Chunk>& cks = use_mono[i] ? c.mono : c.chunks;
-                const std::vector<uint32_t>& offs = use_mono[i] ? c.mono_off : c.chunk_off;
+                const std::vector<Chunk>& cks = use_mono[i] == 1 ? c.mono : use_mono[i] == 2 ? c.fine : c.chunks;
+                const std::vector<uint32_t>& offs = use_mono[i] == 1 ? c.mono_off : use_mono[i] == 2 ? c.fine_off : c.chunk_off;
                 ZcChipRange rg{total_blocks, 0, terms - 1, 0};
                 for (size_t q = 0; q < cks.size(); q++) {
                     ZcDesc d{};
