@@ -889,9 +889,11 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     std::vector<LaunchShape> shapes;
     std::vector<uint16_t> flat_index;                        // FLAT launches: pair -> descriptor, all launches back to back
     const uint32_t FLAT_MAX_PAIRS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_PAIRS"); return e ? (uint32_t)atoi(e) : 16384u; }();   // read per call (tests)
-    // workgroups of a large round: one resident set (256 CUs x 4 workgroups), no tail wave — measured on the core-shaped
-    // shard (GKR kernels, ms): 512: 32.2, 768: 30.1, 1024: 29.2, 1536: 29.7, 3072: 31.3, 6144: 34.3 (SP1HIP_GKR_TILES)
-    static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? (uint32_t)atoi(e) : 1024u; }();
+    // workgroups of a large round. While every workgroup paid an L2 write-back and a serialised ticket in its tail
+    // (round_sync.hpp) one resident set — 256 CUs x 4 workgroups — was the optimum; without them finer tiles balance the
+    // tail better. GKR kernels on the core-shaped shard, ms (SP1HIP_GKR_TILES): 512: 24.6, 768: 22.3, 1024: 21.4,
+    // 2048: 21.0, 3072: 20.8, 4096: 20.6, 6144: 20.8, 8192: 20.9, 12288: 21.2.
+    static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? (uint32_t)atoi(e) : 4096u; }();
     auto fill_descs = [&](RoundDesc* out, int v, int j, bool last, const std::vector<uint32_t>& live, int cur,
                           const std::vector<size_t>& so_prev, const std::vector<size_t>& so_next) {
         // pairs handled per interaction: sums-only launch: ceil(rows / 2); fold launches: ceil(ceil(rows / 2) / 2)
