@@ -888,7 +888,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     struct LaunchShape { uint32_t tiles, tile_size, total_pairs; size_t flat_off; bool flat; };
     std::vector<LaunchShape> shapes;
     std::vector<uint16_t> flat_index;                        // FLAT launches: pair -> descriptor, all launches back to back
-    const uint32_t FLAT_MAX_PAIRS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_PAIRS"); return e ? (uint32_t)atoi(e) : 16384u; }();   // read per call (tests)
+    const uint32_t FLAT_MAX_PAIRS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_PAIRS"); return e ? (uint32_t)atoi(e) : 65536u; }();   // read per call (tests)
     // workgroups of a large round. While every workgroup paid an L2 write-back and a serialised ticket in its tail
     // (round_sync.hpp) one resident set — 256 CUs x 4 workgroups — was the optimum; without them finer tiles balance the
     // tail better. GKR kernels on the core-shaped shard, ms (SP1HIP_GKR_TILES): 512: 24.6, 768: 22.3, 1024: 21.4,

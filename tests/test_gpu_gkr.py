@@ -57,7 +57,7 @@ def test_gkr_proof_matches_oracle(api, monkeypatch, n_tuples, L, with_empty, dup
 @pytest.mark.parametrize("flat_pairs", ["0", "64"])     # 0: every round one workgroup per tile; 64: both forms inside one layer
 @pytest.mark.parametrize("n_tuples,L,with_empty,dup", [(37, 7, True, 3), (300, 10, True, 3)])
 def test_gkr_small_round_forms_give_the_same_bytes(api, monkeypatch, n_tuples, L, with_empty, dup, flat_pairs):
-    """Rounds with few pairs run one pair per lane (SP1HIP_GKR_FLAT_PAIRS, default 16384 — every round of these sizes);
+    """Rounds with few pairs run one pair per lane (SP1HIP_GKR_FLAT_PAIRS, default 65536 — every round of these sizes);
     forcing the tiled form, or a mix, must not change a byte."""
     monkeypatch.setenv("SP1HIP_GKR_FLAT_PAIRS", flat_pairs)
     chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
