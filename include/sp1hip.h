@@ -345,6 +345,16 @@ int sp1hip_zerocheck_prove(const sp1hip_zc_chip_t* chips, int n_chips, int max_l
                            sp1hip_challenger_t* challenger, uint8_t* h_proof, size_t* proof_len,
                            sp1hip_stream_t stream);
 
+/* Host-only check of the constraint-program compiler (no GPU needed): plans `program` exactly as sp1hip_zerocheck_prove
+ * does (immediates folded, instruction order chosen, registers allocated, fused multiply-adds, forwarded operands; the
+ * chunked / undivided / finely cut forms) and interprets the chosen form on ONE row (Montgomery words). form: 0 = the whole
+ * allocated program, 1 = chunks, 2 = undivided, 3 = fine. out_values[k] = value of constraint k at the row; out_stats
+ * (optional) = {instruction words, pieces, registers}. Fails if a constraint is not evaluated exactly once. */
+int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width,
+                               const uint32_t* main_row, const uint32_t* prep_row, const uint32_t* publics,
+                               uint32_t n_publics, int form, uint32_t* out_values, uint32_t n_constraints,
+                               uint32_t* out_stats);
+
 /* ---------------------------------------------------------------- one whole shard proof
  * A chip of the shard with everything the stages need: constraint program (zerocheck, see sp1hip_zc_chip_t),
  * interaction program (LogUp-GKR, see sp1hip_gkr_chip_t) and its device traces. Chips in name order. */

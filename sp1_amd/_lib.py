@@ -168,6 +168,8 @@ PROTOTYPES = [
     ("sp1hip_prove_shard_with_pk", None, [_vp, C.POINTER(ShardChip), _int, u32p, _int, u32p, _int, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
                                       _vp, u8p, C.POINTER(_sz), _vp]),
+    ("sp1hip_zerocheck_plan_eval", None, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.c_uint32, _int, u32p,
+                                          C.c_uint32, u32p]),
 ]
 
 _lib = None

@@ -847,23 +847,28 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
     return SP1HIP_SUCCESS;
 }
 
-// host evaluation of the program on an all-zero row (padded_row_adjustment, shard.rs:L524-L536)
-static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
-    const uint32_t n = (uint32_t)(c.prog.size() / 4);
-    std::vector<uint32_t> reg(c.n_regs + 4, 0);
-    Ext acc = kb::ext_zero();
+// Host interpreter of allocated program words on ONE row (Montgomery words; null row = all zeros): every ASSERT_ZERO hands
+// (constraint index, value) to `on_assert`. The same semantics as run_program on the device, in the base field.
+template <class F>
+static void eval_words_row(const uint32_t* words, size_t n, uint32_t n_regs, const uint32_t* main_row, const uint32_t* prep_row,
+                           const uint32_t* publics, F&& on_assert) {
+    std::vector<uint32_t> reg(n_regs + 4, 0);
     uint32_t prev = 0;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t opw = c.prog[4 * k], op = opw & 0xffu, dst = c.prog[4 * k + 1], x = c.prog[4 * k + 2], y = c.prog[4 * k + 3];
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t opw = words[4 * k], op = opw & 0xffu, dst = words[4 * k + 1], x = words[4 * k + 2], y = words[4 * k + 3];
         const uint32_t A = (opw & ZC_A_PREV) ? prev : (op >= ZC_ADD && op != ZC_TOUCH ? reg[x] : 0u);
         const bool bin = (op >= ZC_ADD && op <= ZC_MUL) || op == ZC_RSUB;
         const uint32_t B = (bin && (opw & ZC_B_PREV)) ? prev : (bin ? reg[y] : 0u);
         uint32_t res = 0;
         switch (op) {
-            case ZC_LOAD_MAIN: case ZC_LOAD_PREP:
-                if (!(opw & ZC_DST_TEMP)) for (uint32_t j = 0; j <= ((opw >> 16) & 3u); j++) reg[dst + j] = 0;
-                prev = 0;
+            case ZC_LOAD_MAIN: case ZC_LOAD_PREP: {
+                const uint32_t* row = op == ZC_LOAD_MAIN ? main_row : prep_row;
+                for (uint32_t j = 0; j <= ((opw >> 16) & 3u); j++) {
+                    prev = row ? row[x + j] : 0u;
+                    if (!(opw & ZC_DST_TEMP)) reg[dst + j] = prev;
+                }
                 continue;
+            }
             case ZC_TOUCH: continue;
             case ZC_CONST: res = x; break;
             case ZC_PUBLIC: res = publics[x]; break;
@@ -877,12 +882,77 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
             case ZC_CSUB: res = kb::sub(y, A); break;
             case ZC_MULC: res = kb::mul(A, y); break;
             case ZC_MADC: res = kb::add((opw & ZC_B_PREV) ? prev : reg[dst >> 16], kb::mul(A, y)); break;
-            default: acc = acc + kb::ext_mul_base(c.alpha_pows[y], A); continue;
+            default: on_assert(y, A); continue;
         }
         prev = res;
         if (!(opw & ZC_DST_TEMP)) reg[dst & 0xffffu] = res;
     }
+}
+
+// host evaluation of the program on an all-zero row (padded_row_adjustment, shard.rs:L524-L536)
+static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
+    Ext acc = kb::ext_zero();
+    eval_words_row(c.prog.data(), c.prog.size() / 4, c.n_regs, nullptr, nullptr, publics,
+                   [&](uint32_t idx, uint32_t v) { acc = acc + kb::ext_mul_base(c.alpha_pows[idx], v); });
     return acc;
+}
+
+// The plan of a program (immediates folded, instruction order chosen, registers allocated; chunked, undivided and finely
+// cut forms) depends on the program alone: a machine's chips are planned once per process and looked up afterwards (a
+// prover proves the same machine shard after shard; planning 33 chips costs ~1.3 ms of host time per proof).
+static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width, int chip_index,
+                       std::shared_ptr<const ZcPlan>* out) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix(main_width); mix(prep_width); mix(n_instr);
+    for (size_t k = 0; k < (size_t)n_instr * 3; k++) mix(program[k]);
+    static std::mutex plan_mutex;
+    static std::unordered_map<uint64_t, std::shared_ptr<const ZcPlan>> plan_cache;
+    std::shared_ptr<const ZcPlan> plan;
+    {
+        std::lock_guard<std::mutex> lk(plan_mutex);
+        auto it = plan_cache.find(h);
+        if (it != plan_cache.end() && it->second->n_instr == n_instr && it->second->main_w == main_width && it->second->prep_w == prep_width &&
+            (n_instr == 0 || memcmp(it->second->source.data(), program, (size_t)n_instr * 12) == 0))
+            plan = it->second;
+    }
+    if (!plan) {
+        std::shared_ptr<ZcPlan> np(new ZcPlan());
+        np->n_instr = n_instr; np->main_w = main_width; np->prep_w = prep_width;
+        np->source.assign(program, program + (size_t)n_instr * 3);
+        // fold constants into immediates, then pick the instruction order with the smallest register file
+        std::vector<uint32_t> folded, sched;
+        fold_immediates(program, n_instr, &folded);
+        static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
+        uint32_t best_regs = 0xffffffffu;
+        for (int mode = 0; mode < 3; mode++) {
+            if (forced_mode >= 0 && mode != forced_mode) continue;
+            std::vector<uint32_t> cand;
+            std::vector<Chunk> mono;
+            schedule_program(folded.data(), n_instr, main_width, mode, &cand);
+            SP1HIP_TRY(build_chunks(cand.data(), (uint32_t)(cand.size() / 3), main_width, prep_width, 0xffffffffu, &mono));
+            uint32_t regs = 0;
+            for (auto& ck : mono) regs = std::max(regs, ck.n_regs);
+            if (regs < best_regs) { best_regs = regs; sched.swap(cand); np->mono.swap(mono); }
+        }
+        const uint32_t n_sched = (uint32_t)(sched.size() / 3);
+        static const bool zc_debug = getenv("SP1HIP_ZC_DEBUG") != nullptr;
+        if (zc_debug) {
+            size_t mono_instr = 0;
+            for (auto& ck : np->mono) mono_instr += ck.prog.size() / 4;
+            fprintf(stderr, "[sp1hip zc] chip %d: %u ssa instrs, %u+%u cols -> undivided program %zu words, %u registers\n",
+                    chip_index, n_instr, main_width, prep_width, mono_instr, best_regs);
+        }
+        SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &np->prog, &np->n_regs));
+        SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, ZC_CHUNK_LIMIT, &np->chunks));
+        SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT));
+        plan = np;
+        std::lock_guard<std::mutex> lk(plan_mutex);
+        if (plan_cache.size() > 4096) plan_cache.clear();
+        plan_cache[h] = plan;
+    }
+    *out = plan;
+    return SP1HIP_SUCCESS;
 }
 
 // register-file bytes one lane needs in LDS
@@ -1014,60 +1084,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (op == ZC_PUBLIC) SP1HIP_REQUIRE((int)a < n_publics, "public value index out of range");
         }
         SP1HIP_REQUIRE(asserts == chips[i].num_constraints, "num_constraints does not match the program");
-        // The plan of a program (immediates folded, instruction order chosen, registers allocated, chunked and undivided
-        // forms) depends on the program alone: a machine's chips are planned once per process and looked up afterwards
-        // (a prover proves the same machine shard after shard; planning 33 chips costs ~1.3 ms of host time per proof).
         {
-            uint64_t h = 1469598103934665603ull;
-            auto mix = [&](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
-            mix(chips[i].main_width); mix(chips[i].prep_width); mix(chips[i].n_instr);
-            for (size_t k = 0; k < (size_t)chips[i].n_instr * 3; k++) mix(chips[i].program[k]);
-            static std::mutex plan_mutex;
-            static std::unordered_map<uint64_t, std::shared_ptr<const ZcPlan>> plan_cache;
             std::shared_ptr<const ZcPlan> plan;
-            {
-                std::lock_guard<std::mutex> lk(plan_mutex);
-                auto it = plan_cache.find(h);
-                if (it != plan_cache.end() && it->second->n_instr == chips[i].n_instr && it->second->main_w == chips[i].main_width &&
-                    it->second->prep_w == chips[i].prep_width &&
-                    (chips[i].n_instr == 0 || memcmp(it->second->source.data(), chips[i].program, (size_t)chips[i].n_instr * 12) == 0))
-                    plan = it->second;
-            }
-            if (!plan) {
-                std::shared_ptr<ZcPlan> np(new ZcPlan());
-                np->n_instr = chips[i].n_instr; np->main_w = chips[i].main_width; np->prep_w = chips[i].prep_width;
-                np->source.assign(chips[i].program, chips[i].program + (size_t)chips[i].n_instr * 3);
-                // fold constants into immediates, then pick the instruction order with the smallest register file
-                std::vector<uint32_t> folded, sched;
-                fold_immediates(chips[i].program, chips[i].n_instr, &folded);
-                static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
-                uint32_t best_regs = 0xffffffffu;
-                for (int mode = 0; mode < 3; mode++) {
-                    if (forced_mode >= 0 && mode != forced_mode) continue;
-                    std::vector<uint32_t> cand;
-                    std::vector<Chunk> mono;
-                    schedule_program(folded.data(), chips[i].n_instr, chips[i].main_width, mode, &cand);
-                    SP1HIP_TRY(build_chunks(cand.data(), (uint32_t)(cand.size() / 3), chips[i].main_width, chips[i].prep_width, 0xffffffffu, &mono));
-                    uint32_t regs = 0;
-                    for (auto& ck : mono) regs = std::max(regs, ck.n_regs);
-                    if (regs < best_regs) { best_regs = regs; sched.swap(cand); np->mono.swap(mono); }
-                }
-                const uint32_t n_sched = (uint32_t)(sched.size() / 3);
-                static const bool zc_debug = getenv("SP1HIP_ZC_DEBUG") != nullptr;
-                if (zc_debug) {
-                    size_t mono_instr = 0;
-                    for (auto& ck : np->mono) mono_instr += ck.prog.size() / 4;
-                    fprintf(stderr, "[sp1hip zc] chip %d: %u ssa instrs, %u constraints, %u+%u cols -> undivided program %zu words, %u registers\n",
-                            i, chips[i].n_instr, chips[i].num_constraints, chips[i].main_width, chips[i].prep_width, mono_instr, best_regs);
-                }
-                SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &np->prog, &np->n_regs));
-                SP1HIP_TRY(build_chunks(sched.data(), n_sched, chips[i].main_width, chips[i].prep_width, ZC_CHUNK_LIMIT, &np->chunks));
-                SP1HIP_TRY(build_chunks(sched.data(), n_sched, chips[i].main_width, chips[i].prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT));
-                plan = np;
-                std::lock_guard<std::mutex> lk(plan_mutex);
-                if (plan_cache.size() > 4096) plan_cache.clear();
-                plan_cache[h] = plan;
-            }
+            SP1HIP_TRY(zc_get_plan(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, i, &plan));
             c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono; c->fine = plan->fine;
         }
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
@@ -1454,6 +1473,45 @@ __global__ __launch_bounds__(256) void fix_last_variable_kernel(const uint32_t* 
     for (int q = 0; q < 4; q++) out[((size_t)c * 4 + q) * out_rows + i] = r.c[q];
 }
 }  // namespace sp1hip
+
+// Host-only: plans `program` exactly as sp1hip_zerocheck_prove does and interprets the chosen form of it on one row.
+extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width,
+                                          const uint32_t* main_row, const uint32_t* prep_row, const uint32_t* publics,
+                                          uint32_t n_publics, int form, uint32_t* out_values, uint32_t n_constraints,
+                                          uint32_t* out_stats) {
+    SP1HIP_REQUIRE(program || n_instr == 0, "null program");
+    SP1HIP_REQUIRE(out_values || n_constraints == 0, "null output");
+    SP1HIP_REQUIRE(form >= 0 && form <= 3, "form: 0 whole program, 1 chunks, 2 undivided, 3 fine");
+    uint32_t asserts = 0;
+    for (uint32_t k = 0; k < n_instr; k++) {
+        const uint32_t op = program[3 * k], a = program[3 * k + 1];
+        SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO, "bad opcode in constraint program");
+        if (op == ZC_ASSERT_ZERO) asserts++;
+        if (op == ZC_LOAD_MAIN) SP1HIP_REQUIRE(a < main_width && main_row, "main column out of range");
+        if (op == ZC_LOAD_PREP) SP1HIP_REQUIRE(a < prep_width && prep_row, "preprocessed column out of range");
+        if (op == ZC_PUBLIC) SP1HIP_REQUIRE(a < n_publics && publics, "public value index out of range");
+    }
+    SP1HIP_REQUIRE(asserts == n_constraints, "n_constraints does not match the program");
+    std::shared_ptr<const ZcPlan> plan;
+    SP1HIP_TRY(zc_get_plan(program, n_instr, main_width, prep_width, -1, &plan));
+    std::vector<uint32_t> seen(n_constraints, 0);
+    auto on_assert = [&](uint32_t idx, uint32_t v) { if (idx < n_constraints) { out_values[idx] = v; seen[idx]++; } };
+    uint32_t words = 0, pieces = 0, regs = 0;
+    if (form == 0) {
+        eval_words_row(plan->prog.data(), plan->prog.size() / 4, plan->n_regs, main_row, prep_row, publics, on_assert);
+        words = (uint32_t)(plan->prog.size() / 4); pieces = 1; regs = plan->n_regs;
+    } else {
+        const std::vector<Chunk>& cks = form == 1 ? plan->chunks : form == 2 ? plan->mono : plan->fine;
+        for (const Chunk& ck : cks) {
+            // (every ASSERT carries its chip-wide constraint index, whatever piece it ended up in)
+            eval_words_row(ck.prog.data(), ck.prog.size() / 4, ck.n_regs, main_row, prep_row, publics, on_assert);
+            words += (uint32_t)(ck.prog.size() / 4); pieces++; regs = std::max(regs, ck.n_regs);
+        }
+    }
+    for (uint32_t k = 0; k < n_constraints; k++) SP1HIP_REQUIRE(seen[k] == 1, "a constraint was not evaluated exactly once");
+    if (out_stats) { out_stats[0] = words; out_stats[1] = pieces; out_stats[2] = regs; }
+    return SP1HIP_SUCCESS;
+}
 
 extern "C" int sp1hip_fix_last_variable(const uint32_t* d_in, uint64_t rows, uint32_t width, int in_is_ext, sp1hip_ext_t alpha,
                                         const uint32_t* d_padding, uint32_t* d_out, sp1hip_stream_t stream) {

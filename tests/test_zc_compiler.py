@@ -1,0 +1,123 @@
+"""The constraint-program compiler of the zerocheck interpreter, checked on the CPU (no GPU): `sp1hip_zerocheck_plan_eval`
+plans a program exactly as the prover does — immediates folded, instructions reordered, registers allocated with operand
+forwarding, multiply-adds fused, forwarded operands put first (RSUB), and the chunked / undivided / finely cut forms — and
+interprets the result on one row. Every form must give, constraint by constraint, what a direct evaluation of the
+caller's SSA program gives (tests/machine_check.py, numpy). Covers the synthetic AIRs of the GPU tests and the eight real
+chips of the recursion machine."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from machine_check import P, constraint_values
+from sp1_amd import _lib
+from sp1_amd.machines import recursion
+
+zc_airs = pytest.importorskip("zc_airs")
+
+R = (1 << 32) % P
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _plan_eval(lib, air, main_row, prep_row, publics, form):
+    prog = np.ascontiguousarray(air.to_array().reshape(-1), dtype=np.uint32)
+    n_c = air.num_constraints
+    out = np.zeros(max(n_c, 1), dtype=np.uint32)
+    stats = np.zeros(3, dtype=np.uint32)
+    to_m = lambda v: np.ascontiguousarray((v.astype(np.uint64) * np.uint64(R)) % np.uint64(P), dtype=np.uint32)
+    m, p, pub = to_m(main_row), to_m(prep_row), to_m(publics)
+    st = lib.sp1hip_zerocheck_plan_eval(_u32p(prog), len(air.instrs), air.main_width, air.prep_width, _u32p(m), _u32p(p), _u32p(pub),
+                                        len(pub), form, _u32p(out), n_c, _u32p(stats))
+    assert st == 0, lib.sp1hip_last_error().decode()
+    r_inv = pow(1 << 32, -1, P)
+    return (out[:n_c].astype(np.uint64) * np.uint64(r_inv)) % np.uint64(P), stats
+
+
+def _check(lib, air, seed, n_publics):
+    rng = np.random.default_rng(seed)
+    main = rng.integers(0, P, size=(3, max(air.main_width, 1)), dtype=np.uint64)
+    prep = rng.integers(0, P, size=(3, max(air.prep_width, 1)), dtype=np.uint64)
+    main[2] = 0                                       # the all-zero row (padded-row adjustment) is one of the rows
+    prep[2] = 0
+    publics = rng.integers(0, P, size=max(n_publics, 1), dtype=np.uint64)
+    want = constraint_values(air, prep, main, publics)
+    for row in range(3):
+        for form in range(4):
+            got, stats = _plan_eval(lib, air, main[row], prep[row], publics, form)
+            assert np.array_equal(got, want[row]), (air.name, row, form)
+            assert stats[0] > 0 or air.num_constraints == 0
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def test_compiled_forms_of_the_synthetic_airs_evaluate_like_the_ssa(lib):
+    airs = [zc_airs.air_mul(), zc_airs.air_affine(), zc_airs.air_sbox(), zc_airs.air_chain(), zc_airs.air_chain(300),
+            zc_airs.air_manyregs(), zc_airs.air_manyregs(120)]
+    for k, air in enumerate(airs):
+        _check(lib, air, 100 + k, 8)
+
+
+def test_compiled_forms_of_the_recursion_chips_evaluate_like_the_ssa(lib):
+    for k, (air, _) in enumerate(recursion.compress_machine()):
+        if air.num_constraints:
+            _check(lib, air, 200 + k, 200)
+
+
+def test_plan_eval_rejects_a_wrong_constraint_count(lib):
+    air = zc_airs.air_mul()
+    prog = np.ascontiguousarray(air.to_array().reshape(-1), dtype=np.uint32)
+    row = np.zeros(max(air.main_width, 1), dtype=np.uint32)
+    out = np.zeros(air.num_constraints + 1, dtype=np.uint32)
+    st = lib.sp1hip_zerocheck_plan_eval(_u32p(prog), len(air.instrs), air.main_width, air.prep_width, _u32p(row), _u32p(row), _u32p(row),
+                                        1, 0, _u32p(out), air.num_constraints + 1, None)
+    assert st != 0
+
+
+def _random_air(rng, n_ops, main_w, prep_w, n_publics):
+    """A random SSA program: loads / constants / publics feeding a random DAG of ADD / SUB / MUL / NEG, asserts sprinkled in;
+    biased towards the shapes the compiler rewrites (products by constants feeding sums, re-use of the last value, squares)."""
+    from sp1_amd.air import AirProgram
+    air = AirProgram("Fuzz", main_w, prep_w)
+    vals = []
+    for c in range(main_w):
+        vals.append(air.main(c))
+    for c in range(prep_w):
+        vals.append(air.prep(c))
+    for _ in range(3):
+        vals.append(air.const(int(rng.integers(0, P))))
+    if n_publics:
+        vals.append(air.public(int(rng.integers(0, n_publics))))
+    for _ in range(n_ops):
+        kind = rng.integers(0, 10)
+        last = vals[-1]
+        pick = lambda: vals[int(rng.integers(0, len(vals)))] if rng.integers(0, 3) else last
+        if kind <= 2:
+            v = pick() + pick()
+        elif kind <= 4:
+            v = pick() - pick()
+        elif kind <= 6:
+            v = pick() * pick()
+        elif kind == 7:
+            v = pick() + pick() * air.const(int(rng.integers(0, P)))       # multiply-add by a constant
+        elif kind == 8:
+            v = pick() - air.const(int(rng.integers(1, 1 << 16))) * pick()
+        else:
+            v = -pick()
+        vals.append(v)
+        if rng.integers(0, 6) == 0:
+            air.assert_zero(vals[int(rng.integers(max(0, len(vals) - 8), len(vals)))])
+    air.assert_zero(vals[-1])
+    return air
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_compiled_forms_of_random_programs_evaluate_like_the_ssa(lib, seed):
+    rng = np.random.default_rng(7000 + seed)
+    air = _random_air(rng, int(rng.integers(5, 500)), int(rng.integers(1, 40)), int(rng.integers(0, 6)), 4)
+    _check(lib, air, 9000 + seed, 4)
