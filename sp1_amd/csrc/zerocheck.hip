@@ -1203,6 +1203,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             size_t chunk_words = 0, mono_words = 0;
             for (auto& ck : c.chunks) chunk_words += ck.prog.size();
             for (auto& ck : c.mono) mono_words += ck.prog.size();
+            // (a shorter undivided program with the same register file is NOT enough: measured on the term-major Poseidon2
+            // program — 2,804 words undivided against 3,808 in 28 chunks, 20 registers either way — the undivided form is
+            // 36 % slower: 45 KB of instruction words stream through a 16 KB scalar cache, a chunk's 2-5 KB stay in it)
             use_mono[i] = mono_enabled && c.chunks.size() > 1 && terms >= ZC_MONO_MIN_TERMS && mono_wg != 0 && 2 * chunk_words > 3 * mono_words;
             static const bool fine_enabled = [] { const char* e = getenv("SP1HIP_ZC_FINE"); return !(e && e[0] == '0'); }();
             if (!use_mono[i] && fine_enabled && terms <= ZC_FINE_MAX_TERMS && c.fine.size() > c.chunks.size()) use_mono[i] = 2;

@@ -184,7 +184,7 @@ def poseidon2_wide():
     # computed here, mod p): same polynomial, hence the same value at every point (the reference's own proof verifies
     # against this form, tests/test_recursion_machine.py), but 35 independent constraints of ~100 operations and a
     # handful of live values instead of one long chain — what the zerocheck kernels need to run wide.
-    air._seen = None                                      # no sharing across constraints (sharing the cubes was measured slower: 47 vs 41 ms)
+    air._seen = None                                      # (sharing is explicit below: the same term object feeds every sum)
 
     def lin_scale(f, k):
         return {t: (c * k) % P for t, c in f.items()}
@@ -195,23 +195,34 @@ def poseidon2_wide():
             out[t] = (out.get(t, 0) + c) % P
         return out
 
-    def emit(form):
-        acc = None
-        for (kind, idx), coeff in sorted(form.items()):
-            if coeff == 0:
-                continue
-            if kind == "x":
-                term = air.main(P2_INT(idx))
-            else:                                         # cube of round idx: its lane-0 input is a column
-                y = (air.main(P2_INT(0)) if idx == 0 else air.main(P2_S0(idx - 1))) + rc[4 + idx][0]
-                term = y * y * y
-            if coeff != 1:
-                term = term * coeff
-            acc = term if acc is None else acc + term
-        return acc
+    def term_value(kind, idx):
+        if kind == "x":
+            return air.main(P2_INT(idx))
+        y = (air.main(P2_INT(0)) if idx == 0 else air.main(P2_S0(idx - 1))) + rc[4 + idx][0]    # cube of round idx: its lane-0 input is a column
+        return y * y * y
+
+    def emit_group(targets):
+        """targets: [(column, linear form)]. TERM-MAJOR: every column / cube the group depends on is formed once and added,
+        times its coefficient, to the running sum of each constraint that uses it; a constraint is asserted as soon as its
+        last term is in. In this order a group keeps one term and its open sums alive — not every term of every
+        constraint — and the terms are shared by construction (the interpreter's chunks keep asserts that share their
+        cones together)."""
+        terms = sorted({t for _, f in targets for t, c in f.items() if c}, key=lambda t: (t[0] == "c", t[1]))
+        last = [max((k for k, t in enumerate(terms) if f.get(t, 0)), default=-1) for _, f in targets]
+        accs = [None] * len(targets)
+        for k, t in enumerate(terms):
+            term = term_value(*t)
+            for j, (col, f) in enumerate(targets):
+                c = f.get(t, 0)
+                if c:
+                    v = term if c == 1 else term * c
+                    accs[j] = v if accs[j] is None else accs[j] + v
+                if last[j] == k:
+                    air.assert_zero(air.main(col) - accs[j])
 
     lanes = {i: {("x", i): 1} for i in range(1, 16)}      # passive lanes as linear forms
     lane0 = None
+    s0_targets = []
     for r in range(20):
         cube = {("c", r): 1}
         total = dict(cube)
@@ -220,10 +231,9 @@ def poseidon2_wide():
         lane0 = lin_scale(lin_add(total, lin_scale(cube, INTERNAL_DIAG[0])), R_INV)
         lanes = {i: lin_scale(lin_add(total, lin_scale(lanes[i], INTERNAL_DIAG[i])), R_INV) for i in range(1, 16)}
         if r < 19:
-            air.assert_zero(air.main(P2_S0(r)) - emit(lane0))
-    air.assert_zero(air.main(P2_EXT(4, 0)) - emit(lane0))
-    for i in range(1, 16):
-        air.assert_zero(air.main(P2_EXT(4, i)) - emit(lanes[i]))
+            s0_targets.append((P2_S0(r), lane0))
+    emit_group(s0_targets)
+    emit_group([(P2_EXT(4, 0), lane0)] + [(P2_EXT(4, i), lanes[i]) for i in range(1, 16)])
     return air, it
 
 
