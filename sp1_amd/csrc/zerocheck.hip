@@ -944,7 +944,9 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                     chip_index, n_instr, main_width, prep_width, mono_instr, best_regs);
         }
         SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &np->prog, &np->n_regs));
-        SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, ZC_CHUNK_LIMIT, &np->chunks));
+        static const uint32_t chunk_limit = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_LIMIT"); return e ? (uint32_t)atoi(e) : ZC_CHUNK_LIMIT; }();
+        static const uint32_t chunk_hard = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_HARD_MAX"); return e ? (uint32_t)atoi(e) : ZC_CHUNK_HARD_MAX; }();
+        SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, chunk_limit, &np->chunks, chunk_hard));
         SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT));
         plan = np;
         std::lock_guard<std::mutex> lk(plan_mutex);
