@@ -108,6 +108,79 @@ def cpu_baseline(api, scale_log2):
                       "(cgroup quota); %.2f s wall" % (1 << (2 * scale_log2), meta["area_cells"], L, cores, r["seconds"])}
 
 
+# ---- the pinned verifier on the timed proof (checker only, untimed, in a child process) --------------------------------
+def verify_child(path):
+    """oracle shard_verify (the restated ShardVerifier::verify_shard that accepts the reference's real ShardProof) on one
+    proof: every Merkle opening, fold, sumcheck round, lookup balance and constraint evaluation. Prints {"rc": 0} if accepted."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+    z = np.load(path)
+    L, lsh, kind = int(z["L"]), int(z["lsh"]), str(z["kind"])
+    if kind == "core":
+        from core_shard import chip_programs, load_shape
+        progs = [chip_programs(c["name"], c["width"], c["prep_width"], c["constraints"], c["interactions"])
+                 for c in sorted(load_shape()["chips"], key=lambda c: c["name"])]
+    else:
+        from sp1_amd.machines import recursion as R
+        progs = R.compress_machine()
+    shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
+              for a, i in progs]
+    ch = orc.Challenger()
+    ch.observe(z["commit"])
+    t0 = time.perf_counter()
+    rc = orc.shard_verify(shapes, z["commit"], z["proof"].tobytes(), L, lsh, ch, 2, 124, 16)
+    print(json.dumps({"rc": int(rc), "seconds": time.perf_counter() - t0, "state_matches": bool(np.array_equal(ch.state(), z["state"]))}))
+
+
+def verify_proof(kind, proof, commit, state, L, lsh):
+    """Runs verify_child on `proof`; returns True iff the verifier accepts AND ends in the prover's transcript state."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "proof.npz")
+        np.savez(path, proof=np.frombuffer(proof, np.uint8), commit=np.asarray(commit, np.uint32), state=np.asarray(state, np.uint32),
+                 L=L, lsh=lsh, kind=kind)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--verify-child", path], capture_output=True, text=True)
+    if r.returncode != 0:
+        print("verifier child failed:\n" + r.stderr[-2000:], file=sys.stderr)
+        return False
+    v = json.loads(r.stdout.strip().splitlines()[-1])
+    return v["rc"] == 0 and v["state_matches"]
+
+
+def real_machine(api, repeat=4):
+    """The one REAL machine in the tree at its real shape (bench/bench_recursion.py): the eight chips of
+    RecursionAir::compress_machine() with the table heights of the reference's own compress proof (8.9e7 cells), real
+    constraints and interactions, satisfying traces. Whole sp1hip_prove_shard, traces resident in HBM."""
+    import torch
+    from sp1_amd.machines import recursion as R, recursion_trace as RT
+    L, lsh = 21, 20
+    tabs, pv = RT.generate(dict(RT.REFERENCE_COMPRESS_HEIGHTS), seed=1)
+    m = R.compress_machine()
+    area = int(sum(p.size + mm.size for p, mm in tabs.values()))
+    dev = [(a, i, api.ColMajor.from_row_major_host(tabs[a.name][1]), api.ColMajor.from_row_major_host(tabs[a.name][0])) for a, i in m]
+    del tabs
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    commit, prep = jp.commit_multilinears([d[3] for d in dev])
+    times, proof, ch = [], None, None
+    for _ in range(repeat + 1):
+        ch = api.DuplexChallenger()
+        ch.observe(commit)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        proof = api.prove_shard(dev, pv, prep, L, lsh, 32, ch)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    ms = 1e3 * sum(times[1:]) / repeat                      # the first proof warms the arenas
+    return {"machine": "recursion compress machine (8 chips, 220 constraints, 51 interactions; sp1_amd/machines/recursion.py, pinned "
+                       "by the reference's own ShardProof), table heights of the reference's compress proof",
+            "cells": area, "ms_per_proof": ms, "cells_per_s": area / (ms * 1e-3), "proof_bytes": len(proof), "proofs_timed": repeat,
+            "verified": verify_proof("recursion", proof, commit, ch.state(), L, lsh)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +189,11 @@ def main():
     ap.add_argument("--scale-log2", type=int, default=0, help="prove a shard of area CORE >> 2k (testing aid; the bench line is k = 0)")
     ap.add_argument("--cpu-sample-scale-log2", type=int, default=6)
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--verify-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) verification of the last timed proof")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even at --gpus 1 (the N = 1 line then runs the same barrier / "
+                         "max-over-ranks collectives as N = 8; RCCL when --backend nccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (2-in-flight, commit-only, CPU baseline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -124,6 +202,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_child is not None:
         return cpu_baseline_child(args.cpu_baseline_child)
+    if args.verify_child is not None:
+        return verify_child(args.verify_child)
 
     import torch
     import torch.distributed as dist
@@ -134,7 +214,13 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:                                       # plain `python bench.py --force-dist`: a one-rank rendezvous
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -151,15 +237,19 @@ def main():
     prep_commit, prep_data = jp.commit_multilinears([c[3] for c in chips if c[3] is not None])   # setup (the proving key)
     torch.cuda.synchronize()
 
+    last_state = [None]
+
     def step(stream=None):
         ch = api.DuplexChallenger()
         ch.observe(prep_commit)                                              # stands for vk.observe_into
-        return api.prove_shard(chips, [], prep_data, L, lsh, 32, ch, stream=stream)
+        blob = api.prove_shard(chips, [], prep_data, L, lsh, 32, ch, stream=stream)
+        last_state[0] = ch
+        return blob
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     api.check(lib.sp1hip_timers_reset())
@@ -169,13 +259,21 @@ def main():
     for _ in range(args.steps):
         proof = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     api.check(lib.sp1hip_timers_enable(0))
     tl = {name: timers_read(api, name) for name in TIMERS}
     dt = shards.max_over_ranks(dt)                 # shards are striped one per rank: no data-path collective
+    timed_state = last_state[0].state()
+
+    # the pinned verifier on the LAST TIMED proof (rank 0, untimed): a line without `verified: true` is not printed
+    verified = None
+    if rank == 0 and not args.no_verify:
+        verified = verify_proof("core", proof, prep_commit, timed_state, L, lsh)
+        if not verified:
+            raise SystemExit("bench.py: the pinned verifier REJECTED the timed proof; no result line")
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:      # untimed extras; N > 1 runs measure scaling only
@@ -219,9 +317,11 @@ def main():
             del sd
         torch.cuda.synchronize()
         extras["commit_only"] = {"ms": 1e3 * (time.perf_counter() - t1) / 3, "cells": sum(c[2].height * c[2].width for c in chips)}
+        del streams
+        extras["real_machine"] = real_machine(api)
         if not args.no_cpu_baseline:
             extras["cpu_baseline"] = cpu_baseline(api, max(args.cpu_sample_scale_log2, k))
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     if rank == 0:
@@ -264,6 +364,19 @@ def main():
         dom_ms, dom_launches = ms[dom], launches[dom]
         achieved = alg[dom] / dom_launches / (dom_ms / dom_launches * 1e-3) / 1e9
         ms_per_step = 1e3 * dt / args.steps
+        # HBM traffic of the dominant kernel from the committed PMC table (FETCH_SIZE / WRITE_SIZE collected in separate
+        # rocprofv3 --pmc passes over this same command by bench/pmc_traffic.sh; gfx950 corrections as the microarch guide
+        # prescribes are applied there and stated in the file). Per launch, like `achieved`; null if the table has no row.
+        traffic, traffic_note = None, "no committed PMC table"
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
+                tt = json.load(f)
+            row = tt["kernels"].get(dom)
+            if row is not None and k == 0:
+                traffic = row["hbm_bytes_per_launch"]
+                traffic_note = "%s (%s)" % (tt["source"], row.get("note", ""))
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "core shard prove throughput: trace cells proved/sec (whole ShardProof; synthetic core-shaped shard, see config)",
             "value": world * args.steps * area / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -279,18 +392,25 @@ def main():
                        "area_cells": area, "first_layer_entries": meta["first_layer_entries"], "proof_bytes": len(proof),
                        "parallelism": "independent shards, one per GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_over_algorithmic": (traffic / (alg[dom] / dom_launches)) if traffic else None,
+                         "traffic_source": traffic_note,
                          "avg_launch_ms": dom_ms / dom_launches, "launches_per_step": dom_launches,
                          "algorithmic_bytes_per_launch": alg[dom] // dom_launches,
                          "note": "dominant kernel of the step by measured launch time; it is VALU-bound, not HBM-bound (see stages."
-                                 + dom + "); traffic: PMC passes are collected offline (profiles/), not inside this run",
+                                 + dom + "); traffic: HBM bytes per launch from the committed PMC passes (profiles/r03_traffic.json), "
+                                 "algorithmic bytes = SURVEY 8(d): 4 N S + 32 N per commit, divided over the launches",
                          "stages": stages},
             "cpu_baseline": extras.get("cpu_baseline"),
+            "verified": verified,
+            "host_threads": lib.sp1hip_host_threads(),
+            "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},
+            "real_machine": extras.get("real_machine"),
             "two_in_flight": extras.get("two_in_flight"),
             "commit_only": extras.get("commit_only"),
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

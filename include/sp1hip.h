@@ -65,6 +65,9 @@ int sp1hip_mem_info(size_t* free_bytes, size_t* total_bytes);
 /* The library keeps its working buffers (codewords, trees, fold layers) in per-stream free lists so that
  * steady-state proving never calls the driver; this returns every cached block to the driver. */
 int sp1hip_mem_trim(size_t* released_bytes);
+/* Host threads (the caller included) the library uses for the arithmetic between device hand-overs: SP1HIP_HOST_THREADS,
+ * else min(8, CPUs / (2 x LOCAL_WORLD_SIZE)) with CPUs honouring the cgroup quota. Decided once per process. */
+int sp1hip_host_threads(void);
 int sp1hip_malloc(void** d_ptr, size_t bytes);
 int sp1hip_free(void* d_ptr);
 int sp1hip_malloc_async(void** d_ptr, size_t bytes, sp1hip_stream_t stream);

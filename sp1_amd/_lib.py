@@ -85,6 +85,7 @@ PROTOTYPES = [
     ("sp1hip_get_device", None, [C.POINTER(_int)]),
     ("sp1hip_mem_info", None, [C.POINTER(_sz), C.POINTER(_sz)]),
     ("sp1hip_mem_trim", None, [C.POINTER(_sz)]),
+    ("sp1hip_host_threads", _int, []),
     ("sp1hip_malloc", None, [C.POINTER(_vp), _sz]),
     ("sp1hip_free", None, [_vp]),
     ("sp1hip_malloc_async", None, [C.POINTER(_vp), _sz, _vp]),

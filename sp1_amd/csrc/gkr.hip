@@ -893,7 +893,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     // (round_sync.hpp) one resident set — 256 CUs x 4 workgroups — was the optimum; without them finer tiles balance the
     // tail better. GKR kernels on the core-shaped shard, ms (SP1HIP_GKR_TILES): 512: 24.6, 768: 22.3, 1024: 21.4,
     // 2048: 21.0, 3072: 20.8, 4096: 20.6, 6144: 20.8, 8192: 20.9, 12288: 21.2.
-    static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? (uint32_t)atoi(e) : 4096u; }();
+    static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 1u) : 4096u; }();
     auto fill_descs = [&](RoundDesc* out, int v, int j, bool last, const std::vector<uint32_t>& live, int cur,
                           const std::vector<size_t>& so_prev, const std::vector<size_t>& so_next) {
         // pairs handled per interaction: sums-only launch: ceil(rows / 2); fold launches: ceil(ceil(rows / 2) / 2)
@@ -1017,6 +1017,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             });
         }
         const std::vector<Ext>& eq_int = eq_tabs[niv];
+        par.park();                                          // the helpers sleep through the device rounds of the layer
         SP1HIP_TRY(stage.upload(d_eq_int.p, eq_int.data(), (size_t)W * 16));
         PointArg pa{};
         for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
@@ -1073,7 +1074,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             if (j == 0) {
                 tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_sum_first", s);
-                const RoundSync rs = chain ? RoundSync{rsync.d_counter, nullptr} : rsync.next();
+                const RoundSync rs = chain ? rsync.chained() : rsync.next();
 #define SP1HIP_GKR_SUM_FIRST(NB, FL) hipLaunchKernelGGL((round_sum_first<NB, FL>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca, fa)
                 if (v + 1 == L) { if (shape.flat) SP1HIP_GKR_SUM_FIRST(true, true); else SP1HIP_GKR_SUM_FIRST(true, false); }
                 else { if (shape.flat) SP1HIP_GKR_SUM_FIRST(false, true); else SP1HIP_GKR_SUM_FIRST(false, false); }
@@ -1085,7 +1086,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 for (uint32_t i = 0; i < K; i++) { const uint32_t o = (live[i] + 1) / 2; so_next[i + 1] = so_next[i] + o; max_out = std::max(max_out, o); }
                 tiles = shape.tiles;
                 ScopedTimer tm("gkr_round_fold_sum", s);
-                const RoundSync rs = chain ? RoundSync{rsync.d_counter, nullptr} : rsync.next();
+                const RoundSync rs = chain ? rsync.chained() : rsync.next();
 #define SP1HIP_GKR_FOLD_SUM(F, NB, FL) hipLaunchKernelGGL((round_fold_sum<F, NB, true, FL>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca, fa)
                 if (j == 1 && v + 1 == L) { if (shape.flat) SP1HIP_GKR_FOLD_SUM(true, true, true); else SP1HIP_GKR_FOLD_SUM(true, true, false); }
                 else if (j == 1) { if (shape.flat) SP1HIP_GKR_FOLD_SUM(true, false, true); else SP1HIP_GKR_FOLD_SUM(true, false, false); }
@@ -1117,6 +1118,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         }
         // bind the last row variable: one value per (interaction, table), dense over 2^niv on the host
         std::vector<Ext> tn0(W, kb::ext_zero()), td0(W, one), tn1(W, kb::ext_zero()), td1(W, one);
+        par.wake();                                          // their wake-up hides behind the last fold and its hand-over
         {
             so_next.assign(K + 1, 0);
             for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + (live[i] + 1) / 2;
@@ -1137,6 +1139,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 GkrChain hc;
                 SP1HIP_TRY(mb.fetch(d_rout.p, sizeof(GkrRoundOut) / 4 * (size_t)v, outs.data()));
                 SP1HIP_TRY(mb.fetch(d_chain.p, sizeof(GkrChain) / 4, &hc));
+                rsync.settled();                                 // every chained launch of this layer has completed
                 for (int j = 0; j < v; j++) {
                     Poly4 pj;
                     for (int d = 0; d < 4; d++) pj[d] = outs[j].poly[d];

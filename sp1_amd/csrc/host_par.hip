@@ -10,6 +10,8 @@
 #include <mutex>
 #include <thread>
 
+#include <pthread.h>
+
 #if defined(__x86_64__)
 #include <immintrin.h>
 #define SP1HIP_CPU_PAUSE() _mm_pause()
@@ -52,6 +54,8 @@ struct Pool {
     }
 };
 
+Pool* g_pool_for_fork = nullptr;
+
 Pool* pool() {
     // never destroyed: the helpers are detached and sleep on the condition variable when no scope is open
     static Pool* p = [] {
@@ -76,6 +80,11 @@ Pool* pool() {
         n = std::max(1, std::min(n, HostPar::Scope::MAX_THREADS));
         q->helpers = n - 1;
         for (int i = 1; i <= q->helpers; i++) std::thread([q, i] { q->helper(i); }).detach();
+        g_pool_for_fork = q;
+        // threads do not survive fork(): a child that inherited `helpers > 0` would wait for acknowledgements forever
+        (void)pthread_atfork(nullptr, nullptr, [] {
+            if (Pool* c = g_pool_for_fork) { c->helpers = 0; c->taken.store(false, std::memory_order_relaxed); }
+        });
         return q;
     }();
     return p;
@@ -100,17 +109,36 @@ HostPar::Scope::Scope() {
 
 HostPar::Scope::~Scope() {
     if (!owner_) return;
+    park();
+    pool()->taken.store(false, std::memory_order_release);
+}
+
+void HostPar::Scope::park() {
+    if (!owner_ || parked_) return;
     Pool* p = pool();
     {
         std::lock_guard<std::mutex> lk(p->m);
         p->active = false;
     }
     p->spinning.store(false, std::memory_order_release);
-    p->taken.store(false, std::memory_order_release);
+    parked_ = true;
+}
+
+void HostPar::Scope::wake() {
+    if (!owner_ || !parked_) return;
+    Pool* p = pool();
+    p->spinning.store(true, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        p->active = true;
+    }
+    p->cv.notify_all();
+    parked_ = false;
 }
 
 void HostPar::Scope::dispatch(int parts, void (*fn)(void*, int), void* ctx) {
     Pool* p = pool();
+    if (parked_) wake();                               // a job while parked: correct, only pays the wake-up here
     p->fn = fn; p->ctx = ctx; p->parts = parts;
     p->acked.store(0, std::memory_order_relaxed);
     p->epoch.fetch_add(1, std::memory_order_release);
@@ -121,3 +149,5 @@ void HostPar::Scope::dispatch(int parts, void (*fn)(void*, int), void* ctx) {
 }
 
 }  // namespace sp1hip
+
+extern "C" int sp1hip_host_threads(void) { return sp1hip::pool()->helpers + 1; }

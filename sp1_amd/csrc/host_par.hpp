@@ -40,11 +40,17 @@ class HostPar {
             }, &ctx);
         }
         static constexpr int MAX_THREADS = 16;
+        // The helpers SPIN while the scope is awake. A stage that alternates long device phases with short bursts of host
+        // loops parks them in between (they sleep on a condition variable) and wakes them a little BEFORE the next burst —
+        // e.g. right before the launch whose result the burst consumes — so the ~50 us futex wake-up hides behind the device.
+        void park();
+        void wake();
 
      private:
         void dispatch(int parts, void (*fn)(void*, int), void* ctx);
         int threads_ = 1;
         bool owner_ = false;
+        bool parked_ = false;
     };
 };
 

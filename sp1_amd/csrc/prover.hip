@@ -16,6 +16,7 @@
 // kernel on the caller's stream. One host<->device sync per fold round (16 B + 32 B read back).
 // PoW witnesses: the SMALLEST valid witness is returned (the reference's rayon `find_any` returns
 // any valid one).
+#include <atomic>
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -182,7 +183,7 @@ struct sp1hip_basefold_data_s {
     // The blocks go back to the free list of the stream that created them, which orders their reuse behind that stream's
     // work only. A handle that was also read on ANOTHER stream (a proving key's preprocessed commitment is opened by every
     // prover, each on its own stream) waits for the device before it lets go.
-    bool foreign_use = false;
+    std::atomic<bool> foreign_use{false};
     ~sp1hip_basefold_data_s() { if (foreign_use) (void)hipDeviceSynchronize(); }
 };
 

@@ -24,6 +24,13 @@
 #include "common.hpp"
 #include "kb31.hpp"
 
+// The fence-free hand-over below is correct only where (a) sc1 stores write through to memory past the XCD-private L2s
+// and (b) `s_waitcnt vmcnt(0)` also waits for STORES (gfx942 / gfx950; gfx10+ counts stores in vscnt and would race
+// silently). This library is written for gfx950 only, so any other device target is a build error, not a fallback.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "round_sync.hpp: the sc1 + vmcnt(0) hand-over is only valid on gfx942/gfx950"
+#endif
+
 namespace sp1hip {
 
 struct RoundSync {                       // device-visible handles
@@ -33,6 +40,7 @@ struct RoundSync {                       // device-visible handles
 
 constexpr uint32_t RS_GROUPS = 32, RS_GROUP_STRIDE = 64;             // counter words: group g at g * STRIDE, level 2 at GROUPS * STRIDE
 constexpr size_t RS_COUNTER_BYTES = (size_t)(RS_GROUPS + 1) * RS_GROUP_STRIDE * 4;
+constexpr size_t RS_SLOT_WORDS = 64;                                 // host slot: sequence number + up to 63 words of sums
 
 // one lane per workgroup: true for the workgroup that arrives last; leaves every counter zero for the next launch
 __device__ __forceinline__ bool rs_ticket_is_last(uint32_t* counter, uint32_t block_linear, uint32_t total_blocks) {
@@ -123,7 +131,7 @@ void round_sync_release(RoundSyncSlot slot);
 
 struct RoundSyncHost {
     uint32_t* d_counter = nullptr;
-    uint32_t* h_slot = nullptr;            // pinned + mapped, 32 words
+    uint32_t* h_slot = nullptr;            // pinned + mapped, RS_SLOT_WORDS words
     uint32_t seq = 0;
     hipStream_t s = nullptr;
     int init(hipStream_t stream) {
@@ -143,6 +151,10 @@ struct RoundSyncHost {
         if (d_counter) round_sync_release(RoundSyncSlot{d_counter, h_slot});
     }
     RoundSync next() { seq++; pending = true; return RoundSync{d_counter, (volatile uint32_t*)h_slot}; }
+    // a launch that takes tickets from the counter but finishes its round on the device (no host slot): still "pending"
+    // until the caller has seen a later hand-over on the stream (settled())
+    RoundSync chained() { pending = true; return RoundSync{d_counter, nullptr}; }
+    void settled() { pending = false; }
     // copies n_words sums (from slot[1..]) into out
     int wait(uint32_t* out, int n_words) {
         volatile uint32_t* slot = h_slot;

@@ -103,7 +103,7 @@ struct ArenaKey {
 };
 static std::mutex g_arena_mutex;
 static std::map<ArenaKey, std::vector<void*>> g_arena;
-static size_t g_arena_cached_bytes = 0;
+static std::map<int, size_t> g_arena_cached_bytes;       // free-listed bytes per device (the cap is per device too)
 
 // Size classes in steps of 1/8 of a power of two (<= 12.5 % internal slack): real shards have varying table heights,
 // and exact-size keys would cache a new block for nearly every proof and never reuse it.
@@ -118,13 +118,22 @@ static size_t arena_round(size_t bytes) {
 // two provers in flight plus the blocks an earlier stream left behind, a 64 GB cap was crossed at the end of every proof
 // and each crossing costs hipFree (a device synchronise) now and hipMalloc on the next proof — 234 ms per proof instead
 // of ~85 whenever both provers' blocks met in the free lists.
-static size_t arena_cap_bytes() {
-    static const size_t cap = [] {
-        if (const char* e = getenv("SP1HIP_ARENA_CAP_GB")) return (size_t)atof(e) << 30;
+static size_t arena_cap_bytes(int dev) {
+    // computed once per device, with that device current (arena_alloc / arena_free run with the caller's device set)
+    static std::map<int, size_t> caps;            // guarded by g_arena_mutex (every caller holds it)
+    auto it = caps.find(dev);
+    if (it != caps.end()) return it->second;
+    size_t cap;
+    if (const char* e = getenv("SP1HIP_ARENA_CAP_GB")) {
+        // fractional values are legal ("0.5"); below 1 GiB every free would evict (hipFree = a device synchronise)
+        const double gb = atof(e);
+        cap = (size_t)(std::max(gb, 1.0) * (double)((size_t)1 << 30));
+    } else {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); return (size_t)64 << 30; }
-        return total_b / 2;
-    }();
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); cap = (size_t)64 << 30; }
+        else cap = total_b / 2;
+    }
+    caps[dev] = cap;
     return cap;
 }
 
@@ -138,7 +147,7 @@ int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
         if (it != g_arena.end() && !it->second.empty()) {
             *ptr = it->second.back();
             it->second.pop_back();
-            g_arena_cached_bytes -= sz;
+            g_arena_cached_bytes[dev] -= sz;
             return SP1HIP_SUCCESS;
         }
     }
@@ -161,10 +170,10 @@ void arena_free(void* ptr, size_t bytes, hipStream_t stream) {
     {
         std::lock_guard<std::mutex> lock(g_arena_mutex);
         g_arena[ArenaKey{dev, stream, sz}].push_back(ptr);
-        g_arena_cached_bytes += sz;
+        g_arena_cached_bytes[dev] += sz;
         // over the cap: drop this device's largest cached blocks (never the one just returned: it may still be in use by
         // work queued on its stream; the others were free-listed earlier, and hipFree waits for the device anyway)
-        while (g_arena_cached_bytes > arena_cap_bytes()) {
+        while (g_arena_cached_bytes[dev] > arena_cap_bytes(dev)) {
             auto best = g_arena.end();
             for (auto it = g_arena.begin(); it != g_arena.end(); ++it)
                 if (it->first.device == dev && !it->second.empty() && !(it->second.size() == 1 && it->second.back() == ptr) &&
@@ -173,7 +182,7 @@ void arena_free(void* ptr, size_t bytes, hipStream_t stream) {
             if (best == g_arena.end()) break;
             void* victim = best->second.front() == ptr ? best->second.back() : best->second.front();
             best->second.erase(std::find(best->second.begin(), best->second.end(), victim));
-            g_arena_cached_bytes -= best->first.bytes;
+            g_arena_cached_bytes[dev] -= best->first.bytes;
             evict.push_back(victim);
         }
     }
@@ -186,8 +195,9 @@ size_t arena_trim() {
     {
         std::lock_guard<std::mutex> lock(g_arena_mutex);
         old.swap(g_arena);
-        freed = g_arena_cached_bytes;
-        g_arena_cached_bytes = 0;
+        freed = 0;
+        for (auto& kv : g_arena_cached_bytes) freed += kv.second;
+        g_arena_cached_bytes.clear();
     }
     (void)hipDeviceSynchronize();
     for (auto& kv : old)
@@ -249,8 +259,8 @@ int round_sync_acquire(RoundSyncSlot* out) {
     RoundSyncSlot slot{nullptr, nullptr};
     SP1HIP_HIP(hipMalloc((void**)&slot.d_counter, RS_COUNTER_BYTES));
     SP1HIP_HIP(hipMemset(slot.d_counter, 0, RS_COUNTER_BYTES));
-    SP1HIP_HIP(hipHostMalloc((void**)&slot.h_slot, 32 * 4, hipHostMallocMapped));
-    memset(slot.h_slot, 0, 32 * 4);
+    SP1HIP_HIP(hipHostMalloc((void**)&slot.h_slot, RS_SLOT_WORDS * 4, hipHostMallocMapped));
+    memset(slot.h_slot, 0, RS_SLOT_WORDS * 4);
     *out = slot;
     return SP1HIP_SUCCESS;
 }

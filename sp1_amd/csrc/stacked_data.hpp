@@ -3,6 +3,7 @@
 // (/root/reference/slop/crates/stacked/src/prover.rs:L20-L31) plus, when it came from
 // sp1hip_jagged_commit, the `JaggedProverData` fields (/root/reference/slop/crates/jagged/src/prover.rs:L36-L46).
 #pragma once
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
@@ -21,7 +22,7 @@ struct sp1hip_stacked_data_s {
     std::vector<uint64_t> row_counts, column_counts;   // per table, the two padding tables appended
     uint64_t padding_column_count = 0;
     uint32_t jagged_commit[8];
-    bool foreign_use = false;            // read on a stream other than `stream` (see sp1hip_basefold_data_s)
+    std::atomic<bool> foreign_use{false};            // read on a stream other than `stream` (see sp1hip_basefold_data_s)
     ~sp1hip_stacked_data_s() {
         if (foreign_use) (void)hipDeviceSynchronize();
         if (basefold) sp1hip_basefold_data_free(basefold);

@@ -924,6 +924,7 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         std::vector<uint32_t> folded, sched;
         fold_immediates(program, n_instr, &folded);
         static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
+        SP1HIP_REQUIRE(forced_mode <= 2, "SP1HIP_ZC_SCHEDULE must be 0, 1 or 2 (a debug knob; unset = try all three)");
         uint32_t best_regs = 0xffffffffu;
         for (int mode = 0; mode < 3; mode++) {
             if (forced_mode >= 0 && mode != forced_mode) continue;
@@ -944,8 +945,8 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                     chip_index, n_instr, main_width, prep_width, mono_instr, best_regs);
         }
         SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &np->prog, &np->n_regs));
-        static const uint32_t chunk_limit = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_LIMIT"); return e ? (uint32_t)atoi(e) : ZC_CHUNK_LIMIT; }();
-        static const uint32_t chunk_hard = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_HARD_MAX"); return e ? (uint32_t)atoi(e) : ZC_CHUNK_HARD_MAX; }();
+        static const uint32_t chunk_limit = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_LIMIT"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 8u) : ZC_CHUNK_LIMIT; }();
+        static const uint32_t chunk_hard = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_HARD_MAX"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 8u) : ZC_CHUNK_HARD_MAX; }();
         SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, chunk_limit, &np->chunks, chunk_hard));
         SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT));
         plan = np;
@@ -1240,7 +1241,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
                 const uint32_t bp = g.wg ? g.wg : 256u;
                 uint32_t blocks = (terms + bp - 1) / bp;
-                static const uint32_t max_pairs = [] { const char* e = getenv("SP1HIP_ZC_MAX_PAIRS"); return e ? (uint32_t)atoi(e) : 131072u; }();
+                static const uint32_t max_pairs = [] { const char* e = getenv("SP1HIP_ZC_MAX_PAIRS"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 256u) : 131072u; }();
                 if (blocks > max_pairs / bp) blocks = std::max(1u, max_pairs / bp);
                 const std::vector<Chunk>& cks = use_mono[i] == 1 ? c.mono : use_mono[i] == 2 ? c.fine : c.chunks;
                 const std::vector<uint32_t>& offs = use_mono[i] == 1 ? c.mono_off : use_mono[i] == 2 ? c.fine_off : c.chunk_off;

@@ -23,7 +23,7 @@ def _device():
 
 def max_over_ranks(value):
     """Max of a python float over all ranks (used for the bench's max-over-ranks timing)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -35,7 +35,7 @@ def gather_blobs(blobs):
 
     Two fixed-shape collectives (counts/lengths, then zero-padded payloads), so it runs unchanged on
     RCCL (device tensors) and gloo (host tensors)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return dict(blobs)
     world, dev = dist.get_world_size(), _device()
     items = sorted(blobs.items())

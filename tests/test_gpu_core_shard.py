@@ -73,3 +73,28 @@ def test_core_shaped_shard_at_a_64th_of_core_size_verifies(api):
     proof = api.prove_shard(chips, [], prep, L, lsh, 32, ch)
     assert orc.shard_verify(_shapes_only(chips), commit, proof, L, lsh, v, 2, 124, 16) == 0
     assert np.array_equal(v.state(), ch.state())
+
+
+def test_core_shaped_shard_at_core_size_verifies(api):
+    """The bench workload at the bench size: one core-shaped shard of 2^28 + 2^27 cells proven by
+    sp1hip_prove_shard with the production parameters; the pinned verifier accepts, ends in the prover's transcript state,
+    and rejects the proof with one bit flipped. (bench.py runs the same check on its last timed proof.)"""
+    from core_shard import build_core_shard
+    L, lsh = 22, 21
+    chips, meta = build_core_shard(CORE_AREA, L)
+    assert meta["area_cells"] > 4.0e8
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    commit, prep = jp.commit_multilinears([c[3] for c in chips if c[3] is not None])
+    ch, v = api.DuplexChallenger(), orc.Challenger()
+    ch.observe(commit)
+    v.observe(commit)
+    proof = api.prove_shard(chips, [], prep, L, lsh, 32, ch)
+    shapes = _shapes_only(chips)
+    del chips, prep
+    assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) == 0
+    assert np.array_equal(v.state(), ch.state())
+    bad = bytearray(proof)
+    bad[len(bad) // 3] ^= 4
+    v2 = orc.Challenger()
+    v2.observe(commit)
+    assert orc.shard_verify(shapes, commit, bytes(bad), L, lsh, v2, 2, 124, 16) != 0
