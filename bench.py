@@ -34,8 +34,8 @@ CORE_AREA = (1 << 28) + (1 << 27)
 HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GUIDE = 256 * 4 * 32 * 2.4e9   # guide: 4 SIMD-32 per CU, a wave64 instruction issues in 2 cycles -> 78.6 T lane-inst/s
 VALU_PEAK_MEASURED = 256 * 64 * 2.4e9    # measured VOP3-integer / f64 rate (profiles/r01_ubench*.txt): one lane-inst per lane-clock
-TIMERS = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition", "gkr_round_sum_first",
-          "gkr_round_fold_sum", "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",
+TIMERS = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition", "gkr_pass_sum", "gkr_pass_fold_sum", "gkr_pass_fold",
+          "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",
           "jagged_fold_sum", "jagged_batch_evals")
 
 
@@ -204,6 +204,12 @@ def main():
         return cpu_baseline_child(args.cpu_baseline_child)
     if args.verify_child is not None:
         return verify_child(args.verify_child)
+
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes "Librccl path : ..." to fd 1 when a communicator is
+    # torn down. Keep the real stdout aside and point fd 1 at stderr for the rest of the run.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -409,7 +415,8 @@ def main():
             "two_in_flight": extras.get("two_in_flight"),
             "commit_only": extras.get("commit_only"),
         }
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if use_dist:
         dist.destroy_process_group()
 

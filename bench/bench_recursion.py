@@ -41,8 +41,8 @@ def main():
     dev = [(a, i, api.ColMajor.from_row_major_host(tabs[a.name][1]), api.ColMajor.from_row_major_host(tabs[a.name][0])) for a, i in m]
     jp = api.JaggedProver(L, lsh, 32, 2)
     commit, prep = jp.commit_multilinears([d[3] for d in dev])
-    names = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition", "gkr_round_sum_first",
-             "gkr_round_fold_sum", "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",
+    names = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition", "gkr_pass_sum", "gkr_pass_fold_sum", "gkr_pass_fold",
+             "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",
              "jagged_fold_sum", "jagged_batch_evals")
     for rep in range(args.repeat):
         last = rep == args.repeat - 1

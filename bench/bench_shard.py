@@ -72,7 +72,7 @@ def main():
     prep_commit, prep_data = jp.commit_multilinears(prep_tables)
     res = {"area_cells": area, "max_log_row_count": L, "log_stacking_height": lsh, "chips": len(chips), "interactions": n_int}
     stage_timers = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_first_layer", "gkr_transition",
-                    "gkr_round_sum_first", "gkr_round_fold_sum", "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",
+                    "gkr_pass_sum", "gkr_pass_fold_sum", "gkr_pass_fold", "gkr_openings", "zerocheck_round", "zerocheck_fix", "jagged_round0_sum", "jagged_fold0_sum",
                     "jagged_fold_sum", "jagged_batch_evals")
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()

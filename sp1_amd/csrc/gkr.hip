@@ -210,23 +210,46 @@ __global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int 
     st_ext(out, g - 1, acc);
 }
 
-// ================================================================ sumcheck rounds over a row variable
-// Per (chip, interaction): the sources of one round.
-//  FIRST (interleaved): x_n / x_d = level v+1 vectors (rows_x real entries); row r of the layer is the pair
-//                       (entry 2r = "0" half, entry 2r+1 = "1" half).
-//  later: four separate vectors n0, d0, n1, d1 with `rows` real entries each.
-struct RoundDesc {
-    const void* src[4];        // FIRST: {x_n, x_d, -, -}; later: {n0, d0, n1, d1}
-    Ext* dst[4];               // folded n0, d0, n1, d1
-    uint32_t rows;             // real rows r of the layer at this round (FIRST: ceil(rows_x / 2))
-    uint32_t rows_x;           // FIRST only
+// ================================================================ sumcheck over the row variables: two rounds per pass
+// A layer's sumcheck  sum_x eq(pt, x) F(x),  F = lambda (n0 d1 + n1 d0) + d0 d1,  binds the row variables last-first.
+// One PASS over the tables serves TWO rounds (the reference's look-ahead, /root/reference/sp1-gpu/crates/sys/lib/logup_gkr/
+// lookahead.cu:L44-L141, on a different grid and a different work split). With X the last row variable, Y the one before it
+// and q the remaining bits of a row index, the four rows 4q .. 4q+3 of a table are its values at (Y, X) in {0,1}^2, every
+// table is bilinear in (X, Y) there and F is multi-quadratic, so
+//      G(X, Y) = sum_q eq(pt'', q) F_q(X, Y)            (9 coefficients)
+// is known from its values on the grid {0, 1, inf}^2 — "inf" = the leading coefficient, i.e. F evaluated on the DIFFERENCES
+// of the rows, so the grid costs additions only. The host then has both rounds in closed form, no interpolation and no
+// inversion:    p_a(X) = PA eq(pt_a, X) ((1 - pt_b) G(X, 0) + pt_b G(X, 1)),    p_b(Y) = PA eq(pt_a, alpha_a) eq(pt_b, Y) G(alpha_a, Y).
+// The next pass folds with BOTH challenges while it loads (rows 4r .. 4r+3 -> row r; the half-folded layer is never
+// written) and accumulates the grid of the following two rounds from the folded rows in registers. A layer of v row
+// variables is 1 + ceil(v / 2) launches and hand-overs instead of v + 1, and every table is read once per TWO rounds.
+//
+// Work split: one LANE per OUTPUT ROW — the fold is embarrassingly parallel, every load is a coalesced 16 B / lane run in
+// the existing lane-blocked layouts (a lane reads 4 input rows = what one lane of the one-round kernels read), and the
+// register footprint is one row, not one quad. The four rows of a grid cell then sit in the four lanes of a DPP quad:
+//   * the pure points (0,0), (1,0), (0,1), (1,1) are the rows themselves: lane j evaluates F on its own row;
+//   * a difference point needs F on a difference of two rows = B_D d0_D + A_D d1_D: two products, split over the two lanes of
+//     the pair (one takes B d0, the other A d1; the sign of a difference cancels in the product), operands by quad_perm;
+//   * (inf, inf) is the difference of the differences.
+// 7 extension products per row (2 to weigh the row, 2 + 1 + 1 + 1 for the grid) against 6.5 for a lane-per-quad split, and
+// lane j's accumulators mean different grid points for different j: they are separated by class (lane mod 4) once, at the
+// end of the kernel, into the 10 sums the host wants.
+// Numerators are kept TIMES LAMBDA in the folded tables (the fold is linear; the host divides the layer's last values by
+// lambda once): F = (w lambda n1) d0 + (w (lambda n0 + d0)) d1 is two products per grid point instead of four.
+// Padding rows are the constants (0, 1): F = 1 on every padding cell and the cells' eq mass is 1 - (mass of the real cells),
+// as in the one-round kernels (`eq_correction_term`, logup_poly.rs:L521-L530).
+struct PassDesc {
+    const void* src[4];        // FIRST: {level N, level D, -, -} (row r = entries 2r, 2r+1); else {n0, d0, n1, d1}, numerators x lambda
+    Ext* dst[4];               // folded n0, d0, n1, d1 (numerators x lambda)
+    uint32_t rows_in;          // real rows of the layer before this pass folds (FIRST: ceil(rows_x / 2))
+    uint32_t rows_x;           // FIRST only: real entries of the level
     uint32_t eq_int_index;     // global interaction index
-    uint32_t tile0;            // first workgroup of this interaction in the launch (work is split by size, not per interaction)
+    uint32_t tile0;            // tiled launch: first workgroup of this interaction; FLAT: first lane slot
 };
 
-// workgroup -> (interaction, range of its pairs): the interactions differ by orders of magnitude in height, so the
+// workgroup -> (interaction, range of its rows): the interactions differ by orders of magnitude in height, so the
 // launch is a flat list of equally sized tiles; descs[].tile0 is ascending
-__device__ __forceinline__ uint32_t find_desc(const RoundDesc* __restrict__ descs, uint32_t K, uint32_t b) {
+__device__ __forceinline__ uint32_t find_desc(const PassDesc* __restrict__ descs, uint32_t K, uint32_t b) {
     uint32_t lo = 0, hi = K;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -234,31 +257,33 @@ __device__ __forceinline__ uint32_t find_desc(const RoundDesc* __restrict__ desc
     }
     return lo;
 }
-struct Quad { Ext n0, d0, n1, d1; };
+struct Row { Ext n0, d0, n1, d1; };
 
-// Layout of the folded tables in scratch: a lane of the next round wants rows 4k .. 4k+3 of each table, i.e. 64 B at a
+// Layout of the folded tables in scratch: a lane of the next pass wants rows 4k .. 4k+3 of each table, i.e. 64 B at a
 // 64 B lane stride — every load instruction of a wave would touch 32 cache lines for 1 KiB (measured: the L1/TA rate
 // co-bounds the large rounds with the VALUs; with coalesced addresses the same kernel runs 25 % faster). So inside every
 // complete block of 256 rows, row r lives at (r mod 4) * 64 + (r div 4) mod 64: the four loads of a wave are four
-// contiguous 1 KiB runs, and the stores of the producing round (rows 2k, 2k+1 per lane) are two 512 B runs each. The
+// contiguous 1 KiB runs, and the stores of the producing pass (one row per lane) are four 256 B runs each. The
 // last (incomplete) block of a table keeps the natural order, so tables never grow and short tables (what the host
 // fetches after the last fold) are untouched.
 __device__ __forceinline__ uint32_t folded_pos(uint32_t r, uint32_t len) {
     return (r | 255u) < len ? ((r & ~255u) | ((r & 3u) << 6) | ((r >> 2) & 63u)) : r;
 }
 
+__device__ __forceinline__ Row padding_row() { return Row{kb::ext_zero(), kb::ext_one(), kb::ext_zero(), kb::ext_one()}; }
+
+// row r of the layer as this pass finds it (before its fold)
 template <bool FIRST, bool NBASE>
-__device__ __forceinline__ Quad load_quad(const RoundDesc& d, uint32_t r) {
-    Quad q;
-    if (r >= d.rows) { q.n0 = q.n1 = kb::ext_zero(); q.d0 = q.d1 = kb::ext_one(); return q; }
+__device__ __forceinline__ Row load_row(const PassDesc& d, uint32_t r) {
+    Row q = padding_row();
+    if (r >= d.rows_in) return q;
     if (FIRST) {
         const uint32_t ea = level_pos(2 * r, d.rows_x), eb = level_pos(2 * r + 1, d.rows_x);
         q.n0 = load_n<NBASE>(d.src[0], ea);
         q.d0 = ld_ext((const Ext*)d.src[1], ea);
         if (2 * r + 1 < d.rows_x) { q.n1 = load_n<NBASE>(d.src[0], eb); q.d1 = ld_ext((const Ext*)d.src[1], eb); }
-        else { q.n1 = kb::ext_zero(); q.d1 = kb::ext_one(); }
     } else {
-        const uint32_t rp = folded_pos(r, d.rows);
+        const uint32_t rp = folded_pos(r, d.rows_in);
         q.n0 = ld_ext((const Ext*)d.src[0], rp); q.d0 = ld_ext((const Ext*)d.src[1], rp);
         q.n1 = ld_ext((const Ext*)d.src[2], rp); q.d1 = ld_ext((const Ext*)d.src[3], rp);
     }
@@ -266,294 +291,151 @@ __device__ __forceinline__ Quad load_quad(const RoundDesc& d, uint32_t r) {
 }
 
 __device__ __forceinline__ Ext lerp(const Ext& a, const Ext& b, const Ext& t) { return kb::ext_add(a, kb::ext_mul(kb::ext_sub(b, a), t)); }   // t: the round's challenge (wave-uniform, second)
-
-// accumulate the three sums of one row pair (a = row 2k, b = row 2k+1) weighted by w = eq_int: S0 += w T[2k] F(a),
-// Sh += w (T[2k] + T[2k+1]) Fh(a + b), Seq += w (T[2k] + T[2k+1])
-__device__ __forceinline__ void accumulate_pair(const Quad& a, const Quad& b, const Ext& lambda, const Ext& ta, const Ext& tb,
-                                                Ext (&acc)[3]) {
-    const Ext f0 = kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(a.n0, a.d1), kb::ext_mul(a.n1, a.d0)), lambda), kb::ext_mul(a.d0, a.d1));
-    const Ext sn0 = kb::ext_add(a.n0, b.n0), sn1 = kb::ext_add(a.n1, b.n1), sd0 = kb::ext_add(a.d0, b.d0), sd1 = kb::ext_add(a.d1, b.d1);
-    const Ext fh = kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(sn0, sd1), kb::ext_mul(sn1, sd0)), lambda), kb::ext_mul(sd0, sd1));
-    const Ext ts = kb::ext_add(ta, tb);
-    acc[0] = kb::ext_add(acc[0], kb::ext_mul(ta, f0));
-    acc[1] = kb::ext_add(acc[1], kb::ext_mul(ts, fh));
-    acc[2] = kb::ext_add(acc[2], ts);
+__device__ __forceinline__ Row lerp_row(const Row& a, const Row& b, const Ext& t) {
+    return Row{lerp(a.n0, b.n0, t), lerp(a.d0, b.d0, t), lerp(a.n1, b.n1, t), lerp(a.d1, b.d1, t)};
 }
 
-// ---------------------------------------------------------------- device-resident transcript for the row rounds
-// The v row-variable rounds of a layer used to return to the host after every launch (three sums -> the round polynomial
-// -> observe -> sample alpha -> next launch): ~56 us of host round trip around a ~26 us kernel, 231 times per proof. With
-// `GkrChainArgs` the LAST workgroup of a round (the one that already reduces the partial sums) finishes the round itself:
-// it forms the cubic from the sums (the Lagrange basis of the nodes {0, 1, 1/2, b} only depends on the layer's point:
-// the host precomputes it per round), runs the DuplexChallenger on 16 lanes (`permute_coop16`: one state word per lane),
-// and leaves alpha / claim / eq factor for the next launch, which the host has already enqueued. The host sees a layer's
-// messages, challenges and the sponge once, at the end of the layer.
-// (the reference's CUDA path keeps a device challenger for the same reason:
-//  /root/reference/sp1-gpu/crates/sys/include/challenger/challenger.cuh:L13-L170)
-struct GkrChain {                          // device memory, one per proof
-    uint32_t ch_state[16], ch_in[8], ch_out[8];
-    uint32_t ch_n_in, ch_n_out, pad0, pad1;
-    Ext claim, PA, alpha;
-};
-struct GkrRoundConst { Ext pt; Ext basis[3][4]; };     // basis[k] = the cubic that is 1 at node k and 0 at the other three
-struct GkrRoundOut { Ext poly[4]; Ext alpha; };
-struct GkrChainArgs { GkrChain* st; const GkrRoundConst* rc; GkrRoundOut* out; const p2::RoundConstants* p2rc; };
-
-// DuplexChallenger<KoalaBear, 16, 8> spread over the first 16 lanes of a wave (lane r = state word r; lanes 0..7 also
-// hold the input / output buffers). Same semantics as the host object in prover.hip.
-struct CoopChallenger {
-    uint32_t x, in_w, out_w;
-    int n_in, n_out;
-    uint32_t lane;
-    const p2::RoundConstants* rc;
-    __device__ __forceinline__ void duplexing() {
-        if ((int)lane < n_in) x = in_w;
-        n_in = 0;
-        x = p2::permute_coop16(x, lane, *rc);
-        out_w = x;
-        n_out = 8;
-    }
-    __device__ __forceinline__ void observe(uint32_t v) {      // v is the same in every lane
-        n_out = 0;
-        if ((int)lane == n_in) in_w = v;
-        if (++n_in == 8) duplexing();
-    }
-    __device__ __forceinline__ uint32_t sample() {
-        if (n_in != 0 || n_out == 0) duplexing();
-        --n_out;
-        return __shfl(out_w, n_out, 16);
-    }
-};
-
-// Runs in lanes 0..15 of the last workgroup. sums: S0, Sh, Seq (12 words, LDS).
-__device__ __forceinline__ void gkr_round_tail(const uint32_t* sums, const GkrChainArgs& ca) {
-    const uint32_t lane = threadIdx.x;
-    GkrChain* st = ca.st;
-    const Ext S0{{sums[0], sums[1], sums[2], sums[3]}}, Sh{{sums[4], sums[5], sums[6], sums[7]}}, Seq{{sums[8], sums[9], sums[10], sums[11]}};
-    const Ext claim = ld_ext(&st->claim, 0), PA = ld_ext(&st->PA, 0), pt = ld_ext(&ca.rc->pt, 0);
-    const Ext one = kb::ext_one();
-    const uint32_t inv8 = kb::inv(kb::to_monty(8u)), four = kb::to_monty(4u);
-    const Ext corr = kb::ext_sub(one, Seq);
-    const Ext p0 = kb::ext_mul(PA, kb::ext_add(S0, kb::ext_mul(corr, kb::ext_sub(one, pt))));
-    const Ext ph = kb::ext_mul_base(kb::ext_mul(PA, kb::ext_add(Sh, kb::ext_mul_base(corr, four))), inv8);
-    const Ext ys[3] = {p0, kb::ext_sub(claim, p0), ph};
-    Ext poly[4];
+// output row `ro` of a pass that binds FV variables: rows ro 2^FV .. of the input folded with a0 (last variable), then a1
+template <int FV, bool FIRST, bool NBASE>
+__device__ __forceinline__ Row fold_row(const PassDesc& d, uint32_t ro, const Ext& a0, const Ext& a1) {
+    if constexpr (FV == 0) return load_row<FIRST, NBASE>(d, ro);
+    Row in[FV == 0 ? 1 : (1 << FV)];
+    // every load of the row is issued before the first use: one exposed memory latency per row
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        Ext a = kb::ext_zero();
-#pragma unroll
-        for (int k = 0; k < 3; k++) a = kb::ext_add(a, kb::ext_mul(ys[k], ld_ext(&ca.rc->basis[k][d], 0)));
-        poly[d] = a;
-    }
-    CoopChallenger ch;
-    ch.lane = lane; ch.rc = ca.p2rc;
-    ch.x = st->ch_state[lane];
-    ch.in_w = lane < 8 ? st->ch_in[lane] : 0u;
-    ch.out_w = lane < 8 ? st->ch_out[lane] : 0u;
-    ch.n_in = (int)st->ch_n_in; ch.n_out = (int)st->ch_n_out;
-#pragma unroll 1
-    for (int d = 0; d < 4; d++)
-#pragma unroll 1
-        for (int k = 0; k < 4; k++) ch.observe(poly[d].c[k]);
-    Ext alpha;
-#pragma unroll 1
-    for (int k = 0; k < 4; k++) alpha.c[k] = ch.sample();
-    const Ext next_claim = kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(kb::ext_add(kb::ext_mul(poly[3], alpha), poly[2]), alpha), poly[1]), alpha), poly[0]);
-    const Ext next_PA = kb::ext_mul(PA, kb::ext_add(kb::ext_mul(pt, alpha), kb::ext_mul(kb::ext_sub(one, pt), kb::ext_sub(one, alpha))));
-    st->ch_state[lane] = ch.x;
-    if (lane < 8) { st->ch_in[lane] = ch.in_w; st->ch_out[lane] = ch.out_w; }
-    if (lane == 0) {
-        st->ch_n_in = (uint32_t)ch.n_in; st->ch_n_out = (uint32_t)ch.n_out;
-        st_ext(&st->claim, 0, next_claim); st_ext(&st->PA, 0, next_PA); st_ext(&st->alpha, 0, alpha);
-#pragma unroll
-        for (int d = 0; d < 4; d++) st_ext(&ca.out->poly[d], 0, poly[d]);
-        st_ext(&ca.out->alpha, 0, alpha);
+    for (int j = 0; j < (1 << FV); j++) in[j] = load_row<FIRST, NBASE>(d, (ro << FV) + j);
+    if constexpr (FV == 1) return lerp_row(in[0], in[1], a0);
+    else {
+        const Row lo = lerp_row(in[0], in[1], a0), hi = lerp_row(in[2], in[3], a0);
+        return lerp_row(lo, hi, a1);
     }
 }
 
-// rs_finish (round_sync.hpp) with the round finished on the device instead of published to the host
-template <int NS>
-__device__ __forceinline__ void rs_finish_chain(const Ext (&acc)[NS], uint32_t* __restrict__ partials, uint32_t block_linear,
-                                                uint32_t total_blocks, uint32_t* counter, const GkrChainArgs& ca) {
-    static_assert(NS == 3, "the GKR rounds publish three sums");
-    __shared__ uint32_t sm[4][4 * NS];
-    __shared__ uint32_t fin[4 * NS];
-    __shared__ uint32_t last_flag;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t w = wave_sum(acc[s].c[k]);
-            if (lane == 0) sm[wave][4 * s + k] = w;
-        }
-    __syncthreads();
-    if (threadIdx.x < 4 * NS) {
-        uint32_t a = 0;
-        for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
-        rs_store_partial(&partials[(size_t)block_linear * 4 * NS + threadIdx.x], a);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) last_flag = rs_ticket_is_last(counter, block_linear, total_blocks);
-    __syncthreads();
-    if (!last_flag) return;
-    Ext tot[NS];
-#pragma unroll
-    for (int s = 0; s < NS; s++) tot[s] = kb::ext_zero();
-    for (uint32_t i = threadIdx.x; i < total_blocks; i += 256)
-#pragma unroll
-        for (int s = 0; s < NS; s++) tot[s] = kb::ext_add(tot[s], rs_load_partial(partials + ((size_t)i * NS + s) * 4));
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t w = wave_sum(tot[s].c[k]);
-            if (lane == 0) sm[wave][4 * s + k] = w;
-        }
-    __syncthreads();
-    if (threadIdx.x < 4 * NS) {
-        uint32_t a = 0;
-        for (int i = 0; i < 4; i++) a = kb::add(a, sm[i][threadIdx.x]);
-        fin[threadIdx.x] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) gkr_round_tail(fin, ca);
+template <int CTRL>
+__device__ __forceinline__ Ext dpp_ext(const Ext& e) {
+    return Ext{{p2::dpp_mov<CTRL>(e.c[0]), p2::dpp_mov<CTRL>(e.c[1]), p2::dpp_mov<CTRL>(e.c[2]), p2::dpp_mov<CTRL>(e.c[3])}};
+}
+__device__ __forceinline__ Ext sel_ext(bool c, const Ext& a, const Ext& b) {
+    return Ext{{c ? a.c[0] : b.c[0], c ? a.c[1] : b.c[1], c ? a.c[2] : b.c[2], c ? a.c[3] : b.c[3]}};
 }
 
-// Small rounds (FLAT): most of a proof's ~230 row rounds have a handful of pairs per interaction — one workgroup per
-// interaction is then 730 workgroups of one busy lane each, and what the launch costs is the 730 tickets and partial sums of
-// its tail. FLAT launches give every LANE one pair instead: lane p of the launch looks its descriptor up in a host-built
-// table (flat_index[p]; descs[].tile0 = first pair of the interaction), weighs its own sums with its interaction's eq
-// factor, and the launch is total_pairs / 256 workgroups.
-struct FlatArgs { const uint16_t* index; uint32_t total_pairs; };
-
-// round 0 of a layer: sums only. T = partial-Lagrange table of the layer's row point (2^v entries)
-template <bool NBASE, bool FLAT>
-__global__ __launch_bounds__(256) void round_sum_first(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
-                                                       const Ext* __restrict__ T, Ext lambda, uint32_t* __restrict__ partials,
-                                                       RoundSync rs, uint32_t seq, uint32_t K, uint32_t tile_size, GkrChainArgs ca, FlatArgs fa) {
-    Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
-    if (FLAT) {
-        const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-        if (p < fa.total_pairs) {
-            const RoundDesc d = descs[fa.index[p]];
-            const uint32_t k = p - d.tile0;
-            const Quad a = load_quad<true, NBASE>(d, 2 * k), b = load_quad<true, NBASE>(d, 2 * k + 1);
-            accumulate_pair(a, b, lambda, ld_ext(T, 2 * k), ld_ext(T, 2 * k + 1), acc);
-            const Ext w = ld_ext(eq_int, d.eq_int_index);
+// per-lane accumulators of a pass that sums SV rounds: what each one means depends on the lane's class (lane mod 2^SV)
+template <int SV> struct GridAcc { Ext a[SV == 2 ? 5 : 3]; };
+template <int SV>
+__device__ __forceinline__ void grid_init(GridAcc<SV>& g) {
 #pragma unroll
-            for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-        }
+    for (int i = 0; i < (SV == 2 ? 5 : 3); i++) g.a[i] = kb::ext_zero();
+}
+
+// row = this lane's (folded, numerators x lambda) row; w = eq weight of its cell (zero for lanes past the last real cell);
+// j = lane's position inside the cell. ALL lanes of the cell must be active.
+template <int SV>
+__device__ __forceinline__ void grid_accumulate(const Row& row, const Ext& w, uint32_t j, GridAcc<SV>& g) {
+    const Ext A = kb::ext_mul(kb::ext_add(row.n0, row.d0), w), B = kb::ext_mul(row.n1, w);
+    g.a[0] = kb::ext_add(g.a[0], kb::ext_add(kb::ext_mul(B, row.d0), kb::ext_mul(A, row.d1)));       // the pure point of this lane
+    // difference over the last variable (lanes j ^ 1): the even lane takes B d0, the odd lane A d1 — so every lane KEEPS one
+    // pair of operands and SENDS the other pair, the one its partner works on
+    const bool lo1 = (j & 1u) == 0;
+    const Ext P = sel_ext(lo1, B, A), Q = sel_ext(lo1, row.d0, row.d1), PS = sel_ext(lo1, A, B), QS = sel_ext(lo1, row.d1, row.d0);
+    const Ext DP = kb::ext_sub(P, dpp_ext<p2::DPP_QUAD_SWAP1>(PS)), DQ = kb::ext_sub(Q, dpp_ext<p2::DPP_QUAD_SWAP1>(QS));
+    g.a[1] = kb::ext_add(g.a[1], kb::ext_mul(DP, DQ));
+    if constexpr (SV == 2) {
+        // difference over the variable before it (lanes j ^ 2): lanes 0, 1 take B d0, lanes 2, 3 A d1
+        const bool lo2 = (j & 2u) == 0;
+        const Ext P2 = sel_ext(lo2, B, A), Q2 = sel_ext(lo2, row.d0, row.d1), PS2 = sel_ext(lo2, A, B), QS2 = sel_ext(lo2, row.d1, row.d0);
+        const Ext EP = kb::ext_sub(P2, dpp_ext<p2::DPP_QUAD_SWAP2>(PS2)), EQ = kb::ext_sub(Q2, dpp_ext<p2::DPP_QUAD_SWAP2>(QS2));
+        g.a[2] = kb::ext_add(g.a[2], kb::ext_mul(EP, EQ));
+        // both: lanes j and j ^ 2 hold first differences of the SAME pair of tables (B d0 on lanes 0 / 2, A d1 on 1 / 3), so
+        // their difference is the mixed one; computed twice, counted once below
+        const Ext FP = kb::ext_sub(DP, dpp_ext<p2::DPP_QUAD_SWAP2>(DP)), FQ = kb::ext_sub(DQ, dpp_ext<p2::DPP_QUAD_SWAP2>(DQ));
+        g.a[3] = kb::ext_add(g.a[3], kb::ext_mul(FP, FQ));
+    }
+    if (j == 0) g.a[SV == 2 ? 4 : 2] = kb::ext_add(g.a[SV == 2 ? 4 : 2], w);                          // eq mass of the real cells
+}
+
+// SV = 2: G00 G10 G01 G11 | Gi0 Gi1 | G0i G1i | Gii | Seq   (first index: X = last variable; i = "inf")
+// SV = 1: G0 G1 | Gi | Seq
+template <int SV> struct GridOut { static constexpr int NS = SV == 2 ? 10 : 4; };
+template <int SV>
+__device__ __forceinline__ void grid_split(const GridAcc<SV>& g, uint32_t j, const Ext& scale, bool use_scale, Ext (&out)[GridOut<SV>::NS]) {
+    const Ext z = kb::ext_zero();
+    Ext a[SV == 2 ? 5 : 3];
+#pragma unroll
+    for (int i = 0; i < (SV == 2 ? 5 : 3); i++) a[i] = use_scale ? kb::ext_mul(g.a[i], scale) : g.a[i];
+    if constexpr (SV == 2) {
+        out[0] = j == 0 ? a[0] : z; out[1] = j == 1 ? a[0] : z; out[2] = j == 2 ? a[0] : z; out[3] = j == 3 ? a[0] : z;
+        out[4] = j < 2 ? a[1] : z; out[5] = j < 2 ? z : a[1];
+        out[6] = (j & 1u) == 0 ? a[2] : z; out[7] = (j & 1u) == 0 ? z : a[2];
+        out[8] = j < 2 ? a[3] : z;
+        out[9] = a[4];
     } else {
-        const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
-        const uint32_t pairs = (d.rows + 1) / 2;
-        const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
-        for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-            const Quad a = load_quad<true, NBASE>(d, 2 * k), b = load_quad<true, NBASE>(d, 2 * k + 1);
-            accumulate_pair(a, b, lambda, ld_ext(T, 2 * k), ld_ext(T, 2 * k + 1), acc);
-        }
-        const Ext w = ld_ext(eq_int, d.eq_int_index);
-#pragma unroll
-        for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+        out[0] = j == 0 ? a[0] : z; out[1] = j == 1 ? a[0] : z;
+        out[2] = a[1];
+        out[3] = a[2];
     }
-    if (ca.st) rs_finish_chain<3>(acc, partials, blockIdx.x, gridDim.x, rs.counter, ca);
-    else rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
 }
 
-// rows (4k .. 4k+3) -> folded rows (2k, 2k+1), stored; and (if SUM) the next round's sums from the folded pair.
-// Split in two so that the tiled loop can issue the loads of iteration i + 1 before the arithmetic of iteration i.
-// Software-pipelined variant of the tiled loop (loads of iteration i + 1 in flight during the arithmetic of iteration i):
-// 182 VGPRs -> 2 waves per SIMD instead of 4. Measured on the core-shaped shard: later folds -4 %, a layer's first fold -9 %,
-// the top layer's first fold (base-field numerators) +7 %: no net gain — with the lane-blocked layouts the large rounds
-// are bound by VALU issue (2,400 instructions per iteration, a third of them half-rate 64-bit multiply-adds: ~87 % of that
-// bound), not by exposed latency. Off; kept for A/B runs.
-constexpr bool PREFETCH_FOLDS = false;
-struct FoldIn { Quad in[4]; Ext ta, tb; };
-template <bool FIRST, bool NBASE, bool SUM>
-__device__ __forceinline__ void fold_load(const RoundDesc& d, uint32_t k, const Ext* __restrict__ T_next, FoldIn& f) {
-    // every load of the iteration is issued before the first use: one exposed memory latency per iteration instead
-    // of three (rows of h = 0, rows of h = 1, eq table)
-#pragma unroll
-    for (int q = 0; q < 4; q++) f.in[q] = load_quad<FIRST, NBASE>(d, 4 * k + q);
-    if (SUM) { f.ta = ld_ext(T_next, 2 * k); f.tb = ld_ext(T_next, 2 * k + 1); }
-}
-template <bool SUM>
-__device__ __forceinline__ void fold_compute(const RoundDesc& d, uint32_t k, uint32_t rows_out, const Ext& alpha, const Ext& lambda,
-                                             const FoldIn& f, Ext (&acc)[3]) {
-    Quad o[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t ro = 2 * k + h;
-        const Quad& a = f.in[2 * h];
-        const Quad& b = f.in[2 * h + 1];
-        o[h].n0 = lerp(a.n0, b.n0, alpha); o[h].d0 = lerp(a.d0, b.d0, alpha);
-        o[h].n1 = lerp(a.n1, b.n1, alpha); o[h].d1 = lerp(a.d1, b.d1, alpha);
-        // (the fold that binds the last row variable, SUM = false, leaves one row per table for the host: natural order)
-        const uint32_t rq = SUM ? folded_pos(ro, rows_out) : ro;
-        if (ro < rows_out) { st_ext(d.dst[0], rq, o[h].n0); st_ext(d.dst[1], rq, o[h].d0); st_ext(d.dst[2], rq, o[h].n1); st_ext(d.dst[3], rq, o[h].d1); }
-    }
-    if (SUM) accumulate_pair(o[0], o[1], lambda, f.ta, f.tb, acc);
-}
-template <bool FIRST, bool NBASE, bool SUM>
-__device__ __forceinline__ void fold_sum_pair(const RoundDesc& d, uint32_t k, uint32_t rows_out, const Ext& alpha, const Ext& lambda,
-                                              const Ext* __restrict__ T_next, Ext (&acc)[3]) {
-    FoldIn f;
-    fold_load<FIRST, NBASE, SUM>(d, k, T_next, f);
-    fold_compute<SUM>(d, k, rows_out, alpha, lambda, f, acc);
-}
+// Small passes (FLAT): most of a proof's passes have a handful of rows per interaction — one workgroup per interaction is
+// then 730 workgroups of a few busy lanes each, and what the launch costs is the 730 tickets and partial sums of its tail.
+// FLAT launches give every LANE one row instead: lane p of the launch looks its descriptor up in a host-built table
+// (flat_index[p]; descs[].tile0 = first slot of the interaction, slots per interaction = rows rounded up to whole cells)
+// and weighs its own row with its interaction's eq factor.
+struct FlatArgs { const uint16_t* index; uint32_t total_slots; };
 
-// fold rows (2r', 2r'+1) -> r' with alpha for r' = 2k, 2k+1, store, and (if SUM) accumulate the next round's sums
-// from the folded pair. T_next = table of the remaining row variables (half the size).
-template <bool FIRST, bool NBASE, bool SUM, bool FLAT>
-__global__ __launch_bounds__(256) void round_fold_sum(const RoundDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
-                                                      const Ext* __restrict__ T_next, Ext lambda, Ext alpha_arg,
-                                                      uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq, uint32_t K,
-                                                      uint32_t tile_size, GkrChainArgs ca, FlatArgs fa) {
-    const Ext alpha = ca.st ? ld_ext(&ca.st->alpha, 0) : alpha_arg;      // chained: left by the previous round's last workgroup
-    Ext acc[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
-    if (FLAT) {
-        const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-        if (p < fa.total_pairs) {
-            const RoundDesc d = descs[fa.index[p]];
-            fold_sum_pair<FIRST, NBASE, SUM>(d, p - d.tile0, (d.rows + 1) / 2, alpha, lambda, T_next, acc);
-            if (SUM) {
-                const Ext w = ld_ext(eq_int, d.eq_int_index);
-#pragma unroll
-                for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
+// One pass: bind FV variables (fold rows ro 2^FV .. with a0, a1 and store row ro; FV = 0: read only), then accumulate the
+// grid of the next SV rounds (SV = 0: the layer's last fold, nothing to sum). T = partial-Lagrange table of the row
+// variables that remain after those SV rounds.
+template <int FV, int SV, bool FIRST, bool NBASE, bool FLAT>
+__global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
+                                                const Ext* __restrict__ T, Ext lambda, Ext a0, Ext a1,
+                                                uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq, uint32_t K,
+                                                uint32_t tile_size, FlatArgs fa) {
+    static_assert(FV + SV > 0 && FV <= 2 && SV <= 2, "a pass folds and / or sums");
+    constexpr int SVS = SV == 0 ? 1 : SV;                    // (types only; SV = 0 never touches the grid)
+    GridAcc<SVS> g;
+    grid_init<SVS>(g);
+    const uint32_t j = threadIdx.x & ((1u << SV) - 1u);
+    // one row: fold, store, weigh, accumulate. valid = the lane has a slot; rows past rows_out inside a real cell are padding
+    auto do_row = [&](const PassDesc& d, uint32_t ro, bool valid, const Ext& wi, bool use_wi) {
+        const uint32_t rows_out = (d.rows_in + (1u << FV) - 1u) >> FV;
+        Row row = padding_row();
+        if (valid && ro < rows_out) {
+            row = fold_row<FV, FIRST, NBASE>(d, ro, a0, a1);
+            if (FIRST && NBASE && FV == 0) {                 // base-field numerators read as they are: lambda n is 4 products, not 16
+                row.n0 = kb::ext_mul_base(lambda, row.n0.c[0]); row.n1 = kb::ext_mul_base(lambda, row.n1.c[0]);
+            } else if (FIRST) { row.n0 = kb::ext_mul(row.n0, lambda); row.n1 = kb::ext_mul(row.n1, lambda); }
+            if (FV > 0) {
+                const uint32_t rq = folded_pos(ro, rows_out);
+                st_ext(d.dst[0], rq, row.n0); st_ext(d.dst[1], rq, row.d0); st_ext(d.dst[2], rq, row.n1); st_ext(d.dst[3], rq, row.d1);
             }
         }
+        if constexpr (SV > 0) {
+            const uint32_t cells = (rows_out + (1u << SV) - 1u) >> SV;
+            const uint32_t c = ro >> SV;
+            Ext w = kb::ext_zero();
+            if (valid && c < cells) { w = ld_ext(T, c); if (use_wi) w = kb::ext_mul(w, wi); }
+            grid_accumulate<SVS>(row, w, j, g);
+        }
+    };
+    Ext scale = kb::ext_one();
+    if (FLAT) {
+        const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+        const bool valid = p < fa.total_slots;               // slots come in whole cells: a cell's lanes are valid together
+        const PassDesc d = descs[valid ? fa.index[p] : 0];
+        const Ext wi = SV > 0 ? ld_ext(eq_int, d.eq_int_index) : kb::ext_one();
+        do_row(d, p - d.tile0, valid, wi, true);
     } else {
-        const RoundDesc d = descs[find_desc(descs, K, blockIdx.x)];
-        const uint32_t rows_out = (d.rows + 1) / 2;
-        const uint32_t pairs = (rows_out + 1) / 2;
-        const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(pairs, k0 + tile_size);
-        if (PREFETCH_FOLDS && SUM) {
-            // software pipeline: the loads of iteration i + 1 are in flight during the arithmetic of iteration i
-            uint32_t k = k0 + threadIdx.x;
-            FoldIn cur;
-            if (k < k1) fold_load<FIRST, NBASE, SUM>(d, k, T_next, cur);
-            while (k < k1) {
-                const uint32_t kn = k + blockDim.x;
-                FoldIn nxt;
-                if (kn < k1) fold_load<FIRST, NBASE, SUM>(d, kn, T_next, nxt);
-                fold_compute<SUM>(d, k, rows_out, alpha, lambda, cur, acc);
-                if (kn < k1) cur = nxt;
-                k = kn;
-            }
-        } else {
-            for (uint32_t k = k0 + threadIdx.x; k < k1; k += blockDim.x) fold_sum_pair<FIRST, NBASE, SUM>(d, k, rows_out, alpha, lambda, T_next, acc);
-        }
-        if (SUM) {
-            const Ext w = ld_ext(eq_int, d.eq_int_index);
-#pragma unroll
-            for (int s = 0; s < 3; s++) acc[s] = kb::ext_mul(acc[s], w);
-        }
+        const PassDesc d = descs[find_desc(descs, K, blockIdx.x)];
+        const uint32_t rows_out = (d.rows_in + (1u << FV) - 1u) >> FV;
+        const uint32_t slots = ((rows_out + (1u << SV) - 1u) >> SV) << SV;
+        const uint32_t k0 = (blockIdx.x - d.tile0) * tile_size, k1 = min(slots, k0 + tile_size);
+        // every lane runs every iteration (the grid exchanges rows between the lanes of a cell)
+        for (uint32_t base = k0; base < k1; base += 256) do_row(d, base + threadIdx.x, base + threadIdx.x < k1, scale, false);
+        if (SV > 0) scale = ld_ext(eq_int, d.eq_int_index);
     }
-    if (SUM) {
-        if (ca.st) rs_finish_chain<3>(acc, partials, blockIdx.x, gridDim.x, rs.counter, ca);
-        else rs_finish<3>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
+    if constexpr (SV > 0) {
+        Ext out[GridOut<SVS>::NS];
+        grid_split<SVS>(g, j, scale, !FLAT, out);
+        rs_finish<GridOut<SVS>::NS>(out, partials, blockIdx.x, gridDim.x, rs, seq);
     }
 }
 
@@ -866,87 +748,83 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     mark("tree enqueued");
     Mailbox mb;                                              // device -> host hand-overs outside the sumcheck rounds
     SP1HIP_TRY(mb.init(s));
-    // (the descriptors of every round depend on shapes only: they are planned and uploaded WHILE the GPU builds the first
-    // layer and the fraction tree — 3.9 ms of host work at 730 interactions x 231 rounds that used to sit on the critical
-    // path behind the first hand-over)
+    // (the descriptors of every pass depend on shapes only: they are planned and uploaded WHILE the GPU builds the first
+    // layer and the fraction tree — milliseconds of host work at 730 interactions x ~130 passes that would otherwise sit on
+    // the critical path behind the first hand-over)
     // ---- GKR rounds, layer v = 1 .. L-1 (reads level v + 1)
     struct RoundOut { Ext n0, n1, d0, d1; std::vector<Poly4> polys; Ext claimed_sum, eval; std::vector<Ext> point; };
     std::vector<RoundOut> rounds;
-    DeviceBuf d_eq_int, d_T, d_partials, d_out, scratch[2];
+    DeviceBuf d_eq_int, d_T, d_partials, scratch[2];
     SP1HIP_TRY(d_eq_int.alloc((size_t)W * 16, s));
     SP1HIP_TRY(d_T.alloc(((size_t)2 << std::max(L - 1, 1)) * 16, s));
-    SP1HIP_TRY(d_out.alloc(48, s));
     // folded tables: 4 vectors per interaction, at most ceil(rows(level v+1) / 4) entries each after the first fold
     size_t scratch_entries = 0;
     for (uint32_t i = 0; i < K; i++) scratch_entries += (rows_at(info[int_chip[i]].rows, L) + 3) / 4 + 1;
     for (int b = 0; b < 2; b++) SP1HIP_TRY(scratch[b].alloc(std::max<size_t>(scratch_entries, 1) * 64, s));
-    // The descriptors of EVERY round of EVERY layer depend on shapes only: plan them all, upload once, and let each
-    // launch index the table — no per-round host-to-device copy on the critical path.
     auto scratch_ptr = [&](int b, uint32_t i, int which, const std::vector<size_t>& so) -> Ext* { return scratch[b].ext() + 4 * so[i] + (size_t)which * (so[i + 1] - so[i]); };
-    // fills K descriptors of one launch. j = round index inside the layer (0 = sums only, >= 1 fold of round j-1),
-    // last = the fold that binds the last row variable
-    struct LaunchShape { uint32_t tiles, tile_size, total_pairs; size_t flat_off; bool flat; };
-    std::vector<LaunchShape> shapes;
-    std::vector<uint16_t> flat_index;                        // FLAT launches: pair -> descriptor, all launches back to back
-    const uint32_t FLAT_MAX_PAIRS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_PAIRS"); return e ? (uint32_t)atoi(e) : 65536u; }();   // read per call (tests)
-    // workgroups of a large round. While every workgroup paid an L2 write-back and a serialised ticket in its tail
+    // The passes of a layer with v row variables (two rounds per pass, gkr_pass): (fold 0, sum s0 = min(2, v)), then
+    // (fold what was just summed, sum min(2, what remains)) until nothing remains; the last pass only folds.
+    struct PassShape { int fv, sv; bool first; uint32_t tiles, tile_size, total_slots; size_t flat_off; bool flat; };
+    std::vector<PassShape> shapes;
+    std::vector<uint16_t> flat_index;                        // FLAT launches: slot -> descriptor, all launches back to back
+    const uint32_t FLAT_MAX_SLOTS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_SLOTS"); return e ? (uint32_t)atoi(e) : 65536u; }();   // read per call (tests)
+    // workgroups of a large pass. While every workgroup paid an L2 write-back and a serialised ticket in its tail
     // (round_sync.hpp) one resident set — 256 CUs x 4 workgroups — was the optimum; without them finer tiles balance the
-    // tail better. GKR kernels on the core-shaped shard, ms (SP1HIP_GKR_TILES): 512: 24.6, 768: 22.3, 1024: 21.4,
-    // 2048: 21.0, 3072: 20.8, 4096: 20.6, 6144: 20.8, 8192: 20.9, 12288: 21.2.
+    // tail better (sweep of round 2 on the one-round kernels: 4096 best, flat between 2048 and 8192).
     static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 1u) : 4096u; }();
-    auto fill_descs = [&](RoundDesc* out, int v, int j, bool last, const std::vector<uint32_t>& live, int cur,
-                          const std::vector<size_t>& so_prev, const std::vector<size_t>& so_next) {
-        // pairs handled per interaction: sums-only launch: ceil(rows / 2); fold launches: ceil(ceil(rows / 2) / 2)
-        uint64_t total_pairs = 0;
-        auto pairs_of = [&](uint32_t rows) -> uint32_t { const uint32_t p = (rows + 1) / 2; return j == 0 ? p : (p + 1) / 2; };
-        for (uint32_t i = 0; i < K; i++) total_pairs += pairs_of(live[i]);
-        const bool flat = total_pairs <= FLAT_MAX_PAIRS && K <= 65536 && !last;
-        const uint32_t tile_size = flat ? 1u : (uint32_t)std::max<uint64_t>(256, ((total_pairs + TARGET_TILES - 1) / TARGET_TILES + 255) / 256 * 256);
-        const size_t flat_off = flat_index.size();
-        uint32_t tile0 = 0;
-        for (uint32_t i = 0; i < K; i++) {
-            RoundDesc& d = out[i];
-            d = RoundDesc{};
-            d.rows = live[i]; d.eq_int_index = i;
-            const bool from_level = j == 0 || (last ? v == 1 : j == 1);
-            if (from_level) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
-            else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
-            if (j > 0 || last) for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
-            d.tile0 = tile0;
-            const uint32_t n_tiles = (pairs_of(live[i]) + tile_size - 1) / tile_size;
-            if (flat) flat_index.insert(flat_index.end(), n_tiles, (uint16_t)i);
-            tile0 += n_tiles;
-        }
-        if (flat) shapes.push_back(LaunchShape{std::max<uint32_t>((tile0 + 255) / 256, 1), tile_size, tile0, flat_off, true});
-        else shapes.push_back(LaunchShape{std::max<uint32_t>(tile0, 1), tile_size, tile0, 0, false});
-    };
-    std::vector<RoundDesc> all_descs;
+    std::vector<PassDesc> all_descs;
     for (int v = 1; v <= L - 1; v++) {
-        std::vector<uint32_t> live(K);
-        for (uint32_t i = 0; i < K; i++) live[i] = (rows_at(info[int_chip[i]].rows, v + 1) + 1) / 2;
-        int cur = 0;
+        std::vector<uint32_t> rows_in(K);
+        for (uint32_t i = 0; i < K; i++) rows_in[i] = (rows_at(info[int_chip[i]].rows, v + 1) + 1) / 2;
+        int cur = 0, t = v, fv = 0, pass = 0;
         std::vector<size_t> so_prev, so_next;
-        for (int j = 0; j <= v; j++) {
-            const bool last = j == v;
-            if (j > 0) { so_next.assign(K + 1, 0); for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + (live[i] + 1) / 2; }
+        for (;;) {
+            const int sv = std::min(2, t - fv);              // variables left after this pass's fold: t - fv
+            const bool first = pass <= 1;                    // pass 0 only sums, so pass 1 still reads the level
+            if (fv > 0) { so_next.assign(K + 1, 0); for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + ((rows_in[i] + (1u << fv) - 1) >> fv); }
+            uint64_t total_slots = 0;
+            auto slots_of = [&](uint32_t rin) -> uint32_t { const uint32_t ro = (rin + (1u << fv) - 1) >> fv; return ((ro + (1u << sv) - 1) >> sv) << sv; };
+            for (uint32_t i = 0; i < K; i++) total_slots += slots_of(rows_in[i]);
+            const bool flat = total_slots <= FLAT_MAX_SLOTS && K <= 65536;
+            const uint32_t tile_size = flat ? 1u : (uint32_t)std::max<uint64_t>(256, ((total_slots + TARGET_TILES - 1) / TARGET_TILES + 255) / 256 * 256);
+            const size_t flat_off = flat_index.size();
             all_descs.resize(all_descs.size() + K);
-            fill_descs(all_descs.data() + all_descs.size() - K, v, j, last, live, cur, so_prev, so_next);
-            if (j > 0 && !last) { for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2; so_prev = so_next; cur ^= 1; }
+            PassDesc* out = all_descs.data() + all_descs.size() - K;
+            uint32_t tile0 = 0;
+            for (uint32_t i = 0; i < K; i++) {
+                PassDesc& d = out[i];
+                d = PassDesc{};
+                d.rows_in = rows_in[i]; d.eq_int_index = i;
+                if (first) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
+                else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
+                if (fv > 0) for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
+                d.tile0 = tile0;
+                const uint32_t n_tiles = (slots_of(rows_in[i]) + tile_size - 1) / tile_size;
+                if (flat) flat_index.insert(flat_index.end(), n_tiles, (uint16_t)i);
+                tile0 += n_tiles;
+            }
+            if (flat) shapes.push_back(PassShape{fv, sv, first, std::max<uint32_t>((tile0 + 255) / 256, 1), tile_size, tile0, flat_off, true});
+            else shapes.push_back(PassShape{fv, sv, first, std::max<uint32_t>(tile0, 1), tile_size, tile0, 0, false});
+            if (fv > 0) { for (uint32_t i = 0; i < K; i++) rows_in[i] = (rows_in[i] + (1u << fv) - 1) >> fv; so_prev = so_next; cur ^= 1; }
+            t -= fv;
+            pass++;
+            if (sv == 0) break;
+            fv = sv;
         }
     }
-    {   // partial sums: one slot per workgroup of the largest launch
+    {   // partial sums: one slot per workgroup of the largest launch, 10 sums each
         uint32_t max_tiles = 1;
         for (auto& sh : shapes) max_tiles = std::max(max_tiles, sh.tiles);
-        SP1HIP_TRY(d_partials.alloc((size_t)max_tiles * 48, s));
+        SP1HIP_TRY(d_partials.alloc((size_t)max_tiles * 160, s));
     }
-    mark("round descriptors planned");
+    mark("pass descriptors planned");
     DeviceBuf d_all;
-    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(RoundDesc), s, stage));     // all_descs outlives the copy
+    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(PassDesc), s, stage));     // all_descs outlives the copy
     DeviceBuf d_flat;
     if (flat_index.empty()) flat_index.push_back(0);
     flat_index.resize((flat_index.size() + 1) / 2 * 2);
     SP1HIP_TRY(upload(d_flat, flat_index.data(), flat_index.size() * sizeof(uint16_t), s, stage));
-    mark("round descriptors uploaded");
+    mark("pass descriptors uploaded");
     // ---- circuit output = level 1 (<= 2 rows per interaction): index 2 i + r, padding (0, 1)
     std::vector<Ext> out_n(2 * (size_t)W, kb::ext_zero()), out_d(2 * (size_t)W, kb::ext_one());
     {
@@ -971,28 +849,19 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     for (auto& z : eval_point) z = challenger_sample_ext(ch);
     Ext num_eval = eval_mle_host(out_n, eval_point), den_eval = eval_mle_host(out_d, eval_point);
 
-    size_t launch_idx = 0;                                   // next K descriptors of d_all
+    size_t launch_idx = 0;                                   // next pass: shapes[launch_idx], K descriptors of d_all
     RoundSyncHost rsync;
     SP1HIP_TRY(rsync.init(s));
-    const Ext one = kb::ext_one(), inv8 = kb::ext_inv(ext_c(8)), inv2 = kb::ext_inv(ext_c(2)), four = ext_c(4);
-    uint32_t h_sums[12];
-    // device-resident transcript for the row rounds: SP1HIP_GKR_CHAIN=1. Byte-identical proofs (the GPU tests run both),
-    // but OFF by default: measured on MI355X the round finished by one wave of the last workgroup (three cooperative
-    // Poseidon2 permutations + the cubic: ~18 us of dependent instructions) costs what it saves — the host round trip
-    // through mapped pinned memory is ~19 us per round (core-shaped shard: row rounds 32.3 ms chained vs 29.0 ms).
-    const bool chain_enabled = [] { const char* e = getenv("SP1HIP_GKR_CHAIN"); return e && e[0] == '1'; }();   // read per call
-    DeviceBuf d_chain, d_rconst, d_rout;
-    std::vector<std::unique_ptr<std::vector<GkrRoundConst>>> keep_rconst;       // upload sources live to the end of the call
-    std::vector<std::unique_ptr<GkrChain>> keep_chain;
-    const p2::RoundConstants* d_p2rc = nullptr;
-    if (chain_enabled) {
-        const DeviceCtx* ctx;
-        SP1HIP_TRY(get_device_ctx(&ctx));
-        d_p2rc = ctx->d_rc;
-        SP1HIP_TRY(d_chain.alloc(sizeof(GkrChain), s));
-        SP1HIP_TRY(d_rconst.alloc(sizeof(GkrRoundConst) * (size_t)std::max(L, 1), s));
-        SP1HIP_TRY(d_rout.alloc(sizeof(GkrRoundOut) * (size_t)std::max(L, 1), s));
-    }
+    const Ext one = kb::ext_one(), zero = kb::ext_zero(), inv8 = kb::ext_inv(ext_c(8)), inv2 = kb::ext_inv(ext_c(2)), four = ext_c(4);
+    uint32_t h_sums[40];
+    // the cubic  scale (1 - pt + (2 pt - 1) X) (q0 + q1 X + q2 X^2)
+    auto eq_times_quadratic = [&](const Ext& scale, const Ext& pt, const Ext (&q)[3]) -> Poly4 {
+        const Ext e0 = scale * (one - pt), e1 = scale * (pt + pt - one);
+        return Poly4{e0 * q[0], e0 * q[1] + e1 * q[0], e0 * q[2] + e1 * q[1], e1 * q[2]};
+    };
+    // the quadratic with values g0, g1 at 0, 1 and leading coefficient gi
+    auto quadratic = [&](const Ext& g0, const Ext& g1, const Ext& gi, Ext (&q)[3]) { q[0] = g0; q[1] = g1 - g0 - gi; q[2] = gi; };
+    auto eval_quadratic = [&](const Ext (&q)[3], const Ext& x) -> Ext { return (q[2] * x + q[1]) * x + q[0]; };
 
     HostPar::Scope par;                                      // helper threads for the host loops between hand-overs
     double dbg_rows = 0, dbg_int = 0, dbg_head = 0;
@@ -1027,137 +896,99 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
 
         std::vector<Ext> alphas;
         Ext PA = one;                                        // eq factor of the row variables bound so far
-        Poly4 poly{};
-        Ext alpha_r = kb::ext_zero();
-        const bool chain = chain_enabled;
-        if (chain) {
-            // what the device needs to finish a round by itself: the sponge, the running claim, and per round the point
-            // coordinate and the Lagrange basis of the nodes {0, 1, 1/2, (1 - pt) / (1 - 2 pt)} (they depend on the layer's
-            // point only; the fourth node's value is zero, so three basis cubics suffice)
-            keep_rconst.emplace_back(new std::vector<GkrRoundConst>(v));
-            std::vector<GkrRoundConst>& rcs = *keep_rconst.back();
-            for (int j = 0; j < v; j++) {
-                const Ext pt = row_point[v - j - 1];
-                const Ext xs[4] = {kb::ext_zero(), one, inv2, (one - pt) * kb::ext_inv(one - (pt + pt))};
-                rcs[j].pt = pt;
-                for (int k = 0; k < 3; k++) {
-                    Ext ys[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
-                    ys[k] = one;
-                    const Poly4 b = interpolate4(xs, ys);
-                    for (int d = 0; d < 4; d++) rcs[j].basis[k][d] = b[d];
-                }
+        Ext a0 = zero, a1 = zero;                            // the challenges the next pass folds with
+        int t = v;                                           // row variables not yet bound by a FOLD
+        size_t final_rows_total = 0;
+        for (;;) {                                           // the passes of the layer (two rounds each)
+            const PassShape shape = shapes[launch_idx];
+            const PassDesc* d_descs = (const PassDesc*)d_all.p + (launch_idx++) * K;
+            const int fv = shape.fv, sv = shape.sv;
+            t -= fv;                                         // variables left once this pass has folded
+            const FlatArgs fa{(const uint16_t*)d_flat.p + shape.flat_off, shape.total_slots};
+            const bool nbase = shape.first && v + 1 == L;
+            if (sv == 0) par.wake();                         // the helpers' wake-up hides behind the last fold and its hand-over
+            const RoundSync rs = sv > 0 ? rsync.next() : RoundSync{};
+            const Ext* Tp = sv > 0 ? T_of(t - sv) : (const Ext*)nullptr;
+            {
+                ScopedTimer tm(fv == 0 ? "gkr_pass_sum" : sv == 0 ? "gkr_pass_fold" : "gkr_pass_fold_sum", s);
+#define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, lambda, a0, a1, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, fa)
+#define SP1HIP_GKR_PASS_FL(FV, SV, F, NB) do { if (shape.flat) SP1HIP_GKR_PASS(FV, SV, F, NB, true); else SP1HIP_GKR_PASS(FV, SV, F, NB, false); } while (0)
+#define SP1HIP_GKR_PASS_SRC(FV, SV) do { if (nbase) SP1HIP_GKR_PASS_FL(FV, SV, true, true); else if (shape.first) SP1HIP_GKR_PASS_FL(FV, SV, true, false); else SP1HIP_GKR_PASS_FL(FV, SV, false, false); } while (0)
+                if (fv == 0 && sv == 2) { if (nbase) SP1HIP_GKR_PASS_FL(0, 2, true, true); else SP1HIP_GKR_PASS_FL(0, 2, true, false); }
+                else if (fv == 0 && sv == 1) { if (nbase) SP1HIP_GKR_PASS_FL(0, 1, true, true); else SP1HIP_GKR_PASS_FL(0, 1, true, false); }
+                else if (fv == 2 && sv == 2) SP1HIP_GKR_PASS_SRC(2, 2);
+                else if (fv == 2 && sv == 1) SP1HIP_GKR_PASS_SRC(2, 1);
+                else if (fv == 2 && sv == 0) SP1HIP_GKR_PASS_SRC(2, 0);
+                else if (fv == 1 && sv == 0) SP1HIP_GKR_PASS_SRC(1, 0);
+                else { set_error("internal error: GKR pass shape (%d, %d)", fv, sv); return SP1HIP_ERROR_RUNTIME; }
+#undef SP1HIP_GKR_PASS_SRC
+#undef SP1HIP_GKR_PASS_FL
+#undef SP1HIP_GKR_PASS
+                SP1HIP_LAUNCH_CHECK();
             }
-            keep_chain.emplace_back(new GkrChain());
-            GkrChain& hc = *keep_chain.back();
-            uint32_t w34[34];
-            challenger_export(ch, w34);
-            memcpy(hc.ch_state, w34, 64); memcpy(hc.ch_in, w34 + 16, 32); memcpy(hc.ch_out, w34 + 25, 32);
-            hc.ch_n_in = w34[24]; hc.ch_n_out = w34[33]; hc.pad0 = hc.pad1 = 0;
-            hc.claim = claim; hc.PA = one; hc.alpha = kb::ext_zero();
-            SP1HIP_TRY(stage.upload(d_chain.p, &hc, sizeof hc));
-            SP1HIP_TRY(stage.upload(d_rconst.p, rcs.data(), sizeof(GkrRoundConst) * (size_t)v));
-        }
-        // per-interaction live row counts of the current round
-        std::vector<uint32_t> live(K);
-        uint32_t max_live = 0;
-        for (uint32_t i = 0; i < K; i++) { live[i] = (rows_at(info[int_chip[i]].rows, v + 1) + 1) / 2; max_live = std::max(max_live, live[i]); }
-        int cur = 0;
-        std::vector<size_t> so_prev, so_next;
-        for (int j = 0; j < v; j++) {                        // row-variable rounds
-            const int t = v - j;                             // remaining row variables
-            uint32_t tiles;
-            const LaunchShape shape = shapes[launch_idx];
-            const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
-            const GkrChainArgs ca = chain ? GkrChainArgs{(GkrChain*)d_chain.p, (const GkrRoundConst*)d_rconst.p + j, (GkrRoundOut*)d_rout.p + j, d_p2rc}
-                                          : GkrChainArgs{nullptr, nullptr, nullptr, nullptr};
-            const FlatArgs fa{(const uint16_t*)d_flat.p + shape.flat_off, shape.total_pairs};
-            if (j == 0) {
-                tiles = shape.tiles;
-                ScopedTimer tm("gkr_round_sum_first", s);
-                const RoundSync rs = chain ? rsync.chained() : rsync.next();
-#define SP1HIP_GKR_SUM_FIRST(NB, FL) hipLaunchKernelGGL((round_sum_first<NB, FL>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca, fa)
-                if (v + 1 == L) { if (shape.flat) SP1HIP_GKR_SUM_FIRST(true, true); else SP1HIP_GKR_SUM_FIRST(true, false); }
-                else { if (shape.flat) SP1HIP_GKR_SUM_FIRST(false, true); else SP1HIP_GKR_SUM_FIRST(false, false); }
-#undef SP1HIP_GKR_SUM_FIRST
+            if (sv == 0) break;
+            const int ns = sv == 2 ? 10 : 4;
+            SP1HIP_TRY(rsync.wait(h_sums, 4 * ns));
+            Ext S[10];
+            memcpy(S, h_sums, 16 * (size_t)ns);
+            const Ext pt_a = row_point[t - 1];               // the last unbound variable
+            if (sv == 2) {
+                // S: G00 G10 G01 G11 | Gi0 Gi1 | G0i G1i | Gii | Seq (first index: the last variable). The padding cells carry
+                // F = 1, i.e. their eq mass on the constant coefficient: on the four finite grid points
+                const Ext pt_b = row_point[t - 2];
+                const Ext corr = one - S[9];
+                Ext c0[3], c1[3], ci[3];
+                quadratic(S[0] + corr, S[1] + corr, S[4], c0);             // G(X, 0)
+                quadratic(S[2] + corr, S[3] + corr, S[5], c1);             // G(X, 1)
+                quadratic(S[6], S[7], S[8], ci);                           // leading coefficient in Y
+                Ext h[3];
+                for (int k = 0; k < 3; k++) h[k] = c0[k] + pt_b * (c1[k] - c0[k]);
+                Poly4 poly = eq_times_quadratic(PA, pt_a, h);
+                ro.polys.push_back(poly);
+                for (auto& c : poly) observe_ext(ch, c);
+                a0 = challenger_sample_ext(ch);
+                alphas.push_back(a0);
+                claim = poly_eval(poly, a0);
+                PA = PA * (pt_a * a0 + (one - pt_a) * (one - a0));
+                const Ext g0 = eval_quadratic(c0, a0), g1 = eval_quadratic(c1, a0), gi = eval_quadratic(ci, a0);
+                Ext gy[3];
+                quadratic(g0, g1, gi, gy);                                 // G(a0, Y)
+                poly = eq_times_quadratic(PA, pt_b, gy);
+                ro.polys.push_back(poly);
+                for (auto& c : poly) observe_ext(ch, c);
+                a1 = challenger_sample_ext(ch);
+                alphas.push_back(a1);
+                claim = poly_eval(poly, a1);
+                PA = PA * (pt_b * a1 + (one - pt_b) * (one - a1));
             } else {
-                // fold round j-1 with alpha_r into scratch[cur], summing round j
-                so_next.assign(K + 1, 0);
-                uint32_t max_out = 0;
-                for (uint32_t i = 0; i < K; i++) { const uint32_t o = (live[i] + 1) / 2; so_next[i + 1] = so_next[i] + o; max_out = std::max(max_out, o); }
-                tiles = shape.tiles;
-                ScopedTimer tm("gkr_round_fold_sum", s);
-                const RoundSync rs = chain ? rsync.chained() : rsync.next();
-#define SP1HIP_GKR_FOLD_SUM(F, NB, FL) hipLaunchKernelGGL((round_fold_sum<F, NB, true, FL>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, T_of(t), lambda, alpha_r, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, ca, fa)
-                if (j == 1 && v + 1 == L) { if (shape.flat) SP1HIP_GKR_FOLD_SUM(true, true, true); else SP1HIP_GKR_FOLD_SUM(true, true, false); }
-                else if (j == 1) { if (shape.flat) SP1HIP_GKR_FOLD_SUM(true, false, true); else SP1HIP_GKR_FOLD_SUM(true, false, false); }
-                else { if (shape.flat) SP1HIP_GKR_FOLD_SUM(false, false, true); else SP1HIP_GKR_FOLD_SUM(false, false, false); }
-#undef SP1HIP_GKR_FOLD_SUM
-                for (uint32_t i = 0; i < K; i++) live[i] = (live[i] + 1) / 2;
-                so_prev = so_next;
-                cur ^= 1;
+                // S: G0 G1 | Gi | Seq
+                const Ext corr = one - S[3];
+                Ext h[3];
+                quadratic(S[0] + corr, S[1] + corr, S[2], h);
+                Poly4 poly = eq_times_quadratic(PA, pt_a, h);
+                ro.polys.push_back(poly);
+                for (auto& c : poly) observe_ext(ch, c);
+                a0 = challenger_sample_ext(ch);
+                a1 = zero;
+                alphas.push_back(a0);
+                claim = poly_eval(poly, a0);
+                PA = PA * (pt_a * a0 + (one - pt_a) * (one - a0));
             }
-            SP1HIP_LAUNCH_CHECK();
-            (void)tiles;
-            if (chain) continue;                             // the round finishes itself on the device; the next launch follows
-            SP1HIP_TRY(rsync.wait(h_sums, 12));
-            Ext S0, Sh, Seq;
-            memcpy(&S0, h_sums, 16); memcpy(&Sh, h_sums + 4, 16); memcpy(&Seq, h_sums + 8, 16);
-            const Ext pt = row_point[t - 1];
-            const Ext corr = one - Seq;                      // eq mass of the padding entries (before the PA factor)
-            const Ext p0 = PA * (S0 + corr * (one - pt));
-            const Ext ph = PA * (Sh + corr * four) * inv8;
-            const Ext xs[4] = {kb::ext_zero(), one, inv2, (one - pt) * kb::ext_inv(one - (pt + pt))};
-            const Ext ys[4] = {p0, claim - p0, ph, kb::ext_zero()};
-            poly = interpolate4(xs, ys);
-            ro.polys.push_back(poly);
-            for (auto& c : poly) observe_ext(ch, c);
-            alpha_r = challenger_sample_ext(ch);
-            alphas.push_back(alpha_r);
-            claim = poly_eval(poly, alpha_r);
-            PA = PA * (pt * alpha_r + (one - pt) * (one - alpha_r));
         }
-        // bind the last row variable: one value per (interaction, table), dense over 2^niv on the host
+        // the layer's last fold left one row per interaction: dense over 2^niv on the host, numerators still x lambda
         std::vector<Ext> tn0(W, kb::ext_zero()), td0(W, one), tn1(W, kb::ext_zero()), td1(W, one);
-        par.wake();                                          // their wake-up hides behind the last fold and its hand-over
         {
-            so_next.assign(K + 1, 0);
-            for (uint32_t i = 0; i < K; i++) so_next[i + 1] = so_next[i] + (live[i] + 1) / 2;
-            uint32_t max_out = 0;
-            for (uint32_t i = 0; i < K; i++) max_out = std::max<uint32_t>(max_out, (live[i] + 1) / 2);
-            const LaunchShape shape = shapes[launch_idx];
-            const RoundDesc* d_descs = (const RoundDesc*)d_all.p + (launch_idx++) * K;
-            const uint32_t tiles = shape.tiles;
-            (void)max_out;
-            const GkrChainArgs ca = chain ? GkrChainArgs{(GkrChain*)d_chain.p, nullptr, nullptr, nullptr} : GkrChainArgs{nullptr, nullptr, nullptr, nullptr};
-            if (v == 1 && v + 1 == L) hipLaunchKernelGGL((round_fold_sum<true, true, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca, FlatArgs{nullptr, 0u});
-            else if (v == 1) hipLaunchKernelGGL((round_fold_sum<true, false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca, FlatArgs{nullptr, 0u});
-            else hipLaunchKernelGGL((round_fold_sum<false, false, false, false>), dim3(tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, (const Ext*)nullptr, lambda, alpha_r, d_partials.u32(), RoundSync{}, 0u, K, shape.tile_size, ca, FlatArgs{nullptr, 0u});
-            SP1HIP_LAUNCH_CHECK();
-            if (chain) {
-                // ONE hand-over for the layer's v rounds: the messages, the challenges, the running values and the sponge
-                std::vector<GkrRoundOut> outs(v);
-                GkrChain hc;
-                SP1HIP_TRY(mb.fetch(d_rout.p, sizeof(GkrRoundOut) / 4 * (size_t)v, outs.data()));
-                SP1HIP_TRY(mb.fetch(d_chain.p, sizeof(GkrChain) / 4, &hc));
-                rsync.settled();                                 // every chained launch of this layer has completed
-                for (int j = 0; j < v; j++) {
-                    Poly4 pj;
-                    for (int d = 0; d < 4; d++) pj[d] = outs[j].poly[d];
-                    ro.polys.push_back(pj);
-                    alphas.push_back(outs[j].alpha);
-                }
-                uint32_t w34[34];
-                memcpy(w34, hc.ch_state, 64); memcpy(w34 + 16, hc.ch_in, 32); w34[24] = hc.ch_n_in;
-                memcpy(w34 + 25, hc.ch_out, 32); w34[33] = hc.ch_n_out;
-                challenger_import(ch, w34);
-                claim = hc.claim; PA = hc.PA; alpha_r = hc.alpha;
-            }
-            std::vector<Ext> host(std::max<size_t>(so_next[K], 1) * 4);
-            SP1HIP_TRY(mb.fetch(scratch[cur].p, so_next[K] * 16, host.data()));
+            std::vector<size_t> so(K + 1, 0);
+            for (uint32_t i = 0; i < K; i++) so[i + 1] = so[i] + (rows_at(info[int_chip[i]].rows, v + 1) ? 1 : 0);
+            final_rows_total = so[K];
+            const int cur = (int)((((v + 1) / 2)) & 1) ^ 1;  // folding passes of the layer: ceil(v / 2); they alternate scratch[0], [1], ...
+            std::vector<Ext> host(std::max<size_t>(final_rows_total, 1) * 4);
+            SP1HIP_TRY(mb.fetch(scratch[cur].p, final_rows_total * 16, host.data()));
+            const Ext lambda_inv = kb::ext_inv(lambda);
             for (uint32_t i = 0; i < K; i++) {
-                if (so_next[i + 1] == so_next[i]) continue;   // chip without rows: stays (0, 1)
-                const size_t base = 4 * so_next[i], len = so_next[i + 1] - so_next[i];
-                tn0[i] = host[base]; td0[i] = host[base + len]; tn1[i] = host[base + 2 * len]; td1[i] = host[base + 3 * len];
+                if (so[i + 1] == so[i]) continue;            // chip without rows: stays (0, 1)
+                const size_t base = 4 * so[i];
+                tn0[i] = host[base] * lambda_inv; td0[i] = host[base + 1]; tn1[i] = host[base + 2] * lambda_inv; td1[i] = host[base + 3];
             }
         }
         if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_rows += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
@@ -1167,6 +998,8 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         // which gives the padding entries' share of both sums without visiting them. The sums and the folds of a round
         // run on the helper threads (host_par.hpp); the tables ping-pong because a parallel fold cannot be in place.
         Ext eq_scale = one;
+        Poly4 poly{};
+        Ext alpha_r = zero;
         size_t real = K;                                     // entries >= real are the padding fraction (0, 1) in all four tables
         std::vector<Ext> un0(W / 2 + 1), ud0(W / 2 + 1), un1(W / 2 + 1), ud1(W / 2 + 1);
         std::vector<Ext>*tab[2][4] = {{&tn0, &td0, &tn1, &td1}, {&un0, &ud0, &un1, &ud1}};

@@ -27,17 +27,18 @@ def _dev(api, chips):
     return out
 
 
-@pytest.mark.parametrize("chain", ["0", "1"])      # 1: the row rounds finish on the device (device-resident DuplexChallenger)
 @pytest.mark.parametrize("n_tuples,L,with_empty,dup", [
     (4, 3, False, 2),
     (5, 4, True, 3),
     (1, 1, False, 2),
+    (2, 2, False, 1),          # one layer of one row variable: passes (sum 1), (fold 1)
     (3, 5, False, 1),
-    (37, 7, True, 3),          # odd live counts at several levels
+    (9, 6, True, 2),           # odd and even numbers of row variables per layer: (2,2) / (2,1) / (2,0) / (1,0) passes
+    (37, 7, True, 3),          # odd live counts at several levels: partial grid cells
     (300, 10, True, 3),        # multi-tile rows
+    (1300, 12, True, 3),       # several complete lane-blocked blocks per table
 ])
-def test_gkr_proof_matches_oracle(api, monkeypatch, n_tuples, L, with_empty, dup, chain):
-    monkeypatch.setenv("SP1HIP_GKR_CHAIN", chain)
+def test_gkr_proof_matches_oracle(api, n_tuples, L, with_empty, dup):
     chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
     o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
     seed = orc.random_felts((9,), L)
@@ -54,12 +55,12 @@ def test_gkr_proof_matches_oracle(api, monkeypatch, n_tuples, L, with_empty, dup
     assert point.shape == (L, 4) and [o[0] for o in opened] == [c[0].name for c in chips]
 
 
-@pytest.mark.parametrize("flat_pairs", ["0", "64"])     # 0: every round one workgroup per tile; 64: both forms inside one layer
-@pytest.mark.parametrize("n_tuples,L,with_empty,dup", [(37, 7, True, 3), (300, 10, True, 3)])
-def test_gkr_small_round_forms_give_the_same_bytes(api, monkeypatch, n_tuples, L, with_empty, dup, flat_pairs):
-    """Rounds with few pairs run one pair per lane (SP1HIP_GKR_FLAT_PAIRS, default 65536 — every round of these sizes);
-    forcing the tiled form, or a mix, must not change a byte."""
-    monkeypatch.setenv("SP1HIP_GKR_FLAT_PAIRS", flat_pairs)
+@pytest.mark.parametrize("flat_slots", ["0", "64", "1024"])     # 0: every pass one workgroup per tile; 64 / 1024: both forms inside one layer
+@pytest.mark.parametrize("n_tuples,L,with_empty,dup", [(37, 7, True, 3), (300, 10, True, 3), (1300, 12, True, 3)])
+def test_gkr_small_pass_forms_give_the_same_bytes(api, monkeypatch, n_tuples, L, with_empty, dup, flat_slots):
+    """Passes with few rows run one row per lane of a flat launch (SP1HIP_GKR_FLAT_SLOTS, default 65536 — every pass of
+    these sizes); forcing the tiled form, or a mix, must not change a byte."""
+    monkeypatch.setenv("SP1HIP_GKR_FLAT_SLOTS", flat_slots)
     chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
     o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
     seed = orc.random_felts((9,), L)

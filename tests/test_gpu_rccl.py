@@ -56,7 +56,9 @@ def test_bench_line_through_rccl_at_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--scale-log2", "4",
                         "--no-extras", "--force-dist", "--backend", "nccl"], capture_output=True, text=True, timeout=600, env=_env())
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout:\n" + r.stdout[-2000:]
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["verified"] is True
     assert line["dist"] == {"initialised": True, "backend": "nccl"}
     assert line["host_threads"] >= 1 and line["value"] > 0
