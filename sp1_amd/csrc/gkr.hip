@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void transition_kernel(const TransDesc* __rest
 // out holds, for t = 0 .. v, the partial-Lagrange table of the first t coordinates of `pt` at offset 2^t - 1... i.e.
 // table t occupies [2^t - 1, 2^(t+1) - 1). Thread g -> (t, i).
 struct PointArg { Ext c[32]; };
-__global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int v, Ext* __restrict__ out) {
+// out2 = lambda * out: the sums weigh a row's numerators with lambda T and its denominators with T (gkr_pass), so that
+// lambda costs no product of its own
+__global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int v, Ext lambda, Ext* __restrict__ out, Ext* __restrict__ out2) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x + 1;       // 1 .. 2^(v+1) - 1
     if (g >= (2u << v)) return;
     const int t = 31 - __clz(g);
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int 
         acc = kb::ext_mul(acc, bit ? pt.c[j] : kb::ext_sub(kb::ext_one(), pt.c[j]));
     }
     st_ext(out, g - 1, acc);
+    st_ext(out2, g - 1, kb::ext_mul(acc, lambda));
 }
 
 // ================================================================ sumcheck over the row variables: two rounds per pass
@@ -234,13 +237,14 @@ __global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int 
 // 7 extension products per row (2 to weigh the row, 2 + 1 + 1 + 1 for the grid) against 6.5 for a lane-per-quad split, and
 // lane j's accumulators mean different grid points for different j: they are separated by class (lane mod 4) once, at the
 // end of the kernel, into the 10 sums the host wants.
-// Numerators are kept TIMES LAMBDA in the folded tables (the fold is linear; the host divides the layer's last values by
-// lambda once): F = (w lambda n1) d0 + (w (lambda n0 + d0)) d1 is two products per grid point instead of four.
+// lambda rides on the eq weight: with w = eq weight of the cell and wl = lambda w (a second table, built with the first),
+// F w = (wl n1) d0 + (wl n0 + w d0) d1 is three products per row to form B = wl n1 and A = wl n0 + w d0 and then two per
+// grid point instead of four (and on the top layer, whose numerators are base-field words, wl n is four base products).
 // Padding rows are the constants (0, 1): F = 1 on every padding cell and the cells' eq mass is 1 - (mass of the real cells),
 // as in the one-round kernels (`eq_correction_term`, logup_poly.rs:L521-L530).
 struct PassDesc {
-    const void* src[4];        // FIRST: {level N, level D, -, -} (row r = entries 2r, 2r+1); else {n0, d0, n1, d1}, numerators x lambda
-    Ext* dst[4];               // folded n0, d0, n1, d1 (numerators x lambda)
+    const void* src[4];        // FIRST: {level N, level D, -, -} (row r = entries 2r, 2r+1); else {n0, d0, n1, d1}
+    Ext* dst[4];               // folded n0, d0, n1, d1
     uint32_t rows_in;          // real rows of the layer before this pass folds (FIRST: ceil(rows_x / 2))
     uint32_t rows_x;           // FIRST only: real entries of the level
     uint32_t eq_int_index;     // global interaction index
@@ -294,6 +298,17 @@ __device__ __forceinline__ Ext lerp(const Ext& a, const Ext& b, const Ext& t) { 
 __device__ __forceinline__ Row lerp_row(const Row& a, const Row& b, const Ext& t) {
     return Row{lerp(a.n0, b.n0, t), lerp(a.d0, b.d0, t), lerp(a.n1, b.n1, t), lerp(a.d1, b.d1, t)};
 }
+// the same when the numerators are base-field words (coordinate 0 only): a + t (b - a) is four base products
+__device__ __forceinline__ Ext lerp_base(uint32_t a, uint32_t b, const Ext& t) {
+    Ext e = kb::ext_mul_base(t, kb::sub(b, a));
+    e.c[0] = kb::add(e.c[0], a);
+    return e;
+}
+template <bool NBASE>
+__device__ __forceinline__ Row lerp_row_in(const Row& a, const Row& b, const Ext& t) {
+    if (!NBASE) return lerp_row(a, b, t);
+    return Row{lerp_base(a.n0.c[0], b.n0.c[0], t), lerp(a.d0, b.d0, t), lerp_base(a.n1.c[0], b.n1.c[0], t), lerp(a.d1, b.d1, t)};
+}
 
 // output row `ro` of a pass that binds FV variables: rows ro 2^FV .. of the input folded with a0 (last variable), then a1
 template <int FV, bool FIRST, bool NBASE>
@@ -303,9 +318,9 @@ __device__ __forceinline__ Row fold_row(const PassDesc& d, uint32_t ro, const Ex
     // every load of the row is issued before the first use: one exposed memory latency per row
 #pragma unroll
     for (int j = 0; j < (1 << FV); j++) in[j] = load_row<FIRST, NBASE>(d, (ro << FV) + j);
-    if constexpr (FV == 1) return lerp_row(in[0], in[1], a0);
+    if constexpr (FV == 1) return lerp_row_in<NBASE>(in[0], in[1], a0);
     else {
-        const Row lo = lerp_row(in[0], in[1], a0), hi = lerp_row(in[2], in[3], a0);
+        const Row lo = lerp_row_in<NBASE>(in[0], in[1], a0), hi = lerp_row_in<NBASE>(in[2], in[3], a0);
         return lerp_row(lo, hi, a1);
     }
 }
@@ -326,11 +341,12 @@ __device__ __forceinline__ void grid_init(GridAcc<SV>& g) {
     for (int i = 0; i < (SV == 2 ? 5 : 3); i++) g.a[i] = kb::ext_zero();
 }
 
-// row = this lane's (folded, numerators x lambda) row; w = eq weight of its cell (zero for lanes past the last real cell);
-// j = lane's position inside the cell. ALL lanes of the cell must be active.
-template <int SV>
-__device__ __forceinline__ void grid_accumulate(const Row& row, const Ext& w, uint32_t j, GridAcc<SV>& g) {
-    const Ext A = kb::ext_mul(kb::ext_add(row.n0, row.d0), w), B = kb::ext_mul(row.n1, w);
+// row = this lane's (folded) row; w = eq weight of its cell (zero for lanes past the last real cell), wl = lambda w;
+// j = lane's position inside the cell. ALL lanes of the cell must be active. NB: the numerators are base-field words.
+template <int SV, bool NB>
+__device__ __forceinline__ void grid_accumulate(const Row& row, const Ext& w, const Ext& wl, uint32_t j, GridAcc<SV>& g) {
+    const Ext A = kb::ext_add(NB ? kb::ext_mul_base(wl, row.n0.c[0]) : kb::ext_mul(row.n0, wl), kb::ext_mul(row.d0, w));
+    const Ext B = NB ? kb::ext_mul_base(wl, row.n1.c[0]) : kb::ext_mul(row.n1, wl);
     g.a[0] = kb::ext_add(g.a[0], kb::ext_add(kb::ext_mul(B, row.d0), kb::ext_mul(A, row.d1)));       // the pure point of this lane
     // difference over the last variable (lanes j ^ 1): the even lane takes B d0, the odd lane A d1 — so every lane KEEPS one
     // pair of operands and SENDS the other pair, the one its partner works on
@@ -383,10 +399,10 @@ struct FlatArgs { const uint16_t* index; uint32_t total_slots; };
 
 // One pass: bind FV variables (fold rows ro 2^FV .. with a0, a1 and store row ro; FV = 0: read only), then accumulate the
 // grid of the next SV rounds (SV = 0: the layer's last fold, nothing to sum). T = partial-Lagrange table of the row
-// variables that remain after those SV rounds.
+// variables that remain after those SV rounds, TL = lambda T.
 template <int FV, int SV, bool FIRST, bool NBASE, bool FLAT>
 __global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
-                                                const Ext* __restrict__ T, Ext lambda, Ext a0, Ext a1,
+                                                const Ext* __restrict__ T, const Ext* __restrict__ TL, Ext a0, Ext a1,
                                                 uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq, uint32_t K,
                                                 uint32_t tile_size, FlatArgs fa) {
     static_assert(FV + SV > 0 && FV <= 2 && SV <= 2, "a pass folds and / or sums");
@@ -395,14 +411,12 @@ __global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ des
     grid_init<SVS>(g);
     const uint32_t j = threadIdx.x & ((1u << SV) - 1u);
     // one row: fold, store, weigh, accumulate. valid = the lane has a slot; rows past rows_out inside a real cell are padding
+    // (a padding row's numerators are zero: also as base words)
     auto do_row = [&](const PassDesc& d, uint32_t ro, bool valid, const Ext& wi, bool use_wi) {
         const uint32_t rows_out = (d.rows_in + (1u << FV) - 1u) >> FV;
         Row row = padding_row();
         if (valid && ro < rows_out) {
             row = fold_row<FV, FIRST, NBASE>(d, ro, a0, a1);
-            if (FIRST && NBASE && FV == 0) {                 // base-field numerators read as they are: lambda n is 4 products, not 16
-                row.n0 = kb::ext_mul_base(lambda, row.n0.c[0]); row.n1 = kb::ext_mul_base(lambda, row.n1.c[0]);
-            } else if (FIRST) { row.n0 = kb::ext_mul(row.n0, lambda); row.n1 = kb::ext_mul(row.n1, lambda); }
             if (FV > 0) {
                 const uint32_t rq = folded_pos(ro, rows_out);
                 st_ext(d.dst[0], rq, row.n0); st_ext(d.dst[1], rq, row.d0); st_ext(d.dst[2], rq, row.n1); st_ext(d.dst[3], rq, row.d1);
@@ -411,9 +425,12 @@ __global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ des
         if constexpr (SV > 0) {
             const uint32_t cells = (rows_out + (1u << SV) - 1u) >> SV;
             const uint32_t c = ro >> SV;
-            Ext w = kb::ext_zero();
-            if (valid && c < cells) { w = ld_ext(T, c); if (use_wi) w = kb::ext_mul(w, wi); }
-            grid_accumulate<SVS>(row, w, j, g);
+            Ext w = kb::ext_zero(), wl = kb::ext_zero();
+            if (valid && c < cells) {
+                w = ld_ext(T, c); wl = ld_ext(TL, c);
+                if (use_wi) { w = kb::ext_mul(w, wi); wl = kb::ext_mul(wl, wi); }
+            }
+            grid_accumulate<SVS, FIRST && NBASE && FV == 0>(row, w, wl, j, g);
         }
     };
     Ext scale = kb::ext_one();
@@ -754,9 +771,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     // ---- GKR rounds, layer v = 1 .. L-1 (reads level v + 1)
     struct RoundOut { Ext n0, n1, d0, d1; std::vector<Poly4> polys; Ext claimed_sum, eval; std::vector<Ext> point; };
     std::vector<RoundOut> rounds;
-    DeviceBuf d_eq_int, d_T, d_partials, scratch[2];
+    DeviceBuf d_eq_int, d_T, d_TL, d_partials, scratch[2];
     SP1HIP_TRY(d_eq_int.alloc((size_t)W * 16, s));
     SP1HIP_TRY(d_T.alloc(((size_t)2 << std::max(L - 1, 1)) * 16, s));
+    SP1HIP_TRY(d_TL.alloc(((size_t)2 << std::max(L - 1, 1)) * 16, s));
     // folded tables: 4 vectors per interaction, at most ceil(rows(level v+1) / 4) entries each after the first fold
     size_t scratch_entries = 0;
     for (uint32_t i = 0; i < K; i++) scratch_entries += (rows_at(info[int_chip[i]].rows, L) + 3) / 4 + 1;
@@ -890,9 +908,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         SP1HIP_TRY(stage.upload(d_eq_int.p, eq_int.data(), (size_t)W * 16));
         PointArg pa{};
         for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
-        hipLaunchKernelGGL(eq_prefix_tables_kernel, dim3(((2u << v) + 255) / 256), dim3(256), 0, s, pa, v, d_T.ext());
+        hipLaunchKernelGGL(eq_prefix_tables_kernel, dim3(((2u << v) + 255) / 256), dim3(256), 0, s, pa, v, lambda, d_T.ext(), d_TL.ext());
         SP1HIP_LAUNCH_CHECK();
         auto T_of = [&](int t) -> const Ext* { return d_T.ext() + (((size_t)1 << t) - 1); };
+        auto TL_of = [&](int t) -> const Ext* { return d_TL.ext() + (((size_t)1 << t) - 1); };
 
         std::vector<Ext> alphas;
         Ext PA = one;                                        // eq factor of the row variables bound so far
@@ -909,9 +928,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             if (sv == 0) par.wake();                         // the helpers' wake-up hides behind the last fold and its hand-over
             const RoundSync rs = sv > 0 ? rsync.next() : RoundSync{};
             const Ext* Tp = sv > 0 ? T_of(t - sv) : (const Ext*)nullptr;
+            const Ext* TLp = sv > 0 ? TL_of(t - sv) : (const Ext*)nullptr;
             {
                 ScopedTimer tm(fv == 0 ? "gkr_pass_sum" : sv == 0 ? "gkr_pass_fold" : "gkr_pass_fold_sum", s);
-#define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, lambda, a0, a1, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, fa)
+#define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, TLp, a0, a1, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, fa)
 #define SP1HIP_GKR_PASS_FL(FV, SV, F, NB) do { if (shape.flat) SP1HIP_GKR_PASS(FV, SV, F, NB, true); else SP1HIP_GKR_PASS(FV, SV, F, NB, false); } while (0)
 #define SP1HIP_GKR_PASS_SRC(FV, SV) do { if (nbase) SP1HIP_GKR_PASS_FL(FV, SV, true, true); else if (shape.first) SP1HIP_GKR_PASS_FL(FV, SV, true, false); else SP1HIP_GKR_PASS_FL(FV, SV, false, false); } while (0)
                 if (fv == 0 && sv == 2) { if (nbase) SP1HIP_GKR_PASS_FL(0, 2, true, true); else SP1HIP_GKR_PASS_FL(0, 2, true, false); }
@@ -975,7 +995,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 PA = PA * (pt_a * a0 + (one - pt_a) * (one - a0));
             }
         }
-        // the layer's last fold left one row per interaction: dense over 2^niv on the host, numerators still x lambda
+        // the layer's last fold left one row per interaction: dense over 2^niv on the host
         std::vector<Ext> tn0(W, kb::ext_zero()), td0(W, one), tn1(W, kb::ext_zero()), td1(W, one);
         {
             std::vector<size_t> so(K + 1, 0);
@@ -984,11 +1004,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             const int cur = (int)((((v + 1) / 2)) & 1) ^ 1;  // folding passes of the layer: ceil(v / 2); they alternate scratch[0], [1], ...
             std::vector<Ext> host(std::max<size_t>(final_rows_total, 1) * 4);
             SP1HIP_TRY(mb.fetch(scratch[cur].p, final_rows_total * 16, host.data()));
-            const Ext lambda_inv = kb::ext_inv(lambda);
             for (uint32_t i = 0; i < K; i++) {
                 if (so[i + 1] == so[i]) continue;            // chip without rows: stays (0, 1)
                 const size_t base = 4 * so[i];
-                tn0[i] = host[base] * lambda_inv; td0[i] = host[base + 1]; tn1[i] = host[base + 2] * lambda_inv; td1[i] = host[base + 3];
+                tn0[i] = host[base]; td0[i] = host[base + 1]; tn1[i] = host[base + 2]; td1[i] = host[base + 3];
             }
         }
         if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_rows += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
