@@ -181,6 +181,74 @@ def real_machine(api, repeat=4):
             "verified": verify_proof("recursion", proof, commit, ch.state(), L, lsh)}
 
 
+class GpuSampler:
+    """Clock / power of GPU 0 from sysfs while a phase runs (amdgpu hwmon: power1_average or power1_input in microwatts,
+    freq1_input = sclk in Hz): whether several provers in flight run into the package's power management
+     is answered by these samples next to the per-proof times, not by a guess."""
+
+    def __init__(self, period=0.05):
+        import glob
+        self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
+        self.power = next(iter(sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
+                                      glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))), None)
+        self.freq = next(iter(sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))), None)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def __enter__(self):
+        def run():
+            while not self._stop.is_set():
+                self.samples.append((self._read(self.power), self._read(self.freq)))
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thread.join()
+
+    def summary(self):
+        def stats(xs, scale):
+            xs = [x * scale for x in xs if x is not None]
+            return {"mean": sum(xs) / len(xs), "min": min(xs), "max": max(xs)} if xs else None
+        return {"samples": len(self.samples), "power_w": stats([p for p, _ in self.samples], 1e-6),
+                "sclk_mhz": stats([f for _, f in self.samples], 1e-6)}
+
+
+def in_flight(api, chips, area, L, lsh, n_proofs):
+    """The library's prover pool with 1, 2 and 3 slots on the SAME resident shard: throughput with N proofs in flight, the
+    per-proof proving times in completion order, and the GPU's clock / power while each phase runs. Proofs are checked
+    against `sp1hip_prove_shard_with_pk` called directly."""
+    import torch
+    prep_tables = [c[3] for c in chips if c[3] is not None]
+    pk = api.ProvingKey(prep_tables, L, lsh, 32)
+    want = pk.prove_shard(chips, [])
+    torch.cuda.synchronize()
+    out = {"proofs_per_phase": n_proofs, "slots": {}}
+    for n in (1, 2, 3):
+        pool = api.ProverPool(n)
+        for t in [pool.submit(pk, chips) for _ in range(n)]:          # fill every slot's arena
+            assert pool.wait(t)[0] == want, "a pool proof differs from the direct one"
+        torch.cuda.synchronize()
+        with GpuSampler() as smp:
+            t0 = time.perf_counter()
+            tickets = [pool.submit(pk, chips) for _ in range(n_proofs)]
+            res = [pool.wait(t) for t in tickets]
+            dt = time.perf_counter() - t0
+        pool.close()
+        assert all(r[0] == want for r in res), "a pool proof differs from the direct one"
+        out["slots"][str(n)] = {"ms_per_proof": 1e3 * dt / n_proofs, "proofs_per_s": n_proofs / dt, "cells_per_s": n_proofs * area / dt,
+                                "proving_ms_each": [round(r[1]["proving_ms"], 1) for r in res], "gpu": smp.summary()}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,38 +351,9 @@ def main():
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:      # untimed extras; N > 1 runs measure scaling only
-        # (a) two provers in flight on one GPU (two host threads, two streams): the sumcheck rounds of one proof fill the
-        #     transcript round trips of the other; same inputs, byte-identical proofs
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        for s in streams:
-            with torch.cuda.stream(s):
-                step(s)                                                          # fill each stream's arena
-        torch.cuda.synchronize()
-        n_each = max(2, args.steps // 2)
-        bad = []
-        per_proof = {id(s): [] for s in streams}
-
-        def worker(s):
-            for _ in range(n_each):
-                tp = time.perf_counter()
-                with torch.cuda.stream(s):
-                    if step(s) != proof:
-                        bad.append(1)
-                per_proof[id(s)].append(round(1e3 * (time.perf_counter() - tp), 1))
-
-        t1 = time.perf_counter()
-        threads = [threading.Thread(target=worker, args=(s,)) for s in streams]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        assert not bad, "a concurrently produced proof differs from the sequential one"
-        if os.environ.get("SP1HIP_BENCH_DEBUG"):
-            print("two_in_flight per-proof ms:", list(per_proof.values()), file=sys.stderr)
-        extras["two_in_flight"] = {"proofs": 2 * n_each, "ms_per_proof": 1e3 * dt2 / (2 * n_each), "cells_per_s": 2 * n_each * area / dt2,
-                                   "proofs_per_s": 2 * n_each / dt2}
+        # (a) 1, 2, 3 proofs in flight on one GPU through the library's prover pool (sp1hip_pool_*): the sumcheck rounds
+        #     of one proof fill the transcript round trips of the others; same inputs, byte-identical proofs
+        extras["in_flight"] = in_flight(api, chips, area, L, lsh, max(4, args.steps))
         # (b) the commit phase alone (BASELINE config 2's stage: RS encode + Poseidon2 Merkle of the main traces)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -323,7 +362,6 @@ def main():
             del sd
         torch.cuda.synchronize()
         extras["commit_only"] = {"ms": 1e3 * (time.perf_counter() - t1) / 3, "cells": sum(c[2].height * c[2].width for c in chips)}
-        del streams
         extras["real_machine"] = real_machine(api)
         if not args.no_cpu_baseline:
             extras["cpu_baseline"] = cpu_baseline(api, max(args.cpu_sample_scale_log2, k))
@@ -412,7 +450,8 @@ def main():
             "host_threads": lib.sp1hip_host_threads(),
             "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},
             "real_machine": extras.get("real_machine"),
-            "two_in_flight": extras.get("two_in_flight"),
+            "in_flight": extras.get("in_flight"),
+            "value_pipelined": max((v["cells_per_s"] for v in extras["in_flight"]["slots"].values()), default=None) if extras.get("in_flight") else None,
             "commit_only": extras.get("commit_only"),
         }
         result_out.write(json.dumps(out) + "\n")

@@ -443,6 +443,56 @@ int sp1hip_prove_shard_with_pk(const sp1hip_pk_t* pk, const sp1hip_shard_chip_t*
                                int n_publics, const uint32_t* pow_witnesses, int n_pow_witnesses, uint8_t* h_proof, size_t* proof_len,
                                sp1hip_stream_t stream);
 
+/* ---------------------------------------------------------------- prover pool: N shard proofs in flight per GPU
+ * The library-side counterpart of the reference's `ProverSemaphore`
+ * (/root/reference/crates/hypercube/src/prover/permits.rs:L36-L66; its GPU worker builder takes ONE permit,
+ * /root/reference/sp1-gpu/crates/prover_components/src/builder.rs:L107) plus the pinned `trace_buffers` queue of its shard
+ * prover: `n_slots` prover slots (a host thread + a stream each) prove shards concurrently and fill each other's
+ * transcript hand-over gaps, while one stager thread uploads the host traces of the next shards
+ * (`sp1hip_stage_tables`). Tickets are served in submission order. */
+typedef struct sp1hip_pool_s sp1hip_pool_t;
+typedef uint64_t sp1hip_ticket_t;
+
+/* One chip of a shard for the pool: sp1hip_shard_chip_t with the main trace EITHER on the host (`h_main`: row-major
+ * [real_rows][main_width] Montgomery words — pinned memory for a full-rate asynchronous copy — which the pool stages into
+ * a column-major device table it owns) OR already resident (`d_main`, column-major). `d_prep`: the chip's preprocessed
+ * device table (the one the proving key was set up from), or NULL. Everything the struct points to stays caller-owned and
+ * must remain valid and unchanged until the ticket has been waited for. */
+typedef struct {
+    const char* name;
+    const uint32_t* program;
+    uint32_t n_instr, num_constraints;
+    const uint32_t* interactions;
+    uint32_t n_words;
+    uint32_t main_width, prep_width;
+    const uint32_t* h_main;
+    const uint32_t* d_main;
+    const uint32_t* d_prep;
+    uint64_t real_rows;
+} sp1hip_pool_chip_t;
+
+/* Where a ticket spent its time (milliseconds) and which slot proved it. */
+typedef struct {
+    double staging_ms;  /* submit -> host traces enqueued for upload (includes waiting for a staging buffer) */
+    double queued_ms;   /* staged -> a prover slot took it */
+    double proving_ms;  /* sp1hip_prove_shard_with_pk on the slot's stream */
+    int slot;
+} sp1hip_pool_times_t;
+
+int sp1hip_pool_create(int device, int n_slots, sp1hip_pool_t** out);
+/* Finishes every submitted shard, then stops the threads and destroys the streams. */
+void sp1hip_pool_destroy(sp1hip_pool_t* pool);
+/* Queue one shard: `AirProver::prove_shard_with_pk` (/root/reference/crates/hypercube/src/prover/shard.rs:L321-L345) from
+ * the generated traces on. Returns at once. */
+int sp1hip_pool_submit(sp1hip_pool_t* pool, const sp1hip_pk_t* pk, const sp1hip_pool_chip_t* chips, int n_chips,
+                       const uint32_t* h_publics, int n_publics, sp1hip_ticket_t* ticket);
+/* Block until the ticket's proof exists and copy bincode(ShardProof) out (size protocol as sp1hip_prove_shard:
+ * SP1HIP_ERROR_BUFFER_TOO_SMALL sets *proof_len and leaves the ticket claimable). A failed proof returns its status and
+ * message here. `times` may be NULL. A ticket can be collected once. */
+int sp1hip_pool_wait(sp1hip_pool_t* pool, sp1hip_ticket_t ticket, uint8_t* h_proof, size_t* proof_len, sp1hip_pool_times_t* times);
+/* The same without blocking: SP1HIP_ERROR_NOT_READY while the shard is in flight. */
+int sp1hip_pool_try_wait(sp1hip_pool_t* pool, sp1hip_ticket_t ticket, uint8_t* h_proof, size_t* proof_len, sp1hip_pool_times_t* times);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,17 @@ class ShardChip(C.Structure):
                 ("real_rows", C.c_uint64)]
 
 
+class PoolChip(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("program", C.POINTER(C.c_uint32)), ("n_instr", C.c_uint32),
+                ("num_constraints", C.c_uint32), ("interactions", C.POINTER(C.c_uint32)), ("n_words", C.c_uint32),
+                ("main_width", C.c_uint32), ("prep_width", C.c_uint32), ("h_main", C.c_void_p), ("d_main", C.c_void_p),
+                ("d_prep", C.c_void_p), ("real_rows", C.c_uint64)]
+
+
+class PoolTimes(C.Structure):
+    _fields_ = [("staging_ms", C.c_double), ("queued_ms", C.c_double), ("proving_ms", C.c_double), ("slot", C.c_int)]
+
+
 class ShardParams(C.Structure):
     _fields_ = [("max_log_row_count", C.c_int), ("log_stacking_height", C.c_int), ("batch_size", C.c_int),
                 ("fri", FriConfig)]
@@ -64,7 +75,7 @@ class Vk(C.Structure):
 
 
 # status codes of include/sp1hip.h
-SUCCESS, ERROR_INVALID_ARGUMENT, ERROR_BUFFER_TOO_SMALL = 0, -1, -6
+SUCCESS, ERROR_INVALID_ARGUMENT, ERROR_NOT_READY, ERROR_BUFFER_TOO_SMALL = 0, -1, -3, -6
 
 
 class Sp1HipError(RuntimeError):
@@ -169,6 +180,11 @@ PROTOTYPES = [
     ("sp1hip_prove_shard_with_pk", None, [_vp, C.POINTER(ShardChip), _int, u32p, _int, u32p, _int, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
                                       _vp, u8p, C.POINTER(_sz), _vp]),
+    ("sp1hip_pool_create", None, [_int, _int, C.POINTER(_vp)]),
+    ("sp1hip_pool_destroy", "void", [_vp]),
+    ("sp1hip_pool_submit", None, [_vp, _vp, C.POINTER(PoolChip), _int, u32p, _int, C.POINTER(C.c_uint64)]),
+    ("sp1hip_pool_wait", None, [_vp, C.c_uint64, u8p, C.POINTER(_sz), C.POINTER(PoolTimes)]),
+    ("sp1hip_pool_try_wait", None, [_vp, C.c_uint64, u8p, C.POINTER(_sz), C.POINTER(PoolTimes)]),
     ("sp1hip_zerocheck_plan_eval", None, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.c_uint32, _int, u32p,
                                           C.c_uint32, u32p]),
 ]

@@ -574,6 +574,89 @@ class ProvingKey:
             self.h = None
 
 
+class PinnedHost:
+    """Pinned host words (sp1hip_malloc_host) holding one row-major table: what a host trace generator fills and
+    `ProverPool.submit` uploads at full PCIe rate."""
+
+    def __init__(self, table):
+        table = np.ascontiguousarray(table, dtype=np.uint32)
+        self.shape = table.shape
+        p = C.c_void_p()
+        check(_L().sp1hip_malloc_host(C.byref(p), max(table.nbytes, 4)))
+        self.ptr = p
+        if table.nbytes:
+            C.memmove(p, table.ctypes.data, table.nbytes)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            _L().sp1hip_free_host(self.ptr)
+            self.ptr = None
+
+
+class ProverPool:
+    """N shard proofs in flight on one GPU (sp1hip_pool_*): `n_slots` prover slots (thread + stream each) plus a stager
+    that uploads host traces of the next shards while the slots prove — the library-side `ProverSemaphore`."""
+
+    def __init__(self, n_slots, device=None):
+        import torch
+        h = C.c_void_p()
+        check(_L().sp1hip_pool_create(torch.cuda.current_device() if device is None else int(device), int(n_slots), C.byref(h)))
+        self.h, self.n_slots, self._keep = h, int(n_slots), {}
+
+    def submit(self, pk, chips, public_values=()):
+        """chips: [(AirProgram, InteractionProgram, main, prep)] in name order; main is a ColMajor (resident in HBM), a
+        PinnedHost (row-major host words the pool stages) or None; prep: the ColMajor the proving key was set up from."""
+        arr = (_lib.PoolChip * len(chips))()
+        keep = [chips, pk]
+        for i, (air, inter, main, prep) in enumerate(chips):
+            prog = np.ascontiguousarray(air.to_array(), dtype=np.uint32)
+            words = np.ascontiguousarray(inter.to_array(), dtype=np.uint32)
+            keep += [prog, words]
+            if isinstance(main, PinnedHost):
+                rows, h_main, d_main = main.shape[0], main.ptr, None
+            else:
+                rows = main.height if main is not None else 0
+                h_main, d_main = None, (C.c_void_p(main.words.data_ptr()) if rows else None)
+            arr[i] = _lib.PoolChip(inter.name.encode(), prog.ctypes.data_as(_lib.u32p), prog.shape[0], air.num_constraints,
+                                   words.ctypes.data_as(_lib.u32p), words.size, air.main_width, air.prep_width, h_main, d_main,
+                                   C.c_void_p(prep.words.data_ptr()) if prep is not None and rows and air.prep_width else None, rows)
+        pv = np.ascontiguousarray(np.asarray(public_values, dtype=np.uint32).reshape(-1))
+        keep += [arr, pv]
+        t = C.c_uint64()
+        check(_L().sp1hip_pool_submit(self.h, pk.h, arr, len(chips), pv.ctypes.data_as(_lib.u32p) if pv.size else None, int(pv.size),
+                                      C.byref(t)))
+        self._keep[t.value] = keep
+        return t.value
+
+    def wait(self, ticket, block=True):
+        """-> (bincode(ShardProof), {"staging_ms", "queued_ms", "proving_ms", "slot"}); block=False returns None while the
+        shard is in flight."""
+        fn = _L().sp1hip_pool_wait if block else _L().sp1hip_pool_try_wait
+        n, times = C.c_size_t(0), _lib.PoolTimes()
+        st = fn(self.h, ticket, None, C.byref(n), C.byref(times))
+        if st == _lib.ERROR_NOT_READY:
+            return None
+        if st != _lib.ERROR_BUFFER_TOO_SMALL:
+            self._keep.pop(ticket, None)
+            check(st)
+            raise RuntimeError("size query unexpectedly succeeded")
+        buf = (C.c_uint8 * n.value)()
+        st = fn(self.h, ticket, buf, C.byref(n), C.byref(times))
+        self._keep.pop(ticket, None)
+        check(st)
+        return C.string_at(buf, n.value), {"staging_ms": times.staging_ms, "queued_ms": times.queued_ms,
+                                           "proving_ms": times.proving_ms, "slot": times.slot}
+
+    def close(self):
+        if getattr(self, "h", None):
+            _L().sp1hip_pool_destroy(self.h)
+            self.h = None
+            self._keep.clear()
+
+    def __del__(self):
+        self.close()
+
+
 def parse_logup_gkr_proof(blob):
     """The `logup_evaluations` of a bincode(LogupGkrProof): (point [L][4], [(name, main [w][4], prep [w][4] or None)])
     in Montgomery words — the zeta / openings that zerocheck consumes."""
