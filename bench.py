@@ -189,9 +189,19 @@ class GpuSampler:
     def __init__(self, period=0.05):
         import glob
         self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
-        self.power = next(iter(sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") +
-                                      glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))), None)
-        self.freq = next(iter(sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))), None)
+        # the box has several GPUs in sysfs and one visible to HIP: pick the hwmon of OUR device by its PCI address
+        base = "/sys/class/drm/card*/device"
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            if os.path.isdir("/sys/bus/pci/devices/" + addr):
+                base = "/sys/bus/pci/devices/" + addr
+        except Exception:
+            addr = None
+        self.device = addr
+        self.power = next(iter(sorted(glob.glob(base + "/hwmon/hwmon*/power1_average") + glob.glob(base + "/hwmon/hwmon*/power1_input"))), None)
+        self.freq = next(iter(sorted(glob.glob(base + "/hwmon/hwmon*/freq1_input"))), None)
 
     @staticmethod
     def _read(path):
@@ -218,7 +228,7 @@ class GpuSampler:
         def stats(xs, scale):
             xs = [x * scale for x in xs if x is not None]
             return {"mean": sum(xs) / len(xs), "min": min(xs), "max": max(xs)} if xs else None
-        return {"samples": len(self.samples), "power_w": stats([p for p, _ in self.samples], 1e-6),
+        return {"pci": self.device, "samples": len(self.samples), "power_w": stats([p for p, _ in self.samples], 1e-6),
                 "sclk_mhz": stats([f for _, f in self.samples], 1e-6)}
 
 
@@ -233,6 +243,8 @@ def in_flight(api, chips, area, L, lsh, n_proofs):
     torch.cuda.synchronize()
     out = {"proofs_per_phase": n_proofs, "slots": {}}
     for n in (1, 2, 3):
+        released = C.c_size_t()
+        api.check(api._L().sp1hip_mem_trim(C.byref(released)))       # every phase starts from an empty arena and refills it in its warm-up
         pool = api.ProverPool(n)
         for t in [pool.submit(pk, chips) for _ in range(n)]:          # fill every slot's arena
             assert pool.wait(t)[0] == want, "a pool proof differs from the direct one"

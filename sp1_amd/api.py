@@ -570,7 +570,10 @@ class ProvingKey:
 
     def __del__(self):
         if getattr(self, "h", None):
-            _L().sp1hip_pk_free(self.h)
+            try:
+                _L().sp1hip_pk_free(self.h)
+            except TypeError:                    # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
 

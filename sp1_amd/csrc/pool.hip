@@ -234,9 +234,12 @@ void sp1hip_pool_destroy(sp1hip_pool_t* pool) {
     int prev = 0;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(pool->device);
+    // the slots' scratch (a core shard proof cycles ~34 GB per stream) is keyed by stream in the arena: give it back, a
+    // destroyed stream can never reuse it
     (void)hipStreamSynchronize(pool->stage_stream);
+    (void)arena_release_stream(pool->stage_stream);
     (void)hipStreamDestroy(pool->stage_stream);
-    for (hipStream_t s : pool->slot_streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipStream_t s : pool->slot_streams) { (void)hipStreamSynchronize(s); (void)arena_release_stream(s); (void)hipStreamDestroy(s); }
     (void)hipSetDevice(prev);
     delete pool;
 }

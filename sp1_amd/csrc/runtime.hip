@@ -114,7 +114,7 @@ static size_t arena_round(size_t bytes) {
     return ((bytes + step - 1) / step) * step;
 }
 // cached (free-listed) bytes above this are handed back to the driver, largest blocks first: SP1HIP_ARENA_CAP_GB, default
-// half of the device's memory (144 GB on an MI355X). A core-shaped shard proof cycles ~34 GB of scratch per stream; with
+// three quarters of the device's memory (216 GB on an MI355X: three provers in flight cache ~100 GB next to the caller's own stream). A core-shaped shard proof cycles ~34 GB of scratch per stream; with
 // two provers in flight plus the blocks an earlier stream left behind, a 64 GB cap was crossed at the end of every proof
 // and each crossing costs hipFree (a device synchronise) now and hipMalloc on the next proof — 234 ms per proof instead
 // of ~85 whenever both provers' blocks met in the free lists.
@@ -131,7 +131,7 @@ static size_t arena_cap_bytes(int dev) {
     } else {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); cap = (size_t)64 << 30; }
-        else cap = total_b / 2;
+        else cap = total_b / 4 * 3;
     }
     caps[dev] = cap;
     return cap;
@@ -187,6 +187,26 @@ void arena_free(void* ptr, size_t bytes, hipStream_t stream) {
         }
     }
     for (void* p : evict) (void)hipFree(p);
+}
+
+// A stream that is about to be destroyed (a prover pool's slot): its cached blocks can never be reused — hand them back.
+// The caller has synchronised the stream.
+size_t arena_release_stream(hipStream_t stream) {
+    std::vector<std::pair<void*, size_t>> blocks;
+    {
+        std::lock_guard<std::mutex> lock(g_arena_mutex);
+        for (auto it = g_arena.begin(); it != g_arena.end();) {
+            if (it->first.stream == stream) {
+                for (void* p : it->second) { blocks.emplace_back(p, it->first.bytes); g_arena_cached_bytes[it->first.device] -= it->first.bytes; }
+                it = g_arena.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    size_t freed = 0;
+    for (auto& b : blocks) { (void)hipFree(b.first); freed += b.second; }
+    return freed;
 }
 
 size_t arena_trim() {
