@@ -106,21 +106,15 @@ static inline int gkr_beta_seed_dim(const std::vector<GkrChip>& chips) {
     return log2_ceil(arity);
 }
 
-// one GKR round on dense tables; tables are indexed idx = interaction * 2^v + row (row LSB = last variable)
-static inline GkrRoundProof gkr_round_dense(std::vector<E> n0, std::vector<E> d0, std::vector<E> n1, std::vector<E> d1,
-                                            const std::vector<E>& eval_point, const E& num_eval, const E& den_eval, Challenger& ch) {
-    const E lambda = ch.sample_ext();
-    std::vector<E> eq = partial_lagrange(eval_point);
-    GkrRoundProof rp;
-    E claim = num_eval * lambda + den_eval;
-    rp.sumcheck.claimed_sum = claim;
-    const size_t nv = eval_point.size();
+// the rounds of a dense degree-3 sumcheck of sum_x eq[x] (lambda (n0 d1 + n1 d0) + d0 d1)[x] over 2^|pts| entries, binding the
+// LAST variable first; pts[r] = coordinate of the variable round r binds (the root of the eq factor needs it). eq carries
+// every factor already bound. Tables and claim are updated in place; messages / challenges are appended.
+static inline void gkr_dense_rounds(std::vector<E>& n0, std::vector<E>& d0, std::vector<E>& n1, std::vector<E>& d1, std::vector<E>& eq,
+                                    const std::vector<E>& pts, const E& lambda, E& claim, Challenger& ch, std::vector<UniPoly>& polys,
+                                    std::vector<E>& alphas) {
     const E one = E::one(), two = E::from_base(F::two());
     const E inv2 = einv(two), inv8 = einv(E::from_base(F::from_canonical(8)));
-    std::vector<E> alphas;
-    UniPoly uni;
-    E alpha = E::zero();
-    for (size_t r = 0; r < nv; r++) {
+    for (size_t r = 0; r < pts.size(); r++) {
         const size_t half = eq.size() / 2;
         E p0 = E::zero(), ph = E::zero();
 #pragma omp parallel
@@ -137,18 +131,31 @@ static inline GkrRoundProof gkr_round_dense(std::vector<E> n0, std::vector<E> d0
             { p0 += l0; ph += lh; }
         }
         ph = ph * inv8;
-        const E pt = eval_point[nv - 1 - r];
+        const E pt = pts[r];
         const E b_const = (one - pt) * einv(one - (pt + pt));
-        uni = interpolate_univariate({E::zero(), one, inv2, b_const}, {p0, claim - p0, ph, E::zero()});
+        UniPoly uni = interpolate_univariate({E::zero(), one, inv2, b_const}, {p0, claim - p0, ph, E::zero()});
         for (auto& c : uni) ch.observe_ext(c);
-        rp.sumcheck.polys.push_back(uni);
-        alpha = ch.sample_ext();
+        polys.push_back(uni);
+        const E alpha = ch.sample_ext();
         alphas.push_back(alpha);
         claim = uni_eval(uni, alpha);
         n0 = fix_last_variable(n0, alpha); d0 = fix_last_variable(d0, alpha);
         n1 = fix_last_variable(n1, alpha); d1 = fix_last_variable(d1, alpha);
         eq = fix_last_variable(eq, alpha);
     }
+}
+
+// one GKR round on dense tables; tables are indexed idx = interaction * 2^v + row (row LSB = last variable)
+static inline GkrRoundProof gkr_round_dense(std::vector<E> n0, std::vector<E> d0, std::vector<E> n1, std::vector<E> d1,
+                                            const std::vector<E>& eval_point, const E& num_eval, const E& den_eval, Challenger& ch) {
+    const E lambda = ch.sample_ext();
+    std::vector<E> eq = partial_lagrange(eval_point);
+    GkrRoundProof rp;
+    E claim = num_eval * lambda + den_eval;
+    rp.sumcheck.claimed_sum = claim;
+    std::vector<E> alphas;
+    const std::vector<E> pts(eval_point.rbegin(), eval_point.rend());
+    gkr_dense_rounds(n0, d0, n1, d1, eq, pts, lambda, claim, ch, rp.sumcheck.polys, alphas);
     rp.sumcheck.eval = claim;
     rp.sumcheck.point.assign(alphas.rbegin(), alphas.rend());
     rp.numerator_0 = n0[0]; rp.denominator_0 = d0[0]; rp.numerator_1 = n1[0]; rp.denominator_1 = d1[0];
@@ -257,6 +264,185 @@ static inline GkrProof gkr_prove(const std::vector<GkrChip>& chips, int L, Chall
         }
         ch.observe(F::from_canonical((uint32_t)c.main_width));
         for (auto& e : proof.main_evals.back()) ch.observe_ext(e);
+    }
+    return proof;
+}
+
+// ---- the same prover on REAL rows only (jagged-aware), for CPU timing at sizes the dense formulation cannot reach.
+// This is the shape of the reference's CPU prover: every chip's layer lives over its real rows
+// (/root/reference/crates/hypercube/src/logup_gkr/execution.rs:L112-L382: `generate_first_layer`, `layer_transition` on
+// PaddedMle's) and the padding rows — the constant fraction (0, 1) — enter the round polynomial in closed form
+// (`eq_correction_term`, logup_poly.rs:L521-L530). The dense prover above wastes a factor 2^L / rows on a scaled-down shard
+// (1000x at 1 / 4096 of a core shard) and made the CPU baseline meaningless. Same field elements:
+// tests/test_oracle_gkr.py checks the two provers byte for byte. The once-per-layer interaction-variable rounds run on the
+// dense 2^niv-entry tables through gkr_dense_rounds.
+static inline GkrProof gkr_prove_sparse(const std::vector<GkrChip>& chips, int L, Challenger& ch) {
+    GkrProof proof;
+    const int beta_seed_dim = gkr_beta_seed_dim(chips);
+    proof.witness = ch.grind(GKR_GRINDING_BITS);
+    const E alpha = ch.sample_ext();
+    const std::vector<E> beta_seed = sample_point(ch, beta_seed_dim);
+    (void)ch.sample_ext();                                   // _pv_challenge
+    const std::vector<E> betas = partial_lagrange(beta_seed);
+    struct Ref { const GkrChip* chip; const GkrInteraction* in; };
+    std::vector<Ref> ints;
+    for (auto& c : chips) for (auto& i : c.interactions) ints.push_back(Ref{&c, &i});
+    const size_t K = ints.size();
+    const int niv = log2_ceil(K);
+    const size_t W = (size_t)1 << niv;
+    const E one = E::one(), zero = E::zero();
+    auto rows_at = [&](size_t h, int l) -> size_t { return (h + (((size_t)1 << (L - l)) - 1)) >> (L - l); };
+
+    // levels L .. 1 over real rows: lv[l][i] = (N, D) vectors of interaction i
+    std::vector<std::vector<std::vector<E>>> lvN(L + 1, std::vector<std::vector<E>>(K)), lvD(L + 1, std::vector<std::vector<E>>(K));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t i = 0; i < K; i++) {
+        const GkrChip& c = *ints[i].chip;
+        std::vector<E>& n = lvN[L][i];
+        std::vector<E>& d = lvD[L][i];
+        n.resize(c.real_rows); d.resize(c.real_rows);
+        for (size_t r = 0; r < c.real_rows; r++) {
+            F m;
+            interaction_vals(*ints[i].in, c.prep ? c.prep + r * c.prep_width : nullptr, c.main + r * c.main_width, alpha, betas, &m, &d[r]);
+            n[r] = E::from_base(m);
+        }
+        for (int l = L - 1; l >= 1; l--) {
+            const std::vector<E>&un = lvN[l + 1][i], &ud = lvD[l + 1][i];
+            const size_t ro = (un.size() + 1) / 2;
+            lvN[l][i].resize(ro); lvD[l][i].resize(ro);
+            for (size_t r = 0; r < ro; r++) {
+                if (2 * r + 1 < un.size()) {
+                    lvN[l][i][r] = ud[2 * r + 1] * un[2 * r] + ud[2 * r] * un[2 * r + 1];
+                    lvD[l][i][r] = ud[2 * r] * ud[2 * r + 1];
+                } else { lvN[l][i][r] = un[2 * r]; lvD[l][i][r] = ud[2 * r]; }          // partner is a padding row (0, 1)
+            }
+        }
+    }
+    proof.numerator.assign(2 * W, zero); proof.denominator.assign(2 * W, one);
+    for (size_t i = 0; i < K; i++)
+        for (size_t r = 0; r < lvN[1][i].size(); r++) { proof.numerator[2 * i + r] = lvN[1][i][r]; proof.denominator[2 * i + r] = lvD[1][i][r]; }
+    ch.observe(F::from_canonical((uint32_t)proof.numerator.size()));
+    for (auto& e : proof.numerator) ch.observe_ext(e);
+    ch.observe(F::from_canonical((uint32_t)proof.denominator.size()));
+    for (auto& e : proof.denominator) ch.observe_ext(e);
+    std::vector<E> eval_point = sample_point(ch, niv + 1);
+    E num_eval = eval_ext_mle_at_point(proof.numerator, eval_point), den_eval = eval_ext_mle_at_point(proof.denominator, eval_point);
+    const E inv2 = einv(E::from_base(F::two())), inv8 = einv(E::from_base(F::from_canonical(8))), four = E::from_base(F::from_canonical(4));
+    (void)rows_at;
+
+    for (int v = 1; v <= L - 1; v++) {
+        const E lambda = ch.sample_ext();
+        GkrRoundProof rp;
+        E claim = num_eval * lambda + den_eval;
+        rp.sumcheck.claimed_sum = claim;
+        const std::vector<E> int_point(eval_point.begin(), eval_point.begin() + niv), row_point(eval_point.begin() + niv, eval_point.end());
+        const std::vector<E> eq_int = partial_lagrange(int_point);
+        // the layer's four tables over real rows: row r = entries 2r, 2r + 1 of level v + 1
+        std::vector<std::vector<E>> t[4];
+        for (int w = 0; w < 4; w++) t[w].resize(K);
+        for (size_t i = 0; i < K; i++) {
+            const std::vector<E>&un = lvN[v + 1][i], &ud = lvD[v + 1][i];
+            const size_t live = (un.size() + 1) / 2;
+            for (int w = 0; w < 4; w++) t[w][i].resize(live);
+            for (size_t r = 0; r < live; r++) {
+                t[0][i][r] = un[2 * r]; t[1][i][r] = ud[2 * r];
+                const bool has = 2 * r + 1 < un.size();
+                t[2][i][r] = has ? un[2 * r + 1] : zero; t[3][i][r] = has ? ud[2 * r + 1] : one;
+            }
+        }
+        std::vector<E> alphas;
+        E PA = one;                                          // eq factor of the row variables bound so far
+        for (int j = 0; j < v; j++) {
+            const int tt = v - j;                            // remaining row variables
+            const std::vector<E> T = partial_lagrange(std::vector<E>(row_point.begin(), row_point.begin() + tt));
+            E S0 = zero, Sh = zero, Seq = zero;
+#pragma omp parallel
+            {
+                E l0 = zero, lh = zero, le = zero;
+#pragma omp for schedule(dynamic, 4) nowait
+                for (size_t i = 0; i < K; i++) {
+                    const size_t live = t[0][i].size(), pairs = (live + 1) / 2;
+                    E a0 = zero, ah = zero, ae = zero;
+                    for (size_t k = 0; k < pairs; k++) {
+                        const size_t a = 2 * k, b = 2 * k + 1;
+                        const bool hb = b < live;
+                        const E n0a = t[0][i][a], d0a = t[1][i][a], n1a = t[2][i][a], d1a = t[3][i][a];
+                        const E n0b = hb ? t[0][i][b] : zero, d0b = hb ? t[1][i][b] : one, n1b = hb ? t[2][i][b] : zero, d1b = hb ? t[3][i][b] : one;
+                        a0 += T[a] * (lambda * (n0a * d1a + n1a * d0a) + d0a * d1a);
+                        const E sn0 = n0a + n0b, sn1 = n1a + n1b, sd0 = d0a + d0b, sd1 = d1a + d1b, ts = T[a] + T[b];
+                        ah += ts * (lambda * (sn0 * sd1 + sn1 * sd0) + sd0 * sd1);
+                        ae += ts;
+                    }
+                    l0 += eq_int[i] * a0; lh += eq_int[i] * ah; le += eq_int[i] * ae;
+                }
+#pragma omp critical
+                { S0 += l0; Sh += lh; Seq += le; }
+            }
+            const E pt = row_point[tt - 1];
+            const E corr = one - Seq;                        // eq mass of the all-padding pairs (F = 1 there)
+            const E p0 = PA * (S0 + corr * (one - pt));
+            const E ph = PA * (Sh + corr * four) * inv8;
+            const E b_const = (one - pt) * einv(one - (pt + pt));
+            UniPoly uni = interpolate_univariate({zero, one, inv2, b_const}, {p0, claim - p0, ph, zero});
+            for (auto& c : uni) ch.observe_ext(c);
+            rp.sumcheck.polys.push_back(uni);
+            const E ar = ch.sample_ext();
+            alphas.push_back(ar);
+            claim = uni_eval(uni, ar);
+            PA = PA * (pt * ar + (one - pt) * (one - ar));
+#pragma omp parallel for schedule(dynamic, 4)
+            for (size_t i = 0; i < K; i++) {
+                const size_t live = t[0][i].size(), ro = (live + 1) / 2;
+                for (int w = 0; w < 4; w++) {
+                    std::vector<E>& x = t[w][i];
+                    const E pad = (w & 1) ? one : zero;
+                    for (size_t r = 0; r < ro; r++) {
+                        const E lo = x[2 * r], hi = 2 * r + 1 < live ? x[2 * r + 1] : pad;
+                        x[r] = lo + ar * (hi - lo);
+                    }
+                    x.resize(ro);
+                }
+            }
+        }
+        // interaction-variable rounds on the dense 2^niv tables (padding interactions = (0, 1))
+        std::vector<E> n0(W, zero), d0(W, one), n1(W, zero), d1(W, one), eq(W);
+        for (size_t i = 0; i < K; i++)
+            if (!t[0][i].empty()) { n0[i] = t[0][i][0]; d0[i] = t[1][i][0]; n1[i] = t[2][i][0]; d1[i] = t[3][i][0]; }
+        for (size_t i = 0; i < W; i++) eq[i] = eq_int[i] * PA;
+        const std::vector<E> pts(int_point.rbegin(), int_point.rend());
+        gkr_dense_rounds(n0, d0, n1, d1, eq, pts, lambda, claim, ch, rp.sumcheck.polys, alphas);
+        rp.sumcheck.eval = claim;
+        rp.sumcheck.point.assign(alphas.rbegin(), alphas.rend());
+        rp.numerator_0 = n0[0]; rp.denominator_0 = d0[0]; rp.numerator_1 = n1[0]; rp.denominator_1 = d1[0];
+        ch.observe_ext(rp.numerator_0); ch.observe_ext(rp.numerator_1);
+        ch.observe_ext(rp.denominator_0); ch.observe_ext(rp.denominator_1);
+        eval_point = rp.sumcheck.point;
+        const E lc = ch.sample_ext();
+        num_eval = rp.numerator_0 + (rp.numerator_1 - rp.numerator_0) * lc;
+        den_eval = rp.denominator_0 + (rp.denominator_1 - rp.denominator_0) * lc;
+        eval_point.push_back(lc);
+        proof.rounds.push_back(std::move(rp));
+    }
+    proof.point = last_k(eval_point, L);
+    const std::vector<E> eq = partial_lagrange(proof.point);
+    ch.observe(F::from_canonical((uint32_t)chips.size()));
+    proof.main_evals.resize(chips.size()); proof.prep_evals.resize(chips.size());
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t k = 0; k < chips.size(); k++) {
+        const GkrChip& c = chips[k];
+        proof.main_evals[k] = padded_column_evals(c.main, c.real_rows, c.main_width, L, eq);
+        proof.prep_evals[k] = c.prep_width > 0 ? padded_column_evals(c.prep, c.real_rows, c.prep_width, L, eq) : std::vector<E>();
+    }
+    for (size_t k = 0; k < chips.size(); k++) {
+        const GkrChip& c = chips[k];
+        proof.chip_names.push_back(c.name);
+        proof.has_prep.push_back(c.prep_width > 0);
+        if (c.prep_width > 0) {
+            ch.observe(F::from_canonical((uint32_t)c.prep_width));
+            for (auto& e : proof.prep_evals[k]) ch.observe_ext(e);
+        }
+        ch.observe(F::from_canonical((uint32_t)c.main_width));
+        for (auto& e : proof.main_evals[k]) ch.observe_ext(e);
     }
     return proof;
 }

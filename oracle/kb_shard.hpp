@@ -9,6 +9,7 @@
 // (tests/golden: its own bytes, BaseFold queries trimmed to 12) and accepts everything that does not need the
 // recursion machine's chip definitions, ending in the exact transcript state; see tests/test_oracle_golden.py.
 #pragma once
+#include <chrono>
 #include "kb_gkr.hpp"
 
 namespace orc {
@@ -133,9 +134,16 @@ static inline std::vector<GkrChip> gkr_chips_of(const std::vector<ShardChip>& ch
 
 // prove_shard_with_data. `prep_round`: the preprocessed commitment round of the proving key (JaggedRoundData of
 // the chips' preprocessed traces, committed at setup). The challenger has already absorbed the verifying key.
+// wall seconds of the last shard_prove on this thread: commit, LogUp-GKR, zerocheck, jagged evaluation proof (CPU baseline)
+static thread_local double g_stage_seconds[4] = {0, 0, 0, 0};
+// 1: LogUp-GKR over real rows only (gkr_prove_sparse: the reference's CPU shape); 0: the dense, independent formulation
+static int g_gkr_sparse = 0;
+
 static inline ShardProof shard_prove(const std::vector<ShardChip>& chips, const std::vector<F>& publics,
                                      const JaggedRoundData& prep_round, const ShardParams& sp, Challenger& ch) {
     const int L = sp.max_log_row_count;
+    auto t_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = t_now();
     ShardProof proof;
     proof.public_values = publics;
     for (auto& x : publics) ch.observe(x);
@@ -150,7 +158,9 @@ static inline ShardProof shard_prove(const std::vector<ShardChip>& chips, const 
         ch.observe(F::from_canonical((uint32_t)c.name.size()));
         for (char b : c.name) ch.observe(F::from_canonical((uint8_t)b));
     }
-    proof.gkr = gkr_prove(gkr_chips_of(chips), L, ch);
+    g_stage_seconds[0] = t_now() - t0; t0 = t_now();
+    proof.gkr = g_gkr_sparse ? gkr_prove_sparse(gkr_chips_of(chips), L, ch) : gkr_prove(gkr_chips_of(chips), L, ch);
+    g_stage_seconds[1] = t_now() - t0; t0 = t_now();
     const E batching = ch.sample_ext(), gkr_batch = ch.sample_ext();
     std::vector<ZcChipInput> zc(chips.size());
     for (size_t k = 0; k < chips.size(); k++) {
@@ -159,6 +169,7 @@ static inline ShardProof shard_prove(const std::vector<ShardChip>& chips, const 
         zc[k].prep_opening = proof.gkr.prep_evals[k];
     }
     proof.zerocheck = zerocheck_prove(zc, L, proof.gkr.point, batching, gkr_batch, publics, ch);
+    g_stage_seconds[2] = t_now() - t0; t0 = t_now();
     std::vector<E> prep_claims, main_claims;
     for (size_t k = 0; k < chips.size(); k++) {
         const auto& ev = proof.zerocheck.chip_evals[k];
@@ -172,6 +183,7 @@ static inline ShardProof shard_prove(const std::vector<ShardChip>& chips, const 
     proof.degree_bits = L + 1;
     proof.evaluation = jagged_prove(proof.zerocheck.point, {prep_claims, main_claims}, {prep_round, main_round}, L,
                                     sp.log_stacking_height, sp.fri, ch);
+    g_stage_seconds[3] = t_now() - t0;
     return proof;
 }
 

@@ -453,7 +453,7 @@ size_t orc_gkr_prove(int n_chips, const char** names, const uint32_t** progs, co
                      const uint32_t** mains, const uint32_t** preps, const uint64_t* rows, int L, void* challenger, uint8_t* out,
                      size_t cap) {
     std::vector<GkrChip> chips = make_gkr_chips(n_chips, names, progs, main_w, prep_w, mains, preps, rows);
-    GkrProof p = gkr_prove(chips, L, *static_cast<Challenger*>(challenger));
+    GkrProof p = g_gkr_sparse ? gkr_prove_sparse(chips, L, *static_cast<Challenger*>(challenger)) : gkr_prove(chips, L, *static_cast<Challenger*>(challenger));
     std::vector<uint8_t> b = serialize_gkr_proof(p);
     if (b.size() <= cap) memcpy(out, b.data(), b.size());
     return b.size();
@@ -510,6 +510,11 @@ size_t orc_shard_prove(int n, const char** names, const uint32_t** zc_progs, con
     if (b.size() <= cap) memcpy(out, b.data(), b.size());
     return b.size();
 }
+
+// CPU-baseline aids: choose the LogUp-GKR formulation of orc_shard_prove / orc_gkr_prove and read the stage times of the
+// calling thread's last orc_shard_prove (commit, LogUp-GKR, zerocheck, jagged evaluation proof)
+void orc_set_gkr_sparse(int on) { g_gkr_sparse = on; }
+void orc_stage_seconds(double* out4) { for (int k = 0; k < 4; k++) out4[k] = g_stage_seconds[k]; }
 
 // with_chips == 0: n may be 0; everything chip-independent is checked (the reference's real proof)
 int orc_shard_verify(int n, const char** names, const uint32_t** zc_progs, const int* zc_lens, const int* main_w, const int* prep_w,

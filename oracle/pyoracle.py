@@ -93,6 +93,8 @@ def lib():
                                       C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
         L.orc_shard_verify.argtypes = [C.c_int, cpp, C.POINTER(u32p), ip, ip, ip, ip, C.POINTER(u32p), u32p, C.POINTER(C.c_uint8),
                                        C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_stage_seconds.argtypes = [C.POINTER(C.c_double)]
+        L.orc_set_gkr_sparse.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -580,17 +582,36 @@ def _shard_chip_args(chips):
     return n, g[1], zc_ptrs, zc_lens, g[3], g[4], nc, g[2], g[5], g[6], g[7], (airs, g[8])
 
 
-def shard_prove(chips, publics, prep_round, L, lsh, batch, challenger, log_blowup=2, num_queries=124, pow_bits=16):
+def shard_prove(chips, publics, prep_round, L, lsh, batch, challenger, log_blowup=2, num_queries=124, pow_bits=16, capacity=None):
     """ShardProver::prove_shard_with_data -> bincode(ShardProof). prep_round: JaggedRound of the preprocessed traces."""
     n, names, zc, zl, mw, pw, nc, gk, mains, preps, rows, keep = _shard_chip_args(chips)
     pv = _arr(publics).reshape(-1)
     args = (n, names, zc, zl, mw, pw, nc, gk, mains, preps, rows, _p(pv) if pv.size else None, int(pv.size), prep_round.h, L,
             lsh, C.c_size_t(batch), log_blowup, num_queries, pow_bits)
+    if capacity:                                             # ONE pass (the CPU baseline times this): a buffer that is surely large enough
+        buf = (C.c_uint8 * capacity)()
+        size = lib().orc_shard_prove(*args, challenger.h, buf, capacity)
+        if size > capacity:
+            raise ValueError("shard proof needs %d bytes" % size)
+        return bytes(buf[:size]) if size < (1 << 16) else C.string_at(buf, size)
     scratch = challenger.clone()
     size = lib().orc_shard_prove(*args, scratch.h, None, 0)
     buf = (C.c_uint8 * size)()
     lib().orc_shard_prove(*args, challenger.h, buf, size)
     return bytes(buf)
+
+
+def set_gkr_sparse(on):
+    """LogUp-GKR formulation of shard_prove / gkr_prove: False = dense (independent of the GPU algorithm, small sizes only),
+    True = real rows + closed-form padding (the reference's CPU shape; what the CPU baseline times)."""
+    lib().orc_set_gkr_sparse(1 if on else 0)
+
+
+def stage_seconds():
+    """Wall seconds of the calling thread's last shard_prove: {commit, logup_gkr, zerocheck, evaluation_proof}."""
+    out = (C.c_double * 4)()
+    lib().orc_stage_seconds(out)
+    return dict(zip(("commit", "logup_gkr", "zerocheck", "evaluation_proof"), list(out)))
 
 
 def shard_verify(chips, prep_commit, blob, L, lsh, challenger, log_blowup=2, num_queries=124, pow_bits=16):

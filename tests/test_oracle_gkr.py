@@ -43,3 +43,25 @@ def test_gkr_rejects_unbalanced_interactions():
     v = ch.clone()
     blob = orc.gkr_prove(chips, 3, ch)
     assert orc.gkr_verify(chips, [c[1].shape[0] for c in chips], 3, blob, v) == 4     # cumulative sum != 0
+
+
+@pytest.mark.parametrize("n_tuples,L,with_empty,dup", [
+    (4, 3, False, 2), (5, 4, True, 3), (1, 1, False, 2), (2, 2, False, 1), (3, 5, False, 1), (9, 6, True, 2), (37, 7, True, 3),
+    (300, 10, True, 3),
+])
+def test_jagged_aware_prover_equals_the_dense_one(n_tuples, L, with_empty, dup):
+    """gkr_prove_sparse (real rows + closed-form padding: the reference's CPU shape, what bench.py's cpu_baseline times)
+    writes the same bytes and leaves the same transcript as the dense formulation."""
+    chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
+    a, b = orc.Challenger(), orc.Challenger()
+    seed = orc.random_felts((9,), L)
+    a.observe(seed)
+    b.observe(seed)
+    dense = orc.gkr_prove(chips, L, a)
+    try:
+        orc.set_gkr_sparse(True)
+        sparse = orc.gkr_prove(chips, L, b)
+    finally:
+        orc.set_gkr_sparse(False)
+    assert sparse == dense
+    assert np.array_equal(a.state(), b.state())
