@@ -31,6 +31,7 @@
 #include "device_ctx.hpp"
 #include "round_sync.hpp"
 #include "zc_device.hpp"
+#include "zc_jit.hpp"
 
 namespace sp1hip {
 
@@ -463,12 +464,25 @@ struct ZcPlan {                      // everything that depends on a chip's prog
     std::vector<uint32_t> prog;      // allocated [n][4], whole program (padded-row evaluation)
     uint32_t n_regs = 1;
     std::vector<Chunk> chunks, mono, fine;
+    std::vector<uint32_t> sched;     // the scheduled SSA the forms above were cut from (what the compiled kernel is generated from)
+    // its compiled kernel (zc_jit.hpp), requested by the first PROOF that uses the plan (the host-only planner checks never
+    // start a compiler); nullptr: not eligible
+    mutable std::mutex jit_m;
+    mutable bool jit_asked = false;
+    mutable std::shared_ptr<ZcJitKernel> jit;
+    ZcJitKernel* compiled() const {
+        if (!zc_jit_enabled()) return nullptr;
+        std::lock_guard<std::mutex> lk(jit_m);
+        if (!jit_asked) { jit = zc_jit_request(sched.data(), (uint32_t)(sched.size() / 3), main_w, prep_w); jit_asked = true; }
+        return jit.get();
+    }
 };
 
 struct ChipState {
     const sp1hip_zc_chip_t* in;
     std::vector<uint32_t> prog;     // allocated [n][4]
     uint32_t n_regs = 1;
+    ZcJitKernel* jit = nullptr;     // compiled kernel of the chip's program (owned by the cached plan)
     std::vector<Ext> alpha_pows, gkr_pows;
     std::vector<Chunk> chunks;         // split at assert boundaries (parallel across constraints: the small rounds)
     std::vector<uint32_t> chunk_off;   // offset (in instructions) of each chunk inside d_prog
@@ -949,6 +963,7 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         static const uint32_t chunk_hard = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_HARD_MAX"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 8u) : ZC_CHUNK_HARD_MAX; }();
         SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, chunk_limit, &np->chunks, chunk_hard));
         SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT));
+        np->sched = sched;
         plan = np;
         std::lock_guard<std::mutex> lk(plan_mutex);
         if (plan_cache.size() > 4096) plan_cache.clear();
@@ -1091,6 +1106,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             std::shared_ptr<const ZcPlan> plan;
             SP1HIP_TRY(zc_get_plan(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, i, &plan));
             c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono; c->fine = plan->fine;
+            c->jit = plan->compiled();                // found on disk, or queued for the background compiler (the plan cache keeps it alive)
         }
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
@@ -1193,9 +1209,21 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<Group> groups;
         static const bool mono_enabled = [] { const char* e = getenv("SP1HIP_ZC_MONO"); return !(e && e[0] == '0'); }();
         std::vector<char> use_mono(n_chips, 0);
+        // chips whose COMPILED kernel is ready run it while the round is large (zc_jit.hpp): one workgroup evaluates the
+        // three nodes of its row pairs with no decode; everything else goes through the interpreter groups below
+        struct JitLaunch { hipFunction_t fn; int chip; uint32_t desc_index, n_blocks; };
+        std::vector<JitLaunch> jit_launches;
+        std::vector<char> use_jit(n_chips, 0);
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
-            if (c.rows == 0) continue;
+            if (c.rows == 0 || !c.jit || (c.rows + 1) / 2 < ZC_JIT_MIN_TERMS) continue;
+            hipFunction_t fn = nullptr;
+            SP1HIP_TRY(zc_jit_function(c.jit, r == 0, &fn));
+            if (fn) { use_jit[i] = 1; jit_launches.push_back(JitLaunch{fn, i, 0, 0}); }
+        }
+        for (int i = 0; i < n_chips; i++) {
+            ChipState& c = *st[i];
+            if (c.rows == 0 || use_jit[i]) continue;
             const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
             uint32_t mono_regs = 1;
             for (auto& ck : c.mono) mono_regs = std::max(mono_regs, ck.n_regs);
@@ -1264,6 +1292,21 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             g.n_blocks = total_blocks - g.block_lo;
         }
+        for (JitLaunch& jl : jit_launches) {                 // one descriptor and one block range per compiled chip
+            ChipState& c = *st[jl.chip];
+            const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
+            ZcDesc d{};
+            d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+            d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
+            d.block_start = total_blocks; d.n_blocks = std::min<uint32_t>((terms + 255) / 256, 4096u);
+            d.flags = 1u; d.block_pairs = 256;
+            jl.desc_index = (uint32_t)descs.size();
+            jl.n_blocks = d.n_blocks;
+            total_blocks += d.n_blocks;
+            descs.push_back(d);
+            ranges.push_back(ZcChipRange{d.block_start, d.n_blocks, terms - 1, 0});
+            desc_chip.push_back(jl.chip);
+        }
         const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
         // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
         // it now, so that every descriptor of the round goes up in ONE copy
@@ -1326,6 +1369,16 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 const bool fused = fuse_enabled && g.n_blocks >= 4096;
                 if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
                 else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+            }
+            for (const JitLaunch& jl : jit_launches) {
+                const ZcDesc* a_descs = (const ZcDesc*)d_descs.p;
+                uint32_t a_index = jl.desc_index, a_eq_len = 1u << (nv - 1);
+                const uint32_t* a_eq = d_eq.u32();
+                const uint32_t* a_pub = d_publics.u32();
+                uint32_t* a_partial = d_partial.u32();
+                void* args[] = {&a_descs, &a_index, &a_eq, &a_eq_len, &a_pub, &a_partial};
+                SP1HIP_HIP(hipModuleLaunchKernel(jl.fn, jl.n_blocks, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+                g_zc_jit_launches.fetch_add(1, std::memory_order_relaxed);
             }
             if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
@@ -1516,6 +1569,33 @@ extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_in
     }
     for (uint32_t k = 0; k < n_constraints; k++) SP1HIP_REQUIRE(seen[k] == 1, "a constraint was not evaluated exactly once");
     if (out_stats) { out_stats[0] = words; out_stats[1] = pieces; out_stats[2] = regs; }
+    return SP1HIP_SUCCESS;
+}
+
+// Host-only: the HIP source of the compiled kernels of `program` (planned as the prover plans it) and the hash its code
+// object is cached under. Size protocol: *len = capacity on entry, needed size (with the terminating NUL) on return.
+extern "C" int sp1hip_zerocheck_codegen(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width,
+                                        char* out, size_t* len, uint64_t* hash) {
+    SP1HIP_REQUIRE((program || n_instr == 0) && len, "null argument");
+    for (uint32_t k = 0; k < n_instr; k++) {
+        const uint32_t op = program[3 * k], a = program[3 * k + 1];
+        SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO, "bad opcode in constraint program");
+        if (op == ZC_LOAD_MAIN) SP1HIP_REQUIRE(a < main_width, "main column out of range");
+        if (op == ZC_LOAD_PREP) SP1HIP_REQUIRE(a < prep_width, "preprocessed column out of range");
+    }
+    std::shared_ptr<const ZcPlan> plan;
+    SP1HIP_TRY(zc_get_plan(program, n_instr, main_width, prep_width, -1, &plan));
+    const uint32_t n = (uint32_t)(plan->sched.size() / 3);
+    if (hash) *hash = zc_jit_hash(plan->sched.data(), n, main_width, prep_width);
+    const std::string src = zc_codegen(plan->sched.data(), n, main_width, prep_width);
+    const size_t need = src.size() + 1;
+    if (!out || *len < need) {
+        *len = need;
+        set_error("sp1hip_zerocheck_codegen: buffer too small, need %zu bytes", need);
+        return SP1HIP_ERROR_BUFFER_TOO_SMALL;
+    }
+    memcpy(out, src.c_str(), need);
+    *len = need;
     return SP1HIP_SUCCESS;
 }
 
