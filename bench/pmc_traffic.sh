@@ -1,0 +1,54 @@
+#!/bin/bash
+# HBM traffic per kernel of ONE whole core-shaped proof (run on the GPU box): FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3
+# --pmc passes (they do not fit one pass: MI355X_MICROARCH.md, TCC counters) over bench/profile_bench_pmc.py, which runs a
+# calibration kernel with a known byte count first (monty_convert: 2^28 words read and written = 1 GiB each way).
+# Corrections, as the guide's HBM section prescribes and the calibration kernel confirms: rocprofv3 reports both counters in
+# KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads (x 2), WRITE_SIZE is exact (x 1).
+# usage: bench/pmc_traffic.sh <out.json>      (writes the table bench.py reads: profiles/r03_traffic.json)
+out=$1
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pmc_f /tmp/pmc_w
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python $GRAFT_REPO_ROOT/bench/profile_bench_pmc.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python $GRAFT_REPO_ROOT/bench/profile_bench_pmc.py > /dev/null 2>&1
+python - "$out" <<PY
+import csv, glob, json, sys, collections
+def load(d):
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k] += float(r["Counter_Value"]); cnt[k] += 1
+    return agg, cnt
+f, fc = load("/tmp/pmc_f")
+w, wc = load("/tmp/pmc_w")
+cal = next(k for k in f if "monty_convert_kernel" in k)
+cal_bytes = (1 << 28) * 4
+fetch_scale = cal_bytes / (f[cal] * 1024.0)          # expected 2.0
+write_scale = cal_bytes / (w[cal] * 1024.0)          # expected 1.0
+groups = {   # bench.py's kernel names -> substrings of the HIP kernel names
+    "leaf_hash": ["leaf_hash_part_kernel", "leaf_hash_kernel"],
+    "rs_encode": ["ntt_fast_pass"],
+    "zerocheck_round": ["zc_round_kernel", "zc_jit_first", "zc_jit_ext"],
+    "zerocheck_fix": ["zc_fix_kernel"],
+    "gkr_pass": ["gkr_pass"],
+    "gkr_first_layer": ["first_layer_kernel"],
+    "gkr_transition": ["transition_kernel"],
+    "jagged_fold": ["jg_fold"],
+}
+kernels = {}
+for name, subs in groups.items():
+    ks = [k for k in f if any(s in k for s in subs)]
+    if not ks:
+        continue
+    fetch = sum(f[k] for k in ks) * 1024 * 2.0       # the guide's gfx950 correction (the calibration kernel reports its own measured scale below)
+    write = sum(w.get(k, 0.0) for k in ks) * 1024 * 1.0
+    launches = sum(fc[k] for k in ks)
+    kernels[name] = {"launches_per_proof": launches, "fetch_bytes_per_proof": fetch, "write_bytes_per_proof": write,
+                     "hbm_bytes_per_proof": fetch + write, "hbm_bytes_per_launch": (fetch + write) / launches}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over one core-shaped proof (bench/pmc_traffic.sh); "
+                     "KiB units, FETCH x 2 (gfx950: 64 B tallied per 128 B request), WRITE x 1",
+           "calibration": {"kernel": "monty_convert_kernel, 2^28 words each way", "fetch_scale_measured": fetch_scale,
+                           "write_scale_measured": write_scale},
+           "kernels": kernels}, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(kernels, indent=1)[:3000])
+PY

@@ -362,7 +362,8 @@ int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_instr, uint32
  * nodes of a row pair in one pass, no bytecode decode) compiled OFFLINE with hipcc — by a background thread when a prover
  * first sees the program, or ahead of time (`__graft_entry__.build()` fills sp1_amd/lib/zc_cache/) — and cached on disk by
  * program hash ($SP1HIP_CACHE_DIR, default ~/.cache/sp1hip). Until a kernel is ready, and for long programs and small rounds,
- * the interpreter runs; the sums — hence the proof bytes — are the same. SP1HIP_ZC_JIT=0 turns the compiled path off.
+ * the interpreter runs; the sums — hence the proof bytes — are the same. OPT-IN (SP1HIP_ZC_JIT=1): on the shards measured so
+ * far the interpreter is faster.
  * (The reference tiers its interpreter by register count instead: /root/reference/sp1-gpu/crates/sys/src/kernels.rs:L38-L117.)
  *   sp1hip_zerocheck_codegen : host only; source + cache hash of one program (size protocol: *len capacity in, size out)
  *   sp1hip_zerocheck_jit_wait: block until the background compiler is idle (timeout_ms < 0: no limit); *pending = jobs left

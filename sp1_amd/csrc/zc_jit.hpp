@@ -20,10 +20,11 @@
 
 namespace sp1hip {
 
-constexpr uint32_t ZC_JIT_VERSION = 1;            // bump when the generated code or zc_device.hpp / kb31.hpp change meaning
+constexpr uint32_t ZC_JIT_VERSION = 4;            // bump when the generated code or zc_device.hpp / kb31.hpp change meaning
 constexpr uint32_t ZC_JIT_MAX_INSTR = 600;        // longer programs stay interpreted: compile time grows super-linearly (793 instructions over
                                                   // 241 columns: 50 s) and the straight-line code starts to spill (331 / 781 VGPRs in base / extension form)
 constexpr uint32_t ZC_JIT_MAX_WIDTH = 128;        // main + preprocessed columns
+constexpr int ZC_JIT_EXT_MIN_BLOCKS = 2;             // __launch_bounds__(256, n) of the extension-field kernel: n workgroups per CU = n waves per SIMD
 constexpr uint32_t ZC_JIT_MIN_TERMS = 1024;       // row pairs of a chip in a round from which its compiled kernel is used
 
 struct ZcJitKernel;                               // one chip program's compiled kernel (process-wide, shared)
@@ -41,7 +42,9 @@ std::shared_ptr<ZcJitKernel> zc_jit_request(const uint32_t* ssa, uint32_t n, uin
 
 // *fn = the kernel for the CURRENT device if the code object is ready (loads the module on first use), else nullptr.
 int zc_jit_function(ZcJitKernel* k, bool first, hipFunction_t* fn);
-bool zc_jit_enabled();                            // SP1HIP_ZC_JIT != 0 (read per call)
+// `want` side streams (created once per (device, caller stream)) and want + 1 events: [0] fork, [1 + k] join of stream k
+int zc_jit_side_streams(hipStream_t main, int want, hipStream_t** streams, hipEvent_t** events);
+bool zc_jit_enabled();                            // SP1HIP_ZC_JIT=1 (read per call; the compiled path is opt-in)
 extern std::atomic<uint64_t> g_zc_jit_launches;
 
 }  // namespace sp1hip

@@ -1360,6 +1360,38 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_TRY(d_partial.alloc(partial_cap, s));
             }
             ScopedTimer tm("zerocheck_round", s);      // (the reference's SP1_GPU_ZEROCHECK_ROUND_TIMING switch)
+            constexpr int ZC_JIT_SIDE = 6;
+            hipStream_t* jit_side = nullptr;
+            hipEvent_t* jit_ev = nullptr;
+            bool jit_used[ZC_JIT_SIDE] = {false};
+            if (!jit_launches.empty()) {
+                // the compiled kernels of a round are independent of each other and of the interpreter groups below: they
+                // go out on side streams (largest first, to the least loaded stream) between a fork and a join event
+                SP1HIP_TRY(zc_jit_side_streams(s, ZC_JIT_SIDE, &jit_side, &jit_ev));
+                SP1HIP_HIP(hipEventRecord(jit_ev[0], s));
+                std::vector<size_t> order(jit_launches.size());
+                for (size_t k = 0; k < order.size(); k++) order[k] = k;
+                auto cost = [&](const JitLaunch& jl) { return (uint64_t)jl.n_blocks * (st[jl.chip]->in->n_instr + 8); };
+                std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost(jit_launches[a]) > cost(jit_launches[b]); });
+                uint64_t load[ZC_JIT_SIDE] = {0};
+                for (size_t k : order) {
+                    const JitLaunch& jl = jit_launches[k];
+                    int q = 0;
+                    for (int j = 1; j < ZC_JIT_SIDE; j++) if (load[j] < load[q]) q = j;
+                    load[q] += cost(jl);
+                    if (!jit_used[q]) { SP1HIP_HIP(hipStreamWaitEvent(jit_side[q], jit_ev[0], 0)); jit_used[q] = true; }
+                    const ZcDesc* a_descs = (const ZcDesc*)d_descs.p;
+                    uint32_t a_index = jl.desc_index, a_eq_len = 1u << (nv - 1);
+                    const uint32_t* a_eq = d_eq.u32();
+                    const uint32_t* a_pub = d_publics.u32();
+                    uint32_t* a_partial = d_partial.u32();
+                    void* args[] = {&a_descs, &a_index, &a_eq, &a_eq_len, &a_pub, &a_partial};
+                    // few blocks: one workgroup per (block, node), the nodes of the chip run side by side
+                    const uint32_t gy = jl.n_blocks <= 1024 ? (r == 0 ? 2u : 3u) : 1u;
+                    SP1HIP_HIP(hipModuleLaunchKernel(jl.fn, jl.n_blocks, gy, 1, 256, 1, 1, 0, jit_side[q], args, nullptr));
+                    g_zc_jit_launches.fetch_add(1, std::memory_order_relaxed);
+                }
+            }
             for (auto& g : groups) {
                 // SP1HIP_ZC_FUSE_NODES=1: one workgroup evaluates the three nodes of its rows (rows leave HBM once). Measured
                 // on the core-shaped shard: 12.5 ms of round kernels against 11.0 ms unfused — the re-reads of the unfused
@@ -1370,16 +1402,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
                 else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             }
-            for (const JitLaunch& jl : jit_launches) {
-                const ZcDesc* a_descs = (const ZcDesc*)d_descs.p;
-                uint32_t a_index = jl.desc_index, a_eq_len = 1u << (nv - 1);
-                const uint32_t* a_eq = d_eq.u32();
-                const uint32_t* a_pub = d_publics.u32();
-                uint32_t* a_partial = d_partial.u32();
-                void* args[] = {&a_descs, &a_index, &a_eq, &a_eq_len, &a_pub, &a_partial};
-                SP1HIP_HIP(hipModuleLaunchKernel(jl.fn, jl.n_blocks, 1, 1, 256, 1, 1, 0, s, args, nullptr));
-                g_zc_jit_launches.fetch_add(1, std::memory_order_relaxed);
-            }
+            for (int q = 0; q < ZC_JIT_SIDE; q++)                   // join: the reduction needs every compiled kernel's partial sums
+                if (jit_used[q]) { SP1HIP_HIP(hipEventRecord(jit_ev[1 + q], jit_side[q])); SP1HIP_HIP(hipStreamWaitEvent(s, jit_ev[1 + q], 0)); }
             if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
             SP1HIP_LAUNCH_CHECK();
