@@ -36,5 +36,13 @@ with open(sys.argv[1], "w") as o:
     o.write("idle attributed to the kernel the gap follows (us total | gaps | avg us):\\n")
     for k, v in sorted(gaps.items(), key=lambda kv: -kv[1])[:30]:
         o.write("%10.1f | %4d | %7.1f | %s\\n" % (v, gap_n[k], v / gap_n[k], k))
+    # the largest single gaps, with where in the proof they are and the kernels either side
+    singles, cur_end, idx_end = [], seg[0][0], 0
+    for i, (s, e, n) in enumerate(seg):
+        if s > cur_end and i: singles.append((s - cur_end, cur_end - t0, idx_end, i))
+        if e > cur_end: cur_end, idx_end = e, i
+    o.write("largest single gaps (us | at ms | kernels before -> kernels after):\\n")
+    for g, at, a, b in sorted(singles, reverse=True)[:40]:
+        o.write("%8.1f | %7.2f | %s  ->  %s\\n" % (g / 1e3, at / 1e6, " ; ".join(x[2][:40] for x in seg[max(0, a - 1):a + 1]), " ; ".join(x[2][:40] for x in seg[b:b + 2])))
 PY
 cat $out

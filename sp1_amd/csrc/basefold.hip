@@ -144,6 +144,29 @@ __global__ __launch_bounds__(256) void eq_outer_kernel(const uint32_t* __restric
     for (int k = 0; k < 4; k++) out[(size_t)k * len + i] = r.c[k];
 }
 
+// Every prefix table of eq over the first t coordinates, t = 0..d, in one launch: table t is an ext SoA of length 2^t at
+// word offset 4 (2^t - 1). Thread i walks the d coordinates of index i MSB-first and leaves the running product behind
+// at every depth where the remaining bits of i are zero, so the 2^d threads do d products each and no table is a
+// launch of its own (the BaseFold rounds read table lg_m - 1, prover.hip).
+__global__ __launch_bounds__(256) void eq_prefix_soa_kernel(PointArg pt, int d, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (1u << d)) return;
+    kb::Ext acc = kb::ext_one();
+    for (int t = 0;; t++) {
+        const int rest = d - t;
+        if ((i & ((1u << rest) - 1u)) == 0) {
+            const uint32_t len = 1u << t, idx = i >> rest;
+            uint32_t* tab = out + 4 * ((size_t)len - 1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) tab[(size_t)k * len + idx] = acc.c[k];
+        }
+        if (t == d) break;
+        kb::Ext x{{pt.c[t][0], pt.c[t][1], pt.c[t][2], pt.c[t][3]}};
+        const bool bit = (i >> (rest - 1)) & 1u;
+        acc = kb::ext_mul(acc, bit ? x : kb::ext_sub(kb::ext_one(), x));
+    }
+}
+
 // ---------------------------------------------------------------- reductions
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -321,6 +344,17 @@ int ext_fixed_at_zero_async(const uint32_t* d_mle, int lg_n, const uint32_t* d_e
     hipLaunchKernelGGL(fixed_at_zero_partial_kernel, dim3(blocks), dim3(256), 0, s, d_mle, n, d_eq, (uint32_t*)part.p);
     SP1HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)part.p, blocks, 4u, d_out);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+// d_out: 4 (2^(d+1) - 1) words; see eq_prefix_soa_kernel
+int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s) {
+    SP1HIP_REQUIRE(d >= 0 && d <= kb::TWO_ADICITY + 6, "dim out of range");
+    PointArg pt;
+    for (int j = 0; j < d; j++)
+        for (int k = 0; k < 4; k++) pt.c[j][k] = h_point[j].c[k];
+    hipLaunchKernelGGL(eq_prefix_soa_kernel, dim3(((1u << d) + 255) / 256), dim3(256), 0, s, pt, d, d_out);
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }

@@ -213,6 +213,20 @@ __global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int 
     st_ext(out2, g - 1, kb::ext_mul(acc, lambda));
 }
 
+// the partial-Lagrange table of ALL `dim` coordinates of `pt` (the interaction point): built where it is used, so that a
+// layer starts without a host-built table and its upload on the critical path (the host builds its own copy of every
+// prefix table for the interaction-variable rounds WHILE the device runs the row rounds)
+__global__ __launch_bounds__(256) void eq_full_table_kernel(PointArg pt, int dim, Ext* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << dim)) return;
+    Ext acc = kb::ext_one();
+    for (int j = 0; j < dim; j++) {
+        const bool bit = (i >> (dim - 1 - j)) & 1u;
+        acc = kb::ext_mul(acc, bit ? pt.c[j] : kb::ext_sub(kb::ext_one(), pt.c[j]));
+    }
+    st_ext(out, i, acc);
+}
+
 // ================================================================ sumcheck over the row variables: two rounds per pass
 // A layer's sumcheck  sum_x eq(pt, x) F(x),  F = lambda (n0 d1 + n1 d0) + d0 d1,  binds the row variables last-first.
 // One PASS over the tables serves TWO rounds (the reference's look-ahead, /root/reference/sp1-gpu/crates/sys/lib/logup_gkr/
@@ -882,6 +896,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     auto eval_quadratic = [&](const Ext (&q)[3], const Ext& x) -> Ext { return (q[2] * x + q[1]) * x + q[0]; };
 
     HostPar::Scope par;                                      // helper threads for the host loops between hand-overs
+    par.park();                                              // asleep through the device rounds; woken ahead of each layer's host rounds
     double dbg_rows = 0, dbg_int = 0, dbg_head = 0;
     auto dbg_t = std::chrono::steady_clock::now();
     for (int v = 1; v <= L - 1; v++) {
@@ -891,25 +906,34 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         Ext claim = num_eval * lambda + den_eval;
         ro.claimed_sum = claim;
         const std::vector<Ext> int_point(eval_point.begin(), eval_point.begin() + niv), row_point(eval_point.begin() + niv, eval_point.end());
-        // Lagrange tables of every prefix of the interaction point (eq_tabs[m]: the first m coordinates, 2^m entries)
-        std::vector<std::vector<Ext>> eq_tabs(niv + 1);
-        eq_tabs[0] = {one};
-        for (int m = 0; m < niv; m++) {
-            const std::vector<Ext>& ev = eq_tabs[m];
-            std::vector<Ext>& nx = eq_tabs[m + 1];
-            nx.resize(ev.size() * 2);
-            const Ext x = int_point[m];
-            par.run(ev.size(), 64, [&](int, size_t b, size_t e) {
-                for (size_t i = b; i < e; i++) { const Ext pr = ev[i] * x; nx[2 * i] = ev[i] - pr; nx[2 * i + 1] = pr; }
-            });
+        // the device builds its own tables: eq over the interaction point, and over every prefix of the row point (x 1 and x lambda)
+        SP1HIP_REQUIRE(niv <= 32 && v <= 32, "point too long");
+        {
+            PointArg pi{};
+            for (int j = 0; j < niv; j++) pi.c[j] = int_point[j];
+            hipLaunchKernelGGL(eq_full_table_kernel, dim3((W + 255) / 256), dim3(256), 0, s, pi, niv, d_eq_int.ext());
+            SP1HIP_LAUNCH_CHECK();
         }
-        const std::vector<Ext>& eq_int = eq_tabs[niv];
-        par.park();                                          // the helpers sleep through the device rounds of the layer
-        SP1HIP_TRY(stage.upload(d_eq_int.p, eq_int.data(), (size_t)W * 16));
         PointArg pa{};
         for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
         hipLaunchKernelGGL(eq_prefix_tables_kernel, dim3(((2u << v) + 255) / 256), dim3(256), 0, s, pa, v, lambda, d_T.ext(), d_TL.ext());
         SP1HIP_LAUNCH_CHECK();
+        // Lagrange tables of every prefix of the interaction point (eq_tabs[m]: the first m coordinates, 2^m entries) for the
+        // HOST rounds at the end of the layer: built lazily, after the first pass of the layer has been launched
+        std::vector<std::vector<Ext>> eq_tabs(niv + 1);
+        bool eq_tabs_built = false;
+        auto build_eq_tabs = [&]() {
+            if (eq_tabs_built) return;
+            eq_tabs_built = true;
+            eq_tabs[0] = {one};
+            for (int m = 0; m < niv; m++) {
+                const std::vector<Ext>& ev = eq_tabs[m];
+                std::vector<Ext>& nx = eq_tabs[m + 1];
+                nx.resize(ev.size() * 2);
+                const Ext x = int_point[m];
+                for (size_t i = 0; i < ev.size(); i++) { const Ext pr = ev[i] * x; nx[2 * i] = ev[i] - pr; nx[2 * i + 1] = pr; }
+            }
+        };
         auto T_of = [&](int t) -> const Ext* { return d_T.ext() + (((size_t)1 << t) - 1); };
         auto TL_of = [&](int t) -> const Ext* { return d_TL.ext() + (((size_t)1 << t) - 1); };
 
@@ -946,6 +970,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
 #undef SP1HIP_GKR_PASS
                 SP1HIP_LAUNCH_CHECK();
             }
+            build_eq_tabs();                                 // (first pass of the layer only) host work behind a running kernel
             if (sv == 0) break;
             const int ns = sv == 2 ? 10 : 4;
             SP1HIP_TRY(rsync.wait(h_sums, 4 * ns));
@@ -1092,6 +1117,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         den_eval = ro.d0 + (ro.d1 - ro.d0) * lc;
         eval_point.push_back(lc);
         rounds.push_back(std::move(ro));
+        par.park();
     }
 
     if (gkr_debug) fprintf(stderr, "[sp1hip gkr]   of which row-variable rounds %.3f ms, interaction-variable rounds (host) %.3f ms\n", dbg_rows, dbg_int);

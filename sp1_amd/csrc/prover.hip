@@ -36,6 +36,7 @@ int commit_ext_pairs(const uint32_t* d_cw, int lg_n, uint32_t* d_tree, uint32_t*
 int open_ext_pairs(const uint32_t* d_cw, int lg_n, const uint32_t* d_indices, size_t n_idx, uint32_t* d_values, hipStream_t s);
 int shift_indices(uint32_t* d_idx, size_t n, hipStream_t s);
 int ext_fixed_at_zero_async(const uint32_t* d_mle, int lg_n, const uint32_t* d_eq, uint32_t* d_out, hipStream_t s);
+int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s);
 
 static const p2::RoundConstants& host_rc() {
     static const p2::RoundConstants rc = p2::make_round_constants();
@@ -302,7 +303,7 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     SP1HIP_TRY(d_coeffs.alloc(total_len * 16, s));
     SP1HIP_TRY(d_mle[0].alloc(n * 16, s));
     SP1HIP_TRY(d_mle[1].alloc(n * 8 + 16, s));
-    SP1HIP_TRY(d_eq.alloc(n * 8 + 16, s));
+    SP1HIP_TRY(d_eq.alloc(n * 16, s));      // every prefix table of eq(point[0..t), .), t < dim: round r reads table dim - r - 1
     Mailbox mb;                                   // every device -> host hand-over below goes through it (round_sync.hpp)
     SP1HIP_TRY(mb.init(s));
     PinnedStage stage;
@@ -325,14 +326,14 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     std::vector<kb::Ext> uni;
     std::vector<std::array<uint32_t, 8>> fri_commitments;
     int cur = 0;
+    SP1HIP_TRY(eq_prefix_tables_soa_async(point.data(), dim - 1, d_eq.u32(), s));
     for (int r = 0; r < dim; r++) {
         const int lg_m = dim - r;             // current mle has 2^lg_m entries
         const int lg_c = lg_m + lb;           // current codeword has 2^lg_c entries
         kb::Ext last = point.back();
         point.pop_back();
         // zero_val = sum_i eq(point', i) * mle[2 i]
-        SP1HIP_TRY(sp1hip_partial_lagrange(reinterpret_cast<const sp1hip_ext_t*>(point.data()), lg_m - 1, d_eq.u32(), s));
-        SP1HIP_TRY(ext_fixed_at_zero_async(d_mle[cur].u32(), lg_m, d_eq.u32(), d_rb.u32(), s));
+        SP1HIP_TRY(ext_fixed_at_zero_async(d_mle[cur].u32(), lg_m, d_eq.u32() + 4 * (((size_t)1 << (lg_m - 1)) - 1), d_rb.u32(), s));
         // commit to the paired leaves of the current codeword
         trees.emplace_back(new DeviceBuf());
         SP1HIP_TRY(trees.back()->alloc((((size_t)2 << (lg_c - 1)) - 1) * 32, s));
