@@ -158,6 +158,15 @@ int sp1hip_poseidon2_permute(uint32_t* d_states, size_t n, sp1hip_stream_t strea
  * production kernels use the exact-fp64 linear layer + signed S-box of sp1_amd/csrc/poseidon2.hpp; this entry point
  * exists so that the two independent formulations can be compared on hundreds of millions of states. */
 int sp1hip_poseidon2_permute_integer_form(uint32_t* d_states, size_t n, sp1hip_stream_t stream);
+/* The Fiat-Shamir transcript's permutation, on the HOST (no device needed): h_states [n][16] canonical Montgomery
+ * words, permuted in place. The transcript is a duplex sponge (`DuplexChallenger<F, Perm, 16, 8>` through
+ * `IopCtx::Challenger`, /root/reference/slop/crates/challenger/src/lib.rs:L25-L87): every permutation waits for the
+ * one before, and the GPU waits for the transcript, so its latency is proof time. form 0 = what the transcript runs
+ * (AVX-512 on CPUs that have it: sp1_amd/csrc/p2_host.cpp; the scalar integer form otherwise), 1 = scalar integer
+ * form, 2 = scalar fp64 form; all three return the same words. sp1hip_host_permutation_is_vectorised: 1 if form 0 is
+ * the AVX-512 path on this CPU. */
+int sp1hip_poseidon2_permute_host(uint32_t* h_states, size_t n, int form);
+int sp1hip_host_permutation_is_vectorised(void);
 
 /* ---------------------------------------------------------------- BaseFold kernels (a13, a14)
  * batch: out[r] = sum_c coeff[c] * col_c[r] over all columns of all tensors (message order)

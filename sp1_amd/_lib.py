@@ -132,6 +132,8 @@ PROTOTYPES = [
     ("sp1hip_merkle_open", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("sp1hip_poseidon2_permute", None, [_vp, _sz, _vp]),
     ("sp1hip_poseidon2_permute_integer_form", None, [_vp, _sz, _vp]),
+    ("sp1hip_poseidon2_permute_host", None, [_vp, _sz, _int]),
+    ("sp1hip_host_permutation_is_vectorised", None, []),
     ("sp1hip_basefold_batch", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
     ("sp1hip_fold_even_odd", None, [_vp, _int, Ext, _vp, _vp]),
     ("sp1hip_fold_mle", None, [_vp, _int, Ext, _vp, _vp]),

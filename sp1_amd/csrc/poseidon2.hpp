@@ -334,3 +334,8 @@ __device__ __forceinline__ uint32_t permute_coop16(uint32_t x, uint32_t lane, co
 }
 
 }  // namespace p2
+
+// The transcript's permutation on the host (p2_host.cpp): AVX-512 where the CPU has it, the scalar integer form otherwise.
+namespace sp1hip {
+void p2_host_permute(uint32_t (&state)[16]);
+}

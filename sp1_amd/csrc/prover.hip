@@ -38,10 +38,6 @@ int shift_indices(uint32_t* d_idx, size_t n, hipStream_t s);
 int ext_fixed_at_zero_async(const uint32_t* d_mle, int lg_n, const uint32_t* d_eq, uint32_t* d_out, hipStream_t s);
 int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s);
 
-static const p2::RoundConstants& host_rc() {
-    static const p2::RoundConstants rc = p2::make_round_constants();
-    return rc;
-}
 
 // ---------------------------------------------------------------- transcript
 struct DuplexChallenger {
@@ -56,7 +52,7 @@ struct DuplexChallenger {
     void duplexing() {
         for (int i = 0; i < n_in; i++) state[i] = in[i];
         n_in = 0;
-        p2::permute(state, host_rc());
+        p2_host_permute(state);
         for (int i = 0; i < 8; i++) out[i] = state[i];
         n_out = 8;
     }
@@ -120,7 +116,7 @@ static int grind(DuplexChallenger& ch, int bits, uint32_t* witness_monty, hipStr
             uint32_t st[16];
             memcpy(st, base, sizeof st);
             st[pos] = kb::to_monty(w);
-            p2::permute(st, host_rc());
+            p2_host_permute(st);
             if ((kb::from_monty(st[7]) & mask) == 0) { found = w; break; }
         }
     } else {

@@ -20,26 +20,22 @@
 using namespace sp1hip;
 
 namespace {
-const p2::RoundConstants& host_rc() {
-    static const p2::RoundConstants rc = p2::make_round_constants();
-    return rc;
-}
 // PaddingFreeSponge on the host (metadata hashes: a handful of permutations)
 void host_hash(const std::vector<uint32_t>& in, uint32_t out[8]) {
     uint32_t s[16] = {0};
     size_t fill = 0;
     for (uint32_t x : in) {
         s[fill++] = x;
-        if (fill == 8) { p2::permute(s, host_rc()); fill = 0; }
+        if (fill == 8) { p2_host_permute(s); fill = 0; }
     }
-    if (fill) p2::permute(s, host_rc());
+    if (fill) p2_host_permute(s);
     memcpy(out, s, 32);
 }
 void host_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]) {
     uint32_t s[16];
     memcpy(s, l, 32);
     memcpy(s + 8, r, 32);
-    p2::permute(s, host_rc());
+    p2_host_permute(s);
     memcpy(out, s, 32);
 }
 }  // namespace
