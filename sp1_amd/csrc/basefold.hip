@@ -66,15 +66,18 @@ __global__ __launch_bounds__(256) void batch_kernel(const uint32_t* const* __res
     for (int k = 0; k < 4; k++) out[(size_t)k * height + row] = r.c[k];
 }
 
+struct FoldOpenDesc {            // one fold round of the query phase (open_fold_rounds_kernel); vals_off / paths_off in words
+    const uint32_t* cw;
+    const uint32_t* tree;
+    uint32_t lg_c, vals_off, paths_off, pad;
+};
+
 // ---------------------------------------------------------------- folds
 // out[i] = (e0 + e1)/2 + beta * (e0 - e1) / (2 x_i),  x_i = w_N^{bitrev_{lg N}(2 i)}
-__global__ __launch_bounds__(256) void fold_even_odd_kernel(const uint32_t* __restrict__ cw, int lg_n, ExtArg half_beta,
-                                                            const uint32_t* __restrict__ tw_lo,
-                                                            const uint32_t* __restrict__ tw_hi,
-                                                            uint32_t* __restrict__ out) {
+__device__ __forceinline__ void fold_even_odd_at(const uint32_t* __restrict__ cw, int lg_n, const ExtArg& half_beta,
+                                                 const uint32_t* __restrict__ tw_lo, const uint32_t* __restrict__ tw_hi,
+                                                 uint32_t* __restrict__ out, uint32_t i) {
     const uint32_t n = 1u << lg_n, m = n >> 1;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= m) return;
     kb::Ext e0, e1;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -93,12 +96,18 @@ __global__ __launch_bounds__(256) void fold_even_odd_kernel(const uint32_t* __re
 #pragma unroll
     for (int k = 0; k < 4; k++) out[(size_t)k * m + i] = r.c[k];
 }
-
-__global__ __launch_bounds__(256) void fold_mle_kernel(const uint32_t* __restrict__ mle, int lg_n, ExtArg beta,
-                                                       uint32_t* __restrict__ out) {
-    const uint32_t n = 1u << lg_n, m = n >> 1;
+__global__ __launch_bounds__(256) void fold_even_odd_kernel(const uint32_t* __restrict__ cw, int lg_n, ExtArg half_beta,
+                                                            const uint32_t* __restrict__ tw_lo,
+                                                            const uint32_t* __restrict__ tw_hi,
+                                                            uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= m) return;
+    if (i < (1u << (lg_n - 1))) fold_even_odd_at(cw, lg_n, half_beta, tw_lo, tw_hi, out, i);
+}
+
+// out[i] = m[2 i] + beta m[2 i + 1]
+__device__ __forceinline__ kb::Ext fold_mle_at(const uint32_t* __restrict__ mle, int lg_n, const ExtArg& beta,
+                                               uint32_t* __restrict__ out, uint32_t i) {
+    const uint32_t n = 1u << lg_n, m = n >> 1;
     kb::Ext a, b;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -109,6 +118,51 @@ __global__ __launch_bounds__(256) void fold_mle_kernel(const uint32_t* __restric
     kb::Ext r = kb::ext_add(a, kb::ext_mul(b, E(beta)));
 #pragma unroll
     for (int k = 0; k < 4; k++) out[(size_t)k * m + i] = r.c[k];
+    return r;
+}
+__global__ __launch_bounds__(256) void fold_mle_kernel(const uint32_t* __restrict__ mle, int lg_n, ExtArg beta,
+                                                       uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < (1u << (lg_n - 1))) (void)fold_mle_at(mle, lg_n, beta, out, i);
+}
+
+__device__ __forceinline__ void block_sum4(uint32_t (&v)[4], uint32_t* scratch);
+
+// One BaseFold commit-phase round's folds in ONE launch (prover.hip): workgroups [0, cw_blocks) fold the codeword, the
+// rest fold the message AND leave the partial sums of the NEXT round's first univariate value,
+// zero_val' = sum_j eq'[j] mle'[2 j] (eq' = the prefix table of one coordinate less), one ext per workgroup in
+// `partial` — the folded entry is in a register at that point, so the next round needs neither a pass over the new
+// message nor a launch for it. eq_next == nullptr: the message is down to one entry, no next round.
+__global__ __launch_bounds__(256) void fold_round_kernel(const uint32_t* __restrict__ cw, int lg_c, ExtArg half_beta,
+                                                         const uint32_t* __restrict__ tw_lo, const uint32_t* __restrict__ tw_hi,
+                                                         uint32_t* __restrict__ cw_out, uint32_t cw_blocks,
+                                                         const uint32_t* __restrict__ mle, int lg_m, ExtArg beta,
+                                                         uint32_t* __restrict__ mle_out, const uint32_t* __restrict__ eq_next,
+                                                         uint32_t* __restrict__ partial) {
+    __shared__ uint32_t scratch[16];
+    if (blockIdx.x < cw_blocks) {
+        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+        if (i < (1u << (lg_c - 1))) fold_even_odd_at(cw, lg_c, half_beta, tw_lo, tw_hi, cw_out, i);
+        return;
+    }
+    const uint32_t b = blockIdx.x - cw_blocks, i = b * 256u + threadIdx.x, m = 1u << (lg_m - 1);
+    kb::Ext term = kb::ext_zero();
+    if (i < m) {
+        const kb::Ext r = fold_mle_at(mle, lg_m, beta, mle_out, i);
+        if (eq_next && !(i & 1u)) {
+            const uint32_t j = i >> 1, half = m >> 1;
+            kb::Ext e;
+#pragma unroll
+            for (int k = 0; k < 4; k++) e.c[k] = eq_next[(size_t)k * half + j];
+            term = kb::ext_mul(e, r);
+        }
+    }
+    if (!eq_next) return;
+    block_sum4(term.c, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) partial[b * 4 + k] = term.c[k];
+    }
 }
 
 // ---------------------------------------------------------------- eq tables
@@ -231,14 +285,31 @@ __global__ __launch_bounds__(256) void eval_columns_partial_kernel(const uint32_
     }
 }
 
-// out[j] = sum_chunk partial[chunk][j], j over total_width*4 words
-__global__ void sum_partials_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks, uint32_t n_words,
-                                    uint32_t* __restrict__ out) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_words) return;
+// out[j] = sum_chunk partial[chunk][j], j < n_words. A workgroup owns JW consecutive words and walks the chunks with
+// 256 / JW lanes per word (a wave still reads 64 consecutive words of `partial`), then folds the lanes through LDS: the
+// one-lane-per-word loop it replaces was a chain of n_chunks dependent adds behind as many loads (46 us for 512 chunks,
+// once per BaseFold round).
+template <int JW>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const uint32_t* __restrict__ partial, uint32_t n_chunks, uint32_t n_words,
+                                                           uint32_t* __restrict__ out) {
+    constexpr uint32_t CL = 256 / JW;
+    __shared__ uint32_t sm[256];
+    const uint32_t jl = threadIdx.x % JW, cl = threadIdx.x / JW, j = blockIdx.x * JW + jl;
     uint32_t acc = 0;
-    for (uint32_t c = 0; c < n_chunks; c++) acc = kb::add(acc, partial[(size_t)c * n_words + j]);
-    out[j] = acc;
+    if (j < n_words)
+        for (uint32_t c = cl; c < n_chunks; c += CL) acc = kb::add(acc, partial[(size_t)c * n_words + j]);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t h = CL / 2; h >= 1; h >>= 1) {
+        if (cl < h) sm[threadIdx.x] = kb::add(sm[threadIdx.x], sm[threadIdx.x + h * JW]);
+        __syncthreads();
+    }
+    if (cl == 0 && j < n_words) out[j] = sm[jl];
+}
+static void launch_sum_partials(const uint32_t* partial, uint32_t n_chunks, uint32_t n_words, uint32_t* out, hipStream_t s) {
+    if (n_words <= 4) hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(1), dim3(256), 0, s, partial, n_chunks, n_words, out);
+    else hipLaunchKernelGGL(sum_partials_kernel<64>, dim3((n_words + 63) / 64), dim3(256), 0, s, partial, n_chunks, n_words, out);
 }
 
 // partial[block] = sum_i eq[i] * mle[2 i] over the block's range (ext x ext)
@@ -295,6 +366,29 @@ __global__ void open_pairs_kernel(const uint32_t* __restrict__ cw, uint32_t n, c
     values[t] = cw[(size_t)(w & 3) * n + 2 * (size_t)indices[q] + (w >> 2)];
 }
 
+// Every fold round's opening in ONE launch (the query phase was 3 launches per round: shift the indices, gather the
+// pairs, gather the paths): blockIdx.y = round r, whose index is q >> (r + 1); items [0, 8 n_idx) are the opened pair's
+// words, the rest the path's half-digests (layer k of a tree of height h starts at digest 2^(h+1) - 2^(h-k+1)).
+__global__ __launch_bounds__(256) void open_fold_rounds_kernel(const FoldOpenDesc* __restrict__ descs, const uint32_t* __restrict__ indices,
+                                                               uint32_t n_idx, uint32_t* __restrict__ out) {
+    const FoldOpenDesc d = descs[blockIdx.y];
+    const uint32_t lg_h = d.lg_c - 1, r = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_idx * 8u) {
+        const uint32_t q = t >> 3, w = t & 7u;
+        const uint32_t idx = indices[q] >> (r + 1);
+        out[d.vals_off + t] = d.cw[((size_t)(w & 3u) << d.lg_c) + 2 * (size_t)idx + (w >> 2)];
+        return;
+    }
+    const uint32_t u = t - n_idx * 8u;
+    if (u >= n_idx * lg_h * 2u) return;
+    const uint32_t half = u & 1u, qk = u >> 1, k = qk % lg_h, q = qk / lg_h;
+    const uint32_t idx = indices[q] >> (r + 1);
+    const uint64_t off = ((uint64_t)2 << lg_h) - ((uint64_t)2 << (lg_h - k));
+    const uint64_t node = off + ((idx >> k) ^ 1u);
+    reinterpret_cast<uint4*>(out + d.paths_off + (size_t)qk * 8)[half] = reinterpret_cast<const uint4*>(d.tree + node * 8)[half];
+}
+
 __global__ void shift_indices_kernel(uint32_t* idx, size_t n) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) idx[t] >>= 1;
@@ -307,15 +401,19 @@ using namespace sp1hip;
 namespace sp1hip {
 // internal entry points shared with prover.hip
 int merkle_finish_tree(uint32_t* d_tree, int lg_height, uint32_t total_width, uint32_t* d_root_and_commit,
-                       const DeviceCtx* ctx, hipStream_t s);
+                       const DeviceCtx* ctx, hipStream_t s, const uint32_t* d_publish_extra = nullptr,
+                       uint32_t* h_publish_slot = nullptr, uint32_t publish_seq = 0);
 
-int commit_ext_pairs(const uint32_t* d_cw, int lg_n, uint32_t* d_tree, uint32_t* d_root_and_commit, hipStream_t s) {
+// h_publish_slot != null: the tree's last kernel also publishes [d_publish_extra[0..4) | root | commitment] to that mailbox
+// slot with sequence number publish_seq (Mailbox::wait_next on the host side)
+int commit_ext_pairs(const uint32_t* d_cw, int lg_n, uint32_t* d_tree, uint32_t* d_root_and_commit, hipStream_t s,
+                     const uint32_t* d_publish_extra, uint32_t* h_publish_slot, uint32_t publish_seq) {
     const DeviceCtx* ctx;
     SP1HIP_TRY(get_device_ctx(&ctx));
     const uint32_t n = 1u << lg_n, leaves = n >> 1;
     hipLaunchKernelGGL(leaf_hash_pairs_kernel, dim3((leaves + 255) / 256), dim3(256), 0, s, d_cw, n, ctx->d_rc, d_tree);
     SP1HIP_LAUNCH_CHECK();
-    return merkle_finish_tree(d_tree, lg_n - 1, 8, d_root_and_commit, ctx, s);
+    return merkle_finish_tree(d_tree, lg_n - 1, 8, d_root_and_commit, ctx, s, d_publish_extra, h_publish_slot, publish_seq);
 }
 
 int open_ext_pairs(const uint32_t* d_cw, int lg_n, const uint32_t* d_indices, size_t n_idx, uint32_t* d_values,
@@ -323,6 +421,16 @@ int open_ext_pairs(const uint32_t* d_cw, int lg_n, const uint32_t* d_indices, si
     if (!n_idx) return SP1HIP_SUCCESS;
     hipLaunchKernelGGL(open_pairs_kernel, dim3((n_idx * 8 + 255) / 256), dim3(256), 0, s, d_cw, 1u << lg_n, d_indices,
                        n_idx, d_values);
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+int open_fold_rounds(const FoldOpenDesc* d_descs, int n_rounds, int max_lg_c, const uint32_t* d_indices, size_t n_idx,
+                     uint32_t* d_out, hipStream_t s) {
+    if (!n_idx || n_rounds <= 0) return SP1HIP_SUCCESS;
+    const size_t items = n_idx * 8 + n_idx * (size_t)(max_lg_c - 1) * 2;
+    hipLaunchKernelGGL(open_fold_rounds_kernel, dim3((unsigned)((items + 255) / 256), (unsigned)n_rounds), dim3(256), 0, s, d_descs,
+                       d_indices, (uint32_t)n_idx, d_out);
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }
@@ -343,8 +451,28 @@ int ext_fixed_at_zero_async(const uint32_t* d_mle, int lg_n, const uint32_t* d_e
     SP1HIP_TRY(part.alloc((size_t)blocks * 16, s));
     hipLaunchKernelGGL(fixed_at_zero_partial_kernel, dim3(blocks), dim3(256), 0, s, d_mle, n, d_eq, (uint32_t*)part.p);
     SP1HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, (const uint32_t*)part.p, blocks, 4u, d_out);
+    launch_sum_partials((const uint32_t*)part.p, blocks, 4u, d_out, s);
     SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
+// fold_round_kernel + the sum of its partials into d_zero_val (4 words); d_eq_next may be null (then d_zero_val is untouched)
+// d_partial: scratch of 16 bytes per 256 entries of the folded message (caller-owned: no allocation between a round's launches)
+int fold_round_async(const uint32_t* d_cw, int lg_c, const uint32_t* d_mle, int lg_m, const kb::Ext& beta, uint32_t* d_cw_out,
+                     uint32_t* d_mle_out, const uint32_t* d_eq_next, uint32_t* d_zero_val, uint32_t* d_partial, hipStream_t s) {
+    SP1HIP_REQUIRE(lg_c >= 1 && lg_c <= kb::TWO_ADICITY && lg_m >= 1 && lg_m <= 30, "fold sizes out of range");
+    const DeviceCtx* ctx;
+    SP1HIP_TRY(get_device_ctx(&ctx));
+    ExtArg hb, b;
+    for (int k = 0; k < 4; k++) { hb.c[k] = kb::mul(beta.c[k], 0x00ffffffu); b.c[k] = beta.c[k]; }
+    const uint32_t cw_blocks = ((1u << (lg_c - 1)) + 255) / 256, mle_blocks = ((1u << (lg_m - 1)) + 255) / 256;
+    hipLaunchKernelGGL(fold_round_kernel, dim3(cw_blocks + mle_blocks), dim3(256), 0, s, d_cw, lg_c, hb, ctx->d_tw_lo, ctx->d_tw_hi,
+                       d_cw_out, cw_blocks, d_mle, lg_m, b, d_mle_out, d_eq_next, d_partial);
+    SP1HIP_LAUNCH_CHECK();
+    if (d_eq_next) {
+        launch_sum_partials(d_partial, mle_blocks, 4u, d_zero_val, s);
+        SP1HIP_LAUNCH_CHECK();
+    }
     return SP1HIP_SUCCESS;
 }
 
@@ -481,8 +609,7 @@ int sp1hip_mle_eval_columns(const sp1hip_tensor_t* tensors, int n_tensors, int l
     hipLaunchKernelGGL(eval_columns_partial_kernel, grid, dim3(256), 0, s, (const uint32_t* const*)cols.p, tw, height,
                        d_eq, (uint32_t*)part.p);
     SP1HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((tw * 4 + 255) / 256), dim3(256), 0, s, (const uint32_t*)part.p, chunks,
-                       tw * 4, d_evals);
+    launch_sum_partials((const uint32_t*)part.p, chunks, tw * 4, d_evals, s);
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }

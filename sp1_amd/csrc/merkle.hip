@@ -12,7 +12,8 @@
 //    slots per permutation vs 32 bytes loaded), so no LDS staging: extra waves, not tiling, hide
 //    the load latency.
 //  * compress_layer: one lane per parent, 64 B in (2 x dwordx4 x 2), 32 B out.
-//  * compress_top: the last <= 11 levels in one workgroup (one launch instead of eleven ~2 us ones).
+//  * compress_layer_coop: layers of <= 8192 parents, 16 lanes per compression (latency, not throughput, is what a small
+//    layer costs); compress_top: the last <= 7 levels in one workgroup, cooperative form throughout.
 #include "device_ctx.hpp"
 #include "tensor_table.hpp"
 
@@ -185,7 +186,24 @@ __global__ __launch_bounds__(256) void compress_layer_kernel(const uint32_t* __r
     store_digest(parents + (size_t)i * 8, s);
 }
 
-// One workgroup finishes the tree: `layer` holds n (<= 2048, power of two) digests and the parents are laid out
+// The same layer in the cooperative form: 16 lanes per compression (lane r holds word r of the two children, which are 16
+// consecutive words), linear layers as DPP shuffles (poseidon2.hpp). It does ~6x the VALU work of the per-lane form, so it
+// is for the SMALL layers only (<= COOP_LAYER_MAX parents, where the chip is nearly empty and a layer's time is the latency
+// of ONE compression): that latency is ~2.3x shorter here, and a Merkle tree's tail is a chain of such layers — 21 BaseFold
+// trees and 7 commit trees per shard proof. n_parents is a multiple of 4 (whole waves: DPP rows must be fully active).
+__global__ __launch_bounds__(256) void compress_layer_coop_kernel(const uint32_t* __restrict__ children, uint32_t n_parents,
+                                                                  const p2::RoundConstants* __restrict__ rc,
+                                                                  uint32_t* __restrict__ parents) {
+    const uint32_t lane = threadIdx.x & 15u, row = blockIdx.x * 16u + (threadIdx.x >> 4);
+    const uint32_t wave_row0 = blockIdx.x * 16u + ((threadIdx.x >> 6) << 2);
+    if (wave_row0 >= n_parents) return;                                   // wave-uniform
+    uint32_t x = children[(size_t)row * 16 + lane];
+    x = p2::permute_coop16(x, lane, *rc);
+    if (lane < 8) parents[(size_t)row * 8 + lane] = x;
+}
+constexpr uint32_t COOP_LAYER_MAX = 8192, TOP_MAX = 128;
+
+// One workgroup finishes the tree: `layer` holds n (<= 2048, power of two; the host hands over <= TOP_MAX) digests and the parents are laid out
 // right behind it, level after level. Also writes root and the finalised commitment. Levels with >= 64 parents
 // use one lane per compression; the last levels (a chain of dependent compressions with almost no parallelism,
 // i.e. pure latency) use the cooperative permutation — 16 lanes per compression, DPP shuffles for the linear
@@ -194,14 +212,16 @@ __global__ __launch_bounds__(256) void compress_layer_kernel(const uint32_t* __r
 __global__ __launch_bounds__(1024) void compress_top_kernel(uint32_t* layer, uint32_t n, uint32_t lg_height,
                                                             uint32_t total_width,
                                                             const p2::RoundConstants* __restrict__ rc,
-                                                            uint32_t* __restrict__ root_and_commit) {
+                                                            uint32_t* __restrict__ root_and_commit,
+                                                            const uint32_t* __restrict__ publish_extra,
+                                                            volatile uint32_t* publish_slot, uint32_t publish_seq) {
     const uint32_t lane = threadIdx.x & 15u, row = threadIdx.x >> 4;      // cooperative view: 64 rows of 16 lanes
     const uint32_t wave_row0 = (threadIdx.x >> 6) << 2;                   // first row of this wave (wave-uniform)
     uint32_t* cur = layer;
     while (n > 1) {
         uint32_t* nxt = cur + (size_t)n * 8;
         const uint32_t np = n >> 1;
-        if (np > 32) {
+        if (np > 64) {
             for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) {
                 uint32_t s[16];
                 load_pair(cur + (size_t)i * 16, s);
@@ -230,6 +250,19 @@ __global__ __launch_bounds__(1024) void compress_top_kernel(uint32_t* layer, uin
         root_and_commit[lane] = root_word;
         root_and_commit[8 + lane] = x;
     }
+    // Optional hand-over to the host in the same launch (a BaseFold round: the prover waits for [4 extra words | root |
+    // commitment]; a mailbox kernel behind this one was one more launch per round): payload, then — once the stores are
+    // acknowledged — the sequence number, like mailbox_publish_kernel (runtime.hip).
+    if (publish_slot == nullptr) return;
+    if (row == 0) {
+        if (lane < 4) publish_slot[1 + lane] = publish_extra[lane];
+        if (lane < 8) {
+            publish_slot[5 + lane] = root_word;
+            publish_slot[13 + lane] = x;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) publish_slot[0] = publish_seq;
 }
 
 template <bool INTEGER_FORM>
@@ -271,20 +304,24 @@ __global__ void open_paths_kernel(const uint32_t* __restrict__ tree, uint32_t lg
 
 // Compresses the leaf layer at d_tree up to the root and finalises the commitment.
 int merkle_finish_tree(uint32_t* d_tree, int lg_height, uint32_t total_width, uint32_t* d_root_and_commit,
-                       const DeviceCtx* ctx, hipStream_t s) {
+                       const DeviceCtx* ctx, hipStream_t s, const uint32_t* d_publish_extra, uint32_t* h_publish_slot,
+                       uint32_t publish_seq) {
     ScopedTimer t("compress", s);
     uint32_t* cur = d_tree;
     uint32_t n = 1u << lg_height;
-    while (n > 2048) {
+    while (n > TOP_MAX) {
         uint32_t* nxt = cur + (size_t)n * 8;
-        hipLaunchKernelGGL(compress_layer_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, s, cur, n / 2, ctx->d_rc,
-                           nxt);
+        const uint32_t np = n / 2;
+        if (np > COOP_LAYER_MAX)
+            hipLaunchKernelGGL(compress_layer_kernel, dim3((np + 255) / 256), dim3(256), 0, s, cur, np, ctx->d_rc, nxt);
+        else
+            hipLaunchKernelGGL(compress_layer_coop_kernel, dim3((np + 15) / 16), dim3(256), 0, s, cur, np, ctx->d_rc, nxt);
         SP1HIP_LAUNCH_CHECK();
         cur = nxt;
         n >>= 1;
     }
     hipLaunchKernelGGL(compress_top_kernel, dim3(1), dim3(1024), 0, s, cur, n, (uint32_t)lg_height, total_width,
-                       ctx->d_rc, d_root_and_commit);
+                       ctx->d_rc, d_root_and_commit, d_publish_extra, (volatile uint32_t*)h_publish_slot, publish_seq);
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }
@@ -315,7 +352,7 @@ int sp1hip_merkle_commit(const sp1hip_tensor_t* tensors, int n_tensors, int lg_h
                            (const uint32_t* const*)cols.p, tw, height, ctx->d_rc, d_tree);
     }
     SP1HIP_LAUNCH_CHECK();
-    return merkle_finish_tree(d_tree, lg_height, tw, d_root_and_commit, ctx, s);
+    return merkle_finish_tree(d_tree, lg_height, tw, d_root_and_commit, ctx, s, nullptr, nullptr, 0);
 }
 
 int sp1hip_merkle_open(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, const uint32_t* d_tree,

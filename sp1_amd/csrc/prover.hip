@@ -28,13 +28,19 @@
 
 namespace sp1hip {
 
-int merkle_finish_tree(uint32_t*, int, uint32_t, uint32_t*, const DeviceCtx*, hipStream_t);
+int merkle_finish_tree(uint32_t*, int, uint32_t, uint32_t*, const DeviceCtx*, hipStream_t, const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t = 0);
 void leaf_hash_plan(const sp1hip_tensor_t* tensors, int n_tensors, std::vector<LeafPart>* parts);
 int leaf_hash_part(const uint32_t* const* d_cols, uint32_t width, int k, int n_parts, uint32_t height, uint32_t* d_carry,
                    uint32_t* d_tree, const DeviceCtx* ctx, hipStream_t s);
-int commit_ext_pairs(const uint32_t* d_cw, int lg_n, uint32_t* d_tree, uint32_t* d_root_and_commit, hipStream_t s);
+int commit_ext_pairs(const uint32_t* d_cw, int lg_n, uint32_t* d_tree, uint32_t* d_root_and_commit, hipStream_t s,
+                     const uint32_t* d_publish_extra = nullptr, uint32_t* h_publish_slot = nullptr, uint32_t publish_seq = 0);
+int fold_round_async(const uint32_t* d_cw, int lg_c, const uint32_t* d_mle, int lg_m, const kb::Ext& beta, uint32_t* d_cw_out,
+                     uint32_t* d_mle_out, const uint32_t* d_eq_next, uint32_t* d_zero_val, uint32_t* d_partial, hipStream_t s);
 int open_ext_pairs(const uint32_t* d_cw, int lg_n, const uint32_t* d_indices, size_t n_idx, uint32_t* d_values, hipStream_t s);
 int shift_indices(uint32_t* d_idx, size_t n, hipStream_t s);
+struct FoldOpenDesc { const uint32_t* cw; const uint32_t* tree; uint32_t lg_c, vals_off, paths_off, pad; };   // basefold.hip
+int open_fold_rounds(const FoldOpenDesc* d_descs, int n_rounds, int max_lg_c, const uint32_t* d_indices, size_t n_idx,
+                     uint32_t* d_out, hipStream_t s);
 int ext_fixed_at_zero_async(const uint32_t* d_mle, int lg_n, const uint32_t* d_eq, uint32_t* d_out, hipStream_t s);
 int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s);
 
@@ -323,19 +329,30 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     std::vector<std::array<uint32_t, 8>> fri_commitments;
     int cur = 0;
     SP1HIP_TRY(eq_prefix_tables_soa_async(point.data(), dim - 1, d_eq.u32(), s));
+    auto eq_table = [&](int t) { return d_eq.u32() + 4 * (((size_t)1 << t) - 1); };     // eq over the first t coordinates
+    // every round's codeword, tree and the fold scratch are allocated here: between a round's hand-over and its launches
+    // the host does nothing but enqueue (the GPU was waiting 10-16 us per launch behind the allocations)
+    DeviceBuf d_fold_partial;
+    SP1HIP_TRY(d_fold_partial.alloc((((size_t)n / 2 + 255) / 256) * 16, s));
+    for (int r = 0; r < dim; r++) {
+        const int lg_c = dim - r + lb;
+        trees.emplace_back(new DeviceBuf());
+        SP1HIP_TRY(trees.back()->alloc((((size_t)2 << (lg_c - 1)) - 1) * 32, s));
+        cws.emplace_back(new DeviceBuf());
+        SP1HIP_TRY(cws.back()->alloc(((size_t)1 << (lg_c - 1)) * 16, s));
+    }
+    // zero_val of round 0 = sum_i eq(point', i) * mle[2 i]; every later round's comes out of the fold before it
+    SP1HIP_TRY(ext_fixed_at_zero_async(d_mle[cur].u32(), dim, eq_table(dim - 1), d_rb.u32(), s));
     for (int r = 0; r < dim; r++) {
         const int lg_m = dim - r;             // current mle has 2^lg_m entries
         const int lg_c = lg_m + lb;           // current codeword has 2^lg_c entries
         kb::Ext last = point.back();
         point.pop_back();
-        // zero_val = sum_i eq(point', i) * mle[2 i]
-        SP1HIP_TRY(ext_fixed_at_zero_async(d_mle[cur].u32(), lg_m, d_eq.u32() + 4 * (((size_t)1 << (lg_m - 1)) - 1), d_rb.u32(), s));
-        // commit to the paired leaves of the current codeword
-        trees.emplace_back(new DeviceBuf());
-        SP1HIP_TRY(trees.back()->alloc((((size_t)2 << (lg_c - 1)) - 1) * 32, s));
-        SP1HIP_TRY(commit_ext_pairs(cws.back()->u32(), lg_c, trees.back()->u32(), d_rb.u32() + 4, s));
+        // commit to the paired leaves of the current codeword; the tree's last kernel hands [zero_val | root | commitment]
+        // to the host
+        SP1HIP_TRY(commit_ext_pairs(cws[r]->u32(), lg_c, trees[r]->u32(), d_rb.u32() + 4, s, d_rb.u32(), mb.h_slot, mb.seq + 1));
         uint32_t rb[20];
-        SP1HIP_TRY(mb.fetch(d_rb.p, 20, rb));
+        SP1HIP_TRY(mb.wait_next(rb, 20));
         kb::Ext zero_val{{rb[0], rb[1], rb[2], rb[3]}};
         kb::Ext one_val = kb::ext_add(kb::ext_mul(kb::ext_sub(cur_claim, zero_val), kb::ext_inv(last)), zero_val);
         uni.push_back(zero_val);
@@ -349,12 +366,9 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
         fri_commitments.push_back(commit);
         ch.observe_slice(commit.data(), 8);
         kb::Ext beta = ch.sample_ext();
-        sp1hip_ext_t b;
-        memcpy(b.c, beta.c, 16);
-        cws.emplace_back(new DeviceBuf());
-        SP1HIP_TRY(cws.back()->alloc(((size_t)1 << (lg_c - 1)) * 16, s));
-        SP1HIP_TRY(sp1hip_fold_even_odd(cws[cws.size() - 2]->u32(), lg_c, b, cws.back()->u32(), s));
-        SP1HIP_TRY(sp1hip_fold_mle(d_mle[cur].u32(), lg_m, b, d_mle[cur ^ 1].u32(), s));
+        // both folds and the next round's zero_val partials in one launch
+        SP1HIP_TRY(fold_round_async(cws[r]->u32(), lg_c, d_mle[cur].u32(), lg_m, beta, cws[r + 1]->u32(),
+                                    d_mle[cur ^ 1].u32(), lg_m >= 2 ? eq_table(lg_m - 2) : nullptr, d_rb.u32(), d_fold_partial.u32(), s));
         cur ^= 1;
         cur_claim = kb::ext_add(zero_val, kb::ext_mul(beta, one_val));
     }
@@ -405,13 +419,17 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
         SP1HIP_TRY(sp1hip_merkle_open(pd->cw_tensors.data(), (int)pd->cw_tensors.size(), dim + lb, pd->tree.u32(), d_idx.u32(),
                                       nq, d_open.u32() + sl.vals_off, d_open.u32() + sl.paths_off, s));
     }
-    for (int r = 0; r < dim; r++) {
-        const int lg_c = dim + lb - r, lg_h = lg_c - 1;
-        const Slot& sl = slots[n_rounds + r];
-        SP1HIP_TRY(shift_indices(d_idx.u32(), nq, s));
-        SP1HIP_TRY(open_ext_pairs(cws[r]->u32(), lg_c, d_idx.u32(), nq, d_open.u32() + sl.vals_off, s));
-        sp1hip_tensor_t none{nullptr, 0};
-        SP1HIP_TRY(sp1hip_merkle_open(&none, 1, lg_h, trees[r]->u32(), d_idx.u32(), nq, nullptr, d_open.u32() + sl.paths_off, s));
+    {   // every fold round's pairs and paths in one launch
+        SP1HIP_REQUIRE(words < ((size_t)1 << 32), "opening buffer too large");
+        std::vector<FoldOpenDesc> descs(dim);
+        for (int r = 0; r < dim; r++) {
+            const Slot& sl = slots[n_rounds + r];
+            descs[r] = FoldOpenDesc{cws[r]->u32(), trees[r]->u32(), (uint32_t)(dim + lb - r), (uint32_t)sl.vals_off, (uint32_t)sl.paths_off, 0u};
+        }
+        DeviceBuf d_descs;
+        SP1HIP_TRY(d_descs.alloc(descs.size() * sizeof(FoldOpenDesc), s));
+        SP1HIP_TRY(stage.upload(d_descs.p, descs.data(), descs.size() * sizeof(FoldOpenDesc)));
+        SP1HIP_TRY(open_fold_rounds(reinterpret_cast<const FoldOpenDesc*>(d_descs.p), dim, dim + lb, d_idx.u32(), nq, d_open.u32(), s));
     }
     std::vector<uint32_t> opened(std::max<size_t>(words, 1));
     SP1HIP_TRY(mb.fetch(d_open.p, words, opened.data()));      // (its completion also covers the q upload above)
