@@ -167,6 +167,15 @@ int sp1hip_poseidon2_permute_integer_form(uint32_t* d_states, size_t n, sp1hip_s
  * the AVX-512 path on this CPU. */
 int sp1hip_poseidon2_permute_host(uint32_t* h_states, size_t n, int form);
 int sp1hip_host_permutation_is_vectorised(void);
+/* Host-only test hooks for the vectorised interaction-variable rounds of LogUp-GKR (sp1_amd/csrc/gkr_host.cpp; the rounds of
+ * `InteractionLayer`, /root/reference/crates/hypercube/src/logup_gkr/logup_poly.rs:L240-L316, on coefficient planes): tab = 4 tables
+ * (n0, d0, n1, d1) x 4 planes of `stride` words (multiple of 16, >= 2 * pairs rounded up to 8, + 16), eq = 4 planes of eq_stride
+ * words. sums: out24 = [x0 | y0 | xh | yh | e0 | es] over the first real_pairs (even, odd) pairs; fold: out[k] = t[2k] +
+ * alpha (t[2k+1] - t[2k]). Return 0, or -1 when the CPU has no AVX-512 (the library then runs the scalar rounds) or an
+ * argument is malformed. */
+int sp1hip_gkr_host_simd_available(void);
+int sp1hip_gkr_host_round_sums(const uint32_t* tab, size_t stride, const uint32_t* eq, size_t eq_stride, size_t real_pairs, uint32_t* out24);
+int sp1hip_gkr_host_round_fold(const uint32_t* tab, uint32_t* out, size_t stride, size_t real_pairs, const uint32_t* alpha4);
 
 /* ---------------------------------------------------------------- BaseFold kernels (a13, a14)
  * batch: out[r] = sum_c coeff[c] * col_c[r] over all columns of all tensors (message order)

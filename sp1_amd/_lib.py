@@ -134,6 +134,9 @@ PROTOTYPES = [
     ("sp1hip_poseidon2_permute_integer_form", None, [_vp, _sz, _vp]),
     ("sp1hip_poseidon2_permute_host", None, [_vp, _sz, _int]),
     ("sp1hip_host_permutation_is_vectorised", None, []),
+    ("sp1hip_gkr_host_simd_available", None, []),
+    ("sp1hip_gkr_host_round_sums", None, [_vp, _sz, _vp, _sz, _sz, _vp]),
+    ("sp1hip_gkr_host_round_fold", None, [_vp, _vp, _sz, _sz, _vp]),
     ("sp1hip_basefold_batch", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
     ("sp1hip_fold_even_odd", None, [_vp, _int, Ext, _vp, _vp]),
     ("sp1hip_fold_mle", None, [_vp, _int, Ext, _vp, _vp]),

@@ -34,6 +34,12 @@
 
 #include "device_ctx.hpp"
 #include "host_par.hpp"
+
+namespace sp1hip {      // gkr_host.cpp: the interaction-variable rounds in AVX-512 (tables as coefficient planes)
+bool gkr_host_simd_available();
+void gkr_host_round_sums(const uint32_t* tab, size_t stride, const uint32_t* eq, size_t eq_stride, size_t real_pairs, uint32_t out[6][4]);
+void gkr_host_round_fold(const uint32_t* tab, uint32_t* out, size_t stride, size_t real_pairs, const uint32_t alpha[4]);
+}
 #include "round_sync.hpp"
 #include "tensor_table.hpp"
 
@@ -60,6 +66,14 @@ __device__ __forceinline__ Ext ld_ext(const Ext* p, uint32_t i) {
 __device__ __forceinline__ void st_ext(Ext* p, uint32_t i, const Ext& e) {
     const q4_t v = {e.c[0], e.c[1], e.c[2], e.c[3]};
     gptr(reinterpret_cast<q4_t*>(p))[i] = v;
+}
+
+// the same into fine-grained HOST memory: system-scope stores (sc0 sc1: past the write-back L2, which would otherwise keep
+// the line until the kernel ends)
+__device__ __forceinline__ void st_ext_host(Ext* p, uint32_t i, const Ext& e) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(p + i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) __hip_atomic_store(w + k, e.c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- block reduction of NS ext accumulators -> partials[block][4 NS]
@@ -433,7 +447,11 @@ __global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ des
             row = fold_row<FV, FIRST, NBASE>(d, ro, a0, a1);
             if (FV > 0) {
                 const uint32_t rq = folded_pos(ro, rows_out);
-                st_ext(d.dst[0], rq, row.n0); st_ext(d.dst[1], rq, row.d0); st_ext(d.dst[2], rq, row.n1); st_ext(d.dst[3], rq, row.d1);
+                if (SV == 0 && rs.host_slot != nullptr) {    // the layer's last fold, published from this kernel (see the tail)
+                    st_ext_host(d.dst[0], rq, row.n0); st_ext_host(d.dst[1], rq, row.d0); st_ext_host(d.dst[2], rq, row.n1); st_ext_host(d.dst[3], rq, row.d1);
+                } else {
+                    st_ext(d.dst[0], rq, row.n0); st_ext(d.dst[1], rq, row.d0); st_ext(d.dst[2], rq, row.n1); st_ext(d.dst[3], rq, row.d1);
+                }
             }
         }
         if constexpr (SV > 0) {
@@ -467,6 +485,15 @@ __global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ des
         Ext out[GridOut<SVS>::NS];
         grid_split<SVS>(g, j, scale, !FLAT, out);
         rs_finish<GridOut<SVS>::NS>(out, partials, blockIdx.x, gridDim.x, rs, seq);
+    } else if (rs.host_slot != nullptr) {
+        // The layer's last fold stores its rows (one per interaction) STRAIGHT into the mapped host slot — the descriptors'
+        // dst pointers point there — and the workgroup that arrives last publishes the sequence number: the host had been
+        // waiting for a one-workgroup copy kernel behind this one (45 us for 46 KB of 4-byte uncached stores, once per layer).
+        // Same ordering argument as rs_finish: system-scope stores to fine-grained host memory that the wave has been
+        // acknowledged (vmcnt) are visible to the host, and the ticket orders the last workgroup's store behind everybody's.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && rs_ticket_is_last(rs.counter, blockIdx.x, gridDim.x)) rs.host_slot[0] = seq;
     }
 }
 
@@ -805,6 +832,9 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     // tail better (sweep of round 2 on the one-round kernels: 4096 best, flat between 2048 and 8192).
     static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 1u) : 4096u; }();
     std::vector<PassDesc> all_descs;
+    // a layer's last fold (one row per interaction) goes straight to the mailbox slot, 16-byte aligned behind word 0
+    const bool direct_final = (size_t)K * 16 + 4 <= MAILBOX_WORDS;
+    Ext* const host_rows = reinterpret_cast<Ext*>(mb.h_slot + 4);
     for (int v = 1; v <= L - 1; v++) {
         std::vector<uint32_t> rows_in(K);
         for (uint32_t i = 0; i < K; i++) rows_in[i] = (rows_at(info[int_chip[i]].rows, v + 1) + 1) / 2;
@@ -829,7 +859,8 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 d.rows_in = rows_in[i]; d.eq_int_index = i;
                 if (first) { d.src[0] = n_ptr(v + 1, i); d.src[1] = d_ptr(v + 1, i); d.rows_x = rows_at(info[int_chip[i]].rows, v + 1); }
                 else for (int w = 0; w < 4; w++) d.src[w] = scratch_ptr(cur ^ 1, i, w, so_prev);
-                if (fv > 0) for (int w = 0; w < 4; w++) d.dst[w] = scratch_ptr(cur, i, w, so_next);
+                if (fv > 0) for (int w = 0; w < 4; w++)
+                    d.dst[w] = (sv == 0 && direct_final) ? host_rows + 4 * so_next[i] + (size_t)w * (so_next[i + 1] - so_next[i]) : scratch_ptr(cur, i, w, so_next);
                 d.tile0 = tile0;
                 const uint32_t n_tiles = (slots_of(rows_in[i]) + tile_size - 1) / tile_size;
                 if (flat) flat_index.insert(flat_index.end(), n_tiles, (uint16_t)i);
@@ -895,6 +926,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     auto quadratic = [&](const Ext& g0, const Ext& g1, const Ext& gi, Ext (&q)[3]) { q[0] = g0; q[1] = g1 - g0 - gi; q[2] = gi; };
     auto eval_quadratic = [&](const Ext (&q)[3], const Ext& x) -> Ext { return (q[2] * x + q[1]) * x + q[0]; };
 
+    const bool simd = gkr_host_simd_available();             // AVX-512 host rounds: one thread, the helpers stay asleep
     HostPar::Scope par;                                      // helper threads for the host loops between hand-overs
     par.park();                                              // asleep through the device rounds; woken ahead of each layer's host rounds
     double dbg_rows = 0, dbg_int = 0, dbg_head = 0;
@@ -921,6 +953,8 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         // Lagrange tables of every prefix of the interaction point (eq_tabs[m]: the first m coordinates, 2^m entries) for the
         // HOST rounds at the end of the layer: built lazily, after the first pass of the layer has been launched
         std::vector<std::vector<Ext>> eq_tabs(niv + 1);
+        std::vector<std::vector<uint32_t>> eq_soa(niv + 1);
+        auto eq_plane_stride = [](int m) { return ((((size_t)1 << m) + 15) / 16) * 16 + 16; };
         bool eq_tabs_built = false;
         auto build_eq_tabs = [&]() {
             if (eq_tabs_built) return;
@@ -933,6 +967,13 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 const Ext x = int_point[m];
                 for (size_t i = 0; i < ev.size(); i++) { const Ext pr = ev[i] * x; nx[2 * i] = ev[i] - pr; nx[2 * i + 1] = pr; }
             }
+            if (simd)                                         // the same tables as coefficient planes (gkr_host.cpp)
+                for (int m = 1; m <= niv; m++) {
+                    const size_t es = eq_plane_stride(m);
+                    eq_soa[m].assign(4 * es, 0u);
+                    for (size_t i = 0; i < eq_tabs[m].size(); i++)
+                        for (int k = 0; k < 4; k++) eq_soa[m][(size_t)k * es + i] = eq_tabs[m][i].c[k];
+                }
         };
         auto T_of = [&](int t) -> const Ext* { return d_T.ext() + (((size_t)1 << t) - 1); };
         auto TL_of = [&](int t) -> const Ext* { return d_TL.ext() + (((size_t)1 << t) - 1); };
@@ -949,13 +990,15 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             t -= fv;                                         // variables left once this pass has folded
             const FlatArgs fa{(const uint16_t*)d_flat.p + shape.flat_off, shape.total_slots};
             const bool nbase = shape.first && v + 1 == L;
-            if (sv == 0) par.wake();                         // the helpers' wake-up hides behind the last fold and its hand-over
-            const RoundSync rs = sv > 0 ? rsync.next() : RoundSync{};
+            if (!simd && t == sv) par.wake();                // the helpers' wake-up hides behind the layer's last two passes
+            const bool publish_rows = sv == 0 && direct_final;
+            if (publish_rows) { rsync.pending = true; mb.pending = true; }       // (an early error return must drain the stream first)
+            const RoundSync rs = sv > 0 ? rsync.next() : publish_rows ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
             const Ext* Tp = sv > 0 ? T_of(t - sv) : (const Ext*)nullptr;
             const Ext* TLp = sv > 0 ? TL_of(t - sv) : (const Ext*)nullptr;
             {
                 ScopedTimer tm(fv == 0 ? "gkr_pass_sum" : sv == 0 ? "gkr_pass_fold" : "gkr_pass_fold_sum", s);
-#define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, TLp, a0, a1, d_partials.u32(), rs, rsync.seq, K, shape.tile_size, fa)
+#define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, TLp, a0, a1, d_partials.u32(), rs, publish_rows ? mb.seq + 1 : rsync.seq, K, shape.tile_size, fa)
 #define SP1HIP_GKR_PASS_FL(FV, SV, F, NB) do { if (shape.flat) SP1HIP_GKR_PASS(FV, SV, F, NB, true); else SP1HIP_GKR_PASS(FV, SV, F, NB, false); } while (0)
 #define SP1HIP_GKR_PASS_SRC(FV, SV) do { if (nbase) SP1HIP_GKR_PASS_FL(FV, SV, true, true); else if (shape.first) SP1HIP_GKR_PASS_FL(FV, SV, true, false); else SP1HIP_GKR_PASS_FL(FV, SV, false, false); } while (0)
                 if (fv == 0 && sv == 2) { if (nbase) SP1HIP_GKR_PASS_FL(0, 2, true, true); else SP1HIP_GKR_PASS_FL(0, 2, true, false); }
@@ -1021,14 +1064,28 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             }
         }
         // the layer's last fold left one row per interaction: dense over 2^niv on the host
-        std::vector<Ext> tn0(W, kb::ext_zero()), td0(W, one), tn1(W, kb::ext_zero()), td1(W, one);
+        std::vector<Ext> tn0(simd ? 1 : W, kb::ext_zero()), td0(simd ? 1 : W, one), tn1(simd ? 1 : W, kb::ext_zero()), td1(simd ? 1 : W, one);
+        const size_t soa_stride = (((size_t)W + 15) / 16) * 16 + 16;
+        std::vector<uint32_t> soa[2];
         {
             std::vector<size_t> so(K + 1, 0);
             for (uint32_t i = 0; i < K; i++) so[i + 1] = so[i] + (rows_at(info[int_chip[i]].rows, v + 1) ? 1 : 0);
             final_rows_total = so[K];
             const int cur = (int)((((v + 1) / 2)) & 1) ^ 1;  // folding passes of the layer: ceil(v / 2); they alternate scratch[0], [1], ...
             std::vector<Ext> host(std::max<size_t>(final_rows_total, 1) * 4);
-            SP1HIP_TRY(mb.fetch(scratch[cur].p, final_rows_total * 16, host.data()));
+            if (direct_final) { SP1HIP_TRY(mb.wait_next(host.data(), final_rows_total * 16, 4)); rsync.pending = false; }
+            else SP1HIP_TRY(mb.fetch(scratch[cur].p, final_rows_total * 16, host.data()));
+            if (simd) {                                      // coefficient planes: table w, plane k at (4 w + k) stride; all (0, 1) first
+                soa[0].assign(16 * soa_stride, 0u);
+                soa[1].assign(16 * soa_stride, 0u);
+                for (int b = 0; b < 2; b++)
+                    for (int w = 1; w < 4; w += 2) std::fill_n(soa[b].begin() + (size_t)(4 * w) * soa_stride, soa_stride, one.c[0]);
+                for (uint32_t i = 0; i < K; i++) {
+                    if (so[i + 1] == so[i]) continue;
+                    for (int w = 0; w < 4; w++)
+                        for (int k = 0; k < 4; k++) soa[0][(size_t)(4 * w + k) * soa_stride + i] = host[4 * so[i] + w].c[k];
+                }
+            } else
             for (uint32_t i = 0; i < K; i++) {
                 if (so[i + 1] == so[i]) continue;            // chip without rows: stays (0, 1)
                 const size_t base = 4 * so[i];
@@ -1055,8 +1112,14 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             const Ext *n0 = tab[side][0]->data(), *d0 = tab[side][1]->data(), *n1 = tab[side][2]->data(), *d1 = tab[side][3]->data();
             struct alignas(64) Part { Ext x0, y0, xh, yh, e0, es; };
             Part parts[HostPar::Scope::MAX_THREADS];
-            const int nparts_max = par.threads();
+            const int nparts_max = simd ? 1 : par.threads();
             for (int q = 0; q < nparts_max; q++) parts[q] = Part{kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+            if (simd) {
+                uint32_t o6[6][4];
+                gkr_host_round_sums(soa[side].data(), soa_stride, eq_soa[niv - j].data(), eq_plane_stride(niv - j), real_pairs, o6);
+                Ext* dstp[6] = {&parts[0].x0, &parts[0].y0, &parts[0].xh, &parts[0].yh, &parts[0].e0, &parts[0].es};
+                for (int q = 0; q < 6; q++) memcpy(dstp[q]->c, o6[q], 16);
+            } else
             par.run(real_pairs, 24, [&](int part, size_t kb0, size_t ke) {
                 Part acc = parts[part];
                 for (size_t k = kb0; k < ke; k++) {
@@ -1095,17 +1158,28 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             claim = poly_eval(poly, alpha_r);
             eq_scale = eq_scale * (pt * alpha_r + (one - pt) * (one - alpha_r));
             Ext *o0 = tab[side ^ 1][0]->data(), *o1 = tab[side ^ 1][1]->data(), *o2 = tab[side ^ 1][2]->data(), *o3 = tab[side ^ 1][3]->data();
+            if (simd) {
+                gkr_host_round_fold(soa[side].data(), soa[side ^ 1].data(), soa_stride, real_pairs, alpha_r.c);
+                if (real_pairs < half)                       // the entry behind the last real one is the padding fraction (0, 1) again
+                    for (int w = 0; w < 4; w++)
+                        for (int k = 0; k < 4; k++) soa[side ^ 1][(size_t)(4 * w + k) * soa_stride + real_pairs] = (w & 1) && k == 0 ? one.c[0] : 0u;
+            } else
             par.run(real_pairs, 48, [&](int, size_t kb0, size_t ke) {
                 for (size_t k = kb0; k < ke; k++) {
                     o0[k] = n0[2 * k] + alpha_r * (n0[2 * k + 1] - n0[2 * k]); o1[k] = d0[2 * k] + alpha_r * (d0[2 * k + 1] - d0[2 * k]);
                     o2[k] = n1[2 * k] + alpha_r * (n1[2 * k + 1] - n1[2 * k]); o3[k] = d1[2 * k] + alpha_r * (d1[2 * k + 1] - d1[2 * k]);
                 }
             });
-            if (real_pairs < half) { o0[real_pairs] = kb::ext_zero(); o1[real_pairs] = one; o2[real_pairs] = kb::ext_zero(); o3[real_pairs] = one; }
+            if (!simd && real_pairs < half) { o0[real_pairs] = kb::ext_zero(); o1[real_pairs] = one; o2[real_pairs] = kb::ext_zero(); o3[real_pairs] = one; }
             real = real_pairs;
             side ^= 1;
         }
-        const Ext fin_n0 = (*tab[side][0])[0], fin_d0 = (*tab[side][1])[0], fin_n1 = (*tab[side][2])[0], fin_d1 = (*tab[side][3])[0];
+        Ext fin_n0 = (*tab[side][0])[0], fin_d0 = (*tab[side][1])[0], fin_n1 = (*tab[side][2])[0], fin_d1 = (*tab[side][3])[0];
+        if (simd) {
+            Ext* f[4] = {&fin_n0, &fin_d0, &fin_n1, &fin_d1};
+            for (int w = 0; w < 4; w++)
+                for (int k = 0; k < 4; k++) f[w]->c[k] = soa[side][(size_t)(4 * w + k) * soa_stride];
+        }
         if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_int += std::chrono::duration<double, std::milli>(now - dbg_t).count(); dbg_t = now; }
         ro.eval = claim;
         ro.point.assign(alphas.rbegin(), alphas.rend());

@@ -183,7 +183,7 @@ struct RoundSyncHost {
 // stream before the fetch has completed (in-order stream), so host staging buffers handed to earlier
 // hipMemcpyAsync calls may be reused. Measured against the copy + synchronise pair this saves ~30-50 us per
 // round trip (no blit dispatch on completion, no interrupt wake-up); a shard proof has ~170 of them outside GKR.
-constexpr uint32_t MAILBOX_WORDS = 16384;       // payload capacity (64 KiB)
+constexpr uint32_t MAILBOX_WORDS = 16384 + 32;  // payload capacity (64 KiB + room for a 16-byte aligned start, wait_next)
 
 int mailbox_publish(const uint32_t* d_src, uint32_t n_words, uint32_t* h_slot, uint32_t seq, hipStream_t s);   // runtime.hip
 
@@ -220,7 +220,8 @@ struct Mailbox {
     }
     // For kernels that write the slot themselves (payload words [1 ..], then `seq + 1` into word 0): waits for
     // that sequence number and copies the payload out.
-    int wait_next(void* out, size_t n_words) {
+    // first_word: where the kernel put the payload (4 for kernels that store 16-byte vectors: word 1 is not aligned).
+    int wait_next(void* out, size_t n_words, size_t first_word = 1) {
         seq++;
         pending = true;
         volatile uint32_t* slot = h_slot;
@@ -239,7 +240,7 @@ struct Mailbox {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         pending = false;
         uint32_t* o = (uint32_t*)out;
-        for (size_t k = 0; k < n_words; k++) o[k] = slot[1 + k];
+        for (size_t k = 0; k < n_words; k++) o[k] = slot[first_word + k];
         return SP1HIP_SUCCESS;
     }
 };

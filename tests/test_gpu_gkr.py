@@ -72,6 +72,22 @@ def test_gkr_small_pass_forms_give_the_same_bytes(api, monkeypatch, n_tuples, L,
     assert np.array_equal(g_ch.state(), o_ch.state())
 
 
+@pytest.mark.parametrize("n_tuples,L,with_empty,dup", [(5, 4, True, 3), (37, 7, True, 3), (300, 10, True, 3), (1300, 12, True, 3)])
+def test_gkr_scalar_host_rounds_give_the_same_bytes(api, monkeypatch, n_tuples, L, with_empty, dup):
+    """The interaction-variable rounds run in AVX-512 on the host where the CPU has it (gkr_host.cpp; the other GPU tests);
+    SP1HIP_HOST_SIMD=0 forces the scalar rounds on the helper threads — the path of CPUs without AVX-512."""
+    monkeypatch.setenv("SP1HIP_HOST_SIMD", "0")
+    chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    seed = orc.random_felts((9,), L)
+    o_ch.observe(seed)
+    g_ch.observe(seed)
+    want = orc.gkr_prove(chips, L, o_ch)
+    got = api.logup_gkr(_dev(api, chips), L, g_ch)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_gkr_rejects_unsorted_chips_and_keeps_transcript(api):
     chips = make_gkr_chips(4, 3)
     dev = _dev(api, chips)
