@@ -131,6 +131,15 @@ __device__ __forceinline__ void block_reduce_store(const Ext& a, const Ext& b, u
     }
 }
 
+// The end of every round kernel of this file: the two extension sums of the round go through the last-workgroup hand-over
+// of round_sync.hpp (rs_finish: coherent partial stores, ticket, the last workgroup totals and publishes to mapped host
+// memory) — the one-workgroup reduce kernel that used to follow each of the ~120 round launches of a proof is gone.
+struct JgTail { uint32_t* partials; RoundSync rs; uint32_t seq; };
+__device__ __forceinline__ void jg_finish(const Ext& a, const Ext& b, const JgTail& t) {
+    const Ext acc[2] = {a, b};
+    rs_finish<2>(acc, t.partials, blockIdx.x, gridDim.x, t.rs, t.seq);
+}
+
 // Sums the block partials and hands the two ext sums to the host through the mailbox slot (round_sync.hpp): payload
 // words [1..8], then the sequence number — no copy, no stream synchronise.
 __global__ __launch_bounds__(256) void jg_reduce_partials(const uint32_t* __restrict__ partials, uint32_t n,
@@ -161,7 +170,7 @@ __device__ __forceinline__ Ext jg_row_eq(const JgJ& J, uint32_t row) {
 }
 // Lanes take CONSECUTIVE pairs (coalesced 8 B of q and 2 x 4 planes of eq_row per lane) and step by 256 pairs,
 // so a lane stays inside one column for many steps and keeps that column's sums un-multiplied.
-__global__ __launch_bounds__(256) void jg_round0_sum(JgSegs S, JgJ J, uint32_t n_pairs, uint32_t* __restrict__ partials) {
+__global__ __launch_bounds__(256) void jg_round0_sum(JgSegs S, JgJ J, uint32_t n_pairs, JgTail tail) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 256 * JG_ITERS < n_pairs; chunk += gridDim.x) {
         uint32_t c = 0, col_end = 0;
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void jg_round0_sum(JgSegs S, JgJ J, uint32_t n
             eh = kb::ext_add(eh, kb::ext_mul(w, ah));
         }
     }
-    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+    jg_finish(e0, eh, tail);
 }
 
 // ---- round 0, table-major form (every table height even, so dense pairs are row pairs (2k, 2k+1) of one column).
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256) void jg_round0_sum(JgSegs S, JgJ J, uint32_t n
 struct JgTab { const uint32_t* q; uint32_t height, col0, ncols, tile0, x0, tile1, tile2; };   // q: the table's first column in the dense buffer; x0: its dense index; tile0/1/2: first tile in the round-0 / one-level / two-level fold launches
 constexpr uint32_t JG_TAB_PAIRS = 256;                                       // row pairs per tile
 __global__ __launch_bounds__(256) void jg_round0_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles,
-                                                        JgJ J, uint32_t* __restrict__ partials) {
+                                                        JgJ J, JgTail tail) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         uint32_t lo = 0, hi = n_tabs;                     // last table with tile0 <= tile
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256) void jg_round0_tables(const JgTab* __restrict_
         e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
         eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
     }
-    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+    jg_finish(e0, eh, tail);
 }
 
 __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& alpha) {   // a + alpha (b - a)
@@ -261,7 +270,7 @@ __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& a
 template <int LEVELS, bool STORE>
 __global__ __launch_bounds__(256) void jg_fold_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles, JgJ Jl,
                                                       const Ext* __restrict__ col_eq3, Ext alpha0, Ext alpha1, Ext* __restrict__ q_out,
-                                                      uint32_t* __restrict__ partials) {
+                                                      JgTail tail) {
     constexpr uint32_t SPAN = 2u << LEVELS;               // base rows per lane and column
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void jg_fold_tables(const JgTab* __restrict__ 
         e0 = kb::ext_add(e0, kb::ext_mul(r0, kb::dot_finish(u0)));
         eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
     }
-    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+    jg_finish(e0, eh, tail);
 }
 
 // ---- first fold (base q, recomputed J) fused with the next round's sums. One step of a thread: inputs 4k..4k+3,
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(256) void jg_fold_tables(const JgTab* __restrict__ 
 // WRITE_J = false when the next level keeps J factored (jg_foldf_sum): the 16 B/entry j table is never materialised.
 template <bool WRITE_J>
 __global__ __launch_bounds__(256) void jg_fold0_sum(JgSegs S, JgJ J, Ext alpha, uint32_t n_out, Ext* __restrict__ q_out,
-                                                    Ext* __restrict__ j_out, uint32_t* __restrict__ partials) {
+                                                    Ext* __restrict__ j_out, JgTail tail) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     const uint32_t n_thr = (n_out + 1) / 2;
     for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 256 * JG_ITERS < n_thr; chunk += gridDim.x) {
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(256) void jg_fold0_sum(JgSegs S, JgJ J, Ext alpha, 
             eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(jo[0], jo[1]), kb::ext_add(qo[0], qo[1])));
         }
     }
-    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+    jg_finish(e0, eh, tail);
 }
 
 // ---- folds that keep J factored. While every column starts at a multiple of 2^r in the dense order (chip heights
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256) void jg_fold_row_eq(const uint32_t* __restrict
 
 // q_in: level r-1 (n_in live entries); J: level r (prefix >> r, eq_row_r); writes q_out = level r (n_out entries)
 __global__ __launch_bounds__(256) void jg_foldf_sum(const Ext* __restrict__ q_in, uint32_t n_in, JgJ J, Ext alpha, uint32_t n_out,
-                                                    Ext* __restrict__ q_out, uint32_t* __restrict__ partials) {
+                                                    Ext* __restrict__ q_out, JgTail tail) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     const uint32_t n_pairs = (n_out + 1) / 2;
     for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 256 * JG_ITERS < n_pairs; chunk += gridDim.x) {
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(256) void jg_foldf_sum(const Ext* __restrict__ q_in
             eh = kb::ext_add(eh, kb::ext_mul(w, ah));
         }
     }
-    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+    jg_finish(e0, eh, tail);
 }
 
 // j_out[x] = eq_col[c] * eq_row_r[x - prefix_r[c]] for the n entries of level r (leaving the factored form)
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(256) void jg_materialize_j(JgJ J, uint32_t n, Ext* 
 // ---- later folds: ext tables with n_in live entries -> n_out = ceil(n_in / 2), fused with the sums
 __global__ __launch_bounds__(256) void jg_fold_sum(const Ext* __restrict__ q_in, const Ext* __restrict__ j_in, uint32_t n_in,
                                                    Ext alpha, uint32_t n_out, Ext* __restrict__ q_out, Ext* __restrict__ j_out,
-                                                   uint32_t* __restrict__ partials) {
+                                                   JgTail tail) {
     Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
     const uint32_t n_thr = (n_out + 1) / 2;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_thr; k += gridDim.x * blockDim.x) {
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(256) void jg_fold_sum(const Ext* __restrict__ q_in,
         e0 = kb::ext_add(e0, kb::ext_mul(jo[0], qo[0]));
         eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(jo[0], jo[1]), kb::ext_add(qo[0], qo[1])));
     }
-    block_reduce_store(e0, eh, partials + 8 * blockIdx.x);
+    jg_finish(e0, eh, tail);
 }
 
 // ================================================================ jagged-eval sumcheck
@@ -511,7 +520,7 @@ __device__ __forceinline__ Ext dot4(const Ext (&a)[4], const Ext (&b)[4]) {
 // Also accumulates sum_k zcol[k] * suffix[0][k][initial state] into out8[0..3] (full J evaluation).
 template <bool PAIR>
 __global__ __launch_bounds__(256) void je_suffix_kernel(JeCols C, const Ext* __restrict__ mats, int D, Ext* __restrict__ suffix,
-                                                        uint32_t* __restrict__ partials) {
+                                                        JgTail tail) {
     Ext total = kb::ext_zero();
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < C.n; k += gridDim.x * blockDim.x) {
         const uint32_t t = C.t[k], u = C.u[k];
@@ -526,14 +535,14 @@ __global__ __launch_bounds__(256) void je_suffix_kernel(JeCols C, const Ext* __r
         }
         total = kb::ext_add(total, kb::ext_mul(ld_ext(C.zcol, k), s[0]));
     }
-    block_reduce_store(total, kb::ext_zero(), partials + 8 * blockIdx.x);
+    jg_finish(total, kb::ext_zero(), tail);
 }
 
 // One round of the first half (variable = bit r of t_{c+1}). state[k] = {v0[4], v1[4]} of the previous
 // round, inter[k] = eq accumulator. first: r == 0.
 __global__ __launch_bounds__(256) void je_phase1_round(JeCols C, const Ext* __restrict__ mats, const Ext* __restrict__ suffix, int D,
                                                        int r, Ext alpha_prev, Ext half, Ext* __restrict__ state,
-                                                       Ext* __restrict__ inter, uint32_t* __restrict__ partials) {
+                                                       Ext* __restrict__ inter, JgTail tail) {
     Ext y0 = kb::ext_zero(), yh = kb::ext_zero();
     const Ext one = kb::ext_one();
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < C.n; k += gridDim.x * blockDim.x) {
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(256) void je_phase1_round(JeCols C, const Ext* __re
         if (!((u >> r) & 1u)) y0 = kb::ext_add(y0, kb::ext_mul(f, bp0));
         yh = kb::ext_add(yh, kb::ext_mul(kb::ext_mul(f, half), kb::ext_mul(kb::ext_add(bp0, bp1), half)));
     }
-    block_reduce_store(y0, yh, partials + 8 * blockIdx.x);
+    jg_finish(y0, yh, tail);
 }
 
 // One round of the second half (variable = bit rp of t_c; every bit of t_{c+1} is bound). V0 / V1: the
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(256) void je_phase1_round(JeCols C, const Ext* __re
 struct JeV { Ext v[8]; };          // the two prefix row vectors of a phase-2 round, passed by value (128 B of kernarg)
 __global__ __launch_bounds__(256) void je_phase2_round(JeCols C, const Ext* __restrict__ suffix2, int D, int rp, Ext alpha_prev,
                                                        Ext half, JeV V, Ext* __restrict__ inter,
-                                                       uint32_t* __restrict__ partials) {
+                                                       JgTail tail) {
     Ext y0 = kb::ext_zero(), yh = kb::ext_zero();
     const Ext one = kb::ext_one();
     Ext v0[4], v1[4];
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(256) void je_phase2_round(JeCols C, const Ext* __re
         if (!((t >> rp) & 1u)) y0 = kb::ext_add(y0, kb::ext_mul(f, bp0));
         yh = kb::ext_add(yh, kb::ext_mul(kb::ext_mul(f, half), kb::ext_mul(kb::ext_add(bp0, bp1), half)));
     }
-    block_reduce_store(y0, yh, partials + 8 * blockIdx.x);
+    jg_finish(y0, yh, tail);
 }
 
 // ================================================================ host driver
@@ -661,6 +670,7 @@ Ext observe_and_sample(sp1hip_challenger_t* ch, const std::array<Ext, 3>& poly) 
 
 struct Scratch {                    // device scratch shared by all rounds of one proof
     DeviceBuf partials;
+    RoundSyncHost rsync;
     Mailbox mb;
     PinnedStage stage;
     uint32_t h_out[8];
@@ -670,14 +680,16 @@ struct Scratch {                    // device scratch shared by all rounds of on
         s = stream;
         SP1HIP_TRY(partials.alloc((size_t)MAX_BLOCKS * 32, s));
         SP1HIP_TRY(stage.init(s));
+        SP1HIP_TRY(rsync.init(s));
         return mb.init(s);
     }
+    // argument of the round kernel about to be launched (one per launch: it advances the sequence number finish() waits for)
+    JgTail tail() { const RoundSync rs = rsync.next(); return JgTail{partials.u32(), rs, rsync.seq}; }
     static uint32_t blocks_for(uint64_t threads) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), MAX_BLOCKS); }
     // reduce `nb` block partials and bring the two ext sums to the host
     int finish(uint32_t nb, Ext* a, Ext* b) {
-        hipLaunchKernelGGL(jg_reduce_partials, dim3(1), dim3(256), 0, s, partials.u32(), nb, (volatile uint32_t*)mb.h_slot, mb.seq + 1);
-        SP1HIP_LAUNCH_CHECK();
-        SP1HIP_TRY(mb.wait_next(h_out, 8));
+        (void)nb;
+        SP1HIP_TRY(rsync.wait(h_out, 8));
         memcpy(a, h_out, 16);
         memcpy(b, h_out + 4, 16);
         return SP1HIP_SUCCESS;
@@ -742,7 +754,7 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
     const uint32_t nb = Scratch::blocks_for(n);
 
     // all-boolean suffixes; their layer-0 entry gives the claimed J(z_trace) (full_jagged_little_polynomial_evaluation)
-    hipLaunchKernelGGL(je_suffix_kernel<true>, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_mats.p, D, (Ext*)d_suffix.p, sc.partials.u32());
+    hipLaunchKernelGGL(je_suffix_kernel<true>, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_mats.p, D, (Ext*)d_suffix.p, sc.tail());
     SP1HIP_LAUNCH_CHECK();
     Ext expected_sum, unused;
     SP1HIP_TRY(sc.finish(nb, &expected_sum, &unused));
@@ -755,7 +767,7 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
     std::array<Ext, 3> poly{};
     for (int r = 0; r < D; r++) {
         hipLaunchKernelGGL(je_phase1_round, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_mats.p, (const Ext*)d_suffix.p, D, r, alpha,
-                           half, (Ext*)d_state.p, (Ext*)d_inter.p, sc.partials.u32());
+                           half, (Ext*)d_state.p, (Ext*)d_inter.p, sc.tail());
         SP1HIP_LAUNCH_CHECK();
         Ext y0, yh;
         SP1HIP_TRY(sc.finish(nb, &y0, &yh));
@@ -776,7 +788,7 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
     DeviceBuf d_B, d_suffix2;
     SP1HIP_TRY(upload(d_B, B.data(), B.size() * 16, s, sc.stage));
     SP1HIP_TRY(d_suffix2.alloc((size_t)D * n * 64, s));
-    hipLaunchKernelGGL(je_suffix_kernel<false>, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_B.p, D, (Ext*)d_suffix2.p, sc.partials.u32());
+    hipLaunchKernelGGL(je_suffix_kernel<false>, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_B.p, D, (Ext*)d_suffix2.p, sc.tail());
     SP1HIP_LAUNCH_CHECK();
     Ext W[4] = {kb::ext_one(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};     // e_initial^T
     for (int rp = 0; rp < D; rp++) {
@@ -790,7 +802,7 @@ int jagged_eval_prove(const std::vector<uint32_t>& prefix, int log_m, const std:
         JeV Varg;
         memcpy(Varg.v, V, sizeof V);
         hipLaunchKernelGGL(je_phase2_round, dim3(nb), dim3(256), 0, s, C, (const Ext*)d_suffix2.p, D, rp, alpha, half,
-                           Varg, (Ext*)d_inter.p, sc.partials.u32());
+                           Varg, (Ext*)d_inter.p, sc.tail());
         SP1HIP_LAUNCH_CHECK();
         Ext y0, yh;
         SP1HIP_TRY(sc.finish(nb, &y0, &yh));
@@ -1026,10 +1038,10 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
             if (!tabs0.empty()) {
                 nb = Scratch::blocks_for((uint64_t)n_tiles0 * 256);
                 hipLaunchKernelGGL(jg_round0_tables, dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(), n_tiles0, J,
-                                   sc.partials.u32());
+                                   sc.tail());
             } else {
                 nb = Scratch::blocks_for((T / 2 + JG_ITERS - 1) / JG_ITERS);
-                hipLaunchKernelGGL(jg_round0_sum, dim3(nb), dim3(256), 0, s, segs, J, T / 2, sc.partials.u32());
+                hipLaunchKernelGGL(jg_round0_sum, dim3(nb), dim3(256), 0, s, segs, J, T / 2, sc.tail());
             }
         } else if (round == 1) {
             ScopedTimer t("jagged_fold0_sum", s);
@@ -1041,7 +1053,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                 if (skip_level1) {                         // sums only; round 2 folds from the base words again
                     nb = Scratch::blocks_for((uint64_t)n_tiles1 * 256);
                     hipLaunchKernelGGL((jg_fold_tables<1, false>), dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(),
-                                       n_tiles1, J1, (const Ext*)d_col_eq3.p, alpha, alpha, (Ext*)nullptr, sc.partials.u32());
+                                       n_tiles1, J1, (const Ext*)d_col_eq3.p, alpha, alpha, (Ext*)nullptr, sc.tail());
                 } else if (tables_mult4) {
                     // the kernel writes the real tables only: the zero tail of every round (its padding tables) must
                     // read as zero in the next fold
@@ -1049,14 +1061,14 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                         if (z.second > z.first) SP1HIP_HIP(hipMemsetAsync((Ext*)tabs[0].p + z.first / 2, 0, (size_t)((z.second - z.first) / 2) * 16, s));
                     nb = Scratch::blocks_for((uint64_t)n_tiles1 * 256);
                     hipLaunchKernelGGL((jg_fold_tables<1, true>), dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(),
-                                       n_tiles1, J1, (const Ext*)d_col_eq3.p, alpha, alpha, (Ext*)tabs[0].p, sc.partials.u32());
+                                       n_tiles1, J1, (const Ext*)d_col_eq3.p, alpha, alpha, (Ext*)tabs[0].p, sc.tail());
                 } else {
                     hipLaunchKernelGGL(jg_fold0_sum<false>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)nullptr,
-                                       sc.partials.u32());
+                                       sc.tail());
                 }
             } else {
                 hipLaunchKernelGGL(jg_fold0_sum<true>, dim3(nb), dim3(256), 0, s, segs, J, alpha, n_out, (Ext*)tabs[0].p, (Ext*)tabs[1].p,
-                                   sc.partials.u32());
+                                   sc.tail());
             }
             n_live = n_out;
             cur = 0;
@@ -1071,13 +1083,13 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                     if (z.second > z.first) SP1HIP_HIP(hipMemsetAsync((Ext*)tabs[nxt].p + z.first / 4, 0, (size_t)((z.second - z.first) / 4) * 16, s));
                 nb = Scratch::blocks_for((uint64_t)n_tiles2 * 256);
                 hipLaunchKernelGGL((jg_fold_tables<2, true>), dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(),
-                                   n_tiles2, Jl, (const Ext*)d_col_eq3.p, alphas[0], alpha, (Ext*)tabs[nxt].p, sc.partials.u32());
+                                   n_tiles2, Jl, (const Ext*)d_col_eq3.p, alphas[0], alpha, (Ext*)tabs[nxt].p, sc.tail());
             } else if (round <= rf) {                      // factored: level `round` from level `round - 1`
                 JgJ Jl;
                 SP1HIP_TRY(level_J(round, alpha, &Jl));
                 nb = Scratch::blocks_for(((n_out + 1) / 2 + JG_ITERS - 1) / JG_ITERS);
                 hipLaunchKernelGGL(jg_foldf_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, n_live, Jl, alpha, n_out,
-                                   (Ext*)tabs[nxt].p, sc.partials.u32());
+                                   (Ext*)tabs[nxt].p, sc.tail());
             } else {
                 if (!j_materialised) {                     // leave the factored form: j of level round - 1
                     const JgJ Jp{d_prefix_lv.u32() + (size_t)(round - 1) * prefix.size(), ncols, (const Ext*)d_col_eq.p, row_eq_cur, row_len_cur};
@@ -1089,7 +1101,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                 }
                 nb = Scratch::blocks_for((n_out + 1) / 2);
                 hipLaunchKernelGGL(jg_fold_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, (const Ext*)tabs[cur + 1].p, n_live,
-                                   alpha, n_out, (Ext*)tabs[nxt].p, (Ext*)tabs[nxt + 1].p, sc.partials.u32());
+                                   alpha, n_out, (Ext*)tabs[nxt].p, (Ext*)tabs[nxt + 1].p, sc.tail());
             }
             n_live = n_out;
             cur = nxt;

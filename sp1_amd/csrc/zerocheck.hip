@@ -1192,6 +1192,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         SP1HIP_TRY(d_fold[0].alloc(words[0] * 4, s));
         SP1HIP_TRY(d_fold[1].alloc(words[1] * 4, s));
     }
+    std::vector<UniPoly> uni;                                // the chips' round polynomials (5 coefficients each), reused every round
     for (int r = 0; r < L; r++) {
         const int nv = L - r;                       // variables left
         const Ext last = zeta[nv - 1];
@@ -1411,43 +1412,69 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         for (size_t k = 0; k < desc_chip.size(); k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + k * 16, 64);
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
-        // the interpolation nodes {0, 1, 2, 4, b} are the same for every chip of a round: build the five Lagrange
-        // basis polynomials once (exact field arithmetic: the result is the reference's interpolation, whatever the
-        // operation order) and combine them per chip — 25 extension products instead of a full interpolation each
-        const Ext two_c = ext_c(2), four_c = ext_c(4);
+        // (sum_as_poly interpolates through {0, 1, 2, 4, b} with the value at b equal to zero.) Closed form, no allocation: the
+        // Lagrange basis polynomial of node x_k in {0, 1, 2, 4} is C_k(X) (X - b) / (x_k - b), with C_k the basis polynomial of
+        // x_k among those four nodes alone — constants of the field:
+        //   C_0 = (X^3 - 7 X^2 + 14 X - 8) / -8, C_1 = (X^3 - 6 X^2 + 8 X) / 3, C_2 = (X^3 - 5 X^2 + 4 X) / -4, C_3 = (X^3 - 3 X^2 + 2 X) / 24
+        // so a chip's univariate is (X - b) sum_k z_k C_k(X) with z_k = y_k / (x_k - b); the four inverses come from one
+        // inversion (Montgomery's trick). Exact field arithmetic: the same polynomial as any other interpolation.
+        static const struct CubicBasis {
+            uint32_t c[4][4];                                     // c[k][d]: coefficient of X^d in C_k (Montgomery base words)
+            CubicBasis() {
+                const int num[4][4] = {{-8, 14, -7, 1}, {0, 8, -6, 1}, {0, 4, -5, 1}, {0, 2, -3, 1}};
+                const int den[4] = {-8, 3, -4, 24};
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t dm = kb::to_monty(den[k] < 0 ? kb::P - (uint32_t)(-den[k]) : (uint32_t)den[k]);
+                    const uint32_t dinv = kb::ext_inv(kb::ext_from_base(dm)).c[0];
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t nm = kb::to_monty(num[k][d] < 0 ? kb::P - (uint32_t)(-num[k][d]) : (uint32_t)num[k][d]);
+                        c[k][d] = kb::mul(nm, dinv);
+                    }
+                }
+            }
+        } cubic;
         const Ext b_node = (kb::ext_one() - last) * kb::ext_inv(kb::ext_one() - (last + last));
-        const std::vector<Ext> nodes{kb::ext_zero(), kb::ext_one(), two_c, four_c, b_node};
-        UniPoly basis[5];
-        for (int k = 0; k < 5; k++) {
-            std::vector<Ext> e(5, kb::ext_zero());
-            e[k] = kb::ext_one();
-            basis[k] = interpolate(nodes, e);
-            basis[k].resize(5, kb::ext_zero());
+        Ext inv_xb[4];                                            // 1 / (x_k - b), x = 0, 1, 2, 4
+        {
+            const Ext dx[4] = {kb::ext_zero() - b_node, kb::ext_one() - b_node, ext_c(2) - b_node, ext_c(4) - b_node};
+            const Ext p01 = dx[0] * dx[1], p012 = p01 * dx[2], p0123 = p012 * dx[3];
+            Ext run = kb::ext_inv(p0123);
+            inv_xb[3] = run * p012; run = run * dx[3];
+            inv_xb[2] = run * p01; run = run * dx[2];
+            inv_xb[1] = run * dx[0];
+            inv_xb[0] = run * dx[1];
         }
-        std::vector<UniPoly> uni(n_chips);
+        const Ext two = ext_c(2), four = ext_c(4), three = ext_c(3), seven = ext_c(7);
+        const Ext f0 = kb::ext_one() - last, f2 = last * three - kb::ext_one(), f4 = last * seven - three;
+        if ((int)uni.size() != n_chips) uni.assign(n_chips, UniPoly(5, kb::ext_zero()));
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
-            if (c.rows == 0) { uni[i] = UniPoly(5, kb::ext_zero()); continue; }
+            UniPoly& u = uni[i];
+            if (c.rows == 0) { for (auto& cf : u) cf = kb::ext_zero(); continue; }
             const size_t th = (size_t)((c.rows + 1) / 2) - 1;
             const Ext eq_th{{sums[i][12], sums[i][13], sums[i][14], sums[i][15]}};
             const Ext msb = c.eq_adj * eq_th;
             const Ext y0s{{sums[i][0], sums[i][1], sums[i][2], sums[i][3]}}, y2s{{sums[i][4], sums[i][5], sums[i][6], sums[i][7]}},
                 y4s{{sums[i][8], sums[i][9], sums[i][10], sums[i][11]}};
-            const Ext two = ext_c(2), four = ext_c(4), three = ext_c(3), seven = ext_c(7);
             const Ext v0 = c.vgeq.fix(kb::ext_zero()).at(th), v2 = c.vgeq.fix(two).at(th), v4 = c.vgeq.fix(four).at(th);
-            const Ext f0 = kb::ext_one() - last;
-            const Ext y0 = y0s * (f0 * c.eq_adj) - c.pad_adj * v0 * msb * f0;
-            const Ext f2 = last * three - kb::ext_one();
-            const Ext y2 = y2s * (f2 * c.eq_adj) - c.pad_adj * v2 * msb * f2;
-            const Ext f4 = last * seven - three;
-            const Ext y4 = y4s * (f4 * c.eq_adj) - c.pad_adj * v4 * msb * f4;
-            const Ext ys[4] = {y0, round_claims[i] - y0, y2, y4};          // the fifth value, at b, is zero
-            uni[i].assign(5, kb::ext_zero());
-            for (int d = 0; d < 5; d++)
-                for (int k = 0; k < 4; k++) uni[i][d] = uni[i][d] + ys[k] * basis[k][d];
+            const Ext pm = c.pad_adj * msb;
+            const Ext y0 = (y0s * c.eq_adj - pm * v0) * f0;
+            const Ext y2 = (y2s * c.eq_adj - pm * v2) * f2;
+            const Ext y4 = (y4s * c.eq_adj - pm * v4) * f4;
+            const Ext z[4] = {y0 * inv_xb[0], (round_claims[i] - y0) * inv_xb[1], y2 * inv_xb[2], y4 * inv_xb[3]};
+            Ext g[4];                                             // sum_k z_k C_k(X)
+            for (int d = 0; d < 4; d++) {
+                Ext acc = kb::ext_mul_base(z[0], cubic.c[0][d]);
+                for (int k = 1; k < 4; k++) acc = acc + kb::ext_mul_base(z[k], cubic.c[k][d]);
+                g[d] = acc;
+            }
+            u[0] = kb::ext_zero() - b_node * g[0];
+            for (int d = 1; d < 4; d++) u[d] = g[d - 1] - b_node * g[d];
+            u[4] = g[3];
         }
-        UniPoly rlc{kb::ext_zero()};
-        for (auto& u : uni) rlc = uni_add(uni_scale(rlc, lambda), u);
+        UniPoly rlc(n_chips ? 5 : 1, kb::ext_zero());
+        for (auto& u : uni)
+            for (int d = 0; d < 5; d++) rlc[d] = rlc[d] * lambda + u[d];
         for (auto& cf : rlc)
             for (int k = 0; k < 4; k++) challenger_observe(challenger, cf.c[k]);
         msgs.push_back(rlc);
