@@ -228,18 +228,24 @@ struct ByteWriter {
         }
     }
     void ext(const kb::Ext& e) { felts(e.c, 4); }
+    void canonical_words(const uint32_t* c, size_t n) {  // words the device has already taken out of Montgomery form
+        const size_t o = b.size();
+        b.resize(o + 4 * n);
+        memcpy(b.data() + o, c, 4 * n);
+    }
 };
 
-static void write_opening(ByteWriter& w, const std::vector<uint32_t>& values, size_t n_idx, size_t width,
-                          const uint32_t* root, size_t lg_h, const std::vector<uint32_t>& paths) {
-    w.u64(values.size());
-    w.felts(values.data(), values.size());
+// values / paths: CANONICAL words (the query phase converts the whole opening buffer on the device before it leaves)
+static void write_opening(ByteWriter& w, const uint32_t* values, size_t n_values, size_t n_idx, size_t width,
+                          const uint32_t* root, size_t lg_h, const uint32_t* paths, size_t n_paths) {
+    w.u64(n_values);
+    w.canonical_words(values, n_values);
     w.u64(2); w.u64(n_idx); w.u64(width);
     w.felts(root, 8);
     w.u64(lg_h);
     w.u64(width);
     w.u64(n_idx * lg_h);
-    w.felts(paths.data(), paths.size());
+    w.canonical_words(paths, n_paths);
     w.u64(2); w.u64(n_idx); w.u64(lg_h);
 }
 
@@ -431,22 +437,34 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
         SP1HIP_TRY(stage.upload(d_descs.p, descs.data(), descs.size() * sizeof(FoldOpenDesc)));
         SP1HIP_TRY(open_fold_rounds(reinterpret_cast<const FoldOpenDesc*>(d_descs.p), dim, dim + lb, d_idx.u32(), nq, d_open.u32(), s));
     }
-    std::vector<uint32_t> opened(std::max<size_t>(words, 1));
-    SP1HIP_TRY(mb.fetch(d_open.p, words, opened.data()));      // (its completion also covers the q upload above)
-    std::vector<uint32_t> vals, paths;
+    // The opening buffer leaves the device as CANONICAL words (one conversion launch instead of ~340k host reductions) and
+    // lands in a pinned block when it fits one (no pageable bounce, no stream synchronise: the mailbox fence below orders
+    // the host behind the copy).
+    SP1HIP_TRY(sp1hip_from_monty(d_open.u32(), words, (sp1hip_stream_t)s));
+    std::vector<uint32_t> opened_pageable;
+    PinnedBlock dl{nullptr};
+    struct Release { PinnedBlock* b; ~Release() { if (b->h) pinned_stage_release(*b); } } release{&dl};
+    const uint32_t* opened = nullptr;
+    if (words * 4 <= PINNED_STAGE_BYTES && pinned_stage_acquire(&dl) == SP1HIP_SUCCESS) {
+        SP1HIP_HIP(hipMemcpyAsync(dl.h, d_open.p, words * 4, hipMemcpyDeviceToHost, s));
+        SP1HIP_TRY(mb.fetch(nullptr, 0, nullptr));             // (its completion also covers the q upload above)
+        opened = reinterpret_cast<const uint32_t*>(dl.h);
+    } else {
+        dl.h = nullptr;
+        opened_pageable.resize(std::max<size_t>(words, 1));
+        SP1HIP_HIP(hipMemcpyAsync(opened_pageable.data(), d_open.p, words * 4, hipMemcpyDeviceToHost, s));
+        SP1HIP_HIP(hipStreamSynchronize(s));
+        opened = opened_pageable.data();
+    }
     w.u64((uint64_t)n_rounds);
     for (int r = 0; r < n_rounds; r++) {
         const Slot& sl = slots[r];
-        vals.assign(opened.begin() + sl.vals_off, opened.begin() + sl.vals_off + sl.n_vals);
-        paths.assign(opened.begin() + sl.paths_off, opened.begin() + sl.paths_off + sl.n_paths);
-        write_opening(w, vals, nq, rounds[r]->total_width, rounds[r]->root, (size_t)(dim + lb), paths);
+        write_opening(w, opened + sl.vals_off, sl.n_vals, nq, rounds[r]->total_width, rounds[r]->root, (size_t)(dim + lb), opened + sl.paths_off, sl.n_paths);
     }
     w.u64((uint64_t)dim);
     for (int r = 0; r < dim; r++) {
         const Slot& sl = slots[n_rounds + r];
-        vals.assign(opened.begin() + sl.vals_off, opened.begin() + sl.vals_off + sl.n_vals);
-        paths.assign(opened.begin() + sl.paths_off, opened.begin() + sl.paths_off + sl.n_paths);
-        write_opening(w, vals, nq, 8, round_roots[r].data(), (size_t)(dim + lb - r - 1), paths);
+        write_opening(w, opened + sl.vals_off, sl.n_vals, nq, 8, round_roots[r].data(), (size_t)(dim + lb - r - 1), opened + sl.paths_off, sl.n_paths);
     }
     w.ext(final_poly);
     w.felt(pow_witness);
