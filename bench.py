@@ -256,7 +256,7 @@ class GpuSampler:
 
 
 def in_flight(api, chips, area, L, lsh, n_proofs):
-    """The library's prover pool with 1, 2 and 3 slots on the SAME resident shard: throughput with N proofs in flight, the
+    """The library's prover pool with 1 to 4 slots on the SAME resident shard: throughput with N proofs in flight, the
     per-proof proving times in completion order, and the GPU's clock / power while each phase runs. Proofs are checked
     against `sp1hip_prove_shard_with_pk` called directly."""
     import torch
@@ -265,7 +265,7 @@ def in_flight(api, chips, area, L, lsh, n_proofs):
     want = pk.prove_shard(chips, [])
     torch.cuda.synchronize()
     out = {"proofs_per_phase": n_proofs, "slots": {}}
-    for n in (1, 2, 3):
+    for n in (1, 2, 3, 4):
         released = C.c_size_t()
         api.check(api._L().sp1hip_mem_trim(C.byref(released)))       # every phase starts from an empty arena and refills it in its warm-up
         pool = api.ProverPool(n)
