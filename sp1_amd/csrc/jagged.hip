@@ -848,6 +848,10 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     SP1HIP_REQUIRE(h_z_row && rounds && n_rounds > 0 && n_rounds <= 8 && claims_per_round && challenger && proof_len, "bad argument");
     SP1HIP_REQUIRE(max_log_row_count >= 0 && max_log_row_count <= 30, "max_log_row_count out of range");
     hipStream_t s = S(stream);
+    // SP1HIP_JG_TIMING=1: host wall time of the call's parts on stderr
+    const bool jg_timing = [] { const char* e = getenv("SP1HIP_JG_TIMING"); return e && e[0] == '1'; }();
+    std::chrono::steady_clock::time_point jg_t[7];
+    jg_t[0] = std::chrono::steady_clock::now();
     const int lsh = rounds[0]->log_stacking_height;
     SP1HIP_REQUIRE(lsh >= 1, "log_stacking_height must be at least 1");
     uint64_t total_cols = 0, total_area = 0, n_claims = 0;
@@ -1031,6 +1035,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     SP1HIP_TRY(tabs[2].alloc((size_t)std::max<uint32_t>((n1 + 1) / 2, 1) * 16, s));
     uint32_t n_live = T;               // live entries of the current round's tables
     int cur = 0;                       // tabs[cur] (and tabs[cur + 1] once materialised) hold (q, j) of the current level
+    jg_t[1] = std::chrono::steady_clock::now();
     for (int round = 0; round < log_m; round++) {
         uint32_t nb;
         if (round == 0) {
@@ -1137,8 +1142,10 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     const std::vector<Ext>& final_point = sumcheck.point;
 
     // ---- jagged-eval proof
+    jg_t[2] = std::chrono::steady_clock::now();
     Sumcheck jagged_eval;
     SP1HIP_TRY(jagged_eval_prove(prefix, log_m, z_row, z_col, final_point, ch, sc, &jagged_eval));
+    jg_t[3] = std::chrono::steady_clock::now();
 
     // ---- dense PCS: observe the claim, evaluate every stacked column at the stack point, BaseFold-open
     for (int k = 0; k < 4; k++) challenger_observe(ch, q_eval.c[k]);
@@ -1160,6 +1167,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
         bf.push_back(rounds[r]->basefold);
     }
     for (auto& e : flat_claims) for (int k = 0; k < 4; k++) challenger_observe(ch, e.c[k]);
+    jg_t[4] = std::chrono::steady_clock::now();
     std::vector<uint8_t> bf_blob(sp1hip_basefold_proof_size(lsh, round_widths.data(), n_rounds, config));
     size_t bf_len = bf_blob.size();
     SP1HIP_TRY(sp1hip_basefold_prove(reinterpret_cast<const sp1hip_ext_t*>(stack_point.data()), lsh, bf.data(), n_rounds,
@@ -1167,6 +1175,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                                      bf_blob.data(), &bf_len, stream));
 
     // ---- bincode(JaggedPcsProof)
+    jg_t[5] = std::chrono::steady_clock::now();
     Bytes w;
     w.b.assign(bf_blob.begin(), bf_blob.begin() + bf_len);
     w.u64(n_rounds);
@@ -1190,6 +1199,12 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     memcpy(h_proof, w.b.data(), w.b.size());
     *proof_len = w.b.size();
     challenger_restore(challenger, ch);
+    if (jg_timing) {
+        jg_t[6] = std::chrono::steady_clock::now();
+        const auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(jg_t[b] - jg_t[a]).count(); };
+        fprintf(stderr, "[sp1hip jagged] set-up %.3f ms | %d sumcheck rounds %.3f | jagged-eval %.3f | column evaluations %.3f | BaseFold %.3f | proof bytes %.3f\n",
+                ms(0, 1), log_m, ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5), ms(5, 6));
+    }
     return SP1HIP_SUCCESS;
 }
 

@@ -1066,6 +1066,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     hipStream_t s = S(stream);
     const DeviceCtx* ctx;
     SP1HIP_TRY(get_device_ctx(&ctx));
+    // SP1HIP_ZC_TIMING=1: host wall time of the call's three parts on stderr (set-up before the first round | rounds | proof)
+    const bool zc_timing = [] { const char* e = getenv("SP1HIP_ZC_TIMING"); return e && e[0] == '1'; }();
+    const auto zc_t0 = std::chrono::steady_clock::now();
+    auto zc_t1 = zc_t0, zc_t2 = zc_t0;
     const Ext alpha{{alpha_c.c[0], alpha_c.c[1], alpha_c.c[2], alpha_c.c[3]}};
     const Ext gkr{{gkr_c.c[0], gkr_c.c[1], gkr_c.c[2], gkr_c.c[3]}};
     std::vector<uint32_t> publics(h_publics, h_publics + n_publics);
@@ -1193,6 +1197,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         SP1HIP_TRY(d_fold[1].alloc(words[1] * 4, s));
     }
     std::vector<UniPoly> uni;                                // the chips' round polynomials (5 coefficients each), reused every round
+    zc_t1 = std::chrono::steady_clock::now();
     for (int r = 0; r < L; r++) {
         const int nv = L - r;                       // variables left
         const Ext last = zeta[nv - 1];
@@ -1504,6 +1509,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         for (int i = 0; i < n_chips; i++)
             if (st[i]->rows) st[i]->rows = (st[i]->rows + 1) / 2;
     }
+    zc_t2 = std::chrono::steady_clock::now();
     // ---- proof: PartialSumcheckProof + per-chip component evaluations (prep then main)
     ByteOut w;
     w.u64((uint64_t)L);
@@ -1560,6 +1566,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     if (w.b.size() != need) { set_error("internal error: zerocheck proof size %zu != %zu", w.b.size(), need); return SP1HIP_ERROR_RUNTIME; }
     memcpy(h_proof, w.b.data(), need);
     *proof_len = need;
+    if (zc_timing) {
+        const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[sp1hip zerocheck] set-up %.3f ms | %d rounds %.3f ms | openings + proof %.3f ms\n", ms(zc_t0, zc_t1), L, ms(zc_t1, zc_t2),
+                ms(zc_t2, std::chrono::steady_clock::now()));
+    }
     return SP1HIP_SUCCESS;
 }
 

@@ -38,6 +38,18 @@ __global__ __launch_bounds__(256) void tail_kernel(uint32_t* __restrict__ partia
     rs_finish<NS>(acc, partials, blockIdx.x, gridDim.x, rs, seq);
 }
 
+// The other hand-over of the library that crosses workgroups on the way to the HOST (gkr.hip, a layer's last fold): every
+// workgroup stores its rows straight into mapped host memory with system-scope stores, waits for their acknowledgement, takes
+// a ticket; the last one publishes the sequence number. The host must then see EVERY row.
+__global__ __launch_bounds__(256) void rows_kernel(uint32_t* host_rows, uint32_t n_rows, RoundSync rs, uint32_t seq) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < n_rows)
+        for (int k = 0; k < 16; k++) __hip_atomic_store(host_rows + (size_t)r * 16 + k, term_b(r, seq, k >> 2, k & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && rs_ticket_is_last(rs.counter, blockIdx.x, gridDim.x)) rs.host_slot[0] = seq;
+}
+
 template <int NS>
 static void launch(uint32_t grid, uint32_t* d_partials, RoundSync rs, uint32_t seq, uint32_t* d_bulk, uint32_t bulk_words) {
     hipLaunchKernelGGL(tail_kernel<NS>, dim3(grid), dim3(256), 0, 0, d_partials, rs, seq, d_bulk, bulk_words);
@@ -98,7 +110,35 @@ int main(int argc, char** argv) {
                 }
             }
     }
+    // ---- rows written by every workgroup straight to the host
+    long rows_wrong = 0, rows_launches = 0;
+    {
+        const uint32_t max_rows = 1024;
+        uint32_t *h_rows, *d_rows;
+        CHECK(hipHostMalloc(&h_rows, (size_t)(max_rows * 16 + 16) * 4, hipHostMallocMapped));
+        CHECK(hipHostGetDevicePointer((void**)&d_rows, h_rows, 0));
+        const uint32_t row_counts[] = {1, 7, 255, 256, 257, 730, 1024};
+        for (int it = 0; it < rounds; it++) {
+            const uint32_t n_rows = row_counts[it % 7];
+            ++seq;
+            // the sequence number goes to word 0 of the block, the rows start 16 words in
+            hipLaunchKernelGGL(rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, 0, d_rows + 16, n_rows,
+                               RoundSync{d_counter, (volatile uint32_t*)d_rows}, seq);
+            CHECK(hipGetLastError());
+            volatile uint32_t* slot = h_rows;
+            uint64_t spins = 0;
+            while (slot[0] != seq)
+                if ((++spins & 0xfffff) == 0 && hipStreamQuery(0) == hipSuccess && slot[0] != seq) { printf("rows: launch %u finished without publishing\n", seq); return 1; }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            for (uint32_t r = 0; r < n_rows; r++)
+                for (int k = 0; k < 16; k++)
+                    if (slot[16 + (size_t)r * 16 + k] != term_b(r, seq, k >> 2, k & 3)) { if (rows_wrong < 5) printf("WRONG ROW: launch %u row %u word %d\n", seq, r, k); rows_wrong++; }
+            rows_launches++;
+        }
+    }
     CHECK(hipDeviceSynchronize());
+    printf("direct rows: %ld launches, %ld wrong words\n", rows_launches, rows_wrong);
+    wrong += rows_wrong;
     std::vector<uint32_t> counters(RS_COUNTER_BYTES / 4);
     CHECK(hipMemcpy(counters.data(), d_counter, RS_COUNTER_BYTES, hipMemcpyDeviceToHost));
     long dirty = 0;
