@@ -756,6 +756,23 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     auto d_ptr = [&](int l, uint32_t i) -> Ext* { return lvD[l].ext() + off[l][i]; };
 
     mark("parse + level buffers");
+    // The pass descriptors (~10 MB at 730 interactions) go up on the caller's SIDE stream while the first layer and the
+    // fraction tree run: on `s` the copy sat between the last tree kernel and the first hand-over (0.2 ms of an idle GPU).
+    // Their buffer is taken from the arena HERE, before anything of this call is enqueued, and the side stream waits for
+    // this point of `s` — a recycled block's previous user is then out of the way (the arena orders reuse by stream).
+    const uint32_t FLAT_MAX_SLOTS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_SLOTS"); return e ? (uint32_t)atoi(e) : 65536u; }();   // read per call (tests)
+    size_t n_passes_total = 0;
+    for (int v = 1; v <= L - 1; v++) n_passes_total += (size_t)(v + 1) / 2 + 1;     // (0, .), the folds in pairs, the last fold
+    DeviceBuf d_all, d_flat;
+    SP1HIP_TRY(d_all.alloc(std::max<size_t>(n_passes_total * K, 1) * sizeof(PassDesc), s));
+    SP1HIP_TRY(d_flat.alloc((n_passes_total * (size_t)FLAT_MAX_SLOTS + 4) * sizeof(uint16_t), s));    // a flat pass indexes <= FLAT_MAX_SLOTS slots
+    hipStream_t side = nullptr;
+    hipEvent_t* side_ev = nullptr;
+    SP1HIP_TRY(aux_stream_for(s, 2, &side, &side_ev));
+    SP1HIP_HIP(hipEventRecord(side_ev[0], s));
+    SP1HIP_HIP(hipStreamWaitEvent(side, side_ev[0], 0));
+    PinnedStage side_stage;
+    SP1HIP_TRY(side_stage.init(side));
     // ---- first layer
     PinnedStage stage;                                       // small uploads (round_sync.hpp)
     SP1HIP_TRY(stage.init(s));
@@ -826,7 +843,6 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     struct PassShape { int fv, sv; bool first; uint32_t tiles, tile_size, total_slots; size_t flat_off; bool flat; };
     std::vector<PassShape> shapes;
     std::vector<uint16_t> flat_index;                        // FLAT launches: slot -> descriptor, all launches back to back
-    const uint32_t FLAT_MAX_SLOTS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_SLOTS"); return e ? (uint32_t)atoi(e) : 65536u; }();   // read per call (tests)
     // workgroups of a large pass. While every workgroup paid an L2 write-back and a serialised ticket in its tail
     // (round_sync.hpp) one resident set — 256 CUs x 4 workgroups — was the optimum; without them finer tiles balance the
     // tail better (sweep of round 2 on the one-round kernels: 4096 best, flat between 2048 and 8192).
@@ -881,12 +897,14 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         SP1HIP_TRY(d_partials.alloc((size_t)max_tiles * 160, s));
     }
     mark("pass descriptors planned");
-    DeviceBuf d_all;
-    SP1HIP_TRY(upload(d_all, all_descs.data(), all_descs.size() * sizeof(PassDesc), s, stage));     // all_descs outlives the copy
-    DeviceBuf d_flat;
+    SP1HIP_REQUIRE(all_descs.size() == n_passes_total * K, "internal error: pass count");
+    SP1HIP_TRY(side_stage.upload(d_all.p, all_descs.data(), all_descs.size() * sizeof(PassDesc)));
     if (flat_index.empty()) flat_index.push_back(0);
     flat_index.resize((flat_index.size() + 1) / 2 * 2);
-    SP1HIP_TRY(upload(d_flat, flat_index.data(), flat_index.size() * sizeof(uint16_t), s, stage));
+    SP1HIP_REQUIRE(flat_index.size() * sizeof(uint16_t) <= d_flat.n, "internal error: flat index size");
+    SP1HIP_TRY(side_stage.upload(d_flat.p, flat_index.data(), flat_index.size() * sizeof(uint16_t)));
+    SP1HIP_HIP(hipEventRecord(side_ev[1], side));
+    SP1HIP_HIP(hipStreamWaitEvent(s, side_ev[1], 0));        // (enqueued behind the tree: the copies have long finished by then)
     mark("pass descriptors uploaded");
     // ---- circuit output = level 1 (<= 2 rows per interaction): index 2 i + r, padding (0, 1)
     std::vector<Ext> out_n(2 * (size_t)W, kb::ext_zero()), out_d(2 * (size_t)W, kb::ext_one());
