@@ -32,6 +32,7 @@ struct ZcFixDesc {
     const uint32_t* in;
     uint32_t* out;
     uint32_t rows, width, block_start, n_blocks;
+    uint32_t bpc, bpc_magic;        // workgroups per column = ceil(out_rows / 256), and floor(2^32 / bpc) for the division by it
 };
 
 // Table pointers reach the kernels inside descriptors read from memory, so the compiler only knows them as generic
