@@ -19,6 +19,7 @@
 #include <atomic>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -540,8 +541,15 @@ int sp1hip_challenger_state(const sp1hip_challenger_t* ch, uint32_t* out34) {
     return SP1HIP_SUCCESS;
 }
 
-int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg_blowup, uint32_t h_commit[8],
-                       sp1hip_basefold_data_t** out, sp1hip_stream_t stream) {
+}  // extern "C"
+
+namespace sp1hip {
+// sp1hip_commit_mles with a hook: `before_encode(i, stream)` is called right before message i is encoded, on the stream
+// that encodes it — the stacked commit fills message i's slice of its dense buffer there (stacked.hip), so that with the
+// encodes on the side stream the 1.6 GB of table -> dense copies of a core shard run under the leaf hashes of the
+// previous messages instead of in front of the whole commitment.
+int commit_mles_hooked(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg_blowup, uint32_t h_commit[8],
+                       sp1hip_basefold_data_t** out, sp1hip_stream_t stream, const std::function<int(int, hipStream_t)>* before_encode) {
     SP1HIP_REQUIRE(mles && n_mles > 0 && out && h_commit, "bad argument");
     SP1HIP_REQUIRE(lg_n >= 0 && lg_blowup >= 0 && lg_n + lg_blowup <= kb::TWO_ADICITY, "size out of range");
     hipStream_t s = S(stream);
@@ -590,6 +598,7 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
         {
             Join join{aux};
             for (int i = 0; i < n_mles; i++) {
+                if (before_encode) SP1HIP_TRY((*before_encode)(i, aux));
                 SP1HIP_TRY(sp1hip_rs_encode_batch(pd->cws[i]->u32(), mles[i].d_data, lg_n, lg_blowup, mles[i].width, aux));
                 SP1HIP_HIP(hipEventRecord(ev[i], aux));
             }
@@ -610,8 +619,10 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
         *out = pd.release();
         return SP1HIP_SUCCESS;
     }
-    for (int i = 0; i < n_mles; i++)
+    for (int i = 0; i < n_mles; i++) {
+        if (before_encode) SP1HIP_TRY((*before_encode)(i, s));
         SP1HIP_TRY(sp1hip_rs_encode_batch(pd->cws[i]->u32(), mles[i].d_data, lg_n, lg_blowup, mles[i].width, s));
+    }
     SP1HIP_TRY(sp1hip_merkle_commit(pd->cw_tensors.data(), n_mles, lg_h, pd->tree.u32(), rc.u32(), s));
     uint32_t h[16];
     Mailbox mb;
@@ -622,6 +633,14 @@ int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
     memcpy(h_commit, pd->commit, 32);
     *out = pd.release();
     return SP1HIP_SUCCESS;
+}
+}  // namespace sp1hip
+
+extern "C" {
+
+int sp1hip_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg_blowup, uint32_t h_commit[8],
+                       sp1hip_basefold_data_t** out, sp1hip_stream_t stream) {
+    return commit_mles_hooked(mles, n_mles, lg_n, lg_blowup, h_commit, out, stream, nullptr);
 }
 
 void sp1hip_basefold_data_free(sp1hip_basefold_data_t* data) { delete data; }

@@ -12,12 +12,19 @@
 // buffer (no interleave kernel, no second copy).
 #include <cstring>
 #include <memory>
+#include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "device_ctx.hpp"
 #include "stacked_data.hpp"
 
 using namespace sp1hip;
+
+namespace sp1hip {     // prover.hip
+int commit_mles_hooked(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg_blowup, uint32_t h_commit[8],
+                       sp1hip_basefold_data_t** out, sp1hip_stream_t stream, const std::function<int(int, hipStream_t)>* before_encode);
+}
 
 namespace {
 // PaddingFreeSponge on the host (metadata hashes: a handful of permutations)
@@ -66,13 +73,22 @@ int sp1hip_stacked_commit(const sp1hip_table_t* tables, int n_tables, int log_st
     sd->padded = padded;
     sd->log_stacking_height = log_stacking_height;
     SP1HIP_TRY(arena_alloc(&sd->d_dense, padded * 4, s));
-    uint64_t off = 0;
-    for (int i = 0; i < n_tables; i++) {
-        const uint64_t n = tables[i].rows * (uint64_t)tables[i].cols;
-        if (n) SP1HIP_HIP(hipMemcpyAsync((uint32_t*)sd->d_dense + off, tables[i].d_data, n * 4, hipMemcpyDeviceToDevice, s));
-        off += n;
-    }
+    // The tables are concatenated into the dense buffer batch by batch, each batch right before ITS encode and on the stream
+    // that encodes it (commit_mles_hooked): with the encodes on the side stream the copies (1.6 GB of a core shard, 0.7 ms
+    // of HBM time) run under the VALU-bound leaf hashes of the batches before instead of in front of the commitment.
+    std::vector<uint64_t> table_off(n_tables + 1, 0);
+    for (int i = 0; i < n_tables; i++) table_off[i + 1] = table_off[i] + tables[i].rows * (uint64_t)tables[i].cols;
     if (padded > area) SP1HIP_HIP(hipMemsetAsync((uint32_t*)sd->d_dense + area, 0, (padded - area) * 4, s));
+    uint32_t* const dense = (uint32_t*)sd->d_dense;
+    const uint64_t batch_words = (uint64_t)batch_size * H;
+    const std::function<int(int, hipStream_t)> fill_batch = [&](int b, hipStream_t on) -> int {
+        const uint64_t lo = (uint64_t)b * batch_words, hi = std::min<uint64_t>(lo + batch_words, area);
+        for (int i = 0; i < n_tables && lo < hi; i++) {
+            const uint64_t a = std::max(lo, table_off[i]), e = std::min(hi, table_off[i + 1]);
+            if (a < e) SP1HIP_HIP(hipMemcpyAsync(dense + a, tables[i].d_data + (a - table_off[i]), (e - a) * 4, hipMemcpyDeviceToDevice, on));
+        }
+        return SP1HIP_SUCCESS;
+    };
     const uint64_t ncols = area == 0 ? 0 : padded / H;
     // an empty message yields ONE zero-width batch, as the reference's interleave does (fixed_rate.rs:L38-L44)
     if (ncols == 0) sd->batches.push_back({(const uint32_t*)sd->d_dense, 0u});
@@ -81,8 +97,8 @@ int sp1hip_stacked_commit(const sp1hip_table_t* tables, int n_tables, int log_st
         sd->batches.push_back({(const uint32_t*)sd->d_dense + c0 * H, w});
     }
     SP1HIP_REQUIRE(sd->batches.size() <= 128, "more than 128 stacked batches in one commitment");
-    SP1HIP_TRY(sp1hip_commit_mles(sd->batches.data(), (int)sd->batches.size(), log_stacking_height, lg_blowup, sd->commit,
-                                  &sd->basefold, stream));
+    SP1HIP_TRY(commit_mles_hooked(sd->batches.data(), (int)sd->batches.size(), log_stacking_height, lg_blowup, sd->commit,
+                                  &sd->basefold, stream, &fill_batch));
     memcpy(h_commit, sd->commit, 32);
     if (num_added_vals) *num_added_vals = padded - area;
     *out = sd.release();
