@@ -633,10 +633,13 @@ Ext eval_ext_mle_host(const std::vector<Ext>& vals, const std::vector<Ext>& pt) 
     return acc;
 }
 
-struct Bytes {
-    std::vector<uint8_t> b;
-    void u64(uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
-    void felt(uint32_t m) { const uint32_t v = kb::from_monty(m); for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+struct Bytes {                     // bincode writer over the caller's proof buffer
+    uint8_t* p = nullptr;
+    size_t cap = 0, n = 0;
+    bool overflow = false;
+    void raw(const void* src, size_t k) { if (n + k > cap) { overflow = true; return; } memcpy(p + n, src, k); n += k; }
+    void u64(uint64_t v) { raw(&v, 8); }               // little-endian host
+    void felt(uint32_t m) { const uint32_t v = kb::from_monty(m); raw(&v, 4); }
     void ext(const Ext& e) { for (int k = 0; k < 4; k++) felt(e.c[k]); }
 };
 
@@ -1168,16 +1171,18 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     }
     for (auto& e : flat_claims) for (int k = 0; k < 4; k++) challenger_observe(ch, e.c[k]);
     jg_t[4] = std::chrono::steady_clock::now();
-    std::vector<uint8_t> bf_blob(sp1hip_basefold_proof_size(lsh, round_widths.data(), n_rounds, config));
-    size_t bf_len = bf_blob.size();
+    // the BaseFold proof is the first field of JaggedPcsProof: it is written straight into the caller's buffer, the rest behind it
+    size_t bf_len = need;
     SP1HIP_TRY(sp1hip_basefold_prove(reinterpret_cast<const sp1hip_ext_t*>(stack_point.data()), lsh, bf.data(), n_rounds,
                                      reinterpret_cast<const sp1hip_ext_t*>(flat_claims.data()), flat_claims.size(), config, ch,
-                                     bf_blob.data(), &bf_len, stream));
+                                     h_proof, &bf_len, stream));
 
     // ---- bincode(JaggedPcsProof)
     jg_t[5] = std::chrono::steady_clock::now();
     Bytes w;
-    w.b.assign(bf_blob.begin(), bf_blob.begin() + bf_len);
+    w.p = h_proof;
+    w.cap = need;
+    w.n = bf_len;
     w.u64(n_rounds);
     for (auto& ev : batch_evals) { w.u64(ev.size()); for (auto& e : ev) w.ext(e); w.u64(1); w.u64(ev.size()); }
     sumcheck.write(w);
@@ -1192,12 +1197,11 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     w.ext(q_eval);
     w.u64(max_log_row_count);
     w.u64(log_m);
-    if (w.b.size() != need) {
-        set_error("internal error: jagged proof size %zu != expected %zu", w.b.size(), need);
+    if (w.overflow || w.n != need) {
+        set_error("internal error: jagged proof size %zu != expected %zu", w.n, need);
         return SP1HIP_ERROR_RUNTIME;
     }
-    memcpy(h_proof, w.b.data(), w.b.size());
-    *proof_len = w.b.size();
+    *proof_len = w.n;
     challenger_restore(challenger, ch);
     if (jg_timing) {
         jg_t[6] = std::chrono::steady_clock::now();

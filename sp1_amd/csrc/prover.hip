@@ -214,25 +214,32 @@ void challenger_import(sp1hip_challenger_t* ch, const uint32_t* w) {
     ch->ch.n_out = (int)w[33];
 }
 
+// bincode writer straight into the caller's proof buffer (the BaseFold proof of a core shard is 1.4 MB: building it in a
+// vector and copying it out — here, then again in the jagged and the shard wrappers — was five copies of it per proof)
 struct ByteWriter {
-    std::vector<uint8_t> b;
-    void u64(uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
-    void u32(uint32_t v) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+    uint8_t* p = nullptr;
+    size_t cap = 0, n = 0;
+    bool overflow = false;
+    uint8_t* take(size_t k) {
+        if (n + k > cap) { overflow = true; return nullptr; }
+        uint8_t* q = p + n;
+        n += k;
+        return q;
+    }
+    void u64(uint64_t v) { if (uint8_t* q = take(8)) memcpy(q, &v, 8); }      // little-endian host
+    void u32(uint32_t v) { if (uint8_t* q = take(4)) memcpy(q, &v, 4); }
     void felt(uint32_t monty) { u32(kb::from_monty(monty)); }
-    void felts(const uint32_t* m, size_t n) {            // bulk: the openings are ~340k words of a core-scale proof
-        const size_t o = b.size();
-        b.resize(o + 4 * n);
-        uint8_t* p = b.data() + o;
-        for (size_t i = 0; i < n; i++) {
-            const uint32_t c = kb::from_monty(m[i]);     // little-endian host: canonical word == its four bytes
-            memcpy(p + 4 * i, &c, 4);
+    void felts(const uint32_t* m, size_t k) {
+        uint8_t* q = take(4 * k);
+        if (!q) return;
+        for (size_t i = 0; i < k; i++) {
+            const uint32_t c = kb::from_monty(m[i]);     // canonical word == its four bytes
+            memcpy(q + 4 * i, &c, 4);
         }
     }
     void ext(const kb::Ext& e) { felts(e.c, 4); }
-    void canonical_words(const uint32_t* c, size_t n) {  // words the device has already taken out of Montgomery form
-        const size_t o = b.size();
-        b.resize(o + 4 * n);
-        memcpy(b.data() + o, c, 4 * n);
+    void canonical_words(const uint32_t* c, size_t k) {  // words the device has already taken out of Montgomery form
+        if (uint8_t* q = take(4 * k)) memcpy(q, c, 4 * k);
     }
 };
 
@@ -281,7 +288,7 @@ static size_t proof_size(int dim, const std::vector<uint32_t>& widths, const sp1
 
 static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_basefold_data_s* const* rounds, int n_rounds,
                                          const kb::Ext* claims, size_t n_claims, const sp1hip_fri_config_t& cfg,
-                                         DuplexChallenger& ch, std::vector<uint8_t>* out, hipStream_t s) {
+                                         DuplexChallenger& ch, uint8_t* out, size_t out_cap, size_t* out_len, hipStream_t s) {
     const int dim = (int)point.size();
     const int lb = cfg.log_blowup;
     const size_t nq = (size_t)cfg.num_queries;
@@ -299,7 +306,8 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     SP1HIP_REQUIRE(dim + lb <= kb::TWO_ADICITY, "instance exceeds two-adicity");
 
     ByteWriter w;
-    w.b.reserve(proof_size(dim, [&] { std::vector<uint32_t> ws; for (int r = 0; r < n_rounds; r++) ws.push_back(rounds[r]->total_width); return ws; }(), cfg));
+    w.p = out;
+    w.cap = out_cap;
     // Grind for batch randomness, then the batching coefficients.
     uint32_t batch_witness;
     SP1HIP_TRY(grind(ch, 5, &batch_witness, s));
@@ -470,7 +478,8 @@ static int prove_trusted_mle_evaluations(std::vector<kb::Ext> point, sp1hip_base
     w.ext(final_poly);
     w.felt(pow_witness);
     w.felt(batch_witness);
-    out->swap(w.b);
+    SP1HIP_REQUIRE(!w.overflow, "internal error: BaseFold proof larger than its computed size");
+    *out_len = w.n;
     return SP1HIP_SUCCESS;
 }
 
@@ -686,15 +695,14 @@ int sp1hip_basefold_prove(const sp1hip_ext_t* h_point, int dim, sp1hip_basefold_
     std::vector<kb::Ext> point(dim);
     memcpy(point.data(), h_point, (size_t)dim * 16);
     DuplexChallenger ch = challenger->ch;  // commit to the transcript only on success
-    std::vector<uint8_t> blob;
+    size_t written = 0;
     SP1HIP_TRY(prove_trusted_mle_evaluations(point, rounds, n_rounds, reinterpret_cast<const kb::Ext*>(h_claims), n_claims,
-                                             config, ch, &blob, S(stream)));
-    if (blob.size() != need) {
-        set_error("internal error: proof size %zu != expected %zu", blob.size(), need);
+                                             config, ch, h_proof, need, &written, S(stream)));      // written in place
+    if (written != need) {
+        set_error("internal error: proof size %zu != expected %zu", written, need);
         return SP1HIP_ERROR_RUNTIME;
     }
-    memcpy(h_proof, blob.data(), blob.size());
-    *proof_len = blob.size();
+    *proof_len = written;
     challenger->ch = ch;
     return SP1HIP_SUCCESS;
 }

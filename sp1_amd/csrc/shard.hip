@@ -190,16 +190,20 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     claims.insert(claims.end(), main_claims.begin(), main_claims.end());
     const size_t per_round[2] = {prep_claims.size(), main_claims.size()};
     sp1hip_stacked_data_t* rounds[2] = {preprocessed, main_data};
-    std::vector<uint8_t> jag_blob(jag_size);
+    // the evaluation proof is the last field of ShardProof and 90 % of its bytes: written straight into the caller's buffer,
+    // behind the head that is assembled below (every size is known from the shapes)
+    SP1HIP_REQUIRE(need >= jag_size, "internal error: shard proof sizes");
+    uint8_t* const jag_at = h_proof + (need - jag_size);
     size_t jlen = jag_size;
     SP1HIP_TRY(sp1hip_jagged_prove(reinterpret_cast<const sp1hip_ext_t*>(z_row.data()), L, rounds, 2,
-                                   reinterpret_cast<const sp1hip_ext_t*>(claims.data()), per_round, params.fri, ch, jag_blob.data(), &jlen,
+                                   reinterpret_cast<const sp1hip_ext_t*>(claims.data()), per_round, params.fri, ch, jag_at, &jlen,
                                    stream));
+    SP1HIP_REQUIRE(jlen == jag_size, "internal error: jagged proof size");
     (void)s;
 
     // ---- bincode(ShardProof)
     std::vector<uint8_t> out;
-    out.reserve(need);
+    out.reserve(need - jag_size);
     put_u64(out, n_publics);
     for (int i = 0; i < n_publics; i++) put_felt(out, h_publics[i]);
     for (int k = 0; k < 8; k++) put_felt(out, main_commit[k]);
@@ -217,13 +221,12 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         put_u64(out, L + 1);
         for (int b = L; b >= 0; b--) put_felt(out, ((chips[c].real_rows >> b) & 1) ? kb::R1 : 0u);
     }
-    out.insert(out.end(), jag_blob.begin(), jag_blob.begin() + jlen);
-    if (out.size() != need) {
-        set_error("internal error: shard proof size %zu != expected %zu", out.size(), need);
+    if (out.size() + jlen != need) {
+        set_error("internal error: shard proof size %zu != expected %zu", out.size() + jlen, need);
         return SP1HIP_ERROR_RUNTIME;
     }
     memcpy(h_proof, out.data(), out.size());
-    *proof_len = out.size();
+    *proof_len = need;
     challenger_restore(challenger, ch);
     return SP1HIP_SUCCESS;
 }

@@ -17,7 +17,9 @@
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "round_sync.hpp"
 #include "stacked_data.hpp"
+#include "tensor_table.hpp"
 
 using namespace sp1hip;
 
@@ -27,6 +29,20 @@ int commit_mles_hooked(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg
 }
 
 namespace {
+// table slices -> their place in the dense (stacked) buffer: blockIdx.y = slice, the x blocks stride over its words
+struct DenseSeg { const uint32_t* src; uint64_t dst_off, n; };
+__global__ __launch_bounds__(256) void dense_fill_kernel(const DenseSeg* __restrict__ segs, uint32_t* __restrict__ dense) {
+    const DenseSeg sg = segs[blockIdx.y];
+    uint32_t* dst = dense + sg.dst_off;
+    for (uint64_t base = (uint64_t)blockIdx.x * 1024u; base < sg.n; base += (uint64_t)gridDim.x * 1024u) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t i = base + (uint64_t)k * 256u + threadIdx.x;
+            if (i < sg.n) dst[i] = sg.src[i];
+        }
+    }
+}
+
 // PaddingFreeSponge on the host (metadata hashes: a handful of permutations)
 void host_hash(const std::vector<uint32_t>& in, uint32_t out[8]) {
     uint32_t s[16] = {0};
@@ -76,17 +92,37 @@ int sp1hip_stacked_commit(const sp1hip_table_t* tables, int n_tables, int log_st
     // The tables are concatenated into the dense buffer batch by batch, each batch right before ITS encode and on the stream
     // that encodes it (commit_mles_hooked): with the encodes on the side stream the copies (1.6 GB of a core shard, 0.7 ms
     // of HBM time) run under the VALU-bound leaf hashes of the batches before instead of in front of the commitment.
+    // One gather launch per batch (a hipMemcpyAsync per table slice was 35 API calls of ~30 us each at the head of a proof:
+    // the host, not the copies, was what the first leaf hash waited for).
     std::vector<uint64_t> table_off(n_tables + 1, 0);
     for (int i = 0; i < n_tables; i++) table_off[i + 1] = table_off[i] + tables[i].rows * (uint64_t)tables[i].cols;
     if (padded > area) SP1HIP_HIP(hipMemsetAsync((uint32_t*)sd->d_dense + area, 0, (padded - area) * 4, s));
     uint32_t* const dense = (uint32_t*)sd->d_dense;
     const uint64_t batch_words = (uint64_t)batch_size * H;
-    const std::function<int(int, hipStream_t)> fill_batch = [&](int b, hipStream_t on) -> int {
-        const uint64_t lo = (uint64_t)b * batch_words, hi = std::min<uint64_t>(lo + batch_words, area);
+    const uint64_t n_batches_total = area == 0 ? 1 : (padded / H + (uint64_t)batch_size - 1) / (uint64_t)batch_size;
+    std::vector<DenseSeg> segs;
+    std::vector<std::pair<uint32_t, uint32_t>> batch_segs(n_batches_total, {0u, 0u});     // (first segment, count)
+    std::vector<uint64_t> batch_max(n_batches_total, 0);
+    for (uint64_t b = 0; b < n_batches_total; b++) {
+        const uint64_t lo = b * batch_words, hi = std::min<uint64_t>(lo + batch_words, area);
+        batch_segs[b].first = (uint32_t)segs.size();
         for (int i = 0; i < n_tables && lo < hi; i++) {
             const uint64_t a = std::max(lo, table_off[i]), e = std::min(hi, table_off[i + 1]);
-            if (a < e) SP1HIP_HIP(hipMemcpyAsync(dense + a, tables[i].d_data + (a - table_off[i]), (e - a) * 4, hipMemcpyDeviceToDevice, on));
+            if (a < e) { segs.push_back(DenseSeg{tables[i].d_data + (a - table_off[i]), a, e - a}); batch_max[b] = std::max(batch_max[b], e - a); }
         }
+        batch_segs[b].second = (uint32_t)segs.size() - batch_segs[b].first;
+    }
+    AsyncScratch d_segs;
+    PinnedStage seg_stage;
+    SP1HIP_TRY(seg_stage.init(s));
+    SP1HIP_TRY(d_segs.alloc(std::max<size_t>(segs.size(), 1) * sizeof(DenseSeg), s));
+    SP1HIP_TRY(seg_stage.upload(d_segs.p, segs.data(), segs.size() * sizeof(DenseSeg)));
+    const std::function<int(int, hipStream_t)> fill_batch = [&](int b, hipStream_t on) -> int {
+        if ((uint64_t)b >= n_batches_total || batch_segs[b].second == 0) return SP1HIP_SUCCESS;
+        const uint32_t gx = (uint32_t)std::min<uint64_t>((batch_max[b] + 1023) / 1024, 2048);
+        hipLaunchKernelGGL(dense_fill_kernel, dim3(gx, batch_segs[b].second), dim3(256), 0, on,
+                           (const DenseSeg*)d_segs.p + batch_segs[b].first, dense);
+        SP1HIP_LAUNCH_CHECK();
         return SP1HIP_SUCCESS;
     };
     const uint64_t ncols = area == 0 ? 0 : padded / H;
