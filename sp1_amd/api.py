@@ -188,7 +188,10 @@ class DuplexChallenger:
 
     def __del__(self):
         if getattr(self, "h", None) and _L is not None:      # _L is None during interpreter shutdown
-            _L().sp1hip_challenger_free(self.h)
+            try:
+                _L().sp1hip_challenger_free(self.h)
+            except TypeError:                    # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
 
@@ -275,7 +278,10 @@ class BasefoldProverData:
 
     def __del__(self):
         if getattr(self, "h", None):
-            _L().sp1hip_basefold_data_free(self.h)
+            try:
+                _L().sp1hip_basefold_data_free(self.h)
+            except TypeError:                    # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
 
@@ -359,7 +365,10 @@ class StackedData:
 
     def __del__(self):
         if getattr(self, "h", None):
-            _L().sp1hip_stacked_data_free(self.h)
+            try:
+                _L().sp1hip_stacked_data_free(self.h)
+            except TypeError:                    # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
 
@@ -632,7 +641,10 @@ class PinnedHost:
 
     def __del__(self):
         if getattr(self, "ptr", None):
-            _L().sp1hip_free_host(self.ptr)
+            try:
+                _L().sp1hip_free_host(self.ptr)
+            except TypeError:                    # interpreter shutdown: the module globals are already gone
+                pass
             self.ptr = None
 
 

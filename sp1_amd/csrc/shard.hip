@@ -9,6 +9,7 @@
 //   -> jagged evaluation proof at the zerocheck point (sp1hip_jagged_prove)
 // and emits bincode(ShardProof) (/root/reference/crates/hypercube/src/verifier/proof.rs:L47-L94): public_values,
 // main_commitment, logup_gkr_proof, zerocheck_proof, opened_values, evaluation_proof.
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -99,6 +100,10 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         return SP1HIP_ERROR_BUFFER_TOO_SMALL;
     }
 
+    // SP1HIP_SHARD_TIMING=1: host wall time of the stages on stderr
+    const bool sh_timing = [] { const char* e = getenv("SP1HIP_SHARD_TIMING"); return e && e[0] == '1'; }();
+    std::chrono::steady_clock::time_point sh_t[6];
+    sh_t[0] = std::chrono::steady_clock::now();
     sp1hip_challenger_t* ch = nullptr;
     SP1HIP_TRY(sp1hip_challenger_clone(challenger, &ch));
     struct ChGuard { sp1hip_challenger_t* c; ~ChGuard() { sp1hip_challenger_free(c); } } guard{ch};
@@ -121,6 +126,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         for (size_t b = 0; b < nl; b++) challenger_observe(ch, kb::to_monty((uint8_t)chips[c].name[b]));
     }
 
+    sh_t[1] = std::chrono::steady_clock::now();
     // ---- LogUp-GKR
     std::vector<uint8_t> gkr_blob(gkr_size);
     size_t glen = gkr_size;
@@ -154,6 +160,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
             }
         }
     }
+    sh_t[2] = std::chrono::steady_clock::now();
     // ---- zerocheck
     const kb::Ext batching = challenger_sample_ext(ch), gkr_batch = challenger_sample_ext(ch);
     sp1hip_ext_t c_batching, c_gkr;
@@ -185,6 +192,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
             main_claims.insert(main_claims.end(), chip_evals[c].begin() + chips[c].prep_width, chip_evals[c].end());
         }
     }
+    sh_t[3] = std::chrono::steady_clock::now();
     // ---- jagged evaluation proof over [preprocessed round, main round]
     std::vector<kb::Ext> claims = prep_claims;
     claims.insert(claims.end(), main_claims.begin(), main_claims.end());
@@ -202,6 +210,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     (void)s;
 
     // ---- bincode(ShardProof)
+    sh_t[4] = std::chrono::steady_clock::now();
     std::vector<uint8_t> out;
     out.reserve(need - jag_size);
     put_u64(out, n_publics);
@@ -228,6 +237,12 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     memcpy(h_proof, out.data(), out.size());
     *proof_len = need;
     challenger_restore(challenger, ch);
+    if (sh_timing) {
+        sh_t[5] = std::chrono::steady_clock::now();
+        const auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(sh_t[b] - sh_t[a]).count(); };
+        fprintf(stderr, "[sp1hip shard] commit %.3f ms | LogUp-GKR %.3f | zerocheck %.3f | evaluation proof %.3f | proof bytes %.3f\n", ms(0, 1), ms(1, 2),
+                ms(2, 3), ms(3, 4), ms(4, 5));
+    }
     return SP1HIP_SUCCESS;
 }
 
