@@ -14,6 +14,9 @@
 //  * compress_layer: one lane per parent, 64 B in (2 x dwordx4 x 2), 32 B out.
 //  * compress_layer_coop: layers of <= 8192 parents, 16 lanes per compression (latency, not throughput, is what a small
 //    layer costs); compress_top: the last <= 7 levels in one workgroup, cooperative form throughout.
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_ctx.hpp"
 #include "tensor_table.hpp"
 
@@ -96,34 +99,36 @@ template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(256) void leaf_hash_part_kernel(const uint32_t* const* __restrict__ cols, uint32_t width,
                                                              uint32_t height, const p2::RoundConstants* __restrict__ rc,
                                                              uint32_t* __restrict__ carry, uint32_t* __restrict__ leaves) {
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
-    if (row >= height) return;
-    double d[16];
+    // grid-stride over the rows: the launch may be a PERSISTENT grid (leaf_hash_part: a bounded number of workgroups per
+    // CU, so that the encode passes of the next batch, running on the side stream, always find wave slots next to it)
+    for (uint32_t row = blockIdx.x * 256u + threadIdx.x; row < height; row += gridDim.x * 256u) {
+        double d[16];
 #pragma unroll
-    for (int i = 0; i < 8; i++) d[i] = 0.0;
+        for (int i = 0; i < 8; i++) d[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) d[8 + i] = FIRST ? 0.0 : (double)carry[(size_t)i * height + row];
-    const uint32_t full = width >> 3;
-    for (uint32_t k = 0; k < full; k++) {
+        for (int i = 0; i < 8; i++) d[8 + i] = FIRST ? 0.0 : (double)carry[(size_t)i * height + row];
+        const uint32_t full = width >> 3;
+        for (uint32_t k = 0; k < full; k++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) d[j] = (double)gptr(cols[8 * k + j])[row];
-        p2::permute_f64(d, *rc);
-    }
-    if (LAST) {
-        const uint32_t rem = width & 7u;
-        if (rem) {
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if ((uint32_t)j < rem) d[j] = (double)gptr(cols[8 * full + j])[row];
+            for (int j = 0; j < 8; j++) d[j] = (double)gptr(cols[8 * k + j])[row];
             p2::permute_f64(d, *rc);
         }
-        uint32_t s[16];
+        if (LAST) {
+            const uint32_t rem = width & 7u;
+            if (rem) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = p2::canonical_f64(d[j]);
-        store_digest(leaves + (size_t)row * 8, s);
-    } else {
+                for (int j = 0; j < 8; j++)
+                    if ((uint32_t)j < rem) d[j] = (double)gptr(cols[8 * full + j])[row];
+                p2::permute_f64(d, *rc);
+            }
+            uint32_t s[16];
 #pragma unroll
-        for (int i = 0; i < 8; i++) carry[(size_t)i * height + row] = p2::canonical_f64(d[8 + i]);
+            for (int j = 0; j < 8; j++) s[j] = p2::canonical_f64(d[j]);
+            store_digest(leaves + (size_t)row * 8, s);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) carry[(size_t)i * height + row] = p2::canonical_f64(d[8 + i]);
+        }
     }
 }
 
@@ -153,7 +158,10 @@ void leaf_hash_plan(const sp1hip_tensor_t* tensors, int n_tensors, std::vector<L
 int leaf_hash_part(const uint32_t* const* d_cols, uint32_t width, int k, int n_parts, uint32_t height, uint32_t* d_carry,
                    uint32_t* d_tree, const DeviceCtx* ctx, hipStream_t s) {
     ScopedTimer t("leaf_hash", s);
-    const dim3 grid((height + 255) / 256), block(256);
+    // SP1HIP_LEAF_WGS=n: at most n workgroups (persistent grid); 0 / unset: one workgroup per 256 rows
+    const uint32_t cap = [] { const char* e = getenv("SP1HIP_LEAF_WGS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t wgs = (height + 255) / 256;
+    const dim3 grid(cap ? std::min(cap, wgs) : wgs), block(256);
     const bool first = k == 0, last = k == n_parts - 1;
     if (first && last) return SP1HIP_ERROR_INVALID_ARGUMENT;
     if (first)
