@@ -112,10 +112,13 @@ P2H_TARGET void permute_avx512(uint32_t* state) {
     a = correct(fold31(a), p);
     b = correct(fold31(b), p);
     const __m512i ka = _mm512_setr_epi64(1, 0, 1, 2, 3, 4, 5, 6), kb_ = _mm512_setr_epi64(7, 8, 9, 10, 11, 12, 13, 15);
-    const __m512i two_p = _mm512_set1_epi64(2 * (uint64_t)kb::P);
+    // Word 0 lives in its own 128-bit register through the internal rounds: the chain S-box -> new word 0 -> next S-box is the
+    // critical path of the permutation, and it does not have to wait for the broadcast + vector reduction the other 15 words
+    // go through (new_0 = (rest + 2p - t) 2^-32 needs only `rest`, which is ready long before t).
+    __m128i s0 = _mm512_castsi512_si128(a);
+    const __m128i two_p1 = _mm_set1_epi64x(2 * (uint64_t)kb::P);
     for (int r = 0; r < 20; r++) {
-        // word 0 through the S-box on the low 128-bit lane: t = (s0 + rc)^3 R^-2 in [0, 2p)
-        const __m128i s0 = _mm512_castsi512_si128(a);
+        // word 0 through the S-box: t = (s0 + rc)^3 R^-2 in [0, 2p)
         const __m128i y = correct128(_mm_add_epi64(s0, _mm_load_si128((const __m128i*)vc.internal[r])), p1);   // < p + 2^16
         const __m128i y2 = correct128(mred128(_mm_mul_epu32(y, y), nmu1, p1), p1);
         const __m128i t = mred128(_mm_mul_epu32(y2, y), nmu1, p1);
@@ -124,12 +127,14 @@ P2H_TARGET void permute_avx512(uint32_t* state) {
         rest = _mm512_add_epi64(rest, _mm512_shuffle_i64x2(rest, rest, 0x4E));
         rest = _mm512_add_epi64(rest, _mm512_shuffle_i64x2(rest, rest, 0xB1));
         rest = _mm512_add_epi64(rest, _mm512_shuffle_epi32(rest, (_MM_PERM_ENUM)0x4E));
+        // new word 0 = (sum - 2 t) 2^-32 = (rest + 2p - t) 2^-32 with sum = rest + t: < p + 2^5
+        s0 = mred128(_mm_sub_epi64(_mm_add_epi64(_mm512_castsi512_si128(rest), two_p1), t), nmu1, p1);
+        // new_i = (sum + 2^k_i s_i) 2^-32 for the other words (lane 0 of `a` is dead weight until the rounds are over)
         const __m512i sum = _mm512_add_epi64(rest, _mm512_broadcastq_epi64(t));
-        // new_i = (sum + 2^k_i s_i) 2^-32; word 0 enters as 2p - t with k = 1 (== sum - 2 t)
-        a = _mm512_mask_sub_epi64(a, 1, two_p, _mm512_castsi128_si512(t));
         a = mred(_mm512_add_epi64(_mm512_sllv_epi64(a, ka), sum), nmu, p);
         b = mred(_mm512_add_epi64(_mm512_sllv_epi64(b, kb_), sum), nmu, p);
     }
+    a = _mm512_mask_mov_epi64(a, 1, _mm512_castsi128_si512(s0));
     for (int r = 4; r < 8; r++) {
         a = sbox_ext(a, _mm512_load_si512(&vc.ext[r][0]), nmu, p);
         b = sbox_ext(b, _mm512_load_si512(&vc.ext[r][8]), nmu, p);
