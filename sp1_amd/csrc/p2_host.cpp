@@ -120,8 +120,8 @@ P2H_TARGET void permute_avx512(uint32_t* state) {
     for (int r = 0; r < 20; r++) {
         // word 0 through the S-box: t = (s0 + rc)^3 R^-2 in [0, 2p)
         const __m128i y = correct128(_mm_add_epi64(s0, _mm_load_si128((const __m128i*)vc.internal[r])), p1);   // < p + 2^16
-        const __m128i y2 = correct128(mred128(_mm_mul_epu32(y, y), nmu1, p1), p1);
-        const __m128i t = mred128(_mm_mul_epu32(y2, y), nmu1, p1);
+        const __m128i y2 = mred128(_mm_mul_epu32(y, y), nmu1, p1);              // < y^2 / 2^32 + p < 1.5 p: y2 y < 2^63 as it is
+        const __m128i t = mred128(_mm_mul_epu32(y2, y), nmu1, p1);              // < 0.75 p + p
         // meanwhile: the sum of words 1..15 in every lane
         __m512i rest = _mm512_add_epi64(_mm512_maskz_mov_epi64(0xFE, a), b);
         rest = _mm512_add_epi64(rest, _mm512_shuffle_i64x2(rest, rest, 0x4E));
