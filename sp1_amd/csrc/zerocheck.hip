@@ -325,9 +325,16 @@ __global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __res
     const ZcChipRange d = ranges[blockIdx.x];
     const uint32_t word = threadIdx.x % 24, grp = threadIdx.x / 24;   // 10 groups of 24 words (3 passes x 8)
     if (grp < 10) {
-        uint32_t a = 0;
-        for (uint32_t b = grp; b < d.n_blocks; b += 10) a = kb::add(a, partial[((size_t)(d.block_start + b)) * 24 + word]);
-        acc[grp][word] = a;
+        // eight independent partial sums: the loads of a lane are then eight deep in flight instead of one behind each add
+        // (a tall chip has thousands of blocks: the plain loop was 100-130 us in each of the first three rounds)
+        const uint32_t* p = partial + (size_t)d.block_start * 24 + word;
+        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t b = grp;
+        for (; b + 70 < d.n_blocks; b += 80)
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = kb::add(a[u], p[(size_t)(b + 10 * u) * 24]);
+        for (; b < d.n_blocks; b += 10) a[0] = kb::add(a[0], p[(size_t)b * 24]);
+        acc[grp][word] = kb::add(kb::add(kb::add(a[0], a[1]), kb::add(a[2], a[3])), kb::add(kb::add(a[4], a[5]), kb::add(a[6], a[7])));
     }
     __syncthreads();
     if (threadIdx.x < 24) {
