@@ -1054,6 +1054,8 @@ namespace sp1hip {
 void challenger_observe(sp1hip_challenger_t* ch, uint32_t x);
 kb::Ext challenger_sample_ext(sp1hip_challenger_t* ch);
 void challenger_restore(sp1hip_challenger_t* dst, const sp1hip_challenger_t* src);
+// basefold.hip: every prefix table of eq over the first t coordinates of a point, t = 0..d, one launch
+int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s);
 }
 
 static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int max_log_row_count,
@@ -1182,8 +1184,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> zeta(L);
     memcpy(zeta.data(), h_zeta, (size_t)L * 16);
     const Ext lambda = challenger_sample_ext(challenger);
-    DevBuf d_eq;
-    SP1HIP_TRY(d_eq.alloc(((size_t)1 << (L - 1)) * 16, s));
+    // eq(zeta[0 .. t), .) for every t < L in ONE launch (basefold.hip: table t is an ext SoA of length 2^t at word offset
+    // 4 (2^t - 1)); round r reads table L - r - 1. Three small launches per round before.
+    DevBuf d_eq_all;
+    SP1HIP_TRY(d_eq_all.alloc(((size_t)1 << L) * 16, s));
+    SP1HIP_TRY(eq_prefix_tables_soa_async(zeta.data(), L - 1, d_eq_all.u32(), s));
     std::vector<UniPoly> msgs;
     std::vector<Ext> point;   // [alpha_last, ..., alpha_first]
     std::vector<Ext> round_claims = claims;
@@ -1220,7 +1225,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         const int nv = L - r;                       // variables left
         const Ext last = zeta[nv - 1];
         // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
-        SP1HIP_TRY(sp1hip_partial_lagrange(reinterpret_cast<const sp1hip_ext_t*>(zeta.data()), nv - 1, d_eq.u32(), stream));
+        struct EqView { uint32_t* p; uint32_t* u32() const { return p; } } d_eq{d_eq_all.u32() + 4 * (((size_t)1 << (nv - 1)) - 1)};
         // descriptors: one per (chip with real rows, chunk); a chip's blocks are contiguous. Chips are grouped by how
         // their programs run this round — (program staged in LDS?, workgroup width the LDS register file allows) — and
         // every group is one launch over its contiguous block range.
