@@ -954,6 +954,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     par.park();                                              // asleep through the device rounds; woken ahead of each layer's host rounds
     double dbg_rows = 0, dbg_int = 0, dbg_head = 0;
     auto dbg_t = std::chrono::steady_clock::now();
+    auto dbg_pass_t = dbg_t;
+    double dbg_wait = 0, dbg_host = 0, dbg_launch = 0;
+    int dbg_passes = 0;
+    bool dbg_pass_pending = false;
     for (int v = 1; v <= L - 1; v++) {
         if (gkr_debug) dbg_t = std::chrono::steady_clock::now();
         const Ext lambda = challenger_sample_ext(ch);
@@ -1019,6 +1023,9 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             const RoundSync rs = sv > 0 ? rsync.next() : publish_rows ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
             const Ext* Tp = sv > 0 ? T_of(t - sv) : (const Ext*)nullptr;
             const Ext* TLp = sv > 0 ? TL_of(t - sv) : (const Ext*)nullptr;
+            const auto dbg_l0 = std::chrono::steady_clock::now();
+            if (gkr_debug && dbg_pass_pending) dbg_host += std::chrono::duration<double, std::milli>(dbg_l0 - dbg_pass_t).count();
+            dbg_pass_pending = false;
             {
                 ScopedTimer tm(fv == 0 ? "gkr_pass_sum" : sv == 0 ? "gkr_pass_fold" : "gkr_pass_fold_sum", s);
 #define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, TLp, a0, a1, d_partials.u32(), rs, publish_rows ? mb.seq + 1 : rsync.seq, K, shape.tile_size, fa)
@@ -1036,10 +1043,13 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
 #undef SP1HIP_GKR_PASS
                 SP1HIP_LAUNCH_CHECK();
             }
+            if (gkr_debug) dbg_launch += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_l0).count();
             build_eq_tabs();                                 // (first pass of the layer only) host work behind a running kernel
             if (sv == 0) break;
             const int ns = sv == 2 ? 10 : 4;
+            const auto dbg_w0 = std::chrono::steady_clock::now();
             SP1HIP_TRY(rsync.wait(h_sums, 4 * ns));
+            if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_wait += std::chrono::duration<double, std::milli>(now - dbg_w0).count(); dbg_pass_t = now; dbg_passes++; dbg_pass_pending = true; }
             Ext S[10];
             memcpy(S, h_sums, 16 * (size_t)ns);
             const Ext pt_a = row_point[t - 1];               // the last unbound variable
@@ -1218,6 +1228,8 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     }
 
     if (gkr_debug) fprintf(stderr, "[sp1hip gkr]   of which row-variable rounds %.3f ms, interaction-variable rounds (host) %.3f ms\n", dbg_rows, dbg_int);
+    if (gkr_debug) fprintf(stderr, "[sp1hip gkr]   %d hand-overs inside the layers: waiting for the sums %.3f ms, closed forms + transcript %.3f ms, launch calls %.3f ms\n",
+                           dbg_passes, dbg_wait, dbg_host, dbg_launch);
     (void)dbg_head;
     mark("all layers");
     // ---- trace openings at the last L coordinates
