@@ -213,32 +213,36 @@ __global__ __launch_bounds__(256) void transition_kernel(const TransDesc* __rest
 struct PointArg { Ext c[32]; };
 // out2 = lambda * out: the sums weigh a row's numerators with lambda T and its denominators with T (gkr_pass), so that
 // lambda costs no product of its own
-__global__ __launch_bounds__(256) void eq_prefix_tables_kernel(PointArg pt, int v, Ext lambda, Ext* __restrict__ out, Ext* __restrict__ out2) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x + 1;       // 1 .. 2^(v+1) - 1
+// (eq_layer_tables_kernel below builds both: the row prefix tables T / lambda T, and the partial-Lagrange table of ALL
+// coordinates of the interaction point — on the device, so that a layer starts without a host-built table and its upload
+// on the critical path; the host builds its own copy of every prefix table for the interaction-variable rounds WHILE the
+// device runs the row rounds)
+// Both tables of a layer in ONE launch (a launch call is ~4.7 us of host time on the layer's critical path): workgroups
+// [0, full_blocks) build the interaction table, the rest the row prefix tables.
+__global__ __launch_bounds__(256) void eq_layer_tables_kernel(PointArg pi, int niv, Ext* __restrict__ eq_int, uint32_t full_blocks,
+                                                              PointArg pa, int v, Ext lambda, Ext* __restrict__ T, Ext* __restrict__ TL) {
+    if (blockIdx.x < full_blocks) {
+        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+        if (i >= (1u << niv)) return;
+        Ext acc = kb::ext_one();
+        for (int j = 0; j < niv; j++) {
+            const bool bit = (i >> (niv - 1 - j)) & 1u;
+            acc = kb::ext_mul(acc, bit ? pi.c[j] : kb::ext_sub(kb::ext_one(), pi.c[j]));
+        }
+        st_ext(eq_int, i, acc);
+        return;
+    }
+    const uint32_t g = (blockIdx.x - full_blocks) * 256u + threadIdx.x + 1;       // 1 .. 2^(v+1) - 1
     if (g >= (2u << v)) return;
     const int t = 31 - __clz(g);
     const uint32_t i = g - (1u << t);
     Ext acc = kb::ext_one();
     for (int j = 0; j < t; j++) {
         const bool bit = (i >> (t - 1 - j)) & 1u;
-        acc = kb::ext_mul(acc, bit ? pt.c[j] : kb::ext_sub(kb::ext_one(), pt.c[j]));
+        acc = kb::ext_mul(acc, bit ? pa.c[j] : kb::ext_sub(kb::ext_one(), pa.c[j]));
     }
-    st_ext(out, g - 1, acc);
-    st_ext(out2, g - 1, kb::ext_mul(acc, lambda));
-}
-
-// the partial-Lagrange table of ALL `dim` coordinates of `pt` (the interaction point): built where it is used, so that a
-// layer starts without a host-built table and its upload on the critical path (the host builds its own copy of every
-// prefix table for the interaction-variable rounds WHILE the device runs the row rounds)
-__global__ __launch_bounds__(256) void eq_full_table_kernel(PointArg pt, int dim, Ext* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1u << dim)) return;
-    Ext acc = kb::ext_one();
-    for (int j = 0; j < dim; j++) {
-        const bool bit = (i >> (dim - 1 - j)) & 1u;
-        acc = kb::ext_mul(acc, bit ? pt.c[j] : kb::ext_sub(kb::ext_one(), pt.c[j]));
-    }
-    st_ext(out, i, acc);
+    st_ext(T, g - 1, acc);
+    st_ext(TL, g - 1, kb::ext_mul(acc, lambda));
 }
 
 // ================================================================ sumcheck over the row variables: two rounds per pass
@@ -968,15 +972,14 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         // the device builds its own tables: eq over the interaction point, and over every prefix of the row point (x 1 and x lambda)
         SP1HIP_REQUIRE(niv <= 32 && v <= 32, "point too long");
         {
-            PointArg pi{};
+            PointArg pi{}, pa{};
             for (int j = 0; j < niv; j++) pi.c[j] = int_point[j];
-            hipLaunchKernelGGL(eq_full_table_kernel, dim3((W + 255) / 256), dim3(256), 0, s, pi, niv, d_eq_int.ext());
+            for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
+            const uint32_t full_blocks = (W + 255) / 256, prefix_blocks = ((2u << v) + 255) / 256;
+            hipLaunchKernelGGL(eq_layer_tables_kernel, dim3(full_blocks + prefix_blocks), dim3(256), 0, s, pi, niv, d_eq_int.ext(), full_blocks, pa, v,
+                               lambda, d_T.ext(), d_TL.ext());
             SP1HIP_LAUNCH_CHECK();
         }
-        PointArg pa{};
-        for (int j = 0; j < v; j++) pa.c[j] = row_point[j];
-        hipLaunchKernelGGL(eq_prefix_tables_kernel, dim3(((2u << v) + 255) / 256), dim3(256), 0, s, pa, v, lambda, d_T.ext(), d_TL.ext());
-        SP1HIP_LAUNCH_CHECK();
         // Lagrange tables of every prefix of the interaction point (eq_tabs[m]: the first m coordinates, 2^m entries) for the
         // HOST rounds at the end of the layer: built lazily, after the first pass of the layer has been launched
         std::vector<std::vector<Ext>> eq_tabs(niv + 1);
