@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
 template <bool FIRST>
 __global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __restrict__ ranges, const uint32_t* __restrict__ partial,
                                                         const uint32_t* __restrict__ eq, uint32_t eq_len,
-                                                        uint32_t* __restrict__ out) {
+                                                        uint32_t* __restrict__ out, RoundSync rs, uint32_t seq) {
     __shared__ uint32_t acc[10][24];
     const ZcChipRange d = ranges[blockIdx.x];
     const uint32_t word = threadIdx.x % 24, grp = threadIdx.x / 24;   // 10 groups of 24 words (3 passes x 8)
@@ -357,10 +357,24 @@ __global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __res
             y2 = kb::add(A1, B1);
             y4 = kb::add(A2, kb::sub(kb::add(B1, B1), B0));
         }
+        const uint32_t e = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u;
         uint32_t* o = out + (size_t)blockIdx.x * 16;
         o[k] = y0; o[4 + k] = y2; o[8 + k] = y4;
-        o[12 + k] = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u;
+        o[12 + k] = e;
+        if (rs.host_slot != nullptr) {
+            // the round's result goes to the host from HERE (payload words [1 + 16 chip ..)): system-scope stores, and
+            // below the workgroup that arrives last publishes the sequence number — no mailbox kernel behind this one
+            uint32_t* h = const_cast<uint32_t*>(rs.host_slot) + 1 + (size_t)blockIdx.x * 16;
+            __hip_atomic_store(h + k, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(h + 4 + k, y2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(h + 8 + k, y4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(h + 12 + k, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
+    if (rs.host_slot == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && rs_ticket_is_last(rs.counter, blockIdx.x, gridDim.x)) rs.host_slot[0] = seq;
 }
 
 // out[i][c] = x + alpha (y - x), x = row 2i, y = row 2i + 1 (zero beyond the real rows); out is an ext table.
@@ -1106,6 +1120,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     // device->host hand-over goes through the mailbox (round_sync.hpp), so the stream is never drained mid-proof.
     Mailbox mb;
     SP1HIP_TRY(mb.init(s));
+    RoundSyncHost rsync;                          // its counters carry the reduce kernel's last-workgroup ticket
+    SP1HIP_TRY(rsync.init(s));
     PinnedStage stage;                            // small uploads go through a pinned block (round_sync.hpp)
     SP1HIP_TRY(stage.init(s));
     if (n_publics) SP1HIP_TRY(stage.upload(d_publics.p, publics.data(), (size_t)n_publics * 4));
@@ -1435,10 +1451,15 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             for (int q = 0; q < ZC_JIT_SIDE; q++)                   // join: the reduction needs every compiled kernel's partial sums
                 if (jit_used[q]) { SP1HIP_HIP(hipEventRecord(jit_ev[1 + q], jit_side[q])); SP1HIP_HIP(hipStreamWaitEvent(s, jit_ev[1 + q], 0)); }
-            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
-            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32());
+            // the reduce kernel publishes the round's sums itself (ticket on the round-sync counters, payload in the mailbox slot)
+            const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
+            const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
+            if (direct) { rsync.pending = true; mb.pending = true; }
+            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32(), rs_pub, mb.seq + 1);
+            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32(), rs_pub, mb.seq + 1);
             SP1HIP_LAUNCH_CHECK();
-            SP1HIP_TRY(mb.fetch(d_sums.p, (size_t)n_ranges * 16, h_sums.data()));
+            if (direct) { SP1HIP_TRY(mb.wait_next(h_sums.data(), (size_t)n_ranges * 16)); rsync.pending = false; }
+            else SP1HIP_TRY(mb.fetch(d_sums.p, (size_t)n_ranges * 16, h_sums.data()));
         }
         for (size_t k = 0; k < desc_chip.size(); k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + k * 16, 64);
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
