@@ -139,6 +139,9 @@ __device__ __forceinline__ void jg_finish(const Ext& a, const Ext& b, const JgTa
     const Ext acc[2] = {a, b};
     rs_finish<2>(acc, t.partials, blockIdx.x, gridDim.x, t.rs, t.seq);
 }
+__device__ __forceinline__ void jg_finish8(const Ext (&acc)[8], const JgTail& t) {      // the two-round pass: eight sums
+    rs_finish<8>(acc, t.partials, blockIdx.x, gridDim.x, t.rs, t.seq);
+}
 
 // Sums the block partials and hands the two ext sums to the host through the mailbox slot (round_sync.hpp): payload
 // words [1..8], then the sequence number — no copy, no stream synchronise.
@@ -254,6 +257,70 @@ __global__ __launch_bounds__(256) void jg_round0_tables(const JgTab* __restrict_
         eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(r0, r1), kb::dot_finish(us)));
     }
     jg_finish(e0, eh, tail);
+}
+
+// ---- rounds 0 AND 1 from one pass over the base words (table heights % 4 == 0; the look-ahead of the reference's
+// /root/reference/sp1-gpu/crates/sys/lib/experimental/look_ahead.cu:L98 on this file's table-major form). A lane owns base
+// rows 4k .. 4k+3 of a table — the values of q and J at (X, Y) = (bit 0, bit 1) in {0,1}^2 — and walks the columns once,
+// accumulating U_l = sum_c eq_col[c] q[c, 4k + l] unreduced like round 0 does (the same four multiply-adds per element as
+// the two accumulators of jg_round0_tables on a row pair). J(x) = eq_col[c] r_l with r_l = eq_row[4k + l], and everything
+// the two rounds need is bilinear in (r, U):
+//   round 0:  y(0) = sum r_0 U_0 + r_2 U_2,   H = sum (r_0 + r_1)(U_0 + U_1) + (r_2 + r_3)(U_2 + U_3)
+//   round 1 (after alpha_0, with r'(Y) = r_0Y + alpha_0 (r_1Y - r_0Y) and U' likewise):
+//             y'(0) = sum r'(0) U'(0):  a quadratic in alpha_0 through P0 = r_0 U_0, P1 = r_1 U_1, leading coefficient
+//                     (r_1 - r_0)(U_1 - U_0) = 2 (P0 + P1) - (r_0 + r_1)(U_0 + U_1)
+//             H'    = sum (r'(0) + r'(1))(U'(0) + U'(1)):  through Q0 = (r_0 + r_2)(U_0 + U_2), Q1 = (r_1 + r_3)(U_1 + U_3),
+//                     leading coefficient Qinf = ((r_1 + r_3) - (r_0 + r_2))((U_1 + U_3) - (U_0 + U_2))
+// Eight sums: [P0, r_2 U_2, Ha, Hb, P1, Q0, Q1, Qinf] — eight extension products per lane and table, not per element. The
+// second pass over the 1.6 GB of base words that round 1 used to be (jg_fold_tables<1, false>, sums only) is gone.
+__global__ __launch_bounds__(256) void jg_round01_tables(const JgTab* __restrict__ tabs, uint32_t n_tabs, uint32_t n_tiles,
+                                                         JgJ J, JgTail tail) {
+    Ext acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = kb::ext_zero();
+    auto flush = [&](const kb::DotAcc (&u)[4], uint32_t k) {
+        Ext U[4], r[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) { U[l] = kb::dot_finish(u[l]); r[l] = jg_row_eq(J, 4 * k + l); }
+        acc[0] = kb::ext_add(acc[0], kb::ext_mul(r[0], U[0]));
+        acc[1] = kb::ext_add(acc[1], kb::ext_mul(r[2], U[2]));
+        acc[2] = kb::ext_add(acc[2], kb::ext_mul(kb::ext_add(r[0], r[1]), kb::ext_add(U[0], U[1])));
+        acc[3] = kb::ext_add(acc[3], kb::ext_mul(kb::ext_add(r[2], r[3]), kb::ext_add(U[2], U[3])));
+        acc[4] = kb::ext_add(acc[4], kb::ext_mul(r[1], U[1]));
+        const Ext sr0 = kb::ext_add(r[0], r[2]), sr1 = kb::ext_add(r[1], r[3]), sU0 = kb::ext_add(U[0], U[2]), sU1 = kb::ext_add(U[1], U[3]);
+        acc[5] = kb::ext_add(acc[5], kb::ext_mul(sr0, sU0));
+        acc[6] = kb::ext_add(acc[6], kb::ext_mul(sr1, sU1));
+        acc[7] = kb::ext_add(acc[7], kb::ext_mul(kb::ext_sub(sr1, sr0), kb::ext_sub(sU1, sU0)));
+    };
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint32_t lo = 0, hi = n_tabs;                     // last table with tile1 <= tile
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (__builtin_amdgcn_readfirstlane(tabs[mid].tile1) <= tile) lo = mid; else hi = mid;
+        }
+        const JgTab t = tabs[lo];
+        const uint32_t k = (tile - t.tile1) * JG_TAB_PAIRS + threadIdx.x;     // row quad of this lane
+        if (4 * k >= t.height) continue;
+        kb::DotAcc u[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) kb::dot_init(u[l]);
+        const uint32_t* col = t.q + 4 * (size_t)k;
+        for (uint32_t c = 0; c < t.ncols; c++, col += t.height) {
+            if ((c & 0x3fffu) == 0x3fffu) {               // 2^14 columns per accumulator window (never in practice)
+                flush(u, k);
+#pragma unroll
+                for (int l = 0; l < 4; l++) kb::dot_init(u[l]);
+            }
+            const uint4 v = *reinterpret_cast<const uint4*>(col);
+            const Ext w = ld_ext(J.col_eq, t.col0 + c);   // wave-uniform
+            kb::dot_add(u[0], w, v.x);
+            kb::dot_add(u[1], w, v.y);
+            kb::dot_add(u[2], w, v.z);
+            kb::dot_add(u[3], w, v.w);
+        }
+        flush(u, k);
+    }
+    jg_finish8(acc, tail);
 }
 
 __device__ __forceinline__ Ext fold_ext(const Ext& a, const Ext& b, const Ext& alpha) {   // a + alpha (b - a)
@@ -681,7 +748,7 @@ struct Scratch {                    // device scratch shared by all rounds of on
     static constexpr uint32_t MAX_BLOCKS = 2048;
     int init(hipStream_t stream) {
         s = stream;
-        SP1HIP_TRY(partials.alloc((size_t)MAX_BLOCKS * 32, s));
+        SP1HIP_TRY(partials.alloc((size_t)MAX_BLOCKS * 128, s));      // 8 extension sums per workgroup at most (jg_round01_tables)
         SP1HIP_TRY(stage.init(s));
         SP1HIP_TRY(rsync.init(s));
         return mb.init(s);
@@ -690,6 +757,12 @@ struct Scratch {                    // device scratch shared by all rounds of on
     JgTail tail() { const RoundSync rs = rsync.next(); return JgTail{partials.u32(), rs, rsync.seq}; }
     static uint32_t blocks_for(uint64_t threads) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((threads + 255) / 256, 1), MAX_BLOCKS); }
     // reduce `nb` block partials and bring the two ext sums to the host
+    int finish8(Ext (&out)[8]) {
+        uint32_t h[32];
+        SP1HIP_TRY(rsync.wait(h, 32));
+        memcpy(out, h, 128);
+        return SP1HIP_SUCCESS;
+    }
     int finish(uint32_t nb, Ext* a, Ext* b) {
         (void)nb;
         SP1HIP_TRY(rsync.wait(h_out, 8));
@@ -1039,8 +1112,48 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     uint32_t n_live = T;               // live entries of the current round's tables
     int cur = 0;                       // tabs[cur] (and tabs[cur + 1] once materialised) hold (q, j) of the current level
     jg_t[1] = std::chrono::steady_clock::now();
+    // SP1HIP_JAGGED_LOOKAHEAD=0: rounds 0 and 1 as two passes over the base words (the A/B form; the GPU tests run both)
+    const bool lookahead01 = skip_level1 && !tabs0.empty() && log_m >= 2 && !([] { const char* e = getenv("SP1HIP_JAGGED_LOOKAHEAD"); return e && e[0] == '0'; }());
     for (int round = 0; round < log_m; round++) {
         uint32_t nb;
+        if (round == 0 && lookahead01) {
+            // rounds 0 and 1 from ONE pass (jg_round01_tables); round 2 then folds from the base words with both challenges
+            {
+                ScopedTimer t("jagged_round0_sum", s);
+                nb = Scratch::blocks_for((uint64_t)n_tiles1 * 256);
+                hipLaunchKernelGGL(jg_round01_tables, dim3(nb), dim3(256), 0, s, (const JgTab*)d_tabs0.p, (uint32_t)tabs0.size(), n_tiles1, J,
+                                   sc.tail());
+                SP1HIP_LAUNCH_CHECK();
+            }
+            Ext S[8];
+            SP1HIP_TRY(sc.finish8(S));
+            // round 0
+            const Ext y0 = S[0] + S[1], h0 = S[2] + S[3];
+            poly = interpolate(y0, h0, claim - y0);
+            sumcheck.polys.push_back(poly);
+            alpha = observe_and_sample(ch, poly);
+            alphas.push_back(alpha);
+            claim = poly_eval(poly, alpha);
+            // the row-eq table of level 1 (the state later levels fold from), as round 1 would have built it
+            {
+                JgJ J1;
+                SP1HIP_TRY(level_J(1, alpha, &J1));
+            }
+            // round 1: y'(0) and H' are quadratics in alpha_0 through their values at 0, 1 and their leading coefficients
+            const Ext a0 = alpha;
+            const Ext c0 = S[0], c2 = (S[0] + S[4]) + (S[0] + S[4]) - S[2], c1 = S[4] - c0 - c2;
+            const Ext d0 = S[5], d2 = S[7], d1 = S[6] - d0 - d2;
+            const Ext y1 = c0 + (c1 + c2 * a0) * a0, h1 = d0 + (d1 + d2 * a0) * a0;
+            poly = interpolate(y1, h1, claim - y1);
+            sumcheck.polys.push_back(poly);
+            alpha = observe_and_sample(ch, poly);
+            alphas.push_back(alpha);
+            claim = poly_eval(poly, alpha);
+            n_live = (n_live + 1) / 2;
+            cur = 0;
+            round = 1;                                       // the loop continues with round 2
+            continue;
+        }
         if (round == 0) {
             ScopedTimer t("jagged_round0_sum", s);
             if (!tabs0.empty()) {

@@ -61,6 +61,15 @@ def test_jagged_proof_matches_oracle(api, monkeypatch, shapes, L, lsh, batch, fa
     assert orc.jagged_verify(g_commits, z_row, claims, got, lsh, v_ch, lb, nq, pw) == 0
 
 
+@pytest.mark.parametrize("shapes,L,lsh,batch", [BIG[2], BIG[3]])
+def test_jagged_two_pass_form_of_rounds_0_and_1_gives_the_same_bytes(api, monkeypatch, shapes, L, lsh, batch):
+    """With every table height a multiple of 8 the prover takes rounds 0 and 1 of the jagged sumcheck from ONE pass over the
+    base words (jg_round01_tables; the default, which test_jagged_proof_matches_oracle covers on these shapes);
+    SP1HIP_JAGGED_LOOKAHEAD=0 keeps the two-pass form."""
+    monkeypatch.setenv("SP1HIP_JAGGED_LOOKAHEAD", "0")
+    test_jagged_proof_matches_oracle(api, monkeypatch, shapes, L, lsh, batch, "1")
+
+
 def test_jagged_prove_rejects_bad_input_and_keeps_transcript(api):
     shapes, L, lsh, batch = CASES[0]
     _, tabs = make_rounds(shapes, L, lsh, batch, 3)
