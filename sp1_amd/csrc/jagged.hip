@@ -546,6 +546,39 @@ __global__ __launch_bounds__(256) void jg_fold_sum(const Ext* __restrict__ q_in,
     jg_finish(e0, eh, tail);
 }
 
+// The same fold with J still FACTORED on the way in (the first round after the factored levels): a lane computes the j of its
+// four entries from eq_col x eq_row (one column search, then a walk) instead of reading a table that jg_materialize_j would
+// have had to write at full size first — 16 B written and 16 B read per entry of the largest generic level saved.
+__global__ __launch_bounds__(256) void jg_fold_sum_fj(const Ext* __restrict__ q_in, JgJ J, uint32_t n_in, Ext alpha, uint32_t n_out,
+                                                      Ext* __restrict__ q_out, Ext* __restrict__ j_out, JgTail tail) {
+    Ext e0 = kb::ext_zero(), eh = kb::ext_zero();
+    const uint32_t n_thr = (n_out + 1) / 2;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_thr; k += gridDim.x * blockDim.x) {
+        Ext q[4], j[4];
+        uint32_t c = 0;
+        bool have = false;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const uint32_t x = 4 * k + v;
+            if (x >= n_in) { q[v] = kb::ext_zero(); j[v] = kb::ext_zero(); continue; }
+            q[v] = ld_ext(q_in, x);
+            if (!have) { c = jg_find_col(J, x); have = true; }
+            else while (J.prefix[c + 1] <= x) c++;
+            j[v] = jg_j_at(J, c, x - J.prefix[c]);
+        }
+        Ext qo[2], jo[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            qo[h] = fold_ext(q[2 * h], q[2 * h + 1], alpha);
+            jo[h] = fold_ext(j[2 * h], j[2 * h + 1], alpha);
+            if (2 * k + h < n_out) { st_ext(q_out, 2 * k + h, qo[h]); st_ext(j_out, 2 * k + h, jo[h]); }
+        }
+        e0 = kb::ext_add(e0, kb::ext_mul(jo[0], qo[0]));
+        eh = kb::ext_add(eh, kb::ext_mul(kb::ext_add(jo[0], jo[1]), kb::ext_add(qo[0], qo[1])));
+    }
+    jg_finish(e0, eh, tail);
+}
+
 // ================================================================ jagged-eval sumcheck
 // Transfer matrices of the branching program. A layer reads (row bit, index bit, curr-prefix bit,
 // next-prefix bit); with the first two bound to z_row / z_trace values the layer acts on the 4 memory
@@ -1212,17 +1245,18 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                 hipLaunchKernelGGL(jg_foldf_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, n_live, Jl, alpha, n_out,
                                    (Ext*)tabs[nxt].p, sc.tail());
             } else {
-                if (!j_materialised) {                     // leave the factored form: j of level round - 1
-                    const JgJ Jp{d_prefix_lv.u32() + (size_t)(round - 1) * prefix.size(), ncols, (const Ext*)d_col_eq.p, row_eq_cur, row_len_cur};
-                    SP1HIP_TRY(tabs[cur + 1].alloc((size_t)std::max<uint32_t>(n_live, 1) * 16, s));
-                    SP1HIP_TRY(tabs[nxt + 1].alloc((size_t)std::max<uint32_t>(n_out, 1) * 16, s));
-                    hipLaunchKernelGGL(jg_materialize_j, dim3((n_live + 255) / 256), dim3(256), 0, s, Jp, n_live, (Ext*)tabs[cur + 1].p);
-                    SP1HIP_LAUNCH_CHECK();
-                    j_materialised = true;
-                }
                 nb = Scratch::blocks_for((n_out + 1) / 2);
-                hipLaunchKernelGGL(jg_fold_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, (const Ext*)tabs[cur + 1].p, n_live,
-                                   alpha, n_out, (Ext*)tabs[nxt].p, (Ext*)tabs[nxt + 1].p, sc.tail());
+                if (!j_materialised) {                     // leave the factored form: this round computes j of level round - 1 as it loads
+                    const JgJ Jp{d_prefix_lv.u32() + (size_t)(round - 1) * prefix.size(), ncols, (const Ext*)d_col_eq.p, row_eq_cur, row_len_cur};
+                    SP1HIP_TRY(tabs[cur + 1].alloc((size_t)std::max<uint32_t>((n_out + 1) / 2, 1) * 16, s));   // (written by the round after next)
+                    SP1HIP_TRY(tabs[nxt + 1].alloc((size_t)std::max<uint32_t>(n_out, 1) * 16, s));
+                    j_materialised = true;
+                    hipLaunchKernelGGL(jg_fold_sum_fj, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, Jp, n_live, alpha, n_out,
+                                       (Ext*)tabs[nxt].p, (Ext*)tabs[nxt + 1].p, sc.tail());
+                } else {
+                    hipLaunchKernelGGL(jg_fold_sum, dim3(nb), dim3(256), 0, s, (const Ext*)tabs[cur].p, (const Ext*)tabs[cur + 1].p, n_live,
+                                       alpha, n_out, (Ext*)tabs[nxt].p, (Ext*)tabs[nxt + 1].p, sc.tail());
+                }
             }
             n_live = n_out;
             cur = nxt;
