@@ -1237,6 +1237,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     }
     std::vector<UniPoly> uni;                                // the chips' round polynomials (5 coefficients each), reused every round
     zc_t1 = std::chrono::steady_clock::now();
+    auto zc_iter_t = zc_t1;
+    double zc_plan_ms = 0, zc_wait_ms = 0, zc_uni_ms = 0;
     for (int r = 0; r < L; r++) {
         const int nv = L - r;                       // variables left
         const Ext last = zeta[nv - 1];
@@ -1458,8 +1460,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32(), rs_pub, mb.seq + 1);
             else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32(), rs_pub, mb.seq + 1);
             SP1HIP_LAUNCH_CHECK();
+            const auto zc_w0 = std::chrono::steady_clock::now();
+            if (zc_timing) zc_plan_ms += std::chrono::duration<double, std::milli>(zc_w0 - zc_iter_t).count();
             if (direct) { SP1HIP_TRY(mb.wait_next(h_sums.data(), (size_t)n_ranges * 16)); rsync.pending = false; }
             else SP1HIP_TRY(mb.fetch(d_sums.p, (size_t)n_ranges * 16, h_sums.data()));
+            if (zc_timing) { zc_iter_t = std::chrono::steady_clock::now(); zc_wait_ms += std::chrono::duration<double, std::milli>(zc_iter_t - zc_w0).count(); }
         }
         for (size_t k = 0; k < desc_chip.size(); k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + k * 16, 64);
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
@@ -1542,6 +1547,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             if (c.rows == 0) continue;
             c.eq_adj = c.eq_adj * (a_r * last + (kb::ext_one() - a_r) * (kb::ext_one() - last));
         }
+        if (zc_timing) { const auto now = std::chrono::steady_clock::now(); zc_uni_ms += std::chrono::duration<double, std::milli>(now - zc_iter_t).count(); zc_iter_t = now; }
         if (!fds.empty()) {
             ScopedTimer tm("zerocheck_fix", s);
             if (r == 0) hipLaunchKernelGGL(zc_fix_kernel<true>, dim3(fix_blocks), dim3(256), 0, s, d_fix_p, (int)fds.size(), a_r);
@@ -1614,8 +1620,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     *proof_len = need;
     if (zc_timing) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[sp1hip zerocheck] set-up %.3f ms | %d rounds %.3f ms | openings + proof %.3f ms\n", ms(zc_t0, zc_t1), L, ms(zc_t1, zc_t2),
-                ms(zc_t2, std::chrono::steady_clock::now()));
+        fprintf(stderr, "[sp1hip zerocheck] set-up %.3f ms | %d rounds %.3f ms (planning + launches %.3f, waiting for the sums %.3f, univariates + transcript %.3f) | openings + proof %.3f ms\n",
+                ms(zc_t0, zc_t1), L, ms(zc_t1, zc_t2), zc_plan_ms, zc_wait_ms, zc_uni_ms, ms(zc_t2, std::chrono::steady_clock::now()));
     }
     return SP1HIP_SUCCESS;
 }
