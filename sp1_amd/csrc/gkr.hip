@@ -772,14 +772,14 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     const uint32_t FLAT_MAX_SLOTS = [] { const char* e = getenv("SP1HIP_GKR_FLAT_SLOTS"); return e ? (uint32_t)atoi(e) : 65536u; }();   // read per call (tests)
     size_t n_passes_total = 0;
     for (int v = 1; v <= L - 1; v++) n_passes_total += (size_t)(v + 1) / 2 + 1;     // (0, .), the folds in pairs, the last fold
-    DeviceBuf d_all, d_flat;
-    SP1HIP_TRY(d_all.alloc(std::max<size_t>(n_passes_total * K, 1) * sizeof(PassDesc), s));
-    SP1HIP_TRY(d_flat.alloc((n_passes_total * (size_t)FLAT_MAX_SLOTS + 4) * sizeof(uint16_t), s));    // a flat pass indexes <= FLAT_MAX_SLOTS slots
     hipStream_t side = nullptr;
     hipEvent_t* side_ev = nullptr;
     SP1HIP_TRY(aux_stream_for(s, 2, &side, &side_ev));
-    SP1HIP_HIP(hipEventRecord(side_ev[0], s));
-    SP1HIP_HIP(hipStreamWaitEvent(side, side_ev[0], 0));
+    // (their buffers come from the SIDE stream's share of the arena: a recycled block's previous user ran on that stream,
+    // so the copies need not wait for anything on `s`; the blocks go back when this call has seen its last result)
+    DeviceBuf d_all, d_flat;
+    SP1HIP_TRY(d_all.alloc(std::max<size_t>(n_passes_total * K, 1) * sizeof(PassDesc), side));
+    SP1HIP_TRY(d_flat.alloc((n_passes_total * (size_t)FLAT_MAX_SLOTS + 4) * sizeof(uint16_t), side));    // a flat pass indexes <= FLAT_MAX_SLOTS slots
     PinnedStage side_stage;
     SP1HIP_TRY(side_stage.init(side));
     // ---- first layer
@@ -857,6 +857,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     // tail better (sweep of round 2 on the one-round kernels: 4096 best, flat between 2048 and 8192).
     static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 1u) : 4096u; }();
     std::vector<PassDesc> all_descs;
+    all_descs.reserve(n_passes_total * K);                  // ~10 MB at 730 interactions: no regrowth copies while planning
     // a layer's last fold (one row per interaction) goes straight to the mailbox slot, 16-byte aligned behind word 0
     const bool direct_final = (size_t)K * 16 + 4 <= MAILBOX_WORDS;
     Ext* const host_rows = reinterpret_cast<Ext*>(mb.h_slot + 4);
