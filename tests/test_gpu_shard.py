@@ -49,6 +49,14 @@ def test_shard_proof_matches_oracle(api, n_tuples, L, lsh, batch, with_empty, du
     assert orc.shard_verify(chips, g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
 
 
+def test_shard_proof_with_split_persistent_leaf_hash(api, monkeypatch):
+    """The commit's leaf hash in its split form (one launch per stacked batch, SP1HIP_COMMIT_OVERLAP=1: the form large
+    commitments take) as a persistent grid of 3 workgroups (SP1HIP_LEAF_WGS: the rows are then walked by a grid-stride loop)."""
+    monkeypatch.setenv("SP1HIP_COMMIT_OVERLAP", "1")
+    monkeypatch.setenv("SP1HIP_LEAF_WGS", "3")
+    test_shard_proof_matches_oracle(api, 200, 10, 6, 4, True, 3)
+
+
 @pytest.mark.parametrize("scale_log2", [3, 0])
 def test_large_shard_proof_is_accepted_by_the_pinned_verifier(api, scale_log2):
     """Size-independent parity at (and near) the full core-shard size: the verifier is succinct, so the oracle's
