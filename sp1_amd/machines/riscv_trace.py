@@ -1,0 +1,1083 @@
+"""Satisfying traces for the transcribed RISC-V chips of `riscv.py`: a small rv64im EXECUTOR plus the chips' trace generation.
+
+The reference fills its tables from the `ExecutionRecord` of its Rust executor (crates/core/executor) through each chip's
+`generate_trace_into` / `event_to_row` (cited per chip below). That executor and real guest programs are Rust and out of
+scope; what this module executes instead is a *synthetic but real* rv64im program — a loop body of random
+instructions with true RISC-V semantics — and it fills every column from the executed values exactly as the reference's
+`populate` functions would. Nothing is "made to fit": tests/machine_check.py then requires every constraint of every chip
+to vanish on every row and the Byte / Memory / Program / State / Global buses to balance as multisets.
+
+Program shape (vectorisable by construction, all tensors torch.int64, runs on CPU for tests and on the GPU for the bench):
+
+    registers   x0 | B = x1..x8 scalars | PR = x9,x10 pointers into a read-only region | PS = x11,x12 pointers into a
+                store region | D1 = x13..x21 | D2 = x22..x31
+    body        L instructions at pc_base + 4 i, executed K times (a loop: the last instruction is `jal x0, -4 (L - 1)`):
+                  class A  sources in B u {x0}, destination in D1 (ALU ops, AUIPC, JAL) or PR / PS (LUI with a page of the region)
+                  class B  sources in B u D1 u PR u PS, destination in D2 (ALU ops, loads through PR, JALR after its AUIPC)
+                  class S  no register destination: stores through PS, branches (taken branches jump to pc + 4)
+                  tail     `addi xb, xb, step_b` for every scalar (their values are init_b + k step_b in iteration k), then the jump
+    memory      loads read the read-only region (random initial image), stores write the store region; every touched word and
+                register gets a MemoryLocal row (initial record at timestamp 0, final record = last access)
+
+So the value an instruction reads is the value written by the statically known last writer of that register, in this or
+the previous iteration — values come out of three vectorised passes (tail, A, B) instead of a sequential interpreter.
+Timestamps: instruction n runs at clk0 + 8 n (CLK_INC), its accesses at +1 memory, +2 op_c, +3 op_b, +4 op_a
+(MemoryAccessPosition); crossing a 2^24 boundary of the clock produces StateBump / MemoryBump rows like the reference
+(adapter/bump.rs, memory/bump.rs), as does a carry out of the low pc limb.
+
+Byte / Range / Program multiplicities are not re-derived chip by chip: they are COUNTED from the messages the chips' own
+interaction programs send on the generated rows (every message is checked to be a row of the table it addresses).
+
+Closing chips (synthetic, a few rows): `Boundary` stands in for `eval_public_values` (sends the initial CPU state, receives
+the final one: core/executor/src/record.rs:L1020-L1032); `GlobalSink` receives MemoryLocal's `Global` messages where the
+real Global chip (septic-curve digest) would.
+"""
+import numpy as np
+import torch
+
+from ..air import AirProgram, InteractionProgram, P, VCol
+from . import riscv as R
+
+I64 = torch.int64
+MASK16, MASK32 = 0xFFFF, 0xFFFFFFFF
+MIN64 = -(1 << 63)
+POS_OFF = {"M": 1, "C": 2, "B": 3, "A": 4}
+B_REGS, PR_REGS, PS_REGS = list(range(1, 9)), [9, 10], [11, 12]
+D1_REGS, D2_REGS = list(range(13, 22)), list(range(22, 32))
+PAGE = 4096
+
+# instruction kinds: name -> (chip, opcode names)
+ALU_KINDS = {
+    "Add": ["ADD"], "Sub": ["SUB"], "Addi": ["ADDI"], "Bitwise": ["XOR", "OR", "AND"], "Lt": ["SLT", "SLTU"],
+    "Mul": ["MUL", "MULH", "MULHU", "MULHSU", "MULW"], "ShiftLeft": ["SLL", "SLLW"], "ShiftRight": ["SRL", "SRA", "SRLW", "SRAW"],
+    "Addw": ["ADDW"], "Subw": ["SUBW"],
+}
+IMM_CAPABLE = {"Bitwise", "Lt", "ShiftLeft", "ShiftRight", "Addw"}           # ALUTypeReader chips: op_c may be an immediate
+LOAD_KINDS = {"LoadByte": ["LB", "LBU"], "LoadHalf": ["LH", "LHU"], "LoadWord": ["LW", "LWU"], "LoadDouble": ["LD"]}
+STORE_KINDS = {"StoreByte": ["SB"], "StoreHalf": ["SH"], "StoreWord": ["SW"], "StoreDouble": ["SD"]}
+BRANCH_OPS = ["BEQ", "BNE", "BLT", "BGE", "BLTU", "BGEU"]
+ACCESS_BYTES = {"LB": 1, "LBU": 1, "LH": 2, "LHU": 2, "LW": 4, "LWU": 4, "LD": 8, "SB": 1, "SH": 2, "SW": 4, "SD": 8}
+OPC = R.OPC
+
+
+def pad32(n):
+    return max(-(-n // 32) * 32, 32)
+
+
+def fpow(x, e):
+    r = torch.ones_like(x)
+    while e:
+        if e & 1:
+            r = r * x % P
+        x = x * x % P
+        e >>= 1
+    return r
+
+
+def finv(x):
+    return fpow(x % P, P - 2)
+
+
+def limbs16(x):
+    """[n] int64 (two's complement 64-bit values) -> [n, 4] 16-bit limbs."""
+    return torch.stack([(x >> (16 * i)) & MASK16 for i in range(4)], dim=1)
+
+
+def bytes8(x):
+    return torch.stack([(x >> (8 * i)) & 0xFF for i in range(8)], dim=1)
+
+
+def sext32(x):
+    x = x & MASK32
+    return x - ((x >> 31) << 32)
+
+
+def ult(a, b):
+    return (a ^ MIN64) < (b ^ MIN64)
+
+
+def srl(a, s):
+    """logical right shift of int64 by s in [0, 63]"""
+    mask = torch.where(s == 0, torch.full_like(a, -1), (torch.ones_like(a) << (64 - s).clamp(max=63)) - 1)
+    return (a >> s) & mask
+
+
+class Body:
+    """The static loop body. Arrays over body positions."""
+
+    def __init__(self, counts, rng, pc_base, mem_pages):
+        kinds = []
+        for name, n in counts.items():
+            if name in ("Jalr",):
+                kinds += [("JalrPair",)] * n
+            elif name in ALU_KINDS or name in LOAD_KINDS or name in STORE_KINDS or name in ("Branch", "Jal", "UType"):
+                kinds += [(name,)] * n
+            else:
+                raise KeyError(name)
+        order = rng.permutation(len(kinds))
+        op, chip, rd, rs1, rs2, imm, has_imm = [], [], [], [], [], [], []
+
+        def emit(chip_, op_, rd_, rs1_, rs2_, imm_, has_imm_):
+            chip.append(chip_); op.append(OPC[op_]); rd.append(rd_); rs1.append(rs1_); rs2.append(rs2_); imm.append(imm_)
+            has_imm.append(has_imm_)
+
+        pick = lambda lst: lst[int(rng.integers(len(lst)))]
+        r_pages, s_pages = mem_pages
+        self.r_base, self.s_base = 0x100000, 0x100000 + (r_pages + 1) * PAGE
+        self.r_pages, self.s_pages = r_pages, s_pages
+        for idx in order:
+            name = kinds[idx][0]
+            cls_b = bool(rng.integers(2))
+            if name in ALU_KINDS:
+                opn = pick(ALU_KINDS[name])
+                srcs = B_REGS + [0] if not cls_b else B_REGS + D1_REGS + PR_REGS + PS_REGS + [0]
+                dst = pick(D1_REGS) if not cls_b else pick(D2_REGS)
+                use_imm = name == "Addi" or (name in IMM_CAPABLE and bool(rng.integers(2)))
+                if use_imm:
+                    if name in ("ShiftLeft", "ShiftRight"):
+                        v = int(rng.integers(0, 32 if opn.endswith("W") else 64))
+                    else:
+                        v = int(rng.integers(-2048, 2048))
+                    emit(name, opn, dst, pick(srcs), -1, v, True)
+                else:
+                    emit(name, opn, dst, pick(srcs), pick(srcs), 0, False)
+            elif name == "UType":
+                which = int(rng.integers(4))
+                if which == 0:                                                  # LUI: a pointer into the read-only region
+                    emit(name, "LUI", pick(PR_REGS), -1, -1, self.r_base + PAGE * int(rng.integers(r_pages)), True)
+                elif which == 1:
+                    emit(name, "LUI", pick(PS_REGS), -1, -1, self.s_base + PAGE * int(rng.integers(s_pages)), True)
+                else:
+                    v = int(rng.integers(-(1 << 19), 1 << 19)) << 12
+                    emit(name, "AUIPC" if which == 2 else "LUI", pick(D1_REGS), -1, -1, v, True)
+            elif name in LOAD_KINDS:
+                opn = pick(LOAD_KINDS[name])
+                nb = ACCESS_BYTES[opn]
+                emit(name, opn, pick(D2_REGS), pick(PR_REGS), -1, int(rng.integers(0, PAGE // nb)) * nb, True)
+            elif name in STORE_KINDS:
+                opn = pick(STORE_KINDS[name])
+                nb = ACCESS_BYTES[opn]
+                # op_a = rs2 (the stored register), op_b = rs1 (the pointer), op_c = offset (disassembler/rrs.rs:L37-L39)
+                emit(name, opn, pick(B_REGS + D1_REGS + D2_REGS + [0]), pick(PS_REGS), -1, int(rng.integers(0, PAGE // nb)) * nb, True)
+            elif name == "Branch":
+                # op_a = rs1, op_b = rs2, op_c = offset; a taken branch lands on pc + 4 as well
+                regs = B_REGS + D1_REGS + D2_REGS + [0]
+                a = pick(regs)
+                emit(name, pick(BRANCH_OPS), a, a if rng.integers(4) == 0 else pick(regs), -1, 4, True)
+            elif name == "Jal":
+                emit(name, "JAL", pick(D1_REGS), -1, -1, 4, True)
+            elif name == "JalrPair":
+                d = pick(D1_REGS)
+                emit("UType", "AUIPC", d, -1, -1, 0, True)
+                emit("Jalr", "JALR", pick(D2_REGS), d, -1, 8, True)
+        self.steps = [int(rng.integers(-(1 << 40), 1 << 40)) for _ in B_REGS]
+        for r, st in zip(B_REGS, self.steps):
+            # the tail: scalars advance by a 12-bit immediate (the "step" of iteration k is imm, wide values come from init)
+            emit("Addi", "ADDI", r, r, -1, int(st % 4096) - 2048, True)
+        L = len(op) + 1
+        emit("Jal", "JAL", 0, -1, -1, -4 * (L - 1), True)
+        self.L = L
+        self.chip = np.array(chip)
+        self.op, self.rd, self.rs1, self.rs2 = (np.array(a, dtype=np.int64) for a in (op, rd, rs1, rs2))
+        self.imm, self.has_imm = np.array(imm, dtype=np.int64), np.array(has_imm, dtype=bool)
+        self.pc_base = pc_base
+        self.n_tail = len(B_REGS) + 1
+
+
+# which register sits in which access slot, per chip family (None = no access in that slot)
+def _slots(body):
+    """slot A, B, C register numbers per body position (-1 = no access). Stores / branches read op_a (their rs in slot A)."""
+    A = body.rd.copy()
+    B = body.rs1.copy()
+    C = np.where(body.has_imm, -1, body.rs2)
+    is_st_br = np.isin(body.chip, list(STORE_KINDS) + ["Branch"])
+    # stores / branches: rd field holds op_a (a READ), rs1 holds op_b
+    return A, B, C, is_st_br
+
+
+class Execution:
+    def __init__(self, counts, K=1, seed=0, clk0=1, pc_base=0x200000, mem_pages=(4, 4), device="cpu"):
+        rng = np.random.default_rng(seed)
+        self.dev = torch.device(device)
+        self.body = b = Body(counts, rng, pc_base, mem_pages)
+        self.K, self.L, self.clk0 = K, b.L, clk0
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(seed + 1)
+        t = lambda a: torch.as_tensor(a, device=self.dev)
+        L, dev = b.L, self.dev
+        self.op, self.imm, self.has_imm = t(b.op), t(b.imm), t(b.has_imm)
+        sA, sB, sC, st_br = _slots(b)
+        self.slot_reg = {"A": t(sA), "B": t(sB), "C": t(sC)}
+        self.writes_rd = t(~st_br & (sA >= 0))                    # slot A is a write of a new value
+        self.init = torch.randint(MIN64, (1 << 63) - 1, (32,), generator=self.gen, device=dev, dtype=I64)
+        self.init[0] = 0
+        for r in PR_REGS:
+            self.init[r] = b.r_base
+        for r in PS_REGS:
+            self.init[r] = b.s_base
+        # ---- static last-writer tables
+        pos = np.arange(L)
+        writer_pos = {r: pos[(sA == r) & ~st_br] for r in range(32)}
+        self.lastw = t(np.array([wp[-1] if len(wp) else -1 for wp in writer_pos.values()], dtype=np.int64))
+        lw = {}
+        for s, regs in (("A", sA), ("B", sB), ("C", sC)):
+            out = np.full(L, -1, dtype=np.int64)
+            for r in range(32):
+                m = regs == r
+                if m.any() and len(writer_pos[r]):
+                    i = np.searchsorted(writer_pos[r], pos[m], side="left") - 1        # last writer strictly before p
+                    out[m] = np.where(i >= 0, writer_pos[r][np.maximum(i, 0)], -1)
+            lw[s] = t(out)
+        self.lw = lw
+        # ---- static previous-access tables: accesses sorted by (reg, p, time order C < B < A)
+        rows = []
+        for s, regs, o in (("C", sC, 0), ("B", sB, 1), ("A", sA, 2)):
+            m = regs >= 0
+            rows.append(np.stack([regs[m], pos[m], np.full(m.sum(), o)], axis=1))
+        acc = np.concatenate(rows)
+        acc = acc[np.lexsort((acc[:, 2], acc[:, 1], acc[:, 0]))]
+        first = np.r_[True, acc[1:, 0] != acc[:-1, 0]]
+        last_of_reg = np.r_[first[1:], True]
+        prev_idx = np.arange(len(acc)) - 1
+        # the first access of a register in an iteration follows the register's LAST access of the previous iteration
+        seg_last = np.zeros(len(acc), dtype=np.int64)
+        ends = np.nonzero(last_of_reg)[0]
+        starts = np.nonzero(first)[0]
+        for s0, e0 in zip(starts, ends):
+            seg_last[s0:e0 + 1] = e0
+        prev_idx = np.where(first, seg_last, prev_idx)
+        off = np.array([2, 3, 4])
+        self.prev = {}
+        for s, o in (("C", 0), ("B", 1), ("A", 2)):
+            m = acc[:, 2] == o
+            pp, po, wrap = (np.full(L, -1, dtype=np.int64) for _ in range(3))
+            pp[acc[m, 1]] = acc[prev_idx[m], 1]
+            po[acc[m, 1]] = off[acc[prev_idx[m], 2]]
+            wrap[acc[m, 1]] = first[m]
+            self.prev[s] = (t(pp), t(po), t(wrap))
+        self.touched_regs = sorted(set(int(r) for r in acc[:, 0]))
+        self.last_access = {int(acc[e, 0]): (int(acc[e, 1]), int(off[acc[e, 2]])) for e in ends}
+        # ---- values: W[k, p] = value written by position p in iteration k
+        self.W = torch.zeros((K, L), dtype=I64, device=dev)
+        self.kk = torch.arange(K, device=dev)
+        self._run()
+
+    # -- time and pc
+    def T(self, k, p):
+        return self.clk0 + 8 * (k * self.L + p)
+
+    def pc(self, p):
+        return self.body.pc_base + 4 * p
+
+    def reg_value(self, k, p, slot):
+        """Value of the register in `slot` of position p just before instruction (k, p). k, p: index tensors of one shape."""
+        reg = self.slot_reg[slot][p]
+        lw = self.lw[slot][p]
+        lastw = self.lastw[reg.clamp(min=0)]
+        same = lw >= 0
+        prev_it = (~same) & (lastw >= 0) & (k > 0)
+        v = torch.where(same, self.W[k, lw.clamp(min=0)],
+                        torch.where(prev_it, self.W[(k - 1).clamp(min=0), lastw.clamp(min=0)], self.init[reg.clamp(min=0)]))
+        return torch.where(reg == 0, torch.zeros_like(v), v)
+
+    def _grid(self, positions):
+        p = torch.as_tensor(positions, device=self.dev)
+        k = self.kk[:, None].expand(self.K, len(p)).reshape(-1)
+        return k, p[None, :].expand(self.K, len(p)).reshape(-1)
+
+    def _run(self):
+        b, L = self.body, self.L
+        pos = np.arange(L)
+        tail = pos[L - b.n_tail:L - 1]
+        # tail ADDIs: W[k, tail_r] = init_r + (k + 1) imm_r
+        tp = torch.as_tensor(tail, device=self.dev)
+        self.W[:, tp] = self.init[self.slot_reg["A"][tp]][None, :] + (self.kk[:, None] + 1) * self.imm[tp][None, :]
+        sB, sC = b.rs1, np.where(b.has_imm, -1, b.rs2)
+        is_st_br = np.isin(b.chip, list(STORE_KINDS) + ["Branch"])
+        writer = ~is_st_br & (b.rd > 0)
+        body_pos = pos < L - b.n_tail
+        d1like = set(D1_REGS + PR_REGS + PS_REGS)
+        cls_a = writer & body_pos & np.array([int(r) in d1like for r in b.rd])
+        cls_b = writer & body_pos & ~cls_a
+        self.mem = None
+        for mask in (cls_a, cls_b):
+            k, p = self._grid(pos[mask])
+            self.W[k, p] = self._semantics(k, p)
+
+    def operands(self, k, p):
+        bval = self.reg_value(k, p, "B")
+        cval = torch.where(self.has_imm[p], self.imm[p], self.reg_value(k, p, "C"))
+        return bval, cval
+
+    def load_value(self, addr):
+        """64-bit word of the read-only region containing byte address `addr` (a fixed pseudo-random image)."""
+        w = addr >> 3
+        z = w * -7046029254386353131 + 1442695040888963407          # splitmix-style mixing, wrapping int64 arithmetic
+        z = (z ^ srl(z, torch.full_like(z, 30))) * -4658895280553007687
+        z = (z ^ srl(z, torch.full_like(z, 27))) * -7723592293110705685
+        return z ^ srl(z, torch.full_like(z, 31))
+
+    def _semantics(self, k, p):
+        op = self.op[p]
+        bv, cv = self.operands(k, p)
+        pc = self.pc(p)
+        out = torch.zeros_like(bv)
+        sh6, sh5 = cv & 63, cv & 31
+
+        def put(name, val):
+            nonlocal out
+            out = torch.where(op == OPC[name], val, out)
+        put("ADD", bv + cv); put("ADDI", bv + cv); put("SUB", bv - cv)
+        put("XOR", bv ^ cv); put("OR", bv | cv); put("AND", bv & cv)
+        put("SLT", (bv < cv).to(I64)); put("SLTU", ult(bv, cv).to(I64))
+        put("SLL", bv << sh6); put("SLLW", sext32(bv << sh5))
+        put("SRL", srl(bv, sh6)); put("SRA", bv >> sh6)
+        put("SRLW", sext32(srl(bv & MASK32, sh5))); put("SRAW", sext32(bv) >> sh5)
+        put("ADDW", sext32(bv + cv)); put("SUBW", sext32(bv - cv))
+        put("MUL", bv * cv); put("MULW", sext32(bv * cv))
+        for name in ("MULH", "MULHU", "MULHSU"):
+            m = op == OPC[name]
+            if bool(m.any()):
+                out = torch.where(m, mulh(bv, cv, name), out)
+        put("LUI", self.imm[p]); put("AUIPC", pc + self.imm[p])
+        put("JAL", pc + 4); put("JALR", pc + 4)
+        isload = torch.zeros_like(op, dtype=torch.bool)
+        for name in ("LB", "LBU", "LH", "LHU", "LW", "LWU", "LD"):
+            isload |= op == OPC[name]
+        if bool(isload.any()):
+            addr = bv + cv
+            word = self.load_value(addr)
+            sh = (addr & 7) * 8
+            raw = srl(word, sh)
+            put("LD", word)
+            put("LWU", raw & MASK32); put("LW", sext32(raw))
+            put("LHU", raw & MASK16); put("LH", (raw & MASK16) - (((raw >> 15) & 1) << 16))
+            put("LBU", raw & 0xFF); put("LB", (raw & 0xFF) - (((raw >> 7) & 1) << 8))
+        return out
+
+
+def mulh(b, c, name):
+    """High 64 bits of the 128-bit product (signedness per opcode) through 16-bit limbs."""
+    bs = name in ("MULH", "MULHSU")
+    cs = name == "MULH"
+    bl = [(b >> (16 * i)) & MASK16 for i in range(4)] + [((b >> 63) & 1) * MASK16 * int(bs)] * 4
+    cl = [(c >> (16 * i)) & MASK16 for i in range(4)] + [((c >> 63) & 1) * MASK16 * int(cs)] * 4
+    acc = [torch.zeros_like(b) for _ in range(8)]
+    for i in range(8):
+        for j in range(8 - i):
+            acc[i + j] = acc[i + j] + bl[i] * cl[j]
+    carry = torch.zeros_like(b)
+    limbs = []
+    for i in range(8):
+        s = acc[i] + carry
+        limbs.append(s & MASK16)
+        carry = s >> 16
+    return limbs[4] | (limbs[5] << 16) | (limbs[6] << 32) | (limbs[7] << 48)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Table:
+    def __init__(self, air, n, dev):
+        self.air, self.n = air, n
+        self.main = torch.zeros((pad32(n), air.main_width), dtype=I64, device=dev)
+        self.prep = torch.zeros((pad32(n), air.prep_width), dtype=I64, device=dev) if air.prep_width else None
+        self.L = getattr(air, "layout", {})
+
+    def set(self, name, val, off=0):
+        c = self.L[name] + off
+        if not torch.is_tensor(val):
+            self.main[:self.n, c] = val
+        elif val.dim() == 1:
+            self.main[:self.n, c] = val
+        else:
+            self.main[:self.n, c:c + val.shape[1]] = val
+
+
+def generate(counts, K=1, seed=0, clk0=1, pc_base=0x200000, mem_pages=(4, 4), device="cpu"):
+    """counts: {instruction kind: positions in the loop body} over Add, Addi, Sub, Bitwise, Lt, Mul, ShiftLeft, ShiftRight,
+    Addw, Subw, UType, LoadByte/Half/Word/Double, StoreByte/Half/Word/Double, Branch, Jal, Jalr. The body is executed K times.
+    Returns (machine, tables, public_values): machine = [(AirProgram, InteractionProgram)] in chip-name order,
+    tables = {name: (prep, main)} canonical int64 [rows, width] tensors on `device` (rows padded to multiples of 32)."""
+    ex = Execution(counts, K, seed, clk0, pc_base, mem_pages, device)
+    return Tracer(ex).build()
+
+
+class Tracer:
+    def __init__(self, ex):
+        self.ex, self.dev, self.b = ex, ex.dev, ex.body
+        self.tables = {}
+        self.bumps = []              # MemoryBump events: (reg, prev_ts, value, ts)
+        self.state_bumps = []        # (clk_high, clk_low_sent, pc_sent[3], next pc value, next clk value)
+
+    # -- shared column groups
+    def fill_state(self, tb, k, p):
+        T = self.ex.T(k, p)
+        tb.set("state.clk_high", T >> 24)
+        tb.set("state.clk_16_24", (T >> 16) & 0xFF)
+        tb.set("state.clk_0_16", T & MASK16)
+        pc = self.ex.pc(p)
+        tb.set("state.pc", torch.stack([(pc >> (16 * i)) & MASK16 for i in range(3)], dim=1))
+
+    def fill_reg_access(self, tb, prefix, k, p, slot, live=None):
+        """RegisterAccessCols for the access in `slot` (memory/consistency/trace.rs:L22-L33, L104-L127). Returns prev value."""
+        ex = self.ex
+        val = ex.reg_value(k, p, slot)
+        pp, po, wrap = (x[p] for x in ex.prev[slot])
+        kp = k - wrap
+        t_prev = torch.where(kp >= 0, ex.T(kp.clamp(min=0), pp) + po, torch.zeros_like(k))
+        t_cur = ex.T(k, p) + POS_OFF[slot]
+        cross = (t_prev >> 24) != (t_cur >> 24)
+        if live is not None:
+            cross = cross & live
+        if bool(cross.any()):
+            reg = ex.slot_reg[slot][p]
+            self.bumps.append((reg[cross], t_prev[cross], val[cross], (t_cur[cross] >> 24) << 24))
+        old = torch.where(cross, torch.zeros_like(t_prev), t_prev & 0xFFFFFF)
+        diff = (t_cur & 0xFFFFFF) - old - 1
+        if live is not None:                                   # an immediate operand: no access, all-zero timestamp columns
+            old, diff = old * live, diff * live
+        tb.set(prefix + ".prev_value", limbs16(val))
+        tb.set(prefix + ".prev_low", old)
+        tb.set(prefix + ".diff_low_limb", diff & MASK16)
+        return val
+
+    def rows_of(self, chip):
+        pos = np.nonzero(self.b.chip == chip)[0]
+        k, p = self.ex._grid(pos)
+        return k, p
+
+    def table(self, chip, n):
+        air, _ = R.chip(chip)
+        tb = Table(air, n, self.dev)
+        self.tables[chip] = tb
+        return tb
+
+    # -- chips with the R / I / ALU adapters
+    def fill_adapter(self, tb, k, p, kind):
+        ex = self.ex
+        A, Bq = ex.slot_reg["A"][p], ex.slot_reg["B"][p]
+        tb.set("adapter.op_a", A.clamp(min=0))
+        tb.set("adapter.op_a_0", (A == 0).to(I64))
+        a_prev = self.fill_reg_access(tb, "adapter.op_a_memory", k, p, "A")
+        bval = cval = None
+        if kind in ("R", "I", "ALU"):
+            tb.set("adapter.op_b", Bq.clamp(min=0))
+            bval = self.fill_reg_access(tb, "adapter.op_b_memory", k, p, "B")
+        if kind == "R":
+            tb.set("adapter.op_c", ex.slot_reg["C"][p].clamp(min=0))
+            cval = self.fill_reg_access(tb, "adapter.op_c_memory", k, p, "C")
+        elif kind == "I":
+            cval = ex.imm[p]
+            tb.set("adapter.op_c_imm", limbs16(cval))
+        elif kind == "ALU":
+            is_imm = ex.has_imm[p]
+            live = ~is_imm
+            creg = ex.slot_reg["C"][p]
+            cv_reg = self.fill_reg_access(tb, "adapter.op_c_memory", k, p, "C", live=live)
+            cval = torch.where(is_imm, ex.imm[p], cv_reg)
+            tb.set("adapter.op_c_memory.prev_value", limbs16(cval))
+            opc = torch.where(is_imm[:, None], limbs16(ex.imm[p]), torch.stack([creg.clamp(min=0)] + [torch.zeros_like(creg)] * 3, dim=1))
+            tb.set("adapter.op_c", opc)
+            tb.set("adapter.imm_c", is_imm.to(I64))
+        elif kind == "J":
+            pass
+        return a_prev, bval, cval
+
+    def simple_alu(self, chip, kind, extra):
+        k, p = self.rows_of(chip)
+        n = len(p)
+        if n == 0:
+            return
+        tb = self.table(chip, n)
+        self.fill_state(tb, k, p)
+        _, bv, cv = self.fill_adapter(tb, k, p, kind)
+        a = self.ex.W[k, p]
+        extra(tb, k, p, a, bv, cv)
+
+    def build(self):
+        ex, b = self.ex, self.b
+        chips_present = set(b.chip.tolist())
+
+        def value_chip(name, kind, flag=None):
+            def extra(tb, k, p, a, bv, cv):
+                tb.set("value", limbs16(a))
+                tb.set("is_real", 1)
+            self.simple_alu(name, kind, extra)
+        value_chip("Add", "R")
+        value_chip("Addi", "I")
+        value_chip("Sub", "R")
+
+        def addw_extra(tb, k, p, a, bv, cv):
+            la = limbs16(a)
+            tb.set("value", la[:, :2])
+            tb.set("msb", la[:, 1] >> 15)
+            tb.set("is_real", 1)
+        self.simple_alu("Addw", "ALU", addw_extra)
+        self.simple_alu("Subw", "R", addw_extra)
+
+        def bitwise_extra(tb, k, p, a, bv, cv):
+            op = ex.op[p]
+            tb.set("b_low_bytes.low_bytes", limbs16(bv) & 0xFF)
+            tb.set("c_low_bytes.low_bytes", limbs16(cv) & 0xFF)
+            tb.set("result", bytes8(a))
+            for nm in ("XOR", "OR", "AND"):
+                tb.set("is_" + nm.lower(), (op == OPC[nm]).to(I64))
+        self.simple_alu("Bitwise", "ALU", bitwise_extra)
+
+        def lt_extra(tb, k, p, a, bv, cv):
+            signed = ex.op[p] == OPC["SLT"]
+            tb.set("is_slt", signed.to(I64))
+            tb.set("is_sltu", (~signed).to(I64))
+            self.fill_lt(tb, "lt", bv, cv, signed)
+        self.simple_alu("Lt", "ALU", lt_extra)
+        self.simple_alu("Mul", "R", self.mul_extra)
+        self.simple_alu("ShiftLeft", "ALU", self.sll_extra)
+        self.simple_alu("ShiftRight", "ALU", self.sr_extra)
+        self.utype()
+        self.jal()
+        self.jalr()
+        self.branch()
+        self.memory_instructions()
+        self.state_chain()
+        self.memory_local_and_bumps()
+        return self.finish()
+
+    def fill_lt(self, tb, prefix, bv, cv, signed):
+        """LtOperationSigned::populate_signed / LtOperationUnsigned::populate_unsigned (operations/slt.rs:L50-L174)."""
+        bl, cl = limbs16(bv), limbs16(cv)
+        s = signed.to(I64)
+        tb.set(prefix + ".b_msb", (bl[:, 3] >> 15) * s)
+        tb.set(prefix + ".c_msb", (cl[:, 3] >> 15) * s)
+        bc, cc = bl.clone(), cl.clone()
+        bc[:, 3] ^= s << 15
+        cc[:, 3] ^= s << 15
+        ne = bc != cc
+        # the most significant differing limb
+        idx = torch.where(ne[:, 3], 3, torch.where(ne[:, 2], 2, torch.where(ne[:, 1], 1, 0)))
+        any_ne = ne.any(dim=1)
+        flags = torch.zeros_like(bl)
+        flags[torch.arange(len(idx), device=idx.device), idx] = 1
+        flags = flags * any_ne[:, None].to(I64)
+        bsel = (bc * flags).sum(dim=1)
+        csel = (cc * flags).sum(dim=1)
+        tb.set(prefix + ".result.u16_flags", flags)
+        tb.set(prefix + ".result.comparison_limbs", torch.stack([bsel, csel], dim=1))
+        tb.set(prefix + ".result.not_eq_inv", torch.where(any_ne, finv(bsel - csel), torch.zeros_like(bsel)))
+        tb.set(prefix + ".result.bit", (bsel < csel).to(I64))
+
+    def mul_extra(self, tb, k, p, a, bv, cv):
+        """MulOperation::populate (operations/mul.rs:L54-L137)."""
+        op = self.ex.op[p]
+        is_ = {nm: op == OPC[nm] for nm in ("MUL", "MULH", "MULHU", "MULHSU", "MULW")}
+        for nm, m in is_.items():
+            tb.set("is_" + nm.lower(), m.to(I64))
+        tb.set("a", limbs16(a))
+        bb, cb = bytes8(bv), bytes8(cv)
+        b_msb, c_msb = bb[:, 7] >> 7, cb[:, 7] >> 7
+        bse = ((is_["MULH"] | is_["MULHSU"]).to(I64)) * b_msb
+        cse = is_["MULH"].to(I64) * c_msb
+        be = torch.cat([bb, (bse * 0xFF)[:, None].expand(-1, 8)], dim=1)
+        ce = torch.cat([cb, (cse * 0xFF)[:, None].expand(-1, 8)], dim=1)
+        prod = torch.zeros((len(p), 16), dtype=I64, device=self.dev)
+        for i in range(16):
+            for j in range(16 - i):
+                prod[:, i + j] += be[:, i] * ce[:, j]
+        carry = torch.zeros_like(prod)
+        for i in range(16):
+            carry[:, i] = prod[:, i] >> 8
+            prod[:, i] &= 0xFF
+            if i + 1 < 16:
+                prod[:, i + 1] += carry[:, i]
+        tb.set("mul.carry", carry)
+        tb.set("mul.product", prod)
+        tb.set("mul.b_lower_byte.low_bytes", limbs16(bv) & 0xFF)
+        tb.set("mul.c_lower_byte.low_bytes", limbs16(cv) & 0xFF)
+        tb.set("mul.b_msb", b_msb)
+        tb.set("mul.c_msb", c_msb)
+        tb.set("mul.product_msb", is_["MULW"].to(I64) * (limbs16(a)[:, 1] >> 15))
+        tb.set("mul.b_sign_extend", bse)
+        tb.set("mul.c_sign_extend", cse)
+
+    def _shift_fields(self, tb, cv, word_op):
+        c = cv & MASK16
+        tb.set("c_bits", torch.stack([(c >> i) & 1 for i in range(6)], dim=1))
+        amount = ((c >> 4) & 1) + 2 * ((c >> 5) & 1) * (~word_op).to(I64)
+        sh = torch.zeros((len(c), 4), dtype=I64, device=self.dev)
+        sh[torch.arange(len(c), device=self.dev), amount] = 1
+        tb.set("shift_u16", sh)
+        return c & 15
+
+    def sll_extra(self, tb, k, p, a, bv, cv):
+        """ShiftLeftChip::event_to_row (alu/sll/mod.rs)."""
+        op = self.ex.op[p]
+        w = op == OPC["SLLW"]
+        tb.set("is_sll", (~w).to(I64))
+        tb.set("is_sllw", w.to(I64))
+        tb.set("is_sllw_imm", (w & self.ex.has_imm[p]).to(I64))
+        tb.set("a", limbs16(a))
+        s = self._shift_fields(tb, cv, w)
+        tb.set("v_01", 1 << (s & 3))
+        tb.set("v_012", 1 << (s & 7))
+        tb.set("v_0123", 1 << s)
+        bl = limbs16(bv)
+        lower = bl & ((1 << (16 - s))[:, None] - 1)
+        higher = bl >> (16 - s)[:, None]
+        tb.set("lower_limb", lower)
+        tb.set("higher_limb", higher)
+        res = lower << s[:, None]
+        res[:, 1:] += higher[:, :3]
+        tb.set("limb_result", res)
+        tb.set("sllw_msb", w.to(I64) * (limbs16(a)[:, 1] >> 15))
+        for nm in ("v_01", "v_012", "v_0123"):                     # the padded row template (alu/sll/mod.rs:L154-L160)
+            tb.main[tb.n:, tb.L[nm]] = 1
+
+    def sr_extra(self, tb, k, p, a, bv, cv):
+        """ShiftRightChip::event_to_row (alu/sr/mod.rs:L239-L312)."""
+        op = self.ex.op[p]
+        is_ = {nm: op == OPC[nm] for nm in ("SRL", "SRA", "SRLW", "SRAW")}
+        for nm, m in is_.items():
+            tb.set("is_" + nm.lower(), m.to(I64))
+        w = is_["SRLW"] | is_["SRAW"]
+        tb.set("is_w_imm", (w & self.ex.has_imm[p]).to(I64))
+        tb.set("a", limbs16(a))
+        s = self._shift_fields(tb, cv, w)
+        tb.set("v_01", 1 << (4 - (s & 3)))
+        tb.set("v_012", 1 << (8 - (s & 7)))
+        v = 1 << (16 - s)
+        tb.set("v_0123", v)
+        bl = limbs16(bv)
+        msb = torch.where(is_["SRA"], bl[:, 3] >> 15, torch.where(is_["SRAW"], bl[:, 1] >> 15, torch.zeros_like(s)))
+        tb.set("b_msb", msb)
+        tb.set("sra_msb_v0123", msb * v)
+        bl = bl.clone()
+        bl[:, 2:] *= (~w).to(I64)[:, None]
+        tb.set("srw_msb", w.to(I64) * (limbs16(a)[:, 1] >> 15))
+        lower = bl & ((1 << s)[:, None] - 1)
+        higher = bl >> s[:, None]
+        tb.set("lower_limb", lower)
+        tb.set("higher_limb", higher)
+        res = higher.clone()
+        res[:, :3] += lower[:, 1:] * v[:, None]
+        tb.set("limb_result", res)
+        for nm, val in (("v_01", 16), ("v_012", 256), ("v_0123", 65536)):      # padded row template (alu/sr/mod.rs:L165-L171)
+            tb.main[tb.n:, tb.L[nm]] = val
+
+    def utype(self):
+        k, p = self.rows_of("UType")
+        if len(p) == 0:
+            return
+        tb = self.table("UType", len(p))
+        self.fill_state(tb, k, p)
+        self.fill_adapter(tb, k, p, "J")
+        imm = self.ex.imm[p]
+        tb.set("adapter.op_b_imm", limbs16(imm))
+        tb.set("adapter.op_c_imm", limbs16(imm))
+        auipc = self.ex.op[p] == OPC["AUIPC"]
+        pc = self.ex.pc(p)
+        tb.set("addend", limbs16(pc)[:, :3] * auipc.to(I64)[:, None])
+        tb.set("value", limbs16(self.ex.W[k, p]))
+        tb.set("is_auipc", auipc.to(I64))
+        tb.set("is_real", 1)
+
+    def jal(self):
+        k, p = self.rows_of("Jal")
+        if len(p) == 0:
+            return
+        tb = self.table("Jal", len(p))
+        self.fill_state(tb, k, p)
+        self.fill_adapter(tb, k, p, "J")
+        imm = self.ex.imm[p]
+        tb.set("adapter.op_b_imm", limbs16(imm))
+        pc = self.ex.pc(p)
+        tb.set("next_pc", limbs16(pc + imm))
+        rd0 = self.ex.slot_reg["A"][p] == 0
+        tb.set("op_a_value", limbs16(pc + 4) * (~rd0).to(I64)[:, None])
+        tb.set("is_real", 1)
+
+    def jalr(self):
+        k, p = self.rows_of("Jalr")
+        if len(p) == 0:
+            return
+        tb = self.table("Jalr", len(p))
+        self.fill_state(tb, k, p)
+        _, bv, cv = self.fill_adapter(tb, k, p, "I")
+        tb.set("next_pc", limbs16(bv + cv))
+        tb.set("op_a_value", limbs16(self.ex.pc(p) + 4))
+        tb.set("lsb", (bv + cv) & 1)
+        tb.set("is_real", 1)
+
+    def branch(self):
+        k, p = self.rows_of("Branch")
+        if len(p) == 0:
+            return
+        ex = self.ex
+        tb = self.table("Branch", len(p))
+        self.fill_state(tb, k, p)
+        av, bv, _ = self.fill_adapter(tb, k, p, "I")
+        op = ex.op[p]
+        for nm in BRANCH_OPS:
+            tb.set("is_" + nm.lower(), (op == OPC[nm]).to(I64))
+        signed = (op == OPC["BLT"]) | (op == OPC["BGE"])
+        self.fill_lt(tb, "cmp", av, bv, signed)
+        eq = av == bv
+        lt = torch.where(signed, av < bv, ult(av, bv))
+        taken = torch.where(op == OPC["BEQ"], eq, torch.where(op == OPC["BNE"], ~eq,
+                            torch.where((op == OPC["BLT"]) | (op == OPC["BLTU"]), lt, ~lt)))
+        tb.set("is_branching", taken.to(I64))
+        tb.set("next_pc", limbs16(ex.pc(p) + 4)[:, :3])          # taken or not, the offset is 4
+
+    def memory_instructions(self):
+        """Load / store chips' event_to_row (memory/instructions/**) + MemoryAccessCols::populate (consistency/trace.rs:L64-L101)."""
+        ex, b, dev = self.ex, self.b, self.dev
+        names = [c for c in list(LOAD_KINDS) + list(STORE_KINDS) if (b.chip == c).any()]
+        self.mem_words = None
+        if not names:
+            return
+        ks, ps = zip(*(self.rows_of(c) for c in names))
+        k, p = torch.cat(ks), torch.cat(ps)
+        op = ex.op[p]
+        ptr = ex.reg_value(k, p, "B")
+        addr = ptr + ex.imm[p]
+        word = addr >> 3
+        t_cur = ex.T(k, p) + POS_OFF["M"]
+        is_store = torch.zeros_like(op, dtype=torch.bool)
+        nbytes = torch.ones_like(op)
+        for nm, nb in ACCESS_BYTES.items():
+            m = op == OPC[nm]
+            nbytes = torch.where(m, torch.full_like(op, nb), nbytes)
+            if nm.startswith("S"):
+                is_store |= m
+        store_reg_val = ex.reg_value(k, p, "A")                           # stores: op_a = rs2
+        # sort by (word, time)
+        order = torch.argsort(t_cur, stable=True)
+        order = order[torch.argsort(word[order], stable=True)]
+        w_s, t_s = word[order], t_cur[order]
+        first = torch.ones_like(w_s, dtype=torch.bool)
+        first[1:] = w_s[1:] != w_s[:-1]
+        prev_t = torch.where(first, torch.zeros_like(t_s), torch.roll(t_s, 1))
+        # values: byte lanes, last-writer scan within each word's segment
+        idx = torch.arange(len(w_s), device=dev)
+        seg_start = torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), dim=0).values
+        st_s, nb_s, off_s = is_store[order], nbytes[order], (addr[order] & 7)
+        data_s = store_reg_val[order]
+        initial = self.initial_word(w_s)
+        after = torch.zeros_like(initial)
+        for lane in range(8):
+            covers = st_s & (off_s <= lane) & (lane < off_s + nb_s)
+            lastw = torch.cummax(torch.where(covers, idx, torch.full_like(idx, -1)), dim=0).values
+            has = lastw >= seg_start
+            src = lastw.clamp(min=0)
+            byte_from_store = (data_s[src] >> (8 * (lane - off_s[src]).clamp(min=0))) & 0xFF
+            byte = torch.where(has, byte_from_store, (initial >> (8 * lane)) & 0xFF)
+            after = after | (byte << (8 * lane))
+        prev_val = torch.where(first, initial, torch.roll(after, 1))
+        # un-sort
+        inv = torch.empty_like(order)
+        inv[order] = idx
+        prev_t_u, prev_val_u, after_u = prev_t[inv], prev_val[inv], after[inv]
+        # per word: initial value, final value, last timestamp (for MemoryLocal)
+        last = torch.ones_like(first)
+        last[:-1] = first[1:]
+        self.mem_words = (w_s[last], initial[last], after[last], t_s[last])
+        base = 0
+        for c, kc in zip(names, ks):
+            n = len(kc)
+            sl = slice(base, base + n)
+            base += n
+            self.fill_mem_chip(c, k[sl], p[sl], addr[sl], t_cur[sl], prev_t_u[sl], prev_val_u[sl], after_u[sl], store_reg_val[sl])
+
+    def initial_word(self, w):
+        """Initial 64-bit content of word index w: the read-only image, or the store region's initial image (same generator)."""
+        return self.ex.load_value(w << 3)
+
+    def fill_mem_chip(self, chip, k, p, addr, t_cur, t_prev, prev_val, new_val, reg_val):
+        ex = self.ex
+        tb = self.table(chip, len(p))
+        self.fill_state(tb, k, p)
+        self.fill_adapter(tb, k, p, "I")
+        al = limbs16(addr)
+        tb.set("address.value", al[:, :3])
+        tb.set("address.top_two_limb_inv", finv(al[:, 1] + al[:, 2]))
+        tb.set("memory_access.prev_value", limbs16(prev_val))
+        ph, pl, ch, cl = t_prev >> 24, t_prev & 0xFFFFFF, t_cur >> 24, t_cur & 0xFFFFFF
+        same = ph == ch
+        tb.set("memory_access.prev_high", ph)
+        tb.set("memory_access.prev_low", pl)
+        tb.set("memory_access.compare_low", same.to(I64))
+        d = torch.where(same, cl - pl, ch - ph) - 1
+        tb.set("memory_access.diff_low_limb", d & MASK16)
+        tb.set("memory_access.diff_high_limb", d >> 16)
+        op = ex.op[p]
+        bits = [(addr >> i) & 1 for i in range(3)]
+        pvl = limbs16(prev_val)
+        rows = torch.arange(len(p), device=self.dev)
+        if chip in ("LoadByte", "StoreByte"):
+            tb.set("offset_bit", torch.stack(bits, dim=1))
+        elif chip in ("LoadHalf", "StoreHalf"):
+            tb.set("offset_bit", torch.stack(bits[1:], dim=1))
+        elif chip in ("LoadWord", "StoreWord"):
+            tb.set("offset_bit", bits[2])
+        limb = pvl[rows, (addr >> 1) & 3]
+        if chip == "LoadByte":
+            byte = (limb >> (8 * bits[0])) & 0xFF
+            lb = op == OPC["LB"]
+            tb.set("selected_limb", limb)
+            tb.set("selected_limb_low_byte", limb & 0xFF)
+            tb.set("selected_byte", byte)
+            tb.set("msb", lb.to(I64) * (byte >> 7))
+            tb.set("is_lb", lb.to(I64))
+            tb.set("is_lbu", (~lb).to(I64))
+        elif chip == "LoadHalf":
+            lh = op == OPC["LH"]
+            tb.set("selected_half", limb)
+            tb.set("msb", lh.to(I64) * (limb >> 15))
+            tb.set("is_lh", lh.to(I64))
+            tb.set("is_lhu", (~lh).to(I64))
+        elif chip == "LoadWord":
+            lw = op == OPC["LW"]
+            sel = torch.where(bits[2][:, None] == 1, pvl[:, 2:], pvl[:, :2])
+            tb.set("selected_word", sel)
+            tb.set("msb", lw.to(I64) * (sel[:, 1] >> 15))
+            tb.set("is_lw", lw.to(I64))
+            tb.set("is_lwu", (~lw).to(I64))
+        elif chip == "LoadDouble":
+            tb.set("is_real", 1)
+        else:
+            tb.set("is_real", 1)
+            if chip != "StoreDouble":
+                tb.set("store_value", limbs16(new_val))
+            if chip == "StoreByte":
+                rl = reg_val & 0xFF
+                ml, mh = limb & 0xFF, limb >> 8
+                tb.set("mem_limb", limb)
+                tb.set("mem_limb_low_byte", ml)
+                tb.set("register_low_byte", rl)
+                inc = torch.where(bits[0] == 1, 256 * (rl - mh), rl - ml)
+                tb.set("increment", inc % P)
+
+    # -- the CPU state chain: StateBump rows where a sent state is not in normal form (adapter/bump.rs)
+    def state_chain(self):
+        ex, b, dev = self.ex, self.b, self.dev
+        K, L = ex.K, ex.L
+        n = torch.arange(K * L, device=dev)
+        k, p = n // L, n % L
+        T = ex.T(k, p)
+        pc = ex.pc(p)
+        normal_pc = torch.as_tensor(np.isin(b.chip, ["Branch", "Jal", "Jalr"]), device=dev)[p]   # these chips normalise next_pc
+        nxt_pc = torch.where(p == L - 1, torch.full_like(pc, b.pc_base), pc + 4)
+        pc_carry = (~normal_pc) & (((pc & MASK16) + 4) > MASK16)
+        clk_carry = ((T & 0xFFFFFF) + 8) >= (1 << 24)
+        need = pc_carry | clk_carry
+        self.final_state = (int(T[-1]) + 8, int(nxt_pc[-1]))
+        if bool(need.any()):
+            Tn, pcn, nxt, pcc = T[need], pc[need], nxt_pc[need], pc_carry[need]
+            air, _ = R.chip("StateBump")
+            tb = Table(air, len(Tn), dev)
+            self.tables["StateBump"] = tb
+            nT = Tn + 8
+            tb.set("next_clk_32_48", nT >> 32)
+            tb.set("next_clk_24_32", (nT >> 24) & 0xFF)
+            tb.set("next_clk_16_24", (nT >> 16) & 0xFF)
+            tb.set("next_clk_0_16", nT & MASK16)
+            tb.set("clk_high", Tn >> 24)
+            tb.set("clk_low", (Tn & 0xFFFFFF) + 8)
+            tb.set("next_pc", limbs16(nxt)[:, :3])
+            sent = limbs16(pcn)[:, :3].clone()
+            sent_norm = limbs16(nxt)[:, :3]
+            sent[:, 0] += 4
+            tb.set("pc", torch.where(pcc[:, None], sent, sent_norm))
+            tb.set("is_clk", ((nT >> 24) != (Tn >> 24)).to(I64))
+            tb.set("is_real", 1)
+
+    def memory_local_and_bumps(self):
+        """MemoryLocal rows (memory/local.rs generate_trace: one row per touched address) and MemoryBump rows (memory/bump.rs)."""
+        ex, dev = self.ex, self.dev
+        K = ex.K
+        regs = torch.as_tensor(ex.touched_regs, device=dev)
+        lp = torch.as_tensor([ex.last_access[int(r)][0] for r in regs], device=dev)
+        lo = torch.as_tensor([ex.last_access[int(r)][1] for r in regs], device=dev)
+        kk = torch.full_like(lp, K - 1)
+        final_t = ex.T(kk, lp) + lo
+        lastw = ex.lastw[regs]
+        final_v = torch.where(lastw >= 0, ex.W[K - 1, lastw.clamp(min=0)], ex.init[regs])
+        final_v = torch.where(regs == 0, torch.zeros_like(final_v), final_v)
+        init_v = torch.where(regs == 0, torch.zeros_like(final_v), ex.init[regs])
+        addr, iv, fv, ft = regs, init_v, final_v, final_t
+        if self.mem_words is not None:
+            w, wi, wf, wt = self.mem_words
+            addr, iv, fv, ft = torch.cat([addr, w << 3]), torch.cat([iv, wi]), torch.cat([fv, wf]), torch.cat([ft, wt])
+        air, _ = R.chip("MemoryLocal")
+        tb = Table(air, len(addr), dev)
+        self.tables["MemoryLocal"] = tb
+        tb.set("addr", limbs16(addr)[:, :3])
+        tb.set("final_clk_high", ft >> 24)
+        tb.set("final_clk_low", ft & 0xFFFFFF)
+        for tag, v in (("initial", iv), ("final", fv)):
+            l = limbs16(v)
+            tb.set(tag + "_value", l)
+            tb.set(tag + "_value_lower", l[:, 2] & 0xFF)
+            tb.set(tag + "_value_upper", l[:, 2] >> 8)
+        tb.set("is_real", 1)
+        if self.bumps:
+            reg, tp, val, tc = (torch.cat(x) for x in zip(*self.bumps))
+            air, _ = R.chip("MemoryBump")
+            tb = Table(air, len(reg), dev)
+            self.tables["MemoryBump"] = tb
+            tb.set("access.prev_value", limbs16(val))
+            ph, pl, ch = tp >> 24, tp & 0xFFFFFF, tc >> 24
+            tb.set("access.prev_high", ph)
+            tb.set("access.prev_low", pl)
+            tb.set("access.compare_low", 0)
+            d = ch - ph - 1
+            tb.set("access.diff_low_limb", d & MASK16)
+            tb.set("access.diff_high_limb", d >> 16)
+            tb.set("clk_32_48", tc >> 32)
+            tb.set("clk_24_32", (tc >> 24) & 0xFF)
+            tb.set("clk_16_24", 0)
+            tb.set("clk_0_16", 0)
+            tb.set("addr", reg)
+            tb.set("is_real", 1)
+
+    # -- closing chips + table multiplicities
+    def finish(self):
+        ex, b, dev = self.ex, self.b, self.dev
+        machine = {}
+        for name, tb in self.tables.items():
+            machine[name] = R.chip(name)
+        # Boundary: sends the initial state, receives the final one (stands in for eval_public_values' eval_state)
+        air, it = boundary_chip()
+        tb = Table(air, 2, dev)
+        t0, t1 = ex.clk0, self.final_state[0]
+        pc1 = self.final_state[1]
+        if (t1 >> 24) != ((t1 - 8) >> 24) and "StateBump" not in self.tables:
+            raise AssertionError("unreachable: a clock carry always has its StateBump row")
+        tb.main[0] = torch.tensor([t0 >> 24, t0 & 0xFFFFFF] + [(b.pc_base >> (16 * i)) & MASK16 for i in range(3)] + [1, 0], device=dev)
+        tb.main[1] = torch.tensor([t1 >> 24, t1 & 0xFFFFFF] + [(pc1 >> (16 * i)) & MASK16 for i in range(3)] + [0, 1], device=dev)
+        self.tables["Boundary"], machine["Boundary"] = tb, (air, it)
+        # GlobalSink: receives what MemoryLocal sends to the Global chip
+        ml = self.tables["MemoryLocal"]
+        msgs = eval_interactions(R.chip("MemoryLocal")[1], ml.main[:ml.n], None, kinds=(R.GLOBAL,))
+        air, it = global_sink_chip()
+        rows = torch.cat([v for _, v, _ in msgs])
+        tb = Table(air, rows.shape[0], dev)
+        tb.main[:tb.n, :11] = rows
+        tb.main[:tb.n, 11] = 1
+        self.tables["GlobalSink"], machine["GlobalSink"] = tb, (air, it)
+        # Program: one row per body position (program/trusted.rs:L80-L131), multiplicity = K
+        air, it = R.chip("Program")
+        tb = Table(air, ex.L, dev)
+        p = torch.arange(ex.L, device=dev)
+        self._program_rows(tb, p)
+        tb.main[:tb.n, 0] = ex.K
+        if tb.prep.shape[0] > tb.n:                               # padding rows repeat instruction 0 with multiplicity 0
+            tb.prep[tb.n:] = tb.prep[0]
+        self.tables["Program"], machine["Program"] = tb, (air, it)
+        # Byte / Range: multiplicities counted from the messages actually sent
+        byte_air, byte_it = R.chip("Byte")
+        range_air, range_it = R.chip("Range")
+        bt, rt = Table(byte_air, 1 << 16, dev), Table(range_air, 1 << 17, dev)
+        bc = torch.arange(1 << 16, device=dev)
+        bb, cc = bc >> 8, bc & 0xFF
+        bt.prep[:, 0], bt.prep[:, 1], bt.prep[:, 2], bt.prep[:, 3], bt.prep[:, 4] = bb, cc, bb & cc, bb | cc, bb ^ cc
+        bt.prep[:, 5], bt.prep[:, 6] = (bb < cc).to(I64), bb >> 7
+        ri = torch.arange(1 << 17, device=dev)
+        bits = torch.where(ri == 0, torch.zeros_like(ri), (torch.log2(ri.clamp(min=1).to(torch.float64)).floor()).to(I64))
+        rt.prep[:, 0], rt.prep[:, 1] = torch.where(ri == 0, torch.zeros_like(ri), ri - (1 << bits)), bits
+        for name, tbl in self.tables.items():
+            _, it = machine[name]
+            for mult, vals, _ in eval_interactions(it, tbl.main[:tbl.n], tbl.prep[:tbl.n] if tbl.prep is not None else None, kinds=(R.BYTE,), sends_only=True):
+                opc, a, x, y = vals[:, 0], vals[:, 1], vals[:, 2], vals[:, 3]
+                is_range = opc == R.B_RANGE
+                if bool(is_range.any()):
+                    aa, bits_ = a[is_range], x[is_range]
+                    assert bool(((bits_ <= 16) & (aa < (1 << bits_.clamp(max=16))) & (y[is_range] == 0)).all()), (name, "range check fails")
+                    rt.main[:, 0] += torch.bincount((1 << bits_) + aa, weights=mult[is_range].to(torch.float64), minlength=1 << 17).to(I64)
+                nb = ~is_range
+                if bool(nb.any()):
+                    o, aa, xx, yy, mm = opc[nb], a[nb], x[nb], y[nb], mult[nb]
+                    assert bool(((xx < 256) & (yy < 256) & (o < 6)).all()), (name, "byte operand out of range")
+                    row = xx * 256 + yy
+                    want = torch.where(o == R.B_U8RANGE, torch.zeros_like(aa),
+                                       torch.where(o == R.B_MSB, xx >> 7, bt.prep[row, 2 + o.clamp(max=4) - (o > 3).to(I64)]))
+                    assert bool((aa == want).all()), (name, "byte lookup result is wrong")
+                    assert bool(((o != R.B_MSB) | (yy == 0)).all()), name
+                    flat = torch.bincount(row * 6 + o, weights=mm.to(torch.float64), minlength=6 << 16).to(I64)
+                    bt.main += flat.view(1 << 16, 6)
+        self.tables["Byte"], machine["Byte"] = bt, (byte_air, byte_it)
+        self.tables["Range"], machine["Range"] = rt, (range_air, range_it)
+        names = sorted(machine)
+        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, torch.zeros(0, dtype=I64)
+
+    def _program_rows(self, tb, p):
+        ex = self.ex
+        pc = ex.pc(p)
+        tb.prep[:tb.n, 0:3] = limbs16(pc)[:, :3]
+        tb.prep[:tb.n, 3] = ex.op[p]
+        A, Bq, C = ex.slot_reg["A"][p], ex.slot_reg["B"][p], ex.slot_reg["C"][p]
+        op = ex.op[p]
+        tb.prep[:tb.n, 4] = A.clamp(min=0)
+        # op_b: a register number, or the immediate of the J / U types (op_b = op_c = imm for U; JAL: op_b = imm, op_c = 0)
+        utype = (op == OPC["LUI"]) | (op == OPC["AUIPC"])
+        jal = op == OPC["JAL"]
+        imm_l = limbs16(ex.imm[p])
+        regw = lambda r: torch.stack([r.clamp(min=0)] + [torch.zeros_like(r)] * 3, dim=1)
+        tb.prep[:tb.n, 5:9] = torch.where((utype | jal)[:, None], imm_l, regw(Bq))
+        opc = torch.where(ex.has_imm[p][:, None], imm_l, regw(C))
+        opc = torch.where(jal[:, None], torch.zeros_like(opc), opc)
+        tb.prep[:tb.n, 9:13] = opc
+        tb.prep[:tb.n, 13] = (A == 0).to(I64)
+        tb.prep[:tb.n, 14] = (utype | jal).to(I64)
+        tb.prep[:tb.n, 15] = ex.has_imm[p].to(I64)
+
+
+def eval_vcol(v, prep, main):
+    acc = torch.full((main.shape[0],), v.constant, dtype=I64, device=main.device)
+    for kind, col, w in v.terms:
+        acc = (acc + (main if kind == "main" else prep)[:, col] * w) % P
+    return acc
+
+
+def eval_interactions(it, main, prep, kinds=None, sends_only=False):
+    """[(multiplicity [m], values [m, n_values], is_send)] over the rows with a non-zero multiplicity."""
+    out = []
+    for is_send, lst in ((True, it.sends), (False, it.receives)):
+        if sends_only and not is_send:
+            continue
+        for kind, values, mult in lst:
+            if kinds is not None and kind not in kinds:
+                continue
+            m = eval_vcol(mult, prep, main)
+            live = m != 0
+            if not bool(live.any()):
+                continue
+            mm, pl = main[live], (prep[live] if prep is not None else None)
+            vals = torch.stack([eval_vcol(v, pl, mm) for v in values], dim=1)
+            out.append((m[live], vals, is_send))
+    return out
+
+
+def boundary_chip():
+    """Synthetic: [clk_high, clk_low, pc0, pc1, pc2, is_send, is_receive]; sends / receives one State message per row."""
+    from .rv_builder import Builder
+    b = Builder("Boundary", 7)
+    c = [b.main(i) for i in range(7)]
+    b.assert_bool(c[5])
+    b.assert_bool(c[6])
+    b.send(R.STATE, c[:5], c[5])
+    b.receive(R.STATE, c[:5], c[6])
+    return b.air, b.it
+
+
+def global_sink_chip():
+    """Synthetic: receives MemoryLocal's 11-word `Global` messages where the reference's Global chip would."""
+    from .rv_builder import Builder
+    b = Builder("GlobalSink", 12)
+    c = [b.main(i) for i in range(12)]
+    b.assert_bool(c[11])
+    b.receive(R.GLOBAL, c[:11], c[11])
+    return b.air, b.it
+
+
+def to_monty_np(t):
+    """canonical int64 tensor -> Montgomery uint32 numpy (row-major)."""
+    return ((t.cpu().numpy().astype(np.uint64) << np.uint64(32)) % np.uint64(P)).astype(np.uint32)
