@@ -1,0 +1,100 @@
+"""The core shard of REAL RISC-V chips: the rv64im chips transcribed in sp1_amd/machines/riscv.py at the
+heights of the reference's recorded core shard 0 (sp1-gpu/crates/logup_gkr/layer_workloads.json, decoded by chip name in
+riscv.RECORDED_ROWS), proved on traces that sp1_amd/machines/riscv_trace.py EXECUTES (a loop body run K = 13 times: the
+recorded shard executes ~6.2e6 instructions of a 4.7e5-instruction program).
+
+What is real: every chip of that shard except LoadX0 / DivRem / SyscallInstrs / SyscallCore (0.15 % of its area) —
+the 22 instruction chips, MemoryLocal, MemoryBump, StateBump, Program, Byte, Range and the septic-curve Global chip (a
+Poseidon2 permutation + curve arithmetic per row: a third of the shard's cells) — constraints, interactions, and traces
+with RISC-V semantics whose lookups balance. What is synthetic: two 2-row closing chips, `Boundary` and
+`GlobalAccBoundary`, standing in for the interactions of `eval_public_values` (initial / final CPU state, the two ends of
+the global digest chain). `real_global=False` swaps the Global chip for a sink + a filler of its recorded shape (the round-4
+intermediate workload; kept for A/B).
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sp1_amd import api                                            # noqa: E402
+from sp1_amd.machines import riscv as R, riscv_trace as RT         # noqa: E402
+
+K_ITER = 13
+NOT_INSTRUCTIONS = ("Byte", "Range", "Program", "MemoryLocal", "MemoryBump", "StateBump", "Global", "DivRem", "SyscallCore",
+                    "SyscallInstrs", "LoadX0")
+P = api.P
+
+
+def recorded_counts(scale, K=K_ITER):
+    """Loop-body positions per instruction chip so that K executions give `scale` x the recorded heights."""
+    return {n: max(1, int(round(rows * scale / K))) for n, rows in R.RECORDED_ROWS.items() if n not in NOT_INSTRUCTIONS}
+
+
+def to_col_major(t):
+    """canonical int64 [rows, width] on the device -> api.ColMajor (Montgomery words)."""
+    rows, width = t.shape
+    m = ((t << 32) % P).to(torch.int32)
+    return api.ColMajor(m.t().contiguous().view(-1), rows, width)
+
+
+SYNTHETIC = ("Boundary", "GlobalAccBoundary", "GlobalSink", "GlobalFiller")
+
+
+def machine_only(scale=1.0, seed=1, K=K_ITER, device="cuda", real_global=True):
+    counts = recorded_counts(scale, K)
+    pages = max(4, int(600 * scale))
+    machine, tabs, _ = RT.generate(counts, K=K, seed=seed, mem_pages=(pages, pages), device=device, real_global=real_global)
+    return machine, tabs
+
+
+def build_real_shard(scale=1.0, seed=1, K=K_ITER, real_global=True):
+    """[(AirProgram, InteractionProgram, main ColMajor, prep ColMajor | None)] in chip-name order + meta, on cuda."""
+    from core_shard import chip_programs, chip_trace
+    machine, tabs = machine_only(scale, seed, K, "cuda", real_global)
+    chips = {a.name: (a, i, to_col_major(tabs[a.name][1]), to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+             for a, i in machine}
+    real_area = sum(c[2].height * (c[2].width + (c[3].width if c[3] is not None else 0)) for n, c in chips.items()
+                    if n not in SYNTHETIC)
+    del tabs
+    synthetic = [n for n in chips if n in SYNTHETIC]
+    if not real_global:
+        w, ncons, nint = R.RECORDED["Global"]
+        rows = max(32, int(round(R.RECORDED_ROWS["Global"] * scale / 32)) * 32)
+        air, inter = chip_programs("GlobalFiller", w, 0, ncons, nint)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        chips["GlobalFiller"] = (air, inter, chip_trace(rows, w, gen), None)
+        synthetic.append("GlobalFiller")
+    out = [chips[n] for n in sorted(chips)]
+    area = sum(c[2].height * (c[2].width + (c[3].width if c[3] is not None else 0)) for c in out)
+    per_chip = {a.name: {"rows": m.height, "columns": a.main_width + a.prep_width, "constraints": a.num_constraints,
+                         "interactions": i.num_interactions, "instructions": len(a.instrs),
+                         "instr_per_constraint": round(len(a.instrs) / a.num_constraints, 2) if a.num_constraints else None}
+                for a, i, m, _ in out}
+    meta = {"chips": len(out), "real_chips": sorted(n for n in chips if n not in synthetic), "synthetic_chips": synthetic,
+            "area_cells": area, "real_area_cells": real_area, "interactions": sum(c[1].num_interactions for c in out),
+            "constraints": sum(c[0].num_constraints for c in out),
+            "first_layer_entries": sum(c[2].height * c[1].num_interactions for c in out),
+            "instructions_executed": K * sum(recorded_counts(scale, K).values()), "loop_iterations": K, "per_chip": per_chip}
+    return out, meta
+
+
+def programs_for(names):
+    """(AirProgram, InteractionProgram) by chip name, for a verifier child that has no traces."""
+    from core_shard import chip_programs
+    out = []
+    for n in names:
+        if n == "Boundary":
+            out.append(RT.boundary_chip())
+        elif n == "GlobalSink":
+            out.append(RT.global_sink_chip())
+        elif n == "GlobalAccBoundary":
+            out.append(RT.global_acc_boundary_chip())
+        elif n == "GlobalFiller":
+            w, ncons, nint = R.RECORDED["Global"]
+            out.append(chip_programs("GlobalFiller", w, 0, ncons, nint))
+        else:
+            out.append(R.chip(n))
+    return out

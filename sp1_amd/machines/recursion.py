@@ -154,19 +154,14 @@ def _ext_linear(s):
     return [t[j] + sums[j % 4] for j in range(16)]
 
 
-def poseidon2_wide():
+def poseidon2_permutation_constraints(air, base=0):
+    """`eval_external_round` for r = 0..7, then `eval_internal_rounds` (hypercube/src/operations/poseidon2/air.rs:L66-L144) on
+    the 179 columns of a Poseidon2Degree3Cols starting at main column `base`: 128 + 35 constraints, in the reference's order.
+    Shared by Poseidon2WideDeg3 here and by the RISC-V machine's Global chip (riscv.py)."""
     rc = _round_constants()
-    air, it = AirProgram("Poseidon2WideDeg3", P2_WIDTH, 49, cse=True), InteractionProgram("Poseidon2WideDeg3", P2_WIDTH, 49)
-    x00 = air.main(P2_EXT(0, 0))
-    cube = x00 * x00 * x00
-    air.assert_zero(cube - cube)                                     # "dummy constraint to normalize to DEGREE"
-    # prep: input[16] addresses, output[16] x {addr, mult}, is_real
-    for i in range(16):
-        it.receive(MEMORY, _single(VCol.prep(i), VCol.main(P2_EXT(0, i))), VCol.prep(48))
-    for i in range(16):
-        it.send(MEMORY, _single(VCol.prep(16 + 2 * i), VCol.main(P2_OUT(i))), VCol.prep(16 + 2 * i + 1))
+    main = lambda idx: air.main(base + idx)
     for r in range(8):
-        state = [air.main(P2_EXT(r, i)) for i in range(16)]
+        state = [main(P2_EXT(r, i)) for i in range(16)]
         if r == 0:
             state = _ext_linear(state)
         consts = rc[r] if r < 4 else rc[24 + (r - 4)]
@@ -175,7 +170,7 @@ def poseidon2_wide():
         nxt = [P2_INT(i) for i in range(16)] if r == 3 else [P2_OUT(i) for i in range(16)] if r == 7 else \
             [P2_EXT(r + 1, i) for i in range(16)]
         for i in range(16):
-            air.assert_zero(air.main(nxt[i]) - state[i])
+            air.assert_zero(main(nxt[i]) - state[i])
     # Internal rounds, in CLOSED FORM. The reference's eval threads the 15 passive lanes through all 20 rounds, so the
     # constraint on s0[r] depends on every earlier round: one dependency chain of ~1100 operations. But the lanes evolve
     # LINEARLY — x_i' = R (S + d_i x_i), S = cube + sum of the passive lanes — so every lane value is a fixed linear
@@ -197,8 +192,8 @@ def poseidon2_wide():
 
     def term_value(kind, idx):
         if kind == "x":
-            return air.main(P2_INT(idx))
-        y = (air.main(P2_INT(0)) if idx == 0 else air.main(P2_S0(idx - 1))) + rc[4 + idx][0]    # cube of round idx: its lane-0 input is a column
+            return main(P2_INT(idx))
+        y = (main(P2_INT(0)) if idx == 0 else main(P2_S0(idx - 1))) + rc[4 + idx][0]    # cube of round idx: its lane-0 input is a column
         return y * y * y
 
     def emit_group(targets):
@@ -218,7 +213,7 @@ def poseidon2_wide():
                     v = term if c == 1 else term * c
                     accs[j] = v if accs[j] is None else accs[j] + v
                 if last[j] == k:
-                    air.assert_zero(air.main(col) - accs[j])
+                    air.assert_zero(main(col) - accs[j])
 
     lanes = {i: {("x", i): 1} for i in range(1, 16)}      # passive lanes as linear forms
     lane0 = None
@@ -234,6 +229,20 @@ def poseidon2_wide():
             s0_targets.append((P2_S0(r), lane0))
     emit_group(s0_targets)
     emit_group([(P2_EXT(4, 0), lane0)] + [(P2_EXT(4, i), lanes[i]) for i in range(1, 16)])
+
+
+def poseidon2_wide():
+    rc = _round_constants()
+    air, it = AirProgram("Poseidon2WideDeg3", P2_WIDTH, 49, cse=True), InteractionProgram("Poseidon2WideDeg3", P2_WIDTH, 49)
+    x00 = air.main(P2_EXT(0, 0))
+    cube = x00 * x00 * x00
+    air.assert_zero(cube - cube)                                     # "dummy constraint to normalize to DEGREE"
+    # prep: input[16] addresses, output[16] x {addr, mult}, is_real
+    for i in range(16):
+        it.receive(MEMORY, _single(VCol.prep(i), VCol.main(P2_EXT(0, i))), VCol.prep(48))
+    for i in range(16):
+        it.send(MEMORY, _single(VCol.prep(16 + 2 * i), VCol.main(P2_OUT(i))), VCol.prep(16 + 2 * i + 1))
+    poseidon2_permutation_constraints(air)
     return air, it
 
 

@@ -990,12 +990,102 @@ def jalr_chip():                                                           # con
     return _done(b, c)
 
 
+
+# ---- the Global chip: septic-curve digest of every global interaction (global/mod.rs, operations/global_interaction.rs,
+# operations/global_accumulation.rs; F_p^7 = F_p[z] / (z^7 - 3 z - 5), curve y^2 = x^3 + 45 x + 41 z^3: hypercube/src/septic_*.rs)
+CURVE_CUMULATIVE_SUM_START = ([0x1414213, 0x5623730, 0x9504880, 0x1688724, 0x2096980, 0x7856967, 0x1875376],
+                              [2020310104, 1513506566, 1843922297, 2003644209, 805967281, 1882435203, 1623804682])   # septic_digest.rs:L10-L16
+CURVE_WITNESS_DUMMY_POINT = ([0x2718281 + (1 << 24), 0x8284590, 0x4523536, 0x0287471, 0x3526624, 0x9775724, 0x7093699],
+                             [1250555984, 1592495468, 656721246, 420301347, 2125819749, 819876460, 17687681])         # septic_curve.rs:L23-L28
+
+
+def septic_mul(b, x, y):                                                   # septic_extension.rs:L307-L325
+    res = [b.const(0)] * 13
+    for i in range(7):
+        for j in range(7):
+            res[i + j] = res[i + j] + x[i] * y[j]
+    ret = list(res[:7])
+    for i in range(7, 13):
+        ret[i - 7] = ret[i - 7] + res[i] * 5
+        ret[i - 6] = ret[i - 6] + res[i] * 3
+    return ret
+
+
+def septic_add(x, y):
+    return [a + c for a, c in zip(x, y)]
+
+
+def septic_sub(x, y):
+    return [a - c for a, c in zip(x, y)]
+
+
+def curve_formula(b, x):                                                   # septic_curve.rs:L101-L113
+    cube = septic_mul(b, septic_mul(b, x, x), x)
+    out = [c + xi * 45 for c, xi in zip(cube, x)]
+    out[3] = out[3] + 41
+    return out
+
+
+GLOBAL_INTERACTION = S(("x_coordinate", 7), ("y_coordinate", 7), ("permutation", 179), ("offset", 1), ("y6_byte_decomp", 4))
+GLOBAL_ACCUMULATION = S(("initial_digest_x", 7), ("initial_digest_y", 7), ("cumulative_sum_x", 7), ("cumulative_sum_y", 7))
+
+
+def global_chip():
+    from .recursion import P2_EXT, P2_OUT, poseidon2_permutation_constraints
+    b, c, _ = _chip("Global", 241)
+    L = S(("message", 8), ("kind", 1), ("message_0_16bit_limb", 1), ("message_0_8bit_limb", 1), ("interaction", GLOBAL_INTERACTION),
+          ("is_real", 1), ("is_receive", 1), ("is_send", 1), ("index", 1), ("accumulation", GLOBAL_ACCUMULATION))(c)
+    I, A = L.interaction, L.accumulation
+    b.assert_bool(L.is_real)
+    b.receive(GLOBAL, L.message + [L.is_send, L.is_receive, L.kind], L.is_real)
+    # GlobalInteractionOperation::eval_single_digest (operations/global_interaction.rs:L106-L237)
+    b.assert_bool(L.is_real)
+    b.when(L.is_real).assert_eq(L.is_receive + L.is_send, 1)
+    b.assert_bool(L.is_receive)
+    b.assert_bool(L.is_send)
+    send_byte(b, B_U8RANGE, 0, 0, I.offset, L.is_real)
+    b.when(L.is_real).assert_eq(L.message[0], L.message_0_16bit_limb + L.message_0_8bit_limb * (1 << 16))
+    slice_range_check_u16(b, [L.message_0_16bit_limb, L.message[7]], L.is_real)
+    slice_range_check_u8(b, [L.message_0_8bit_limb], L.is_real)
+    send_byte(b, B_RANGE, L.kind, 6, 0, L.is_real)
+    m_trial = [L.message[0] + (1 << 24) * L.kind] + L.message[1:7] + [L.message[7] + (1 << 16) * I.offset] + [b.const(0)] * 8
+    perm = I.permutation
+    for i in range(16):
+        b.when(L.is_real).assert_eq(perm[P2_EXT(0, i)], m_trial[i])
+    base = c.names["interaction.permutation"]
+    poseidon2_permutation_constraints(b.air, base)
+    b.air._seen = {}                                       # (the closed-form internal rounds switch hash-consing off; back on)
+    for i in range(7):
+        b.when(L.is_real).assert_eq(I.x_coordinate[i], perm[P2_OUT(i)])
+    x, y = I.x_coordinate, I.y_coordinate
+    b.assert_all_eq(septic_mul(b, y, y), curve_formula(b, x))
+    y6_value = b.const(0)
+    for i in range(3):
+        y6_value = y6_value + I.y6_byte_decomp[i] * (1 << (8 * i))
+        send_byte(b, B_U8RANGE, 0, 0, I.y6_byte_decomp[i], L.is_real)
+    y6_value = y6_value + I.y6_byte_decomp[3] * (1 << 24)
+    send_byte(b, B_LTU, 1, I.y6_byte_decomp[3], 63, L.is_real)
+    b.when(L.is_receive).assert_eq(y[6], 1 + y6_value)
+    b.when(L.is_send).assert_zero(y[6] + 1 + y6_value)
+    # GlobalAccumulationOperation::eval_accumulation (operations/global_accumulation.rs:L56-L146)
+    b.assert_bool(L.is_real)
+    b.receive(GLOBAL_ACC, [L.index] + A.initial_digest_x + A.initial_digest_y, L.is_real)
+    p1x, p1y, p3x, p3y = A.initial_digest_x, A.initial_digest_y, A.cumulative_sum_x, A.cumulative_sum_y
+    dx, dy = septic_sub(x, p1x), septic_sub(y, p1y)
+    checker_x = septic_sub(septic_mul(b, septic_add(septic_add(p1x, x), p3x), septic_mul(b, dx, dx)), septic_mul(b, dy, dy))
+    checker_y = septic_sub(septic_mul(b, septic_add(p1y, p3y), dx), septic_mul(b, dy, septic_sub(p1x, p3x)))
+    b.assert_all_eq(checker_x, [0] * 7)
+    b.when(L.is_real).assert_all_eq(checker_y, [0] * 7)
+    b.send(GLOBAL_ACC, [L.index + 1] + p3x + p3y, L.is_real)
+    return _done(b, c)
+
+
 CHIPS = {
     "Add": add_chip, "Addi": addi_chip, "Sub": sub_chip, "Bitwise": bitwise_chip, "Lt": lt_chip, "Mul": mul_chip,
     "ShiftLeft": shift_left_chip, "ShiftRight": shift_right_chip, "UType": utype_chip, "MemoryLocal": memory_local_chip,
     "Addw": addw_chip, "Subw": subw_chip, "LoadByte": load_byte_chip, "LoadHalf": load_half_chip, "LoadWord": load_word_chip,
     "LoadDouble": load_double_chip, "StoreByte": store_byte_chip, "StoreHalf": store_half_chip, "StoreWord": store_word_chip,
-    "StoreDouble": store_double_chip, "Branch": branch_chip, "Jal": jal_chip, "Jalr": jalr_chip, "MemoryBump": memory_bump_chip, "StateBump": state_bump_chip, "Program": program_chip, "Byte": byte_chip, "Range": range_chip,
+    "StoreDouble": store_double_chip, "Branch": branch_chip, "Jal": jal_chip, "Jalr": jalr_chip, "MemoryBump": memory_bump_chip, "StateBump": state_bump_chip, "Program": program_chip, "Byte": byte_chip, "Range": range_chip, "Global": global_chip,
 }
 
 _CACHE = {}

@@ -10,10 +10,10 @@ to vanish on every row and the Byte / Memory / Program / State / Global buses to
 Program shape (vectorisable by construction, all tensors torch.int64, runs on CPU for tests and on the GPU for the bench):
 
     registers   x0 | B = x1..x8 scalars | PR = x9,x10 pointers into a read-only region | PS = x11,x12 pointers into a
-                store region | D1 = x13..x21 | D2 = x22..x31
+                store region | D1 = x13..x20 | x21 link register (AUIPC) | D2 = x22..x31
     body        L instructions at pc_base + 4 i, executed K times (a loop: the last instruction is `jal x0, -4 (L - 1)`):
                   class A  sources in B u {x0}, destination in D1 (ALU ops, AUIPC, JAL) or PR / PS (LUI with a page of the region)
-                  class B  sources in B u D1 u PR u PS, destination in D2 (ALU ops, loads through PR, JALR after its AUIPC)
+                  class B  sources in B u D1 u PR u PS, destination in D2 (ALU ops, loads through PR, JALR through the link register)
                   class S  no register destination: stores through PS, branches (taken branches jump to pc + 4)
                   tail     `addi xb, xb, step_b` for every scalar (their values are init_b + k step_b in iteration k), then the jump
     memory      loads read the read-only region (random initial image), stores write the store region; every touched word and
@@ -43,7 +43,7 @@ MASK16, MASK32 = 0xFFFF, 0xFFFFFFFF
 MIN64 = -(1 << 63)
 POS_OFF = {"M": 1, "C": 2, "B": 3, "A": 4}
 B_REGS, PR_REGS, PS_REGS = list(range(1, 9)), [9, 10], [11, 12]
-D1_REGS, D2_REGS = list(range(13, 22)), list(range(22, 32))
+D1_REGS, D2_REGS, LINK_REG = list(range(13, 21)), list(range(22, 32)), 21
 PAGE = 4096
 
 # instruction kinds: name -> (chip, opcode names)
@@ -108,9 +108,7 @@ class Body:
     def __init__(self, counts, rng, pc_base, mem_pages):
         kinds = []
         for name, n in counts.items():
-            if name in ("Jalr",):
-                kinds += [("JalrPair",)] * n
-            elif name in ALU_KINDS or name in LOAD_KINDS or name in STORE_KINDS or name in ("Branch", "Jal", "UType"):
+            if name in ALU_KINDS or name == "Jalr" or name in LOAD_KINDS or name in STORE_KINDS or name in ("Branch", "Jal", "UType"):
                 kinds += [(name,)] * n
             else:
                 raise KeyError(name)
@@ -125,9 +123,20 @@ class Body:
         r_pages, s_pages = mem_pages
         self.r_base, self.s_base = 0x100000, 0x100000 + (r_pages + 1) * PAGE
         self.r_pages, self.s_pages = r_pages, s_pages
+        n_jalr, since_link = int(counts.get("Jalr", 0)), 1 << 30
         for idx in order:
             name = kinds[idx][0]
             cls_b = bool(rng.integers(2))
+            if name == "Jalr":
+                # `auipc x21, 0` every <= 400 instructions keeps a code address in the link register (class A); a JALR then
+                # returns to its own pc + 4 through it: target = x21 + imm (the call / return idiom of compiled code)
+                if since_link > 400:
+                    emit("UType", "AUIPC", LINK_REG, -1, -1, 0, True)
+                    since_link = 0
+                emit("Jalr", "JALR", pick(D2_REGS), LINK_REG, -1, 4 * (since_link + 1) + 4, True)
+                since_link += 1
+                continue
+            since_link += 1
             if name in ALU_KINDS:
                 opn = pick(ALU_KINDS[name])
                 srcs = B_REGS + [0] if not cls_b else B_REGS + D1_REGS + PR_REGS + PS_REGS + [0]
@@ -166,10 +175,6 @@ class Body:
                 emit(name, pick(BRANCH_OPS), a, a if rng.integers(4) == 0 else pick(regs), -1, 4, True)
             elif name == "Jal":
                 emit(name, "JAL", pick(D1_REGS), -1, -1, 4, True)
-            elif name == "JalrPair":
-                d = pick(D1_REGS)
-                emit("UType", "AUIPC", d, -1, -1, 0, True)
-                emit("Jalr", "JALR", pick(D2_REGS), d, -1, 8, True)
         self.steps = [int(rng.integers(-(1 << 40), 1 << 40)) for _ in B_REGS]
         for r, st in zip(B_REGS, self.steps):
             # the tail: scalars advance by a 12-bit immediate (the "step" of iteration k is imm, wide values come from init)
@@ -296,7 +301,7 @@ class Execution:
         is_st_br = np.isin(b.chip, list(STORE_KINDS) + ["Branch"])
         writer = ~is_st_br & (b.rd > 0)
         body_pos = pos < L - b.n_tail
-        d1like = set(D1_REGS + PR_REGS + PS_REGS)
+        d1like = set(D1_REGS + PR_REGS + PS_REGS + [LINK_REG])
         cls_a = writer & body_pos & np.array([int(r) in d1like for r in b.rd])
         cls_b = writer & body_pos & ~cls_a
         self.mem = None
@@ -393,13 +398,15 @@ class Table:
             self.main[:self.n, c:c + val.shape[1]] = val
 
 
-def generate(counts, K=1, seed=0, clk0=1, pc_base=0x200000, mem_pages=(4, 4), device="cpu"):
+def generate(counts, K=1, seed=0, clk0=1, pc_base=0x200000, mem_pages=(4, 4), device="cpu", real_global=True):
     """counts: {instruction kind: positions in the loop body} over Add, Addi, Sub, Bitwise, Lt, Mul, ShiftLeft, ShiftRight,
     Addw, Subw, UType, LoadByte/Half/Word/Double, StoreByte/Half/Word/Double, Branch, Jal, Jalr. The body is executed K times.
     Returns (machine, tables, public_values): machine = [(AirProgram, InteractionProgram)] in chip-name order,
     tables = {name: (prep, main)} canonical int64 [rows, width] tensors on `device` (rows padded to multiples of 32)."""
     ex = Execution(counts, K, seed, clk0, pc_base, mem_pages, device)
-    return Tracer(ex).build()
+    tr = Tracer(ex)
+    tr.real_global = real_global
+    return tr.build()
 
 
 class Tracer:
@@ -957,12 +964,15 @@ class Tracer:
         # GlobalSink: receives what MemoryLocal sends to the Global chip
         ml = self.tables["MemoryLocal"]
         msgs = eval_interactions(R.chip("MemoryLocal")[1], ml.main[:ml.n], None, kinds=(R.GLOBAL,))
-        air, it = global_sink_chip()
-        rows = torch.cat([v for _, v, _ in msgs])
-        tb = Table(air, rows.shape[0], dev)
-        tb.main[:tb.n, :11] = rows
-        tb.main[:tb.n, 11] = 1
-        self.tables["GlobalSink"], machine["GlobalSink"] = tb, (air, it)
+        if getattr(self, "real_global", True):
+            self.global_chip(machine, msgs)
+        else:
+            air, it = global_sink_chip()
+            rows = torch.cat([v for _, v, _ in msgs])
+            tb = Table(air, rows.shape[0], dev)
+            tb.main[:tb.n, :11] = rows
+            tb.main[:tb.n, 11] = 1
+            self.tables["GlobalSink"], machine["GlobalSink"] = tb, (air, it)
         # Program: one row per body position (program/trusted.rs:L80-L131), multiplicity = K
         air, it = R.chip("Program")
         tb = Table(air, ex.L, dev)
@@ -991,7 +1001,7 @@ class Tracer:
                 if bool(is_range.any()):
                     aa, bits_ = a[is_range], x[is_range]
                     assert bool(((bits_ <= 16) & (aa < (1 << bits_.clamp(max=16))) & (y[is_range] == 0)).all()), (name, "range check fails")
-                    rt.main[:, 0] += torch.bincount((1 << bits_) + aa, weights=mult[is_range].to(torch.float64), minlength=1 << 17).to(I64)
+                    tally(rt.main[:, 0], (1 << bits_) + aa, mult[is_range])
                 nb = ~is_range
                 if bool(nb.any()):
                     o, aa, xx, yy, mm = opc[nb], a[nb], x[nb], y[nb], mult[nb]
@@ -1001,12 +1011,65 @@ class Tracer:
                                        torch.where(o == R.B_MSB, xx >> 7, bt.prep[row, 2 + o.clamp(max=4) - (o > 3).to(I64)]))
                     assert bool((aa == want).all()), (name, "byte lookup result is wrong")
                     assert bool(((o != R.B_MSB) | (yy == 0)).all()), name
-                    flat = torch.bincount(row * 6 + o, weights=mm.to(torch.float64), minlength=6 << 16).to(I64)
-                    bt.main += flat.view(1 << 16, 6)
+                    tally(bt.main.view(-1), row * 6 + o, mm)
         self.tables["Byte"], machine["Byte"] = bt, (byte_air, byte_it)
         self.tables["Range"], machine["Range"] = rt, (range_air, range_it)
         names = sorted(machine)
         return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, torch.zeros(0, dtype=I64)
+
+    def global_chip(self, machine, msgs):
+        """GlobalChip::generate_trace_into (global/mod.rs:L131-L260): one row per global interaction event — here the two
+        events of every MemoryLocal row (memory/local.rs generate_dependencies: initial = receive, final = send), in that order."""
+        from . import septic as SE
+        dev = self.dev
+        (_, recv, _), (_, send, _) = msgs                              # MemoryLocal's two Global sends, [rows, 11] each
+        ev = torch.stack([recv, send], dim=1).reshape(-1, 11)
+        n = ev.shape[0]
+        message, is_send, is_recv, kind = ev[:, :8], ev[:, 8], ev[:, 9], ev[:, 10]
+        x, y, off, perm = SE.lift_x(message, kind, is_recv == 1)
+        air, it = R.chip("Global")
+        tb = Table(air, n, dev)
+        tb.set("message", message)
+        tb.set("kind", kind)
+        tb.set("message_0_16bit_limb", message[:, 0] & MASK16)
+        tb.set("message_0_8bit_limb", (message[:, 0] >> 16) & 0xFF)
+        tb.set("interaction.x_coordinate", x)
+        tb.set("interaction.y_coordinate", y)
+        tb.set("interaction.offset", off)
+        rc = torch.where(is_recv == 1, y[:, 6] - 1, P - y[:, 6] - 1)
+        assert bool(((rc >= 0) & (rc < (63 << 24))).all())
+        tb.set("interaction.y6_byte_decomp", torch.stack([rc & 0xFF, (rc >> 8) & 0xFF, (rc >> 16) & 0xFF, rc >> 24], dim=1))
+        tb.set("is_real", 1)
+        tb.set("is_receive", is_recv)
+        tb.set("is_send", is_send)
+        tb.set("index", torch.arange(n, device=dev))
+        start = tuple(torch.tensor(v, dtype=I64, device=dev) for v in R.CURVE_CUMULATIVE_SUM_START)
+        dummy = tuple(torch.tensor(v, dtype=I64, device=dev) for v in R.CURVE_WITNESS_DUMMY_POINT)
+        cx, cy = SE.prefix_sums(start, x, y)
+        tb.set("accumulation.initial_digest_x", torch.cat([start[0][None], cx[:-1]]))
+        tb.set("accumulation.initial_digest_y", torch.cat([start[1][None], cy[:-1]]))
+        tb.set("accumulation.cumulative_sum_x", cx)
+        tb.set("accumulation.cumulative_sum_y", cy)
+        pcol = tb.L["interaction.permutation"]
+        tb.main[:n, pcol:pcol + perm.shape[1]] = perm
+        if tb.main.shape[0] > n:                                       # padding rows: populate_dummy (global/mod.rs:L213-L236)
+            pad = tb.main[n:]
+            pad[:, tb.L["interaction.x_coordinate"]:tb.L["interaction.x_coordinate"] + 7] = dummy[0]
+            pad[:, tb.L["interaction.y_coordinate"]:tb.L["interaction.y_coordinate"] + 7] = dummy[1]
+            pad[:, pcol:pcol + perm.shape[1]] = SE.poseidon2_rows(torch.zeros((1, 16), dtype=I64, device=dev))[0]
+            sdx, sdy = SE.ec_add((start[0][None], start[1][None]), (dummy[0][None], dummy[1][None]))
+            for nm, v in (("initial_digest_x", start[0]), ("initial_digest_y", start[1]), ("cumulative_sum_x", sdx[0]), ("cumulative_sum_y", sdy[0])):
+                c0 = tb.L["accumulation." + nm]
+                pad[:, c0:c0 + 7] = v
+        self.tables["Global"], machine["Global"] = tb, (air, it)
+        # the two ends of the accumulation chain, where eval_public_values' eval_global_sum stands in the reference
+        air, it = global_acc_boundary_chip()
+        bt = Table(air, 2, dev)
+        bt.main[0, 0:15] = torch.cat([torch.zeros(1, dtype=I64, device=dev), start[0], start[1]])
+        bt.main[0, 15] = 1
+        bt.main[1, 0:15] = torch.cat([torch.full((1,), n, dtype=I64, device=dev), cx[-1], cy[-1]])
+        bt.main[1, 16] = 1
+        self.tables["GlobalAccBoundary"], machine["GlobalAccBoundary"] = bt, (air, it)
 
     def _program_rows(self, tb, p):
         ex = self.ex
@@ -1028,6 +1091,17 @@ class Tracer:
         tb.prep[:tb.n, 13] = (A == 0).to(I64)
         tb.prep[:tb.n, 14] = (utype | jal).to(I64)
         tb.prep[:tb.n, 15] = ex.has_imm[p].to(I64)
+
+
+def tally(target, idx, mult):
+    """target[idx] += mult without atomics (a few table rows — limb 0, byte pair (0, 0) — receive millions of messages, and
+    float atomics on one address serialise on the GPU): sort, prefix-sum, difference at the run boundaries."""
+    order = torch.argsort(idx)
+    si, sm = idx[order], torch.cumsum(mult[order], dim=0)
+    last = torch.ones_like(si, dtype=torch.bool)
+    last[:-1] = si[1:] != si[:-1]
+    ends, keys = sm[last], si[last]
+    target[keys] += ends - torch.cat([ends.new_zeros(1), ends[:-1]])
 
 
 def eval_vcol(v, prep, main):
@@ -1075,6 +1149,19 @@ def global_sink_chip():
     c = [b.main(i) for i in range(12)]
     b.assert_bool(c[11])
     b.receive(R.GLOBAL, c[:11], c[11])
+    return b.air, b.it
+
+
+def global_acc_boundary_chip():
+    """Synthetic: [index, x[7], y[7], is_send, is_receive] — sends (0, zero digest), receives (count, final sum) like
+    eval_global_sum (core/executor/src/record.rs:L1331-L1363)."""
+    from .rv_builder import Builder
+    b = Builder("GlobalAccBoundary", 17)
+    c = [b.main(i) for i in range(17)]
+    b.assert_bool(c[15])
+    b.assert_bool(c[16])
+    b.send(R.GLOBAL_ACC, c[:15], c[15])
+    b.receive(R.GLOBAL_ACC, c[:15], c[16])
     return b.air, b.it
 
 

@@ -1,0 +1,108 @@
+"""GPU parity (-m gpu) on the RISC-V core chips (sp1_amd/machines/riscv.py: 29 chips of the rv64im machine transcribed
+from the reference's `Air::eval` bodies) over traces that sp1_amd/machines/riscv_trace.py executes: `sp1hip_prove_shard`
+bytes == the oracle prover's, and the oracle's full verify_shard (zerocheck closing equation with these constraint
+programs + LogUp-GKR interaction check with these interactions) accepts; at 1/64 of the reference's recorded core shard
+with production parameters the verifier accepts and a proof over a corrupted trace is rejected."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import pyoracle as orc  # noqa: E402
+from sp1_amd.machines import riscv_trace as RT  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench"))
+
+SMALL = {"Add": 5, "Addi": 7, "Sub": 3, "Bitwise": 6, "Lt": 6, "Mul": 6, "ShiftLeft": 6, "ShiftRight": 8, "Addw": 3, "Subw": 3,
+         "UType": 12, "LoadByte": 14, "LoadHalf": 5, "LoadWord": 5, "LoadDouble": 5, "StoreByte": 10, "StoreHalf": 5,
+         "StoreWord": 5, "StoreDouble": 5, "Branch": 12, "Jal": 4, "Jalr": 5}
+
+
+@pytest.fixture(scope="module")
+def api():
+    from sp1_amd import api as a
+    torch.cuda.set_device(0)
+    return a
+
+
+def _shapes_only(machine):
+    return [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
+            for a, i in machine]
+
+
+@pytest.mark.parametrize("K,seed,clk0", [(2, 3, 1), (3, 4, (1 << 24) - 8 * 150 + 1)])
+def test_riscv_shard_proof_matches_oracle(api, K, seed, clk0):
+    """Every chip incl. MemoryBump / StateBump rows (second case: the clock crosses a 2^24 boundary mid-shard)."""
+    import core_real
+    LB, NQ, PW = 1, 5, 4
+    L, lsh, batch = 17, 12, 8                               # the Range table has 2^17 rows
+    machine, tabs, _ = RT.generate(SMALL, K=K, seed=seed, clk0=clk0, device="cuda")
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+            for a, i in machine]
+    dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+           for a, i in machine]
+    if clk0 > 1:
+        assert {"MemoryBump", "StateBump"} <= {a.name for a, _ in machine}
+    o_prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, LB)
+    jp = api.JaggedProver(L, lsh, batch, LB)
+    g_commit, g_prep = jp.commit_multilinears([d[3] for d in dev if d[3] is not None])
+    assert np.array_equal(g_commit, o_prep.commit)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    o_ch.observe(o_prep.commit)
+    g_ch.observe(g_commit)
+    v_ch = o_ch.clone()
+    orc.set_gkr_sparse(True)                                # the jagged-aware oracle prover (bytes equal to the dense one)
+    try:
+        want = orc.shard_prove(host, np.zeros(0, np.uint32), o_prep, L, lsh, batch, o_ch, LB, NQ, PW)
+    finally:
+        orc.set_gkr_sparse(False)
+    got = api.prove_shard(dev, [], g_prep, L, lsh, batch, g_ch, LB, NQ, PW)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+    assert orc.shard_verify(_shapes_only(machine), g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
+
+
+def test_riscv_shard_at_a_sixty_fourth_of_the_recorded_shape_verifies(api):
+    """Production parameters (blowup 4, 124 queries, 16-bit PoW); 1/64 of the recorded heights, the real Global chip
+    included (the bench's shard). One wrong cell in the Bitwise table -> the verifier rejects; so does one wrong
+    coordinate of a Global row's curve point."""
+    import core_real
+    chips, meta = core_real.build_real_shard(scale=1 / 64, seed=5)
+    assert len(meta["real_chips"]) >= 27 and "Global" in meta["real_chips"]
+    L, lsh = 17, 16
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    commit, prep = jp.commit_multilinears([c[3] for c in chips if c[3] is not None])
+    ch, v = api.DuplexChallenger(), orc.Challenger()
+    ch.observe(commit)
+    v.observe(commit)
+    proof = api.prove_shard(chips, [], prep, L, lsh, 32, ch)
+    shapes = _shapes_only([(a, i) for a, i, _, _ in chips])
+    assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) == 0
+    assert np.array_equal(v.state(), ch.state())
+    k = [a.name for a, _, _, _ in chips].index("Bitwise")
+    a, i, m, p = chips[k]
+    bad = m.words.clone()
+    col = a.layout["result"]
+    bad[col * m.height + 7] ^= 1 << 20
+    chips2 = list(chips)
+    chips2[k] = (a, i, api.ColMajor(bad, m.height, m.width), p)
+    ch, v = api.DuplexChallenger(), orc.Challenger()
+    ch.observe(commit)
+    v.observe(commit)
+    proof = api.prove_shard(chips2, [], prep, L, lsh, 32, ch)
+    assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) != 0
+    k = [a.name for a, _, _, _ in chips].index("Global")
+    a, i, m, p = chips[k]
+    bad = m.words.clone()
+    bad[(a.layout["interaction.y_coordinate"] + 3) * m.height + 11] ^= 1 << 9
+    chips3 = list(chips)
+    chips3[k] = (a, i, api.ColMajor(bad, m.height, m.width), p)
+    ch, v = api.DuplexChallenger(), orc.Challenger()
+    ch.observe(commit)
+    v.observe(commit)
+    proof = api.prove_shard(chips3, [], prep, L, lsh, 32, ch)
+    assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) != 0
