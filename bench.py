@@ -7,13 +7,15 @@ One "step" = `sp1hip_prove_shard` = `ShardProver::prove_shard_with_data`
 zerocheck -> jagged evaluation proof (jagged sumcheck, jagged-eval, stacked BaseFold opening, 124 queries, 16-bit PoW);
 the output is a complete bincode(ShardProof) that the pinned verifier accepts (tests/test_gpu_shard.py).
 
-Workload (`config.workload`): the core-SHAPED synthetic shard of bench/core_shard.py at CORE size (area 2^28 + 2^27
-trace cells, max_log_row_count 22, stacking height 2^21): 33 chips with the widths / constraint counts of RISC-V chips
-and the 730 interactions and row proportions of a recorded core shard (bench/core_shape.json, from data in the
-reference tree). The reference defines its headline "Core kHz" as cycles / core-proving seconds
-(/root/reference/sp1-gpu/crates/perf/src/report.rs:L52-L60); cycles exist only for real programs (they need the Rust
-executor), so for this synthetic shard `value` is trace CELLS proved per second and `proofs_per_s` rides
-along; nothing is converted to cycles.
+Workload (`config.workload`, round 4): the core shard of REAL RISC-V chips (bench/core_real.py): the 29 rv64im chips
+transcribed from the reference's `Air::eval` bodies (sp1_amd/machines/riscv.py — every chip of the reference's recorded
+core shard 0 except four that hold 0.15 % of its cells) at that shard's recorded heights (3.3e8 trace cells,
+max_log_row_count 22, stacking height 2^21), on traces of an EXECUTED rv64im program (sp1_amd/machines/riscv_trace.py:
+6.2e6 instructions, lookups balanced). `synthetic_core_shaped` carries the round-1..3 workload (bench/core_shard.py) for
+continuity. The reference defines its headline "Core kHz" as cycles / core-proving seconds
+(/root/reference/sp1-gpu/crates/perf/src/report.rs:L52-L60); `config.instructions_executed` is the number of RISC-V
+instructions this shard proves (`riscv_instructions_per_s` rides along: the executor here is this repository's test
+executor, not SP1's, so it is NOT quoted as Core kHz), `value` stays trace CELLS proved per second.
 
 Usage: python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, shards striped
 one per rank, no data-path collective). Prints ONE JSON line on rank 0; see DESIGN.md §8 for every field.
@@ -57,18 +59,37 @@ def effective_cores():
     return n
 
 
+def programs_of(kind, names):
+    """(AirProgram, InteractionProgram) list of a workload, rebuilt by name in a child process that has no traces."""
+    if kind == "real":
+        import core_real
+        return core_real.programs_for(names)
+    if kind == "core":
+        from core_shard import chip_programs, load_shape
+        return [chip_programs(c["name"], c["width"], c["prep_width"], c["constraints"], c["interactions"])
+                for c in sorted(load_shape()["chips"], key=lambda c: c["name"])]
+    from sp1_amd.machines import recursion as R
+    return R.compress_machine()
+
+
+def build_workload(kind, k, L, seed):
+    """chips [(air, inter, main ColMajor, prep ColMajor | None)], meta — `kind` "real" (RISC-V chips) or "core" (synthetic)."""
+    if kind == "real":
+        import core_real
+        return core_real.build_real_shard(scale=1.0 / (1 << (2 * k)), seed=seed)
+    from core_shard import build_core_shard
+    return build_core_shard(CORE_AREA >> (2 * k), L, seed=seed)
+
+
 # ---- CPU baseline: the oracle's prove_shard_with_data on a scaled-down copy of the same shard -------------------------
 def cpu_baseline_child(path):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as orc
-    from core_shard import chip_programs, load_shape
     z = np.load(path)
     L, lsh = int(z["L"]), int(z["lsh"])
-    chips = []
-    for k, c in enumerate(sorted(load_shape()["chips"], key=lambda c: c["name"])):
-        air, inter = chip_programs(c["name"], c["width"], c["prep_width"], c["constraints"], c["interactions"])
-        chips.append((air, inter, z["main%d" % k], z["prep%d" % k] if c["prep_width"] else None))
+    chips = [(air, inter, z["main%d" % k], z["prep%d" % k] if air.prep_width else None)
+             for k, (air, inter) in enumerate(programs_of(str(z["kind"]), [str(n) for n in z["names"]]))]
     t0 = time.perf_counter()
     prep = orc.JaggedRound([c[3] for c in chips if c[3] is not None], L, lsh, 32, 2)
     t_setup = time.perf_counter() - t0
@@ -84,15 +105,14 @@ def cpu_baseline_child(path):
     print(json.dumps({"seconds": dt, "setup_seconds": t_setup, "proof_bytes": len(blob), "stage_seconds": orc.stage_seconds()}))
 
 
-def cpu_sample(api, scale_log2, cores):
+def cpu_sample(api, scale_log2, cores, kind="real"):
     import subprocess
     import tempfile
 
     import numpy as np
-    from core_shard import build_core_shard
-    L, lsh = 22 - scale_log2, 21 - scale_log2
-    chips, meta = build_core_shard(CORE_AREA >> (2 * scale_log2), L)
-    arrays = {"L": L, "lsh": lsh}
+    L, lsh = max(22 - scale_log2, 17), 21 - scale_log2
+    chips, meta = build_workload(kind, scale_log2, L, 42)
+    arrays = {"L": L, "lsh": lsh, "kind": kind, "names": np.array([c[0].name for c in chips])}
     for k, (_, _, main, prep) in enumerate(chips):
         arrays["main%d" % k] = main.to_row_major_host()
         if prep is not None:
@@ -126,7 +146,7 @@ def cpu_baseline(api, scale_log2):
             "quarter_sample": {"cells": small["cells"], "seconds": round(small["seconds"], 2), "cells_per_s": small["cells_per_s"],
                                "ratio_to_value": small["cells_per_s"] / big["cells_per_s"]},
             "sample": "oracle prove_shard_with_data (commit + LogUp-GKR over real rows + zerocheck + jagged evaluation proof, 124 queries, "
-                      "16-bit PoW; one pass) of the same core-shaped shard at 1/%d of the area (%d cells, max_log_row_count %d); "
+                      "16-bit PoW; one pass) of the same real-chip shard (same machine, heights scaled) at 1/%d of the area (%d cells, max_log_row_count %d); "
                       "C++17 + OpenMP, %d threads (cgroup quota); %.2f s wall"
                       % (1 << (2 * scale_log2), big["cells"], big["max_log_row_count"], cores, big["seconds"])}
 
@@ -140,13 +160,7 @@ def verify_child(path):
     import pyoracle as orc
     z = np.load(path)
     L, lsh, kind = int(z["L"]), int(z["lsh"]), str(z["kind"])
-    if kind == "core":
-        from core_shard import chip_programs, load_shape
-        progs = [chip_programs(c["name"], c["width"], c["prep_width"], c["constraints"], c["interactions"])
-                 for c in sorted(load_shape()["chips"], key=lambda c: c["name"])]
-    else:
-        from sp1_amd.machines import recursion as R
-        progs = R.compress_machine()
+    progs = programs_of(kind, [str(n) for n in z["names"]])
     shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
               for a, i in progs]
     ch = orc.Challenger()
@@ -156,7 +170,7 @@ def verify_child(path):
     print(json.dumps({"rc": int(rc), "seconds": time.perf_counter() - t0, "state_matches": bool(np.array_equal(ch.state(), z["state"]))}))
 
 
-def verify_proof(kind, proof, commit, state, L, lsh):
+def verify_proof(kind, proof, commit, state, L, lsh, names=()):
     """Runs verify_child on `proof`; returns True iff the verifier accepts AND ends in the prover's transcript state."""
     import subprocess
     import tempfile
@@ -165,7 +179,7 @@ def verify_proof(kind, proof, commit, state, L, lsh):
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "proof.npz")
         np.savez(path, proof=np.frombuffer(proof, np.uint8), commit=np.asarray(commit, np.uint32), state=np.asarray(state, np.uint32),
-                 L=L, lsh=lsh, kind=kind)
+                 L=L, lsh=lsh, kind=kind, names=np.array(list(names), dtype=str))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--verify-child", path], capture_output=True, text=True)
     if r.returncode != 0:
         print("verifier child failed:\n" + r.stderr[-2000:], file=sys.stderr)
@@ -202,6 +216,28 @@ def real_machine(api, repeat=4):
                        "by the reference's own ShardProof), table heights of the reference's compress proof",
             "cells": area, "ms_per_proof": ms, "cells_per_s": area / (ms * 1e-3), "proof_bytes": len(proof), "proofs_timed": repeat,
             "verified": verify_proof("recursion", proof, commit, ch.state(), L, lsh)}
+
+
+def synthetic_core_shaped(api, k, repeat=3):
+    """The round-1..3 workload (bench/core_shard.py: synthetic constraints on the widths / counts of RISC-V chips) for continuity."""
+    import torch
+    from core_shard import build_core_shard
+    L, lsh = 22 - k, 21 - k
+    chips, meta = build_core_shard(CORE_AREA >> (2 * k), L, seed=42)
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    commit, prep = jp.commit_multilinears([c[3] for c in chips if c[3] is not None])
+    times = []
+    for _ in range(repeat + 1):
+        ch = api.DuplexChallenger()
+        ch.observe(commit)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        api.prove_shard(chips, [], prep, L, lsh, 32, ch)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    ms = 1e3 * sum(times[1:]) / repeat
+    return {"workload": "core-shaped synthetic shard of rounds 1-3 (33 chips, 730 interactions, 1605 synthetic constraints)",
+            "cells": meta["area_cells"], "ms_per_proof": ms, "cells_per_s": meta["area_cells"] / (ms * 1e-3)}
 
 
 class GpuSampler:
@@ -306,6 +342,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="real", choices=["real", "core"],
+                    help="real: the RISC-V chips at the recorded core shard's heights (bench/core_real.py); core: the synthetic "
+                         "core-shaped shard of rounds 1-3 (bench/core_shard.py)")
     ap.add_argument("--scale-log2", type=int, default=0, help="prove a shard of area CORE >> 2k (testing aid; the bench line is k = 0)")
     ap.add_argument("--cpu-sample-scale-log2", type=int, default=2, help="the CPU baseline proves a shard of CORE >> 2k cells (default 1/16 of CORE)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
@@ -352,12 +391,13 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from core_shard import build_core_shard
     from sp1_amd import api, shards
     lib = api._L()
     k = args.scale_log2
-    L, lsh = 22 - k, 21 - k
-    chips, meta = build_core_shard(CORE_AREA >> (2 * k), L, seed=42 + rank)       # every rank proves its own shard
+    kind = args.workload
+    L, lsh = max(22 - k, 17 if kind == "real" else 0), 21 - k            # the Range table of the real machine has 2^17 rows
+    chips, meta = build_workload(kind, k, L, 42 + rank)                  # every rank proves its own shard
+    names = [c[0].name for c in chips]
     area = meta["area_cells"]
     jp = api.JaggedProver(L, lsh, 32, 2)
     prep_commit, prep_data = jp.commit_multilinears([c[3] for c in chips if c[3] is not None])   # setup (the proving key)
@@ -374,8 +414,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # compiled zerocheck kernels: the prebuilt ones (sp1_amd/lib/zc_cache) are picked up by the first proof; anything the
-    # background compiler still owes is waited for here, outside the timed region
     api.zerocheck_jit_wait(-1)
     if args.warmup:
         step()
@@ -402,16 +440,13 @@ def main():
     # the pinned verifier on the LAST TIMED proof (rank 0, untimed): a line without `verified: true` is not printed
     verified = None
     if rank == 0 and not args.no_verify:
-        verified = verify_proof("core", proof, prep_commit, timed_state, L, lsh)
+        verified = verify_proof(kind, proof, prep_commit, timed_state, L, lsh, names)
         if not verified:
             raise SystemExit("bench.py: the pinned verifier REJECTED the timed proof; no result line")
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:      # untimed extras; N > 1 runs measure scaling only
-        # (a) 1, 2, 3 proofs in flight on one GPU through the library's prover pool (sp1hip_pool_*): the sumcheck rounds
-        #     of one proof fill the transcript round trips of the others; same inputs, byte-identical proofs
         extras["in_flight"] = in_flight(api, chips, area, L, lsh, max(4, args.steps))
-        # (b) the commit phase alone (BASELINE config 2's stage: RS encode + Poseidon2 Merkle of the main traces)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
@@ -420,6 +455,8 @@ def main():
         torch.cuda.synchronize()
         extras["commit_only"] = {"ms": 1e3 * (time.perf_counter() - t1) / 3, "cells": sum(c[2].height * c[2].width for c in chips)}
         extras["real_machine"] = real_machine(api)
+        if kind == "real":
+            extras["synthetic_core_shaped"] = synthetic_core_shaped(api, k)
         if not args.no_cpu_baseline:
             extras["cpu_baseline"] = cpu_baseline(api, max(args.cpu_sample_scale_log2, k))
     if use_dist:
@@ -428,86 +465,103 @@ def main():
     if rank == 0:
         ms = {name: m / args.steps for name, (cnt, m) in tl.items() if cnt}
         launches = {name: cnt // args.steps for name, (cnt, m) in tl.items() if cnt}
-        # algorithmic bytes per proof of the streaming kernels: S stacked columns of height
-        # h = 2^lsh, codeword height N = 4 h
         h, A_main = 1 << lsh, sum(c[2].height * c[2].width for c in chips)
         S_cols = -(-A_main // h) + 1
         N = 4 * h
-        alg = {
-            "leaf_hash": 4 * N * S_cols + 32 * N,
-            "ntt": 4 * h * S_cols * 5,
-            "zerocheck_round": 20 * area,            # round 0 reads 4A, rounds >= 1 read 16A of extension tables in total
-            "zerocheck_fix": 36 * area,              # reads 4A + 16A, writes 8A + 8A
-        }
         perms = N * (-(-S_cols // 8)) if S_cols else 0
-        ntt_ms = sum(v for n, v in ms.items() if n.startswith("ntt_pass"))
-        stages = {
-            "leaf_hash": {"ms": ms.get("leaf_hash"), "launches": launches.get("leaf_hash"), "bound": "valu",
-                          "algorithmic_bytes": alg["leaf_hash"], "hbm_frac": alg["leaf_hash"] / (ms["leaf_hash"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                          "permutations": perms,
-                          # 3573 VALU instructions per permutation: SQ_INSTS_VALU of this kernel, profiles/r01_pmc_summary.md
-                          "valu_frac_vs_guide_issue_rate": 3573 * perms / (ms["leaf_hash"] * 1e-3) / VALU_PEAK_GUIDE,
-                          "valu_frac_vs_measured_int_rate": 3573 * perms / (ms["leaf_hash"] * 1e-3) / VALU_PEAK_MEASURED},
-            "rs_encode": {"ms": ntt_ms, "bound": "hbm", "algorithmic_bytes": alg["ntt"],
-                          "hbm_frac": alg["ntt"] / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ntt_ms else None},
-            "zerocheck_round": {"ms": ms.get("zerocheck_round"), "launches": launches.get("zerocheck_round"), "bound": "valu (interpreted constraints)",
-                                "algorithmic_bytes": alg["zerocheck_round"],
-                                "hbm_frac": alg["zerocheck_round"] / (ms["zerocheck_round"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-            "zerocheck_fix": {"ms": ms.get("zerocheck_fix"), "bound": "hbm", "algorithmic_bytes": alg["zerocheck_fix"],
-                              "hbm_frac": alg["zerocheck_fix"] / (ms["zerocheck_fix"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-            "logup_gkr_kernels_ms": sum(v for n, v in ms.items() if n.startswith("gkr_")),
-            "jagged_kernels_ms": sum(v for n, v in ms.items() if n.startswith("jagged_")),
-            "timed_kernels_ms": sum(ms.values()),
+        # kernel groups: (timers summed, algorithmic bytes per proof — SURVEY §8d)
+        groups = {
+            "leaf_hash": (["leaf_hash"], 4 * N * S_cols + 32 * N),
+            "rs_encode": (["ntt_pass0", "ntt_pass1", "ntt_pass2"], 4 * h * S_cols * 5),
+            "zerocheck_round": (["zerocheck_round"], 20 * area),     # round 0 reads 4A, rounds >= 1 read 16A of extension tables in total
+            "zerocheck_fix": (["zerocheck_fix"], 36 * area),         # reads 4A + 16A, writes 8A + 8A
+            "gkr_pass": (["gkr_pass_sum", "gkr_pass_fold_sum", "gkr_pass_fold"], 156 * meta["first_layer_entries"]),
+            "gkr_first_layer": (["gkr_first_layer"], 20 * meta["first_layer_entries"]),
+            "gkr_transition": (["gkr_transition"], 52 * meta["first_layer_entries"]),
+            "jagged_fold": (["jagged_round0_sum", "jagged_fold0_sum", "jagged_fold_sum"], 28 * area),
         }
-        # the dominant kernel of the step, by live-measured launch time (HIP events recorded by the library on the
-        # launch stream, sp1hip_timers_*)
-        dom = max(("leaf_hash", "zerocheck_round", "zerocheck_fix"), key=lambda n: ms.get(n, 0.0))
-        dom_ms, dom_launches = ms[dom], launches[dom]
-        achieved = alg[dom] / dom_launches / (dom_ms / dom_launches * 1e-3) / 1e9
-        ms_per_step = 1e3 * dt / args.steps
-        # HBM traffic of the dominant kernel from the committed PMC table (FETCH_SIZE / WRITE_SIZE collected in separate
-        # rocprofv3 --pmc passes over this same command by bench/pmc_traffic.sh; gfx950 corrections as the microarch guide
-        # prescribes are applied there and stated in the file). Per launch, like `achieved`; null if the table has no row.
-        traffic, traffic_note = None, "no committed PMC table"
+        # PMC table of THIS round (bench/pmc_traffic.sh -> profiles/r04_traffic.json): HBM bytes and SQ_INSTS_VALU per proof
+        # for every kernel group; the roofline fractions below are (table or live value) / (live time) / peak, nothing else
+        pmc, pmc_note = {}, "no committed PMC table for this workload"
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as f:
                 tt = json.load(f)
-            row = tt["kernels"].get(dom)
-            if row is not None and k == 0:
-                traffic = row["hbm_bytes_per_launch"]
-                traffic_note = "%s (%s)" % (tt["source"], row.get("note", ""))
+            if k == 0 and tt.get("workload") == kind:
+                pmc, pmc_note = tt["kernels"], tt["source"]
         except (OSError, ValueError, KeyError):
             pass
+        stages = {}
+        for g, (tn, alg_bytes) in groups.items():
+            g_ms = sum(ms.get(n, 0.0) for n in tn)
+            if not g_ms:
+                continue
+            g_launch = sum(launches.get(n, 0) for n in tn)
+            row = pmc.get(g, {})
+            valu = row.get("valu_lane_insts_per_proof")
+            hbm_frac = alg_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            valu_frac = valu / (g_ms * 1e-3) / VALU_PEAK_MEASURED if valu else None
+            stages[g] = {"ms": g_ms, "launches": g_launch, "algorithmic_bytes": alg_bytes, "hbm_frac": hbm_frac,
+                         "hbm_bytes_pmc": row.get("hbm_bytes_per_proof"), "valu_lane_insts_pmc": valu,
+                         "valu_frac_vs_measured_int_rate": valu_frac,
+                         "valu_frac_vs_guide_issue_rate": valu / (g_ms * 1e-3) / VALU_PEAK_GUIDE if valu else None,
+                         "bound": "valu" if (valu_frac or 0.0) > hbm_frac else "hbm"}
+        if "leaf_hash" in stages:
+            stages["leaf_hash"]["permutations"] = perms
+            if stages["leaf_hash"]["valu_lane_insts_pmc"]:
+                stages["leaf_hash"]["valu_insts_per_permutation"] = stages["leaf_hash"]["valu_lane_insts_pmc"] / perms
+        stages["timed_kernels_ms"] = sum(ms.values())
+        # the dominant kernel group of the step, by live-measured launch time over ALL timed kernels
+        dom = max((g for g in stages if isinstance(stages[g], dict)), key=lambda g: stages[g]["ms"])
+        d = stages[dom]
+        dom_ms, dom_launches, alg_dom = d["ms"], d["launches"], groups[dom][1]
+        ms_per_step = 1e3 * dt / args.steps
+        if d["bound"] == "valu":
+            achieved, peak, unit = d["valu_lane_insts_pmc"] / (dom_ms * 1e-3) / 1e12, VALU_PEAK_MEASURED / 1e12, "T lane-inst/s"
+        else:
+            achieved, peak, unit = alg_dom / (dom_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
+        traffic = d["hbm_bytes_pmc"] / dom_launches if d["hbm_bytes_pmc"] else None
+        workload_text = (
+            "one whole core-shard proof (sp1hip_prove_shard = prove_shard_with_data): %d chips, of which REAL (constraints + interactions "
+            "transcribed from the reference's Air::eval, traces of an executed rv64im program): %s; synthetic closing chips: %s; "
+            "%d interactions / %d constraints; heights of the reference's recorded core shard 0 (layer_workloads.json), %d RISC-V "
+            "instructions executed" % (meta["chips"], ", ".join(meta["real_chips"]), ", ".join(meta["synthetic_chips"]),
+                                       meta["interactions"], meta["constraints"], meta["instructions_executed"])
+            if kind == "real" else
+            "one whole core-shard proof: core-shaped SYNTHETIC shard, %d chips / %d interactions / %d constraints"
+            % (meta["chips"], meta["interactions"], meta["constraints"]))
         out = {
-            "metric": "core shard prove throughput: trace cells proved/sec (whole ShardProof; synthetic core-shaped shard, see config)",
+            "metric": "core shard prove throughput: trace cells proved/sec (whole ShardProof of the RISC-V core machine, see config)",
             "value": world * args.steps * area / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": "synthetic",
             "proofs_per_s": world * args.steps / dt,
-            "config": {"workload": "one whole core-shard proof (sp1hip_prove_shard = prove_shard_with_data): core-shaped synthetic shard, "
-                                   "%d chips / %d interactions / %d constraints (widths, constraint counts, interaction counts and row "
-                                   "proportions from the reference's rv64im_costs.json, rv64im_complexity.json, layer_workloads.json), "
-                                   "area %d cells%s, max_log_row_count %d, stacking height 2^%d, log_blowup 2, 124 queries, 16-bit PoW; "
-                                   "traces resident in HBM" % (meta["chips"], meta["interactions"], meta["constraints"], area,
-                                                               " (CORE = 2^28 + 2^27)" if k == 0 else " (CORE >> %d)" % (2 * k), L, lsh),
+            "riscv_instructions_per_s": world * args.steps * meta["instructions_executed"] / dt if kind == "real" else None,
+            "config": {"workload": workload_text + "; area %d cells%s, max_log_row_count %d, stacking height 2^%d, log_blowup 2, "
+                                   "124 queries, 16-bit PoW; traces resident in HBM" % (area, "" if k == 0 else " (scale 4^-%d)" % k, L, lsh),
                        "area_cells": area, "first_layer_entries": meta["first_layer_entries"], "proof_bytes": len(proof),
+                       "instructions_executed": meta.get("instructions_executed"),
                        "parallelism": "independent shards, one per GPU"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_over_algorithmic": (traffic / (alg[dom] / dom_launches)) if traffic else None,
-                         "traffic_source": traffic_note,
+            "roofline": {"bound": d["bound"], "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_over_algorithmic": (traffic / (alg_dom / dom_launches)) if traffic else None,
+                         "pmc_source": pmc_note, "hbm_frac": d["hbm_frac"], "valu_frac": d["valu_frac_vs_measured_int_rate"],
                          "avg_launch_ms": dom_ms / dom_launches, "launches_per_step": dom_launches,
-                         "algorithmic_bytes_per_launch": alg[dom] // dom_launches,
-                         "note": "dominant kernel of the step by measured launch time; it is VALU-bound, not HBM-bound (see stages."
-                                 + dom + "); traffic: HBM bytes per launch from the committed PMC passes (profiles/r03_traffic.json), "
-                                 "algorithmic bytes = SURVEY 8(d): 4 N S + 32 N per commit, divided over the launches",
+                         "algorithmic_bytes_per_launch": alg_dom // dom_launches,
+                         "note": "dominant kernel group of the step by live launch time (HIP events on the launch stream, all timed "
+                                 "kernels considered); bound = whichever of algorithmic-bytes / time / 8 TB/s and SQ_INSTS_VALU x 64 / "
+                                 "time / 39.3e12 is larger; VALU instructions and HBM bytes from the committed PMC passes of this "
+                                 "round; peaks: HBM 8 TB/s (guide), VALU 256 CU x 64 lanes x 2.4 GHz (measured integer rate; the "
+                                 "guide's packed-issue figure is twice that and is reported beside it in `stages`)",
                          "stages": stages},
             "cpu_baseline": extras.get("cpu_baseline"),
             "verified": verified,
+            "core_real_chips": ({"real_chips": meta["real_chips"], "synthetic_chips": meta["synthetic_chips"],
+                                 "real_area_cells": meta["real_area_cells"], "ms_per_proof": ms_per_step,
+                                 "zerocheck_round_ms": ms.get("zerocheck_round"), "per_chip": meta["per_chip"]} if kind == "real" else None),
             "host_threads": lib.sp1hip_host_threads(),
-            "zerocheck_compiled_kernels": api.zerocheck_jit_stats(),
             "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},
             "real_machine": extras.get("real_machine"),
+            "synthetic_core_shaped": extras.get("synthetic_core_shaped"),
             "in_flight": extras.get("in_flight"),
             "value_pipelined": max((v["cells_per_s"] for v in extras["in_flight"]["slots"].values()), default=None) if extras.get("in_flight") else None,
             "commit_only": extras.get("commit_only"),

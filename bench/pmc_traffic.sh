@@ -4,23 +4,30 @@
 # calibration kernel with a known byte count first (monty_convert: 2^28 words read and written = 1 GiB each way).
 # Corrections, as the guide's HBM section prescribes and the calibration kernel confirms: rocprofv3 reports both counters in
 # KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads (x 2), WRITE_SIZE is exact (x 1).
-# usage: bench/pmc_traffic.sh <out.json>      (writes the table bench.py reads: profiles/r03_traffic.json)
+# A third pass collects SQ_INSTS_VALU (wave-level VALU instructions; x 64 = lane-instructions) and SQ_INSTS_SALU per kernel: the
+# numerators of bench.py's VALU roofline fractions (from THIS round's counters, not a constant).
+# usage: bench/pmc_traffic.sh <out.json>      (writes the table bench.py reads: profiles/r04_traffic.json)
 out=$1
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/pmc_f /tmp/pmc_w
+rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_v
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python $GRAFT_REPO_ROOT/bench/profile_bench_pmc.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- python $GRAFT_REPO_ROOT/bench/profile_bench_pmc.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d /tmp/pmc_v -o v -- python $GRAFT_REPO_ROOT/bench/profile_bench_pmc.py > /dev/null 2>&1
 python - "$out" <<PY
 import csv, glob, json, sys, collections
-def load(d):
+def load(d, counter=None):
     agg, cnt = collections.defaultdict(float), collections.Counter()
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
+            if counter is not None and r["Counter_Name"] != counter:
+                continue
             k = r["Kernel_Name"].split("(")[0]
             agg[k] += float(r["Counter_Value"]); cnt[k] += 1
     return agg, cnt
 f, fc = load("/tmp/pmc_f")
 w, wc = load("/tmp/pmc_w")
+valu, _ = load("/tmp/pmc_v", "SQ_INSTS_VALU")
+salu, _ = load("/tmp/pmc_v", "SQ_INSTS_SALU")
 cal = next(k for k in f if "monty_convert_kernel" in k)
 cal_bytes = (1 << 28) * 4
 fetch_scale = cal_bytes / (f[cal] * 1024.0)          # expected 2.0
@@ -31,6 +38,7 @@ groups = {   # bench.py's kernel names -> substrings of the HIP kernel names
     "zerocheck_round": ["zc_round_kernel", "zc_jit_first", "zc_jit_ext"],
     "zerocheck_fix": ["zc_fix_kernel"],
     "gkr_pass": ["gkr_pass"],
+    "compress": ["compress_layer", "compress_top"],
     "gkr_first_layer": ["first_layer_kernel"],
     "gkr_transition": ["transition_kernel"],
     "jagged_fold": ["jg_fold"],
@@ -44,9 +52,14 @@ for name, subs in groups.items():
     write = sum(w.get(k, 0.0) for k in ks) * 1024 * 1.0
     launches = sum(fc[k] for k in ks)
     kernels[name] = {"launches_per_proof": launches, "fetch_bytes_per_proof": fetch, "write_bytes_per_proof": write,
-                     "hbm_bytes_per_proof": fetch + write, "hbm_bytes_per_launch": (fetch + write) / launches}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over one core-shaped proof (bench/pmc_traffic.sh); "
-                     "KiB units, FETCH x 2 (gfx950: 64 B tallied per 128 B request), WRITE x 1",
+                     "hbm_bytes_per_proof": fetch + write, "hbm_bytes_per_launch": (fetch + write) / launches,
+                     "valu_wave_insts_per_proof": sum(valu.get(k, 0.0) for k in ks),
+                     "valu_lane_insts_per_proof": 64.0 * sum(valu.get(k, 0.0) for k in ks),
+                     "salu_insts_per_proof": sum(salu.get(k, 0.0) for k in ks)}
+json.dump({"workload": "real",
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU SQ_INSTS_SALU, three separate passes over one proof of the "
+                     "real-chip core shard (bench/pmc_traffic.sh -> profiles/r04_traffic.json); KiB units, FETCH x 2 (gfx950: 64 B "
+                     "tallied per 128 B request), WRITE x 1; SQ_INSTS_VALU counts wave instructions (x 64 lanes)",
            "calibration": {"kernel": "monty_convert_kernel, 2^28 words each way", "fetch_scale_measured": fetch_scale,
                            "write_scale_measured": write_scale},
            "kernels": kernels}, open(sys.argv[1], "w"), indent=1)

@@ -1,5 +1,5 @@
 """Workload for the round-2 PMC passes: a calibration kernel with a known byte count (monty_convert: 2^28 words read and
-written, 4 B per lane coalesced), then ONE whole core-shaped shard proof exactly as bench.py times it."""
+written, 4 B per lane coalesced), then ONE whole proof of bench.py's workload (the real-chip core shard) exactly as bench.py times it."""
 import os
 import runpy
 import sys
@@ -15,5 +15,5 @@ buf = torch.zeros(n, dtype=torch.int32, device="cuda")
 api.check(api._L().sp1hip_to_monty(api._dptr(buf), n, api._stream_ptr()))
 torch.cuda.synchronize()
 del buf
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-extras"]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-extras", "--no-verify"]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")

@@ -1030,8 +1030,51 @@ GLOBAL_INTERACTION = S(("x_coordinate", 7), ("y_coordinate", 7), ("permutation",
 GLOBAL_ACCUMULATION = S(("initial_digest_x", 7), ("initial_digest_y", 7), ("cumulative_sum_x", 7), ("cumulative_sum_y", 7))
 
 
-def global_chip():
+def septic_product_coeffs(b, xf, yf, square=False):
+    """The seven coefficients of x y in F_p[z] / (z^7 - 3 z - 5), as independent expression trees emitted COEFFICIENT by
+    coefficient: ret[k] = T_k + 5 T_(k+7) + 3 T_(k+6) with T_s = sum_{i+j=s} x_i y_j, so only one group sum T_s is shared —
+    between coefficients k and k + 1 — and nothing else stays live (the reference's `Mul` accumulates all 13 group sums at
+    once: same polynomials, 13 + 14 live values). xf(i) / yf(i) BUILD operand i afresh at every use (cheap affine forms are
+    recomputed rather than kept in a register); square=True uses the symmetry of x x (28 products instead of 49)."""
+    T = {}
+
+    def group(s_):
+        if s_ not in T:
+            acc = None
+            for i in range(7):
+                j = s_ - i
+                if not 0 <= j < 7:
+                    continue
+                if square:
+                    if i > j:
+                        continue
+                    t = xf(i) * xf(j)
+                    if i < j:
+                        t = t * 2
+                else:
+                    t = xf(i) * yf(j)
+                acc = t if acc is None else acc + t
+            T[s_] = acc
+        return T[s_]
+    out = []
+    for k in range(7):
+        r = group(k)
+        if k + 7 <= 12:
+            r = r + group(k + 7) * 5
+        if k >= 1:
+            r = r + group(k + 6) * 3
+        out.append(r)
+    return out
+
+
+def global_chip(form=None):
+    """form="reference": septic products accumulated like the reference's `SepticExtension::mul` (13 group sums at once);
+    "coefficient-major" (default): the same constraint polynomials emitted coefficient by coefficient with cheap operands
+    recomputed — 12 live values instead of 41, so the zerocheck interpreter runs the chip four times as wide (DESIGN.md §7.2;
+    tests/test_riscv_machine.py checks the two forms agree on random rows)."""
+    import os
     from .recursion import P2_EXT, P2_OUT, poseidon2_permutation_constraints
+    form = form or os.environ.get("SP1_GLOBAL_FORM", "coefficient-major")
     b, c, _ = _chip("Global", 241)
     L = S(("message", 8), ("kind", 1), ("message_0_16bit_limb", 1), ("message_0_8bit_limb", 1), ("interaction", GLOBAL_INTERACTION),
           ("is_real", 1), ("is_receive", 1), ("is_send", 1), ("index", 1), ("accumulation", GLOBAL_ACCUMULATION))(c)
@@ -1053,12 +1096,33 @@ def global_chip():
     for i in range(16):
         b.when(L.is_real).assert_eq(perm[P2_EXT(0, i)], m_trial[i])
     base = c.names["interaction.permutation"]
-    poseidon2_permutation_constraints(b.air, base)
-    b.air._seen = {}                                       # (the closed-form internal rounds switch hash-consing off; back on)
-    for i in range(7):
-        b.when(L.is_real).assert_eq(I.x_coordinate[i], perm[P2_OUT(i)])
-    x, y = I.x_coordinate, I.y_coordinate
-    b.assert_all_eq(septic_mul(b, y, y), curve_formula(b, x))
+    poseidon2_permutation_constraints(b.air, base)             # (switches the AirProgram's hash-consing off)
+    xc, yc = c.names["interaction.x_coordinate"], c.names["interaction.y_coordinate"]
+    ac = {nm: c.names["accumulation." + nm] for nm in ("initial_digest_x", "initial_digest_y", "cumulative_sum_x", "cumulative_sum_y")}
+    if form == "reference":
+        b.air._seen = {}
+        for i in range(7):
+            b.when(L.is_real).assert_eq(I.x_coordinate[i], perm[P2_OUT(i)])
+        x, y = I.x_coordinate, I.y_coordinate
+        b.assert_all_eq(septic_mul(b, y, y), curve_formula(b, x))
+    else:
+        from .rv_builder import Sym, _MAIN
+        fresh = lambda col: Sym(b, _MAIN, col, None, ({("main", col): 1}, 0))     # a new load at every use
+        if form == "coefficient-major-shared-xy":                                # x, y loaded once (14 registers), the rest afresh
+            _xy = {col: b.main(col) for col in list(range(xc, xc + 7)) + list(range(yc, yc + 7))}
+            _f0 = fresh
+            fresh = lambda col: _xy[col] if col in _xy else _f0(col)
+        for i in range(7):
+            b.when(L.is_real).assert_eq(fresh(xc + i), fresh(base + P2_OUT(i)))
+        y2 = septic_product_coeffs(b, lambda i: fresh(yc + i), None, square=True)
+        x2 = septic_product_coeffs(b, lambda i: fresh(xc + i), None, square=True)
+        x3 = septic_product_coeffs(b, lambda i: x2[i], lambda j: fresh(xc + j))
+        for k in range(7):
+            rhs = x3[k] + fresh(xc + k) * 45
+            if k == 3:
+                rhs = rhs + 41
+            b.assert_eq(y2[k], rhs)
+        y = [fresh(yc + i) for i in range(7)]
     y6_value = b.const(0)
     for i in range(3):
         y6_value = y6_value + I.y6_byte_decomp[i] * (1 << (8 * i))
@@ -1071,11 +1135,27 @@ def global_chip():
     b.assert_bool(L.is_real)
     b.receive(GLOBAL_ACC, [L.index] + A.initial_digest_x + A.initial_digest_y, L.is_real)
     p1x, p1y, p3x, p3y = A.initial_digest_x, A.initial_digest_y, A.cumulative_sum_x, A.cumulative_sum_y
-    dx, dy = septic_sub(x, p1x), septic_sub(y, p1y)
-    checker_x = septic_sub(septic_mul(b, septic_add(septic_add(p1x, x), p3x), septic_mul(b, dx, dx)), septic_mul(b, dy, dy))
-    checker_y = septic_sub(septic_mul(b, septic_add(p1y, p3y), dx), septic_mul(b, dy, septic_sub(p1x, p3x)))
-    b.assert_all_eq(checker_x, [0] * 7)
-    b.when(L.is_real).assert_all_eq(checker_y, [0] * 7)
+    if form == "reference":
+        dx, dy = septic_sub(x, p1x), septic_sub(y, p1y)
+        checker_x = septic_sub(septic_mul(b, septic_add(septic_add(p1x, x), p3x), septic_mul(b, dx, dx)), septic_mul(b, dy, dy))
+        checker_y = septic_sub(septic_mul(b, septic_add(p1y, p3y), dx), septic_mul(b, dy, septic_sub(p1x, p3x)))
+        b.assert_all_eq(checker_x, [0] * 7)
+        b.when(L.is_real).assert_all_eq(checker_y, [0] * 7)
+    else:
+        dxf = lambda i: fresh(xc + i) - fresh(ac["initial_digest_x"] + i)
+        dyf = lambda i: fresh(yc + i) - fresh(ac["initial_digest_y"] + i)
+        sxf = lambda i: (fresh(ac["initial_digest_x"] + i) + fresh(xc + i)) + fresh(ac["cumulative_sum_x"] + i)
+        dx2 = septic_product_coeffs(b, dxf, None, square=True)                  # 7 values kept across the next product
+        sd = septic_product_coeffs(b, sxf, lambda j: dx2[j])
+        dy2 = septic_product_coeffs(b, dyf, None, square=True)
+        for k in range(7):
+            b.assert_eq(sd[k] - dy2[k], 0)
+        syf = lambda i: fresh(ac["initial_digest_y"] + i) + fresh(ac["cumulative_sum_y"] + i)
+        pxf = lambda i: fresh(ac["initial_digest_x"] + i) - fresh(ac["cumulative_sum_x"] + i)
+        u = septic_product_coeffs(b, syf, dxf)
+        v = septic_product_coeffs(b, dyf, pxf)
+        for k in range(7):
+            b.when(L.is_real).assert_eq(u[k] - v[k], 0)
     b.send(GLOBAL_ACC, [L.index + 1] + p3x + p3y, L.is_real)
     return _done(b, c)
 
