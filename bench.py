@@ -414,7 +414,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    api.zerocheck_jit_wait(-1)
     if args.warmup:
         step()
     torch.cuda.synchronize()

@@ -35,7 +35,7 @@ write_scale = cal_bytes / (w[cal] * 1024.0)          # expected 1.0
 groups = {   # bench.py's kernel names -> substrings of the HIP kernel names
     "leaf_hash": ["leaf_hash_part_kernel", "leaf_hash_kernel"],
     "rs_encode": ["ntt_fast_pass"],
-    "zerocheck_round": ["zc_round_kernel", "zc_jit_first", "zc_jit_ext"],
+    "zerocheck_round": ["zc_round_kernel", "zc_macro_kernel"],
     "zerocheck_fix": ["zc_fix_kernel"],
     "gkr_pass": ["gkr_pass"],
     "compress": ["compress_layer", "compress_top"],

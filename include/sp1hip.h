@@ -376,22 +376,6 @@ int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_instr, uint32
                                uint32_t n_publics, int form, uint32_t* out_values, uint32_t n_constraints,
                                uint32_t* out_stats);
 
-/* Compiled constraint kernels. Chips whose program is short enough get a straight-line HIP kernel (all three interpolation
- * nodes of a row pair in one pass, no bytecode decode) compiled OFFLINE with hipcc — by a background thread when a prover
- * first sees the program, or ahead of time (`__graft_entry__.build()` fills sp1_amd/lib/zc_cache/) — and cached on disk by
- * program hash ($SP1HIP_CACHE_DIR, default ~/.cache/sp1hip). Until a kernel is ready, and for long programs and small rounds,
- * the interpreter runs; the sums — hence the proof bytes — are the same. OPT-IN (SP1HIP_ZC_JIT=1): on the shards measured so
- * far the interpreter is faster.
- * (The reference tiers its interpreter by register count instead: /root/reference/sp1-gpu/crates/sys/src/kernels.rs:L38-L117.)
- *   sp1hip_zerocheck_codegen : host only; source + cache hash of one program (size protocol: *len capacity in, size out)
- *   sp1hip_zerocheck_jit_wait: block until the background compiler is idle (timeout_ms < 0: no limit); *pending = jobs left
- *   sp1hip_zerocheck_jit_stats: kernels ready / failed to compile / still queued in this process, and how many times a
- *                               compiled kernel has been launched */
-int sp1hip_zerocheck_codegen(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width, char* out,
-                             size_t* len, uint64_t* hash);
-int sp1hip_zerocheck_jit_wait(int timeout_ms, int* pending);
-int sp1hip_zerocheck_jit_stats(int* ready, int* failed, int* pending, uint64_t* launches);
-
 /* ---------------------------------------------------------------- one whole shard proof
  * A chip of the shard with everything the stages need: constraint program (zerocheck, see sp1hip_zc_chip_t),
  * interaction program (LogUp-GKR, see sp1hip_gkr_chip_t) and its device traces. Chips in name order. */

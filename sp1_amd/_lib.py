@@ -185,9 +185,6 @@ PROTOTYPES = [
     ("sp1hip_prove_shard_with_pk", None, [_vp, C.POINTER(ShardChip), _int, u32p, _int, u32p, _int, u8p, C.POINTER(_sz), _vp]),
     ("sp1hip_zerocheck_prove", None, [C.POINTER(ZcChip), _int, _int, C.POINTER(Ext), C.POINTER(Ext), Ext, Ext, u32p, _int,
                                       _vp, u8p, C.POINTER(_sz), _vp]),
-    ("sp1hip_zerocheck_codegen", None, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.POINTER(_sz), C.POINTER(C.c_uint64)]),
-    ("sp1hip_zerocheck_jit_wait", None, [_int, C.POINTER(_int)]),
-    ("sp1hip_zerocheck_jit_stats", None, [C.POINTER(_int), C.POINTER(_int), C.POINTER(_int), C.POINTER(C.c_uint64)]),
     ("sp1hip_pool_create", None, [_int, _int, C.POINTER(_vp)]),
     ("sp1hip_pool_destroy", "void", [_vp]),
     ("sp1hip_pool_submit", None, [_vp, _vp, C.POINTER(PoolChip), _int, u32p, _int, C.POINTER(C.c_uint64)]),

@@ -600,32 +600,6 @@ class ProvingKey:
             self.h = None
 
 
-def zerocheck_codegen(air):
-    """(HIP source, cache hash) of the compiled zerocheck kernels of an AirProgram (host only; sp1hip_zerocheck_codegen)."""
-    prog = np.ascontiguousarray(air.to_array(), dtype=np.uint32).reshape(-1, 3)
-    n, h = C.c_size_t(0), C.c_uint64()
-    args = [prog.ctypes.data_as(_lib.u32p) if prog.size else None, prog.shape[0], air.main_width, air.prep_width]
-    st = _L().sp1hip_zerocheck_codegen(*args, None, C.byref(n), C.byref(h))
-    if st != _lib.ERROR_BUFFER_TOO_SMALL:
-        check(st)
-    buf = C.create_string_buffer(n.value)
-    check(_L().sp1hip_zerocheck_codegen(*args, buf, C.byref(n), C.byref(h)))
-    return buf.value.decode(), h.value
-
-
-def zerocheck_jit_wait(timeout_ms=-1):
-    """Block until the background compiler of the zerocheck kernels is idle; returns the number of jobs still pending."""
-    pending = C.c_int()
-    check(_L().sp1hip_zerocheck_jit_wait(int(timeout_ms), C.byref(pending)))
-    return pending.value
-
-
-def zerocheck_jit_stats():
-    r, f, p, n = C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
-    check(_L().sp1hip_zerocheck_jit_stats(C.byref(r), C.byref(f), C.byref(p), C.byref(n)))
-    return {"ready": r.value, "failed": f.value, "pending": p.value, "launches": n.value}
-
-
 class PinnedHost:
     """Pinned host words (sp1hip_malloc_host) holding one row-major table: what a host trace generator fills and
     `ProverPool.submit` uploads at full PCIe rate."""

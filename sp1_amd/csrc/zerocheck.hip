@@ -31,7 +31,6 @@
 #include "device_ctx.hpp"
 #include "round_sync.hpp"
 #include "zc_device.hpp"
-#include "zc_jit.hpp"
 
 namespace sp1hip {
 
@@ -496,25 +495,13 @@ struct ZcPlan {                      // everything that depends on a chip's prog
     std::vector<uint32_t> prog;      // allocated [n][4], whole program (padded-row evaluation)
     uint32_t n_regs = 1;
     std::vector<Chunk> chunks, mono, fine;
-    std::vector<uint32_t> sched;     // the scheduled SSA the forms above were cut from (what the compiled kernel is generated from)
-    // its compiled kernel (zc_jit.hpp), requested by the first PROOF that uses the plan (the host-only planner checks never
-    // start a compiler); nullptr: not eligible
-    mutable std::mutex jit_m;
-    mutable bool jit_asked = false;
-    mutable std::shared_ptr<ZcJitKernel> jit;
-    ZcJitKernel* compiled() const {
-        if (!zc_jit_enabled()) return nullptr;
-        std::lock_guard<std::mutex> lk(jit_m);
-        if (!jit_asked) { jit = zc_jit_request(sched.data(), (uint32_t)(sched.size() / 3), main_w, prep_w); jit_asked = true; }
-        return jit.get();
-    }
+    std::vector<uint32_t> sched;     // the scheduled SSA the forms above were cut from
 };
 
 struct ChipState {
     const sp1hip_zc_chip_t* in;
     std::vector<uint32_t> prog;     // allocated [n][4]
     uint32_t n_regs = 1;
-    ZcJitKernel* jit = nullptr;     // compiled kernel of the chip's program (owned by the cached plan)
     std::vector<Ext> alpha_pows, gkr_pows;
     std::vector<Chunk> chunks;         // split at assert boundaries (parallel across constraints: the small rounds)
     std::vector<uint32_t> chunk_off;   // offset (in instructions) of each chunk inside d_prog
@@ -1146,7 +1133,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             std::shared_ptr<const ZcPlan> plan;
             SP1HIP_TRY(zc_get_plan(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, i, &plan));
             c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono; c->fine = plan->fine;
-            c->jit = plan->compiled();                // found on disk, or queued for the background compiler (the plan cache keeps it alive)
         }
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
@@ -1256,21 +1242,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<Group> groups;
         static const bool mono_enabled = [] { const char* e = getenv("SP1HIP_ZC_MONO"); return !(e && e[0] == '0'); }();
         std::vector<char> use_mono(n_chips, 0);
-        // chips whose COMPILED kernel is ready run it while the round is large (zc_jit.hpp): one workgroup evaluates the
-        // three nodes of its row pairs with no decode; everything else goes through the interpreter groups below
-        struct JitLaunch { hipFunction_t fn; int chip; uint32_t desc_index, n_blocks; };
-        std::vector<JitLaunch> jit_launches;
-        std::vector<char> use_jit(n_chips, 0);
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
-            if (c.rows == 0 || !c.jit || (c.rows + 1) / 2 < ZC_JIT_MIN_TERMS) continue;
-            hipFunction_t fn = nullptr;
-            SP1HIP_TRY(zc_jit_function(c.jit, r == 0, &fn));
-            if (fn) { use_jit[i] = 1; jit_launches.push_back(JitLaunch{fn, i, 0, 0}); }
-        }
-        for (int i = 0; i < n_chips; i++) {
-            ChipState& c = *st[i];
-            if (c.rows == 0 || use_jit[i]) continue;
+            if (c.rows == 0) continue;
             const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
             uint32_t mono_regs = 1;
             for (auto& ck : c.mono) mono_regs = std::max(mono_regs, ck.n_regs);
@@ -1339,21 +1313,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             g.n_blocks = total_blocks - g.block_lo;
         }
-        for (JitLaunch& jl : jit_launches) {                 // one descriptor and one block range per compiled chip
-            ChipState& c = *st[jl.chip];
-            const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
-            ZcDesc d{};
-            d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
-            d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
-            d.block_start = total_blocks; d.n_blocks = std::min<uint32_t>((terms + 255) / 256, 4096u);
-            d.flags = 1u; d.block_pairs = 256;
-            jl.desc_index = (uint32_t)descs.size();
-            jl.n_blocks = d.n_blocks;
-            total_blocks += d.n_blocks;
-            descs.push_back(d);
-            ranges.push_back(ZcChipRange{d.block_start, d.n_blocks, terms - 1, 0});
-            desc_chip.push_back(jl.chip);
-        }
         const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
         // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
         // it now, so that every descriptor of the round goes up in ONE copy
@@ -1409,38 +1368,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_TRY(d_partial.alloc(partial_cap, s));
             }
             ScopedTimer tm("zerocheck_round", s);      // (the reference's SP1_GPU_ZEROCHECK_ROUND_TIMING switch)
-            constexpr int ZC_JIT_SIDE = 6;
-            hipStream_t* jit_side = nullptr;
-            hipEvent_t* jit_ev = nullptr;
-            bool jit_used[ZC_JIT_SIDE] = {false};
-            if (!jit_launches.empty()) {
-                // the compiled kernels of a round are independent of each other and of the interpreter groups below: they
-                // go out on side streams (largest first, to the least loaded stream) between a fork and a join event
-                SP1HIP_TRY(zc_jit_side_streams(s, ZC_JIT_SIDE, &jit_side, &jit_ev));
-                SP1HIP_HIP(hipEventRecord(jit_ev[0], s));
-                std::vector<size_t> order(jit_launches.size());
-                for (size_t k = 0; k < order.size(); k++) order[k] = k;
-                auto cost = [&](const JitLaunch& jl) { return (uint64_t)jl.n_blocks * (st[jl.chip]->in->n_instr + 8); };
-                std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost(jit_launches[a]) > cost(jit_launches[b]); });
-                uint64_t load[ZC_JIT_SIDE] = {0};
-                for (size_t k : order) {
-                    const JitLaunch& jl = jit_launches[k];
-                    int q = 0;
-                    for (int j = 1; j < ZC_JIT_SIDE; j++) if (load[j] < load[q]) q = j;
-                    load[q] += cost(jl);
-                    if (!jit_used[q]) { SP1HIP_HIP(hipStreamWaitEvent(jit_side[q], jit_ev[0], 0)); jit_used[q] = true; }
-                    const ZcDesc* a_descs = (const ZcDesc*)d_descs.p;
-                    uint32_t a_index = jl.desc_index, a_eq_len = 1u << (nv - 1);
-                    const uint32_t* a_eq = d_eq.u32();
-                    const uint32_t* a_pub = d_publics.u32();
-                    uint32_t* a_partial = d_partial.u32();
-                    void* args[] = {&a_descs, &a_index, &a_eq, &a_eq_len, &a_pub, &a_partial};
-                    // few blocks: one workgroup per (block, node), the nodes of the chip run side by side
-                    const uint32_t gy = jl.n_blocks <= 1024 ? (r == 0 ? 2u : 3u) : 1u;
-                    SP1HIP_HIP(hipModuleLaunchKernel(jl.fn, jl.n_blocks, gy, 1, 256, 1, 1, 0, jit_side[q], args, nullptr));
-                    g_zc_jit_launches.fetch_add(1, std::memory_order_relaxed);
-                }
-            }
             for (auto& g : groups) {
                 // SP1HIP_ZC_FUSE_NODES=1: one workgroup evaluates the three nodes of its rows (rows leave HBM once). Measured
                 // on the core-shaped shard: 12.5 ms of round kernels against 11.0 ms unfused — the re-reads of the unfused
@@ -1451,8 +1378,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
                 else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             }
-            for (int q = 0; q < ZC_JIT_SIDE; q++)                   // join: the reduction needs every compiled kernel's partial sums
-                if (jit_used[q]) { SP1HIP_HIP(hipEventRecord(jit_ev[1 + q], jit_side[q])); SP1HIP_HIP(hipStreamWaitEvent(s, jit_ev[1 + q], 0)); }
             // the reduce kernel publishes the round's sums itself (ticket on the round-sync counters, payload in the mailbox slot)
             const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
             const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
@@ -1683,33 +1608,6 @@ extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_in
     }
     for (uint32_t k = 0; k < n_constraints; k++) SP1HIP_REQUIRE(seen[k] == 1, "a constraint was not evaluated exactly once");
     if (out_stats) { out_stats[0] = words; out_stats[1] = pieces; out_stats[2] = regs; }
-    return SP1HIP_SUCCESS;
-}
-
-// Host-only: the HIP source of the compiled kernels of `program` (planned as the prover plans it) and the hash its code
-// object is cached under. Size protocol: *len = capacity on entry, needed size (with the terminating NUL) on return.
-extern "C" int sp1hip_zerocheck_codegen(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width,
-                                        char* out, size_t* len, uint64_t* hash) {
-    SP1HIP_REQUIRE((program || n_instr == 0) && len, "null argument");
-    for (uint32_t k = 0; k < n_instr; k++) {
-        const uint32_t op = program[3 * k], a = program[3 * k + 1];
-        SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO, "bad opcode in constraint program");
-        if (op == ZC_LOAD_MAIN) SP1HIP_REQUIRE(a < main_width, "main column out of range");
-        if (op == ZC_LOAD_PREP) SP1HIP_REQUIRE(a < prep_width, "preprocessed column out of range");
-    }
-    std::shared_ptr<const ZcPlan> plan;
-    SP1HIP_TRY(zc_get_plan(program, n_instr, main_width, prep_width, -1, &plan));
-    const uint32_t n = (uint32_t)(plan->sched.size() / 3);
-    if (hash) *hash = zc_jit_hash(plan->sched.data(), n, main_width, prep_width);
-    const std::string src = zc_codegen(plan->sched.data(), n, main_width, prep_width);
-    const size_t need = src.size() + 1;
-    if (!out || *len < need) {
-        *len = need;
-        set_error("sp1hip_zerocheck_codegen: buffer too small, need %zu bytes", need);
-        return SP1HIP_ERROR_BUFFER_TOO_SMALL;
-    }
-    memcpy(out, src.c_str(), need);
-    *len = need;
     return SP1HIP_SUCCESS;
 }
 
