@@ -343,6 +343,11 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
  * (instruction k defines value k): 0 LOAD_MAIN col, 1 LOAD_PREP col, 2 CONST canonical, 3 PUBLIC idx,
  * 4 ADD, 5 SUB, 6 MUL, 7 NEG a, 8 ASSERT_ZERO a — the data form of `Air::eval` over
  * `ConstraintSumcheckFolder` (/root/reference/crates/hypercube/src/folder.rs:L276-L323); single-row constraints.
+ * Optional pseudo-instruction 16 HINT kind col (defines no value, asserts nothing): kind 1 = "the next 163 ASSERT_ZEROs are
+ * the Poseidon2 permutation sub-AIR — eval_external_round r = 0..7, then eval_internal_rounds,
+ * /root/reference/crates/hypercube/src/operations/poseidon2/air.rs:L66-L144 — over main columns [col, col + 179)"; the
+ * prover then evaluates those constraints with a fused kernel instead of interpreting them (the hint is verified against the
+ * program before it is used; SP1HIP_ZC_MACRO=0 ignores hints; the proof bytes do not depend on it).
  * Traces: column-major device tensors with `real_rows` rows (padding rows are implicit zeros). */
 typedef struct {
     const uint32_t* program;

@@ -30,7 +30,8 @@
 namespace orc {
 
 enum ZcOp : uint32_t { ZC_LOAD_MAIN = 0, ZC_LOAD_PREP = 1, ZC_CONST = 2, ZC_PUBLIC = 3, ZC_ADD = 4, ZC_SUB = 5, ZC_MUL = 6,
-                       ZC_NEG = 7, ZC_ASSERT_ZERO = 8 };
+                       ZC_NEG = 7, ZC_ASSERT_ZERO = 8,
+                       ZC_HINT = 16 };   // pseudo-instruction (a fused-kernel hint for provers): defines no value, asserts nothing
 
 struct ZcInstr {
     uint32_t op, a, b;   // SSA: the value of instruction k is register k (ASSERT_ZERO defines none)
@@ -69,6 +70,7 @@ static inline E eval_constraints(const ZcAir& air, const K* prep, const K* main,
             case ZC_MUL: reg[k] = reg[in.a] * reg[in.b]; break;
             case ZC_NEG: reg[k] = -reg[in.a]; break;
             case ZC_ASSERT_ZERO: acc += KOps<K>::scale(alpha_pows[ci++], reg[in.a]); break;
+            case ZC_HINT: break;
             default: throw std::runtime_error("bad zerocheck opcode");
         }
     }

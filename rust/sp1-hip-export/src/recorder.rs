@@ -2,7 +2,9 @@
 //! `[op, a, b]` (instruction k defines value k) in the opcode set of include/sp1hip.h:
 //!
 //!   0 LOAD_MAIN col | 1 LOAD_PREP col | 2 CONST canonical | 3 PUBLIC idx | 4 ADD a b | 5 SUB a b | 6 MUL a b | 7 NEG a |
-//!   8 ASSERT_ZERO a
+//!   8 ASSERT_ZERO a | 16 HINT kind col (optional pseudo-instruction, no value: kind 1 = "the next 163 asserts are the
+//!   Poseidon2 permutation sub-AIR over main columns [col, col + 179)", what `hint_poseidon2` below records when a chip's
+//!   eval enters `eval_external_round` / `eval_internal_rounds`; the HIP prover evaluates such a block with a fused kernel)
 //!
 //! Same job as the reference's `DagBuilder` (sp1-gpu/crates/air/src/ir/builder.rs:L29-L66, expr.rs, var.rs), different
 //! design: no global DAG behind a mutex, no node enum — a thread-local instruction list with hash-consing (a repeated load /
@@ -36,6 +38,8 @@ const SUB: u32 = 5;
 const MUL: u32 = 6;
 const NEG: u32 = 7;
 const ASSERT_ZERO: u32 = 8;
+const HINT: u32 = 16;
+const HINT_POSEIDON2: u32 = 1;
 
 #[derive(Default)]
 struct Tape {
@@ -66,6 +70,13 @@ thread_local! {
 
 fn emit(op: u32, a: u32, b: u32) -> u32 {
     TAPE.with(|t| t.borrow_mut().emit(op, a, b))
+}
+
+/// Marks the start of a Poseidon2 permutation sub-AIR (the operation's columns start at main column `first_col`): the
+/// exporter calls this from its `SP1OperationBuilder` hook for the chips that embed a `Poseidon2Operation` (Global,
+/// Poseidon2Wide) right before lowering the operation. Never merged, defines no value.
+pub fn hint_poseidon2(first_col: u32) {
+    TAPE.with(|t| t.borrow_mut().instrs.push([HINT, HINT_POSEIDON2, first_col]));
 }
 
 fn constant(f: F) -> u32 {

@@ -1,0 +1,118 @@
+// sp1_amd/csrc/zc_poseidon2.hpp — the Poseidon2 permutation sub-AIR of the zerocheck as ONE fused evaluation.
+//
+// A third of a core shard's cells (the Global chip: one permutation per global interaction) and the heaviest chip of the
+// recursion machine (Poseidon2WideDeg3) carry the same 163 constraints over the same 179 columns:
+// `eval_external_round` for r = 0..7 and `eval_internal_rounds`
+// (/root/reference/crates/hypercube/src/operations/poseidon2/air.rs:L66-L144) over a `Poseidon2Degree3Cols`
+// (/root/reference/crates/hypercube/src/operations/poseidon2/permutation.rs:L44-L56). As interpreted bytecode they are
+// ~3,800 instruction words per row pair and node whose operands make a round trip through the LDS register file each, with one
+// scalar instruction of decode per vector instruction: 21 % of the VALU issue rate and 0.9 TB/s on the real-chip shard
+// (profiles/r04_traffic.json). A caller's program may therefore carry a HINT pseudo-instruction (op 16: kind, first main
+// column) in front of those constraints; the planner (zerocheck.hip) then drops the 163 asserts from the bytecode and emits
+// nine self-contained pieces instead — external round q (q = 0..7) and the 20 internal rounds (q = 8) — evaluated here with the
+// state in VGPRs: the sequential form of the reference, no register file, no decode. The hint changes nothing but speed: the
+// SSA program stays the definition (the oracle and the verifier ignore op 16), the planner CHECKS the hint against the SSA
+// on a pseudo-random row before trusting it, and the proof bytes are the same (tests compare them with the oracle's).
+#pragma once
+#include "kb31.hpp"
+#include "poseidon2.hpp"
+
+namespace sp1hip {
+
+constexpr uint32_t ZC_HINT = 16;               // SSA pseudo-op: [16, kind, first main column]; defines no value
+constexpr uint32_t ZC_HINT_POSEIDON2 = 1;
+constexpr uint32_t ZC_P2_CONSTRAINTS = 163, ZC_P2_COLUMNS = 179, ZC_P2_PIECES = 9;
+// column map of Poseidon2Degree3Cols
+constexpr int ZC_P2_EXT = 0, ZC_P2_INT = 128, ZC_P2_S0 = 144, ZC_P2_OUT = 163;
+
+struct P2Base {
+    using T = uint32_t;
+    static KB_HD T add(T a, T b) { return kb::add(a, b); }
+    static KB_HD T sub(T a, T b) { return kb::sub(a, b); }
+    static KB_HD T mul(T a, T b) { return kb::mul(a, b); }
+    static KB_HD T addc(T a, uint32_t c) { return kb::add(a, c); }
+    static KB_HD T mulc(T a, uint32_t c) { return kb::mul(a, c); }
+};
+struct P2Ext {
+    using T = kb::Ext;
+    static KB_HD T add(const T& a, const T& b) { return kb::ext_add(a, b); }
+    static KB_HD T sub(const T& a, const T& b) { return kb::ext_sub(a, b); }
+    static KB_HD T mul(const T& a, const T& b) { return kb::ext_mul(a, b); }
+    static KB_HD T addc(T a, uint32_t c) { a.c[0] = kb::add(a.c[0], c); return a; }
+    static KB_HD T mulc(const T& a, uint32_t c) { return kb::ext_mul_base(a, c); }
+};
+
+// external_linear_layer_mut (air.rs:L17-L45): circ(2 M4, M4, M4, M4) — additions only
+template <class F> KB_HD void zc_p2_external_linear(typename F::T* s) {
+    using T = typename F::T;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+        const T x0 = s[j], x1 = s[j + 1], x2 = s[j + 2], x3 = s[j + 3];
+        const T t01 = F::add(x0, x1), t23 = F::add(x2, x3);
+        const T t0123 = F::add(t01, t23);
+        const T t01123 = F::add(t0123, x1), t01233 = F::add(t0123, x3);
+        s[j] = F::add(t01123, t01);
+        s[j + 1] = F::add(t01123, F::add(x2, x2));
+        s[j + 2] = F::add(t01233, t23);
+        s[j + 3] = F::add(t01233, F::add(x0, x0));
+    }
+    T sums[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) sums[k] = F::add(F::add(s[k], s[k + 4]), F::add(s[k + 8], s[k + 12]));
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[j] = F::add(s[j], sums[j & 3]);
+}
+
+// internal_linear_layer_mut (air.rs:L47-L66): s_i <- (sum + d_i s_i) 2^-32, d = [-2, 1, 2, 4, ..., 2^13, 2^15]. In Montgomery
+// form the factor 2^-32 is the word 1 (mulc(x, 1) is one reduction) and d_i 2^-32 is the plain word d_i mod p.
+template <class F> KB_HD void zc_p2_internal_linear(typename F::T* s) {
+    using T = typename F::T;
+    T sum = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) sum = F::add(sum, s[i]);
+    const T sr = F::mulc(sum, 1u);
+    s[0] = F::add(sr, F::mulc(s[0], kb::P - 2u));
+#pragma unroll
+    for (int i = 1; i < 16; i++) s[i] = F::add(sr, F::mulc(s[i], i == 15 ? (1u << 15) : (1u << (i - 1))));
+}
+
+// Piece q of the 163 constraints. ld(column, owned) returns the leaf value of a column of the permutation (0..178); `owned`
+// marks the ONE load of that column, over all nine pieces, that also carries the GKR-opening batching term. sink(j, value):
+// constraint j (0..162, the reference's order) evaluates to `value`.
+template <class F, class RC, class Load, class Sink>
+KB_HD void zc_p2_piece(uint32_t q, const RC* rc, Load&& ld, Sink&& sink) {
+    using T = typename F::T;
+    T s[16];
+    if (q < 8) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = ld(ZC_P2_EXT + 16 * q + i, true);
+        if (q == 0) zc_p2_external_linear<F>(s);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const T x = F::addc(s[i], rc->ext[q][i]);
+            s[i] = F::mul(F::mul(x, x), x);
+        }
+        zc_p2_external_linear<F>(s);
+        const uint32_t nxt = q == 3 ? ZC_P2_INT : q == 7 ? ZC_P2_OUT : ZC_P2_EXT + 16 * (q + 1);
+#pragma unroll
+        for (int i = 0; i < 16; i++) sink(16 * q + i, F::sub(ld(nxt + i, q == 7), s[i]));      // assert_eq(next_state[i], state[i])
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = ld(ZC_P2_INT + i, true);
+    T lane0 = s[0];
+#pragma unroll 1
+    for (int r = 0; r < 20; r++) {
+        const T x = F::addc(lane0, rc->internal[r]);
+        s[0] = F::mul(F::mul(x, x), x);
+        zc_p2_internal_linear<F>(s);
+        if (r < 19) {
+            lane0 = ld(ZC_P2_S0 + r, true);                                                    // the next round starts from the COLUMN
+            sink(128 + r, F::sub(lane0, s[0]));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) sink(147 + i, F::sub(ld(ZC_P2_EXT + 64 + i, false), s[i]));   // external_rounds_state[4]
+}
+
+}  // namespace sp1hip

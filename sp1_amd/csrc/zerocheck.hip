@@ -31,6 +31,7 @@
 #include "device_ctx.hpp"
 #include "round_sync.hpp"
 #include "zc_device.hpp"
+#include "zc_poseidon2.hpp"
 
 namespace sp1hip {
 
@@ -315,6 +316,65 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
     }
 }
 
+
+// The fused Poseidon2 pieces (zc_poseidon2.hpp): one workgroup = 256 row pairs of one piece at one node, like the interpreter's
+// workgroups and into the same partial-sum layout; descriptor flags bit 1 marks a macro piece, bits 8..11 its index q, `pad`
+// its first main column. Every column of the permutation is loaded exactly once per piece; the loads a piece OWNS carry the
+// GKR-opening batching term, so the interpreter's pieces never touch those columns for it (the planner pre-marks them).
+constexpr uint32_t ZC_DESC_MACRO = 2u;
+template <bool FIRST>
+__global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                       uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
+                                                       const p2::RoundConstants* __restrict__ rc_p) {
+    using K = KT<FIRST>;
+    using F = typename std::conditional<FIRST, P2Base, P2Ext>::type;
+    using T = typename K::T;
+    __shared__ uint32_t red[32];
+    if (threadIdx.x < 32) red[threadIdx.x] = 0;
+    const uint32_t bid = block_base + blockIdx.x / 3u;
+    const int pass = (int)(blockIdx.x % 3u), t = 2 * pass;
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const uint32_t q = (d.flags >> 8) & 15u, base_col = d.pad;
+    const auto* rc = (const p2::RoundConstants __attribute__((address_space(4)))*)(uintptr_t)rc_p;    // wave-uniform: scalar loads
+    __syncthreads();
+    const uint32_t terms = (d.rows + 1) / 2;
+    const bool gkr = !FIRST && pass < 2;
+    kb::Ext sa = kb::ext_zero(), sb = kb::ext_zero();
+    if (!(FIRST && pass == 0))                         // round 0, node 0: the constraints vanish and the GKR pass is the interpreter's
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < terms; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, terms); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
+        auto ld = [&](uint32_t c, bool owned) -> T {
+            const T v = leaf<FIRST>(d.main, base_col + c, d.rows, i, t);
+            if (gkr && owned) vb = kb::ext_add(vb, K::scale(load_ext_aos(d.gkr_pows, base_col + c), v));
+            return v;
+        };
+        auto sink = [&](uint32_t j, const T& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
+        zc_p2_piece<F>(q, rc, ld, sink);
+        sa = kb::ext_add(sa, kb::ext_mul(va, e));
+        sb = kb::ext_add(sb, kb::ext_mul(vb, e));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = sa.c[k]; v[4 + k] = sb.c[k]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = zc_wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) red[wave * 8 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const uint32_t k = threadIdx.x;
+        partial[((size_t)bid * 3 + pass) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
+    }
+}
+
 // One workgroup per chip: sums its workgroups' partials and forms (y0, y2, y4, eq[th]) -> out[chip][16].
 template <bool FIRST>
 __global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __restrict__ ranges, const uint32_t* __restrict__ partial,
@@ -484,6 +544,8 @@ struct DevBuf {
     uint32_t* u32() const { return (uint32_t*)p; }
 };
 
+struct ZcMacro { uint32_t kind, base_col, first_constraint; };   // a hinted sub-AIR: its constraints are [first, first + 163)
+
 struct Chunk {
     std::vector<uint32_t> prog;   // allocated [n][4]
     uint32_t n_regs = 1, alpha_off = 0;
@@ -496,10 +558,12 @@ struct ZcPlan {                      // everything that depends on a chip's prog
     uint32_t n_regs = 1;
     std::vector<Chunk> chunks, mono, fine;
     std::vector<uint32_t> sched;     // the scheduled SSA the forms above were cut from
+    std::vector<ZcMacro> macros;     // hinted sub-AIRs evaluated by fused kernels (zc_poseidon2.hpp); their asserts are not in the forms above
 };
 
 struct ChipState {
     const sp1hip_zc_chip_t* in;
+    std::vector<ZcMacro> macros;
     std::vector<uint32_t> prog;     // allocated [n][4]
     uint32_t n_regs = 1;
     std::vector<Ext> alpha_pows, gkr_pows;
@@ -774,7 +838,7 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
 // keeps the late, tiny sumcheck rounds from being one wave interpreting thousands of instructions
 // serially (cf. the reference's chunked bytecode, /root/reference/sp1-gpu/crates/air/src/ir/bytecode.rs:L27-L110).
 static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32_t prep_w, uint32_t limit,
-                        std::vector<Chunk>* out, uint32_t hard_max = ZC_CHUNK_HARD_MAX) {
+                        std::vector<Chunk>* out, uint32_t hard_max = ZC_CHUNK_HARD_MAX, const std::vector<ZcMacro>* macros = nullptr) {
     std::vector<uint32_t> stamp(n, 0xffffffffu);
     std::vector<uint8_t> cone_seen(n, 0);
     std::vector<uint32_t> members, asserts, stack;
@@ -859,6 +923,9 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
     // GKR visits: the first load of each column, in chunk order, carries the flag; columns no constraint
     // reads get TOUCH pseudo-instructions in extra chunks
     std::vector<bool> seen_m(main_w, false), seen_p(prep_w, false);
+    if (macros)                                    // the fused pieces of a hinted sub-AIR carry the GKR term of its columns themselves
+        for (const ZcMacro& m : *macros)
+            for (uint32_t c = 0; c < ZC_P2_COLUMNS; c++) seen_m[m.base_col + c] = true;
     for (auto& c : *out)
         for (size_t k = 0; k < c.prog.size() / 4; k++) {
             uint32_t* o = c.prog.data() + 4 * k;
@@ -930,6 +997,12 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     return acc;
 }
 
+static uint32_t asserts_total(const uint32_t* program, uint32_t n) {
+    uint32_t a = 0;
+    for (uint32_t k = 0; k < n; k++) a += program[3 * k] == ZC_ASSERT_ZERO;
+    return a;
+}
+
 // The plan of a program (immediates folded, instruction order chosen, registers allocated; chunked, undivided and finely
 // cut forms) depends on the program alone: a machine's chips are planned once per process and looked up afterwards (a
 // prover proves the same machine shard after shard; planning 33 chips costs ~1.3 ms of host time per proof).
@@ -953,6 +1026,33 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         std::shared_ptr<ZcPlan> np(new ZcPlan());
         np->n_instr = n_instr; np->main_w = main_width; np->prep_w = prep_width;
         np->source.assign(program, program + (size_t)n_instr * 3);
+        // hinted sub-AIRs (zc_poseidon2.hpp): the HINT pseudo-instructions become harmless constants, the hints are CHECKED
+        // against the SSA, and the asserts they cover leave the interpreted forms (not the whole program `prog`, which the
+        // host still evaluates on the all-zero row)
+        std::vector<uint32_t> clean(program, program + (size_t)n_instr * 3);
+        {
+            uint32_t asserts_before = 0;
+            for (uint32_t k = 0; k < n_instr; k++) {
+                if (clean[3 * k] == ZC_ASSERT_ZERO) asserts_before++;
+                if (clean[3 * k] != ZC_HINT) continue;
+                SP1HIP_REQUIRE(clean[3 * k + 1] == ZC_HINT_POSEIDON2, "unknown hint kind in constraint program");
+                SP1HIP_REQUIRE((uint64_t)clean[3 * k + 2] + ZC_P2_COLUMNS <= main_width, "Poseidon2 hint: columns out of range");
+                np->macros.push_back(ZcMacro{ZC_HINT_POSEIDON2, clean[3 * k + 2], asserts_before});
+                clean[3 * k] = ZC_CONST; clean[3 * k + 1] = 0; clean[3 * k + 2] = 0;
+            }
+            static const bool macros_enabled = [] { const char* e = getenv("SP1HIP_ZC_MACRO"); return !(e && e[0] == '0'); }();
+            if (!macros_enabled) np->macros.clear();
+        }
+        program = clean.data();
+        auto hinted = [&](uint32_t idx) {
+            for (const ZcMacro& m : np->macros) if (idx >= m.first_constraint && idx < m.first_constraint + ZC_P2_CONSTRAINTS) return true;
+            return false;
+        };
+        auto drop_hinted = [&](std::vector<uint32_t>& sch) {      // asserts carry their constraint index in operand b by now
+            if (np->macros.empty()) return;
+            for (size_t k = 0; k < sch.size() / 3; k++)
+                if (sch[3 * k] == ZC_ASSERT_ZERO && hinted(sch[3 * k + 2])) { sch[3 * k] = ZC_CONST; sch[3 * k + 1] = 0; sch[3 * k + 2] = 0; }
+        };
         // fold constants into immediates, then pick the instruction order with the smallest register file
         std::vector<uint32_t> folded, sched;
         fold_immediates(program, n_instr, &folded);
@@ -964,7 +1064,9 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
             std::vector<uint32_t> cand;
             std::vector<Chunk> mono;
             schedule_program(folded.data(), n_instr, main_width, mode, &cand);
-            SP1HIP_TRY(build_chunks(cand.data(), (uint32_t)(cand.size() / 3), main_width, prep_width, 0xffffffffu, &mono));
+            std::vector<uint32_t> cand_f = cand;
+            drop_hinted(cand_f);
+            SP1HIP_TRY(build_chunks(cand_f.data(), (uint32_t)(cand_f.size() / 3), main_width, prep_width, 0xffffffffu, &mono, ZC_CHUNK_HARD_MAX, &np->macros));
             uint32_t regs = 0;
             for (auto& ck : mono) regs = std::max(regs, ck.n_regs);
             if (regs < best_regs) { best_regs = regs; sched.swap(cand); np->mono.swap(mono); }
@@ -980,9 +1082,33 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         SP1HIP_TRY(allocate_registers(sched.data(), n_sched, &np->prog, &np->n_regs));
         static const uint32_t chunk_limit = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_LIMIT"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 8u) : ZC_CHUNK_LIMIT; }();
         static const uint32_t chunk_hard = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_HARD_MAX"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 8u) : ZC_CHUNK_HARD_MAX; }();
-        SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, chunk_limit, &np->chunks, chunk_hard));
-        SP1HIP_TRY(build_chunks(sched.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT));
+        std::vector<uint32_t> sched_f = sched;
+        drop_hinted(sched_f);
+        SP1HIP_TRY(build_chunks(sched_f.data(), n_sched, main_width, prep_width, chunk_limit, &np->chunks, chunk_hard, &np->macros));
+        SP1HIP_TRY(build_chunks(sched_f.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT, &np->macros));
         np->sched = sched;
+        // trust, but verify: on a pseudo-random row the fused pieces must give what the caller's SSA gives for the constraints
+        // they replace (a hint on the wrong columns, or on constraints that are not the Poseidon2 sub-AIR, is an error here)
+        if (!np->macros.empty()) {
+            std::vector<uint32_t> row(main_width), prow(std::max<uint32_t>(prep_width, 1u)), want(asserts_total(program, n_instr), 0u);
+            uint64_t x = 0x9E3779B97F4A7C15ull ^ h;
+            auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x % kb::P); };
+            for (auto& v : row) v = rnd();
+            for (auto& v : prow) v = rnd();
+            uint32_t n_pub = 1;
+            for (uint32_t k = 0; k < n_instr; k++) if (program[3 * k] == ZC_PUBLIC) n_pub = std::max(n_pub, program[3 * k + 1] + 1);
+            std::vector<uint32_t> pub(n_pub, 0u);
+            eval_words_row(np->prog.data(), np->prog.size() / 4, np->n_regs, row.data(), prow.data(), pub.data(),
+                           [&](uint32_t idx, uint32_t v) { if (idx < want.size()) want[idx] = v; });
+            static const p2::RoundConstants host_rc = p2::make_round_constants();
+            for (const ZcMacro& m : np->macros)
+                for (uint32_t q = 0; q < ZC_P2_PIECES; q++) {
+                    bool ok = true;
+                    zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return row[m.base_col + c]; },
+                                        [&](uint32_t j, uint32_t v) { ok &= (m.first_constraint + j < want.size() && want[m.first_constraint + j] == v); });
+                    SP1HIP_REQUIRE(ok, "Poseidon2 hint does not match the constraints it annotates");
+                }
+        }
         plan = np;
         std::lock_guard<std::mutex> lk(plan_mutex);
         if (plan_cache.size() > 4096) plan_cache.clear();
@@ -1122,7 +1248,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         uint32_t asserts = 0;
         for (uint32_t k = 0; k < chips[i].n_instr; k++) {
             const uint32_t op = chips[i].program[3 * k], a = chips[i].program[3 * k + 1];
-            SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO, "bad opcode in constraint program");
+            SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO || op == ZC_HINT, "bad opcode in constraint program");
             if (op == ZC_ASSERT_ZERO) asserts++;
             if (op == ZC_LOAD_MAIN) SP1HIP_REQUIRE(a < chips[i].main_width, "main column out of range");
             if (op == ZC_LOAD_PREP) SP1HIP_REQUIRE(a < chips[i].prep_width, "preprocessed column out of range");
@@ -1133,6 +1259,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             std::shared_ptr<const ZcPlan> plan;
             SP1HIP_TRY(zc_get_plan(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, i, &plan));
             c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono; c->fine = plan->fine;
+            c->macros = plan->macros;
         }
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
@@ -1195,14 +1322,14 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> point;   // [alpha_last, ..., alpha_first]
     std::vector<Ext> round_claims = claims;
     std::vector<std::array<uint32_t, 16>> sums(n_chips);
-    std::vector<uint32_t> h_sums((size_t)n_chips * 16);
+    std::vector<uint32_t> h_sums((size_t)n_chips * 32);      // up to two reduction ranges per chip (interpreter + fused pieces)
     DevBuf d_descs, d_partial, d_sums;       // d_descs: the round's descriptors [ZcDesc.. | ZcChipRange.. | ZcFixDesc..]
     size_t partial_cap = 0, descs_cap = 0;
     std::vector<std::unique_ptr<std::vector<ZcDesc>>> keep_descs;
     std::vector<std::unique_ptr<std::vector<ZcChipRange>>> keep_ranges;
     std::vector<std::unique_ptr<std::vector<ZcFixDesc>>> keep_fds;
     std::vector<std::unique_ptr<std::vector<uint8_t>>> keep_packs;
-    SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 64, s));
+    SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 128, s));
     // The folded extension tables of all chips live in two ping-pong buffers sized once (round r writes half r & 1;
     // every round's tables are half the size of the previous round's): no allocation inside the round loop — it used to
     // be ~66 arena calls per round.
@@ -1313,6 +1440,30 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             g.n_blocks = total_blocks - g.block_lo;
         }
+        // the fused pieces of hinted sub-AIRs: their own block range (and reduction range) per chip, one launch for all of them
+        const uint32_t macro_block_lo = total_blocks;
+        for (int i = 0; i < n_chips; i++) {
+            ChipState& c = *st[i];
+            if (c.rows == 0 || c.macros.empty()) continue;
+            const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
+            const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
+            ZcChipRange rg{total_blocks, 0, terms - 1, 0};
+            for (const ZcMacro& m : c.macros)
+                for (uint32_t q = 0; q < ZC_P2_PIECES; q++) {
+                    ZcDesc d{};
+                    d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+                    d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
+                    d.block_start = total_blocks; d.n_blocks = blocks;
+                    d.alpha_off = m.first_constraint; d.flags = ZC_DESC_MACRO | (q << 8);
+                    d.block_pairs = 256; d.pad = m.base_col;
+                    total_blocks += blocks;
+                    descs.push_back(d);
+                }
+            rg.n_blocks = total_blocks - rg.block_start;
+            ranges.push_back(rg);
+            desc_chip.push_back(i);
+        }
+        const uint32_t macro_blocks = total_blocks - macro_block_lo;
         const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
         // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
         // it now, so that every descriptor of the round goes up in ONE copy
@@ -1378,6 +1529,13 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
                 else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             }
+            if (macro_blocks) {
+                const DeviceCtx* dctx;
+                SP1HIP_TRY(get_device_ctx(&dctx));
+                if (r == 0) hipLaunchKernelGGL(zc_macro_kernel<true>, dim3(macro_blocks * 3), dim3(256), 0, s, (const ZcDesc*)d_descs.p, n_descs, d_eq.u32(), 1u << (nv - 1), d_partial.u32(), macro_block_lo, dctx->d_rc);
+                else hipLaunchKernelGGL(zc_macro_kernel<false>, dim3(macro_blocks * 3), dim3(256), 0, s, (const ZcDesc*)d_descs.p, n_descs, d_eq.u32(), 1u << (nv - 1), d_partial.u32(), macro_block_lo, dctx->d_rc);
+                SP1HIP_LAUNCH_CHECK();
+            }
             // the reduce kernel publishes the round's sums itself (ticket on the round-sync counters, payload in the mailbox slot)
             const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
             const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
@@ -1391,7 +1549,15 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             else SP1HIP_TRY(mb.fetch(d_sums.p, (size_t)n_ranges * 16, h_sums.data()));
             if (zc_timing) { zc_iter_t = std::chrono::steady_clock::now(); zc_wait_ms += std::chrono::duration<double, std::milli>(zc_iter_t - zc_w0).count(); }
         }
-        for (size_t k = 0; k < desc_chip.size(); k++) memcpy(sums[desc_chip[k]].data(), h_sums.data() + k * 16, 64);
+        {   // a chip with fused pieces has a second range: its sums ADD to the interpreter's (the eq entry is the same)
+            std::vector<char> have(n_chips, 0);
+            for (size_t k = 0; k < desc_chip.size(); k++) {
+                const int ci = desc_chip[k];
+                const uint32_t* src = h_sums.data() + k * 16;
+                if (!have[ci]) { memcpy(sums[ci].data(), src, 64); have[ci] = 1; }
+                else for (int w = 0; w < 12; w++) sums[ci][w] = kb::add(sums[ci][w], src[w]);
+            }
+        }
         // ---- univariate messages (sum_as_poly.rs:L187-L287)
         // (sum_as_poly interpolates through {0, 1, 2, 4, b} with the value at b equal to zero.) Closed form, no allocation: the
         // Lagrange basis polynomial of node x_k in {0, 1, 2, 4} is C_k(X) (X - b) / (x_k - b), with C_k the basis polynomial of
@@ -1583,7 +1749,7 @@ extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_in
     uint32_t asserts = 0;
     for (uint32_t k = 0; k < n_instr; k++) {
         const uint32_t op = program[3 * k], a = program[3 * k + 1];
-        SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO, "bad opcode in constraint program");
+        SP1HIP_REQUIRE(op <= ZC_ASSERT_ZERO || op == ZC_HINT, "bad opcode in constraint program");
         if (op == ZC_ASSERT_ZERO) asserts++;
         if (op == ZC_LOAD_MAIN) SP1HIP_REQUIRE(a < main_width && main_row, "main column out of range");
         if (op == ZC_LOAD_PREP) SP1HIP_REQUIRE(a < prep_width && prep_row, "preprocessed column out of range");
@@ -1605,6 +1771,15 @@ extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_in
             eval_words_row(ck.prog.data(), ck.prog.size() / 4, ck.n_regs, main_row, prep_row, publics, on_assert);
             words += (uint32_t)(ck.prog.size() / 4); pieces++; regs = std::max(regs, ck.n_regs);
         }
+    }
+    if (form != 0) {                                  // the forms the GPU runs: hinted constraints come from the fused pieces
+        static const p2::RoundConstants host_rc = p2::make_round_constants();
+        for (const ZcMacro& m : plan->macros)
+            for (uint32_t q = 0; q < ZC_P2_PIECES; q++) {
+                zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return main_row[m.base_col + c]; },
+                                    [&](uint32_t j, uint32_t v) { on_assert(m.first_constraint + j, v); });
+                pieces++;
+            }
     }
     for (uint32_t k = 0; k < n_constraints; k++) SP1HIP_REQUIRE(seen[k] == 1, "a constraint was not evaluated exactly once");
     if (out_stats) { out_stats[0] = words; out_stats[1] = pieces; out_stats[2] = regs; }

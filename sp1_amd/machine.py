@@ -28,7 +28,7 @@ this image, which has no Rust toolchain) and this library: one JSON document per
 """
 import json
 
-from .air import ADD, ASSERT_ZERO, CONST, LOAD_MAIN, LOAD_PREP, MUL, NEG, PUBLIC, SUB, AirProgram, InteractionProgram, P, VCol
+from .air import ADD, ASSERT_ZERO, CONST, HINT, LOAD_MAIN, LOAD_PREP, MUL, NEG, PUBLIC, SUB, AirProgram, InteractionProgram, P, VCol
 
 _BINARY, _UNARY = (ADD, SUB, MUL), (NEG, ASSERT_ZERO)
 
@@ -77,7 +77,7 @@ def load_machine(doc):
                 raise ValueError("%s: constant not canonical" % where)
             if op in _BINARY and not (0 <= a < k and 0 <= b < k) or op in _UNARY and not 0 <= a < k:
                 raise ValueError("%s: operand is not an earlier value" % where)
-            if not 0 <= op <= ASSERT_ZERO or op == PUBLIC and a < 0:
+            if not (0 <= op <= ASSERT_ZERO or op == HINT) or op == PUBLIC and a < 0:
                 raise ValueError("%s: bad opcode / operand" % where)
             air.instrs.append((op, a, b))
             air.num_constraints += op == ASSERT_ZERO

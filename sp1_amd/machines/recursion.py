@@ -160,6 +160,7 @@ def poseidon2_permutation_constraints(air, base=0):
     Shared by Poseidon2WideDeg3 here and by the RISC-V machine's Global chip (riscv.py)."""
     rc = _round_constants()
     main = lambda idx: air.main(base + idx)
+    air.hint_poseidon2(base)                              # provers may evaluate these 163 constraints with a fused kernel
     for r in range(8):
         state = [main(P2_EXT(r, i)) for i in range(16)]
         if r == 0:

@@ -40,6 +40,8 @@ def constraint_values(air, prep, main, publics):
         elif op == ASSERT_ZERO:
             out.append(vals[a])
             v = None
+        else:                                   # HINT: no value, no constraint
+            v = None
         vals.append(v)
     return np.stack(out, axis=1) if out else np.zeros((rows, 0), dtype=U)
 

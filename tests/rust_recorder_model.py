@@ -3,7 +3,7 @@ the exporter: two machine descriptions are THE SAME MACHINE if, on random rows, 
 every interaction the same (kind, multiplicity, values) — instruction numbering is free."""
 import numpy as np
 
-from sp1_amd.air import ADD, ASSERT_ZERO, CONST, LOAD_MAIN, LOAD_PREP, MUL, NEG, PUBLIC, SUB
+from sp1_amd.air import ADD, ASSERT_ZERO, CONST, HINT, LOAD_MAIN, LOAD_PREP, MUL, NEG, PUBLIC, SUB
 
 P = 0x7F000001
 
@@ -48,6 +48,8 @@ def record(program, prep_width, main_width, n_publics):
             new[k] = t.emit(op, new[a], new[b])
         elif op == NEG:
             new[k] = t.emit(NEG, new[a])
+        elif op == HINT:                                  # `Tape::hint`: copied through, defines no value
+            t.instrs.append((op, a, b))
         else:
             new[k] = t.emit(ASSERT_ZERO, new[a])
     return t.instrs
@@ -72,6 +74,8 @@ def constraint_values(instrs, prep_row, main_row, publics):
             v = vals[a] * vals[b] % P
         elif op == NEG:
             v = -vals[a] % P
+        elif op == HINT:
+            v = 0
         else:
             v = vals[a]
             out.append(v)

@@ -11,7 +11,7 @@ import pytest
 
 from machine_check import P, constraint_values
 from sp1_amd import _lib
-from sp1_amd.machines import recursion
+from sp1_amd.machines import recursion, riscv
 
 zc_airs = pytest.importorskip("zc_airs")
 
@@ -121,3 +121,10 @@ def test_compiled_forms_of_random_programs_evaluate_like_the_ssa(lib, seed):
     rng = np.random.default_rng(7000 + seed)
     air = _random_air(rng, int(rng.integers(5, 500)), int(rng.integers(1, 40)), int(rng.integers(0, 6)), 4)
     _check(lib, air, 9000 + seed, 4)
+
+
+def test_compiled_forms_of_the_riscv_chips_evaluate_like_the_ssa(lib):
+    """Incl. Global, whose Poseidon2 block is evaluated by the fused pieces (zc_poseidon2.hpp) in forms 1-3: the host model of
+    those pieces must give the 163 hinted constraints exactly what the SSA gives."""
+    for k, name in enumerate(("Global", "Mul", "ShiftRight", "Branch", "LoadByte", "StoreByte", "Addi")):
+        _check(lib, riscv.chip(name)[0], 300 + k, 4)
