@@ -91,6 +91,17 @@ class AirProgram:
         assert 0 <= base_col and base_col + 179 <= self.main_width
         self.instrs.append((HINT, HINT_POSEIDON2, base_col))
 
+    def hint_septic_curve(self, xy_col):
+        """The 7 asserts that follow are y^2 - (x^3 + 45 x + 41 z^3) over F_p^7, x = main columns [xy_col, +7), y = the next 7
+        (operations/global_interaction.rs:L203-L208)."""
+        self.instrs.append((HINT, 2, xy_col))
+
+    def hint_septic_sum(self, xy_col, acc_col, is_real_col):
+        """The 14 asserts that follow are sum_checker_x and is_real * sum_checker_y for p1 = main columns [acc_col, +14),
+        p2 = [xy_col, +14), p3 = [acc_col + 14, +14) (operations/global_accumulation.rs:L83-L131)."""
+        assert xy_col < (1 << 16) and acc_col < (1 << 16) and is_real_col < (1 << 24)
+        self.instrs.append((HINT, 3 | (is_real_col << 8), xy_col | (acc_col << 16)))
+
     def assert_zero(self, e):
         self._emit(ASSERT_ZERO, e.idx, 0)
         self.num_constraints += 1

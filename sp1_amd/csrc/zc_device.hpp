@@ -20,7 +20,8 @@ struct ZcDesc {
     uint32_t block_start, n_blocks;
     uint32_t alpha_off;          // index of this chunk's first constraint in alpha_pows
     uint32_t flags;              // bit 0: first chunk of its chip (owns the round-0 GKR-only pass)
-    uint32_t block_pairs, pad;   // row pairs per block = the width of the workgroups of this chip's launch group
+    uint32_t block_pairs, pad;   // row pairs per block = the width of the workgroups of this chip's launch group; pad: a fused piece's first column
+    uint32_t aux0, aux1;         // fused pieces (zc_poseidon2.hpp): second column base / is_real column
 };
 
 // Blocks of one chip (all its chunks are contiguous) for the reduction, plus the eq entry it needs.

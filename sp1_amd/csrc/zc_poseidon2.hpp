@@ -115,4 +115,97 @@ KB_HD void zc_p2_piece(uint32_t q, const RC* rc, Load&& ld, Sink&& sink) {
     for (int i = 0; i < 16; i++) sink(147 + i, F::sub(ld(ZC_P2_EXT + 64 + i, false), s[i]));   // external_rounds_state[4]
 }
 
+
+// ---- the septic-curve constraints of the Global chip (operations/global_interaction.rs:L203-L208,
+// operations/global_accumulation.rs:L83-L131): F_p^7 = F_p[z] / (z^7 - 3 z - 5), curve y^2 = x^3 + 45 x + 41 z^3
+// (hypercube/src/septic_extension.rs:L307-L325, septic_curve.rs:L101-L113, L170-L188). Hints:
+//   [16, 2, xy]                          the next 7 asserts are  y^2 - (x^3 + 45 x + 41 z^3)             x = cols xy..xy+6, y = xy+7..xy+13
+//   [16, 3 | is_real << 8, xy | acc << 16]  the next 14 asserts are sum_checker_x (7) and is_real * sum_checker_y (7) for
+//                                        p1 = (acc .. acc+13), p2 = (xy .. xy+13), p3 = (acc+14 .. acc+27)
+constexpr uint32_t ZC_HINT_SEPTIC_CURVE = 2, ZC_HINT_SEPTIC_SUM = 3;
+
+// coefficient k of a b (square: a a, by symmetry) — one coefficient at a time keeps the live set small (one accumulator)
+template <class F, bool SQUARE, class A, class B>
+KB_HD typename F::T zc_septic_coeff(int k, A&& a, B&& b) {
+    using T = typename F::T;
+    auto group = [&](int s_) {                    // T_s = sum_{i + j = s} a_i b_j
+        T acc{};
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int j = s_ - i;
+            if (j < 0 || j > 6) continue;
+            if (SQUARE && i > j) continue;
+            T t = F::mul(a(i), SQUARE ? a(j) : b(j));
+            if (SQUARE && i < j) t = F::add(t, t);
+            acc = first ? t : F::add(acc, t);
+            first = false;
+        }
+        return acc;
+    };
+    T r = group(k);
+    if (k + 7 <= 12) r = F::add(r, F::mulc(group(k + 7), kb::to_monty(5)));
+    if (k >= 1) r = F::add(r, F::mulc(group(k + 6), kb::to_monty(3)));
+    return r;
+}
+
+// piece 0 of kind 2: the curve equation. ld(column relative to xy, owned).
+template <class F, class Load, class Sink>
+KB_HD void zc_septic_curve_piece(Load&& ld, Sink&& sink) {
+    using T = typename F::T;
+    T x[7], y[7], x2[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { x[i] = ld(i, true); y[i] = ld(7 + i, true); }
+#pragma unroll
+    for (int k = 0; k < 7; k++) x2[k] = zc_septic_coeff<F, true>(k, [&](int i) { return x[i]; }, [&](int i) { return x[i]; });
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const T y2 = zc_septic_coeff<F, true>(k, [&](int i) { return y[i]; }, [&](int i) { return y[i]; });
+        T x3 = zc_septic_coeff<F, false>(k, [&](int i) { return x2[i]; }, [&](int i) { return x[i]; });
+        x3 = F::add(x3, F::mulc(x[k], kb::to_monty(45)));
+        if (k == 3) x3 = F::addc(x3, kb::to_monty(41));
+        sink(k, F::sub(y2, x3));
+    }
+}
+
+// pieces of kind 3: q = 0: sum_checker_x, q = 1: is_real * sum_checker_y. xy(col, owned) / acc(col, owned) / real().
+template <class F, class LoadXY, class LoadAcc, class Real, class Sink>
+KB_HD void zc_septic_sum_piece(uint32_t q, LoadXY&& xy, LoadAcc&& acc, Real&& real, Sink&& sink) {
+    using T = typename F::T;
+    T dx[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) dx[i] = F::sub(xy(i, false), acc(i, q == 0));
+    if (q == 0) {
+        T sx[7], dy[7], d2[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            sx[i] = F::add(F::add(acc(i, false), xy(i, false)), acc(14 + i, true));
+            dy[i] = F::sub(xy(7 + i, false), acc(7 + i, true));
+        }
+#pragma unroll
+        for (int k = 0; k < 7; k++) d2[k] = zc_septic_coeff<F, true>(k, [&](int i) { return dx[i]; }, [&](int i) { return dx[i]; });
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const T a = zc_septic_coeff<F, false>(k, [&](int i) { return sx[i]; }, [&](int i) { return d2[i]; });
+            const T b = zc_septic_coeff<F, true>(k, [&](int i) { return dy[i]; }, [&](int i) { return dy[i]; });
+            sink(k, F::sub(a, b));
+        }
+        return;
+    }
+    T sy[7], dy[7], px[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        sy[i] = F::add(acc(7 + i, false), acc(21 + i, true));
+        dy[i] = F::sub(xy(7 + i, false), acc(7 + i, false));
+        px[i] = F::sub(acc(i, false), acc(14 + i, false));
+    }
+    const T r = real();
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const T u = zc_septic_coeff<F, false>(k, [&](int i) { return sy[i]; }, [&](int i) { return dx[i]; });
+        const T v = zc_septic_coeff<F, false>(k, [&](int i) { return dy[i]; }, [&](int i) { return px[i]; });
+        sink(7 + k, F::mul(r, F::sub(u, v)));
+    }
+}
+
 }  // namespace sp1hip

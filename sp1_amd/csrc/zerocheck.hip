@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
     const uint32_t bid = block_base + blockIdx.x / 3u;
     const int pass = (int)(blockIdx.x % 3u), t = 2 * pass;
     const ZcDesc d = zc_find_desc(descs, n_descs, bid);
-    const uint32_t q = (d.flags >> 8) & 15u, base_col = d.pad;
+    const uint32_t q = (d.flags >> 8) & 15u, kind = (d.flags >> 12) & 15u, base_col = d.pad;
     const auto* rc = (const p2::RoundConstants __attribute__((address_space(4)))*)(uintptr_t)rc_p;    // wave-uniform: scalar loads
     __syncthreads();
     const uint32_t terms = (d.rows + 1) / 2;
@@ -347,13 +347,17 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
         kb::Ext va = kb::ext_zero(), vb = kb::ext_zero();
-        auto ld = [&](uint32_t c, bool owned) -> T {
-            const T v = leaf<FIRST>(d.main, base_col + c, d.rows, i, t);
-            if (gkr && owned) vb = kb::ext_add(vb, K::scale(load_ext_aos(d.gkr_pows, base_col + c), v));
+        auto ld_at = [&](uint32_t col, bool owned) -> T {
+            const T v = leaf<FIRST>(d.main, col, d.rows, i, t);
+            if (gkr && owned) vb = kb::ext_add(vb, K::scale(load_ext_aos(d.gkr_pows, col), v));
             return v;
         };
+        auto ld = [&](uint32_t c, bool owned) -> T { return ld_at(base_col + c, owned); };
         auto sink = [&](uint32_t j, const T& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
-        zc_p2_piece<F>(q, rc, ld, sink);
+        if (kind == ZC_HINT_POSEIDON2) zc_p2_piece<F>(q, rc, ld, sink);
+        else if (kind == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);
+        else zc_septic_sum_piece<F>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); },
+                                    [&]() -> T { return ld_at(d.aux1, false); }, sink);
         sa = kb::ext_add(sa, kb::ext_mul(va, e));
         sb = kb::ext_add(sb, kb::ext_mul(vb, e));
     }
@@ -544,7 +548,17 @@ struct DevBuf {
     uint32_t* u32() const { return (uint32_t*)p; }
 };
 
-struct ZcMacro { uint32_t kind, base_col, first_constraint; };   // a hinted sub-AIR: its constraints are [first, first + 163)
+struct ZcMacro {                 // a hinted sub-AIR: its constraints are [first_constraint, first_constraint + n_constraints())
+    uint32_t kind, base_col, first_constraint, aux0 = 0, aux1 = 0;
+    uint32_t n_constraints() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
+    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 1u : 2u; }
+    // the columns whose GKR-opening term the fused pieces carry: [lo, lo + n)
+    void owned(uint32_t* lo, uint32_t* n) const {
+        if (kind == ZC_HINT_POSEIDON2) { *lo = base_col; *n = ZC_P2_COLUMNS; }
+        else if (kind == ZC_HINT_SEPTIC_CURVE) { *lo = base_col; *n = 14; }
+        else { *lo = aux0; *n = 28; }
+    }
+};
 
 struct Chunk {
     std::vector<uint32_t> prog;   // allocated [n][4]
@@ -924,8 +938,11 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
     // reads get TOUCH pseudo-instructions in extra chunks
     std::vector<bool> seen_m(main_w, false), seen_p(prep_w, false);
     if (macros)                                    // the fused pieces of a hinted sub-AIR carry the GKR term of its columns themselves
-        for (const ZcMacro& m : *macros)
-            for (uint32_t c = 0; c < ZC_P2_COLUMNS; c++) seen_m[m.base_col + c] = true;
+        for (const ZcMacro& m : *macros) {
+            uint32_t lo, cnt;
+            m.owned(&lo, &cnt);
+            for (uint32_t c = 0; c < cnt; c++) seen_m[lo + c] = true;
+        }
     for (auto& c : *out)
         for (size_t k = 0; k < c.prog.size() / 4; k++) {
             uint32_t* o = c.prog.data() + 4 * k;
@@ -997,6 +1014,21 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
     return acc;
 }
 
+// host model of the fused pieces on ONE row of base-field words (the planner's check of a hint, sp1hip_zerocheck_plan_eval)
+template <class Sink>
+static void macro_eval_row(const ZcMacro& m, const uint32_t* main_row, Sink&& sink) {
+    static const p2::RoundConstants host_rc = p2::make_round_constants();
+    for (uint32_t q = 0; q < m.n_pieces(); q++) {
+        if (m.kind == ZC_HINT_POSEIDON2)
+            zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
+        else if (m.kind == ZC_HINT_SEPTIC_CURVE)
+            zc_septic_curve_piece<P2Base>([&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
+        else
+            zc_septic_sum_piece<P2Base>(q, [&](uint32_t c, bool) { return main_row[m.base_col + c]; },
+                                        [&](uint32_t c, bool) { return main_row[m.aux0 + c]; }, [&]() { return main_row[m.aux1]; }, sink);
+    }
+}
+
 static uint32_t asserts_total(const uint32_t* program, uint32_t n) {
     uint32_t a = 0;
     for (uint32_t k = 0; k < n; k++) a += program[3 * k] == ZC_ASSERT_ZERO;
@@ -1035,9 +1067,13 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
             for (uint32_t k = 0; k < n_instr; k++) {
                 if (clean[3 * k] == ZC_ASSERT_ZERO) asserts_before++;
                 if (clean[3 * k] != ZC_HINT) continue;
-                SP1HIP_REQUIRE(clean[3 * k + 1] == ZC_HINT_POSEIDON2, "unknown hint kind in constraint program");
-                SP1HIP_REQUIRE((uint64_t)clean[3 * k + 2] + ZC_P2_COLUMNS <= main_width, "Poseidon2 hint: columns out of range");
-                np->macros.push_back(ZcMacro{ZC_HINT_POSEIDON2, clean[3 * k + 2], asserts_before});
+                const uint32_t kind = clean[3 * k + 1] & 0xffu, w1 = clean[3 * k + 1] >> 8, w2 = clean[3 * k + 2];
+                SP1HIP_REQUIRE(kind >= ZC_HINT_POSEIDON2 && kind <= ZC_HINT_SEPTIC_SUM, "unknown hint kind in constraint program");
+                ZcMacro m{kind, kind == ZC_HINT_SEPTIC_SUM ? (w2 & 0xffffu) : w2, asserts_before};
+                if (kind == ZC_HINT_SEPTIC_SUM) { m.aux0 = w2 >> 16; m.aux1 = w1; }
+                SP1HIP_REQUIRE((uint64_t)m.base_col + (kind == ZC_HINT_POSEIDON2 ? ZC_P2_COLUMNS : 14u) <= main_width &&
+                               (kind != ZC_HINT_SEPTIC_SUM || ((uint64_t)m.aux0 + 28 <= main_width && m.aux1 < main_width)), "hint: columns out of range");
+                np->macros.push_back(m);
                 clean[3 * k] = ZC_CONST; clean[3 * k + 1] = 0; clean[3 * k + 2] = 0;
             }
             static const bool macros_enabled = [] { const char* e = getenv("SP1HIP_ZC_MACRO"); return !(e && e[0] == '0'); }();
@@ -1045,7 +1081,7 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         }
         program = clean.data();
         auto hinted = [&](uint32_t idx) {
-            for (const ZcMacro& m : np->macros) if (idx >= m.first_constraint && idx < m.first_constraint + ZC_P2_CONSTRAINTS) return true;
+            for (const ZcMacro& m : np->macros) if (idx >= m.first_constraint && idx < m.first_constraint + m.n_constraints()) return true;
             return false;
         };
         auto drop_hinted = [&](std::vector<uint32_t>& sch) {      // asserts carry their constraint index in operand b by now
@@ -1100,14 +1136,15 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
             std::vector<uint32_t> pub(n_pub, 0u);
             eval_words_row(np->prog.data(), np->prog.size() / 4, np->n_regs, row.data(), prow.data(), pub.data(),
                            [&](uint32_t idx, uint32_t v) { if (idx < want.size()) want[idx] = v; });
-            static const p2::RoundConstants host_rc = p2::make_round_constants();
-            for (const ZcMacro& m : np->macros)
-                for (uint32_t q = 0; q < ZC_P2_PIECES; q++) {
-                    bool ok = true;
-                    zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return row[m.base_col + c]; },
-                                        [&](uint32_t j, uint32_t v) { ok &= (m.first_constraint + j < want.size() && want[m.first_constraint + j] == v); });
-                    SP1HIP_REQUIRE(ok, "Poseidon2 hint does not match the constraints it annotates");
-                }
+            for (const ZcMacro& m : np->macros) {
+                bool ok = true;
+                uint32_t n_seen = 0;
+                macro_eval_row(m, row.data(), [&](uint32_t j, uint32_t v) {
+                    n_seen++;
+                    ok &= (m.first_constraint + j < want.size() && want[m.first_constraint + j] == v);
+                });
+                SP1HIP_REQUIRE(ok && n_seen == m.n_constraints(), "a fused-kernel hint does not match the constraints it annotates");
+            }
         }
         plan = np;
         std::lock_guard<std::mutex> lk(plan_mutex);
@@ -1449,13 +1486,13 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
             ZcChipRange rg{total_blocks, 0, terms - 1, 0};
             for (const ZcMacro& m : c.macros)
-                for (uint32_t q = 0; q < ZC_P2_PIECES; q++) {
+                for (uint32_t q = 0; q < m.n_pieces(); q++) {
                     ZcDesc d{};
                     d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
                     d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
                     d.block_start = total_blocks; d.n_blocks = blocks;
-                    d.alpha_off = m.first_constraint; d.flags = ZC_DESC_MACRO | (q << 8);
-                    d.block_pairs = 256; d.pad = m.base_col;
+                    d.alpha_off = m.first_constraint; d.flags = ZC_DESC_MACRO | (q << 8) | (m.kind << 12);
+                    d.block_pairs = 256; d.pad = m.base_col; d.aux0 = m.aux0; d.aux1 = m.aux1;
                     total_blocks += blocks;
                     descs.push_back(d);
                 }
@@ -1773,13 +1810,10 @@ extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_in
         }
     }
     if (form != 0) {                                  // the forms the GPU runs: hinted constraints come from the fused pieces
-        static const p2::RoundConstants host_rc = p2::make_round_constants();
-        for (const ZcMacro& m : plan->macros)
-            for (uint32_t q = 0; q < ZC_P2_PIECES; q++) {
-                zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return main_row[m.base_col + c]; },
-                                    [&](uint32_t j, uint32_t v) { on_assert(m.first_constraint + j, v); });
-                pieces++;
-            }
+        for (const ZcMacro& m : plan->macros) {
+            macro_eval_row(m, main_row, [&](uint32_t j, uint32_t v) { on_assert(m.first_constraint + j, v); });
+            pieces += m.n_pieces();
+        }
     }
     for (uint32_t k = 0; k < n_constraints; k++) SP1HIP_REQUIRE(seen[k] == 1, "a constraint was not evaluated exactly once");
     if (out_stats) { out_stats[0] = words; out_stats[1] = pieces; out_stats[2] = regs; }

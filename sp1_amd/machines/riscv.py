@@ -1114,6 +1114,7 @@ def global_chip(form=None):
             fresh = lambda col: _xy[col] if col in _xy else _f0(col)
         for i in range(7):
             b.when(L.is_real).assert_eq(fresh(xc + i), fresh(base + P2_OUT(i)))
+        b.air.hint_septic_curve(xc)
         y2 = septic_product_coeffs(b, lambda i: fresh(yc + i), None, square=True)
         x2 = septic_product_coeffs(b, lambda i: fresh(xc + i), None, square=True)
         x3 = septic_product_coeffs(b, lambda i: x2[i], lambda j: fresh(xc + j))
@@ -1142,6 +1143,7 @@ def global_chip(form=None):
         b.assert_all_eq(checker_x, [0] * 7)
         b.when(L.is_real).assert_all_eq(checker_y, [0] * 7)
     else:
+        b.air.hint_septic_sum(xc, ac["initial_digest_x"], c.names["is_real"])
         dxf = lambda i: fresh(xc + i) - fresh(ac["initial_digest_x"] + i)
         dyf = lambda i: fresh(yc + i) - fresh(ac["initial_digest_y"] + i)
         sxf = lambda i: (fresh(ac["initial_digest_x"] + i) + fresh(xc + i)) + fresh(ac["cumulative_sum_x"] + i)
