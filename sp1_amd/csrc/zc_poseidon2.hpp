@@ -124,11 +124,15 @@ KB_HD void zc_p2_piece(uint32_t q, const RC* rc, Load&& ld, Sink&& sink) {
 //                                        p1 = (acc .. acc+13), p2 = (xy .. xy+13), p3 = (acc+14 .. acc+27)
 constexpr uint32_t ZC_HINT_SEPTIC_CURVE = 2, ZC_HINT_SEPTIC_SUM = 3;
 
-// coefficient k of a b (square: a a, by symmetry) — one coefficient at a time keeps the live set small (one accumulator)
-template <class F, bool SQUARE, class A, class B>
-KB_HD typename F::T zc_septic_coeff(int k, A&& a, B&& b) {
+// res = a b in F_p^7 (SQUARE: a a with the symmetric products doubled): the 13 group sums T_s = sum_{i + j = s} a_i b_j are
+// formed one after the other and folded into the 7 result coefficients at once (z^7 = 3 z + 5: T_s -> 5 res[s - 7] + 3 res[s - 6]),
+// every index a compile-time constant: two operands, one result and one group sum are live, nothing is computed twice.
+template <class F, bool SQUARE>
+KB_HD void zc_septic_mul(const typename F::T* a, const typename F::T* b, typename F::T* res) {
     using T = typename F::T;
-    auto group = [&](int s_) {                    // T_s = sum_{i + j = s} a_i b_j
+    const uint32_t c5 = kb::to_monty(5), c3 = kb::to_monty(3);
+#pragma unroll
+    for (int s_ = 0; s_ < 13; s_++) {
         T acc{};
         bool first = true;
 #pragma unroll
@@ -136,76 +140,75 @@ KB_HD typename F::T zc_septic_coeff(int k, A&& a, B&& b) {
             const int j = s_ - i;
             if (j < 0 || j > 6) continue;
             if (SQUARE && i > j) continue;
-            T t = F::mul(a(i), SQUARE ? a(j) : b(j));
+            T t = F::mul(a[i], SQUARE ? a[j] : b[j]);
             if (SQUARE && i < j) t = F::add(t, t);
             acc = first ? t : F::add(acc, t);
             first = false;
         }
-        return acc;
-    };
-    T r = group(k);
-    if (k + 7 <= 12) r = F::add(r, F::mulc(group(k + 7), kb::to_monty(5)));
-    if (k >= 1) r = F::add(r, F::mulc(group(k + 6), kb::to_monty(3)));
-    return r;
+        if (s_ < 7) res[s_] = acc;
+        else {
+            res[s_ - 7] = F::add(res[s_ - 7], F::mulc(acc, c5));
+            res[s_ - 6] = F::add(res[s_ - 6], F::mulc(acc, c3));
+        }
+    }
 }
 
 // piece 0 of kind 2: the curve equation. ld(column relative to xy, owned).
 template <class F, class Load, class Sink>
 KB_HD void zc_septic_curve_piece(Load&& ld, Sink&& sink) {
     using T = typename F::T;
-    T x[7], y[7], x2[7];
+    T x[7], t[7], u[7];
 #pragma unroll
-    for (int i = 0; i < 7; i++) { x[i] = ld(i, true); y[i] = ld(7 + i, true); }
-#pragma unroll
-    for (int k = 0; k < 7; k++) x2[k] = zc_septic_coeff<F, true>(k, [&](int i) { return x[i]; }, [&](int i) { return x[i]; });
+    for (int i = 0; i < 7; i++) x[i] = ld(i, true);
+    zc_septic_mul<F, true>(x, x, t);                      // x^2
+    zc_septic_mul<F, false>(t, x, u);                     // x^3
 #pragma unroll
     for (int k = 0; k < 7; k++) {
-        const T y2 = zc_septic_coeff<F, true>(k, [&](int i) { return y[i]; }, [&](int i) { return y[i]; });
-        T x3 = zc_septic_coeff<F, false>(k, [&](int i) { return x2[i]; }, [&](int i) { return x[i]; });
-        x3 = F::add(x3, F::mulc(x[k], kb::to_monty(45)));
-        if (k == 3) x3 = F::addc(x3, kb::to_monty(41));
-        sink(k, F::sub(y2, x3));
+        u[k] = F::add(u[k], F::mulc(x[k], kb::to_monty(45)));
+        x[k] = ld(7 + k, true);                           // y takes x's registers
     }
+    u[3] = F::addc(u[3], kb::to_monty(41));
+    zc_septic_mul<F, true>(x, x, t);                      // y^2
+#pragma unroll
+    for (int k = 0; k < 7; k++) sink(k, F::sub(t[k], u[k]));
 }
 
 // pieces of kind 3: q = 0: sum_checker_x, q = 1: is_real * sum_checker_y. xy(col, owned) / acc(col, owned) / real().
 template <class F, class LoadXY, class LoadAcc, class Real, class Sink>
 KB_HD void zc_septic_sum_piece(uint32_t q, LoadXY&& xy, LoadAcc&& acc, Real&& real, Sink&& sink) {
     using T = typename F::T;
-    T dx[7];
+    T a[7], b[7], c[7];
+    if (q == 0) {                                         // (p1.x + p2.x + p3.x) (p2.x - p1.x)^2 - (p2.y - p1.y)^2
 #pragma unroll
-    for (int i = 0; i < 7; i++) dx[i] = F::sub(xy(i, false), acc(i, q == 0));
-    if (q == 0) {
-        T sx[7], dy[7], d2[7];
+        for (int i = 0; i < 7; i++) a[i] = F::sub(xy(i, false), acc(i, true));
+        zc_septic_mul<F, true>(a, a, b);                  // dx^2
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-            sx[i] = F::add(F::add(acc(i, false), xy(i, false)), acc(14 + i, true));
-            dy[i] = F::sub(xy(7 + i, false), acc(7 + i, true));
-        }
+        for (int i = 0; i < 7; i++) a[i] = F::add(F::add(acc(i, false), xy(i, false)), acc(14 + i, true));
+        zc_septic_mul<F, false>(a, b, c);
 #pragma unroll
-        for (int k = 0; k < 7; k++) d2[k] = zc_septic_coeff<F, true>(k, [&](int i) { return dx[i]; }, [&](int i) { return dx[i]; });
+        for (int i = 0; i < 7; i++) a[i] = F::sub(xy(7 + i, false), acc(7 + i, true));
+        zc_septic_mul<F, true>(a, a, b);                  // dy^2
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            const T a = zc_septic_coeff<F, false>(k, [&](int i) { return sx[i]; }, [&](int i) { return d2[i]; });
-            const T b = zc_septic_coeff<F, true>(k, [&](int i) { return dy[i]; }, [&](int i) { return dy[i]; });
-            sink(k, F::sub(a, b));
-        }
+        for (int k = 0; k < 7; k++) sink(k, F::sub(c[k], b[k]));
         return;
     }
-    T sy[7], dy[7], px[7];
+    // is_real ((p1.y + p3.y) (p2.x - p1.x) - (p2.y - p1.y) (p1.x - p3.x))
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        sy[i] = F::add(acc(7 + i, false), acc(21 + i, true));
-        dy[i] = F::sub(xy(7 + i, false), acc(7 + i, false));
-        px[i] = F::sub(acc(i, false), acc(14 + i, false));
+        a[i] = F::add(acc(7 + i, false), acc(21 + i, true));
+        b[i] = F::sub(xy(i, false), acc(i, false));
     }
+    zc_septic_mul<F, false>(a, b, c);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        a[i] = F::sub(xy(7 + i, false), acc(7 + i, false));
+        b[i] = F::sub(acc(i, false), acc(14 + i, false));
+    }
+    T d[7];
+    zc_septic_mul<F, false>(a, b, d);
     const T r = real();
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const T u = zc_septic_coeff<F, false>(k, [&](int i) { return sy[i]; }, [&](int i) { return dx[i]; });
-        const T v = zc_septic_coeff<F, false>(k, [&](int i) { return dy[i]; }, [&](int i) { return px[i]; });
-        sink(7 + k, F::mul(r, F::sub(u, v)));
-    }
+    for (int k = 0; k < 7; k++) sink(7 + k, F::mul(r, F::sub(c[k], d[k])));
 }
 
 }  // namespace sp1hip

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
 // its first main column. Every column of the permutation is loaded exactly once per piece; the loads a piece OWNS carry the
 // GKR-opening batching term, so the interpreter's pieces never touch those columns for it (the planner pre-marks them).
 constexpr uint32_t ZC_DESC_MACRO = 2u;
-template <bool FIRST>
+template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
                                                        uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
                                                        const p2::RoundConstants* __restrict__ rc_p) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
     const uint32_t bid = block_base + blockIdx.x / 3u;
     const int pass = (int)(blockIdx.x % 3u), t = 2 * pass;
     const ZcDesc d = zc_find_desc(descs, n_descs, bid);
-    const uint32_t q = (d.flags >> 8) & 15u, kind = (d.flags >> 12) & 15u, base_col = d.pad;
+    const uint32_t q = (d.flags >> 8) & 15u, base_col = d.pad;       // (every descriptor of this launch has kind KIND)
     const auto* rc = (const p2::RoundConstants __attribute__((address_space(4)))*)(uintptr_t)rc_p;    // wave-uniform: scalar loads
     __syncthreads();
     const uint32_t terms = (d.rows + 1) / 2;
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
         };
         auto ld = [&](uint32_t c, bool owned) -> T { return ld_at(base_col + c, owned); };
         auto sink = [&](uint32_t j, const T& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
-        if (kind == ZC_HINT_POSEIDON2) zc_p2_piece<F>(q, rc, ld, sink);
-        else if (kind == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);
+        if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<F>(q, rc, ld, sink);
+        else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);
         else zc_septic_sum_piece<F>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); },
                                     [&]() -> T { return ld_at(d.aux1, false); }, sink);
         sa = kb::ext_add(sa, kb::ext_mul(va, e));
@@ -1359,14 +1359,14 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> point;   // [alpha_last, ..., alpha_first]
     std::vector<Ext> round_claims = claims;
     std::vector<std::array<uint32_t, 16>> sums(n_chips);
-    std::vector<uint32_t> h_sums((size_t)n_chips * 32);      // up to two reduction ranges per chip (interpreter + fused pieces)
+    std::vector<uint32_t> h_sums((size_t)n_chips * 64);      // up to four reduction ranges per chip (interpreter + one per kind of fused piece)
     DevBuf d_descs, d_partial, d_sums;       // d_descs: the round's descriptors [ZcDesc.. | ZcChipRange.. | ZcFixDesc..]
     size_t partial_cap = 0, descs_cap = 0;
     std::vector<std::unique_ptr<std::vector<ZcDesc>>> keep_descs;
     std::vector<std::unique_ptr<std::vector<ZcChipRange>>> keep_ranges;
     std::vector<std::unique_ptr<std::vector<ZcFixDesc>>> keep_fds;
     std::vector<std::unique_ptr<std::vector<uint8_t>>> keep_packs;
-    SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 128, s));
+    SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 256, s));
     // The folded extension tables of all chips live in two ping-pong buffers sized once (round r writes half r & 1;
     // every round's tables are half the size of the previous round's): no allocation inside the round loop — it used to
     // be ~66 arena calls per round.
@@ -1477,30 +1477,35 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             g.n_blocks = total_blocks - g.block_lo;
         }
-        // the fused pieces of hinted sub-AIRs: their own block range (and reduction range) per chip, one launch for all of them
-        const uint32_t macro_block_lo = total_blocks;
-        for (int i = 0; i < n_chips; i++) {
-            ChipState& c = *st[i];
-            if (c.rows == 0 || c.macros.empty()) continue;
-            const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
-            const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
-            ZcChipRange rg{total_blocks, 0, terms - 1, 0};
-            for (const ZcMacro& m : c.macros)
-                for (uint32_t q = 0; q < m.n_pieces(); q++) {
-                    ZcDesc d{};
-                    d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
-                    d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
-                    d.block_start = total_blocks; d.n_blocks = blocks;
-                    d.alpha_off = m.first_constraint; d.flags = ZC_DESC_MACRO | (q << 8) | (m.kind << 12);
-                    d.block_pairs = 256; d.pad = m.base_col; d.aux0 = m.aux0; d.aux1 = m.aux1;
-                    total_blocks += blocks;
-                    descs.push_back(d);
+        // the fused pieces of hinted sub-AIRs: one launch per kind (each kind is its own kernel with its own register budget),
+        // one block range — and one reduction range — per (kind, chip)
+        uint32_t macro_lo[4] = {0, 0, 0, 0}, macro_n[4] = {0, 0, 0, 0};
+        for (uint32_t kind = ZC_HINT_POSEIDON2; kind <= ZC_HINT_SEPTIC_SUM; kind++) {
+            macro_lo[kind] = total_blocks;
+            for (int i = 0; i < n_chips; i++) {
+                ChipState& c = *st[i];
+                if (c.rows == 0) continue;
+                const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
+                const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
+                ZcChipRange rg{total_blocks, 0, terms - 1, 0};
+                for (const ZcMacro& m : c.macros) {
+                    if (m.kind != kind) continue;
+                    for (uint32_t q = 0; q < m.n_pieces(); q++) {
+                        ZcDesc d{};
+                        d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+                        d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
+                        d.block_start = total_blocks; d.n_blocks = blocks;
+                        d.alpha_off = m.first_constraint; d.flags = ZC_DESC_MACRO | (q << 8) | (m.kind << 12);
+                        d.block_pairs = 256; d.pad = m.base_col; d.aux0 = m.aux0; d.aux1 = m.aux1;
+                        total_blocks += blocks;
+                        descs.push_back(d);
+                    }
                 }
-            rg.n_blocks = total_blocks - rg.block_start;
-            ranges.push_back(rg);
-            desc_chip.push_back(i);
+                rg.n_blocks = total_blocks - rg.block_start;
+                if (rg.n_blocks) { ranges.push_back(rg); desc_chip.push_back(i); }
+            }
+            macro_n[kind] = total_blocks - macro_lo[kind];
         }
-        const uint32_t macro_blocks = total_blocks - macro_block_lo;
         const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
         // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
         // it now, so that every descriptor of the round goes up in ONE copy
@@ -1566,12 +1571,21 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
                 else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
             }
-            if (macro_blocks) {
+            if (macro_n[1] | macro_n[2] | macro_n[3]) {
                 const DeviceCtx* dctx;
                 SP1HIP_TRY(get_device_ctx(&dctx));
-                if (r == 0) hipLaunchKernelGGL(zc_macro_kernel<true>, dim3(macro_blocks * 3), dim3(256), 0, s, (const ZcDesc*)d_descs.p, n_descs, d_eq.u32(), 1u << (nv - 1), d_partial.u32(), macro_block_lo, dctx->d_rc);
-                else hipLaunchKernelGGL(zc_macro_kernel<false>, dim3(macro_blocks * 3), dim3(256), 0, s, (const ZcDesc*)d_descs.p, n_descs, d_eq.u32(), 1u << (nv - 1), d_partial.u32(), macro_block_lo, dctx->d_rc);
-                SP1HIP_LAUNCH_CHECK();
+                const ZcDesc* dd = (const ZcDesc*)d_descs.p;
+                const uint32_t eq_len = 1u << (nv - 1);
+#define SP1HIP_ZC_MACRO_LAUNCH(KIND)                                                                                                   \
+                if (macro_n[KIND]) {                                                                                                   \
+                    if (r == 0) hipLaunchKernelGGL((zc_macro_kernel<true, KIND>), dim3(macro_n[KIND] * 3), dim3(256), 0, s, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[KIND], dctx->d_rc); \
+                    else hipLaunchKernelGGL((zc_macro_kernel<false, KIND>), dim3(macro_n[KIND] * 3), dim3(256), 0, s, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[KIND], dctx->d_rc); \
+                    SP1HIP_LAUNCH_CHECK();                                                                                             \
+                }
+                SP1HIP_ZC_MACRO_LAUNCH(1u)
+                SP1HIP_ZC_MACRO_LAUNCH(2u)
+                SP1HIP_ZC_MACRO_LAUNCH(3u)
+#undef SP1HIP_ZC_MACRO_LAUNCH
             }
             // the reduce kernel publishes the round's sums itself (ticket on the round-sync counters, payload in the mailbox slot)
             const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
