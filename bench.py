@@ -422,6 +422,7 @@ def main():
         torch.cuda.synchronize()
     api.check(lib.sp1hip_timers_reset())
     api.check(lib.sp1hip_timers_enable(1))
+    cpu0 = time.process_time()                               # user + system time of every thread of this process
     t0 = time.perf_counter()
     proof = None
     for _ in range(args.steps):
@@ -431,6 +432,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host_cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
     api.check(lib.sp1hip_timers_enable(0))
     tl = {name: timers_read(api, name) for name in TIMERS}
     dt = shards.max_over_ranks(dt)                 # shards are striped one per rank: no data-path collective
@@ -557,7 +559,7 @@ def main():
             "core_real_chips": ({"real_chips": meta["real_chips"], "synthetic_chips": meta["synthetic_chips"],
                                  "real_area_cells": meta["real_area_cells"], "ms_per_proof": ms_per_step,
                                  "zerocheck_round_ms": ms.get("zerocheck_round"), "per_chip": meta["per_chip"]} if kind == "real" else None),
-            "host_threads": lib.sp1hip_host_threads(),
+            "host_threads": lib.sp1hip_host_threads(), "host_cpu_ms_per_proof": host_cpu_ms,
             "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},
             "real_machine": extras.get("real_machine"),
             "synthetic_core_shaped": extras.get("synthetic_core_shaped"),

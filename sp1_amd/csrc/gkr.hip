@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ des
         // acknowledged (vmcnt) are visible to the host, and the ticket orders the last workgroup's store behind everybody's.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0 && rs_ticket_is_last(rs.counter, blockIdx.x, gridDim.x)) rs.host_slot[0] = seq;
+        if (threadIdx.x == 0 && rs_ticket_is_last_acq_rel(rs.counter, blockIdx.x, gridDim.x)) rs_publish_seq(rs.host_slot, seq);
     }
 }
 

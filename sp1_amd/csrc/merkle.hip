@@ -270,7 +270,8 @@ __global__ __launch_bounds__(1024) void compress_top_kernel(uint32_t* layer, uin
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) publish_slot[0] = publish_seq;
+    // (only wave 0 is left here: its payload stores are acknowledged — vmcnt counts the whole wave — then ONE release store)
+    if (threadIdx.x == 0) __hip_atomic_store(const_cast<uint32_t*>(publish_slot), publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <bool INTEGER_FORM>

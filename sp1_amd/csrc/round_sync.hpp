@@ -56,6 +56,26 @@ __device__ __forceinline__ bool rs_ticket_is_last(uint32_t* counter, uint32_t bl
     __hip_atomic_store(c2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
+// The same ticket for kernels whose workgroups write their PAYLOAD straight into the host slot (zc_reduce_kernel, the last fold
+// of a LogUp-GKR layer) and let the last arrival publish the sequence number: here the workgroup that writes `seq` is not the
+// one that wrote the payload, so the hand-over is a release by every producer and an acquire by the publisher in the HIP memory
+// model — the ticket is an acq_rel read-modify-write and `seq` a system-scope release store. These launches have a
+// few dozen workgroups per round, so the per-workgroup L2 write-back that rs_finish avoids (thousands of workgroups) costs
+// nothing measurable here.
+__device__ __forceinline__ bool rs_ticket_is_last_acq_rel(uint32_t* counter, uint32_t block_linear, uint32_t total_blocks) {
+    const uint32_t g = block_linear % RS_GROUPS, members = (total_blocks - g + RS_GROUPS - 1) / RS_GROUPS;
+    uint32_t* cg = counter + g * RS_GROUP_STRIDE;
+    if (__hip_atomic_fetch_add(cg, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+    __hip_atomic_store(cg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* c2 = counter + RS_GROUPS * RS_GROUP_STRIDE;
+    const uint32_t groups = total_blocks < RS_GROUPS ? total_blocks : RS_GROUPS;
+    if (__hip_atomic_fetch_add(c2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != groups - 1) return false;
+    __hip_atomic_store(c2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+__device__ __forceinline__ void rs_publish_seq(volatile uint32_t* slot, uint32_t seq) {
+    __hip_atomic_store(const_cast<uint32_t*>(slot), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void rs_store_partial(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ kb::Ext rs_load_partial(const uint32_t* q) {
     kb::Ext e;

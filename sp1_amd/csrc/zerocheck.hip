@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __res
     if (rs.host_slot == nullptr) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 && rs_ticket_is_last(rs.counter, blockIdx.x, gridDim.x)) rs.host_slot[0] = seq;
+    if (threadIdx.x == 0 && rs_ticket_is_last_acq_rel(rs.counter, blockIdx.x, gridDim.x)) rs_publish_seq(rs.host_slot, seq);
 }
 
 // out[i][c] = x + alpha (y - x), x = row 2i, y = row 2i + 1 (zero beyond the real rows); out is an ext table.

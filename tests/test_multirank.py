@@ -46,11 +46,12 @@ def _worker(rank, world, port, n_shards, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_shards", [7, 1, 0])
-def test_striping_and_blob_exchange_gloo(n_shards):
+@pytest.mark.parametrize("world,n_shards", [(2, 7), (2, 1), (2, 0), (8, 19), (8, 5)])
+def test_striping_and_blob_exchange_gloo(world, n_shards):
+    """world 8 = BASELINE's node (configs 4 and 5): striping with more ranks than shards (8 ranks, 5 shards) included."""
     import __graft_entry__ as g
     g.build_hip()
-    world, port = 2, 29500 + (os.getpid() % 2000) + n_shards
+    port = 29500 + (os.getpid() % 2000) + n_shards + 37 * world
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_shards, q)) for r in range(world)]
@@ -66,7 +67,7 @@ def test_striping_and_blob_exchange_gloo(n_shards):
     for rank, mine, merged, t in results:
         assert mine == list(range(rank, n_shards, world))
         assert merged == want                                      # every rank ends with every proof blob
-        assert t == 2.0                                            # max over ranks
+        assert t == float(world)                                   # max over ranks of 1 + rank
 
 
 def _combine(kids):
@@ -86,7 +87,7 @@ def _tree_worker(rank, world, port, n_shards, arity, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_shards,arity", [(2, 7, 2), (2, 8, 3), (3, 5, 2), (2, 1, 2)])
+@pytest.mark.parametrize("world,n_shards,arity", [(2, 7, 2), (2, 8, 3), (3, 5, 2), (2, 1, 2), (8, 21, 2), (8, 8, 3), (8, 3, 2)])
 def test_compress_tree_over_ranks_gloo(world, n_shards, arity):
     """The recursion-tree reduce step: point-to-point proof movement to the parent's rank, same root as one process."""
     import __graft_entry__ as g
