@@ -66,6 +66,31 @@ def test_riscv_shard_proof_matches_oracle(api, K, seed, clk0):
     assert orc.shard_verify(_shapes_only(machine), g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
 
 
+def test_riscv_shard_bytes_at_1_256_of_the_recorded_shape_match_the_oracle(api):
+    """whole-proof byte equality at 1/256 of the recorded core shard (the bench's machine, the real Global chip
+    included, production parameters: blowup 4, 124 queries, 16-bit PoW) — the jagged-aware oracle proves it in a few seconds."""
+    import core_real
+    machine, tabs = core_real.machine_only(scale=1 / 256, seed=9, device="cuda")
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+            for a, i in machine]
+    dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+           for a, i in machine]
+    L, lsh, batch = 17, 14, 32
+    o_prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, 2)
+    commit, prep = api.JaggedProver(L, lsh, batch, 2).commit_multilinears([d[3] for d in dev if d[3] is not None])
+    assert np.array_equal(commit, o_prep.commit)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    o_ch.observe(commit)
+    g_ch.observe(commit)
+    orc.set_gkr_sparse(True)
+    try:
+        want = orc.shard_prove(host, np.zeros(0, np.uint32), o_prep, L, lsh, batch, o_ch, 2, 124, 16)
+    finally:
+        orc.set_gkr_sparse(False)
+    got = api.prove_shard(dev, [], prep, L, lsh, batch, g_ch)
+    assert got == want and np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_riscv_shard_at_a_sixty_fourth_of_the_recorded_shape_verifies(api):
     """Production parameters (blowup 4, 124 queries, 16-bit PoW); 1/64 of the recorded heights, the real Global chip
     included (the bench's shard). One wrong cell in the Bitwise table -> the verifier rejects; so does one wrong
