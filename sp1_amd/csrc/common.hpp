@@ -44,6 +44,18 @@ struct ScopedTimer {
     ~ScopedTimer() { if (idx >= 0) timer_end(idx, s); }
 };
 
+// roctx ranges around the stages of a proof (the reference's NvtxLayer, sp1-gpu/crates/tracing/src/tracer.rs): what
+// `rocprofv3 --marker-trace` shows next to the kernel trace. The marker library (librocprofiler-sdk-roctx, else libroctx64) is
+// looked up with dlopen the first time a range opens; without it — or with SP1HIP_ROCTX=0 — a range costs one branch.
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 // A side stream (and n_events reusable events) paired with the caller's stream (runtime.hip).
 int aux_stream_for(hipStream_t main, int n_events, hipStream_t* aux, hipEvent_t** events);
 

@@ -961,6 +961,12 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     const bool jg_timing = [] { const char* e = getenv("SP1HIP_JG_TIMING"); return e && e[0] == '1'; }();
     std::chrono::steady_clock::time_point jg_t[7];
     jg_t[0] = std::chrono::steady_clock::now();
+    struct StageMarks {                                   // roctx sub-ranges of the evaluation proof (rocprofv3 --marker-trace)
+        bool open = false;
+        void next(const char* name) { if (open) roctx_pop(); roctx_push(name); open = true; }
+        ~StageMarks() { if (open) roctx_pop(); }
+    } marks;
+    marks.next("jagged_setup");
     const int lsh = rounds[0]->log_stacking_height;
     SP1HIP_REQUIRE(lsh >= 1, "log_stacking_height must be at least 1");
     uint64_t total_cols = 0, total_area = 0, n_claims = 0;
@@ -1051,6 +1057,7 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
     const uint32_t T = segs.total;
 
     // ---- jagged sumcheck: log_m rounds
+    marks.next("jagged_sumcheck");
     Sumcheck sumcheck;
     sumcheck.claimed_sum = sumcheck_claim;
     std::vector<Ext> alphas;
@@ -1293,9 +1300,11 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
 
     // ---- jagged-eval proof
     jg_t[2] = std::chrono::steady_clock::now();
+    marks.next("jagged_eval");
     Sumcheck jagged_eval;
     SP1HIP_TRY(jagged_eval_prove(prefix, log_m, z_row, z_col, final_point, ch, sc, &jagged_eval));
     jg_t[3] = std::chrono::steady_clock::now();
+    marks.next("stacked_basefold_open");
 
     // ---- dense PCS: observe the claim, evaluate every stacked column at the stack point, BaseFold-open
     for (int k = 0; k < 4; k++) challenger_observe(ch, q_eval.c[k]);

@@ -2,6 +2,7 @@
 // per-device context. HIP-native equivalents of the reference's runtime shims
 // (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L16-L172): hipMallocAsync-backed allocation,
 // streams, events; no globals other than the per-device contexts.
+#include <dlfcn.h>
 #include <cstring>
 #include <algorithm>
 #include <cstdlib>
@@ -358,6 +359,30 @@ void pinned_stage_release(PinnedBlock b) {
 }  // namespace sp1hip
 
 using namespace sp1hip;
+
+namespace sp1hip {
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char* e = getenv("SP1HIP_ROCTX");
+        if (e && e[0] == '0') return;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const RoctxApi& roctx_api() { static const RoctxApi api; return api; }
+}  // namespace
+void roctx_push(const char* name) { const RoctxApi& a = roctx_api(); if (a.push) a.push(name); }
+void roctx_pop() { const RoctxApi& a = roctx_api(); if (a.pop) a.pop(); }
+}  // namespace sp1hip
 
 extern "C" {
 

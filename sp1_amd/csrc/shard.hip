@@ -104,6 +104,14 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     const bool sh_timing = [] { const char* e = getenv("SP1HIP_SHARD_TIMING"); return e && e[0] == '1'; }();
     std::chrono::steady_clock::time_point sh_t[6];
     sh_t[0] = std::chrono::steady_clock::now();
+    // roctx ranges per stage (rocprofv3 --marker-trace): one open range at a time, closed on every exit path
+    RoctxRange proof_range("sp1hip_prove_shard");
+    struct StageMarks {
+        bool open = false;
+        void next(const char* name) { if (open) roctx_pop(); roctx_push(name); open = true; }
+        ~StageMarks() { if (open) roctx_pop(); }
+    } marks;
+    marks.next("commit");
     sp1hip_challenger_t* ch = nullptr;
     SP1HIP_TRY(sp1hip_challenger_clone(challenger, &ch));
     struct ChGuard { sp1hip_challenger_t* c; ~ChGuard() { sp1hip_challenger_free(c); } } guard{ch};
@@ -127,6 +135,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     }
 
     sh_t[1] = std::chrono::steady_clock::now();
+    marks.next("logup_gkr");
     // ---- LogUp-GKR
     std::vector<uint8_t> gkr_blob(gkr_size);
     size_t glen = gkr_size;
@@ -161,6 +170,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         }
     }
     sh_t[2] = std::chrono::steady_clock::now();
+    marks.next("zerocheck");
     // ---- zerocheck
     const kb::Ext batching = challenger_sample_ext(ch), gkr_batch = challenger_sample_ext(ch);
     sp1hip_ext_t c_batching, c_gkr;
@@ -193,6 +203,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         }
     }
     sh_t[3] = std::chrono::steady_clock::now();
+    marks.next("evaluation_proof");
     // ---- jagged evaluation proof over [preprocessed round, main round]
     std::vector<kb::Ext> claims = prep_claims;
     claims.insert(claims.end(), main_claims.begin(), main_claims.end());
@@ -211,6 +222,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
 
     // ---- bincode(ShardProof)
     sh_t[4] = std::chrono::steady_clock::now();
+    marks.next("proof_bytes");
     std::vector<uint8_t> out;
     out.reserve(need - jag_size);
     put_u64(out, n_publics);
