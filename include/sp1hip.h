@@ -177,6 +177,19 @@ int sp1hip_gkr_host_simd_available(void);
 int sp1hip_gkr_host_round_sums(const uint32_t* tab, size_t stride, const uint32_t* eq, size_t eq_stride, size_t real_pairs, uint32_t* out24);
 int sp1hip_gkr_host_round_fold(const uint32_t* tab, uint32_t* out, size_t stride, size_t real_pairs, const uint32_t* alpha4);
 
+/* ---------------------------------------------------------------- the commit path over BabyBear (BASELINE config 2, "both fields")
+ * The second `IopCtx` of the reference (/root/reference/slop/crates/baby-bear/src/baby_bear_poseidon2.rs:L11-L55): p = 2^31 - 2^27 + 1,
+ * Montgomery words (R = 2^32), Poseidon2 width 16 with x^7, 8 + 13 rounds, same sponge / compression / commit_tensors and the same
+ * layouts as the KoalaBear entry points above. PARITY NOTE: the internal diffusion matrix is not restated in the reference tree
+ * (oracle/bb_commit.hpp). sp1hip_bb_commit_mles: d_codewords[k] receives the codeword of mle k (2^(lg_n + lg_blowup) x width,
+ * column-major), d_tree the (2^(lg + 1) - 1) digests leaf-first; synchronises the stream to return the commitment. */
+int sp1hip_bb_rs_encode_batch(uint32_t* d_out, const uint32_t* d_in, int lg_n, int lg_blowup, size_t n_cols, sp1hip_stream_t stream);
+int sp1hip_bb_merkle_commit(const sp1hip_tensor_t* tensors, int n_tensors, int lg_height, uint32_t* d_tree,
+                            uint32_t* d_root_and_commit, sp1hip_stream_t stream);
+int sp1hip_bb_commit_mles(const sp1hip_tensor_t* mles, int n_mles, int lg_n, int lg_blowup, uint32_t* const* d_codewords,
+                          uint32_t* d_tree, uint32_t h_commit[8], sp1hip_stream_t stream);
+int sp1hip_bb_poseidon2_permute(uint32_t* d_states, size_t n, sp1hip_stream_t stream);
+
 /* ---------------------------------------------------------------- BaseFold kernels (a13, a14)
  * batch: out[r] = sum_c coeff[c] * col_c[r] over all columns of all tensors (message order)
  *   (`FriCpuProver::batch`, /root/reference/slop/crates/basefold-prover/src/fri.rs:L31-L80).

@@ -19,6 +19,8 @@ static inline F* FP(uint32_t* p) { return reinterpret_cast<F*>(p); }
 static inline E load_e(const uint32_t* p) { E e; memcpy(&e, p, 16); return e; }
 static inline Digest load_d(const uint32_t* p) { Digest d; memcpy(&d, p, 32); return d; }
 
+#include "bb_commit.hpp"
+
 extern "C" {
 
 // ---- field ----------------------------------------------------------------------------------
@@ -531,5 +533,30 @@ int orc_shard_verify(int n, const char** names, const uint32_t** zc_progs, const
         return -1;
     }
 }
+
+// ---- BabyBear commit path (bb_commit.hpp): mles [n][w_k] row-major Montgomery words (R = 2^32 mod the BabyBear prime)
+// -> codewords (optional), the Merkle tree leaf-first (optional), commitment[8]
+void orc_bb_commit_mles(const uint32_t* const* mles, const int* widths, int n_mles, int log_n, int log_blowup, uint32_t* commit,
+                        uint32_t* const* codewords_out, uint32_t* tree_out) {
+    const size_t N = (size_t)1 << (log_n + log_blowup);
+    std::vector<std::vector<orcbb::F>> cw(n_mles);
+    std::vector<const orcbb::F*> ptrs;
+    std::vector<int> ws(widths, widths + n_mles);
+    for (int k = 0; k < n_mles; k++) {
+        cw[k].resize(N * (size_t)widths[k]);
+        orcbb::rs_encode(reinterpret_cast<const orcbb::F*>(mles[k]), log_n, widths[k], log_blowup, cw[k].data());
+        ptrs.push_back(cw[k].data());
+        if (codewords_out && codewords_out[k]) memcpy(codewords_out[k], cw[k].data(), cw[k].size() * 4);
+    }
+    std::vector<orcbb::Digest> tree;
+    orcbb::Digest c;
+    orcbb::merkle_commit(ptrs, ws, N, &tree, &c);
+    for (int i = 0; i < 8; i++) commit[i] = c.d[i].v;
+    if (tree_out) memcpy(tree_out, tree.data(), tree.size() * sizeof(orcbb::Digest));
+}
+void orc_bb_permute(uint32_t* states, size_t n) {
+    for (size_t i = 0; i < n; i++) orcbb::permute(reinterpret_cast<orcbb::F*>(states + 16 * i));
+}
+uint32_t orc_bb_two_adic_generator(int bits) { return orcbb::two_adic_generator(bits).canonical(); }
 
 }  // extern "C"

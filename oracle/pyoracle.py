@@ -123,6 +123,53 @@ def from_monty(x):
     return a
 
 
+BB_P = 0x78000001
+
+
+def bb_to_monty(x):
+    return ((np.asarray(x, dtype=np.uint64) << np.uint64(32)) % np.uint64(BB_P)).astype(np.uint32)
+
+
+def bb_from_monty(x):
+    return (np.asarray(x, dtype=np.uint64) * np.uint64(pow(1 << 32, -1, BB_P)) % np.uint64(BB_P)).astype(np.uint32)
+
+
+def bb_random_felts(shape, seed):
+    """The documented generator (SplitMix64(seed) -> x mod p) over BabyBear, Montgomery form."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return bb_to_monty((z % np.uint64(BB_P)).astype(np.uint32)).reshape(shape)
+
+
+def bb_commit_mles(mles, log_blowup, want_codewords=False, want_tree=False):
+    """BabyBear `commit_mles` (RS encode + Poseidon2 Merkle commitment) on the CPU oracle: (commit[8], codewords | None, tree | None)."""
+    mles = [_arr(m) for m in mles]
+    log_n = mles[0].shape[0].bit_length() - 1
+    N = 1 << (log_n + log_blowup)
+    widths = (C.c_int * len(mles))(*[m.shape[1] for m in mles])
+    commit = np.zeros(8, np.uint32)
+    cws = [np.zeros((N, m.shape[1]), np.uint32) for m in mles] if want_codewords else None
+    tree = np.zeros((2 * N - 1, 8), np.uint32) if want_tree else None
+    L = lib()
+    L.orc_bb_commit_mles.restype = None
+    L.orc_bb_commit_mles(_ptr_array(mles), widths, len(mles), log_n, log_blowup, _p(commit),
+                         _ptr_array(cws) if cws is not None else None, _p(tree) if tree is not None else None)
+    return commit, cws, tree
+
+
+def bb_permute(states):
+    s = np.ascontiguousarray(states, dtype=np.uint32).copy()
+    L = lib()
+    L.orc_bb_permute.restype = None
+    L.orc_bb_permute(_p(s), C.c_size_t(s.size // 16))
+    return s
+
+
 def random_felts(shape, seed):
     """SplitMix64(seed) stream reduced mod p, returned in Montgomery form."""
     n = int(np.prod(shape))

@@ -131,6 +131,10 @@ PROTOTYPES = [
     ("sp1hip_merkle_commit", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
     ("sp1hip_merkle_open", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("sp1hip_poseidon2_permute", None, [_vp, _sz, _vp]),
+    ("sp1hip_bb_rs_encode_batch", None, [_vp, _vp, _int, _int, _sz, _vp]),
+    ("sp1hip_bb_merkle_commit", None, [C.POINTER(Tensor), _int, _int, _vp, _vp, _vp]),
+    ("sp1hip_bb_commit_mles", None, [C.POINTER(Tensor), _int, _int, _int, C.POINTER(_vp), _vp, u32p, _vp]),
+    ("sp1hip_bb_poseidon2_permute", None, [_vp, _sz, _vp]),
     ("sp1hip_poseidon2_permute_integer_form", None, [_vp, _sz, _vp]),
     ("sp1hip_poseidon2_permute_host", None, [_vp, _sz, _int]),
     ("sp1hip_host_permutation_is_vectorised", None, []),

@@ -600,6 +600,27 @@ class ProvingKey:
             self.h = None
 
 
+def bb_commit_mles(mles, log_blowup, stream=None):
+    """BabyBear `commit_mles` (sp1hip_bb_commit_mles): mles = ColMajor tensors of equal height 2^lg_n holding BabyBear Montgomery
+    words. Returns (commitment [8] numpy, codewords [ColMajor], tree words as a device tensor [(2 N - 1) * 8])."""
+    lg_n = mles[0].height.bit_length() - 1
+    N = mles[0].height << log_blowup
+    arr = (Tensor * len(mles))(*[m.as_tensor_struct() for m in mles])
+    cws = [device_words(N * m.width) for m in mles]
+    ptrs = (C.c_void_p * len(mles))(*[c.data_ptr() for c in cws])
+    tree = device_words((2 * N - 1) * 8)
+    commit = np.zeros(8, np.uint32)
+    check(_L().sp1hip_bb_commit_mles(arr, len(mles), lg_n, log_blowup, ptrs, _dptr(tree), commit.ctypes.data_as(_lib.u32p), _stream_ptr(stream)))
+    return commit, [ColMajor(c, N, m.width) for c, m in zip(cws, mles)], tree
+
+
+def bb_poseidon2_permute(states, stream=None):
+    """[n, 16] numpy BabyBear Montgomery words -> permuted (sp1hip_bb_poseidon2_permute)."""
+    d = to_device(np.ascontiguousarray(states, dtype=np.uint32).reshape(-1))
+    check(_L().sp1hip_bb_poseidon2_permute(_dptr(d), d.numel() // 16, _stream_ptr(stream)))
+    return to_host(d, (d.numel() // 16, 16))
+
+
 class PinnedHost:
     """Pinned host words (sp1hip_malloc_host) holding one row-major table: what a host trace generator fills and
     `ProverPool.submit` uploads at full PCIe rate."""

@@ -178,3 +178,33 @@ def test_interleave_fixed_rate():
     assert len(got) == len(want)
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+def test_babybear_oracle_field_ntt_and_commit_conventions():
+    """The BabyBear oracle (oracle/bb_commit.hpp): published field constants (two-adic generator of order 2^27 = 440564289), the
+    RS encode is the DFT of the zero-padded coefficients in bit-reversed order (checked against a naive evaluation), and the
+    commitment chain is compress(root, hash([log_height, total_width])) over a leaf-first tree."""
+    import ctypes as C
+    lib = orc.lib()
+    lib.orc_bb_two_adic_generator.restype = C.c_uint32
+    P = orc.BB_P
+    assert P == (1 << 31) - (1 << 27) + 1 and lib.orc_bb_two_adic_generator(27) == 440564289
+    g = lib.orc_bb_two_adic_generator(7)
+    assert pow(g, 128, P) == 1 and pow(g, 64, P) != 1
+    ms = [orc.bb_random_felts((64, 5), 1), orc.bb_random_felts((64, 3), 2)]
+    commit, cws, tree = orc.bb_commit_mles(ms, 1, True, True)
+    co = orc.bb_from_monty(ms[1][:, 2]).astype(object)
+    cw = orc.bb_from_monty(cws[1][:, 2])
+    rev = lambda x: int(format(x, "07b")[::-1], 2)
+    for j in range(0, 128, 5):
+        assert sum(int(co[i]) * pow(g, (rev(j) * i) % 128, P) for i in range(64)) % P == int(cw[j])
+    # leaf 3 = sponge over row 3 of both codewords; parents = compress; commitment = compress(root, hash([7, 8]))
+    perm = lambda s: orc.bb_permute(np.array(s, np.uint32).reshape(1, 16))[0]
+    row = list(cws[0][3]) + list(cws[1][3])
+    st = perm(row[:8] + [0] * 8)
+    assert np.array_equal(st[:8], tree[3])
+    assert np.array_equal(perm(list(tree[0]) + list(tree[1]))[:8], tree[128])
+    meta = perm(list(orc.bb_to_monty(np.array([7, 8], np.uint32))) + [0] * 14)[:8]
+    assert np.array_equal(perm(list(tree[-1]) + list(meta))[:8], commit)
+    # the zero state is not a fixed point and the permutation is not KoalaBear's
+    assert orc.bb_permute(np.zeros((1, 16), np.uint32)).any()
