@@ -10,6 +10,7 @@ python - "$out" <<PY
 import csv, glob, sys, collections
 rows = list(csv.DictReader(open(glob.glob("/tmp/prof_gap/*kernel_trace.csv")[0])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]) for r in rows)
+meta = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): (int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), r.get("Queue_Id", "?")) for r in rows}
 # proofs start with the first ntt pass after a jagged/basefold tail: find starts of 'first_layer_kernel' and cut one proof = [previous commit start, next commit start)
 starts = [i for i, e in enumerate(ev) if "first_layer_kernel" in e[2]]
 # the last proof's kernels: from the first kernel after the previous proof's last kernel... approximate: between midpoint marks
@@ -44,5 +45,12 @@ with open(sys.argv[1], "w") as o:
     o.write("largest single gaps (us | at ms | kernels before -> kernels after):\\n")
     for g, at, a, b in sorted(singles, reverse=True)[:40]:
         o.write("%8.1f | %7.2f | %s  ->  %s\\n" % (g / 1e3, at / 1e6, " ; ".join(x[2][:40] for x in seg[max(0, a - 1):a + 1]), " ; ".join(x[2][:40] for x in seg[b:b + 2])))
+# every launch of the last proof: start offset (us) | idle before it | duration | workgroups | queue | kernel
+with open(sys.argv[1].replace(".txt", "") + "_timeline.txt", "w") as o:
+    end = t0
+    for s, e, n in seg:
+        wgs, q = meta.get((s, e), (0, "?"))
+        o.write("%9.1f +%7.1f dur %8.1f wgs %6d q%s %s\\n" % ((s - t0) / 1e3, max(0, s - end) / 1e3, (e - s) / 1e3, wgs, q, n.replace("sp1hip::", "").replace("void ", "")))
+        end = max(end, e)
 PY
 cat $out

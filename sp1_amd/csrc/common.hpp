@@ -58,6 +58,8 @@ struct RoctxRange {
 
 // A side stream (and n_events reusable events) paired with the caller's stream (runtime.hip).
 int aux_stream_for(hipStream_t main, int n_events, hipStream_t* aux, hipEvent_t** events);
+int fork_streams_for(hipStream_t main, int n, hipStream_t** streams, hipEvent_t** events);
+void release_stream_helpers(hipStream_t main);
 
 }  // namespace sp1hip
 

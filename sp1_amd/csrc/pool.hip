@@ -236,10 +236,18 @@ void sp1hip_pool_destroy(sp1hip_pool_t* pool) {
     (void)hipSetDevice(pool->device);
     // the slots' scratch (a core shard proof cycles ~34 GB per stream) is keyed by stream in the arena: give it back, a
     // destroyed stream can never reuse it
+    // (and so are the helper streams created for them: the commit's encode stream, the GKR's descriptor stream, the
+    // zerocheck's fork streams — each with events and arena blocks of its own)
     (void)hipStreamSynchronize(pool->stage_stream);
+    release_stream_helpers(pool->stage_stream);
     (void)arena_release_stream(pool->stage_stream);
     (void)hipStreamDestroy(pool->stage_stream);
-    for (hipStream_t s : pool->slot_streams) { (void)hipStreamSynchronize(s); (void)arena_release_stream(s); (void)hipStreamDestroy(s); }
+    for (hipStream_t s : pool->slot_streams) {
+        (void)hipStreamSynchronize(s);
+        release_stream_helpers(s);
+        (void)arena_release_stream(s);
+        (void)hipStreamDestroy(s);
+    }
     (void)hipSetDevice(prev);
     delete pool;
 }

@@ -87,6 +87,63 @@ int aux_stream_for(hipStream_t main, int n_events, hipStream_t* aux, hipEvent_t*
     return SP1HIP_SUCCESS;
 }
 
+// Fork streams: `n` ordinary-priority streams per (device, caller stream) for launches of one round that do not depend on
+// each other (the zerocheck's interpreter groups and fused pieces). events[0] is the fork event, events[1 + i] the join
+// event of streams[i].
+struct ForkRec { std::vector<hipStream_t> streams; std::vector<hipEvent_t> events; };
+static std::map<std::pair<int, hipStream_t>, ForkRec> g_fork;
+
+int fork_streams_for(hipStream_t main, int n, hipStream_t** streams, hipEvent_t** events) {
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    ForkRec& r = g_fork[{dev, main}];
+    while ((int)r.streams.size() < n) {
+        hipStream_t st;
+        SP1HIP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        r.streams.push_back(st);
+    }
+    while ((int)r.events.size() < n + 1) {
+        hipEvent_t e;
+        SP1HIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        r.events.push_back(e);
+    }
+    *streams = r.streams.data();
+    *events = r.events.data();
+    return SP1HIP_SUCCESS;
+}
+
+// The caller's stream is about to be destroyed (a prover pool's slot; the caller has synchronised it): destroy the helper
+// streams and events that were created for it and hand their cached arena blocks back. Without this every pool
+// create / destroy cycle left one high-priority stream, its events and its arena blocks behind.
+void release_stream_helpers(hipStream_t main) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;
+    {
+        std::lock_guard<std::mutex> lock(g_aux_mutex);
+        auto a = g_aux.find({dev, main});
+        if (a != g_aux.end()) {
+            if (a->second.aux) streams.push_back(a->second.aux);
+            events.insert(events.end(), a->second.events.begin(), a->second.events.end());
+            g_aux.erase(a);
+        }
+        auto f = g_fork.find({dev, main});
+        if (f != g_fork.end()) {
+            streams.insert(streams.end(), f->second.streams.begin(), f->second.streams.end());
+            events.insert(events.end(), f->second.events.begin(), f->second.events.end());
+            g_fork.erase(f);
+        }
+    }
+    for (hipStream_t st : streams) {
+        (void)hipStreamSynchronize(st);
+        (void)arena_release_stream(st);
+        (void)hipStreamDestroy(st);
+    }
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+}
+
 // ---- stream-keyed buffer arena -------------------------------------------------------------------
 // Steady-state proving allocates the same sizes over and over on one stream (codewords, trees, fold
 // layers). Freed blocks are kept in a per-(device, stream, size) free list and handed back without

@@ -110,6 +110,11 @@ constexpr uint32_t ZC_CHUNK_HARD_MAX = 320; // a chunk may grow to this while it
 // interprets a chunk serially at ~0.35 us per instruction — so they run a third form of the program, cut into pieces of
 // ~ZC_FINE_LIMIT instructions with no regard for recomputation: more workgroups, each a third as long
 constexpr uint32_t ZC_FINE_LIMIT = 32, ZC_FINE_MAX_TERMS = 64;
+// rounds with at most this many workgroups (x 3 nodes) launch their groups / fused pieces on fork streams; the default forks every round
+// (the large rounds gain the overlap of one launch's tail with the next one's head). SP1HIP_ZC_FORK_MAX_BLOCKS overrides (A/B runs).
+constexpr uint32_t ZC_FORK_MAX_BLOCKS = 1u << 30;
+// rounds with at most this many workgroups are "small": every launch is at its latency floor (the two septic kinds then share one launch)
+constexpr uint32_t ZC_SMALL_ROUND_WGS = 16384;
 constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB); longer programs read global memory
 
 typedef uint32_t zc_word_t __attribute__((ext_vector_type(4)));       // one instruction: op | flags, dst, a, b
@@ -218,6 +223,61 @@ __device__ __forceinline__ ZcDesc zc_find_desc(const ZcDesc* __restrict__ descs,
     return descs[lo];
 }
 
+// the sums of one range from its partials -> (y0, y2, y4, eq[th]); all threads of the workgroup call this, the results are
+// valid in threads 0..3 (word k of each extension element)
+template <bool FIRST>
+__device__ __forceinline__ void zc_reduce_range(const ZcChipRange& d, const uint32_t* __restrict__ partial, const uint32_t* __restrict__ eq,
+                                                uint32_t eq_len, uint32_t (&acc)[10][24], uint32_t& y0, uint32_t& y2, uint32_t& y4, uint32_t& e) {
+    const uint32_t word = threadIdx.x % 24, grp = threadIdx.x / 24, n_grp = min(blockDim.x / 24u, 10u);
+    auto ld = [&](const uint32_t* q) -> uint32_t { return *q; };
+    if (grp < n_grp) {
+        // eight independent partial sums: the loads of a lane are then eight deep in flight instead of one behind each add
+        // (a tall chip has thousands of blocks: the plain loop was 100-130 us in each of the first three rounds)
+        const uint32_t* p = partial + (size_t)d.block_start * 24 + word;
+        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t b = grp;
+        for (; b + 7 * n_grp < d.n_blocks; b += 8 * n_grp)
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = kb::add(a[u], ld(p + (size_t)(b + n_grp * u) * 24));
+        for (; b < d.n_blocks; b += n_grp) a[0] = kb::add(a[0], ld(p + (size_t)b * 24));
+        acc[grp][word] = kb::add(kb::add(kb::add(a[0], a[1]), kb::add(a[2], a[3])), kb::add(kb::add(a[4], a[5]), kb::add(a[6], a[7])));
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        uint32_t a = 0;
+        for (uint32_t g = 0; g < n_grp; g++) a = kb::add(a, acc[g][threadIdx.x]);
+        acc[0][threadIdx.x] = a;
+    }
+    __syncthreads();
+    y0 = y2 = y4 = e = 0;
+    if (threadIdx.x < 4) {
+        const uint32_t k = threadIdx.x;
+        // S[p][0..4) = A of pass p, S[p][4..8) = B of pass p
+        const uint32_t A0 = acc[0][k], B0 = acc[0][4 + k], A1 = acc[0][8 + k], B1 = acc[0][12 + k], A2 = acc[0][16 + k];
+        if (FIRST) {       // g0 = A0, g2 = B0, C(2) = A1, C(4) = A2
+            y0 = A0;
+            y2 = kb::add(A1, B0);
+            y4 = kb::add(A2, kb::sub(kb::add(B0, B0), A0));
+        } else {           // C(0) = A0, g0 = B0, C(2) = A1, g2 = B1, C(4) = A2
+            y0 = kb::add(A0, B0);
+            y2 = kb::add(A1, B1);
+            y4 = kb::add(A2, kb::sub(kb::add(B1, B1), B0));
+        }
+        e = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u;
+    }
+}
+// payload words [1 + 16 range ..) of the host slot: system-scope stores from threads 0..3
+__device__ __forceinline__ void zc_store_host_sums(volatile uint32_t* host_slot, uint32_t range, uint32_t y0, uint32_t y2, uint32_t y4, uint32_t e) {
+    if (threadIdx.x < 4) {
+        const uint32_t k = threadIdx.x;
+        uint32_t* h = const_cast<uint32_t*>(host_slot) + 1 + (size_t)range * 16;
+        __hip_atomic_store(h + k, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(h + 4 + k, y2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(h + 8 + k, y4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(h + 12 + k, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // One launch per sumcheck round covers EVERY chip and the three interpolation nodes:
 //   blockIdx.x = 3 b + p -> (chip, block b of 256 row pairs), pass p (node t = 2p).
 // A pass-p workgroup writes two extension partial sums [A | B] (8 words):
@@ -322,6 +382,9 @@ __global__ __launch_bounds__(256) void zc_round_kernel(const ZcDesc* __restrict_
 // its first main column. Every column of the permutation is loaded exactly once per piece; the loads a piece OWNS carry the
 // GKR-opening batching term, so the interpreter's pieces never touch those columns for it (the planner pre-marks them).
 constexpr uint32_t ZC_DESC_MACRO = 2u;
+// KIND of a launch that carries the pieces of BOTH septic kinds (they are adjacent block ranges; the kind comes from the descriptor): in
+// the small rounds every launch is at its latency floor and the two septic launches would share a hardware queue (a process has four)
+constexpr uint32_t ZC_MACRO_BOTH_SEPTIC = 4u;
 template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
                                                        uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
@@ -356,6 +419,7 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
         auto sink = [&](uint32_t j, const T& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
         if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<F>(q, rc, ld, sink);
         else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);
+        else if (KIND == ZC_MACRO_BOTH_SEPTIC && ((d.flags >> 12) & 15u) == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);   // (wave-uniform)
         else zc_septic_sum_piece<F>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); },
                                     [&]() -> T { return ld_at(d.aux1, false); }, sink);
         sa = kb::ext_add(sa, kb::ext_mul(va, e));
@@ -386,54 +450,17 @@ __global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __res
                                                         uint32_t* __restrict__ out, RoundSync rs, uint32_t seq) {
     __shared__ uint32_t acc[10][24];
     const ZcChipRange d = ranges[blockIdx.x];
-    const uint32_t word = threadIdx.x % 24, grp = threadIdx.x / 24;   // 10 groups of 24 words (3 passes x 8)
-    if (grp < 10) {
-        // eight independent partial sums: the loads of a lane are then eight deep in flight instead of one behind each add
-        // (a tall chip has thousands of blocks: the plain loop was 100-130 us in each of the first three rounds)
-        const uint32_t* p = partial + (size_t)d.block_start * 24 + word;
-        uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t b = grp;
-        for (; b + 70 < d.n_blocks; b += 80)
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = kb::add(a[u], p[(size_t)(b + 10 * u) * 24]);
-        for (; b < d.n_blocks; b += 10) a[0] = kb::add(a[0], p[(size_t)b * 24]);
-        acc[grp][word] = kb::add(kb::add(kb::add(a[0], a[1]), kb::add(a[2], a[3])), kb::add(kb::add(a[4], a[5]), kb::add(a[6], a[7])));
-    }
-    __syncthreads();
-    if (threadIdx.x < 24) {
-        uint32_t a = 0;
-        for (int g = 0; g < 10; g++) a = kb::add(a, acc[g][threadIdx.x]);
-        acc[0][threadIdx.x] = a;
-    }
-    __syncthreads();
+    uint32_t y0, y2, y4, e;
+    zc_reduce_range<FIRST>(d, partial, eq, eq_len, acc, y0, y2, y4, e);
     if (threadIdx.x < 4) {
         const uint32_t k = threadIdx.x;
-        // S[p][0..4) = A of pass p, S[p][4..8) = B of pass p
-        const uint32_t A0 = acc[0][k], B0 = acc[0][4 + k], A1 = acc[0][8 + k], B1 = acc[0][12 + k], A2 = acc[0][16 + k];
-        uint32_t y0, y2, y4;
-        if (FIRST) {       // g0 = A0, g2 = B0, C(2) = A1, C(4) = A2
-            y0 = A0;
-            y2 = kb::add(A1, B0);
-            y4 = kb::add(A2, kb::sub(kb::add(B0, B0), A0));
-        } else {           // C(0) = A0, g0 = B0, C(2) = A1, g2 = B1, C(4) = A2
-            y0 = kb::add(A0, B0);
-            y2 = kb::add(A1, B1);
-            y4 = kb::add(A2, kb::sub(kb::add(B1, B1), B0));
-        }
-        const uint32_t e = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u;
         uint32_t* o = out + (size_t)blockIdx.x * 16;
         o[k] = y0; o[4 + k] = y2; o[8 + k] = y4;
         o[12 + k] = e;
-        if (rs.host_slot != nullptr) {
-            // the round's result goes to the host from HERE (payload words [1 + 16 chip ..)): system-scope stores, and
-            // below the workgroup that arrives last publishes the sequence number — no mailbox kernel behind this one
-            uint32_t* h = const_cast<uint32_t*>(rs.host_slot) + 1 + (size_t)blockIdx.x * 16;
-            __hip_atomic_store(h + k, y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(h + 4 + k, y2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(h + 8 + k, y4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(h + 12 + k, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
+    // the round's result goes to the host from HERE (payload words [1 + 16 chip ..)): system-scope stores, and below the
+    // workgroup that arrives last publishes the sequence number — no mailbox kernel behind this one
+    if (rs.host_slot != nullptr) zc_store_host_sums(rs.host_slot, blockIdx.x, y0, y2, y4, e);
     if (rs.host_slot == nullptr) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1360,12 +1387,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     std::vector<Ext> round_claims = claims;
     std::vector<std::array<uint32_t, 16>> sums(n_chips);
     std::vector<uint32_t> h_sums((size_t)n_chips * 64);      // up to four reduction ranges per chip (interpreter + one per kind of fused piece)
-    DevBuf d_descs, d_partial, d_sums;       // d_descs: the round's descriptors [ZcDesc.. | ZcChipRange.. | ZcFixDesc..]
-    size_t partial_cap = 0, descs_cap = 0;
-    std::vector<std::unique_ptr<std::vector<ZcDesc>>> keep_descs;
-    std::vector<std::unique_ptr<std::vector<ZcChipRange>>> keep_ranges;
-    std::vector<std::unique_ptr<std::vector<ZcFixDesc>>> keep_fds;
-    std::vector<std::unique_ptr<std::vector<uint8_t>>> keep_packs;
+    DevBuf d_partial, d_sums;
+    size_t partial_cap = 0;
     SP1HIP_TRY(d_sums.alloc((size_t)n_chips * 256, s));
     // The folded extension tables of all chips live in two ping-pong buffers sized once (round r writes half r & 1;
     // every round's tables are half the size of the previous round's): no allocation inside the round loop — it used to
@@ -1389,27 +1412,41 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     zc_t1 = std::chrono::steady_clock::now();
     auto zc_iter_t = zc_t1;
     double zc_plan_ms = 0, zc_wait_ms = 0, zc_uni_ms = 0;
-    for (int r = 0; r < L; r++) {
-        const int nv = L - r;                       // variables left
-        const Ext last = zeta[nv - 1];
-        // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
-        struct EqView { uint32_t* p; uint32_t* u32() const { return p; } } d_eq{d_eq_all.u32() + 4 * (((size_t)1 << (nv - 1)) - 1)};
+    // ---- the plan of a round: which chips run in which form, the descriptors of every launch, the reduction ranges and the table
+    // update that ends the round. It depends on the tables' heights and addresses only — not on anything the transcript
+    // produces — so round r + 1 is planned and its descriptors uploaded while round r's kernels run (the host used to do
+    // this between the fix launch and the round's first launch, ~35 us per round with the device idle).
+    struct Group { bool staged; uint32_t wg, max_regs, max_instr, block_lo, n_blocks; std::vector<int> chips; };
+    struct RoundPlan {
+        std::vector<ZcDesc> descs;
+        std::vector<ZcChipRange> ranges;
+        std::vector<int> desc_chip;
+        std::vector<Group> groups;
+        uint32_t total_blocks = 0, macro_lo[4] = {0, 0, 0, 0}, macro_n[4] = {0, 0, 0, 0};
+        std::vector<ZcFixDesc> fds;
+        std::vector<uint32_t*> fresh;
+        std::vector<std::pair<int, bool>> owner;
+        uint32_t fix_blocks = 0;
+        size_t off_ranges = 0, off_fds = 0, pack_bytes = 0;
+        std::vector<uint8_t> pack;
+        std::vector<uint64_t> rows_next;
+        std::vector<const uint32_t*> main_next, prep_next;
+    };
+    auto plan_round = [&](int r, const std::vector<uint64_t>& vrows, const std::vector<const uint32_t*>& vmain,
+                          const std::vector<const uint32_t*>& vprep, RoundPlan& rp) -> int {
         // descriptors: one per (chip with real rows, chunk); a chip's blocks are contiguous. Chips are grouped by how
         // their programs run this round — (program staged in LDS?, workgroup width the LDS register file allows) — and
         // every group is one launch over its contiguous block range.
-        keep_descs.emplace_back(new std::vector<ZcDesc>());
-        keep_ranges.emplace_back(new std::vector<ZcChipRange>());
-        std::vector<ZcDesc>& descs = *keep_descs.back();
-        std::vector<ZcChipRange>& ranges = *keep_ranges.back();
-        std::vector<int> desc_chip;
-        struct Group { bool staged; uint32_t wg, max_regs, max_instr, block_lo, n_blocks; std::vector<int> chips; };
-        std::vector<Group> groups;
+        std::vector<ZcDesc>& descs = rp.descs;
+        std::vector<ZcChipRange>& ranges = rp.ranges;
+        std::vector<int>& desc_chip = rp.desc_chip;
+        std::vector<Group>& groups = rp.groups;
         static const bool mono_enabled = [] { const char* e = getenv("SP1HIP_ZC_MONO"); return !(e && e[0] == '0'); }();
         std::vector<char> use_mono(n_chips, 0);
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
-            if (c.rows == 0) continue;
-            const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
+            if (vrows[i] == 0) continue;
+            const uint32_t terms = (uint32_t)((vrows[i] + 1) / 2);
             uint32_t mono_regs = 1;
             for (auto& ck : c.mono) mono_regs = std::max(mono_regs, ck.n_regs);
             const uint32_t mono_wg = r == 0 ? zc_wg_for<true>(mono_regs, 128) : zc_wg_for<false>(mono_regs, 128);
@@ -1446,12 +1483,13 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             groups[g].max_instr = std::max(groups[g].max_instr, instr);
             groups[g].chips.push_back(i);
         }
-        uint32_t total_blocks = 0;
+        uint32_t& total_blocks = rp.total_blocks;
+        total_blocks = 0;
         for (auto& g : groups) {
             g.block_lo = total_blocks;
             for (int i : g.chips) {
                 ChipState& c = *st[i];
-                const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
+                const uint32_t terms = (uint32_t)((vrows[i] + 1) / 2);
                 const uint32_t bp = g.wg ? g.wg : 256u;
                 uint32_t blocks = (terms + bp - 1) / bp;
                 static const uint32_t max_pairs = [] { const char* e = getenv("SP1HIP_ZC_MAX_PAIRS"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 256u) : 131072u; }();
@@ -1463,8 +1501,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     ZcDesc d{};
                     d.prog = c.p_prog + (size_t)offs[q] * 4;
                     d.n_instr = (uint32_t)(cks[q].prog.size() / 4);
-                    d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
-                    d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
+                    d.main = vmain[i]; d.prep = vprep[i]; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+                    d.rows = (uint32_t)vrows[i]; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
                     d.block_start = total_blocks; d.n_blocks = blocks;
                     d.alpha_off = cks[q].alpha_off; d.flags = q == 0 ? 1u : 0u;
                     d.block_pairs = bp;
@@ -1479,25 +1517,26 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         // the fused pieces of hinted sub-AIRs: one launch per kind (each kind is its own kernel with its own register budget),
         // one block range — and one reduction range — per (kind, chip)
-        uint32_t macro_lo[4] = {0, 0, 0, 0}, macro_n[4] = {0, 0, 0, 0};
+        uint32_t (&macro_lo)[4] = rp.macro_lo;
+        uint32_t (&macro_n)[4] = rp.macro_n;
         for (uint32_t kind = ZC_HINT_POSEIDON2; kind <= ZC_HINT_SEPTIC_SUM; kind++) {
             macro_lo[kind] = total_blocks;
             for (int i = 0; i < n_chips; i++) {
                 ChipState& c = *st[i];
-                if (c.rows == 0) continue;
-                const uint32_t terms = (uint32_t)((c.rows + 1) / 2);
+                if (vrows[i] == 0) continue;
+                const uint32_t terms = (uint32_t)((vrows[i] + 1) / 2);
                 const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
                 ZcChipRange rg{total_blocks, 0, terms - 1, 0};
                 for (const ZcMacro& m : c.macros) {
                     if (m.kind != kind) continue;
                     for (uint32_t q = 0; q < m.n_pieces(); q++) {
                         ZcDesc d{};
-                        d.main = c.d_main; d.prep = c.d_prep; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
-                        d.rows = (uint32_t)c.rows; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
+                        d.main = vmain[i]; d.prep = vprep[i]; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+                        d.rows = (uint32_t)vrows[i]; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
                         d.block_start = total_blocks; d.n_blocks = blocks;
                         d.alpha_off = m.first_constraint; d.flags = ZC_DESC_MACRO | (q << 8) | (m.kind << 12);
                         d.block_pairs = 256; d.pad = m.base_col; d.aux0 = m.aux0; d.aux1 = m.aux1;
-                        total_blocks += blocks;
+                            total_blocks += blocks;
                         descs.push_back(d);
                     }
                 }
@@ -1506,29 +1545,28 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             macro_n[kind] = total_blocks - macro_lo[kind];
         }
-        const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
         // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
         // it now, so that every descriptor of the round goes up in ONE copy
-        keep_fds.emplace_back(new std::vector<ZcFixDesc>());
-        std::vector<ZcFixDesc>& fds = *keep_fds.back();
-        std::vector<uint32_t*> fresh;              // the folded tables: slices of the round's half of the ping-pong buffer
-        std::vector<std::pair<int, bool>> owner;   // (chip, is_main)
-        uint32_t fix_blocks = 0;
+        std::vector<ZcFixDesc>& fds = rp.fds;
+        std::vector<uint32_t*>& fresh = rp.fresh;              // the folded tables: slices of the round's half of the ping-pong buffer
+        std::vector<std::pair<int, bool>>& owner = rp.owner;   // (chip, is_main)
+        uint32_t& fix_blocks = rp.fix_blocks;
+        fix_blocks = 0;
         size_t fold_words = 0;
         uint32_t* const fold_base = (uint32_t*)d_fold[r & 1].p;
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
-            if (c.rows == 0) continue;
-            const uint64_t out_rows = (c.rows + 1) / 2;
+            if (vrows[i] == 0) continue;
+            const uint64_t out_rows = (vrows[i] + 1) / 2;
             for (int which = 0; which < 2; which++) {
                 const uint32_t width = which == 0 ? c.in->main_width : c.in->prep_width;
                 if (width == 0) continue;
                 uint32_t* const nb = fold_base + fold_words;
                 fold_words += ((size_t)out_rows * width * 4 + 3) & ~(size_t)3;
                 ZcFixDesc fd{};
-                fd.in = which == 0 ? c.d_main : c.d_prep;
+                fd.in = which == 0 ? vmain[i] : vprep[i];
                 fd.out = nb;
-                fd.rows = (uint32_t)c.rows; fd.width = width; fd.block_start = fix_blocks;
+                fd.rows = (uint32_t)vrows[i]; fd.width = width; fd.block_start = fix_blocks;
                 fd.bpc = (uint32_t)((out_rows + ZC_FIX_ROWS - 1) / ZC_FIX_ROWS);
                 fd.bpc_magic = (uint32_t)((((uint64_t)1 << 32) / fd.bpc) & 0xffffffffull);      // (bpc == 1 is special-cased in the kernel)
                 fd.n_blocks = fd.bpc * width;
@@ -1538,22 +1576,66 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 owner.push_back({i, which == 0});
             }
         }
-        const size_t off_ranges = (descs.size() * sizeof(ZcDesc) + 15) & ~(size_t)15;
-        const size_t off_fds = (off_ranges + ranges.size() * sizeof(ZcChipRange) + 15) & ~(size_t)15;
-        const size_t pack_bytes = off_fds + fds.size() * sizeof(ZcFixDesc);
-        keep_packs.emplace_back(new std::vector<uint8_t>(std::max<size_t>(pack_bytes, 16), 0));
-        std::vector<uint8_t>& pack = *keep_packs.back();
+        const size_t off_ranges = rp.off_ranges = (descs.size() * sizeof(ZcDesc) + 15) & ~(size_t)15;
+        const size_t off_fds = rp.off_fds = (off_ranges + ranges.size() * sizeof(ZcChipRange) + 15) & ~(size_t)15;
+        const size_t pack_bytes = rp.pack_bytes = off_fds + fds.size() * sizeof(ZcFixDesc);
+        std::vector<uint8_t>& pack = rp.pack;
+        pack.assign(std::max<size_t>(pack_bytes, 16), 0);
         if (!descs.empty()) memcpy(pack.data(), descs.data(), descs.size() * sizeof(ZcDesc));
         if (!ranges.empty()) memcpy(pack.data() + off_ranges, ranges.data(), ranges.size() * sizeof(ZcChipRange));
         if (!fds.empty()) memcpy(pack.data() + off_fds, fds.data(), fds.size() * sizeof(ZcFixDesc));
-        if (pack.size() > descs_cap) {
-            d_descs.release();
-            descs_cap = pack.size();
-            SP1HIP_TRY(d_descs.alloc(descs_cap, s));
+        // the tables the round AFTER this one reads (once the fix launch planned above has run)
+        rp.rows_next = vrows; rp.main_next = vmain; rp.prep_next = vprep;
+        for (size_t k = 0; k < fds.size(); k++) {
+            if (owner[k].second) rp.main_next[owner[k].first] = fresh[k]; else rp.prep_next[owner[k].first] = fresh[k];
         }
-        SP1HIP_TRY(stage.upload(d_descs.p, pack.data(), pack_bytes));
-        const ZcChipRange* d_ranges_p = (const ZcChipRange*)((const uint8_t*)d_descs.p + off_ranges);
-        const ZcFixDesc* d_fix_p = (const ZcFixDesc*)((const uint8_t*)d_descs.p + off_fds);
+        for (int i = 0; i < n_chips; i++) if (rp.rows_next[i]) rp.rows_next[i] = (rp.rows_next[i] + 1) / 2;
+        return SP1HIP_SUCCESS;
+    };
+    // the descriptors of rounds r and r + 1 live in two buffers: round r + 1's go up while round r's launches read theirs
+    DevBuf d_descs2[2];
+    size_t descs_cap2[2] = {0, 0};
+    auto upload_plan = [&](const RoundPlan& rp, int which) -> int {
+        if (rp.pack.size() > descs_cap2[which]) {
+            d_descs2[which].release();
+            descs_cap2[which] = rp.pack.size();
+            SP1HIP_TRY(d_descs2[which].alloc(descs_cap2[which], s));
+        }
+        return stage.upload(d_descs2[which].p, rp.pack.data(), rp.pack_bytes);
+    };
+    std::vector<std::unique_ptr<RoundPlan>> plans;           // (kept until the call returns)
+    {
+        std::vector<uint64_t> rows0(n_chips);
+        std::vector<const uint32_t*> main0(n_chips), prep0(n_chips);
+        for (int i = 0; i < n_chips; i++) { rows0[i] = st[i]->rows; main0[i] = st[i]->d_main; prep0[i] = st[i]->d_prep; }
+        plans.emplace_back(new RoundPlan());
+        if (L > 0) {
+            SP1HIP_TRY(plan_round(0, rows0, main0, prep0, *plans.back()));
+            SP1HIP_TRY(upload_plan(*plans.back(), 0));
+        }
+    }
+    for (int r = 0; r < L; r++) {
+        const int nv = L - r;                       // variables left
+        const Ext last = zeta[nv - 1];
+        // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
+        struct EqView { uint32_t* p; uint32_t* u32() const { return p; } } d_eq{d_eq_all.u32() + 4 * (((size_t)1 << (nv - 1)) - 1)};
+        RoundPlan& rp = *plans[r];
+        std::vector<ZcDesc>& descs = rp.descs;
+        std::vector<ZcChipRange>& ranges = rp.ranges;
+        std::vector<int>& desc_chip = rp.desc_chip;
+        std::vector<Group>& groups = rp.groups;
+        const uint32_t total_blocks = rp.total_blocks;
+        uint32_t (&macro_lo)[4] = rp.macro_lo;
+        uint32_t (&macro_n)[4] = rp.macro_n;
+        std::vector<ZcFixDesc>& fds = rp.fds;
+        std::vector<uint32_t*>& fresh = rp.fresh;
+        std::vector<std::pair<int, bool>>& owner = rp.owner;
+        const uint32_t fix_blocks = rp.fix_blocks;
+        const int n_descs = (int)descs.size(), n_ranges = (int)ranges.size();
+        DevBuf& d_descs = d_descs2[r & 1];
+        const ZcChipRange* d_ranges_p = (const ZcChipRange*)((const uint8_t*)d_descs.p + rp.off_ranges);
+        const ZcFixDesc* d_fix_p = (const ZcFixDesc*)((const uint8_t*)d_descs.p + rp.off_fds);
+        (void)ranges;
         if (n_descs) {
             if ((size_t)total_blocks * 24 * 4 > partial_cap) {
                 d_partial.release();
@@ -1561,44 +1643,115 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_TRY(d_partial.alloc(partial_cap, s));
             }
             ScopedTimer tm("zerocheck_round", s);      // (the reference's SP1_GPU_ZEROCHECK_ROUND_TIMING switch)
-            for (auto& g : groups) {
-                // SP1HIP_ZC_FUSE_NODES=1: one workgroup evaluates the three nodes of its rows (rows leave HBM once). Measured
-                // on the core-shaped shard: 12.5 ms of round kernels against 11.0 ms unfused — the re-reads of the unfused
-                // form already meet in the memory-side cache (FETCH_SIZE counts those hits), and fusing costs a third of
-                // the parallelism. Off by default; kept for A/B runs.
-                static const bool fuse_enabled = [] { const char* e = getenv("SP1HIP_ZC_FUSE_NODES"); return e && e[0] == '1'; }();
-                const bool fused = fuse_enabled && g.n_blocks >= 4096;
-                if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
-                else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, (const ZcDesc*)d_descs.p, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), 1u << (nv - 1), d_publics.u32(), d_partial.u32(), s));
+            // The launches of a round (one per interpreter group, one per kind of fused piece) read the same tables and write
+            // disjoint slots of d_partial: nothing orders them but the stream. They go out on fork streams — a round then
+            // costs its LONGEST launch instead of their sum (five launches of 30-70 us each in the last fifteen rounds of a
+            // core shard; in the large rounds one launch's tail overlaps the next one's head). SP1HIP_ZC_FORK=0: one stream.
+            static const bool fork_enabled = [] { const char* e = getenv("SP1HIP_ZC_FORK"); return !(e && e[0] == '0'); }();
+            static const bool fuse_nodes = [] { const char* e = getenv("SP1HIP_ZC_FUSE_NODES"); return e && e[0] == '1'; }();
+            const int n_launches = (int)groups.size() + (macro_n[1] ? 1 : 0) + (macro_n[2] ? 1 : 0) + (macro_n[3] ? 1 : 0);
+            static const uint32_t fork_max_blocks = [] { const char* e = getenv("SP1HIP_ZC_FORK_MAX_BLOCKS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : ZC_FORK_MAX_BLOCKS; }();
+            const bool forked = fork_enabled && n_launches > 1 && total_blocks <= fork_max_blocks;
+            // the round's sums reach the host through the mailbox slot when they fit it (they do for any real machine)
+            const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
+            const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
+            constexpr int N_FORK = 3;                  // + the caller's stream = the four hardware queues a process gets by default
+            hipStream_t* fork_s = nullptr;
+            hipEvent_t* fork_ev = nullptr;
+            bool fork_used[N_FORK] = {false, false, false};
+            if (forked) {
+                SP1HIP_TRY(fork_streams_for(s, N_FORK, &fork_s, &fork_ev));
+                SP1HIP_HIP(hipEventRecord(fork_ev[0], s));           // behind the descriptor upload and the previous round's fix
             }
-            if (macro_n[1] | macro_n[2] | macro_n[3]) {
-                const DeviceCtx* dctx;
-                SP1HIP_TRY(get_device_ctx(&dctx));
-                const ZcDesc* dd = (const ZcDesc*)d_descs.p;
-                const uint32_t eq_len = 1u << (nv - 1);
+            // longest expected launch first, each on the stream with the least expected work so far (a fused piece is one
+            // long dependent chain per workgroup: ~75 / 50 / 60 us at its floor, an interpreter group ~50; above the floor
+            // a launch grows with its workgroups per 1024 resident ones)
+            struct Launch { int kind; size_t group; double est; int slot; };           // kind 0: interpreter group, 1..3: fused pieces
+            std::vector<Launch> order;
+            {
+                static const double floor_us[4] = {45.0, 75.0, 45.0, 60.0};
+                for (size_t g = 0; g < groups.size(); g++) order.push_back({0, g, floor_us[0] * (1.0 + groups[g].n_blocks * 3 / 1024.0), 0});
+                const bool both_septic = forked && r > 0 && macro_n[2] && macro_n[3] && (uint64_t)total_blocks * 3 <= ZC_SMALL_ROUND_WGS;
+                for (int kind = 1; kind <= 3; kind++) {
+                    if (!macro_n[kind] || (both_septic && kind == 2)) continue;
+                    if (both_septic && kind == 3) order.push_back({(int)ZC_MACRO_BOTH_SEPTIC, 0, floor_us[3] * (1.0 + (macro_n[2] + macro_n[3]) * 3 / 1024.0), 0});
+                    else order.push_back({kind, 0, floor_us[kind] * (1.0 + macro_n[kind] * 3 / 1024.0), 0});
+                }
+                if (forked) {
+                    std::stable_sort(order.begin(), order.end(), [](const Launch& a, const Launch& b) { return a.est > b.est; });
+                    double load[N_FORK + 1] = {0, 7, 14, 21};          // (the launches leave the host ~7 us apart)
+                    for (Launch& ln : order) {
+                        int best = 0;
+                        for (int k = 1; k <= N_FORK; k++) if (load[k] < load[best]) best = k;
+                        ln.slot = best;
+                        load[best] += ln.est;
+                    }
+                }
+            }
+            const DeviceCtx* dctx;
+            SP1HIP_TRY(get_device_ctx(&dctx));
+            const ZcDesc* dd = (const ZcDesc*)d_descs.p;
+            const uint32_t eq_len = 1u << (nv - 1);
+            for (const Launch& ln : order) {
+                hipStream_t ls = s;
+                if (forked && ln.slot > 0) {
+                    const int k = ln.slot - 1;
+                    if (!fork_used[k]) { fork_used[k] = true; SP1HIP_HIP(hipStreamWaitEvent(fork_s[k], fork_ev[0], 0)); }
+                    ls = fork_s[k];
+                }
+                if (ln.kind == 0) {
+                    const auto& g = groups[ln.group];
+                    // SP1HIP_ZC_FUSE_NODES=1: one workgroup evaluates the three nodes of its rows (rows leave HBM once). Measured
+                    // on the core-shaped shard: 12.5 ms of round kernels against 11.0 ms unfused — the re-reads of the unfused
+                    // form already meet in the memory-side cache (FETCH_SIZE counts those hits), and fusing costs a third of
+                    // the parallelism. Off by default; kept for A/B runs.
+                    const bool fused = fuse_nodes && g.n_blocks >= 4096;
+                    if (r == 0) SP1HIP_TRY(launch_round<true>(g.max_regs, g.staged, fused, dd, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), eq_len, d_publics.u32(), d_partial.u32(), ls));
+                    else SP1HIP_TRY(launch_round<false>(g.max_regs, g.staged, fused, dd, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq.u32(), eq_len, d_publics.u32(), d_partial.u32(), ls));
+                    continue;
+                }
 #define SP1HIP_ZC_MACRO_LAUNCH(KIND)                                                                                                   \
-                if (macro_n[KIND]) {                                                                                                   \
-                    if (r == 0) hipLaunchKernelGGL((zc_macro_kernel<true, KIND>), dim3(macro_n[KIND] * 3), dim3(256), 0, s, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[KIND], dctx->d_rc); \
-                    else hipLaunchKernelGGL((zc_macro_kernel<false, KIND>), dim3(macro_n[KIND] * 3), dim3(256), 0, s, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[KIND], dctx->d_rc); \
+                if (ln.kind == (int)KIND) {                                                                                            \
+                    if (r == 0) hipLaunchKernelGGL((zc_macro_kernel<true, KIND>), dim3(macro_n[KIND] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[KIND], dctx->d_rc); \
+                    else hipLaunchKernelGGL((zc_macro_kernel<false, KIND>), dim3(macro_n[KIND] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[KIND], dctx->d_rc); \
                     SP1HIP_LAUNCH_CHECK();                                                                                             \
                 }
                 SP1HIP_ZC_MACRO_LAUNCH(1u)
                 SP1HIP_ZC_MACRO_LAUNCH(2u)
                 SP1HIP_ZC_MACRO_LAUNCH(3u)
 #undef SP1HIP_ZC_MACRO_LAUNCH
+                if (ln.kind == (int)ZC_MACRO_BOTH_SEPTIC) {          // (never round 0: that round is far above the small-round bound)
+                    hipLaunchKernelGGL((zc_macro_kernel<false, ZC_MACRO_BOTH_SEPTIC>), dim3((macro_n[2] + macro_n[3]) * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[2], dctx->d_rc);
+                    SP1HIP_LAUNCH_CHECK();
+                }
             }
+            if (forked)
+                for (int k = 0; k < N_FORK; k++)
+                    if (fork_used[k]) {
+                        SP1HIP_HIP(hipEventRecord(fork_ev[1 + k], fork_s[k]));
+                        SP1HIP_HIP(hipStreamWaitEvent(s, fork_ev[1 + k], 0));   // the reduction (and everything after it) follows every launch
+                    }
             // the reduce kernel publishes the round's sums itself (ticket on the round-sync counters, payload in the mailbox slot)
-            const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
-            const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
             if (direct) { rsync.pending = true; mb.pending = true; }
-            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32(), rs_pub, mb.seq + 1);
-            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), 1u << (nv - 1), d_sums.u32(), rs_pub, mb.seq + 1);
+            if (r == 0) hipLaunchKernelGGL(zc_reduce_kernel<true>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), eq_len, d_sums.u32(), rs_pub, mb.seq + 1);
+            else hipLaunchKernelGGL(zc_reduce_kernel<false>, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq.u32(), eq_len, d_sums.u32(), rs_pub, mb.seq + 1);
             SP1HIP_LAUNCH_CHECK();
+            // the next round's plan and descriptors, behind this round's launches (see plan_round)
+            if (r + 1 < L && (int)plans.size() == r + 1) {
+                plans.emplace_back(new RoundPlan());
+                SP1HIP_TRY(plan_round(r + 1, rp.rows_next, rp.main_next, rp.prep_next, *plans.back()));
+                SP1HIP_TRY(upload_plan(*plans.back(), (r + 1) & 1));
+            }
             const auto zc_w0 = std::chrono::steady_clock::now();
             if (zc_timing) zc_plan_ms += std::chrono::duration<double, std::milli>(zc_w0 - zc_iter_t).count();
             if (direct) { SP1HIP_TRY(mb.wait_next(h_sums.data(), (size_t)n_ranges * 16)); rsync.pending = false; }
             else SP1HIP_TRY(mb.fetch(d_sums.p, (size_t)n_ranges * 16, h_sums.data()));
             if (zc_timing) { zc_iter_t = std::chrono::steady_clock::now(); zc_wait_ms += std::chrono::duration<double, std::milli>(zc_iter_t - zc_w0).count(); }
+        }
+        if (r + 1 < L && (int)plans.size() == r + 1) {           // (a round without descriptors: nothing was launched above)
+            plans.emplace_back(new RoundPlan());
+            SP1HIP_TRY(plan_round(r + 1, rp.rows_next, rp.main_next, rp.prep_next, *plans.back()));
+            SP1HIP_TRY(upload_plan(*plans.back(), (r + 1) & 1));
         }
         {   // a chip with fused pieces has a second range: its sums ADD to the interpreter's (the eq entry is the same)
             std::vector<char> have(n_chips, 0);
