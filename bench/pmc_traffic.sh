@@ -16,10 +16,15 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -
 python - "$out" <<PY
 import csv, glob, json, sys, collections
 def load(d, counter=None):
+    # only what is dispatched from the calibration kernel on (bench.py launches it right before its timed loop): the set-up —
+    # torch's trace building, the preprocessed commitment — is not the proof's
     agg, cnt = collections.defaultdict(float), collections.Counter()
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(fn)):
-            if counter is not None and r["Counter_Name"] != counter:
+        rows = [r for r in csv.DictReader(open(fn)) if counter is None or r["Counter_Name"] == counter]
+        cal_ids = [int(r["Dispatch_Id"]) for r in rows if "monty_convert_kernel" in r["Kernel_Name"]]
+        first = min(cal_ids) if cal_ids else 0
+        for r in rows:
+            if int(r["Dispatch_Id"]) < first:
                 continue
             k = r["Kernel_Name"].split("(")[0]
             agg[k] += float(r["Counter_Value"]); cnt[k] += 1
@@ -56,6 +61,15 @@ for name, subs in groups.items():
                      "valu_wave_insts_per_proof": sum(valu.get(k, 0.0) for k in ks),
                      "valu_lane_insts_per_proof": 64.0 * sum(valu.get(k, 0.0) for k in ks),
                      "salu_insts_per_proof": sum(salu.get(k, 0.0) for k in ks)}
+# every kernel of the library inside the proof (the calibration kernel and torch's trace-building kernels are not the proof's)
+own = [k for k in f if ("sp1hip::" in k or "rocclr" in k) and "monty_convert" not in k and "tracegen" not in k]
+kernels["all_kernels"] = {"launches_per_proof": sum(fc[k] for k in own),
+                          "fetch_bytes_per_proof": sum(f[k] for k in own) * 2048.0, "write_bytes_per_proof": sum(w.get(k, 0.0) for k in own) * 1024.0,
+                          "hbm_bytes_per_proof": sum(f[k] for k in own) * 2048.0 + sum(w.get(k, 0.0) for k in own) * 1024.0,
+                          "valu_wave_insts_per_proof": sum(valu.get(k, 0.0) for k in own),
+                          "valu_lane_insts_per_proof": 64.0 * sum(valu.get(k, 0.0) for k in own),
+                          "salu_insts_per_proof": sum(salu.get(k, 0.0) for k in own)}
+kernels["all_kernels"]["hbm_bytes_per_launch"] = kernels["all_kernels"]["hbm_bytes_per_proof"] / max(1, kernels["all_kernels"]["launches_per_proof"])
 json.dump({"workload": "real",
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU SQ_INSTS_SALU, three separate passes over one proof of the "
                      "real-chip core shard (bench/pmc_traffic.sh -> profiles/r04_traffic.json); KiB units, FETCH x 2 (gfx950: 64 B "

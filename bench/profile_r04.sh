@@ -1,13 +1,16 @@
 #!/bin/bash
 # Round-4 profile set (run on the GPU box; everything lands under gpurun_out/r04/, the summaries are copied to profiles/):
+#  0. FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU+SALU in separate --pmc passes              -> traffic.json  (bench.py reads profiles/r04_traffic.json)
 #  1. bench.py as the driver runs it (extras included)                                   -> bench.json
 #  2. rocprofv3 --kernel-trace --stats --marker-trace of the bench command (no extras)   -> bench_kernel_stats.csv, marker ranges
-#  3. FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU+SALU in separate --pmc passes              -> traffic.json  (bench.py reads profiles/r04_traffic.json)
 #  4. where the GPU idles inside one proof (bench/gap_trace.sh)                          -> gap_trace.txt
 #  5. stage walls of the real-chip shard and the recursion shard                         -> real_stages.txt, bench_recursion.txt
 out=$GRAFT_REPO_ROOT/gpurun_out/r04
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
+# the PMC table first: bench.py reads profiles/r04_traffic.json for the roofline object, and it must be the table of THIS build
+timeout 900 bash bench/pmc_traffic.sh $out/traffic.json > $out/traffic.log 2>&1
+cp $out/traffic.json profiles/r04_traffic.json
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_stats
@@ -30,7 +33,6 @@ if os.path.exists(p):
     os.remove(p)
 PY
 cd $GRAFT_REPO_ROOT
-timeout 900 bash bench/pmc_traffic.sh $out/traffic.json > $out/traffic.log 2>&1
 timeout 300 bash bench/gap_trace.sh $out/gap_trace.txt > /dev/null 2>&1
 SP1HIP_SHARD_TIMING=1 timeout 200 python bench/bench_real.py 0 4 > $out/real_stages.txt 2>&1
 SP1HIP_SHARD_TIMING=1 timeout 200 python bench/bench_recursion.py --repeat 4 --stages > $out/bench_recursion.txt 2>&1

@@ -516,7 +516,9 @@ typedef struct {
 } sp1hip_pool_times_t;
 
 int sp1hip_pool_create(int device, int n_slots, sp1hip_pool_t** out);
-/* Finishes every submitted shard, then stops the threads and destroys the streams. */
+/* Finishes every submitted shard, then stops the threads and destroys the streams (the slots' helper streams, their events and
+   every arena block cached for them included). Like any destructor of this ABI it must not run concurrently with another
+   call on the same pool: a thread blocked in sp1hip_pool_wait holds a pointer into it. */
 void sp1hip_pool_destroy(sp1hip_pool_t* pool);
 /* Queue one shard: `AirProver::prove_shard_with_pk` (/root/reference/crates/hypercube/src/prover/shard.rs:L321-L345) from
  * the generated traces on. Returns at once. */

@@ -181,7 +181,11 @@ struct sp1hip_pool_s {
         size_t need = 0;
         const int q = sp1hip_prove_shard_with_pk(j->pk, chips.data(), (int)chips.size(), pub, (int)j->publics.size(), nullptr, 0,
                                                  nullptr, &need, s);
-        if (q != SP1HIP_ERROR_BUFFER_TOO_SMALL) return q == SP1HIP_SUCCESS ? SP1HIP_ERROR_RUNTIME : q;
+        if (q == SP1HIP_SUCCESS) {            // (the size query is specified to fail with BUFFER_TOO_SMALL)
+            set_error("internal error: the proof size query succeeded without a buffer");
+            return SP1HIP_ERROR_RUNTIME;
+        }
+        if (q != SP1HIP_ERROR_BUFFER_TOO_SMALL) return q;
         j->proof.resize(need);
         size_t len = need;
         SP1HIP_TRY(sp1hip_prove_shard_with_pk(j->pk, chips.data(), (int)chips.size(), pub, (int)j->publics.size(), nullptr, 0,
@@ -204,12 +208,35 @@ int sp1hip_pool_create(int device, int n_slots, sp1hip_pool_t** out) {
     std::unique_ptr<sp1hip_pool_s> p(new sp1hip_pool_s());
     p->device = device;
     p->n_slots = n_slots;
-    SP1HIP_HIP(hipStreamCreateWithFlags(&p->stage_stream, hipStreamNonBlocking));
-    p->slot_streams.resize(n_slots);
-    for (int i = 0; i < n_slots; i++) SP1HIP_HIP(hipStreamCreateWithFlags(&p->slot_streams[i], hipStreamNonBlocking));
+    // Nothing may leak or cross the C ABI as an exception when creation fails half-way: streams made so far are destroyed,
+    // threads started so far are stopped and joined, and the failure comes back as a status code.
     sp1hip_pool_s* raw = p.get();
-    p->stager = std::thread([raw] { raw->stager_main(); });
-    for (int i = 0; i < n_slots; i++) p->workers.emplace_back([raw, i] { raw->worker_main(i); });
+    auto undo = [&](int status) {
+        {
+            std::lock_guard<std::mutex> lk(raw->m);
+            raw->stop = true;
+        }
+        raw->cv_in.notify_all();
+        raw->cv_ready.notify_all();
+        raw->cv_room.notify_all();
+        if (raw->stager.joinable()) raw->stager.join();
+        for (auto& w : raw->workers) if (w.joinable()) w.join();
+        if (raw->stage_stream) (void)hipStreamDestroy(raw->stage_stream);
+        for (hipStream_t st : raw->slot_streams) if (st) (void)hipStreamDestroy(st);
+        (void)hipSetDevice(prev);
+        return status;
+    };
+    hipError_t he = hipStreamCreateWithFlags(&p->stage_stream, hipStreamNonBlocking);
+    p->slot_streams.assign(n_slots, nullptr);
+    for (int i = 0; i < n_slots && he == hipSuccess; i++) he = hipStreamCreateWithFlags(&p->slot_streams[i], hipStreamNonBlocking);
+    if (he != hipSuccess) return undo(map_hip_error(he, "sp1hip_pool_create: stream creation failed"));
+    try {
+        p->stager = std::thread([raw] { raw->stager_main(); });
+        for (int i = 0; i < n_slots; i++) p->workers.emplace_back([raw, i] { raw->worker_main(i); });
+    } catch (const std::exception& e) {
+        set_error("sp1hip_pool_create: could not start the pool's threads (%s)", e.what());
+        return undo(SP1HIP_ERROR_RUNTIME);
+    }
     (void)hipSetDevice(prev);
     *out = p.release();
     return SP1HIP_SUCCESS;

@@ -195,6 +195,7 @@ static size_t arena_cap_bytes(int dev) {
     return cap;
 }
 
+size_t arena_trim_device(int dev);
 int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
     int dev = 0;
     SP1HIP_HIP(hipGetDevice(&dev));
@@ -210,9 +211,32 @@ int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
         }
     }
     hipError_t e = hipMalloc(ptr, sz);
-    if (e == hipErrorOutOfMemory) {       // give cached blocks back to the driver and retry once
+    if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
-        arena_trim();
+        // 1. a block of this size class cached for ANOTHER stream of this device (free lists are per stream because reuse is
+        //    ordered by the stream; a block changes streams only behind a synchronisation of the stream that last used it)
+        hipStream_t donor = nullptr;
+        void* stolen = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_arena_mutex);
+            for (auto it = g_arena.begin(); it != g_arena.end(); ++it)
+                if (it->first.device == dev && it->first.bytes == sz && it->first.stream != stream && !it->second.empty()) {
+                    stolen = it->second.back();
+                    it->second.pop_back();
+                    g_arena_cached_bytes[dev] -= sz;
+                    donor = it->first.stream;
+                    break;
+                }
+        }
+        if (stolen) {
+            const hipError_t se = hipStreamSynchronize(donor);
+            if (se == hipSuccess) { *ptr = stolen; return SP1HIP_SUCCESS; }
+            (void)hipGetLastError();          // (the donor stream is gone: the block cannot be in use any more)
+            *ptr = stolen;
+            return SP1HIP_SUCCESS;
+        }
+        // 2. give THIS device's cached blocks back to the driver and retry once (other devices' provers are not stalled)
+        arena_trim_device(dev);
         e = hipMalloc(ptr, sz);
     }
     SP1HIP_HIP(e);
@@ -267,19 +291,40 @@ size_t arena_release_stream(hipStream_t stream) {
     return freed;
 }
 
-size_t arena_trim() {
-    std::map<ArenaKey, std::vector<void*>> old;
-    size_t freed;
+// every cached block of one device (the current one must be `dev`: hipDeviceSynchronize / hipFree act on it)
+size_t arena_trim_device(int dev) {
+    std::vector<void*> blocks;
+    size_t freed = 0;
     {
         std::lock_guard<std::mutex> lock(g_arena_mutex);
-        old.swap(g_arena);
-        freed = 0;
-        for (auto& kv : g_arena_cached_bytes) freed += kv.second;
-        g_arena_cached_bytes.clear();
+        for (auto it = g_arena.begin(); it != g_arena.end();) {
+            if (it->first.device == dev) {
+                for (void* p : it->second) { blocks.push_back(p); freed += it->first.bytes; }
+                it = g_arena.erase(it);
+            } else ++it;
+        }
+        g_arena_cached_bytes[dev] = 0;
     }
     (void)hipDeviceSynchronize();
-    for (auto& kv : old)
-        for (void* p : kv.second) (void)hipFree(p);
+    for (void* p : blocks) (void)hipFree(p);
+    return freed;
+}
+
+// sp1hip_mem_trim: every device's cache
+size_t arena_trim() {
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lock(g_arena_mutex);
+        for (auto& kv : g_arena) if (std::find(devs.begin(), devs.end(), kv.first.device) == devs.end()) devs.push_back(kv.first.device);
+    }
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) return 0;
+    size_t freed = 0;
+    for (int d : devs) {
+        if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
+        freed += arena_trim_device(d);
+    }
+    (void)hipSetDevice(prev);
     return freed;
 }
 

@@ -106,11 +106,21 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     sh_t[0] = std::chrono::steady_clock::now();
     // roctx ranges per stage (rocprofv3 --marker-trace): one open range at a time, closed on every exit path
     RoctxRange proof_range("sp1hip_prove_shard");
+    // (with the event timers on — sp1hip_timers_enable — every stage is also a timer "stage_<name>" on the caller's stream: the
+    // window the stage's kernels share, which is what bench.py prices the overlapped commit kernels against)
     struct StageMarks {
+        hipStream_t s;
         bool open = false;
-        void next(const char* name) { if (open) roctx_pop(); roctx_push(name); open = true; }
-        ~StageMarks() { if (open) roctx_pop(); }
-    } marks;
+        int idx = -1;
+        void close() { if (idx >= 0) timer_end(idx, s); idx = -1; if (open) roctx_pop(); open = false; }
+        void next(const char* name) {
+            close();
+            roctx_push(name);
+            open = true;
+            if (timers_on()) { char buf[64]; snprintf(buf, sizeof buf, "stage_%s", name); idx = timer_begin(buf, s); }
+        }
+        ~StageMarks() { close(); }
+    } marks{S(stream)};
     marks.next("commit");
     sp1hip_challenger_t* ch = nullptr;
     SP1HIP_TRY(sp1hip_challenger_clone(challenger, &ch));
