@@ -120,13 +120,85 @@ constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB
 typedef uint32_t zc_word_t __attribute__((ext_vector_type(4)));       // one instruction: op | flags, dst, a, b
 typedef const zc_word_t __attribute__((address_space(4)))* zc_const_prog_t;
 
+// ---- the first two rounds in one pass over the base-field traces ("bivariate", the reference's
+// sp1-gpu/crates/sys/include/zerocheck/bivariate.cuh:L1-L118 restated for this interpreter) ---------------------------------
+// Rows are taken four at a time (row 4 q + 2 X + Y: Y is the last variable, bound by round 0, X the one round 1 binds) and the
+// constraint polynomial is summed on the grid {0, 1, 2, 4}^2 minus its four boolean corners (constraints vanish on real rows,
+// and a padded row's value cancels against the geq correction): per node e the kernels leave
+//     A_e = sum_q eq(q) C(T_q(X_e, Y_e)),      T_q(X, Y) = r00 + X (r10 - r00) + Y (r01 - r00) + X Y (r11 - r10 - r01 + r00)
+// with eq over the nv - 2 variables of the quad index, and the four corner sums B of the (linear) GKR batching term; the host
+// assembles BOTH round messages from them (zerocheck_prove_impl): round 0 needs H(X, t) for X in {0, 1}, t in {0, 2, 4}, round 1
+// the cubic through H(t, 0), H(t, 1), H(t, 2), H(t, 4) at the first challenge. Everything is base-field arithmetic — round 1's
+// extension-field pass over the once-folded tables (the most expensive round of the sequential form) and one of the two table
+// updates disappear. Node order (X, Y): (0,2) (0,4) (1,2) (1,4) (2,0) (2,1) (2,2) (2,4) (4,0) (4,1) (4,2) (4,4).
+constexpr int ZC_BIV_NODES = 12;
+struct ZcBivNode { uint32_t cx, cy, cxy; };
+__host__ __device__ __forceinline__ ZcBivNode zc_biv_node(uint32_t e) {       // wave-uniform e: the fields stay in SGPRs
+    constexpr uint32_t XS[12] = {0, 0, 1, 1, 2, 2, 2, 2, 4, 4, 4, 4}, YS[12] = {2, 4, 2, 4, 0, 1, 2, 4, 0, 1, 2, 4};
+    return ZcBivNode{XS[e], YS[e], XS[e] * YS[e]};
+}
+// v < 2^36 -> v mod p, reduced: with v = t 2^31 + lo, v - t p = lo + t (2^24 - 1) < 2 p
+__host__ __device__ __forceinline__ uint32_t zc_reduce36(uint64_t v) {
+    const uint32_t t = (uint32_t)(v >> 31), lo = (uint32_t)v & 0x7fffffffu;
+    const uint32_t r = lo + t * 0xffffffu;
+    return kb::umin(r, r - kb::P);
+}
+__host__ __device__ __forceinline__ uint32_t zc_biv_interp(uint32_t r00, uint32_t r01, uint32_t r10, uint32_t r11, const ZcBivNode& nd) {
+    const uint32_t dy = kb::sub(r01, r00), dx = kb::sub(r10, r00), dxy = kb::sub(kb::sub(r11, r10), dy);
+    return zc_reduce36((uint64_t)r00 + (uint64_t)nd.cx * dx + (uint64_t)nd.cy * dy + (uint64_t)nd.cxy * dxy);   // <= (1 + 4 + 4 + 16) p
+}
+// column `col` of the quad q at node nd (rows past the table's height are zero: the virtual padding)
+__device__ __forceinline__ uint32_t zc_biv_leaf(const uint32_t* tbl, uint32_t col, uint32_t rows, uint32_t q, const ZcBivNode& nd) {
+    const zc_global_words_t g = (zc_global_words_t)tbl + (size_t)col * rows;
+    const uint32_t r = 4 * q;
+    const uint32_t r00 = g[r], r01 = r + 1 < rows ? g[r + 1] : 0u, r10 = r + 2 < rows ? g[r + 2] : 0u, r11 = r + 3 < rows ? g[r + 3] : 0u;
+    return zc_biv_interp(r00, r01, r10, r11, nd);
+}
+
+// Four nodes per pass: the interpreter's cost per base-field operation is mostly decode and register-file traffic, so one pass
+// of the program carries the values of FOUR grid nodes (nodes 4 g .. 4 g + 3) in an Ext-shaped container — the instruction is
+// decoded once, the register file is the extension rounds' (16-byte slots), the arithmetic is element-wise.
+struct KT4 {
+    using T = kb::Ext;
+    static __device__ __forceinline__ T zero() { return kb::ext_zero(); }
+    static __device__ __forceinline__ T from_f(uint32_t x) { return kb::Ext{{x, x, x, x}}; }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return kb::ext_add(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return kb::ext_sub(a, b); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) {
+        return kb::Ext{{kb::mul(a.c[0], b.c[0]), kb::mul(a.c[1], b.c[1]), kb::mul(a.c[2], b.c[2]), kb::mul(a.c[3], b.c[3])}};
+    }
+};
+struct KC4 {
+    static __device__ __forceinline__ kb::Ext addc(const kb::Ext& a, uint32_t c) { return kb::Ext{{kb::add(a.c[0], c), kb::add(a.c[1], c), kb::add(a.c[2], c), kb::add(a.c[3], c)}}; }
+    static __device__ __forceinline__ kb::Ext subc(const kb::Ext& a, uint32_t c) { return kb::Ext{{kb::sub(a.c[0], c), kb::sub(a.c[1], c), kb::sub(a.c[2], c), kb::sub(a.c[3], c)}}; }
+    static __device__ __forceinline__ kb::Ext csub(uint32_t c, const kb::Ext& a) { return kb::Ext{{kb::sub(c, a.c[0]), kb::sub(c, a.c[1]), kb::sub(c, a.c[2]), kb::sub(c, a.c[3])}}; }
+    static __device__ __forceinline__ kb::Ext mulc(const kb::Ext& a, uint32_t c) { return kb::ext_mul_base(a, c); }
+};
+// column `col` of the quad q at the four nodes of group g: the rows are loaded once
+__device__ __forceinline__ kb::Ext zc_biv_leaf4(const uint32_t* tbl, uint32_t col, uint32_t rows, uint32_t q, uint32_t grp) {
+    const zc_global_words_t g = (zc_global_words_t)tbl + (size_t)col * rows;
+    const uint32_t r = 4 * q;
+    const uint32_t r00 = g[r], r01 = r + 1 < rows ? g[r + 1] : 0u, r10 = r + 2 < rows ? g[r + 2] : 0u, r11 = r + 3 < rows ? g[r + 3] : 0u;
+    const uint32_t dy = kb::sub(r01, r00), dx = kb::sub(r10, r00), dxy = kb::sub(kb::sub(r11, r10), dy);
+    kb::Ext out;
+#pragma unroll
+    for (uint32_t n = 0; n < 4; n++) {
+        const ZcBivNode nd = zc_biv_node(4 * grp + n);
+        out.c[n] = zc_reduce36((uint64_t)r00 + (uint64_t)nd.cx * dx + (uint64_t)nd.cy * dy + (uint64_t)nd.cxy * dxy);
+    }
+    return out;
+}
+
 // One pass of the program at node t. With `gkr`, the first load of every column also accumulates
 // gkr_pow[column] * value into *g (main columns first, then preprocessed): the batching term costs no
 // extra loads. `prog` points to LDS (or global memory for very long programs).
-template <bool FIRST, int MAXR, typename PROG>
-__device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG prog, const ZcDesc& d,
+// BIV: i is a quad index and t a node GROUP of the bivariate grid (nodes 4 t .. 4 t + 3, KT4: four base-field values per
+// register, the extension rounds' register file); the four constraint sums are ADDED to g[0..4), no GKR term here.
+template <bool FIRST, int MAXR, bool BIV = false, typename PROG>
+__device__ __forceinline__ kb::Ext run_program(RegFile<(BIV ? false : FIRST), MAXR>& reg, PROG prog, const ZcDesc& d,
                                                const uint32_t* __restrict__ publics, uint32_t i, int t, const bool gkr, kb::Ext* g) {
-    using K = KT<FIRST>;
+    using K = typename std::conditional<BIV, KT4, KT<FIRST>>::type;
+    using KCc = typename std::conditional<BIV, KC4, KC<FIRST>>::type;
     using T = typename K::T;
     kb::Ext acc = kb::ext_zero();
     T prev = K::zero();                   // the value the last value-producing instruction produced (operand forwarding)
@@ -141,6 +213,19 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
             const uint32_t cnt = ((opw >> 16) & 3u) + 1;
             const uint32_t* tbl = op == ZC_LOAD_MAIN ? d.main : d.prep;
             const uint32_t gbase = op == ZC_LOAD_MAIN ? 0u : d.main_w;
+            if constexpr (BIV) {
+                T v[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (j < cnt) v[j] = zc_biv_leaf4(tbl, x + j, d.rows, i, (uint32_t)t);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (j < cnt) {
+                        if (!(opw & ZC_DST_TEMP)) reg.set(dst + j, v[j]);
+                        prev = v[j];
+                    }
+                continue;
+            } else {
             T r0[4], r1[4];
             const bool odd = 2 * i + 1 < d.rows;
 #pragma unroll
@@ -162,17 +247,26 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
                     prev = v;
                 }
             continue;
+            }
         }
         if (op == ZC_TOUCH) {
-            if (gkr) {
-                T v = leaf<FIRST>(y ? d.prep : d.main, x, d.rows, i, t);
-                *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, (y ? d.main_w : 0u) + x), v));
+            if constexpr (!BIV) {
+                if (gkr) {
+                    T v = leaf<FIRST>(y ? d.prep : d.main, x, d.rows, i, t);
+                    *g = kb::ext_add(*g, K::scale(load_ext_aos(d.gkr_pows, (y ? d.main_w : 0u) + x), v));
+                }
             }
             continue;
         }
         if (op == ZC_ASSERT_ZERO) {                                   // y: the constraint's index; `prev` stays what it was
             const T a = (opw & ZC_A_PREV) ? prev : reg.get(x);
-            acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, y), a));
+            if constexpr (BIV) {
+                const kb::Ext pw = load_ext_aos(d.alpha_pows, y);
+#pragma unroll
+                for (int n = 0; n < 4; n++) g[n] = kb::ext_add(g[n], kb::ext_mul_base(pw, a.c[n]));
+            } else {
+                acc = kb::ext_add(acc, K::scale(load_ext_aos(d.alpha_pows, y), a));
+            }
             continue;
         }
         // The forwarded value `prev` is dead once this instruction has read it, so the A operand is loaded INTO it when it
@@ -183,11 +277,11 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
         if (op == ZC_MADC) {
             if (opw & ZC_B_PREV) {                                    // the running sum is the forwarded value
                 const T term = (opw & ZC_A_PREV) ? prev : reg.get(x);
-                res = K::add(prev, KC<FIRST>::mulc(term, y));
+                res = K::add(prev, KCc::mulc(term, y));
             } else {
                 const T accv = reg.get(dst >> 16);
                 if (!(opw & ZC_A_PREV)) prev = reg.get(x);
-                res = K::add(accv, KC<FIRST>::mulc(prev, y));
+                res = K::add(accv, KCc::mulc(prev, y));
             }
         } else if (op == ZC_CONST) {
             res = K::from_f(x);                                       // host pre-converts to Montgomery
@@ -201,10 +295,10 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<FIRST, MAXR>& reg, PROG p
                 case ZC_RSUB: res = K::sub(reg.get(y), prev); break;
                 case ZC_MUL: res = K::mul(prev, (opw & ZC_B_PREV) ? prev : reg.get(y)); break;
                 case ZC_NEG: res = K::sub(K::zero(), prev); break;
-                case ZC_ADDC: res = KC<FIRST>::addc(prev, y); break;
-                case ZC_SUBC: res = KC<FIRST>::subc(prev, y); break;
-                case ZC_CSUB: res = KC<FIRST>::csub(y, prev); break;
-                default: res = KC<FIRST>::mulc(prev, y); break;      // ZC_MULC
+                case ZC_ADDC: res = KCc::addc(prev, y); break;
+                case ZC_SUBC: res = KCc::subc(prev, y); break;
+                case ZC_CSUB: res = KCc::csub(y, prev); break;
+                default: res = KCc::mulc(prev, y); break;      // ZC_MULC
             }
         }
         prev = res;
@@ -443,6 +537,168 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
     }
 }
 
+// ---- bivariate kernels. Interpreter: blockIdx.x = 3 b + g -> (block b of `block_pairs` row QUADS of one chunk, node group g =
+// nodes 4 g .. 4 g + 3, four node values per register: KT4). A node's slot is [A | B] like the single-round kernels': A = sum eq
+// C(node e); B = the GKR batching term's corner sum (X, Y) = (e >> 1, e & 1) for e < 4 from the chip's first chunk (zero
+// elsewhere). partial[(12 bid + e) * 8 ..).
+constexpr uint32_t ZC_BIV_GROUPS = 3;
+template <int MAXR, bool STAGED>
+__global__ __launch_bounds__(256) void zc_biv_round_kernel(const ZcDesc* __restrict__ descs, int n_descs,
+                                                           const uint32_t* __restrict__ eq, uint32_t eq_len,
+                                                           const uint32_t* __restrict__ publics, uint32_t* __restrict__ partial,
+                                                           uint32_t rf_off, uint32_t block_base) {
+    using K = KT<true>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* red = lds;                                   // [4][8] reduction scratch
+    uint4* lprog = reinterpret_cast<uint4*>(lds + 32);
+    RegFile<false, MAXR> reg;                              // four base-field values per register (KT4)
+    if constexpr (MAXR == 0) {
+        reg.base = (decltype(reg.base))(lds + rf_off) + threadIdx.x;
+        reg.stride = blockDim.x;
+    }
+    if (threadIdx.x < 32) red[threadIdx.x] = 0;
+    const uint32_t bid = block_base + blockIdx.x / ZC_BIV_GROUPS;
+    const uint32_t grp = blockIdx.x % ZC_BIV_GROUPS;
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    if constexpr (STAGED) {
+        const uint4* src = reinterpret_cast<const uint4*>(d.prog);
+        for (uint32_t k = threadIdx.x; k < d.n_instr; k += blockDim.x) lprog[k] = src[k];
+    }
+    __syncthreads();
+    const uint32_t quads = (d.rows + 3) / 4;
+    const bool corners = grp == 0 && (d.flags & 1u);
+    kb::Ext sa[4], sb[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) { sa[n] = kb::ext_zero(); sb[n] = kb::ext_zero(); }
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < quads; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, quads); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        kb::Ext va[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+        if constexpr (STAGED) (void)run_program<true, MAXR, true>(reg, (const zc_word_t*)lprog, d, publics, i, (int)grp, false, va);
+        else (void)run_program<true, MAXR, true>(reg, (zc_const_prog_t)(uintptr_t)d.prog, d, publics, i, (int)grp, false, va);
+#pragma unroll
+        for (int n = 0; n < 4; n++) sa[n] = kb::ext_add(sa[n], kb::ext_mul(va[n], e));
+        if (corners) {                                      // row 4 i + n of every column, weighted by the GKR powers
+            kb::Ext vb[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+            for (uint32_t c = 0; c < d.main_w + d.prep_w; c++) {
+                const kb::Ext pw = load_ext_aos(d.gkr_pows, c);
+                const uint32_t* tbl = c < d.main_w ? d.main : d.prep;
+                const uint32_t col = c < d.main_w ? c : c - d.main_w;
+#pragma unroll
+                for (uint32_t n = 0; n < 4; n++)
+                    if (4 * i + n < d.rows) vb[n] = kb::ext_add(vb[n], K::scale(pw, K::load(tbl, col, d.rows, 4 * i + n)));
+            }
+#pragma unroll
+            for (int n = 0; n < 4; n++) sb[n] = kb::ext_add(sb[n], kb::ext_mul(vb[n], e));
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = sa[n].c[k]; v[4 + k] = sb[n].c[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = zc_wave_sum(v[k]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) red[wave * 8 + k] = v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const uint32_t k = threadIdx.x;
+            partial[((size_t)bid * ZC_BIV_NODES + 4 * grp + n) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
+        }
+    }
+}
+
+// the fused pieces on the bivariate grid (base-field arithmetic: the pieces' P2Base forms; no GKR term here)
+template <uint32_t KIND>
+__global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                           uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
+                                                           const p2::RoundConstants* __restrict__ rc_p) {
+    using K = KT<true>;
+    __shared__ uint32_t red[32];
+    if (threadIdx.x < 32) red[threadIdx.x] = 0;
+    const uint32_t bid = block_base + blockIdx.x / (uint32_t)ZC_BIV_NODES;
+    const uint32_t node = blockIdx.x % (uint32_t)ZC_BIV_NODES;
+    const ZcBivNode nd = zc_biv_node(node);
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const uint32_t q = (d.flags >> 8) & 15u, base_col = d.pad;
+    const auto* rc = (const p2::RoundConstants __attribute__((address_space(4)))*)(uintptr_t)rc_p;
+    __syncthreads();
+    const uint32_t quads = (d.rows + 3) / 4;
+    kb::Ext sa = kb::ext_zero();
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < quads; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, quads); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        kb::Ext va = kb::ext_zero();
+        auto ld_at = [&](uint32_t col, bool) -> uint32_t { return zc_biv_leaf(d.main, col, d.rows, i, nd); };
+        auto ld = [&](uint32_t c, bool owned) -> uint32_t { return ld_at(base_col + c, owned); };
+        auto sink = [&](uint32_t j, const uint32_t& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
+        if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<P2Base>(q, rc, ld, sink);
+        else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<P2Base>(ld, sink);
+        else zc_septic_sum_piece<P2Base>(q, ld, [&](uint32_t c, bool owned) -> uint32_t { return ld_at(d.aux0 + c, owned); },
+                                         [&]() -> uint32_t { return ld_at(d.aux1, false); }, sink);
+        sa = kb::ext_add(sa, kb::ext_mul(va, e));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = zc_wave_sum(sa.c[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) red[wave * 8 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const uint32_t k = threadIdx.x;
+        partial[((size_t)bid * ZC_BIV_NODES + node) * 8 + k] = k < 4 ? kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k])) : 0u;
+    }
+}
+
+// One workgroup per range: A_e summed over the range's blocks (12 ext), the four corner sums B (4 ext), eq[th] (1 ext):
+// out[range][68] and, with a host slot, payload words [1 + 68 range ..); the last workgroup publishes `seq`.
+constexpr uint32_t ZC_BIV_SUM_WORDS = 68;
+__global__ __launch_bounds__(256) void zc_biv_reduce_kernel(const ZcChipRange* __restrict__ ranges, const uint32_t* __restrict__ partial,
+                                                            const uint32_t* __restrict__ eq, uint32_t eq_len,
+                                                            uint32_t* __restrict__ out, RoundSync rs, uint32_t seq) {
+    __shared__ uint32_t acc[2][96];
+    const ZcChipRange d = ranges[blockIdx.x];
+    const uint32_t word = threadIdx.x % 96, grp = threadIdx.x / 96;       // two groups of 96 words (12 nodes x [A | B])
+    if (grp < 2) {
+        const uint32_t* p = partial + (size_t)d.block_start * 96 + word;
+        uint32_t a[4] = {0, 0, 0, 0};
+        uint32_t b = grp;
+        for (; b + 6 < d.n_blocks; b += 8)
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[u] = kb::add(a[u], p[(size_t)(b + 2 * u) * 96]);
+        for (; b < d.n_blocks; b += 2) a[0] = kb::add(a[0], p[(size_t)b * 96]);
+        acc[grp][word] = kb::add(kb::add(a[0], a[1]), kb::add(a[2], a[3]));
+    }
+    __syncthreads();
+    if (threadIdx.x < ZC_BIV_SUM_WORDS) {
+        const uint32_t w = threadIdx.x;
+        uint32_t val;
+        if (w < 48) { const uint32_t e = w >> 2, k = w & 3; val = kb::add(acc[0][e * 8 + k], acc[1][e * 8 + k]); }                 // A_e
+        else if (w < 64) { const uint32_t e = (w - 48) >> 2, k = w & 3; val = kb::add(acc[0][e * 8 + 4 + k], acc[1][e * 8 + 4 + k]); }   // B_e, e < 4
+        else { const uint32_t k = w - 64; val = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u; }
+        out[(size_t)blockIdx.x * ZC_BIV_SUM_WORDS + w] = val;
+        if (rs.host_slot != nullptr)
+            __hip_atomic_store(const_cast<uint32_t*>(rs.host_slot) + 1 + (size_t)blockIdx.x * ZC_BIV_SUM_WORDS + w, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (rs.host_slot == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && rs_ticket_is_last_acq_rel(rs.counter, blockIdx.x, gridDim.x)) rs_publish_seq(rs.host_slot, seq);
+}
+
 // One workgroup per chip: sums its workgroups' partials and forms (y0, y2, y4, eq[th]) -> out[chip][16].
 template <bool FIRST>
 __global__ __launch_bounds__(256) void zc_reduce_kernel(const ZcChipRange* __restrict__ ranges, const uint32_t* __restrict__ partial,
@@ -495,6 +751,38 @@ __global__ __launch_bounds__(256) void zc_fix_kernel(const ZcFixDesc* __restrict
         const kb::Ext r = kb::ext_add(K::scale(alpha, K::sub(y, x)), K::to_ext(x));
 #pragma unroll
         for (int q = 0; q < 4; q++) gptr(d.out)[((size_t)c * 4 + q) * out_rows + i] = r.c[q];
+    }
+}
+
+// The table update behind the bivariate rounds: out[q][c] = T_q(X = a1, Y = a0) — the fold by the first challenge and then by
+// the second, from the base-field rows (fix_last_variable.rs applied twice): one pass, 4 A bytes read and 4 A written instead of
+// 4 A + 8 A read and 8 A + 4 A written by two updates. Descriptors as for zc_fix_kernel with out_rows = ceil(rows / 4).
+__global__ __launch_bounds__(256) void zc_fix2_kernel(const ZcFixDesc* __restrict__ descs, int n_descs, kb::Ext a0, kb::Ext a1) {
+    int lo = 0, hi = n_descs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (__builtin_amdgcn_readfirstlane(descs[mid].block_start) <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ZcFixDesc d = descs[lo];
+    const uint32_t out_rows = (d.rows + 3) / 4;
+    const uint32_t lb = blockIdx.x - d.block_start;
+    uint32_t c = d.bpc == 1 ? lb : __umulhi(lb, d.bpc_magic);
+    uint32_t tile = lb - c * d.bpc;
+    if (tile >= d.bpc) { tile -= d.bpc; c++; }
+    if (tile >= d.bpc) { tile -= d.bpc; c++; }
+    const uint32_t i0 = tile * ZC_FIX_ROWS, i1 = min(out_rows, i0 + ZC_FIX_ROWS);
+    const zc_global_words_t g = (zc_global_words_t)d.in + (size_t)c * d.rows;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256u) {
+        const uint32_t r = 4 * i;
+        const uint32_t r00 = g[r], r01 = r + 1 < d.rows ? g[r + 1] : 0u, r10 = r + 2 < d.rows ? g[r + 2] : 0u, r11 = r + 3 < d.rows ? g[r + 3] : 0u;
+        const uint32_t dy = kb::sub(r01, r00), dx = kb::sub(r10, r00), dxy = kb::sub(kb::sub(r11, r10), dy);
+        kb::Ext lo_row = kb::ext_mul_base(a0, dy);             // row 2 i of the once-folded table: r00 + a0 (r01 - r00)
+        lo_row.c[0] = kb::add(lo_row.c[0], r00);
+        kb::Ext slope = kb::ext_mul_base(a0, dxy);             // (row 2 i + 1) - (row 2 i) = (r10 - r00) + a0 ((r11 - r10) - (r01 - r00))
+        slope.c[0] = kb::add(slope.c[0], dx);
+        const kb::Ext res = kb::ext_add(lo_row, kb::ext_mul(slope, a1));
+#pragma unroll
+        for (int k = 0; k < 4; k++) gptr(d.out)[((size_t)c * 4 + k) * out_rows + i] = res.c[k];
     }
 }
 
@@ -1246,6 +1534,37 @@ void challenger_observe(sp1hip_challenger_t* ch, uint32_t x);
 kb::Ext challenger_sample_ext(sp1hip_challenger_t* ch);
 void challenger_restore(sp1hip_challenger_t* dst, const sp1hip_challenger_t* src);
 // basefold.hip: every prefix table of eq over the first t coordinates of a point, t = 0..d, one launch
+// the same for the bivariate kernels: three node-group workgroups per block of row quads, the extension rounds' register file
+static int launch_biv_round(uint32_t max_regs, bool staged, const ZcDesc* d_descs, int n_descs, uint32_t block_lo, uint32_t n_blocks,
+                            uint32_t max_instr, const uint32_t* eq, uint32_t eq_len, const uint32_t* publics, uint32_t* partial, hipStream_t s) {
+    const size_t lds = 32 * 4 + (staged ? (size_t)max_instr * 16 : 0);
+    const dim3 grid(n_blocks * ZC_BIV_GROUPS);
+    static const bool force_vgpr = [] { const char* e = getenv("SP1HIP_ZC_REGFILE"); return e && e[0] == 'v'; }();
+    const uint32_t wg = force_vgpr ? 0 : zc_wg_for<false>(max_regs, lds);      // 16-byte slots: four node values per register
+    if (wg) {
+        const size_t total = lds + zc_rf_lane_bytes<false>(max_regs) * wg;
+        if (staged) {
+            auto kern = zc_biv_round_kernel<0, true>;
+            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
+        } else {
+            auto kern = zc_biv_round_kernel<0, false>;
+            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
+        }
+        SP1HIP_LAUNCH_CHECK();
+        return SP1HIP_SUCCESS;
+    }
+    SP1HIP_REQUIRE(staged, "internal: unstaged program without an LDS register file");
+    if (max_regs <= 16) hipLaunchKernelGGL((zc_biv_round_kernel<16, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    else if (max_regs <= 32) hipLaunchKernelGGL((zc_biv_round_kernel<32, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    else if (max_regs <= 256) hipLaunchKernelGGL((zc_biv_round_kernel<256, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_biv_round_kernel<1024, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
+    else { set_error("constraint program needs %u live registers (max 1024)", max_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
+    SP1HIP_LAUNCH_CHECK();
+    return SP1HIP_SUCCESS;
+}
+
 int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s);
 }
 
@@ -1412,6 +1731,81 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     zc_t1 = std::chrono::steady_clock::now();
     auto zc_iter_t = zc_t1;
     double zc_plan_ms = 0, zc_wait_ms = 0, zc_uni_ms = 0;
+    // ---- one round's messages from the chips' values at 0, 2, 4 (sum_as_poly.rs:L187-L287), the transcript, the state behind it.
+    // hv[i][k]: chip i's round polynomial at X = 0, 2, 4 WITHOUT the eq factor of the variable being bound (`last` = its zeta
+    // coordinate); the value at 1 comes from the chip's running claim. sum_as_poly interpolates through {0, 1, 2, 4, b} with the
+    // value at b equal to zero. Closed form, no allocation: the Lagrange basis polynomial of node x_k in {0, 1, 2, 4} is
+    // C_k(X) (X - b) / (x_k - b), with C_k the basis polynomial of x_k among those four nodes alone — constants of the field:
+    //   C_0 = (X^3 - 7 X^2 + 14 X - 8) / -8, C_1 = (X^3 - 6 X^2 + 8 X) / 3, C_2 = (X^3 - 5 X^2 + 4 X) / -4, C_3 = (X^3 - 3 X^2 + 2 X) / 24
+    // so a chip's univariate is (X - b) sum_k z_k C_k(X) with z_k = y_k / (x_k - b); the four inverses come from one
+    // inversion (Montgomery's trick). Exact field arithmetic: the same polynomial as any other interpolation.
+    static const struct CubicBasis {
+        uint32_t c[4][4];                                     // c[k][d]: coefficient of X^d in C_k (Montgomery base words)
+        CubicBasis() {
+            const int num[4][4] = {{-8, 14, -7, 1}, {0, 8, -6, 1}, {0, 4, -5, 1}, {0, 2, -3, 1}};
+            const int den[4] = {-8, 3, -4, 24};
+            for (int k = 0; k < 4; k++) {
+                const uint32_t dm = kb::to_monty(den[k] < 0 ? kb::P - (uint32_t)(-den[k]) : (uint32_t)den[k]);
+                const uint32_t dinv = kb::ext_inv(kb::ext_from_base(dm)).c[0];
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t nm = kb::to_monty(num[k][d] < 0 ? kb::P - (uint32_t)(-num[k][d]) : (uint32_t)num[k][d]);
+                    c[k][d] = kb::mul(nm, dinv);
+                }
+            }
+        }
+    } cubic;
+    auto round_messages = [&](const Ext& last, const std::vector<std::array<Ext, 3>>& hv) -> Ext {
+        const Ext b_node = (kb::ext_one() - last) * kb::ext_inv(kb::ext_one() - (last + last));
+        Ext inv_xb[4];                                            // 1 / (x_k - b), x = 0, 1, 2, 4
+        {
+            const Ext dx[4] = {kb::ext_zero() - b_node, kb::ext_one() - b_node, ext_c(2) - b_node, ext_c(4) - b_node};
+            const Ext p01 = dx[0] * dx[1], p012 = p01 * dx[2], p0123 = p012 * dx[3];
+            Ext run = kb::ext_inv(p0123);
+            inv_xb[3] = run * p012; run = run * dx[3];
+            inv_xb[2] = run * p01; run = run * dx[2];
+            inv_xb[1] = run * dx[0];
+            inv_xb[0] = run * dx[1];
+        }
+        const Ext three = ext_c(3), seven = ext_c(7);
+        const Ext f0 = kb::ext_one() - last, f2 = last * three - kb::ext_one(), f4 = last * seven - three;
+        if ((int)uni.size() != n_chips) uni.assign(n_chips, UniPoly(5, kb::ext_zero()));
+        for (int i = 0; i < n_chips; i++) {
+            ChipState& c = *st[i];
+            UniPoly& u = uni[i];
+            if (c.rows == 0) { for (auto& cf : u) cf = kb::ext_zero(); continue; }
+            const Ext y0 = hv[i][0] * f0, y2 = hv[i][1] * f2, y4 = hv[i][2] * f4;
+            const Ext z[4] = {y0 * inv_xb[0], (round_claims[i] - y0) * inv_xb[1], y2 * inv_xb[2], y4 * inv_xb[3]};
+            Ext g[4];                                             // sum_k z_k C_k(X)
+            for (int d = 0; d < 4; d++) {
+                Ext acc = kb::ext_mul_base(z[0], cubic.c[0][d]);
+                for (int k = 1; k < 4; k++) acc = acc + kb::ext_mul_base(z[k], cubic.c[k][d]);
+                g[d] = acc;
+            }
+            u[0] = kb::ext_zero() - b_node * g[0];
+            for (int d = 1; d < 4; d++) u[d] = g[d - 1] - b_node * g[d];
+            u[4] = g[3];
+        }
+        UniPoly rlc(n_chips ? 5 : 1, kb::ext_zero());
+        for (auto& u : uni)
+            for (int d = 0; d < 5; d++) rlc[d] = rlc[d] * lambda + u[d];
+        for (auto& cf : rlc)
+            for (int k = 0; k < 4; k++) challenger_observe(challenger, cf.c[k]);
+        msgs.push_back(rlc);
+        const Ext a_r = challenger_sample_ext(challenger);
+        point.insert(point.begin(), a_r);
+        for (int i = 0; i < n_chips; i++) {
+            round_claims[i] = uni_eval(uni[i], a_r);
+            st[i]->uni = uni[i];
+        }
+        // the variable is bound: the virtual geq polynomial and the eq factor of the bound variables follow (fix_last_variable.rs)
+        for (int i = 0; i < n_chips; i++) {
+            ChipState& c = *st[i];
+            c.vgeq = c.vgeq.fix(a_r);
+            if (c.rows == 0) continue;
+            c.eq_adj = c.eq_adj * (a_r * last + (kb::ext_one() - a_r) * (kb::ext_one() - last));
+        }
+        return a_r;
+    };
     // ---- the plan of a round: which chips run in which form, the descriptors of every launch, the reduction ranges and the table
     // update that ends the round. It depends on the tables' heights and addresses only — not on anything the transcript
     // produces — so round r + 1 is planned and its descriptors uploaded while round r's kernels run (the host used to do
@@ -1432,8 +1826,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<uint64_t> rows_next;
         std::vector<const uint32_t*> main_next, prep_next;
     };
+    // biv: the plan of rounds 0 AND 1 together (bivariate kernels): the units are row quads, the table update folds by both
+    // challenges (zc_fix2_kernel) into the buffer round 1 would have written, the reduction ranges carry the quad of the first padded row
     auto plan_round = [&](int r, const std::vector<uint64_t>& vrows, const std::vector<const uint32_t*>& vmain,
-                          const std::vector<const uint32_t*>& vprep, RoundPlan& rp) -> int {
+                          const std::vector<const uint32_t*>& vprep, RoundPlan& rp, bool biv) -> int {
+        const uint64_t unit = biv ? 4 : 2;                  // rows per term
         // descriptors: one per (chip with real rows, chunk); a chip's blocks are contiguous. Chips are grouped by how
         // their programs run this round — (program staged in LDS?, workgroup width the LDS register file allows) — and
         // every group is one launch over its contiguous block range.
@@ -1446,10 +1843,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
             if (vrows[i] == 0) continue;
-            const uint32_t terms = (uint32_t)((vrows[i] + 1) / 2);
+            const uint32_t terms = (uint32_t)((vrows[i] + unit - 1) / unit);
             uint32_t mono_regs = 1;
             for (auto& ck : c.mono) mono_regs = std::max(mono_regs, ck.n_regs);
-            const uint32_t mono_wg = r == 0 ? zc_wg_for<true>(mono_regs, 128) : zc_wg_for<false>(mono_regs, 128);
+            const uint32_t mono_wg = (r == 0 && !biv) ? zc_wg_for<true>(mono_regs, 128) : zc_wg_for<false>(mono_regs, 128);
             // the undivided program pays off when chunking recomputes a lot (long dependency chains shared by many
             // constraints); a program of self-contained constraints runs as chunks in every round: same work, small
             // register files, and as many workgroups as there are constraints
@@ -1471,7 +1868,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             // (recursion shard 14.6 vs 13.8 ms of round kernels, core-shaped 10.4 vs 10.1); the VGPR / scratch tier still stages.
             const uint32_t stage_max = [] { const char* e = getenv("SP1HIP_ZC_STAGE_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();   // read per call (tests)
             bool staged = instr <= stage_max;
-            uint32_t wg = r == 0 ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
+            uint32_t wg = (r == 0 && !biv) ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
             if (wg == 0) {                  // the file does not fit LDS: VGPR / scratch tier, program staged
                 SP1HIP_REQUIRE(instr <= ZC_LDS_PROG_MAX, "constraint program too large (one constraint with too many live values)");
                 staged = true;
@@ -1489,14 +1886,14 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             g.block_lo = total_blocks;
             for (int i : g.chips) {
                 ChipState& c = *st[i];
-                const uint32_t terms = (uint32_t)((vrows[i] + 1) / 2);
+                const uint32_t terms = (uint32_t)((vrows[i] + unit - 1) / unit);
                 const uint32_t bp = g.wg ? g.wg : 256u;
                 uint32_t blocks = (terms + bp - 1) / bp;
                 static const uint32_t max_pairs = [] { const char* e = getenv("SP1HIP_ZC_MAX_PAIRS"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 256u) : 131072u; }();
                 if (blocks > max_pairs / bp) blocks = std::max(1u, max_pairs / bp);
                 const std::vector<Chunk>& cks = use_mono[i] == 1 ? c.mono : use_mono[i] == 2 ? c.fine : c.chunks;
                 const std::vector<uint32_t>& offs = use_mono[i] == 1 ? c.mono_off : use_mono[i] == 2 ? c.fine_off : c.chunk_off;
-                ZcChipRange rg{total_blocks, 0, terms - 1, 0};
+                ZcChipRange rg{total_blocks, 0, biv ? (uint32_t)(vrows[i] / 4) : terms - 1, 0};
                 for (size_t q = 0; q < cks.size(); q++) {
                     ZcDesc d{};
                     d.prog = c.p_prog + (size_t)offs[q] * 4;
@@ -1524,9 +1921,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             for (int i = 0; i < n_chips; i++) {
                 ChipState& c = *st[i];
                 if (vrows[i] == 0) continue;
-                const uint32_t terms = (uint32_t)((vrows[i] + 1) / 2);
+                const uint32_t terms = (uint32_t)((vrows[i] + unit - 1) / unit);
                 const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
-                ZcChipRange rg{total_blocks, 0, terms - 1, 0};
+                ZcChipRange rg{total_blocks, 0, biv ? (uint32_t)(vrows[i] / 4) : terms - 1, 0};
                 for (const ZcMacro& m : c.macros) {
                     if (m.kind != kind) continue;
                     for (uint32_t q = 0; q < m.n_pieces(); q++) {
@@ -1553,11 +1950,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         uint32_t& fix_blocks = rp.fix_blocks;
         fix_blocks = 0;
         size_t fold_words = 0;
-        uint32_t* const fold_base = (uint32_t*)d_fold[r & 1].p;
+        uint32_t* const fold_base = (uint32_t*)d_fold[biv ? 1 : (r & 1)].p;
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
             if (vrows[i] == 0) continue;
-            const uint64_t out_rows = (vrows[i] + 1) / 2;
+            const uint64_t out_rows = (vrows[i] + unit - 1) / unit;
             for (int which = 0; which < 2; which++) {
                 const uint32_t width = which == 0 ? c.in->main_width : c.in->prep_width;
                 if (width == 0) continue;
@@ -1589,7 +1986,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         for (size_t k = 0; k < fds.size(); k++) {
             if (owner[k].second) rp.main_next[owner[k].first] = fresh[k]; else rp.prep_next[owner[k].first] = fresh[k];
         }
-        for (int i = 0; i < n_chips; i++) if (rp.rows_next[i]) rp.rows_next[i] = (rp.rows_next[i] + 1) / 2;
+        for (int i = 0; i < n_chips; i++) if (rp.rows_next[i]) rp.rows_next[i] = (rp.rows_next[i] + unit - 1) / unit;
         return SP1HIP_SUCCESS;
     };
     // the descriptors of rounds r and r + 1 live in two buffers: round r + 1's go up while round r's launches read theirs
@@ -1603,6 +2000,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         return stage.upload(d_descs2[which].p, rp.pack.data(), rp.pack_bytes);
     };
+    // SP1HIP_ZC_BIVARIATE=0: the sequential first two rounds (A/B runs; the proof bytes are the same)
+    static const bool biv_enabled = [] { const char* e = getenv("SP1HIP_ZC_BIVARIATE"); return !(e && e[0] == '0'); }();
+    const bool biv = biv_enabled && L >= 2;
     std::vector<std::unique_ptr<RoundPlan>> plans;           // (kept until the call returns)
     {
         std::vector<uint64_t> rows0(n_chips);
@@ -1610,11 +2010,176 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         for (int i = 0; i < n_chips; i++) { rows0[i] = st[i]->rows; main0[i] = st[i]->d_main; prep0[i] = st[i]->d_prep; }
         plans.emplace_back(new RoundPlan());
         if (L > 0) {
-            SP1HIP_TRY(plan_round(0, rows0, main0, prep0, *plans.back()));
-            SP1HIP_TRY(upload_plan(*plans.back(), 0));
+            SP1HIP_TRY(plan_round(0, rows0, main0, prep0, *plans.back(), biv));
+            SP1HIP_TRY(upload_plan(*plans.back(), biv ? 1 : 0));      // (round 2's plan takes buffer 0 while the bivariate launches still read theirs)
         }
     }
-    for (int r = 0; r < L; r++) {
+    int r_first = 0;
+    if (biv) {
+        // ================= rounds 0 and 1 from ONE pass over the base-field traces (see zc_biv_node) =================
+        RoundPlan& rp = *plans[0];
+        const int nv = L;
+        const uint32_t eq_len = 1u << (nv - 2);
+        const uint32_t* d_eq = d_eq_all.u32() + 4 * (((size_t)1 << (nv - 2)) - 1);    // eq over the nv - 2 variables of the quad index
+        const int n_descs = (int)rp.descs.size(), n_ranges = (int)rp.ranges.size();
+        DevBuf& d_descs = d_descs2[1];
+        const ZcDesc* dd = (const ZcDesc*)d_descs.p;
+        const ZcChipRange* d_ranges_p = (const ZcChipRange*)((const uint8_t*)d_descs.p + rp.off_ranges);
+        const ZcFixDesc* d_fix_p = (const ZcFixDesc*)((const uint8_t*)d_descs.p + rp.off_fds);
+        std::vector<uint32_t> bsums((size_t)std::max(n_ranges, 1) * ZC_BIV_SUM_WORDS);
+        if (n_descs) {
+            partial_cap = (size_t)rp.total_blocks * ZC_BIV_NODES * 8 * 4;
+            SP1HIP_TRY(d_partial.alloc(partial_cap, s));
+            DevBuf d_bsums;
+            SP1HIP_TRY(d_bsums.alloc(bsums.size() * 4, s));
+            const DeviceCtx* dctx;
+            SP1HIP_TRY(get_device_ctx(&dctx));
+            {
+                ScopedTimer tm("zerocheck_round", s);
+                // the launches on fork streams, joined in front of the reduction (as in the later rounds)
+                static const bool fork_enabled = [] { const char* e = getenv("SP1HIP_ZC_FORK"); return !(e && e[0] == '0'); }();
+                const int n_launches = (int)rp.groups.size() + (rp.macro_n[1] ? 1 : 0) + (rp.macro_n[2] ? 1 : 0) + (rp.macro_n[3] ? 1 : 0);
+                const bool forked = fork_enabled && n_launches > 1;
+                constexpr int N_FORK = 3;
+                hipStream_t* fork_s = nullptr;
+                hipEvent_t* fork_ev = nullptr;
+                if (forked) {
+                    SP1HIP_TRY(fork_streams_for(s, N_FORK, &fork_s, &fork_ev));
+                    SP1HIP_HIP(hipEventRecord(fork_ev[0], s));
+                }
+                bool fork_used[N_FORK] = {false, false, false};
+                int launch_no = 0;
+                auto next_stream = [&]() -> hipStream_t {
+                    const int slot = forked ? launch_no++ % (N_FORK + 1) : 0;
+                    if (slot == 0) return s;
+                    if (!fork_used[slot - 1]) { fork_used[slot - 1] = true; (void)hipStreamWaitEvent(fork_s[slot - 1], fork_ev[0], 0); }
+                    return fork_s[slot - 1];
+                };
+                for (auto& g : rp.groups)
+                    SP1HIP_TRY(launch_biv_round(g.max_regs, g.staged, dd, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq, eq_len, d_publics.u32(), d_partial.u32(), next_stream()));
+#define SP1HIP_ZC_BIV_MACRO_LAUNCH(KIND)                                                                                                 \
+                if (rp.macro_n[KIND]) {                                                                                                \
+                    hipLaunchKernelGGL((zc_biv_macro_kernel<KIND>), dim3(rp.macro_n[KIND] * (uint32_t)ZC_BIV_NODES), dim3(256), 0, next_stream(), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[KIND], dctx->d_rc); \
+                    SP1HIP_LAUNCH_CHECK();                                                                                             \
+                }
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(1u)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u)
+#undef SP1HIP_ZC_BIV_MACRO_LAUNCH
+                if (forked)
+                    for (int k = 0; k < N_FORK; k++)
+                        if (fork_used[k]) {
+                            SP1HIP_HIP(hipEventRecord(fork_ev[1 + k], fork_s[k]));
+                            SP1HIP_HIP(hipStreamWaitEvent(s, fork_ev[1 + k], 0));
+                        }
+                const bool direct = (size_t)n_ranges * ZC_BIV_SUM_WORDS + 1 <= MAILBOX_WORDS;
+                const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
+                if (direct) { rsync.pending = true; mb.pending = true; }
+                hipLaunchKernelGGL(zc_biv_reduce_kernel, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq, eq_len, d_bsums.u32(), rs_pub, mb.seq + 1);
+                SP1HIP_LAUNCH_CHECK();
+                // round 2's plan and descriptors behind the running launches
+                plans.emplace_back(new RoundPlan());                           // (index 1: round 1 has no plan of its own)
+                if (L > 2) {
+                    plans.emplace_back(new RoundPlan());
+                    SP1HIP_TRY(plan_round(2, rp.rows_next, rp.main_next, rp.prep_next, *plans.back(), false));
+                    SP1HIP_TRY(upload_plan(*plans.back(), 0));
+                }
+                const auto zc_w0 = std::chrono::steady_clock::now();
+                if (zc_timing) zc_plan_ms += std::chrono::duration<double, std::milli>(zc_w0 - zc_iter_t).count();
+                if (direct) { SP1HIP_TRY(mb.wait_next(bsums.data(), (size_t)n_ranges * ZC_BIV_SUM_WORDS)); rsync.pending = false; }
+                else SP1HIP_TRY(mb.fetch(d_bsums.p, (size_t)n_ranges * ZC_BIV_SUM_WORDS, bsums.data()));
+                if (zc_timing) { zc_iter_t = std::chrono::steady_clock::now(); zc_wait_ms += std::chrono::duration<double, std::milli>(zc_iter_t - zc_w0).count(); }
+            }
+        } else {
+            plans.emplace_back(new RoundPlan());
+            if (L > 2) {
+                plans.emplace_back(new RoundPlan());
+                SP1HIP_TRY(plan_round(2, rp.rows_next, rp.main_next, rp.prep_next, *plans.back(), false));
+                SP1HIP_TRY(upload_plan(*plans.back(), 0));
+            }
+        }
+        // ---- per chip: H(X, Y) on {0, 1, 2, 4}^2. Boolean corners: the GKR term's corner sums (constraints vanish on real rows, a
+        // padded row's constant cancels against geq). Elsewhere: A + (bilinear extension of the corner sums) - pad_adj eq[qb] geq_b(X, Y),
+        // qb = the quad of the first padded row, geq_b = the bilinear extension of [row >= rows] over that quad (zero when it
+        // holds no real row: such a quad is not summed and cancels by itself).
+        static const int NODE_X[12] = {0, 0, 1, 1, 2, 2, 2, 2, 4, 4, 4, 4}, NODE_Y[12] = {2, 4, 2, 4, 0, 1, 2, 4, 0, 1, 2, 4};
+        auto xi = [](int v) { return v == 4 ? 3 : v; };             // index of a coordinate in {0, 1, 2, 4}
+        auto small = [](int64_t v) -> Ext { return ext_c((uint32_t)(((v % (int64_t)kb::P) + (int64_t)kb::P) % (int64_t)kb::P)); };
+        std::vector<std::array<std::array<Ext, 4>, 4>> H(n_chips);  // H[i][x index][y index]
+        {
+            std::vector<std::array<Ext, 17>> cs(n_chips);           // merged sums of a chip's ranges: A_0..11, B_0..3, eq[qb]
+            std::vector<char> have(n_chips, 0);
+            for (size_t k = 0; k < rp.desc_chip.size(); k++) {
+                const int ci = rp.desc_chip[k];
+                const uint32_t* src = bsums.data() + k * ZC_BIV_SUM_WORDS;
+                for (int e = 0; e < 17; e++) {
+                    const Ext v{{src[4 * e], src[4 * e + 1], src[4 * e + 2], src[4 * e + 3]}};
+                    if (!have[ci] || e == 16) cs[ci][e] = v; else cs[ci][e] = cs[ci][e] + v;
+                }
+                have[ci] = 1;
+            }
+            for (int i = 0; i < n_chips; i++) {
+                ChipState& c = *st[i];
+                if (c.rows == 0) continue;
+                const Ext* A = cs[i].data();
+                const Ext G00 = cs[i][12], G01 = cs[i][13], G10 = cs[i][14], G11 = cs[i][15];   // B_e: corner (X, Y) = (e >> 1, e & 1)
+                const Ext gx = G10 - G00, gy = G01 - G00, gxy = (G11 - G10) - gy;
+                const int m = (int)(c.rows % 4);                    // rows of the boundary quad that are real
+                const Ext pe = m ? c.pad_adj * cs[i][16] : kb::ext_zero();
+                H[i][0][0] = G00; H[i][0][1] = G01; H[i][1][0] = G10; H[i][1][1] = G11;
+                for (int e = 0; e < 12; e++) {
+                    const int x = NODE_X[e], y = NODE_Y[e];
+                    Ext h = A[e] + G00 + gx * small(x) + gy * small(y) + gxy * small(x * y);
+                    if (m) {
+                        const int i01 = 1 >= m, i10 = 2 >= m;           // [row 4 qb + k >= rows] for k = 1, 2 (k = 0: real, k = 3: padded)
+                        const int64_t gq = (int64_t)x * i10 + (int64_t)y * i01 + (int64_t)x * y * (1 - i10 - i01);
+                        h = h - pe * small(gq);
+                    }
+                    H[i][xi(x)][xi(y)] = h;
+                }
+            }
+        }
+        std::vector<std::array<Ext, 3>> hv(n_chips);
+        // ---- round 0 binds Y (the last variable): h(t) = (1 - z_X) H(0, t) + z_X H(1, t)
+        const Ext zX = zeta[nv - 2], zY = zeta[nv - 1];
+        for (int i = 0; i < n_chips; i++) {
+            if (st[i]->rows == 0) continue;
+            for (int k = 0; k < 3; k++) { const int t = k == 0 ? 0 : k + 1; hv[i][k] = (kb::ext_one() - zX) * H[i][0][t] + zX * H[i][1][t]; }
+        }
+        const Ext a0 = round_messages(zY, hv);
+        // ---- round 1 binds X: h(t) = eq(z_Y, a0) x the cubic through H(t, 0), H(t, 1), H(t, 2), H(t, 4) at a0
+        Ext Lk[4];                                                   // C_k(a0)
+        for (int k = 0; k < 4; k++) {
+            Ext acc = kb::ext_from_base(cubic.c[k][3]);
+            for (int d = 2; d >= 0; d--) acc = acc * a0 + kb::ext_from_base(cubic.c[k][d]);
+            Lk[k] = acc;
+        }
+        for (int i = 0; i < n_chips; i++) {
+            ChipState& c = *st[i];
+            if (c.rows == 0) continue;
+            for (int k = 0; k < 3; k++) {
+                const int t = k == 0 ? 0 : k + 1;                   // index of 0, 2, 4 in {0, 1, 2, 4}
+                const Ext v = H[i][t][0] * Lk[0] + H[i][t][1] * Lk[1] + H[i][t][2] * Lk[2] + H[i][t][3] * Lk[3];
+                hv[i][k] = c.eq_adj * v;                            // eq_adj = eq(z_Y, a0) since round_messages
+            }
+        }
+        const Ext a1 = round_messages(zX, hv);
+        if (zc_timing) { const auto now = std::chrono::steady_clock::now(); zc_uni_ms += std::chrono::duration<double, std::milli>(now - zc_iter_t).count(); zc_iter_t = now; }
+        // ---- the tables folded by both challenges
+        if (!rp.fds.empty()) {
+            ScopedTimer tm("zerocheck_fix", s);
+            hipLaunchKernelGGL(zc_fix2_kernel, dim3(rp.fix_blocks), dim3(256), 0, s, d_fix_p, (int)rp.fds.size(), a0, a1);
+            SP1HIP_LAUNCH_CHECK();
+            for (size_t k = 0; k < rp.fds.size(); k++) {
+                ChipState& c = *st[rp.owner[k].first];
+                if (rp.owner[k].second) c.d_main = rp.fresh[k]; else c.d_prep = rp.fresh[k];
+            }
+        }
+        for (int i = 0; i < n_chips; i++)
+            if (st[i]->rows) st[i]->rows = (st[i]->rows + 3) / 4;
+        r_first = 2;
+    }
+    for (int r = r_first; r < L; r++) {
         const int nv = L - r;                       // variables left
         const Ext last = zeta[nv - 1];
         // eq(zeta[0 .. nv-1), .) is shared by every chip with real rows
@@ -1739,7 +2304,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             // the next round's plan and descriptors, behind this round's launches (see plan_round)
             if (r + 1 < L && (int)plans.size() == r + 1) {
                 plans.emplace_back(new RoundPlan());
-                SP1HIP_TRY(plan_round(r + 1, rp.rows_next, rp.main_next, rp.prep_next, *plans.back()));
+                SP1HIP_TRY(plan_round(r + 1, rp.rows_next, rp.main_next, rp.prep_next, *plans.back(), false));
                 SP1HIP_TRY(upload_plan(*plans.back(), (r + 1) & 1));
             }
             const auto zc_w0 = std::chrono::steady_clock::now();
@@ -1750,7 +2315,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         if (r + 1 < L && (int)plans.size() == r + 1) {           // (a round without descriptors: nothing was launched above)
             plans.emplace_back(new RoundPlan());
-            SP1HIP_TRY(plan_round(r + 1, rp.rows_next, rp.main_next, rp.prep_next, *plans.back()));
+            SP1HIP_TRY(plan_round(r + 1, rp.rows_next, rp.main_next, rp.prep_next, *plans.back(), false));
             SP1HIP_TRY(upload_plan(*plans.back(), (r + 1) & 1));
         }
         {   // a chip with fused pieces has a second range: its sums ADD to the interpreter's (the eq entry is the same)
@@ -1762,86 +2327,25 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 else for (int w = 0; w < 12; w++) sums[ci][w] = kb::add(sums[ci][w], src[w]);
             }
         }
-        // ---- univariate messages (sum_as_poly.rs:L187-L287)
-        // (sum_as_poly interpolates through {0, 1, 2, 4, b} with the value at b equal to zero.) Closed form, no allocation: the
-        // Lagrange basis polynomial of node x_k in {0, 1, 2, 4} is C_k(X) (X - b) / (x_k - b), with C_k the basis polynomial of
-        // x_k among those four nodes alone — constants of the field:
-        //   C_0 = (X^3 - 7 X^2 + 14 X - 8) / -8, C_1 = (X^3 - 6 X^2 + 8 X) / 3, C_2 = (X^3 - 5 X^2 + 4 X) / -4, C_3 = (X^3 - 3 X^2 + 2 X) / 24
-        // so a chip's univariate is (X - b) sum_k z_k C_k(X) with z_k = y_k / (x_k - b); the four inverses come from one
-        // inversion (Montgomery's trick). Exact field arithmetic: the same polynomial as any other interpolation.
-        static const struct CubicBasis {
-            uint32_t c[4][4];                                     // c[k][d]: coefficient of X^d in C_k (Montgomery base words)
-            CubicBasis() {
-                const int num[4][4] = {{-8, 14, -7, 1}, {0, 8, -6, 1}, {0, 4, -5, 1}, {0, 2, -3, 1}};
-                const int den[4] = {-8, 3, -4, 24};
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t dm = kb::to_monty(den[k] < 0 ? kb::P - (uint32_t)(-den[k]) : (uint32_t)den[k]);
-                    const uint32_t dinv = kb::ext_inv(kb::ext_from_base(dm)).c[0];
-                    for (int d = 0; d < 4; d++) {
-                        const uint32_t nm = kb::to_monty(num[k][d] < 0 ? kb::P - (uint32_t)(-num[k][d]) : (uint32_t)num[k][d]);
-                        c[k][d] = kb::mul(nm, dinv);
-                    }
-                }
-            }
-        } cubic;
-        const Ext b_node = (kb::ext_one() - last) * kb::ext_inv(kb::ext_one() - (last + last));
-        Ext inv_xb[4];                                            // 1 / (x_k - b), x = 0, 1, 2, 4
+        // ---- univariate messages (sum_as_poly.rs:L187-L287): the values of every chip's round polynomial at 0, 2, 4 without the
+        // eq factor of the variable being bound
+        std::vector<std::array<Ext, 3>> hv(n_chips);
         {
-            const Ext dx[4] = {kb::ext_zero() - b_node, kb::ext_one() - b_node, ext_c(2) - b_node, ext_c(4) - b_node};
-            const Ext p01 = dx[0] * dx[1], p012 = p01 * dx[2], p0123 = p012 * dx[3];
-            Ext run = kb::ext_inv(p0123);
-            inv_xb[3] = run * p012; run = run * dx[3];
-            inv_xb[2] = run * p01; run = run * dx[2];
-            inv_xb[1] = run * dx[0];
-            inv_xb[0] = run * dx[1];
-        }
-        const Ext two = ext_c(2), four = ext_c(4), three = ext_c(3), seven = ext_c(7);
-        const Ext f0 = kb::ext_one() - last, f2 = last * three - kb::ext_one(), f4 = last * seven - three;
-        if ((int)uni.size() != n_chips) uni.assign(n_chips, UniPoly(5, kb::ext_zero()));
-        for (int i = 0; i < n_chips; i++) {
-            ChipState& c = *st[i];
-            UniPoly& u = uni[i];
-            if (c.rows == 0) { for (auto& cf : u) cf = kb::ext_zero(); continue; }
-            const size_t th = (size_t)((c.rows + 1) / 2) - 1;
-            const Ext eq_th{{sums[i][12], sums[i][13], sums[i][14], sums[i][15]}};
-            const Ext msb = c.eq_adj * eq_th;
-            const Ext y0s{{sums[i][0], sums[i][1], sums[i][2], sums[i][3]}}, y2s{{sums[i][4], sums[i][5], sums[i][6], sums[i][7]}},
-                y4s{{sums[i][8], sums[i][9], sums[i][10], sums[i][11]}};
-            const Ext v0 = c.vgeq.fix(kb::ext_zero()).at(th), v2 = c.vgeq.fix(two).at(th), v4 = c.vgeq.fix(four).at(th);
-            const Ext pm = c.pad_adj * msb;
-            const Ext y0 = (y0s * c.eq_adj - pm * v0) * f0;
-            const Ext y2 = (y2s * c.eq_adj - pm * v2) * f2;
-            const Ext y4 = (y4s * c.eq_adj - pm * v4) * f4;
-            const Ext z[4] = {y0 * inv_xb[0], (round_claims[i] - y0) * inv_xb[1], y2 * inv_xb[2], y4 * inv_xb[3]};
-            Ext g[4];                                             // sum_k z_k C_k(X)
-            for (int d = 0; d < 4; d++) {
-                Ext acc = kb::ext_mul_base(z[0], cubic.c[0][d]);
-                for (int k = 1; k < 4; k++) acc = acc + kb::ext_mul_base(z[k], cubic.c[k][d]);
-                g[d] = acc;
+            const Ext two = ext_c(2), four = ext_c(4);
+            for (int i = 0; i < n_chips; i++) {
+                ChipState& c = *st[i];
+                if (c.rows == 0) continue;
+                const size_t th = (size_t)((c.rows + 1) / 2) - 1;
+                const Ext eq_th{{sums[i][12], sums[i][13], sums[i][14], sums[i][15]}};
+                const Ext msb = c.eq_adj * eq_th;
+                const Ext y0s{{sums[i][0], sums[i][1], sums[i][2], sums[i][3]}}, y2s{{sums[i][4], sums[i][5], sums[i][6], sums[i][7]}},
+                    y4s{{sums[i][8], sums[i][9], sums[i][10], sums[i][11]}};
+                const Ext v0 = c.vgeq.fix(kb::ext_zero()).at(th), v2 = c.vgeq.fix(two).at(th), v4 = c.vgeq.fix(four).at(th);
+                const Ext pm = c.pad_adj * msb;
+                hv[i] = {y0s * c.eq_adj - pm * v0, y2s * c.eq_adj - pm * v2, y4s * c.eq_adj - pm * v4};
             }
-            u[0] = kb::ext_zero() - b_node * g[0];
-            for (int d = 1; d < 4; d++) u[d] = g[d - 1] - b_node * g[d];
-            u[4] = g[3];
         }
-        UniPoly rlc(n_chips ? 5 : 1, kb::ext_zero());
-        for (auto& u : uni)
-            for (int d = 0; d < 5; d++) rlc[d] = rlc[d] * lambda + u[d];
-        for (auto& cf : rlc)
-            for (int k = 0; k < 4; k++) challenger_observe(challenger, cf.c[k]);
-        msgs.push_back(rlc);
-        const Ext a_r = challenger_sample_ext(challenger);
-        point.insert(point.begin(), a_r);
-        for (int i = 0; i < n_chips; i++) {
-            round_claims[i] = uni_eval(uni[i], a_r);
-            st[i]->uni = uni[i];
-        }
-        // ---- fix the last variable of every table (fix_last_variable.rs): one launch for all chips (planned above)
-        for (int i = 0; i < n_chips; i++) {
-            ChipState& c = *st[i];
-            c.vgeq = c.vgeq.fix(a_r);
-            if (c.rows == 0) continue;
-            c.eq_adj = c.eq_adj * (a_r * last + (kb::ext_one() - a_r) * (kb::ext_one() - last));
-        }
+        const Ext a_r = round_messages(last, hv);
         if (zc_timing) { const auto now = std::chrono::steady_clock::now(); zc_uni_ms += std::chrono::duration<double, std::milli>(now - zc_iter_t).count(); zc_iter_t = now; }
         if (!fds.empty()) {
             ScopedTimer tm("zerocheck_fix", s);
