@@ -663,35 +663,46 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
     }
 }
 
-// One workgroup per range: A_e summed over the range's blocks (12 ext), the four corner sums B (4 ext), eq[th] (1 ext):
-// out[range][68] and, with a host slot, payload words [1 + 68 range ..); the last workgroup publishes `seq`.
+// One workgroup per (range, node): the node's [A | B] summed over the range's blocks. Per range the output is A_0..11 (12 ext),
+// the four corner sums B_0..3 (4 ext), eq[th] (1 ext): out[range][68] and, with a host slot, payload words [1 + 68 range ..);
+// the last workgroup of the launch publishes `seq`. (One workgroup per range took 235 us for a chip of 12k blocks.)
 constexpr uint32_t ZC_BIV_SUM_WORDS = 68;
 __global__ __launch_bounds__(256) void zc_biv_reduce_kernel(const ZcChipRange* __restrict__ ranges, const uint32_t* __restrict__ partial,
                                                             const uint32_t* __restrict__ eq, uint32_t eq_len,
                                                             uint32_t* __restrict__ out, RoundSync rs, uint32_t seq) {
-    __shared__ uint32_t acc[2][96];
-    const ZcChipRange d = ranges[blockIdx.x];
-    const uint32_t word = threadIdx.x % 96, grp = threadIdx.x / 96;       // two groups of 96 words (12 nodes x [A | B])
-    if (grp < 2) {
-        const uint32_t* p = partial + (size_t)d.block_start * 96 + word;
+    __shared__ uint32_t acc[32][8];
+    const uint32_t range = blockIdx.x / (uint32_t)ZC_BIV_NODES, node = blockIdx.x % (uint32_t)ZC_BIV_NODES;
+    const ZcChipRange d = ranges[range];
+    const uint32_t word = threadIdx.x & 7u, grp = threadIdx.x >> 3;       // 32 groups of 8 words
+    {
+        const uint32_t* p = partial + ((size_t)d.block_start * ZC_BIV_NODES + node) * 8 + word;
         uint32_t a[4] = {0, 0, 0, 0};
         uint32_t b = grp;
-        for (; b + 6 < d.n_blocks; b += 8)
+        for (; b + 96 < d.n_blocks; b += 128)
 #pragma unroll
-            for (int u = 0; u < 4; u++) a[u] = kb::add(a[u], p[(size_t)(b + 2 * u) * 96]);
-        for (; b < d.n_blocks; b += 2) a[0] = kb::add(a[0], p[(size_t)b * 96]);
+            for (int u = 0; u < 4; u++) a[u] = kb::add(a[u], p[(size_t)(b + 32 * u) * (ZC_BIV_NODES * 8)]);
+        for (; b < d.n_blocks; b += 32) a[0] = kb::add(a[0], p[(size_t)b * (ZC_BIV_NODES * 8)]);
         acc[grp][word] = kb::add(kb::add(a[0], a[1]), kb::add(a[2], a[3]));
     }
     __syncthreads();
-    if (threadIdx.x < ZC_BIV_SUM_WORDS) {
+    if (threadIdx.x < 12) {
+        // words 0..3: A_node -> [4 node ..), words 4..7: B_node -> [48 + 4 node ..) for node < 4, words 8..11: eq[th] -> [64 ..) from node 0
         const uint32_t w = threadIdx.x;
-        uint32_t val;
-        if (w < 48) { const uint32_t e = w >> 2, k = w & 3; val = kb::add(acc[0][e * 8 + k], acc[1][e * 8 + k]); }                 // A_e
-        else if (w < 64) { const uint32_t e = (w - 48) >> 2, k = w & 3; val = kb::add(acc[0][e * 8 + 4 + k], acc[1][e * 8 + 4 + k]); }   // B_e, e < 4
-        else { const uint32_t k = w - 64; val = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u; }
-        out[(size_t)blockIdx.x * ZC_BIV_SUM_WORDS + w] = val;
-        if (rs.host_slot != nullptr)
-            __hip_atomic_store(const_cast<uint32_t*>(rs.host_slot) + 1 + (size_t)blockIdx.x * ZC_BIV_SUM_WORDS + w, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t val = 0, dst = 0xffffffffu;
+        if (w < 8) {
+            for (uint32_t g = 0; g < 32; g++) val = kb::add(val, acc[g][w]);
+            if (w < 4) dst = 4 * node + w;
+            else if (node < 4) dst = 48 + 4 * node + (w - 4);
+        } else if (node == 0) {
+            const uint32_t k = w - 8;
+            val = d.th < eq_len ? eq[(size_t)k * eq_len + d.th] : 0u;
+            dst = 64 + k;
+        }
+        if (dst != 0xffffffffu) {
+            out[(size_t)range * ZC_BIV_SUM_WORDS + dst] = val;
+            if (rs.host_slot != nullptr)
+                __hip_atomic_store(const_cast<uint32_t*>(rs.host_slot) + 1 + (size_t)range * ZC_BIV_SUM_WORDS + dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (rs.host_slot == nullptr) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2048,23 +2059,28 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     SP1HIP_HIP(hipEventRecord(fork_ev[0], s));
                 }
                 bool fork_used[N_FORK] = {false, false, false};
-                int launch_no = 0;
-                auto next_stream = [&]() -> hipStream_t {
-                    const int slot = forked ? launch_no++ % (N_FORK + 1) : 0;
-                    if (slot == 0) return s;
+                auto stream_of = [&](int slot) -> hipStream_t {         // slot 0: the caller's stream
+                    if (!forked || slot == 0) return s;
                     if (!fork_used[slot - 1]) { fork_used[slot - 1] = true; (void)hipStreamWaitEvent(fork_s[slot - 1], fork_ev[0], 0); }
                     return fork_s[slot - 1];
                 };
-                for (auto& g : rp.groups)
-                    SP1HIP_TRY(launch_biv_round(g.max_regs, g.staged, dd, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq, eq_len, d_publics.u32(), d_partial.u32(), next_stream()));
-#define SP1HIP_ZC_BIV_MACRO_LAUNCH(KIND)                                                                                                 \
+                // these launches fill the device together (the round is throughput-bound: 5.1 ms on the core shard however they are
+                // placed): the largest interpreter group on the caller's stream, the Poseidon2 pieces on the second, the other
+                // interpreter groups on the third, the septic pieces on the fourth
+                size_t big = 0;
+                for (size_t g = 1; g < rp.groups.size(); g++) if (rp.groups[g].n_blocks > rp.groups[big].n_blocks) big = g;
+                for (size_t gi = 0; gi < rp.groups.size(); gi++) {
+                    const auto& g = rp.groups[gi];
+                    SP1HIP_TRY(launch_biv_round(g.max_regs, g.staged, dd, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq, eq_len, d_publics.u32(), d_partial.u32(), stream_of(gi == big ? 0 : 2)));
+                }
+#define SP1HIP_ZC_BIV_MACRO_LAUNCH(KIND, SLOT)                                                                                           \
                 if (rp.macro_n[KIND]) {                                                                                                \
-                    hipLaunchKernelGGL((zc_biv_macro_kernel<KIND>), dim3(rp.macro_n[KIND] * (uint32_t)ZC_BIV_NODES), dim3(256), 0, next_stream(), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[KIND], dctx->d_rc); \
+                    hipLaunchKernelGGL((zc_biv_macro_kernel<KIND>), dim3(rp.macro_n[KIND] * (uint32_t)ZC_BIV_NODES), dim3(256), 0, stream_of(SLOT), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[KIND], dctx->d_rc); \
                     SP1HIP_LAUNCH_CHECK();                                                                                             \
                 }
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(1u)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 3)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 3)
 #undef SP1HIP_ZC_BIV_MACRO_LAUNCH
                 if (forked)
                     for (int k = 0; k < N_FORK; k++)
@@ -2075,7 +2091,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 const bool direct = (size_t)n_ranges * ZC_BIV_SUM_WORDS + 1 <= MAILBOX_WORDS;
                 const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
                 if (direct) { rsync.pending = true; mb.pending = true; }
-                hipLaunchKernelGGL(zc_biv_reduce_kernel, dim3(n_ranges), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq, eq_len, d_bsums.u32(), rs_pub, mb.seq + 1);
+                hipLaunchKernelGGL(zc_biv_reduce_kernel, dim3(n_ranges * ZC_BIV_NODES), dim3(256), 0, s, d_ranges_p, d_partial.u32(), d_eq, eq_len, d_bsums.u32(), rs_pub, mb.seq + 1);
                 SP1HIP_LAUNCH_CHECK();
                 // round 2's plan and descriptors behind the running launches
                 plans.emplace_back(new RoundPlan());                           // (index 1: round 1 has no plan of its own)
@@ -2245,6 +2261,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 if (forked) {
                     std::stable_sort(order.begin(), order.end(), [](const Launch& a, const Launch& b) { return a.est > b.est; });
                     double load[N_FORK + 1] = {0, 7, 14, 21};          // (the launches leave the host ~7 us apart)
+                    // (in the rounds whose launches fill the device the kernel on the fourth queue starts ~0.84 ms after the others —
+                    // profiles/r04_gap_trace_timeline.txt — and four queues still beat three: 2.0 against 2.2 ms in round 2)
                     for (Launch& ln : order) {
                         int best = 0;
                         for (int k = 1; k <= N_FORK; k++) if (load[k] < load[best]) best = k;
