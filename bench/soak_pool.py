@@ -1,14 +1,21 @@
-"""Soak (GPU box): N proofs of the core-shaped shard through a 3-slot pool and N/4 on the direct path, every proof compared
+"""Soak (GPU box): N proofs of a core shard through a 3-slot pool and N/4 on the direct path, every proof compared
 byte for byte with the first one — the hand-over protocols (rs_finish, direct host rows, mailbox publishes) run ~350 times
-per proof. usage: python bench/soak_pool.py [n_proofs]"""
+per proof. usage: python bench/soak_pool.py [n_proofs] [real|core]     (real: the rv64im machine, bench.py's workload — default;
+core: the synthetic core-shaped shard of rounds 1-3)"""
 import os, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
 import torch
 from sp1_amd import api
-from core_shard import build_core_shard
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+kind = sys.argv[2] if len(sys.argv) > 2 else "real"
 L, lsh = 22, 21
-chips, meta = build_core_shard(3 << 27, L)
+torch.cuda.set_device(0)
+if kind == "real":
+    import core_real
+    chips, meta = core_real.build_real_shard()
+else:
+    from core_shard import build_core_shard
+    chips, meta = build_core_shard(3 << 27, L)
 pk = api.ProvingKey([c[3] for c in chips if c[3] is not None], L, lsh, 32)
 want = pk.prove_shard(chips, [])
 bad = 0

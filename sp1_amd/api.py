@@ -704,7 +704,10 @@ class ProverPool:
             self._keep.clear()
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except TypeError:                        # interpreter shutdown: the module globals are already gone
+            pass
 
 
 def parse_logup_gkr_proof(blob):

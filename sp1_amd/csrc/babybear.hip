@@ -250,6 +250,7 @@ static int get_bb_ctx(BbCtx** out) {
         const RoundConstants rc = make_round_constants();
         SP1HIP_HIP(hipMalloc((void**)&c->d_rc, sizeof rc));
         SP1HIP_HIP(hipMemcpy(c->d_rc, &rc, sizeof rc, hipMemcpyHostToDevice));
+        SP1HIP_HIP(hipDeviceSynchronize());      // (once per device: read from non-blocking streams)
     }
     *out = c;
     return SP1HIP_SUCCESS;

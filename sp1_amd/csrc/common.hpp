@@ -23,6 +23,23 @@ template <class T> __device__ __forceinline__ __attribute__((address_space(1))) 
 }
 
 void set_error(const char* fmt, ...);
+// what the calling thread is in the middle of (a stage of a shard proof): carried by the time-out messages of the device -> host
+// hand-overs, whose wait loops know nothing about their caller. wait_timeout_seconds(): SP1HIP_WAIT_TIMEOUT_S, default 60.
+void set_stage_note(const char* note);
+const char* stage_note();
+int wait_timeout_seconds();
+// Provers (shard proofs, or stand-alone stage calls) in flight in this process, counted once per calling thread however the
+// entry points nest. The zerocheck spreads a round's launches over fork streams only while it is the ONLY prover: with several
+// provers in flight the device is filled by the other proofs anyway, and the forks' cross-stream events on the process's four
+// hardware queues cost more than they hide (3-slot pool on the real-chip shard: 55.1 ms per proof without forks, 60.6 with).
+struct ActiveProver {
+    bool counted;
+    ActiveProver();
+    ~ActiveProver();
+    ActiveProver(const ActiveProver&) = delete;
+    ActiveProver& operator=(const ActiveProver&) = delete;
+};
+int active_provers();
 int map_hip_error(hipError_t e, const char* what);
 
 inline hipStream_t S(sp1hip_stream_t s) { return static_cast<hipStream_t>(s); }

@@ -186,8 +186,9 @@ struct RoundSyncHost {
             if ((++spins & 0xffff) == 0) {
                 const hipError_t q = hipStreamQuery(s);
                 if (q != hipSuccess && q != hipErrorNotReady) return map_hip_error(q, "kernel failed while the host waited for a round result");
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-                    set_error("timed out waiting for a sumcheck round result");
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(wait_timeout_seconds())) {
+                    set_error("timed out waiting for a sumcheck round result (stage %s; expected sequence %u, the slot holds %u; stream query %d)",
+                              stage_note(), seq, slot[0], (int)q);
                     return SP1HIP_ERROR_RUNTIME;
                 }
             }
@@ -253,8 +254,9 @@ struct Mailbox {
             if ((++spins & 0xffff) == 0) {
                 const hipError_t q = hipStreamQuery(s);
                 if (q != hipSuccess && q != hipErrorNotReady) return map_hip_error(q, "kernel failed while the host waited for a result");
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-                    set_error("timed out waiting for a device result");
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(wait_timeout_seconds())) {
+                    set_error("timed out waiting for a device result (stage %s; expected sequence %u, the slot holds %u; stream query %d)",
+                              stage_note(), seq, slot[0], (int)q);
                     return SP1HIP_ERROR_RUNTIME;
                 }
             }

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -16,6 +17,18 @@
 namespace sp1hip {
 
 static thread_local std::string g_last_error;
+static thread_local const char* g_stage_note = "";
+void set_stage_note(const char* note) { g_stage_note = note ? note : ""; }
+const char* stage_note() { return g_stage_note; }
+static std::atomic<int> g_active_provers{0};
+static thread_local int g_prover_depth = 0;
+ActiveProver::ActiveProver() : counted(g_prover_depth++ == 0) { if (counted) g_active_provers.fetch_add(1, std::memory_order_relaxed); }
+ActiveProver::~ActiveProver() { g_prover_depth--; if (counted) g_active_provers.fetch_sub(1, std::memory_order_relaxed); }
+int active_provers() { return g_active_provers.load(std::memory_order_relaxed); }
+int wait_timeout_seconds() {
+    static const int t = [] { const char* e = getenv("SP1HIP_WAIT_TIMEOUT_S"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 60; }();
+    return t;
+}
 
 void set_error(const char* fmt, ...) {
     char buf[512];
@@ -361,6 +374,7 @@ int get_device_ctx(const DeviceCtx** out) {
         SP1HIP_HIP(hipMalloc((void**)&c->d_tw_hi, TW_HI * 4));
         SP1HIP_HIP(hipMemcpy(c->d_tw_lo, lo.data(), TW_LO * 4, hipMemcpyHostToDevice));
         SP1HIP_HIP(hipMemcpy(c->d_tw_hi, hi.data(), TW_HI * 4, hipMemcpyHostToDevice));
+        SP1HIP_HIP(hipDeviceSynchronize());      // (once per device: the tables are read from non-blocking streams)
         g_ctx[dev] = c;
     }
     *out = g_ctx[dev];
@@ -382,6 +396,11 @@ int round_sync_acquire(RoundSyncSlot* out) {
     RoundSyncSlot slot{nullptr, nullptr};
     SP1HIP_HIP(hipMalloc((void**)&slot.d_counter, RS_COUNTER_BYTES));
     SP1HIP_HIP(hipMemset(slot.d_counter, 0, RS_COUNTER_BYTES));
+    // hipMemset of device memory is a fill kernel on the NULL stream and may return before it has run; the provers' streams are
+    // non-blocking ones, which the NULL stream does not order — without this the first round kernel to take tickets from a NEW
+    // slot could race the fill (seen once in ~1,000 pool proofs: a 4-slot pool's first proofs create the process's fourth slot
+    // while three provers run; the tickets never added up and the host timed out on a sequence number that was never written)
+    SP1HIP_HIP(hipDeviceSynchronize());
     SP1HIP_HIP(hipHostMalloc((void**)&slot.h_slot, RS_SLOT_WORDS * 4, hipHostMallocMapped));
     memset(slot.h_slot, 0, RS_SLOT_WORDS * 4);
     *out = slot;

@@ -51,6 +51,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
                        uint8_t* h_proof, size_t* proof_len, sp1hip_stream_t stream) {
     SP1HIP_REQUIRE(chips && n_chips > 0 && preprocessed && challenger && proof_len, "bad argument");
     SP1HIP_REQUIRE(h_publics || n_publics == 0, "null public values");
+    ActiveProver active;                                     // (counted for the zerocheck's fork-stream decision: common.hpp)
     const int L = params.max_log_row_count, lsh = params.log_stacking_height;
     SP1HIP_REQUIRE(preprocessed->jagged && preprocessed->max_log_row_count == L && preprocessed->log_stacking_height == lsh,
                    "the preprocessed round was committed with different parameters");
@@ -112,10 +113,11 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         hipStream_t s;
         bool open = false;
         int idx = -1;
-        void close() { if (idx >= 0) timer_end(idx, s); idx = -1; if (open) roctx_pop(); open = false; }
+        void close() { if (idx >= 0) timer_end(idx, s); idx = -1; if (open) roctx_pop(); open = false; set_stage_note(""); }
         void next(const char* name) {
             close();
             roctx_push(name);
+            set_stage_note(name);
             open = true;
             if (timers_on()) { char buf[64]; snprintf(buf, sizeof buf, "stage_%s", name); idx = timer_begin(buf, s); }
         }

@@ -1587,6 +1587,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     SP1HIP_REQUIRE(chips && n_chips > 0 && h_zeta && h_openings && challenger && proof_len, "null argument");
     SP1HIP_REQUIRE(max_log_row_count >= 1 && max_log_row_count <= 30, "max_log_row_count out of range");
     SP1HIP_REQUIRE(h_publics || n_publics == 0, "null publics");
+    ActiveProver active;                                     // a stand-alone call counts as a prover too
     const int L = max_log_row_count;
     size_t total_w = 0;
     for (int i = 0; i < n_chips; i++) {
@@ -2050,7 +2051,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 // the launches on fork streams, joined in front of the reduction (as in the later rounds)
                 static const bool fork_enabled = [] { const char* e = getenv("SP1HIP_ZC_FORK"); return !(e && e[0] == '0'); }();
                 const int n_launches = (int)rp.groups.size() + (rp.macro_n[1] ? 1 : 0) + (rp.macro_n[2] ? 1 : 0) + (rp.macro_n[3] ? 1 : 0);
-                const bool forked = fork_enabled && n_launches > 1;
+                const bool forked = fork_enabled && n_launches > 1 && active_provers() <= 1;
                 constexpr int N_FORK = 3;
                 hipStream_t* fork_s = nullptr;
                 hipEvent_t* fork_ev = nullptr;
@@ -2232,7 +2233,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             static const bool fuse_nodes = [] { const char* e = getenv("SP1HIP_ZC_FUSE_NODES"); return e && e[0] == '1'; }();
             const int n_launches = (int)groups.size() + (macro_n[1] ? 1 : 0) + (macro_n[2] ? 1 : 0) + (macro_n[3] ? 1 : 0);
             static const uint32_t fork_max_blocks = [] { const char* e = getenv("SP1HIP_ZC_FORK_MAX_BLOCKS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : ZC_FORK_MAX_BLOCKS; }();
-            const bool forked = fork_enabled && n_launches > 1 && total_blocks <= fork_max_blocks;
+            const bool forked = fork_enabled && n_launches > 1 && total_blocks <= fork_max_blocks && active_provers() <= 1;
             // the round's sums reach the host through the mailbox slot when they fit it (they do for any real machine)
             const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
             const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
