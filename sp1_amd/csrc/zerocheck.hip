@@ -2012,8 +2012,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         return stage.upload(d_descs2[which].p, rp.pack.data(), rp.pack_bytes);
     };
-    // SP1HIP_ZC_BIVARIATE=0: the sequential first two rounds (A/B runs; the proof bytes are the same)
-    static const bool biv_enabled = [] { const char* e = getenv("SP1HIP_ZC_BIVARIATE"); return !(e && e[0] == '0'); }();
+    // SP1HIP_ZC_BIVARIATE=0: the sequential first two rounds; SP1HIP_ZC_FORK=0: every launch of a round on the caller's stream
+    // (A/B runs and the tests of those paths — read per call; the proof bytes are the same)
+    const bool biv_enabled = [] { const char* e = getenv("SP1HIP_ZC_BIVARIATE"); return !(e && e[0] == '0'); }();
+    const bool fork_enabled = [] { const char* e = getenv("SP1HIP_ZC_FORK"); return !(e && e[0] == '0'); }();
     const bool biv = biv_enabled && L >= 2;
     std::vector<std::unique_ptr<RoundPlan>> plans;           // (kept until the call returns)
     {
@@ -2049,7 +2051,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             {
                 ScopedTimer tm("zerocheck_round", s);
                 // the launches on fork streams, joined in front of the reduction (as in the later rounds)
-                static const bool fork_enabled = [] { const char* e = getenv("SP1HIP_ZC_FORK"); return !(e && e[0] == '0'); }();
                 const int n_launches = (int)rp.groups.size() + (rp.macro_n[1] ? 1 : 0) + (rp.macro_n[2] ? 1 : 0) + (rp.macro_n[3] ? 1 : 0);
                 const bool forked = fork_enabled && n_launches > 1 && active_provers() <= 1;
                 constexpr int N_FORK = 3;
@@ -2229,7 +2230,6 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             // disjoint slots of d_partial: nothing orders them but the stream. They go out on fork streams — a round then
             // costs its LONGEST launch instead of their sum (five launches of 30-70 us each in the last fifteen rounds of a
             // core shard; in the large rounds one launch's tail overlaps the next one's head). SP1HIP_ZC_FORK=0: one stream.
-            static const bool fork_enabled = [] { const char* e = getenv("SP1HIP_ZC_FORK"); return !(e && e[0] == '0'); }();
             static const bool fuse_nodes = [] { const char* e = getenv("SP1HIP_ZC_FUSE_NODES"); return e && e[0] == '1'; }();
             const int n_launches = (int)groups.size() + (macro_n[1] ? 1 : 0) + (macro_n[2] ? 1 : 0) + (macro_n[3] ? 1 : 0);
             static const uint32_t fork_max_blocks = [] { const char* e = getenv("SP1HIP_ZC_FORK_MAX_BLOCKS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : ZC_FORK_MAX_BLOCKS; }();

@@ -72,6 +72,27 @@ def test_zerocheck_programs_staged_in_lds_give_the_same_bytes(api, monkeypatch, 
     assert np.array_equal(g_ch.state(), o_ch.state())
 
 
+@pytest.mark.parametrize("env", [{"SP1HIP_ZC_BIVARIATE": "0"}, {"SP1HIP_ZC_FORK": "0"}, {"SP1HIP_ZC_BIVARIATE": "0", "SP1HIP_ZC_FORK": "0"}])
+@pytest.mark.parametrize("heights,L", [
+    ({"Mul": 5, "Affine": 3, "Sbox": 6}, 3),
+    ({"Affine": 1000, "Mul": 4096, "Sbox": 2049, "Sbox2": 1}, 12),
+    ({"Chain": 300, "Manyregs": 1000, "Mul": 77}, 10),
+])
+def test_zerocheck_sequential_rounds_and_single_stream_give_the_same_bytes(api, monkeypatch, env, heights, L):
+    """The default path proves rounds 0 and 1 from one pass over the base-field traces (bivariate grid) and spreads a round's
+    launches over fork streams; SP1HIP_ZC_BIVARIATE=0 / SP1HIP_ZC_FORK=0 select the sequential rounds / one stream: same bytes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    chips, zc, zeta, alpha, gkr, publics, o_ch = setup(heights, L, 40 + L)
+    g_ch = api.DuplexChallenger()
+    g_ch.observe(orc.random_felts((8,), 40 + L))
+    g_ch.sample_point(L); g_ch.sample_ext_element(); g_ch.sample_ext_element()
+    want = orc.zerocheck_prove(zc, L, zeta, alpha, gkr, publics, o_ch)
+    got = api.zerocheck(_gpu_chips(api, chips), L, zeta, np.concatenate([c.openings for c in zc]), alpha, gkr, publics, g_ch)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_zerocheck_rejects_bad_programs_and_keeps_transcript(api):
     chips, zc, zeta, alpha, gkr, publics, _ = setup({"Mul": 4}, 2, 3)
     g = _gpu_chips(api, chips)
