@@ -91,6 +91,33 @@ def test_riscv_shard_bytes_at_1_256_of_the_recorded_shape_match_the_oracle(api):
     assert got == want and np.array_equal(g_ch.state(), o_ch.state())
 
 
+def test_riscv_shard_bytes_at_a_sixteenth_of_the_recorded_shape_match_the_oracle(api):
+    """Whole-proof byte equality at 1/16 of the recorded core shard (2.4e7 trace cells, max_log_row_count 20: the size of bench.py's
+    cpu_baseline sample) — multi-block sums in every kernel, the fused pieces and the bivariate rounds at scale; the jagged-aware
+    oracle proves it in a few seconds on the box's 16 threads."""
+    import core_real
+    machine, tabs = core_real.machine_only(scale=1 / 16, seed=13, device="cuda")
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+            for a, i in machine]
+    dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+           for a, i in machine]
+    del tabs
+    L, lsh, batch = 20, 19, 32
+    o_prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, 2)
+    commit, prep = api.JaggedProver(L, lsh, batch, 2).commit_multilinears([d[3] for d in dev if d[3] is not None])
+    assert np.array_equal(commit, o_prep.commit)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    o_ch.observe(commit)
+    g_ch.observe(commit)
+    orc.set_gkr_sparse(True)
+    try:
+        want = orc.shard_prove(host, np.zeros(0, np.uint32), o_prep, L, lsh, batch, o_ch, 2, 124, 16)
+    finally:
+        orc.set_gkr_sparse(False)
+    got = api.prove_shard(dev, [], prep, L, lsh, batch, g_ch)
+    assert got == want and np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_riscv_shard_at_a_sixty_fourth_of_the_recorded_shape_verifies(api):
     """Production parameters (blowup 4, 124 queries, 16-bit PoW); 1/64 of the recorded heights, the real Global chip
     included (the bench's shard). One wrong cell in the Bitwise table -> the verifier rejects; so does one wrong
