@@ -65,6 +65,12 @@ int sp1hip_mem_info(size_t* free_bytes, size_t* total_bytes);
 /* The library keeps its working buffers (codewords, trees, fold layers) in per-stream free lists so that
  * steady-state proving never calls the driver; this returns every cached block to the driver. */
 int sp1hip_mem_trim(size_t* released_bytes);
+/* A caller stream that has been passed to this library owns helper streams (the commit's encode stream, the zerocheck's fork
+ * streams), their events and the working buffers cached for it and for them. Call this BEFORE destroying such a stream (the
+ * prover pool does it for its own slots): it waits for the stream, destroys the helpers and hands every block cached for them
+ * and for the stream back to the driver. Without it the helpers outlive the stream, and a later stream that reuses the handle
+ * value would inherit them. */
+int sp1hip_stream_release(sp1hip_stream_t stream);
 /* Host threads (the caller included) the library uses for the arithmetic between device hand-overs: SP1HIP_HOST_THREADS,
  * else min(8, CPUs / (2 x LOCAL_WORLD_SIZE)) with CPUs honouring the cgroup quota. Decided once per process. */
 int sp1hip_host_threads(void);
@@ -79,7 +85,7 @@ int sp1hip_memcpy_d2h_async(void* h_dst, const void* d_src, size_t bytes, sp1hip
 int sp1hip_memcpy_d2d_async(void* d_dst, const void* d_src, size_t bytes, sp1hip_stream_t stream);
 int sp1hip_memset_async(void* d_dst, int value, size_t bytes, sp1hip_stream_t stream);
 int sp1hip_stream_create(sp1hip_stream_t* stream);
-int sp1hip_stream_destroy(sp1hip_stream_t stream);
+int sp1hip_stream_destroy(sp1hip_stream_t stream);     /* releases what the library keeps for the stream first (sp1hip_stream_release) */
 int sp1hip_stream_synchronize(sp1hip_stream_t stream);
 int sp1hip_stream_query(sp1hip_stream_t stream); /* SP1HIP_ERROR_NOT_READY while work is pending */
 int sp1hip_event_create(sp1hip_event_t* event);

@@ -96,6 +96,7 @@ PROTOTYPES = [
     ("sp1hip_get_device", None, [C.POINTER(_int)]),
     ("sp1hip_mem_info", None, [C.POINTER(_sz), C.POINTER(_sz)]),
     ("sp1hip_mem_trim", None, [C.POINTER(_sz)]),
+    ("sp1hip_stream_release", None, [C.c_void_p]),
     ("sp1hip_host_threads", _int, []),
     ("sp1hip_malloc", None, [C.POINTER(_vp), _sz]),
     ("sp1hip_free", None, [_vp]),

@@ -533,6 +533,15 @@ int sp1hip_timers_read(const char* name, uint64_t* launches, double* total_ms) {
     return SP1HIP_SUCCESS;
 }
 
+int sp1hip_stream_release(sp1hip_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    SP1HIP_REQUIRE(s != nullptr, "the default stream is never released");
+    SP1HIP_HIP(hipStreamSynchronize(s));
+    release_stream_helpers(s);
+    (void)arena_release_stream(s);
+    return SP1HIP_SUCCESS;
+}
+
 int sp1hip_mem_trim(size_t* released_bytes) {
     const size_t n = arena_trim();
     if (released_bytes) *released_bytes = n;
@@ -594,7 +603,11 @@ int sp1hip_stream_create(sp1hip_stream_t* stream) {
     *stream = s;
     return SP1HIP_SUCCESS;
 }
-int sp1hip_stream_destroy(sp1hip_stream_t stream) { SP1HIP_HIP(hipStreamDestroy(S(stream))); return SP1HIP_SUCCESS; }
+int sp1hip_stream_destroy(sp1hip_stream_t stream) {
+    if (stream) SP1HIP_TRY(sp1hip_stream_release(stream));     // its helper streams, events and cached buffers go with it
+    SP1HIP_HIP(hipStreamDestroy(S(stream)));
+    return SP1HIP_SUCCESS;
+}
 int sp1hip_stream_synchronize(sp1hip_stream_t stream) { SP1HIP_HIP(hipStreamSynchronize(S(stream))); return SP1HIP_SUCCESS; }
 int sp1hip_stream_query(sp1hip_stream_t stream) {
     hipError_t e = hipStreamQuery(S(stream));

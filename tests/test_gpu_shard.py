@@ -123,6 +123,37 @@ def test_concurrent_shard_provers_give_identical_proofs(api):
     assert all(p == ref for k in out for p in out[k]) and len(out) == 3
 
 
+def test_stream_release_between_generations_of_caller_streams(api):
+    """A caller stream owns helper streams (the commit's encode stream, the zerocheck's fork streams), events and cached buffers:
+    `sp1hip_stream_release` hands them back before the stream goes away, and the next generation of streams — which may reuse
+    the handle values — proves the same bytes."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "bench"))
+    from synthetic_shard import build_shard
+    from sp1_amd import _lib
+    L, lsh = 16, 15
+    chips, prep_prep, shapes, area = build_shard(L, lsh, ((1 << 28) + (1 << 27)) >> 10)
+    jp = api.JaggedProver(L, lsh, 32, 2)
+    prep_commit, prep_data = jp.commit_multilinears([prep_prep])
+
+    def prove(stream):
+        ch = api.DuplexChallenger()
+        ch.observe(prep_commit)
+        with torch.cuda.stream(stream):
+            return api.prove_shard(chips, [], prep_data, L, lsh, 32, ch, stream=stream)
+
+    ref = prove(torch.cuda.current_stream())
+    for generation in range(4):
+        s = torch.cuda.Stream()
+        assert prove(s) == ref and prove(s) == ref
+        _lib.check(_lib.load().sp1hip_stream_release(s.cuda_stream))
+        del s
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.Sp1HipError):
+        _lib.check(_lib.load().sp1hip_stream_release(None))        # the default stream is never released
+
+
 def test_prove_shard_size_protocol_and_transcript_rollback(api):
     chips, publics = make_shard_chips(4, 23)
     L, lsh, batch = 3, 2, 2
