@@ -28,6 +28,9 @@ void set_error(const char* fmt, ...);
 void set_stage_note(const char* note);
 const char* stage_note();
 int wait_timeout_seconds();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of once per launch (a driver call in
+// front of every zerocheck round launch and every 256-point encode pass).
+int ensure_dynamic_lds(const void* kernel, int bytes);
 // Provers (shard proofs, or stand-alone stage calls) in flight in this process, counted once per calling thread however the
 // entry points nest. The zerocheck spreads a round's launches over fork streams only while it is the ONLY prover: with several
 // provers in flight the device is filled by the other proofs anyway, and the forks' cross-stream events on the process's four

@@ -264,7 +264,7 @@ static int launch_pass(FastPassArgs args, bool strided, bool first, bool zero_qu
                                  : ntt_fast_pass<A, B, true, false, WAVES>)
                         : (first ? ntt_fast_pass<A, B, false, true, WAVES> : ntt_fast_pass<A, B, false, false, WAVES>);
     if (lds > 48 * 1024)   // 256-point tiles need ~65 KiB of the CU's 160 KiB LDS
-        SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), lds, s, args.in, args.out, args.tw_r, args.tw_lane, args.tw_lo, args.tw_hi,
                        args.lg_total, args.lg_seg, args.lg_n_in);
     SP1HIP_LAUNCH_CHECK();

@@ -25,6 +25,22 @@ static thread_local int g_prover_depth = 0;
 ActiveProver::ActiveProver() : counted(g_prover_depth++ == 0) { if (counted) g_active_provers.fetch_add(1, std::memory_order_relaxed); }
 ActiveProver::~ActiveProver() { g_prover_depth--; if (counted) g_active_provers.fetch_sub(1, std::memory_order_relaxed); }
 int active_provers() { return g_active_provers.load(std::memory_order_relaxed); }
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex m;
+    static std::map<std::pair<int, const void*>, int> done;       // (device, kernel) -> the size already granted
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(m);
+        auto it = done.find({dev, kernel});
+        if (it != done.end() && it->second >= bytes) return SP1HIP_SUCCESS;
+    }
+    SP1HIP_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    std::lock_guard<std::mutex> lock(m);
+    int& v = done[{dev, kernel}];
+    v = std::max(v, bytes);
+    return SP1HIP_SUCCESS;
+}
 int wait_timeout_seconds() {
     static const int t = [] { const char* e = getenv("SP1HIP_WAIT_TIMEOUT_S"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 60; }();
     return t;

@@ -1505,11 +1505,11 @@ static int launch_round(uint32_t max_regs, bool staged, bool fused, const ZcDesc
         const size_t total = lds + zc_rf_lane_bytes<FIRST>(max_regs) * wg;
         if (staged) {
             auto kern = zc_round_kernel<FIRST, 0, true>;
-            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
             hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
         } else {
             auto kern = zc_round_kernel<FIRST, 0, false>;
-            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
             hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
         }
         SP1HIP_LAUNCH_CHECK();
@@ -1556,11 +1556,11 @@ static int launch_biv_round(uint32_t max_regs, bool staged, const ZcDesc* d_desc
         const size_t total = lds + zc_rf_lane_bytes<false>(max_regs) * wg;
         if (staged) {
             auto kern = zc_biv_round_kernel<0, true>;
-            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
             hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
         } else {
             auto kern = zc_biv_round_kernel<0, false>;
-            if (total > 48 * 1024) SP1HIP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZC_LDS_BUDGET));
+            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
             hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
         }
         SP1HIP_LAUNCH_CHECK();
