@@ -854,8 +854,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     std::vector<uint16_t> flat_index;                        // FLAT launches: slot -> descriptor, all launches back to back
     // workgroups of a large pass. While every workgroup paid an L2 write-back and a serialised ticket in its tail
     // (round_sync.hpp) one resident set — 256 CUs x 4 workgroups — was the optimum; without them finer tiles balance the
-    // tail better (sweep of round 2 on the one-round kernels: 4096 best, flat between 2048 and 8192).
-    static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 1u) : 4096u; }();
+    // tail better (sweep of round 2 on the one-round kernels: 4096 best, flat between 2048 and 8192). Round 4, two-round passes on
+    // the real-chip shard (alternating runs on three boxes): 1024-3072 tiles are within 0.3 ms of each other, 4096 is 0.7-1.0 ms
+    // slower over the stage, 8192 / 16384 1.4 / 3.2 ms slower — a pass carries more state per workgroup than a round kernel did.
+    static const uint32_t TARGET_TILES = [] { const char* e = getenv("SP1HIP_GKR_TILES"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 1u) : 2048u; }();
     std::vector<PassDesc> all_descs;
     all_descs.reserve(n_passes_total * K);                  // ~10 MB at 730 interactions: no regrowth copies while planning
     // a layer's last fold (one row per interaction) goes straight to the mailbox slot, 16-byte aligned behind word 0
