@@ -399,6 +399,10 @@ int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_instr, uint32
                                const uint32_t* main_row, const uint32_t* prep_row, const uint32_t* publics,
                                uint32_t n_publics, int form, uint32_t* out_values, uint32_t n_constraints,
                                uint32_t* out_stats);
+/* Host-only: the bilinear extension of a column's row quad (r00, r01, r10, r11 = rows 4q .. 4q + 3, Montgomery words) at node
+ * `node` (0 .. 11) of the bivariate grid the fused first two zerocheck rounds evaluate — the same function the kernels call
+ * (zc_biv_interp: one 36-bit accumulation and its reduction); for tests of its edge cases without a GPU. */
+int sp1hip_zerocheck_biv_interp_host(uint32_t r00, uint32_t r01, uint32_t r10, uint32_t r11, uint32_t node, uint32_t* out);
 
 /* ---------------------------------------------------------------- one whole shard proof
  * A chip of the shard with everything the stages need: constraint program (zerocheck, see sp1hip_zc_chip_t),

@@ -195,6 +195,7 @@ PROTOTYPES = [
     ("sp1hip_pool_submit", None, [_vp, _vp, C.POINTER(PoolChip), _int, u32p, _int, C.POINTER(C.c_uint64)]),
     ("sp1hip_pool_wait", None, [_vp, C.c_uint64, u8p, C.POINTER(_sz), C.POINTER(PoolTimes)]),
     ("sp1hip_pool_try_wait", None, [_vp, C.c_uint64, u8p, C.POINTER(_sz), C.POINTER(PoolTimes)]),
+    ("sp1hip_zerocheck_biv_interp_host", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
     ("sp1hip_zerocheck_plan_eval", None, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.c_uint32, _int, u32p,
                                           C.c_uint32, u32p]),
 ]

@@ -2466,6 +2466,13 @@ __global__ __launch_bounds__(256) void fix_last_variable_kernel(const uint32_t* 
 }  // namespace sp1hip
 
 // Host-only: plans `program` exactly as sp1hip_zerocheck_prove does and interprets the chosen form of it on one row.
+extern "C" int sp1hip_zerocheck_biv_interp_host(uint32_t r00, uint32_t r01, uint32_t r10, uint32_t r11, uint32_t node, uint32_t* out) {
+    SP1HIP_REQUIRE(out && node < (uint32_t)ZC_BIV_NODES, "node out of range");
+    SP1HIP_REQUIRE(r00 < kb::P && r01 < kb::P && r10 < kb::P && r11 < kb::P, "word not reduced");
+    *out = zc_biv_interp(r00, r01, r10, r11, zc_biv_node(node));
+    return SP1HIP_SUCCESS;
+}
+
 extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width,
                                           const uint32_t* main_row, const uint32_t* prep_row, const uint32_t* publics,
                                           uint32_t n_publics, int form, uint32_t* out_values, uint32_t n_constraints,

@@ -112,3 +112,26 @@ def test_bivariate_grid_reproduces_the_two_sequential_rounds(nv):
     rng = random.Random(5 + nv)
     for rows in range(1, (1 << nv) + 1):
         run(nv, rows, rng)
+
+
+def test_the_library_interpolation_at_every_node_and_at_the_extremes():
+    """`zc_biv_interp` (what the bivariate kernels run per column and node: one 36-bit accumulation, one reduction) against plain
+    integers — on Montgomery words, which the affine map preserves — incl. the all-(p - 1) and alternating extremes."""
+    import ctypes as C
+
+    import numpy as np
+
+    from sp1_amd import _lib
+    lib = _lib.load()
+    NODES = [(0, 2), (0, 4), (1, 2), (1, 4), (2, 0), (2, 1), (2, 2), (2, 4), (4, 0), (4, 1), (4, 2), (4, 4)]
+    rng = random.Random(11)
+    cases = [(P - 1,) * 4, (0, P - 1, P - 1, 0), (P - 1, 0, 0, P - 1), (P - 1, 0, 0, 0), (0, 0, 0, P - 1), (0, P - 1, 0, 0), (1, 0, 0, 0)]
+    cases += [tuple(rng.randrange(P) for _ in range(4)) for _ in range(200)]
+    out = np.zeros(1, np.uint32)
+    for r00, r01, r10, r11 in cases:
+        for e, (x, y) in enumerate(NODES):
+            _lib.check(lib.sp1hip_zerocheck_biv_interp_host(r00, r01, r10, r11, e, out.ctypes.data_as(_lib.u32p)))
+            want = (r00 + x * (r10 - r00) + y * (r01 - r00) + x * y * (r11 - r10 - r01 + r00)) % P
+            assert int(out[0]) == want, (r00, r01, r10, r11, e)
+    with pytest.raises(_lib.Sp1HipError):
+        _lib.check(lib.sp1hip_zerocheck_biv_interp_host(0, 0, 0, 0, 12, out.ctypes.data_as(_lib.u32p)))
