@@ -4,7 +4,8 @@
 //!   0 LOAD_MAIN col | 1 LOAD_PREP col | 2 CONST canonical | 3 PUBLIC idx | 4 ADD a b | 5 SUB a b | 6 MUL a b | 7 NEG a |
 //!   8 ASSERT_ZERO a | 16 HINT kind col (optional pseudo-instruction, no value: kind 1 = "the next 163 asserts are the
 //!   Poseidon2 permutation sub-AIR over main columns [col, col + 179)", what `hint_poseidon2` below records when a chip's
-//!   eval enters `eval_external_round` / `eval_internal_rounds`; the HIP prover evaluates such a block with a fused kernel)
+//!   eval enters `eval_external_round` / `eval_internal_rounds`; kinds 2 / 3 = the septic curve equation / sum checker of the
+//!   Global chip, `hint_septic_curve` / `hint_septic_sum`; the HIP prover evaluates such a block with a fused kernel)
 //!
 //! Same job as the reference's `DagBuilder` (sp1-gpu/crates/air/src/ir/builder.rs:L29-L66, expr.rs, var.rs), different
 //! design: no global DAG behind a mutex, no node enum — a thread-local instruction list with hash-consing (a repeated load /
@@ -77,6 +78,20 @@ fn emit(op: u32, a: u32, b: u32) -> u32 {
 /// Poseidon2Wide) right before lowering the operation. Never merged, defines no value.
 pub fn hint_poseidon2(first_col: u32) {
     TAPE.with(|t| t.borrow_mut().instrs.push([HINT, HINT_POSEIDON2, first_col]));
+}
+
+/// The 7 asserts that follow are the septic curve equation y^2 = x^3 + 45 x + 41 z^3 over main columns [xy_col, xy_col + 14)
+/// (x then y; `GlobalInteractionOperation::eval_single_digest`, operations/global_interaction.rs:L203-L208). Kind 2.
+pub fn hint_septic_curve(xy_col: u32) {
+    TAPE.with(|t| t.borrow_mut().instrs.push([HINT, 2, xy_col]));
+}
+
+/// The 14 asserts that follow are `sum_checker_x` and `is_real * sum_checker_y` of the global accumulation
+/// (operations/global_accumulation.rs:L83-L131) for p1 = main columns [acc_col, +14), p2 = [xy_col, +14), p3 = [acc_col + 14, +14).
+/// Kind 3; the operand words carry the `is_real` column (bits 8.. of the first) and both column bases (16 bits each).
+pub fn hint_septic_sum(xy_col: u32, acc_col: u32, is_real_col: u32) {
+    assert!(xy_col < (1 << 16) && acc_col < (1 << 16) && is_real_col < (1 << 24));
+    TAPE.with(|t| t.borrow_mut().instrs.push([HINT, 3 | (is_real_col << 8), xy_col | (acc_col << 16)]));
 }
 
 fn constant(f: F) -> u32 {
