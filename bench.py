@@ -7,9 +7,9 @@ One "step" = `sp1hip_prove_shard` = `ShardProver::prove_shard_with_data`
 zerocheck -> jagged evaluation proof (jagged sumcheck, jagged-eval, stacked BaseFold opening, 124 queries, 16-bit PoW);
 the output is a complete bincode(ShardProof) that the pinned verifier accepts (tests/test_gpu_shard.py).
 
-Workload (`config.workload`, round 4): the core shard of REAL RISC-V chips (bench/core_real.py): the 29 rv64im chips
+Workload (`config.workload`, round 4): the core shard of REAL RISC-V chips (bench/core_real.py): the 30 rv64im chips
 transcribed from the reference's `Air::eval` bodies (sp1_amd/machines/riscv.py — every chip of the reference's recorded
-core shard 0 except four that hold 0.15 % of its cells) at that shard's recorded heights (3.7e8 trace cells against
+core shard 0 except DivRem and the two syscall chips, 48 rows together) at that shard's recorded heights (3.7e8 trace cells against
 3.74e8 recorded; Global and MemoryLocal 0.96x, Program 1.55x — see bench/core_real.py — max_log_row_count 22, stacking
 height 2^21), on traces of an EXECUTED rv64im program (sp1_amd/machines/riscv_trace.py: 6.2e6 instructions, lookups balanced). `synthetic_core_shaped` carries the round-1..3 workload (bench/core_shard.py) for
 continuity. The reference defines its headline "Core kHz" as cycles / core-proving seconds

@@ -25,7 +25,7 @@ from sp1_amd.machines import riscv as R, riscv_trace as RT         # noqa: E402
 # 0.96x their recorded heights (13 gave 0.65x: fewer positions than recorded touched words); Program is 1.55x as tall in exchange.
 K_ITER = 8
 NOT_INSTRUCTIONS = ("Byte", "Range", "Program", "MemoryLocal", "MemoryBump", "StateBump", "Global", "DivRem", "SyscallCore",
-                    "SyscallInstrs", "LoadX0")
+                    "SyscallInstrs")
 P = api.P
 
 

@@ -834,6 +834,30 @@ def load_word_chip():                                                      # loa
     return _done(b, c)
 
 
+def load_x0_chip():                                                        # load/load_x0.rs:L220-L388
+    """Loads whose destination is x0: the access to memory (and its alignment / address checks) happens, the value goes nowhere."""
+    b, c, _ = _chip("LoadX0", 48)
+    L = S(("state", CPU_STATE), ("adapter", I_TYPE), ("address", ADDRESS_OP), ("memory_access", MEM_ACCESS), ("offset_bit", 3),
+          ("is_lb", 1), ("is_lbu", 1), ("is_lh", 1), ("is_lhu", 1), ("is_lw", 1), ("is_lwu", 1), ("is_ld", 1))(c)
+    sel = [("LB", L.is_lb), ("LBU", L.is_lbu), ("LH", L.is_lh), ("LHU", L.is_lhu), ("LW", L.is_lw), ("LWU", L.is_lwu), ("LD", L.is_ld)]
+    opcode = sum((f * OPC[n] for n, f in sel[1:]), sel[0][1] * OPC[sel[0][0]])
+    is_real = L.is_lb + L.is_lbu + L.is_lh + L.is_lhu + L.is_lw + L.is_lwu + L.is_ld
+    for _, f in sel:
+        b.assert_bool(f)
+    b.assert_bool(is_real)
+    ob = L.offset_bit
+    aligned = eval_address(b, L.adapter.op_b_memory.prev_value, L.adapter.op_c_imm, ob[0], ob[1], ob[2], is_real, L.address)
+    b.when(L.is_ld).assert_zero(ob[2])
+    b.when(L.is_lw + L.is_lwu + L.is_ld).assert_zero(ob[1])
+    b.when(L.is_lh + L.is_lhu + L.is_lw + L.is_lwu + L.is_ld).assert_zero(ob[0])
+    eval_memory_access(b, *_mem_clk(L.state), aligned, L.memory_access, L.memory_access.prev_value, is_real)
+    b.when(is_real).assert_one(L.adapter.op_a_0)
+    b.when_not(is_real).assert_zero(L.adapter.op_a_0)
+    eval_cpu_state(b, L.state, next_pc_inc(L.state), CLK_INC, is_real)
+    eval_i_type(b, L.state, opcode, L.adapter.op_a_memory.prev_value, L.adapter, is_real, is_real)      # ITypeReaderImmutable
+    return _done(b, c)
+
+
 def store_double_chip():                                                   # store/store_double.rs
     b, c, _ = _chip("StoreDouble", 39)
     L = S(("state", CPU_STATE), ("adapter", I_TYPE), ("address", ADDRESS_OP), ("memory_access", MEM_ACCESS), ("is_real", 1))(c)
@@ -1166,7 +1190,7 @@ CHIPS = {
     "Add": add_chip, "Addi": addi_chip, "Sub": sub_chip, "Bitwise": bitwise_chip, "Lt": lt_chip, "Mul": mul_chip,
     "ShiftLeft": shift_left_chip, "ShiftRight": shift_right_chip, "UType": utype_chip, "MemoryLocal": memory_local_chip,
     "Addw": addw_chip, "Subw": subw_chip, "LoadByte": load_byte_chip, "LoadHalf": load_half_chip, "LoadWord": load_word_chip,
-    "LoadDouble": load_double_chip, "StoreByte": store_byte_chip, "StoreHalf": store_half_chip, "StoreWord": store_word_chip,
+    "LoadDouble": load_double_chip, "LoadX0": load_x0_chip, "StoreByte": store_byte_chip, "StoreHalf": store_half_chip, "StoreWord": store_word_chip,
     "StoreDouble": store_double_chip, "Branch": branch_chip, "Jal": jal_chip, "Jalr": jalr_chip, "MemoryBump": memory_bump_chip, "StateBump": state_bump_chip, "Program": program_chip, "Byte": byte_chip, "Range": range_chip, "Global": global_chip,
 }
 

@@ -53,7 +53,8 @@ ALU_KINDS = {
     "Addw": ["ADDW"], "Subw": ["SUBW"],
 }
 IMM_CAPABLE = {"Bitwise", "Lt", "ShiftLeft", "ShiftRight", "Addw"}           # ALUTypeReader chips: op_c may be an immediate
-LOAD_KINDS = {"LoadByte": ["LB", "LBU"], "LoadHalf": ["LH", "LHU"], "LoadWord": ["LW", "LWU"], "LoadDouble": ["LD"]}
+LOAD_KINDS = {"LoadByte": ["LB", "LBU"], "LoadHalf": ["LH", "LHU"], "LoadWord": ["LW", "LWU"], "LoadDouble": ["LD"],
+              "LoadX0": ["LB", "LBU", "LH", "LHU", "LW", "LWU", "LD"]}          # LoadX0: any load whose destination is x0
 STORE_KINDS = {"StoreByte": ["SB"], "StoreHalf": ["SH"], "StoreWord": ["SW"], "StoreDouble": ["SD"]}
 BRANCH_OPS = ["BEQ", "BNE", "BLT", "BGE", "BLTU", "BGEU"]
 ACCESS_BYTES = {"LB": 1, "LBU": 1, "LH": 2, "LHU": 2, "LW": 4, "LWU": 4, "LD": 8, "SB": 1, "SH": 2, "SW": 4, "SD": 8}
@@ -162,7 +163,7 @@ class Body:
             elif name in LOAD_KINDS:
                 opn = pick(LOAD_KINDS[name])
                 nb = ACCESS_BYTES[opn]
-                emit(name, opn, pick(D2_REGS), pick(PR_REGS), -1, int(rng.integers(0, PAGE // nb)) * nb, True)
+                emit(name, opn, 0 if name == "LoadX0" else pick(D2_REGS), pick(PR_REGS), -1, int(rng.integers(0, PAGE // nb)) * nb, True)
             elif name in STORE_KINDS:
                 opn = pick(STORE_KINDS[name])
                 nb = ACCESS_BYTES[opn]
@@ -818,7 +819,7 @@ class Tracer:
         bits = [(addr >> i) & 1 for i in range(3)]
         pvl = limbs16(prev_val)
         rows = torch.arange(len(p), device=self.dev)
-        if chip in ("LoadByte", "StoreByte"):
+        if chip in ("LoadByte", "StoreByte", "LoadX0"):
             tb.set("offset_bit", torch.stack(bits, dim=1))
         elif chip in ("LoadHalf", "StoreHalf"):
             tb.set("offset_bit", torch.stack(bits[1:], dim=1))
@@ -849,6 +850,9 @@ class Tracer:
             tb.set("is_lwu", (~lw).to(I64))
         elif chip == "LoadDouble":
             tb.set("is_real", 1)
+        elif chip == "LoadX0":
+            for nm in LOAD_KINDS["LoadX0"]:
+                tb.set("is_" + nm.lower(), (op == OPC[nm]).to(I64))
         else:
             tb.set("is_real", 1)
             if chip != "StoreDouble":

@@ -1,4 +1,4 @@
-"""GPU parity (-m gpu) on the RISC-V core chips (sp1_amd/machines/riscv.py: 29 chips of the rv64im machine transcribed
+"""GPU parity (-m gpu) on the RISC-V core chips (sp1_amd/machines/riscv.py: 30 chips of the rv64im machine transcribed
 from the reference's `Air::eval` bodies) over traces that sp1_amd/machines/riscv_trace.py executes: `sp1hip_prove_shard`
 bytes == the oracle prover's, and the oracle's full verify_shard (zerocheck closing equation with these constraint
 programs + LogUp-GKR interaction check with these interactions) accepts; at 1/64 of the reference's recorded core shard

@@ -20,7 +20,7 @@ torch = pytest.importorskip("torch")
 # chips have their CURRENT column and constraint counts, and more interactions than the recording
 NEWER_THAN_RECORDING = {"Jal": 18, "Jalr": 22, "MemoryBump": 8, "Global": 12}
 FULL = {"Add": 5, "Addi": 7, "Sub": 3, "Bitwise": 6, "Lt": 6, "Mul": 6, "ShiftLeft": 6, "ShiftRight": 8, "Addw": 3, "Subw": 3,
-        "UType": 12, "LoadByte": 14, "LoadHalf": 5, "LoadWord": 5, "LoadDouble": 5, "StoreByte": 10, "StoreHalf": 5,
+        "UType": 12, "LoadByte": 14, "LoadHalf": 5, "LoadWord": 5, "LoadDouble": 5, "LoadX0": 9, "StoreByte": 10, "StoreHalf": 5,
         "StoreWord": 5, "StoreDouble": 5, "Branch": 12, "Jal": 4, "Jalr": 9}
 
 
