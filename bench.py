@@ -41,6 +41,25 @@ TIMERS = ("ntt_pass0", "ntt_pass1", "ntt_pass2", "leaf_hash", "compress", "gkr_f
           "jagged_fold_sum", "jagged_batch_evals", "stage_commit", "stage_logup_gkr", "stage_zerocheck", "stage_evaluation_proof")
 
 
+def thread_cpu_times():
+    """{tid: (user + system seconds, comm)} of this process's threads (/proc/self/task)."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{tid}/stat") as f:
+                    st = f.read()
+                comm = st[st.index("(") + 1:st.rindex(")")]
+                fields = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = ((int(fields[11]) + int(fields[12])) / tick, comm)
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def timers_read(api, name):
     n, ms = C.c_uint64(), C.c_double()
     api.check(api._L().sp1hip_timers_read(name.encode(), C.byref(n), C.byref(ms)))
@@ -429,6 +448,7 @@ def main():
     api.check(lib.sp1hip_timers_reset())
     api.check(lib.sp1hip_timers_enable(1))
     cpu0 = time.process_time()                               # user + system time of every thread of this process
+    thr0 = thread_cpu_times()
     t0 = time.perf_counter()
     proof = None
     for _ in range(args.steps):
@@ -439,6 +459,16 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     host_cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps
+    thr1 = thread_cpu_times()
+    # where the host CPU time goes: the calling thread (transcript + waiting for hand-overs) against everything else (the HIP
+    # runtime's own threads, helpers), ms per proof
+    me = threading.get_native_id()
+    host_cpu_by_thread = {"caller": round(1e3 * (thr1.get(me, (0, ""))[0] - thr0.get(me, (0, ""))[0]) / args.steps, 2)}
+    for tid, (t, comm) in thr1.items():
+        if tid != me:
+            d = 1e3 * (t - thr0.get(tid, (0, ""))[0]) / args.steps
+            if d >= 0.05:
+                host_cpu_by_thread[comm] = round(host_cpu_by_thread.get(comm, 0) + d, 2)
     api.check(lib.sp1hip_timers_enable(0))
     tl = {name: timers_read(api, name) for name in TIMERS}
     dt = shards.max_over_ranks(dt)                 # shards are striped one per rank: no data-path collective
@@ -461,6 +491,24 @@ def main():
             del sd
         torch.cuda.synchronize()
         extras["commit_only"] = {"ms": 1e3 * (time.perf_counter() - t1) / 3, "cells": sum(c[2].height * c[2].width for c in chips)}
+        # the RS encode of the shard's stacked columns ALONE (in the proof it runs under the leaf hash): batches of 32 columns of
+        # height 2^lsh, blowup 4, the same three passes
+        try:
+            S_all = -(-sum(c[2].height * c[2].width for c in chips) // (1 << lsh)) + 1
+            cols = api.ColMajor(api.device_words((1 << lsh) * 32), 1 << lsh, 32)
+            cw = api.device_words((4 << lsh) * 32)
+            n_batches = -(-S_all // 32)
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n_batches):
+                    api.check(lib.sp1hip_rs_encode_batch(api._dptr(cw), api._dptr(cols.words), lsh, 2, 32, api._stream_ptr()))
+                torch.cuda.synchronize()
+                extras["rs_encode_alone_ms"] = 1e3 * (time.perf_counter() - t1)
+            del cols, cw
+        except Exception as e:                                    # an extra, never the reason a line is missing
+            extras["rs_encode_alone_ms"] = None
+            print("bench.py: rs_encode alone not measured: %r" % (e,), file=sys.stderr)
         extras["real_machine"] = real_machine(api)
         if kind == "real":
             extras["synthetic_core_shaped"] = synthetic_core_shaped(api, k)
@@ -477,11 +525,15 @@ def main():
         N = 4 * h
         perms = N * (-(-S_cols // 8)) if S_cols else 0
         # kernel groups: (timers summed, algorithmic bytes per proof — SURVEY §8d)
+        zc_bivariate = os.environ.get("SP1HIP_ZC_BIVARIATE", "1") != "0"
         groups = {
             "leaf_hash": (["leaf_hash"], 4 * N * S_cols + 32 * N),
             "rs_encode": (["ntt_pass0", "ntt_pass1", "ntt_pass2"], 4 * h * S_cols * 5),
-            "zerocheck_round": (["zerocheck_round"], 20 * area),     # round 0 reads 4A, rounds >= 1 read 16A of extension tables in total
-            "zerocheck_fix": (["zerocheck_fix"], 36 * area),         # reads 4A + 16A, writes 8A + 8A
+            # bivariate (default): rounds 0 + 1 read the base traces once (4A), rounds >= 2 read extension tables of A/4, A/8 ...
+            # rows (8A in total); the table updates: fix2 reads 4A and writes 4A, later updates read 8A and write 4A in total.
+            # sequential (SP1HIP_ZC_BIVARIATE=0): round 0 reads 4A, rounds >= 1 16A; updates read 4A + 16A, write 8A + 8A
+            "zerocheck_round": (["zerocheck_round"], (12 if zc_bivariate else 20) * area),
+            "zerocheck_fix": (["zerocheck_fix"], (20 if zc_bivariate else 36) * area),
             "gkr_pass": (["gkr_pass_sum", "gkr_pass_fold_sum", "gkr_pass_fold"], 156 * meta["first_layer_entries"]),
             "gkr_first_layer": (["gkr_first_layer"], 20 * meta["first_layer_entries"]),
             "gkr_transition": (["gkr_transition"], 52 * meta["first_layer_entries"]),
@@ -542,6 +594,17 @@ def main():
         stages["windows"] = windows
         # the dominant kernel group of the step, by live-measured launch time over ALL timed kernels
         dom = max((g for g in groups if g in stages), key=lambda g: stages[g]["ms"])
+        overlapped = None
+        if dom in ("rs_encode", "leaf_hash") and "commit" in windows and "leaf_hash" in stages and "rs_encode" in stages:
+            # the two commit groups run CONCURRENTLY (encode of batch k + 1 under the leaf hash of batch k): their summed launch
+            # times are stretched by each other. The window's largest consumer is the one with more of its binding resource
+            # (VALU lane-instructions from the PMC table, else its time alone); the other is reported beside it
+            big = max(("leaf_hash", "rs_encode"), key=lambda g: stages[g]["valu_lane_insts_pmc"] or stages[g]["ms"])
+            other = "rs_encode" if big == "leaf_hash" else "leaf_hash"
+            dom = big
+            overlapped = {"group": other, "in_step_ms": stages[other]["ms"], "alone_ms": extras.get("rs_encode_alone_ms") if other == "rs_encode" else None,
+                          "window": "commit", "window_ms": windows["commit"]["ms"],
+                          "window_valu_frac": windows["commit"]["valu_frac_vs_measured_int_rate"]}
         d = stages[dom]
         dom_ms, dom_launches, alg_dom = d["ms"], d["launches"], groups[dom][1]
         ms_per_step = 1e3 * dt / args.steps
@@ -550,24 +613,28 @@ def main():
         else:
             achieved, peak, unit = alg_dom / (dom_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
         traffic = d["hbm_bytes_pmc"] / dom_launches if d["hbm_bytes_pmc"] else None
-        workload_text = (
-            "one whole core-shard proof (sp1hip_prove_shard = prove_shard_with_data): %d chips, of which REAL (constraints + interactions "
-            "transcribed from the reference's Air::eval, traces of an executed rv64im program): %s; synthetic closing chips: %s; "
-            "%d interactions / %d constraints; heights of the reference's recorded core shard 0 (layer_workloads.json), %d RISC-V "
-            "instructions executed" % (meta["chips"], ", ".join(meta["real_chips"]), ", ".join(meta["synthetic_chips"]),
-                                       meta["interactions"], meta["constraints"], meta["instructions_executed"])
-            if kind == "real" else
-            "one whole core-shard proof: core-shaped SYNTHETIC shard, %d chips / %d interactions / %d constraints"
-            % (meta["chips"], meta["interactions"], meta["constraints"]))
+        # (the essentials first: the driver's parse truncates long strings)
+        if kind == "real":
+            workload_text = ("core shard, rv64im machine: %d real chips + %d closing chips, %d constraints, %d interactions, heights of "
+                             "the reference's recorded core shard 0, %d instructions executed"
+                             % (len(meta["real_chips"]), len(meta["synthetic_chips"]), meta["constraints"], meta["interactions"],
+                                meta["instructions_executed"]))
+        elif kind == "precompile":
+            workload_text = ("precompile shard: %d real chips (%s), %d constraints, %d interactions"
+                             % (len(meta["real_chips"]), ", ".join(meta["real_chips"]), meta["constraints"], meta["interactions"]))
+        else:
+            workload_text = ("core-shaped SYNTHETIC shard: %d chips, %d constraints, %d interactions"
+                             % (meta["chips"], meta["constraints"], meta["interactions"]))
         out = {
             "metric": "core shard prove throughput: trace cells proved/sec (whole ShardProof of the RISC-V core machine, see config)",
             "value": world * args.steps * area / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": "synthetic",
+            "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": ("synthetic: traces of an rv64im test program executed by this repository's executor + 2 synthetic closing chips"
+                     if kind == "real" else "synthetic: seeded traces of real chips" if kind == "precompile" else "synthetic"),
             "proofs_per_s": world * args.steps / dt,
             "riscv_instructions_per_s": world * args.steps * meta["instructions_executed"] / dt if kind == "real" else None,
-            "config": {"workload": workload_text + "; area %d cells%s, max_log_row_count %d, stacking height 2^%d, log_blowup 2, "
-                                   "124 queries, 16-bit PoW; traces resident in HBM" % (area, "" if k == 0 else " (scale 4^-%d)" % k, L, lsh),
+            "config": {"workload": workload_text + "; %d cells%s, L %d, stack 2^%d, blowup 4, 124 queries, 16-bit PoW; one whole ShardProof "
+                                   "(sp1hip_prove_shard), traces resident in HBM" % (area, "" if k == 0 else " (scale 4^-%d)" % k, L, lsh),
                        "area_cells": area, "first_layer_entries": meta["first_layer_entries"], "proof_bytes": len(proof),
                        "instructions_executed": meta.get("instructions_executed"),
                        "parallelism": "independent shards, one per GPU"},
@@ -575,7 +642,7 @@ def main():
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / (alg_dom / dom_launches)) if traffic else None,
                          "pmc_source": pmc_note, "hbm_frac": d["hbm_frac"], "valu_frac": d["valu_frac_vs_measured_int_rate"],
-                         "avg_launch_ms": dom_ms / dom_launches, "launches_per_step": dom_launches,
+                         "avg_launch_ms": dom_ms / dom_launches, "launches_per_step": dom_launches, "overlapped_with": overlapped,
                          "algorithmic_bytes_per_launch": alg_dom // dom_launches,
                          "note": "dominant kernel group of the step by live launch time (HIP events on the launch stream, all timed "
                                  "kernels considered); bound = whichever of algorithmic-bytes / time / 8 TB/s and SQ_INSTS_VALU x 64 / "
@@ -588,7 +655,8 @@ def main():
             "core_real_chips": ({"real_chips": meta["real_chips"], "synthetic_chips": meta["synthetic_chips"],
                                  "real_area_cells": meta["real_area_cells"], "ms_per_proof": ms_per_step,
                                  "zerocheck_round_ms": ms.get("zerocheck_round"), "per_chip": meta["per_chip"]} if kind == "real" else None),
-            "host_threads": lib.sp1hip_host_threads(), "host_cpu_ms_per_proof": host_cpu_ms,
+            "host_threads": lib.sp1hip_host_threads(), "host_cpu_ms_per_proof": host_cpu_ms, "host_cpu_ms_by_thread": host_cpu_by_thread,
+            "host_wait": os.environ.get("SP1HIP_WAIT", "predict"),
             "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},
             "real_machine": extras.get("real_machine"),
             "synthetic_core_shaped": extras.get("synthetic_core_shaped"),

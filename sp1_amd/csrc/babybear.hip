@@ -14,6 +14,7 @@
 //                   LDS (every global access a 64 B run per row of the tile), twiddles from one table per transform size
 //   bb_leaf_hash    one lane per row, the sponge state in VGPRs across all tensors' columns (coalesced column reads)
 //   bb_compress     one lane per parent
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -246,24 +247,29 @@ static int get_bb_ctx(BbCtx** out) {
     std::lock_guard<std::mutex> lk(g);
     BbCtx*& c = per_device[dev];
     if (!c) {
-        c = new BbCtx();
+        // published only when fully initialised: a failed allocation / copy must not leave a half-made context cached
+        std::unique_ptr<BbCtx> fresh(new BbCtx());
         const RoundConstants rc = make_round_constants();
-        SP1HIP_HIP(hipMalloc((void**)&c->d_rc, sizeof rc));
-        SP1HIP_HIP(hipMemcpy(c->d_rc, &rc, sizeof rc, hipMemcpyHostToDevice));
-        SP1HIP_HIP(hipDeviceSynchronize());      // (once per device: read from non-blocking streams)
+        SP1HIP_HIP(hipMalloc((void**)&fresh->d_rc, sizeof rc));
+        hipError_t e = hipMemcpy(fresh->d_rc, &rc, sizeof rc, hipMemcpyHostToDevice);      // synchronous: complete on return
+        if (e != hipSuccess) { (void)hipFree(fresh->d_rc); return map_hip_error(e, "uploading the BabyBear round constants"); }
+        c = fresh.release();
     }
     *out = c;
     return SP1HIP_SUCCESS;
 }
 static int twiddles_for(BbCtx* c, int log_N, hipStream_t s, const uint32_t** out) {
     std::lock_guard<std::mutex> lk(c->m);
-    uint32_t*& t = c->twiddles[log_N];
+    auto it = c->twiddles.find(log_N);
+    uint32_t* t = it == c->twiddles.end() ? nullptr : it->second;
     if (!t) {
         const uint64_t half = log_N ? ((uint64_t)1 << (log_N - 1)) : 1;
         SP1HIP_HIP(hipMalloc((void**)&t, half * 4));
         hipLaunchKernelGGL(bb_twiddle_kernel, dim3((unsigned)((half + 4095) / 4096)), dim3(256), 0, s, t, half, two_adic_generator(log_N), to_monty(1));
-        SP1HIP_LAUNCH_CHECK();
-        SP1HIP_HIP(hipStreamSynchronize(s));      // the table is shared by later calls on any stream
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);      // the table is shared by later calls on any stream
+        if (e != hipSuccess) { (void)hipFree(t); return map_hip_error(e, "building a BabyBear twiddle table"); }   // nothing cached on failure
+        c->twiddles[log_N] = t;
     }
     *out = t;
     return SP1HIP_SUCCESS;

@@ -28,6 +28,21 @@ void set_error(const char* fmt, ...);
 void set_stage_note(const char* note);
 const char* stage_note();
 int wait_timeout_seconds();
+// Device -> host hand-overs (round_sync.hpp) wait on a sequence number in mapped pinned memory. wait_for_seq() spins — unless the
+// calling thread is inside a WaitPlan (one whole shard proof) that has seen this hand-over before: a proof is a fixed sequence of
+// ~700 hand-overs whose durations repeat from proof to proof of the same shape, so the thread SLEEPS until shortly before the
+// expected arrival (clock_nanosleep, absolute) and spins only through the margin. A hand-over that arrives earlier than
+// predicted is found late by at most what was left of the sleep, and the next prediction is shortened; unknown shapes, the first
+// proof of a shape and hand-overs under 150 us are spun as before. SP1HIP_WAIT=spin turns the sleeping off.
+int wait_for_seq(volatile uint32_t* slot, uint32_t seq, hipStream_t s, const char* what);
+struct WaitPlan {                                   // RAII: opened by the shard prover around one proof
+    bool opened;
+    bool ok = false;                                // set by the owner when the proof succeeded: only then is the timeline kept
+    explicit WaitPlan(uint64_t shape_signature);
+    ~WaitPlan();
+    WaitPlan(const WaitPlan&) = delete;
+    WaitPlan& operator=(const WaitPlan&) = delete;
+};
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of once per launch (a driver call in
 // front of every zerocheck round launch and every 256-point encode pass).
 int ensure_dynamic_lds(const void* kernel, int bytes);

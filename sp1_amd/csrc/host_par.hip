@@ -43,9 +43,13 @@ struct Pool {
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return active; });
             }
+            uint32_t idle = 0;
             while (spinning.load(std::memory_order_acquire)) {
                 const uint64_t e = epoch.load(std::memory_order_acquire);
-                if (e == seen) { SP1HIP_CPU_PAUSE(); continue; }
+                // (a helper that has spun for a while without work gives its time slice away: on an oversubscribed host the
+                // thread it is waiting for may not be running)
+                if (e == seen) { if (++idle > 4096) { idle = 0; std::this_thread::yield(); } else SP1HIP_CPU_PAUSE(); continue; }
+                idle = 0;
                 seen = e;
                 if (index < parts) fn(ctx, index);
                 acked.fetch_add(1, std::memory_order_release);
@@ -145,7 +149,10 @@ void HostPar::Scope::dispatch(int parts, void (*fn)(void*, int), void* ctx) {
     fn(ctx, 0);
     // every helper acknowledges every epoch (also those without a part): none can be between "saw the epoch" and "read
     // the job" when the next job is written
-    while (p->acked.load(std::memory_order_acquire) != p->helpers) SP1HIP_CPU_PAUSE();
+    uint32_t idle = 0;
+    while (p->acked.load(std::memory_order_acquire) != p->helpers) {
+        if (++idle > 4096) { idle = 0; std::this_thread::yield(); } else SP1HIP_CPU_PAUSE();
+    }
 }
 
 }  // namespace sp1hip

@@ -180,19 +180,7 @@ struct RoundSyncHost {
     // copies n_words sums (from slot[1..]) into out
     int wait(uint32_t* out, int n_words) {
         volatile uint32_t* slot = h_slot;
-        const auto t0 = std::chrono::steady_clock::now();
-        uint64_t spins = 0;
-        while (slot[0] != seq) {
-            if ((++spins & 0xffff) == 0) {
-                const hipError_t q = hipStreamQuery(s);
-                if (q != hipSuccess && q != hipErrorNotReady) return map_hip_error(q, "kernel failed while the host waited for a round result");
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(wait_timeout_seconds())) {
-                    set_error("timed out waiting for a sumcheck round result (stage %s; expected sequence %u, the slot holds %u; stream query %d)",
-                              stage_note(), seq, slot[0], (int)q);
-                    return SP1HIP_ERROR_RUNTIME;
-                }
-            }
-        }
+        SP1HIP_TRY(wait_for_seq(slot, seq, s, "a sumcheck round result"));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         pending = false;
         for (int k = 0; k < n_words; k++) out[k] = slot[1 + k];
@@ -248,19 +236,7 @@ struct Mailbox {
         seq++;
         pending = true;
         volatile uint32_t* slot = h_slot;
-        const auto t0 = std::chrono::steady_clock::now();
-        uint64_t spins = 0;
-        while (slot[0] != seq) {
-            if ((++spins & 0xffff) == 0) {
-                const hipError_t q = hipStreamQuery(s);
-                if (q != hipSuccess && q != hipErrorNotReady) return map_hip_error(q, "kernel failed while the host waited for a result");
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(wait_timeout_seconds())) {
-                    set_error("timed out waiting for a device result (stage %s; expected sequence %u, the slot holds %u; stream query %d)",
-                              stage_note(), seq, slot[0], (int)q);
-                    return SP1HIP_ERROR_RUNTIME;
-                }
-            }
-        }
+        SP1HIP_TRY(wait_for_seq(slot, seq, s, "a device result"));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         pending = false;
         uint32_t* o = (uint32_t*)out;

@@ -3,6 +3,10 @@
 // (/root/reference/sp1-gpu/crates/sys/src/runtime.rs:L16-L172): hipMallocAsync-backed allocation,
 // streams, events; no globals other than the per-device contexts.
 #include <dlfcn.h>
+#include <sys/prctl.h>
+#include <time.h>
+#include <cerrno>
+#include <chrono>
 #include <cstring>
 #include <algorithm>
 #include <cstdlib>
@@ -44,6 +48,100 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
 int wait_timeout_seconds() {
     static const int t = [] { const char* e = getenv("SP1HIP_WAIT_TIMEOUT_S"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 60; }();
     return t;
+}
+
+// ---- predictive hand-over waits (common.hpp: wait_for_seq / WaitPlan)
+namespace {
+struct WaitTimeline { std::vector<float> last, prev; uint64_t used = 0; };       // microseconds per hand-over ordinal
+struct WaitState {
+    std::map<uint64_t, WaitTimeline> shapes;          // by shape signature (a thread proves a handful of shapes)
+    WaitTimeline* cur = nullptr;
+    uint64_t cur_sig = 0;
+    std::vector<float> rec;                           // this proof's measured waits
+    int depth = 0;
+    uint64_t clock = 0;
+    bool slack_set = false;
+};
+thread_local WaitState g_wait;
+constexpr float WAIT_MIN_PREDICTED_US = 150.f, WAIT_MARGIN_US = 60.f, WAIT_MARGIN_FRAC = 0.10f;
+bool wait_sleeping_enabled() {
+    static const bool on = [] { const char* e = getenv("SP1HIP_WAIT"); return !(e && strcmp(e, "spin") == 0); }();
+    return on;
+}
+}  // namespace
+
+WaitPlan::WaitPlan(uint64_t sig) : opened(false) {
+    WaitState& w = g_wait;
+    if (w.depth++ > 0 || !wait_sleeping_enabled()) return;
+    opened = true;
+    if (!w.slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL); w.slack_set = true; }   // 2 us instead of the default 50
+    auto it = w.shapes.find(sig);
+    w.cur = it == w.shapes.end() ? nullptr : &it->second;
+    w.cur_sig = sig;
+    w.rec.clear();
+    w.rec.reserve(w.cur ? w.cur->last.size() + 16 : 1024);
+}
+
+WaitPlan::~WaitPlan() {
+    WaitState& w = g_wait;
+    w.depth--;
+    if (!opened) return;
+    if (ok && !w.rec.empty()) {
+        if (!w.cur && w.shapes.size() >= 8) {          // keep the eight most recently used shapes
+            auto victim = w.shapes.begin();
+            for (auto it = w.shapes.begin(); it != w.shapes.end(); ++it) if (it->second.used < victim->second.used) victim = it;
+            w.shapes.erase(victim);
+        }
+        WaitTimeline& t = w.shapes[w.cur_sig];
+        t.used = ++w.clock;
+        if (t.last.size() == w.rec.size()) t.prev.swap(t.last); else t.prev = w.rec;     // a different hand-over count: start over
+        t.last = w.rec;
+    }
+    w.cur = nullptr;
+    w.rec.clear();
+}
+
+int wait_for_seq(volatile uint32_t* slot, uint32_t seq, hipStream_t s, const char* what) {
+    using clk = std::chrono::steady_clock;
+    WaitState& w = g_wait;
+    const bool planned = w.depth > 0 && wait_sleeping_enabled();
+    const auto t0 = clk::now();
+    bool overslept = false;
+    float predicted = 0.f;
+    if (planned && w.cur && slot[0] != seq) {
+        const size_t ord = w.rec.size();
+        if (ord < w.cur->last.size() && ord < w.cur->prev.size()) {
+            predicted = std::min(w.cur->last[ord], w.cur->prev[ord]);
+            if (predicted >= WAIT_MIN_PREDICTED_US) {
+                const float sleep_us = predicted - std::max(WAIT_MARGIN_US, WAIT_MARGIN_FRAC * predicted);
+                timespec now_ts;
+                clock_gettime(CLOCK_MONOTONIC, &now_ts);
+                const long long until = (long long)now_ts.tv_sec * 1000000000LL + now_ts.tv_nsec + (long long)(sleep_us * 1e3f);
+                timespec ts{(time_t)(until / 1000000000LL), (long)(until % 1000000000LL)};
+                while (clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, nullptr) == EINTR) {}
+                overslept = slot[0] == seq;
+            }
+        }
+    }
+    uint64_t spins = 0;
+    while (slot[0] != seq) {
+        if ((++spins & 0xffff) == 0) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipSuccess && q != hipErrorNotReady) { set_error("kernel failed while the host waited for %s", what); return map_hip_error(q, "kernel failed while the host waited for a device result"); }
+            if (clk::now() - t0 > std::chrono::seconds(wait_timeout_seconds())) {
+                set_error("timed out waiting for %s (stage %s; expected sequence %u, the slot holds %u; stream query %d)",
+                          what, stage_note(), seq, slot[0], (int)q);
+                return SP1HIP_ERROR_RUNTIME;
+            }
+        }
+    }
+    if (planned) {
+        float us = std::chrono::duration<float, std::micro>(clk::now() - t0).count();
+        // the result was already there when the sleep ended: its true arrival is unknown, so wake earlier next time
+        if (overslept) us = 0.75f * std::min(us, predicted);
+        w.rec.push_back(us);
+    }
+    return SP1HIP_SUCCESS;
 }
 
 void set_error(const char* fmt, ...) {
@@ -258,11 +356,23 @@ int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
                 }
         }
         if (stolen) {
+            // (the NULL stream is a legal donor; a destroyed stream's blocks were released with it — arena_release_stream —
+            // so a donor found in the free lists is normally alive)
             const hipError_t se = hipStreamSynchronize(donor);
             if (se == hipSuccess) { *ptr = stolen; return SP1HIP_SUCCESS; }
-            (void)hipGetLastError();          // (the donor stream is gone: the block cannot be in use any more)
-            *ptr = stolen;
-            return SP1HIP_SUCCESS;
+            (void)hipGetLastError();
+            if (se == hipErrorInvalidHandle || se == hipErrorContextIsDestroyed || se == hipErrorInvalidResourceHandle) {
+                *ptr = stolen;                // the donor stream is gone: nothing of it can still be running
+                return SP1HIP_SUCCESS;
+            }
+            // any other failure (a sticky device fault, a lost device): the block may still be in use — it goes back to its
+            // list and the error is the caller's
+            {
+                std::lock_guard<std::mutex> lock(g_arena_mutex);
+                g_arena[ArenaKey{dev, donor, sz}].push_back(stolen);
+                g_arena_cached_bytes[dev] += sz;
+            }
+            return map_hip_error(se, "hipStreamSynchronize(donor stream of a cached block)");
         }
         // 2. give THIS device's cached blocks back to the driver and retry once (other devices' provers are not stalled)
         arena_trim_device(dev);
@@ -411,13 +521,24 @@ int round_sync_acquire(RoundSyncSlot* out) {
     }
     RoundSyncSlot slot{nullptr, nullptr};
     SP1HIP_HIP(hipMalloc((void**)&slot.d_counter, RS_COUNTER_BYTES));
-    SP1HIP_HIP(hipMemset(slot.d_counter, 0, RS_COUNTER_BYTES));
-    // hipMemset of device memory is a fill kernel on the NULL stream and may return before it has run; the provers' streams are
-    // non-blocking ones, which the NULL stream does not order — without this the first round kernel to take tickets from a NEW
-    // slot could race the fill (seen once in ~1,000 pool proofs: a 4-slot pool's first proofs create the process's fourth slot
-    // while three provers run; the tickets never added up and the host timed out on a sequence number that was never written)
-    SP1HIP_HIP(hipDeviceSynchronize());
-    SP1HIP_HIP(hipHostMalloc((void**)&slot.h_slot, RS_SLOT_WORDS * 4, hipHostMallocMapped));
+    // The counters must be zero before the first ticket. hipMemset is a fill kernel on the NULL stream and may return before it
+    // has run; the provers' streams are non-blocking ones, which the NULL stream does not order — the first round kernel to take
+    // tickets from a NEW slot could race the fill (seen once in ~1,000 pool proofs, round 4). So: fill on a private stream and
+    // wait for THAT stream only (round 4 used hipDeviceSynchronize, which stalled a new slot on every prover's in-flight work).
+    hipError_t e;
+    {
+        static std::mutex fill_mutex;
+        static hipStream_t fill_stream[64] = {};
+        std::lock_guard<std::mutex> lock(fill_mutex);
+        e = fill_stream[dev] ? hipSuccess : hipStreamCreateWithFlags(&fill_stream[dev], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemsetAsync(slot.d_counter, 0, RS_COUNTER_BYTES, fill_stream[dev]);
+        if (e == hipSuccess) e = hipStreamSynchronize(fill_stream[dev]);
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void**)&slot.h_slot, RS_SLOT_WORDS * 4, hipHostMallocMapped);
+    if (e != hipSuccess) {
+        (void)hipFree(slot.d_counter);
+        return map_hip_error(e, "creating a round-sync slot");
+    }
     memset(slot.h_slot, 0, RS_SLOT_WORDS * 4);
     *out = slot;
     return SP1HIP_SUCCESS;

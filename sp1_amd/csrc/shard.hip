@@ -77,6 +77,13 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     }
     SP1HIP_REQUIRE(prep_cols > 0, "a shard needs at least one preprocessed column (two commitment rounds)");
     SP1HIP_REQUIRE(main_area > 0, "empty shard");
+    // the proof's hand-over timeline repeats between proofs of one shape (common.hpp: WaitPlan)
+    uint64_t shape_sig = 0xcbf29ce484222325ull;
+    {
+        auto mix = [&](uint64_t v) { shape_sig = (shape_sig ^ v) * 0x100000001b3ull; };
+        mix((uint64_t)n_chips); mix((uint64_t)L); mix((uint64_t)lsh); mix((uint64_t)params.fri.log_blowup); mix((uint64_t)params.fri.num_queries);
+        for (int c = 0; c < n_chips; c++) { mix(chips[c].real_rows); mix((uint64_t)chips[c].main_width << 32 | (uint32_t)chips[c].n_instr); }
+    }
 
     // ---- exact proof size from the shapes
     size_t gkr_size = 0, zc_size = 0;
@@ -123,6 +130,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         }
         ~StageMarks() { close(); }
     } marks{S(stream)};
+    WaitPlan wait_plan(shape_sig);
     marks.next("commit");
     sp1hip_challenger_t* ch = nullptr;
     SP1HIP_TRY(sp1hip_challenger_clone(challenger, &ch));
@@ -267,6 +275,7 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         fprintf(stderr, "[sp1hip shard] commit %.3f ms | LogUp-GKR %.3f | zerocheck %.3f | evaluation proof %.3f | proof bytes %.3f\n", ms(0, 1), ms(1, 2),
                 ms(2, 3), ms(3, 4), ms(4, 5));
     }
+    wait_plan.ok = true;
     return SP1HIP_SUCCESS;
 }
 

@@ -18,8 +18,10 @@
 // pair), block-reduced to three extension sums. Traces are column-major, so every leaf load of a
 // wave is one coalesced 256 B run; the program, alpha/gkr powers and publics are wave-uniform
 // scalar loads. Round 0 works on base-field words, later rounds on extension words (4 sub-columns
-// per column). The register file lives in per-lane scratch (runtime-indexed); an ahead-of-time
-// specialised kernel per chip (registers in VGPRs, no decode) is the planned replacement.
+// per column). The register file lives in LDS (up to 64 extension registers per lane; beyond that, VGPR / scratch
+// tiers); hinted sub-AIRs (Poseidon2 permutation, septic curve, Keccak-f round) are evaluated by fused pieces with
+// their state in VGPRs instead (zc_poseidon2.hpp). Per-chip compiled kernels were built in round 3,
+// measured slower than this interpreter and removed in round 4.
 #include <algorithm>
 #include <array>
 #include <cstring>
@@ -893,6 +895,7 @@ struct Chunk {
 
 struct ZcPlan {                      // everything that depends on a chip's program only (cached per process)
     uint32_t n_instr = 0, main_w = 0, prep_w = 0;
+    bool macros_enabled = true;      // SP1HIP_ZC_MACRO when the plan was made (part of the cache key)
     std::vector<uint32_t> source;    // the caller's [n][3] program (collision check)
     std::vector<uint32_t> prog;      // allocated [n][4], whole program (padded-row evaluation)
     uint32_t n_regs = 1;
@@ -1368,7 +1371,9 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                        std::shared_ptr<const ZcPlan>* out) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
-    mix(main_width); mix(prep_width); mix(n_instr);
+    // SP1HIP_ZC_MACRO=0 ignores hints; read per call like the BIVARIATE / FORK switches and part of the cache key
+    const bool macros_enabled = [] { const char* e = getenv("SP1HIP_ZC_MACRO"); return !(e && e[0] == '0'); }();
+    mix(main_width); mix(prep_width); mix(n_instr); mix(macros_enabled ? 1u : 0u);
     for (size_t k = 0; k < (size_t)n_instr * 3; k++) mix(program[k]);
     static std::mutex plan_mutex;
     static std::unordered_map<uint64_t, std::shared_ptr<const ZcPlan>> plan_cache;
@@ -1377,12 +1382,12 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         std::lock_guard<std::mutex> lk(plan_mutex);
         auto it = plan_cache.find(h);
         if (it != plan_cache.end() && it->second->n_instr == n_instr && it->second->main_w == main_width && it->second->prep_w == prep_width &&
-            (n_instr == 0 || memcmp(it->second->source.data(), program, (size_t)n_instr * 12) == 0))
+            it->second->macros_enabled == macros_enabled && (n_instr == 0 || memcmp(it->second->source.data(), program, (size_t)n_instr * 12) == 0))
             plan = it->second;
     }
     if (!plan) {
         std::shared_ptr<ZcPlan> np(new ZcPlan());
-        np->n_instr = n_instr; np->main_w = main_width; np->prep_w = prep_width;
+        np->n_instr = n_instr; np->main_w = main_width; np->prep_w = prep_width; np->macros_enabled = macros_enabled;
         np->source.assign(program, program + (size_t)n_instr * 3);
         // hinted sub-AIRs (zc_poseidon2.hpp): the HINT pseudo-instructions become harmless constants, the hints are CHECKED
         // against the SSA, and the asserts they cover leave the interpreted forms (not the whole program `prog`, which the
@@ -1402,8 +1407,21 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                 np->macros.push_back(m);
                 clean[3 * k] = ZC_CONST; clean[3 * k + 1] = 0; clean[3 * k + 2] = 0;
             }
-            static const bool macros_enabled = [] { const char* e = getenv("SP1HIP_ZC_MACRO"); return !(e && e[0] == '0'); }();
             if (!macros_enabled) np->macros.clear();
+            // each hint is checked against the SSA on its own (below); two hints that overlap — a duplicated HINT, two sum
+            // checkers sharing accumulator columns — would each pass and then count their constraints and the GKR batching
+            // term of their columns twice: a silently invalid proof. Constraint ranges and owned columns must be disjoint.
+            for (size_t a = 0; a < np->macros.size(); a++)
+                for (size_t b = a + 1; b < np->macros.size(); b++) {
+                    const ZcMacro &ma = np->macros[a], &mb = np->macros[b];
+                    const bool c_overlap = ma.first_constraint < mb.first_constraint + mb.n_constraints() &&
+                                           mb.first_constraint < ma.first_constraint + ma.n_constraints();
+                    uint32_t alo, an, blo, bn;
+                    ma.owned(&alo, &an); mb.owned(&blo, &bn);
+                    const bool o_overlap = alo < blo + bn && blo < alo + an;
+                    SP1HIP_REQUIRE(!c_overlap, "two fused-kernel hints cover the same constraints");
+                    SP1HIP_REQUIRE(!o_overlap, "two fused-kernel hints own the same columns");
+                }
         }
         program = clean.data();
         auto hinted = [&](uint32_t idx) {

@@ -158,3 +158,69 @@ def test_riscv_shard_at_a_sixty_fourth_of_the_recorded_shape_verifies(api):
     v.observe(commit)
     proof = api.prove_shard(chips3, [], prep, L, lsh, 32, ch)
     assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) != 0
+
+
+def _small_riscv_case(api, seed=21):
+    import core_real
+    L, lsh, batch = 17, 12, 8
+    machine, tabs, _ = RT.generate(SMALL, K=2, seed=seed, device="cuda")
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+            for a, i in machine]
+    dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+           for a, i in machine]
+    return machine, host, dev, L, lsh, batch
+
+
+@pytest.mark.parametrize("env", [{"SP1HIP_ZC_BIVARIATE": "0"}, {"SP1HIP_ZC_FORK": "0"}, {"SP1HIP_ZC_BIVARIATE": "0", "SP1HIP_ZC_FORK": "0"},
+                                 {"SP1HIP_ZC_MACRO": "0"}, {"SP1HIP_WAIT": "spin"}])
+def test_riscv_shard_with_hinted_chip_under_every_zerocheck_switch(api, monkeypatch, env):
+    """the sequential rounds (zc_macro_kernel<true, KIND>: the round-0 form of the fused Poseidon2 / septic pieces) and the
+    single-stream launch path, on a machine with a HINTed chip (Global); also hints ignored (the interpreter evaluates the
+    sub-AIRs) — same bytes as the oracle in every configuration."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    LB, NQ, PW = 1, 5, 4
+    machine, host, dev, L, lsh, batch = _small_riscv_case(api)
+    assert any(a.name == "Global" for a, _ in machine)
+    o_prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, LB)
+    g_commit, g_prep = api.JaggedProver(L, lsh, batch, LB).commit_multilinears([d[3] for d in dev if d[3] is not None])
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    o_ch.observe(o_prep.commit)
+    g_ch.observe(g_commit)
+    orc.set_gkr_sparse(True)
+    try:
+        want = orc.shard_prove(host, np.zeros(0, np.uint32), o_prep, L, lsh, batch, o_ch, LB, NQ, PW)
+    finally:
+        orc.set_gkr_sparse(False)
+    got = api.prove_shard(dev, [], g_prep, L, lsh, batch, g_ch, LB, NQ, PW)
+    assert got == want and np.array_equal(g_ch.state(), o_ch.state())
+
+
+def test_riscv_pool_proofs_match_the_oracle(api):
+    """several provers in flight take the non-forked launch path; pool proofs of the rv64im machine (hinted Global chip)
+    are checked byte for byte against the ORACLE, three in flight, repeated (the second round of proofs also runs on the learned
+    hand-over timeline: common.hpp WaitPlan)."""
+    LB, NQ, PW = 1, 5, 4
+    machine, host, dev, L, lsh, batch = _small_riscv_case(api, seed=22)
+    o_prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, LB)
+    pk = api.ProvingKey([d[3] for d in dev if d[3] is not None], L, lsh, batch, log_blowup=LB, num_queries=NQ, pow_bits=PW)
+    direct = pk.prove_shard(dev, [])
+    pool = api.ProverPool(3)
+    tickets = [pool.submit(pk, dev) for _ in range(9)]
+    for t in tickets:
+        proof, _ = pool.wait(t)
+        assert proof == direct
+    pool.close()
+    # the oracle prover from the same transcript head (vk.observe_into = commit, pc_start, septic x / y, flag, 6 zeros)
+    assert np.array_equal(pk.preprocessed_commit, o_prep.commit)
+    o_ch = orc.Challenger()
+    o_ch.observe(np.concatenate([o_prep.commit, np.zeros(3 + 14 + 7, np.uint32)]))
+    g_head = api.DuplexChallenger()
+    pk.observe_into(g_head)
+    assert np.array_equal(o_ch.state(), g_head.state())
+    orc.set_gkr_sparse(True)
+    try:
+        want = orc.shard_prove(host, np.zeros(0, np.uint32), o_prep, L, lsh, batch, o_ch, LB, NQ, PW)
+    finally:
+        orc.set_gkr_sparse(False)
+    assert direct == want

@@ -128,3 +128,39 @@ def test_compiled_forms_of_the_riscv_chips_evaluate_like_the_ssa(lib):
     those pieces must give the 163 hinted constraints exactly what the SSA gives."""
     for k, name in enumerate(("Global", "Mul", "ShiftRight", "Branch", "LoadByte", "StoreByte", "Addi")):
         _check(lib, riscv.chip(name)[0], 300 + k, 4)
+
+
+def test_planner_rejects_overlapping_hints(lib):
+    """each hint is checked against the SSA on its own; two hints over the same constraints / columns (a duplicated
+    HINT) would each pass and then be counted twice. The planner must refuse the program."""
+    import copy
+    from sp1_amd.air import HINT
+    air = riscv.chip("Global")[0]
+    hints = [k for k, ins in enumerate(air.instrs) if ins[0] == HINT]
+    assert hints, "the Global chip carries hints"
+    dup = copy.copy(air)
+    dup.instrs = list(air.instrs)
+    dup.instrs.insert(hints[0] + 1, air.instrs[hints[0]])          # the same hint twice in a row
+    # the duplicated pseudo-instruction shifts the value numbering: renumber operand references behind it
+    at = hints[0] + 1
+    fixed = []
+    from sp1_amd import air as A
+    for k, ins in enumerate(dup.instrs):
+        op, a, b = ins
+        if k > at and op not in (A.CONST, A.LOAD_MAIN, A.LOAD_PREP, A.PUBLIC, HINT):
+            a = a + 1 if a >= at else a
+            if op in (A.ADD, A.SUB, A.MUL):
+                b = b + 1 if b >= at else b
+        fixed.append((op, a, b))
+    dup.instrs = fixed
+    rng = np.random.default_rng(1)
+    row = rng.integers(0, P, size=air.main_width, dtype=np.uint64)
+    prow = rng.integers(0, P, size=max(air.prep_width, 1), dtype=np.uint64)
+    pub = rng.integers(0, P, size=4, dtype=np.uint64)
+    prog = np.ascontiguousarray(dup.to_array().reshape(-1), dtype=np.uint32)
+    out = np.zeros(air.num_constraints, dtype=np.uint32)
+    stats = np.zeros(3, dtype=np.uint32)
+    u = lambda v: np.ascontiguousarray(v, dtype=np.uint32)
+    st = lib.sp1hip_zerocheck_plan_eval(_u32p(prog), len(dup.instrs), air.main_width, air.prep_width, _u32p(u(row)), _u32p(u(prow)),
+                                        _u32p(u(pub)), 4, 1, _u32p(out), air.num_constraints, _u32p(stats))
+    assert st != 0 and b"same constraints" in lib.sp1hip_last_error()
