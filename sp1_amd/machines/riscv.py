@@ -1200,7 +1200,11 @@ _CACHE = {}
 def chip(name):
     """(AirProgram, InteractionProgram) of a transcribed chip; `air.layout` maps dotted column names to indices."""
     if name not in _CACHE:
-        _CACHE[name] = CHIPS[name]()
+        if name in CHIPS:
+            _CACHE[name] = CHIPS[name]()
+        else:                                     # DivRem, the syscall chips, global memory init / finalize, Keccak (riscv_more.py)
+            from .riscv_more import MORE_CHIPS
+            _CACHE[name] = MORE_CHIPS[name]()
     return _CACHE[name]
 
 
