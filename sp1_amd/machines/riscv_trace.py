@@ -43,15 +43,23 @@ MASK16, MASK32 = 0xFFFF, 0xFFFFFFFF
 MIN64 = -(1 << 63)
 POS_OFF = {"M": 1, "C": 2, "B": 3, "A": 4}
 B_REGS, PR_REGS, PS_REGS = list(range(1, 9)), [9, 10], [11, 12]
-D1_REGS, D2_REGS, LINK_REG = list(range(13, 21)), list(range(22, 32)), 21
+D1_REGS, D2_REGS, LINK_REG = list(range(13, 20)), list(range(22, 31)), 21      # x20 / x31 carry syscall codes (ECALL_CODES)
 PAGE = 4096
 
 # instruction kinds: name -> (chip, opcode names)
 ALU_KINDS = {
     "Add": ["ADD"], "Sub": ["SUB"], "Addi": ["ADDI"], "Bitwise": ["XOR", "OR", "AND"], "Lt": ["SLT", "SLTU"],
     "Mul": ["MUL", "MULH", "MULHU", "MULHSU", "MULW"], "ShiftLeft": ["SLL", "SLLW"], "ShiftRight": ["SRL", "SRA", "SRLW", "SRAW"],
-    "Addw": ["ADDW"], "Subw": ["SUBW"],
+    "Addw": ["ADDW"], "Subw": ["SUBW"], "DivRem": ["DIV", "DIVU", "REM", "REMU", "DIVW", "DIVUW", "REMW", "REMUW"],
 }
+# ECALLs of the loop body (kind "Ecall"): `addi x31, x0 | x20, code` (+ `lui x20, hi` for a 3-byte code) then `ecall` with
+# op_a = x31, op_b = x10, op_c = x11 — the reference's decoder always names x5 / x10 / x11 (core/executor: Instruction::new(ECALL,
+# 5, 10, 11)), the SyscallInstrs AIR takes the registers from the program table like any R-type row. Codes that neither change
+# op_a nor read public values: WRITE, EXIT_UNCONSTRAINED, HINT_LEN (no table), KECCAK_PERMUTE / SHA_EXTEND (own table: the row
+# is also a SyscallCore row and a Global send; the precompile itself lives in another shard).
+ECALL_CODES = [0x02, 0x04, 0xF0, 0x00_01_01_09, 0x00_30_01_05]
+SYSCALL_REG, SYSCALL_HI_REG = 31, 20
+ECALL_EXTRA_CLK = 256                                                          # syscall/instructions/air.rs:L66-L72
 IMM_CAPABLE = {"Bitwise", "Lt", "ShiftLeft", "ShiftRight", "Addw"}           # ALUTypeReader chips: op_c may be an immediate
 LOAD_KINDS = {"LoadByte": ["LB", "LBU"], "LoadHalf": ["LH", "LHU"], "LoadWord": ["LW", "LWU"], "LoadDouble": ["LD"],
               "LoadX0": ["LB", "LBU", "LH", "LHU", "LW", "LWU", "LD"]}          # LoadX0: any load whose destination is x0
@@ -109,7 +117,7 @@ class Body:
     def __init__(self, counts, rng, pc_base, mem_pages):
         kinds = []
         for name, n in counts.items():
-            if name in ALU_KINDS or name == "Jalr" or name in LOAD_KINDS or name in STORE_KINDS or name in ("Branch", "Jal", "UType"):
+            if name in ALU_KINDS or name == "Jalr" or name in LOAD_KINDS or name in STORE_KINDS or name in ("Branch", "Jal", "UType", "Ecall"):
                 kinds += [(name,)] * n
             else:
                 raise KeyError(name)
@@ -138,6 +146,18 @@ class Body:
                 since_link += 1
                 continue
             since_link += 1
+            if name == "Ecall":
+                code = ECALL_CODES[int(rng.integers(len(ECALL_CODES)))]
+                lo = code & 0x7FF
+                if code >> 11:
+                    emit("UType", "LUI", SYSCALL_HI_REG, -1, -1, code - lo, True)
+                    emit("Addi", "ADDI", SYSCALL_REG, SYSCALL_HI_REG, -1, lo, True)
+                    since_link += 2
+                else:
+                    emit("Addi", "ADDI", SYSCALL_REG, 0, -1, lo, True)
+                    since_link += 1
+                emit("SyscallInstrs", "ECALL", SYSCALL_REG, PR_REGS[1], PS_REGS[0], 0, False)
+                continue
             if name in ALU_KINDS:
                 opn = pick(ALU_KINDS[name])
                 srcs = B_REGS + [0] if not cls_b else B_REGS + D1_REGS + PR_REGS + PS_REGS + [0]
@@ -188,6 +208,10 @@ class Body:
         self.imm, self.has_imm = np.array(imm, dtype=np.int64), np.array(has_imm, dtype=bool)
         self.pc_base = pc_base
         self.n_tail = len(B_REGS) + 1
+        # clock: 8 per instruction (CLK_INC), an ECALL advances it by 8 + 256
+        self.clk_inc = np.where(self.chip == "SyscallInstrs", 8 + ECALL_EXTRA_CLK, 8).astype(np.int64)
+        self.clk_off = np.concatenate([[0], np.cumsum(self.clk_inc)[:-1]]).astype(np.int64)
+        self.clk_per_iter = int(self.clk_inc.sum())
 
 
 # which register sits in which access slot, per chip family (None = no access in that slot)
@@ -212,6 +236,7 @@ class Execution:
         t = lambda a: torch.as_tensor(a, device=self.dev)
         L, dev = b.L, self.dev
         self.op, self.imm, self.has_imm = t(b.op), t(b.imm), t(b.has_imm)
+        self.clk_off, self.clk_inc = t(b.clk_off), t(b.clk_inc)
         sA, sB, sC, st_br = _slots(b)
         self.slot_reg = {"A": t(sA), "B": t(sB), "C": t(sC)}
         self.writes_rd = t(~st_br & (sA >= 0))                    # slot A is a write of a new value
@@ -270,7 +295,7 @@ class Execution:
 
     # -- time and pc
     def T(self, k, p):
-        return self.clk0 + 8 * (k * self.L + p)
+        return self.clk0 + k * self.body.clk_per_iter + self.clk_off[p]
 
     def pc(self, p):
         return self.body.pc_base + 4 * p
@@ -302,11 +327,14 @@ class Execution:
         is_st_br = np.isin(b.chip, list(STORE_KINDS) + ["Branch"])
         writer = ~is_st_br & (b.rd > 0)
         body_pos = pos < L - b.n_tail
-        d1like = set(D1_REGS + PR_REGS + PS_REGS + [LINK_REG])
+        d1like = set(D1_REGS + PR_REGS + PS_REGS + [LINK_REG, SYSCALL_HI_REG])
         cls_a = writer & body_pos & np.array([int(r) in d1like for r in b.rd])
-        cls_b = writer & body_pos & ~cls_a
+        cls_c = writer & body_pos & (b.chip == "SyscallInstrs")           # an ECALL re-writes the value its `addi` (class B) produced
+        cls_b = writer & body_pos & ~cls_a & ~cls_c
         self.mem = None
-        for mask in (cls_a, cls_b):
+        for mask in (cls_a, cls_b, cls_c):
+            if not mask.any():
+                continue
             k, p = self._grid(pos[mask])
             self.W[k, p] = self._semantics(k, p)
 
@@ -345,6 +373,16 @@ class Execution:
             m = op == OPC[name]
             if bool(m.any()):
                 out = torch.where(m, mulh(bv, cv, name), out)
+        m_ec = op == OPC["ECALL"]
+        if bool(m_ec.any()):
+            out = torch.where(m_ec, self.reg_value(k, p, "A"), out)
+        m_div = torch.zeros_like(op, dtype=torch.bool)
+        for name in ALU_KINDS["DivRem"]:
+            m_div |= op == OPC[name]
+        if bool(m_div.any()):
+            idx = torch.nonzero(m_div)[:, 0]
+            vals = [divrem_result(int(o), int(x), int(y)) for o, x, y in zip(op[idx].tolist(), bv[idx].tolist(), cv[idx].tolist())]
+            out[idx] = torch.as_tensor([v[0] for v in vals], dtype=I64, device=out.device)
         put("LUI", self.imm[p]); put("AUIPC", pc + self.imm[p])
         put("JAL", pc + 4); put("JALR", pc + 4)
         isload = torch.zeros_like(op, dtype=torch.bool)
@@ -360,6 +398,182 @@ class Execution:
             put("LHU", raw & MASK16); put("LH", (raw & MASK16) - (((raw >> 15) & 1) << 16))
             put("LBU", raw & 0xFF); put("LB", (raw & 0xFF) - (((raw >> 7) & 1) << 8))
         return out
+
+
+U64 = (1 << 64) - 1
+_S64 = lambda v: v - (1 << 64) if v >> 63 else v                      # u64 -> i64 (python ints)
+_S32 = lambda v: (v & MASK32) - (1 << 32) if (v >> 31) & 1 else v & MASK32
+_TDIV = lambda a, b: abs(a) // abs(b) * (1 if (a < 0) == (b < 0) else -1)      # truncating division
+
+
+def divrem_result(op, b, c):
+    """(value written to rd, quotient, remainder), all as SIGNED int64 python ints; b, c signed int64.
+    `get_quotient_and_remainder` (core/executor/src/utils.rs:L73-L93) + the opcode's choice."""
+    name = OPC_NAME[op]
+    bu, cu = b & U64, c & U64
+    word = name.endswith("W")
+    signed = name in ("DIV", "REM", "DIVW", "REMW")
+    if not word and cu == 0:
+        q, r = U64, bu
+    elif word and (cu & MASK32) == 0:
+        q, r = U64, _S32(bu) & U64
+    elif signed and not word:
+        bs, cs = _S64(bu), _S64(cu)
+        q = _TDIV(bs, cs)
+        q, r = q & U64, (bs - _TDIV(bs, cs) * cs) & U64
+    elif signed and word:
+        bs, cs = _S32(bu), _S32(cu)
+        q = _TDIV(bs, cs)
+        r = bs - q * cs
+        q, r = _S32(q & MASK32) & U64, _S32(r & MASK32) & U64
+    elif word:
+        bb, cc = bu & MASK32, cu & MASK32
+        q, r = _S32(bb // cc) & U64, _S32(bb % cc) & U64
+    else:
+        q, r = bu // cu, bu % cu
+    a = q if name.startswith("DIV") else r
+    return _S64(a), q, r
+
+
+OPC_NAME = {v: k for k, v in OPC.items()}
+
+
+def divrem_rows(L, width, n_padded, ops, bvals, cvals):
+    """DivRem's own columns (everything but the CPU state and the register-access bookkeeping of the adapter) for the events
+    (opcode number, b, c) — b, c signed int64 python ints — plus the reference's padding rows: alu/divrem/mod.rs:L262-L586
+    (event_to_row; padding rows = 0 / 1). Returns canonical [n_padded, width] int64."""
+    rows = np.zeros((n_padded, width), dtype=np.int64)
+    n = len(ops)
+
+    def put(r, name, vals, off=0):
+        vals = vals if isinstance(vals, (list, tuple)) else [vals]
+        c0 = L[name] + off
+        rows[r, c0:c0 + len(vals)] = vals
+    w16 = lambda v: [(v >> (16 * i)) & MASK16 for i in range(4)]
+    inv = lambda v: pow(v % P, P - 2, P) if v % P else 0
+
+    def is_zero_word(r, prefix, limbs):                    # IsZeroWordOperation::populate_from_field_element
+        res = []
+        for i, x in enumerate(limbs):
+            put(r, "%s.is_zero_limb.%d.inverse" % (prefix, i), inv(x))
+            put(r, "%s.is_zero_limb.%d.result" % (prefix, i), int(x % P == 0))
+            res.append(int(x % P == 0))
+        put(r, prefix + ".is_zero_first_half", res[0] * res[1])
+        put(r, prefix + ".is_zero_second_half", res[2] * res[3])
+        put(r, prefix + ".result", int(all(res)))
+        return int(all(res))
+
+    def mul_op(r, prefix, x, y, is_mulh):                   # MulOperation::populate (operations/mul.rs:L54-L137)
+        xb = [(x >> (8 * i)) & 0xFF for i in range(8)]
+        yb = [(y >> (8 * i)) & 0xFF for i in range(8)]
+        b_msb, c_msb = xb[7] >> 7, yb[7] >> 7
+        bse, cse = (b_msb if is_mulh else 0), (c_msb if is_mulh else 0)
+        xe, ye = xb + [bse * 0xFF] * 8, yb + [cse * 0xFF] * 8
+        prod = [0] * 16
+        for i in range(16):
+            for j in range(16 - i):
+                prod[i + j] += xe[i] * ye[j]
+        carry = [0] * 16
+        for i in range(16):
+            carry[i] = prod[i] >> 8
+            prod[i] &= 0xFF
+            if i + 1 < 16:
+                prod[i + 1] += carry[i]
+        put(r, prefix + ".carry", carry)
+        put(r, prefix + ".product", prod)
+        put(r, prefix + ".b_lower_byte.low_bytes", [v & 0xFF for v in w16(x)])
+        put(r, prefix + ".c_lower_byte.low_bytes", [v & 0xFF for v in w16(y)])
+        put(r, prefix + ".b_msb", b_msb)
+        put(r, prefix + ".c_msb", c_msb)
+        put(r, prefix + ".b_sign_extend", bse)
+        put(r, prefix + ".c_sign_extend", cse)
+
+    for r, (op, b_, c_) in enumerate(zip(ops, bvals, cvals)):
+        name = OPC_NAME[op]
+        word, signed = name.endswith("W"), name in ("DIV", "REM", "DIVW", "REMW")
+        eb, ec = b_ & U64, c_ & U64                                     # event.b / event.c
+        a_, q, rem = divrem_result(op, b_, c_)
+        bq = (_S32(eb) & U64) if word and signed else (eb & MASK32) if word else eb
+        cq = (_S32(ec) & U64) if word and signed else (ec & MASK32) if word else ec
+        put(r, "a", w16(a_ & U64)); put(r, "b", w16(bq)); put(r, "c", w16(cq))
+        put(r, "is_real", 1)
+        put(r, "is_" + name.lower(), 1)
+        put(r, "is_real_not_word", int(not word))
+        c0 = is_zero_word(r, "is_c_0", w16(cq))
+        put(r, "quotient", w16(q)); put(r, "remainder", w16(rem))
+        qc = (q & MASK32) if word and not signed else q
+        rc = (rem & MASK32) if word and not signed else rem
+        put(r, "quotient_comp", w16(qc)); put(r, "remainder_comp", w16(rc))
+        rem_neg = b_neg = c_neg = overflow = 0
+        if signed and not word:
+            rem_neg, b_neg, c_neg = rem >> 63, eb >> 63, ec >> 63
+            overflow = int(eb == 1 << 63 and ec == U64)
+            abs_rem, abs_c = abs(_S64(rem)), abs(_S64(ec))
+        elif signed:
+            rem_neg, b_neg, c_neg = (rem >> 31) & 1, (eb >> 31) & 1, (ec >> 31) & 1
+            overflow = int(eb & MASK32 == 1 << 31 and ec & MASK32 == MASK32)
+            abs_rem, abs_c = abs(_S64(rem)), abs(_S64(cq))
+        elif word:
+            abs_rem, abs_c = rc, ec & MASK32
+        else:
+            abs_rem, abs_c = rc, ec
+        put(r, "rem_neg", rem_neg); put(r, "b_neg", b_neg); put(r, "c_neg", c_neg); put(r, "is_overflow", overflow)
+        put(r, "abs_remainder", w16(abs_rem)); put(r, "abs_c", w16(abs_c)); put(r, "max_abs_c_or_1", w16(max(1, abs_c)))
+        ob, oc = ((eb & MASK32, 1 << 31), (ec & MASK32, MASK32)) if word else ((eb, 1 << 63), (ec, U64))
+        is_zero_word(r, "is_overflow_b", [x - y for x, y in zip(w16(ob[0]), w16(ob[1]))])
+        is_zero_word(r, "is_overflow_c", [x - y for x, y in zip(w16(oc[0]), w16(oc[1]))])
+        put(r, "b_neg_not_overflow", b_neg * (1 - overflow))
+        put(r, "b_not_neg_not_overflow", (1 - b_neg) * (1 - overflow))
+        put(r, "abs_c_alu_event", c_neg); put(r, "abs_rem_alu_event", rem_neg)
+        if c_neg:
+            put(r, "c_neg_operation.value", w16((cq + abs_c) & U64))
+        if rem_neg:
+            put(r, "rem_neg_operation.value", w16((rem + abs_rem) & U64))
+        if word:
+            put(r, "b_msb", (eb >> 31) & 1); put(r, "c_msb", (ec >> 31) & 1)
+            put(r, "rem_msb", (rem >> 31) & 1); put(r, "quot_msb", (q >> 31) & 1)
+        else:
+            put(r, "b_msb", bq >> 63); put(r, "c_msb", cq >> 63); put(r, "rem_msb", rem >> 63)
+        put(r, "remainder_check_multiplicity", 1 - c0)
+        if not c0:                                            # LtOperationUnsigned::populate_unsigned(abs_rem, max(abs_c, 1))
+            xl, yl = w16(abs_rem), w16(max(1, abs_c))
+            d = [i for i in (3, 2, 1, 0) if xl[i] != yl[i]]
+            if d:
+                i = d[0]
+                flags = [int(j == i) for j in range(4)]
+                put(r, "remainder_lt_operation.u16_flags", flags)
+                put(r, "remainder_lt_operation.comparison_limbs", [xl[i], yl[i]])
+                put(r, "remainder_lt_operation.not_eq_inv", inv(xl[i] - yl[i]))
+                put(r, "remainder_lt_operation.bit", int(xl[i] < yl[i]))
+        lower = (qc * cq) & U64
+        if signed:
+            upper = ((_S64(qc) * _S64(cq)) >> 64) & U64
+        else:
+            upper = ((qc * cq) >> 64) & U64
+        ctq = w16(lower) + w16(upper)
+        put(r, "c_times_quotient", ctq)
+        mul_op(r, "c_times_quotient_lower", qc, cq, False)
+        if not word:
+            mul_op(r, "c_times_quotient_upper", qc, cq, signed)
+        rem16 = w16(rc) + [rem_neg * MASK16] * 4
+        carry, prev = [], 0
+        for i in range(8):
+            x = ctq[i] + rem16[i] + prev
+            prev = x >> 16
+            carry.append(prev)
+        put(r, "carry", carry)
+    for r in range(n, rows.shape[0]):                         # padding rows: 0 / 1 (quotient = remainder = 0)
+        put(r, "is_divu", 1)
+        put(r, "adapter.op_c_memory.prev_value", [1, 0, 0, 0])
+        put(r, "abs_c", [1, 0, 0, 0]); put(r, "c", [1, 0, 0, 0]); put(r, "max_abs_c_or_1", [1, 0, 0, 0])
+        put(r, "b_not_neg_not_overflow", 1)
+        is_zero_word(r, "is_c_0", [1, 0, 0, 0])
+    for r, (b_, c_) in enumerate(zip(bvals, cvals)):              # the operands as the adapter's register reads see them
+        put(r, "adapter.op_b_memory.prev_value", w16(b_ & U64))
+        put(r, "adapter.op_c_memory.prev_value", w16(c_ & U64))
+    return rows % P
+
+
 
 
 def mulh(b, c, name):
@@ -539,6 +753,8 @@ class Tracer:
             self.fill_lt(tb, "lt", bv, cv, signed)
         self.simple_alu("Lt", "ALU", lt_extra)
         self.simple_alu("Mul", "R", self.mul_extra)
+        self.simple_alu("DivRem", "R", self.divrem_extra)
+        self.syscall_instrs()
         self.simple_alu("ShiftLeft", "ALU", self.sll_extra)
         self.simple_alu("ShiftRight", "ALU", self.sr_extra)
         self.utype()
@@ -605,6 +821,52 @@ class Tracer:
         tb.set("mul.product_msb", is_["MULW"].to(I64) * (limbs16(a)[:, 1] >> 15))
         tb.set("mul.b_sign_extend", bse)
         tb.set("mul.c_sign_extend", cse)
+
+    # -- DivRem (alu/divrem/mod.rs:L262-L563 event_to_row; padding rows L565-L586)
+    def divrem_extra(self, tb, k, p, a, bv, cv):
+        n, L = len(p), tb.L
+        rows = divrem_rows(L, tb.air.main_width, tb.main.shape[0], self.ex.op[p].tolist(), bv.tolist(), cv.tolist())
+        keep = tb.main.clone()                                    # state / adapter columns were filled by simple_alu
+        tb.main[:] = torch.as_tensor(rows, device=self.dev)
+        lo, hi = L["state.clk_high"], L["a"]
+        tb.main[:n, lo:hi] = keep[:n, lo:hi]
+
+    # -- SyscallInstrs + SyscallCore (syscall/instructions/trace.rs event_to_row; syscall/chip.rs generate_trace_into)
+    def syscall_instrs(self):
+        k, p = self.rows_of("SyscallInstrs")
+        n = len(p)
+        if n == 0:
+            return
+        ex = self.ex
+        tb = self.table("SyscallInstrs", n)
+        self.fill_state(tb, k, p)
+        code, bv, cv = self.fill_adapter(tb, k, p, "R")
+        tb.set("next_pc", limbs16(ex.pc(p) + 4)[:, :3] + 0)
+        # next_pc is NOT normalised: limb 0 = pc[0] + 4 (air.rs:L128-L140)
+        pcl = limbs16(ex.pc(p))[:, :3].clone()
+        pcl[:, 0] += 4
+        tb.set("next_pc", pcl)
+        tb.set("op_a_value", limbs16(ex.W[k, p]))
+        tb.set("a_low_bytes.low_bytes", limbs16(code) & 0xFF)
+        sid = code & 0xFF
+        for nm, c_ in (("is_enter_unconstrained", 0x03), ("is_hint_len", 0xF0), ("is_halt_check", 0x00), ("is_commit", 0x10),
+                       ("is_commit_deferred_proofs", 0x1A)):
+            d = (sid - c_) % P
+            tb.set(nm + ".inverse", torch.where(d == 0, torch.zeros_like(d), finv(d)))
+            tb.set(nm + ".result", (d == 0).to(I64))
+        assert not bool(((sid == 0) | (sid == 3) | (sid == 0x10) | (sid == 0x1A)).any()), "HALT / COMMIT / ENTER_UNCONSTRAINED are not executed here"
+        tb.set("is_real", 1)
+        # SyscallCore: one row per ecall with its own table (syscall/chip.rs: events with should_send)
+        send = ((code >> 8) & 0xFF) == 1
+        if bool(send.any()):
+            T = ex.T(k, p)[send]
+            sc = self.table("SyscallCore", int(send.sum()))
+            sc.set("clk_high", T >> 24)
+            sc.set("clk_low", T & 0xFFFFFF)
+            sc.set("syscall_id", sid[send])
+            sc.set("arg1", limbs16(bv[send])[:, :3])
+            sc.set("arg2", limbs16(cv[send])[:, :3])
+            sc.set("is_real", 1)
 
     def _shift_fields(self, tb, cv, word_op):
         c = cv & MASK16
@@ -877,21 +1139,22 @@ class Tracer:
         normal_pc = torch.as_tensor(np.isin(b.chip, ["Branch", "Jal", "Jalr"]), device=dev)[p]   # these chips normalise next_pc
         nxt_pc = torch.where(p == L - 1, torch.full_like(pc, b.pc_base), pc + 4)
         pc_carry = (~normal_pc) & (((pc & MASK16) + 4) > MASK16)
-        clk_carry = ((T & 0xFFFFFF) + 8) >= (1 << 24)
+        inc = ex.clk_inc[p]
+        clk_carry = ((T & 0xFFFFFF) + inc) >= (1 << 24)
         need = pc_carry | clk_carry
-        self.final_state = (int(T[-1]) + 8, int(nxt_pc[-1]))
+        self.final_state = (int(T[-1]) + int(inc[-1]), int(nxt_pc[-1]))
         if bool(need.any()):
-            Tn, pcn, nxt, pcc = T[need], pc[need], nxt_pc[need], pc_carry[need]
+            Tn, pcn, nxt, pcc, incn = T[need], pc[need], nxt_pc[need], pc_carry[need], inc[need]
             air, _ = R.chip("StateBump")
             tb = Table(air, len(Tn), dev)
             self.tables["StateBump"] = tb
-            nT = Tn + 8
+            nT = Tn + incn
             tb.set("next_clk_32_48", nT >> 32)
             tb.set("next_clk_24_32", (nT >> 24) & 0xFF)
             tb.set("next_clk_16_24", (nT >> 16) & 0xFF)
             tb.set("next_clk_0_16", nT & MASK16)
             tb.set("clk_high", Tn >> 24)
-            tb.set("clk_low", (Tn & 0xFFFFFF) + 8)
+            tb.set("clk_low", (Tn & 0xFFFFFF) + incn)
             tb.set("next_pc", limbs16(nxt)[:, :3])
             sent = limbs16(pcn)[:, :3].clone()
             sent_norm = limbs16(nxt)[:, :3]
@@ -968,11 +1231,17 @@ class Tracer:
         # GlobalSink: receives what MemoryLocal sends to the Global chip
         ml = self.tables["MemoryLocal"]
         msgs = eval_interactions(R.chip("MemoryLocal")[1], ml.main[:ml.n], None, kinds=(R.GLOBAL,))
+        (_, recv, _), (_, send, _) = msgs                              # MemoryLocal's two Global sends, [rows, 11] each
+        events = [torch.stack([recv, send], dim=1).reshape(-1, 11)]    # per row: initial = receive, final = send
+        for name in ("SyscallCore",):                                  # the other chips of a core shard that talk to the Global chip
+            if name in self.tables:
+                t_ = self.tables[name]
+                events += [v for _, v, _ in eval_interactions(R.chip(name)[1], t_.main[:t_.n], None, kinds=(R.GLOBAL,))]
         if getattr(self, "real_global", True):
-            self.global_chip(machine, msgs)
+            self.global_chip(machine, torch.cat(events))
         else:
             air, it = global_sink_chip()
-            rows = torch.cat([v for _, v, _ in msgs])
+            rows = torch.cat(events)
             tb = Table(air, rows.shape[0], dev)
             tb.main[:tb.n, :11] = rows
             tb.main[:tb.n, 11] = 1
@@ -986,7 +1255,14 @@ class Tracer:
         if tb.prep.shape[0] > tb.n:                               # padding rows repeat instruction 0 with multiplicity 0
             tb.prep[tb.n:] = tb.prep[0]
         self.tables["Program"], machine["Program"] = tb, (air, it)
-        # Byte / Range: multiplicities counted from the messages actually sent
+        self.byte_range_tables(machine)
+        names = sorted(machine)
+        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, torch.zeros(0, dtype=I64)
+
+    def byte_range_tables(self, machine):
+        """Byte / Range tables (bytes/trace.rs, range/trace.rs) with multiplicities COUNTED from the byte messages every table of
+        `self.tables` sends on its rows; every message is checked to be a row of the table it addresses."""
+        dev = self.dev
         byte_air, byte_it = R.chip("Byte")
         range_air, range_it = R.chip("Range")
         bt, rt = Table(byte_air, 1 << 16, dev), Table(range_air, 1 << 17, dev)
@@ -1018,16 +1294,13 @@ class Tracer:
                     tally(bt.main.view(-1), row * 6 + o, mm)
         self.tables["Byte"], machine["Byte"] = bt, (byte_air, byte_it)
         self.tables["Range"], machine["Range"] = rt, (range_air, range_it)
-        names = sorted(machine)
-        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, torch.zeros(0, dtype=I64)
 
-    def global_chip(self, machine, msgs):
-        """GlobalChip::generate_trace_into (global/mod.rs:L131-L260): one row per global interaction event — here the two
-        events of every MemoryLocal row (memory/local.rs generate_dependencies: initial = receive, final = send), in that order."""
+    def global_chip(self, machine, ev):
+        """GlobalChip::generate_trace_into (global/mod.rs:L131-L260): one row per global interaction event `ev` [n, 11] — the two
+        events of every MemoryLocal row (memory/local.rs generate_dependencies: initial = receive, final = send), then the
+        syscall events of SyscallCore."""
         from . import septic as SE
         dev = self.dev
-        (_, recv, _), (_, send, _) = msgs                              # MemoryLocal's two Global sends, [rows, 11] each
-        ev = torch.stack([recv, send], dim=1).reshape(-1, 11)
         n = ev.shape[0]
         message, is_send, is_recv, kind = ev[:, :8], ev[:, 8], ev[:, 9], ev[:, 10]
         x, y, off, perm = SE.lift_x(message, kind, is_recv == 1)

@@ -1,0 +1,147 @@
+"""The chips real programs' shards contain beyond the 30 of riscv.py (sp1_amd/machines/riscv_more.py): DivRem,
+SyscallCore / SyscallPrecompile / SyscallInstrs, MemoryGlobalInit / Finalize, KeccakPermute and its controller.
+
+Pins, as for riscv.py: column counts == rv64im_costs.json, constraint counts == rv64im_complexity.json, interaction counts == the
+recorded core shard where it has the chip (DivRem 135, SyscallCore 4, SyscallInstrs 30) — and semantics: executed traces
+(riscv_trace.py: DIV/REM and ECALL instructions in the loop body; riscv_more_trace.py: a Keccak precompile shard whose
+permutation is computed and checked against hashlib, a global-memory shard) satisfy every constraint and balance every bus."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import machine_check as MC
+import pyoracle as orc
+from sp1_amd.machines import riscv as R
+from sp1_amd.machines import riscv_more as M
+from sp1_amd.machines import riscv_more_trace as MT
+from sp1_amd.machines import riscv_trace as RT
+
+PUBLICS = np.zeros(M.PV_NUM_ELTS, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("name", sorted(M.MORE_RECORDED))
+def test_counts_equal_the_reference_tables(name):
+    cols, cons, inter = M.MORE_RECORDED[name]
+    s = R.stats(name)
+    assert (s["columns"], s["constraints"]) == (cols, cons)
+    if inter is not None:
+        assert s["interactions"] == inter
+    if name in R.RECORDED:                                   # the three chips riscv.py already listed from the reference's tables
+        assert R.RECORDED[name] == (cols, cons, inter)
+
+
+def _check(machine, tabs, publics=PUBLICS):
+    chips = []
+    for air, it in machine:
+        prep, main = tabs[air.name]
+        m = main.numpy().astype(np.uint64)
+        pr = prep.numpy().astype(np.uint64) if prep is not None else None
+        assert (main >= 0).all() and (m < MC.P).all(), air.name
+        if air.num_constraints:
+            cv = MC.constraint_values(air, pr, m, publics)
+            assert not cv.any(), (air.name, sorted(set(np.argwhere(cv != 0)[:, 1]))[:8])
+        chips.append((it, pr, m))
+    return MC.bus_imbalance(chips)
+
+
+CORE = {"Add": 3, "Addi": 5, "Sub": 2, "Bitwise": 3, "Lt": 3, "Mul": 3, "DivRem": 24, "Ecall": 12, "UType": 8, "LoadWord": 3, "LoadByte": 3,
+        "StoreWord": 3, "StoreByte": 3, "Branch": 5, "Jal": 2, "Jalr": 2}
+
+
+@pytest.mark.parametrize("K,seed,clk0", [(3, 5, 1), (2, 6, (1 << 24) - 8 * 40 + 1)])
+def test_executed_core_traces_with_divrem_and_ecalls(K, seed, clk0):
+    """DIV / DIVU / REM / REMU / DIVW / DIVUW / REMW / REMUW (x0 operands give divisions by zero) and ECALLs — with and without a
+    table of their own (SyscallCore rows, Global sends), the clock advancing by 8 + 256 — next to the other instructions."""
+    machine, tabs, _ = RT.generate(CORE, K=K, seed=seed, clk0=clk0)
+    names = {a.name for a, _ in machine}
+    assert {"DivRem", "SyscallInstrs", "SyscallCore", "Global", "MemoryLocal"} <= names
+    assert not _check(machine, tabs)
+    ops = set(tabs["Program"][0][:, 3].tolist())
+    assert {R.OPC[o] for o in ("DIV", "DIVU", "REM", "REMU", "DIVW", "DIVUW", "REMW", "REMUW", "ECALL")} <= ops
+
+
+def test_divrem_special_cases():
+    """Overflow (MIN / -1, both widths), division by zero, every sign combination, operands that only differ above bit 31."""
+    air, _ = R.chip("DivRem")
+    MIN64, MIN32 = -(1 << 63), -(1 << 31)
+    cases = []
+    for name in RT.ALU_KINDS["DivRem"]:
+        for b, c in ((MIN64, -1), (MIN32, -1), (MIN32 & 0xFFFFFFFF, 0xFFFFFFFF), (7, 0), (-7, 0), (0, 0), (-7, 2), (7, -2), (-7, -2), (7, 2),
+                     (1 << 40 | 5, 1 << 35 | 3), (-1, 1), (MIN64, 1), (12345678901234, -987654321), (-(1 << 62), 3), ((1 << 63) - 1, -1)):
+            cases.append((R.OPC[name], b, c))
+    rows = RT.divrem_rows(air.layout, air.main_width, RT.pad32(len(cases)), [c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+    cv = MC.constraint_values(air, None, rows.astype(np.uint64), PUBLICS)
+    assert not cv.any(), sorted(set(np.argwhere(cv != 0)[:, 1]))[:8]
+    # semantics of the written value against Python's own arithmetic (RISC-V spec: truncating division, x / 0 = -1, x % 0 = x)
+    for op, b, c in cases:
+        name = RT.OPC_NAME[op]
+        a, q, r = RT.divrem_result(op, b, c)
+        if name in ("DIVU", "REMU") and c & RT.U64:
+            assert (q, r) == divmod(b & RT.U64, c & RT.U64)
+        if name in ("DIV", "REM") and c and not (b == MIN64 and c == -1):
+            assert RT._S64(q) * c + RT._S64(r) == b and abs(RT._S64(r)) < abs(c)
+    # a wrong quotient limb is caught
+    bad = rows.copy()
+    bad[3, air.layout["quotient"]] = (bad[3, air.layout["quotient"]] + 1) % MC.P
+    assert MC.constraint_values(air, None, bad.astype(np.uint64), PUBLICS).any()
+
+
+def test_keccak_rows_compute_the_permutation():
+    st = [0] * 25
+    st[0], st[16] = 0x06, 0x80 << 56                        # SHA3-256 padding of the empty message (rate 136 bytes)
+    _, out = MT.keccak_f_rows(st)
+    assert b"".join(v.to_bytes(8, "little") for v in out[:4]) == hashlib.sha3_256(b"").digest()
+
+
+def test_precompile_shard_satisfies_every_chip_and_balances():
+    machine, tabs, _ = MT.precompile_shard(3, seed=1)
+    names = [a.name for a, _ in machine]
+    assert names == ["Byte", "Global", "GlobalAccBoundary", "KeccakPermute", "KeccakPermuteControl", "MemoryLocal", "Range", "SyscallPrecompile"]
+    assert tabs["KeccakPermute"][1].shape == (96, 2640)
+    assert not _check(machine, tabs)
+    # one flipped state bit in one round: the constraints (or the Keccak bus) notice
+    air = R.chip("KeccakPermute")[0]
+    for col in (air.layout["keccak.a_prime.2.3"] + 17, air.layout["keccak.a_prime_prime.1.1"], air.layout["keccak.c.4"] + 63):
+        t = {k: (p, m.clone()) for k, (p, m) in tabs.items()}
+        t["KeccakPermute"][1][30, col] = (t["KeccakPermute"][1][30, col] + 1) % MC.P
+        try:
+            imbalance = _check(machine, t)
+        except AssertionError:
+            continue
+        assert imbalance, col
+
+
+@pytest.mark.parametrize("with_zero", [True, False])
+def test_memory_shard_satisfies_every_chip_and_balances(with_zero):
+    machine, tabs, _ = MT.memory_shard(40, seed=2, with_zero=with_zero)
+    assert {"MemoryGlobalInit", "MemoryGlobalFinalize", "Global"} <= {a.name for a, _ in machine}
+    assert not _check(machine, tabs)
+    t = {k: (p, m.clone()) for k, (p, m) in tabs.items()}
+    lay = R.chip("MemoryGlobalInit")[0].layout
+    t["MemoryGlobalInit"][1][5, lay["addr"]], t["MemoryGlobalInit"][1][6, lay["addr"]] = tabs["MemoryGlobalInit"][1][6, lay["addr"]], tabs["MemoryGlobalInit"][1][5, lay["addr"]]
+    with pytest.raises(AssertionError):                      # addresses out of order: the comparison constraints fail
+        assert not _check(machine, t)
+
+
+def test_oracle_proves_and_verifies_the_precompile_shard():
+    machine, tabs, pv = MT.precompile_shard(2, seed=4)
+    chips = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+             for a, i in machine]
+    L, lsh, batch, LB, NQ, PW = 17, 12, 8, 1, 5, 4
+    prep = orc.JaggedRound([c[3] for c in chips if c[3] is not None], L, lsh, batch, LB)
+    ch = orc.Challenger()
+    ch.observe(prep.commit)
+    v = ch.clone()
+    publics = np.zeros(M.PV_NUM_ELTS, np.uint32)
+    orc.set_gkr_sparse(True)
+    try:
+        blob = orc.shard_prove(chips, publics, prep, L, lsh, batch, ch, LB, NQ, PW)
+    finally:
+        orc.set_gkr_sparse(False)
+    shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
+              for a, i in machine]
+    assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v.clone(), LB, NQ, PW) == 0
+    bad = bytearray(blob)
+    bad[len(bad) // 3] ^= 1
+    assert orc.shard_verify(shapes, prep.commit, bytes(bad), L, lsh, v.clone(), LB, NQ, PW) != 0
