@@ -80,7 +80,7 @@ def effective_cores():
 
 def programs_of(kind, names):
     """(AirProgram, InteractionProgram) list of a workload, rebuilt by name in a child process that has no traces."""
-    if kind == "real":
+    if kind in ("real", "precompile"):
         import core_real
         return core_real.programs_for(names)
     if kind == "core":
@@ -91,11 +91,22 @@ def programs_of(kind, names):
     return R.compress_machine()
 
 
+def publics_of(kind):
+    """The public values a workload's shard proofs carry: the real machines read PublicValues words (SyscallInstrs: commit /
+    exit-code words, all zero here: no COMMIT or HALT is executed), the synthetic shards have none."""
+    import numpy as np
+    return np.zeros(160 if kind in ("real", "precompile") else 0, np.uint32)
+
+
 def build_workload(kind, k, L, seed):
-    """chips [(air, inter, main ColMajor, prep ColMajor | None)], meta — `kind` "real" (RISC-V chips) or "core" (synthetic)."""
+    """chips [(air, inter, main ColMajor, prep ColMajor | None)], meta — `kind` "real" (the rv64im core shard), "precompile" (a Keccak
+    precompile shard: the wide-chip regime) or "core" (synthetic)."""
     if kind == "real":
         import core_real
         return core_real.build_real_shard(scale=1.0 / (1 << (2 * k)), seed=seed)
+    if kind == "precompile":
+        import precompile_shard
+        return precompile_shard.build_precompile_shard(max(1, precompile_shard.FULL_EVENTS >> (2 * k)), seed=seed)
     from core_shard import build_core_shard
     return build_core_shard(CORE_AREA >> (2 * k), L, seed=seed)
 
@@ -119,7 +130,7 @@ def cpu_baseline_child(path):
     # GPU algorithm) costs 2^L / rows more and is not what a CPU prover does. ONE pass (no size query).
     orc.set_gkr_sparse(True)
     t0 = time.perf_counter()
-    blob = orc.shard_prove(chips, np.zeros(0, np.uint32), prep, L, lsh, 32, ch, 2, 124, 16, capacity=64 << 20)
+    blob = orc.shard_prove(chips, publics_of(str(z["kind"])), prep, L, lsh, 32, ch, 2, 124, 16, capacity=64 << 20)
     dt = time.perf_counter() - t0
     print(json.dumps({"seconds": dt, "setup_seconds": t_setup, "proof_bytes": len(blob), "stage_seconds": orc.stage_seconds()}))
 
@@ -151,14 +162,14 @@ def cpu_sample(api, scale_log2, cores, kind="real"):
     return r
 
 
-def cpu_baseline(api, scale_log2):
+def cpu_baseline(api, scale_log2, kind="real"):
     """The CPU oracle (a C++17/OpenMP restatement of the reference's prover, NOT the reference binary) proving the same
     shard shape scaled down by 4^scale_log2 — at a scale where its time grows with the area: the rate at a quarter of the
     sample rides along as the check (cells/s within 2x between 1/256 and 1/64) — in a child process so OpenMP is
     sized to the cores this container may use; per-stage seconds from the oracle's own timers."""
     cores = effective_cores()
-    big = cpu_sample(api, scale_log2, cores)
-    small = cpu_sample(api, scale_log2 + 1, cores)
+    big = cpu_sample(api, scale_log2, cores, kind)
+    small = cpu_sample(api, scale_log2 + 1, cores, kind)
     return {"value": big["cells_per_s"], "unit": "cells/s", "cores": cores, "kind": "port",
             "stage_seconds": {k: round(v, 3) for k, v in big["stage_seconds"].items()},
             "seconds": round(big["seconds"], 2), "cells": big["cells"],
@@ -310,26 +321,26 @@ class GpuSampler:
                 "sclk_mhz": stats([f for _, f in self.samples], 1e-6)}
 
 
-def in_flight(api, chips, area, L, lsh, n_proofs):
+def in_flight(api, chips, area, L, lsh, n_proofs, publics=()):
     """The library's prover pool with 1 to 4 slots on the SAME resident shard: throughput with N proofs in flight, the
     per-proof proving times in completion order, and the GPU's clock / power while each phase runs. Proofs are checked
     against `sp1hip_prove_shard_with_pk` called directly."""
     import torch
     prep_tables = [c[3] for c in chips if c[3] is not None]
     pk = api.ProvingKey(prep_tables, L, lsh, 32)
-    want = pk.prove_shard(chips, [])
+    want = pk.prove_shard(chips, publics)
     torch.cuda.synchronize()
     out = {"proofs_per_phase": n_proofs, "slots": {}}
     for n in (1, 2, 3, 4):
         released = C.c_size_t()
         api.check(api._L().sp1hip_mem_trim(C.byref(released)))       # every phase starts from an empty arena and refills it in its warm-up
         pool = api.ProverPool(n)
-        for t in [pool.submit(pk, chips) for _ in range(n)]:          # fill every slot's arena
+        for t in [pool.submit(pk, chips, publics) for _ in range(n)]:          # fill every slot's arena
             assert pool.wait(t)[0] == want, "a pool proof differs from the direct one"
         torch.cuda.synchronize()
         with GpuSampler() as smp:
             t0 = time.perf_counter()
-            tickets = [pool.submit(pk, chips) for _ in range(n_proofs)]
+            tickets = [pool.submit(pk, chips, publics) for _ in range(n_proofs)]
             res = [pool.wait(t) for t in tickets]
             dt = time.perf_counter() - t0
         pool.close()
@@ -341,11 +352,11 @@ def in_flight(api, chips, area, L, lsh, n_proofs):
     host = [(a, i, api.PinnedHost(m.to_row_major_host()) if m is not None else None, pr) for (a, i, m, pr) in chips]
     host_bytes = sum(4 * c[2].shape[0] * c[2].shape[1] for c in host if c[2] is not None)
     pool = api.ProverPool(3)
-    for t in [pool.submit(pk, host) for _ in range(3)]:
+    for t in [pool.submit(pk, host, publics) for _ in range(3)]:
         assert pool.wait(t)[0] == want, "a staged pool proof differs from the direct one"
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = [pool.wait(t) for t in [pool.submit(pk, host) for _ in range(n_proofs)]]
+    res = [pool.wait(t) for t in [pool.submit(pk, host, publics) for _ in range(n_proofs)]]
     dt = time.perf_counter() - t0
     pool.close()
     assert all(r[0] == want for r in res), "a staged pool proof differs from the direct one"
@@ -361,9 +372,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="real", choices=["real", "core"],
+    ap.add_argument("--workload", default="real", choices=["real", "core", "precompile"],
                     help="real: the RISC-V chips at the recorded core shard's heights (bench/core_real.py); core: the synthetic "
-                         "core-shaped shard of rounds 1-3 (bench/core_shard.py)")
+                         "core-shaped shard of rounds 1-3 (bench/core_shard.py); precompile: a Keccak precompile shard, 82 %% of its "
+                         "area in the 2,640-column KeccakPermute chip (bench/precompile_shard.py)")
     ap.add_argument("--scale-log2", type=int, default=0, help="prove a shard of area CORE >> 2k (testing aid; the bench line is k = 0)")
     ap.add_argument("--cpu-sample-scale-log2", type=int, default=2, help="the CPU baseline proves a shard of CORE >> 2k cells (default 1/16 of CORE)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
@@ -414,7 +426,7 @@ def main():
     lib = api._L()
     k = args.scale_log2
     kind = args.workload
-    L, lsh = max(22 - k, 17 if kind == "real" else 0), 21 - k            # the Range table of the real machine has 2^17 rows
+    L, lsh = max(22 - k, 17 if kind in ("real", "precompile") else 0), 21 - k            # the Range table of the real machines has 2^17 rows
     chips, meta = build_workload(kind, k, L, 42 + rank)                  # every rank proves its own shard
     names = [c[0].name for c in chips]
     area = meta["area_cells"]
@@ -423,11 +435,12 @@ def main():
     torch.cuda.synchronize()
 
     last_state = [None]
+    publics = publics_of(kind)
 
     def step(stream=None):
         ch = api.DuplexChallenger()
         ch.observe(prep_commit)                                              # stands for vk.observe_into
-        blob = api.prove_shard(chips, [], prep_data, L, lsh, 32, ch, stream=stream)
+        blob = api.prove_shard(chips, publics, prep_data, L, lsh, 32, ch, stream=stream)
         last_state[0] = ch
         return blob
 
@@ -483,7 +496,7 @@ def main():
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:      # untimed extras; N > 1 runs measure scaling only
-        extras["in_flight"] = in_flight(api, chips, area, L, lsh, max(4, args.steps))
+        extras["in_flight"] = in_flight(api, chips, area, L, lsh, max(4, args.steps), publics)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
@@ -533,7 +546,7 @@ def main():
         if kind == "real":
             extras["synthetic_core_shaped"] = synthetic_core_shaped(api, k)
         if not args.no_cpu_baseline:
-            extras["cpu_baseline"] = cpu_baseline(api, max(args.cpu_sample_scale_log2, k))
+            extras["cpu_baseline"] = cpu_baseline(api, max(args.cpu_sample_scale_log2, k), kind)
     if use_dist:
         dist.barrier()
 
@@ -674,7 +687,9 @@ def main():
             "verified": verified,
             "core_real_chips": ({"real_chips": meta["real_chips"], "synthetic_chips": meta["synthetic_chips"],
                                  "real_area_cells": meta["real_area_cells"], "ms_per_proof": ms_per_step,
-                                 "zerocheck_round_ms": ms.get("zerocheck_round"), "per_chip": meta["per_chip"]} if kind == "real" else None),
+                                 "zerocheck_round_ms": ms.get("zerocheck_round"), "zerocheck_stage_ms": ms.get("stage_zerocheck"),
+                                 "wide_chip_area_fraction": meta.get("wide_chip_area_fraction"), "per_chip": meta["per_chip"]}
+                                if kind in ("real", "precompile") else None),
             "host_threads": lib.sp1hip_host_threads(), "host_cpu_ms_per_proof": host_cpu_ms, "host_cpu_ms_by_thread": host_cpu_by_thread,
             "host_wait": os.environ.get("SP1HIP_WAIT", "predict"), "host_cpu_untimed": extras.get("host_cpu_untimed"),
             "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},

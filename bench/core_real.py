@@ -3,9 +3,9 @@ heights of the reference's recorded core shard 0 (sp1-gpu/crates/logup_gkr/layer
 riscv.RECORDED_ROWS), proved on traces that sp1_amd/machines/riscv_trace.py EXECUTES (a loop body run K = 13 times: the
 recorded shard executes ~6.2e6 instructions of a 4.7e5-instruction program).
 
-What is real: every chip of that shard except LoadX0 / DivRem / SyscallInstrs / SyscallCore (0.15 % of its area) —
-the 22 instruction chips, MemoryLocal, MemoryBump, StateBump, Program, Byte, Range and the septic-curve Global chip (a
-Poseidon2 permutation + curve arithmetic per row: a third of the shard's cells) — constraints, interactions, and traces
+What is real: EVERY chip of that shard (round 5 added DivRem, SyscallInstrs and SyscallCore: riscv_more.py) —
+the 25 instruction chips, MemoryLocal, MemoryBump, StateBump, Program, Byte, Range, SyscallCore and the septic-curve Global chip
+(a Poseidon2 permutation + curve arithmetic per row: a third of the shard's cells) — constraints, interactions, and traces
 with RISC-V semantics whose lookups balance. What is synthetic: two 2-row closing chips, `Boundary` and
 `GlobalAccBoundary`, standing in for the interactions of `eval_public_values` (initial / final CPU state, the two ends of
 the global digest chain). `real_global=False` swaps the Global chip for a sink + a filler of its recorded shape (the round-4
@@ -24,14 +24,17 @@ from sp1_amd.machines import riscv as R, riscv_trace as RT         # noqa: E402
 # 8 executions of the loop body: the body then holds enough distinct load/store positions that MemoryLocal and Global come out at
 # 0.96x their recorded heights (13 gave 0.65x: fewer positions than recorded touched words); Program is 1.55x as tall in exchange.
 K_ITER = 8
-NOT_INSTRUCTIONS = ("Byte", "Range", "Program", "MemoryLocal", "MemoryBump", "StateBump", "Global", "DivRem", "SyscallCore",
-                    "SyscallInstrs")
+NOT_INSTRUCTIONS = ("Byte", "Range", "Program", "MemoryLocal", "MemoryBump", "StateBump", "Global", "SyscallCore", "SyscallInstrs")
+PUBLIC_VALUES = 160          # SP1_PROOF_NUM_PV_ELTS (hypercube/src/air/public_values.rs:L19): SyscallInstrs reads commit / exit-code words
 P = api.P
 
 
 def recorded_counts(scale, K=K_ITER):
     """Loop-body positions per instruction chip so that K executions give `scale` x the recorded heights."""
-    return {n: max(1, int(round(rows * scale / K))) for n, rows in R.RECORDED_ROWS.items() if n not in NOT_INSTRUCTIONS}
+    counts = {n: max(1, int(round(rows * scale / K))) for n, rows in R.RECORDED_ROWS.items() if n not in NOT_INSTRUCTIONS}
+    # SyscallInstrs rows are ECALLs of the body (a quarter of them, in the recorded shard, have a table: SyscallCore)
+    counts["Ecall"] = max(1, int(round(R.RECORDED_ROWS["SyscallInstrs"] * scale / K)))
+    return counts
 
 
 def to_col_major(t):

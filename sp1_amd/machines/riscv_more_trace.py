@@ -59,126 +59,152 @@ def _limbs(v):
     return [(v >> (16 * i)) & MASK16 for i in range(4)]
 
 
-def keccak_permute_table(events, dev):
+def _rotl(v, n):
+    """64-bit rotate left of int64 tensors (two's complement bit patterns)."""
+    if n == 0:
+        return v
+    return (v << n) | RT.srl(v, torch.full_like(v, 64 - n))
+
+
+def keccak_round_tensors(state):
+    """The same 24 rounds as keccak_f_rows, vectorised over permutations: state [n, 25] int64 (lane x + 5 y as a bit pattern).
+    Returns a list of 24 dicts of tensors (a [n,5,5] as [y][x], c [n,5], c_prime [n,5], a_prime [n,5,5], a_prime_prime [n,5,5],
+    appp00 [n]) and the final state [n, 25]."""
+    a = state.clone()
+    rows = []
+    for rnd in range(24):
+        A = a.reshape(-1, 5, 5)                                                       # [n, y, x]
+        C = A[:, 0] ^ A[:, 1] ^ A[:, 2] ^ A[:, 3] ^ A[:, 4]                          # [n, x]
+        Cp = torch.stack([C[:, x] ^ C[:, (x + 4) % 5] ^ _rotl(C[:, (x + 1) % 5], 1) for x in range(5)], dim=1)
+        Ap = A ^ C[:, None, :] ^ Cp[:, None, :]
+        Bm = torch.zeros_like(Ap)
+        for x in range(5):
+            for y in range(5):
+                Bm[:, (2 * x + 3 * y) % 5, y] = _rotl(Ap[:, y, x], M.KECCAK_R[x][y])
+        App = torch.stack([Bm[:, :, x] ^ (~Bm[:, :, (x + 1) % 5] & Bm[:, :, (x + 2) % 5]) for x in range(5)], dim=2)
+        appp00 = App[:, 0, 0] ^ RT._S64(M.KECCAK_RC[rnd])
+        rows.append({"a": A, "c": C, "c_prime": Cp, "a_prime": Ap, "a_prime_prime": App, "appp00": appp00})
+        nxt = App.clone()
+        nxt[:, 0, 0] = appp00
+        a = nxt.reshape(-1, 25)
+    return rows, a
+
+
+def _bits_t(v):
+    """[...] int64 -> [..., 64] bits, little-endian."""
+    z = torch.arange(64, device=v.device)
+    return (v[..., None] >> z) & 1
+
+
+def _limbs_t(v):
+    return torch.stack([(v >> (16 * i)) & MASK16 for i in range(4)], dim=-1)
+
+
+def keccak_permute_table(clk, addr, pre, dev):
     """KeccakPermuteChip::generate_trace_into (keccak256/trace.rs:L63-L162): 24 rows per event, padding rows = the rows of a
-    permutation of the zero state with is_real = 0. events: [(clk, state_addr, pre_state[25])]."""
+    permutation of the zero state with is_real = 0. clk, addr: [n] int64; pre: [n, 25] int64 lane bit patterns."""
     air, _ = R.chip("KeccakPermute")
     L = air.layout
-    n = 24 * len(events)
+    n_ev = pre.shape[0]
+    n = 24 * n_ev
     tb = RT.Table(air, n, dev)
-    rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
-
-    def fill(r0, kr, preimage, real, clk, addr):
-        for rnd, kv in enumerate(kr):
-            r = r0 + rnd
-            if r >= rows.shape[0]:
-                return
-            rows[r, L["keccak.step_flags"] + rnd] = 1
-            rows[r, L["keccak.export"]] = int(rnd == 23)
-            for y in range(5):
-                for x in range(5):
-                    for nm, grid in (("preimage", preimage), ("a", kv["a"]), ("a_prime_prime", kv["a_prime_prime"])):
-                        c0 = L["keccak.%s.%d.%d" % (nm, y, x)]
-                        rows[r, c0:c0 + 4] = _limbs(grid[y][x])
-                    c0 = L["keccak.a_prime.%d.%d" % (y, x)]
-                    rows[r, c0:c0 + 64] = _bits(kv["a_prime"][y][x])
-            for x in range(5):
-                rows[r, L["keccak.c.%d" % x]:L["keccak.c.%d" % x] + 64] = _bits(kv["c"][x])
-                rows[r, L["keccak.c_prime.%d" % x]:L["keccak.c_prime.%d" % x] + 64] = _bits(kv["c_prime"][x])
-            c0 = L["keccak.a_prime_prime_0_0_bits"]
-            rows[r, c0:c0 + 64] = _bits(kv["a_prime_prime"][0][0])
-            c0 = L["keccak.a_prime_prime_prime_0_0_limbs"]
-            rows[r, c0:c0 + 4] = _limbs(kv["appp00"])
-            if real:
-                rows[r, L["clk_high"]], rows[r, L["clk_low"]] = clk >> 24, clk & 0xFFFFFF
-                rows[r, L["state_addr"]:L["state_addr"] + 3] = _limbs(addr)[:3]
-                rows[r, L["index"]], rows[r, L["is_real"]] = rnd, 1
-    posts = []
-    for e, (clk, addr, pre) in enumerate(events):
-        kr, post = keccak_f_rows(pre)
-        fill(24 * e, kr, [[pre[x + 5 * y] for x in range(5)] for y in range(5)], True, clk, addr)
-        posts.append(post)
-    if rows.shape[0] > n:
-        kr0, _ = keccak_f_rows([0] * 25)
-        fill(n, kr0, [[0] * 5 for _ in range(5)], False, 0, 0)
-    tb.main[:] = torch.as_tensor(rows, device=dev)
-    return tb, posts
+    n_pad = tb.main.shape[0] - n
+    # one extra "event" (the zero state) supplies the padding rows
+    allpre = torch.cat([pre, torch.zeros((1, 25), dtype=I64, device=dev)]) if n_pad else pre
+    rounds, post = keccak_round_tensors(allpre)
+    E = allpre.shape[0]
+    view = torch.zeros((E, 24, air.main_width), dtype=I64, device=dev)
+    pre_l = _limbs_t(allpre.reshape(E, 5, 5))                                            # [E, y, x, 4]
+    for rnd, kv in enumerate(rounds):
+        row = view[:, rnd]
+        row[:, L["keccak.step_flags"] + rnd] = 1
+        row[:, L["keccak.export"]] = int(rnd == 23)
+        c0 = L["keccak.preimage.0.0"]
+        row[:, c0:c0 + 100] = pre_l.reshape(E, 100)
+        c0 = L["keccak.a.0.0"]
+        row[:, c0:c0 + 100] = _limbs_t(kv["a"]).reshape(E, 100)
+        c0 = L["keccak.c.0"]
+        row[:, c0:c0 + 320] = _bits_t(kv["c"]).reshape(E, 320)
+        c0 = L["keccak.c_prime.0"]
+        row[:, c0:c0 + 320] = _bits_t(kv["c_prime"]).reshape(E, 320)
+        c0 = L["keccak.a_prime.0.0"]
+        row[:, c0:c0 + 1600] = _bits_t(kv["a_prime"]).reshape(E, 1600)
+        c0 = L["keccak.a_prime_prime.0.0"]
+        row[:, c0:c0 + 100] = _limbs_t(kv["a_prime_prime"]).reshape(E, 100)
+        c0 = L["keccak.a_prime_prime_0_0_bits"]
+        row[:, c0:c0 + 64] = _bits_t(kv["a_prime_prime"][:, 0, 0])
+        c0 = L["keccak.a_prime_prime_prime_0_0_limbs"]
+        row[:, c0:c0 + 4] = _limbs_t(kv["appp00"])
+        row[:n_ev, L["clk_high"]], row[:n_ev, L["clk_low"]] = clk >> 24, clk & 0xFFFFFF
+        row[:n_ev, L["state_addr"]:L["state_addr"] + 3] = _limbs_t(addr)[:, :3]
+        row[:n_ev, L["index"]], row[:n_ev, L["is_real"]] = rnd, 1
+    flat = view.reshape(E * 24, air.main_width)
+    tb.main[:] = flat[:tb.main.shape[0]]
+    assert n_pad <= 24
+    return tb, post[:n_ev]
 
 
-def _mem_access(rows, L, r, prefix, prev_val, t_prev, t_cur):
-    """MemoryAccessCols::populate (memory/consistency/trace.rs:L36-L101)."""
+def _mem_access_t(tb, prefix, prev_val, t_prev, t_cur):
+    """MemoryAccessCols::populate (memory/consistency/trace.rs:L36-L101), one column group, all rows."""
     ph, pl, ch, cl = t_prev >> 24, t_prev & 0xFFFFFF, t_cur >> 24, t_cur & 0xFFFFFF
-    same = int(ph == ch)
-    d = (cl - pl if same else ch - ph) - 1
-    assert d >= 0
-    c0 = L[prefix + ".prev_value"]
-    rows[r, c0:c0 + 4] = _limbs(prev_val)
-    rows[r, L[prefix + ".prev_high"]], rows[r, L[prefix + ".prev_low"]] = ph, pl
-    rows[r, L[prefix + ".compare_low"]] = same
-    rows[r, L[prefix + ".diff_low_limb"]], rows[r, L[prefix + ".diff_high_limb"]] = d & MASK16, d >> 16
+    same = ph == ch
+    d = torch.where(same, cl - pl, ch - ph) - 1
+    assert bool((d >= 0).all())
+    tb.set(prefix + ".prev_value", _limbs_t(prev_val))
+    tb.set(prefix + ".prev_high", ph)
+    tb.set(prefix + ".prev_low", pl)
+    tb.set(prefix + ".compare_low", same.to(I64))
+    tb.set(prefix + ".diff_low_limb", d & MASK16)
+    tb.set(prefix + ".diff_high_limb", d >> 16)
 
 
 def precompile_shard(n_events, seed=0, device="cpu", clk0=(5 << 24) + 1001):
-    """A KECCAK_PERMUTE precompile shard of `n_events` syscalls: (machine, tables, publics) like riscv_trace.generate."""
+    """A KECCAK_PERMUTE precompile shard of `n_events` syscalls: (machine, tables, publics) like riscv_trace.generate
+    (vectorised torch.int64: CPU in the tests, the GPU in the bench)."""
     dev = torch.device(device)
-    rng = np.random.default_rng(seed)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
     tr = RT.Tracer.__new__(RT.Tracer)
     tr.dev, tr.tables = dev, {}
-    # events: distinct, 8-aligned, non-overlapping state addresses >= 2^16; increasing clocks (≡ 1 mod 8 like every instruction)
-    base = 0x20_0000
-    slots = rng.permutation(4 * n_events + 4)[:n_events]
-    events, prev_t = [], {}
-    for e in range(n_events):
-        addr = base + 256 * int(slots[e])                                      # 200-byte states in 256-byte slots
-        clk = clk0 + 8 * 40 * e
-        pre = [int(v) for v in rng.integers(0, 1 << 63, 25, dtype=np.int64)]
-        pre = [(v << 1 | int(rng.integers(2))) & U64 for v in pre]
-        events.append((clk, addr, pre))
-    # KeccakPermute
-    kp, posts = keccak_permute_table(events, dev)
+    # events: distinct, 8-aligned, non-overlapping state addresses >= 2^16 (200-byte states in 256-byte slots); increasing clocks
+    # (= 1 mod 8 like every instruction's)
+    slots = torch.randperm(4 * n_events + 4, generator=gen, device=dev)[:n_events]
+    addr = 0x20_0000 + 256 * slots
+    clk = clk0 + 8 * 40 * torch.arange(n_events, device=dev)
+    pre = torch.randint(RT.MIN64, (1 << 63) - 1, (n_events, 25), generator=gen, device=dev, dtype=I64)
+    kp, post = keccak_permute_table(clk, addr, pre, dev)
     tr.tables["KeccakPermute"] = kp
     # KeccakPermuteControl (controller.rs:L155-L237)
-    air, _ = R.chip("KeccakPermuteControl")
-    L = air.layout
-    ct = RT.Table(air, n_events, dev)
-    rows = np.zeros((ct.main.shape[0], air.main_width), dtype=np.int64)
-    inv = lambda v: pow(v % P, P - 2, P) if v % P else 0
-    words = []                                                                  # MemoryLocal rows: (addr, t_init, v_init, t_final, v_final)
-    for r, ((clk, addr, pre), post) in enumerate(zip(events, posts)):
-        rows[r, L["clk_high"]], rows[r, L["clk_low"]], rows[r, L["is_real"]] = clk >> 24, clk & 0xFFFFFF, 1
-        al = _limbs(addr)
-        rows[r, L["state_addr.addr"]:L["state_addr.addr"] + 3] = al[:3]            # SyscallAddrOperation::populate (syscall_addr.rs:L27-L46)
-        top = al[1] + al[2]
-        rows[r, L["state_addr.top_two_limb_min"]] = inv(top)
-        dmax = top - 2 * MASK16
-        rows[r, L["state_addr.top_two_limb_max.inverse"]], rows[r, L["state_addr.top_two_limb_max.result"]] = inv(dmax), int(dmax % P == 0)
-        for i in range(25):
-            wa = addr + 8 * i
-            c0 = L["addrs.%d.value" % i]
-            rows[r, c0:c0 + 3] = _limbs(wa)[:3]
-            t_prev = int(rng.integers(1, clk0 - 8))                                 # the word's last access, in an earlier shard
-            _mem_access(rows, L, r, "initial_memory_access.%d" % i, pre[i], t_prev, clk)
-            _mem_access(rows, L, r, "final_memory_access.%d" % i, pre[i], clk, clk + 1)
-            c0 = L["final_value.%d" % i]
-            rows[r, c0:c0 + 4] = _limbs(post[i])
-            words.append((wa, t_prev, RT._S64(pre[i]), clk + 1, RT._S64(post[i])))
-    ct.main[:] = torch.as_tensor(rows, device=dev)
+    ct = RT.Table(R.chip("KeccakPermuteControl")[0], n_events, dev)
+    ct.set("clk_high", clk >> 24); ct.set("clk_low", clk & 0xFFFFFF); ct.set("is_real", 1)
+    al = _limbs_t(addr)
+    ct.set("state_addr.addr", al[:, :3])                                                # SyscallAddrOperation::populate (syscall_addr.rs:L27-L46)
+    top = al[:, 1] + al[:, 2]
+    ct.set("state_addr.top_two_limb_min", RT.finv(top))
+    dmax = (top - 2 * MASK16) % P
+    ct.set("state_addr.top_two_limb_max.inverse", torch.where(dmax == 0, torch.zeros_like(dmax), RT.finv(dmax)))
+    ct.set("state_addr.top_two_limb_max.result", (dmax == 0).to(I64))
+    t_prev = torch.randint(1, clk0 - 8, (n_events, 25), generator=gen, device=dev, dtype=I64)       # last accesses, in earlier shards
+    for i in range(25):
+        ct.set("addrs.%d.value" % i, _limbs_t(addr + 8 * i)[:, :3])
+        _mem_access_t(ct, "initial_memory_access.%d" % i, pre[:, i], t_prev[:, i], clk)
+        _mem_access_t(ct, "final_memory_access.%d" % i, pre[:, i], clk, clk + 1)
+        ct.set("final_value.%d" % i, _limbs_t(post[:, i]))
     tr.tables["KeccakPermuteControl"] = ct
     # SyscallPrecompile (syscall/chip.rs:L196-L254)
-    air, _ = R.chip("SyscallPrecompile")
-    st = RT.Table(air, n_events, dev)
-    for r, (clk, addr, _) in enumerate(events):
-        st.main[r] = torch.tensor([clk >> 24, clk & 0xFFFFFF, M.SYS_KECCAK_PERMUTE] + _limbs(addr)[:3] + [0, 0, 0, 1], device=dev)
+    st = RT.Table(R.chip("SyscallPrecompile")[0], n_events, dev)
+    st.set("clk_high", clk >> 24); st.set("clk_low", clk & 0xFFFFFF); st.set("syscall_id", M.SYS_KECCAK_PERMUTE)
+    st.set("arg1", al[:, :3]); st.set("is_real", 1)
     tr.tables["SyscallPrecompile"] = st
     # MemoryLocal (memory/local.rs:L98-L250): one row per touched word
-    air, _ = R.chip("MemoryLocal")
-    ml = RT.Table(air, len(words), dev)
-    wt = torch.tensor(words, dtype=I64, device=dev)
-    ml.set("addr", RT.limbs16(wt[:, 0])[:, :3])
-    ml.set("initial_clk_high", wt[:, 1] >> 24); ml.set("initial_clk_low", wt[:, 1] & 0xFFFFFF)
-    ml.set("final_clk_high", wt[:, 3] >> 24); ml.set("final_clk_low", wt[:, 3] & 0xFFFFFF)
-    for tag, col in (("initial", 2), ("final", 4)):
-        l = RT.limbs16(wt[:, col])
+    ml = RT.Table(R.chip("MemoryLocal")[0], 25 * n_events, dev)
+    wa = (addr[:, None] + 8 * torch.arange(25, device=dev)[None, :]).reshape(-1)
+    tp, tf = t_prev.reshape(-1), (clk[:, None] + 1).expand(-1, 25).reshape(-1)
+    ml.set("addr", _limbs_t(wa)[:, :3])
+    ml.set("initial_clk_high", tp >> 24); ml.set("initial_clk_low", tp & 0xFFFFFF)
+    ml.set("final_clk_high", tf >> 24); ml.set("final_clk_low", tf & 0xFFFFFF)
+    for tag, v in (("initial", pre.reshape(-1)), ("final", post.reshape(-1))):
+        l = _limbs_t(v)
         ml.set(tag + "_value", l)
         ml.set(tag + "_value_lower", l[:, 2] & 0xFF)
         ml.set(tag + "_value_upper", l[:, 2] >> 8)

@@ -145,3 +145,16 @@ def test_oracle_proves_and_verifies_the_precompile_shard():
     bad = bytearray(blob)
     bad[len(bad) // 3] ^= 1
     assert orc.shard_verify(shapes, prep.commit, bytes(bad), L, lsh, v.clone(), LB, NQ, PW) != 0
+
+
+def test_vectorised_keccak_rounds_equal_the_scalar_ones():
+    import torch
+    rng = np.random.default_rng(8)
+    pre = rng.integers(-(1 << 63), (1 << 63) - 1, size=(3, 25), dtype=np.int64)
+    rounds, post = MT.keccak_round_tensors(torch.as_tensor(pre))
+    for e in range(3):
+        want_rows, want_post = MT.keccak_f_rows([int(v) & MT.U64 for v in pre[e]])
+        assert [int(v) & MT.U64 for v in post[e]] == want_post
+        for rnd in (0, 7, 23):
+            assert [[int(v) & MT.U64 for v in row] for row in rounds[rnd]["a_prime"][e]] == want_rows[rnd]["a_prime"]
+            assert int(rounds[rnd]["appp00"][e]) & MT.U64 == want_rows[rnd]["appp00"]
