@@ -477,11 +477,12 @@ def main():
     # runtime's own threads, helpers), ms per proof
     me = threading.get_native_id()
     host_cpu_by_thread = {"caller": round(1e3 * (thr1.get(me, (0, ""))[0] - thr0.get(me, (0, ""))[0]) / args.steps, 2)}
-    for tid, (t, comm) in thr1.items():
-        if tid != me:
-            d = 1e3 * (t - thr0.get(tid, (0, ""))[0]) / args.steps
-            if d >= 0.05:
-                host_cpu_by_thread[comm] = round(host_cpu_by_thread.get(comm, 0) + d, 2)
+    others = sorted(((1e3 * (t - thr0.get(tid, (0, ""))[0]) / args.steps, comm, tid) for tid, (t, comm) in thr1.items() if tid != me), reverse=True)
+    for rank_, (d, comm, tid) in enumerate(others):
+        if d >= 0.05:                                        # the busiest other threads one by one (the HIP runtime's are all named like the process)
+            key = "%s#%d" % (comm, rank_) if rank_ < 4 else comm + "#rest"
+            host_cpu_by_thread[key] = round(host_cpu_by_thread.get(key, 0) + d, 2)
+    host_cpu_by_thread["threads"] = len(thr1)
     api.check(lib.sp1hip_timers_enable(0))
     tl = {name: timers_read(api, name) for name in TIMERS}
     dt = shards.max_over_ranks(dt)                 # shards are striped one per rank: no data-path collective

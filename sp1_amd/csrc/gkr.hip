@@ -701,7 +701,7 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             SP1HIP_REQUIRE(p + 3 <= end, "truncated interaction program");
             std::vector<uint32_t> w{p[0], kb::to_monty(p[1] % kb::P), p[2]};
             const uint32_t nv = p[2];
-            SP1HIP_REQUIRE(p[0] <= 1 && p[1] < kb::P && nv < 64, "bad interaction header");
+            SP1HIP_REQUIRE(p[0] <= 1 && p[1] < kb::P && nv < 4096, "bad interaction header");      // (the Keccak bus carries 106 values per message)
             p += 3;
             SP1HIP_REQUIRE(vcol(w), "bad multiplicity column");
             for (uint32_t j = 0; j < nv; j++) SP1HIP_REQUIRE(vcol(w), "bad value column (index or weight out of range)");
