@@ -37,35 +37,14 @@
 
 namespace sp1hip {
 
-// ---- register files ------------------------------------------------------------------------------
-// The program is wave-uniform, so register numbers are SGPR values. For up to 32 registers the file is
-// kept in VGPRs as 16/32-wide vectors indexed with a uniform index (GPR-index mode, s_set_gpr_idx_on):
-// no memory traffic per interpreted instruction. Larger programs fall back to per-lane scratch.
-typedef uint32_t v32u __attribute__((ext_vector_type(32)));
-typedef uint32_t v16u __attribute__((ext_vector_type(16)));
+// ---- register file -------------------------------------------------------------------------------
+// The program is wave-uniform, so register numbers are SGPR values. The file lives in LDS (the only tier since round 5: the
+// VGPR-vector files of rounds 1-4 — s_set_gpr_idx triples per word — and the per-lane scratch files for programs with more
+// than 64 live values — 4 to 16 KB of scratch per lane — are gone; a program whose register file does not fit the 160 KB of
+// LDS even for one wave is cut into finer chunks by the planner, zc_wg_for / plan_round).
+template <bool FIRST, int MAXR> struct RegFile;
 
-template <bool FIRST, int MAXR> struct RegFile {
-    typename KT<FIRST>::T r[MAXR];
-    __device__ __forceinline__ typename KT<FIRST>::T get(uint32_t i) const { return r[i]; }
-    __device__ __forceinline__ void set(uint32_t i, const typename KT<FIRST>::T& v) { r[i] = v; }
-};
-#define SP1HIP_VREGFILE(N, V)                                                                                       \
-    template <> struct RegFile<true, N> {                                                                            \
-        V r;                                                                                                         \
-        __device__ __forceinline__ uint32_t get(uint32_t i) const { return r[i]; }                                  \
-        __device__ __forceinline__ void set(uint32_t i, uint32_t v) { r[i] = v; }                                   \
-    };                                                                                                               \
-    template <> struct RegFile<false, N> {                                                                           \
-        V c0, c1, c2, c3;                                                                                            \
-        __device__ __forceinline__ kb::Ext get(uint32_t i) const { return kb::Ext{{c0[i], c1[i], c2[i], c3[i]}}; }   \
-        __device__ __forceinline__ void set(uint32_t i, const kb::Ext& v) {                                          \
-            c0[i] = v.c[0]; c1[i] = v.c[1]; c2[i] = v.c[2]; c3[i] = v.c[3];                                          \
-        }                                                                                                            \
-    };
-SP1HIP_VREGFILE(16, v16u)
-SP1HIP_VREGFILE(32, v32u)
-
-// MAXR == 0: the file lives in LDS, register i of a lane at slot i * 256 + lane (16 B slots for extension values: one
+// The file: register i of a lane at slot i * (workgroup width) + lane (16 B slots for extension values: one
 // ds_read_b128 / ds_write_b128 per access, conflict-free). Indexing a VGPR vector with a wave-uniform index costs an
 // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off triple per word — ~36 instructions of pure register traffic around a
 // 12-instruction extension add; the LDS file makes an interpreted op cost its arithmetic plus three LDS accesses,
@@ -117,7 +96,6 @@ constexpr uint32_t ZC_FINE_LIMIT = 32, ZC_FINE_MAX_TERMS = 64;
 constexpr uint32_t ZC_FORK_MAX_BLOCKS = 1u << 30;
 // rounds with at most this many workgroups are "small": every launch is at its latency floor (the two septic kinds then share one launch)
 constexpr uint32_t ZC_SMALL_ROUND_WGS = 16384;
-constexpr uint32_t ZC_LDS_PROG_MAX = 3072; // instructions staged in LDS (48 KiB); longer programs read global memory
 
 typedef uint32_t zc_word_t __attribute__((ext_vector_type(4)));       // one instruction: op | flags, dst, a, b
 typedef const zc_word_t __attribute__((address_space(4)))* zc_const_prog_t;
@@ -1501,13 +1479,30 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
 
 // register-file bytes one lane needs in LDS
 template <bool FIRST> static inline size_t zc_rf_lane_bytes(uint32_t n_regs) { return (size_t)n_regs * (FIRST ? 4 : 16); }
-constexpr size_t ZC_LDS_BUDGET = 64 * 1024;
+constexpr size_t ZC_LDS_CU = 160 * 1024;          // LDS of a gfx950 compute unit; one workgroup may declare all of it
+constexpr size_t ZC_LDS_BUDGET = ZC_LDS_CU;
 
-// widest workgroup (256 / 128 / 64 lanes) whose LDS register file fits the budget; 0 if even one wave does not
+// The workgroup width (256 / 128 / 64 lanes) that keeps the most lanes resident per compute unit given what the LDS register
+// file costs: a CU holds floor(160 KB / LDS per workgroup) workgroups, so a file of R extension registers (16 R bytes per lane)
+// allows ~10240 / R lanes however they are grouped, and narrower workgroups pack the remainder better (R = 50: three 64-lane
+// workgroups = 192 lanes against one 128-lane workgroup). Ties go to the wider workgroup. 0 if even one wave's file does not
+// fit 160 KB (R > 160 in the extension rounds): the caller then runs the chip's finer chunks.
 template <bool FIRST> static inline uint32_t zc_wg_for(uint32_t n_regs, size_t other_lds) {
-    for (uint32_t wg = 256; wg >= 64; wg >>= 1)
-        if (other_lds + zc_rf_lane_bytes<FIRST>(n_regs) * wg <= ZC_LDS_BUDGET) return wg;
-    return 0;
+    // SP1HIP_ZC_WG=occ: always the occupancy rule above. Default: the widest workgroup whose file fits 64 KB (the rule every
+    // measurement of rounds 2-4 was taken with), the occupancy rule only for files beyond that (65 .. 160 registers: one to
+    // two waves per CU — slow, but no scratch)
+    const bool occ = [] { const char* e = getenv("SP1HIP_ZC_WG"); return e && e[0] == 'o'; }();
+    if (!occ)
+        for (uint32_t wg = 256; wg >= 64; wg >>= 1)
+            if (other_lds + zc_rf_lane_bytes<FIRST>(n_regs) * wg <= 64 * 1024) return wg;
+    uint32_t best = 0, best_lanes = 0;
+    for (uint32_t wg = 256; wg >= 64; wg >>= 1) {
+        const size_t per_wg = other_lds + zc_rf_lane_bytes<FIRST>(n_regs) * wg;
+        if (per_wg > ZC_LDS_CU) continue;
+        const uint32_t lanes = (uint32_t)std::min<size_t>(ZC_LDS_CU / per_wg, 2048 / wg) * wg;      // also: 32 waves per CU
+        if (lanes > best_lanes) { best_lanes = lanes; best = wg; }
+    }
+    return best;
 }
 
 // One group of descriptors = a contiguous block range [block_lo, block_lo + n_blocks) launched together.
@@ -1517,29 +1512,18 @@ static int launch_round(uint32_t max_regs, bool staged, bool fused, const ZcDesc
     const size_t lds = 32 * 4 + (staged ? (size_t)max_instr * 16 : 0);
     dim3 grid(fused ? n_blocks : n_blocks * 3);      // unfused: workgroup 3 b + p = node p of block b
     const uint32_t ff = fused ? 1u : 0u;
-    static const bool force_vgpr = [] { const char* e = getenv("SP1HIP_ZC_REGFILE"); return e && e[0] == 'v'; }();
-    const uint32_t wg = force_vgpr ? 0 : zc_wg_for<FIRST>(max_regs, lds);
-    if (wg) {
-        const size_t total = lds + zc_rf_lane_bytes<FIRST>(max_regs) * wg;
-        if (staged) {
-            auto kern = zc_round_kernel<FIRST, 0, true>;
-            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
-            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
-        } else {
-            auto kern = zc_round_kernel<FIRST, 0, false>;
-            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
-            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
-        }
-        SP1HIP_LAUNCH_CHECK();
-        return SP1HIP_SUCCESS;
+    const uint32_t wg = zc_wg_for<FIRST>(max_regs, lds);
+    SP1HIP_REQUIRE(wg != 0, "internal: a register file that does not fit LDS reached the launch (plan_round cuts such programs finer)");
+    const size_t total = lds + zc_rf_lane_bytes<FIRST>(max_regs) * wg;
+    if (staged) {
+        auto kern = zc_round_kernel<FIRST, 0, true>;
+        if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
+        hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
+    } else {
+        auto kern = zc_round_kernel<FIRST, 0, false>;
+        if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
+        hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo, ff);
     }
-    // register file in VGPRs / scratch (programs whose file does not fit LDS, or SP1HIP_ZC_REGFILE=vgpr for A/B runs)
-    SP1HIP_REQUIRE(staged, "internal: unstaged program without an LDS register file");
-    if (max_regs <= 16) hipLaunchKernelGGL((zc_round_kernel<FIRST, 16, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
-    else if (max_regs <= 32) hipLaunchKernelGGL((zc_round_kernel<FIRST, 32, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
-    else if (max_regs <= 256) hipLaunchKernelGGL((zc_round_kernel<FIRST, 256, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
-    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_round_kernel<FIRST, 1024, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo, ff);
-    else { set_error("constraint program needs %u live registers (max 1024)", max_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }
@@ -1568,28 +1552,18 @@ static int launch_biv_round(uint32_t max_regs, bool staged, const ZcDesc* d_desc
                             uint32_t max_instr, const uint32_t* eq, uint32_t eq_len, const uint32_t* publics, uint32_t* partial, hipStream_t s) {
     const size_t lds = 32 * 4 + (staged ? (size_t)max_instr * 16 : 0);
     const dim3 grid(n_blocks * ZC_BIV_GROUPS);
-    static const bool force_vgpr = [] { const char* e = getenv("SP1HIP_ZC_REGFILE"); return e && e[0] == 'v'; }();
-    const uint32_t wg = force_vgpr ? 0 : zc_wg_for<false>(max_regs, lds);      // 16-byte slots: four node values per register
-    if (wg) {
-        const size_t total = lds + zc_rf_lane_bytes<false>(max_regs) * wg;
-        if (staged) {
-            auto kern = zc_biv_round_kernel<0, true>;
-            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
-            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
-        } else {
-            auto kern = zc_biv_round_kernel<0, false>;
-            if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
-            hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
-        }
-        SP1HIP_LAUNCH_CHECK();
-        return SP1HIP_SUCCESS;
+    const uint32_t wg = zc_wg_for<false>(max_regs, lds);      // 16-byte slots: four node values per register
+    SP1HIP_REQUIRE(wg != 0, "internal: a register file that does not fit LDS reached the launch (plan_round cuts such programs finer)");
+    const size_t total = lds + zc_rf_lane_bytes<false>(max_regs) * wg;
+    if (staged) {
+        auto kern = zc_biv_round_kernel<0, true>;
+        if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
+        hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
+    } else {
+        auto kern = zc_biv_round_kernel<0, false>;
+        if (total > 48 * 1024) SP1HIP_TRY(ensure_dynamic_lds((const void*)kern, (int)ZC_LDS_BUDGET));
+        hipLaunchKernelGGL(kern, grid, dim3(wg), total, s, d_descs, n_descs, eq, eq_len, publics, partial, (uint32_t)(lds / 4), block_lo);
     }
-    SP1HIP_REQUIRE(staged, "internal: unstaged program without an LDS register file");
-    if (max_regs <= 16) hipLaunchKernelGGL((zc_biv_round_kernel<16, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
-    else if (max_regs <= 32) hipLaunchKernelGGL((zc_biv_round_kernel<32, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
-    else if (max_regs <= 256) hipLaunchKernelGGL((zc_biv_round_kernel<256, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
-    else if (max_regs <= 1024) hipLaunchKernelGGL((zc_biv_round_kernel<1024, true>), grid, dim3(256), lds, s, d_descs, n_descs, eq, eq_len, publics, partial, 0u, block_lo);
-    else { set_error("constraint program needs %u live registers (max 1024)", max_regs); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     SP1HIP_LAUNCH_CHECK();
     return SP1HIP_SUCCESS;
 }
@@ -1899,10 +1873,14 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             const uint32_t stage_max = [] { const char* e = getenv("SP1HIP_ZC_STAGE_MAX"); return e ? (uint32_t)atoi(e) : 0u; }();   // read per call (tests)
             bool staged = instr <= stage_max;
             uint32_t wg = (r == 0 && !biv) ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
-            if (wg == 0) {                  // the file does not fit LDS: VGPR / scratch tier, program staged
-                SP1HIP_REQUIRE(instr <= ZC_LDS_PROG_MAX, "constraint program too large (one constraint with too many live values)");
-                staged = true;
+            if (wg == 0 && use_mono[i] != 2) {      // the file does not fit LDS even for one wave: the finest cut of the program
+                use_mono[i] = 2;
+                regs = 1; instr = 1;
+                for (auto& ck : c.fine) { regs = std::max(regs, ck.n_regs); instr = std::max<uint32_t>(instr, (uint32_t)(ck.prog.size() / 4)); }
+                staged = instr <= stage_max;
+                wg = (r == 0 && !biv) ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
             }
+            SP1HIP_REQUIRE(wg != 0, "constraint program too large: one constraint keeps more than 160 extension values live (the LDS register file of one wave)");
             size_t g = 0;
             for (; g < groups.size(); g++) if (groups[g].staged == staged && groups[g].wg == wg) break;
             if (g == groups.size()) groups.push_back(Group{staged, wg, 1, 1, 0, 0, {}});
