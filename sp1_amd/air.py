@@ -102,6 +102,12 @@ class AirProgram:
         assert xy_col < (1 << 16) and acc_col < (1 << 16) and is_real_col < (1 << 24)
         self.instrs.append((HINT, 3 | (is_real_col << 8), xy_col | (acc_col << 16)))
 
+    def hint_keccak(self, base_col):
+        """The 2,858 asserts that follow are one Keccak-f round over main columns [base_col, base_col + 2633) (`KeccakCols`) with the
+        round index at base_col + 2638 and is_real at base_col + 2639 (keccak256/air.rs:L40-L164, everything after assert_bool(is_real))."""
+        assert 0 <= base_col and base_col + 2640 <= self.main_width
+        self.instrs.append((HINT, 5, base_col))
+
     def assert_zero(self, e):
         self._emit(ASSERT_ZERO, e.idx, 0)
         self.num_constraints += 1

@@ -148,7 +148,7 @@ __device__ __forceinline__ void rs_finish(const kb::Ext (&acc)[NS], uint32_t* __
 // free list: hipMalloc / hipFree / hipHostMalloc synchronise the device and would serialise provers that run
 // concurrently on other streams.
 struct RoundSyncSlot { uint32_t* d_counter; uint32_t* h_slot; };
-int round_sync_acquire(RoundSyncSlot* out);        // runtime.hip
+int round_sync_acquire(RoundSyncSlot* out, hipStream_t stream);        // runtime.hip: a NEW slot is zeroed on `stream`, ahead of its first user
 void round_sync_release(RoundSyncSlot slot);
 
 struct RoundSyncHost {
@@ -159,7 +159,7 @@ struct RoundSyncHost {
     int init(hipStream_t stream) {
         s = stream;
         RoundSyncSlot slot;
-        SP1HIP_TRY(round_sync_acquire(&slot));
+        SP1HIP_TRY(round_sync_acquire(&slot, stream));
         d_counter = slot.d_counter;
         h_slot = slot.h_slot;
         seq = h_slot[0];                   // continue the slot's sequence (its counter is zero between uses)

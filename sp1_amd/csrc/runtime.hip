@@ -513,7 +513,7 @@ int get_device_ctx(const DeviceCtx** out) {
 static std::mutex g_rs_mutex;
 static std::vector<RoundSyncSlot> g_rs_free[64];
 
-int round_sync_acquire(RoundSyncSlot* out) {
+int round_sync_acquire(RoundSyncSlot* out, hipStream_t stream) {
     int dev = 0;
     SP1HIP_HIP(hipGetDevice(&dev));
     SP1HIP_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
@@ -525,19 +525,15 @@ int round_sync_acquire(RoundSyncSlot* out) {
     SP1HIP_HIP(hipMalloc((void**)&slot.d_counter, RS_COUNTER_BYTES));
     // The counters must be zero before the first ticket. hipMemset is a fill kernel on the NULL stream and may return before it
     // has run; the provers' streams are non-blocking ones, which the NULL stream does not order — the first round kernel to take
-    // tickets from a NEW slot could race the fill (seen once in ~1,000 pool proofs, round 4). So: fill on a private stream and
-    // wait for THAT stream only (round 4 used hipDeviceSynchronize, which stalled a new slot on every prover's in-flight work).
-    hipError_t e;
-    {
-        static std::mutex fill_mutex;
-        static hipStream_t fill_stream[64] = {};
-        std::lock_guard<std::mutex> lock(fill_mutex);
-        e = fill_stream[dev] ? hipSuccess : hipStreamCreateWithFlags(&fill_stream[dev], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMemsetAsync(slot.d_counter, 0, RS_COUNTER_BYTES, fill_stream[dev]);
-        if (e == hipSuccess) e = hipStreamSynchronize(fill_stream[dev]);
-    }
+    // tickets from a NEW slot could race the fill (seen once in ~1,000 pool proofs, round 4, fixed there with a device
+    // synchronise: a stall on every prover's in-flight work). The fill now goes on the ACQUIRING prover's own stream: every kernel
+    // that takes tickets from this slot is launched on that stream, or on a fork stream behind an event of it, after this call —
+    // stream order is all it needs, nothing waits. (A private fill stream was tried first and cost 2 ms per proof: one more HIP
+    // stream shifts the round-robin mapping of the prover's four streams onto the process's hardware queues — round 5)
+    hipError_t e = hipMemsetAsync(slot.d_counter, 0, RS_COUNTER_BYTES, stream);
     if (e == hipSuccess) e = hipHostMalloc((void**)&slot.h_slot, RS_SLOT_WORDS * 4, hipHostMallocMapped);
     if (e != hipSuccess) {
+        (void)hipStreamSynchronize(stream);
         (void)hipFree(slot.d_counter);
         return map_hip_error(e, "creating a round-sync slot");
     }

@@ -34,6 +34,7 @@
 #include "round_sync.hpp"
 #include "zc_device.hpp"
 #include "zc_poseidon2.hpp"
+#include "zc_keccak.hpp"
 
 namespace sp1hip {
 
@@ -459,6 +460,7 @@ constexpr uint32_t ZC_DESC_MACRO = 2u;
 // KIND of a launch that carries the pieces of BOTH septic kinds (they are adjacent block ranges; the kind comes from the descriptor): in
 // the small rounds every launch is at its latency floor and the two septic launches would share a hardware queue (a process has four)
 constexpr uint32_t ZC_MACRO_BOTH_SEPTIC = 4u;
+constexpr uint32_t ZC_MACRO_KINDS = 6;        // kinds 1..3, the launch shape 4, Keccak = 5
 template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
                                                        uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
         auto ld = [&](uint32_t c, bool owned) -> T { return ld_at(base_col + c, owned); };
         auto sink = [&](uint32_t j, const T& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
         if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<F>(q, rc, ld, sink);
+        else if constexpr (KIND == ZC_HINT_KECCAK) zc_keccak_piece<F>(q, ld, sink);
         else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);
         else if (KIND == ZC_MACRO_BOTH_SEPTIC && ((d.flags >> 12) & 15u) == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);   // (wave-uniform)
         else zc_septic_sum_piece<F>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); },
@@ -622,6 +625,7 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
         auto ld = [&](uint32_t c, bool owned) -> uint32_t { return ld_at(base_col + c, owned); };
         auto sink = [&](uint32_t j, const uint32_t& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
         if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<P2Base>(q, rc, ld, sink);
+        else if constexpr (KIND == ZC_HINT_KECCAK) zc_keccak_piece<P2Base>(q, ld, sink);
         else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<P2Base>(ld, sink);
         else zc_septic_sum_piece<P2Base>(q, ld, [&](uint32_t c, bool owned) -> uint32_t { return ld_at(d.aux0 + c, owned); },
                                          [&]() -> uint32_t { return ld_at(d.aux1, false); }, sink);
@@ -856,11 +860,12 @@ struct DevBuf {
 
 struct ZcMacro {                 // a hinted sub-AIR: its constraints are [first_constraint, first_constraint + n_constraints())
     uint32_t kind, base_col, first_constraint, aux0 = 0, aux1 = 0;
-    uint32_t n_constraints() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
-    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 1u : 2u; }
+    uint32_t n_constraints() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_KECCAK ? ZC_KK_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
+    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_KECCAK ? ZC_KK_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 1u : 2u; }
     // the columns whose GKR-opening term the fused pieces carry: [lo, lo + n)
     void owned(uint32_t* lo, uint32_t* n) const {
         if (kind == ZC_HINT_POSEIDON2) { *lo = base_col; *n = ZC_P2_COLUMNS; }
+        else if (kind == ZC_HINT_KECCAK) { *lo = base_col; *n = ZC_KK_COLUMNS; }
         else if (kind == ZC_HINT_SEPTIC_CURVE) { *lo = base_col; *n = 14; }
         else { *lo = aux0; *n = 28; }
     }
@@ -1328,6 +1333,8 @@ static void macro_eval_row(const ZcMacro& m, const uint32_t* main_row, Sink&& si
     for (uint32_t q = 0; q < m.n_pieces(); q++) {
         if (m.kind == ZC_HINT_POSEIDON2)
             zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
+        else if (m.kind == ZC_HINT_KECCAK)
+            zc_keccak_piece<P2Base>(q, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
         else if (m.kind == ZC_HINT_SEPTIC_CURVE)
             zc_septic_curve_piece<P2Base>([&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
         else
@@ -1377,10 +1384,10 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                 if (clean[3 * k] == ZC_ASSERT_ZERO) asserts_before++;
                 if (clean[3 * k] != ZC_HINT) continue;
                 const uint32_t kind = clean[3 * k + 1] & 0xffu, w1 = clean[3 * k + 1] >> 8, w2 = clean[3 * k + 2];
-                SP1HIP_REQUIRE(kind >= ZC_HINT_POSEIDON2 && kind <= ZC_HINT_SEPTIC_SUM, "unknown hint kind in constraint program");
+                SP1HIP_REQUIRE((kind >= ZC_HINT_POSEIDON2 && kind <= ZC_HINT_SEPTIC_SUM) || kind == ZC_HINT_KECCAK, "unknown hint kind in constraint program");
                 ZcMacro m{kind, kind == ZC_HINT_SEPTIC_SUM ? (w2 & 0xffffu) : w2, asserts_before};
                 if (kind == ZC_HINT_SEPTIC_SUM) { m.aux0 = w2 >> 16; m.aux1 = w1; }
-                SP1HIP_REQUIRE((uint64_t)m.base_col + (kind == ZC_HINT_POSEIDON2 ? ZC_P2_COLUMNS : 14u) <= main_width &&
+                SP1HIP_REQUIRE((uint64_t)m.base_col + (kind == ZC_HINT_POSEIDON2 ? ZC_P2_COLUMNS : kind == ZC_HINT_KECCAK ? KK_IS_REAL + 1 : 14u) <= main_width &&
                                (kind != ZC_HINT_SEPTIC_SUM || ((uint64_t)m.aux0 + 28 <= main_width && m.aux1 < main_width)), "hint: columns out of range");
                 np->macros.push_back(m);
                 clean[3 * k] = ZC_CONST; clean[3 * k + 1] = 0; clean[3 * k + 2] = 0;
@@ -1569,6 +1576,13 @@ static int launch_biv_round(uint32_t max_regs, bool staged, const ZcDesc* d_desc
 }
 
 int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s);
+}
+
+// fork streams a round's launches are spread over, besides the caller's own (SP1HIP_ZC_NFORK = 1..3, default 3: with the caller's
+// stream the four hardware queues a process gets by default)
+static int zc_fork_streams() {
+    static const int n = [] { const char* e = getenv("SP1HIP_ZC_NFORK"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > 3 ? 3 : v; }();
+    return n;
 }
 
 static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int max_log_row_count,
@@ -1820,7 +1834,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<ZcChipRange> ranges;
         std::vector<int> desc_chip;
         std::vector<Group> groups;
-        uint32_t total_blocks = 0, macro_lo[4] = {0, 0, 0, 0}, macro_n[4] = {0, 0, 0, 0};
+        uint32_t total_blocks = 0, macro_lo[ZC_MACRO_KINDS] = {}, macro_n[ZC_MACRO_KINDS] = {};
         std::vector<ZcFixDesc> fds;
         std::vector<uint32_t*> fresh;
         std::vector<std::pair<int, bool>> owner;
@@ -1922,9 +1936,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         // the fused pieces of hinted sub-AIRs: one launch per kind (each kind is its own kernel with its own register budget),
         // one block range — and one reduction range — per (kind, chip)
-        uint32_t (&macro_lo)[4] = rp.macro_lo;
-        uint32_t (&macro_n)[4] = rp.macro_n;
-        for (uint32_t kind = ZC_HINT_POSEIDON2; kind <= ZC_HINT_SEPTIC_SUM; kind++) {
+        uint32_t (&macro_lo)[ZC_MACRO_KINDS] = rp.macro_lo;
+        uint32_t (&macro_n)[ZC_MACRO_KINDS] = rp.macro_n;
+        for (uint32_t kind = ZC_HINT_POSEIDON2; kind < ZC_MACRO_KINDS; kind++) {
+            if (kind == ZC_MACRO_BOTH_SEPTIC) continue;                   // (a launch shape, not a hint kind)
             macro_lo[kind] = total_blocks;
             for (int i = 0; i < n_chips; i++) {
                 ChipState& c = *st[i];
@@ -2047,9 +2062,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             {
                 ScopedTimer tm("zerocheck_round", s);
                 // the launches on fork streams, joined in front of the reduction (as in the later rounds)
-                const int n_launches = (int)rp.groups.size() + (rp.macro_n[1] ? 1 : 0) + (rp.macro_n[2] ? 1 : 0) + (rp.macro_n[3] ? 1 : 0);
+                const int n_launches = (int)rp.groups.size() + (rp.macro_n[1] ? 1 : 0) + (rp.macro_n[2] ? 1 : 0) + (rp.macro_n[3] ? 1 : 0) + (rp.macro_n[5] ? 1 : 0);
                 const bool forked = fork_enabled && n_launches > 1 && active_provers() <= 1;
                 constexpr int N_FORK = 3;
+                const int n_fork = zc_fork_streams();
                 hipStream_t* fork_s = nullptr;
                 hipEvent_t* fork_ev = nullptr;
                 if (forked) {
@@ -2059,6 +2075,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 bool fork_used[N_FORK] = {false, false, false};
                 auto stream_of = [&](int slot) -> hipStream_t {         // slot 0: the caller's stream
                     if (!forked || slot == 0) return s;
+                    if (slot > n_fork) slot = 1 + (slot - 1) % n_fork;
                     if (!fork_used[slot - 1]) { fork_used[slot - 1] = true; (void)hipStreamWaitEvent(fork_s[slot - 1], fork_ev[0], 0); }
                     return fork_s[slot - 1];
                 };
@@ -2079,6 +2096,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 3)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 3)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(5u, 1)
 #undef SP1HIP_ZC_BIV_MACRO_LAUNCH
                 if (forked)
                     for (int k = 0; k < N_FORK; k++)
@@ -2204,8 +2222,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<int>& desc_chip = rp.desc_chip;
         std::vector<Group>& groups = rp.groups;
         const uint32_t total_blocks = rp.total_blocks;
-        uint32_t (&macro_lo)[4] = rp.macro_lo;
-        uint32_t (&macro_n)[4] = rp.macro_n;
+        uint32_t (&macro_lo)[ZC_MACRO_KINDS] = rp.macro_lo;
+        uint32_t (&macro_n)[ZC_MACRO_KINDS] = rp.macro_n;
         std::vector<ZcFixDesc>& fds = rp.fds;
         std::vector<uint32_t*>& fresh = rp.fresh;
         std::vector<std::pair<int, bool>>& owner = rp.owner;
@@ -2227,13 +2245,14 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             // costs its LONGEST launch instead of their sum (five launches of 30-70 us each in the last fifteen rounds of a
             // core shard; in the large rounds one launch's tail overlaps the next one's head). SP1HIP_ZC_FORK=0: one stream.
             static const bool fuse_nodes = [] { const char* e = getenv("SP1HIP_ZC_FUSE_NODES"); return e && e[0] == '1'; }();
-            const int n_launches = (int)groups.size() + (macro_n[1] ? 1 : 0) + (macro_n[2] ? 1 : 0) + (macro_n[3] ? 1 : 0);
+            const int n_launches = (int)groups.size() + (macro_n[1] ? 1 : 0) + (macro_n[2] ? 1 : 0) + (macro_n[3] ? 1 : 0) + (macro_n[5] ? 1 : 0);
             static const uint32_t fork_max_blocks = [] { const char* e = getenv("SP1HIP_ZC_FORK_MAX_BLOCKS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : ZC_FORK_MAX_BLOCKS; }();
             const bool forked = fork_enabled && n_launches > 1 && total_blocks <= fork_max_blocks && active_provers() <= 1;
             // the round's sums reach the host through the mailbox slot when they fit it (they do for any real machine)
             const bool direct = (size_t)n_ranges * 16 + 1 <= MAILBOX_WORDS;
             const RoundSync rs_pub = direct ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
             constexpr int N_FORK = 3;                  // + the caller's stream = the four hardware queues a process gets by default
+            const int n_fork = zc_fork_streams();      // SP1HIP_ZC_NFORK = 1..3 fork streams (A/B knob)
             hipStream_t* fork_s = nullptr;
             hipEvent_t* fork_ev = nullptr;
             bool fork_used[N_FORK] = {false, false, false};
@@ -2247,7 +2266,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             struct Launch { int kind; size_t group; double est; int slot; };           // kind 0: interpreter group, 1..3: fused pieces
             std::vector<Launch> order;
             {
-                static const double floor_us[4] = {45.0, 75.0, 45.0, 60.0};
+                static const double floor_us[ZC_MACRO_KINDS] = {45.0, 75.0, 45.0, 60.0, 60.0, 120.0};
                 for (size_t g = 0; g < groups.size(); g++) order.push_back({0, g, floor_us[0] * (1.0 + groups[g].n_blocks * 3 / 1024.0), 0});
                 const bool both_septic = forked && r > 0 && macro_n[2] && macro_n[3] && (uint64_t)total_blocks * 3 <= ZC_SMALL_ROUND_WGS;
                 for (int kind = 1; kind <= 3; kind++) {
@@ -2255,6 +2274,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     if (both_septic && kind == 3) order.push_back({(int)ZC_MACRO_BOTH_SEPTIC, 0, floor_us[3] * (1.0 + (macro_n[2] + macro_n[3]) * 3 / 1024.0), 0});
                     else order.push_back({kind, 0, floor_us[kind] * (1.0 + macro_n[kind] * 3 / 1024.0), 0});
                 }
+                if (macro_n[ZC_HINT_KECCAK]) order.push_back({(int)ZC_HINT_KECCAK, 0, floor_us[ZC_HINT_KECCAK] * (1.0 + macro_n[ZC_HINT_KECCAK] * 3 / 1024.0), 0});
                 if (forked) {
                     std::stable_sort(order.begin(), order.end(), [](const Launch& a, const Launch& b) { return a.est > b.est; });
                     double load[N_FORK + 1] = {0, 7, 14, 21};          // (the launches leave the host ~7 us apart)
@@ -2262,7 +2282,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     // profiles/r04_gap_trace_timeline.txt — and four queues still beat three: 2.0 against 2.2 ms in round 2)
                     for (Launch& ln : order) {
                         int best = 0;
-                        for (int k = 1; k <= N_FORK; k++) if (load[k] < load[best]) best = k;
+                        for (int k = 1; k <= n_fork; k++) if (load[k] < load[best]) best = k;
                         ln.slot = best;
                         load[best] += ln.est;
                     }
@@ -2299,6 +2319,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_MACRO_LAUNCH(1u)
                 SP1HIP_ZC_MACRO_LAUNCH(2u)
                 SP1HIP_ZC_MACRO_LAUNCH(3u)
+                SP1HIP_ZC_MACRO_LAUNCH(5u)
 #undef SP1HIP_ZC_MACRO_LAUNCH
                 if (ln.kind == (int)ZC_MACRO_BOTH_SEPTIC) {          // (never round 0: that round is far above the small-round bound)
                     hipLaunchKernelGGL((zc_macro_kernel<false, ZC_MACRO_BOTH_SEPTIC>), dim3((macro_n[2] + macro_n[3]) * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[2], dctx->d_rc);

@@ -355,6 +355,7 @@ def keccak_permute_chip():                                                      
     L = S(("keccak", KECCAK_COLS), ("clk_high", 1), ("clk_low", 1), ("state_addr", 3), ("index", 1), ("is_real", 1))(c)
     k = L.keccak
     b.assert_bool(L.is_real)
+    b.air.hint_keccak(0)                                                                  # a prover may evaluate what follows with fused pieces (sp1_amd/csrc/zc_keccak.hpp)
     andn = lambda x, y: y - x * y
     xor = lambda x, y: x + y - x * (y * 2)
     xor3 = lambda x, y, z: xor(x, xor(y, z))
