@@ -459,6 +459,16 @@ int sp1hip_tracegen_recursion_prefix_sum_checks(uint32_t* d_trace, uint64_t heig
 int sp1hip_tracegen_recursion_poseidon2_wide(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
                                              sp1hip_stream_t stream);
 
+/* Device trace generation for the RISC-V machine's Global chip (`CudaTracegenAir for GlobalChip`,
+ * /root/reference/sp1-gpu/crates/sys/lib/tracegen/riscv/global.cu:L1-L252; CPU definition
+ * /root/reference/crates/core/machine/src/global/mod.rs:L131-L260): events = `GlobalInteractionEvent { message: [u32; 8],
+ * is_receive: bool, kind: u8 }` as 9 u32 words each (word 8 = is_receive | kind << 8, the `#[repr(C)]` image); writes the
+ * column-major [241][height] table: message, limbs, the Poseidon2 permutation's 179 columns, the lifted curve point, the running
+ * digest sum (a scan over the septic curve's group law) and the reference's padding rows. Synchronises the stream before it
+ * returns (it reports an event without a curve point as an error). */
+int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
+                                 sp1hip_stream_t stream);
+
 /* ---------------------------------------------------------------- the AirProver slot: setup / proving key
  * `MachineVerifyingKey` (/root/reference/crates/hypercube/src/verifier/config.rs:L71-L81), Montgomery words. The
  * septic digest is x[7] then y[7]. */

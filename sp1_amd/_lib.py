@@ -183,6 +183,7 @@ PROTOTYPES = [
     ("sp1hip_tracegen_recursion_memory_var", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_tracegen_recursion_prefix_sum_checks", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_tracegen_recursion_poseidon2_wide", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_tracegen_riscv_global", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_setup", None, [C.POINTER(Table), _int, u32p, u32p, C.c_uint32, ShardParams, C.POINTER(_vp), _vp]),
     ("sp1hip_pk_free", "void", [_vp]),
     ("sp1hip_pk_vk", None, [_vp, C.POINTER(Vk)]),

@@ -545,6 +545,15 @@ def tracegen_recursion(chip, events, height, stream=None):
     return ColMajor(out, int(height), width)
 
 
+def tracegen_riscv_global(events, height, stream=None):
+    """`generate_trace_device` for the RISC-V Global chip (sp1hip_tracegen_riscv_global): events = device int32 tensor [n, 9]
+    (message[8], is_receive | kind << 8); returns the column-major [241][height] table as a ColMajor."""
+    n = int(events.shape[0])
+    out = device_words(241 * height)
+    check(_L().sp1hip_tracegen_riscv_global(_dptr(out), int(height), _dptr(events) if n else None, n, _stream_ptr(stream)))
+    return ColMajor(out, int(height), 241)
+
+
 class ProvingKey:
     """`ProvingKey` of the AirProver slot: the preprocessed commitment round + the verifying key (sp1hip_setup).
     Keeps the preprocessed device tables alive."""

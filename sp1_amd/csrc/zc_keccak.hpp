@@ -86,7 +86,7 @@ KB_HD void zc_keccak_piece(uint32_t q, Load&& ld, Sink&& sink) {
     }
     if (q <= 5) {                                      // theta's column parities for one x
         const uint32_t x = q - 1, xm = (x + 4) % 5, xp = (x + 1) % 5;
-#pragma unroll 1
+#pragma unroll 2
         for (uint32_t z = 0; z < 64; z++) {
             const T c = ld(KK_C + x * 64 + z, true);
             const T cpr = ld(KK_CP + x * 64 + z, true);
@@ -108,7 +108,7 @@ KB_HD void zc_keccak_piece(uint32_t q, Load&& ld, Sink&& sink) {
 #pragma unroll 1
             for (uint32_t limb = 0; limb < 4; limb++) {
                 T acc;
-#pragma unroll 1
+#pragma unroll 4
                 for (uint32_t k = 0; k < 16; k++) {
                     const uint32_t z = limb * 16 + 15 - k;
                     const T ap = ld(KK_AP + (y * 5 + x) * 64 + z, true);
@@ -131,7 +131,7 @@ KB_HD void zc_keccak_piece(uint32_t q, Load&& ld, Sink&& sink) {
 #pragma unroll 1
             for (uint32_t limb = 0; limb < 4; limb++) {
                 T acc;
-#pragma unroll 1
+#pragma unroll 4
                 for (uint32_t k = 0; k < 16; k++) {
                     const uint32_t z = limb * 16 + 15 - k;
                     const T b1 = ld(b_col((x + 1) % 5, z), false), b2 = ld(b_col((x + 2) % 5, z), false);
