@@ -270,6 +270,105 @@ def synthetic_core_shaped(api, k, repeat=3):
             "cells": meta["area_cells"], "ms_per_proof": ms, "cells_per_s": meta["area_cells"] / (ms * 1e-3)}
 
 
+def tree_mode(api, shards, dist, torch, args, rank, world, use_dist, chips, meta, prep_commit, prep_data, L, lsh, publics, kind, names):
+    """BASELINE config 5's shape (`CompressTree::reduce_proofs`, crates/prover/src/worker/controller/compress.rs:L234-L420) on the
+    backends this box has: K core shards striped over the ranks (each rank proves ITS shard's traces K / W times, with a different
+    transcript head per leaf so that the leaf proofs differ), then the proofs are reduced to one root — every parent a ShardProof
+    of the reference's recursion compress machine that commits to its children (shards.recursion_combine), proven on the parent's
+    rank with sp1hip_prove_shard; children travel point to point (RCCL send / recv under nccl, gloo otherwise). The WHOLE job is
+    inside the timed region; per-level times and bytes are collected on every rank."""
+    import numpy as np
+    from sp1_amd.machines import recursion as R
+    from sp1_amd.machines import recursion_trace as RT
+    k = args.scale_log2
+    n_leaves = args.tree_leaves or 2 * world + 1
+    # the recursion machine of a tree node: the reference's compress shape scaled like the leaves
+    counts = {n: max(8, h >> (2 * k)) for n, h in RT.REFERENCE_COMPRESS_HEIGHTS.items() if n != "PublicValues"}
+    rL, rlsh = max(21 - k, 8), max(20 - k, 7)
+    rmachine = R.compress_machine()
+    node_jp = api.JaggedProver(rL, rlsh, 32, 2)
+
+    def prove_node(tables, pv):
+        # a node's recursion program (its preprocessed tables carry the digest rows) is set up INSIDE the timed region, like the
+        # reference's per-node program; the blob that travels = the node's preprocessed commitment + bincode(ShardProof)
+        dev = [(a, i, api.ColMajor.from_row_major_host(tables[a.name][1]), api.ColMajor.from_row_major_host(tables[a.name][0])) for a, i in rmachine]
+        commit, prep = node_jp.commit_multilinears([d[3] for d in dev])
+        ch = api.DuplexChallenger()
+        ch.observe(commit)
+        return bytes(np.asarray(commit, np.uint32).tobytes()) + api.prove_shard(dev, pv, prep, rL, rlsh, 32, ch)
+    combine = shards.recursion_combine(prove_node, counts, seed=7)
+
+    def leaf(i):
+        ch = api.DuplexChallenger()
+        ch.observe(prep_commit)
+        ch.observe(np.array([i + 1], dtype=np.uint32))      # a per-leaf transcript head: K different proofs of the rank's shard
+        return api.prove_shard(chips, publics, prep_data, L, lsh, 32, ch)
+    # warm-up: one leaf and one node (arena, plans, pinned slots)
+    leaf(10 ** 6)
+    combine([b"warm", b"up"])
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    levels = []
+    t0 = time.perf_counter()
+    mine = shards.stripe(n_leaves, world, rank)
+    leaves = {i: leaf(i) for i in mine}
+    torch.cuda.synchronize()
+    t_leaves = time.perf_counter() - t0
+    root = shards.reduce_tree(leaves, n_leaves, combine, 2, on_level=lambda li, st: levels.append(dict(st, level=li)))
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    dt = shards.max_over_ranks(time.perf_counter() - t0)
+    t_leaves = shards.max_over_ranks(t_leaves)
+    # per-level table: max over ranks of the times, sum over ranks of the bytes
+    table = []
+    for li in range(len(levels)):
+        st = levels[li]
+        row = {"level": li, "nodes": st["nodes"], "parents": st["parents"],
+               "exchange_ms": 1e3 * shards.max_over_ranks(st["exchange_s"]), "prove_ms": 1e3 * shards.max_over_ranks(st["prove_s"])}
+        if use_dist:
+            t = torch.tensor([st["sent_bytes"], st["proved"]], dtype=torch.int64, device=shards._device())
+            dist.all_reduce(t)
+            row["bytes_moved"], row["proved"] = int(t[0]), int(t[1])
+        else:
+            row["bytes_moved"], row["proved"] = st["sent_bytes"], st["proved"]
+        table.append(row)
+    if rank != 0:
+        return None
+    # the root is a ShardProof of the recursion machine: full verification by the oracle (untimed)
+    verified = None
+    if not args.no_verify and root is not None:
+        verified = verify_tree_root(root, rL, rlsh)
+    area = meta["area_cells"]
+    return {"metric": "core shards proved AND reduced to one root proof through the recursion compress tree: leaf trace cells / s (whole job)",
+            "value": n_leaves * area / dt, "unit": "cells/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * dt,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery words)",
+            "data": "synthetic", "mode": "tree",
+            "config": {"workload": "%d leaves (%s shard, scale 4^-%d, %d cells each) over %d ranks + binary compress tree of recursion-machine "
+                                   "ShardProofs (%d cells per node)" % (n_leaves, kind, k, area, world, sum(counts.values())),
+                       "backend": args.backend if use_dist else None, "leaves": n_leaves, "arity": 2},
+            "tree": {"leaves_ms": 1e3 * t_leaves, "levels": table, "root_bytes": len(root) if root else None, "root_verified": verified}}
+
+
+def verify_tree_root(root, rL, rlsh):
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "root.npz")
+        commit = np.frombuffer(root[:32], dtype=np.uint32).copy()
+        ch_state = np.zeros(0, np.uint32)
+        np.savez(path, proof=np.frombuffer(root[32:], np.uint8), commit=commit, state=ch_state, L=rL, lsh=rlsh, kind="recursion",
+                 names=np.array([], dtype=str))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--verify-child", path], capture_output=True, text=True)
+    if r.returncode != 0:
+        print("verifier child failed:\n" + r.stderr[-2000:], file=sys.stderr)
+        return False
+    return json.loads(r.stdout.strip().splitlines()[-1])["rc"] == 0
+
+
 class GpuSampler:
     """Clock / power of GPU 0 from sysfs while a phase runs (amdgpu hwmon: power1_average or power1_input in microwatts,
     freq1_input = sclk in Hz): whether several provers in flight run into the package's power management
@@ -386,6 +485,12 @@ def main():
                          "max-over-ranks collectives as N = 8; RCCL when --backend nccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (2-in-flight, commit-only, CPU baseline)")
+    ap.add_argument("--mode", default="shard", choices=["shard", "tree"],
+                    help="shard (default): every rank proves its own shard, weak scaling. tree: BASELINE config 5's shape — "
+                         "--tree-leaves core shards striped over the ranks, their proofs reduced to ONE root through the recursion "
+                         "compress tree (shards.reduce_tree + recursion_combine: every node a ShardProof of the recursion machine), "
+                         "leaves + tree inside the timed region")
+    ap.add_argument("--tree-leaves", type=int, default=0, help="leaves of --mode tree (default 2 x ranks + 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL; gloo lets "
                          "several ranks share one GPU when testing the N > 1 path on a 1-GPU box)")
@@ -436,6 +541,14 @@ def main():
 
     last_state = [None]
     publics = publics_of(kind)
+    if args.mode == "tree":
+        out = tree_mode(api, shards, dist, torch, args, rank, world, use_dist, chips, meta, prep_commit, prep_data, L, lsh, publics, kind, names)
+        if rank == 0:
+            result_out.write(json.dumps(out) + "\n")
+            result_out.flush()
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     def step(stream=None):
         ch = api.DuplexChallenger()

@@ -1,3 +1,4 @@
+#include <omp.h>
 // oracle/oracle_capi.cpp — TEST INFRASTRUCTURE ONLY.
 //
 // C ABI over the CPU oracle (kb_field.hpp / kb_hash.hpp / kb_pcs.hpp / kb_zerocheck.hpp) so that
@@ -516,6 +517,9 @@ size_t orc_shard_prove(int n, const char** names, const uint32_t** zc_progs, con
 // CPU-baseline aids: choose the LogUp-GKR formulation of orc_shard_prove / orc_gkr_prove and read the stage times of the
 // calling thread's last orc_shard_prove (commit, LogUp-GKR, zerocheck, jagged evaluation proof)
 void orc_set_gkr_sparse(int on) { g_gkr_sparse = on; }
+// OpenMP threads of this process's oracle (tests with several oracle processes on one box: the environment variable is read
+// when the OpenMP runtime loads, which torch's import has usually done already)
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void orc_stage_seconds(double* out4) { for (int k = 0; k < 4; k++) out4[k] = g_stage_seconds[k]; }
 
 // with_chips == 0: n may be 0; everything chip-independent is checked (the reference's real proof)

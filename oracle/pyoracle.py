@@ -95,6 +95,8 @@ def lib():
                                        C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_stage_seconds.argtypes = [C.POINTER(C.c_double)]
         L.orc_set_gkr_sparse.argtypes = [C.c_int]
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = None
         _lib = L
     return _lib
 
@@ -646,6 +648,11 @@ def shard_prove(chips, publics, prep_round, L, lsh, batch, challenger, log_blowu
     buf = (C.c_uint8 * size)()
     lib().orc_shard_prove(*args, challenger.h, buf, size)
     return bytes(buf)
+
+
+def set_threads(n):
+    """OpenMP threads of the oracle in this process (several oracle processes on one box: tests/test_multirank.py)."""
+    lib().orc_set_threads(int(n))
 
 
 def set_gkr_sparse(on):

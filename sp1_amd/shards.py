@@ -65,7 +65,7 @@ def gather_blobs(blobs):
     return out
 
 
-def reduce_tree(leaf_blobs, n_leaves, combine, arity=2):
+def reduce_tree(leaf_blobs, n_leaves, combine, arity=2, on_level=None):
     """The recursion compress tree across ranks (`CompressTree::reduce_proofs`,
     /root/reference/crates/prover/src/worker/controller/compress.rs:L234-L420): adjacent ranges of proofs are batched
     `arity` at a time into a parent node until one proof is left. Nodes of every level are striped over the ranks like
@@ -77,16 +77,22 @@ def reduce_tree(leaf_blobs, n_leaves, combine, arity=2):
     leaf_blobs: {leaf index: bytes} for the leaves THIS rank proved (`stripe`); n_leaves: global leaf count;
     combine(list_of_child_blobs) -> bytes proves a parent (a RecursionAir shard whose witness is the child proofs —
     the same `sp1hip_prove_shard` hot path with another machine description). A node with a single child is carried
-    up unchanged. Returns the root blob on rank 0 and None elsewhere."""
+    up unchanged. Returns the root blob on rank 0 and None elsewhere.
+    on_level(level_index, stats): called on every rank after each level with this rank's {"nodes", "parents", "proved",
+    "sent_bytes", "recv_bytes", "exchange_s", "prove_s"} (the bench's per-level table)."""
+    import time
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     level = dict(leaf_blobs)
     n = int(n_leaves)
     if n == 0:
         return None
+    level_index = 0
     while n > 1:
         n_parents = (n + arity - 1) // arity
         have = {}                       # child index -> blob, for the parents this rank owns
+        sent = recvd = 0
+        t_level = time.perf_counter()
         if world == 1:
             have = level
         else:
@@ -111,21 +117,32 @@ def reduce_tree(leaf_blobs, n_leaves, combine, arity=2):
                     elif rank == src:
                         t = torch.frombuffer(bytearray(level[c]), dtype=torch.uint8).to(dev)
                         keep.append(t)
+                        sent += len(level[c])
                         ops.append(dist.P2POp(dist.isend, t, owner))
                     elif rank == owner:
                         t = torch.empty(lens[c], dtype=torch.uint8, device=dev)
                         recv_bufs[c] = t
+                        recvd += lens[c]
                         ops.append(dist.P2POp(dist.irecv, t, src))
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
             for c, t in recv_bufs.items():
                 have[c] = bytes(t.cpu().numpy().tobytes())
-        nxt = {}
+        t_prove = time.perf_counter()
+        nxt, proved = {}, 0
         for j in range(rank, n_parents, world):
             kids = [have[c] for c in range(j * arity, min((j + 1) * arity, n))]
-            nxt[j] = kids[0] if len(kids) == 1 else combine(kids)
+            if len(kids) == 1:
+                nxt[j] = kids[0]
+            else:
+                nxt[j] = combine(kids)
+                proved += 1
+        if on_level is not None:
+            on_level(level_index, {"nodes": n, "parents": n_parents, "proved": proved, "sent_bytes": sent, "recv_bytes": recvd,
+                                   "exchange_s": t_prove - t_level, "prove_s": time.perf_counter() - t_prove})
         level, n = nxt, n_parents
+        level_index += 1
     return level.get(0) if rank == 0 else None
 
 
