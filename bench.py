@@ -462,6 +462,48 @@ def in_flight(api, chips, area, L, lsh, n_proofs, publics=()):
     out["staged_from_host"] = {"slots": 3, "ms_per_proof": 1e3 * dt / n_proofs, "cells_per_s": n_proofs * area / dt,
                                "host_trace_bytes_per_proof": host_bytes, "staging_ms_each": [round(r[1]["staging_ms"], 1) for r in res],
                                "note": "pinned row-major host traces -> column-major device tables inside the pipeline (PCIe-inclusive; never `value`)"}
+    # The Global chip generated ON THE DEVICE (sp1hip_tracegen_riscv_global: a third of a core shard's cells never cross PCIe):
+    # events are read back from the resident table once (setup), the device table must equal it word for word, then the same
+    # staged pipeline runs with every OTHER trace coming from pinned host memory
+    gi = next((k for k, c in enumerate(chips) if c[0].name == "Global" and c[0].main_width == 241), None)
+    if gi is not None:
+        try:
+            import numpy as np
+            g = chips[gi][2]
+            gw = g.words.view(g.width, g.height)
+            lay = chips[gi][0].layout
+            r_inv = pow(1 << 32, -1, api.P)
+            canon = lambda col: ((gw[col].to(torch.int64) & 0xFFFFFFFF) * r_inv) % api.P
+            n_ev = int(canon(lay["is_real"]).sum())
+            ev = torch.stack([canon(lay["message"] + j)[:n_ev] for j in range(8)] + [(canon(lay["is_receive"]) | (canon(lay["kind"]) << 8))[:n_ev]], dim=1)
+            ev = ev.to(torch.int32).contiguous()
+            tms = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                table = api.tracegen_riscv_global(ev, g.height)
+                torch.cuda.synchronize()
+                tms.append(1e3 * (time.perf_counter() - t1))
+            same = bool(torch.equal(table.words, g.words))
+            host2 = [(a, i, (table if k == gi else m), pr) for k, (a, i, m, pr) in enumerate(host)]
+            pool = api.ProverPool(3)
+            for t in [pool.submit(pk, host2, publics) for _ in range(3)]:
+                assert pool.wait(t)[0] == want, "a proof from the device-generated Global table differs"
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = [pool.wait(t) for t in [pool.submit(pk, host2, publics) for _ in range(n_proofs)]]
+            dt = time.perf_counter() - t0
+            pool.close()
+            gb = 4 * g.height * g.width
+            out["staged_global_on_device"] = {
+                "slots": 3, "ms_per_proof": 1e3 * dt / n_proofs, "tracegen_global_ms": min(tms), "global_rows": g.height, "global_events": n_ev,
+                "device_table_equals_host_trace": same, "host_trace_bytes_per_proof": host_bytes - gb,
+                "ms_per_proof_plus_tracegen": 1e3 * dt / n_proofs + min(tms),
+                "note": "every trace but Global staged from pinned host memory, Global generated on the device from its %d events "
+                        "(the tracegen time is listed beside the pipeline's; run back to back it is the upper bound of their sum)" % n_ev}
+            del host2, table
+        except Exception as e:                        # an extra: never the reason a line is missing
+            print("bench.py: staged_global_on_device not measured: %r" % (e,), file=sys.stderr)
     del host
     return out
 

@@ -6,12 +6,15 @@
 // per CU): 114 ms of round kernels per shard proof against 16 ms for a whole core shard (profiles/r05_precompile_before.txt).
 // The constraints are a handful of REGULAR loop nests over (x, y, z), so a caller's program may carry `[16, 5, base_col]` in front of
 // the 2,858 asserts that follow `assert_bool(is_real)`; the planner checks the hint against the SSA on a pseudo-random row
-// (zerocheck.hip) and the asserts are then evaluated by sixteen self-contained pieces with a few live values each:
+// (zerocheck.hip) and the asserts are then evaluated by eleven self-contained pieces with a dozen live values each:
 //   q = 0          step flags (24 booleans, their sum, the round index), the bits of A''[0, 0] and the round-constant xor;
 //                  also carries the GKR term of the two column groups no constraint reads (export, preimage)
-//   q = 1 + x      C'[x, z] = xor3(C[x, z], C[x - 1, z], C[x + 1, z - 1]) and the parity check of A'[., x, z] against C'[x, z]
-//   q = 6 + y      the limbs of A[y, x] from xor3(A'[y, x, z], C[x, z], C'[x, z])
-//   q = 11 + y     the limbs of A''[y, x] from B = rho-pi(A') and chi
+//   q = 1 + x      lane column x: C'[x, z] = xor3(C[x, z], C[x - 1, z], C[x + 1, z - 1]), the parity check of A'[., x, z] against
+//                  C'[x, z], and the limbs of A[y, x] from xor3(A'[y, x, z], C[x, z], C'[x, z]) for the five y — C[x], C'[x] and
+//                  A'[., x] are loaded once for all of them
+//   q = 6 + y      the limbs of A''[y, .]: the five lanes B[., y] = rho-pi(A') bit by bit, chi for the five x at once
+// 4,900 column loads per row pair and node (the first cut — one piece per constraint family — had 12,900: the pieces are bound
+// by cache bandwidth, not by arithmetic: profiles/r05_precompile_kernel_stats_keccak_pieces_v1.csv)
 // Columns: KeccakCols of p3-keccak-air (field order: sp1_amd/machines/riscv_more.py) followed by KeccakMemCols' own seven.
 #pragma once
 #include "kb31.hpp"
@@ -20,7 +23,7 @@
 namespace sp1hip {
 
 constexpr uint32_t ZC_HINT_KECCAK = 5;
-constexpr uint32_t ZC_KK_CONSTRAINTS = 2858, ZC_KK_COLUMNS = 2633, ZC_KK_PIECES = 16;
+constexpr uint32_t ZC_KK_CONSTRAINTS = 2858, ZC_KK_COLUMNS = 2633, ZC_KK_PIECES = 11;
 constexpr uint32_t KK_FLAGS = 0, KK_EXPORT = 24, KK_PRE = 25, KK_A = 125, KK_C = 225, KK_CP = 545, KK_AP = 865, KK_APP = 2465,
                    KK_APP00 = 2565, KK_APPP00 = 2629, KK_INDEX = 2638, KK_IS_REAL = 2639;
 // constraint numbering inside the hint (the reference's order of assertion)
@@ -84,63 +87,69 @@ KB_HD void zc_keccak_piece(uint32_t q, Load&& ld, Sink&& sink) {
         }
         return;
     }
-    if (q <= 5) {                                      // theta's column parities for one x
+    if (q <= 5) {
+        // everything that lives in lane column x: C'[x, z] and the parity check, and — sharing the loads of C[x, .], C'[x, .] and
+        // A'[., x, .] — the limbs of A[y, x] for all five y (xor3(A', C, C') = xor(A', xor(C, C')))
         const uint32_t x = q - 1, xm = (x + 4) % 5, xp = (x + 1) % 5;
-#pragma unroll 2
-        for (uint32_t z = 0; z < 64; z++) {
-            const T c = ld(KK_C + x * 64 + z, true);
-            const T cpr = ld(KK_CP + x * 64 + z, true);
-            sink(KK_J_CP + (x * 64 + z) * 2, zc_kk_bool<F>(c));
-            const T inner = zc_kk_xor<F>(ld(KK_C + xm * 64 + z, false), ld(KK_C + xp * 64 + (z + 63) % 64, false));
-            sink(KK_J_CP + (x * 64 + z) * 2 + 1, F::sub(cpr, zc_kk_xor<F>(c, inner)));
-            T d = ld(KK_AP + x * 64 + z, false);
 #pragma unroll 1
-            for (uint32_t y = 1; y < 5; y++) d = F::add(d, ld(KK_AP + (y * 5 + x) * 64 + z, false));
-            d = F::sub(d, cpr);
-            sink(KK_J_DIFF + x * 64 + z, F::mul(F::mul(d, F::addc(d, kb::P - kb::to_monty(2))), F::addc(d, kb::P - kb::to_monty(4))));
+        for (uint32_t limb = 0; limb < 4; limb++) {
+            T acc[5];
+#pragma unroll 2
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t z = limb * 16 + 15 - k;
+                const T c = ld(KK_C + x * 64 + z, true);
+                const T cpr = ld(KK_CP + x * 64 + z, true);
+                sink(KK_J_CP + (x * 64 + z) * 2, zc_kk_bool<F>(c));
+                const T inner = zc_kk_xor<F>(ld(KK_C + xm * 64 + z, false), ld(KK_C + xp * 64 + (z + 63) % 64, false));
+                sink(KK_J_CP + (x * 64 + z) * 2 + 1, F::sub(cpr, zc_kk_xor<F>(c, inner)));
+                const T cc = zc_kk_xor<F>(c, cpr);
+                T d = F::sub(F::mulc(c, 0u), cpr);
+#pragma unroll
+                for (uint32_t y = 0; y < 5; y++) {
+                    const T ap = ld(KK_AP + (y * 5 + x) * 64 + z, true);
+                    sink(KK_J_A + ((y * 5 + x) * 4 + limb) * 17 + k, zc_kk_bool<F>(ap));
+                    const T bit = zc_kk_xor<F>(ap, cc);
+                    acc[y] = k == 0 ? bit : F::add(F::add(acc[y], acc[y]), bit);
+                    d = F::add(d, ap);
+                }
+                sink(KK_J_DIFF + x * 64 + z, F::mul(F::mul(d, F::addc(d, kb::P - kb::to_monty(2))), F::addc(d, kb::P - kb::to_monty(4))));
+            }
+#pragma unroll
+            for (uint32_t y = 0; y < 5; y++)
+                sink(KK_J_A + ((y * 5 + x) * 4 + limb) * 17 + 16, F::sub(acc[y], ld(KK_A + (y * 5 + x) * 4 + limb, true)));
         }
         return;
     }
-    if (q <= 10) {                                     // A[y, x] limbs against A' ^ C ^ C'
+    {                                                  // the limbs of A''[y, .]: chi over the five lanes B[., y] = rho-pi(A'), each bit loaded once
         const uint32_t y = q - 6;
-#pragma unroll 1
-        for (uint32_t x = 0; x < 5; x++)
-#pragma unroll 1
-            for (uint32_t limb = 0; limb < 4; limb++) {
-                T acc;
-#pragma unroll 4
-                for (uint32_t k = 0; k < 16; k++) {
-                    const uint32_t z = limb * 16 + 15 - k;
-                    const T ap = ld(KK_AP + (y * 5 + x) * 64 + z, true);
-                    sink(KK_J_A + ((y * 5 + x) * 4 + limb) * 17 + k, zc_kk_bool<F>(ap));
-                    const T bit = zc_kk_xor<F>(ap, zc_kk_xor<F>(ld(KK_C + x * 64 + z, false), ld(KK_CP + x * 64 + z, false)));
-                    acc = k == 0 ? bit : F::add(F::add(acc, acc), bit);
-                }
-                sink(KK_J_A + ((y * 5 + x) * 4 + limb) * 17 + 16, F::sub(acc, ld(KK_A + (y * 5 + x) * 4 + limb, true)));
-            }
-        return;
-    }
-    {                                                  // A''[y, x] limbs: chi over B = rho-pi(A')
-        const uint32_t y = q - 11;
-        auto b_col = [&](uint32_t bx, uint32_t z) -> uint32_t {            // B[bx, y, z] = A'[(bx + 3 y) % 5, bx][z - r]
+        uint32_t bcol[5], brot[5];
+#pragma unroll
+        for (uint32_t bx = 0; bx < 5; bx++) {          // B[bx, y, z] = A'[(bx + 3 y) % 5, bx][z - r]
             const uint32_t xa = (bx + 3 * y) % 5, ya = bx;
-            return KK_AP + (ya * 5 + xa) * 64 + (z + 64 - R[xa * 5 + ya]) % 64;
-        };
+            bcol[bx] = KK_AP + (ya * 5 + xa) * 64;
+            brot[bx] = 64 - R[xa * 5 + ya];
+        }
 #pragma unroll 1
-        for (uint32_t x = 0; x < 5; x++)
-#pragma unroll 1
-            for (uint32_t limb = 0; limb < 4; limb++) {
-                T acc;
-#pragma unroll 4
-                for (uint32_t k = 0; k < 16; k++) {
-                    const uint32_t z = limb * 16 + 15 - k;
-                    const T b1 = ld(b_col((x + 1) % 5, z), false), b2 = ld(b_col((x + 2) % 5, z), false);
-                    const T andn = F::sub(b2, F::mul(b1, b2));
-                    const T bit = zc_kk_xor<F>(ld(b_col(x, z), false), andn);
-                    acc = k == 0 ? bit : F::add(F::add(acc, acc), bit);
+        for (uint32_t limb = 0; limb < 4; limb++) {
+            T acc[5];
+#pragma unroll 2
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t z = limb * 16 + 15 - k;
+                T bv[5];
+#pragma unroll
+                for (uint32_t bx = 0; bx < 5; bx++) bv[bx] = ld(bcol[bx] + (z + brot[bx]) % 64, false);
+#pragma unroll
+                for (uint32_t x = 0; x < 5; x++) {
+                    const T& b1 = bv[(x + 1) % 5];
+                    const T& b2 = bv[(x + 2) % 5];
+                    const T bit = zc_kk_xor<F>(bv[x], F::sub(b2, F::mul(b1, b2)));
+                    acc[x] = k == 0 ? bit : F::add(F::add(acc[x], acc[x]), bit);
                 }
-                sink(KK_J_APP + (y * 5 + x) * 4 + limb, F::sub(acc, ld(KK_APP + (y * 5 + x) * 4 + limb, true)));
             }
+#pragma unroll
+            for (uint32_t x = 0; x < 5; x++)
+                sink(KK_J_APP + (y * 5 + x) * 4 + limb, F::sub(acc[x], ld(KK_APP + (y * 5 + x) * 4 + limb, true)));
+        }
     }
 }
 

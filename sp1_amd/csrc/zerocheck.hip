@@ -647,6 +647,68 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
     }
 }
 
+// The Keccak pieces on the bivariate grid, FOUR nodes per pass (node group g = nodes 4 g .. 4 g + 3, like the interpreter's KT4
+// passes): the pieces are bound by the bandwidth their column loads draw from the caches, and one node per workgroup reads the
+// four rows of every column twelve times. Here the rows are loaded once per group and interpolated to the group's four nodes; the
+// arithmetic is element-wise on the 4-vector. blockIdx.x = 3 b + g.
+struct P2Base4 {
+    using T = kb::Ext;                                   // four base-field node values
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return kb::ext_add(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return kb::ext_sub(a, b); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return KT4::mul(a, b); }
+    static __device__ __forceinline__ T addc(const T& a, uint32_t c) { return KC4::addc(a, c); }
+    static __device__ __forceinline__ T mulc(const T& a, uint32_t c) { return kb::ext_mul_base(a, c); }
+};
+__global__ __launch_bounds__(256) void zc_biv_keccak_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                            uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base) {
+    using K = KT<true>;
+    __shared__ uint32_t red[4][32];
+    const uint32_t bid = block_base + blockIdx.x / ZC_BIV_GROUPS;
+    const uint32_t grp = blockIdx.x % ZC_BIV_GROUPS;
+    const ZcBivNode n0 = zc_biv_node(4 * grp), n1 = zc_biv_node(4 * grp + 1), n2 = zc_biv_node(4 * grp + 2), n3 = zc_biv_node(4 * grp + 3);
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const uint32_t q = (d.flags >> 8) & 15u, base_col = d.pad;
+    const uint32_t quads = (d.rows + 3) / 4;
+    kb::Ext sa[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < quads; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, quads); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        kb::Ext va[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+        auto ld = [&](uint32_t c, bool) -> kb::Ext {
+            const zc_global_words_t g = (zc_global_words_t)d.main + (size_t)(base_col + c) * d.rows;
+            const uint32_t r = 4 * i;
+            const uint32_t r00 = g[r], r01 = r + 1 < d.rows ? g[r + 1] : 0u, r10 = r + 2 < d.rows ? g[r + 2] : 0u, r11 = r + 3 < d.rows ? g[r + 3] : 0u;
+            return kb::Ext{{zc_biv_interp(r00, r01, r10, r11, n0), zc_biv_interp(r00, r01, r10, r11, n1), zc_biv_interp(r00, r01, r10, r11, n2),
+                            zc_biv_interp(r00, r01, r10, r11, n3)}};
+        };
+        auto sink = [&](uint32_t j, const kb::Ext& v) {
+            const kb::Ext a = load_ext_aos(d.alpha_pows, d.alpha_off + j);
+#pragma unroll
+            for (int n = 0; n < 4; n++) va[n] = kb::ext_add(va[n], K::scale(a, v.c[n]));
+        };
+        zc_keccak_piece<P2Base4>(q, ld, sink);
+#pragma unroll
+        for (int n = 0; n < 4; n++) sa[n] = kb::ext_add(sa[n], kb::ext_mul(va[n], e));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t v = zc_wave_sum(sa[n].c[k]);
+            if (lane == 0) red[wave][n * 4 + k] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const uint32_t n = threadIdx.x >> 3, k = threadIdx.x & 7u;
+        const uint32_t w = n * 4 + (k & 3u);
+        partial[((size_t)bid * ZC_BIV_NODES + 4 * grp + n) * 8 + k] =
+            k < 4 ? kb::add(kb::add(red[0][w], red[1][w]), kb::add(red[2][w], red[3][w])) : 0u;
+    }
+}
+
 // One workgroup per (range, node): the node's [A | B] summed over the range's blocks. Per range the output is A_0..11 (12 ext),
 // the four corner sums B_0..3 (4 ext), eq[th] (1 ext): out[range][68] and, with a host slot, payload words [1 + 68 range ..);
 // the last workgroup of the launch publishes `seq`. (One workgroup per range took 235 us for a chip of 12k blocks.)
@@ -2096,7 +2158,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 3)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 3)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(5u, 1)
+                if (rp.macro_n[ZC_HINT_KECCAK]) {          // four nodes per pass: three node-group workgroups per block
+                    hipLaunchKernelGGL(zc_biv_keccak_kernel, dim3(rp.macro_n[ZC_HINT_KECCAK] * ZC_BIV_GROUPS), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_KECCAK]);
+                    SP1HIP_LAUNCH_CHECK();
+                }
 #undef SP1HIP_ZC_BIV_MACRO_LAUNCH
                 if (forked)
                     for (int k = 0; k < N_FORK; k++)

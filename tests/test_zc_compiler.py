@@ -130,6 +130,14 @@ def test_compiled_forms_of_the_riscv_chips_evaluate_like_the_ssa(lib):
         _check(lib, riscv.chip(name)[0], 300 + k, 4)
 
 
+def test_compiled_forms_of_the_round_5_chips_evaluate_like_the_ssa(lib):
+    """DivRem, the syscall chips, the Keccak controller — and KeccakPermute, whose 2,858 hinted constraints are evaluated by the
+    fused Keccak pieces (zc_keccak.hpp) in forms 1-3: their host model must give every constraint what the SSA gives (random rows,
+    the all-zero row included; SyscallInstrs reads 148 public values)."""
+    for k, name in enumerate(("KeccakPermute", "DivRem", "SyscallInstrs", "SyscallCore", "KeccakPermuteControl", "MemoryGlobalInit")):
+        _check(lib, riscv.chip(name)[0], 400 + k, 160)
+
+
 def test_planner_rejects_overlapping_hints(lib):
     """each hint is checked against the SSA on its own; two hints over the same constraints / columns (a duplicated
     HINT) would each pass and then be counted twice. The planner must refuse the program."""
