@@ -631,10 +631,22 @@ def _shard_chip_args(chips):
     return n, g[1], zc_ptrs, zc_lens, g[3], g[4], nc, g[2], g[5], g[6], g[7], (airs, g[8])
 
 
+def _check_publics(chips, n_publics):
+    """A constraint program that reads public value i needs at least i + 1 of them (the C side indexes the array unchecked)."""
+    need = 0
+    for c in chips:
+        for op, a, _ in c[0].instrs:
+            if op == 3:                                     # PUBLIC idx
+                need = max(need, a + 1)
+    if need > n_publics:
+        raise ValueError("the constraint programs read public value %d; only %d were passed" % (need - 1, n_publics))
+
+
 def shard_prove(chips, publics, prep_round, L, lsh, batch, challenger, log_blowup=2, num_queries=124, pow_bits=16, capacity=None):
     """ShardProver::prove_shard_with_data -> bincode(ShardProof). prep_round: JaggedRound of the preprocessed traces."""
     n, names, zc, zl, mw, pw, nc, gk, mains, preps, rows, keep = _shard_chip_args(chips)
     pv = _arr(publics).reshape(-1)
+    _check_publics(chips, pv.size)
     args = (n, names, zc, zl, mw, pw, nc, gk, mains, preps, rows, _p(pv) if pv.size else None, int(pv.size), prep_round.h, L,
             lsh, C.c_size_t(batch), log_blowup, num_queries, pow_bits)
     if capacity:                                             # ONE pass (the CPU baseline times this): a buffer that is surely large enough

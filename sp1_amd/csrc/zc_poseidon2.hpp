@@ -17,6 +17,20 @@
 #include "kb31.hpp"
 #include "poseidon2.hpp"
 
+// A scheduling fence between the extension-field products of the fused pieces: left alone, the machine scheduler interleaves a
+// dozen independent 16-multiply products for ILP and the pieces end up at 210-256 VGPRs (two waves per SIMD, or one); with one
+// product in flight at a time the live set is what the algorithm needs (two septic operands, a group sum, an accumulator).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a column index the optimiser cannot see through: a SECOND load of a column the piece has read before is then a real load
+// instead of 28 registers kept alive across a septic product (the columns are in cache; the registers are what is scarce)
+#define ZC_OPAQUE_ASM(v) asm volatile("" : "+s"(v))
+#else
+#define ZC_SCHED_FENCE() ((void)0)
+#define ZC_OPAQUE_ASM(v) ((void)0)
+#endif
+__host__ __device__ __forceinline__ uint32_t zc_opaque(uint32_t v) { ZC_OPAQUE_ASM(v); return v; }
+
 namespace sp1hip {
 
 constexpr uint32_t ZC_HINT = 16;               // SSA pseudo-op: [16, kind, first main column]; defines no value
@@ -85,21 +99,23 @@ KB_HD void zc_p2_piece(uint32_t q, const RC* rc, Load&& ld, Sink&& sink) {
     T s[16];
     if (q < 8) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = ld(ZC_P2_EXT + 16 * q + i, true);
+        for (int i = 0; i < 16; i++) { s[i] = ld(ZC_P2_EXT + 16 * q + i, true); if (i & 1) ZC_SCHED_FENCE(); }   // two columns' loads in flight
         if (q == 0) zc_p2_external_linear<F>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const T x = F::addc(s[i], rc->ext[q][i]);
             s[i] = F::mul(F::mul(x, x), x);
+            ZC_SCHED_FENCE();
         }
         zc_p2_external_linear<F>(s);
+        ZC_SCHED_FENCE();
         const uint32_t nxt = q == 3 ? ZC_P2_INT : q == 7 ? ZC_P2_OUT : ZC_P2_EXT + 16 * (q + 1);
 #pragma unroll
-        for (int i = 0; i < 16; i++) sink(16 * q + i, F::sub(ld(nxt + i, q == 7), s[i]));      // assert_eq(next_state[i], state[i])
+        for (int i = 0; i < 16; i++) { sink(16 * q + i, F::sub(ld(nxt + i, q == 7), s[i])); ZC_SCHED_FENCE(); }      // assert_eq(next_state[i], state[i])
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = ld(ZC_P2_INT + i, true);
+    for (int i = 0; i < 16; i++) { s[i] = ld(ZC_P2_INT + i, true); if (i & 1) ZC_SCHED_FENCE(); }
     T lane0 = s[0];
 #pragma unroll 1
     for (int r = 0; r < 20; r++) {
@@ -112,7 +128,7 @@ KB_HD void zc_p2_piece(uint32_t q, const RC* rc, Load&& ld, Sink&& sink) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) sink(147 + i, F::sub(ld(ZC_P2_EXT + 64 + i, false), s[i]));   // external_rounds_state[4]
+    for (int i = 0; i < 16; i++) { sink(147 + i, F::sub(ld(ZC_P2_EXT + 64 + i, false), s[i])); ZC_SCHED_FENCE(); }   // external_rounds_state[4]
 }
 
 
@@ -144,6 +160,7 @@ KB_HD void zc_septic_mul(const typename F::T* a, const typename F::T* b, typenam
             if (SQUARE && i < j) t = F::add(t, t);
             acc = first ? t : F::add(acc, t);
             first = false;
+            ZC_SCHED_FENCE();
         }
         if (s_ < 7) res[s_] = acc;
         else {
@@ -209,6 +226,101 @@ KB_HD void zc_septic_sum_piece(uint32_t q, LoadXY&& xy, LoadAcc&& acc, Real&& re
     const T r = real();
 #pragma unroll
     for (int k = 0; k < 7; k++) sink(7 + k, F::mul(r, F::sub(c[k], d[k])));
+}
+
+
+// ---- the septic pieces as the GPU runs them (round 5): weighted group sums instead of result coefficients.
+// A septic product whose seven coefficients are constraints j0 .. j0 + 6 contributes sum_k alpha_{j0 + k} (a b)_k to the round's
+// sum; with T_s = sum_{i + j = s} a_i b_j and z^7 = 3 z + 5 that is sum_s w_s T_s, w_s = alpha_{j0 + s} for s < 7 and
+// 5 alpha_{j0 + s - 7} + 3 alpha_{j0 + s - 6} above — so the product is never materialised: two operands, one group sum and one
+// accumulator are live (the result array and the seven alpha products of the per-coefficient form are gone), and a constraint's
+// terms may come from DIFFERENT pieces (the sum over pieces is linear). Curve equation: 2 pieces (x^3 + 45 x + 41 z^3 / y^2), sum
+// checkers: 4 (sx dx^2 / dy^2 / sy dx / dy px). The per-coefficient functions above stay the host model the planner checks hints
+// with; these are what the kernels call (checked by every GPU proof against the oracle).
+// K: KT<FIRST> of zc_device.hpp (K::scale(ext, T) = ext * T); alpha(j): wave-uniform alpha power of constraint j of the hint.
+template <class F, class K, bool SQUARE, class Alpha>
+__device__ __forceinline__ kb::Ext zc_septic_mul_weighted(const typename F::T* a, const typename F::T* b, Alpha&& alpha, uint32_t j0) {
+    using T = typename F::T;
+    const uint32_t c5 = kb::to_monty(5), c3 = kb::to_monty(3);
+    kb::Ext out = kb::ext_zero();
+#pragma unroll
+    for (int s_ = 0; s_ < 13; s_++) {
+        T acc{};
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int j = s_ - i;
+            if (j < 0 || j > 6) continue;
+            if (SQUARE && i > j) continue;
+            T t = F::mul(a[i], SQUARE ? a[j] : b[j]);
+            if (SQUARE && i < j) t = F::add(t, t);
+            acc = first ? t : F::add(acc, t);
+            first = false;
+            ZC_SCHED_FENCE();
+        }
+        const kb::Ext w = s_ < 7 ? alpha(j0 + s_)
+                                 : kb::ext_add(kb::ext_mul_base(alpha(j0 + s_ - 7), c5), kb::ext_mul_base(alpha(j0 + s_ - 6), c3));
+        out = kb::ext_add(out, K::scale(w, acc));
+        ZC_SCHED_FENCE();
+    }
+    return out;
+}
+template <class F, class K, class Load, class Alpha, class Emit>
+__device__ __forceinline__ void zc_septic_curve_piece_w(uint32_t q, Load&& ld, Alpha&& alpha, Emit&& emit) {
+    using T = typename F::T;
+    T x[7];
+    if (q == 1) {                                         // + y^2
+#pragma unroll
+        for (int i = 0; i < 7; i++) { x[i] = ld(7 + i, true); ZC_SCHED_FENCE(); }
+        emit(zc_septic_mul_weighted<F, K, true>(x, x, alpha, 0));
+        return;
+    }
+    T t[7];                                               // - (x^3 + 45 x + 41 z^3)
+#pragma unroll
+    for (int i = 0; i < 7; i++) { x[i] = ld(i, true); ZC_SCHED_FENCE(); }
+    zc_septic_mul<F, true>(x, x, t);
+    kb::Ext acc = zc_septic_mul_weighted<F, K, false>(t, x, alpha, 0);
+#pragma unroll
+    for (int k = 0; k < 7; k++) { acc = kb::ext_add(acc, K::scale(alpha(k), F::mulc(x[k], kb::to_monty(45)))); ZC_SCHED_FENCE(); }
+    acc = kb::ext_add(acc, kb::ext_mul_base(alpha(3), kb::to_monty(41)));
+    emit(kb::ext_sub(kb::ext_zero(), acc));
+}
+template <class F, class K, class LoadXY, class LoadAcc, class Real, class Alpha, class Emit>
+__device__ __forceinline__ void zc_septic_sum_piece_w(uint32_t q, LoadXY&& xy, LoadAcc&& acc, Real&& real, Alpha&& alpha, Emit&& emit) {
+    using T = typename F::T;
+    T a[7], b[7];
+    if (q == 0) {                                         // + (p1.x + p2.x + p3.x) (p2.x - p1.x)^2           constraints 0..6
+#pragma unroll
+        for (int i = 0; i < 7; i++) { a[i] = F::sub(xy(i, false), acc(i, true)); ZC_SCHED_FENCE(); }
+        zc_septic_mul<F, true>(a, a, b);
+#pragma unroll
+        for (int i = 0; i < 7; i++) { a[i] = F::add(F::add(acc(zc_opaque(i), false), xy(zc_opaque(i), false)), acc(14 + i, true)); ZC_SCHED_FENCE(); }
+        emit(zc_septic_mul_weighted<F, K, false>(a, b, alpha, 0));
+        return;
+    }
+    if (q == 1) {                                         // - (p2.y - p1.y)^2
+#pragma unroll
+        for (int i = 0; i < 7; i++) { a[i] = F::sub(xy(7 + i, false), acc(7 + i, true)); ZC_SCHED_FENCE(); }
+        emit(kb::ext_sub(kb::ext_zero(), zc_septic_mul_weighted<F, K, true>(a, a, alpha, 0)));
+        return;
+    }
+    if (q == 2) {                                         // + is_real (p1.y + p3.y) (p2.x - p1.x)                    constraints 7..13
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            a[i] = F::add(acc(7 + i, false), acc(21 + i, true));
+            b[i] = F::sub(xy(i, false), acc(i, false));
+            ZC_SCHED_FENCE();
+        }
+        emit(K::scale(zc_septic_mul_weighted<F, K, false>(a, b, alpha, 7), real()));
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {                         // - is_real (p2.y - p1.y) (p1.x - p3.x)
+        a[i] = F::sub(xy(7 + i, false), acc(7 + i, false));
+        b[i] = F::sub(acc(i, false), acc(14 + i, false));
+        ZC_SCHED_FENCE();
+    }
+    emit(kb::ext_sub(kb::ext_zero(), K::scale(zc_septic_mul_weighted<F, K, false>(a, b, alpha, 7), real())));
 }
 
 }  // namespace sp1hip

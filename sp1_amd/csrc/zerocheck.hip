@@ -493,12 +493,14 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
         };
         auto ld = [&](uint32_t c, bool owned) -> T { return ld_at(base_col + c, owned); };
         auto sink = [&](uint32_t j, const T& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
+        auto alpha = [&](uint32_t j) -> kb::Ext { return load_ext_aos(d.alpha_pows, d.alpha_off + j); };
+        auto emit = [&](const kb::Ext& v) { va = kb::ext_add(va, v); };
         if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<F>(q, rc, ld, sink);
         else if constexpr (KIND == ZC_HINT_KECCAK) zc_keccak_piece<F>(q, ld, sink);
-        else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);
-        else if (KIND == ZC_MACRO_BOTH_SEPTIC && ((d.flags >> 12) & 15u) == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<F>(ld, sink);   // (wave-uniform)
-        else zc_septic_sum_piece<F>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); },
-                                    [&]() -> T { return ld_at(d.aux1, false); }, sink);
+        else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece_w<F, K>(q, ld, alpha, emit);
+        else if (KIND == ZC_MACRO_BOTH_SEPTIC && ((d.flags >> 12) & 15u) == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece_w<F, K>(q, ld, alpha, emit);   // (wave-uniform)
+        else zc_septic_sum_piece_w<F, K>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); },
+                                         [&]() -> T { return ld_at(d.aux1, false); }, alpha, emit);
         sa = kb::ext_add(sa, kb::ext_mul(va, e));
         sb = kb::ext_add(sb, kb::ext_mul(vb, e));
     }
@@ -624,11 +626,13 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
         auto ld_at = [&](uint32_t col, bool) -> uint32_t { return zc_biv_leaf(d.main, col, d.rows, i, nd); };
         auto ld = [&](uint32_t c, bool owned) -> uint32_t { return ld_at(base_col + c, owned); };
         auto sink = [&](uint32_t j, const uint32_t& v) { va = kb::ext_add(va, K::scale(load_ext_aos(d.alpha_pows, d.alpha_off + j), v)); };
+        auto alpha = [&](uint32_t j) -> kb::Ext { return load_ext_aos(d.alpha_pows, d.alpha_off + j); };
+        auto emit = [&](const kb::Ext& v) { va = kb::ext_add(va, v); };
         if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<P2Base>(q, rc, ld, sink);
         else if constexpr (KIND == ZC_HINT_KECCAK) zc_keccak_piece<P2Base>(q, ld, sink);
-        else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece<P2Base>(ld, sink);
-        else zc_septic_sum_piece<P2Base>(q, ld, [&](uint32_t c, bool owned) -> uint32_t { return ld_at(d.aux0 + c, owned); },
-                                         [&]() -> uint32_t { return ld_at(d.aux1, false); }, sink);
+        else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece_w<P2Base, K>(q, ld, alpha, emit);
+        else zc_septic_sum_piece_w<P2Base, K>(q, ld, [&](uint32_t c, bool owned) -> uint32_t { return ld_at(d.aux0 + c, owned); },
+                                              [&]() -> uint32_t { return ld_at(d.aux1, false); }, alpha, emit);
         sa = kb::ext_add(sa, kb::ext_mul(va, e));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -923,7 +927,9 @@ struct DevBuf {
 struct ZcMacro {                 // a hinted sub-AIR: its constraints are [first_constraint, first_constraint + n_constraints())
     uint32_t kind, base_col, first_constraint, aux0 = 0, aux1 = 0;
     uint32_t n_constraints() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_KECCAK ? ZC_KK_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
-    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_KECCAK ? ZC_KK_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 1u : 2u; }
+    // pieces the kernels run (the septic kinds: weighted forms, zc_septic_*_piece_w) / pieces of the host model (per-coefficient forms)
+    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_KECCAK ? ZC_KK_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 2u : 4u; }
+    uint32_t n_host_pieces() const { return kind == ZC_HINT_SEPTIC_CURVE ? 1u : kind == ZC_HINT_SEPTIC_SUM ? 2u : n_pieces(); }
     // the columns whose GKR-opening term the fused pieces carry: [lo, lo + n)
     void owned(uint32_t* lo, uint32_t* n) const {
         if (kind == ZC_HINT_POSEIDON2) { *lo = base_col; *n = ZC_P2_COLUMNS; }
@@ -1392,7 +1398,7 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
 template <class Sink>
 static void macro_eval_row(const ZcMacro& m, const uint32_t* main_row, Sink&& sink) {
     static const p2::RoundConstants host_rc = p2::make_round_constants();
-    for (uint32_t q = 0; q < m.n_pieces(); q++) {
+    for (uint32_t q = 0; q < m.n_host_pieces(); q++) {
         if (m.kind == ZC_HINT_POSEIDON2)
             zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
         else if (m.kind == ZC_HINT_KECCAK)

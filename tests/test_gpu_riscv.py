@@ -17,6 +17,7 @@ from sp1_amd.machines import riscv_trace as RT  # noqa: E402
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench"))
 
+PUBLICS = np.zeros(160, np.uint32)      # SP1_PROOF_NUM_PV_ELTS: SyscallInstrs (in the recorded shard) reads commit / exit-code words
 SMALL = {"Add": 5, "Addi": 7, "Sub": 3, "Bitwise": 6, "Lt": 6, "Mul": 6, "ShiftLeft": 6, "ShiftRight": 8, "Addw": 3, "Subw": 3,
          "UType": 12, "LoadByte": 14, "LoadHalf": 5, "LoadWord": 5, "LoadDouble": 5, "StoreByte": 10, "StoreHalf": 5,
          "StoreWord": 5, "StoreDouble": 5, "Branch": 12, "Jal": 4, "Jalr": 5}
@@ -84,10 +85,10 @@ def test_riscv_shard_bytes_at_1_256_of_the_recorded_shape_match_the_oracle(api):
     g_ch.observe(commit)
     orc.set_gkr_sparse(True)
     try:
-        want = orc.shard_prove(host, np.zeros(0, np.uint32), o_prep, L, lsh, batch, o_ch, 2, 124, 16)
+        want = orc.shard_prove(host, PUBLICS, o_prep, L, lsh, batch, o_ch, 2, 124, 16)
     finally:
         orc.set_gkr_sparse(False)
-    got = api.prove_shard(dev, [], prep, L, lsh, batch, g_ch)
+    got = api.prove_shard(dev, PUBLICS, prep, L, lsh, batch, g_ch)
     assert got == want and np.array_equal(g_ch.state(), o_ch.state())
 
 
@@ -111,10 +112,10 @@ def test_riscv_shard_bytes_at_a_sixteenth_of_the_recorded_shape_match_the_oracle
     g_ch.observe(commit)
     orc.set_gkr_sparse(True)
     try:
-        want = orc.shard_prove(host, np.zeros(0, np.uint32), o_prep, L, lsh, batch, o_ch, 2, 124, 16)
+        want = orc.shard_prove(host, PUBLICS, o_prep, L, lsh, batch, o_ch, 2, 124, 16)
     finally:
         orc.set_gkr_sparse(False)
-    got = api.prove_shard(dev, [], prep, L, lsh, batch, g_ch)
+    got = api.prove_shard(dev, PUBLICS, prep, L, lsh, batch, g_ch)
     assert got == want and np.array_equal(g_ch.state(), o_ch.state())
 
 
@@ -131,7 +132,7 @@ def test_riscv_shard_at_a_sixty_fourth_of_the_recorded_shape_verifies(api):
     ch, v = api.DuplexChallenger(), orc.Challenger()
     ch.observe(commit)
     v.observe(commit)
-    proof = api.prove_shard(chips, [], prep, L, lsh, 32, ch)
+    proof = api.prove_shard(chips, PUBLICS, prep, L, lsh, 32, ch)
     shapes = _shapes_only([(a, i) for a, i, _, _ in chips])
     assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) == 0
     assert np.array_equal(v.state(), ch.state())
@@ -145,7 +146,7 @@ def test_riscv_shard_at_a_sixty_fourth_of_the_recorded_shape_verifies(api):
     ch, v = api.DuplexChallenger(), orc.Challenger()
     ch.observe(commit)
     v.observe(commit)
-    proof = api.prove_shard(chips2, [], prep, L, lsh, 32, ch)
+    proof = api.prove_shard(chips2, PUBLICS, prep, L, lsh, 32, ch)
     assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) != 0
     k = [a.name for a, _, _, _ in chips].index("Global")
     a, i, m, p = chips[k]
@@ -156,7 +157,7 @@ def test_riscv_shard_at_a_sixty_fourth_of_the_recorded_shape_verifies(api):
     ch, v = api.DuplexChallenger(), orc.Challenger()
     ch.observe(commit)
     v.observe(commit)
-    proof = api.prove_shard(chips3, [], prep, L, lsh, 32, ch)
+    proof = api.prove_shard(chips3, PUBLICS, prep, L, lsh, 32, ch)
     assert orc.shard_verify(shapes, commit, proof, L, lsh, v, 2, 124, 16) != 0
 
 
