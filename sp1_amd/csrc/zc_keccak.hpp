@@ -40,6 +40,9 @@ template <class F> KB_HD typename F::T zc_kk_bool(const typename F::T& a) { retu
 template <class F, class Load, class Sink>
 KB_HD void zc_keccak_piece(uint32_t q, Load&& ld, Sink&& sink) {
     using T = typename F::T;
+    // bits of a limb in flight per lane: two for one-word values; one for extension values and 4-node vectors (4 words each: a
+    // second bit costs ~60 VGPRs = a wave per SIMD, and the pieces are latency-bound: occupancy buys more than ILP)
+    constexpr int KK_UNROLL = sizeof(T) > 4 ? 1 : 2;
     // rotation offsets r[x][y] (FIPS 202 section 3.2.2) and the round constants
     constexpr uint8_t R[25] = {0, 36, 3, 41, 18, 1, 44, 10, 45, 2, 62, 6, 43, 15, 61, 28, 55, 25, 21, 56, 27, 20, 39, 8, 14};
     constexpr uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,
@@ -94,7 +97,7 @@ KB_HD void zc_keccak_piece(uint32_t q, Load&& ld, Sink&& sink) {
 #pragma unroll 1
         for (uint32_t limb = 0; limb < 4; limb++) {
             T acc[5];
-#pragma unroll 2
+#pragma unroll KK_UNROLL
             for (uint32_t k = 0; k < 16; k++) {
                 const uint32_t z = limb * 16 + 15 - k;
                 const T c = ld(KK_C + x * 64 + z, true);
@@ -132,7 +135,7 @@ KB_HD void zc_keccak_piece(uint32_t q, Load&& ld, Sink&& sink) {
 #pragma unroll 1
         for (uint32_t limb = 0; limb < 4; limb++) {
             T acc[5];
-#pragma unroll 2
+#pragma unroll KK_UNROLL
             for (uint32_t k = 0; k < 16; k++) {
                 const uint32_t z = limb * 16 + 15 - k;
                 T bv[5];
