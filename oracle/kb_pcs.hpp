@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "kb_hash.hpp"
+#include "kb_simd.hpp"
 
 namespace orc {
 
@@ -45,6 +46,7 @@ static inline void rs_encode(const F* in, int log_n, int w, int log_blowup, F* o
         for (size_t i = 0; i < N / 2; i++) { tw[i] = cur; cur *= g; }
     }
     // decimation-in-frequency: natural order in, bit-reversed order out
+    const bool use_simd = simd::simd_available();
     for (int s = log_N; s >= 1; s--) {
         const size_t half = (size_t)1 << (s - 1), stride = N >> s;
 #pragma omp parallel for schedule(static)
@@ -53,6 +55,7 @@ static inline void rs_encode(const F* in, int log_n, int w, int log_blowup, F* o
             F* a = out + (blk * 2 * half + j) * w;
             F* b = a + half * w;
             F t = tw[j * stride];
+            if (use_simd && w >= 16) { simd::butterfly_row(a, b, t, w); continue; }
             for (int c = 0; c < w; c++) {
                 F x = a[c], y = b[c];
                 a[c] = x + y;
@@ -85,19 +88,32 @@ static inline MerkleTree merkle_commit(const std::vector<TensorRef>& ts) {
     mt.log_height = 0;
     while (((size_t)1 << mt.log_height) < h) mt.log_height++;
     std::vector<Digest> cur(h);
+    const bool use_simd = simd::simd_available();
+    if (use_simd && h >= 16) {                               // sixteen rows per permutation (kb_simd.hpp)
+        std::vector<simd::RowSrc> src;
+        for (auto& t : ts) src.push_back(simd::RowSrc{t.data, t.width});
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < h; i++) {
-        Sponge sp;
-        for (auto& t : ts)
-            for (int c = 0; c < t.width; c++) sp.absorb(t.data[i * t.width + c]);
-        cur[i] = sp.finish();
+        for (size_t i = 0; i < h; i += 16) simd::hash_rows16(src.data(), src.size(), i, cur.data() + i);
+    } else {
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < h; i++) {
+            Sponge sp;
+            for (auto& t : ts)
+                for (int c = 0; c < t.width; c++) sp.absorb(t.data[i * t.width + c]);
+            cur[i] = sp.finish();
+        }
     }
     mt.layers.push_back(cur);
     while (mt.layers.back().size() > 1) {
         const std::vector<Digest>& prev = mt.layers.back();
         std::vector<Digest> next(prev.size() / 2);
+        if (use_simd && next.size() >= 16) {
 #pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < next.size(); i++) next[i] = compress(prev[2 * i], prev[2 * i + 1]);
+            for (size_t i = 0; i < next.size(); i += 16) simd::compress16(prev.data(), i, next.data());
+        } else {
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < next.size(); i++) next[i] = compress(prev[2 * i], prev[2 * i + 1]);
+        }
         mt.layers.push_back(std::move(next));
     }
     mt.root = mt.layers.back()[0];
