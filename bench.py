@@ -730,16 +730,18 @@ def main():
             "gkr_transition": (["gkr_transition"], 52 * meta["first_layer_entries"]),
             "jagged_fold": (["jagged_round0_sum", "jagged_fold0_sum", "jagged_fold_sum"], 28 * area),
         }
-        # PMC table of THIS round (bench/pmc_traffic.sh -> profiles/r04_traffic.json): HBM bytes and SQ_INSTS_VALU per proof
-        # for every kernel group; the roofline fractions below are (table or live value) / (live time) / peak, nothing else
+        # PMC table of THIS round (bench/pmc_traffic.sh -> profiles/r05_traffic.json, r05_traffic_precompile.json): HBM bytes and
+        # SQ_INSTS_VALU per proof for every kernel group; the roofline fractions below are (table or live value) / (live time) / peak
         pmc, pmc_note = {}, "no committed PMC table for this workload"
-        try:
-            with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as f:
-                tt = json.load(f)
-            if k == 0 and tt.get("workload") == kind:
-                pmc, pmc_note = tt["kernels"], tt["source"]
-        except (OSError, ValueError, KeyError):
-            pass
+        for fn in ("r05_traffic.json", "r05_traffic_precompile.json", "r04_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    tt = json.load(f)
+                if k == 0 and tt.get("workload") == kind:
+                    pmc, pmc_note = tt["kernels"], tt["source"] + " [profiles/%s]" % fn
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         stages = {}
         for g, (tn, alg_bytes) in groups.items():
             g_ms = sum(ms.get(n, 0.0) for n in tn)

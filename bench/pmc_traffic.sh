@@ -6,8 +6,9 @@
 # KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads (x 2), WRITE_SIZE is exact (x 1).
 # A third pass collects SQ_INSTS_VALU (wave-level VALU instructions; x 64 = lane-instructions) and SQ_INSTS_SALU per kernel: the
 # numerators of bench.py's VALU roofline fractions (from THIS round's counters, not a constant).
-# usage: bench/pmc_traffic.sh <out.json>      (writes the table bench.py reads: profiles/r04_traffic.json)
+# usage: bench/pmc_traffic.sh <out.json> [real|precompile]     (writes the table bench.py reads: profiles/r05_traffic[_precompile].json)
 out=$1
+export SP1HIP_PMC_WORKLOAD=${2:-real}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_v
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python $GRAFT_REPO_ROOT/bench/profile_bench_pmc.py > /dev/null 2>&1
@@ -40,7 +41,7 @@ write_scale = cal_bytes / (w[cal] * 1024.0)          # expected 1.0
 groups = {   # bench.py's kernel names -> substrings of the HIP kernel names
     "leaf_hash": ["leaf_hash_part_kernel", "leaf_hash_kernel"],
     "rs_encode": ["ntt_fast_pass"],
-    "zerocheck_round": ["zc_round_kernel", "zc_macro_kernel", "zc_biv_round_kernel", "zc_biv_macro_kernel"],
+    "zerocheck_round": ["zc_round_kernel", "zc_macro_kernel", "zc_biv_round_kernel", "zc_biv_macro_kernel", "zc_biv_keccak_kernel"],
     "zerocheck_fix": ["zc_fix_kernel", "zc_fix2_kernel"],
     "gkr_pass": ["gkr_pass"],
     "compress": ["compress_layer", "compress_top"],
@@ -70,9 +71,10 @@ kernels["all_kernels"] = {"launches_per_proof": sum(fc[k] for k in own),
                           "valu_lane_insts_per_proof": 64.0 * sum(valu.get(k, 0.0) for k in own),
                           "salu_insts_per_proof": sum(salu.get(k, 0.0) for k in own)}
 kernels["all_kernels"]["hbm_bytes_per_launch"] = kernels["all_kernels"]["hbm_bytes_per_proof"] / max(1, kernels["all_kernels"]["launches_per_proof"])
-json.dump({"workload": "real",
+import os
+json.dump({"workload": os.environ.get("SP1HIP_PMC_WORKLOAD", "real"),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU SQ_INSTS_SALU, three separate passes over one proof of the "
-                     "real-chip core shard (bench/pmc_traffic.sh -> profiles/r04_traffic.json); KiB units, FETCH x 2 (gfx950: 64 B "
+                     "bench workload named in `workload` (bench/pmc_traffic.sh -> profiles/r05_traffic*.json); KiB units, FETCH x 2 (gfx950: 64 B "
                      "tallied per 128 B request), WRITE x 1; SQ_INSTS_VALU counts wave instructions (x 64 lanes)",
            "calibration": {"kernel": "monty_convert_kernel, 2^28 words each way", "fetch_scale_measured": fetch_scale,
                            "write_scale_measured": write_scale},

@@ -9,5 +9,5 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["SP1HIP_BENCH_PMC_MARK"] = "1"
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-extras", "--no-verify"]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-extras", "--no-verify", "--workload", os.environ.get("SP1HIP_PMC_WORKLOAD", "real")]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
