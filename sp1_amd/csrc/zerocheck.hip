@@ -651,6 +651,83 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
     }
 }
 
+// The Keccak pieces in the extension rounds, the THREE nodes of a row pair per pass (SP1HIP_ZC_KECCAK3, default on): the pieces are
+// bound by the bandwidth of their column loads, and one node per workgroup reads both rows of every column three times. Here a
+// lane loads the two rows once and carries the values at t = 0, 2, 4 through the piece (element-wise arithmetic on three extension
+// values: 12 VGPRs per live value). blockIdx.x = block; partial slots of the three nodes as the per-node kernels write them.
+struct E3 { kb::Ext n[3]; };
+struct P2Ext3 {
+    using T = E3;
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return T{{kb::ext_add(a.n[0], b.n[0]), kb::ext_add(a.n[1], b.n[1]), kb::ext_add(a.n[2], b.n[2])}}; }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return T{{kb::ext_sub(a.n[0], b.n[0]), kb::ext_sub(a.n[1], b.n[1]), kb::ext_sub(a.n[2], b.n[2])}}; }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return T{{kb::ext_mul(a.n[0], b.n[0]), kb::ext_mul(a.n[1], b.n[1]), kb::ext_mul(a.n[2], b.n[2])}}; }
+    static __device__ __forceinline__ T addc(T a, uint32_t c) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) a.n[k].c[0] = kb::add(a.n[k].c[0], c);
+        return a;
+    }
+    static __device__ __forceinline__ T mulc(const T& a, uint32_t c) { return T{{kb::ext_mul_base(a.n[0], c), kb::ext_mul_base(a.n[1], c), kb::ext_mul_base(a.n[2], c)}}; }
+};
+__global__ __launch_bounds__(256) void zc_keccak3_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                         uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base) {
+    using K = KT<false>;
+    __shared__ uint32_t red[4][24];
+    const uint32_t bid = block_base + blockIdx.x;
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const uint32_t q = (d.flags >> 8) & 15u, base_col = d.pad;
+    const uint32_t terms = (d.rows + 1) / 2;
+    kb::Ext sa[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()}, sb[2] = {kb::ext_zero(), kb::ext_zero()};
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < terms; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, terms); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        kb::Ext va[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()}, vb[2] = {kb::ext_zero(), kb::ext_zero()};
+        const bool odd = 2 * i + 1 < d.rows;
+        auto ld = [&](uint32_t c, bool owned) -> E3 {
+            const uint32_t col = base_col + c;
+            const kb::Ext r0 = K::load(d.main, col, d.rows, 2 * i);
+            const kb::Ext r1 = odd ? K::load(d.main, col, d.rows, 2 * i + 1) : kb::ext_zero();
+            const kb::Ext slope = kb::ext_sub(r1, r0), s2 = kb::ext_add(slope, slope);
+            E3 v;
+            v.n[0] = r0;
+            v.n[1] = kb::ext_add(s2, r0);
+            v.n[2] = kb::ext_add(kb::ext_add(s2, s2), r0);
+            if (owned) {                                   // the GKR-opening batching term at nodes 0 and 2 (g(4) = 2 g(2) - g(0))
+                const kb::Ext pw = load_ext_aos(d.gkr_pows, col);
+                vb[0] = kb::ext_add(vb[0], kb::ext_mul(v.n[0], pw));
+                vb[1] = kb::ext_add(vb[1], kb::ext_mul(v.n[1], pw));
+            }
+            return v;
+        };
+        auto sink = [&](uint32_t j, const E3& v) {
+            const kb::Ext a = load_ext_aos(d.alpha_pows, d.alpha_off + j);
+#pragma unroll
+            for (int n = 0; n < 3; n++) va[n] = kb::ext_add(va[n], kb::ext_mul(v.n[n], a));
+        };
+        zc_keccak_piece<P2Ext3>(q, ld, sink);
+#pragma unroll
+        for (int n = 0; n < 3; n++) sa[n] = kb::ext_add(sa[n], kb::ext_mul(va[n], e));
+#pragma unroll
+        for (int n = 0; n < 2; n++) sb[n] = kb::ext_add(sb[n], kb::ext_mul(vb[n], e));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // words: pass p -> [A_p (4) | B_p (4)], B_2 = 0
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t w = k < 4 ? sa[p].c[k] : (p < 2 ? sb[p].c[k - 4] : 0u);
+            const uint32_t v = zc_wave_sum(w);
+            if (lane == 0) red[wave][p * 8 + k] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        const uint32_t w = threadIdx.x;
+        partial[(size_t)bid * 24 + w] = kb::add(kb::add(red[0][w], red[1][w]), kb::add(red[2][w], red[3][w]));
+    }
+}
+
 // The Keccak pieces on the bivariate grid, FOUR nodes per pass (node group g = nodes 4 g .. 4 g + 3, like the interpreter's KT4
 // passes): the pieces are bound by the bandwidth their column loads draw from the caches, and one node per workgroup reads the
 // four rows of every column twelve times. Here the rows are loaded once per group and interpolated to the group's four nodes; the
@@ -2390,7 +2467,13 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_MACRO_LAUNCH(1u)
                 SP1HIP_ZC_MACRO_LAUNCH(2u)
                 SP1HIP_ZC_MACRO_LAUNCH(3u)
-                SP1HIP_ZC_MACRO_LAUNCH(5u)
+                if (ln.kind == (int)ZC_HINT_KECCAK) {
+                    const bool keccak3 = [] { const char* e = getenv("SP1HIP_ZC_KECCAK3"); return !(e && e[0] == '0'); }();   // (read per call: tests run both)
+                    if (r == 0) hipLaunchKernelGGL((zc_macro_kernel<true, 5u>), dim3(macro_n[5] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5], dctx->d_rc);
+                    else if (keccak3) hipLaunchKernelGGL(zc_keccak3_kernel, dim3(macro_n[5]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5]);
+                    else hipLaunchKernelGGL((zc_macro_kernel<false, 5u>), dim3(macro_n[5] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5], dctx->d_rc);
+                    SP1HIP_LAUNCH_CHECK();
+                }
 #undef SP1HIP_ZC_MACRO_LAUNCH
                 if (ln.kind == (int)ZC_MACRO_BOTH_SEPTIC) {          // (never round 0: that round is far above the small-round bound)
                     hipLaunchKernelGGL((zc_macro_kernel<false, ZC_MACRO_BOTH_SEPTIC>), dim3((macro_n[2] + macro_n[3]) * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[2], dctx->d_rc);
