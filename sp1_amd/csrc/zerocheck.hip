@@ -651,10 +651,12 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
     }
 }
 
-// The Keccak pieces in the extension rounds, the THREE nodes of a row pair per pass (SP1HIP_ZC_KECCAK3, default on): the pieces are
+// The Keccak pieces in the extension rounds, the THREE nodes of a row pair per pass (SP1HIP_ZC_KECCAK3=1; off by default, see below): the pieces are
 // bound by the bandwidth of their column loads, and one node per workgroup reads both rows of every column three times. Here a
 // lane loads the two rows once and carries the values at t = 0, 2, 4 through the piece (element-wise arithmetic on three extension
 // values: 12 VGPRs per live value). blockIdx.x = block; partial slots of the three nodes as the per-node kernels write them.
+// Measured (round 5, precompile shard): 250 VGPRs, two waves per SIMD, zerocheck rounds 31.0 ms against 22.0 ms for one node per
+// workgroup -- the saved loads do not pay for the lost occupancy, so the per-node kernels stay the default.
 struct E3 { kb::Ext n[3]; };
 struct P2Ext3 {
     using T = E3;
@@ -2468,7 +2470,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_MACRO_LAUNCH(2u)
                 SP1HIP_ZC_MACRO_LAUNCH(3u)
                 if (ln.kind == (int)ZC_HINT_KECCAK) {
-                    const bool keccak3 = [] { const char* e = getenv("SP1HIP_ZC_KECCAK3"); return !(e && e[0] == '0'); }();   // (read per call: tests run both)
+                    const bool keccak3 = [] { const char* e = getenv("SP1HIP_ZC_KECCAK3"); return e && e[0] == '1'; }();   // (read per call: tests run both)
                     if (r == 0) hipLaunchKernelGGL((zc_macro_kernel<true, 5u>), dim3(macro_n[5] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5], dctx->d_rc);
                     else if (keccak3) hipLaunchKernelGGL(zc_keccak3_kernel, dim3(macro_n[5]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5]);
                     else hipLaunchKernelGGL((zc_macro_kernel<false, 5u>), dim3(macro_n[5] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5], dctx->d_rc);

@@ -65,7 +65,7 @@ def test_core_shard_with_divrem_and_ecalls_matches_oracle(api):
 
 
 @pytest.mark.parametrize("n_events,env", [(2, {}), (12, {}), (12, {"SP1HIP_ZC_BIVARIATE": "0"}), (12, {"SP1HIP_ZC_MACRO": "0"}),
-                                          (12, {"SP1HIP_ZC_KECCAK3": "0"}), (12, {"SP1HIP_ZC_KECCAK3": "0", "SP1HIP_ZC_BIVARIATE": "0"})])
+                                          (12, {"SP1HIP_ZC_KECCAK3": "1"}), (12, {"SP1HIP_ZC_KECCAK3": "1", "SP1HIP_ZC_BIVARIATE": "0"})])
 def test_keccak_precompile_shard_matches_oracle(api, monkeypatch, n_events, env):
     """The wide chip through every zerocheck path: 48 / 288 rows of 2,640 columns (288 rows = the multi-block forms of the round
     kernels), sequential rounds, hints ignored."""
