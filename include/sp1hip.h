@@ -469,6 +469,52 @@ int sp1hip_tracegen_recursion_poseidon2_wide(uint32_t* d_trace, uint64_t height,
 int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
                                  sp1hip_stream_t stream);
 
+/* ---------------------------------------------------------------- guest execution (host code, no device work)
+ * An rv64im executor for SP1 guest ELFs: what `MinimalExecutor` + `TracingVM` do for the core prover
+ * (/root/reference/crates/core/executor/src/minimal.rs, tracing.rs:L57-L147, vm.rs:L139-L431; the controller's shard loop is
+ * /root/reference/crates/prover/src/worker/controller/core.rs:L231). It runs the program one shard of at most `max_cycles`
+ * instructions at a time and hands back the events the chips' trace generation starts from:
+ *   events        [n_events][SP1HIP_RV64_EVENT_WORDS] u64 per executed instruction: pc, clk, opcode (the reference's `Opcode`
+ *                 discriminant), op_a, op_b, op_c, flags (1 imm_b | 2 imm_c | 4 memory access), a, b, c, previous value of op_a,
+ *                 previous timestamps of the op_a / op_b / op_c register accesses, memory address, previous timestamp and value of
+ *                 the memory word, its new value, next pc, one spare word
+ *   local memory  [n_local][5] u64 per address touched in the shard (registers are addresses 0..31): address, timestamp and
+ *                 value before the shard's first access, timestamp and value after its last (`MemoryLocalEvent`,
+ *                 events/memory.rs)
+ *   keccak        [n_keccak][SP1HIP_RV64_KECCAK_WORDS] u64 per KECCAK_PERMUTE call: clk, state pointer, 25 x (previous timestamp,
+ *                 word read), the 25 words written
+ * After the program halts, sp1hip_rv64_global_memory lists every address the run touched as (address, initial value, final value,
+ * final timestamp): the `MemoryGlobalInit` / `MemoryGlobalFinalize` events. Supervisor mode only; system calls: HALT, WRITE,
+ * ENTER / EXIT_UNCONSTRAINED, COMMIT, COMMIT_DEFERRED_PROOFS, HINT_LEN, HINT_READ, KECCAK_PERMUTE (any other stops the run with
+ * SP1HIP_ERROR_RUNTIME and a message naming it). The pointers stay valid until the next call on the same handle. */
+#define SP1HIP_RV64_EVENT_WORDS 20
+#define SP1HIP_RV64_KECCAK_WORDS 77
+typedef void* sp1hip_rv64_vm_t;
+typedef struct {
+    uint64_t shard;                      /* index of this shard in the run */
+    uint64_t n_events, n_local, n_keccak;
+    uint64_t pc_start, next_pc;          /* `PublicValues::pc_start / next_pc` (HALT_PC = 1 after HALT) */
+    uint64_t clk_start, clk_end;         /* `initial_timestamp / last_timestamp` */
+    uint32_t halted, exit_code;
+    uint32_t commit_syscall, commit_deferred_syscall;
+    uint32_t committed_value_digest[8];  /* as set by COMMIT so far */
+    uint32_t deferred_proofs_digest[8];
+} sp1hip_rv64_shard_info;
+int sp1hip_rv64_create(const uint8_t* elf, uint64_t elf_len, sp1hip_rv64_vm_t* out);
+void sp1hip_rv64_destroy(sp1hip_rv64_vm_t vm);
+/* One entry of the input stream (`SP1Stdin::write_slice`): what the guest's next HINT_LEN / HINT_READ pair consumes. */
+int sp1hip_rv64_write_stdin(sp1hip_rv64_vm_t vm, const uint8_t* data, uint64_t len);
+int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t vm, uint64_t max_cycles, sp1hip_rv64_shard_info* info);
+const uint64_t* sp1hip_rv64_events(sp1hip_rv64_vm_t vm);
+const uint64_t* sp1hip_rv64_local_memory(sp1hip_rv64_vm_t vm);
+const uint64_t* sp1hip_rv64_keccak_events(sp1hip_rv64_vm_t vm);
+/* The transpiled program (`Program::instructions`): [n][6] u64 = opcode, op_a, op_b, op_c, imm_b, imm_c; instruction i sits at
+ * pc_base + 4 i. */
+int sp1hip_rv64_program(sp1hip_rv64_vm_t vm, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table);
+int sp1hip_rv64_global_memory(sp1hip_rv64_vm_t vm, uint64_t* n, const uint64_t** table);
+/* which = 0: the bytes written to the public-values descriptor; 1: stdout / stderr. */
+int sp1hip_rv64_output(sp1hip_rv64_vm_t vm, int which, const uint8_t** data, uint64_t* len);
+
 /* ---------------------------------------------------------------- the AirProver slot: setup / proving key
  * `MachineVerifyingKey` (/root/reference/crates/hypercube/src/verifier/config.rs:L71-L81), Montgomery words. The
  * septic digest is x[7] then y[7]. */

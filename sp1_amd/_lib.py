@@ -69,6 +69,14 @@ class ShardParams(C.Structure):
                 ("fri", FriConfig)]
 
 
+class Rv64ShardInfo(C.Structure):
+    _fields_ = [("shard", C.c_uint64), ("n_events", C.c_uint64), ("n_local", C.c_uint64), ("n_keccak", C.c_uint64),
+                ("pc_start", C.c_uint64), ("next_pc", C.c_uint64), ("clk_start", C.c_uint64), ("clk_end", C.c_uint64),
+                ("halted", C.c_uint32), ("exit_code", C.c_uint32), ("commit_syscall", C.c_uint32),
+                ("commit_deferred_syscall", C.c_uint32), ("committed_value_digest", C.c_uint32 * 8),
+                ("deferred_proofs_digest", C.c_uint32 * 8)]
+
+
 class Vk(C.Structure):
     _fields_ = [("pc_start", C.c_uint32 * 3), ("initial_global_cumulative_sum", C.c_uint32 * 14),
                 ("preprocessed_commit", C.c_uint32 * 8), ("enable_untrusted_programs", C.c_uint32)]
@@ -184,6 +192,16 @@ PROTOTYPES = [
     ("sp1hip_tracegen_recursion_prefix_sum_checks", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_tracegen_recursion_poseidon2_wide", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_tracegen_riscv_global", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_rv64_create", None, [u8p, C.c_uint64, C.POINTER(_vp)]),
+    ("sp1hip_rv64_destroy", "void", [_vp]),
+    ("sp1hip_rv64_write_stdin", None, [_vp, u8p, C.c_uint64]),
+    ("sp1hip_rv64_run_shard", None, [_vp, C.c_uint64, C.POINTER(Rv64ShardInfo)]),
+    ("sp1hip_rv64_events", C.POINTER(C.c_uint64), [_vp]),
+    ("sp1hip_rv64_local_memory", C.POINTER(C.c_uint64), [_vp]),
+    ("sp1hip_rv64_keccak_events", C.POINTER(C.c_uint64), [_vp]),
+    ("sp1hip_rv64_program", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
+    ("sp1hip_rv64_global_memory", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
+    ("sp1hip_rv64_output", None, [_vp, _int, C.POINTER(u8p), C.POINTER(C.c_uint64)]),
     ("sp1hip_setup", None, [C.POINTER(Table), _int, u32p, u32p, C.c_uint32, ShardParams, C.POINTER(_vp), _vp]),
     ("sp1hip_pk_free", "void", [_vp]),
     ("sp1hip_pk_vk", None, [_vp, C.POINTER(Vk)]),

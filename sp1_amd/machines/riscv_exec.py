@@ -1,0 +1,355 @@
+"""Real guest programs: the rv64im executor of libsp1hip.so (sp1_amd/csrc/rv64_exec.cpp) and, from its events, the tables of
+every chip of a core shard — what `MinimalExecutor` + `TracingVM` + the chips' `generate_trace_into` do in the reference
+(/root/reference/crates/core/executor/src/{minimal,tracing,vm}.rs; crates/core/machine/src/**/trace.rs as cited in
+riscv_trace.py, whose column fillers this module drives with executed events instead of the synthetic loop body).
+
+    ex = Executor(open(elf, "rb").read(), stdin=[n.to_bytes(4, "little")])
+    for shard in ex.shards(max_cycles=1 << 21):               # ExecutedShard: events, local memory, public values
+        machine, tables, publics = shard_tables(ex, shard, device)   # every chip's (prep, main), ready for api.prove_shard
+
+The proof statement per shard is the reference's: the chips' constraints hold on every row, the Byte / Range / Program / Memory
+/ State buses balance inside the shard, and what crosses shards (memory states, syscalls) goes through the Global chip's digest.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+
+EV_WORDS, KECCAK_WORDS = 20, 77
+(E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
+ E_NEXT_PC, E_SPARE) = range(EV_WORDS)
+
+
+class ExecutedShard:
+    """One shard of an execution: `events` [n, 20] / `local` [m, 5] / `keccak` [k, 77] int64 arrays (two's complement images of
+    the executor's u64 words) and the shard's public-value fields."""
+
+    def __init__(self, info, events, local, keccak):
+        self.index = int(info.shard)
+        self.events, self.local, self.keccak = events, local, keccak
+        self.pc_start, self.next_pc = int(info.pc_start), int(info.next_pc)
+        self.clk_start, self.clk_end = int(info.clk_start), int(info.clk_end)
+        self.halted, self.exit_code = bool(info.halted), int(info.exit_code)
+        self.commit_syscall, self.commit_deferred_syscall = int(info.commit_syscall), int(info.commit_deferred_syscall)
+        self.committed_value_digest = [int(x) for x in info.committed_value_digest]
+        self.deferred_proofs_digest = [int(x) for x in info.deferred_proofs_digest]
+
+    @property
+    def cycles(self):
+        return self.events.shape[0]
+
+
+class Executor:
+    def __init__(self, elf, stdin=()):
+        self.lib = _lib.load()
+        buf = (C.c_uint8 * len(elf)).from_buffer_copy(elf)
+        h = C.c_void_p()
+        _lib.check(self.lib.sp1hip_rv64_create(buf, len(elf), C.byref(h)))
+        self.h = h
+        for entry in stdin:
+            self.write_stdin(entry)
+        self.halted = False
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.sp1hip_rv64_destroy(self.h)
+            self.h = None
+
+    def write_stdin(self, data):
+        data = bytes(data)
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        _lib.check(self.lib.sp1hip_rv64_write_stdin(self.h, buf, len(data)))
+
+    @staticmethod
+    def _matrix(ptr, rows, cols):
+        if rows == 0:
+            return np.zeros((0, cols), dtype=np.int64)
+        return np.ctypeslib.as_array(ptr, shape=(rows * cols,)).view(np.int64).reshape(rows, cols).copy()
+
+    def run_shard(self, max_cycles):
+        info = _lib.Rv64ShardInfo()
+        _lib.check(self.lib.sp1hip_rv64_run_shard(self.h, int(max_cycles), C.byref(info)))
+        shard = ExecutedShard(info, self._matrix(self.lib.sp1hip_rv64_events(self.h), info.n_events, EV_WORDS),
+                              self._matrix(self.lib.sp1hip_rv64_local_memory(self.h), info.n_local, 5),
+                              self._matrix(self.lib.sp1hip_rv64_keccak_events(self.h), info.n_keccak, KECCAK_WORDS))
+        self.halted = shard.halted
+        return shard
+
+    def shards(self, max_cycles):
+        while not self.halted:
+            yield self.run_shard(max_cycles)
+
+    def program(self):
+        """(pc_base, [n, 6] int64: opcode, op_a, op_b, op_c, imm_b, imm_c)."""
+        base, n, tab = C.c_uint64(), C.c_uint64(), C.POINTER(C.c_uint64)()
+        _lib.check(self.lib.sp1hip_rv64_program(self.h, C.byref(base), C.byref(n), C.byref(tab)))
+        return int(base.value), self._matrix(tab, n.value, 6)
+
+    def global_memory(self):
+        """[t, 4] int64 per address the run touched: address, initial value, final value, final timestamp."""
+        n, tab = C.c_uint64(), C.POINTER(C.c_uint64)()
+        _lib.check(self.lib.sp1hip_rv64_global_memory(self.h, C.byref(n), C.byref(tab)))
+        return self._matrix(tab, n.value, 4)
+
+    def output(self, which=0):
+        p, n = _lib.u8p(), C.c_uint64()
+        _lib.check(self.lib.sp1hip_rv64_output(self.h, which, C.byref(p), C.byref(n)))
+        return bytes(np.ctypeslib.as_array(p, shape=(n.value,))) if n.value else b""
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# events -> tables
+import types
+
+import torch
+
+from . import riscv as R
+from . import riscv_trace as RT
+from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, bytes8, finv, limbs16
+
+_OPN = {v: k for k, v in OPC.items()}
+_ALU_CHIP = {}
+for _chip, _ops in RT.ALU_KINDS.items():
+    for _o in _ops:
+        _ALU_CHIP[OPC[_o]] = _chip
+_MEM_CHIP = {"LB": "LoadByte", "LBU": "LoadByte", "LH": "LoadHalf", "LHU": "LoadHalf", "LW": "LoadWord", "LWU": "LoadWord", "LD": "LoadDouble",
+             "SB": "StoreByte", "SH": "StoreHalf", "SW": "StoreWord", "SD": "StoreDouble"}
+PV_WORDS = 160
+# PublicValues<[T; 4], [T; 3], [T; 4], T> word offsets (hypercube/src/air/public_values.rs:L33-L168, `mprotect` off)
+PV = dict(prev_committed_value_digest=0, committed_value_digest=32, prev_deferred_proofs_digest=64, deferred_proofs_digest=72, pc_start=80,
+          next_pc=83, prev_exit_code=86, exit_code=87, is_execution_shard=88, previous_init_addr=89, last_init_addr=92,
+          previous_finalize_addr=95, last_finalize_addr=98, initial_timestamp=113, last_timestamp=117, is_timestamp_high_eq=121,
+          inv_timestamp_high=122, is_timestamp_low_eq=123, inv_timestamp_low=124, global_init_count=125, global_finalize_count=126,
+          global_count=129, global_cumulative_sum=130, prev_commit_syscall=144, commit_syscall=145, prev_commit_deferred_syscall=146,
+          commit_deferred_syscall=147, initial_timestamp_inv=148, last_timestamp_inv=149, is_first_execution_shard=150)
+
+
+def chip_of_events(ev):
+    """The table every executed instruction goes to (tracing.rs: emit_alu_event L1153-L1228, emit_mem_instr_event L1096-L1150)."""
+    op, rd = ev[:, E_OP], ev[:, E_OPA]
+    names = np.empty(len(op), dtype=object)
+    for o in np.unique(op):
+        nm = _OPN[int(o)]
+        m = op == o
+        if o <= OPC["REMUW"]:
+            names[m & (rd != 0)] = _ALU_CHIP[int(o)]
+            names[m & (rd == 0)] = "AluX0"
+        elif nm in _MEM_CHIP:
+            names[m] = _MEM_CHIP[nm]
+            if nm.startswith("L"):
+                names[m & (rd == 0)] = "LoadX0"
+        elif nm in RT.BRANCH_OPS:
+            names[m] = "Branch"
+        else:
+            names[m] = {"JAL": "Jal", "JALR": "Jalr", "AUIPC": "UType", "LUI": "UType", "ECALL": "SyscallInstrs"}[nm]
+    return names
+
+
+class EventView:
+    """An `ExecutedShard` behind the interface riscv_trace.Tracer's column fillers read an execution through: one "iteration"
+    (K = 1) whose positions are the shard's executed instructions."""
+    K = 1
+
+    def __init__(self, shard, pc_base, device):
+        self.dev = torch.device(device)
+        ev = torch.as_tensor(shard.events, device=self.dev)
+        self.ev, self.L, self.clk0 = ev, ev.shape[0], shard.clk_start
+        self.op = ev[:, E_OP]
+        imm_b, imm_c = (ev[:, E_FLAGS] & 1) == 1, (ev[:, E_FLAGS] & 2) == 2
+        self.has_imm = imm_c
+        self.imm = torch.where(self.op == OPC["JAL"], ev[:, E_OPB], ev[:, E_OPC])
+        neg = torch.full_like(self.op, -1)
+        self.slot_reg = {"A": ev[:, E_OPA], "B": torch.where(imm_b, neg, ev[:, E_OPB]), "C": torch.where(imm_c, neg, ev[:, E_OPC])}
+        self.W = ev[:, E_A][None, :]
+        self.values = {"A": ev[:, E_A_PREV], "B": ev[:, E_B], "C": ev[:, E_C]}
+        self.prev_ts = {"A": ev[:, E_A_PTS], "B": ev[:, E_B_PTS], "C": ev[:, E_C_PTS]}
+        self.clk_inc = torch.where(self.op == OPC["ECALL"], 8 + RT.ECALL_EXTRA_CLK, 8)
+        self.body = types.SimpleNamespace(chip=chip_of_events(shard.events), pc_base=pc_base)
+
+    def T(self, k, p):
+        return self.ev[p, E_CLK]
+
+    def pc(self, p):
+        return self.ev[p, E_PC]
+
+    def reg_value(self, k, p, slot):
+        return self.values[slot][p]
+
+    def _grid(self, positions):
+        p = torch.as_tensor(np.asarray(positions, dtype=np.int64), device=self.dev)
+        return torch.zeros_like(p), p
+
+
+class EventTracer(RT.Tracer):
+    """riscv_trace.Tracer over executed events. The per-chip column fillers (adapters, ALU / shift / multiply / divide
+    operations, load / store chips, SyscallInstrs, Global) are the base class's; what changes is where the timeline comes from:
+    previous timestamps and memory states are the executor's records instead of the loop body's static analysis."""
+
+    def __init__(self, executor, shard, device="cpu"):
+        self.pc_base, self.program = executor.program()
+        self.shard = shard
+        super().__init__(EventView(shard, self.pc_base, device))
+        self.real_global = True
+
+    def _prev_ts(self, k, p, slot):
+        return self.ex.prev_ts[slot][p]
+
+    def build(self):
+        def alu_x0(tb, k, p, a, bv, cv):
+            tb.set("opcode", self.ex.op[p])
+            tb.set("is_real", 1)
+        self.simple_alu("AluX0", "ALU", alu_x0)
+        return super().build()
+
+    def branch(self):
+        super().branch()
+        if "Branch" in self.tables:
+            _, p = self.rows_of("Branch")
+            self.tables["Branch"].set("next_pc", limbs16(self.ex.ev[p, E_NEXT_PC])[:, :3])
+
+    def jalr(self):
+        super().jalr()
+        if "Jalr" in self.tables:
+            _, p = self.rows_of("Jalr")
+            tb, rd0 = self.tables["Jalr"], self.ex.slot_reg["A"][p] == 0
+            tb.set("op_a_value", limbs16(self.ex.pc(p) + 4) * (~rd0).to(I64)[:, None])
+
+    def memory_instructions(self):
+        ex, ev = self.ex, self.ex.ev
+        self.mem_words = None
+        for c in list(RT.LOAD_KINDS) + list(RT.STORE_KINDS):
+            k, p = self.rows_of(c)
+            if len(p):
+                self.fill_mem_chip(c, k, p, ev[p, E_MADDR], ev[p, E_CLK] + POS_OFF["M"], ev[p, E_M_PTS], ev[p, E_M_PREV], ev[p, E_M_NEW],
+                                   ex.values["A"][p])
+
+    def state_chain(self):
+        ex, ev, dev = self.ex, self.ex.ev, self.dev
+        T, pc, nxt_pc, inc = ev[:, E_CLK], ev[:, E_PC], ev[:, E_NEXT_PC], ex.clk_inc
+        op = ex.op
+        halt = (op == OPC["ECALL"]) & ((ev[:, E_A_PREV] & 0xFF) == 0)
+        normal_pc = ((op >= OPC["BEQ"]) & (op <= OPC["JALR"])) | halt                    # these rows send next_pc in normal form
+        pc_carry = (~normal_pc) & (((pc & MASK16) + 4) > MASK16)
+        clk_carry = ((T & 0xFFFFFF) + inc) >= (1 << 24)
+        need = pc_carry | clk_carry
+        self.final_state = (self.shard.clk_end, self.shard.next_pc)
+        if bool(need.any()):
+            Tn, pcn, nxt, pcc, incn = T[need], pc[need], nxt_pc[need], pc_carry[need], inc[need]
+            air, _ = R.chip("StateBump")
+            tb = Table(air, len(Tn), dev)
+            self.tables["StateBump"] = tb
+            nT = Tn + incn
+            tb.set("next_clk_32_48", nT >> 32)
+            tb.set("next_clk_24_32", (nT >> 24) & 0xFF)
+            tb.set("next_clk_16_24", (nT >> 16) & 0xFF)
+            tb.set("next_clk_0_16", nT & MASK16)
+            tb.set("clk_high", Tn >> 24)
+            tb.set("clk_low", (Tn & 0xFFFFFF) + incn)
+            tb.set("next_pc", limbs16(nxt)[:, :3])
+            sent = limbs16(pcn)[:, :3].clone()
+            sent[:, 0] += 4
+            tb.set("pc", torch.where(pcc[:, None], sent, limbs16(nxt)[:, :3]))
+            tb.set("is_clk", ((nT >> 24) != (Tn >> 24)).to(I64))
+            tb.set("is_real", 1)
+
+    def memory_local_and_bumps(self):
+        dev = self.dev
+        loc = torch.as_tensor(self.shard.local, device=dev)
+        addr, it, iv, ft, fv = (loc[:, i] for i in range(5))
+        air, _ = R.chip("MemoryLocal")
+        tb = Table(air, len(addr), dev)
+        self.tables["MemoryLocal"] = tb
+        tb.set("addr", limbs16(addr)[:, :3])
+        tb.set("initial_clk_high", it >> 24)
+        tb.set("initial_clk_low", it & 0xFFFFFF)
+        tb.set("final_clk_high", ft >> 24)
+        tb.set("final_clk_low", ft & 0xFFFFFF)
+        for tag, v in (("initial", iv), ("final", fv)):
+            l = limbs16(v)
+            tb.set(tag + "_value", l)
+            tb.set(tag + "_value_lower", l[:, 2] & 0xFF)
+            tb.set(tag + "_value_upper", l[:, 2] >> 8)
+        tb.set("is_real", 1)
+        self._bump_rows()
+
+    def _program_table(self):
+        """Program: one row per instruction of the ELF's text (program/trusted.rs:L80-L131), multiplicity = executions in this shard."""
+        dev, prog = self.dev, torch.as_tensor(self.program, device=self.dev)
+        n = prog.shape[0]
+        air, it = R.chip("Program")
+        tb = Table(air, n, dev)
+        pc = self.pc_base + 4 * torch.arange(n, device=dev)
+        op, a, b_, c_, imm_b, imm_c = (prog[:, i] for i in range(6))
+        tb.prep[:n, 0:3] = limbs16(pc)[:, :3]
+        tb.prep[:n, 3], tb.prep[:n, 4] = op, a
+        regw = lambda r: torch.stack([r] + [torch.zeros_like(r)] * 3, dim=1)
+        tb.prep[:n, 5:9] = torch.where((imm_b == 1)[:, None], limbs16(b_), regw(b_))
+        tb.prep[:n, 9:13] = torch.where((imm_c == 1)[:, None], limbs16(c_), regw(c_))
+        tb.prep[:n, 13] = (a == 0).to(I64)
+        tb.prep[:n, 14], tb.prep[:n, 15] = imm_b, imm_c
+        idx = (self.ex.ev[:, E_PC] - self.pc_base) >> 2
+        tb.main[:n, 0] = torch.bincount(idx, minlength=n)
+        if tb.prep.shape[0] > n:
+            tb.prep[n:] = tb.prep[0]
+        return tb, (air, it)
+
+    def public_values(self, global_sum=None, n_global=0):
+        sh, pv = self.shard, [0] * PV_WORDS
+
+        def put(name, vals):
+            pv[PV[name]:PV[name] + len(vals)] = [int(v) for v in vals]
+        l16 = lambda v, n: [(v >> (16 * i)) & MASK16 for i in range(n)]
+        words = lambda ws: [(w >> (8 * i)) & 0xFF for w in ws for i in range(4)]
+        put("committed_value_digest", words(sh.committed_value_digest))
+        put("deferred_proofs_digest", sh.deferred_proofs_digest)
+        put("pc_start", l16(sh.pc_start, 3))
+        put("next_pc", l16(sh.next_pc, 3))
+        put("exit_code", [sh.exit_code])
+        put("is_execution_shard", [1])
+        put("initial_timestamp", l16(sh.clk_start, 4))
+        put("last_timestamp", l16(sh.clk_end, 4))
+        hi0, hi1, lo0, lo1 = sh.clk_start >> 24, sh.clk_end >> 24, sh.clk_start & 0xFFFFFF, sh.clk_end & 0xFFFFFF
+        put("is_timestamp_high_eq", [int(hi0 == hi1)])
+        put("inv_timestamp_high", [pow((hi1 - hi0) % P, P - 2, P)])
+        put("is_timestamp_low_eq", [int(lo0 == lo1)])
+        put("inv_timestamp_low", [pow((lo1 - lo0) % P, P - 2, P)])
+        put("global_count", [n_global])
+        if global_sum is not None:
+            put("global_cumulative_sum", global_sum)
+        put("commit_syscall", [sh.commit_syscall])
+        put("commit_deferred_syscall", [sh.commit_deferred_syscall])
+        put("is_first_execution_shard", [int(sh.index == 0)])
+        return torch.tensor(pv, dtype=I64)
+
+    def finish(self):
+        ex, dev, sh = self.ex, self.dev, self.shard
+        machine = {name: R.chip(name) for name in self.tables}
+        air, it = RT.boundary_chip()
+        tb = Table(air, 2, dev)
+        t0, t1 = sh.clk_start, sh.clk_end
+        tb.main[0] = torch.tensor([t0 >> 24, t0 & 0xFFFFFF] + [(sh.pc_start >> (16 * i)) & MASK16 for i in range(3)] + [1, 0], device=dev)
+        tb.main[1] = torch.tensor([t1 >> 24, t1 & 0xFFFFFF] + [(sh.next_pc >> (16 * i)) & MASK16 for i in range(3)] + [0, 1], device=dev)
+        self.tables["Boundary"], machine["Boundary"] = tb, (air, it)
+        ml = self.tables["MemoryLocal"]
+        (_, recv, _), (_, send, _) = RT.eval_interactions(R.chip("MemoryLocal")[1], ml.main[:ml.n], None, kinds=(R.GLOBAL,))
+        events = [torch.stack([recv, send], dim=1).reshape(-1, 11)]
+        if "SyscallCore" in self.tables:
+            t_ = self.tables["SyscallCore"]
+            events += [v for _, v, _ in RT.eval_interactions(R.chip("SyscallCore")[1], t_.main[:t_.n], None, kinds=(R.GLOBAL,))]
+        self.global_events = torch.cat(events)
+        self.global_chip(machine, self.global_events)
+        self.tables["Program"], machine["Program"] = self._program_table()
+        self.byte_range_tables(machine)
+        g = self.tables["Global"]
+        cx = g.main[g.n - 1, g.L["accumulation.cumulative_sum_x"]:g.L["accumulation.cumulative_sum_x"] + 7]
+        cy = g.main[g.n - 1, g.L["accumulation.cumulative_sum_y"]:g.L["accumulation.cumulative_sum_y"] + 7]
+        publics = self.public_values(cx.tolist() + cy.tolist(), g.n)
+        names = sorted(machine)
+        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, publics
+
+
+def shard_tables(executor, shard, device="cpu"):
+    """(machine, tables, public values) of one executed shard: machine = [(AirProgram, InteractionProgram)] in chip-name order,
+    tables = {name: (prep, main)} canonical int64 tensors on `device`, public values = the shard's 160 words."""
+    return EventTracer(executor, shard, device).build()

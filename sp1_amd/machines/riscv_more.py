@@ -2,6 +2,7 @@
 riscv.py — DivRem, the syscall chips, global memory initialisation / finalisation, and one precompile with its controller.
 
     chip                  width  constraints  reference eval
+    AluX0                    34       17      alu/alu_x0.rs:L236-L340
     DivRem                  246      348      alu/divrem/mod.rs:L597-L1313
     SyscallCore              10        2      syscall/chip.rs:L299-L420   (shard_kind = Core)
     SyscallPrecompile        10        2      syscall/chip.rs:L299-L420   (shard_kind = Precompile)
@@ -22,8 +23,8 @@ reference makes of it (keccak256/air.rs) are pinned; the field order below is th
 permutes columns, not polynomials.
 """
 from ..air import P
-from .riscv import (ADDRESS_OP, B_LTU, B_RANGE, B_U8RANGE, BYTE, CLK_INC, CPU_STATE, GLOBAL, INV, LT_UNSIGNED, MEM_ACCESS, MEMORY, MUL_OP, OPC,
-                    PC_INC, R_TYPE, S, SYSCALL, U16_TO_U8, _chip, _done, clk_low_of, eval_add, eval_addr_add, eval_compare_u16, eval_cpu_state,
+from .riscv import (ADDRESS_OP, ALU_TYPE, B_LTU, B_RANGE, B_U8RANGE, BYTE, CLK_INC, CPU_STATE, GLOBAL, INV, LT_UNSIGNED, MEM_ACCESS, MEMORY, MUL_OP, OPC,
+                    PC_INC, R_TYPE, S, SYSCALL, U16_TO_U8, _chip, _done, clk_low_of, eval_add, eval_addr_add, eval_alu_type, eval_compare_u16, eval_cpu_state,
                     eval_lt_unsigned, eval_memory_access, eval_msb, eval_mul, eval_r_type, next_pc_inc, send_byte, slice_range_check_u16,
                     slice_range_check_u8, u16_to_u8_safe)
 
@@ -205,6 +206,21 @@ def syscall_instrs_chip():                                                      
     b.when(L.is_halt).assert_zero(L.next_pc[1])
     b.when(L.is_halt).assert_zero(L.next_pc[2])
     b.when(L.is_halt).assert_eq(word_reduce(b, op_b), b.public(PV_EXIT_CODE))
+    return _done(b, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def alu_x0_chip():                                                                        # alu/alu_x0.rs:L236-L340
+    """Every ALU instruction whose destination is x0: the result is discarded, the row only ties the instruction to the program
+    table and performs the register accesses (op_a is 'written' with its previous value, which `op_a_0` forces to zero)."""
+    b, c, _ = _chip("AluX0", 34)
+    L = S(("state", CPU_STATE), ("adapter", ALU_TYPE), ("opcode", 1), ("is_real", 1))(c)
+    b.assert_bool(L.is_real)
+    b.when(L.is_real).assert_one(L.adapter.op_a_0)
+    b.when_not(L.is_real).assert_zero(L.adapter.op_a_0)
+    eval_cpu_state(b, L.state, next_pc_inc(L.state), CLK_INC, L.is_real)
+    send_byte(b, B_LTU, 1, L.opcode, 29, L.is_real)
+    eval_alu_type(b, L.state, L.opcode, L.adapter.op_a_memory.prev_value, L.adapter, L.is_real, L.is_real)
     return _done(b, c)
 
 
@@ -446,14 +462,14 @@ def keccak_control_chip():                                                      
 
 
 MORE_CHIPS = {
-    "DivRem": divrem_chip, "SyscallCore": lambda: syscall_chip("core"), "SyscallPrecompile": lambda: syscall_chip("precompile"),
+    "AluX0": alu_x0_chip, "DivRem": divrem_chip, "SyscallCore": lambda: syscall_chip("core"), "SyscallPrecompile": lambda: syscall_chip("precompile"),
     "SyscallInstrs": syscall_instrs_chip, "MemoryGlobalInit": lambda: memory_global_chip("init"),
     "MemoryGlobalFinalize": lambda: memory_global_chip("finalize"), "KeccakPermute": keccak_permute_chip,
     "KeccakPermuteControl": keccak_control_chip,
 }
 # (columns, constraints) from rv64im_costs.json / rv64im_complexity.json; interactions of the recorded core shard where it has the chip
 MORE_RECORDED = {
-    "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
+    "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
     "MemoryGlobalInit": (30, 31, None), "MemoryGlobalFinalize": (30, 31, None), "KeccakPermute": (2640, 2859, None),
     "KeccakPermuteControl": (634, 331, None),
 }

@@ -644,9 +644,7 @@ class Tracer:
         """RegisterAccessCols for the access in `slot` (memory/consistency/trace.rs:L22-L33, L104-L127). Returns prev value."""
         ex = self.ex
         val = ex.reg_value(k, p, slot)
-        pp, po, wrap = (x[p] for x in ex.prev[slot])
-        kp = k - wrap
-        t_prev = torch.where(kp >= 0, ex.T(kp.clamp(min=0), pp) + po, torch.zeros_like(k))
+        t_prev = self._prev_ts(k, p, slot)
         t_cur = ex.T(k, p) + POS_OFF[slot]
         cross = (t_prev >> 24) != (t_cur >> 24)
         if live is not None:
@@ -662,6 +660,13 @@ class Tracer:
         tb.set(prefix + ".prev_low", old)
         tb.set(prefix + ".diff_low_limb", diff & MASK16)
         return val
+
+    def _prev_ts(self, k, p, slot):
+        """Timestamp of the previous access of the register in `slot` (0 = the initial record)."""
+        ex = self.ex
+        pp, po, wrap = (x[p] for x in ex.prev[slot])
+        kp = k - wrap
+        return torch.where(kp >= 0, ex.T(kp.clamp(min=0), pp) + po, torch.zeros_like(k))
 
     def rows_of(self, chip):
         pos = np.nonzero(self.b.chip == chip)[0]
@@ -841,20 +846,31 @@ class Tracer:
         tb = self.table("SyscallInstrs", n)
         self.fill_state(tb, k, p)
         code, bv, cv = self.fill_adapter(tb, k, p, "R")
-        tb.set("next_pc", limbs16(ex.pc(p) + 4)[:, :3] + 0)
-        # next_pc is NOT normalised: limb 0 = pc[0] + 4 (air.rs:L128-L140)
+        sid = code & 0xFF
+        halt = sid == 0x00
+        # next_pc is NOT normalised: limb 0 = pc[0] + 4 (air.rs:L128-L140); HALT jumps to HALT_PC = 1
         pcl = limbs16(ex.pc(p))[:, :3].clone()
         pcl[:, 0] += 4
+        pcl = torch.where(halt[:, None], torch.tensor([1, 0, 0], dtype=I64, device=self.dev)[None, :], pcl)
         tb.set("next_pc", pcl)
+        tb.set("is_halt", halt.to(I64))
         tb.set("op_a_value", limbs16(ex.W[k, p]))
         tb.set("a_low_bytes.low_bytes", limbs16(code) & 0xFF)
-        sid = code & 0xFF
         for nm, c_ in (("is_enter_unconstrained", 0x03), ("is_hint_len", 0xF0), ("is_halt_check", 0x00), ("is_commit", 0x10),
                        ("is_commit_deferred_proofs", 0x1A)):
             d = (sid - c_) % P
             tb.set(nm + ".inverse", torch.where(d == 0, torch.zeros_like(d), finv(d)))
             tb.set(nm + ".result", (d == 0).to(I64))
-        assert not bool(((sid == 0) | (sid == 3) | (sid == 0x10) | (sid == 0x1A)).any()), "HALT / COMMIT / ENTER_UNCONSTRAINED are not executed here"
+        # COMMIT / COMMIT_DEFERRED_PROOFS: op_b indexes the digest word, COMMIT's op_c is the word itself (trace.rs:L200-L229)
+        commit, cdp = sid == 0x10, sid == 0x1A
+        idx = (bv & 7) * (commit | cdp).to(I64)
+        bitmap = torch.zeros((n, 8), dtype=I64, device=self.dev)
+        bitmap[torch.arange(n, device=self.dev), idx] = (commit | cdp).to(I64)
+        tb.set("index_bitmap", bitmap)
+        tb.set("expected_public_values_digest", bytes8(cv)[:, :4] * commit.to(I64)[:, None])
+        top = (P - 1) >> 16
+        tb.set("op_b_range_check", (halt & (limbs16(bv)[:, 1] < top)).to(I64))
+        tb.set("op_c_range_check", (cdp & (limbs16(cv)[:, 1] < top)).to(I64))
         tb.set("is_real", 1)
         # SyscallCore: one row per ecall with its own table (syscall/chip.rs: events with should_send)
         send = ((code >> 8) & 0xFF) == 1
@@ -1192,7 +1208,11 @@ class Tracer:
             tb.set(tag + "_value_lower", l[:, 2] & 0xFF)
             tb.set(tag + "_value_upper", l[:, 2] >> 8)
         tb.set("is_real", 1)
+        self._bump_rows()
+
+    def _bump_rows(self):
         if self.bumps:
+            dev = self.dev
             reg, tp, val, tc = (torch.cat(x) for x in zip(*self.bumps))
             air, _ = R.chip("MemoryBump")
             tb = Table(air, len(reg), dev)
