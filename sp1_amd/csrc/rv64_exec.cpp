@@ -100,7 +100,7 @@ Instr decode(uint32_t w) {
     }
 }
 
-struct Cell { uint64_t val = 0, ts = 0; uint32_t shard = 0; bool ever = false; };
+struct Cell { uint64_t val = 0, ts = 0; uint32_t shard = 0, open = 0; bool ever = false; };   // open: this shard's local entry of the address
 constexpr int PAGE_WORDS = 512;
 struct Page { Cell w[PAGE_WORDS]; };
 
@@ -146,6 +146,7 @@ struct Vm {
     // the shard being recorded
     std::vector<uint64_t> events;                                      // [n][EV]
     std::vector<uint64_t> local;                                       // [m][5]: addr, initial ts, initial value, (final ts, final value)
+    std::vector<uint8_t> local_closed;
     std::vector<uint64_t> precompile;                                  // Keccak events: [k][clk, pointer, 25 x (previous timestamp, word read), 25 words written]
     // the whole run
     std::vector<uint64_t> touched;                                     // [t][2]: addr, initial value (then final value, final ts)
@@ -166,9 +167,21 @@ struct Vm {
     void touch(Cell& c, uint64_t addr) {                               // first access of `addr` in this shard / in the run
         if (c.shard != shard + 1) {
             c.shard = shard + 1;
+            c.open = (uint32_t)(local.size() / 5);
             local.insert(local.end(), {addr, c.ts, c.val, 0, 0});
+            local_closed.push_back(0);
             if (!c.ever) { c.ever = true; touched.insert(touched.end(), {addr, c.val}); }
         }
+    }
+    // a precompile's access: its shard carries its own local memory events (tracing.rs:L1619-L1630), so the CPU's entry of the
+    // address, if one is open, ends here; the next CPU access opens another
+    void touch_precompile(Cell& c, uint64_t addr) {
+        if (c.shard == shard + 1) {
+            local[5 * (size_t)c.open + 3] = c.ts; local[5 * (size_t)c.open + 4] = c.val;
+            local_closed[c.open] = 1;
+            c.shard = 0;
+        }
+        if (!c.ever) { c.ever = true; touched.insert(touched.end(), {addr, c.val}); }
     }
     // register accesses (addresses 0..31)
     uint64_t rr(uint32_t r, uint64_t pos, uint64_t& prev_ts) {
@@ -386,7 +399,7 @@ struct Vm {
                 uint64_t st[25];
                 std::vector<uint64_t> rec = {clk, b};
                 for (int i = 0; i < 25; ++i) {                        // reads at clk
-                    Cell& m = cell(b + 8 * i); touch(m, b + 8 * i);
+                    Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i);
                     st[i] = m.val; rec.push_back(m.ts); rec.push_back(m.val); m.ts = clk;
                 }
                 keccak_f(st);
@@ -409,6 +422,7 @@ struct Vm {
 
     void finish_shard() {
         for (size_t i = 0; i < local.size(); i += 5) {
+            if (local_closed[i / 5]) continue;
             const uint64_t addr = local[i];
             const Cell& c = addr < 32 ? regs[addr] : cell(addr);
             local[i + 3] = c.ts; local[i + 4] = c.val;
@@ -469,7 +483,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     if (!h || !info) { sp1hip::set_error("sp1hip_rv64_run_shard: null argument"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
-    vm.events.clear(); vm.local.clear(); vm.precompile.clear();
+    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear();
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
     while (!vm.halted && (vm.unc || vm.cycles - c0 < max_cycles))

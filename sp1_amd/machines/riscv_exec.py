@@ -353,3 +353,42 @@ def shard_tables(executor, shard, device="cpu"):
     """(machine, tables, public values) of one executed shard: machine = [(AirProgram, InteractionProgram)] in chip-name order,
     tables = {name: (prep, main)} canonical int64 tensors on `device`, public values = the shard's 160 words."""
     return EventTracer(executor, shard, device).build()
+
+
+def program_shards(executor, max_cycles, device="cpu"):
+    """Every shard of a run, in the order the reference's controller emits them: the core shards as the program executes
+    (`(kind, machine, tables, publics, global events, ExecutedShard)` with kind = "core"), then one precompile shard for the
+    KECCAK_PERMUTE calls if there were any ("keccak"), then the memory shard: MemoryGlobalInit / MemoryGlobalFinalize over
+    every address the run touched ("memory"). The global events of all shards cancel as a multiset: that is the statement the
+    shards' septic-curve digests add up to."""
+    from . import riscv_more_trace as MT
+    keccak = []
+    for shard in executor.shards(max_cycles):
+        tr = EventTracer(executor, shard, device)
+        machine, tables, publics = tr.build()
+        if shard.keccak.shape[0]:
+            keccak.append(shard.keccak)
+        yield "core", machine, tables, publics, tr.global_events, shard
+    if keccak:
+        kk = torch.as_tensor(np.concatenate(keccak), device=device)
+        rd = kk[:, 2:52].reshape(-1, 25, 2)
+        machine, tables, publics, gev = MT.precompile_shard_from(kk[:, 0], kk[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(), device)
+        yield "keccak", machine, tables, publics, gev, None
+    gm = executor.global_memory()
+    gm = gm[np.argsort(gm[:, 0].astype(np.uint64))]
+    if gm.shape[0] == 0 or gm[0, 0] != 0:                  # register x0 opens the address chain whether or not the program read it
+        gm = np.concatenate([np.zeros((1, 4), dtype=np.int64), gm])
+    addrs = [int(a) for a in gm[:, 0]]
+    machine, tables, publics, gev = MT.memory_shard_from(addrs, [(int(v), 0) for v in gm[:, 1]], [(int(v), int(t)) for v, t in gm[:, 2:4]], device)
+    yield "memory", machine, tables, publics, gev, None
+
+
+def global_events_balance(event_lists):
+    """The cross-shard statement: over all shards, every Global message is sent exactly as often as it is received
+    (events [n, 11] = message[8], is_send, is_receive, kind). Returns the messages that do not cancel."""
+    ev = torch.cat([e.cpu() for e in event_lists]).numpy()
+    tally = {}
+    for row in ev:
+        key = tuple(int(x) for x in row[:8]) + (int(row[10]),)
+        tally[key] = tally.get(key, 0) + int(row[8]) - int(row[9])
+    return {k: v for k, v in tally.items() if v}

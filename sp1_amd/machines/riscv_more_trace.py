@@ -159,19 +159,28 @@ def _mem_access_t(tb, prefix, prev_val, t_prev, t_cur):
 
 
 def precompile_shard(n_events, seed=0, device="cpu", clk0=(5 << 24) + 1001):
-    """A KECCAK_PERMUTE precompile shard of `n_events` syscalls: (machine, tables, publics) like riscv_trace.generate
-    (vectorised torch.int64: CPU in the tests, the GPU in the bench)."""
+    """A KECCAK_PERMUTE precompile shard of `n_events` random syscalls (see precompile_shard_from)."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    tr = RT.Tracer.__new__(RT.Tracer)
-    tr.dev, tr.tables = dev, {}
     # events: distinct, 8-aligned, non-overlapping state addresses >= 2^16 (200-byte states in 256-byte slots); increasing clocks
     # (= 1 mod 8 like every instruction's)
     slots = torch.randperm(4 * n_events + 4, generator=gen, device=dev)[:n_events]
     addr = 0x20_0000 + 256 * slots
     clk = clk0 + 8 * 40 * torch.arange(n_events, device=dev)
     pre = torch.randint(RT.MIN64, (1 << 63) - 1, (n_events, 25), generator=gen, device=dev, dtype=I64)
+    t_prev = torch.randint(1, clk0 - 8, (n_events, 25), generator=gen, device=dev, dtype=I64)       # last accesses, in earlier shards
+    return precompile_shard_from(clk, addr, pre, t_prev, dev)[:3]
+
+
+def precompile_shard_from(clk, addr, pre, t_prev, device="cpu"):
+    """The KECCAK_PERMUTE precompile shard of the syscalls (clk [n], state pointer addr [n], state read pre [n, 25], previous
+    timestamps of its words t_prev [n, 25]): (machine, tables, publics, global events) — the first three like riscv_trace.generate
+    (vectorised torch.int64: CPU in the tests, the GPU in the bench). Reads happen at clk, writes at clk + 1 (keccak256/permute.rs)."""
+    dev = torch.device(device)
+    n_events = int(clk.shape[0])
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
     kp, post = keccak_permute_table(clk, addr, pre, dev)
     tr.tables["KeccakPermute"] = kp
     # KeccakPermuteControl (controller.rs:L155-L237)
@@ -184,7 +193,6 @@ def precompile_shard(n_events, seed=0, device="cpu", clk0=(5 << 24) + 1001):
     dmax = (top - 2 * MASK16) % P
     ct.set("state_addr.top_two_limb_max.inverse", torch.where(dmax == 0, torch.zeros_like(dmax), RT.finv(dmax)))
     ct.set("state_addr.top_two_limb_max.result", (dmax == 0).to(I64))
-    t_prev = torch.randint(1, clk0 - 8, (n_events, 25), generator=gen, device=dev, dtype=I64)       # last accesses, in earlier shards
     for i in range(25):
         ct.set("addrs.%d.value" % i, _limbs_t(addr + 8 * i)[:, :3])
         _mem_access_t(ct, "initial_memory_access.%d" % i, pre[:, i], t_prev[:, i], clk)
@@ -215,10 +223,20 @@ def precompile_shard(n_events, seed=0, device="cpu", clk0=(5 << 24) + 1001):
     (_, recv, _), (_, send, _) = RT.eval_interactions(R.chip("MemoryLocal")[1], ml.main[:ml.n], None, kinds=(R.GLOBAL,))
     ev = [torch.stack([recv, send], dim=1).reshape(-1, 11)]
     ev += [v for _, v, _ in RT.eval_interactions(R.chip("SyscallPrecompile")[1], st.main[:st.n], None, kinds=(R.GLOBAL,))]
-    tr.global_chip(machine, torch.cat(ev))
+    tr.global_events = torch.cat(ev)
+    tr.global_chip(machine, tr.global_events)
     tr.byte_range_tables(machine)
     names = sorted(machine)
-    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, torch.zeros(M.PV_NUM_ELTS, dtype=I64)
+    publics = torch.zeros(M.PV_NUM_ELTS, dtype=I64)
+    _global_publics(publics, tr.tables["Global"])
+    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, publics, tr.global_events
+
+
+def _global_publics(publics, g):
+    """global_count and global_cumulative_sum (public_values.rs) from the Global table's last real row."""
+    publics[129] = g.n
+    for i, nm in enumerate(("accumulation.cumulative_sum_x", "accumulation.cumulative_sum_y")):
+        publics[130 + 7 * i:137 + 7 * i] = g.main[g.n - 1, g.L[nm]:g.L[nm] + 7].cpu()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -235,28 +253,38 @@ def control_boundary_chip(name, kind):
 
 
 def memory_shard(n_words, seed=0, device="cpu", with_zero=True):
-    """Global memory initialisation and finalisation of `n_words` addresses (memory/global.rs generate_trace_into: events sorted
-    by address, the chain of (index, prev_addr, validity) control messages, one Global event per word)."""
-    dev = torch.device(device)
+    """Global memory initialisation and finalisation of `n_words` random addresses (see memory_shard_from)."""
     rng = np.random.default_rng(seed)
-    tr = RT.Tracer.__new__(RT.Tracer)
-    tr.dev, tr.tables = dev, {}
     addrs = np.sort(rng.choice(np.arange(1, 1 << 20), size=n_words - int(with_zero), replace=False)) * 8 + (1 << 16)       # all > 2^16
     if with_zero:
         addrs = np.concatenate([[0], addrs])                # register x0: address 0 with value 0 (the `is_comp = 0` row)
+    word = lambda a: 0 if a == 0 else int(rng.integers(0, 1 << 63, dtype=np.int64)) * 2 + int(rng.integers(2))
+    init = [(word(int(a)), int(rng.integers(1, 1 << 40))) for a in addrs]
+    fin = [(word(int(a)), int(rng.integers(1, 1 << 40))) for a in addrs]
+    # the first memory shard starts at previous_addr = 0 and must initialise address 0 (register x0) with 0; a later one
+    # continues from the previous shard's last address (public values previous_init_addr / previous_finalize_addr)
+    return memory_shard_from([int(a) for a in addrs], init, fin, device, previous_addr=0 if with_zero else 1 << 16)[:3]
+
+
+def memory_shard_from(addrs, init, fin, device="cpu", previous_addr=0):
+    """The memory shard of a run (memory/global.rs generate_trace_into): MemoryGlobalInit / MemoryGlobalFinalize rows for the
+    strictly increasing addresses `addrs` — init[i] / fin[i] = (value, timestamp) of address i (the Init chip's Global message
+    carries timestamp 0 whatever its clk columns hold) —, the chain of (index, prev_addr, validity) control messages closed by two
+    boundary rows, one Global event per row, the Global chip and the byte tables. Returns (machine, tables, publics, global events)."""
+    dev = torch.device(device)
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    n_words = len(addrs)
     inv = lambda v: pow(int(v) % P, P - 2, P) if int(v) % P else 0
     machine, ev = {}, []
-    for name, kind in (("MemoryGlobalInit", M.MEMORY_GLOBAL_INIT_CONTROL), ("MemoryGlobalFinalize", M.MEMORY_GLOBAL_FINALIZE_CONTROL)):
+    for name, kind, recs in (("MemoryGlobalInit", M.MEMORY_GLOBAL_INIT_CONTROL, init), ("MemoryGlobalFinalize", M.MEMORY_GLOBAL_FINALIZE_CONTROL, fin)):
         air, it = R.chip(name)
         L = air.layout
         tb = RT.Table(air, n_words, dev)
         rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
-        # the first memory shard starts at previous_addr = 0 and must initialise address 0 (register x0) with 0; a later one
-        # continues from the previous shard's last address (public values previous_init_addr / previous_finalize_addr)
-        prev = previous_addr = 0 if with_zero else 1 << 16
+        prev = previous_addr
         for i, a in enumerate(int(x) for x in addrs):
-            v = 0 if a == 0 else int(rng.integers(0, 1 << 63, dtype=np.int64)) * 2 + int(rng.integers(2))
-            t = int(rng.integers(1, 1 << 40))
+            v, t = (int(x) & ((1 << 64) - 1) for x in recs[i])
             r = i
             rows[r, L["clk_high"]], rows[r, L["clk_low"]] = t >> 24, t & 0xFFFFFF
             rows[r, L["index"]] = i
@@ -288,7 +316,13 @@ def memory_shard(n_words, seed=0, device="cpu", with_zero=True):
         bt.main[0] = torch.tensor([0] + _limbs(previous_addr)[:3] + [1, 1, 0], device=dev)
         bt.main[1] = torch.tensor([n_words] + _limbs(int(addrs[-1]))[:3] + [int(rows[n_words - 1, L["is_comp"]]), 0, 1], device=dev)
         tr.tables[bair.name], machine[bair.name] = bt, (bair, bit)
-    tr.global_chip(machine, torch.cat(ev))
+    tr.global_events = torch.cat(ev)
+    tr.global_chip(machine, tr.global_events)
     tr.byte_range_tables(machine)
     names = sorted(machine)
-    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, torch.zeros(M.PV_NUM_ELTS, dtype=I64)
+    publics = torch.zeros(M.PV_NUM_ELTS, dtype=I64)
+    for off, a in ((89, previous_addr), (92, int(addrs[-1])), (95, previous_addr), (98, int(addrs[-1]))):   # previous / last init, finalize addr
+        publics[off:off + 3] = torch.tensor(_limbs(a)[:3])
+    publics[125], publics[126] = n_words, n_words                                         # global_init_count, global_finalize_count
+    _global_publics(publics, tr.tables["Global"])
+    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, publics, tr.global_events

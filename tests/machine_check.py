@@ -67,3 +67,38 @@ def bus_imbalance(chips):
                     key = (kind,) + tuple(int(x) for x in cols[r])
                     tally[key] = (tally.get(key, 0) + sign * int(m[r])) % P
     return {k: v for k, v in tally.items() if v}
+
+
+def bus_imbalance_fast(chips, seed=1):
+    """The same multiset check for large tables: every message is folded to a 64-bit key (random odd multipliers, wrapping
+    arithmetic), keys are sorted and the signed multiplicities summed per key. Returns the number of keys whose sum is non-zero
+    mod p (0 = balanced, up to a 2^-64-sized collision chance)."""
+    rng = np.random.default_rng(seed)
+    coef = rng.integers(0, 1 << 63, size=4097, dtype=np.int64).astype(U) * U(2) + U(1)
+    keys, mults = [], []
+    for it, prep, main in chips:
+        for sign, lst in ((1, it.sends), (-1, it.receives)):
+            for kind, values, mult in lst:
+                m = _vcol(mult, prep, main)
+                live = np.nonzero(m)[0]
+                if not len(live):
+                    continue
+                mm, pl = main[live], (prep[live] if prep is not None else None)
+                key = np.full(len(live), (kind + 1) * 0x9E3779B97F4A7C15 % (1 << 64), dtype=U)
+                with np.errstate(over="ignore"):
+                    for i, v in enumerate(values):
+                        key = key * U(0x100000001B3) + _vcol(v, pl, mm) * coef[i]
+                    key = key + U(len(values)) * coef[4096]
+                ms = m[live].astype(np.int64)
+                ms = np.where(ms > P // 2, ms - P, ms)              # multiplicities are small signed counts
+                keys.append(key)
+                mults.append(sign * ms)
+    if not keys:
+        return 0
+    keys, mults = np.concatenate(keys), np.concatenate(mults)
+    order = np.argsort(keys, kind="stable")
+    ks, cs = keys[order], np.cumsum(mults[order])
+    last = np.r_[ks[1:] != ks[:-1], True]
+    ends = cs[last]
+    sums = ends - np.r_[0, ends[:-1]]
+    return int(np.count_nonzero(sums % P))

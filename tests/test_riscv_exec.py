@@ -1,0 +1,215 @@
+"""Real guest programs (CPU): the rv64im executor of libsp1hip.so (host code: no GPU needed) and the tables made from its events.
+
+* the reference's own guest binaries (bench/programs/*.elf, unmodified copies of /root/reference/sp1-gpu/crates/prover_components/
+  programs/*/riscv64im-succinct-zkvm-elf — workload inputs, see bench/programs/README.md) run to HALT with exit code 0; the
+  public-values digest the guest COMMITs (SHA-256 computed by some thousands of executed rv64im instructions) equals hashlib's
+  over the bytes it wrote to the public-values descriptor;
+* on every shard of those runs — core shards, the KECCAK_PERMUTE precompile shard, the memory shard — every constraint of every
+  chip vanishes on every row and every bus balances, and over the whole run the Global messages cancel (what the shards'
+  septic digests add up to);
+* instruction semantics against an independent model written from the RISC-V specification, on operands that include the
+  division and shift edge cases (hand-assembled programs: tests/rv_asm.py), with x0 destinations (AluX0 / LoadX0 rows)."""
+import hashlib
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import machine_check as MC
+import rv_asm as A
+
+from sp1_amd.machines import riscv_exec as X
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+M64 = (1 << 64) - 1
+
+
+def _elf(name):
+    return open(os.path.join(ROOT, "bench", "programs", name + ".elf"), "rb").read()
+
+
+def check_shard(machine, tabs, publics):
+    """Every constraint on every row, every bus: returns (failing chips, unbalanced message keys)."""
+    chips, bad, pv = [], [], publics.numpy().astype(np.uint64)
+    for air, it in machine:
+        prep, main = tabs[air.name]
+        m = main.numpy().astype(np.uint64)
+        pr = prep.numpy().astype(np.uint64) if prep is not None else None
+        assert (main >= 0).all() and (m < MC.P).all(), air.name
+        if air.num_constraints and MC.constraint_values(air, pr, m, pv).any():
+            bad.append(air.name)
+        chips.append((it, pr, m))
+    return bad, MC.bus_imbalance_fast(chips)
+
+
+def run_program(elf, stdin, max_cycles):
+    ex = X.Executor(elf, stdin=stdin)
+    kinds, gevs, cycles, last = [], [], 0, None
+    for kind, machine, tabs, publics, gev, sh in X.program_shards(ex, max_cycles):
+        bad, imb = check_shard(machine, tabs, publics)
+        assert not bad and not imb, (kind, bad, imb)
+        kinds.append(kind)
+        gevs.append(gev)
+        if sh is not None:
+            cycles, last = cycles + sh.cycles, sh
+    assert not X.global_events_balance(gevs)
+    return ex, kinds, cycles, last
+
+
+def _digest_words(data):
+    return list(struct.unpack("<8I", hashlib.sha256(data).digest()))
+
+
+def test_fibonacci_elf_runs_and_every_shard_checks():
+    # `stdin.write(&n)` with n: usize (sp1-gpu/crates/perf/src/lib.rs:L25-L29): bincode = 8 little-endian bytes
+    ex, kinds, cycles, last = run_program(_elf("fibonacci"), [struct.pack("<Q", 300)], 3000)
+    assert kinds == ["core"] * 3 + ["memory"] and cycles > 8000
+    assert last.halted and last.exit_code == 0 and last.next_pc == 1
+    assert ex.output(1).startswith(b"result: ")
+    assert last.commit_syscall == 1 and last.committed_value_digest == _digest_words(ex.output(0))
+    # the cycle count is a function of n: 9 instructions per iteration
+    ex2, _, cycles2, _ = run_program(_elf("fibonacci"), [struct.pack("<Q", 400)], 1 << 20)
+    assert cycles2 - cycles == 900 and ex2.output(1) != ex.output(1)
+
+
+def test_keccak_elf_with_its_precompile_shard():
+    ex, kinds, cycles, last = run_program(_elf("keccak"), [bytes(300)], 4000)
+    assert kinds[-2:] == ["keccak", "memory"] and set(kinds[:-2]) == {"core"}
+    assert last.halted and last.exit_code == 0
+    assert len(ex.output(0)) == 32 and last.committed_value_digest == _digest_words(ex.output(0))
+
+
+def test_loop_elf():
+    ex, kinds, cycles, last = run_program(_elf("loop"), [struct.pack("<Q", 500)], 1 << 20)
+    assert kinds == ["core", "memory"] and last.exit_code == 0
+    assert last.committed_value_digest == _digest_words(ex.output(0))
+
+
+def test_guest_panic_is_an_exit_code_not_an_executor_error():
+    ex = X.Executor(_elf("loop"), stdin=[b"\x01\x02\x03"])                # too short for the usize the guest deserialises
+    shards = list(ex.shards(1 << 20))
+    assert shards[-1].halted and shards[-1].exit_code == 1 and b"panicked" in ex.output(1)
+
+
+def test_fast_bus_check_sees_a_missing_message():
+    ex = X.Executor(_elf("fibonacci"), stdin=[struct.pack("<Q", 5)])
+    sh = ex.run_shard(1 << 20)
+    machine, tabs, publics = X.shard_tables(ex, sh)
+    assert check_shard(machine, tabs, publics) == ([], 0)
+    main = tabs["Add"][1]
+    main[0, R_LAYOUT("Add")["value"]] = (main[0, R_LAYOUT("Add")["value"]] + 1) % MC.P       # a wrong sum: constraint AND memory bus
+    bad, imb = check_shard(machine, tabs, publics)
+    assert bad == ["Add"] and imb > 0
+
+
+def R_LAYOUT(chip):
+    from sp1_amd.machines import riscv as R
+    return R.chip(chip)[0].layout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# instruction semantics against the specification
+def _s(v, bits=64):
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def _tdiv(a, b):
+    q = abs(a) // abs(b)
+    return q if (a < 0) == (b < 0) else -q
+
+
+def spec(op, b, c):
+    """rd of `op rd, rs1 = b, rs2 = c` per the unprivileged specification (chapters RV64I and M), as a u64."""
+    sb, sc, wb, wc = _s(b), _s(c), _s(b, 32), _s(c, 32)
+    sx = lambda v: _s(v, 32) & M64
+    f = {
+        "add": lambda: b + c, "sub": lambda: b - c, "xor": lambda: b ^ c, "or": lambda: b | c, "and": lambda: b & c,
+        "sll": lambda: b << (c & 63), "srl": lambda: b >> (c & 63), "sra": lambda: sb >> (c & 63),
+        "slt": lambda: int(sb < sc), "sltu": lambda: int(b < c),
+        "mul": lambda: b * c, "mulh": lambda: (sb * sc) >> 64, "mulhu": lambda: (b * c) >> 64, "mulhsu": lambda: (sb * c) >> 64,
+        "div": lambda: -1 if c == 0 else _tdiv(sb, sc), "divu": lambda: M64 if c == 0 else b // c,
+        "rem": lambda: sb if c == 0 else sb - sc * _tdiv(sb, sc), "remu": lambda: b if c == 0 else b % c,
+        "addw": lambda: sx(b + c), "subw": lambda: sx(b - c), "mulw": lambda: sx(b * c),
+        "sllw": lambda: sx(b << (c & 31)), "srlw": lambda: sx((b & 0xFFFFFFFF) >> (c & 31)), "sraw": lambda: sx(wb >> (c & 31)),
+        "divw": lambda: -1 if wc == 0 else sx(_tdiv(wb, wc)), "divuw": lambda: M64 if wc == 0 else sx((b & 0xFFFFFFFF) // (c & 0xFFFFFFFF)),
+        "remw": lambda: sx(wb) if wc == 0 else sx(wb - wc * _tdiv(wb, wc)),
+        "remuw": lambda: sx(wb) if wc == 0 else sx((b & 0xFFFFFFFF) % (c & 0xFFFFFFFF)),
+    }[op]
+    return f() & M64
+
+
+EDGE = [0, 1, 2, M64, 1 << 63, (1 << 63) - 1, 1 << 31, (1 << 31) - 1, 0xFFFFFFFF, 0x80000000_00000001, 7, (-7) & M64, 63, 64, 31, 32]
+
+
+def test_alu_semantics_against_the_specification_and_their_tables():
+    rng = np.random.default_rng(5)
+    ops = sorted(A.R_OPS)
+    cases = [(op, b, c) for op in ops for b, c in [(EDGE[i], EDGE[j]) for i, j in rng.integers(0, len(EDGE), (6, 2))]]
+    cases += [(op, int(rng.integers(0, 1 << 63)) * 2 + 1, int(rng.integers(0, 1 << 63)) * 2) for op in ops for _ in range(2)]
+    cases += [("div", 1 << 63, M64), ("rem", 1 << 63, M64), ("divw", 1 << 31, 0xFFFFFFFF), ("remw", 1 << 31, 0xFFFFFFFF), ("divu", 5, 0),
+              ("div", 5, 0), ("remuw", 5, 0)]
+    words, want = [], []
+    for i, (op, b, c) in enumerate(cases):
+        rd = 0 if i % 11 == 10 else 13 + i % 5                            # some results are discarded into x0: AluX0 rows
+        words += A.li(6, b) + A.li(7, c) + [A.enc(op, rd, 6, 7)]
+        if rd:                                                           # keep the result: store it
+            words += [A.enc("sd", rd, 28, 8 * len(want))]
+            want.append(spec(op, b, c))
+    prologue = A.li(28, 0x78100000)
+    words = prologue + words + A.halt(0)
+    ex = X.Executor(A.elf(words, data=bytes(8 * len(want) + 8)))
+    sh = ex.run_shard(1 << 20)
+    assert sh.halted and sh.exit_code == 0
+    gm = {int(r[0]): int(r[2]) & M64 for r in ex.global_memory()}
+    got = [gm[0x78100000 + 8 * i] for i in range(len(want))]
+    wrong = [(cases[i], hex(g), hex(w)) for i, (g, w) in enumerate(zip(got, want)) if g != w]
+    assert not wrong, wrong[:5]
+    machine, tabs, publics = X.shard_tables(ex, sh)
+    names = {a.name for a, _ in machine}
+    assert {"AluX0", "DivRem", "Mul", "ShiftLeft", "ShiftRight", "Lt", "Addw", "Subw", "StoreDouble"} <= names
+    assert check_shard(machine, tabs, publics) == ([], 0)
+
+
+def test_loads_stores_branches_jumps_and_their_tables():
+    w = A.li(28, 0x78100000) + A.li(6, 0x8877665544332211) + [
+        A.enc("sd", 6, 28, 0), A.enc("sb", 6, 28, 9), A.enc("sh", 6, 28, 18), A.enc("sw", 6, 28, 28),
+        A.enc("lb", 13, 28, 7), A.enc("lbu", 14, 28, 7), A.enc("lh", 15, 28, 6), A.enc("lhu", 16, 28, 6), A.enc("lw", 17, 28, 4),
+        A.enc("lwu", 18, 28, 4), A.enc("ld", 19, 28, 0), A.enc("ld", 0, 28, 8), A.enc("lbu", 0, 28, 1),          # LoadX0 rows
+        A.enc("sd", 13, 28, 32), A.enc("sd", 14, 28, 40), A.enc("sd", 15, 28, 48), A.enc("sd", 16, 28, 56), A.enc("sd", 17, 28, 64),
+        A.enc("sd", 18, 28, 72), A.enc("sd", 19, 28, 80),
+        A.enc("blt", 13, 0, 8), A.enc("addi", 20, 0, 1),                  # taken: skips the addi
+        A.enc("bgeu", 13, 0, 8), A.enc("addi", 21, 0, 2),                 # taken (unsigned): skips
+        A.enc("beq", 13, 14, 8), A.enc("addi", 22, 0, 3),                 # not taken
+        A.enc("jal", 1, 8), A.enc("addi", 23, 0, 4),                      # skips; x1 = pc + 4
+        A.enc("auipc", 24, 0), A.enc("jalr", 0, 24, 12), A.enc("addi", 25, 0, 5),      # jumps over the addi, rd = x0
+        A.enc("sd", 20, 28, 88), A.enc("sd", 22, 28, 96), A.enc("sd", 23, 28, 104), A.enc("sd", 25, 28, 112),
+    ] + A.halt(0)
+    ex = X.Executor(A.elf(w, data=bytes(128)))
+    sh = ex.run_shard(1 << 20)
+    assert sh.halted and sh.exit_code == 0
+    gm = {int(r[0]): int(r[2]) & M64 for r in ex.global_memory()}
+    mem = lambda off: gm[0x78100000 + off]
+    assert mem(0) == 0x8877665544332211 and mem(8) == 0x1100 and mem(16) == 0x2211_0000 and mem(24) == 0x44332211_00000000
+    assert [mem(32 + 8 * i) for i in range(7)] == [0xFFFFFFFFFFFFFF88, 0x88, 0xFFFFFFFFFFFF8877, 0x8877, 0xFFFFFFFF88776655, 0x88776655,
+                                                   0x8877665544332211]
+    assert [mem(88), mem(96), mem(104), mem(112)] == [0, 3, 0, 0]
+    machine, tabs, publics = X.shard_tables(ex, sh)
+    assert {"LoadX0", "LoadByte", "LoadHalf", "LoadWord", "StoreByte", "StoreHalf", "StoreWord", "Branch", "Jal", "Jalr", "UType"} <= {a.name for a, _ in machine}
+    assert check_shard(machine, tabs, publics) == ([], 0)
+
+
+def test_executor_errors_are_reported_not_swallowed():
+    from sp1_amd import _lib
+    with pytest.raises(_lib.Sp1HipError):
+        X.Executor(b"not an elf" * 10)
+    ex = X.Executor(A.elf(A.li(28, 0x78100001) + [A.enc("ld", 5, 28, 0)] + A.halt(0), data=bytes(16)))      # misaligned load
+    with pytest.raises(_lib.Sp1HipError, match="misaligned"):
+        ex.run_shard(100)
+    ex = X.Executor(A.elf(A.li(5, 0x0001_0107) + [A.enc("ecall")] + A.halt(0)))                               # ED_ADD: not implemented
+    with pytest.raises(_lib.Sp1HipError, match="0x10107"):
+        ex.run_shard(100)
