@@ -80,7 +80,7 @@ def effective_cores():
 
 def programs_of(kind, names):
     """(AirProgram, InteractionProgram) list of a workload, rebuilt by name in a child process that has no traces."""
-    if kind in ("real", "precompile"):
+    if kind in ("real", "precompile") + PROGRAMS:
         import core_real
         return core_real.programs_for(names)
     if kind == "core":
@@ -89,6 +89,9 @@ def programs_of(kind, names):
                 for c in sorted(load_shape()["chips"], key=lambda c: c["name"])]
     from sp1_amd.machines import recursion as R
     return R.compress_machine()
+
+
+PROGRAMS = ("fibonacci", "loop", "keccak")                  # real guest programs: bench/program_shard.py
 
 
 def publics_of(kind):
@@ -107,6 +110,9 @@ def build_workload(kind, k, L, seed):
     if kind == "precompile":
         import precompile_shard
         return precompile_shard.build_precompile_shard(max(1, precompile_shard.FULL_EVENTS >> (2 * k)), seed=seed)
+    if kind in PROGRAMS:
+        import program_shard
+        return program_shard.build_program_shard(kind, k, shard_index=seed - 42)     # rank r proves shard r of the same execution
     from core_shard import build_core_shard
     return build_core_shard(CORE_AREA >> (2 * k), L, seed=seed)
 
@@ -130,7 +136,8 @@ def cpu_baseline_child(path):
     # GPU algorithm) costs 2^L / rows more and is not what a CPU prover does. ONE pass (no size query).
     orc.set_gkr_sparse(True)
     t0 = time.perf_counter()
-    blob = orc.shard_prove(chips, publics_of(str(z["kind"])), prep, L, lsh, 32, ch, 2, 124, 16, capacity=64 << 20)
+    publics = z["publics"] if "publics" in z.files else publics_of(str(z["kind"]))
+    blob = orc.shard_prove(chips, publics, prep, L, lsh, 32, ch, 2, 124, 16, capacity=64 << 20)
     dt = time.perf_counter() - t0
     print(json.dumps({"seconds": dt, "setup_seconds": t_setup, "proof_bytes": len(blob), "stage_seconds": orc.stage_seconds()}))
 
@@ -143,6 +150,8 @@ def cpu_sample(api, scale_log2, cores, kind="real"):
     L, lsh = max(22 - scale_log2, 17), 21 - scale_log2
     chips, meta = build_workload(kind, scale_log2, L, 42)
     arrays = {"L": L, "lsh": lsh, "kind": kind, "names": np.array([c[0].name for c in chips])}
+    if "publics" in meta:
+        arrays["publics"] = meta["publics"]
     for k, (_, _, main, prep) in enumerate(chips):
         arrays["main%d" % k] = main.to_row_major_host()
         if prep is not None:
@@ -515,7 +524,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="real", choices=["real", "core", "precompile"],
+    ap.add_argument("--workload", default="real", choices=["real", "core", "precompile"] + list(PROGRAMS),
                     help="real: the RISC-V chips at the recorded core shard's heights (bench/core_real.py); core: the synthetic "
                          "core-shaped shard of rounds 1-3 (bench/core_shard.py); precompile: a Keccak precompile shard, 82 %% of its "
                          "area in the 2,640-column KeccakPermute chip (bench/precompile_shard.py)")
@@ -575,7 +584,7 @@ def main():
     lib = api._L()
     k = args.scale_log2
     kind = args.workload
-    L, lsh = max(22 - k, 17 if kind in ("real", "precompile") else 0), 21 - k            # the Range table of the real machines has 2^17 rows
+    L, lsh = max(22 - k, 17 if kind in ("real", "precompile") + PROGRAMS else 0), 21 - k   # the Range table of the real machines has 2^17 rows
     chips, meta = build_workload(kind, k, L, 42 + rank)                  # every rank proves its own shard
     names = [c[0].name for c in chips]
     area = meta["area_cells"]
@@ -584,7 +593,7 @@ def main():
     torch.cuda.synchronize()
 
     last_state = [None]
-    publics = publics_of(kind)
+    publics = meta["publics"] if "publics" in meta else publics_of(kind)   # a real program's shard carries its own public values
     if args.mode == "tree":
         out = tree_mode(api, shards, dist, torch, args, rank, world, use_dist, chips, meta, prep_commit, prep_data, L, lsh, publics, kind, names)
         if rank == 0:
@@ -815,22 +824,37 @@ def main():
         elif kind == "precompile":
             workload_text = ("precompile shard: %d real chips (%s), %d constraints, %d interactions"
                              % (len(meta["real_chips"]), ", ".join(meta["real_chips"]), meta["constraints"], meta["interactions"]))
+        elif kind in PROGRAMS:
+            workload_text = ("core shard %d of the reference's `%s` guest ELF (%d cycles = executed rv64im instructions, %.1f cells per cycle): "
+                             "%d real chips + %d closing chips, %d constraints, %d interactions"
+                             % (meta["shard_index"], kind, meta["cycles"], meta["cells_per_cycle"], len(meta["real_chips"]),
+                                len(meta["synthetic_chips"]), meta["constraints"], meta["interactions"]))
         else:
             workload_text = ("core-shaped SYNTHETIC shard: %d chips, %d constraints, %d interactions"
                              % (meta["chips"], meta["constraints"], meta["interactions"]))
+        cells_per_s = world * args.steps * area / dt
+        cycles = meta.get("cycles", meta.get("instructions_executed"))
+        if kind in PROGRAMS:            # BASELINE.json's metric, on the guest it names: RISC-V cycles proved per second
+            headline = {"metric": "RISC-V cycles proved/sec (core shard prove): whole ShardProof of a full core shard of the reference's "
+                                  "`%s` guest, see config" % kind,
+                        "value": world * args.steps * meta["cycles"] / dt, "unit": "cycles/s"}
+        else:
+            headline = {"metric": "core shard prove throughput: trace cells proved/sec (whole ShardProof of the RISC-V core machine, see config)",
+                        "value": cells_per_s, "unit": "cells/s"}
         out = {
-            "metric": "core shard prove throughput: trace cells proved/sec (whole ShardProof of the RISC-V core machine, see config)",
-            "value": world * args.steps * area / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            **headline, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": ("synthetic: traces of an rv64im test program executed by this repository's executor + 2 synthetic closing chips"
-                     if kind == "real" else "synthetic: seeded traces of real chips" if kind == "precompile" else "synthetic"),
-            "proofs_per_s": world * args.steps / dt,
-            "riscv_instructions_per_s": world * args.steps * meta["instructions_executed"] / dt if kind == "real" else None,
+                     if kind == "real" else "synthetic: seeded traces of real chips" if kind == "precompile"
+                     else "the reference's guest binary (bench/programs/%s.elf) on a synthetic input of sp1-gpu perf's form, executed by this "
+                          "repository's rv64im executor; 2 synthetic closing chips stand for eval_public_values" % kind if kind in PROGRAMS else "synthetic"),
+            "proofs_per_s": world * args.steps / dt, "cells_per_s": cells_per_s,
+            "riscv_instructions_per_s": world * args.steps * cycles / dt if cycles else None,
             "config": {"workload": workload_text + "; %d cells%s, L %d, stack 2^%d, blowup 4, 124 queries, 16-bit PoW; one whole ShardProof "
                                    "(sp1hip_prove_shard), traces resident in HBM" % (area, "" if k == 0 else " (scale 4^-%d)" % k, L, lsh),
                        "area_cells": area, "first_layer_entries": meta["first_layer_entries"], "proof_bytes": len(proof),
-                       "instructions_executed": meta.get("instructions_executed"),
-                       "parallelism": "independent shards, one per GPU"},
+                       "instructions_executed": cycles, "program": meta.get("program"), "shard_index": meta.get("shard_index"),
+                       "parallelism": "independent shards, one per GPU" + (" (rank r proves shard r of one execution)" if kind in PROGRAMS else "")},
             "roofline": {"bound": d["bound"], "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / (alg_dom / dom_launches)) if traffic else None,
@@ -849,7 +873,7 @@ def main():
                                  "real_area_cells": meta["real_area_cells"], "ms_per_proof": ms_per_step,
                                  "zerocheck_round_ms": ms.get("zerocheck_round"), "zerocheck_stage_ms": ms.get("stage_zerocheck"),
                                  "wide_chip_area_fraction": meta.get("wide_chip_area_fraction"), "per_chip": meta["per_chip"]}
-                                if kind in ("real", "precompile") else None),
+                                if kind in ("real", "precompile") + PROGRAMS else None),
             "host_threads": lib.sp1hip_host_threads(), "host_cpu_ms_per_proof": host_cpu_ms, "host_cpu_ms_by_thread": host_cpu_by_thread,
             "host_wait": os.environ.get("SP1HIP_WAIT", "predict"), "host_cpu_untimed": extras.get("host_cpu_untimed"),
             "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},

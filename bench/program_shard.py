@@ -1,0 +1,58 @@
+"""Core shards of REAL guest programs (VERDICT r4 "real-program workloads: no"): the reference's own benchmark guests
+(bench/programs/*.elf, see the README there) executed by the rv64im executor of libsp1hip.so and traced by
+sp1_amd/machines/riscv_exec.py — every chip a real chip of the RISC-V machine, the events those of the guest's execution.
+
+The default is what BASELINE.json's metric is quoted on: a full core shard of `fibonacci` ("RISC-V cycles proved / second").
+Shard size: the reference cuts a shard when its estimated trace area reaches ELEMENT_THRESHOLD = 2^28 + 2^27 cells or a
+chip reaches 2^22 rows (/root/reference/crates/core/executor/src/opts.rs:L12-L14); fibonacci's loop costs 45.6 cells per
+cycle (9 instructions per iteration: Add, Addi, Sub, Mul x 2, Addw, ShiftRight, Branch, ...), so the area binds first, at
+8.8e6 cycles. `FULL_CYCLES = 2^23` (8.39e6 cycles, 3.9e8 cells incl. the fixed tables) is the power of two below it.
+Rank r of a multi-GPU run proves shard r of the same execution: independent shards, one per GPU, no data-path collective."""
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FULL_CYCLES = 1 << 23
+CYCLES_PER_UNIT = {"fibonacci": 9, "loop": 4, "keccak": 7}       # measured: cycles per loop iteration / per input byte
+
+
+def stdin_of(program, cycles):
+    """The input of sp1-gpu/crates/perf/src/lib.rs:L23-L45 sized so that the run lasts at least `cycles` cycles."""
+    n = cycles // CYCLES_PER_UNIT[program] + 1
+    return [bytes(n)] if program == "keccak" else [struct.pack("<Q", n)]  # `write_vec(vec![0u8; n])` / `write(&n)`, n: usize
+
+
+def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
+    """[(AirProgram, InteractionProgram, main ColMajor, prep ColMajor | None)] in chip-name order + meta for core shard
+    `shard_index` of `program` run with shards of FULL_CYCLES >> 2k cycles."""
+    from core_real import SYNTHETIC, to_col_major
+    from sp1_amd.machines import riscv_exec as X, riscv_trace as RT
+    max_cycles = FULL_CYCLES >> (2 * k)
+    elf = open(os.path.join(ROOT, "bench", "programs", program + ".elf"), "rb").read()
+    ex = X.Executor(elf, stdin=stdin_of(program, (shard_index + 1) * max_cycles + max_cycles // 8))
+    for _ in range(shard_index + 1):
+        shard = ex.run_shard(max_cycles)
+    assert shard.cycles == max_cycles and not shard.halted, "the run is too short for a full shard %d" % shard_index
+    machine, tabs, publics = X.shard_tables(ex, shard, device)
+    out = []
+    for a, i in machine:
+        prep, main = tabs[a.name]
+        out.append((a, i, to_col_major(main), to_col_major(prep) if prep is not None else None))
+        tabs[a.name] = None
+    area = sum(c[2].height * (c[2].width + (c[3].width if c[3] is not None else 0)) for c in out)
+    synthetic = [c[0].name for c in out if c[0].name in SYNTHETIC]
+    per_chip = {a.name: {"rows": m.height, "columns": a.main_width + a.prep_width, "constraints": a.num_constraints,
+                         "interactions": i.num_interactions, "instructions": len(a.instrs)} for a, i, m, _ in out}
+    meta = {"chips": len(out), "real_chips": sorted(c[0].name for c in out if c[0].name not in synthetic), "synthetic_chips": synthetic,
+            "area_cells": area, "real_area_cells": area - sum(c[2].height * c[2].width for c in out if c[0].name in synthetic),
+            "interactions": sum(c[1].num_interactions for c in out), "constraints": sum(c[0].num_constraints for c in out),
+            "first_layer_entries": sum(c[2].height * c[1].num_interactions for c in out),
+            "program": program, "shard_index": shard_index, "cycles": shard.cycles, "clk": [shard.clk_start, shard.clk_end],
+            "pc_start": shard.pc_start, "next_pc": shard.next_pc, "cells_per_cycle": area / shard.cycles,
+            "publics": RT.to_monty_np(publics), "per_chip": per_chip}       # Montgomery words, like the tables
+    return out, meta

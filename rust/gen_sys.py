@@ -13,7 +13,7 @@ OUT = os.path.join(ROOT, "rust", "sp1-hip-sys", "src", "lib.rs")
 
 SCALARS = {"int": "c_int", "size_t": "usize", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "float": "f32",
            "double": "f64", "char": "c_char", "void": "c_void"}
-HANDLES = {"sp1hip_stream_t": "Stream", "sp1hip_event_t": "Event", "sp1hip_ticket_t": "Ticket"}
+HANDLES = {"sp1hip_stream_t": "Stream", "sp1hip_event_t": "Event", "sp1hip_ticket_t": "Ticket", "sp1hip_rv64_vm_t": "Rv64Vm"}
 
 
 def rust_struct_name(c):
@@ -129,6 +129,8 @@ def generate():
     w.append("pub type Event = *mut c_void;")
     w.append("/// `sp1hip_ticket_t`: one shard submitted to a prover pool.")
     w.append("pub type Ticket = u64;")
+    w.append("/// `sp1hip_rv64_vm_t`: one guest execution (host code).")
+    w.append("pub type Rv64Vm = *mut c_void;")
     w.append("")
     for name, items in enums:
         w.append("/// `%s`" % name)

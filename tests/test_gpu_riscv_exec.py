@@ -1,0 +1,108 @@
+"""GPU parity (-m gpu) on REAL guest programs: the reference's fibonacci / keccak guests (bench/programs/*.elf) executed by the
+rv64im executor of libsp1hip.so, every shard of the run — core shards, the KECCAK_PERMUTE precompile shard, the memory shard —
+proved by `sp1hip_prove_shard` with the shard's own public values: bytes == the oracle prover's on the same tables, and the
+oracle's verify_shard accepts. One larger fibonacci shard (2^18 cycles) with production parameters."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import pyoracle as orc  # noqa: E402
+from sp1_amd.machines import riscv_exec as X  # noqa: E402
+from sp1_amd.machines import riscv_trace as RT  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bench"))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from sp1_amd import api as a
+    torch.cuda.set_device(0)
+    return a
+
+
+def _elf(name):
+    return open(os.path.join(ROOT, "bench", "programs", name + ".elf"), "rb").read()
+
+
+def _shapes_only(machine):
+    return [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
+            for a, i in machine]
+
+
+def prove_both(api, machine, tabs, publics, L, lsh, batch, LB, NQ, PW, verify=True):
+    import core_real
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+            for a, i in machine]
+    dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+           for a, i in machine]
+    pv = RT.to_monty_np(publics)                          # public values travel as Montgomery words, like the tables
+    o_prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, LB)
+    g_commit, g_prep = api.JaggedProver(L, lsh, batch, LB).commit_multilinears([d[3] for d in dev if d[3] is not None])
+    assert np.array_equal(g_commit, o_prep.commit)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    o_ch.observe(o_prep.commit)
+    g_ch.observe(g_commit)
+    v_ch = o_ch.clone()
+    orc.set_gkr_sparse(True)                                # the jagged-aware oracle prover (bytes equal to the dense one)
+    try:
+        want = orc.shard_prove(host, pv, o_prep, L, lsh, batch, o_ch, LB, NQ, PW)
+    finally:
+        orc.set_gkr_sparse(False)
+    got = api.prove_shard(dev, pv, g_prep, L, lsh, batch, g_ch, LB, NQ, PW)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+    if verify:
+        assert orc.shard_verify(_shapes_only(machine), g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
+
+
+@pytest.mark.parametrize("program,stdin,max_cycles,kinds", [
+    ("fibonacci", [struct.pack("<Q", 300)], 3000, ["core", "core", "core", "memory"]),
+    ("keccak", [bytes(300)], 6000, ["core", "core", "keccak", "memory"]),
+])
+def test_every_shard_of_a_real_program_matches_the_oracle(api, program, stdin, max_cycles, kinds):
+    ex = X.Executor(_elf(program), stdin=stdin)
+    seen, gevs = [], []
+    for kind, machine, tabs, publics, gev, sh in X.program_shards(ex, max_cycles, device="cuda"):
+        prove_both(api, machine, tabs, publics, 17, 12, 8, 1, 5, 4)     # the Range table has 2^17 rows
+        seen.append(kind)
+        gevs.append(gev)
+    assert seen == kinds
+    assert not X.global_events_balance(gevs)
+
+
+def test_a_fibonacci_shard_with_production_parameters_matches_the_oracle(api):
+    """2^18 cycles of the reference's fibonacci guest (1.3e7 trace cells), blowup 4, 124 queries, 16-bit PoW."""
+    ex = X.Executor(_elf("fibonacci"), stdin=[struct.pack("<Q", 40000)])
+    sh = ex.run_shard(1 << 18)
+    assert sh.cycles == 1 << 18 and not sh.halted
+    machine, tabs, publics = X.shard_tables(ex, sh, device="cuda")
+    prove_both(api, machine, tabs, publics, 18, 17, 32, 2, 124, 16)
+
+
+def test_a_corrupted_real_trace_is_rejected(api):
+    """The GPU prover proves what it is given; the verifier is what refuses a shard whose Mul row is wrong."""
+    import core_real
+    ex = X.Executor(_elf("fibonacci"), stdin=[struct.pack("<Q", 100)])
+    sh = ex.run_shard(1 << 20)
+    machine, tabs, publics = X.shard_tables(ex, sh, device="cuda")
+    from sp1_amd.machines import riscv as R
+    col = R.chip("Mul")[0].layout["a"]
+    tabs["Mul"][1][3, col] = (tabs["Mul"][1][3, col] + 1) % RT.P
+    dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+           for a, i in machine]
+    pv = RT.to_monty_np(publics)
+    L, lsh, batch = 17, 12, 8
+    commit, prep = api.JaggedProver(L, lsh, batch, 1).commit_multilinears([d[3] for d in dev if d[3] is not None])
+    ch = api.DuplexChallenger()
+    ch.observe(commit)
+    proof = api.prove_shard(dev, pv, prep, L, lsh, batch, ch, 1, 5, 4)
+    v_ch = orc.Challenger()
+    v_ch.observe(commit)
+    assert orc.shard_verify(_shapes_only(machine), commit, proof, L, lsh, v_ch, 1, 5, 4) != 0

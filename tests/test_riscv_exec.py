@@ -213,3 +213,33 @@ def test_executor_errors_are_reported_not_swallowed():
     ex = X.Executor(A.elf(A.li(5, 0x0001_0107) + [A.enc("ecall")] + A.halt(0)))                               # ED_ADD: not implemented
     with pytest.raises(_lib.Sp1HipError, match="0x10107"):
         ex.run_shard(100)
+
+
+def test_the_oracle_proves_and_verifies_the_halting_shard_with_its_public_values():
+    """The shard that executes COMMIT x 8, COMMIT_DEFERRED_PROOFS x 8 and HALT reads the committed digest, the exit code and the
+    commit flags from its public values: the pinned verifier accepts the proof with the shard's own values and rejects it when
+    one digest byte is different."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+    from sp1_amd.machines import riscv_trace as RT
+    ex = X.Executor(_elf("fibonacci"), stdin=[struct.pack("<Q", 20)])
+    sh = ex.run_shard(1 << 20)
+    assert sh.halted
+    machine, tabs, publics = X.shard_tables(ex, sh)
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None) for a, i in machine]
+    shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None) for a, i in machine]
+    L, lsh, batch = 17, 12, 8
+    prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, 1)
+    orc.set_gkr_sparse(True)
+    try:
+        for flip, want_ok in ((None, True), (X.PV["committed_value_digest"] + 5, False)):
+            pv = publics.clone()
+            if flip is not None:
+                pv[flip] = (pv[flip] + 1) % 256
+            ch = orc.Challenger()
+            ch.observe(prep.commit)
+            v_ch = ch.clone()
+            blob = orc.shard_prove(host, RT.to_monty_np(pv), prep, L, lsh, batch, ch, 1, 5, 4)
+            assert (orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4) == 0) == want_ok
+    finally:
+        orc.set_gkr_sparse(False)
