@@ -35,8 +35,8 @@ def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
     max_cycles = FULL_CYCLES >> (2 * k)
     elf = open(os.path.join(ROOT, "bench", "programs", program + ".elf"), "rb").read()
     ex = X.Executor(elf, stdin=stdin_of(program, (shard_index + 1) * max_cycles + max_cycles // 8))
-    for _ in range(shard_index + 1):
-        shard = ex.run_shard(max_cycles)
+    for i in range(shard_index + 1):                         # the shards before this rank's run without keeping their events
+        shard = ex.run_shard(max_cycles, record=i == shard_index, copy=False)
     assert shard.cycles == max_cycles and not shard.halted, "the run is too short for a full shard %d" % shard_index
     machine, tabs, publics = X.shard_tables(ex, shard, device)
     out = []

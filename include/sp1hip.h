@@ -492,19 +492,23 @@ int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint3
 typedef void* sp1hip_rv64_vm_t;
 typedef struct {
     uint64_t shard;                      /* index of this shard in the run */
-    uint64_t n_events, n_local, n_keccak;
+    uint64_t n_cycles;                   /* instructions executed in this shard */
+    uint64_t n_events, n_local, n_keccak; /* n_events = n_cycles, or 0 when recording is off */
     uint64_t pc_start, next_pc;          /* `PublicValues::pc_start / next_pc` (HALT_PC = 1 after HALT) */
     uint64_t clk_start, clk_end;         /* `initial_timestamp / last_timestamp` */
     uint32_t halted, exit_code;
     uint32_t commit_syscall, commit_deferred_syscall;
     uint32_t committed_value_digest[8];  /* as set by COMMIT so far */
     uint32_t deferred_proofs_digest[8];
-} sp1hip_rv64_shard_info;
+} sp1hip_rv64_shard_info_t;
 int sp1hip_rv64_create(const uint8_t* elf, uint64_t elf_len, sp1hip_rv64_vm_t* out);
 void sp1hip_rv64_destroy(sp1hip_rv64_vm_t vm);
 /* One entry of the input stream (`SP1Stdin::write_slice`): what the guest's next HINT_LEN / HINT_READ pair consumes. */
 int sp1hip_rv64_write_stdin(sp1hip_rv64_vm_t vm, const uint8_t* data, uint64_t len);
-int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t vm, uint64_t max_cycles, sp1hip_rv64_shard_info* info);
+int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t vm, uint64_t max_cycles, sp1hip_rv64_shard_info_t* info);
+/* on = 0: the following shards run without keeping their instruction events (a rank that proves shard r of an execution runs
+ * shards 0..r-1 this way); memory state, local memory events and public values are kept as always. */
+int sp1hip_rv64_set_recording(sp1hip_rv64_vm_t vm, int on);
 const uint64_t* sp1hip_rv64_events(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_local_memory(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_keccak_events(sp1hip_rv64_vm_t vm);

@@ -70,7 +70,7 @@ class ShardParams(C.Structure):
 
 
 class Rv64ShardInfo(C.Structure):
-    _fields_ = [("shard", C.c_uint64), ("n_events", C.c_uint64), ("n_local", C.c_uint64), ("n_keccak", C.c_uint64),
+    _fields_ = [("shard", C.c_uint64), ("n_cycles", C.c_uint64), ("n_events", C.c_uint64), ("n_local", C.c_uint64), ("n_keccak", C.c_uint64),
                 ("pc_start", C.c_uint64), ("next_pc", C.c_uint64), ("clk_start", C.c_uint64), ("clk_end", C.c_uint64),
                 ("halted", C.c_uint32), ("exit_code", C.c_uint32), ("commit_syscall", C.c_uint32),
                 ("commit_deferred_syscall", C.c_uint32), ("committed_value_digest", C.c_uint32 * 8),
@@ -196,6 +196,7 @@ PROTOTYPES = [
     ("sp1hip_rv64_destroy", "void", [_vp]),
     ("sp1hip_rv64_write_stdin", None, [_vp, u8p, C.c_uint64]),
     ("sp1hip_rv64_run_shard", None, [_vp, C.c_uint64, C.POINTER(Rv64ShardInfo)]),
+    ("sp1hip_rv64_set_recording", None, [_vp, _int]),
     ("sp1hip_rv64_events", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_local_memory", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_keccak_events", C.POINTER(C.c_uint64), [_vp]),

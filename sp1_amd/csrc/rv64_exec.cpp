@@ -414,11 +414,12 @@ struct Vm {
             next_clk += ECALL_EXTRA;
         } else return fail(in.op == EBREAK ? "ebreak" : "unimplemented instruction 0x%08x", words[idx]);
         e[E_A] = a; e[E_B] = b; e[E_C] = c; e[E_NEXT_PC] = next_pc;
-        events.insert(events.end(), e, e + EV);
+        if (record) events.insert(events.end(), e, e + EV);
         pc = next_pc; clk = next_clk; ++cycles;
         return true;
     }
     bool resume_enter = false;
+    bool record = true;                                               // sp1hip_rv64_set_recording: instruction events are kept
 
     void finish_shard() {
         for (size_t i = 0; i < local.size(); i += 5) {
@@ -479,22 +480,29 @@ int sp1hip_rv64_write_stdin(sp1hip_rv64_vm_t h, const uint8_t* data, uint64_t le
     return SP1HIP_SUCCESS;
 }
 
-int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_shard_info* info) {
+int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_shard_info_t* info) {
     if (!h || !info) { sp1hip::set_error("sp1hip_rv64_run_shard: null argument"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear();
+    if (vm.record && max_cycles <= (1ull << 26)) vm.events.reserve((size_t)max_cycles * EV);   // one allocation, not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
     while (!vm.halted && (vm.unc || vm.cycles - c0 < max_cycles))
         if (!vm.step()) { sp1hip::set_error("sp1hip_rv64_run_shard: %s", vm.error.c_str()); return SP1HIP_ERROR_RUNTIME; }
     vm.finish_shard();
-    info->n_events = vm.events.size() / EV; info->n_local = vm.local.size() / 5; info->n_keccak = vm.precompile.size() / SP1HIP_RV64_KECCAK_WORDS;
+    info->n_cycles = vm.cycles - c0; info->n_events = vm.events.size() / EV; info->n_local = vm.local.size() / 5; info->n_keccak = vm.precompile.size() / SP1HIP_RV64_KECCAK_WORDS;
     info->next_pc = vm.pc; info->clk_end = vm.clk; info->halted = vm.halted; info->exit_code = vm.exit_code;
     info->shard = vm.shard++;
     info->commit_syscall = vm.commit_syscall; info->commit_deferred_syscall = vm.commit_deferred_syscall;
     memcpy(info->committed_value_digest, vm.committed_digest, sizeof vm.committed_digest);
     memcpy(info->deferred_proofs_digest, vm.deferred_digest, sizeof vm.deferred_digest);
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_rv64_set_recording(sp1hip_rv64_vm_t h, int on) {
+    if (!h) { sp1hip::set_error("sp1hip_rv64_set_recording: null handle"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
+    ((Vm*)h)->record = on != 0;
     return SP1HIP_SUCCESS;
 }
 

@@ -26,7 +26,7 @@ class ExecutedShard:
     the executor's u64 words) and the shard's public-value fields."""
 
     def __init__(self, info, events, local, keccak):
-        self.index = int(info.shard)
+        self.index, self.cycles = int(info.shard), int(info.n_cycles)
         self.events, self.local, self.keccak = events, local, keccak
         self.pc_start, self.next_pc = int(info.pc_start), int(info.next_pc)
         self.clk_start, self.clk_end = int(info.clk_start), int(info.clk_end)
@@ -34,10 +34,6 @@ class ExecutedShard:
         self.commit_syscall, self.commit_deferred_syscall = int(info.commit_syscall), int(info.commit_deferred_syscall)
         self.committed_value_digest = [int(x) for x in info.committed_value_digest]
         self.deferred_proofs_digest = [int(x) for x in info.deferred_proofs_digest]
-
-    @property
-    def cycles(self):
-        return self.events.shape[0]
 
 
 class Executor:
@@ -62,15 +58,20 @@ class Executor:
         _lib.check(self.lib.sp1hip_rv64_write_stdin(self.h, buf, len(data)))
 
     @staticmethod
-    def _matrix(ptr, rows, cols):
+    def _matrix(ptr, rows, cols, copy=True):
         if rows == 0:
             return np.zeros((0, cols), dtype=np.int64)
-        return np.ctypeslib.as_array(ptr, shape=(rows * cols,)).view(np.int64).reshape(rows, cols).copy()
+        m = np.ctypeslib.as_array(ptr, shape=(rows * cols,)).view(np.int64).reshape(rows, cols)
+        return m.copy() if copy else m
 
-    def run_shard(self, max_cycles):
+    def run_shard(self, max_cycles, record=True, copy=True):
+        """The next shard. record=False: run it without keeping its instruction events (`events` comes back empty).
+        copy=False: `events` is a view of the executor's buffer, valid until the next run_shard (a full shard is 1.3 GB)."""
+        _lib.check(self.lib.sp1hip_rv64_set_recording(self.h, int(bool(record))))
         info = _lib.Rv64ShardInfo()
         _lib.check(self.lib.sp1hip_rv64_run_shard(self.h, int(max_cycles), C.byref(info)))
-        shard = ExecutedShard(info, self._matrix(self.lib.sp1hip_rv64_events(self.h), info.n_events, EV_WORDS),
+        n_events = info.n_events if record else 0
+        shard = ExecutedShard(info, self._matrix(self.lib.sp1hip_rv64_events(self.h), n_events, EV_WORDS, copy),
                               self._matrix(self.lib.sp1hip_rv64_local_memory(self.h), info.n_local, 5),
                               self._matrix(self.lib.sp1hip_rv64_keccak_events(self.h), info.n_keccak, KECCAK_WORDS))
         self.halted = shard.halted
