@@ -7,15 +7,17 @@ One "step" = `sp1hip_prove_shard` = `ShardProver::prove_shard_with_data`
 zerocheck -> jagged evaluation proof (jagged sumcheck, jagged-eval, stacked BaseFold opening, 124 queries, 16-bit PoW);
 the output is a complete bincode(ShardProof) that the pinned verifier accepts (tests/test_gpu_shard.py).
 
-Workload (`config.workload`, round 4): the core shard of REAL RISC-V chips (bench/core_real.py): the 30 rv64im chips
-transcribed from the reference's `Air::eval` bodies (sp1_amd/machines/riscv.py — every chip of the reference's recorded
-core shard 0 except DivRem and the two syscall chips, 48 rows together) at that shard's recorded heights (3.7e8 trace cells against
-3.74e8 recorded; Global and MemoryLocal 0.96x, Program 1.55x — see bench/core_real.py — max_log_row_count 22, stacking
-height 2^21), on traces of an EXECUTED rv64im program (sp1_amd/machines/riscv_trace.py: 6.2e6 instructions, lookups balanced). `synthetic_core_shaped` carries the round-1..3 workload (bench/core_shard.py) for
-continuity. The reference defines its headline "Core kHz" as cycles / core-proving seconds
-(/root/reference/sp1-gpu/crates/perf/src/report.rs:L52-L60); `config.instructions_executed` is the number of RISC-V
-instructions this shard proves (`riscv_instructions_per_s` rides along: the executor here is this repository's test
-executor, not SP1's, so it is NOT quoted as Core kHz), `value` stays trace CELLS proved per second.
+Workload (`config.workload`, default since round 5): a FULL CORE SHARD OF THE REFERENCE'S `fibonacci` GUEST — the program
+BASELINE.json's metric is quoted on — executed by the rv64im executor of libsp1hip.so (sp1_amd/csrc/rv64_exec.cpp) and traced
+by sp1_amd/machines/riscv_exec.py: 2^23 executed cycles (the power of two below the 8.8e6 cycles at which the reference's area
+threshold of 2^28 + 2^27 cells cuts a fibonacci shard: bench/program_shard.py), 4.1e8 trace cells, every chip a real chip of
+the RISC-V machine with the constraints and interactions transcribed from the reference's `Air::eval` bodies, the shard's own
+public values. `value` = RISC-V CYCLES PROVED PER SECOND, the reference's "Core kHz" x 1000
+(/root/reference/sp1-gpu/crates/perf/src/report.rs:L52-L60: cycles / core-proving seconds); `cells_per_s` rides along.
+`--workload loop|keccak` are the other guests of the reference's perf harness this executor runs. The earlier workloads stay:
+`--workload real` (rounds 4-5: the RISC-V chips at the heights of the reference's recorded core shard 0, bench/core_real.py, on
+traces of a synthetic rv64im loop executed by riscv_trace.py; `value` = cells/s), `precompile` (a Keccak precompile shard),
+`core` (rounds 1-3: synthetic constraints on the recorded widths).
 
 Usage: python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run, shards striped
 one per rank, no data-path collective). Prints ONE JSON line on rank 0; see DESIGN.md §8 for every field.
@@ -167,6 +169,7 @@ def cpu_sample(api, scale_log2, cores, kind="real"):
     r = json.loads(out.strip().splitlines()[-1])
     r["cells"] = meta["area_cells"]
     r["cells_per_s"] = meta["area_cells"] / r["seconds"]
+    r["cycles"] = meta.get("cycles")
     r["max_log_row_count"] = L
     return r
 
@@ -179,7 +182,10 @@ def cpu_baseline(api, scale_log2, kind="real"):
     cores = effective_cores()
     big = cpu_sample(api, scale_log2, cores, kind)
     small = cpu_sample(api, scale_log2 + 1, cores, kind)
-    return {"value": big["cells_per_s"], "unit": "cells/s", "cores": cores, "kind": "port",
+    # the same unit as `value`: cycles/s for a guest program's shard, cells/s otherwise
+    head = ({"value": big["cycles"] / big["seconds"], "unit": "cycles/s", "cycles": big["cycles"], "cells_per_s": big["cells_per_s"]}
+            if kind in PROGRAMS else {"value": big["cells_per_s"], "unit": "cells/s"})
+    return {**head, "cores": cores, "kind": "port",
             "stage_seconds": {k: round(v, 3) for k, v in big["stage_seconds"].items()},
             "seconds": round(big["seconds"], 2), "cells": big["cells"], "sample_fraction": "1/%d" % (1 << (2 * scale_log2)),
             "simd": "AVX-512 leaf hash / Merkle compress (16 permutations per register) and RS-encode butterflies (16 columns) in the oracle's own "
@@ -524,8 +530,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="real", choices=["real", "core", "precompile"] + list(PROGRAMS),
-                    help="real: the RISC-V chips at the recorded core shard's heights (bench/core_real.py); core: the synthetic "
+    ap.add_argument("--workload", default="fibonacci", choices=["real", "core", "precompile"] + list(PROGRAMS),
+                    help="fibonacci | loop | keccak: a full core shard of that guest of the reference's perf harness (bench/program_shard.py; "
+                         "value = cycles/s); real: the RISC-V chips at the recorded core shard's heights (bench/core_real.py); core: the synthetic "
                          "core-shaped shard of rounds 1-3 (bench/core_shard.py); precompile: a Keccak precompile shard, 82 %% of its "
                          "area in the 2,640-column KeccakPermute chip (bench/precompile_shard.py)")
     ap.add_argument("--scale-log2", type=int, default=0, help="prove a shard of area CORE >> 2k (testing aid; the bench line is k = 0)")
@@ -742,7 +749,7 @@ def main():
         # PMC table of THIS round (bench/pmc_traffic.sh -> profiles/r05_traffic.json, r05_traffic_precompile.json): HBM bytes and
         # SQ_INSTS_VALU per proof for every kernel group; the roofline fractions below are (table or live value) / (live time) / peak
         pmc, pmc_note = {}, "no committed PMC table for this workload"
-        for fn in ("r05_traffic.json", "r05_traffic_precompile.json", "r04_traffic.json"):
+        for fn in ("r05_traffic_%s.json" % kind, "r05_traffic.json", "r05_traffic_precompile.json", "r04_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tt = json.load(f)
