@@ -887,7 +887,9 @@ def main():
             "real_machine": extras.get("real_machine"),
             "synthetic_core_shaped": extras.get("synthetic_core_shaped"),
             "in_flight": extras.get("in_flight"),
-            "value_pipelined": max((v["cells_per_s"] for v in extras["in_flight"]["slots"].values()), default=None) if extras.get("in_flight") else None,
+            # the best of the in-flight runs, in the unit of `value`
+            "value_pipelined": (max((v["cells_per_s"] for v in extras["in_flight"]["slots"].values()), default=None)
+                                * (meta["cycles"] / area if kind in PROGRAMS else 1.0)) if extras.get("in_flight") else None,
             "commit_only": extras.get("commit_only"),
         }
         result_out.write(json.dumps(out) + "\n")
