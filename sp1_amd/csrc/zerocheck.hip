@@ -85,6 +85,13 @@ constexpr uint32_t ZC_ADDC = 10, ZC_SUBC = 11, ZC_CSUB = 12, ZC_MULC = 13;
 // register, c; ZC_A_PREV: term = previous value, ZC_B_PREV: acc = previous value.
 constexpr uint32_t ZC_MADC = 14;
 constexpr uint32_t ZC_RSUB = 15;           // b - a: a SUB whose forwarded operand is the subtrahend (register allocation, host)
+// acc + a * b / acc - a * b: a MUL whose single use is the ADD / SUB that is the next value-producing instruction (host peephole in
+// allocate_registers, like MADC). The sums of products real chips are made of (MulOperation: 136 byte products in 16 chains) are
+// emitted term by term with the running sum as the previous value, so a chain becomes MUL, MAD, MAD, ... with the sum FORWARDED:
+// two LDS reads per term and no write, instead of a MUL (two reads) and an ADD (a read and a write) — and half the decodes.
+// Word: op | flags, dst | (acc register << 16), a, b; ZC_B_PREV: acc = previous value (a, b from the file); else ZC_A_PREV: a =
+// previous value.
+constexpr uint32_t ZC_MAD = 16, ZC_MSB = 17;
 constexpr uint32_t ZC_MONO_MIN_TERMS = 1024; // rounds with at least this many row pairs run a chip's program in ONE piece
 constexpr uint32_t ZC_CHUNK_LIMIT = 96;    // target instructions per chunk (host-side program splitting)
 constexpr uint32_t ZC_CHUNK_HARD_MAX = 320; // a chunk may grow to this while its asserts share most of their cones
@@ -264,6 +271,17 @@ __device__ __forceinline__ kb::Ext run_program(RegFile<(BIV ? false : FIRST), MA
                 if (!(opw & ZC_A_PREV)) prev = reg.get(x);
                 res = K::add(accv, KCc::mulc(prev, y));
             }
+        } else if (op == ZC_MAD || op == ZC_MSB) {
+            T accv;
+            if (opw & ZC_B_PREV) {                                    // the running sum is the forwarded value
+                accv = prev;
+                prev = reg.get(x);
+            } else {
+                accv = reg.get(dst >> 16);
+                if (!(opw & ZC_A_PREV)) prev = reg.get(x);
+            }
+            const T m = K::mul(prev, reg.get(y));
+            res = op == ZC_MAD ? K::add(accv, m) : K::sub(accv, m);
         } else if (op == ZC_CONST) {
             res = K::from_f(x);                                       // host pre-converts to Montgomery
         } else if (op == ZC_PUBLIC) {
@@ -1190,14 +1208,21 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
     std::vector<char> fused(n, 0);
     std::vector<int> fused_src(n, -1);         // for the user: the MULC it absorbs
     static const bool madc_enabled = [] { const char* e = getenv("SP1HIP_ZC_MADC"); return !(e && e[0] == '0'); }();
-    if (madc_enabled)
+    static const bool mad_enabled = [] { const char* e = getenv("SP1HIP_ZC_MAD"); return !(e && e[0] == '0'); }();
+    if (madc_enabled || mad_enabled)
         for (uint32_t k = 0; k + 1 < n; k++) {
-            if (ssa[3 * k] != ZC_MULC || n_uses[k] != 1) continue;
+            const bool is_mulc = ssa[3 * k] == ZC_MULC && madc_enabled;
+            const bool is_mul = ssa[3 * k] == ZC_MUL && mad_enabled && ssa[3 * k + 1] != ssa[3 * k + 2];
+            if (!(is_mulc || is_mul) || n_uses[k] != 1) continue;
             uint32_t u = k + 1;
             while (u < n && ssa[3 * u] == ZC_ASSERT_ZERO) u++;
             if (u >= n || fused_src[u] >= 0) continue;
             const uint32_t uop = ssa[3 * u], ua = ssa[3 * u + 1], ub = ssa[3 * u + 2];
             if (ua == ub) continue;
+            if (is_mul) {                      // the other summand must not be one of the factors (it may live in `prev` only)
+                const uint32_t other = ua == k ? ub : ua;
+                if (other == ssa[3 * k + 1] || other == ssa[3 * k + 2]) continue;
+            }
             if ((uop == ZC_ADD && (ua == k || ub == k)) || (uop == ZC_SUB && ub == k)) { fused[k] = 1; fused_src[u] = (int)k; }
         }
     {   // next_val[k]: the first value-producing (emitted) instruction after k
@@ -1243,6 +1268,35 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
         if (group_len[k] == 0) continue;       // merged into the group's first LOAD
         if (fused[k]) continue;                // emitted with its user
         uint32_t word = op, ra = a, rb = b;
+        if (fused_src[k] >= 0 && ssa[3 * fused_src[k]] == ZC_MUL) {      // acc +- (x * y)  ->  MAD / MSB
+            const uint32_t m = (uint32_t)fused_src[k], acc = a == m ? b : a;
+            uint32_t fx = ssa[3 * m + 1], fy = ssa[3 * m + 2];
+            uint32_t racc = 0, rx = 0, ry = 0;
+            word = op == ZC_SUB ? ZC_MSB : ZC_MAD;
+            if ((int)acc == last_value) word |= ZC_B_PREV;
+            else {
+                racc = reg_of[acc];
+                if ((int)fy == last_value) std::swap(fx, fy);        // the forwarded factor must be the first one
+                if ((int)fx == last_value) word |= ZC_A_PREV;
+            }
+            if (!(word & ZC_A_PREV)) rx = reg_of[fx];
+            ry = reg_of[fy];
+            if ((!(word & ZC_A_PREV) && rx == 0xffffffffu) || ry == 0xffffffffu || (!(word & ZC_B_PREV) && racc == 0xffffffffu)) {
+                set_error("internal: operand of fused multiply-add %u has no register", k);
+                return SP1HIP_ERROR_RUNTIME;
+            }
+            if (word & ZC_A_PREV) rx = 0;
+            for (uint32_t f : {fx, fy})
+                if (last_use[f] == (int)m && reg_of[f] != 0xffffffffu) { busy[reg_of[f]] = 0; reg_of[f] = 0xffffffffu; }
+            if (last_use[acc] == (int)k && reg_of[acc] != 0xffffffffu) { busy[reg_of[acc]] = 0; reg_of[acc] = 0xffffffffu; }
+            uint32_t dst = 0;
+            if (is_temp(k) || n_uses[k] == 0) word |= ZC_DST_TEMP;
+            else { dst = take(1); reg_of[k] = dst; }
+            if (dst > 0xffffu || racc > 0xffffu) { set_error("constraint program needs more than 65536 registers"); return SP1HIP_ERROR_RUNTIME; }
+            last_value = (int)k;
+            out->insert(out->end(), {word, dst | (racc << 16), rx, ry});
+            continue;
+        }
         if (fused_src[k] >= 0) {               // acc +- (term * c)  ->  MADC
             const uint32_t m = (uint32_t)fused_src[k], term = ssa[3 * m + 1], acc = a == m ? b : a;
             const uint32_t c = kb::to_monty(ssa[3 * m + 2] % kb::P);
@@ -1458,6 +1512,8 @@ static void eval_words_row(const uint32_t* words, size_t n, uint32_t n_regs, con
             case ZC_CSUB: res = kb::sub(y, A); break;
             case ZC_MULC: res = kb::mul(A, y); break;
             case ZC_MADC: res = kb::add((opw & ZC_B_PREV) ? prev : reg[dst >> 16], kb::mul(A, y)); break;
+            case ZC_MAD: res = kb::add((opw & ZC_B_PREV) ? prev : reg[dst >> 16], kb::mul(A, reg[y])); break;
+            case ZC_MSB: res = kb::sub((opw & ZC_B_PREV) ? prev : reg[dst >> 16], kb::mul(A, reg[y])); break;
             default: on_assert(y, A); continue;
         }
         prev = res;
