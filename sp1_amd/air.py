@@ -108,6 +108,13 @@ class AirProgram:
         assert 0 <= base_col and base_col + 2640 <= self.main_width
         self.instrs.append((HINT, 5, base_col))
 
+    def hint_mul(self, mul_col, op_b_col):
+        """The 16 asserts that follow are MulOperation's product constraints (operations/mul.rs:L196-L236): is_real * (product[k] -
+        (m[k] + carry[k - 1] - 256 carry[k])) for the `MulOperation` struct at main columns [mul_col, +45), the chip's five opcode
+        flags right behind it (is_real = their sum), the 16-bit limbs of b at [op_b_col, +4) and those of c at [op_b_col + 7, +4)."""
+        assert 0 <= mul_col and mul_col + 50 <= self.main_width and 0 <= op_b_col and op_b_col + 11 <= self.main_width
+        self.instrs.append((HINT, 6 | (op_b_col << 8), mul_col))
+
     def assert_zero(self, e):
         self._emit(ASSERT_ZERO, e.idx, 0)
         self.num_constraints += 1

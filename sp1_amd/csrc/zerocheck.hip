@@ -35,6 +35,7 @@
 #include "zc_device.hpp"
 #include "zc_poseidon2.hpp"
 #include "zc_keccak.hpp"
+#include "zc_mul.hpp"
 
 namespace sp1hip {
 
@@ -478,7 +479,7 @@ constexpr uint32_t ZC_DESC_MACRO = 2u;
 // KIND of a launch that carries the pieces of BOTH septic kinds (they are adjacent block ranges; the kind comes from the descriptor): in
 // the small rounds every launch is at its latency floor and the two septic launches would share a hardware queue (a process has four)
 constexpr uint32_t ZC_MACRO_BOTH_SEPTIC = 4u;
-constexpr uint32_t ZC_MACRO_KINDS = 6;        // kinds 1..3, the launch shape 4, Keccak = 5
+constexpr uint32_t ZC_MACRO_KINDS = 7;        // kinds 1..3, the launch shape 4, Keccak = 5, MulOperation products = 6
 template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
                                                        uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict_
         auto emit = [&](const kb::Ext& v) { va = kb::ext_add(va, v); };
         if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<F>(q, rc, ld, sink);
         else if constexpr (KIND == ZC_HINT_KECCAK) zc_keccak_piece<F>(q, ld, sink);
+        else if constexpr (KIND == ZC_HINT_MUL) zc_mul_piece<F>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); }, sink);
         else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece_w<F, K>(q, ld, alpha, emit);
         else if (KIND == ZC_MACRO_BOTH_SEPTIC && ((d.flags >> 12) & 15u) == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece_w<F, K>(q, ld, alpha, emit);   // (wave-uniform)
         else zc_septic_sum_piece_w<F, K>(q, ld, [&](uint32_t c, bool owned) -> T { return ld_at(d.aux0 + c, owned); },
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
         auto emit = [&](const kb::Ext& v) { va = kb::ext_add(va, v); };
         if constexpr (KIND == ZC_HINT_POSEIDON2) zc_p2_piece<P2Base>(q, rc, ld, sink);
         else if constexpr (KIND == ZC_HINT_KECCAK) zc_keccak_piece<P2Base>(q, ld, sink);
+        else if constexpr (KIND == ZC_HINT_MUL) zc_mul_piece<P2Base>(q, ld, [&](uint32_t c, bool owned) -> uint32_t { return ld_at(d.aux0 + c, owned); }, sink);
         else if constexpr (KIND == ZC_HINT_SEPTIC_CURVE) zc_septic_curve_piece_w<P2Base, K>(q, ld, alpha, emit);
         else zc_septic_sum_piece_w<P2Base, K>(q, ld, [&](uint32_t c, bool owned) -> uint32_t { return ld_at(d.aux0 + c, owned); },
                                               [&]() -> uint32_t { return ld_at(d.aux1, false); }, alpha, emit);
@@ -1023,14 +1026,15 @@ struct DevBuf {
 
 struct ZcMacro {                 // a hinted sub-AIR: its constraints are [first_constraint, first_constraint + n_constraints())
     uint32_t kind, base_col, first_constraint, aux0 = 0, aux1 = 0;
-    uint32_t n_constraints() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_KECCAK ? ZC_KK_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
+    uint32_t n_constraints() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_KECCAK ? ZC_KK_CONSTRAINTS : kind == ZC_HINT_MUL ? ZC_MUL_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
     // pieces the kernels run (the septic kinds: weighted forms, zc_septic_*_piece_w) / pieces of the host model (per-coefficient forms)
-    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_KECCAK ? ZC_KK_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 2u : 4u; }
+    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_KECCAK ? ZC_KK_PIECES : kind == ZC_HINT_MUL ? ZC_MUL_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 2u : 4u; }
     uint32_t n_host_pieces() const { return kind == ZC_HINT_SEPTIC_CURVE ? 1u : kind == ZC_HINT_SEPTIC_SUM ? 2u : n_pieces(); }
     // the columns whose GKR-opening term the fused pieces carry: [lo, lo + n)
     void owned(uint32_t* lo, uint32_t* n) const {
         if (kind == ZC_HINT_POSEIDON2) { *lo = base_col; *n = ZC_P2_COLUMNS; }
         else if (kind == ZC_HINT_KECCAK) { *lo = base_col; *n = ZC_KK_COLUMNS; }
+        else if (kind == ZC_HINT_MUL) { *lo = base_col + MUL_CARRY; *n = ZC_MUL_OWNED; }
         else if (kind == ZC_HINT_SEPTIC_CURVE) { *lo = base_col; *n = 14; }
         else { *lo = aux0; *n = 28; }
     }
@@ -1538,6 +1542,8 @@ static void macro_eval_row(const ZcMacro& m, const uint32_t* main_row, Sink&& si
             zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
         else if (m.kind == ZC_HINT_KECCAK)
             zc_keccak_piece<P2Base>(q, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
+        else if (m.kind == ZC_HINT_MUL)
+            zc_mul_piece<P2Base>(q, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, [&](uint32_t c, bool) { return main_row[m.aux0 + c]; }, sink);
         else if (m.kind == ZC_HINT_SEPTIC_CURVE)
             zc_septic_curve_piece<P2Base>([&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
         else
@@ -1587,11 +1593,13 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                 if (clean[3 * k] == ZC_ASSERT_ZERO) asserts_before++;
                 if (clean[3 * k] != ZC_HINT) continue;
                 const uint32_t kind = clean[3 * k + 1] & 0xffu, w1 = clean[3 * k + 1] >> 8, w2 = clean[3 * k + 2];
-                SP1HIP_REQUIRE((kind >= ZC_HINT_POSEIDON2 && kind <= ZC_HINT_SEPTIC_SUM) || kind == ZC_HINT_KECCAK, "unknown hint kind in constraint program");
+                SP1HIP_REQUIRE((kind >= ZC_HINT_POSEIDON2 && kind <= ZC_HINT_SEPTIC_SUM) || kind == ZC_HINT_KECCAK || kind == ZC_HINT_MUL, "unknown hint kind in constraint program");
                 ZcMacro m{kind, kind == ZC_HINT_SEPTIC_SUM ? (w2 & 0xffffu) : w2, asserts_before};
                 if (kind == ZC_HINT_SEPTIC_SUM) { m.aux0 = w2 >> 16; m.aux1 = w1; }
-                SP1HIP_REQUIRE((uint64_t)m.base_col + (kind == ZC_HINT_POSEIDON2 ? ZC_P2_COLUMNS : kind == ZC_HINT_KECCAK ? KK_IS_REAL + 1 : 14u) <= main_width &&
-                               (kind != ZC_HINT_SEPTIC_SUM || ((uint64_t)m.aux0 + 28 <= main_width && m.aux1 < main_width)), "hint: columns out of range");
+                if (kind == ZC_HINT_MUL) m.aux0 = w1;                 // the first limb of op_b's value (op_c's: seven columns further)
+                SP1HIP_REQUIRE((uint64_t)m.base_col + (kind == ZC_HINT_POSEIDON2 ? ZC_P2_COLUMNS : kind == ZC_HINT_KECCAK ? KK_IS_REAL + 1 : kind == ZC_HINT_MUL ? MUL_COLUMNS : 14u) <= main_width &&
+                               (kind != ZC_HINT_SEPTIC_SUM || ((uint64_t)m.aux0 + 28 <= main_width && m.aux1 < main_width)) &&
+                               (kind != ZC_HINT_MUL || (uint64_t)m.aux0 + MUL_OPC_FROM_OPB + 4 <= main_width), "hint: columns out of range");
                 np->macros.push_back(m);
                 clean[3 * k] = ZC_CONST; clean[3 * k + 1] = 0; clean[3 * k + 2] = 0;
             }
@@ -1673,7 +1681,11 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                 uint32_t n_seen = 0;
                 macro_eval_row(m, row.data(), [&](uint32_t j, uint32_t v) {
                     n_seen++;
-                    ok &= (m.first_constraint + j < want.size() && want[m.first_constraint + j] == v);
+                    const bool same = m.first_constraint + j < want.size() && want[m.first_constraint + j] == v;
+                    if (!same && zc_debug)
+                        fprintf(stderr, "[sp1hip zc] hint kind %u: constraint %u + %u: pieces give %08x, the program %08x\n", m.kind, m.first_constraint, j,
+                                v, m.first_constraint + j < want.size() ? want[m.first_constraint + j] : 0u);
+                    ok &= same;
                 });
                 SP1HIP_REQUIRE(ok && n_seen == m.n_constraints(), "a fused-kernel hint does not match the constraints it annotates");
             }
@@ -2299,6 +2311,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 3)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 3)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(6u, 1)
                 if (rp.macro_n[ZC_HINT_KECCAK]) {          // four nodes per pass: three node-group workgroups per block
                     hipLaunchKernelGGL(zc_biv_keccak_kernel, dim3(rp.macro_n[ZC_HINT_KECCAK] * ZC_BIV_GROUPS), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_KECCAK]);
                     SP1HIP_LAUNCH_CHECK();
@@ -2472,7 +2485,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             struct Launch { int kind; size_t group; double est; int slot; };           // kind 0: interpreter group, 1..3: fused pieces
             std::vector<Launch> order;
             {
-                static const double floor_us[ZC_MACRO_KINDS] = {45.0, 75.0, 45.0, 60.0, 60.0, 120.0};
+                static const double floor_us[ZC_MACRO_KINDS] = {45.0, 75.0, 45.0, 60.0, 60.0, 120.0, 45.0};
                 for (size_t g = 0; g < groups.size(); g++) order.push_back({0, g, floor_us[0] * (1.0 + groups[g].n_blocks * 3 / 1024.0), 0});
                 const bool both_septic = forked && r > 0 && macro_n[2] && macro_n[3] && (uint64_t)total_blocks * 3 <= ZC_SMALL_ROUND_WGS;
                 for (int kind = 1; kind <= 3; kind++) {
@@ -2481,6 +2494,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     else order.push_back({kind, 0, floor_us[kind] * (1.0 + macro_n[kind] * 3 / 1024.0), 0});
                 }
                 if (macro_n[ZC_HINT_KECCAK]) order.push_back({(int)ZC_HINT_KECCAK, 0, floor_us[ZC_HINT_KECCAK] * (1.0 + macro_n[ZC_HINT_KECCAK] * 3 / 1024.0), 0});
+                if (macro_n[ZC_HINT_MUL]) order.push_back({(int)ZC_HINT_MUL, 0, floor_us[ZC_HINT_MUL] * (1.0 + macro_n[ZC_HINT_MUL] * 3 / 1024.0), 0});
                 if (forked) {
                     std::stable_sort(order.begin(), order.end(), [](const Launch& a, const Launch& b) { return a.est > b.est; });
                     double load[N_FORK + 1] = {0, 7, 14, 21};          // (the launches leave the host ~7 us apart)
@@ -2525,6 +2539,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_MACRO_LAUNCH(1u)
                 SP1HIP_ZC_MACRO_LAUNCH(2u)
                 SP1HIP_ZC_MACRO_LAUNCH(3u)
+                SP1HIP_ZC_MACRO_LAUNCH(6u)
                 if (ln.kind == (int)ZC_HINT_KECCAK) {
                     const bool keccak3 = [] { const char* e = getenv("SP1HIP_ZC_KECCAK3"); return e && e[0] == '1'; }();   // (read per call: tests run both)
                     if (r == 0) hipLaunchKernelGGL((zc_macro_kernel<true, 5u>), dim3(macro_n[5] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5], dctx->d_rc);

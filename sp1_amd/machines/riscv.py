@@ -330,7 +330,7 @@ def eval_lt_signed(b, x, y, c, is_signed, is_real):                        # ope
     eval_lt_unsigned(b, xc, yc, c.result, is_real)
 
 
-def eval_mul(b, a, x, y, c, is_real, is_mul, is_mulh, is_mulw, is_mulhu, is_mulhsu):      # operations/mul.rs:L140-L302
+def eval_mul(b, a, x, y, c, is_real, is_mul, is_mulh, is_mulw, is_mulhu, is_mulhsu, hint_products=None):   # operations/mul.rs:L140-L302
     xb = u16_to_u8_safe(b, x, c.b_lower_byte.low_bytes, is_real)
     yb = u16_to_u8_safe(b, y, c.c_lower_byte.low_bytes, is_real)
     for msb, byte in ((c.b_msb, xb[7]), (c.c_msb, yb[7])):
@@ -345,6 +345,8 @@ def eval_mul(b, a, x, y, c, is_real, is_mul, is_mulh, is_mulw, is_mulhu, is_mulh
         for j in range(16):
             if i + j < 16:
                 m[i + j] = m[i + j] + xe[i] * ye[j]
+    if hint_products is not None:          # the chip tells a prover that the next 16 asserts are these products (air.hint_mul)
+        hint_products()
     for i in range(16):
         if i == 0:
             b.when(is_real).assert_eq(c.product[i], m[i] - c.carry[i] * (1 << 8))
@@ -487,8 +489,10 @@ def mul_chip():
     L = S(("state", CPU_STATE), ("adapter", R_TYPE), ("a", 4), ("mul", MUL_OP), ("is_mul", 1), ("is_mulh", 1), ("is_mulhu", 1),
           ("is_mulhsu", 1), ("is_mulw", 1))(c)
     is_real = L.is_mul + L.is_mulh + L.is_mulhu + L.is_mulhsu + L.is_mulw
+    # MulCols is #[repr(C)]: the MulOperation struct, then the five flags whose sum is is_real (alu/mul/mod.rs:L41-L68)
+    hint = lambda: b.air.hint_mul(c.names["mul.carry"], c.names["adapter.op_b_memory.prev_value"])
     eval_mul(b, L.a, L.adapter.op_b_memory.prev_value, L.adapter.op_c_memory.prev_value, L.mul, is_real, L.is_mul, L.is_mulh,
-             L.is_mulw, L.is_mulhu, L.is_mulhsu)
+             L.is_mulw, L.is_mulhu, L.is_mulhsu, hint_products=hint)
     for x in (L.is_mul, L.is_mulh, L.is_mulhu, L.is_mulw, L.is_mulhsu, is_real):
         b.assert_bool(x)
     opcode = (L.is_mul * OPC["MUL"] + L.is_mulh * OPC["MULH"] + L.is_mulhu * OPC["MULHU"] + L.is_mulhsu * OPC["MULHSU"]
