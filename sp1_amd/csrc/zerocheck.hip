@@ -1048,6 +1048,7 @@ struct Chunk {
 struct ZcPlan {                      // everything that depends on a chip's program only (cached per process)
     uint32_t n_instr = 0, main_w = 0, prep_w = 0;
     bool macros_enabled = true;      // SP1HIP_ZC_MACRO when the plan was made (part of the cache key)
+    bool mul_enabled = true;         // whether the MulOperation hints are honoured (the chip's height, see zc_get_plan)
     std::vector<uint32_t> source;    // the caller's [n][3] program (collision check)
     std::vector<uint32_t> prog;      // allocated [n][4], whole program (padded-row evaluation)
     uint32_t n_regs = 1;
@@ -1561,13 +1562,19 @@ static uint32_t asserts_total(const uint32_t* program, uint32_t n) {
 // The plan of a program (immediates folded, instruction order chosen, registers allocated; chunked, undivided and finely
 // cut forms) depends on the program alone: a machine's chips are planned once per process and looked up afterwards (a
 // prover proves the same machine shard after shard; planning 33 chips costs ~1.3 ms of host time per proof).
+// `rows`: the chip's height in this proof. The MulOperation piece (kind 6) replaces interpreter work that grows with the height by
+// one more launch per round: below ZC_MUL_MIN_ROWS rows (SP1HIP_ZC_MUL_MIN_ROWS) that launch sits at its latency floor in every
+// round and the hint is ignored — the recorded core shard has 128 Mul rows, a fibonacci shard 1.9 million.
+constexpr uint64_t ZC_MUL_MIN_ROWS = 1u << 16;
 static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width, int chip_index,
-                       std::shared_ptr<const ZcPlan>* out) {
+                       std::shared_ptr<const ZcPlan>* out, uint64_t rows = ~0ull) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint32_t v) { h = (h ^ v) * 1099511628211ull; };
     // SP1HIP_ZC_MACRO=0 ignores hints; read per call like the BIVARIATE / FORK switches and part of the cache key
     const bool macros_enabled = [] { const char* e = getenv("SP1HIP_ZC_MACRO"); return !(e && e[0] == '0'); }();
-    mix(main_width); mix(prep_width); mix(n_instr); mix(macros_enabled ? 1u : 0u);
+    const uint64_t mul_min_rows = [] { const char* e = getenv("SP1HIP_ZC_MUL_MIN_ROWS"); return e ? (uint64_t)strtoull(e, nullptr, 10) : ZC_MUL_MIN_ROWS; }();
+    const bool mul_enabled = macros_enabled && rows >= mul_min_rows;
+    mix(main_width); mix(prep_width); mix(n_instr); mix((macros_enabled ? 1u : 0u) | (mul_enabled ? 2u : 0u));
     for (size_t k = 0; k < (size_t)n_instr * 3; k++) mix(program[k]);
     static std::mutex plan_mutex;
     static std::unordered_map<uint64_t, std::shared_ptr<const ZcPlan>> plan_cache;
@@ -1576,12 +1583,12 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         std::lock_guard<std::mutex> lk(plan_mutex);
         auto it = plan_cache.find(h);
         if (it != plan_cache.end() && it->second->n_instr == n_instr && it->second->main_w == main_width && it->second->prep_w == prep_width &&
-            it->second->macros_enabled == macros_enabled && (n_instr == 0 || memcmp(it->second->source.data(), program, (size_t)n_instr * 12) == 0))
+            it->second->macros_enabled == macros_enabled && it->second->mul_enabled == mul_enabled && (n_instr == 0 || memcmp(it->second->source.data(), program, (size_t)n_instr * 12) == 0))
             plan = it->second;
     }
     if (!plan) {
         std::shared_ptr<ZcPlan> np(new ZcPlan());
-        np->n_instr = n_instr; np->main_w = main_width; np->prep_w = prep_width; np->macros_enabled = macros_enabled;
+        np->n_instr = n_instr; np->main_w = main_width; np->prep_w = prep_width; np->macros_enabled = macros_enabled; np->mul_enabled = mul_enabled;
         np->source.assign(program, program + (size_t)n_instr * 3);
         // hinted sub-AIRs (zc_poseidon2.hpp): the HINT pseudo-instructions become harmless constants, the hints are CHECKED
         // against the SSA, and the asserts they cover leave the interpreted forms (not the whole program `prog`, which the
@@ -1604,6 +1611,7 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                 clean[3 * k] = ZC_CONST; clean[3 * k + 1] = 0; clean[3 * k + 2] = 0;
             }
             if (!macros_enabled) np->macros.clear();
+            if (!mul_enabled) np->macros.erase(std::remove_if(np->macros.begin(), np->macros.end(), [](const ZcMacro& m) { return m.kind == ZC_HINT_MUL; }), np->macros.end());
             // each hint is checked against the SSA on its own (below); two hints that overlap — a duplicated HINT, two sum
             // checkers sharing accumulator columns — would each pass and then count their constraints and the GKR batching
             // term of their columns twice: a silently invalid proof. Constraint ranges and owned columns must be disjoint.
@@ -1873,7 +1881,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         SP1HIP_REQUIRE(asserts == chips[i].num_constraints, "num_constraints does not match the program");
         {
             std::shared_ptr<const ZcPlan> plan;
-            SP1HIP_TRY(zc_get_plan(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, i, &plan));
+            SP1HIP_TRY(zc_get_plan(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, i, &plan, chips[i].real_rows));
             c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono; c->fine = plan->fine;
             c->macros = plan->macros;
         }

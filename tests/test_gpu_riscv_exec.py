@@ -66,7 +66,8 @@ def prove_both(api, machine, tabs, publics, L, lsh, batch, LB, NQ, PW, verify=Tr
     ("fibonacci", [struct.pack("<Q", 300)], 3000, ["core", "core", "core", "memory"]),
     ("keccak", [bytes(300)], 6000, ["core", "core", "keccak", "memory"]),
 ])
-def test_every_shard_of_a_real_program_matches_the_oracle(api, program, stdin, max_cycles, kinds):
+def test_every_shard_of_a_real_program_matches_the_oracle(api, program, stdin, max_cycles, kinds, monkeypatch):
+    monkeypatch.setenv("SP1HIP_ZC_MUL_MIN_ROWS", "0")                    # the fused MulOperation piece on these small tables too
     ex = X.Executor(_elf(program), stdin=stdin)
     seen, gevs = [], []
     for kind, machine, tabs, publics, gev, sh in X.program_shards(ex, max_cycles, device="cuda"):
@@ -77,8 +78,12 @@ def test_every_shard_of_a_real_program_matches_the_oracle(api, program, stdin, m
     assert not X.global_events_balance(gevs)
 
 
-def test_a_fibonacci_shard_with_production_parameters_matches_the_oracle(api):
-    """2^18 cycles of the reference's fibonacci guest (1.3e7 trace cells), blowup 4, 124 queries, 16-bit PoW."""
+@pytest.mark.parametrize("mul_min_rows", ["0", None])
+def test_a_fibonacci_shard_with_production_parameters_matches_the_oracle(api, mul_min_rows, monkeypatch):
+    """2^18 cycles of the reference's fibonacci guest (1.3e7 trace cells), blowup 4, 124 queries, 16-bit PoW — with the fused
+    MulOperation piece forced on (it is honoured from 2^16 Mul rows; this shard has 58k) and with the default rule."""
+    if mul_min_rows is not None:
+        monkeypatch.setenv("SP1HIP_ZC_MUL_MIN_ROWS", mul_min_rows)
     ex = X.Executor(_elf("fibonacci"), stdin=[struct.pack("<Q", 40000)])
     sh = ex.run_shard(1 << 18)
     assert sh.cycles == 1 << 18 and not sh.halted
