@@ -13,6 +13,7 @@
 //                                    initial memory: timestamp 0), vm/syscall/{halt,commit,deferred}.rs; unconstrained blocks
 //                                    run without a trace and are rolled back (minimal/arch/portable/mod.rs:L258-L280)
 //   Keccak precompile                vm/syscall/precompiles/keccak256/permute.rs (reads at clk, writes at clk + 1)
+//   Poseidon2 precompile             vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs (eight words rewritten at clk)
 //   per-shard local memory events    tracing.rs:L548-L577, L1490-L1515 (first / last access of every address touched in the shard)
 // User mode (page protection, untrusted programs), the trap context and the other precompiles are not implemented: an ELF that
 // needs them stops with an error naming the system call.
@@ -27,6 +28,7 @@
 
 #include "../../include/sp1hip.h"
 #include "common.hpp"
+#include "kb31.hpp"
 
 namespace {
 
@@ -40,7 +42,7 @@ struct Instr { uint32_t op; uint32_t a; uint64_t b, c; bool imm_b, imm_c; };
 
 constexpr uint64_t HALT_PC = 1, CLK_INC = 8, ECALL_EXTRA = 256;
 constexpr uint64_t SYS_HALT = 0x00, SYS_WRITE = 0x02, SYS_ENTER_UNC = 0x03, SYS_EXIT_UNC = 0x04, SYS_KECCAK = 0x00010109,
-                   SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
+                   SYS_POSEIDON2 = 0x00000133, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
 constexpr uint64_t FD_PUBLIC_VALUES = 13, FD_HINT = 14;
 
 Instr decode(uint32_t w) {
@@ -147,6 +149,7 @@ struct Vm {
     std::vector<uint64_t> events;                                      // [n][EV]
     std::vector<uint64_t> local;                                       // [m][5]: addr, initial ts, initial value, (final ts, final value)
     std::vector<uint8_t> local_closed;
+    std::vector<uint64_t> poseidon2;                                   // POSEIDON2 events: [k][clk, pointer, 8 x (previous timestamp, word read), 8 words written]
     std::vector<uint64_t> precompile;                                  // Keccak events: [k][clk, pointer, 25 x (previous timestamp, word read), 25 words written]
     // the whole run
     std::vector<uint64_t> touched;                                     // [t][2]: addr, initial value (then final value, final ts)
@@ -407,6 +410,27 @@ struct Vm {
                 precompile.insert(precompile.end(), rec.begin(), rec.end());
                 break;
             }
+            case SYS_POSEIDON2: {                                      // vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs
+                if ((b & 7) || c != 0) return fail("POSEIDON2 arguments");
+                uint32_t st[16];
+                std::vector<uint64_t> rec = {clk, b};
+                for (int i = 0; i < 8; ++i) {                          // eight words = sixteen field elements, rewritten in place at clk
+                    Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i);
+                    const uint32_t lo = (uint32_t)m.val, hi = (uint32_t)(m.val >> 32);
+                    if (lo >= kb::P || hi >= kb::P) return fail("POSEIDON2 input is not a field element");
+                    st[2 * i] = kb::to_monty(lo); st[2 * i + 1] = kb::to_monty(hi);
+                    rec.push_back(m.ts); rec.push_back(m.val);
+                }
+                if (sp1hip_poseidon2_permute_host(st, 1, 1) != SP1HIP_SUCCESS) return fail("POSEIDON2 permutation failed");
+                for (int i = 0; i < 8; ++i) {
+                    Cell& m = cell(b + 8 * i);
+                    m.val = (uint64_t)kb::from_monty(st[2 * i]) | ((uint64_t)kb::from_monty(st[2 * i + 1]) << 32);
+                    m.ts = clk;
+                    rec.push_back(m.val);
+                }
+                poseidon2.insert(poseidon2.end(), rec.begin(), rec.end());
+                break;
+            }
             case SYS_EXIT_UNC: case SYS_VERIFY_PROOF: break;
             default: return fail("system call 0x%llx is not implemented", (unsigned long long)code);
             }
@@ -484,7 +508,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     if (!h || !info) { sp1hip::set_error("sp1hip_rv64_run_shard: null argument"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
-    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear();
+    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear();
     if (vm.record && max_cycles <= (1ull << 26)) vm.events.reserve((size_t)max_cycles * EV);   // one allocation, not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
@@ -492,6 +516,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
         if (!vm.step()) { sp1hip::set_error("sp1hip_rv64_run_shard: %s", vm.error.c_str()); return SP1HIP_ERROR_RUNTIME; }
     vm.finish_shard();
     info->n_cycles = vm.cycles - c0; info->n_events = vm.events.size() / EV; info->n_local = vm.local.size() / 5; info->n_keccak = vm.precompile.size() / SP1HIP_RV64_KECCAK_WORDS;
+    info->n_poseidon2 = vm.poseidon2.size() / SP1HIP_RV64_POSEIDON2_WORDS;
     info->next_pc = vm.pc; info->clk_end = vm.clk; info->halted = vm.halted; info->exit_code = vm.exit_code;
     info->shard = vm.shard++;
     info->commit_syscall = vm.commit_syscall; info->commit_deferred_syscall = vm.commit_deferred_syscall;
@@ -509,6 +534,7 @@ int sp1hip_rv64_set_recording(sp1hip_rv64_vm_t h, int on) {
 const uint64_t* sp1hip_rv64_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->events.data(); }
 const uint64_t* sp1hip_rv64_local_memory(sp1hip_rv64_vm_t h) { return ((Vm*)h)->local.data(); }
 const uint64_t* sp1hip_rv64_keccak_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->precompile.data(); }
+const uint64_t* sp1hip_rv64_poseidon2_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->poseidon2.data(); }
 
 int sp1hip_rv64_program(sp1hip_rv64_vm_t h, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table) {
     if (!h) return SP1HIP_ERROR_INVALID_ARGUMENT;

@@ -16,7 +16,7 @@ import numpy as np
 
 from .. import _lib
 
-EV_WORDS, KECCAK_WORDS = 20, 77
+EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS = 20, 77, 26
 (E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
  E_NEXT_PC, E_SPARE) = range(EV_WORDS)
 
@@ -25,9 +25,9 @@ class ExecutedShard:
     """One shard of an execution: `events` [n, 20] / `local` [m, 5] / `keccak` [k, 77] int64 arrays (two's complement images of
     the executor's u64 words) and the shard's public-value fields."""
 
-    def __init__(self, info, events, local, keccak):
+    def __init__(self, info, events, local, keccak, poseidon2):
         self.index, self.cycles = int(info.shard), int(info.n_cycles)
-        self.events, self.local, self.keccak = events, local, keccak
+        self.events, self.local, self.keccak, self.poseidon2 = events, local, keccak, poseidon2
         self.pc_start, self.next_pc = int(info.pc_start), int(info.next_pc)
         self.clk_start, self.clk_end = int(info.clk_start), int(info.clk_end)
         self.halted, self.exit_code = bool(info.halted), int(info.exit_code)
@@ -73,7 +73,8 @@ class Executor:
         n_events = info.n_events if record else 0
         shard = ExecutedShard(info, self._matrix(self.lib.sp1hip_rv64_events(self.h), n_events, EV_WORDS, copy),
                               self._matrix(self.lib.sp1hip_rv64_local_memory(self.h), info.n_local, 5),
-                              self._matrix(self.lib.sp1hip_rv64_keccak_events(self.h), info.n_keccak, KECCAK_WORDS))
+                              self._matrix(self.lib.sp1hip_rv64_keccak_events(self.h), info.n_keccak, KECCAK_WORDS),
+                              self._matrix(self.lib.sp1hip_rv64_poseidon2_events(self.h), info.n_poseidon2, POSEIDON2_WORDS))
         self.halted = shard.halted
         return shard
 
@@ -359,22 +360,30 @@ def shard_tables(executor, shard, device="cpu"):
 def program_shards(executor, max_cycles, device="cpu"):
     """Every shard of a run, in the order the reference's controller emits them: the core shards as the program executes
     (`(kind, machine, tables, publics, global events, ExecutedShard)` with kind = "core"), then one precompile shard for the
-    KECCAK_PERMUTE calls if there were any ("keccak"), then the memory shard: MemoryGlobalInit / MemoryGlobalFinalize over
+    KECCAK_PERMUTE calls and one for the POSEIDON2 calls if there were any ("keccak", "poseidon2"), then the memory shard: MemoryGlobalInit / MemoryGlobalFinalize over
     every address the run touched ("memory"). The global events of all shards cancel as a multiset: that is the statement the
     shards' septic-curve digests add up to."""
     from . import riscv_more_trace as MT
-    keccak = []
+    keccak, poseidon2 = [], []
     for shard in executor.shards(max_cycles):
         tr = EventTracer(executor, shard, device)
         machine, tables, publics = tr.build()
         if shard.keccak.shape[0]:
             keccak.append(shard.keccak)
+        if shard.poseidon2.shape[0]:
+            poseidon2.append(shard.poseidon2)
         yield "core", machine, tables, publics, tr.global_events, shard
     if keccak:
         kk = torch.as_tensor(np.concatenate(keccak), device=device)
         rd = kk[:, 2:52].reshape(-1, 25, 2)
         machine, tables, publics, gev = MT.precompile_shard_from(kk[:, 0], kk[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(), device)
         yield "keccak", machine, tables, publics, gev, None
+    if poseidon2:
+        pp = torch.as_tensor(np.concatenate(poseidon2), device=device)
+        rd = pp[:, 2:18].reshape(-1, 8, 2)
+        machine, tables, publics, gev = MT.poseidon2_shard_from(pp[:, 0], pp[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(),
+                                                               pp[:, 18:26].contiguous(), device)
+        yield "poseidon2", machine, tables, publics, gev, None
     gm = executor.global_memory()
     gm = gm[np.argsort(gm[:, 0].astype(np.uint64))]
     if gm.shape[0] == 0 or gm[0, 0] != 0:                  # register x0 opens the address chain whether or not the program read it

@@ -11,6 +11,7 @@ riscv.py — DivRem, the syscall chips, global memory initialisation / finalisat
     MemoryGlobalFinalize     30       31      memory/global.rs:L307-L474  (kind = Finalize)
     KeccakPermute          2640     2859      syscall/precompiles/keccak256/air.rs:L29-L200
     KeccakPermuteControl    634      331      syscall/precompiles/keccak256/controller.rs:L243-L398
+    Poseidon2               348      497      syscall/precompiles/poseidon2/air.rs:L424-L607
 
 Same method and the same pins as riscv.py: every `eval` (Supervisor mode, `mprotect` off) transcribed operation by operation in
 the reference's call order against the recording builder; column counts == rv64im_costs.json, `assert_zero` counts ==
@@ -31,6 +32,7 @@ from .riscv import (ADDRESS_OP, ALU_TYPE, B_LTU, B_RANGE, B_U8RANGE, BYTE, CLK_I
 KECCAK, MEMORY_GLOBAL_INIT_CONTROL, MEMORY_GLOBAL_FINALIZE_CONTROL = 12, 14, 15         # hypercube/src/lookup/interaction.rs:L53-L62
 # SyscallCode (core/executor/src/syscall_code.rs:L48-L105): byte 0 = syscall id, byte 1 = "has its own table"
 SYS_HALT, SYS_ENTER_UNCONSTRAINED, SYS_COMMIT, SYS_COMMIT_DEFERRED_PROOFS, SYS_HINT_LEN, SYS_KECCAK_PERMUTE = 0x00, 0x03, 0x10, 0x1A, 0xF0, 0x09
+SYS_POSEIDON2 = 0x33
 HALT_PC = 1                                                                              # core/executor/src/lib.rs:L100
 U16_MAX = 0xFFFF
 
@@ -461,7 +463,42 @@ def keccak_control_chip():                                                      
     return _done(b, c)
 
 
+def poseidon2_chip():                                                                     # syscall/precompiles/poseidon2/air.rs:L424-L607
+    """The POSEIDON2 precompile: eight u64 words at `ptr` (sixteen field elements, low half first) are read and rewritten in place
+    by one KoalaBear Poseidon2 permutation — the same `Poseidon2Operation` sub-AIR as the Global chip's (hinted for a fused kernel)."""
+    from .recursion import P2_EXT, P2_OUT, P2_WIDTH, poseidon2_permutation_constraints
+    b, c, _ = _chip("Poseidon2", 348)
+    L = S(("clk_high", 1), ("clk_low", 1), ("ptr", SYSCALL_ADDR), ("addrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(8)]),
+          ("memory", lambda c_, p: [MEM_ACCESS(c_, p + "%d." % i) for i in range(8)]),
+          ("hash_result", lambda c_, p: [c_.arr(4, p + "%d" % i) for i in range(8)]), ("hash_result_range_checkers", 16),
+          ("input_range_checkers", 16), ("permutation", P2_WIDTH), ("is_real", 1))(c)
+    ptr = eval_syscall_addr(b, 64, L.ptr, L.is_real)
+    for i in range(8):
+        eval_addr_add(b, list(ptr) + [b.const(0)], word_of_u64(8 * i), L.addrs[i].value, L.is_real)
+    for i in range(8):                                                                    # eval_memory_access_slice_write (air/memory.rs)
+        eval_memory_access(b, L.clk_high, L.clk_low, L.addrs[i].value, L.memory[i], L.hash_result[i], L.is_real)
+    inputs, outputs = [], []
+    for words, checkers, out in (([m.prev_value for m in L.memory], L.input_range_checkers, inputs),
+                                 (L.hash_result, L.hash_result_range_checkers, outputs)):
+        for i in range(8):
+            w = words[i]
+            out += [w[0] + w[1] * (1 << 16), w[2] + w[3] * (1 << 16)]
+            slice_range_check_u16(b, w, L.is_real)
+            eval_field_word_range_check(b, [w[0], w[1], b.const(0), b.const(0)], checkers[2 * i], L.is_real)
+            eval_field_word_range_check(b, [w[2], w[3], b.const(0), b.const(0)], checkers[2 * i + 1], L.is_real)
+    perm = L.permutation
+    for i in range(16):
+        b.when(L.is_real).assert_eq(perm[P2_EXT(0, i)], inputs[i])
+    poseidon2_permutation_constraints(b.air, c.names["permutation"])
+    for i in range(16):
+        b.when(L.is_real).assert_eq(perm[P2_OUT(i)], outputs[i])
+    send_syscall(b, L.clk_high, L.clk_low, SYS_POSEIDON2, ptr, [0, 0, 0], L.is_real, receive=True)
+    b.assert_bool(L.is_real)
+    return _done(b, c)
+
+
 MORE_CHIPS = {
+    "Poseidon2": poseidon2_chip,
     "AluX0": alu_x0_chip, "DivRem": divrem_chip, "SyscallCore": lambda: syscall_chip("core"), "SyscallPrecompile": lambda: syscall_chip("precompile"),
     "SyscallInstrs": syscall_instrs_chip, "MemoryGlobalInit": lambda: memory_global_chip("init"),
     "MemoryGlobalFinalize": lambda: memory_global_chip("finalize"), "KeccakPermute": keccak_permute_chip,
@@ -469,7 +506,7 @@ MORE_CHIPS = {
 }
 # (columns, constraints) from rv64im_costs.json / rv64im_complexity.json; interactions of the recorded core shard where it has the chip
 MORE_RECORDED = {
-    "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
+    "Poseidon2": (348, 497, None), "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
     "MemoryGlobalInit": (30, 31, None), "MemoryGlobalFinalize": (30, 31, None), "KeccakPermute": (2640, 2859, None),
     "KeccakPermuteControl": (634, 331, None),
 }

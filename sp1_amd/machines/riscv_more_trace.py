@@ -186,32 +186,33 @@ def precompile_shard_from(clk, addr, pre, t_prev, device="cpu"):
     # KeccakPermuteControl (controller.rs:L155-L237)
     ct = RT.Table(R.chip("KeccakPermuteControl")[0], n_events, dev)
     ct.set("clk_high", clk >> 24); ct.set("clk_low", clk & 0xFFFFFF); ct.set("is_real", 1)
-    al = _limbs_t(addr)
-    ct.set("state_addr.addr", al[:, :3])                                                # SyscallAddrOperation::populate (syscall_addr.rs:L27-L46)
-    top = al[:, 1] + al[:, 2]
-    ct.set("state_addr.top_two_limb_min", RT.finv(top))
-    dmax = (top - 2 * MASK16) % P
-    ct.set("state_addr.top_two_limb_max.inverse", torch.where(dmax == 0, torch.zeros_like(dmax), RT.finv(dmax)))
-    ct.set("state_addr.top_two_limb_max.result", (dmax == 0).to(I64))
+    al = _syscall_addr_t(ct, "state_addr", addr)
     for i in range(25):
         ct.set("addrs.%d.value" % i, _limbs_t(addr + 8 * i)[:, :3])
         _mem_access_t(ct, "initial_memory_access.%d" % i, pre[:, i], t_prev[:, i], clk)
         _mem_access_t(ct, "final_memory_access.%d" % i, pre[:, i], clk, clk + 1)
         ct.set("final_value.%d" % i, _limbs_t(post[:, i]))
     tr.tables["KeccakPermuteControl"] = ct
-    # SyscallPrecompile (syscall/chip.rs:L196-L254)
-    st = RT.Table(R.chip("SyscallPrecompile")[0], n_events, dev)
-    st.set("clk_high", clk >> 24); st.set("clk_low", clk & 0xFFFFFF); st.set("syscall_id", M.SYS_KECCAK_PERMUTE)
-    st.set("arg1", al[:, :3]); st.set("is_real", 1)
-    tr.tables["SyscallPrecompile"] = st
-    # MemoryLocal (memory/local.rs:L98-L250): one row per touched word
-    ml = RT.Table(R.chip("MemoryLocal")[0], 25 * n_events, dev)
     wa = (addr[:, None] + 8 * torch.arange(25, device=dev)[None, :]).reshape(-1)
-    tp, tf = t_prev.reshape(-1), (clk[:, None] + 1).expand(-1, 25).reshape(-1)
-    ml.set("addr", _limbs_t(wa)[:, :3])
-    ml.set("initial_clk_high", tp >> 24); ml.set("initial_clk_low", tp & 0xFFFFFF)
-    ml.set("final_clk_high", tf >> 24); ml.set("final_clk_low", tf & 0xFFFFFF)
-    for tag, v in (("initial", pre.reshape(-1)), ("final", post.reshape(-1))):
+    return _close_precompile_shard(tr, M.SYS_KECCAK_PERMUTE, clk, al, wa, t_prev.reshape(-1), (clk[:, None] + 1).expand(-1, 25).reshape(-1),
+                                   pre.reshape(-1), post.reshape(-1))
+
+
+def _close_precompile_shard(tr, syscall_id, clk, ptr_limbs, word_addr, t_initial, t_final, v_initial, v_final):
+    """What every precompile shard has around its own chips: SyscallPrecompile (one row per call), MemoryLocal (one row per touched
+    word: state before the call's first and after its last access), the Global chip over their events, the byte tables."""
+    dev = tr.dev
+    # SyscallPrecompile (syscall/chip.rs:L196-L254)
+    st = RT.Table(R.chip("SyscallPrecompile")[0], int(clk.shape[0]), dev)
+    st.set("clk_high", clk >> 24); st.set("clk_low", clk & 0xFFFFFF); st.set("syscall_id", syscall_id)
+    st.set("arg1", ptr_limbs[:, :3]); st.set("is_real", 1)
+    tr.tables["SyscallPrecompile"] = st
+    # MemoryLocal (memory/local.rs:L98-L250)
+    ml = RT.Table(R.chip("MemoryLocal")[0], int(word_addr.shape[0]), dev)
+    ml.set("addr", _limbs_t(word_addr)[:, :3])
+    ml.set("initial_clk_high", t_initial >> 24); ml.set("initial_clk_low", t_initial & 0xFFFFFF)
+    ml.set("final_clk_high", t_final >> 24); ml.set("final_clk_low", t_final & 0xFFFFFF)
+    for tag, v in (("initial", v_initial), ("final", v_final)):
         l = _limbs_t(v)
         ml.set(tag + "_value", l)
         ml.set(tag + "_value_lower", l[:, 2] & 0xFF)
@@ -230,6 +231,53 @@ def precompile_shard_from(clk, addr, pre, t_prev, device="cpu"):
     publics = torch.zeros(M.PV_NUM_ELTS, dtype=I64)
     _global_publics(publics, tr.tables["Global"])
     return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, publics, tr.global_events
+
+
+def _syscall_addr_t(tb, prefix, addr):
+    """SyscallAddrOperation::populate (operations/syscall_addr.rs:L27-L46); returns the address limbs."""
+    al = _limbs_t(addr)
+    tb.set(prefix + ".addr", al[:, :3])
+    top = al[:, 1] + al[:, 2]
+    tb.set(prefix + ".top_two_limb_min", RT.finv(top))
+    dmax = (top - 2 * MASK16) % P
+    tb.set(prefix + ".top_two_limb_max.inverse", torch.where(dmax == 0, torch.zeros_like(dmax), RT.finv(dmax)))
+    tb.set(prefix + ".top_two_limb_max.result", (dmax == 0).to(I64))
+    return al
+
+
+def poseidon2_shard_from(clk, ptr, pre, t_prev, post, device="cpu"):
+    """The POSEIDON2 precompile shard of the syscalls (clk [n], pointer ptr [n], the eight words read pre [n, 8] with their previous
+    timestamps t_prev [n, 8], the eight words written post [n, 8] — at clk, in place): the Poseidon2 chip's rows
+    (`generate_trace_into`, syscall/precompiles/poseidon2/air.rs:L107-L290: the permutation's 179 columns are RECOMPUTED from the
+    words read, so a wrong `post` fails the output constraints), SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
+    from . import septic as SE
+    dev = torch.device(device)
+    n = int(clk.shape[0])
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    air, _ = R.chip("Poseidon2")
+    tb = RT.Table(air, n, dev)
+    tb.set("clk_high", clk >> 24); tb.set("clk_low", clk & 0xFFFFFF); tb.set("is_real", 1)
+    al = _syscall_addr_t(tb, "ptr", ptr)
+    top = (P - 1) >> 16
+    lo32, hi32 = lambda v: v & 0xFFFFFFFF, lambda v: (v >> 32) & 0xFFFFFFFF
+    for i in range(8):
+        tb.set("addrs.%d.value" % i, _limbs_t(ptr + 8 * i)[:, :3])
+        _mem_access_t(tb, "memory.%d" % i, pre[:, i], t_prev[:, i], clk)
+        hl, pl = _limbs_t(post[:, i]), _limbs_t(pre[:, i])
+        tb.set("hash_result.%d" % i, hl)
+        for name, l in (("hash_result_range_checkers", hl), ("input_range_checkers", pl)):   # SP1FieldWordRangeChecker::populate
+            tb.set(name, (l[:, 1] < top).to(I64), off=2 * i)
+            tb.set(name, (l[:, 3] < top).to(I64), off=2 * i + 1)
+    state = torch.stack([f(pre[:, i]) for i in range(8) for f in (lo32, hi32)], dim=1)
+    pcol = tb.L["permutation"]
+    tb.main[:n, pcol:pcol + SE.P2_WIDTH] = SE.poseidon2_rows(state)
+    if tb.main.shape[0] > n:                                   # padding rows: the permutation of the zero state (air.rs:L283-L290)
+        tb.main[n:, pcol:pcol + SE.P2_WIDTH] = SE.poseidon2_rows(torch.zeros((1, 16), dtype=I64, device=dev))[0]
+    tr.tables["Poseidon2"] = tb
+    wa = (ptr[:, None] + 8 * torch.arange(8, device=dev)[None, :]).reshape(-1)
+    return _close_precompile_shard(tr, M.SYS_POSEIDON2, clk, al, wa, t_prev.reshape(-1), clk[:, None].expand(-1, 8).reshape(-1),
+                                   pre.reshape(-1), post.reshape(-1))
 
 
 def _global_publics(publics, g):
