@@ -463,6 +463,261 @@ def keccak_control_chip():                                                      
     return _done(b, c)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# SHA-256 precompiles: operations on u32 values held as two 16-bit limbs
+FIXED_ROT = S(("value", 2), ("higher_limb", 2))                                          # operations/fixed_rotate_right.rs:L14-L20, fixed_shift_right.rs
+U32_TO_U8 = S(("low_bytes", 2),)                                                         # operations/u32_operation.rs
+BYTE_OP_U32 = S(("b_low_bytes", U32_TO_U8), ("c_low_bytes", U32_TO_U8), ("value", 4))    # xor_u32.rs / and_u32.rs
+HALF_WORD = S(("value", 2),)                                                             # not_u32.rs, add4.rs, add5.rs, add_u32.rs
+CLK_OP = S(("next_clk_16_24", 1), ("next_clk_0_16", 1), ("is_overflow", 1))              # operations/clk.rs
+SHA_EXTEND, SHA_COMPRESS = 10, 11                                                        # hypercube/src/lookup/interaction.rs:L45-L49
+SYS_SHA_EXTEND, SYS_SHA_COMPRESS = 0x05, 0x06
+B_AND, B_XOR = 0, 2                                                                      # ByteOpcode (core/executor/src/opcode.rs): AND = 0, OR = 1, XOR = 2
+SHA_K = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]   # FIPS 180-4 §4.2.2
+
+
+def eval_fixed_rotate_right(b, x, rotation, cols, is_real, shift=False):                   # fixed_rotate_right.rs:L63-L112 / fixed_shift_right.rs:L66-L115
+    b.assert_bool(is_real)
+    nl, nb = rotation // 16, rotation % 16
+    mult = 1 << (16 - nb)
+    limbs = [x[i + nl] if i + nl < 2 else b.const(0) for i in range(2)] if shift else [x[nl % 2], x[(1 + nl) % 2]]
+    lower = []
+    for i in range(2):
+        lower.append(limbs[i] - cols.higher_limb[i] * (1 << nb))
+        send_byte(b, B_RANGE, lower[i], nb, 0, is_real)
+        send_byte(b, B_RANGE, cols.higher_limb[i], 16 - nb, 0, is_real)
+    if shift:
+        b.when(is_real).assert_eq(cols.value[1], cols.higher_limb[1])
+    else:
+        b.when(is_real).assert_eq(cols.value[1], cols.higher_limb[1] + lower[0] * mult)
+    b.when(is_real).assert_eq(cols.value[0], cols.higher_limb[0] + lower[1] * mult)
+
+
+def _u32_to_u8(x, cols):                                                                  # u32_operation.rs: eval_u32_to_u8_unsafe
+    out = []
+    for i in range(2):
+        out += [cols.low_bytes[i], (x[i] - cols.low_bytes[i]) * INV(1 << 8)]
+    return out
+
+
+def eval_byte_op_u32(b, opcode, x, y, cols, is_real):                                     # xor_u32.rs:L61-L92 / and_u32.rs:L58-L89
+    b.assert_bool(is_real)
+    xb, yb = _u32_to_u8(x, cols.b_low_bytes), _u32_to_u8(y, cols.c_low_bytes)
+    for i in range(4):
+        send_byte(b, opcode, cols.value[i], xb[i], yb[i], is_real)
+    return [cols.value[0] + cols.value[1] * (1 << 8), cols.value[2] + cols.value[3] * (1 << 8)]
+
+
+def eval_not_u32(b, a, cols, is_real):                                                    # not_u32.rs:L27-L39
+    for i in range(2):
+        b.when(is_real).assert_eq(cols.value[i] + a[i], U16_MAX)
+
+
+def eval_add_n(b, words, cols, is_real):                                                  # add4.rs:L59-L88, add5.rs:L66-L96
+    b.assert_bool(is_real)
+    carry, carries = b.const(0), []
+    for i in range(2):
+        acc = carry - cols.value[i]
+        for w in words:
+            acc = acc + w[i]
+        carry = acc * INV(1 << 16)
+        carries.append(carry)
+    slice_range_check_u16(b, cols.value, is_real)
+    slice_range_check_u8(b, carries, is_real)
+
+
+def eval_add_u32(b, x, y, cols, is_real):                                                 # add_u32.rs:L36-L58
+    b.assert_bool(is_real)
+    w, carry = b.when(is_real), b.const(0)
+    for i in range(2):
+        carry = (x[i] + y[i] - cols.value[i] + carry) * INV(1 << 16)
+        w.assert_bool(carry)
+    slice_range_check_u16(b, cols.value, is_real)
+
+
+def eval_clk(b, clk_low, increment, cols, is_real):                                       # clk.rs:L61-L88; returns (is_overflow, next clk_low)
+    b.assert_bool(is_real)
+    b.assert_bool(cols.is_overflow)
+    nxt = cols.next_clk_0_16 + cols.next_clk_16_24 * (1 << 16)
+    b.when(is_real).assert_eq(clk_low + increment - cols.is_overflow * (1 << 24), nxt)
+    send_byte(b, B_RANGE, cols.next_clk_0_16, 16, 0, is_real)
+    slice_range_check_u8(b, [cols.next_clk_16_24, b.const(0)], is_real)
+    return cols.is_overflow, nxt
+
+
+def _expr_word(b, e):                                                                     # Word::extend_expr: (e, 0, 0, 0)
+    return [e, b.const(0), b.const(0), b.const(0)]
+
+
+def sha_extend_chip():                                                                    # sha256/extend/air.rs:L28-L317
+    b, c, _ = _chip("ShaExtend", 128)
+    L = S(("clk_high", 1), ("clk_low", 1), ("next_clk", CLK_OP), ("w_ptr", 3), ("w_i_minus_15_ptr", ADDR_ADD_OP), ("w_i_minus_2_ptr", ADDR_ADD_OP),
+          ("w_i_minus_16_ptr", ADDR_ADD_OP), ("w_i_minus_7_ptr", ADDR_ADD_OP), ("w_i_ptr", ADDR_ADD_OP), ("i", 1),
+          ("w_i_minus_15", MEM_ACCESS), ("w_i_minus_15_rr_7", FIXED_ROT), ("w_i_minus_15_rr_18", FIXED_ROT), ("w_i_minus_15_rs_3", FIXED_ROT),
+          ("s0_intermediate", BYTE_OP_U32), ("s0", BYTE_OP_U32),
+          ("w_i_minus_2", MEM_ACCESS), ("w_i_minus_2_rr_17", FIXED_ROT), ("w_i_minus_2_rr_19", FIXED_ROT), ("w_i_minus_2_rs_10", FIXED_ROT),
+          ("s1_intermediate", BYTE_OP_U32), ("s1", BYTE_OP_U32), ("w_i_minus_16", MEM_ACCESS), ("w_i_minus_7", MEM_ACCESS), ("s2", HALF_WORD),
+          ("w_i", MEM_ACCESS), ("is_real", 1))(c)
+    b.assert_bool(L.is_real)
+    head = [L.clk_high, L.clk_low] + L.w_ptr
+    b.receive(SHA_EXTEND, head + [L.i], L.is_real)
+    b.send(SHA_EXTEND, head + [L.i + 1], L.is_real)
+    send_byte(b, B_LTU, 1, L.i - 16, 48, L.is_real)
+    overflow, next_low = eval_clk(b, L.clk_low, L.i - 16, L.next_clk, L.is_real)
+    next_high = L.clk_high + overflow
+    ptr = L.w_ptr + [b.const(0)]
+    halves = {}
+    for name, off in (("w_i_minus_15", 15), ("w_i_minus_2", 2), ("w_i_minus_16", 16), ("w_i_minus_7", 7)):
+        addr, acc = getattr(L, name + "_ptr"), getattr(L, name)
+        eval_addr_add(b, ptr, _expr_word(b, (L.i - off) * 8), addr.value, L.is_real)
+        eval_memory_access(b, next_high, next_low, addr.value, acc, acc.prev_value, L.is_real)      # a read
+        halves[name] = [acc.prev_value[0], acc.prev_value[1]]
+        b.assert_zero(acc.prev_value[2])
+        b.assert_zero(acc.prev_value[3])
+    eval_fixed_rotate_right(b, halves["w_i_minus_15"], 7, L.w_i_minus_15_rr_7, L.is_real)
+    eval_fixed_rotate_right(b, halves["w_i_minus_15"], 18, L.w_i_minus_15_rr_18, L.is_real)
+    eval_fixed_rotate_right(b, halves["w_i_minus_15"], 3, L.w_i_minus_15_rs_3, L.is_real, shift=True)
+    t = eval_byte_op_u32(b, B_XOR, L.w_i_minus_15_rr_7.value, L.w_i_minus_15_rr_18.value, L.s0_intermediate, L.is_real)
+    s0 = eval_byte_op_u32(b, B_XOR, t, L.w_i_minus_15_rs_3.value, L.s0, L.is_real)
+    eval_fixed_rotate_right(b, halves["w_i_minus_2"], 17, L.w_i_minus_2_rr_17, L.is_real)
+    eval_fixed_rotate_right(b, halves["w_i_minus_2"], 19, L.w_i_minus_2_rr_19, L.is_real)
+    eval_fixed_rotate_right(b, halves["w_i_minus_2"], 10, L.w_i_minus_2_rs_10, L.is_real, shift=True)
+    t = eval_byte_op_u32(b, B_XOR, L.w_i_minus_2_rr_17.value, L.w_i_minus_2_rr_19.value, L.s1_intermediate, L.is_real)
+    s1 = eval_byte_op_u32(b, B_XOR, t, L.w_i_minus_2_rs_10.value, L.s1, L.is_real)
+    eval_add_n(b, [halves["w_i_minus_16"], s0, halves["w_i_minus_7"], s1], L.s2, L.is_real)
+    eval_addr_add(b, ptr, _expr_word(b, L.i * 8), L.w_i_ptr.value, L.is_real)
+    eval_memory_access(b, next_high, next_low, L.w_i_ptr.value, L.w_i, [L.s2.value[0], L.s2.value[1], b.const(0), b.const(0)], L.is_real)
+    return _done(b, c)
+
+
+def sha_extend_control_chip():                                                            # sha256/extend/controller.rs:L172-L311
+    b, c, _ = _chip("ShaExtendControl", 18)
+    L = S(("clk_high", 1), ("clk_low", 1), ("w_ptr", SYSCALL_ADDR), ("w_16th_addr", ADDR_ADD_OP), ("w_17th_addr", ADDR_ADD_OP),
+          ("w_64th_addr", ADDR_ADD_OP), ("is_real", 1))(c)
+    b.assert_bool(L.is_real)
+    w_ptr = eval_syscall_addr(b, 512, L.w_ptr, L.is_real)
+    for cols, off in ((L.w_16th_addr, 15), (L.w_17th_addr, 16), (L.w_64th_addr, 63)):
+        eval_addr_add(b, list(w_ptr) + [b.const(0)], word_of_u64(off * 8), cols.value, L.is_real)
+    send_syscall(b, L.clk_high, L.clk_low, SYS_SHA_EXTEND, w_ptr, [0, 0, 0], L.is_real, receive=True)
+    b.send(SHA_EXTEND, [L.clk_high, L.clk_low + 1] + list(w_ptr) + [16], L.is_real)
+    b.receive(SHA_EXTEND, [L.clk_high, L.clk_low + 1] + list(w_ptr) + [64], L.is_real)
+    return _done(b, c)
+
+
+def sha_compress_chip():                                                                  # sha256/compress/air.rs:L34-L500
+    b, c, _ = _chip("ShaCompress", 206)
+    L = S(("clk_high", 1), ("clk_low", 1), ("w_ptr", 3), ("h_ptr", 3), ("index", 1), ("octet", 8), ("octet_num", 10), ("mem", MEM_ACCESS),
+          ("mem_value", 2), ("mem_addr", 3), ("mem_addr_init", ADDR_ADD_OP), ("mem_addr_compress", ADDR_ADD_OP), ("mem_addr_finalize", ADDR_ADD_OP),
+          ("a", 2), ("b", 2), ("c", 2), ("d", 2), ("e", 2), ("f", 2), ("g", 2), ("h", 2), ("k", 2),
+          ("e_rr_6", FIXED_ROT), ("e_rr_11", FIXED_ROT), ("e_rr_25", FIXED_ROT), ("s1_intermediate", BYTE_OP_U32), ("s1", BYTE_OP_U32),
+          ("e_and_f", BYTE_OP_U32), ("e_not", HALF_WORD), ("e_not_and_g", BYTE_OP_U32), ("ch", BYTE_OP_U32), ("temp1", HALF_WORD),
+          ("a_rr_2", FIXED_ROT), ("a_rr_13", FIXED_ROT), ("a_rr_22", FIXED_ROT), ("s0_intermediate", BYTE_OP_U32), ("s0", BYTE_OP_U32),
+          ("a_and_b", BYTE_OP_U32), ("a_and_c", BYTE_OP_U32), ("b_and_c", BYTE_OP_U32), ("maj_intermediate", BYTE_OP_U32), ("maj", BYTE_OP_U32),
+          ("temp2", HALF_WORD), ("d_add_temp1", HALF_WORD), ("temp1_add_temp2", HALF_WORD), ("finalized_operand", 2), ("finalize_add", HALF_WORD),
+          ("is_initialize", 1), ("is_compression", 1), ("is_finalize", 1), ("is_real", 1))(c)
+    # eval_control_flow_flags (L52-L160)
+    b.assert_bool(L.is_real)
+    computed, s_ = b.const(0), b.const(0)
+    for i in range(8):
+        b.assert_bool(L.octet[i])
+        s_ = s_ + L.octet[i]
+        computed = computed + L.octet[i] * i
+    b.assert_one(s_)
+    s_ = b.const(0)
+    for i in range(10):
+        b.assert_bool(L.octet_num[i])
+        s_ = s_ + L.octet_num[i]
+        computed = computed + L.octet_num[i] * (8 * i)
+    b.assert_one(s_)
+    b.assert_eq(L.index, computed)
+    b.assert_eq(L.is_initialize, L.octet_num[0] * L.is_real)
+    mid = L.octet_num[1]
+    for i in range(2, 9):
+        mid = mid + L.octet_num[i]
+    b.assert_eq(L.is_compression, mid * L.is_real)
+    b.assert_eq(L.is_finalize, L.octet_num[9] * L.is_real)
+    vars8 = [L.a, L.b, L.c, L.d, L.e, L.f, L.g, L.h]
+    head = [L.clk_high, L.clk_low] + L.w_ptr + L.h_ptr
+    flat = lambda ws: [x for w in ws for x in w]
+    b.receive(SHA_COMPRESS, head + [L.index] + flat(vars8), L.is_real)
+    b.send(SHA_COMPRESS, head + [L.index + 1] + flat(vars8), L.is_initialize + L.is_finalize)
+    b.send(SHA_COMPRESS, head + [L.index + 1] + flat([L.temp1_add_temp2.value, L.a, L.b, L.c, L.d_add_temp1.value, L.e, L.f, L.g]), L.is_compression)
+    # eval_memory (L162-L253)
+    zero = b.const(0)
+    mem_word = [L.mem_value[0], L.mem_value[1], zero, zero]
+    eval_memory_access(b, L.clk_high, L.clk_low + L.is_compression + L.is_finalize * 2, L.mem_addr, L.mem, mem_word, L.is_real)
+    b.when(L.is_initialize + L.is_compression).assert_word_eq(L.mem.prev_value, mem_word)
+    b.assert_zero(L.mem.prev_value[2])
+    b.assert_zero(L.mem.prev_value[3])
+    b.when(L.is_initialize).assert_all_eq(L.mem_addr, L.mem_addr_init.value)
+    b.when(L.is_compression).assert_all_eq(L.mem_addr, L.mem_addr_compress.value)
+    b.when(L.is_finalize).assert_all_eq(L.mem_addr, L.mem_addr_finalize.value)
+    eval_addr_add(b, L.h_ptr + [zero], _expr_word(b, L.index * 8), L.mem_addr_init.value, L.is_initialize)
+    eval_addr_add(b, L.w_ptr + [zero], _expr_word(b, (L.index - 8) * 8), L.mem_addr_compress.value, L.is_compression)
+    eval_addr_add(b, L.h_ptr + [zero], _expr_word(b, (L.index - 72) * 8), L.mem_addr_finalize.value, L.is_finalize)
+    for i, v in enumerate(vars8):
+        vw = [v[0], v[1], zero, zero]
+        b.when(L.is_initialize * L.octet[i]).assert_word_eq(vw, L.mem.prev_value)
+        b.when(L.is_initialize * L.octet[i]).assert_word_eq(vw, mem_word)
+    b.when(L.is_finalize).assert_all_eq(L.mem_value, L.finalize_add.value)
+    # eval_compression_ops (L255-L451)
+    for i in range(64):
+        b.when(L.octet_num[i // 8 + 1] * L.octet[i % 8]).assert_all_eq(L.k, [SHA_K[i] & 0xFFFF, SHA_K[i] >> 16])
+    ic = L.is_compression
+    eval_fixed_rotate_right(b, L.e, 6, L.e_rr_6, ic)
+    eval_fixed_rotate_right(b, L.e, 11, L.e_rr_11, ic)
+    eval_fixed_rotate_right(b, L.e, 25, L.e_rr_25, ic)
+    t = eval_byte_op_u32(b, B_XOR, L.e_rr_6.value, L.e_rr_11.value, L.s1_intermediate, ic)
+    s1 = eval_byte_op_u32(b, B_XOR, t, L.e_rr_25.value, L.s1, ic)
+    e_and_f = eval_byte_op_u32(b, B_AND, L.e, L.f, L.e_and_f, ic)
+    eval_not_u32(b, L.e, L.e_not, ic)
+    e_not_and_g = eval_byte_op_u32(b, B_AND, L.e_not.value, L.g, L.e_not_and_g, ic)
+    ch = eval_byte_op_u32(b, B_XOR, e_and_f, e_not_and_g, L.ch, ic)
+    eval_add_n(b, [L.h, s1, ch, L.k, L.mem_value], L.temp1, ic)
+    eval_fixed_rotate_right(b, L.a, 2, L.a_rr_2, ic)
+    eval_fixed_rotate_right(b, L.a, 13, L.a_rr_13, ic)
+    eval_fixed_rotate_right(b, L.a, 22, L.a_rr_22, ic)
+    t = eval_byte_op_u32(b, B_XOR, L.a_rr_2.value, L.a_rr_13.value, L.s0_intermediate, ic)
+    s0 = eval_byte_op_u32(b, B_XOR, t, L.a_rr_22.value, L.s0, ic)
+    a_and_b = eval_byte_op_u32(b, B_AND, L.a, L.b, L.a_and_b, ic)
+    a_and_c = eval_byte_op_u32(b, B_AND, L.a, L.c, L.a_and_c, ic)
+    b_and_c = eval_byte_op_u32(b, B_AND, L.b, L.c, L.b_and_c, ic)
+    t = eval_byte_op_u32(b, B_XOR, a_and_b, a_and_c, L.maj_intermediate, ic)
+    maj = eval_byte_op_u32(b, B_XOR, t, b_and_c, L.maj, ic)
+    eval_add_u32(b, s0, maj, L.temp2, ic)
+    eval_add_u32(b, L.d, L.temp1.value, L.d_add_temp1, ic)
+    eval_add_u32(b, L.temp1.value, L.temp2.value, L.temp1_add_temp2, ic)
+    # eval_finalize_ops (L453-L482)
+    filt = [b.const(0), b.const(0)]
+    for flag, v in zip(L.octet, vars8):
+        filt = [filt[0] + flag * v[0], filt[1] + flag * v[1]]
+    b.when(L.is_finalize).assert_all_eq(filt, L.finalized_operand)
+    eval_add_u32(b, [L.mem.prev_value[0], L.mem.prev_value[1]], L.finalized_operand, L.finalize_add, L.is_finalize)
+    return _done(b, c)
+
+
+def sha_compress_control_chip():                                                          # sha256/compress/controller.rs:L205-L345
+    b, c, _ = _chip("ShaCompressControl", 53)
+    L = S(("clk_high", 1), ("clk_low", 1), ("w_ptr", SYSCALL_ADDR), ("h_ptr", SYSCALL_ADDR), ("w_slice_end", ADDR_ADD_OP), ("h_slice_end", ADDR_ADD_OP),
+          ("is_real", 1), ("initial_state", 16), ("final_state", 16))(c)
+    b.assert_bool(L.is_real)
+    w_ptr = eval_syscall_addr(b, 512, L.w_ptr, L.is_real)
+    h_ptr = eval_syscall_addr(b, 64, L.h_ptr, L.is_real)
+    eval_addr_add(b, list(w_ptr) + [b.const(0)], word_of_u64(63 * 8), L.w_slice_end.value, L.is_real)
+    eval_addr_add(b, list(h_ptr) + [b.const(0)], word_of_u64(7 * 8), L.h_slice_end.value, L.is_real)
+    send_syscall(b, L.clk_high, L.clk_low, SYS_SHA_COMPRESS, w_ptr, h_ptr, L.is_real, receive=True)
+    head = [L.clk_high, L.clk_low] + list(w_ptr) + list(h_ptr)
+    b.send(SHA_COMPRESS, head + [0] + L.initial_state, L.is_real)
+    b.receive(SHA_COMPRESS, head + [80] + L.final_state, L.is_real)
+    return _done(b, c)
+
+
 def poseidon2_chip():                                                                     # syscall/precompiles/poseidon2/air.rs:L424-L607
     """The POSEIDON2 precompile: eight u64 words at `ptr` (sixteen field elements, low half first) are read and rewritten in place
     by one KoalaBear Poseidon2 permutation — the same `Poseidon2Operation` sub-AIR as the Global chip's (hinted for a fused kernel)."""
@@ -498,7 +753,8 @@ def poseidon2_chip():                                                           
 
 
 MORE_CHIPS = {
-    "Poseidon2": poseidon2_chip,
+    "Poseidon2": poseidon2_chip, "ShaExtend": sha_extend_chip, "ShaExtendControl": sha_extend_control_chip, "ShaCompress": sha_compress_chip,
+    "ShaCompressControl": sha_compress_control_chip,
     "AluX0": alu_x0_chip, "DivRem": divrem_chip, "SyscallCore": lambda: syscall_chip("core"), "SyscallPrecompile": lambda: syscall_chip("precompile"),
     "SyscallInstrs": syscall_instrs_chip, "MemoryGlobalInit": lambda: memory_global_chip("init"),
     "MemoryGlobalFinalize": lambda: memory_global_chip("finalize"), "KeccakPermute": keccak_permute_chip,
@@ -506,7 +762,8 @@ MORE_CHIPS = {
 }
 # (columns, constraints) from rv64im_costs.json / rv64im_complexity.json; interactions of the recorded core shard where it has the chip
 MORE_RECORDED = {
-    "Poseidon2": (348, 497, None), "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
+    "Poseidon2": (348, 497, None), "ShaExtend": (128, 80, None), "ShaExtendControl": (18, 21, None), "ShaCompress": (206, 300, None),
+    "ShaCompressControl": (53, 21, None), "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
     "MemoryGlobalInit": (30, 31, None), "MemoryGlobalFinalize": (30, 31, None), "KeccakPermute": (2640, 2859, None),
     "KeccakPermuteControl": (634, 331, None),
 }
