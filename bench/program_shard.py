@@ -18,13 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FULL_CYCLES = 1 << 23
-CYCLES_PER_UNIT = {"fibonacci": 9, "loop": 4, "keccak": 7}       # measured: cycles per loop iteration / per input byte
+CYCLES_PER_UNIT = {"fibonacci": 9, "loop": 4, "keccak": 7, "sha2": 4, "poseidon2": 9}   # measured: cycles per loop iteration / per input byte
 
 
 def stdin_of(program, cycles):
     """The input of sp1-gpu/crates/perf/src/lib.rs:L23-L45 sized so that the run lasts at least `cycles` cycles."""
     n = cycles // CYCLES_PER_UNIT[program] + 1
-    return [bytes(n)] if program == "keccak" else [struct.pack("<Q", n)]  # `write_vec(vec![0u8; n])` / `write(&n)`, n: usize
+    return [bytes(n)] if program in ("keccak", "sha2") else [struct.pack("<Q", n)]  # `write_vec(vec![0u8; n])` / `write(&n)`, n: usize
 
 
 def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):

@@ -13,6 +13,8 @@
 //                                    initial memory: timestamp 0), vm/syscall/{halt,commit,deferred}.rs; unconstrained blocks
 //                                    run without a trace and are rolled back (minimal/arch/portable/mod.rs:L258-L280)
 //   Keccak precompile                vm/syscall/precompiles/keccak256/permute.rs (reads at clk, writes at clk + 1)
+//   SHA-256 precompiles              vm/syscall/precompiles/sha256/{extend,compress}.rs (extend: step i at clk + 1 + (i - 16); compress:
+//                                    h read at clk, w at clk + 1, h written at clk + 2)
 //   Poseidon2 precompile             vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs (eight words rewritten at clk)
 //   per-shard local memory events    tracing.rs:L548-L577, L1490-L1515 (first / last access of every address touched in the shard)
 // User mode (page protection, untrusted programs), the trap context and the other precompiles are not implemented: an ELF that
@@ -42,7 +44,7 @@ struct Instr { uint32_t op; uint32_t a; uint64_t b, c; bool imm_b, imm_c; };
 
 constexpr uint64_t HALT_PC = 1, CLK_INC = 8, ECALL_EXTRA = 256;
 constexpr uint64_t SYS_HALT = 0x00, SYS_WRITE = 0x02, SYS_ENTER_UNC = 0x03, SYS_EXIT_UNC = 0x04, SYS_KECCAK = 0x00010109,
-                   SYS_POSEIDON2 = 0x00000133, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
+                   SYS_POSEIDON2 = 0x00000133, SYS_SHA_EXTEND = 0x00300105, SYS_SHA_COMPRESS = 0x00010106, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
 constexpr uint64_t FD_PUBLIC_VALUES = 13, FD_HINT = 14;
 
 Instr decode(uint32_t w) {
@@ -149,6 +151,8 @@ struct Vm {
     std::vector<uint64_t> events;                                      // [n][EV]
     std::vector<uint64_t> local;                                       // [m][5]: addr, initial ts, initial value, (final ts, final value)
     std::vector<uint8_t> local_closed;
+    std::vector<uint64_t> sha_extend;                                  // [k][clk, w_ptr, 48 x (4 x (previous timestamp, word read), previous timestamp and value of w[i], w[i] written), 64 x (timestamp, value before; after)]
+    std::vector<uint64_t> sha_compress;                                // [k][clk, w_ptr, h_ptr, 8 x (previous timestamp, h word), 64 x (previous timestamp, w word), 8 h words written]
     std::vector<uint64_t> poseidon2;                                   // POSEIDON2 events: [k][clk, pointer, 8 x (previous timestamp, word read), 8 words written]
     std::vector<uint64_t> precompile;                                  // Keccak events: [k][clk, pointer, 25 x (previous timestamp, word read), 25 words written]
     // the whole run
@@ -410,6 +414,58 @@ struct Vm {
                 precompile.insert(precompile.end(), rec.begin(), rec.end());
                 break;
             }
+            case SYS_SHA_EXTEND: {                                     // vm/syscall/precompiles/sha256/extend.rs, minimal/.../sha256/extend.rs
+                if ((b & 7) || c != 0) return fail("SHA_EXTEND arguments");
+                std::vector<uint64_t> rec = {clk, b};
+                uint64_t first[64][2];                                 // the 64 words' state before the call
+                for (int i = 0; i < 64; ++i) { Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i); first[i][0] = m.ts; first[i][1] = m.val; }
+                auto rotr = [](uint32_t v, int r) { return (v >> r) | (v << (32 - r)); };
+                for (int i = 16; i < 64; ++i) {                        // step i at clk + 1 + (i - 16): four reads, one write
+                    const uint64_t ts = clk + 1 + (uint64_t)(i - 16);
+                    uint32_t v[4];
+                    const int offs[4] = {15, 2, 16, 7};
+                    for (int k = 0; k < 4; ++k) {
+                        Cell& m = cell(b + 8 * (uint64_t)(i - offs[k]));
+                        rec.push_back(m.ts); rec.push_back(m.val);
+                        v[k] = (uint32_t)m.val; m.ts = ts;
+                    }
+                    const uint32_t s0 = rotr(v[0], 7) ^ rotr(v[0], 18) ^ (v[0] >> 3), s1 = rotr(v[1], 17) ^ rotr(v[1], 19) ^ (v[1] >> 10);
+                    const uint32_t wi = s1 + v[2] + s0 + v[3];
+                    Cell& m = cell(b + 8 * (uint64_t)i);
+                    rec.push_back(m.ts); rec.push_back(m.val); rec.push_back(wi);
+                    m.ts = ts; m.val = wi;
+                }
+                for (int i = 0; i < 64; ++i) { Cell& m = cell(b + 8 * i); rec.insert(rec.end(), {first[i][0], first[i][1], m.ts, m.val}); }
+                sha_extend.insert(sha_extend.end(), rec.begin(), rec.end());
+                break;
+            }
+            case SYS_SHA_COMPRESS: {                                   // vm/syscall/precompiles/sha256/compress.rs: h read at clk, w at clk + 1, h written at clk + 2
+                if ((b & 7) || (c & 7)) return fail("SHA_COMPRESS arguments");
+                static const uint32_t K[64] = {
+                    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+                    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+                    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+                    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+                    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+                    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+                auto rotr = [](uint32_t v, int r) { return (v >> r) | (v << (32 - r)); };
+                std::vector<uint64_t> rec = {clk, b, c};
+                uint32_t h[8], w[64];
+                for (int i = 0; i < 8; ++i) { Cell& m = cell(c + 8 * i); touch_precompile(m, c + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); h[i] = (uint32_t)m.val; m.ts = clk; }
+                for (int i = 0; i < 64; ++i) { Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); w[i] = (uint32_t)m.val; m.ts = clk + 1; }
+                uint32_t v[8];
+                memcpy(v, h, sizeof v);
+                for (int i = 0; i < 64; ++i) {
+                    const uint32_t s1 = rotr(v[4], 6) ^ rotr(v[4], 11) ^ rotr(v[4], 25), ch = (v[4] & v[5]) ^ (~v[4] & v[6]);
+                    const uint32_t t1 = v[7] + s1 + ch + K[i] + w[i];
+                    const uint32_t s0 = rotr(v[0], 2) ^ rotr(v[0], 13) ^ rotr(v[0], 22), maj = (v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]);
+                    const uint32_t t2 = s0 + maj;
+                    v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+                }
+                for (int i = 0; i < 8; ++i) { Cell& m = cell(c + 8 * i); m.val = (uint32_t)(h[i] + v[i]); m.ts = clk + 2; rec.push_back(m.val); }
+                sha_compress.insert(sha_compress.end(), rec.begin(), rec.end());
+                break;
+            }
             case SYS_POSEIDON2: {                                      // vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs
                 if ((b & 7) || c != 0) return fail("POSEIDON2 arguments");
                 uint32_t st[16];
@@ -508,7 +564,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     if (!h || !info) { sp1hip::set_error("sp1hip_rv64_run_shard: null argument"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
-    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear();
+    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear();
     if (vm.record && max_cycles <= (1ull << 26)) vm.events.reserve((size_t)max_cycles * EV);   // one allocation, not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
@@ -517,6 +573,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     vm.finish_shard();
     info->n_cycles = vm.cycles - c0; info->n_events = vm.events.size() / EV; info->n_local = vm.local.size() / 5; info->n_keccak = vm.precompile.size() / SP1HIP_RV64_KECCAK_WORDS;
     info->n_poseidon2 = vm.poseidon2.size() / SP1HIP_RV64_POSEIDON2_WORDS;
+    info->n_sha_extend = vm.sha_extend.size() / SP1HIP_RV64_SHA_EXTEND_WORDS; info->n_sha_compress = vm.sha_compress.size() / SP1HIP_RV64_SHA_COMPRESS_WORDS;
     info->next_pc = vm.pc; info->clk_end = vm.clk; info->halted = vm.halted; info->exit_code = vm.exit_code;
     info->shard = vm.shard++;
     info->commit_syscall = vm.commit_syscall; info->commit_deferred_syscall = vm.commit_deferred_syscall;
@@ -535,6 +592,8 @@ const uint64_t* sp1hip_rv64_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->events
 const uint64_t* sp1hip_rv64_local_memory(sp1hip_rv64_vm_t h) { return ((Vm*)h)->local.data(); }
 const uint64_t* sp1hip_rv64_keccak_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->precompile.data(); }
 const uint64_t* sp1hip_rv64_poseidon2_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->poseidon2.data(); }
+const uint64_t* sp1hip_rv64_sha_extend_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->sha_extend.data(); }
+const uint64_t* sp1hip_rv64_sha_compress_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->sha_compress.data(); }
 
 int sp1hip_rv64_program(sp1hip_rv64_vm_t h, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table) {
     if (!h) return SP1HIP_ERROR_INVALID_ARGUMENT;

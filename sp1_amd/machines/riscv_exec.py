@@ -16,7 +16,7 @@ import numpy as np
 
 from .. import _lib
 
-EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS = 20, 77, 26
+EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS, SHA_EXTEND_WORDS, SHA_COMPRESS_WORDS = 20, 77, 26, 786, 155
 (E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
  E_NEXT_PC, E_SPARE) = range(EV_WORDS)
 
@@ -25,9 +25,10 @@ class ExecutedShard:
     """One shard of an execution: `events` [n, 20] / `local` [m, 5] / `keccak` [k, 77] int64 arrays (two's complement images of
     the executor's u64 words) and the shard's public-value fields."""
 
-    def __init__(self, info, events, local, keccak, poseidon2):
+    def __init__(self, info, events, local, keccak, poseidon2, sha_extend, sha_compress):
         self.index, self.cycles = int(info.shard), int(info.n_cycles)
         self.events, self.local, self.keccak, self.poseidon2 = events, local, keccak, poseidon2
+        self.sha_extend, self.sha_compress = sha_extend, sha_compress
         self.pc_start, self.next_pc = int(info.pc_start), int(info.next_pc)
         self.clk_start, self.clk_end = int(info.clk_start), int(info.clk_end)
         self.halted, self.exit_code = bool(info.halted), int(info.exit_code)
@@ -74,7 +75,9 @@ class Executor:
         shard = ExecutedShard(info, self._matrix(self.lib.sp1hip_rv64_events(self.h), n_events, EV_WORDS, copy),
                               self._matrix(self.lib.sp1hip_rv64_local_memory(self.h), info.n_local, 5),
                               self._matrix(self.lib.sp1hip_rv64_keccak_events(self.h), info.n_keccak, KECCAK_WORDS),
-                              self._matrix(self.lib.sp1hip_rv64_poseidon2_events(self.h), info.n_poseidon2, POSEIDON2_WORDS))
+                              self._matrix(self.lib.sp1hip_rv64_poseidon2_events(self.h), info.n_poseidon2, POSEIDON2_WORDS),
+                              self._matrix(self.lib.sp1hip_rv64_sha_extend_events(self.h), info.n_sha_extend, SHA_EXTEND_WORDS),
+                              self._matrix(self.lib.sp1hip_rv64_sha_compress_events(self.h), info.n_sha_compress, SHA_COMPRESS_WORDS))
         self.halted = shard.halted
         return shard
 
@@ -360,11 +363,12 @@ def shard_tables(executor, shard, device="cpu"):
 def program_shards(executor, max_cycles, device="cpu"):
     """Every shard of a run, in the order the reference's controller emits them: the core shards as the program executes
     (`(kind, machine, tables, publics, global events, ExecutedShard)` with kind = "core"), then one precompile shard for the
-    KECCAK_PERMUTE calls and one for the POSEIDON2 calls if there were any ("keccak", "poseidon2"), then the memory shard: MemoryGlobalInit / MemoryGlobalFinalize over
+    KECCAK_PERMUTE, POSEIDON2, SHA_EXTEND and SHA_COMPRESS calls each if there were any ("keccak", "poseidon2", "sha_extend",
+    "sha_compress"), then the memory shard: MemoryGlobalInit / MemoryGlobalFinalize over
     every address the run touched ("memory"). The global events of all shards cancel as a multiset: that is the statement the
     shards' septic-curve digests add up to."""
     from . import riscv_more_trace as MT
-    keccak, poseidon2 = [], []
+    keccak, poseidon2, sha_extend, sha_compress = [], [], [], []
     for shard in executor.shards(max_cycles):
         tr = EventTracer(executor, shard, device)
         machine, tables, publics = tr.build()
@@ -372,6 +376,10 @@ def program_shards(executor, max_cycles, device="cpu"):
             keccak.append(shard.keccak)
         if shard.poseidon2.shape[0]:
             poseidon2.append(shard.poseidon2)
+        if shard.sha_extend.shape[0]:
+            sha_extend.append(shard.sha_extend)
+        if shard.sha_compress.shape[0]:
+            sha_compress.append(shard.sha_compress)
         yield "core", machine, tables, publics, tr.global_events, shard
     if keccak:
         kk = torch.as_tensor(np.concatenate(keccak), device=device)
@@ -384,6 +392,10 @@ def program_shards(executor, max_cycles, device="cpu"):
         machine, tables, publics, gev = MT.poseidon2_shard_from(pp[:, 0], pp[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(),
                                                                pp[:, 18:26].contiguous(), device)
         yield "poseidon2", machine, tables, publics, gev, None
+    for name, evs, build in (("sha_extend", sha_extend, MT.sha_extend_shard_from), ("sha_compress", sha_compress, MT.sha_compress_shard_from)):
+        if evs:
+            machine, tables, publics, gev = build(np.concatenate(evs), device)
+            yield name, machine, tables, publics, gev, None
     gm = executor.global_memory()
     gm = gm[np.argsort(gm[:, 0].astype(np.uint64))]
     if gm.shape[0] == 0 or gm[0, 0] != 0:                  # register x0 opens the address chain whether or not the program read it

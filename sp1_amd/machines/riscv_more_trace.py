@@ -198,7 +198,7 @@ def precompile_shard_from(clk, addr, pre, t_prev, device="cpu"):
                                    pre.reshape(-1), post.reshape(-1))
 
 
-def _close_precompile_shard(tr, syscall_id, clk, ptr_limbs, word_addr, t_initial, t_final, v_initial, v_final):
+def _close_precompile_shard(tr, syscall_id, clk, ptr_limbs, word_addr, t_initial, t_final, v_initial, v_final, arg2_limbs=None):
     """What every precompile shard has around its own chips: SyscallPrecompile (one row per call), MemoryLocal (one row per touched
     word: state before the call's first and after its last access), the Global chip over their events, the byte tables."""
     dev = tr.dev
@@ -206,6 +206,8 @@ def _close_precompile_shard(tr, syscall_id, clk, ptr_limbs, word_addr, t_initial
     st = RT.Table(R.chip("SyscallPrecompile")[0], int(clk.shape[0]), dev)
     st.set("clk_high", clk >> 24); st.set("clk_low", clk & 0xFFFFFF); st.set("syscall_id", syscall_id)
     st.set("arg1", ptr_limbs[:, :3]); st.set("is_real", 1)
+    if arg2_limbs is not None:
+        st.set("arg2", arg2_limbs[:, :3])
     tr.tables["SyscallPrecompile"] = st
     # MemoryLocal (memory/local.rs:L98-L250)
     ml = RT.Table(R.chip("MemoryLocal")[0], int(word_addr.shape[0]), dev)
@@ -374,3 +376,210 @@ def memory_shard_from(addrs, init, fin, device="cpu", previous_addr=0):
     publics[125], publics[126] = n_words, n_words                                         # global_init_count, global_finalize_count
     _global_publics(publics, tr.tables["Global"])
     return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, publics, tr.global_events
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SHA-256 precompile shards (syscall/precompiles/sha256/{extend,compress}/trace.rs), vectorised over rows
+M32 = 0xFFFFFFFF
+
+
+def _half(v):
+    return torch.stack([v & MASK16, (v >> 16) & MASK16], dim=-1)
+
+
+def _set_fixed(tb, prefix, x, r, shift=False):
+    """FixedRotateRightOperation / FixedShiftRightOperation::populate (fixed_rotate_right.rs:L37-L61, fixed_shift_right.rs:L36-L64)."""
+    nl, nb = r // 16, r % 16
+    out = (x >> r) if shift else (((x >> r) | (x << (32 - r))) & M32)
+    limbs = _half(x)
+    zero = torch.zeros_like(x)
+    rot = [limbs[:, i + nl] if i + nl < 2 else zero for i in range(2)] if shift else [limbs[:, nl % 2], limbs[:, (1 + nl) % 2]]
+    tb.set(prefix + ".value", _half(out))
+    tb.set(prefix + ".higher_limb", torch.stack([rot[0] >> nb, rot[1] >> nb], dim=1))
+    return out
+
+
+def _set_byte_op(tb, prefix, x, y, op):
+    """XorU32Operation / AndU32Operation::populate (xor_u32.rs:L26-L59)."""
+    out = (x ^ y) if op == "xor" else (x & y)
+    for nm, v in (("b_low_bytes", x), ("c_low_bytes", y)):
+        tb.set(prefix + "." + nm + ".low_bytes", torch.stack([v & 0xFF, (v >> 16) & 0xFF], dim=1))
+    tb.set(prefix + ".value", torch.stack([(out >> (8 * i)) & 0xFF for i in range(4)], dim=1))
+    return out
+
+
+def _set_sum(tb, prefix, *terms):
+    out = terms[0]
+    for t in terms[1:]:
+        out = (out + t) & M32
+    tb.set(prefix + ".value", _half(out))
+    return out
+
+
+def sha_extend_shard_from(events, device="cpu"):
+    """The SHA_EXTEND precompile shard of the executor's events ([n, 786] int64: riscv_exec.SHA_EXTEND_WORDS): ShaExtend (48 rows per
+    call, `event_to_rows`, extend/trace.rs:L82-L190), ShaExtendControl, SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
+    dev = torch.device(device)
+    ev = torch.as_tensor(events, device=dev)
+    n = ev.shape[0]
+    clk, w_ptr = ev[:, 0], ev[:, 1]
+    steps = ev[:, 2:2 + 48 * 11].reshape(n, 48, 11)
+    around = ev[:, 2 + 48 * 11:].reshape(n, 64, 4)
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    rows = 48 * n
+    tb = RT.Table(R.chip("ShaExtend")[0], rows, dev)
+    rep = lambda v: v[:, None].expand(-1, 48).reshape(-1)
+    i = (16 + torch.arange(48, device=dev))[None, :].expand(n, -1).reshape(-1)
+    c, wp = rep(clk), rep(w_ptr)
+    row_low = (c & 0xFFFFFF) + 1                                                          # the controller hands over (clk_high, clk_low + 1)
+    tb.set("clk_high", c >> 24); tb.set("clk_low", row_low); tb.set("i", i); tb.set("is_real", 1)
+    nxt = row_low + (i - 16)
+    over = (nxt >> 24) & 1
+    tb.set("next_clk.is_overflow", over)
+    tb.set("next_clk.next_clk_16_24", (nxt >> 16) & 0xFF)
+    tb.set("next_clk.next_clk_0_16", nxt & MASK16)
+    ts = c + 1 + (i - 16)
+    tb.set("w_ptr", _limbs_t(wp)[:, :3])
+    st = steps.reshape(rows, 11)
+    vals = {}
+    for k, (name, off) in enumerate((("w_i_minus_15", 15), ("w_i_minus_2", 2), ("w_i_minus_16", 16), ("w_i_minus_7", 7))):
+        tb.set(name + "_ptr.value", _limbs_t(wp + 8 * (i - off))[:, :3])
+        _mem_access_t(tb, name, st[:, 2 * k + 1], st[:, 2 * k], ts)
+        vals[name] = st[:, 2 * k + 1] & M32
+    tb.set("w_i_ptr.value", _limbs_t(wp + 8 * i)[:, :3])
+    _mem_access_t(tb, "w_i", st[:, 9], st[:, 8], ts)
+    x = vals["w_i_minus_15"]
+    a7, a18, a3 = _set_fixed(tb, "w_i_minus_15_rr_7", x, 7), _set_fixed(tb, "w_i_minus_15_rr_18", x, 18), _set_fixed(tb, "w_i_minus_15_rs_3", x, 3, shift=True)
+    s0 = _set_byte_op(tb, "s0", _set_byte_op(tb, "s0_intermediate", a7, a18, "xor"), a3, "xor")
+    x = vals["w_i_minus_2"]
+    b17, b19, b10 = _set_fixed(tb, "w_i_minus_2_rr_17", x, 17), _set_fixed(tb, "w_i_minus_2_rr_19", x, 19), _set_fixed(tb, "w_i_minus_2_rs_10", x, 10, shift=True)
+    s1 = _set_byte_op(tb, "s1", _set_byte_op(tb, "s1_intermediate", b17, b19, "xor"), b10, "xor")
+    s2 = _set_sum(tb, "s2", vals["w_i_minus_16"], s0, vals["w_i_minus_7"], s1)
+    assert bool((s2 == (st[:, 10] & M32)).all()), "the executor's w[i] is not the extension of its inputs"
+    tr.tables["ShaExtend"] = tb
+    ct = RT.Table(R.chip("ShaExtendControl")[0], n, dev)
+    ct.set("clk_high", clk >> 24); ct.set("clk_low", clk & 0xFFFFFF); ct.set("is_real", 1)
+    al = _syscall_addr_t(ct, "w_ptr", w_ptr)
+    for name, off in (("w_16th_addr", 15), ("w_17th_addr", 16), ("w_64th_addr", 63)):
+        ct.set(name + ".value", _limbs_t(w_ptr + 8 * off)[:, :3])
+    tr.tables["ShaExtendControl"] = ct
+    wa = (w_ptr[:, None] + 8 * torch.arange(64, device=dev)[None, :]).reshape(-1)
+    ar = around.reshape(-1, 4)
+    return _close_precompile_shard(tr, M.SYS_SHA_EXTEND, clk, al, wa, ar[:, 0], ar[:, 2], ar[:, 1], ar[:, 3])
+
+
+def sha_compress_shard_from(events, device="cpu"):
+    """The SHA_COMPRESS precompile shard of the executor's events ([n, 155] int64): ShaCompress (80 rows per call: 8 initialise, 64
+    compress, 8 finalise; padding rows keep cycling the octet flags, compress/trace.rs:L78-L104, L120-L360), ShaCompressControl, ..."""
+    dev = torch.device(device)
+    ev = torch.as_tensor(events, device=dev)
+    n = ev.shape[0]
+    clk, w_ptr, h_ptr = ev[:, 0], ev[:, 1], ev[:, 2]
+    h_rd = ev[:, 3:19].reshape(n, 8, 2)                                                    # (previous timestamp, value)
+    w_rd = ev[:, 19:147].reshape(n, 64, 2)
+    h_wr = ev[:, 147:155]
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    rows = 80 * n
+    air = R.chip("ShaCompress")[0]
+    tb = RT.Table(air, rows, dev)
+    total = tb.main.shape[0]
+    # flags, index and k on EVERY row, padding included
+    idx = torch.arange(total, device=dev) % 80
+    octet, onum = idx % 8, idx // 8
+    ar = torch.arange(total, device=dev)
+    tb.main[ar, tb.L["octet"] + octet] = 1
+    tb.main[ar, tb.L["octet_num"] + onum] = 1
+    tb.main[:, tb.L["index"]] = idx
+    K = torch.tensor(M.SHA_K, dtype=I64, device=dev)
+    kk = torch.where((onum >= 1) & (onum <= 8), K[(idx - 8).clamp(0, 63)], torch.zeros_like(idx))
+    tb.main[:, tb.L["k"]:tb.L["k"] + 2] = _half(kk)
+    # the 80 states of every call
+    h0 = h_rd[:, :, 1] & M32                                                              # [n, 8]
+    w = w_rd[:, :, 1] & M32
+    rotr = lambda v, r: ((v >> r) | (v << (32 - r))) & M32
+    state = torch.zeros((n, 80, 8), dtype=I64, device=dev)
+    state[:, :8] = h0[:, None, :]
+    v = h0.clone()
+    for j in range(64):
+        state[:, 8 + j] = v
+        a_, b_, c_, d_, e_, f_, g_, hh = (v[:, q] for q in range(8))
+        s1 = rotr(e_, 6) ^ rotr(e_, 11) ^ rotr(e_, 25)
+        ch = (e_ & f_) ^ ((~e_ & M32) & g_)
+        t1 = (hh + s1 + ch + int(M.SHA_K[j]) + w[:, j]) & M32
+        s0 = rotr(a_, 2) ^ rotr(a_, 13) ^ rotr(a_, 22)
+        mj = (a_ & b_) ^ (a_ & c_) ^ (b_ & c_)
+        t2 = (s0 + mj) & M32
+        v = torch.stack([(t1 + t2) & M32, a_, b_, c_, (d_ + t1) & M32, e_, f_, g_], dim=1)
+    state[:, 72:] = v[:, None, :]
+    assert bool((((h0 + v) & M32) == (h_wr & M32)).all()), "the executor's digest words are not the compression of its inputs"
+    rep = lambda t: t[:, None].expand(-1, 80).reshape(-1)
+    c = rep(clk)
+    tb.set("clk_high", c >> 24); tb.set("clk_low", c & 0xFFFFFF); tb.set("is_real", 1)
+    tb.set("w_ptr", _limbs_t(rep(w_ptr))[:, :3]); tb.set("h_ptr", _limbs_t(rep(h_ptr))[:, :3])
+    S = state.reshape(rows, 8)
+    for q, nm in enumerate("abcdefgh"):
+        tb.set(nm, _half(S[:, q]))
+    j = idx[:rows]
+    phase = torch.where(j < 8, 0, torch.where(j < 72, 1, 2))
+    tb.set("is_initialize", (phase == 0).to(I64)); tb.set("is_compression", (phase == 1).to(I64)); tb.set("is_finalize", (phase == 2).to(I64))
+    # the memory access of the row: h[j] read at clk, w[j - 8] read at clk + 1, h[j - 72] written at clk + 2
+    hq, wq = (j % 8), (j - 8).clamp(0, 63)
+    ev_i = torch.arange(n, device=dev)[:, None].expand(-1, 80).reshape(-1)
+    addr = torch.where(phase == 1, rep(w_ptr) + 8 * wq, rep(h_ptr) + 8 * hq)
+    t_prev = torch.where(phase == 0, h_rd[ev_i, hq, 0], torch.where(phase == 1, w_rd[ev_i, wq, 0], c))
+    prev_v = torch.where(phase == 1, w_rd[ev_i, wq, 1], h_rd[ev_i, hq, 1])
+    new_v = torch.where(phase == 2, h_wr[ev_i, hq], prev_v)
+    _mem_access_t(tb, "mem", prev_v, t_prev, c + phase)
+    tb.set("mem_value", _half(new_v & M32))
+    al = _limbs_t(addr)[:, :3]
+    tb.set("mem_addr", al)
+    for ph, nm in ((0, "mem_addr_init"), (1, "mem_addr_compress"), (2, "mem_addr_finalize")):
+        tb.set(nm + ".value", al * (phase == ph).to(I64)[:, None])
+    # compression rows
+    cm = (phase == 1).to(I64)
+    a_, b_, c_, d_, e_, f_, g_, hh = (S[:, q] * cm for q in range(8))
+    wv = (prev_v & M32) * cm
+    kq = kk[:rows] * cm
+    e6, e11, e25 = _set_fixed(tb, "e_rr_6", e_, 6), _set_fixed(tb, "e_rr_11", e_, 11), _set_fixed(tb, "e_rr_25", e_, 25)
+    s1 = _set_byte_op(tb, "s1", _set_byte_op(tb, "s1_intermediate", e6, e11, "xor"), e25, "xor")
+    eaf = _set_byte_op(tb, "e_and_f", e_, f_, "and")
+    en = (~e_) & M32
+    tb.set("e_not.value", _half(en))
+    eng = _set_byte_op(tb, "e_not_and_g", en, g_, "and")
+    ch = _set_byte_op(tb, "ch", eaf, eng, "xor")
+    t1 = _set_sum(tb, "temp1", hh, s1, ch, kq, wv)
+    a2, a13, a22 = _set_fixed(tb, "a_rr_2", a_, 2), _set_fixed(tb, "a_rr_13", a_, 13), _set_fixed(tb, "a_rr_22", a_, 22)
+    s0 = _set_byte_op(tb, "s0", _set_byte_op(tb, "s0_intermediate", a2, a13, "xor"), a22, "xor")
+    ab, ac, bc = _set_byte_op(tb, "a_and_b", a_, b_, "and"), _set_byte_op(tb, "a_and_c", a_, c_, "and"), _set_byte_op(tb, "b_and_c", b_, c_, "and")
+    mj = _set_byte_op(tb, "maj", _set_byte_op(tb, "maj_intermediate", ab, ac, "xor"), bc, "xor")
+    t2 = _set_sum(tb, "temp2", s0, mj)
+    _set_sum(tb, "d_add_temp1", d_, t1)
+    _set_sum(tb, "temp1_add_temp2", t1, t2)
+    # every column group above was written on all rows with the compression mask applied to its INPUTS: a non-compression row holds
+    # the operations' values on zero inputs — zero, except e_not = 0xffff 0xffff — which its constraints do not read; the reference
+    # leaves those rows zero, so clear them
+    first, last = tb.L["e_rr_6.value"], tb.L["temp1_add_temp2.value"] + 2
+    tb.main[:rows, first:last] *= cm[:, None]
+    # finalise rows
+    fm = (phase == 2).to(I64)
+    operand = S[torch.arange(rows, device=dev), hq] * fm
+    tb.set("finalized_operand", _half(operand))
+    tb.set("finalize_add.value", _half(((prev_v & M32) + operand) & M32) * fm[:, None])
+    tr.tables["ShaCompress"] = tb
+    ct = RT.Table(R.chip("ShaCompressControl")[0], n, dev)
+    ct.set("clk_high", clk >> 24); ct.set("clk_low", clk & 0xFFFFFF); ct.set("is_real", 1)
+    wl = _syscall_addr_t(ct, "w_ptr", w_ptr)
+    hl = _syscall_addr_t(ct, "h_ptr", h_ptr)
+    ct.set("w_slice_end.value", _limbs_t(w_ptr + 63 * 8)[:, :3]); ct.set("h_slice_end.value", _limbs_t(h_ptr + 7 * 8)[:, :3])
+    ct.set("initial_state", _half(h0).reshape(n, 16)); ct.set("final_state", _half(v).reshape(n, 16))
+    tr.tables["ShaCompressControl"] = ct
+    # local memory: the eight h words (read at clk, written at clk + 2), the 64 w words (read at clk + 1)
+    eight, sixty4 = torch.arange(8, device=dev)[None, :], torch.arange(64, device=dev)[None, :]
+    wa = torch.cat([(h_ptr[:, None] + 8 * eight).reshape(-1), (w_ptr[:, None] + 8 * sixty4).reshape(-1)])
+    t_i = torch.cat([h_rd[:, :, 0].reshape(-1), w_rd[:, :, 0].reshape(-1)])
+    v_i = torch.cat([h_rd[:, :, 1].reshape(-1), w_rd[:, :, 1].reshape(-1)])
+    t_f = torch.cat([(clk[:, None] + 2).expand(-1, 8).reshape(-1), (clk[:, None] + 1).expand(-1, 64).reshape(-1)])
+    v_f = torch.cat([h_wr.reshape(-1), w_rd[:, :, 1].reshape(-1)])
+    return _close_precompile_shard(tr, M.SYS_SHA_COMPRESS, clk, wl, wa, t_i, t_f, v_i, v_f, arg2_limbs=hl)   # arg2 = h_ptr

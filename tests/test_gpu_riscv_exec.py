@@ -65,6 +65,8 @@ def prove_both(api, machine, tabs, publics, L, lsh, batch, LB, NQ, PW, verify=Tr
 @pytest.mark.parametrize("program,stdin,max_cycles,kinds", [
     ("fibonacci", [struct.pack("<Q", 300)], 3000, ["core", "core", "core", "memory"]),
     ("keccak", [bytes(300)], 6000, ["core", "core", "keccak", "memory"]),
+    ("sha2", [bytes(100)], 1 << 20, ["core", "sha_extend", "sha_compress", "memory"]),
+    ("poseidon2", [struct.pack("<Q", 20)], 1 << 20, ["core", "poseidon2", "sha_extend", "sha_compress", "memory"]),
 ])
 def test_every_shard_of_a_real_program_matches_the_oracle(api, program, stdin, max_cycles, kinds, monkeypatch):
     monkeypatch.setenv("SP1HIP_ZC_MUL_MIN_ROWS", "0")                    # the fused MulOperation piece on these small tables too

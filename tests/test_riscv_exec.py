@@ -83,6 +83,58 @@ def test_keccak_elf_with_its_precompile_shard():
     assert len(ex.output(0)) == 32 and last.committed_value_digest == _digest_words(ex.output(0))
 
 
+def test_sha2_elf_with_its_two_precompile_shards():
+    data = bytes(range(200))
+    ex, kinds, cycles, last = run_program(_elf("sha2"), [data], 8000)
+    assert kinds[-3:] == ["sha_extend", "sha_compress", "memory"] and set(kinds[:-3]) == {"core"}
+    assert last.halted and last.exit_code == 0
+    assert hashlib.sha256(data).digest() in ex.output(0)                 # the guest commits SHA-256 of its input, computed by the precompiles
+    assert last.committed_value_digest == _digest_words(ex.output(0))    # ... and so is the digest of its public values
+
+
+def test_poseidon2_elf_with_its_precompile_shards():
+    ex, kinds, cycles, last = run_program(_elf("poseidon2"), [struct.pack("<Q", 20)], 1 << 20)
+    assert kinds == ["core", "poseidon2", "sha_extend", "sha_compress", "memory"]
+    assert last.halted and last.exit_code == 0 and b"successfully evaluated poseidon2" in ex.output(1)
+    assert last.committed_value_digest == _digest_words(ex.output(0))
+
+
+def test_poseidon2_system_call_against_the_host_permutation():
+    """Two POSEIDON2 calls from a hand-assembled program (the second on a state the CPU touched in between): the words written are
+    the library's host permutation of the words read, and every shard of the run checks."""
+    import ctypes
+    from sp1_amd import _lib
+
+    def permute(words):                                                   # canonical words -> canonical words
+        m = np.ascontiguousarray((words.astype(np.uint64) << np.uint64(32)) % np.uint64(MC.P), dtype=np.uint32)
+        _lib.check(_lib.load().sp1hip_poseidon2_permute_host(m.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 1, 1))
+        return (m.astype(np.uint64) * np.uint64(MC.R_INV)) % np.uint64(MC.P)
+    state = [(17 * i + 3, (1 << 30) + i) for i in range(8)]
+    data = b"".join(struct.pack("<II", lo, hi) for lo, hi in state) + bytes(64)
+    w = A.li(10, 0x78100000) + A.li(11, 0) + A.li(5, 0x133) + [A.enc("ecall")] + [A.enc("ld", 13, 10, 0), A.enc("sd", 13, 10, 64)] \
+        + A.li(5, 0x133) + [A.enc("ecall")] + A.halt(0)
+    ex, kinds, _, last = run_program(A.elf(w, data=data), [], 1 << 20)
+    assert kinds == ["core", "poseidon2", "memory"] and last.exit_code == 0
+    gm = {int(r[0]): int(r[2]) & M64 for r in ex.global_memory()}
+    flat = np.array([x for pair in state for x in pair], dtype=np.uint32)
+    once = permute(flat)
+    twice = permute(once)
+    assert [gm[0x78100000 + 8 * i] for i in range(8)] == [int(twice[2 * i]) | (int(twice[2 * i + 1]) << 32) for i in range(8)]
+    assert gm[0x78100000 + 64] == int(once[0]) | (int(once[1]) << 32)     # the CPU copied word 0 of the first result
+
+
+def test_a_flipped_sha_cell_is_caught():
+    from sp1_amd.machines import riscv as R
+    ex = X.Executor(_elf("sha2"), stdin=[bytes(10)])
+    shards = list(X.program_shards(ex, 1 << 20))
+    kind, machine, tabs, publics, _, _ = next(s for s in shards if s[0] == "sha_compress")
+    assert check_shard(machine, tabs, publics) == ([], 0)
+    col = R.chip("ShaCompress")[0].layout["temp1.value"]
+    tabs["ShaCompress"][1][20, col] = (tabs["ShaCompress"][1][20, col] + 1) % MC.P
+    bad, imb = check_shard(machine, tabs, publics)
+    assert bad == ["ShaCompress"]
+
+
 def test_loop_elf():
     ex, kinds, cycles, last = run_program(_elf("loop"), [struct.pack("<Q", 500)], 1 << 20)
     assert kinds == ["core", "memory"] and last.exit_code == 0
