@@ -18,6 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FULL_CYCLES = 1 << 23
+# the other guests: the power of two below the cycle count at which THEIR mix reaches the area threshold (measured cells per cycle:
+# loop 37, keccak 61, poseidon2 65, sha2 113)
+FULL_CYCLES_OF = {"fibonacci": 1 << 23, "loop": 1 << 23, "keccak": 1 << 22, "poseidon2": 1 << 22, "sha2": 1 << 21}
 CYCLES_PER_UNIT = {"fibonacci": 9, "loop": 4, "keccak": 7, "sha2": 4, "poseidon2": 9}   # measured: cycles per loop iteration / per input byte
 
 
@@ -29,10 +32,10 @@ def stdin_of(program, cycles):
 
 def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
     """[(AirProgram, InteractionProgram, main ColMajor, prep ColMajor | None)] in chip-name order + meta for core shard
-    `shard_index` of `program` run with shards of FULL_CYCLES >> 2k cycles."""
+    `shard_index` of `program` run with shards of FULL_CYCLES_OF[program] >> 2k cycles."""
     from core_real import SYNTHETIC, to_col_major
     from sp1_amd.machines import riscv_exec as X, riscv_trace as RT
-    max_cycles = FULL_CYCLES >> (2 * k)
+    max_cycles = FULL_CYCLES_OF[program] >> (2 * k)
     elf = open(os.path.join(ROOT, "bench", "programs", program + ".elf"), "rb").read()
     ex = X.Executor(elf, stdin=stdin_of(program, (shard_index + 1) * max_cycles + max_cycles // 8))
     for i in range(shard_index + 1):                         # the shards before this rank's run without keeping their events
