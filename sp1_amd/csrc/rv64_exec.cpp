@@ -19,6 +19,7 @@
 //   per-shard local memory events    tracing.rs:L548-L577, L1490-L1515 (first / last access of every address touched in the shard)
 // User mode (page protection, untrusted programs), the trap context and the other precompiles are not implemented: an ELF that
 // needs them stops with an error naming the system call.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -565,7 +566,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear();
-    if (vm.record && max_cycles <= (1ull << 26)) vm.events.reserve((size_t)max_cycles * EV);   // one allocation, not a doubling chain of copies
+    if (vm.record) vm.events.reserve((size_t)std::min<uint64_t>(max_cycles, 1ull << 24) * EV);   // one allocation (at most 2.7 GB), not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
     while (!vm.halted && (vm.unc || vm.cycles - c0 < max_cycles))
