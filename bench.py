@@ -93,7 +93,7 @@ def programs_of(kind, names):
     return R.compress_machine()
 
 
-PROGRAMS = ("fibonacci", "loop", "keccak", "sha2", "poseidon2")   # real guest programs: bench/program_shard.py
+PROGRAMS = ("fibonacci", "loop", "keccak", "sha2", "poseidon2", "rsp")   # real guest programs: bench/program_shard.py
 
 
 def publics_of(kind):

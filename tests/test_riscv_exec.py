@@ -135,6 +135,27 @@ def test_a_flipped_sha_cell_is_caught():
     assert bad == ["ShaCompress"]
 
 
+def test_rsp_elf_core_shards_until_its_first_hook():
+    """The Reth block-execution client on a recorded input: its first phases (deserialisation, witness database) are ordinary
+    rv64im + KECCAK_PERMUTE; a shard from the start and one from 3e7 cycles in check row by row. The run ends with an error at
+    the first hook (fd 20), which the executor names instead of skipping."""
+    from sp1_amd import _lib
+    data = open(os.path.join(ROOT, "bench", "programs", "rsp_input_21740136.bin"), "rb").read()
+    ex = X.Executor(_elf("rsp"), stdin=[data])
+    sh = ex.run_shard(1 << 16)
+    machine, tabs, publics = X.shard_tables(ex, sh)
+    assert check_shard(machine, tabs, publics) == ([], 0)
+    ex.run_shard(30_000_000, record=False)
+    sh = ex.run_shard(1 << 16)
+    assert sh.cycles == 1 << 16 and sh.clk_start > 8 * 30_000_000
+    machine, tabs, publics = X.shard_tables(ex, sh)
+    assert check_shard(machine, tabs, publics) == ([], 0)
+    assert {"LoadByte", "StoreDouble", "Bitwise", "Global"} <= {a.name for a, _ in machine}
+    with pytest.raises(_lib.Sp1HipError, match="hook"):
+        while True:
+            ex.run_shard(1 << 24, record=False)
+
+
 def test_loop_elf():
     ex, kinds, cycles, last = run_program(_elf("loop"), [struct.pack("<Q", 500)], 1 << 20)
     assert kinds == ["core", "memory"] and last.exit_code == 0
