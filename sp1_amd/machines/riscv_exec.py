@@ -11,10 +11,15 @@ The proof statement per shard is the reference's: the chips' constraints hold on
 / State buses balance inside the shard, and what crosses shards (memory states, syscalls) goes through the Global chip's digest.
 """
 import ctypes as C
+import types
 
 import numpy as np
+import torch
 
 from .. import _lib
+from . import riscv as R
+from . import riscv_trace as RT
+from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, limbs16
 
 EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS, SHA_EXTEND_WORDS, SHA_COMPRESS_WORDS = 20, 77, 26, 786, 155
 (E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
@@ -105,14 +110,6 @@ class Executor:
 
 # ---------------------------------------------------------------------------------------------------------------------
 # events -> tables
-import types
-
-import torch
-
-from . import riscv as R
-from . import riscv_trace as RT
-from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, bytes8, finv, limbs16
-
 _OPN = {v: k for k, v in OPC.items()}
 _ALU_CHIP = {}
 for _chip, _ops in RT.ALU_KINDS.items():

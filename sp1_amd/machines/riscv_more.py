@@ -24,7 +24,7 @@ reference makes of it (keccak256/air.rs) are pinned; the field order below is th
 permutes columns, not polynomials.
 """
 from ..air import P
-from .riscv import (ADDRESS_OP, ALU_TYPE, B_LTU, B_RANGE, B_U8RANGE, BYTE, CLK_INC, CPU_STATE, GLOBAL, INV, LT_UNSIGNED, MEM_ACCESS, MEMORY, MUL_OP, OPC,
+from .riscv import (ADDRESS_OP, ALU_TYPE, B_AND, B_LTU, B_RANGE, B_U8RANGE, B_XOR, BYTE, CLK_INC, CPU_STATE, GLOBAL, INV, LT_UNSIGNED, MEM_ACCESS, MEMORY, MUL_OP, OPC,
                     PC_INC, R_TYPE, S, SYSCALL, U16_TO_U8, _chip, _done, clk_low_of, eval_add, eval_addr_add, eval_alu_type, eval_compare_u16, eval_cpu_state,
                     eval_lt_unsigned, eval_memory_access, eval_msb, eval_mul, eval_r_type, next_pc_inc, send_byte, slice_range_check_u16,
                     slice_range_check_u8, u16_to_u8_safe)
@@ -472,7 +472,6 @@ HALF_WORD = S(("value", 2),)                                                    
 CLK_OP = S(("next_clk_16_24", 1), ("next_clk_0_16", 1), ("is_overflow", 1))              # operations/clk.rs
 SHA_EXTEND, SHA_COMPRESS = 10, 11                                                        # hypercube/src/lookup/interaction.rs:L45-L49
 SYS_SHA_EXTEND, SYS_SHA_COMPRESS = 0x05, 0x06
-B_AND, B_XOR = 0, 2                                                                      # ByteOpcode (core/executor/src/opcode.rs): AND = 0, OR = 1, XOR = 2
 SHA_K = [
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
     0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
