@@ -1718,10 +1718,11 @@ constexpr size_t ZC_LDS_BUDGET = ZC_LDS_CU;
 // workgroups = 192 lanes against one 128-lane workgroup). Ties go to the wider workgroup. 0 if even one wave's file does not
 // fit 160 KB (R > 160 in the extension rounds): the caller then runs the chip's finer chunks.
 template <bool FIRST> static inline uint32_t zc_wg_for(uint32_t n_regs, size_t other_lds) {
-    // SP1HIP_ZC_WG=occ: always the occupancy rule above. Default: the widest workgroup whose file fits 64 KB (the rule every
-    // measurement of rounds 2-4 was taken with), the occupancy rule only for files beyond that (65 .. 160 registers: one to
-    // two waves per CU — slow, but no scratch)
-    const bool occ = [] { const char* e = getenv("SP1HIP_ZC_WG"); return e && e[0] == 'o'; }();
+    // Default (end of round 5): the occupancy rule above — the workgroup width that puts the most lanes on a CU. SP1HIP_ZC_WG=legacy:
+    // the widest workgroup whose file fits 64 KB (the rule every measurement of rounds 2-4 was taken with), the occupancy rule
+    // only for files beyond that. Measured with two fork streams: fibonacci shard 86.4-86.8 either way, recorded-shape shard
+    // 74.7 -> 74.2-74.6 (a 15-register program runs 640 lanes per CU instead of 512, a 7-register one 2,048 instead of 1,280)
+    const bool occ = [] { const char* e = getenv("SP1HIP_ZC_WG"); return !(e && e[0] == 'l'); }();     // default: occupancy; "legacy": the 64 KB rule
     if (!occ)
         for (uint32_t wg = 256; wg >= 64; wg >>= 1)
             if (other_lds + zc_rf_lane_bytes<FIRST>(n_regs) * wg <= 64 * 1024) return wg;
@@ -1801,10 +1802,12 @@ static int launch_biv_round(uint32_t max_regs, bool staged, const ZcDesc* d_desc
 int eq_prefix_tables_soa_async(const kb::Ext* h_point, int d, uint32_t* d_out, hipStream_t s);
 }
 
-// fork streams a round's launches are spread over, besides the caller's own (SP1HIP_ZC_NFORK = 1..3, default 3: with the caller's
-// stream the four hardware queues a process gets by default)
+// fork streams a round's launches are spread over, besides the caller's own (SP1HIP_ZC_NFORK = 1..3). Default 2 since the end of
+// round 5: with three (+ the caller's = the four hardware queues a process gets) the commit's side stream shares a queue with one of
+// them; measured A/B/A/B on one box, whole proof: fibonacci shard 89.2 -> 86.4-86.8 ms, recorded-shape shard 76.8 -> 74.7 (one
+// fork: 88.0 / —)
 static int zc_fork_streams() {
-    static const int n = [] { const char* e = getenv("SP1HIP_ZC_NFORK"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v > 3 ? 3 : v; }();
+    static const int n = [] { const char* e = getenv("SP1HIP_ZC_NFORK"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 3 ? 3 : v; }();
     return n;
 }
 
