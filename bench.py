@@ -853,7 +853,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": ("synthetic: traces of an rv64im test program executed by this repository's executor + 2 synthetic closing chips"
                      if kind == "real" else "synthetic: seeded traces of real chips" if kind == "precompile"
-                     else "the reference's guest binary (bench/programs/%s.elf) on a synthetic input of sp1-gpu perf's form, executed by this "
+                     else "the reference's guest binary (bench/programs/%s.elf.gz) on a synthetic input of sp1-gpu perf's form, executed by this "
                           "repository's rv64im executor; 2 synthetic closing chips stand for eval_public_values" % kind if kind in PROGRAMS else "synthetic"),
             "proofs_per_s": world * args.steps / dt, "cells_per_s": cells_per_s,
             "riscv_instructions_per_s": world * args.steps * cycles / dt if cycles else None,

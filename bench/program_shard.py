@@ -1,5 +1,5 @@
 """Core shards of REAL guest programs (VERDICT r4 "real-program workloads: no"): the reference's own benchmark guests
-(bench/programs/*.elf, see the README there) executed by the rv64im executor of libsp1hip.so and traced by
+(bench/programs/*.elf.gz, see the README there) executed by the rv64im executor of libsp1hip.so and traced by
 sp1_amd/machines/riscv_exec.py — every chip a real chip of the RISC-V machine, the events those of the guest's execution.
 
 The default is what BASELINE.json's metric is quoted on: a full core shard of `fibonacci` ("RISC-V cycles proved / second").
@@ -29,7 +29,8 @@ def stdin_of(program, cycles):
     if program == "rsp":             # `write_vec(client_input)`: block 21740136 of the reference's perf inputs (lib.rs:L47-L52). The guest runs
         # 4.8e7 cycles (deserialisation, witness database: 5 full core shards) before its first hook — a hint computed outside the
         # VM (fd 20), which this executor does not implement: the shards before it are complete
-        return [open(os.path.join(ROOT, "bench", "programs", "rsp_input_21740136.bin"), "rb").read()]
+        from sp1_amd.machines.riscv_exec import guest_file
+        return [guest_file("rsp_input_21740136.bin")]
     n = cycles // CYCLES_PER_UNIT[program] + 1
     return [bytes(n)] if program in ("keccak", "sha2") else [struct.pack("<Q", n)]  # `write_vec(vec![0u8; n])` / `write(&n)`, n: usize
 
@@ -40,7 +41,7 @@ def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
     from core_real import SYNTHETIC, to_col_major
     from sp1_amd.machines import riscv_exec as X, riscv_trace as RT
     max_cycles = FULL_CYCLES_OF[program] >> (2 * k)
-    elf = open(os.path.join(ROOT, "bench", "programs", program + ".elf"), "rb").read()
+    elf = X.guest_file(program + ".elf")
     ex = X.Executor(elf, stdin=stdin_of(program, (shard_index + 1) * max_cycles + max_cycles // 8))
     for i in range(shard_index + 1):                         # the shards before this rank's run without keeping their events
         shard = ex.run_shard(max_cycles, record=i == shard_index, copy=False)

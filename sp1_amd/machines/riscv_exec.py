@@ -11,6 +11,8 @@ The proof statement per shard is the reference's: the chips' constraints hold on
 / State buses balance inside the shard, and what crosses shards (memory states, syscalls) goes through the Global chip's digest.
 """
 import ctypes as C
+import gzip
+import os
 import types
 
 import numpy as np
@@ -24,6 +26,16 @@ from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, limbs16
 EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS, SHA_EXTEND_WORDS, SHA_COMPRESS_WORDS = 20, 77, 26, 786, 155
 (E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
  E_NEXT_PC, E_SPARE) = range(EV_WORDS)
+
+
+GUESTS_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "bench", "programs")
+
+
+def guest_file(name):
+    """The bytes of bench/programs/<name>.gz: the reference's guest binaries (and rsp's input) are stored gzip-compressed,
+    unmodified otherwise (bench/programs/README.md)."""
+    with gzip.open(os.path.join(GUESTS_DIR, name + ".gz"), "rb") as f:
+        return f.read()
 
 
 class ExecutedShard:

@@ -1,4 +1,4 @@
-"""GPU parity (-m gpu) on REAL guest programs: the reference's fibonacci / keccak guests (bench/programs/*.elf) executed by the
+"""GPU parity (-m gpu) on REAL guest programs: the reference's fibonacci / keccak guests (bench/programs/*.elf.gz) executed by the
 rv64im executor of libsp1hip.so, every shard of the run — core shards, the KECCAK_PERMUTE precompile shard, the memory shard —
 proved by `sp1hip_prove_shard` with the shard's own public values: bytes == the oracle prover's on the same tables, and the
 oracle's verify_shard accepts. One larger fibonacci shard (2^18 cycles) with production parameters."""
@@ -28,7 +28,7 @@ def api():
 
 
 def _elf(name):
-    return open(os.path.join(ROOT, "bench", "programs", name + ".elf"), "rb").read()
+    return X.guest_file(name + ".elf")
 
 
 def _shapes_only(machine):

@@ -1,6 +1,6 @@
 """Real guest programs (CPU): the rv64im executor of libsp1hip.so (host code: no GPU needed) and the tables made from its events.
 
-* the reference's own guest binaries (bench/programs/*.elf, unmodified copies of /root/reference/sp1-gpu/crates/prover_components/
+* the reference's own guest binaries (bench/programs/*.elf.gz, gzip-compressed but otherwise unmodified copies of /root/reference/sp1-gpu/crates/prover_components/
   programs/*/riscv64im-succinct-zkvm-elf — workload inputs, see bench/programs/README.md) run to HALT with exit code 0; the
   public-values digest the guest COMMITs (SHA-256 computed by some thousands of executed rv64im instructions) equals hashlib's
   over the bytes it wrote to the public-values descriptor;
@@ -29,7 +29,7 @@ M64 = (1 << 64) - 1
 
 
 def _elf(name):
-    return open(os.path.join(ROOT, "bench", "programs", name + ".elf"), "rb").read()
+    return X.guest_file(name + ".elf")
 
 
 def check_shard(machine, tabs, publics):
@@ -140,7 +140,7 @@ def test_rsp_elf_core_shards_until_its_first_hook():
     rv64im + KECCAK_PERMUTE; a shard from the start and one from 3e7 cycles in check row by row. The run ends with an error at
     the first hook (fd 20), which the executor names instead of skipping."""
     from sp1_amd import _lib
-    data = open(os.path.join(ROOT, "bench", "programs", "rsp_input_21740136.bin"), "rb").read()
+    data = X.guest_file("rsp_input_21740136.bin")
     ex = X.Executor(_elf("rsp"), stdin=[data])
     sh = ex.run_shard(1 << 16)
     machine, tabs, publics = X.shard_tables(ex, sh)
