@@ -60,6 +60,22 @@ def run_program(elf, stdin, max_cycles):
     return ex, kinds, cycles, last
 
 
+GUEST_SHA256 = {   # of the files in the reference tree (bench/programs/README.md names them): the fixtures are those bytes
+    "fibonacci.elf": "b37b2e0ab54497b1b0e24001a4e7d556479563dcfcc2802f77278141a3c109b4",
+    "loop.elf": "daa497ce9a59cc06a014cb437457737dab0b9e27063a00c6619e814ba457677a",
+    "keccak.elf": "cf37e0e70fb9f72f095f36e2b2a8a398d1463ee14f5bfc6da010128b8f72dfbf",
+    "sha2.elf": "233da949bacfd62e8d9356c19acb4bbe0e42c60a5f327dc213df8efef56f8965",
+    "poseidon2.elf": "c1335ee14dfd1d2ff92d8159468bc4b8f034cb6b8b556e2947c7e5942c0a72b3",
+    "rsp.elf": "6077a757923815224135f8b6d7e312ceebe3dc4ce5fef57a9619a65a81ff2dd1",
+    "rsp_input_21740136.bin": "b52377988c8cf68246234790c7c4cde97d670fa94d86d5f65e8501998d458e25",
+}
+
+
+def test_guest_fixtures_are_the_reference_binaries():
+    for name, digest in GUEST_SHA256.items():
+        assert hashlib.sha256(X.guest_file(name)).hexdigest() == digest, name
+
+
 def _digest_words(data):
     return list(struct.unpack("<8I", hashlib.sha256(data).digest()))
 
