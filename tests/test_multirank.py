@@ -255,3 +255,57 @@ def test_compress_tree_at_world_8_fully_verifies_the_root_gloo():
         assert sum(results[r][1][li][3] for r in range(world)) == want_proved
         assert sum(results[r][1][li][4] for r in range(world)) == sum(results[r][1][li][5] for r in range(world))   # bytes sent == bytes received
     assert sum(results[r][1][0][4] for r in range(world)) > 0
+
+
+# ---- a real guest across ranks: rank r proves shard r of ONE execution (bench.py's program workloads, bench/program_shard.py)
+def _guest_shard_worker(rank, world, port, max_cycles, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import struct
+    import pyoracle as orc
+    from sp1_amd import shards
+    from sp1_amd.machines import riscv_exec as X, riscv_trace as RT
+    orc.set_threads(1)
+    ex = X.Executor(X.guest_file("fibonacci.elf"), stdin=[struct.pack("<Q", 10_000)])
+    for i in range(rank + 1):                       # the shards before this rank's run without keeping their events
+        sh = ex.run_shard(max_cycles, record=i == rank)
+    machine, tabs, publics = X.shard_tables(ex, sh)
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None) for a, i in machine]
+    L, lsh, batch = 17, 12, 8
+    prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, 1)
+    ch = orc.Challenger()
+    ch.observe(prep.commit)
+    orc.set_gkr_sparse(True)
+    proof = orc.shard_prove(host, RT.to_monty_np(publics), prep, L, lsh, batch, ch, 1, 5, 4)
+    shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None) for a, i in machine]
+    v_ch = orc.Challenger()
+    v_ch.observe(prep.commit)
+    ok = orc.shard_verify(shapes, prep.commit, proof, L, lsh, v_ch, 1, 5, 4) == 0
+    merged = shards.gather_blobs({rank: proof})
+    q.put((rank, ok, sh.index, sh.clk_start, sh.clk_end, sh.pc_start, sh.next_pc, sorted((k, len(v)) for k, v in merged.items())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_prove_consecutive_shards_of_one_guest_execution_gloo():
+    """The reference's fibonacci guest, world 2: rank r runs shards 0..r-1 with recording off and proves shard r (the oracle
+    prover stands in for the GPU here); the proofs verify, the shards chain (clock and pc), and every rank ends up with both."""
+    import __graft_entry__ as g
+    g.build_hip()
+    g.build_oracle()
+    world, max_cycles = 2, 2000
+    port = 29500 + (os.getpid() % 2000) + 911
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_guest_shard_worker, args=(r, world, port, max_cycles, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, i0, c0s, c0e, p0s, p0n, m0), (r1, ok1, i1, c1s, c1e, p1s, p1n, m1) = results
+    assert ok0 and ok1 and (i0, i1) == (0, 1)
+    assert c0s == 1 and c1s == c0e and p1s == p0n                 # shard 1 starts where shard 0 stopped
+    assert m0 == m1 and [k for k, _ in m0] == [0, 1] and all(n > 10_000 for _, n in m0)
