@@ -45,7 +45,7 @@ struct Instr { uint32_t op; uint32_t a; uint64_t b, c; bool imm_b, imm_c; };
 
 constexpr uint64_t HALT_PC = 1, CLK_INC = 8, ECALL_EXTRA = 256;
 constexpr uint64_t SYS_HALT = 0x00, SYS_WRITE = 0x02, SYS_ENTER_UNC = 0x03, SYS_EXIT_UNC = 0x04, SYS_KECCAK = 0x00010109,
-                   SYS_POSEIDON2 = 0x00000133, SYS_SHA_EXTEND = 0x00300105, SYS_SHA_COMPRESS = 0x00010106, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
+                   SYS_POSEIDON2 = 0x00000133, SYS_UINT256_MUL = 0x0001011D, SYS_SHA_EXTEND = 0x00300105, SYS_SHA_COMPRESS = 0x00010106, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
 constexpr uint64_t FD_PUBLIC_VALUES = 13, FD_HINT = 14;
 
 Instr decode(uint32_t w) {
@@ -119,6 +119,33 @@ const uint64_t KECCAK_RC[24] = {
     0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
     0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
 
+// (x * y) mod m on 256-bit little-endian limbs; m = 0 means 2^256 (vm/syscall/uint256.rs, minimal/precompiles/uint256.rs)
+void uint256_mulmod(const uint64_t x[4], const uint64_t y[4], const uint64_t m[4], uint64_t out[4]) {
+    uint64_t prod[8] = {0};
+    for (int i = 0; i < 4; ++i) {
+        unsigned __int128 carry = 0;
+        for (int j = 0; j < 4; ++j) {
+            const unsigned __int128 t = (unsigned __int128)x[i] * y[j] + prod[i + j] + carry;
+            prod[i + j] = (uint64_t)t; carry = t >> 64;
+        }
+        prod[i + 4] = (uint64_t)carry;
+    }
+    if (!(m[0] | m[1] | m[2] | m[3])) { memcpy(out, prod, 32); return; }
+    uint64_t rem[5] = {0};                                             // one bit wider than m while shifting
+    for (int bit = 511; bit >= 0; --bit) {
+        for (int k = 4; k > 0; --k) rem[k] = (rem[k] << 1) | (rem[k - 1] >> 63);
+        rem[0] = (rem[0] << 1) | ((prod[bit >> 6] >> (bit & 63)) & 1);
+        bool ge = rem[4] != 0;
+        if (!ge) { ge = true; for (int k = 3; k >= 0; --k) if (rem[k] != m[k]) { ge = rem[k] > m[k]; break; } }
+        if (ge) {
+            unsigned __int128 borrow = 0;
+            for (int k = 0; k < 4; ++k) { const unsigned __int128 t = (unsigned __int128)rem[k] - m[k] - borrow; rem[k] = (uint64_t)t; borrow = (t >> 64) & 1; }
+            rem[4] -= (uint64_t)borrow;
+        }
+    }
+    memcpy(out, rem, 32);
+}
+
 void keccak_f(uint64_t s[25]) {                                        // FIPS 202, state s[x + 5 y]
     static const int rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     auto rl = [](uint64_t v, int r) { return r ? (v << r) | (v >> (64 - r)) : v; };
@@ -154,6 +181,7 @@ struct Vm {
     std::vector<uint8_t> local_closed;
     std::vector<uint64_t> sha_extend;                                  // [k][clk, w_ptr, 48 x (4 x (previous timestamp, word read), previous timestamp and value of w[i], w[i] written), 64 x (timestamp, value before; after)]
     std::vector<uint64_t> sha_compress;                                // [k][clk, w_ptr, h_ptr, 8 x (previous timestamp, h word), 64 x (previous timestamp, w word), 8 h words written]
+    std::vector<uint64_t> uint256;                                     // [k][clk, x_ptr, y_ptr, 4 x (previous timestamp, x word), 8 x (previous timestamp, y / modulus word), 4 x words written]
     std::vector<uint64_t> poseidon2;                                   // POSEIDON2 events: [k][clk, pointer, 8 x (previous timestamp, word read), 8 words written]
     std::vector<uint64_t> precompile;                                  // Keccak events: [k][clk, pointer, 25 x (previous timestamp, word read), 25 words written]
     // the whole run
@@ -467,6 +495,17 @@ struct Vm {
                 sha_compress.insert(sha_compress.end(), rec.begin(), rec.end());
                 break;
             }
+            case SYS_UINT256_MUL: {                                    // y and the modulus (y_ptr + 32) read at clk, x rewritten at clk + 1
+                if ((b & 7) || (c & 7)) return fail("UINT256_MUL arguments");
+                std::vector<uint64_t> rec = {clk, b, c};
+                uint64_t x[4], ym[8], r[4];
+                for (int i = 0; i < 4; ++i) { Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); x[i] = m.val; }
+                for (int i = 0; i < 8; ++i) { Cell& m = cell(c + 8 * i); touch_precompile(m, c + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); ym[i] = m.val; m.ts = clk; }
+                uint256_mulmod(x, ym, ym + 4, r);
+                for (int i = 0; i < 4; ++i) { Cell& m = cell(b + 8 * i); m.val = r[i]; m.ts = clk + 1; rec.push_back(r[i]); }
+                uint256.insert(uint256.end(), rec.begin(), rec.end());
+                break;
+            }
             case SYS_POSEIDON2: {                                      // vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs
                 if ((b & 7) || c != 0) return fail("POSEIDON2 arguments");
                 uint32_t st[16];
@@ -565,7 +604,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     if (!h || !info) { sp1hip::set_error("sp1hip_rv64_run_shard: null argument"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
-    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear();
+    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear(); vm.uint256.clear();
     if (vm.record) vm.events.reserve((size_t)std::min<uint64_t>(max_cycles, 1ull << 24) * EV);   // one allocation (at most 2.7 GB), not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
@@ -575,6 +614,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     info->n_cycles = vm.cycles - c0; info->n_events = vm.events.size() / EV; info->n_local = vm.local.size() / 5; info->n_keccak = vm.precompile.size() / SP1HIP_RV64_KECCAK_WORDS;
     info->n_poseidon2 = vm.poseidon2.size() / SP1HIP_RV64_POSEIDON2_WORDS;
     info->n_sha_extend = vm.sha_extend.size() / SP1HIP_RV64_SHA_EXTEND_WORDS; info->n_sha_compress = vm.sha_compress.size() / SP1HIP_RV64_SHA_COMPRESS_WORDS;
+    info->n_uint256 = vm.uint256.size() / SP1HIP_RV64_UINT256_WORDS;
     info->next_pc = vm.pc; info->clk_end = vm.clk; info->halted = vm.halted; info->exit_code = vm.exit_code;
     info->shard = vm.shard++;
     info->commit_syscall = vm.commit_syscall; info->commit_deferred_syscall = vm.commit_deferred_syscall;
@@ -595,6 +635,7 @@ const uint64_t* sp1hip_rv64_keccak_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)-
 const uint64_t* sp1hip_rv64_poseidon2_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->poseidon2.data(); }
 const uint64_t* sp1hip_rv64_sha_extend_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->sha_extend.data(); }
 const uint64_t* sp1hip_rv64_sha_compress_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->sha_compress.data(); }
+const uint64_t* sp1hip_rv64_uint256_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->uint256.data(); }
 
 int sp1hip_rv64_program(sp1hip_rv64_vm_t h, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table) {
     if (!h) return SP1HIP_ERROR_INVALID_ARGUMENT;

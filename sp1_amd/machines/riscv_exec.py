@@ -23,7 +23,7 @@ from . import riscv as R
 from . import riscv_trace as RT
 from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, limbs16
 
-EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS, SHA_EXTEND_WORDS, SHA_COMPRESS_WORDS = 20, 77, 26, 786, 155
+EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS, SHA_EXTEND_WORDS, SHA_COMPRESS_WORDS, UINT256_WORDS = 20, 77, 26, 786, 155, 31
 (E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
  E_NEXT_PC, E_SPARE) = range(EV_WORDS)
 
@@ -42,10 +42,10 @@ class ExecutedShard:
     """One shard of an execution: `events` [n, 20] / `local` [m, 5] / `keccak` [k, 77] int64 arrays (two's complement images of
     the executor's u64 words) and the shard's public-value fields."""
 
-    def __init__(self, info, events, local, keccak, poseidon2, sha_extend, sha_compress):
+    def __init__(self, info, events, local, keccak, poseidon2, sha_extend, sha_compress, uint256):
         self.index, self.cycles = int(info.shard), int(info.n_cycles)
         self.events, self.local, self.keccak, self.poseidon2 = events, local, keccak, poseidon2
-        self.sha_extend, self.sha_compress = sha_extend, sha_compress
+        self.sha_extend, self.sha_compress, self.uint256 = sha_extend, sha_compress, uint256
         self.pc_start, self.next_pc = int(info.pc_start), int(info.next_pc)
         self.clk_start, self.clk_end = int(info.clk_start), int(info.clk_end)
         self.halted, self.exit_code = bool(info.halted), int(info.exit_code)
@@ -94,7 +94,8 @@ class Executor:
                               self._matrix(self.lib.sp1hip_rv64_keccak_events(self.h), info.n_keccak, KECCAK_WORDS),
                               self._matrix(self.lib.sp1hip_rv64_poseidon2_events(self.h), info.n_poseidon2, POSEIDON2_WORDS),
                               self._matrix(self.lib.sp1hip_rv64_sha_extend_events(self.h), info.n_sha_extend, SHA_EXTEND_WORDS),
-                              self._matrix(self.lib.sp1hip_rv64_sha_compress_events(self.h), info.n_sha_compress, SHA_COMPRESS_WORDS))
+                              self._matrix(self.lib.sp1hip_rv64_sha_compress_events(self.h), info.n_sha_compress, SHA_COMPRESS_WORDS),
+                              self._matrix(self.lib.sp1hip_rv64_uint256_events(self.h), info.n_uint256, UINT256_WORDS))
         self.halted = shard.halted
         return shard
 
@@ -377,7 +378,7 @@ def program_shards(executor, max_cycles, device="cpu"):
     every address the run touched ("memory"). The global events of all shards cancel as a multiset: that is the statement the
     shards' septic-curve digests add up to."""
     from . import riscv_more_trace as MT
-    keccak, poseidon2, sha_extend, sha_compress = [], [], [], []
+    keccak, poseidon2, sha_extend, sha_compress, uint256 = [], [], [], [], []
     for shard in executor.shards(max_cycles):
         tr = EventTracer(executor, shard, device)
         machine, tables, publics = tr.build()
@@ -389,6 +390,8 @@ def program_shards(executor, max_cycles, device="cpu"):
             sha_extend.append(shard.sha_extend)
         if shard.sha_compress.shape[0]:
             sha_compress.append(shard.sha_compress)
+        if shard.uint256.shape[0]:
+            uint256.append(shard.uint256)
         yield "core", machine, tables, publics, tr.global_events, shard
     if keccak:
         kk = torch.as_tensor(np.concatenate(keccak), device=device)
@@ -401,7 +404,8 @@ def program_shards(executor, max_cycles, device="cpu"):
         machine, tables, publics, gev = MT.poseidon2_shard_from(pp[:, 0], pp[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(),
                                                                pp[:, 18:26].contiguous(), device)
         yield "poseidon2", machine, tables, publics, gev, None
-    for name, evs, build in (("sha_extend", sha_extend, MT.sha_extend_shard_from), ("sha_compress", sha_compress, MT.sha_compress_shard_from)):
+    for name, evs, build in (("sha_extend", sha_extend, MT.sha_extend_shard_from), ("sha_compress", sha_compress, MT.sha_compress_shard_from),
+                             ("uint256", uint256, MT.uint256_shard_from)):
         if evs:
             machine, tables, publics, gev = build(np.concatenate(evs), device)
             yield name, machine, tables, publics, gev, None

@@ -717,6 +717,121 @@ def sha_compress_control_chip():                                                
     return _done(b, c)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Field operations on byte limbs (operations/field/): polynomials over expressions, lowest coefficient first
+def _poly_add(p, q):
+    n = max(len(p), len(q))
+    return [(p[i] if i < len(p) else 0) + (q[i] if i < len(q) else 0) for i in range(n)]
+
+
+def _poly_sub(p, q):
+    n = max(len(p), len(q))
+    return [(p[i] if i < len(p) else 0) - (q[i] if i < len(q) else 0) for i in range(n)]
+
+
+def _poly_mul(p, q):
+    out = [0] * (len(p) + len(q) - 1)
+    for i, a in enumerate(p):
+        for j, c in enumerate(q):
+            out[i + j] = out[i + j] + a * c
+    return out
+
+
+def _poly_scale(p, k):
+    return [a * k for a in p]
+
+
+WITNESS_OFFSET = 1 << 14                                                                  # curves/src/{uint256,weierstrass/*}.rs
+
+
+def FIELD_OP(n_limbs, n_witness):                                                         # field_op.rs:L18-L24
+    return S(("result", n_limbs), ("carry", n_limbs), ("witness", n_witness))
+
+
+def FIELD_LT(n_limbs):                                                                    # field/range.rs:L18-L27
+    return S(("byte_flags", n_limbs), ("lhs_comparison_byte", 1), ("rhs_comparison_byte", 1))
+
+
+MEM_ACCESS_U8 = S(("memory_access", MEM_ACCESS), ("prev_value_u8", U16_TO_U8))            # memory/consistency/columns.rs:L38-L43
+
+
+def eval_field_op_polynomials(b, cols, p_op, p_modulus, p_result, is_real):               # field_op.rs eval_with_polynomials + util_air.rs
+    p_vanishing = _poly_sub(_poly_sub(p_op, p_result), _poly_mul(cols.carry, p_modulus))
+    witness = [w - WITNESS_OFFSET for w in cols.witness]
+    rhs = _poly_mul(witness, [-(1 << 8), 1])
+    for cst in _poly_sub(p_vanishing, rhs):
+        b.assert_zero(cst)
+    slice_range_check_u8(b, cols.result, is_real)
+    slice_range_check_u8(b, cols.carry, is_real)
+    slice_range_check_u16(b, cols.witness, is_real)
+
+
+def eval_field_lt(b, cols, lhs, rhs, is_real):                                            # field/range.rs:L64-L139
+    s_ = b.const(0)
+    for f in cols.byte_flags:
+        b.when(is_real).assert_bool(f)
+        s_ = s_ + f
+    b.when(is_real).assert_one(s_)
+    visited, lb, rb = b.const(0), b.const(0), b.const(0)
+    for lbyte, rbyte, f in zip(reversed(lhs), reversed(rhs), reversed(cols.byte_flags)):
+        visited = visited + f
+        lb = lb + lbyte * f
+        rb = rb + f * rbyte
+        b.when(is_real).when_not(visited).assert_eq(lbyte, rbyte)
+    b.when(is_real).assert_eq(cols.lhs_comparison_byte, lb)
+    b.when(is_real).assert_eq(cols.rhs_comparison_byte, rb)
+    send_byte(b, B_LTU, 1, cols.lhs_comparison_byte, cols.rhs_comparison_byte, is_real)
+
+
+def generate_limbs(b, accesses, is_real):                                                 # air/mod.rs:L22-L43
+    out = []
+    for acc in accesses:
+        out += u16_to_u8_safe(b, acc.memory_access.prev_value, acc.prev_value_u8.low_bytes, is_real)
+    return out
+
+
+def limbs_to_words(limbs):                                                                # utils/mod.rs:L26-L40
+    return [[limbs[8 * w + 2 * k] + limbs[8 * w + 2 * k + 1] * (1 << 8) for k in range(4)] for w in range(len(limbs) // 8)]
+
+
+SYS_UINT256_MUL = 0x1D
+
+
+def uint256_mul_chip():                                                                   # syscall/precompiles/uint256/air.rs:L318-L517
+    b, c, _ = _chip("Uint256MulMod", 371)
+    accs = lambda n: (lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(n)])
+    L = S(("clk_high", 1), ("clk_low", 1), ("x_ptr", SYSCALL_ADDR), ("y_ptr", SYSCALL_ADDR),
+          ("x_addrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(4)]),
+          ("y_and_modulus_addrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(8)]),
+          ("x_memory", accs(4)), ("y_memory", accs(4)), ("modulus_memory", accs(4)), ("modulus_is_zero", IS_ZERO), ("modulus_is_not_zero", 1),
+          ("output", FIELD_OP(32, 63)), ("output_range_check", FIELD_LT(32)), ("is_real", 1))(c)
+    x_limbs = generate_limbs(b, L.x_memory, L.is_real)
+    y_limbs = generate_limbs(b, L.y_memory, L.is_real)
+    m_limbs = generate_limbs(b, L.modulus_memory, L.is_real)
+    byte_sum = m_limbs[0]
+    for v in m_limbs[1:]:
+        byte_sum = byte_sum + v
+    eval_is_zero(b, byte_sum, L.modulus_is_zero, L.is_real)
+    mz = L.modulus_is_zero.result
+    p_modulus = _poly_add(_poly_scale(m_limbs, 1 - mz), [0] * 32 + [mz])                   # the modulus, or 2^256 when it is zero
+    eval_field_op_polynomials(b, L.output, _poly_mul(x_limbs, y_limbs), p_modulus, L.output.result, L.is_real)
+    eval_field_lt(b, L.output_range_check, L.output.result, m_limbs, L.modulus_is_not_zero)
+    b.assert_eq(L.modulus_is_not_zero, L.is_real * (1 - mz))
+    result_words = limbs_to_words(L.output.result)
+    x_ptr = eval_syscall_addr(b, 32, L.x_ptr, L.is_real)
+    y_ptr = eval_syscall_addr(b, 64, L.y_ptr, L.is_real)
+    for i in range(4):
+        eval_addr_add(b, list(x_ptr) + [b.const(0)], word_of_u64(8 * i), L.x_addrs[i].value, L.is_real)
+    for i in range(8):
+        eval_addr_add(b, list(y_ptr) + [b.const(0)], word_of_u64(8 * i), L.y_and_modulus_addrs[i].value, L.is_real)
+    for i in range(4):
+        eval_memory_access(b, L.clk_high, L.clk_low + 1, L.x_addrs[i].value, L.x_memory[i].memory_access, result_words[i], L.is_real)
+    for i, acc in enumerate(L.y_memory + L.modulus_memory):
+        eval_memory_access(b, L.clk_high, L.clk_low, L.y_and_modulus_addrs[i].value, acc.memory_access, acc.memory_access.prev_value, L.is_real)
+    send_syscall(b, L.clk_high, L.clk_low, SYS_UINT256_MUL, x_ptr, y_ptr, L.is_real, receive=True)
+    return _done(b, c)
+
+
 def poseidon2_chip():                                                                     # syscall/precompiles/poseidon2/air.rs:L424-L607
     """The POSEIDON2 precompile: eight u64 words at `ptr` (sixteen field elements, low half first) are read and rewritten in place
     by one KoalaBear Poseidon2 permutation — the same `Poseidon2Operation` sub-AIR as the Global chip's (hinted for a fused kernel)."""
@@ -752,7 +867,7 @@ def poseidon2_chip():                                                           
 
 
 MORE_CHIPS = {
-    "Poseidon2": poseidon2_chip, "ShaExtend": sha_extend_chip, "ShaExtendControl": sha_extend_control_chip, "ShaCompress": sha_compress_chip,
+    "Uint256MulMod": uint256_mul_chip, "Poseidon2": poseidon2_chip, "ShaExtend": sha_extend_chip, "ShaExtendControl": sha_extend_control_chip, "ShaCompress": sha_compress_chip,
     "ShaCompressControl": sha_compress_control_chip,
     "AluX0": alu_x0_chip, "DivRem": divrem_chip, "SyscallCore": lambda: syscall_chip("core"), "SyscallPrecompile": lambda: syscall_chip("precompile"),
     "SyscallInstrs": syscall_instrs_chip, "MemoryGlobalInit": lambda: memory_global_chip("init"),
@@ -761,7 +876,7 @@ MORE_CHIPS = {
 }
 # (columns, constraints) from rv64im_costs.json / rv64im_complexity.json; interactions of the recorded core shard where it has the chip
 MORE_RECORDED = {
-    "Poseidon2": (348, 497, None), "ShaExtend": (128, 80, None), "ShaExtendControl": (18, 21, None), "ShaCompress": (206, 300, None),
+    "Uint256MulMod": (371, 253, None), "Poseidon2": (348, 497, None), "ShaExtend": (128, 80, None), "ShaExtendControl": (18, 21, None), "ShaCompress": (206, 300, None),
     "ShaCompressControl": (53, 21, None), "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
     "MemoryGlobalInit": (30, 31, None), "MemoryGlobalFinalize": (30, 31, None), "KeccakPermute": (2640, 2859, None),
     "KeccakPermuteControl": (634, 331, None),

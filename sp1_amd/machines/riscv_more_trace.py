@@ -583,3 +583,111 @@ def sha_compress_shard_from(events, device="cpu"):
     t_f = torch.cat([(clk[:, None] + 2).expand(-1, 8).reshape(-1), (clk[:, None] + 1).expand(-1, 64).reshape(-1)])
     v_f = torch.cat([h_wr.reshape(-1), w_rd[:, :, 1].reshape(-1)])
     return _close_precompile_shard(tr, M.SYS_SHA_COMPRESS, clk, wl, wa, t_i, t_f, v_i, v_f, arg2_limbs=hl)   # arg2 = h_ptr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# field operations on byte limbs (operations/field/field_op.rs populate_*; Python integers: precompile calls are few)
+def field_op_columns(a, b, modulus, n_limbs, n_witness, op="mul", n_modulus_limbs=None):
+    """FieldOpCols::populate_with_modulus (field_op.rs:L224-L300): (result, carry, witness) byte / u16 lists and the integer
+    result, for result = a op b mod modulus with op in {"add", "mul"} (sub / div are the same identities with a and result swapped)."""
+    n_mod = n_modulus_limbs or n_limbs
+    val = a + b if op == "add" else a * b
+    result = val % modulus
+    carry = (val - result) // modulus
+    by = lambda v, n: [(v >> (8 * i)) & 0xFF for i in range(n)]
+    pa, pb, pr, pc, pm = by(a, n_limbs), by(b, n_limbs), by(result, n_limbs), by(carry, n_limbs), by(modulus, n_mod)
+    van = [0] * (n_witness + 1)
+    if op == "add":
+        for i in range(n_limbs):
+            van[i] += pa[i] + pb[i]
+    else:
+        for i in range(n_limbs):
+            for j in range(n_limbs):
+                van[i + j] += pa[i] * pb[j]
+    for i in range(n_limbs):
+        van[i] -= pr[i]
+    for i in range(n_limbs):
+        for j in range(n_mod):
+            van[i + j] -= pc[i] * pm[j]
+    # divide by (x - 256): synthetic division from the top (field_op.rs:L71-L78)
+    w = [0] * n_witness
+    acc = van[n_witness]
+    for i in range(n_witness - 1, -1, -1):
+        w[i] = acc
+        acc = van[i] + acc * 256
+    assert acc == 0, "the vanishing polynomial does not vanish at 256"
+    witness = [x + (1 << 14) for x in w]
+    assert all(0 <= x < (1 << 16) for x in witness)
+    return pr, pc, witness, result
+
+
+def field_lt_columns(lhs, rhs, n_limbs):
+    """FieldLtCols::populate (field/range.rs:L30-L61): byte flags and the two comparison bytes for lhs < rhs."""
+    assert lhs < rhs
+    flags, lb, rb = [0] * n_limbs, 0, 0
+    for i in range(n_limbs - 1, -1, -1):
+        x, y = (lhs >> (8 * i)) & 0xFF, (rhs >> (8 * i)) & 0xFF
+        if x < y:
+            flags[i], lb, rb = 1, x, y
+            break
+    return flags, lb, rb
+
+
+def uint256_shard_from(events, device="cpu"):
+    """The UINT256_MUL precompile shard of the executor's events ([n, 31] int64): Uint256MulMod rows (`generate_trace_into`,
+    syscall/precompiles/uint256/air.rs:L118-L290), SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
+    dev = torch.device(device)
+    ev = np.asarray(events).astype(np.uint64)
+    n = ev.shape[0]
+    air = R.chip("Uint256MulMod")[0]
+    L = air.layout
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    tb = RT.Table(air, n, dev)
+    rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
+    u = lambda v: int(v)
+    word = lambda ws: sum(u(x) << (64 * i) for i, x in enumerate(ws))
+    for r in range(n):
+        e = ev[r]
+        clk, xp, yp = u(e[0]), u(e[1]), u(e[2])
+        xs, ys = e[3:11].reshape(4, 2), e[11:27].reshape(8, 2)
+        x, y, m = word(xs[:, 1]), word(ys[:4, 1]), word(ys[4:, 1])
+        res, car, wit, out = field_op_columns(x, y, m if m else 1 << 256, 32, 63, "mul", n_modulus_limbs=33)
+        assert out == word(e[27:31]), "the executor's product is not x * y mod modulus"
+        rows[r, L["output.result"]:L["output.result"] + 32] = res
+        rows[r, L["output.carry"]:L["output.carry"] + 32] = car
+        rows[r, L["output.witness"]:L["output.witness"] + 63] = wit
+        s = sum((m >> (8 * i)) & 0xFF for i in range(32))
+        rows[r, L["modulus_is_zero.inverse"]] = pow(s, P - 2, P) if s else 0
+        rows[r, L["modulus_is_zero.result"]] = int(s == 0)
+        rows[r, L["modulus_is_not_zero"]] = int(s != 0)
+        if m:
+            flags, lb, rb = field_lt_columns(out, m, 32)
+            rows[r, L["output_range_check.byte_flags"]:L["output_range_check.byte_flags"] + 32] = flags
+            rows[r, L["output_range_check.lhs_comparison_byte"]], rows[r, L["output_range_check.rhs_comparison_byte"]] = lb, rb
+    rows[n:, L["output.witness"]:L["output.witness"] + 63] = 1 << 14       # padding rows: the field operation on zero operands (air.rs:L266-L280)
+    tb.main[:] = torch.as_tensor(rows, device=dev)
+    t = torch.as_tensor(ev.astype(np.int64), device=dev)
+    clk, xp, yp = t[:, 0], t[:, 1], t[:, 2]
+    tb.set("clk_high", clk >> 24); tb.set("clk_low", clk & 0xFFFFFF); tb.set("is_real", 1)
+    xl = _syscall_addr_t(tb, "x_ptr", xp)
+    yl = _syscall_addr_t(tb, "y_ptr", yp)
+    xs, ys = t[:, 3:11].reshape(n, 4, 2), t[:, 11:27].reshape(n, 8, 2)
+    low_bytes = lambda v: torch.stack([(v >> (16 * k)) & 0xFF for k in range(4)], dim=1)
+    for i in range(4):
+        tb.set("x_addrs.%d.value" % i, _limbs_t(xp + 8 * i)[:, :3])
+        _mem_access_t(tb, "x_memory.%d.memory_access" % i, xs[:, i, 1], xs[:, i, 0], clk + 1)
+        tb.set("x_memory.%d.prev_value_u8.low_bytes" % i, low_bytes(xs[:, i, 1]))
+    for i in range(8):
+        tb.set("y_and_modulus_addrs.%d.value" % i, _limbs_t(yp + 8 * i)[:, :3])
+        name = ("y_memory.%d" % i) if i < 4 else ("modulus_memory.%d" % (i - 4))
+        _mem_access_t(tb, name + ".memory_access", ys[:, i, 1], ys[:, i, 0], clk)
+        tb.set(name + ".prev_value_u8.low_bytes", low_bytes(ys[:, i, 1]))
+    tr.tables["Uint256MulMod"] = tb
+    four, eight = torch.arange(4, device=dev)[None, :], torch.arange(8, device=dev)[None, :]
+    wa = torch.cat([(xp[:, None] + 8 * four).reshape(-1), (yp[:, None] + 8 * eight).reshape(-1)])
+    t_i = torch.cat([xs[:, :, 0].reshape(-1), ys[:, :, 0].reshape(-1)])
+    v_i = torch.cat([xs[:, :, 1].reshape(-1), ys[:, :, 1].reshape(-1)])
+    t_f = torch.cat([(clk[:, None] + 1).expand(-1, 4).reshape(-1), clk[:, None].expand(-1, 8).reshape(-1)])
+    v_f = torch.cat([t[:, 27:31].reshape(-1), ys[:, :, 1].reshape(-1)])
+    return _close_precompile_shard(tr, M.SYS_UINT256_MUL, clk, xl, wa, t_i, t_f, v_i, v_f, arg2_limbs=yl)

@@ -139,6 +139,22 @@ def test_poseidon2_system_call_against_the_host_permutation():
     assert gm[0x78100000 + 64] == int(once[0]) | (int(once[1]) << 32)     # the CPU copied word 0 of the first result
 
 
+def test_uint256_mulmod_system_call_and_its_shard():
+    """UINT256_MUL from a hand-assembled program: x <- x * y mod m for four operand sets (a zero modulus means 2^256), against
+    Python's integers; the precompile shard (FieldOpCols: the byte-limb polynomial identity with its witness, FieldLtCols) checks."""
+    words = lambda v: b"".join(struct.pack("<Q", (v >> (64 * i)) & M64) for i in range(4))
+    cases = [(0x1234567890ABCDEF << 130 | 77, (1 << 255) + 12345, (1 << 256) - 189), (3, 5, 0), ((1 << 256) - 1, (1 << 256) - 1, 0), (7, 9, 1 << 200)]
+    data, prog = b"", A.li(28, 0x78100000)
+    for i, (x, y, m) in enumerate(cases):
+        data += words(x) + words(y) + words(m)
+        prog += [A.enc("addi", 10, 28, 96 * i), A.enc("addi", 11, 28, 96 * i + 32)] + A.li(5, 0x0001011D) + [A.enc("ecall")]
+    ex, kinds, _, last = run_program(A.elf(prog + A.halt(0), data=data + bytes(32)), [], 1 << 20)
+    assert kinds == ["core", "uint256", "memory"] and last.exit_code == 0
+    gm = {int(r[0]): int(r[2]) & M64 for r in ex.global_memory()}
+    for i, (x, y, m) in enumerate(cases):
+        assert sum(gm[0x78100000 + 96 * i + 8 * k] << (64 * k) for k in range(4)) == (x * y) % (m if m else 1 << 256)
+
+
 def test_a_flipped_sha_cell_is_caught():
     from sp1_amd.machines import riscv as R
     ex = X.Executor(_elf("sha2"), stdin=[bytes(10)])
