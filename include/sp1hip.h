@@ -493,7 +493,7 @@ int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint3
  *                 modulus word), the 4 x words written (x * y mod modulus; a zero modulus means 2^256)
  * After the program halts, sp1hip_rv64_global_memory lists every address the run touched as (address, initial value, final value,
  * final timestamp): the `MemoryGlobalInit` / `MemoryGlobalFinalize` events. Supervisor mode only; system calls: HALT, WRITE,
- * ENTER / EXIT_UNCONSTRAINED, COMMIT, COMMIT_DEFERRED_PROOFS, HINT_LEN, HINT_READ, KECCAK_PERMUTE, POSEIDON2, SHA_EXTEND, SHA_COMPRESS, UINT256_MUL (any other stops the run with
+ * ENTER / EXIT_UNCONSTRAINED, COMMIT, COMMIT_DEFERRED_PROOFS, HINT_LEN, HINT_READ, KECCAK_PERMUTE, POSEIDON2, SHA_EXTEND, SHA_COMPRESS, UINT256_MUL, SECP256K1_ADD, SECP256K1_DOUBLE (any other stops the run with
  * SP1HIP_ERROR_RUNTIME and a message naming it). The pointers stay valid until the next call on the same handle. */
 #define SP1HIP_RV64_EVENT_WORDS 20
 #define SP1HIP_RV64_KECCAK_WORDS 77
@@ -501,11 +501,13 @@ int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint3
 #define SP1HIP_RV64_SHA_EXTEND_WORDS 786
 #define SP1HIP_RV64_SHA_COMPRESS_WORDS 155
 #define SP1HIP_RV64_UINT256_WORDS 31
+#define SP1HIP_RV64_SECP_ADD_WORDS 43
+#define SP1HIP_RV64_SECP_DOUBLE_WORDS 26
 typedef void* sp1hip_rv64_vm_t;
 typedef struct {
     uint64_t shard;                      /* index of this shard in the run */
     uint64_t n_cycles;                   /* instructions executed in this shard */
-    uint64_t n_events, n_local, n_keccak, n_poseidon2, n_sha_extend, n_sha_compress, n_uint256; /* n_events = n_cycles, or 0 when recording is off */
+    uint64_t n_events, n_local, n_keccak, n_poseidon2, n_sha_extend, n_sha_compress, n_uint256, n_secp256k1_add, n_secp256k1_double; /* n_events = n_cycles, or 0 when recording is off */
     uint64_t pc_start, next_pc;          /* `PublicValues::pc_start / next_pc` (HALT_PC = 1 after HALT) */
     uint64_t clk_start, clk_end;         /* `initial_timestamp / last_timestamp` */
     uint32_t halted, exit_code;
@@ -528,6 +530,8 @@ const uint64_t* sp1hip_rv64_poseidon2_events(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_sha_extend_events(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_sha_compress_events(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_uint256_events(sp1hip_rv64_vm_t vm);
+const uint64_t* sp1hip_rv64_secp256k1_add_events(sp1hip_rv64_vm_t vm);     /* [n][43]: clk, p_ptr, q_ptr, 8 x (ts, p word), 8 x (ts, q word), 8 p words written */
+const uint64_t* sp1hip_rv64_secp256k1_double_events(sp1hip_rv64_vm_t vm);  /* [n][26]: clk, p_ptr, 8 x (ts, p word), 8 p words written */
 /* The transpiled program (`Program::instructions`): [n][6] u64 = opcode, op_a, op_b, op_c, imm_b, imm_c; instruction i sits at
  * pc_base + 4 i. */
 int sp1hip_rv64_program(sp1hip_rv64_vm_t vm, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table);

@@ -70,7 +70,7 @@ class ShardParams(C.Structure):
 
 
 class Rv64ShardInfo(C.Structure):
-    _fields_ = [("shard", C.c_uint64), ("n_cycles", C.c_uint64), ("n_events", C.c_uint64), ("n_local", C.c_uint64), ("n_keccak", C.c_uint64), ("n_poseidon2", C.c_uint64), ("n_sha_extend", C.c_uint64), ("n_sha_compress", C.c_uint64), ("n_uint256", C.c_uint64),
+    _fields_ = [("shard", C.c_uint64), ("n_cycles", C.c_uint64), ("n_events", C.c_uint64), ("n_local", C.c_uint64), ("n_keccak", C.c_uint64), ("n_poseidon2", C.c_uint64), ("n_sha_extend", C.c_uint64), ("n_sha_compress", C.c_uint64), ("n_uint256", C.c_uint64), ("n_secp256k1_add", C.c_uint64), ("n_secp256k1_double", C.c_uint64),
                 ("pc_start", C.c_uint64), ("next_pc", C.c_uint64), ("clk_start", C.c_uint64), ("clk_end", C.c_uint64),
                 ("halted", C.c_uint32), ("exit_code", C.c_uint32), ("commit_syscall", C.c_uint32),
                 ("commit_deferred_syscall", C.c_uint32), ("committed_value_digest", C.c_uint32 * 8),
@@ -204,6 +204,8 @@ PROTOTYPES = [
     ("sp1hip_rv64_sha_extend_events", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_sha_compress_events", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_uint256_events", C.POINTER(C.c_uint64), [_vp]),
+    ("sp1hip_rv64_secp256k1_add_events", C.POINTER(C.c_uint64), [_vp]),
+    ("sp1hip_rv64_secp256k1_double_events", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_program", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_global_memory", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_output", None, [_vp, _int, C.POINTER(u8p), C.POINTER(C.c_uint64)]),

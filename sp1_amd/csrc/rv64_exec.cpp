@@ -45,8 +45,8 @@ struct Instr { uint32_t op; uint32_t a; uint64_t b, c; bool imm_b, imm_c; };
 
 constexpr uint64_t HALT_PC = 1, CLK_INC = 8, ECALL_EXTRA = 256;
 constexpr uint64_t SYS_HALT = 0x00, SYS_WRITE = 0x02, SYS_ENTER_UNC = 0x03, SYS_EXIT_UNC = 0x04, SYS_KECCAK = 0x00010109,
-                   SYS_POSEIDON2 = 0x00000133, SYS_UINT256_MUL = 0x0001011D, SYS_SHA_EXTEND = 0x00300105, SYS_SHA_COMPRESS = 0x00010106, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
-constexpr uint64_t FD_PUBLIC_VALUES = 13, FD_HINT = 14;
+                   SYS_POSEIDON2 = 0x00000133, SYS_UINT256_MUL = 0x0001011D, SYS_SECP256K1_ADD = 0x0001010A, SYS_SECP256K1_DOUBLE = 0x0000010B, SYS_SHA_EXTEND = 0x00300105, SYS_SHA_COMPRESS = 0x00010106, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
+constexpr uint64_t FD_PUBLIC_VALUES = 13, FD_HINT = 14, FD_FP_SQRT = 20, FD_FP_INV = 21;
 
 Instr decode(uint32_t w) {
     auto R = [&](uint32_t op) { return Instr{op, (w >> 7) & 31, (w >> 15) & 31, (w >> 20) & 31, false, false}; };
@@ -146,6 +146,48 @@ void uint256_mulmod(const uint64_t x[4], const uint64_t y[4], const uint64_t m[4
     memcpy(out, rem, 32);
 }
 
+// secp256k1's base field on 256-bit little-endian limbs: p = 2^256 - 2^32 - 977 (curves/src/weierstrass/secp256k1.rs)
+struct U256 { uint64_t w[4]; };
+const U256 SECP_P = {{0xFFFFFFFEFFFFFC2Full, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull}};
+bool u256_ge(const U256& a, const U256& b) { for (int k = 3; k >= 0; --k) if (a.w[k] != b.w[k]) return a.w[k] > b.w[k]; return true; }
+U256 fp_mul(const U256& a, const U256& b) {                           // 2^256 = 2^32 + 977 (mod p): fold the high half twice
+    uint64_t prod[8] = {0};
+    for (int i = 0; i < 4; ++i) {
+        unsigned __int128 carry = 0;
+        for (int j = 0; j < 4; ++j) { const unsigned __int128 t = (unsigned __int128)a.w[i] * b.w[j] + prod[i + j] + carry; prod[i + j] = (uint64_t)t; carry = t >> 64; }
+        prod[i + 4] = (uint64_t)carry;
+    }
+    const uint64_t C = 0x1000003D1ull;
+    uint64_t lo[5];
+    unsigned __int128 c = 0;
+    for (int k = 0; k < 4; ++k) { c += (unsigned __int128)prod[4 + k] * C + prod[k]; lo[k] = (uint64_t)c; c >>= 64; }
+    lo[4] = (uint64_t)c;                                                // < 2^34
+    c = (unsigned __int128)lo[4] * C;
+    U256 r;
+    for (int k = 0; k < 4; ++k) { c += lo[k]; r.w[k] = (uint64_t)c; c >>= 64; }
+    if (c) { c = C; for (int k = 0; k < 4; ++k) { c += r.w[k]; r.w[k] = (uint64_t)c; c >>= 64; } }   // one more 2^256: cannot carry again
+    if (u256_ge(r, SECP_P)) { unsigned __int128 borrow = 0; for (int k = 0; k < 4; ++k) { const unsigned __int128 t = (unsigned __int128)r.w[k] - SECP_P.w[k] - borrow; r.w[k] = (uint64_t)t; borrow = (t >> 64) & 1; } }
+    return r;
+}
+U256 fp_sub(const U256& a, const U256& b) {                            // a, b < p
+    U256 r; unsigned __int128 borrow = 0;
+    for (int k = 0; k < 4; ++k) { const unsigned __int128 t = (unsigned __int128)a.w[k] - b.w[k] - borrow; r.w[k] = (uint64_t)t; borrow = (t >> 64) & 1; }
+    if (borrow) { unsigned __int128 c = 0; for (int k = 0; k < 4; ++k) { c += (unsigned __int128)r.w[k] + SECP_P.w[k]; r.w[k] = (uint64_t)c; c >>= 64; } }
+    return r;
+}
+U256 fp_add(const U256& a, const U256& b) {
+    U256 r; unsigned __int128 c = 0;
+    for (int k = 0; k < 4; ++k) { c += (unsigned __int128)a.w[k] + b.w[k]; r.w[k] = (uint64_t)c; c >>= 64; }
+    if (c || u256_ge(r, SECP_P)) { unsigned __int128 borrow = 0; for (int k = 0; k < 4; ++k) { const unsigned __int128 t = (unsigned __int128)r.w[k] - SECP_P.w[k] - borrow; r.w[k] = (uint64_t)t; borrow = (t >> 64) & 1; } }
+    return r;
+}
+U256 fp_inv(const U256& a) {                                           // a^(p - 2)
+    U256 e = SECP_P; e.w[0] -= 2;
+    U256 r = {{1, 0, 0, 0}}, base = a;
+    for (int bit = 0; bit < 256; ++bit) { if ((e.w[bit >> 6] >> (bit & 63)) & 1) r = fp_mul(r, base); base = fp_mul(base, base); }
+    return r;
+}
+
 void keccak_f(uint64_t s[25]) {                                        // FIPS 202, state s[x + 5 y]
     static const int rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     auto rl = [](uint64_t v, int r) { return r ? (v << r) | (v >> (64 - r)) : v; };
@@ -181,6 +223,7 @@ struct Vm {
     std::vector<uint8_t> local_closed;
     std::vector<uint64_t> sha_extend;                                  // [k][clk, w_ptr, 48 x (4 x (previous timestamp, word read), previous timestamp and value of w[i], w[i] written), 64 x (timestamp, value before; after)]
     std::vector<uint64_t> sha_compress;                                // [k][clk, w_ptr, h_ptr, 8 x (previous timestamp, h word), 64 x (previous timestamp, w word), 8 h words written]
+    std::vector<uint64_t> secp_add, secp_double;                       // [k][clk, p_ptr, q_ptr, 8 x (ts, p word), 8 x (ts, q word), 8 p words written] / [k][clk, p_ptr, 8 x (ts, p word), 8 written]
     std::vector<uint64_t> uint256;                                     // [k][clk, x_ptr, y_ptr, 4 x (previous timestamp, x word), 8 x (previous timestamp, y / modulus word), 4 x words written]
     std::vector<uint64_t> poseidon2;                                   // POSEIDON2 events: [k][clk, pointer, 8 x (previous timestamp, word read), 8 words written]
     std::vector<uint64_t> precompile;                                  // Keccak events: [k][clk, pointer, 25 x (previous timestamp, word read), 25 words written]
@@ -338,7 +381,53 @@ struct Vm {
         if (fd == 1 || fd == 2) out.insert(out.end(), bytes.begin(), bytes.end());
         else if (fd == FD_PUBLIC_VALUES) public_values.insert(public_values.end(), bytes.begin(), bytes.end());
         else if (fd == FD_HINT) input.push_front(std::move(bytes));
+        else if (fd == FD_FP_SQRT || fd == FD_FP_INV) return hook_fp(fd, bytes);
         else return fail("WRITE to file descriptor %llu (a hook) is not implemented", (unsigned long long)fd);
+        return true;
+    }
+
+    // The field hooks (executor/src/hook.rs:L228-L306): hints computed outside the VM and pushed to the FRONT of the input stream,
+    // which the guest then reads and CHECKS inside the VM (one multiplication), so nothing here is trusted. [len: u32 BE | element |
+    // modulus | (sqrt only) a non-residue], all big endian, `len` bytes each; 256-bit fields only, square roots for p = 3 (mod 4).
+    bool hook_fp(uint64_t fd, const std::vector<uint8_t>& buf) {
+        const bool is_sqrt = fd == FD_FP_SQRT;
+        if (buf.size() < 4) return fail("field hook: short buffer");
+        const uint64_t len = ((uint64_t)buf[0] << 24) | ((uint64_t)buf[1] << 16) | ((uint64_t)buf[2] << 8) | buf[3];
+        if (buf.size() != 4 + (is_sqrt ? 3 : 2) * len) return fail("field hook: invalid buffer length");
+        if (len != 32) return fail("field hook for %llu-byte fields is not implemented (fd %llu)", (unsigned long long)len, (unsigned long long)fd);
+        auto be = [&](uint64_t at) { U256 v = {}; for (int i = 0; i < 32; ++i) v.w[(31 - i) >> 3] |= (uint64_t)buf[at + i] << (8 * ((31 - i) & 7)); return v; };
+        auto to_be = [](const U256& v) { std::vector<uint8_t> o(32); for (int i = 0; i < 32; ++i) o[i] = (uint8_t)(v.w[(31 - i) >> 3] >> (8 * ((31 - i) & 7))); return o; };
+        const U256 x = be(4), m = be(36);
+        const U256 zero = {};
+        auto is_zero = [](const U256& v) { return !(v.w[0] | v.w[1] | v.w[2] | v.w[3]); };
+        auto mul = [&](const U256& a, const U256& b) { U256 r; uint256_mulmod(a.w, b.w, m.w, r.w); return r; };
+        auto pow = [&](const U256& a, const U256& e) {
+            U256 r = {{1, 0, 0, 0}}, base = a;
+            for (int bit = 0; bit < 256; ++bit) { if ((e.w[bit >> 6] >> (bit & 63)) & 1) r = mul(r, base); base = mul(base, base); }
+            return r;
+        };
+        if (is_zero(m) || !u256_ge(m, x) || u256_ge(x, m)) return fail("field hook: the element is not reduced");
+        if (!is_sqrt) {
+            if (is_zero(x)) return fail("field hook: inverse of zero");
+            U256 e = m; if (e.w[0] < 2) return fail("field hook: modulus"); e.w[0] -= 2;
+            input.push_front(to_be(pow(x, e)));
+            return true;
+        }
+        const U256 nqr = be(68);
+        if (u256_ge(nqr, m)) return fail("field hook: the non-residue is not reduced");
+        if ((m.w[0] & 3) != 3) return fail("field hook: square roots need p = 3 (mod 4) here (Tonelli-Shanks is not implemented)");
+        U256 e = m;                                                    // (p + 1) / 4 = (p >> 2) + 1 for p = 3 (mod 4)
+        for (int k = 0; k < 4; ++k) e.w[k] = (e.w[k] >> 2) | (k < 3 ? e.w[k + 1] << 62 : 0);
+        for (int k = 0; k < 4 && ++e.w[k] == 0; ++k) {}
+        uint8_t status = 1;
+        U256 root = zero;
+        if (!is_zero(x)) {
+            root = pow(x, e);
+            const U256 sq = mul(root, root);
+            if (memcmp(sq.w, x.w, 32) != 0) { status = 0; root = pow(mul(nqr, x), e); }   // not a square: the root of nqr * x proves it
+        }
+        input.push_front(to_be(root));
+        input.push_front(std::vector<uint8_t>{status});
         return true;
     }
 
@@ -506,6 +595,33 @@ struct Vm {
                 uint256.insert(uint256.end(), rec.begin(), rec.end());
                 break;
             }
+            case SYS_SECP256K1_ADD: case SYS_SECP256K1_DOUBLE: {       // vm/syscall/precompiles/weierstrass/{add,double}.rs: affine, no special cases
+                const bool is_add = code == SYS_SECP256K1_ADD;
+                if ((b & 7) || (is_add && (c & 7)) || (!is_add && c != 0)) return fail("SECP256K1 point arguments");
+                std::vector<uint64_t> rec = {clk, b};
+                if (is_add) rec.push_back(c);
+                U256 px, py, qx = {}, qy = {};
+                for (int i = 0; i < 8; ++i) { Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); (i < 4 ? px : py).w[i & 3] = m.val; }
+                if (is_add)
+                    for (int i = 0; i < 8; ++i) { Cell& m = cell(c + 8 * i); touch_precompile(m, c + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); (i < 4 ? qx : qy).w[i & 3] = m.val; m.ts = clk; }
+                if (!u256_ge(SECP_P, px) || u256_ge(px, SECP_P) || u256_ge(py, SECP_P) || (is_add && (u256_ge(qx, SECP_P) || u256_ge(qy, SECP_P)))) return fail("SECP256K1 coordinate is not reduced");
+                U256 slope;
+                if (is_add) {
+                    const U256 den = fp_sub(qx, px);
+                    if (!(den.w[0] | den.w[1] | den.w[2] | den.w[3])) return fail("SECP256K1_ADD of points with equal x");
+                    slope = fp_mul(fp_sub(qy, py), fp_inv(den));
+                } else {
+                    const U256 three = {{3, 0, 0, 0}}, two = {{2, 0, 0, 0}};
+                    const U256 den = fp_mul(two, py);
+                    if (!(den.w[0] | den.w[1] | den.w[2] | den.w[3])) return fail("SECP256K1_DOUBLE of a point with y = 0");
+                    slope = fp_mul(fp_mul(three, fp_mul(px, px)), fp_inv(den));
+                }
+                const U256 x3 = fp_sub(fp_mul(slope, slope), is_add ? fp_add(px, qx) : fp_add(px, px));
+                const U256 y3 = fp_sub(fp_mul(slope, fp_sub(px, x3)), py);
+                for (int i = 0; i < 8; ++i) { Cell& m = cell(b + 8 * i); m.val = (i < 4 ? x3 : y3).w[i & 3]; m.ts = is_add ? clk + 1 : clk; rec.push_back(m.val); }
+                (is_add ? secp_add : secp_double).insert((is_add ? secp_add : secp_double).end(), rec.begin(), rec.end());
+                break;
+            }
             case SYS_POSEIDON2: {                                      // vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs
                 if ((b & 7) || c != 0) return fail("POSEIDON2 arguments");
                 uint32_t st[16];
@@ -604,7 +720,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     if (!h || !info) { sp1hip::set_error("sp1hip_rv64_run_shard: null argument"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
-    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear(); vm.uint256.clear();
+    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear(); vm.uint256.clear(); vm.secp_add.clear(); vm.secp_double.clear();
     if (vm.record) vm.events.reserve((size_t)std::min<uint64_t>(max_cycles, 1ull << 24) * EV);   // one allocation (at most 2.7 GB), not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
@@ -615,6 +731,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     info->n_poseidon2 = vm.poseidon2.size() / SP1HIP_RV64_POSEIDON2_WORDS;
     info->n_sha_extend = vm.sha_extend.size() / SP1HIP_RV64_SHA_EXTEND_WORDS; info->n_sha_compress = vm.sha_compress.size() / SP1HIP_RV64_SHA_COMPRESS_WORDS;
     info->n_uint256 = vm.uint256.size() / SP1HIP_RV64_UINT256_WORDS;
+    info->n_secp256k1_add = vm.secp_add.size() / SP1HIP_RV64_SECP_ADD_WORDS; info->n_secp256k1_double = vm.secp_double.size() / SP1HIP_RV64_SECP_DOUBLE_WORDS;
     info->next_pc = vm.pc; info->clk_end = vm.clk; info->halted = vm.halted; info->exit_code = vm.exit_code;
     info->shard = vm.shard++;
     info->commit_syscall = vm.commit_syscall; info->commit_deferred_syscall = vm.commit_deferred_syscall;
@@ -636,6 +753,8 @@ const uint64_t* sp1hip_rv64_poseidon2_events(sp1hip_rv64_vm_t h) { return ((Vm*)
 const uint64_t* sp1hip_rv64_sha_extend_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->sha_extend.data(); }
 const uint64_t* sp1hip_rv64_sha_compress_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->sha_compress.data(); }
 const uint64_t* sp1hip_rv64_uint256_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->uint256.data(); }
+const uint64_t* sp1hip_rv64_secp256k1_add_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->secp_add.data(); }
+const uint64_t* sp1hip_rv64_secp256k1_double_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->secp_double.data(); }
 
 int sp1hip_rv64_program(sp1hip_rv64_vm_t h, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table) {
     if (!h) return SP1HIP_ERROR_INVALID_ARGUMENT;

@@ -24,6 +24,7 @@ from . import riscv_trace as RT
 from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, limbs16
 
 EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS, SHA_EXTEND_WORDS, SHA_COMPRESS_WORDS, UINT256_WORDS = 20, 77, 26, 786, 155, 31
+SECP_ADD_WORDS, SECP_DOUBLE_WORDS = 43, 26
 (E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
  E_NEXT_PC, E_SPARE) = range(EV_WORDS)
 
@@ -42,10 +43,11 @@ class ExecutedShard:
     """One shard of an execution: `events` [n, 20] / `local` [m, 5] / `keccak` [k, 77] int64 arrays (two's complement images of
     the executor's u64 words) and the shard's public-value fields."""
 
-    def __init__(self, info, events, local, keccak, poseidon2, sha_extend, sha_compress, uint256):
+    def __init__(self, info, events, local, keccak, poseidon2, sha_extend, sha_compress, uint256, secp_add, secp_double):
         self.index, self.cycles = int(info.shard), int(info.n_cycles)
         self.events, self.local, self.keccak, self.poseidon2 = events, local, keccak, poseidon2
         self.sha_extend, self.sha_compress, self.uint256 = sha_extend, sha_compress, uint256
+        self.secp256k1_add, self.secp256k1_double = secp_add, secp_double
         self.pc_start, self.next_pc = int(info.pc_start), int(info.next_pc)
         self.clk_start, self.clk_end = int(info.clk_start), int(info.clk_end)
         self.halted, self.exit_code = bool(info.halted), int(info.exit_code)
@@ -95,7 +97,9 @@ class Executor:
                               self._matrix(self.lib.sp1hip_rv64_poseidon2_events(self.h), info.n_poseidon2, POSEIDON2_WORDS),
                               self._matrix(self.lib.sp1hip_rv64_sha_extend_events(self.h), info.n_sha_extend, SHA_EXTEND_WORDS),
                               self._matrix(self.lib.sp1hip_rv64_sha_compress_events(self.h), info.n_sha_compress, SHA_COMPRESS_WORDS),
-                              self._matrix(self.lib.sp1hip_rv64_uint256_events(self.h), info.n_uint256, UINT256_WORDS))
+                              self._matrix(self.lib.sp1hip_rv64_uint256_events(self.h), info.n_uint256, UINT256_WORDS),
+                              self._matrix(self.lib.sp1hip_rv64_secp256k1_add_events(self.h), info.n_secp256k1_add, SECP_ADD_WORDS),
+                              self._matrix(self.lib.sp1hip_rv64_secp256k1_double_events(self.h), info.n_secp256k1_double, SECP_DOUBLE_WORDS))
         self.halted = shard.halted
         return shard
 
@@ -370,6 +374,31 @@ def shard_tables(executor, shard, device="cpu"):
     return EventTracer(executor, shard, device).build()
 
 
+ELEMENT_THRESHOLD, HEIGHT_THRESHOLD = (1 << 28) + (1 << 27), 1 << 22        # core/executor/src/opts.rs:L12-L14
+# kind: (chip, control chip | None, rows per event, touched addresses) — air.rs:L473-L480, syscall_code.rs:L439-L479
+PRECOMPILES = {"keccak": ("KeccakPermute", "KeccakPermuteControl", 24, 25), "poseidon2": ("Poseidon2", None, 1, 8),
+               "sha_extend": ("ShaExtend", "ShaExtendControl", 48, 64), "sha_compress": ("ShaCompress", "ShaCompressControl", 80, 72),
+               "uint256": ("Uint256MulMod", None, 1, 12), "secp256k1_add": ("Secp256k1AddAssign", None, 1, 16),
+               "secp256k1_double": ("Secp256k1DoubleAssign", None, 1, 8)}
+
+
+def split_thresholds(program_rows):
+    """`SplitOpts::new` (core/executor/src/opts.rs:L186-L240): how many events of one system call, and how many memory
+    initialise / finalise events, go into one shard — the trace area left beside the fixed tables divided by the cost of one event
+    (its chip rows, control row, MemoryLocal / Global rows per touched address, SyscallPrecompile row: utils.rs:L117-L154),
+    bounded by the height limit, rounded down to 32."""
+    cost = lambda name: (lambda a: a.main_width + a.prep_width)(R.chip(name)[0])
+    trunc = lambda v: v // 32 * 32
+    area = ELEMENT_THRESHOLD - (-(-program_rows // 32) * 32 * cost("Program") + (1 << 16) * cost("Byte") + (1 << 17) * cost("Range"))
+    out = {}
+    for kind, (chip_name, control, rows, touched) in PRECOMPILES.items():
+        per = rows * cost(chip_name) + (cost(control) if control else 0) + touched * cost("MemoryLocal") + 2 * touched * cost("Global")
+        per += cost("SyscallPrecompile") + cost("Global")
+        out[kind] = min(trunc(area // per), trunc(HEIGHT_THRESHOLD // max(rows, 2 * touched + 1)))
+    out["memory"] = trunc(min(area // (cost("MemoryGlobalInit") + cost("Global")), HEIGHT_THRESHOLD) // 2)
+    return out
+
+
 def program_shards(executor, max_cycles, device="cpu"):
     """Every shard of a run, in the order the reference's controller emits them: the core shards as the program executes
     (`(kind, machine, tables, publics, global events, ExecutedShard)` with kind = "core"), then one precompile shard for the
@@ -378,7 +407,7 @@ def program_shards(executor, max_cycles, device="cpu"):
     every address the run touched ("memory"). The global events of all shards cancel as a multiset: that is the statement the
     shards' septic-curve digests add up to."""
     from . import riscv_more_trace as MT
-    keccak, poseidon2, sha_extend, sha_compress, uint256 = [], [], [], [], []
+    keccak, poseidon2, sha_extend, sha_compress, uint256, secp_add, secp_double = [], [], [], [], [], [], []
     for shard in executor.shards(max_cycles):
         tr = EventTracer(executor, shard, device)
         machine, tables, publics = tr.build()
@@ -392,30 +421,42 @@ def program_shards(executor, max_cycles, device="cpu"):
             sha_compress.append(shard.sha_compress)
         if shard.uint256.shape[0]:
             uint256.append(shard.uint256)
+        if shard.secp256k1_add.shape[0]:
+            secp_add.append(shard.secp256k1_add)
+        if shard.secp256k1_double.shape[0]:
+            secp_double.append(shard.secp256k1_double)
         yield "core", machine, tables, publics, tr.global_events, shard
-    if keccak:
-        kk = torch.as_tensor(np.concatenate(keccak), device=device)
+    limit = split_thresholds(executor.program()[1].shape[0])
+    chunks = lambda kind, evs: (lambda a: [a[i:i + limit[kind]] for i in range(0, a.shape[0], limit[kind])])(np.concatenate(evs)) if evs else []
+    for kk in chunks("keccak", keccak):
+        kk = torch.as_tensor(kk, device=device)
         rd = kk[:, 2:52].reshape(-1, 25, 2)
         machine, tables, publics, gev = MT.precompile_shard_from(kk[:, 0], kk[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(), device)
         yield "keccak", machine, tables, publics, gev, None
-    if poseidon2:
-        pp = torch.as_tensor(np.concatenate(poseidon2), device=device)
+    for pp in chunks("poseidon2", poseidon2):
+        pp = torch.as_tensor(pp, device=device)
         rd = pp[:, 2:18].reshape(-1, 8, 2)
         machine, tables, publics, gev = MT.poseidon2_shard_from(pp[:, 0], pp[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(),
                                                                pp[:, 18:26].contiguous(), device)
         yield "poseidon2", machine, tables, publics, gev, None
     for name, evs, build in (("sha_extend", sha_extend, MT.sha_extend_shard_from), ("sha_compress", sha_compress, MT.sha_compress_shard_from),
-                             ("uint256", uint256, MT.uint256_shard_from)):
-        if evs:
-            machine, tables, publics, gev = build(np.concatenate(evs), device)
+                             ("uint256", uint256, MT.uint256_shard_from), ("secp256k1_add", secp_add, MT.secp256k1_add_shard_from),
+                             ("secp256k1_double", secp_double, MT.secp256k1_double_shard_from)):
+        for part in chunks(name, evs):
+            machine, tables, publics, gev = build(part, device)
             yield name, machine, tables, publics, gev, None
     gm = executor.global_memory()
     gm = gm[np.argsort(gm[:, 0].astype(np.uint64))]
     if gm.shape[0] == 0 or gm[0, 0] != 0:                  # register x0 opens the address chain whether or not the program read it
         gm = np.concatenate([np.zeros((1, 4), dtype=np.int64), gm])
-    addrs = [int(a) for a in gm[:, 0]]
-    machine, tables, publics, gev = MT.memory_shard_from(addrs, [(int(v), 0) for v in gm[:, 1]], [(int(v), int(t)) for v, t in gm[:, 2:4]], device)
-    yield "memory", machine, tables, publics, gev, None
+    previous = 0
+    for at in range(0, gm.shape[0], limit["memory"]):       # `split` (record.rs): init and finalise events chunked alike, zipped
+        part = gm[at:at + limit["memory"]]
+        addrs = [int(a) for a in part[:, 0].astype(np.uint64)]
+        machine, tables, publics, gev = MT.memory_shard_from(addrs, [(int(v), 0) for v in part[:, 1]], [(int(v), int(t)) for v, t in part[:, 2:4]],
+                                                             device, previous_addr=previous)
+        previous = addrs[-1]
+        yield "memory", machine, tables, publics, gev, None
 
 
 def global_events_balance(event_lists):

@@ -832,6 +832,100 @@ def uint256_mul_chip():                                                         
     return _done(b, c)
 
 
+SECP256K1_P = (1 << 256) - (1 << 32) - 977                                                # curves/src/weierstrass/secp256k1.rs:L29-L45
+SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE = 0x0A, 0x0B
+
+
+def eval_field_op(b, cols, a, bb, op, modulus, is_real):                                  # FieldOpCols::eval (field_op.rs:L472-L500)
+    """result = a op bb mod `modulus` (an integer: the curve's base field) on 32 byte limbs; sub / div are the add / mul identities
+    with the result in a's place (result + bb = a, result * bb = a)."""
+    p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(32)]
+    if op in ("add", "mul"):
+        p_a, p_res = a, cols.result
+    else:
+        p_a, p_res = cols.result, a
+    p_op = _poly_add(p_a, bb) if op in ("add", "sub") else _poly_mul(p_a, bb)
+    eval_field_op_polynomials(b, cols, p_op, p_mod, p_res, is_real)
+
+
+def weierstrass_add_chip(name="Secp256k1AddAssign", modulus=SECP256K1_P, syscall_id=SYS_SECP256K1_ADD):   # weierstrass/weierstrass_add.rs:L420-L610
+    b, c, _ = _chip(name, 1599)
+    accs = lambda n: (lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(n)])
+    addrs = lambda n: (lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(n)])
+    FO = FIELD_OP(32, 62)
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("p_ptr", SYSCALL_ADDR), ("q_ptr", SYSCALL_ADDR), ("p_addrs", addrs(8)), ("q_addrs", addrs(8)),
+          ("p_access", accs(8)), ("q_access", accs(8)), ("slope_denominator", FO), ("inverse_check", FO), ("slope_numerator", FO), ("slope", FO),
+          ("slope_squared", FO), ("p_x_plus_q_x", FO), ("x3_ins", FO), ("p_x_minus_x", FO), ("y3_ins", FO), ("slope_times_p_x_minus_x", FO),
+          ("x3_range", FIELD_LT(32)), ("y3_range", FIELD_LT(32)))(c)
+    r = L.is_real
+    p_x, p_y = generate_limbs(b, L.p_access[:4], r), generate_limbs(b, L.p_access[4:], r)
+    q_x, q_y = generate_limbs(b, L.q_access[:4], r), generate_limbs(b, L.q_access[4:], r)
+    eval_field_op(b, L.slope_numerator, q_y, p_y, "sub", modulus, r)
+    eval_field_op(b, L.slope_denominator, q_x, p_x, "sub", modulus, r)
+    one = [b.const(1)] + [b.const(0)] * 31
+    eval_field_op(b, L.inverse_check, one, L.slope_denominator.result, "div", modulus, r)
+    eval_field_op(b, L.slope, L.slope_numerator.result, L.slope_denominator.result, "div", modulus, r)
+    slope = L.slope.result
+    eval_field_op(b, L.slope_squared, slope, slope, "mul", modulus, r)
+    eval_field_op(b, L.p_x_plus_q_x, p_x, q_x, "add", modulus, r)
+    eval_field_op(b, L.x3_ins, L.slope_squared.result, L.p_x_plus_q_x.result, "sub", modulus, r)
+    x = L.x3_ins.result
+    eval_field_op(b, L.p_x_minus_x, p_x, x, "sub", modulus, r)
+    eval_field_op(b, L.slope_times_p_x_minus_x, slope, L.p_x_minus_x.result, "mul", modulus, r)
+    eval_field_op(b, L.y3_ins, L.slope_times_p_x_minus_x.result, p_y, "sub", modulus, r)
+    mod_limbs = [b.const((modulus >> (8 * i)) & 0xFF) for i in range(32)]
+    eval_field_lt(b, L.x3_range, L.x3_ins.result, mod_limbs, r)
+    eval_field_lt(b, L.y3_range, L.y3_ins.result, mod_limbs, r)
+    result_words = limbs_to_words(L.x3_ins.result) + limbs_to_words(L.y3_ins.result)
+    p_ptr = eval_syscall_addr(b, 64, L.p_ptr, r)
+    q_ptr = eval_syscall_addr(b, 64, L.q_ptr, r)
+    for i in range(8):
+        eval_addr_add(b, list(p_ptr) + [b.const(0)], word_of_u64(8 * i), L.p_addrs[i].value, r)
+    for i in range(8):
+        eval_addr_add(b, list(q_ptr) + [b.const(0)], word_of_u64(8 * i), L.q_addrs[i].value, r)
+    for i in range(8):
+        acc = L.q_access[i].memory_access
+        eval_memory_access(b, L.clk_high, L.clk_low, L.q_addrs[i].value, acc, acc.prev_value, r)
+    for i in range(8):
+        eval_memory_access(b, L.clk_high, L.clk_low + 1, L.p_addrs[i].value, L.p_access[i].memory_access, result_words[i], r)
+    send_syscall(b, L.clk_high, L.clk_low, syscall_id, p_ptr, q_ptr, r, receive=True)
+    return _done(b, c)
+
+
+def weierstrass_double_chip(name="Secp256k1DoubleAssign", modulus=SECP256K1_P, a_coeff=0, syscall_id=SYS_SECP256K1_DOUBLE):   # weierstrass_double.rs:L415-L620
+    b, c, _ = _chip(name, 1591)
+    FO = FIELD_OP(32, 62)
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("p_ptr", SYSCALL_ADDR), ("p_addrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(8)]),
+          ("p_access", lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(8)]), ("slope_denominator", FO), ("slope_numerator", FO), ("slope", FO),
+          ("p_x_squared", FO), ("p_x_squared_times_3", FO), ("slope_squared", FO), ("p_x_plus_p_x", FO), ("x3_ins", FO), ("p_x_minus_x", FO), ("y3_ins", FO),
+          ("slope_times_p_x_minus_x", FO), ("x3_range", FIELD_LT(32)), ("y3_range", FIELD_LT(32)))(c)
+    r = L.is_real
+    p_x, p_y = generate_limbs(b, L.p_access[:4], r), generate_limbs(b, L.p_access[4:], r)
+    const_limbs = lambda v: [b.const((v >> (8 * i)) & 0xFF) for i in range(32)]
+    eval_field_op(b, L.p_x_squared, p_x, p_x, "mul", modulus, r)
+    eval_field_op(b, L.p_x_squared_times_3, L.p_x_squared.result, const_limbs(3), "mul", modulus, r)
+    eval_field_op(b, L.slope_numerator, const_limbs(a_coeff), L.p_x_squared_times_3.result, "add", modulus, r)
+    eval_field_op(b, L.slope_denominator, const_limbs(2), p_y, "mul", modulus, r)
+    eval_field_op(b, L.slope, L.slope_numerator.result, L.slope_denominator.result, "div", modulus, r)
+    slope = L.slope.result
+    eval_field_op(b, L.slope_squared, slope, slope, "mul", modulus, r)
+    eval_field_op(b, L.p_x_plus_p_x, p_x, p_x, "add", modulus, r)
+    eval_field_op(b, L.x3_ins, L.slope_squared.result, L.p_x_plus_p_x.result, "sub", modulus, r)
+    eval_field_op(b, L.p_x_minus_x, p_x, L.x3_ins.result, "sub", modulus, r)
+    eval_field_op(b, L.slope_times_p_x_minus_x, slope, L.p_x_minus_x.result, "mul", modulus, r)
+    eval_field_op(b, L.y3_ins, L.slope_times_p_x_minus_x.result, p_y, "sub", modulus, r)
+    eval_field_lt(b, L.x3_range, L.x3_ins.result, const_limbs(modulus), r)
+    eval_field_lt(b, L.y3_range, L.y3_ins.result, const_limbs(modulus), r)
+    result_words = limbs_to_words(L.x3_ins.result) + limbs_to_words(L.y3_ins.result)
+    p_ptr = eval_syscall_addr(b, 64, L.p_ptr, r)
+    for i in range(8):
+        eval_addr_add(b, list(p_ptr) + [b.const(0)], word_of_u64(8 * i), L.p_addrs[i].value, r)
+    for i in range(8):
+        eval_memory_access(b, L.clk_high, L.clk_low, L.p_addrs[i].value, L.p_access[i].memory_access, result_words[i], r)
+    send_syscall(b, L.clk_high, L.clk_low, syscall_id, p_ptr, [0, 0, 0], r, receive=True)
+    return _done(b, c)
+
+
 def poseidon2_chip():                                                                     # syscall/precompiles/poseidon2/air.rs:L424-L607
     """The POSEIDON2 precompile: eight u64 words at `ptr` (sixteen field elements, low half first) are read and rewritten in place
     by one KoalaBear Poseidon2 permutation — the same `Poseidon2Operation` sub-AIR as the Global chip's (hinted for a fused kernel)."""
@@ -867,7 +961,7 @@ def poseidon2_chip():                                                           
 
 
 MORE_CHIPS = {
-    "Uint256MulMod": uint256_mul_chip, "Poseidon2": poseidon2_chip, "ShaExtend": sha_extend_chip, "ShaExtendControl": sha_extend_control_chip, "ShaCompress": sha_compress_chip,
+    "Secp256k1AddAssign": weierstrass_add_chip, "Secp256k1DoubleAssign": weierstrass_double_chip, "Uint256MulMod": uint256_mul_chip, "Poseidon2": poseidon2_chip, "ShaExtend": sha_extend_chip, "ShaExtendControl": sha_extend_control_chip, "ShaCompress": sha_compress_chip,
     "ShaCompressControl": sha_compress_control_chip,
     "AluX0": alu_x0_chip, "DivRem": divrem_chip, "SyscallCore": lambda: syscall_chip("core"), "SyscallPrecompile": lambda: syscall_chip("precompile"),
     "SyscallInstrs": syscall_instrs_chip, "MemoryGlobalInit": lambda: memory_global_chip("init"),
@@ -876,7 +970,7 @@ MORE_CHIPS = {
 }
 # (columns, constraints) from rv64im_costs.json / rv64im_complexity.json; interactions of the recorded core shard where it has the chip
 MORE_RECORDED = {
-    "Uint256MulMod": (371, 253, None), "Poseidon2": (348, 497, None), "ShaExtend": (128, 80, None), "ShaExtendControl": (18, 21, None), "ShaCompress": (206, 300, None),
+    "Secp256k1AddAssign": (1599, 918, None), "Secp256k1DoubleAssign": (1591, 904, None), "Uint256MulMod": (371, 253, None), "Poseidon2": (348, 497, None), "ShaExtend": (128, 80, None), "ShaExtendControl": (18, 21, None), "ShaCompress": (206, 300, None),
     "ShaCompressControl": (53, 21, None), "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
     "MemoryGlobalInit": (30, 31, None), "MemoryGlobalFinalize": (30, 31, None), "KeccakPermute": (2640, 2859, None),
     "KeccakPermuteControl": (634, 331, None),

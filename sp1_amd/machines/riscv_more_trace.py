@@ -691,3 +691,203 @@ def uint256_shard_from(events, device="cpu"):
     t_f = torch.cat([(clk[:, None] + 1).expand(-1, 4).reshape(-1), clk[:, None].expand(-1, 8).reshape(-1)])
     v_f = torch.cat([t[:, 27:31].reshape(-1), ys[:, :, 1].reshape(-1)])
     return _close_precompile_shard(tr, M.SYS_UINT256_MUL, clk, xl, wa, t_i, t_f, v_i, v_f, arg2_limbs=yl)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# secp256k1 point addition / doubling (syscall/precompiles/weierstrass/weierstrass_{add,double}.rs)
+def _le_bytes(vals, n):
+    return np.frombuffer(b"".join(int(v).to_bytes(n, "little") for v in vals), dtype=np.uint8).reshape(len(vals), n).astype(np.int64)
+
+
+def field_op_columns_batch(A, B, modulus, n_limbs, n_witness, op):
+    """`field_op_columns` for lists of operands: the integer arithmetic stays with Python (a few microseconds per row), the
+    byte-limb polynomial identity and its division by (x - 256) run over all rows at once."""
+    vals = [a + b for a, b in zip(A, B)] if op == "add" else [a * b for a, b in zip(A, B)]
+    res = [v % modulus for v in vals]
+    pa, pb, pr = _le_bytes(A, n_limbs), _le_bytes(B, n_limbs), _le_bytes(res, n_limbs)
+    pc = _le_bytes([v // modulus for v in vals], n_limbs)
+    pm = [(modulus >> (8 * j)) & 0xFF for j in range(n_limbs)]
+    van = np.zeros((len(A), n_witness + 1), dtype=np.int64)
+    if op == "add":
+        van[:, :n_limbs] += pa + pb
+    else:
+        for i in range(n_limbs):
+            van[:, i:i + n_limbs] += pa[:, i:i + 1] * pb
+    van[:, :n_limbs] -= pr
+    for j in range(n_limbs):
+        if pm[j]:
+            van[:, j:j + n_limbs] -= pc * pm[j]
+    wit = np.zeros((len(A), n_witness), dtype=np.int64)
+    acc = van[:, n_witness].copy()
+    for i in range(n_witness - 1, -1, -1):                              # synthetic division from the top (field_op.rs:L71-L78)
+        wit[:, i] = acc
+        acc = van[:, i] + acc * 256
+    assert not acc.any(), "the vanishing polynomial does not vanish at 256"
+    wit += 1 << 14
+    assert wit.min() >= 0 and wit.max() < (1 << 16)
+    return pr, pc, wit, res
+
+
+def _set_field_op(rows, L, prefix, A, B, op, modulus=M.SECP256K1_P, n_limbs=32, n_witness=62):
+    """FieldOpCols::populate_with_modulus (field_op.rs:L286-L345) into rows[:len(A)]: sub / div are stated as result + b = a and
+    result * b = a, with the `result` columns holding the difference / quotient."""
+    n = len(A)
+    if op == "sub":
+        result = [(modulus + a - b) % modulus for a, b in zip(A, B)]
+        _, car, wit, back = field_op_columns_batch(result, B, modulus, n_limbs, n_witness, "add")
+        assert back == [a % modulus for a in A]
+        res = _le_bytes(result, n_limbs)
+    elif op == "div":
+        assert all(b % modulus for b in B), "division by zero is not allowed"
+        result = [a * pow(b, modulus - 2, modulus) % modulus for a, b in zip(A, B)]
+        _, car, wit, back = field_op_columns_batch(result, B, modulus, n_limbs, n_witness, "mul")
+        assert back == [a % modulus for a in A]
+        res = _le_bytes(result, n_limbs)
+    else:
+        res, car, wit, result = field_op_columns_batch(A, B, modulus, n_limbs, n_witness, op)
+    rows[:n, L[prefix + ".result"]:L[prefix + ".result"] + n_limbs] = res
+    rows[:n, L[prefix + ".carry"]:L[prefix + ".carry"] + n_limbs] = car
+    rows[:n, L[prefix + ".witness"]:L[prefix + ".witness"] + n_witness] = wit
+    return result
+
+
+def _set_field_lt(rows, L, prefix, lhs, rhs=M.SECP256K1_P, n_limbs=32):
+    """FieldLtCols::populate (field/range.rs:L30-L61) into rows[:len(lhs)]: the flag at the most significant differing byte."""
+    n = len(lhs)
+    assert all(x < rhs for x in lhs)
+    x = _le_bytes(lhs, n_limbs)
+    y = np.array([(rhs >> (8 * j)) & 0xFF for j in range(n_limbs)], dtype=np.int64)[None, :]
+    at = n_limbs - 1 - np.argmax((x != y)[:, ::-1], axis=1)
+    r = np.arange(n)
+    flags = np.zeros((n, n_limbs), dtype=np.int64)
+    flags[r, at] = 1
+    rows[:n, L[prefix + ".byte_flags"]:L[prefix + ".byte_flags"] + n_limbs] = flags
+    rows[:n, L[prefix + ".lhs_comparison_byte"]] = x[r, at]
+    rows[:n, L[prefix + ".rhs_comparison_byte"]] = y[0, at]
+
+
+def _secp_add_field_ops(row, L, px, py, qx, qy):                          # populate_field_ops, weierstrass_add.rs:L95-L165
+    num = _set_field_op(row, L, "slope_numerator", qy, py, "sub")
+    den = _set_field_op(row, L, "slope_denominator", qx, px, "sub")
+    _set_field_op(row, L, "inverse_check", [1] * len(den), den, "div")
+    slope = _set_field_op(row, L, "slope", num, den, "div")
+    sq = _set_field_op(row, L, "slope_squared", slope, slope, "mul")
+    pq = _set_field_op(row, L, "p_x_plus_q_x", px, qx, "add")
+    x3 = _set_field_op(row, L, "x3_ins", sq, pq, "sub")
+    _set_field_lt(row, L, "x3_range", x3)
+    d = _set_field_op(row, L, "p_x_minus_x", px, x3, "sub")
+    sd = _set_field_op(row, L, "slope_times_p_x_minus_x", slope, d, "mul")
+    y3 = _set_field_op(row, L, "y3_ins", sd, py, "sub")
+    _set_field_lt(row, L, "y3_range", y3)
+    return x3, y3
+
+
+def _secp_double_field_ops(row, L, px, py, a_coeff=0):                    # populate_field_ops, weierstrass_double.rs:L89-L160
+    xx = _set_field_op(row, L, "p_x_squared", px, px, "mul")
+    xx3 = _set_field_op(row, L, "p_x_squared_times_3", xx, [3] * len(px), "mul")
+    num = _set_field_op(row, L, "slope_numerator", [a_coeff] * len(px), xx3, "add")
+    den = _set_field_op(row, L, "slope_denominator", [2] * len(px), py, "mul")
+    slope = _set_field_op(row, L, "slope", num, den, "div")
+    sq = _set_field_op(row, L, "slope_squared", slope, slope, "mul")
+    pp = _set_field_op(row, L, "p_x_plus_p_x", px, px, "add")
+    x3 = _set_field_op(row, L, "x3_ins", sq, pp, "sub")
+    _set_field_lt(row, L, "x3_range", x3)
+    d = _set_field_op(row, L, "p_x_minus_x", px, x3, "sub")
+    sd = _set_field_op(row, L, "slope_times_p_x_minus_x", slope, d, "mul")
+    y3 = _set_field_op(row, L, "y3_ins", sd, py, "sub")
+    _set_field_lt(row, L, "y3_range", y3)
+    return x3, y3
+
+
+def _dummy_access(row, L, prefix):
+    """A MemoryAccessColsU8 populated from the reference's dummy record {value 1, timestamp 1, prev_timestamp 0}: the padding rows'
+    operands are small non-zero constants so that the (unconditional) field operations have an inverse to work with."""
+    row[L[prefix + ".memory_access.prev_value"]] = 1
+    row[L[prefix + ".memory_access.compare_low"]] = 1
+    row[L[prefix + ".prev_value_u8.low_bytes"]] = 1
+
+
+_word256 = lambda ws: sum(int(x) << (64 * i) for i, x in enumerate(ws))
+_low_bytes = lambda v: torch.stack([(v >> (16 * k)) & 0xFF for k in range(4)], dim=1)
+
+
+def secp256k1_add_shard_from(events, device="cpu"):
+    """The SECP256K1_ADD precompile shard of the executor's events ([n, 43] int64): Secp256k1AddAssign rows (`populate_row` and
+    the dummy row of `generate_trace_into`, weierstrass_add.rs:L246-L330, L612-L680), SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
+    dev = torch.device(device)
+    ev = np.asarray(events).astype(np.uint64)
+    n = ev.shape[0]
+    air = R.chip("Secp256k1AddAssign")[0]
+    L = air.layout
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    tb = RT.Table(air, n, dev)
+    rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
+    coord = lambda cols: [_word256(w) for w in ev[:, cols]]
+    if n:
+        x3, y3 = _secp_add_field_ops(rows, L, coord([4, 6, 8, 10]), coord([12, 14, 16, 18]), coord([20, 22, 24, 26]), coord([28, 30, 32, 34]))
+        assert x3 == coord([35, 36, 37, 38]) and y3 == coord([39, 40, 41, 42]), "the executor's sum is not p + q"
+    if rows.shape[0] > n:
+        _secp_add_field_ops(rows[n:n + 1], L, [0], [0], [1], [1])
+        _dummy_access(rows[n], L, "q_access.0")
+        _dummy_access(rows[n], L, "q_access.4")
+        rows[n + 1:] = rows[n]
+    tb.main[:] = torch.as_tensor(rows, device=dev)
+    t = torch.as_tensor(ev.astype(np.int64), device=dev)
+    clk, pp, qp = t[:, 0], t[:, 1], t[:, 2]
+    tb.set("clk_high", clk >> 24); tb.set("clk_low", clk & 0xFFFFFF); tb.set("is_real", 1)
+    pl = _syscall_addr_t(tb, "p_ptr", pp)
+    ql = _syscall_addr_t(tb, "q_ptr", qp)
+    ps, qs = t[:, 3:19].reshape(n, 8, 2), t[:, 19:35].reshape(n, 8, 2)
+    for i in range(8):
+        tb.set("p_addrs.%d.value" % i, _limbs_t(pp + 8 * i)[:, :3])
+        tb.set("q_addrs.%d.value" % i, _limbs_t(qp + 8 * i)[:, :3])
+        _mem_access_t(tb, "p_access.%d.memory_access" % i, ps[:, i, 1], ps[:, i, 0], clk + 1)
+        tb.set("p_access.%d.prev_value_u8.low_bytes" % i, _low_bytes(ps[:, i, 1]))
+        _mem_access_t(tb, "q_access.%d.memory_access" % i, qs[:, i, 1], qs[:, i, 0], clk)
+        tb.set("q_access.%d.prev_value_u8.low_bytes" % i, _low_bytes(qs[:, i, 1]))
+    tr.tables["Secp256k1AddAssign"] = tb
+    eight = torch.arange(8, device=dev)[None, :]
+    wa = torch.cat([(pp[:, None] + 8 * eight).reshape(-1), (qp[:, None] + 8 * eight).reshape(-1)])
+    t_i = torch.cat([ps[:, :, 0].reshape(-1), qs[:, :, 0].reshape(-1)])
+    v_i = torch.cat([ps[:, :, 1].reshape(-1), qs[:, :, 1].reshape(-1)])
+    t_f = torch.cat([(clk[:, None] + 1).expand(-1, 8).reshape(-1), clk[:, None].expand(-1, 8).reshape(-1)])
+    v_f = torch.cat([t[:, 35:43].reshape(-1), qs[:, :, 1].reshape(-1)])
+    return _close_precompile_shard(tr, M.SYS_SECP256K1_ADD, clk, pl, wa, t_i, t_f, v_i, v_f, arg2_limbs=ql)
+
+
+def secp256k1_double_shard_from(events, device="cpu"):
+    """The SECP256K1_DOUBLE precompile shard of the executor's events ([n, 26] int64): Secp256k1DoubleAssign rows
+    (weierstrass_double.rs:L262-L380: the point is rewritten in place at clk), SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
+    dev = torch.device(device)
+    ev = np.asarray(events).astype(np.uint64)
+    n = ev.shape[0]
+    air = R.chip("Secp256k1DoubleAssign")[0]
+    L = air.layout
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    tb = RT.Table(air, n, dev)
+    rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
+    coord = lambda cols: [_word256(w) for w in ev[:, cols]]
+    if n:
+        x3, y3 = _secp_double_field_ops(rows, L, coord([3, 5, 7, 9]), coord([11, 13, 15, 17]))
+        assert x3 == coord([18, 19, 20, 21]) and y3 == coord([22, 23, 24, 25]), "the executor's point is not 2 p"
+    if rows.shape[0] > n:
+        _secp_double_field_ops(rows[n:n + 1], L, [0], [1])
+        _dummy_access(rows[n], L, "p_access.4")
+        rows[n + 1:] = rows[n]
+    tb.main[:] = torch.as_tensor(rows, device=dev)
+    t = torch.as_tensor(ev.astype(np.int64), device=dev)
+    clk, pp = t[:, 0], t[:, 1]
+    tb.set("clk_high", clk >> 24); tb.set("clk_low", clk & 0xFFFFFF); tb.set("is_real", 1)
+    pl = _syscall_addr_t(tb, "p_ptr", pp)
+    ps = t[:, 2:18].reshape(n, 8, 2)
+    for i in range(8):
+        tb.set("p_addrs.%d.value" % i, _limbs_t(pp + 8 * i)[:, :3])
+        _mem_access_t(tb, "p_access.%d.memory_access" % i, ps[:, i, 1], ps[:, i, 0], clk)
+        tb.set("p_access.%d.prev_value_u8.low_bytes" % i, _low_bytes(ps[:, i, 1]))
+    tr.tables["Secp256k1DoubleAssign"] = tb
+    eight = torch.arange(8, device=dev)[None, :]
+    wa = (pp[:, None] + 8 * eight).reshape(-1)
+    return _close_precompile_shard(tr, M.SYS_SECP256K1_DOUBLE, clk, pl, wa, ps[:, :, 0].reshape(-1), clk[:, None].expand(-1, 8).reshape(-1),
+                                   ps[:, :, 1].reshape(-1), t[:, 18:26].reshape(-1))

@@ -155,6 +155,42 @@ def test_uint256_mulmod_system_call_and_its_shard():
         assert sum(gm[0x78100000 + 96 * i + 8 * k] << (64 * k) for k in range(4)) == (x * y) % (m if m else 1 << 256)
 
 
+def test_secp256k1_add_and_double_system_calls_and_their_shards():
+    """3G by the precompiles from a hand-assembled program: p <- 2 p (SECP256K1_DOUBLE, in place), then q <- q + p with q = G
+    (SECP256K1_ADD writes its first argument), then the sum doubled again — against Python's affine arithmetic; both precompile
+    shards (ten / eleven FieldOpCols per row, padding rows on the reference's dummy operands) check row by row."""
+    Pm = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F
+    G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+
+    def add(p, q):
+        lam = (3 * p[0] * p[0] * pow(2 * p[1], Pm - 2, Pm) if p == q else (q[1] - p[1]) * pow(q[0] - p[0], Pm - 2, Pm)) % Pm
+        x = (lam * lam - p[0] - q[0]) % Pm
+        return x, (lam * (p[0] - x) - p[1]) % Pm
+    words = lambda v: b"".join(struct.pack("<Q", (v >> (64 * i)) & M64) for i in range(4))
+    data = words(G[0]) + words(G[1]) + words(G[0]) + words(G[1])
+    prog = A.li(28, 0x78100000)
+    prog += [A.enc("addi", 10, 28, 0), A.enc("addi", 11, 0, 0)] + A.li(5, 0x0000010B) + [A.enc("ecall")]          # p = 2G
+    prog += [A.enc("addi", 10, 28, 64), A.enc("addi", 11, 28, 0)] + A.li(5, 0x0001010A) + [A.enc("ecall")]        # q = G + 2G
+    prog += [A.enc("addi", 10, 28, 64), A.enc("addi", 11, 0, 0)] + A.li(5, 0x0000010B) + [A.enc("ecall")]         # q = 6G
+    ex, kinds, _, last = run_program(A.elf(prog + A.halt(0), data=data + bytes(32)), [], 1 << 20)
+    assert kinds == ["core", "secp256k1_add", "secp256k1_double", "memory"] and last.exit_code == 0
+    gm = {int(r[0]): int(r[2]) & M64 for r in ex.global_memory()}
+    point = lambda off: tuple(sum(gm[0x78100000 + off + 32 * c + 8 * k] << (64 * k) for k in range(4)) for c in range(2))
+    g2 = add(G, G)
+    g3 = add(G, g2)
+    assert point(0) == g2 and point(64) == add(g3, g3)
+
+
+def test_secp256k1_add_of_equal_x_is_an_executor_error():
+    from sp1_amd import _lib
+    words = lambda v: b"".join(struct.pack("<Q", (v >> (64 * i)) & M64) for i in range(4))
+    data = (words(5) + words(7)) * 2
+    prog = A.li(28, 0x78100000) + [A.enc("addi", 10, 28, 0), A.enc("addi", 11, 28, 64)] + A.li(5, 0x0001010A) + [A.enc("ecall")]
+    ex = X.Executor(A.elf(prog + A.halt(0), data=data + bytes(32)), stdin=[])
+    with pytest.raises(_lib.Sp1HipError, match="equal x"):
+        ex.run_shard(1 << 20)
+
+
 def test_a_flipped_sha_cell_is_caught():
     from sp1_amd.machines import riscv as R
     ex = X.Executor(_elf("sha2"), stdin=[bytes(10)])
@@ -167,11 +203,12 @@ def test_a_flipped_sha_cell_is_caught():
     assert bad == ["ShaCompress"]
 
 
-def test_rsp_elf_core_shards_until_its_first_hook():
-    """The Reth block-execution client on a recorded input: its first phases (deserialisation, witness database) are ordinary
-    rv64im + KECCAK_PERMUTE; a shard from the start and one from 3e7 cycles in check row by row. The run ends with an error at
-    the first hook (fd 20), which the executor names instead of skipping."""
-    from sp1_amd import _lib
+def test_rsp_elf_runs_a_whole_block():
+    """The Reth block-execution client on the reference's recorded input (block 21740136), start to HALT: 9.8e7 cycles, 23k
+    KECCAK_PERMUTE calls, 81k secp256k1 point operations (signature recovery; their square-root hints come from the FP_SQRT hook
+    and are checked by the guest), SHA-256 of the committed block hash. A core shard from the start and one from 3e7 cycles in,
+    and the first events of both curve precompiles, check row by row; the committed digest is SHA-256 of the public values."""
+    from sp1_amd.machines import riscv_more_trace as MT
     data = X.guest_file("rsp_input_21740136.bin")
     ex = X.Executor(_elf("rsp"), stdin=[data])
     sh = ex.run_shard(1 << 16)
@@ -183,9 +220,43 @@ def test_rsp_elf_core_shards_until_its_first_hook():
     machine, tabs, publics = X.shard_tables(ex, sh)
     assert check_shard(machine, tabs, publics) == ([], 0)
     assert {"LoadByte", "StoreDouble", "Bitwise", "Global"} <= {a.name for a, _ in machine}
+    cycles, counts, first = 30_000_000 + (2 << 16), {"keccak": 0, "secp256k1_add": 0, "secp256k1_double": 0, "sha_compress": 0}, {}
+    while not sh.halted:
+        sh = ex.run_shard(1 << 22, copy=False)
+        cycles += sh.cycles
+        for k in counts:
+            ev = getattr(sh, k)
+            counts[k] += ev.shape[0]
+            if ev.shape[0] and k not in first:
+                first[k] = np.array(ev[:40])
+    assert sh.exit_code == 0 and cycles == 98_339_210
+    # (668 more KECCAK_PERMUTE calls in the 3e7 cycles that ran without recording: 23254 in all)
+    assert counts == {"keccak": 22586, "secp256k1_add": 26874, "secp256k1_double": 53760, "sha_compress": 12}
+    assert sh.committed_value_digest == _digest_words(ex.output(0))
+    for kind, build in (("secp256k1_add", MT.secp256k1_add_shard_from), ("secp256k1_double", MT.secp256k1_double_shard_from)):
+        machine, tabs, publics, _ = build(first[kind])
+        assert check_shard(machine, tabs, publics)[0] == []          # a slice of the run: its Global messages balance only with the rest
+    assert X.split_thresholds(ex.program()[1].shape[0])["keccak"] < counts["keccak"]        # the Keccak calls do not fit one shard
+
+
+def test_precompile_and_memory_events_split_into_shards_at_the_thresholds(monkeypatch):
+    """With the thresholds of `SplitOpts::new` shrunk (2 Keccak calls, 96 addresses per shard) the keccak guest's run has several
+    precompile and memory shards; each checks on its own — the memory shards chained through previous_init_addr — and the Global
+    messages of all of them still cancel. The real thresholds for this program are those of the reference's cost model."""
+    real = X.split_thresholds(4096)
+    assert real["keccak"] % 32 == 0 and 4000 < real["keccak"] < 6000 and real["secp256k1_double"] > real["secp256k1_add"] > 30000
+    assert real["memory"] % 32 == 0 and real["memory"] <= (1 << 22) // 2
+    monkeypatch.setattr(X, "split_thresholds", lambda rows: dict(real, keccak=2, memory=96))
+    ex, kinds, _, last = run_program(_elf("keccak"), [bytes(300)], 1 << 20)
+    assert kinds.count("keccak") >= 2 and kinds.count("memory") >= 2 and last.exit_code == 0
+
+
+def test_an_unknown_hook_is_an_executor_error():
+    from sp1_amd import _lib
+    prog = A.li(10, 15) + A.li(11, 0x78100000) + A.li(12, 8) + A.li(5, 2) + [A.enc("ecall")]       # WRITE(fd 15 = ecrecover hook, buf, 8)
+    ex = X.Executor(A.elf(prog + A.halt(0), data=bytes(32)), stdin=[])
     with pytest.raises(_lib.Sp1HipError, match="hook"):
-        while True:
-            ex.run_shard(1 << 24, record=False)
+        ex.run_shard(1 << 20)
 
 
 def test_loop_elf():
