@@ -1,0 +1,132 @@
+"""A WHOLE guest program proved shard by shard on one GPU: every core shard, every precompile shard (cut at the reference's
+`SplitOpts` thresholds), every memory shard of one execution — what the reference's perf harness times as "core proving" and
+divides the cycle count by (/root/reference/sp1-gpu/crates/perf/src/report.rs:L52-L60).
+
+    python bench/prove_program.py --program rsp            # the Reth block of the reference's perf inputs: 9.8e7 cycles, 23 shards
+    python bench/prove_program.py --program fibonacci --cycles 30000000
+
+Per shard: the executor runs until the reference's shard-cutting rule ends the shard (trace-area estimator, host, C++), the tracer builds the tables ON THE DEVICE
+(torch: plumbing; the tables of a production deployment come from the Rust host's tracegen), `sp1hip_prove_shard` proves them with
+production parameters (blowup 4, 124 queries, 16-bit PoW) and the shard's own public values. Timed per shard: executor, tables,
+setup (the preprocessed commitment — the proving key, per shard shape here), prove. ONE JSON line at the end:
+`prove_seconds` = the sum of the prove calls, `cycles_per_s` = cycles / prove_seconds (the harness's definition), and the same with
+the tables and the executor included (this repository's Python tracer is NOT the product; the number is there so that nothing is hidden).
+`--verify` runs the pinned verifier (oracle/: checker only, untimed) on the first proof of every shard kind; the Global messages of
+all shards must cancel (the statement their septic digests add up to), which is checked on the events the tracer returns.
+`--dry-run` builds every shard and proves nothing (no GPU needed: the CPU check of this script)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bench"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--program", default="rsp")
+    ap.add_argument("--cycles", type=int, default=0, help="size the input for at least this many cycles (not for rsp: its input is a recorded block)")
+    ap.add_argument("--shard-cycles", type=int, default=0, help="cut core shards at this many cycles instead of by trace area (the default: the "
+                    "reference's rule, ShapeChecker with ELEMENT_THRESHOLD 2^28 + 2^27 / HEIGHT_THRESHOLD 2^22, inside the executor)")
+    ap.add_argument("--max-shards", type=int, default=0, help="stop after this many shards (0 = the whole run)")
+    ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--dry-run", action="store_true")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from program_shard import FULL_CYCLES_OF, stdin_of
+    from sp1_amd.machines import riscv_exec as X, riscv_trace as RT
+    device = "cpu" if args.dry_run else "cuda"
+    if not args.dry_run:
+        from core_real import to_col_major
+        from sp1_amd import api
+        torch.cuda.set_device(0)
+    shard_cycles = args.shard_cycles or 1 << 40
+    L, lsh = 22, 21
+    ex = X.Executor(X.guest_file(args.program + ".elf"), stdin=stdin_of(args.program, args.cycles or 3 * FULL_CYCLES_OF[args.program]))
+    if not args.shard_cycles:
+        ex.cut_by_area()
+    shards, gevs, kept, cycles, last = [], [], {}, 0, None
+    t_all = time.perf_counter()
+    t_prev = t_all
+    gen = X.program_shards(ex, shard_cycles, device=device)
+    while True:
+        try:
+            kind, machine, tabs, publics, gev, sh = next(gen)
+        except StopIteration:
+            break
+        if device == "cuda":
+            torch.cuda.synchronize()
+        t_build = time.perf_counter() - t_prev                          # executor + tables of this shard (the generator ran both)
+        area = sum(int(tabs[a.name][1].shape[0]) * (a.main_width + a.prep_width) for a, _ in machine)
+        row = {"kind": kind, "chips": len(machine), "cells": area, "build_s": round(t_build, 3),
+               "rows": {a.name: int(tabs[a.name][1].shape[0]) for a, _ in machine if a.name not in ("Byte", "Range", "Program")}}
+        if sh is not None:
+            row["cycles"], row["estimated_cells"] = sh.cycles, sh.estimated_area
+            cycles, last = cycles + sh.cycles, sh
+        gevs.append(gev.cpu())
+        if not args.dry_run:
+            chips = [(a, i, to_col_major(tabs[a.name][1]), to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None) for a, i in machine]
+            tabs.clear()
+            pv = RT.to_monty_np(publics)
+            t0 = time.perf_counter()
+            commit, prep = api.JaggedProver(L, lsh, 32, 2).commit_multilinears([c[3] for c in chips if c[3] is not None])
+            torch.cuda.synchronize()
+            row["setup_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+            ch = api.DuplexChallenger()
+            ch.observe(commit)
+            t0 = time.perf_counter()
+            proof = api.prove_shard(chips, pv, prep, L, lsh, 32, ch)
+            torch.cuda.synchronize()
+            row["prove_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+            row["proof_bytes"] = len(proof)
+            if args.verify and kind not in kept:
+                kept[kind] = (machine, np.asarray(commit).copy(), proof, ch.state().copy())
+            del chips, prep
+        shards.append(row)
+        print(json.dumps(row), file=sys.stderr, flush=True)
+        if args.max_shards and len(shards) >= args.max_shards:
+            break
+        t_prev = time.perf_counter()
+    wall = time.perf_counter() - t_all
+    whole = not args.max_shards or len(shards) < args.max_shards
+    out = {"program": args.program, "cycles": cycles, "shards": len(shards), "whole_run": bool(whole and last is not None and last.halted),
+           "exit_code": last.exit_code if last is not None and last.halted else None,
+           "kinds": {k: sum(1 for s in shards if s["kind"] == k) for k in dict.fromkeys(s["kind"] for s in shards)},
+           "cells": sum(s["cells"] for s in shards), "build_seconds": round(sum(s["build_s"] for s in shards), 2), "wall_seconds": round(wall, 2),
+           "core_shards_cut": "by trace area (reference's ShapeChecker)" if not args.shard_cycles else "every %d cycles" % shard_cycles, "parameters": "max_log_row_count 22, stack 2^21, blowup 4, 124 queries, 16-bit PoW"}
+    if whole:
+        out["global_messages_cancel"] = not X.global_events_balance(gevs)
+    if not args.dry_run:
+        prove_s = sum(s["prove_ms"] for s in shards) / 1e3
+        out.update({"prove_seconds": round(prove_s, 4), "setup_seconds": round(sum(s["setup_ms"] for s in shards) / 1e3, 4),
+                    "cycles_per_s": round(cycles / prove_s), "cells_per_s": round(out["cells"] / prove_s),
+                    "cycles_per_s_incl_python_tracegen_and_executor": round(cycles / wall),
+                    "prove_ms_by_kind": {k: round(sum(s["prove_ms"] for s in shards if s["kind"] == k) / out["kinds"][k], 2) for k in out["kinds"]}})
+        if args.verify:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import pyoracle as orc                                       # the checker (test infrastructure), after everything timed
+            ver = {}
+            for kind, (machine, commit, proof, state) in kept.items():
+                shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None) for a, i in machine]
+                v_ch = orc.Challenger()
+                v_ch.observe(commit)
+                t0 = time.perf_counter()
+                rc = orc.shard_verify(shapes, commit, proof, L, lsh, v_ch, 2, 124, 16)
+                ver[kind] = {"rc": int(rc), "state_matches": bool(np.array_equal(v_ch.state(), state)), "seconds": round(time.perf_counter() - t0, 2)}
+            out["verified_first_of_kind"] = ver
+    out["per_shard"] = shards
+    line = json.dumps(out)
+    print(line)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()

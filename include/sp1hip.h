@@ -514,7 +514,24 @@ typedef struct {
     uint32_t commit_syscall, commit_deferred_syscall;
     uint32_t committed_value_digest[8];  /* as set by COMMIT so far */
     uint32_t deferred_proofs_digest[8];
+    uint64_t estimated_area, estimated_max_height;   /* the shard-cutting estimator's totals (0 without sp1hip_rv64_set_shard_limits) */
 } sp1hip_rv64_shard_info_t;
+
+/* Shard cutting by trace area, as the reference's executor does it (`ShapeChecker`, crates/core/executor/src/vm/shapes.rs:L27-L245;
+ * thresholds `ShardingThreshold`, opts.rs:L12-L14, less the HALT allowance of splicing.rs:L413-L428): after every instruction
+ * the estimate grows by the cost (columns) of the instruction's chip, by memory_local_cost + 2 global_cost per address first
+ * touched in the shard, by syscall_core_cost + global_cost per call sent to a precompile shard, by 32 memory_bump_cost +
+ * state_bump_cost when the clock's high limb moves; a shard ends when the estimate reaches element_threshold or a table
+ * height_threshold rows — never between a COMMIT and the HALT. opcode_cost / opcode_chip are indexed by the opcode numbers of
+ * sp1hip_rv64_events (chip: any numbering < 64 that groups the opcodes of one table); ALU / load instructions into x0 go to the
+ * AluX0 / LoadX0 tables. fixed_area = the preprocessed tables (Program, Byte, Range). The caller owns the cost model: this
+ * library does not know the chips. */
+typedef struct {
+    uint64_t element_threshold, height_threshold, fixed_area;
+    uint64_t opcode_cost[64];
+    uint32_t opcode_chip[64];
+    uint64_t alu_x0_cost, load_x0_cost, memory_local_cost, global_cost, syscall_core_cost, memory_bump_cost, state_bump_cost;
+} sp1hip_rv64_shard_limits_t;
 int sp1hip_rv64_create(const uint8_t* elf, uint64_t elf_len, sp1hip_rv64_vm_t* out);
 void sp1hip_rv64_destroy(sp1hip_rv64_vm_t vm);
 /* One entry of the input stream (`SP1Stdin::write_slice`): what the guest's next HINT_LEN / HINT_READ pair consumes. */
@@ -523,6 +540,9 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t vm, uint64_t max_cycles, sp1hip_rv64_
 /* on = 0: the following shards run without keeping their instruction events (a rank that proves shard r of an execution runs
  * shards 0..r-1 this way); memory state, local memory events and public values are kept as always. */
 int sp1hip_rv64_set_recording(sp1hip_rv64_vm_t vm, int on);
+/* limits != NULL: sp1hip_rv64_run_shard also ends a shard where the estimator above says so (max_cycles still bounds it);
+ * NULL: cycle counts only (the default). */
+int sp1hip_rv64_set_shard_limits(sp1hip_rv64_vm_t vm, const sp1hip_rv64_shard_limits_t* limits);
 const uint64_t* sp1hip_rv64_events(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_local_memory(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_keccak_events(sp1hip_rv64_vm_t vm);

@@ -74,7 +74,14 @@ class Rv64ShardInfo(C.Structure):
                 ("pc_start", C.c_uint64), ("next_pc", C.c_uint64), ("clk_start", C.c_uint64), ("clk_end", C.c_uint64),
                 ("halted", C.c_uint32), ("exit_code", C.c_uint32), ("commit_syscall", C.c_uint32),
                 ("commit_deferred_syscall", C.c_uint32), ("committed_value_digest", C.c_uint32 * 8),
-                ("deferred_proofs_digest", C.c_uint32 * 8)]
+                ("deferred_proofs_digest", C.c_uint32 * 8), ("estimated_area", C.c_uint64), ("estimated_max_height", C.c_uint64)]
+
+
+class Rv64ShardLimits(C.Structure):
+    _fields_ = [("element_threshold", C.c_uint64), ("height_threshold", C.c_uint64), ("fixed_area", C.c_uint64),
+                ("opcode_cost", C.c_uint64 * 64), ("opcode_chip", C.c_uint32 * 64), ("alu_x0_cost", C.c_uint64), ("load_x0_cost", C.c_uint64),
+                ("memory_local_cost", C.c_uint64), ("global_cost", C.c_uint64), ("syscall_core_cost", C.c_uint64),
+                ("memory_bump_cost", C.c_uint64), ("state_bump_cost", C.c_uint64)]
 
 
 class Vk(C.Structure):
@@ -197,6 +204,7 @@ PROTOTYPES = [
     ("sp1hip_rv64_write_stdin", None, [_vp, u8p, C.c_uint64]),
     ("sp1hip_rv64_run_shard", None, [_vp, C.c_uint64, C.POINTER(Rv64ShardInfo)]),
     ("sp1hip_rv64_set_recording", None, [_vp, _int]),
+    ("sp1hip_rv64_set_shard_limits", None, [_vp, C.POINTER(Rv64ShardLimits)]),
     ("sp1hip_rv64_events", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_local_memory", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_keccak_events", C.POINTER(C.c_uint64), [_vp]),

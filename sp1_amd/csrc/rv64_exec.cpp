@@ -249,6 +249,7 @@ struct Vm {
             c.open = (uint32_t)(local.size() / 5);
             local.insert(local.end(), {addr, c.ts, c.val, 0, 0});
             local_closed.push_back(0);
+            if (addr >= 32) ++est_new_local;
             if (!c.ever) { c.ever = true; touched.insert(touched.end(), {addr, c.val}); }
         }
     }
@@ -494,7 +495,7 @@ struct Vm {
                 return true;
             }
             c = rr(11, 2, e[E_C_PTS]); b = rr(10, 3, e[E_B_PTS]);
-            a = code;
+            a = code; regs_code_of_this_ecall = code;
             switch (code) {
             case SYS_ENTER_UNC: a = 0; resume_enter = false; break;
             case SYS_HALT: next_pc = HALT_PC; exit_code = (uint32_t)b; halted = true; break;
@@ -651,8 +652,48 @@ struct Vm {
         } else return fail(in.op == EBREAK ? "ebreak" : "unimplemented instruction 0x%08x", words[idx]);
         e[E_A] = a; e[E_B] = b; e[E_C] = c; e[E_NEXT_PC] = next_pc;
         if (record) events.insert(events.end(), e, e + EV);
+        if (limits.on) estimate(in, in.op == ECALL && ((regs_code_of_this_ecall >> 8) & 0xFF) == 1, (clk >> 24) != (next_clk >> 24));
         pc = next_pc; clk = next_clk; ++cycles;
         return true;
+    }
+
+    // The shard-cutting estimator (vm/shapes.rs:L27-L245, `ShapeChecker`): trace area and tallest table of the shard so far, kept
+    // per executed instruction from the chips' costs — the row of the instruction's chip, a MemoryLocal row and two Global rows
+    // per address first touched (the 32 registers are assumed touched up front), a SyscallCore and a Global row per call sent to
+    // a precompile shard, 32 MemoryBump rows and a StateBump row when the clock's high limb moves. The shard ends when the area
+    // reaches the element threshold or a table the height threshold (both less the HALT allowance, splicing.rs:L413-L428),
+    // unless a COMMIT has begun (the commit rows and the HALT share a shard). Costs and thresholds come from the caller.
+    struct Limits {
+        bool on = false;
+        uint64_t element_threshold = 0, height_threshold = 0, fixed_area = 0;
+        uint64_t op_cost[64] = {0}; uint32_t op_chip[64] = {0};
+        uint64_t alu_x0 = 0, load_x0 = 0, memory_local = 0, global = 0, syscall_core = 0, memory_bump = 0, state_bump = 0;
+    } limits;
+    enum { H_ALU_X0 = 64, H_LOAD_X0, H_LOCAL, H_GLOBAL, H_SYSCALL_CORE, H_MEMORY_BUMP, H_STATE_BUMP, H_COUNT };
+    uint64_t est_area = 0, est_max_height = 0, est_new_local = 0, est_heights[H_COUNT] = {0};
+    uint64_t regs_code_of_this_ecall = 0;
+    void estimate_reset() {
+        est_area = limits.fixed_area + (1ull << 18) + (1ull << 18);      // MAXIMUM_PADDING_AREA + MAXIMUM_CYCLE_AREA
+        est_max_height = 0; est_new_local = 32;
+        memset(est_heights, 0, sizeof est_heights);
+    }
+    void est_add(uint32_t chip, uint64_t rows, uint64_t cost) {
+        est_heights[chip] += rows; est_area += rows * cost;
+        if (est_heights[chip] > est_max_height) est_max_height = est_heights[chip];
+    }
+    void estimate(const Instr& in, bool sent, bool clk_high_moves) {
+        if (in.op <= REMUW && in.a == 0) est_add(H_ALU_X0, 1, limits.alu_x0);
+        else if (in.op >= LB && in.op <= LD && in.a == 0) est_add(H_LOAD_X0, 1, limits.load_x0);
+        else est_add(limits.op_chip[in.op] & 63, 1, limits.op_cost[in.op]);
+        const uint64_t n = est_new_local; est_new_local = 0;
+        est_add(H_LOCAL, n, limits.memory_local);
+        est_add(H_GLOBAL, 2 * n + (sent ? 1 : 0), limits.global);
+        if (clk_high_moves) { est_add(H_MEMORY_BUMP, 32, limits.memory_bump); est_add(H_STATE_BUMP, 1, limits.state_bump); }
+        if (sent) est_add(H_SYSCALL_CORE, 1, limits.syscall_core);
+    }
+    bool shard_limit_reached() const {
+        return limits.on && !commit_syscall && !commit_deferred_syscall &&
+               (est_area + (1ull << 18) >= limits.element_threshold || est_max_height + (1ull << 10) >= limits.height_threshold);
     }
     bool resume_enter = false;
     bool record = true;                                               // sp1hip_rv64_set_recording: instruction events are kept
@@ -724,7 +765,8 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     if (vm.record) vm.events.reserve((size_t)std::min<uint64_t>(max_cycles, 1ull << 24) * EV);   // one allocation (at most 2.7 GB), not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
-    while (!vm.halted && (vm.unc || vm.cycles - c0 < max_cycles))
+    vm.estimate_reset();
+    while (!vm.halted && (vm.unc || (vm.cycles - c0 < max_cycles && !vm.shard_limit_reached())))
         if (!vm.step()) { sp1hip::set_error("sp1hip_rv64_run_shard: %s", vm.error.c_str()); return SP1HIP_ERROR_RUNTIME; }
     vm.finish_shard();
     info->n_cycles = vm.cycles - c0; info->n_events = vm.events.size() / EV; info->n_local = vm.local.size() / 5; info->n_keccak = vm.precompile.size() / SP1HIP_RV64_KECCAK_WORDS;
@@ -732,11 +774,26 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     info->n_sha_extend = vm.sha_extend.size() / SP1HIP_RV64_SHA_EXTEND_WORDS; info->n_sha_compress = vm.sha_compress.size() / SP1HIP_RV64_SHA_COMPRESS_WORDS;
     info->n_uint256 = vm.uint256.size() / SP1HIP_RV64_UINT256_WORDS;
     info->n_secp256k1_add = vm.secp_add.size() / SP1HIP_RV64_SECP_ADD_WORDS; info->n_secp256k1_double = vm.secp_double.size() / SP1HIP_RV64_SECP_DOUBLE_WORDS;
+    info->estimated_area = vm.limits.on ? vm.est_area : 0; info->estimated_max_height = vm.limits.on ? vm.est_max_height : 0;
     info->next_pc = vm.pc; info->clk_end = vm.clk; info->halted = vm.halted; info->exit_code = vm.exit_code;
     info->shard = vm.shard++;
     info->commit_syscall = vm.commit_syscall; info->commit_deferred_syscall = vm.commit_deferred_syscall;
     memcpy(info->committed_value_digest, vm.committed_digest, sizeof vm.committed_digest);
     memcpy(info->deferred_proofs_digest, vm.deferred_digest, sizeof vm.deferred_digest);
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_rv64_set_shard_limits(sp1hip_rv64_vm_t h, const sp1hip_rv64_shard_limits_t* l) {
+    if (!h) { sp1hip::set_error("sp1hip_rv64_set_shard_limits: null handle"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
+    Vm& vm = *(Vm*)h;
+    vm.limits = Vm::Limits();
+    if (!l) return SP1HIP_SUCCESS;                                    // back to cycle counts only
+    if (l->element_threshold < (1ull << 18) || l->height_threshold < (1ull << 10)) { sp1hip::set_error("sp1hip_rv64_set_shard_limits: thresholds below the HALT allowance"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
+    vm.limits.on = true;
+    vm.limits.element_threshold = l->element_threshold; vm.limits.height_threshold = l->height_threshold; vm.limits.fixed_area = l->fixed_area;
+    for (int k = 0; k < 64; ++k) { vm.limits.op_cost[k] = l->opcode_cost[k]; vm.limits.op_chip[k] = l->opcode_chip[k]; }
+    vm.limits.alu_x0 = l->alu_x0_cost; vm.limits.load_x0 = l->load_x0_cost; vm.limits.memory_local = l->memory_local_cost; vm.limits.global = l->global_cost;
+    vm.limits.syscall_core = l->syscall_core_cost; vm.limits.memory_bump = l->memory_bump_cost; vm.limits.state_bump = l->state_bump_cost;
     return SP1HIP_SUCCESS;
 }
 

@@ -54,6 +54,7 @@ class ExecutedShard:
         self.commit_syscall, self.commit_deferred_syscall = int(info.commit_syscall), int(info.commit_deferred_syscall)
         self.committed_value_digest = [int(x) for x in info.committed_value_digest]
         self.deferred_proofs_digest = [int(x) for x in info.deferred_proofs_digest]
+        self.estimated_area, self.estimated_max_height = int(info.estimated_area), int(info.estimated_max_height)
 
 
 class Executor:
@@ -102,6 +103,33 @@ class Executor:
                               self._matrix(self.lib.sp1hip_rv64_secp256k1_double_events(self.h), info.n_secp256k1_double, SECP_DOUBLE_WORDS))
         self.halted = shard.halted
         return shard
+
+    def cut_by_area(self, element_threshold=None, height_threshold=None):
+        """Shards end where the reference's executor would end them (`ShapeChecker`, vm/shapes.rs; thresholds opts.rs:L12-L14):
+        when the estimated trace area or a table's height reaches its threshold. The cost model — columns per chip — is this
+        package's chips' (pinned to rv64im_costs.json); the estimator itself runs inside the executor, instruction by instruction."""
+        cost = lambda name: (lambda a: a.main_width + a.prep_width)(R.chip(name)[0])
+        lim = _lib.Rv64ShardLimits()
+        lim.element_threshold = ELEMENT_THRESHOLD if element_threshold is None else element_threshold
+        lim.height_threshold = HEIGHT_THRESHOLD if height_threshold is None else height_threshold
+        rows = self.program()[1].shape[0]
+        lim.fixed_area = -(-rows // 32) * 32 * cost("Program") + (1 << 16) * cost("Byte") + (1 << 17) * cost("Range")
+        chips = {}
+        for name, o in OPC.items():
+            if o <= OPC["REMUW"]:
+                chip = _ALU_CHIP[o]
+            elif name in _MEM_CHIP:
+                chip = _MEM_CHIP[name]
+            elif name in RT.BRANCH_OPS:
+                chip = "Branch"
+            else:
+                chip = {"JAL": "Jal", "JALR": "Jalr", "AUIPC": "UType", "LUI": "UType", "ECALL": "SyscallInstrs"}.get(name)
+            if chip is not None:
+                lim.opcode_cost[o], lim.opcode_chip[o] = cost(chip), chips.setdefault(chip, len(chips))
+        lim.alu_x0_cost, lim.load_x0_cost, lim.memory_local_cost, lim.global_cost = cost("AluX0"), cost("LoadX0"), cost("MemoryLocal"), cost("Global")
+        lim.syscall_core_cost, lim.memory_bump_cost, lim.state_bump_cost = cost("SyscallCore"), cost("MemoryBump"), cost("StateBump")
+        _lib.check(self.lib.sp1hip_rv64_set_shard_limits(self.h, C.byref(lim)))
+        return self
 
     def shards(self, max_cycles):
         while not self.halted:
@@ -452,10 +480,10 @@ def program_shards(executor, max_cycles, device="cpu"):
     previous = 0
     for at in range(0, gm.shape[0], limit["memory"]):       # `split` (record.rs): init and finalise events chunked alike, zipped
         part = gm[at:at + limit["memory"]]
-        addrs = [int(a) for a in part[:, 0].astype(np.uint64)]
-        machine, tables, publics, gev = MT.memory_shard_from(addrs, [(int(v), 0) for v in part[:, 1]], [(int(v), int(t)) for v, t in part[:, 2:4]],
+        addrs = part[:, 0].astype(np.uint64)
+        machine, tables, publics, gev = MT.memory_shard_from(addrs, np.stack([part[:, 1], np.zeros_like(part[:, 1])], axis=1), part[:, 2:4],
                                                              device, previous_addr=previous)
-        previous = addrs[-1]
+        previous = int(addrs[-1])
         yield "memory", machine, tables, publics, gev, None
 
 
@@ -463,6 +491,20 @@ def global_events_balance(event_lists):
     """The cross-shard statement: over all shards, every Global message is sent exactly as often as it is received
     (events [n, 11] = message[8], is_send, is_receive, kind). Returns the messages that do not cancel."""
     ev = torch.cat([e.cpu() for e in event_lists]).numpy()
+    if ev.shape[0] > (1 << 18):
+        # a large run (millions of messages): first two independent 64-bit multiset fingerprints — sum of (send - receive) *
+        # mix(message, kind) with wrap-around —, which are both zero when everything cancels; the exact tally below only otherwise
+        u = ev.astype(np.uint64)
+        sign = (ev[:, 8] - ev[:, 9]).astype(np.uint64)
+        clean = True
+        for seed in (0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F):
+            h = np.full(ev.shape[0], seed, dtype=np.uint64)
+            for col in list(range(8)) + [10]:
+                h = (h ^ u[:, col]) * np.uint64(0x100000001B3 | (seed & 0xFFFF0000))
+                h ^= h >> np.uint64(29)
+            clean &= int((h * sign).sum(dtype=np.uint64)) == 0
+        if clean:
+            return []
     tally = {}
     for row in ev:
         key = tuple(int(x) for x in row[:8]) + (int(row[10]),)

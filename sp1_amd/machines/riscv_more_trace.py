@@ -59,6 +59,21 @@ def _limbs(v):
     return [(v >> (16 * i)) & MASK16 for i in range(4)]
 
 
+def _limbs_np(v):
+    return np.stack([(v >> np.uint64(16 * i)) & np.uint64(MASK16) for i in range(4)], axis=1).astype(np.int64)
+
+
+def _inv_np(v):
+    """Inverses mod P of an int64 array (0 -> 0): v^(P - 2) by square and multiply, products below 2^62."""
+    base, out, e = np.asarray(v, dtype=np.int64) % P, np.ones(np.shape(v), dtype=np.int64), P - 2
+    while e:
+        if e & 1:
+            out = out * base % P
+        base = base * base % P
+        e >>= 1
+    return np.where(np.asarray(v) % P == 0, 0, out)
+
+
 def _rotl(v, n):
     """64-bit rotate left of int64 tensors (two's complement bit patterns)."""
     if n == 0:
@@ -325,38 +340,41 @@ def memory_shard_from(addrs, init, fin, device="cpu", previous_addr=0):
     tr = RT.Tracer.__new__(RT.Tracer)
     tr.dev, tr.tables = dev, {}
     n_words = len(addrs)
-    inv = lambda v: pow(int(v) % P, P - 2, P) if int(v) % P else 0
+    addr_np = np.asarray(addrs, dtype=np.uint64)
     machine, ev = {}, []
     for name, kind, recs in (("MemoryGlobalInit", M.MEMORY_GLOBAL_INIT_CONTROL, init), ("MemoryGlobalFinalize", M.MEMORY_GLOBAL_FINALIZE_CONTROL, fin)):
         air, it = R.chip(name)
         L = air.layout
         tb = RT.Table(air, n_words, dev)
         rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
-        prev = previous_addr
-        for i, a in enumerate(int(x) for x in addrs):
-            v, t = (int(x) & ((1 << 64) - 1) for x in recs[i])
-            r = i
-            rows[r, L["clk_high"]], rows[r, L["clk_low"]] = t >> 24, t & 0xFFFFFF
-            rows[r, L["index"]] = i
-            rows[r, L["prev_addr"]:L["prev_addr"] + 3] = _limbs(prev)[:3]
-            rows[r, L["addr"]:L["addr"] + 3] = _limbs(a)[:3]
-            vl = _limbs(v)
-            rows[r, L["value"]:L["value"] + 4] = vl
-            rows[r, L["value_lower"]], rows[r, L["value_upper"]] = vl[2] & 0xFF, vl[2] >> 8
-            rows[r, L["is_real"]] = 1
-            rows[r, L["prev_valid"]] = 0 if (prev == 0 and i != 0) else 1
-            s = sum(_limbs(prev)[:3])
-            rows[r, L["is_prev_addr_zero.inverse"]], rows[r, L["is_prev_addr_zero.result"]] = inv(s), int(s == 0)
-            rows[r, L["is_index_zero.inverse"]], rows[r, L["is_index_zero.result"]] = inv(i), int(i == 0)
-            if prev != 0 or i != 0:
-                rows[r, L["is_comp"]] = 1
-                xl, yl = _limbs(prev), _limbs(a)
-                j = [q for q in (3, 2, 1, 0) if xl[q] != yl[q]][0]
-                rows[r, L["lt_cols.u16_flags"] + j] = 1
-                rows[r, L["lt_cols.comparison_limbs"]], rows[r, L["lt_cols.comparison_limbs"] + 1] = xl[j], yl[j]
-                rows[r, L["lt_cols.not_eq_inv"]] = inv(xl[j] - yl[j])
-                rows[r, L["lt_cols.bit"]] = int(xl[j] < yl[j])
-            prev = a
+        n = n_words                                                     # all rows at once: a large program touches millions of words
+        rec = recs.astype(np.uint64) if isinstance(recs, np.ndarray) else np.array([[int(x) & ((1 << 64) - 1) for x in r] for r in recs], dtype=np.uint64)
+        v, t = rec[:, 0], rec[:, 1].astype(np.int64)
+        prev = np.concatenate([np.array([previous_addr], dtype=np.uint64), addr_np[:-1]])
+        idx = np.arange(n, dtype=np.int64)
+        xl, yl, vl = _limbs_np(prev), _limbs_np(addr_np), _limbs_np(v)
+        rows[:n, L["clk_high"]], rows[:n, L["clk_low"]] = t >> 24, t & 0xFFFFFF
+        rows[:n, L["index"]] = idx
+        rows[:n, L["prev_addr"]:L["prev_addr"] + 3] = xl[:, :3]
+        rows[:n, L["addr"]:L["addr"] + 3] = yl[:, :3]
+        rows[:n, L["value"]:L["value"] + 4] = vl
+        rows[:n, L["value_lower"]], rows[:n, L["value_upper"]] = vl[:, 2] & 0xFF, vl[:, 2] >> 8
+        rows[:n, L["is_real"]] = 1
+        rows[:n, L["prev_valid"]] = 1 - ((prev == 0) & (idx != 0))
+        s_ = xl[:, :3].sum(axis=1)
+        rows[:n, L["is_prev_addr_zero.inverse"]], rows[:n, L["is_prev_addr_zero.result"]] = _inv_np(s_), s_ == 0
+        rows[:n, L["is_index_zero.inverse"]], rows[:n, L["is_index_zero.result"]] = _inv_np(idx), idx == 0
+        comp = (prev != 0) | (idx != 0)
+        assert bool((addr_np[comp] > prev[comp]).all()), "addresses must increase strictly"
+        j = 3 - np.argmax((xl != yl)[:, ::-1], axis=1)                   # the most significant limb that differs
+        xj, yj = xl[idx, j], yl[idx, j]
+        rows[:n, L["is_comp"]] = comp
+        flags = np.zeros((n, 4), dtype=np.int64)
+        flags[idx, j] = comp
+        rows[:n, L["lt_cols.u16_flags"]:L["lt_cols.u16_flags"] + 4] = flags
+        rows[:n, L["lt_cols.comparison_limbs"]], rows[:n, L["lt_cols.comparison_limbs"] + 1] = xj * comp, yj * comp
+        rows[:n, L["lt_cols.not_eq_inv"]] = _inv_np((xj - yj) % P) * comp
+        rows[:n, L["lt_cols.bit"]] = (xj < yj) & comp
         tb.main[:] = torch.as_tensor(rows % P, device=dev)
         tr.tables[name], machine[name] = tb, (air, it)
         ev += [v_ for _, v_, _ in RT.eval_interactions(it, tb.main[:tb.n], None, kinds=(R.GLOBAL,))]

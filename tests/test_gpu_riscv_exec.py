@@ -80,6 +80,28 @@ def test_every_shard_of_a_real_program_matches_the_oracle(api, program, stdin, m
     assert not X.global_events_balance(gevs)
 
 
+def test_the_big_integer_precompile_shards_match_the_oracle(api):
+    """UINT256_MUL, SECP256K1_DOUBLE and SECP256K1_ADD from a hand-assembled program (2G, then G + 2G, then a 256-bit modular
+    product): the FieldOpCols chips — 23k-instruction constraint programs, 1.1k byte / range lookups per row — through the GPU prover."""
+    import rv_asm as A
+    M64 = (1 << 64) - 1
+    G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+    words = lambda v: b"".join(struct.pack("<Q", (v >> (64 * i)) & M64) for i in range(4))
+    data = words(G[0]) + words(G[1]) + words(G[0]) + words(G[1]) + words(0x1234567890ABCDEF << 130 | 77) + words((1 << 255) + 12345) + words((1 << 256) - 189)
+    prog = A.li(28, 0x78100000)
+    prog += [A.enc("addi", 10, 28, 0), A.enc("addi", 11, 0, 0)] + A.li(5, 0x0000010B) + [A.enc("ecall")]
+    prog += [A.enc("addi", 10, 28, 64), A.enc("addi", 11, 28, 0)] + A.li(5, 0x0001010A) + [A.enc("ecall")]
+    prog += [A.enc("addi", 10, 28, 128), A.enc("addi", 11, 28, 160)] + A.li(5, 0x0001011D) + [A.enc("ecall")]
+    ex = X.Executor(A.elf(prog + A.halt(0), data=data + bytes(32)), stdin=[])
+    seen, gevs = [], []
+    for kind, machine, tabs, publics, gev, sh in X.program_shards(ex, 1 << 20, device="cuda"):
+        prove_both(api, machine, tabs, publics, 17, 12, 8, 1, 5, 4)
+        seen.append(kind)
+        gevs.append(gev)
+    assert seen == ["core", "uint256", "secp256k1_add", "secp256k1_double", "memory"]
+    assert not X.global_events_balance(gevs)
+
+
 @pytest.mark.parametrize("mul_min_rows", ["0", None])
 def test_a_fibonacci_shard_with_production_parameters_matches_the_oracle(api, mul_min_rows, monkeypatch):
     """2^18 cycles of the reference's fibonacci guest (1.3e7 trace cells), blowup 4, 124 queries, 16-bit PoW — with the fused

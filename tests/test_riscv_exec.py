@@ -251,6 +251,51 @@ def test_precompile_and_memory_events_split_into_shards_at_the_thresholds(monkey
     assert kinds.count("keccak") >= 2 and kinds.count("memory") >= 2 and last.exit_code == 0
 
 
+def test_global_message_balance_of_a_large_run_uses_fingerprints_and_still_names_what_is_missing():
+    rng = np.random.default_rng(5)
+    n = 300_000
+    msg = rng.integers(0, 1 << 30, size=(n, 8))
+    kind = rng.integers(1, 12, size=(n, 1))
+    one, zero = np.ones((n, 1), dtype=np.int64), np.zeros((n, 1), dtype=np.int64)
+    sends = torch.as_tensor(np.concatenate([msg, one, zero, kind], axis=1))
+    recvs = torch.as_tensor(np.concatenate([msg, zero, one, kind], axis=1)[rng.permutation(n)])
+    assert X.global_events_balance([sends, recvs]) == []
+    recvs[12345, 3] += 1
+    assert len(X.global_events_balance([sends, recvs])) == 2           # the message that was never received, the one never sent
+
+
+def test_core_shards_are_cut_by_the_trace_area_estimator():
+    """`cut_by_area`: the executor ends a shard where the reference's ShapeChecker would — when the estimated trace area reaches the
+    element threshold less the HALT allowance. With the threshold set 2e6 cells above the fixed tables the fibonacci guest's run
+    is cut into several shards whose REAL tables (what the tracer builds, padded to 32 rows) stay below the threshold and within a
+    few per cent of the estimate; every shard still checks and the Global messages cancel. No cut between COMMIT and HALT."""
+    from sp1_amd.machines import riscv as R
+    cost = lambda name: (lambda a: a.main_width + a.prep_width)(R.chip(name)[0])
+    ex = X.Executor(_elf("fibonacci"), stdin=[struct.pack("<Q", 10000)])
+    rows = ex.program()[1].shape[0]
+    fixed = -(-rows // 32) * 32 * cost("Program") + (1 << 16) * cost("Byte") + (1 << 17) * cost("Range")
+    threshold = fixed + 2_000_000
+    ex.cut_by_area(element_threshold=threshold)
+    kinds, gevs, sizes = [], [], []
+    for kind, machine, tabs, publics, gev, sh in X.program_shards(ex, 1 << 40):
+        assert check_shard(machine, tabs, publics) == ([], 0)
+        kinds.append(kind)
+        gevs.append(gev)
+        if kind == "core":
+            real = sum(int(tabs[a.name][1].shape[0]) * (a.main_width + a.prep_width) for a, _ in machine)
+            sizes.append((sh.cycles, sh.estimated_area, real, sh.halted))
+    assert not X.global_events_balance(gevs)
+    assert kinds.count("core") >= 3
+    for cycles, est, real, halted in sizes:
+        assert real <= threshold and abs(est - real) < 0.25 * (threshold - fixed) + (1 << 19)
+        if not halted:
+            assert threshold - (1 << 18) <= est < threshold - (1 << 18) + (1 << 18)        # stopped at the first instruction past the limit
+    assert sizes[-1][3]
+    # cycle counts alone again
+    from sp1_amd import _lib
+    _lib.check(ex.lib.sp1hip_rv64_set_shard_limits(ex.h, None))
+
+
 def test_an_unknown_hook_is_an_executor_error():
     from sp1_amd import _lib
     prog = A.li(10, 15) + A.li(11, 0x78100000) + A.li(12, 8) + A.li(5, 2) + [A.enc("ecall")]       # WRITE(fd 15 = ecrecover hook, buf, 8)

@@ -138,6 +138,18 @@ def test_compiled_forms_of_the_round_5_chips_evaluate_like_the_ssa(lib):
         _check(lib, riscv.chip(name)[0], 400 + k, 160)
 
 
+def test_compiled_forms_of_the_precompile_chips_evaluate_like_the_ssa(lib):
+    """The precompile chips of the real-program shards: the curve chips are the longest programs the interpreter runs (23k
+    instructions; chunked into ~145 pieces of <= 119 registers so that a wave's register file fits in LDS)."""
+    for k, name in enumerate(("Secp256k1AddAssign", "Secp256k1DoubleAssign", "Uint256MulMod", "ShaCompress", "ShaExtend", "Poseidon2")):
+        air = riscv.chip(name)[0]
+        _check(lib, air, 500 + k, 8)
+        rng = np.random.default_rng(k)
+        row = rng.integers(0, P, size=air.main_width, dtype=np.uint64)
+        _, stats = _plan_eval(lib, air, row, np.zeros(1, dtype=np.uint64), np.zeros(8, dtype=np.uint64), 1)
+        assert stats[2] * 16 * 64 <= 160 * 1024, (name, stats)          # one wave's extension registers fit the CU's LDS
+
+
 def test_planner_rejects_overlapping_hints(lib):
     """each hint is checked against the SSA on its own; two hints over the same constraints / columns (a duplicated
     HINT) would each pass and then be counted twice. The planner must refuse the program."""
