@@ -2,7 +2,7 @@
 `SplitOpts` thresholds), every memory shard of one execution — what the reference's perf harness times as "core proving" and
 divides the cycle count by (/root/reference/sp1-gpu/crates/perf/src/report.rs:L52-L60).
 
-    python bench/prove_program.py --program rsp            # the Reth block of the reference's perf inputs: 9.8e7 cycles, 23 shards
+    python bench/prove_program.py --program rsp            # the Reth block of the reference's perf inputs: 9.8e7 cycles, 26 shards
     python bench/prove_program.py --program fibonacci --cycles 30000000
 
 Per shard: the executor runs until the reference's shard-cutting rule ends the shard (trace-area estimator, host, C++), the tracer builds the tables ON THE DEVICE
@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--shard-cycles", type=int, default=0, help="cut core shards at this many cycles instead of by trace area (the default: the "
                     "reference's rule, ShapeChecker with ELEMENT_THRESHOLD 2^28 + 2^27 / HEIGHT_THRESHOLD 2^22, inside the executor)")
     ap.add_argument("--max-shards", type=int, default=0, help="stop after this many shards (0 = the whole run)")
+    ap.add_argument("--core-shards", type=int, default=0, help="trace and prove only the first N core shards (the others are executed, not "
+                    "proved), then every precompile and memory shard: a bounded sample of every shard kind of the run")
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--out", default="")
@@ -44,8 +46,11 @@ def main():
     device = "cpu" if args.dry_run else "cuda"
     if not args.dry_run:
         from core_real import to_col_major
+        import ctypes as C
         from sp1_amd import api
         torch.cuda.set_device(0)
+        lib = api._L()
+        api.check(lib.sp1hip_timers_enable(1))
     shard_cycles = args.shard_cycles or 1 << 40
     L, lsh = 22, 21
     ex = X.Executor(X.guest_file(args.program + ".elf"), stdin=stdin_of(args.program, args.cycles or 3 * FULL_CYCLES_OF[args.program]))
@@ -54,7 +59,7 @@ def main():
     shards, gevs, kept, cycles, last = [], [], {}, 0, None
     t_all = time.perf_counter()
     t_prev = t_all
-    gen = X.program_shards(ex, shard_cycles, device=device)
+    gen = X.program_shards(ex, shard_cycles, device=device, core_limit=args.core_shards or None)
     while True:
         try:
             kind, machine, tabs, publics, gev, sh = next(gen)
@@ -80,10 +85,16 @@ def main():
             row["setup_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
             ch = api.DuplexChallenger()
             ch.observe(commit)
+            api.check(lib.sp1hip_timers_reset())
             t0 = time.perf_counter()
             proof = api.prove_shard(chips, pv, prep, L, lsh, 32, ch)
             torch.cuda.synchronize()
             row["prove_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+            row["stage_ms"] = {}
+            for name in ("stage_commit", "stage_logup_gkr", "stage_zerocheck", "stage_evaluation_proof"):   # the library's own stage clocks
+                n_, ms_ = C.c_uint64(), C.c_double()
+                api.check(lib.sp1hip_timers_read(name.encode(), C.byref(n_), C.byref(ms_)))
+                row["stage_ms"][name[6:]] = round(ms_.value, 2)
             row["proof_bytes"] = len(proof)
             if args.verify and kind not in kept:
                 kept[kind] = (machine, np.asarray(commit).copy(), proof, ch.state().copy())
@@ -94,12 +105,16 @@ def main():
             break
         t_prev = time.perf_counter()
     wall = time.perf_counter() - t_all
-    whole = not args.max_shards or len(shards) < args.max_shards
+    whole = (not args.max_shards or len(shards) < args.max_shards) and not args.core_shards
+    if args.core_shards:                                     # the cycles of the core shards that were executed but not proved
+        out_note = "core shards beyond the first %d executed, not proved" % args.core_shards
     out = {"program": args.program, "cycles": cycles, "shards": len(shards), "whole_run": bool(whole and last is not None and last.halted),
            "exit_code": last.exit_code if last is not None and last.halted else None,
            "kinds": {k: sum(1 for s in shards if s["kind"] == k) for k in dict.fromkeys(s["kind"] for s in shards)},
            "cells": sum(s["cells"] for s in shards), "build_seconds": round(sum(s["build_s"] for s in shards), 2), "wall_seconds": round(wall, 2),
            "core_shards_cut": "by trace area (reference's ShapeChecker)" if not args.shard_cycles else "every %d cycles" % shard_cycles, "parameters": "max_log_row_count 22, stack 2^21, blowup 4, 124 queries, 16-bit PoW"}
+    if args.core_shards:
+        out["note"] = out_note
     if whole:
         out["global_messages_cancel"] = not X.global_events_balance(gevs)
     if not args.dry_run:
@@ -107,7 +122,9 @@ def main():
         out.update({"prove_seconds": round(prove_s, 4), "setup_seconds": round(sum(s["setup_ms"] for s in shards) / 1e3, 4),
                     "cycles_per_s": round(cycles / prove_s), "cells_per_s": round(out["cells"] / prove_s),
                     "cycles_per_s_incl_python_tracegen_and_executor": round(cycles / wall),
-                    "prove_ms_by_kind": {k: round(sum(s["prove_ms"] for s in shards if s["kind"] == k) / out["kinds"][k], 2) for k in out["kinds"]}})
+                    "prove_ms_by_kind": {k: round(sum(s["prove_ms"] for s in shards if s["kind"] == k) / out["kinds"][k], 2) for k in out["kinds"]},
+                    "stage_ms_by_kind": {k: {st: round(sum(s["stage_ms"][st] for s in shards if s["kind"] == k) / out["kinds"][k], 2)
+                                             for st in ("commit", "logup_gkr", "zerocheck", "evaluation_proof")} for k in out["kinds"]}})
         if args.verify:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as orc                                       # the checker (test infrastructure), after everything timed

@@ -427,18 +427,24 @@ def split_thresholds(program_rows):
     return out
 
 
-def program_shards(executor, max_cycles, device="cpu"):
+def program_shards(executor, max_cycles, device="cpu", core_limit=None):
     """Every shard of a run, in the order the reference's controller emits them: the core shards as the program executes
     (`(kind, machine, tables, publics, global events, ExecutedShard)` with kind = "core"), then one precompile shard for the
     KECCAK_PERMUTE, POSEIDON2, SHA_EXTEND and SHA_COMPRESS calls each if there were any ("keccak", "poseidon2", "sha_extend",
     "sha_compress"), then the memory shard: MemoryGlobalInit / MemoryGlobalFinalize over
     every address the run touched ("memory"). The global events of all shards cancel as a multiset: that is the statement the
-    shards' septic-curve digests add up to."""
+    shards' septic-curve digests add up to. `core_limit`: only the first so many core shards are traced and yielded (the rest of
+    the program still runs, so every precompile and memory shard is there)."""
     from . import riscv_more_trace as MT
     keccak, poseidon2, sha_extend, sha_compress, uint256, secp_add, secp_double = [], [], [], [], [], [], []
-    for shard in executor.shards(max_cycles):
-        tr = EventTracer(executor, shard, device)
-        machine, tables, publics = tr.build()
+    n_core = 0
+    while not executor.halted:
+        keep = core_limit is None or n_core < core_limit     # beyond the limit: executed (their precompile calls count), not traced
+        shard = executor.run_shard(max_cycles, record=keep)
+        n_core += 1
+        if keep:
+            tr = EventTracer(executor, shard, device)
+            machine, tables, publics = tr.build()
         if shard.keccak.shape[0]:
             keccak.append(shard.keccak)
         if shard.poseidon2.shape[0]:
@@ -453,7 +459,9 @@ def program_shards(executor, max_cycles, device="cpu"):
             secp_add.append(shard.secp256k1_add)
         if shard.secp256k1_double.shape[0]:
             secp_double.append(shard.secp256k1_double)
-        yield "core", machine, tables, publics, tr.global_events, shard
+        if keep:
+            yield "core", machine, tables, publics, tr.global_events, shard
+            del tr, machine, tables
     limit = split_thresholds(executor.program()[1].shape[0])
     chunks = lambda kind, evs: (lambda a: [a[i:i + limit[kind]] for i in range(0, a.shape[0], limit[kind])])(np.concatenate(evs)) if evs else []
     for kk in chunks("keccak", keccak):
