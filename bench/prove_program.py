@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--max-shards", type=int, default=0, help="stop after this many shards (0 = the whole run)")
     ap.add_argument("--core-shards", type=int, default=0, help="trace and prove only the first N core shards (the others are executed, not "
                     "proved), then every precompile and memory shard: a bounded sample of every shard kind of the run")
+    ap.add_argument("--in-flight", type=int, default=0, help="after the shard-by-shard pass, prove ALL shards again through the library's "
+                    "prover pool with this many proofs in flight (tables resident in HBM; proofs must equal the first pass's)")
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--out", default="")
@@ -56,7 +58,7 @@ def main():
     ex = X.Executor(X.guest_file(args.program + ".elf"), stdin=stdin_of(args.program, args.cycles or 3 * FULL_CYCLES_OF[args.program]))
     if not args.shard_cycles:
         ex.cut_by_area()
-    shards, gevs, kept, cycles, last = [], [], {}, 0, None
+    shards, gevs, kept, cycles, last, resident = [], [], {}, 0, None, []
     t_all = time.perf_counter()
     t_prev = t_all
     gen = X.program_shards(ex, shard_cycles, device=device, core_limit=args.core_shards or None)
@@ -80,14 +82,13 @@ def main():
             tabs.clear()
             pv = RT.to_monty_np(publics)
             t0 = time.perf_counter()
-            commit, prep = api.JaggedProver(L, lsh, 32, 2).commit_multilinears([c[3] for c in chips if c[3] is not None])
+            pk = api.ProvingKey([c[3] for c in chips if c[3] is not None], L, lsh, 32)     # sp1hip_setup: the preprocessed commitment + vk
+            commit = pk.preprocessed_commit
             torch.cuda.synchronize()
             row["setup_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
-            ch = api.DuplexChallenger()
-            ch.observe(commit)
             api.check(lib.sp1hip_timers_reset())
             t0 = time.perf_counter()
-            proof = api.prove_shard(chips, pv, prep, L, lsh, 32, ch)
+            proof = pk.prove_shard(chips, pv)                                             # from the transcript head vk.observe_into leaves
             torch.cuda.synchronize()
             row["prove_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
             row["stage_ms"] = {}
@@ -97,8 +98,12 @@ def main():
                 row["stage_ms"][name[6:]] = round(ms_.value, 2)
             row["proof_bytes"] = len(proof)
             if args.verify and kind not in kept:
-                kept[kind] = (machine, np.asarray(commit).copy(), proof, ch.state().copy())
-            del chips, prep
+                kept[kind] = (machine, np.asarray(commit).copy(), proof)
+            if args.in_flight:
+                resident.append((pk, chips, pv, proof))
+                torch.cuda.empty_cache()                                                  # the tracer's int64 intermediates go back to the driver
+            else:
+                del chips, pk
         shards.append(row)
         print(json.dumps(row), file=sys.stderr, flush=True)
         if args.max_shards and len(shards) >= args.max_shards:
@@ -125,17 +130,59 @@ def main():
                     "prove_ms_by_kind": {k: round(sum(s["prove_ms"] for s in shards if s["kind"] == k) / out["kinds"][k], 2) for k in out["kinds"]},
                     "stage_ms_by_kind": {k: {st: round(sum(s["stage_ms"][st] for s in shards if s["kind"] == k) / out["kinds"][k], 2)
                                              for st in ("commit", "logup_gkr", "zerocheck", "evaluation_proof")} for k in out["kinds"]}})
+        if args.in_flight and args.out:                      # what has been measured so far, should the pooled pass fail
+            with open(args.out, "w") as f:
+                f.write(json.dumps(dict(out, per_shard=shards)) + "\n")
+        if args.in_flight:
+            # every shard of the run again, through the prover pool: N slots (a thread and a stream each), tables resident in HBM.
+            # The direct pass's arena goes back to the driver first; should N slots' arenas not fit beside the resident tables
+            # the pass is repeated with one slot fewer
+            gib = lambda: [round(x / 2**30, 1) for x in torch.cuda.mem_get_info()]
+            out["hbm_free_total_gib"] = {"after_direct_pass": gib()}
+            released = C.c_size_t()
+            api.check(lib.sp1hip_mem_trim(C.byref(released)))
+            torch.cuda.empty_cache()
+            out["hbm_free_total_gib"]["after_trim"] = gib()
+            slots = args.in_flight
+            while slots >= 1:
+                pool = api.ProverPool(slots)
+                try:
+                    for t in [pool.submit(pk, chips, pv) for pk, chips, pv, _ in resident[:slots]]:   # fill every slot's arena (untimed)
+                        pool.wait(t)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    res, tickets = [], []
+                    for pk, chips, pv, _ in resident:            # at most 2 N tickets outstanding: results are collected as they come
+                        tickets.append(pool.submit(pk, chips, pv))
+                        if len(tickets) - len(res) >= 2 * slots:
+                            res.append(pool.wait(tickets[len(res)]))
+                    while len(res) < len(tickets):
+                        res.append(pool.wait(tickets[len(res)]))
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                except Exception as e:                           # out of memory: fewer slots
+                    out.setdefault("in_flight_failures", []).append({"slots": slots, "error": str(e)[-200:], "hbm_free_total_gib": gib()})
+                    pool.close()
+                    api.check(lib.sp1hip_mem_trim(C.byref(released)))
+                    slots -= 1
+                    continue
+                pool.close()
+                same = all(r[0] == want for r, (_, _, _, want) in zip(res, resident))
+                out["in_flight"] = {"slots": slots, "prove_seconds": round(dt, 4), "cycles_per_s": round(cycles / dt), "cells_per_s": round(out["cells"] / dt),
+                                    "proofs_equal_the_direct_pass": bool(same), "proving_ms_each": [round(r[1]["proving_ms"], 1) for r in res],
+                                    "hbm_free_total_gib": gib()}
+                break
         if args.verify:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as orc                                       # the checker (test infrastructure), after everything timed
             ver = {}
-            for kind, (machine, commit, proof, state) in kept.items():
+            for kind, (machine, commit, proof) in kept.items():
                 shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None) for a, i in machine]
                 v_ch = orc.Challenger()
-                v_ch.observe(commit)
+                v_ch.observe(np.concatenate([commit, np.zeros(3 + 14 + 7, np.uint32)]))   # vk.observe_into: commit, pc_start, septic x / y, flag, 6 zeros
                 t0 = time.perf_counter()
                 rc = orc.shard_verify(shapes, commit, proof, L, lsh, v_ch, 2, 124, 16)
-                ver[kind] = {"rc": int(rc), "state_matches": bool(np.array_equal(v_ch.state(), state)), "seconds": round(time.perf_counter() - t0, 2)}
+                ver[kind] = {"rc": int(rc), "seconds": round(time.perf_counter() - t0, 2)}
             out["verified_first_of_kind"] = ver
     out["per_shard"] = shards
     line = json.dumps(out)

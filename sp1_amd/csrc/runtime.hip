@@ -13,6 +13,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "device_ctx.hpp"
@@ -291,6 +292,10 @@ struct ArenaKey {
 static std::mutex g_arena_mutex;
 static std::map<ArenaKey, std::vector<void*>> g_arena;
 static std::map<int, size_t> g_arena_cached_bytes;       // free-listed bytes per device (the cap is per device too)
+// the size class a block was ALLOCATED with (>= 1 MiB blocks): a request may be served by a cached block of a slightly larger
+// class (arena_alloc), and the block must return to its own list, not to the list of the request it last served
+static std::unordered_map<void*, size_t> g_arena_block_class;
+constexpr size_t ARENA_NEAR_FIT_MIN = (size_t)1 << 20;
 
 // Size classes in steps of 1/8 of a power of two (<= 12.5 % internal slack): real shards have varying table heights,
 // and exact-size keys would cache a new block for nearly every proof and never reuse it.
@@ -338,6 +343,18 @@ int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
             g_arena_cached_bytes[dev] -= sz;
             return SP1HIP_SUCCESS;
         }
+        // near fit: the smallest cached block of THIS stream in the next size classes (up to 1.5 x the request). The shards of
+        // a real program all differ in their table heights (round 5, the 26 shards of the rsp block: 107 GB of cached blocks
+        // after one pass on one stream, and with three provers in flight the device ran out of memory — a full trim, 1.6 s
+        // of stall — every ten proofs); a request that misses its own class by one or two steps takes the neighbour's block
+        if (sz >= ARENA_NEAR_FIT_MIN)
+            for (auto nf = g_arena.upper_bound(ArenaKey{dev, stream, sz}); nf != g_arena.end() && nf->first.device == dev && nf->first.stream == stream && nf->first.bytes <= sz + sz / 2; ++nf)
+                if (!nf->second.empty()) {
+                    *ptr = nf->second.back();
+                    nf->second.pop_back();
+                    g_arena_cached_bytes[dev] -= nf->first.bytes;
+                    return SP1HIP_SUCCESS;
+                }
     }
     hipError_t e = hipMalloc(ptr, sz);
     if (e == hipErrorOutOfMemory) {
@@ -381,6 +398,10 @@ int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
         e = hipMalloc(ptr, sz);
     }
     SP1HIP_HIP(e);
+    if (sz >= ARENA_NEAR_FIT_MIN) {
+        std::lock_guard<std::mutex> lock(g_arena_mutex);
+        g_arena_block_class[*ptr] = sz;
+    }
     return SP1HIP_SUCCESS;
 }
 
@@ -388,10 +409,14 @@ void arena_free(void* ptr, size_t bytes, hipStream_t stream) {
     if (!ptr) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
-    const size_t sz = arena_round(bytes);
+    size_t sz = arena_round(bytes);
     std::vector<void*> evict;
     {
         std::lock_guard<std::mutex> lock(g_arena_mutex);
+        if (sz >= ARENA_NEAR_FIT_MIN) {            // the class the block was allocated with (it may have served a smaller request)
+            auto bc = g_arena_block_class.find(ptr);
+            if (bc != g_arena_block_class.end()) sz = bc->second;
+        }
         g_arena[ArenaKey{dev, stream, sz}].push_back(ptr);
         g_arena_cached_bytes[dev] += sz;
         // over the cap: drop this device's largest cached blocks (never the one just returned: it may still be in use by
@@ -406,6 +431,7 @@ void arena_free(void* ptr, size_t bytes, hipStream_t stream) {
             void* victim = best->second.front() == ptr ? best->second.back() : best->second.front();
             best->second.erase(std::find(best->second.begin(), best->second.end(), victim));
             g_arena_cached_bytes[dev] -= best->first.bytes;
+            g_arena_block_class.erase(victim);
             evict.push_back(victim);
         }
     }
@@ -420,7 +446,7 @@ size_t arena_release_stream(hipStream_t stream) {
         std::lock_guard<std::mutex> lock(g_arena_mutex);
         for (auto it = g_arena.begin(); it != g_arena.end();) {
             if (it->first.stream == stream) {
-                for (void* p : it->second) { blocks.emplace_back(p, it->first.bytes); g_arena_cached_bytes[it->first.device] -= it->first.bytes; }
+                for (void* p : it->second) { blocks.emplace_back(p, it->first.bytes); g_arena_cached_bytes[it->first.device] -= it->first.bytes; g_arena_block_class.erase(p); }
                 it = g_arena.erase(it);
             } else {
                 ++it;
@@ -440,7 +466,7 @@ size_t arena_trim_device(int dev) {
         std::lock_guard<std::mutex> lock(g_arena_mutex);
         for (auto it = g_arena.begin(); it != g_arena.end();) {
             if (it->first.device == dev) {
-                for (void* p : it->second) { blocks.push_back(p); freed += it->first.bytes; }
+                for (void* p : it->second) { blocks.push_back(p); freed += it->first.bytes; g_arena_block_class.erase(p); }
                 it = g_arena.erase(it);
             } else ++it;
         }

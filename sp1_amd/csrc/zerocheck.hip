@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -1109,8 +1110,60 @@ static void fold_immediates(const uint32_t* ssa, uint32_t n, std::vector<uint32_
 // chips are local in the column layout (an operation's columns are contiguous), so this keeps few values alive at a
 // time: the register file of a 250-column chip shrinks from "every shared sub-expression of the chip" to the handful
 // one operation needs, which is what decides the workgroup width / occupancy of the interpreter (launch_round).
-// mode 0: original order (asserts tagged only); 1: by last column; 2: by first column.
+// mode 0: original order (asserts tagged only); 1: by last column; 2: by first column; 3: by last column over a program whose
+// cheap values are rematerialised at every use (below), each load emitted right before the instruction that reads it.
+
+// Rematerialisation (host), for the FieldOpCols chips (round 5: secp256k1 add / double, uint256): their constraints are
+// coefficient-wise convolutions sum_i a[i] b[k - i] over 32-limb operands that are COLUMNS, 63 coefficients per field operation,
+// ten operations per row. With every column loaded once and kept, ~100 values are live throughout (two operands, the carry, the
+// byte decompositions of the point) and a wave's register file takes 120 KB of LDS: ONE wave per compute unit. Here every use of
+// a column (and of a value computed from columns in at most 4 instructions — the high byte (u16 - low) / 256 of a memory limb —
+// or in at most 7 if it is used at most 8 times) gets its own copy right before the user; a product then costs LOAD, LOAD (forwarded), MAD
+// instead of MAD, the program is ~3x longer — and the file shrinks to the accumulators and the few values that are worth keeping.
+static void rematerialize_cheap(const uint32_t* ssa, uint32_t n, std::vector<uint32_t>* out) {
+    auto is_bin = [](uint32_t op) { return op == ZC_ADD || op == ZC_SUB || op == ZC_MUL; };
+    auto is_un = [](uint32_t op) { return op == ZC_NEG || op == ZC_ASSERT_ZERO || zc_is_imm(op); };
+    std::vector<uint32_t> uses(n, 0), cone(n, 1);
+    std::vector<char> remat(n, 0);
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t op = ssa[3 * k];
+        if (is_bin(op)) { uses[ssa[3 * k + 1]]++; uses[ssa[3 * k + 2]]++; }
+        else if (is_un(op)) uses[ssa[3 * k + 1]]++;
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t op = ssa[3 * k], a = ssa[3 * k + 1], b = ssa[3 * k + 2];
+        if (op == ZC_ASSERT_ZERO) continue;
+        if (is_bin(op)) { cone[k] = cone[a] + cone[b] + 1; remat[k] = remat[a] && remat[b] && (cone[k] <= 4 || (cone[k] <= 7 && uses[k] <= 8)); }
+        else if (is_un(op)) { cone[k] = cone[a] + 1; remat[k] = remat[a] && (cone[k] <= 4 || (cone[k] <= 7 && uses[k] <= 8)); }
+        else remat[k] = 1;                       // LOAD_MAIN / LOAD_PREP / CONST / PUBLIC
+    }
+    out->clear();
+    std::vector<uint32_t> where(n, 0xffffffffu), stack;
+    auto push = [&](uint32_t op, uint32_t a, uint32_t b) { out->insert(out->end(), {op, a, b}); return (uint32_t)(out->size() / 3 - 1); };
+    // a fresh copy of the cone of a rematerialisable value (at most 7 instructions: recursion depth is bounded)
+    std::function<uint32_t(uint32_t)> clone = [&](uint32_t v) -> uint32_t {
+        if (!remat[v]) return where[v];
+        const uint32_t op = ssa[3 * v], a = ssa[3 * v + 1], b = ssa[3 * v + 2];
+        if (is_bin(op)) { const uint32_t x = clone(a), y = clone(b); return push(op, x, y); }
+        if (is_un(op)) { const uint32_t x = clone(a); return push(op, x, b); }
+        return push(op, a, b);
+    };
+    for (uint32_t k = 0; k < n; k++) {
+        if (remat[k]) continue;                  // emitted where it is used
+        const uint32_t op = ssa[3 * k], a = ssa[3 * k + 1], b = ssa[3 * k + 2];
+        if (is_bin(op)) { const uint32_t x = clone(a), y = clone(b); where[k] = push(op, x, y); }
+        else if (is_un(op)) { const uint32_t x = clone(a); where[k] = push(op, x, b); }
+        else where[k] = push(op, a, b);
+    }
+}
+
 static void schedule_program(const uint32_t* ssa, uint32_t n, uint32_t main_w, int mode, std::vector<uint32_t>* out) {
+    std::vector<uint32_t> remat_ssa;
+    const bool lazy = mode == 3;
+    if (lazy) {
+        rematerialize_cheap(ssa, n, &remat_ssa);
+        ssa = remat_ssa.data(); n = (uint32_t)(remat_ssa.size() / 3); mode = 1;
+    }
     auto is_bin = [](uint32_t op) { return op == ZC_ADD || op == ZC_SUB || op == ZC_MUL; };
     auto is_un = [](uint32_t op) { return op == ZC_NEG || op == ZC_ASSERT_ZERO || zc_is_imm(op); };
     std::vector<uint32_t> asserts, idx_of(n, 0);
@@ -1162,7 +1215,7 @@ static void schedule_program(const uint32_t* ssa, uint32_t n, uint32_t main_w, i
         }
         for (uint32_t v : seen_here) visited[v] = 0;
         std::sort(loads.begin(), loads.end(), [&](uint32_t x, uint32_t y) { return lo[x] < lo[y]; });
-        for (uint32_t v : loads) emit(v);
+        if (!lazy) for (uint32_t v : loads) emit(v);
         // 2. the rest of the cone, operands before users (iterative post-order)
         stack.assign(1, ssa[3 * as + 1]);
         while (!stack.empty()) {
@@ -1641,10 +1694,14 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         std::vector<uint32_t> folded, sched;
         fold_immediates(program, n_instr, &folded);
         static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
-        SP1HIP_REQUIRE(forced_mode <= 2, "SP1HIP_ZC_SCHEDULE must be 0, 1 or 2 (a debug knob; unset = try all three)");
+        SP1HIP_REQUIRE(forced_mode <= 3, "SP1HIP_ZC_SCHEDULE must be 0, 1, 2 or 3 (a debug knob; unset = try them)");
+        // mode 3 (rematerialised loads: a ~3x longer program with a much smaller file) only where the file is the problem: when the
+        // best of the other orders needs at least this many registers (SP1HIP_ZC_LAZY_MIN_REGS; 128 = fewer than five waves' files per CU)
+        static const uint32_t lazy_min_regs = [] { const char* e = getenv("SP1HIP_ZC_LAZY_MIN_REGS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 128u; }();
         uint32_t best_regs = 0xffffffffu;
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 4; mode++) {
             if (forced_mode >= 0 && mode != forced_mode) continue;
+            if (forced_mode < 0 && mode == 3 && best_regs < lazy_min_regs) continue;
             std::vector<uint32_t> cand;
             std::vector<Chunk> mono;
             schedule_program(folded.data(), n_instr, main_width, mode, &cand);
