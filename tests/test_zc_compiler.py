@@ -150,8 +150,8 @@ def test_compiled_forms_of_the_precompile_chips_evaluate_like_the_ssa(lib):
         assert stats[2] * 16 * 64 <= 160 * 1024, (name, stats)          # one wave's extension registers fit the CU's LDS
         if name in ("Secp256k1AddAssign", "Secp256k1DoubleAssign", "Uint256MulMod"):
             # the FieldOpCols chips take the rematerialising schedule (columns re-loaded at every use): 214 / 225 / 195 registers
-            # with every column kept -> at most 20, for a program under twice as long
-            assert stats[2] <= 20 and stats[0] < 2 * len(air.instrs), (name, stats)
+            # with every column kept -> at most 20, for a chunked program under three times the length of the SSA
+            assert stats[2] <= 20 and stats[0] < 3 * len(air.instrs), (name, stats)
 
 
 def test_planner_rejects_overlapping_hints(lib):
