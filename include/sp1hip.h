@@ -493,7 +493,7 @@ int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint3
  *                 modulus word), the 4 x words written (x * y mod modulus; a zero modulus means 2^256)
  * After the program halts, sp1hip_rv64_global_memory lists every address the run touched as (address, initial value, final value,
  * final timestamp): the `MemoryGlobalInit` / `MemoryGlobalFinalize` events. Supervisor mode only; system calls: HALT, WRITE,
- * ENTER / EXIT_UNCONSTRAINED, COMMIT, COMMIT_DEFERRED_PROOFS, HINT_LEN, HINT_READ, KECCAK_PERMUTE, POSEIDON2, SHA_EXTEND, SHA_COMPRESS, UINT256_MUL, SECP256K1_ADD, SECP256K1_DOUBLE (any other stops the run with
+ * ENTER / EXIT_UNCONSTRAINED, COMMIT, COMMIT_DEFERRED_PROOFS, HINT_LEN, HINT_READ, KECCAK_PERMUTE, POSEIDON2, SHA_EXTEND, SHA_COMPRESS, UINT256_MUL, SECP256K1_ADD, SECP256K1_DOUBLE, and the families of sp1hip_rv64_precompile_events (any other stops the run with
  * SP1HIP_ERROR_RUNTIME and a message naming it). The pointers stay valid until the next call on the same handle. */
 #define SP1HIP_RV64_EVENT_WORDS 20
 #define SP1HIP_RV64_KECCAK_WORDS 77
@@ -503,6 +503,35 @@ int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint3
 #define SP1HIP_RV64_UINT256_WORDS 31
 #define SP1HIP_RV64_SECP_ADD_WORDS 43
 #define SP1HIP_RV64_SECP_DOUBLE_WORDS 26
+/* The other field / curve precompiles, one family per chip that proves them (sp1hip_rv64_precompile_events). Every event starts
+ * [clk, first argument, second argument, system-call code]; then
+ *   two-operand calls (curve additions, ED_ADD, Fp / Fp2 operations): n x (previous timestamp, x word), n x (previous timestamp,
+ *     y word), the n x words written at clk + 1 (y is read at clk) — n = 8 / 12 words for a secp256r1 / bn254 / ed25519 or a
+ *     bls12-381 point or Fp2 element, 4 / 6 for an Fp element;
+ *   doublings: n x (previous timestamp, word), the n words written (at clk);
+ *   ED_DECOMPRESS (second argument = the sign bit): 4 x (previous timestamp, x word before), 4 x (previous timestamp, y word read
+ *     at pointer + 32), the 4 x words written at clk + 1;
+ *   UINT256_ADD_CARRY / UINT256_MUL_CARRY: the pointers c, d, e (registers x12, x13, x14), those registers' previous timestamps,
+ *     4 x (previous timestamp, word before) for each of a, b, c (read at clk, clk + 1, clk + 2), d, e (rewritten at clk + 3,
+ *     clk + 4), the 4 d and 4 e words written (low and high half of a + b + c or a * b + c).
+ * Operands must be reduced field elements; the affine formulas have no special cases (equal x in an addition, y = 0 in a
+ * doubling and points off the curve whose denominators vanish stop the run with SP1HIP_ERROR_RUNTIME). */
+#define SP1HIP_RV64_FAMILY_SECP256R1_ADD 0
+#define SP1HIP_RV64_FAMILY_SECP256R1_DOUBLE 1
+#define SP1HIP_RV64_FAMILY_BN254_ADD 2
+#define SP1HIP_RV64_FAMILY_BN254_DOUBLE 3
+#define SP1HIP_RV64_FAMILY_BLS12381_ADD 4
+#define SP1HIP_RV64_FAMILY_BLS12381_DOUBLE 5
+#define SP1HIP_RV64_FAMILY_BN254_FP 6
+#define SP1HIP_RV64_FAMILY_BLS12381_FP 7
+#define SP1HIP_RV64_FAMILY_BN254_FP2_ADDSUB 8
+#define SP1HIP_RV64_FAMILY_BLS12381_FP2_ADDSUB 9
+#define SP1HIP_RV64_FAMILY_BN254_FP2_MUL 10
+#define SP1HIP_RV64_FAMILY_BLS12381_FP2_MUL 11
+#define SP1HIP_RV64_FAMILY_ED_ADD 12
+#define SP1HIP_RV64_FAMILY_ED_DECOMPRESS 13
+#define SP1HIP_RV64_FAMILY_UINT256_OPS 14
+#define SP1HIP_RV64_FAMILIES 15
 typedef void* sp1hip_rv64_vm_t;
 typedef struct {
     uint64_t shard;                      /* index of this shard in the run */
@@ -552,6 +581,8 @@ const uint64_t* sp1hip_rv64_sha_compress_events(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_uint256_events(sp1hip_rv64_vm_t vm);
 const uint64_t* sp1hip_rv64_secp256k1_add_events(sp1hip_rv64_vm_t vm);     /* [n][43]: clk, p_ptr, q_ptr, 8 x (ts, p word), 8 x (ts, q word), 8 p words written */
 const uint64_t* sp1hip_rv64_secp256k1_double_events(sp1hip_rv64_vm_t vm);  /* [n][26]: clk, p_ptr, 8 x (ts, p word), 8 p words written */
+/* The shard's events of one SP1HIP_RV64_FAMILY_*: [n_events][words_per_event] u64, layouts above. */
+int sp1hip_rv64_precompile_events(sp1hip_rv64_vm_t vm, uint32_t family, uint64_t* n_events, uint64_t* words_per_event, const uint64_t** data);
 /* The transpiled program (`Program::instructions`): [n][6] u64 = opcode, op_a, op_b, op_c, imm_b, imm_c; instruction i sits at
  * pc_base + 4 i. */
 int sp1hip_rv64_program(sp1hip_rv64_vm_t vm, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table);

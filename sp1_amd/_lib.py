@@ -214,6 +214,7 @@ PROTOTYPES = [
     ("sp1hip_rv64_uint256_events", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_secp256k1_add_events", C.POINTER(C.c_uint64), [_vp]),
     ("sp1hip_rv64_secp256k1_double_events", C.POINTER(C.c_uint64), [_vp]),
+    ("sp1hip_rv64_precompile_events", None, [_vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_program", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_global_memory", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_output", None, [_vp, _int, C.POINTER(u8p), C.POINTER(C.c_uint64)]),

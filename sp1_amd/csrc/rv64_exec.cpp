@@ -32,6 +32,7 @@
 #include "../../include/sp1hip.h"
 #include "common.hpp"
 #include "kb31.hpp"
+#include "rv64_bigmod.hpp"
 
 namespace {
 
@@ -46,6 +47,18 @@ struct Instr { uint32_t op; uint32_t a; uint64_t b, c; bool imm_b, imm_c; };
 constexpr uint64_t HALT_PC = 1, CLK_INC = 8, ECALL_EXTRA = 256;
 constexpr uint64_t SYS_HALT = 0x00, SYS_WRITE = 0x02, SYS_ENTER_UNC = 0x03, SYS_EXIT_UNC = 0x04, SYS_KECCAK = 0x00010109,
                    SYS_POSEIDON2 = 0x00000133, SYS_UINT256_MUL = 0x0001011D, SYS_SECP256K1_ADD = 0x0001010A, SYS_SECP256K1_DOUBLE = 0x0000010B, SYS_SHA_EXTEND = 0x00300105, SYS_SHA_COMPRESS = 0x00010106, SYS_COMMIT = 0x10, SYS_COMMIT_DEFERRED = 0x1A, SYS_VERIFY_PROOF = 0x1B, SYS_HINT_LEN = 0xF0, SYS_HINT_READ = 0xF1;
+// The field / curve precompiles behind sp1hip_rv64_precompile_events (syscall_code.rs:L65-L168): family = the chip that proves them
+constexpr uint64_t SYS_ED_ADD = 0x00010107, SYS_ED_DECOMPRESS = 0x00000108, SYS_BN254_ADD = 0x0001010E, SYS_BN254_DOUBLE = 0x0000010F,
+                   SYS_BLS12381_ADD = 0x0001011E, SYS_BLS12381_DOUBLE = 0x0000011F, SYS_BLS12381_FP_ADD = 0x00010120, SYS_BLS12381_FP2_MUL = 0x00010125,
+                   SYS_BN254_FP_ADD = 0x00010126, SYS_BN254_FP2_MUL = 0x0001012B, SYS_SECP256R1_ADD = 0x0001012C, SYS_SECP256R1_DOUBLE = 0x0000012D,
+                   SYS_UINT256_ADD_CARRY = 0x00010130, SYS_UINT256_MUL_CARRY = 0x00010131;
+enum Family { F_SECP256R1_ADD, F_SECP256R1_DOUBLE, F_BN254_ADD, F_BN254_DOUBLE, F_BLS12381_ADD, F_BLS12381_DOUBLE, F_BN254_FP, F_BLS12381_FP,
+              F_BN254_FP2_ADDSUB, F_BLS12381_FP2_ADDSUB, F_BN254_FP2_MUL, F_BLS12381_FP2_MUL, F_ED_ADD, F_ED_DECOMPRESS, F_UINT256_OPS, N_FAMILIES };
+static_assert(N_FAMILIES == SP1HIP_RV64_FAMILIES, "include/sp1hip.h lists the families");
+// u64 words per event: [clk, arg1, arg2, syscall code] + two-operand calls n x (ts, x word), n x (ts, y word), n x words written;
+// doublings n x (ts, word), n written; ED_DECOMPRESS 4 x (ts, x word before), 4 x (ts, y word), 4 x words written; UINT256 add /
+// mul with carry: c, d, e pointers, the timestamps of x12 / x13 / x14 before, 5 x 4 x (ts, word before) for a, b, c, d, e, 4 d and 4 e words written
+constexpr uint32_t FAMILY_WORDS[N_FAMILIES] = {44, 28, 44, 28, 64, 40, 24, 34, 44, 64, 44, 64, 44, 24, 58};
 constexpr uint64_t FD_PUBLIC_VALUES = 13, FD_HINT = 14, FD_FP_SQRT = 20, FD_FP_INV = 21;
 
 Instr decode(uint32_t w) {
@@ -201,6 +214,19 @@ void keccak_f(uint64_t s[25]) {                                        // FIPS 2
     }
 }
 
+// The base fields of the curve / tower precompiles (curves/src/weierstrass/{secp256r1,bn254,bls12_381}.rs, edwards/ed25519.rs)
+const uint64_t SECP256R1_P_W[4] = {0xFFFFFFFFFFFFFFFFull, 0x00000000FFFFFFFFull, 0x0000000000000000ull, 0xFFFFFFFF00000001ull};
+const uint64_t BN254_P_W[4] = {0x3C208C16D87CFD47ull, 0x97816A916871CA8Dull, 0xB85045B68181585Dull, 0x30644E72E131A029ull};
+const uint64_t BLS12381_P_W[6] = {0xB9FEFFFFFFFFAAABull, 0x1EABFFFEB153FFFFull, 0x6730D2A0F6B0F624ull, 0x64774B84F38512BFull, 0x4B1BA7B6434BACD7ull, 0x1A0111EA397FE69Aull};
+const uint64_t ED25519_P_W[4] = {0xFFFFFFFFFFFFFFEDull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0x7FFFFFFFFFFFFFFFull};
+const uint64_t ED25519_D_W[4] = {0x75EB4DCA135978A3ull, 0x00700A4D4141D8ABull, 0x8CC740797779E898ull, 0x52036CEE2B6FFE73ull};
+const uint64_t ED25519_SQRT_M1_W[4] = {0xC4EE1B274A0EA0B0ull, 0x2F431806AD2FE478ull, 0x2B4D00993DFBD7A7ull, 0x2B8324804FC1DF0Bull};
+const uint64_t ED25519_P_PLUS_3_OVER_8_W[4] = {0xFFFFFFFFFFFFFFFEull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0x0FFFFFFFFFFFFFFFull};
+const bigmod::Field& field_secp256r1() { static const bigmod::Field f(SECP256R1_P_W, 4); return f; }
+const bigmod::Field& field_bn254() { static const bigmod::Field f(BN254_P_W, 4); return f; }
+const bigmod::Field& field_bls12381() { static const bigmod::Field f(BLS12381_P_W, 6); return f; }
+const bigmod::Field& field_ed25519() { static const bigmod::Field f(ED25519_P_W, 4); return f; }
+
 struct Vm {
     std::vector<Instr> program;
     std::vector<uint32_t> words;
@@ -224,6 +250,7 @@ struct Vm {
     std::vector<uint64_t> sha_extend;                                  // [k][clk, w_ptr, 48 x (4 x (previous timestamp, word read), previous timestamp and value of w[i], w[i] written), 64 x (timestamp, value before; after)]
     std::vector<uint64_t> sha_compress;                                // [k][clk, w_ptr, h_ptr, 8 x (previous timestamp, h word), 64 x (previous timestamp, w word), 8 h words written]
     std::vector<uint64_t> secp_add, secp_double;                       // [k][clk, p_ptr, q_ptr, 8 x (ts, p word), 8 x (ts, q word), 8 p words written] / [k][clk, p_ptr, 8 x (ts, p word), 8 written]
+    std::vector<uint64_t> family[N_FAMILIES];                          // [k][FAMILY_WORDS[f]]: the field / curve precompiles (layouts above)
     std::vector<uint64_t> uint256;                                     // [k][clk, x_ptr, y_ptr, 4 x (previous timestamp, x word), 8 x (previous timestamp, y / modulus word), 4 x words written]
     std::vector<uint64_t> poseidon2;                                   // POSEIDON2 events: [k][clk, pointer, 8 x (previous timestamp, word read), 8 words written]
     std::vector<uint64_t> precompile;                                  // Keccak events: [k][clk, pointer, 25 x (previous timestamp, word read), 25 words written]
@@ -371,6 +398,159 @@ struct Vm {
             } else return fail("system call 0x%llx inside an unconstrained block", (unsigned long long)code);
         } else return fail("unimplemented instruction in an unconstrained block");
         pc = next_pc;
+        return true;
+    }
+
+    // ---- the field / curve precompiles (one generic modular arithmetic, rv64_bigmod.hpp). Common shape (minimal/precompiles/ec.rs,
+    // fptower/*.rs): the second operand is read at clk, the first is read and rewritten at clk + 1; operands must be reduced
+    // (the chips' carries only fit then) and the affine formulas have no special cases, as in the reference's.
+    using BI = bigmod::Int;
+    // reads `n` words at `ptr` for a precompile: (previous timestamp, value) pairs appended to rec, the words returned; the cells'
+    // timestamps become `ts` when `stamp` (a read), stay for the caller to set otherwise (a slice that is rewritten)
+    // what SyscallAddrOperation constrains (operations/syscall_addr.rs:L51-L93): 8-aligned, above the registers' 2^16, the slice below 2^48
+    static bool slice_ok(uint64_t ptr, int n_words) { return !(ptr & 7) && ptr >= (1ull << 16) && ptr + 8 * (uint64_t)n_words <= (1ull << 48); }
+    void read_words(uint64_t ptr, int n, uint64_t ts, bool stamp, std::vector<uint64_t>& rec, uint64_t* out) {
+        for (int i = 0; i < n; ++i) { Cell& m = cell(ptr + 8 * i); touch_precompile(m, ptr + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); out[i] = m.val; if (stamp) m.ts = ts; }
+    }
+    void write_words(uint64_t ptr, int n, uint64_t ts, const uint64_t* v, std::vector<uint64_t>& rec) {
+        for (int i = 0; i < n; ++i) { Cell& m = cell(ptr + 8 * i); m.val = v[i]; m.ts = ts; rec.push_back(v[i]); }
+    }
+    bool sys_weierstrass(uint64_t code, uint64_t p_ptr, uint64_t q_ptr) {   // minimal/precompiles/ec.rs ec_add / ec_double, curves/src/weierstrass/mod.rs
+        const bool is_add = code == SYS_SECP256R1_ADD || code == SYS_BN254_ADD || code == SYS_BLS12381_ADD;
+        const bool r1 = code == SYS_SECP256R1_ADD || code == SYS_SECP256R1_DOUBLE, bn = code == SYS_BN254_ADD || code == SYS_BN254_DOUBLE;
+        const bigmod::Field& F = r1 ? field_secp256r1() : bn ? field_bn254() : field_bls12381();
+        const int fam = (r1 ? F_SECP256R1_ADD : bn ? F_BN254_ADD : F_BLS12381_ADD) + (is_add ? 0 : 1), n = F.n, nw = 2 * n;
+        if (!slice_ok(p_ptr, nw) || (is_add && !slice_ok(q_ptr, nw)) || (!is_add && q_ptr != 0)) return fail("curve point arguments (system call 0x%llx)", (unsigned long long)code);
+        std::vector<uint64_t> rec = {clk, p_ptr, q_ptr, code};
+        uint64_t pw[12], qw[12] = {0};
+        std::vector<uint64_t> q_rec;                                      // q is read first (at clk): a word shared with p then carries clk into p's access
+        if (is_add) read_words(q_ptr, nw, clk, true, q_rec, qw);
+        read_words(p_ptr, nw, 0, false, rec, pw);
+        rec.insert(rec.end(), q_rec.begin(), q_rec.end());
+        const BI px = bigmod::from_words(pw, n), py = bigmod::from_words(pw + n, n), qx = bigmod::from_words(qw, n), qy = bigmod::from_words(qw + n, n);
+        if (!F.reduced(px) || !F.reduced(py) || !F.reduced(qx) || !F.reduced(qy)) return fail("curve coordinate is not reduced (system call 0x%llx)", (unsigned long long)code);
+        BI slope;
+        if (is_add) {
+            const BI den = F.sub(qx, px);
+            if (bigmod::is_zero(den)) return fail("curve addition of points with equal x (system call 0x%llx)", (unsigned long long)code);
+            slope = F.mul(F.sub(qy, py), F.inv(den));
+        } else {
+            const BI den = F.dbl(py);
+            if (bigmod::is_zero(den)) return fail("curve doubling of a point with y = 0 (system call 0x%llx)", (unsigned long long)code);
+            const BI xx = F.mul(px, px);
+            BI num = F.add(F.dbl(xx), xx);
+            if (r1) num = F.sub(num, bigmod::small(3));                 // a = -3 on secp256r1, 0 on the other curves
+            slope = F.mul(num, F.inv(den));
+        }
+        const BI x3 = F.sub(F.mul(slope, slope), is_add ? F.add(px, qx) : F.dbl(px));
+        const BI y3 = F.sub(F.mul(slope, F.sub(px, x3)), py);
+        uint64_t out[12];
+        memcpy(out, x3.w, 8 * n); memcpy(out + n, y3.w, 8 * n);
+        write_words(p_ptr, nw, is_add ? clk + 1 : clk, out, rec);
+        family[fam].insert(family[fam].end(), rec.begin(), rec.end());
+        return true;
+    }
+    bool sys_fptower(uint64_t code, uint64_t x_ptr, uint64_t y_ptr) {    // minimal/precompiles/fptower/{fp,fp2_addsub,fp2_mul}.rs
+        const bool bls = code < SYS_BN254_FP_ADD;
+        const int k = (int)(code - (bls ? SYS_BLS12381_FP_ADD : SYS_BN254_FP_ADD));   // 0..2: Fp add / sub / mul; 3, 4: Fp2 add / sub; 5: Fp2 mul
+        const bigmod::Field& F = bls ? field_bls12381() : field_bn254();
+        const int fam = (k < 3 ? F_BN254_FP : k < 5 ? F_BN254_FP2_ADDSUB : F_BN254_FP2_MUL) + (bls ? 1 : 0), n = F.n, nw = k < 3 ? n : 2 * n;
+        if (!slice_ok(x_ptr, nw) || !slice_ok(y_ptr, nw)) return fail("field operand pointers (system call 0x%llx)", (unsigned long long)code);
+        std::vector<uint64_t> rec = {clk, x_ptr, y_ptr, code};
+        uint64_t xw[12], yw[12];
+        std::vector<uint64_t> y_rec;                                      // y is read first (at clk): x <- x op x is legal, its words then carry clk into x's access
+        read_words(y_ptr, nw, clk, true, y_rec, yw);
+        read_words(x_ptr, nw, 0, false, rec, xw);
+        rec.insert(rec.end(), y_rec.begin(), y_rec.end());
+        BI a[2], bb[2], r[2];
+        for (int h = 0; h < nw / n; ++h) {
+            a[h] = bigmod::from_words(xw + h * n, n); bb[h] = bigmod::from_words(yw + h * n, n);
+            if (!F.reduced(a[h]) || !F.reduced(bb[h])) return fail("field operand is not reduced (system call 0x%llx)", (unsigned long long)code);
+        }
+        if (k == 0 || k == 3) for (int h = 0; h < nw / n; ++h) r[h] = F.add(a[h], bb[h]);
+        else if (k == 1 || k == 4) for (int h = 0; h < nw / n; ++h) r[h] = F.sub(a[h], bb[h]);
+        else if (k == 2) r[0] = F.mul(a[0], bb[0]);
+        else { r[0] = F.sub(F.mul(a[0], bb[0]), F.mul(a[1], bb[1])); r[1] = F.add(F.mul(a[0], bb[1]), F.mul(a[1], bb[0])); }   // u^2 = -1
+        uint64_t out[12];
+        for (int h = 0; h < nw / n; ++h) memcpy(out + h * n, r[h].w, 8 * n);
+        write_words(x_ptr, nw, clk + 1, out, rec);
+        family[fam].insert(family[fam].end(), rec.begin(), rec.end());
+        return true;
+    }
+    bool sys_ed_add(uint64_t p_ptr, uint64_t q_ptr) {                    // twisted Edwards, a = -1 (curves/src/edwards/mod.rs ed_add)
+        const bigmod::Field& F = field_ed25519();
+        if (!slice_ok(p_ptr, 8) || !slice_ok(q_ptr, 8)) return fail("ED_ADD arguments");
+        std::vector<uint64_t> rec = {clk, p_ptr, q_ptr, SYS_ED_ADD};
+        uint64_t pw[8], qw[8];
+        std::vector<uint64_t> q_rec;
+        read_words(q_ptr, 8, clk, true, q_rec, qw);
+        read_words(p_ptr, 8, 0, false, rec, pw);
+        rec.insert(rec.end(), q_rec.begin(), q_rec.end());
+        const BI x1 = bigmod::from_words(pw, 4), y1 = bigmod::from_words(pw + 4, 4), x2 = bigmod::from_words(qw, 4), y2 = bigmod::from_words(qw + 4, 4);
+        if (!F.reduced(x1) || !F.reduced(y1) || !F.reduced(x2) || !F.reduced(y2)) return fail("ED_ADD coordinate is not reduced");
+        const BI xn = F.add(F.mul(x1, y2), F.mul(x2, y1)), yn = F.add(F.mul(y1, y2), F.mul(x1, x2));
+        const BI df = F.mul(bigmod::from_words(ED25519_D_W, 4), F.mul(F.mul(x1, y1), F.mul(x2, y2)));
+        const BI dx = F.add(bigmod::small(1), df), dy = F.sub(bigmod::small(1), df);
+        if (bigmod::is_zero(dx) || bigmod::is_zero(dy)) return fail("ED_ADD: a denominator vanishes (a point is not on the curve)");
+        const BI x3 = F.mul(xn, F.inv(dx)), y3 = F.mul(yn, F.inv(dy));
+        uint64_t out[8];
+        memcpy(out, x3.w, 32); memcpy(out + 4, y3.w, 32);
+        write_words(p_ptr, 8, clk + 1, out, rec);
+        family[F_ED_ADD].insert(family[F_ED_ADD].end(), rec.begin(), rec.end());
+        return true;
+    }
+    bool sys_ed_decompress(uint64_t ptr, uint64_t sign) {                // minimal/precompiles/edwards/decompress.rs; curves/src/edwards/ed25519.rs:L75-L145
+        const bigmod::Field& F = field_ed25519();
+        if (!slice_ok(ptr, 8) || sign > 1) return fail("ED_DECOMPRESS arguments");
+        std::vector<uint64_t> rec = {clk, ptr, sign, SYS_ED_DECOMPRESS};
+        uint64_t xw[4], yw[4];
+        read_words(ptr, 4, 0, false, rec, xw);                           // disjoint from the y half: the order does not matter
+        read_words(ptr + 32, 4, clk, true, rec, yw);
+        const BI y = bigmod::from_words(yw, 4);
+        if (!F.reduced(y)) return fail("ED_DECOMPRESS: y is not a reduced field element (the sign bit travels in the second argument)");
+        const BI yy = F.mul(y, y), u = F.sub(yy, bigmod::small(1)), v = F.add(F.mul(bigmod::from_words(ED25519_D_W, 4), yy), bigmod::small(1));
+        const BI a = F.mul(u, F.inv(v));
+        BI beta = F.pow(a, bigmod::from_words(ED25519_P_PLUS_3_OVER_8_W, 4));
+        const BI bsq = F.mul(beta, beta);
+        if (bigmod::eq(bsq, F.neg(a)) && !bigmod::is_zero(a)) beta = F.mul(beta, bigmod::from_words(ED25519_SQRT_M1_W, 4));
+        else if (!bigmod::eq(bsq, a)) return fail("ED_DECOMPRESS: not a point of the curve (u / v is not a square)");
+        if (beta.w[0] & 1) beta = F.neg(beta);                          // the even root; the chip negates it when sign = 1
+        const BI x = sign ? F.neg(beta) : beta;
+        write_words(ptr, 4, clk + 1, x.w, rec);
+        family[F_ED_DECOMPRESS].insert(family[F_ED_DECOMPRESS].end(), rec.begin(), rec.end());
+        return true;
+    }
+    bool sys_uint256_ops(uint64_t code, uint64_t a_ptr, uint64_t b_ptr) { // vm/syscall/uint256_ops.rs: d, e <- low, high words of a + b + c | a * b + c
+        std::vector<uint64_t> rec = {clk, a_ptr, b_ptr, code};
+        uint64_t ptrs[3], reg_ts[3];
+        for (int i = 0; i < 3; ++i) { Cell& r = regs[12 + i]; touch_precompile(r, 12 + i); ptrs[i] = r.val; reg_ts[i] = r.ts; r.ts = clk; }
+        rec.insert(rec.end(), ptrs, ptrs + 3); rec.insert(rec.end(), reg_ts, reg_ts + 3);
+        const uint64_t c_ptr = ptrs[0], d_ptr = ptrs[1], e_ptr = ptrs[2];
+        if (!slice_ok(a_ptr, 4) || !slice_ok(b_ptr, 4) || !slice_ok(c_ptr, 4) || !slice_ok(d_ptr, 4) || !slice_ok(e_ptr, 4)) return fail("UINT256 add / mul with carry: pointer arguments");
+        uint64_t a[4], bw[4], c[4], scratch[4];
+        read_words(a_ptr, 4, clk, true, rec, a);
+        read_words(b_ptr, 4, clk + 1, true, rec, bw);
+        read_words(c_ptr, 4, clk + 2, true, rec, c);
+        uint64_t res[9] = {0};
+        if (code == SYS_UINT256_ADD_CARRY) {
+            unsigned __int128 carry = 0;
+            for (int k = 0; k < 4; ++k) { carry += (unsigned __int128)a[k] + bw[k] + c[k]; res[k] = (uint64_t)carry; carry >>= 64; }
+            res[4] = (uint64_t)carry;
+        } else {
+            for (int i = 0; i < 4; ++i) {
+                unsigned __int128 carry = 0;
+                for (int j = 0; j < 4; ++j) { carry += (unsigned __int128)a[i] * bw[j] + res[i + j]; res[i + j] = (uint64_t)carry; carry >>= 64; }
+                res[i + 4] = (uint64_t)carry;
+            }
+            unsigned __int128 carry = 0;
+            for (int k = 0; k < 8; ++k) { carry += (unsigned __int128)res[k] + (k < 4 ? c[k] : 0); res[k] = (uint64_t)carry; carry >>= 64; }
+        }
+        read_words(d_ptr, 4, 0, false, rec, scratch);                   // the words d and e held before
+        for (int i = 0; i < 4; ++i) { Cell& m = cell(d_ptr + 8 * i); m.val = res[i]; m.ts = clk + 3; }
+        read_words(e_ptr, 4, 0, false, rec, scratch);
+        for (int i = 0; i < 4; ++i) { Cell& m = cell(e_ptr + 8 * i); m.val = res[4 + i]; m.ts = clk + 4; }
+        rec.insert(rec.end(), res, res + 8);
+        family[F_UINT256_OPS].insert(family[F_UINT256_OPS].end(), rec.begin(), rec.end());
         return true;
     }
 
@@ -623,6 +803,16 @@ struct Vm {
                 (is_add ? secp_add : secp_double).insert((is_add ? secp_add : secp_double).end(), rec.begin(), rec.end());
                 break;
             }
+            case SYS_SECP256R1_ADD: case SYS_BN254_ADD: case SYS_BLS12381_ADD: case SYS_SECP256R1_DOUBLE: case SYS_BN254_DOUBLE: case SYS_BLS12381_DOUBLE:
+                if (!sys_weierstrass(code, b, c)) return false;
+                break;
+            case SYS_BLS12381_FP_ADD: case SYS_BLS12381_FP_ADD + 1: case SYS_BLS12381_FP_ADD + 2: case SYS_BLS12381_FP_ADD + 3: case SYS_BLS12381_FP_ADD + 4: case SYS_BLS12381_FP2_MUL:
+            case SYS_BN254_FP_ADD: case SYS_BN254_FP_ADD + 1: case SYS_BN254_FP_ADD + 2: case SYS_BN254_FP_ADD + 3: case SYS_BN254_FP_ADD + 4: case SYS_BN254_FP2_MUL:
+                if (!sys_fptower(code, b, c)) return false;
+                break;
+            case SYS_ED_ADD: if (!sys_ed_add(b, c)) return false; break;
+            case SYS_ED_DECOMPRESS: if (!sys_ed_decompress(b, c)) return false; break;
+            case SYS_UINT256_ADD_CARRY: case SYS_UINT256_MUL_CARRY: if (!sys_uint256_ops(code, b, c)) return false; break;
             case SYS_POSEIDON2: {                                      // vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs
                 if ((b & 7) || c != 0) return fail("POSEIDON2 arguments");
                 uint32_t st[16];
@@ -761,7 +951,7 @@ int sp1hip_rv64_run_shard(sp1hip_rv64_vm_t h, uint64_t max_cycles, sp1hip_rv64_s
     if (!h || !info) { sp1hip::set_error("sp1hip_rv64_run_shard: null argument"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
     Vm& vm = *(Vm*)h;
     if (vm.halted) { sp1hip::set_error("sp1hip_rv64_run_shard: the program has halted"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
-    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear(); vm.uint256.clear(); vm.secp_add.clear(); vm.secp_double.clear();
+    vm.events.clear(); vm.local.clear(); vm.local_closed.clear(); vm.precompile.clear(); vm.poseidon2.clear(); vm.sha_extend.clear(); vm.sha_compress.clear(); vm.uint256.clear(); vm.secp_add.clear(); vm.secp_double.clear(); for (auto& f : vm.family) f.clear();
     if (vm.record) vm.events.reserve((size_t)std::min<uint64_t>(max_cycles, 1ull << 24) * EV);   // one allocation (at most 2.7 GB), not a doubling chain of copies
     info->pc_start = vm.pc; info->clk_start = vm.clk;
     const uint64_t c0 = vm.cycles;
@@ -812,6 +1002,12 @@ const uint64_t* sp1hip_rv64_sha_compress_events(sp1hip_rv64_vm_t h) { return ((V
 const uint64_t* sp1hip_rv64_uint256_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->uint256.data(); }
 const uint64_t* sp1hip_rv64_secp256k1_add_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->secp_add.data(); }
 const uint64_t* sp1hip_rv64_secp256k1_double_events(sp1hip_rv64_vm_t h) { return ((Vm*)h)->secp_double.data(); }
+int sp1hip_rv64_precompile_events(sp1hip_rv64_vm_t h, uint32_t family, uint64_t* n_events, uint64_t* words_per_event, const uint64_t** data) {
+    if (!h || family >= N_FAMILIES || !n_events || !words_per_event || !data) { sp1hip::set_error("sp1hip_rv64_precompile_events: null argument or unknown family"); return SP1HIP_ERROR_INVALID_ARGUMENT; }
+    const std::vector<uint64_t>& v = ((Vm*)h)->family[family];
+    *words_per_event = FAMILY_WORDS[family]; *n_events = v.size() / FAMILY_WORDS[family]; *data = v.data();
+    return SP1HIP_SUCCESS;
+}
 
 int sp1hip_rv64_program(sp1hip_rv64_vm_t h, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table) {
     if (!h) return SP1HIP_ERROR_INVALID_ARGUMENT;

@@ -25,6 +25,12 @@ from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, limbs16
 
 EV_WORDS, KECCAK_WORDS, POSEIDON2_WORDS, SHA_EXTEND_WORDS, SHA_COMPRESS_WORDS, UINT256_WORDS = 20, 77, 26, 786, 155, 31
 SECP_ADD_WORDS, SECP_DOUBLE_WORDS = 43, 26
+# kind: (SP1HIP_RV64_FAMILY_*, chip) — the field / curve precompiles behind sp1hip_rv64_precompile_events (include/sp1hip.h)
+FAMILIES = {"secp256r1_add": (0, "Secp256r1AddAssign"), "secp256r1_double": (1, "Secp256r1DoubleAssign"), "bn254_add": (2, "Bn254AddAssign"),
+            "bn254_double": (3, "Bn254DoubleAssign"), "bls12381_add": (4, "Bls12381AddAssign"), "bls12381_double": (5, "Bls12381DoubleAssign"),
+            "bn254_fp": (6, "Bn254FpOpAssign"), "bls12381_fp": (7, "Bls12381FpOpAssign"), "bn254_fp2_addsub": (8, "Bn254Fp2AddSubAssign"),
+            "bls12381_fp2_addsub": (9, "Bls12381Fp2AddSubAssign"), "bn254_fp2_mul": (10, "Bn254Fp2MulAssign"), "bls12381_fp2_mul": (11, "Bls12381Fp2MulAssign"),
+            "ed_add": (12, "EdAddAssign"), "ed_decompress": (13, "EdDecompress"), "uint256_ops": (14, "Uint256Ops")}
 (E_PC, E_CLK, E_OP, E_OPA, E_OPB, E_OPC, E_FLAGS, E_A, E_B, E_C, E_A_PREV, E_A_PTS, E_B_PTS, E_C_PTS, E_MADDR, E_M_PTS, E_M_PREV, E_M_NEW,
  E_NEXT_PC, E_SPARE) = range(EV_WORDS)
 
@@ -48,6 +54,7 @@ class ExecutedShard:
         self.events, self.local, self.keccak, self.poseidon2 = events, local, keccak, poseidon2
         self.sha_extend, self.sha_compress, self.uint256 = sha_extend, sha_compress, uint256
         self.secp256k1_add, self.secp256k1_double = secp_add, secp_double
+        self.families = {}                                        # kind (FAMILIES) -> [n, words] events, only the kinds that occurred
         self.pc_start, self.next_pc = int(info.pc_start), int(info.next_pc)
         self.clk_start, self.clk_end = int(info.clk_start), int(info.clk_end)
         self.halted, self.exit_code = bool(info.halted), int(info.exit_code)
@@ -101,6 +108,11 @@ class Executor:
                               self._matrix(self.lib.sp1hip_rv64_uint256_events(self.h), info.n_uint256, UINT256_WORDS),
                               self._matrix(self.lib.sp1hip_rv64_secp256k1_add_events(self.h), info.n_secp256k1_add, SECP_ADD_WORDS),
                               self._matrix(self.lib.sp1hip_rv64_secp256k1_double_events(self.h), info.n_secp256k1_double, SECP_DOUBLE_WORDS))
+        n_ev, n_words, data = C.c_uint64(), C.c_uint64(), C.POINTER(C.c_uint64)()
+        for kind, (family, _) in FAMILIES.items():
+            _lib.check(self.lib.sp1hip_rv64_precompile_events(self.h, family, C.byref(n_ev), C.byref(n_words), C.byref(data)))
+            if n_ev.value:
+                shard.families[kind] = self._matrix(data, n_ev.value, n_words.value)
         self.halted = shard.halted
         return shard
 
@@ -407,7 +419,10 @@ ELEMENT_THRESHOLD, HEIGHT_THRESHOLD = (1 << 28) + (1 << 27), 1 << 22        # co
 PRECOMPILES = {"keccak": ("KeccakPermute", "KeccakPermuteControl", 24, 25), "poseidon2": ("Poseidon2", None, 1, 8),
                "sha_extend": ("ShaExtend", "ShaExtendControl", 48, 64), "sha_compress": ("ShaCompress", "ShaCompressControl", 80, 72),
                "uint256": ("Uint256MulMod", None, 1, 12), "secp256k1_add": ("Secp256k1AddAssign", None, 1, 16),
-               "secp256k1_double": ("Secp256k1DoubleAssign", None, 1, 8)}
+               "secp256k1_double": ("Secp256k1DoubleAssign", None, 1, 8),
+               **{k: (FAMILIES[k][1], None, 1, t) for k, t in (("secp256r1_add", 16), ("secp256r1_double", 8), ("bn254_add", 16), ("bn254_double", 8),
+                   ("bls12381_add", 24), ("bls12381_double", 12), ("bn254_fp", 8), ("bls12381_fp", 12), ("bn254_fp2_addsub", 16), ("bls12381_fp2_addsub", 24),
+                   ("bn254_fp2_mul", 16), ("bls12381_fp2_mul", 24), ("ed_add", 16), ("ed_decompress", 8), ("uint256_ops", 20))}}
 
 
 def split_thresholds(program_rows):
@@ -437,6 +452,7 @@ def program_shards(executor, max_cycles, device="cpu", core_limit=None):
     the program still runs, so every precompile and memory shard is there)."""
     from . import riscv_more_trace as MT
     keccak, poseidon2, sha_extend, sha_compress, uint256, secp_add, secp_double = [], [], [], [], [], [], []
+    families = {}
     n_core = 0
     while not executor.halted:
         keep = core_limit is None or n_core < core_limit     # beyond the limit: executed (their precompile calls count), not traced
@@ -459,6 +475,8 @@ def program_shards(executor, max_cycles, device="cpu", core_limit=None):
             secp_add.append(shard.secp256k1_add)
         if shard.secp256k1_double.shape[0]:
             secp_double.append(shard.secp256k1_double)
+        for kind, evs in shard.families.items():
+            families.setdefault(kind, []).append(evs)
         if keep:
             yield "core", machine, tables, publics, tr.global_events, shard
             del tr, machine, tables
@@ -481,6 +499,10 @@ def program_shards(executor, max_cycles, device="cpu", core_limit=None):
         for part in chunks(name, evs):
             machine, tables, publics, gev = build(part, device)
             yield name, machine, tables, publics, gev, None
+    for kind in FAMILIES:                                    # one chip per kind; Fp / UINT256 kinds hold all their system calls' events
+        for part in chunks(kind, families.get(kind)):
+            machine, tables, publics, gev = MT.family_shard_from(kind, part, device)
+            yield kind, machine, tables, publics, gev, None
     gm = executor.global_memory()
     gm = gm[np.argsort(gm[:, 0].astype(np.uint64))]
     if gm.shape[0] == 0 or gm[0, 0] != 0:                  # register x0 opens the address chain whether or not the program read it

@@ -23,6 +23,8 @@ NOT pinned by anything in the reference tree: the ORDER of the fields inside `Ke
 reference makes of it (keccak256/air.rs) are pinned; the field order below is the published Plonky3 one. A different order
 permutes columns, not polynomials.
 """
+import types
+
 from ..air import P
 from .riscv import (ADDRESS_OP, ALU_TYPE, B_AND, B_LTU, B_RANGE, B_U8RANGE, B_XOR, BYTE, CLK_INC, CPU_STATE, GLOBAL, INV, LT_UNSIGNED, MEM_ACCESS, MEMORY, MUL_OP, OPC,
                     PC_INC, R_TYPE, S, SYSCALL, U16_TO_U8, _chip, _done, clk_low_of, eval_add, eval_addr_add, eval_alu_type, eval_compare_u16, eval_cpu_state,
@@ -755,9 +757,9 @@ def FIELD_LT(n_limbs):                                                          
 MEM_ACCESS_U8 = S(("memory_access", MEM_ACCESS), ("prev_value_u8", U16_TO_U8))            # memory/consistency/columns.rs:L38-L43
 
 
-def eval_field_op_polynomials(b, cols, p_op, p_modulus, p_result, is_real):               # field_op.rs eval_with_polynomials + util_air.rs
+def eval_field_op_polynomials(b, cols, p_op, p_modulus, p_result, is_real, witness_offset=WITNESS_OFFSET):   # field_op.rs eval_with_polynomials + util_air.rs
     p_vanishing = _poly_sub(_poly_sub(p_op, p_result), _poly_mul(cols.carry, p_modulus))
-    witness = [w - WITNESS_OFFSET for w in cols.witness]
+    witness = [w - witness_offset for w in cols.witness]
     rhs = _poly_mul(witness, [-(1 << 8), 1])
     for cst in _poly_sub(p_vanishing, rhs):
         b.assert_zero(cst)
@@ -836,93 +838,372 @@ SECP256K1_P = (1 << 256) - (1 << 32) - 977                                      
 SYS_SECP256K1_ADD, SYS_SECP256K1_DOUBLE = 0x0A, 0x0B
 
 
-def eval_field_op(b, cols, a, bb, op, modulus, is_real):                                  # FieldOpCols::eval (field_op.rs:L472-L500)
-    """result = a op bb mod `modulus` (an integer: the curve's base field) on 32 byte limbs; sub / div are the add / mul identities
-    with the result in a's place (result + bb = a, result * bb = a)."""
-    p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(32)]
+def eval_field_op(b, cols, a, bb, op, modulus, is_real, witness_offset=WITNESS_OFFSET, result=None):   # FieldOpCols::eval (field_op.rs:L472-L500)
+    """result = a op bb mod `modulus` (an integer: the curve's base field) on byte limbs (as many as the `result` columns); sub /
+    div are the add / mul identities with the result in a's place (result + bb = a, result * bb = a). `result`: other limbs
+    standing in for the result columns (FieldSqrtCols checks sqrt * sqrt = a that way, field_sqrt.rs:L86-L90)."""
+    p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(len(cols.result))]
+    if result is not None:
+        cols = types.SimpleNamespace(result=result, carry=cols.carry, witness=cols.witness)
     if op in ("add", "mul"):
         p_a, p_res = a, cols.result
     else:
         p_a, p_res = cols.result, a
     p_op = _poly_add(p_a, bb) if op in ("add", "sub") else _poly_mul(p_a, bb)
-    eval_field_op_polynomials(b, cols, p_op, p_mod, p_res, is_real)
+    eval_field_op_polynomials(b, cols, p_op, p_mod, p_res, is_real, witness_offset)
 
 
-def weierstrass_add_chip(name="Secp256k1AddAssign", modulus=SECP256K1_P, syscall_id=SYS_SECP256K1_ADD):   # weierstrass/weierstrass_add.rs:L420-L610
-    b, c, _ = _chip(name, 1599)
+# curve: (base-field modulus, a coefficient, byte limbs, witness limbs, witness offset) — curves/src/weierstrass/{secp256k1,secp256r1,bn254,bls12_381}.rs
+SECP256R1_P = (1 << 256) - (1 << 224) + (1 << 192) + (1 << 96) - 1
+BN254_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+BLS12381_P = 4002409555221667393417789825735904156556882819939007885332058136124031650490837864442687629129015664037894272559787
+CURVES = {"Secp256k1": (SECP256K1_P, 0, 32, 62, 1 << 14), "Secp256r1": (SECP256R1_P, SECP256R1_P - 3, 32, 62, 1 << 14),
+          "Bn254": (BN254_P, 0, 32, 62, 1 << 14), "Bls12381": (BLS12381_P, 0, 48, 94, 1 << 15)}
+# (SyscallCode's low byte of the curve's ADD, of its DOUBLE) — syscall_code.rs:L74-L159
+CURVE_SYSCALLS = {"Secp256k1": (0x0A, 0x0B), "Secp256r1": (0x2C, 0x2D), "Bn254": (0x0E, 0x0F), "Bls12381": (0x1E, 0x1F)}
+
+
+def weierstrass_add_chip(curve="Secp256k1"):                                              # weierstrass/weierstrass_add.rs:L420-L610
+    modulus, _, nl, nw, off = CURVES[curve]
+    words = nl // 4                                                                       # u64 words of an affine point
+    b, c, _ = _chip(curve + "AddAssign", {32: 1599, 48: 2399}[nl])
     accs = lambda n: (lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(n)])
     addrs = lambda n: (lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(n)])
-    FO = FIELD_OP(32, 62)
-    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("p_ptr", SYSCALL_ADDR), ("q_ptr", SYSCALL_ADDR), ("p_addrs", addrs(8)), ("q_addrs", addrs(8)),
-          ("p_access", accs(8)), ("q_access", accs(8)), ("slope_denominator", FO), ("inverse_check", FO), ("slope_numerator", FO), ("slope", FO),
+    FO = FIELD_OP(nl, nw)
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("p_ptr", SYSCALL_ADDR), ("q_ptr", SYSCALL_ADDR), ("p_addrs", addrs(words)), ("q_addrs", addrs(words)),
+          ("p_access", accs(words)), ("q_access", accs(words)), ("slope_denominator", FO), ("inverse_check", FO), ("slope_numerator", FO), ("slope", FO),
           ("slope_squared", FO), ("p_x_plus_q_x", FO), ("x3_ins", FO), ("p_x_minus_x", FO), ("y3_ins", FO), ("slope_times_p_x_minus_x", FO),
-          ("x3_range", FIELD_LT(32)), ("y3_range", FIELD_LT(32)))(c)
+          ("x3_range", FIELD_LT(nl)), ("y3_range", FIELD_LT(nl)))(c)
     r = L.is_real
-    p_x, p_y = generate_limbs(b, L.p_access[:4], r), generate_limbs(b, L.p_access[4:], r)
-    q_x, q_y = generate_limbs(b, L.q_access[:4], r), generate_limbs(b, L.q_access[4:], r)
-    eval_field_op(b, L.slope_numerator, q_y, p_y, "sub", modulus, r)
-    eval_field_op(b, L.slope_denominator, q_x, p_x, "sub", modulus, r)
-    one = [b.const(1)] + [b.const(0)] * 31
-    eval_field_op(b, L.inverse_check, one, L.slope_denominator.result, "div", modulus, r)
-    eval_field_op(b, L.slope, L.slope_numerator.result, L.slope_denominator.result, "div", modulus, r)
+    op = lambda cols, x, y, o: eval_field_op(b, cols, x, y, o, modulus, r, off)
+    h = words // 2
+    p_x, p_y = generate_limbs(b, L.p_access[:h], r), generate_limbs(b, L.p_access[h:], r)
+    q_x, q_y = generate_limbs(b, L.q_access[:h], r), generate_limbs(b, L.q_access[h:], r)
+    op(L.slope_numerator, q_y, p_y, "sub")
+    op(L.slope_denominator, q_x, p_x, "sub")
+    one = [b.const(1)] + [b.const(0)] * (nl - 1)
+    op(L.inverse_check, one, L.slope_denominator.result, "div")
+    op(L.slope, L.slope_numerator.result, L.slope_denominator.result, "div")
     slope = L.slope.result
-    eval_field_op(b, L.slope_squared, slope, slope, "mul", modulus, r)
-    eval_field_op(b, L.p_x_plus_q_x, p_x, q_x, "add", modulus, r)
-    eval_field_op(b, L.x3_ins, L.slope_squared.result, L.p_x_plus_q_x.result, "sub", modulus, r)
+    op(L.slope_squared, slope, slope, "mul")
+    op(L.p_x_plus_q_x, p_x, q_x, "add")
+    op(L.x3_ins, L.slope_squared.result, L.p_x_plus_q_x.result, "sub")
     x = L.x3_ins.result
-    eval_field_op(b, L.p_x_minus_x, p_x, x, "sub", modulus, r)
-    eval_field_op(b, L.slope_times_p_x_minus_x, slope, L.p_x_minus_x.result, "mul", modulus, r)
-    eval_field_op(b, L.y3_ins, L.slope_times_p_x_minus_x.result, p_y, "sub", modulus, r)
-    mod_limbs = [b.const((modulus >> (8 * i)) & 0xFF) for i in range(32)]
+    op(L.p_x_minus_x, p_x, x, "sub")
+    op(L.slope_times_p_x_minus_x, slope, L.p_x_minus_x.result, "mul")
+    op(L.y3_ins, L.slope_times_p_x_minus_x.result, p_y, "sub")
+    mod_limbs = [b.const((modulus >> (8 * i)) & 0xFF) for i in range(nl)]
     eval_field_lt(b, L.x3_range, L.x3_ins.result, mod_limbs, r)
     eval_field_lt(b, L.y3_range, L.y3_ins.result, mod_limbs, r)
     result_words = limbs_to_words(L.x3_ins.result) + limbs_to_words(L.y3_ins.result)
-    p_ptr = eval_syscall_addr(b, 64, L.p_ptr, r)
-    q_ptr = eval_syscall_addr(b, 64, L.q_ptr, r)
-    for i in range(8):
+    p_ptr = eval_syscall_addr(b, 2 * nl, L.p_ptr, r)
+    q_ptr = eval_syscall_addr(b, 2 * nl, L.q_ptr, r)
+    for i in range(words):
         eval_addr_add(b, list(p_ptr) + [b.const(0)], word_of_u64(8 * i), L.p_addrs[i].value, r)
-    for i in range(8):
+    for i in range(words):
         eval_addr_add(b, list(q_ptr) + [b.const(0)], word_of_u64(8 * i), L.q_addrs[i].value, r)
-    for i in range(8):
+    for i in range(words):
         acc = L.q_access[i].memory_access
         eval_memory_access(b, L.clk_high, L.clk_low, L.q_addrs[i].value, acc, acc.prev_value, r)
-    for i in range(8):
+    for i in range(words):
         eval_memory_access(b, L.clk_high, L.clk_low + 1, L.p_addrs[i].value, L.p_access[i].memory_access, result_words[i], r)
-    send_syscall(b, L.clk_high, L.clk_low, syscall_id, p_ptr, q_ptr, r, receive=True)
+    send_syscall(b, L.clk_high, L.clk_low, CURVE_SYSCALLS[curve][0], p_ptr, q_ptr, r, receive=True)
     return _done(b, c)
 
 
-def weierstrass_double_chip(name="Secp256k1DoubleAssign", modulus=SECP256K1_P, a_coeff=0, syscall_id=SYS_SECP256K1_DOUBLE):   # weierstrass_double.rs:L415-L620
-    b, c, _ = _chip(name, 1591)
-    FO = FIELD_OP(32, 62)
-    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("p_ptr", SYSCALL_ADDR), ("p_addrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(8)]),
-          ("p_access", lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(8)]), ("slope_denominator", FO), ("slope_numerator", FO), ("slope", FO),
+def weierstrass_double_chip(curve="Secp256k1"):                                           # weierstrass_double.rs:L415-L620
+    modulus, a_coeff, nl, nw, off = CURVES[curve]
+    words = nl // 4
+    b, c, _ = _chip(curve + "DoubleAssign", {32: 1591, 48: 2391}[nl])
+    FO = FIELD_OP(nl, nw)
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("p_ptr", SYSCALL_ADDR), ("p_addrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(words)]),
+          ("p_access", lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(words)]), ("slope_denominator", FO), ("slope_numerator", FO), ("slope", FO),
           ("p_x_squared", FO), ("p_x_squared_times_3", FO), ("slope_squared", FO), ("p_x_plus_p_x", FO), ("x3_ins", FO), ("p_x_minus_x", FO), ("y3_ins", FO),
-          ("slope_times_p_x_minus_x", FO), ("x3_range", FIELD_LT(32)), ("y3_range", FIELD_LT(32)))(c)
+          ("slope_times_p_x_minus_x", FO), ("x3_range", FIELD_LT(nl)), ("y3_range", FIELD_LT(nl)))(c)
     r = L.is_real
-    p_x, p_y = generate_limbs(b, L.p_access[:4], r), generate_limbs(b, L.p_access[4:], r)
-    const_limbs = lambda v: [b.const((v >> (8 * i)) & 0xFF) for i in range(32)]
-    eval_field_op(b, L.p_x_squared, p_x, p_x, "mul", modulus, r)
-    eval_field_op(b, L.p_x_squared_times_3, L.p_x_squared.result, const_limbs(3), "mul", modulus, r)
-    eval_field_op(b, L.slope_numerator, const_limbs(a_coeff), L.p_x_squared_times_3.result, "add", modulus, r)
-    eval_field_op(b, L.slope_denominator, const_limbs(2), p_y, "mul", modulus, r)
-    eval_field_op(b, L.slope, L.slope_numerator.result, L.slope_denominator.result, "div", modulus, r)
+    op = lambda cols, x, y, o: eval_field_op(b, cols, x, y, o, modulus, r, off)
+    h = words // 2
+    p_x, p_y = generate_limbs(b, L.p_access[:h], r), generate_limbs(b, L.p_access[h:], r)
+    const_limbs = lambda v: [b.const((v >> (8 * i)) & 0xFF) for i in range(nl)]
+    op(L.p_x_squared, p_x, p_x, "mul")
+    op(L.p_x_squared_times_3, L.p_x_squared.result, const_limbs(3), "mul")
+    op(L.slope_numerator, const_limbs(a_coeff), L.p_x_squared_times_3.result, "add")
+    op(L.slope_denominator, const_limbs(2), p_y, "mul")
+    op(L.slope, L.slope_numerator.result, L.slope_denominator.result, "div")
     slope = L.slope.result
-    eval_field_op(b, L.slope_squared, slope, slope, "mul", modulus, r)
-    eval_field_op(b, L.p_x_plus_p_x, p_x, p_x, "add", modulus, r)
-    eval_field_op(b, L.x3_ins, L.slope_squared.result, L.p_x_plus_p_x.result, "sub", modulus, r)
-    eval_field_op(b, L.p_x_minus_x, p_x, L.x3_ins.result, "sub", modulus, r)
-    eval_field_op(b, L.slope_times_p_x_minus_x, slope, L.p_x_minus_x.result, "mul", modulus, r)
-    eval_field_op(b, L.y3_ins, L.slope_times_p_x_minus_x.result, p_y, "sub", modulus, r)
+    op(L.slope_squared, slope, slope, "mul")
+    op(L.p_x_plus_p_x, p_x, p_x, "add")
+    op(L.x3_ins, L.slope_squared.result, L.p_x_plus_p_x.result, "sub")
+    op(L.p_x_minus_x, p_x, L.x3_ins.result, "sub")
+    op(L.slope_times_p_x_minus_x, slope, L.p_x_minus_x.result, "mul")
+    op(L.y3_ins, L.slope_times_p_x_minus_x.result, p_y, "sub")
     eval_field_lt(b, L.x3_range, L.x3_ins.result, const_limbs(modulus), r)
     eval_field_lt(b, L.y3_range, L.y3_ins.result, const_limbs(modulus), r)
     result_words = limbs_to_words(L.x3_ins.result) + limbs_to_words(L.y3_ins.result)
-    p_ptr = eval_syscall_addr(b, 64, L.p_ptr, r)
-    for i in range(8):
+    p_ptr = eval_syscall_addr(b, 2 * nl, L.p_ptr, r)
+    for i in range(words):
         eval_addr_add(b, list(p_ptr) + [b.const(0)], word_of_u64(8 * i), L.p_addrs[i].value, r)
-    for i in range(8):
+    for i in range(words):
         eval_memory_access(b, L.clk_high, L.clk_low, L.p_addrs[i].value, L.p_access[i].memory_access, result_words[i], r)
-    send_syscall(b, L.clk_high, L.clk_low, syscall_id, p_ptr, [0, 0, 0], r, receive=True)
+    send_syscall(b, L.clk_high, L.clk_low, CURVE_SYSCALLS[curve][1], p_ptr, [0, 0, 0], r, receive=True)
+    return _done(b, c)
+
+
+# field-tower precompiles (syscall/precompiles/fptower/): (ADD, SUB, MUL) of Fp, then of Fp2 — syscall_code.rs:L118-L153
+FP_FIELDS = {"Bn254": (BN254_P, 32, 62, 1 << 14), "Bls12381": (BLS12381_P, 48, 94, 1 << 15)}
+FP_SYSCALLS = {"Bn254": (0x26, 0x27, 0x28, 0x29, 0x2A, 0x2B), "Bls12381": (0x20, 0x21, 0x22, 0x23, 0x24, 0x25)}
+
+
+def _binary_memory(b, L, words, length):
+    """What every x <- x op y precompile does with its two operands: pointer checks, word addresses, y read at clk, x rewritten
+    with `result_words` at clk + 1 (fp.rs:L378-L425 and the same lines of the other chips). Returns a closure taking the words."""
+    r = L.is_real
+    x_ptr = eval_syscall_addr(b, length, L.x_ptr, r)
+    y_ptr = eval_syscall_addr(b, length, L.y_ptr, r)
+    for i in range(words):
+        eval_addr_add(b, list(x_ptr) + [b.const(0)], word_of_u64(8 * i), L.x_addrs[i].value, r)
+    for i in range(words):
+        eval_addr_add(b, list(y_ptr) + [b.const(0)], word_of_u64(8 * i), L.y_addrs[i].value, r)
+
+    def finish(result_words, syscall_id):
+        for i in range(words):
+            acc = L.y_access[i].memory_access
+            eval_memory_access(b, L.clk_high, L.clk_low, L.y_addrs[i].value, acc, acc.prev_value, r)
+        for i in range(words):
+            eval_memory_access(b, L.clk_high, L.clk_low + 1, L.x_addrs[i].value, L.x_access[i].memory_access, result_words[i], r)
+        send_syscall(b, L.clk_high, L.clk_low, syscall_id, x_ptr, y_ptr, r, receive=True)
+    return finish
+
+
+def eval_field_op_variable(b, cols, a, bb, modulus, is_add, is_sub, is_mul, is_real, witness_offset):   # FieldOpCols::eval_variable (field_op.rs:L367-L401, is_div = 0)
+    p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(len(cols.result))]
+    p_result = _poly_add(_poly_scale(cols.result, is_add + is_mul), _poly_scale(a, is_sub))
+    p_op = _poly_add(_poly_add(_poly_scale(_poly_add(a, bb), is_add), _poly_scale(_poly_add(cols.result, bb), is_sub)), _poly_scale(_poly_mul(a, bb), is_mul))
+    eval_field_op_polynomials(b, cols, p_op, p_mod, p_result, is_real, witness_offset)
+
+
+def fp_op_chip(field):                                                                    # fptower/fp.rs:L292-L461
+    modulus, nl, nw, off = FP_FIELDS[field]
+    words = nl // 8
+    b, c, _ = _chip(field + "FpOpAssign", {32: 306, 48: 450}[nl])
+    accs = lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(words)]
+    addrs = lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(words)]
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("is_add", 1), ("is_sub", 1), ("is_mul", 1), ("x_ptr", SYSCALL_ADDR), ("y_ptr", SYSCALL_ADDR),
+          ("x_addrs", addrs), ("y_addrs", addrs), ("x_access", accs), ("y_access", accs), ("output", FIELD_OP(nl, nw)), ("output_range", FIELD_LT(nl)))(c)
+    for f in (L.is_add, L.is_sub, L.is_mul, L.is_real):
+        b.assert_bool(f)
+    b.assert_eq(L.is_add + L.is_sub + L.is_mul, 1)
+    p_ = generate_limbs(b, L.x_access, L.is_real)
+    q_ = generate_limbs(b, L.y_access, L.is_real)
+    eval_field_op_variable(b, L.output, p_, q_, modulus, L.is_add, L.is_sub, L.is_mul, L.is_real, off)
+    eval_field_lt(b, L.output_range, L.output.result, [b.const((modulus >> (8 * i)) & 0xFF) for i in range(nl)], L.is_real)
+    finish = _binary_memory(b, L, words, nl)
+    add_id, sub_id, mul_id = FP_SYSCALLS[field][:3]
+    finish(limbs_to_words(L.output.result), L.is_add * add_id + L.is_sub * sub_id + L.is_mul * mul_id)
+    return _done(b, c)
+
+
+def fp2_addsub_chip(field):                                                               # fptower/fp2_addsub.rs:L318-L501
+    modulus, nl, nw, off = FP_FIELDS[field]
+    words = nl // 4
+    b, c, _ = _chip(field + "Fp2AddSubAssign", {32: 592, 48: 880}[nl])
+    accs = lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(words)]
+    addrs = lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(words)]
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("is_add", 1), ("x_ptr", SYSCALL_ADDR), ("y_ptr", SYSCALL_ADDR), ("x_addrs", addrs), ("y_addrs", addrs),
+          ("x_access", accs), ("y_access", accs), ("c0", FIELD_OP(nl, nw)), ("c1", FIELD_OP(nl, nw)), ("c0_range", FIELD_LT(nl)), ("c1_range", FIELD_LT(nl)))(c)
+    b.assert_bool(L.is_add)
+    r, h = L.is_real, words // 2
+    p_x, q_x = generate_limbs(b, L.x_access[:h], r), generate_limbs(b, L.y_access[:h], r)
+    p_y, q_y = generate_limbs(b, L.x_access[h:], r), generate_limbs(b, L.y_access[h:], r)
+    eval_field_op_variable(b, L.c0, p_x, q_x, modulus, L.is_add, 1 - L.is_add, 0, r, off)
+    eval_field_op_variable(b, L.c1, p_y, q_y, modulus, L.is_add, 1 - L.is_add, 0, r, off)
+    mod_limbs = [b.const((modulus >> (8 * i)) & 0xFF) for i in range(nl)]
+    eval_field_lt(b, L.c0_range, L.c0.result, mod_limbs, r)
+    eval_field_lt(b, L.c1_range, L.c1.result, mod_limbs, r)
+    finish = _binary_memory(b, L, words, 2 * nl)
+    add_id, sub_id = FP_SYSCALLS[field][3:5]
+    finish(limbs_to_words(L.c0.result) + limbs_to_words(L.c1.result), L.is_add * add_id + (1 - L.is_add) * sub_id)
+    return _done(b, c)
+
+
+def fp2_mul_chip(field):                                                                  # fptower/fp2_mul.rs:L340-L545
+    modulus, nl, nw, off = FP_FIELDS[field]
+    words = nl // 4
+    b, c, _ = _chip(field + "Fp2MulAssign", {32: 1095, 48: 1639}[nl])
+    accs = lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(words)]
+    addrs = lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(words)]
+    FO = FIELD_OP(nl, nw)
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("x_ptr", SYSCALL_ADDR), ("y_ptr", SYSCALL_ADDR), ("x_addrs", addrs), ("y_addrs", addrs),
+          ("x_access", accs), ("y_access", accs), ("a0_mul_b0", FO), ("a1_mul_b1", FO), ("a0_mul_b1", FO), ("a1_mul_b0", FO), ("c0", FO), ("c1", FO),
+          ("c0_range", FIELD_LT(nl)), ("c1_range", FIELD_LT(nl)))(c)
+    r, h = L.is_real, words // 2
+    op = lambda cols, x, y, o: eval_field_op(b, cols, x, y, o, modulus, r, off)
+    p_x, q_x = generate_limbs(b, L.x_access[:h], r), generate_limbs(b, L.y_access[:h], r)
+    p_y, q_y = generate_limbs(b, L.x_access[h:], r), generate_limbs(b, L.y_access[h:], r)
+    op(L.a0_mul_b0, p_x, q_x, "mul")
+    op(L.a1_mul_b1, p_y, q_y, "mul")
+    op(L.c0, L.a0_mul_b0.result, L.a1_mul_b1.result, "sub")
+    op(L.a0_mul_b1, p_x, q_y, "mul")
+    op(L.a1_mul_b0, p_y, q_x, "mul")
+    op(L.c1, L.a0_mul_b1.result, L.a1_mul_b0.result, "add")
+    mod_limbs = [b.const((modulus >> (8 * i)) & 0xFF) for i in range(nl)]
+    eval_field_lt(b, L.c0_range, L.c0.result, mod_limbs, r)
+    eval_field_lt(b, L.c1_range, L.c1.result, mod_limbs, r)
+    finish = _binary_memory(b, L, words, 2 * nl)
+    finish(limbs_to_words(L.c0.result) + limbs_to_words(L.c1.result), FP_SYSCALLS[field][5])
+    return _done(b, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ed25519 (syscall/precompiles/edwards/; curves/src/edwards/ed25519.rs:L24-L50)
+ED25519_P = (1 << 255) - 19
+ED25519_D = 37095705934669439343138083508754565189542113879843219016388785533085940283555
+SYS_ED_ADD, SYS_ED_DECOMPRESS = 0x07, 0x08
+
+
+def eval_field_inner_product(b, cols, a_list, b_list, modulus, is_real):                  # field_inner_product.rs:L106-L145
+    p_ip = []
+    for pa, pb in zip(a_list, b_list):
+        p_ip = _poly_add(p_ip, _poly_mul(pa, pb))
+    p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(len(cols.result))]
+    eval_field_op_polynomials(b, cols, p_ip, p_mod, cols.result, is_real)
+
+
+def eval_field_den(b, cols, a, bb, sign, modulus, is_real):                               # field_den.rs:L113-L150: result = a / (1 + bb) or a / (1 - bb)
+    lhs = _poly_add(_poly_mul(bb, cols.result), cols.result if sign else a)
+    p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(len(cols.result))]
+    eval_field_op_polynomials(b, cols, lhs, p_mod, a if sign else cols.result, is_real)
+
+
+def ed_add_chip():                                                                        # edwards/ed_add.rs:L330-L470
+    b, c, _ = _chip("EdAddAssign", 1347)
+    accs = lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(8)]
+    addrs = lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(8)]
+    FO = FIELD_OP(32, 62)
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("x_ptr", SYSCALL_ADDR), ("y_ptr", SYSCALL_ADDR), ("x_addrs", addrs), ("y_addrs", addrs),
+          ("x_access", accs), ("y_access", accs), ("x3_numerator", FO), ("y3_numerator", FO), ("x1_mul_y1", FO), ("x2_mul_y2", FO), ("f", FO), ("d_mul_f", FO),
+          ("x3_ins", FO), ("y3_ins", FO), ("x3_range", FIELD_LT(32)), ("y3_range", FIELD_LT(32)))(c)            # x_* = the reference's p_*, y_* = its q_*
+    r = L.is_real
+    x1, x2 = generate_limbs(b, L.x_access[:4], r), generate_limbs(b, L.y_access[:4], r)
+    y1, y2 = generate_limbs(b, L.x_access[4:], r), generate_limbs(b, L.y_access[4:], r)
+    eval_field_inner_product(b, L.x3_numerator, [x1, x2], [y2, y1], ED25519_P, r)
+    eval_field_inner_product(b, L.y3_numerator, [y1, x1], [y2, x2], ED25519_P, r)
+    op = lambda cols, x, y, o: eval_field_op(b, cols, x, y, o, ED25519_P, r)
+    op(L.x1_mul_y1, x1, y1, "mul")
+    op(L.x2_mul_y2, x2, y2, "mul")
+    op(L.f, L.x1_mul_y1.result, L.x2_mul_y2.result, "mul")
+    const_limbs = lambda v: [b.const((v >> (8 * i)) & 0xFF) for i in range(32)]
+    op(L.d_mul_f, L.f.result, const_limbs(ED25519_D), "mul")
+    eval_field_den(b, L.x3_ins, L.x3_numerator.result, L.d_mul_f.result, True, ED25519_P, r)
+    eval_field_lt(b, L.x3_range, L.x3_ins.result, const_limbs(ED25519_P), r)
+    eval_field_den(b, L.y3_ins, L.y3_numerator.result, L.d_mul_f.result, False, ED25519_P, r)
+    eval_field_lt(b, L.y3_range, L.y3_ins.result, const_limbs(ED25519_P), r)
+    result_words = limbs_to_words(L.x3_ins.result) + limbs_to_words(L.y3_ins.result)
+    x_ptr = eval_syscall_addr(b, 64, L.x_ptr, r)
+    y_ptr = eval_syscall_addr(b, 64, L.y_ptr, r)
+    for i in range(8):
+        eval_addr_add(b, list(y_ptr) + [b.const(0)], word_of_u64(8 * i), L.y_addrs[i].value, r)
+    for i in range(8):
+        eval_addr_add(b, list(x_ptr) + [b.const(0)], word_of_u64(8 * i), L.x_addrs[i].value, r)
+    for i in range(8):
+        acc = L.y_access[i].memory_access
+        eval_memory_access(b, L.clk_high, L.clk_low, L.y_addrs[i].value, acc, acc.prev_value, r)
+    for i in range(8):
+        eval_memory_access(b, L.clk_high, L.clk_low + 1, L.x_addrs[i].value, L.x_access[i].memory_access, result_words[i], r)
+    send_syscall(b, L.clk_high, L.clk_low, SYS_ED_ADD, x_ptr, y_ptr, r, receive=True)
+    return _done(b, c)
+
+
+def ed_decompress_chip():                                                                 # edwards/ed_decompress.rs:L197-L330, L451-L476
+    b, c, _ = _chip("EdDecompress", 1123)
+    FO = FIELD_OP(32, 62)
+    L = S(("is_real", 1), ("clk_high", 1), ("clk_low", 1), ("ptr", SYSCALL_ADDR), ("read_ptrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(4)]),
+          ("addrs", lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(4)]), ("sign", 1),
+          ("x_access", lambda c_, p: [MEM_ACCESS(c_, p + "%d." % i) for i in range(4)]), ("x_value", lambda c_, p: [c_.arr(4, p + "%d" % i) for i in range(4)]),
+          ("y_access", lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(4)]), ("neg_x_range", FIELD_LT(32)), ("y_range", FIELD_LT(32)),
+          ("yy", FO), ("u", FO), ("dyy", FO), ("v", FO), ("u_div_v", FO),
+          ("x", S(("multiplication", FO), ("range", FIELD_LT(32)), ("lsb", 1))), ("neg_x", FO))(c)
+    r = L.is_real
+    b.assert_bool(L.sign)
+    b.assert_bool(r)
+    y = generate_limbs(b, L.y_access, r)
+    const_limbs = lambda v: [b.const((v >> (8 * i)) & 0xFF) for i in range(32)]
+    mod_limbs = const_limbs(ED25519_P)
+    op = lambda cols, x, yv, o, **kw: eval_field_op(b, cols, x, yv, o, ED25519_P, r, **kw)
+    eval_field_lt(b, L.y_range, y, mod_limbs, r)
+    op(L.yy, y, y, "mul")
+    op(L.u, L.yy.result, [b.const(1)], "sub")
+    op(L.dyy, const_limbs(ED25519_D), L.yy.result, "mul")
+    op(L.v, [b.const(1)], L.dyy.result, "add")
+    op(L.u_div_v, L.u.result, L.v.result, "div")
+    sqrt = L.x.multiplication.result                                                      # FieldSqrtCols::eval (field_sqrt.rs:L75-L113), is_odd = 0
+    op(L.x.multiplication, sqrt, sqrt, "mul", result=L.u_div_v.result)
+    eval_field_lt(b, L.x.range, sqrt, mod_limbs, r)
+    slice_range_check_u8(b, sqrt, r)
+    b.assert_bool(L.x.lsb)
+    b.when(r).assert_eq(L.x.lsb, 0)
+    send_byte(b, B_AND, L.x.lsb, sqrt[0], 1, r)
+    op(L.neg_x, [b.const(0)], sqrt, "sub")
+    eval_field_lt(b, L.neg_x_range, L.neg_x.result, mod_limbs, r)
+    ptr = eval_syscall_addr(b, 64, L.ptr, r)
+    for i in range(4):
+        eval_addr_add(b, list(ptr) + [b.const(0)], word_of_u64(8 * i), L.addrs[i].value, r)
+    for i in range(4):
+        eval_addr_add(b, list(ptr) + [b.const(0)], word_of_u64(8 * i + 32), L.read_ptrs[i].value, r)
+    for i in range(4):
+        acc = L.y_access[i].memory_access
+        eval_memory_access(b, L.clk_high, L.clk_low, L.read_ptrs[i].value, acc, acc.prev_value, r)
+    for i in range(4):
+        eval_memory_access(b, L.clk_high, L.clk_low + 1, L.addrs[i].value, L.x_access[i], L.x_value[i], r)
+    for words, cond in ((limbs_to_words(L.neg_x.result), L.sign), (limbs_to_words(sqrt), 1 - L.sign)):
+        for w, xv in zip(words, L.x_value):
+            for k in range(4):
+                b.when(r).when(cond).assert_eq(w[k], xv[k])
+    send_syscall(b, L.clk_high, L.clk_low, SYS_ED_DECOMPRESS, ptr, [L.sign, 0, 0], r, receive=True)
+    return _done(b, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+SYS_UINT256_ADD_CARRY, SYS_UINT256_MUL_CARRY = 0x30, 0x31
+
+
+def uint256_ops_chip():                                                                   # syscall/precompiles/uint256_ops/air.rs:L117-L402
+    """d, e <- low and high 256 bits of a + b + c or a * b + c: a and b at the call's two arguments, the pointers c, d, e in
+    registers x12, x13, x14 (read by this chip); five slices at clk .. clk + 4."""
+    b, c, _ = _chip("Uint256Ops", 477)
+    addrs = lambda c_, p: [ADDR_ADD_OP(c_, p + "%d." % i) for i in range(4)]
+    accs8 = lambda c_, p: [MEM_ACCESS_U8(c_, p + "%d." % i) for i in range(4)]
+    accs = lambda c_, p: [MEM_ACCESS(c_, p + "%d." % i) for i in range(4)]
+    L = S(("clk_high", 1), ("clk_low", 1), ("a_ptr", SYSCALL_ADDR), ("a_addrs", addrs), ("b_ptr", SYSCALL_ADDR), ("b_addrs", addrs),
+          ("c_ptr", SYSCALL_ADDR), ("c_ptr_memory", MEM_ACCESS), ("c_addrs", addrs), ("d_ptr", SYSCALL_ADDR), ("d_ptr_memory", MEM_ACCESS), ("d_addrs", addrs),
+          ("e_ptr", SYSCALL_ADDR), ("e_ptr_memory", MEM_ACCESS), ("e_addrs", addrs), ("a_memory", accs8), ("b_memory", accs8), ("c_memory", accs8),
+          ("d_memory", accs), ("e_memory", accs), ("field_op", FIELD_OP(32, 63)), ("is_add", 1), ("is_mul", 1), ("is_real", 1))(c)
+    r = L.is_real
+    b.assert_bool(L.is_add)
+    b.assert_bool(L.is_mul)
+    b.assert_bool(r)
+    b.assert_eq(r, L.is_add + L.is_mul)
+    ptrs = {k: eval_syscall_addr(b, 32, getattr(L, k + "_ptr"), r) for k in "abcde"}
+    send_syscall(b, L.clk_high, L.clk_low, L.is_add * SYS_UINT256_ADD_CARRY + L.is_mul * SYS_UINT256_MUL_CARRY, ptrs["a"], ptrs["b"], r, receive=True)
+    for k, reg in (("c", 12), ("d", 13), ("e", 14)):
+        acc = getattr(L, k + "_ptr_memory")
+        eval_memory_access(b, L.clk_high, L.clk_low, [b.const(reg), b.const(0), b.const(0)], acc, acc.prev_value, r)
+        for have, want in zip(acc.prev_value, list(ptrs[k]) + [b.const(0)]):
+            b.assert_eq(have, want)
+    for i in range(4):
+        for k in "abcde":
+            eval_addr_add(b, list(ptrs[k]) + [b.const(0)], word_of_u64(8 * i), getattr(L, k + "_addrs")[i].value, r)
+    for at, k in enumerate("abc"):
+        for i in range(4):
+            acc = getattr(L, k + "_memory")[i].memory_access
+            eval_memory_access(b, L.clk_high, L.clk_low + at, getattr(L, k + "_addrs")[i].value, acc, acc.prev_value, r)
+    a_l, b_l, c_l = (generate_limbs(b, getattr(L, k + "_memory"), r) for k in "abc")
+    p_op = _poly_add(_poly_add(_poly_scale(_poly_add(a_l, b_l), L.is_add), _poly_scale(_poly_mul(a_l, b_l), L.is_mul)), c_l)   # eval_add_mul_and_carry
+    eval_field_op_polynomials(b, L.field_op, p_op, [0] * 32 + [1], L.field_op.result, r)
+    for at, k, limbs in ((3, "d", L.field_op.result), (4, "e", L.field_op.carry)):
+        words = limbs_to_words(limbs)
+        for i in range(4):
+            eval_memory_access(b, L.clk_high, L.clk_low + at, getattr(L, k + "_addrs")[i].value, getattr(L, k + "_memory")[i], words[i], r)
     return _done(b, c)
 
 
@@ -961,7 +1242,12 @@ def poseidon2_chip():                                                           
 
 
 MORE_CHIPS = {
-    "Secp256k1AddAssign": weierstrass_add_chip, "Secp256k1DoubleAssign": weierstrass_double_chip, "Uint256MulMod": uint256_mul_chip, "Poseidon2": poseidon2_chip, "ShaExtend": sha_extend_chip, "ShaExtendControl": sha_extend_control_chip, "ShaCompress": sha_compress_chip,
+    "Secp256k1AddAssign": weierstrass_add_chip, "Secp256k1DoubleAssign": weierstrass_double_chip,
+    **{cv + "AddAssign": (lambda cv=cv: weierstrass_add_chip(cv)) for cv in ("Secp256r1", "Bn254", "Bls12381")},
+    **{cv + "DoubleAssign": (lambda cv=cv: weierstrass_double_chip(cv)) for cv in ("Secp256r1", "Bn254", "Bls12381")},
+    **{f + "FpOpAssign": (lambda f=f: fp_op_chip(f)) for f in FP_FIELDS}, **{f + "Fp2AddSubAssign": (lambda f=f: fp2_addsub_chip(f)) for f in FP_FIELDS},
+    **{f + "Fp2MulAssign": (lambda f=f: fp2_mul_chip(f)) for f in FP_FIELDS}, "EdAddAssign": ed_add_chip, "EdDecompress": ed_decompress_chip,
+    "Uint256Ops": uint256_ops_chip, "Uint256MulMod": uint256_mul_chip, "Poseidon2": poseidon2_chip, "ShaExtend": sha_extend_chip, "ShaExtendControl": sha_extend_control_chip, "ShaCompress": sha_compress_chip,
     "ShaCompressControl": sha_compress_control_chip,
     "AluX0": alu_x0_chip, "DivRem": divrem_chip, "SyscallCore": lambda: syscall_chip("core"), "SyscallPrecompile": lambda: syscall_chip("precompile"),
     "SyscallInstrs": syscall_instrs_chip, "MemoryGlobalInit": lambda: memory_global_chip("init"),
@@ -970,7 +1256,12 @@ MORE_CHIPS = {
 }
 # (columns, constraints) from rv64im_costs.json / rv64im_complexity.json; interactions of the recorded core shard where it has the chip
 MORE_RECORDED = {
-    "Secp256k1AddAssign": (1599, 918, None), "Secp256k1DoubleAssign": (1591, 904, None), "Uint256MulMod": (371, 253, None), "Poseidon2": (348, 497, None), "ShaExtend": (128, 80, None), "ShaExtendControl": (18, 21, None), "ShaCompress": (206, 300, None),
+    "Secp256k1AddAssign": (1599, 918, None), "Secp256k1DoubleAssign": (1591, 904, None), "Secp256r1AddAssign": (1599, 918, None),
+    "Secp256r1DoubleAssign": (1591, 904, None), "Bn254AddAssign": (1599, 918, None), "Bn254DoubleAssign": (1591, 904, None),
+    "Bls12381AddAssign": (2399, 1374, None), "Bls12381DoubleAssign": (2391, 1356, None),
+    "Bn254FpOpAssign": (306, 217, None), "Bls12381FpOpAssign": (450, 317, None), "Bn254Fp2AddSubAssign": (592, 415, None), "Bls12381Fp2AddSubAssign": (880, 615, None),
+    "Bn254Fp2MulAssign": (1095, 666, None), "Bls12381Fp2MulAssign": (1639, 994, None), "EdAddAssign": (1347, 792, None), "EdDecompress": (1123, 755, None),
+    "Uint256Ops": (477, 297, None), "Uint256MulMod": (371, 253, None), "Poseidon2": (348, 497, None), "ShaExtend": (128, 80, None), "ShaExtendControl": (18, 21, None), "ShaCompress": (206, 300, None),
     "ShaCompressControl": (53, 21, None), "AluX0": (34, 17, None), "DivRem": (246, 348, 135), "SyscallCore": (10, 2, 4), "SyscallPrecompile": (10, 2, None), "SyscallInstrs": (65, 93, 30),
     "MemoryGlobalInit": (30, 31, None), "MemoryGlobalFinalize": (30, 31, None), "KeccakPermute": (2640, 2859, None),
     "KeccakPermuteControl": (634, 331, None),

@@ -717,7 +717,7 @@ def _le_bytes(vals, n):
     return np.frombuffer(b"".join(int(v).to_bytes(n, "little") for v in vals), dtype=np.uint8).reshape(len(vals), n).astype(np.int64)
 
 
-def field_op_columns_batch(A, B, modulus, n_limbs, n_witness, op):
+def field_op_columns_batch(A, B, modulus, n_limbs, n_witness, op, offset=1 << 14):
     """`field_op_columns` for lists of operands: the integer arithmetic stays with Python (a few microseconds per row), the
     byte-limb polynomial identity and its division by (x - 256) run over all rows at once."""
     vals = [a + b for a, b in zip(A, B)] if op == "add" else [a * b for a, b in zip(A, B)]
@@ -741,28 +741,28 @@ def field_op_columns_batch(A, B, modulus, n_limbs, n_witness, op):
         wit[:, i] = acc
         acc = van[:, i] + acc * 256
     assert not acc.any(), "the vanishing polynomial does not vanish at 256"
-    wit += 1 << 14
+    wit += offset
     assert wit.min() >= 0 and wit.max() < (1 << 16)
     return pr, pc, wit, res
 
 
-def _set_field_op(rows, L, prefix, A, B, op, modulus=M.SECP256K1_P, n_limbs=32, n_witness=62):
+def _set_field_op(rows, L, prefix, A, B, op, modulus=M.SECP256K1_P, n_limbs=32, n_witness=62, offset=1 << 14):
     """FieldOpCols::populate_with_modulus (field_op.rs:L286-L345) into rows[:len(A)]: sub / div are stated as result + b = a and
     result * b = a, with the `result` columns holding the difference / quotient."""
     n = len(A)
     if op == "sub":
         result = [(modulus + a - b) % modulus for a, b in zip(A, B)]
-        _, car, wit, back = field_op_columns_batch(result, B, modulus, n_limbs, n_witness, "add")
+        _, car, wit, back = field_op_columns_batch(result, B, modulus, n_limbs, n_witness, "add", offset)
         assert back == [a % modulus for a in A]
         res = _le_bytes(result, n_limbs)
     elif op == "div":
         assert all(b % modulus for b in B), "division by zero is not allowed"
         result = [a * pow(b, modulus - 2, modulus) % modulus for a, b in zip(A, B)]
-        _, car, wit, back = field_op_columns_batch(result, B, modulus, n_limbs, n_witness, "mul")
+        _, car, wit, back = field_op_columns_batch(result, B, modulus, n_limbs, n_witness, "mul", offset)
         assert back == [a % modulus for a in A]
         res = _le_bytes(result, n_limbs)
     else:
-        res, car, wit, result = field_op_columns_batch(A, B, modulus, n_limbs, n_witness, op)
+        res, car, wit, result = field_op_columns_batch(A, B, modulus, n_limbs, n_witness, op, offset)
     rows[:n, L[prefix + ".result"]:L[prefix + ".result"] + n_limbs] = res
     rows[:n, L[prefix + ".carry"]:L[prefix + ".carry"] + n_limbs] = car
     rows[:n, L[prefix + ".witness"]:L[prefix + ".witness"] + n_witness] = wit
@@ -784,36 +784,45 @@ def _set_field_lt(rows, L, prefix, lhs, rhs=M.SECP256K1_P, n_limbs=32):
     rows[:n, L[prefix + ".rhs_comparison_byte"]] = y[0, at]
 
 
-def _secp_add_field_ops(row, L, px, py, qx, qy):                          # populate_field_ops, weierstrass_add.rs:L95-L165
-    num = _set_field_op(row, L, "slope_numerator", qy, py, "sub")
-    den = _set_field_op(row, L, "slope_denominator", qx, px, "sub")
-    _set_field_op(row, L, "inverse_check", [1] * len(den), den, "div")
-    slope = _set_field_op(row, L, "slope", num, den, "div")
-    sq = _set_field_op(row, L, "slope_squared", slope, slope, "mul")
-    pq = _set_field_op(row, L, "p_x_plus_q_x", px, qx, "add")
-    x3 = _set_field_op(row, L, "x3_ins", sq, pq, "sub")
-    _set_field_lt(row, L, "x3_range", x3)
-    d = _set_field_op(row, L, "p_x_minus_x", px, x3, "sub")
-    sd = _set_field_op(row, L, "slope_times_p_x_minus_x", slope, d, "mul")
-    y3 = _set_field_op(row, L, "y3_ins", sd, py, "sub")
-    _set_field_lt(row, L, "y3_range", y3)
+def _curve_ops(row, L, curve):
+    modulus, _, nl, nw, off = M.CURVES[curve]
+    return (lambda prefix, A, B, op: _set_field_op(row, L, prefix, A, B, op, modulus, nl, nw, off),
+            lambda prefix, lhs: _set_field_lt(row, L, prefix, lhs, modulus, nl))
+
+
+def _secp_add_field_ops(row, L, px, py, qx, qy, curve="Secp256k1"):      # populate_field_ops, weierstrass_add.rs:L95-L165
+    fo, lt = _curve_ops(row, L, curve)
+    num = fo("slope_numerator", qy, py, "sub")
+    den = fo("slope_denominator", qx, px, "sub")
+    fo("inverse_check", [1] * len(den), den, "div")
+    slope = fo("slope", num, den, "div")
+    sq = fo("slope_squared", slope, slope, "mul")
+    pq = fo("p_x_plus_q_x", px, qx, "add")
+    x3 = fo("x3_ins", sq, pq, "sub")
+    lt("x3_range", x3)
+    d = fo("p_x_minus_x", px, x3, "sub")
+    sd = fo("slope_times_p_x_minus_x", slope, d, "mul")
+    y3 = fo("y3_ins", sd, py, "sub")
+    lt("y3_range", y3)
     return x3, y3
 
 
-def _secp_double_field_ops(row, L, px, py, a_coeff=0):                    # populate_field_ops, weierstrass_double.rs:L89-L160
-    xx = _set_field_op(row, L, "p_x_squared", px, px, "mul")
-    xx3 = _set_field_op(row, L, "p_x_squared_times_3", xx, [3] * len(px), "mul")
-    num = _set_field_op(row, L, "slope_numerator", [a_coeff] * len(px), xx3, "add")
-    den = _set_field_op(row, L, "slope_denominator", [2] * len(px), py, "mul")
-    slope = _set_field_op(row, L, "slope", num, den, "div")
-    sq = _set_field_op(row, L, "slope_squared", slope, slope, "mul")
-    pp = _set_field_op(row, L, "p_x_plus_p_x", px, px, "add")
-    x3 = _set_field_op(row, L, "x3_ins", sq, pp, "sub")
-    _set_field_lt(row, L, "x3_range", x3)
-    d = _set_field_op(row, L, "p_x_minus_x", px, x3, "sub")
-    sd = _set_field_op(row, L, "slope_times_p_x_minus_x", slope, d, "mul")
-    y3 = _set_field_op(row, L, "y3_ins", sd, py, "sub")
-    _set_field_lt(row, L, "y3_range", y3)
+def _secp_double_field_ops(row, L, px, py, curve="Secp256k1"):           # populate_field_ops, weierstrass_double.rs:L89-L160
+    fo, lt = _curve_ops(row, L, curve)
+    a_coeff = M.CURVES[curve][1]
+    xx = fo("p_x_squared", px, px, "mul")
+    xx3 = fo("p_x_squared_times_3", xx, [3] * len(px), "mul")
+    num = fo("slope_numerator", [a_coeff] * len(px), xx3, "add")
+    den = fo("slope_denominator", [2] * len(px), py, "mul")
+    slope = fo("slope", num, den, "div")
+    sq = fo("slope_squared", slope, slope, "mul")
+    pp = fo("p_x_plus_p_x", px, px, "add")
+    x3 = fo("x3_ins", sq, pp, "sub")
+    lt("x3_range", x3)
+    d = fo("p_x_minus_x", px, x3, "sub")
+    sd = fo("slope_times_p_x_minus_x", slope, d, "mul")
+    y3 = fo("y3_ins", sd, py, "sub")
+    lt("y3_range", y3)
     return x3, y3
 
 
@@ -909,3 +918,322 @@ def secp256k1_double_shard_from(events, device="cpu"):
     wa = (pp[:, None] + 8 * eight).reshape(-1)
     return _close_precompile_shard(tr, M.SYS_SECP256K1_DOUBLE, clk, pl, wa, ps[:, :, 0].reshape(-1), clk[:, None].expand(-1, 8).reshape(-1),
                                    ps[:, :, 1].reshape(-1), t[:, 18:26].reshape(-1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The other field / curve precompiles (sp1hip_rv64_precompile_events): one builder over the shapes they share
+_int_of = lambda ws: sum(int(x) << (64 * i) for i, x in enumerate(ws))
+# kind: (chip, shape, column prefixes of the two operands, u64 words per operand)
+FAMILY_SHAPES = {
+    **{cv.lower() + "_add": (cv + "AddAssign", "curve_add", ("p", "q"), M.CURVES[cv][2] // 4) for cv in ("Secp256r1", "Bn254", "Bls12381")},
+    **{cv.lower() + "_double": (cv + "DoubleAssign", "curve_double", ("p",), M.CURVES[cv][2] // 4) for cv in ("Secp256r1", "Bn254", "Bls12381")},
+    **{f.lower() + "_fp": (f + "FpOpAssign", "fp", ("x", "y"), M.FP_FIELDS[f][1] // 8) for f in M.FP_FIELDS},
+    **{f.lower() + "_fp2_addsub": (f + "Fp2AddSubAssign", "fp2_addsub", ("x", "y"), M.FP_FIELDS[f][1] // 4) for f in M.FP_FIELDS},
+    **{f.lower() + "_fp2_mul": (f + "Fp2MulAssign", "fp2_mul", ("x", "y"), M.FP_FIELDS[f][1] // 4) for f in M.FP_FIELDS},
+    "ed_add": ("EdAddAssign", "ed_add", ("x", "y"), 8), "ed_decompress": ("EdDecompress", "ed_decompress", (), 4),
+    "uint256_ops": ("Uint256Ops", "uint256_ops", (), 4),
+}
+
+
+def _fp_field_ops(rows, L, chip_name, shape, code, xs, ys):
+    """The FieldOpCols of the tower chips (populate_field_ops of fptower/{fp,fp2_addsub,fp2_mul}.rs) for operand lists xs / ys
+    (one or two components each, lists of integers per row) and the rows' system-call codes; returns the result components."""
+    field = "Bn254" if chip_name.startswith("Bn254") else "Bls12381"
+    modulus, nl, nw, off = M.FP_FIELDS[field]
+    fo = lambda prefix, A, B, op, r=rows: _set_field_op(r, L, prefix, A, B, op, modulus, nl, nw, off)
+    lt = lambda prefix, lhs, r=rows: _set_field_lt(r, L, prefix, lhs, modulus, nl)
+    n = len(xs[0])
+    k = np.asarray([int(c) & 0xFF for c in code]) - M.FP_SYSCALLS[field][0]         # 0..5 as in FP_SYSCALLS
+    if shape == "fp2_mul":
+        a0b0, a1b1 = fo("a0_mul_b0", xs[0], ys[0], "mul"), fo("a1_mul_b1", xs[1], ys[1], "mul")
+        a0b1, a1b0 = fo("a0_mul_b1", xs[0], ys[1], "mul"), fo("a1_mul_b0", xs[1], ys[0], "mul")
+        out = [fo("c0", a0b0, a1b1, "sub"), fo("c1", a0b1, a1b0, "add")]
+        lt("c0_range", out[0]); lt("c1_range", out[1])
+        return out
+    names = ("output",) if shape == "fp" else ("c0", "c1")
+    base = 0 if shape == "fp" else 3
+    out = [[0] * n for _ in names]
+    for op_i, op in enumerate(("add", "sub", "mul")[:3 if shape == "fp" else 2]):     # rows of one operation together
+        at = np.nonzero(k == base + op_i)[0]
+        if at.size == 0:
+            continue
+        sub = rows[at]
+        for c, name in enumerate(names):
+            res = _set_field_op(sub, L, name, [xs[c][i] for i in at], [ys[c][i] for i in at], op, modulus, nl, nw, off)
+            _set_field_lt(sub, L, name + "_range", res, modulus, nl)
+            for i, v in zip(at, res):
+                out[c][i] = v
+        if shape == "fp":
+            sub[:, L["is_" + op]] = 1
+        else:
+            sub[:, L["is_add"]] = int(op == "add")
+        rows[at] = sub
+    return out
+
+
+def _ed_field_ops(rows, L, x1, y1, x2, y2):                               # populate_field_ops, edwards/ed_add.rs:L94-L130
+    Pm, D = M.ED25519_P, M.ED25519_D
+    n = len(x1)
+    fo = lambda prefix, A, B, op: _set_field_op(rows, L, prefix, A, B, op, Pm)
+
+    def witness(prefix, van_terms, result, carry):
+        """result / carry / witness columns of the identity sum(a_i * b_i) (+ linear terms) = result-side + carry * p, given as the
+        integer polynomial `van` per row (FieldInnerProductCols / FieldDenCols populate: division of the vanishing polynomial by x - 256)."""
+        van = van_terms
+        pc = _le_bytes(carry, 32)
+        pm = [(Pm >> (8 * j)) & 0xFF for j in range(32)]
+        for j in range(32):
+            if pm[j]:
+                van[:, j:j + 32] -= pc * pm[j]
+        wit = np.zeros((n, 62), dtype=np.int64)
+        acc = van[:, 62].copy()
+        for i in range(61, -1, -1):
+            wit[:, i] = acc
+            acc = van[:, i] + acc * 256
+        assert not acc.any(), "the vanishing polynomial does not vanish at 256"
+        wit += 1 << 14
+        assert wit.min() >= 0 and wit.max() < (1 << 16)
+        rows[:n, L[prefix + ".result"]:L[prefix + ".result"] + 32] = _le_bytes(result, 32)
+        rows[:n, L[prefix + ".carry"]:L[prefix + ".carry"] + 32] = pc
+        rows[:n, L[prefix + ".witness"]:L[prefix + ".witness"] + 62] = wit
+
+    def conv(A, B):
+        pa, pb = _le_bytes(A, 32), _le_bytes(B, 32)
+        out = np.zeros((n, 63), dtype=np.int64)
+        for i in range(32):
+            out[:, i:i + 32] += pa[:, i:i + 1] * pb
+        return out
+
+    def inner(prefix, A, B):                                              # FieldInnerProductCols::populate (field_inner_product.rs:L29-L103)
+        ip = [a0 * b0 + a1 * b1 for a0, b0, a1, b1 in zip(A[0], B[0], A[1], B[1])]
+        res = [v % Pm for v in ip]
+        van = conv(A[0], B[0]) + conv(A[1], B[1])
+        van[:, :32] -= _le_bytes(res, 32)
+        witness(prefix, van, res, [v // Pm for v in ip])
+        return res
+
+    def den(prefix, a, b, sign):                                          # FieldDenCols::populate (field_den.rs:L29-L110)
+        dens = [((bv if sign else Pm - bv) + 1) % Pm for bv in b]
+        assert all(dens), "a denominator vanishes"
+        res = [av * pow(dv, Pm - 2, Pm) % Pm for av, dv in zip(a, dens)]
+        lhs = [bv * r + (r if sign else av) for av, bv, r in zip(a, b, res)]
+        rhs = a if sign else res
+        car = [(lv - rv) // Pm for lv, rv in zip(lhs, rhs)]
+        assert all((lv - rv) % Pm == 0 for lv, rv in zip(lhs, rhs))
+        van = conv(b, res)
+        van[:, :32] += (_le_bytes(res, 32) - _le_bytes(a, 32)) * (1 if sign else -1)
+        witness(prefix, van, res, car)
+        return res
+
+    xn = inner("x3_numerator", [x1, x2], [y2, y1])
+    yn = inner("y3_numerator", [y1, x1], [y2, x2])
+    x1y1, x2y2 = fo("x1_mul_y1", x1, y1, "mul"), fo("x2_mul_y2", x2, y2, "mul")
+    f = fo("f", x1y1, x2y2, "mul")
+    df = fo("d_mul_f", f, [D] * n, "mul")
+    x3 = den("x3_ins", xn, df, True)
+    y3 = den("y3_ins", yn, df, False)
+    _set_field_lt(rows, L, "x3_range", x3, Pm)
+    _set_field_lt(rows, L, "y3_range", y3, Pm)
+    return x3, y3
+
+
+def ed25519_even_sqrt(a):
+    """`ed25519_sqrt` (curves/src/edwards/ed25519.rs:L75-L120): the even square root of a, or None."""
+    Pm = M.ED25519_P
+    beta = pow(a, (Pm + 3) // 8, Pm)
+    if beta * beta % Pm == (Pm - a) % Pm:
+        beta = beta * 19681161376707505956807079304988542015446066515923890162744021073123829784752 % Pm
+    if beta * beta % Pm != a % Pm:
+        return None
+    return Pm - beta if beta & 1 else beta
+
+
+def _ed_decompress_field_ops(rows, L, ys):                                # populate_field_ops, edwards/ed_decompress.rs:L157-L180
+    Pm, D = M.ED25519_P, M.ED25519_D
+    n = len(ys)
+    fo = lambda prefix, A, B, op: _set_field_op(rows, L, prefix, A, B, op, Pm)
+    _set_field_lt(rows, L, "y_range", ys, Pm)
+    yy = fo("yy", ys, ys, "mul")
+    u = fo("u", yy, [1] * n, "sub")
+    dyy = fo("dyy", [D] * n, yy, "mul")
+    v = fo("v", [1] * n, dyy, "add")
+    uv = fo("u_div_v", u, v, "div")
+    xs = [ed25519_even_sqrt(a) for a in uv]
+    assert all(x is not None for x in xs), "u / v is not a square"
+    sq = fo("x.multiplication", xs, xs, "mul")                            # FieldSqrtCols::populate (field_sqrt.rs:L29-L70)
+    assert sq == uv
+    rows[:n, L["x.multiplication.result"]:L["x.multiplication.result"] + 32] = _le_bytes(xs, 32)
+    _set_field_lt(rows, L, "x.range", xs, Pm)
+    rows[:n, L["x.lsb"]] = 0
+    neg = fo("neg_x", [0] * n, xs, "sub")
+    _set_field_lt(rows, L, "neg_x_range", neg, Pm)
+    return xs, neg
+
+
+def family_shard_from(kind, events, device="cpu"):
+    """The precompile shard of one family's events ([n, words] int64, the layouts of include/sp1hip.h): the chip's rows (the
+    reference's `populate_field_ops` / padding rows, cited at each filler), SyscallPrecompile, MemoryLocal, Global, Byte, Range.
+    Every result the executor wrote is recomputed here from the operands it read and compared."""
+    chip_name, shape, names, nw = FAMILY_SHAPES[kind]
+    dev = torch.device(device)
+    ev = np.asarray(events).astype(np.uint64)
+    n = ev.shape[0]
+    air = R.chip(chip_name)[0]
+    L = air.layout
+    tr = RT.Tracer.__new__(RT.Tracer)
+    tr.dev, tr.tables = dev, {}
+    tb = RT.Table(air, n, dev)
+    rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
+    t = torch.as_tensor(ev.astype(np.int64), device=dev)
+    clk, a1, a2, code = t[:, 0], t[:, 1], t[:, 2], t[:, 3] & 0xFF
+    pad = rows.shape[0] > n
+    ints = lambda block, lo, hi: [_int_of(w) for w in block[:, lo:hi]]    # block [n, words] of u64 values -> integers
+    arange = lambda k: torch.arange(k, device=dev)[None, :]
+    if shape in ("curve_add", "curve_double", "fp", "fp2_addsub", "fp2_mul", "ed_add"):
+        two = len(names) == 2
+        xs = ev[:, 4:4 + 2 * nw].reshape(n, nw, 2)
+        ys = ev[:, 4 + 2 * nw:4 + 4 * nw].reshape(n, nw, 2) if two else None
+        out = ev[:, 4 + (4 if two else 2) * nw:]
+        h = nw // 2
+        if shape.startswith("curve"):
+            curve = chip_name[:chip_name.index("Add" if two else "Double")]
+            if n:
+                got = (_secp_add_field_ops(rows, L, ints(xs[:, :, 1], 0, h), ints(xs[:, :, 1], h, nw), ints(ys[:, :, 1], 0, h), ints(ys[:, :, 1], h, nw), curve)
+                       if two else _secp_double_field_ops(rows, L, ints(xs[:, :, 1], 0, h), ints(xs[:, :, 1], h, nw), curve))
+            if pad:                                                      # the dummy row of generate_trace_into (weierstrass_add.rs:L290-L330, _double.rs:L300-L340)
+                if two:
+                    _secp_add_field_ops(rows[n:n + 1], L, [0], [0], [1], [1], curve)
+                    _dummy_access(rows[n], L, "q_access.0"); _dummy_access(rows[n], L, "q_access.%d" % h)
+                else:
+                    _secp_double_field_ops(rows[n:n + 1], L, [0], [1], curve)
+                    _dummy_access(rows[n], L, "p_access.%d" % h)
+        elif shape == "ed_add":
+            if n:
+                got = _ed_field_ops(rows, L, ints(xs[:, :, 1], 0, 4), ints(xs[:, :, 1], 4, 8), ints(ys[:, :, 1], 0, 4), ints(ys[:, :, 1], 4, 8))
+            if pad:
+                _ed_field_ops(rows[n:n + 1], L, [0], [0], [0], [0])
+        else:
+            comps = 1 if shape == "fp" else 2
+            w = nw // comps
+            if n:
+                got = _fp_field_ops(rows, L, chip_name, shape, ev[:, 3], [ints(xs[:, :, 1], c * w, (c + 1) * w) for c in range(comps)],
+                                    [ints(ys[:, :, 1], c * w, (c + 1) * w) for c in range(comps)])
+            if pad:                                                      # the field operations on zero operands, as an addition (fp.rs:L238-L248)
+                field = "Bn254" if chip_name.startswith("Bn254") else "Bls12381"
+                pad_code = [M.FP_SYSCALLS[field][{"fp": 0, "fp2_addsub": 3, "fp2_mul": 5}[shape]]]
+                _fp_field_ops(rows[n:n + 1], L, chip_name, shape, pad_code, [[0]] * comps, [[0]] * comps)
+        if n:
+            wr = len(got)
+            assert all(got[c] == ints(out, c * nw // wr, (c + 1) * nw // wr) for c in range(wr)), "the executor's result is not what the operands give"
+        if pad:
+            rows[n + 1:] = rows[n]
+        tb.main[:] = torch.as_tensor(rows, device=dev)
+        tb.set("clk_high", clk >> 24); tb.set("clk_low", clk & 0xFFFFFF); tb.set("is_real", 1)
+        xa = names[0]
+        xl = _syscall_addr_t(tb, xa + "_ptr", a1)
+        xst, yst = t[:, 4:4 + 2 * nw].reshape(n, nw, 2), (t[:, 4 + 2 * nw:4 + 4 * nw].reshape(n, nw, 2) if two else None)
+        x_ts = clk + 1 if two else clk
+        for i in range(nw):
+            tb.set("%s_addrs.%d.value" % (xa, i), _limbs_t(a1 + 8 * i)[:, :3])
+            _mem_access_t(tb, "%s_access.%d.memory_access" % (xa, i), xst[:, i, 1], xst[:, i, 0], x_ts)
+            tb.set("%s_access.%d.prev_value_u8.low_bytes" % (xa, i), _low_bytes(xst[:, i, 1]))
+        if two:
+            yl = _syscall_addr_t(tb, names[1] + "_ptr", a2)
+            for i in range(nw):
+                tb.set("%s_addrs.%d.value" % (names[1], i), _limbs_t(a2 + 8 * i)[:, :3])
+                _mem_access_t(tb, "%s_access.%d.memory_access" % (names[1], i), yst[:, i, 1], yst[:, i, 0], clk)
+                tb.set("%s_access.%d.prev_value_u8.low_bytes" % (names[1], i), _low_bytes(yst[:, i, 1]))
+        tr.tables[chip_name] = tb
+        outs = t[:, 4 + (4 if two else 2) * nw:]
+        wa = (a1[:, None] + 8 * arange(nw)).reshape(-1)
+        t_i, v_i, t_f, v_f = xst[:, :, 0].reshape(-1), xst[:, :, 1].reshape(-1), x_ts[:, None].expand(-1, nw).reshape(-1), outs.reshape(-1)
+        if two:
+            wa = torch.cat([wa, (a2[:, None] + 8 * arange(nw)).reshape(-1)])
+            t_i, v_i = torch.cat([t_i, yst[:, :, 0].reshape(-1)]), torch.cat([v_i, yst[:, :, 1].reshape(-1)])
+            t_f, v_f = torch.cat([t_f, clk[:, None].expand(-1, nw).reshape(-1)]), torch.cat([v_f, yst[:, :, 1].reshape(-1)])
+        return _close_precompile_shard(tr, code, clk, xl, wa, t_i, t_f, v_i, v_f, arg2_limbs=yl if two else None)
+    if shape == "ed_decompress":
+        xs, ys, out = ev[:, 4:12].reshape(n, 4, 2), ev[:, 12:20].reshape(n, 4, 2), ev[:, 20:24]
+        if n:
+            roots, negs = _ed_decompress_field_ops(rows, L, ints(ys[:, :, 1], 0, 4))
+            want = [ng if int(sg) else rt for rt, ng, sg in zip(roots, negs, ev[:, 2])]
+            assert want == ints(out, 0, 4), "the executor's x is not the root with the requested sign"
+        if pad:
+            _ed_decompress_field_ops(rows[n:n + 1], L, [0])
+            rows[n + 1:] = rows[n]
+        tb.main[:] = torch.as_tensor(rows, device=dev)
+        tb.set("clk_high", clk >> 24); tb.set("clk_low", clk & 0xFFFFFF); tb.set("is_real", 1); tb.set("sign", a2)
+        pl = _syscall_addr_t(tb, "ptr", a1)
+        xst, yst, outs = t[:, 4:12].reshape(n, 4, 2), t[:, 12:20].reshape(n, 4, 2), t[:, 20:24]
+        for i in range(4):
+            tb.set("addrs.%d.value" % i, _limbs_t(a1 + 8 * i)[:, :3])
+            tb.set("read_ptrs.%d.value" % i, _limbs_t(a1 + 32 + 8 * i)[:, :3])
+            _mem_access_t(tb, "x_access.%d" % i, xst[:, i, 1], xst[:, i, 0], clk + 1)
+            tb.set("x_value.%d" % i, _limbs_t(outs[:, i]))
+            _mem_access_t(tb, "y_access.%d.memory_access" % i, yst[:, i, 1], yst[:, i, 0], clk)
+            tb.set("y_access.%d.prev_value_u8.low_bytes" % i, _low_bytes(yst[:, i, 1]))
+        tr.tables[chip_name] = tb
+        wa = torch.cat([(a1[:, None] + 8 * arange(4)).reshape(-1), (a1[:, None] + 32 + 8 * arange(4)).reshape(-1)])
+        t_i, v_i = torch.cat([xst[:, :, 0].reshape(-1), yst[:, :, 0].reshape(-1)]), torch.cat([xst[:, :, 1].reshape(-1), yst[:, :, 1].reshape(-1)])
+        t_f = torch.cat([(clk[:, None] + 1).expand(-1, 4).reshape(-1), clk[:, None].expand(-1, 4).reshape(-1)])
+        v_f = torch.cat([outs.reshape(-1), yst[:, :, 1].reshape(-1)])
+        return _close_precompile_shard(tr, code, clk, pl, wa, t_i, t_f, v_i, v_f, arg2_limbs=_limbs_t(a2))
+    assert shape == "uint256_ops"
+    blocks = ev[:, 10:50].reshape(n, 5, 4, 2)                             # a, b, c, d, e: (previous timestamp, word before)
+    is_mul = (ev[:, 3] & np.uint64(0xFF)) == M.SYS_UINT256_MUL_CARRY
+    if n:                                                                 # populate_conditional_op_and_carry (field_op.rs:L100-L200), modulus 2^256
+        a, b, c = (ints(blocks[:, k, :, 1], 0, 4) for k in range(3))
+        full = [(x * y if m else x + y) + z for x, y, z, m in zip(a, b, c, is_mul)]
+        assert [v & ((1 << 256) - 1) for v in full] == ints(ev[:, 50:54], 0, 4) and [v >> 256 for v in full] == ints(ev[:, 54:58], 0, 4), "d, e are not a op b + c"
+    def fill(rs, a, b, c, mul):
+        k = len(a)
+        pa, pb, pc = _le_bytes(a, 32), _le_bytes(b, 32), _le_bytes(c, 32)
+        full = [(x * y if m else x + y) + z for x, y, z, m in zip(a, b, c, mul)]
+        res, car = _le_bytes([v & ((1 << 256) - 1) for v in full], 32), _le_bytes([v >> 256 for v in full], 32)
+        van = np.zeros((k, 64), dtype=np.int64)
+        mk = np.asarray(mul, dtype=np.int64)[:, None]
+        for i in range(32):
+            van[:, i:i + 32] += pa[:, i:i + 1] * pb * mk
+        van[:, :32] += (pa + pb) * (1 - mk) + pc - res
+        van[:, 32:64] -= car
+        wit = np.zeros((k, 63), dtype=np.int64)
+        acc = van[:, 63].copy()
+        for i in range(62, -1, -1):
+            wit[:, i] = acc
+            acc = van[:, i] + acc * 256
+        assert not acc.any()
+        wit += 1 << 14
+        assert wit.min() >= 0 and wit.max() < (1 << 16)
+        rs[:k, L["field_op.result"]:L["field_op.result"] + 32] = res
+        rs[:k, L["field_op.carry"]:L["field_op.carry"] + 32] = car
+        rs[:k, L["field_op.witness"]:L["field_op.witness"] + 63] = wit
+    if n:
+        fill(rows, a, b, c, list(is_mul))
+    if pad:
+        fill(rows[n:n + 1], [0], [0], [0], [False])
+        rows[n + 1:] = rows[n]
+    tb.main[:] = torch.as_tensor(rows, device=dev)
+    tb.set("clk_high", clk >> 24); tb.set("clk_low", clk & 0xFFFFFF); tb.set("is_real", 1)
+    tb.set("is_mul", torch.as_tensor(is_mul.astype(np.int64), device=dev)); tb.set("is_add", torch.as_tensor((~is_mul).astype(np.int64), device=dev))
+    ptrs = {"a": a1, "b": a2, "c": t[:, 4], "d": t[:, 5], "e": t[:, 6]}
+    limbs = {k: _syscall_addr_t(tb, k + "_ptr", v) for k, v in ptrs.items()}
+    for j, k in enumerate("cde"):
+        _mem_access_t(tb, k + "_ptr_memory", ptrs[k], t[:, 7 + j], clk)
+    bt = t[:, 10:50].reshape(n, 5, 4, 2)
+    outs = {"d": t[:, 50:54], "e": t[:, 54:58]}
+    for j, k in enumerate("abcde"):
+        for i in range(4):
+            tb.set("%s_addrs.%d.value" % (k, i), _limbs_t(ptrs[k] + 8 * i)[:, :3])
+            if j < 3:
+                _mem_access_t(tb, "%s_memory.%d.memory_access" % (k, i), bt[:, j, i, 1], bt[:, j, i, 0], clk + j)
+                tb.set("%s_memory.%d.prev_value_u8.low_bytes" % (k, i), _low_bytes(bt[:, j, i, 1]))
+            else:
+                _mem_access_t(tb, "%s_memory.%d" % (k, i), bt[:, j, i, 1], bt[:, j, i, 0], clk + j)
+    tr.tables[chip_name] = tb
+    regs = torch.tensor([12, 13, 14], dtype=I64, device=dev)[None, :].expand(n, -1)
+    wa = torch.cat([regs.reshape(-1)] + [(ptrs[k][:, None] + 8 * arange(4)).reshape(-1) for k in "abcde"])
+    t_i = torch.cat([t[:, 7:10].reshape(-1)] + [bt[:, j, :, 0].reshape(-1) for j in range(5)])
+    v_i = torch.cat([t[:, 4:7].reshape(-1)] + [bt[:, j, :, 1].reshape(-1) for j in range(5)])
+    t_f = torch.cat([clk[:, None].expand(-1, 3).reshape(-1)] + [(clk[:, None] + j).expand(-1, 4).reshape(-1) for j in range(5)])
+    v_f = torch.cat([t[:, 4:7].reshape(-1)] + [bt[:, j, :, 1].reshape(-1) for j in range(3)] + [outs["d"].reshape(-1), outs["e"].reshape(-1)])
+    return _close_precompile_shard(tr, code, clk, limbs["a"], wa, t_i, t_f, v_i, v_f, arg2_limbs=limbs["b"])

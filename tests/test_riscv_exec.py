@@ -431,8 +431,8 @@ def test_executor_errors_are_reported_not_swallowed():
     ex = X.Executor(A.elf(A.li(28, 0x78100001) + [A.enc("ld", 5, 28, 0)] + A.halt(0), data=bytes(16)))      # misaligned load
     with pytest.raises(_lib.Sp1HipError, match="misaligned"):
         ex.run_shard(100)
-    ex = X.Executor(A.elf(A.li(5, 0x0001_0107) + [A.enc("ecall")] + A.halt(0)))                               # ED_ADD: not implemented
-    with pytest.raises(_lib.Sp1HipError, match="0x10107"):
+    ex = X.Executor(A.elf(A.li(5, 0x0000_010C) + [A.enc("ecall")] + A.halt(0)))                               # SECP256K1_DECOMPRESS: not implemented
+    with pytest.raises(_lib.Sp1HipError, match="0x10c"):
         ex.run_shard(100)
 
 

@@ -141,7 +141,12 @@ def test_compiled_forms_of_the_round_5_chips_evaluate_like_the_ssa(lib):
 def test_compiled_forms_of_the_precompile_chips_evaluate_like_the_ssa(lib):
     """The precompile chips of the real-program shards: the curve chips are the longest programs the interpreter runs (23k
     instructions)."""
-    for k, name in enumerate(("Secp256k1AddAssign", "Secp256k1DoubleAssign", "Uint256MulMod", "ShaCompress", "ShaExtend", "Poseidon2")):
+    names = ("Secp256k1AddAssign", "Secp256k1DoubleAssign", "Uint256MulMod", "ShaCompress", "ShaExtend", "Poseidon2",
+             # the other curve / tower chips (48-limb bls12-381 operands: up to 71k instructions; inner products and the
+             # operation-selected polynomials of the Fp chips)
+             "Secp256r1AddAssign", "Bn254DoubleAssign", "Bls12381AddAssign", "Bls12381DoubleAssign", "Bn254FpOpAssign", "Bls12381FpOpAssign",
+             "Bn254Fp2AddSubAssign", "Bls12381Fp2AddSubAssign", "Bn254Fp2MulAssign", "Bls12381Fp2MulAssign", "EdAddAssign", "EdDecompress", "Uint256Ops")
+    for k, name in enumerate(names):
         air = riscv.chip(name)[0]
         _check(lib, air, 500 + k, 8)
         rng = np.random.default_rng(k)
