@@ -303,9 +303,72 @@ def select():
     return air, it
 
 
+def _int_linear(s):
+    """internal_linear_layer_mut (hypercube/src/operations/poseidon2/air.rs:L53-L66): x_i <- R^-1 (sum + diag_i x_i)."""
+    total = s[0]
+    for x in s[1:]:
+        total = total + x
+    return [(total + x * d) * R_INV for x, d in zip(s, INTERNAL_DIAG)]
+
+
+def poseidon2_linear_layer():
+    """chips/poseidon2_helper/linear.rs:L222-L288 (the wrap machine's Poseidon2 in pieces): four blocks read, the external or the
+    internal linear layer of the sixteen values written — the layer's output only exists inside the interactions' values.
+    main: input[4][4]; prep: input addrs[4], output addrs[4], external, internal."""
+    air, it = AirProgram("Poseidon2LinearLayer", 16, 10, cse=True), InteractionProgram("Poseidon2LinearLayer", 16, 10)
+    external, internal = air.prep(8), air.prep(9)
+    is_real = external + internal
+    for f in (external, internal, is_real):
+        air.assert_zero(f * (f - 1))
+    real = VCol.prep(8) + VCol.prep(9)
+    state = [VCol.main(i) for i in range(16)]
+    for i in range(4):
+        it.receive(MEMORY, _block(VCol.prep(i), state[4 * i:4 * i + 4]), real)
+    ext, inn = _ext_linear(state), _int_linear(state)
+    for i in range(4):
+        it.send(MEMORY, _block(VCol.prep(4 + i), ext[4 * i:4 * i + 4]), VCol.prep(8))
+        it.send(MEMORY, _block(VCol.prep(4 + i), inn[4 * i:4 * i + 4]), VCol.prep(9))
+    return air, it
+
+
+def poseidon2_sbox():
+    """chips/poseidon2_helper/sbox.rs:L213-L254: output = input^3 lane by lane; the internal form writes back only lane 0 cubed.
+    main: input[4], output[4]; prep: input addr, output addr, external, internal."""
+    air, it = AirProgram("Poseidon2SBox", 8, 4, cse=True), InteractionProgram("Poseidon2SBox", 8, 4)
+    external, internal = air.prep(2), air.prep(3)
+    is_real = external + internal
+    for f in (external, internal, is_real):
+        air.assert_zero(f * (f - 1))
+    it.receive(MEMORY, _block(VCol.prep(0), [VCol.main(i) for i in range(4)]), VCol.prep(2) + VCol.prep(3))
+    for i in range(4):
+        x = air.main(i)
+        air.assert_zero(x * x * x - air.main(4 + i))
+    it.send(MEMORY, _block(VCol.prep(1), [VCol.main(4 + i) for i in range(4)]), VCol.prep(2))
+    it.send(MEMORY, _block(VCol.prep(1), [VCol.main(4), VCol.main(1), VCol.main(2), VCol.main(3)]), VCol.prep(3))
+    return air, it
+
+
+def ext_felt_convert():
+    """chips/poseidon2_helper/convert.rs:L216-L239: an extension element and its four coordinates as base elements, one of the two
+    sides read and the other written (the signs live in the preprocessed multiplicities). main: input[4]; prep: addrs[5], mults[5]."""
+    air, it = AirProgram("ExtFeltConvert", 4, 10, cse=True), InteractionProgram("ExtFeltConvert", 4, 10)
+    it.receive(MEMORY, _block(VCol.prep(0), [VCol.main(i) for i in range(4)]), VCol.prep(5))
+    for i in range(4):
+        it.send(MEMORY, _single(VCol.prep(1 + i), VCol.main(i)), VCol.prep(6 + i))
+    return air, it
+
+
 def compress_machine():
     """[(AirProgram, InteractionProgram)] of `RecursionAir::<F, 3, 2>::compress_machine()` (= shrink_machine),
     sorted by chip name."""
     chips = [base_alu(), ext_alu(), memory_const(), memory_var(2), poseidon2_wide(), prefix_sum_checks(), public_values(),
              select()]
+    return sorted(chips, key=lambda c: c[0].name)
+
+
+def wrap_machine():
+    """`RecursionAir::<F, 3, 2>::wrap_machine()` (recursion/machine/src/machine.rs:L115-L128): Poseidon2 in pieces — linear layers,
+    S-boxes, extension / base conversions — instead of the wide chip; no PrefixSumChecks."""
+    chips = [base_alu(), ext_alu(), memory_const(), memory_var(2), poseidon2_linear_layer(), poseidon2_sbox(), ext_felt_convert(),
+             select(), public_values()]
     return sorted(chips, key=lambda c: c[0].name)

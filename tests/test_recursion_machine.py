@@ -200,3 +200,96 @@ def test_oracle_proves_and_fully_verifies_a_recursion_shard(seed, L, lsh, batch)
     v = ch.clone()
     blob = orc.shard_prove(chips, pv, prep, L, lsh, batch, ch, 1, 5, 4)
     assert orc.shard_verify(_shapes_only(m), prep.commit, blob, L, lsh, v, 1, 5, 4) != 0
+
+
+def test_the_wrap_machine_chips_compose_the_permutation_and_balance_their_memory():
+    """The wrap machine replaces the wide Poseidon2 chip by Poseidon2LinearLayer / Poseidon2SBox / ExtFeltConvert rows
+    (recursion/machine/src/chips/poseidon2_helper/). Here one permutation is laid out as such rows — every value that crosses
+    between rows goes through the Memory bus at a fresh address —: the linear layers and cubes, taken from the chips' own
+    interaction expressions, compose to the oracle's permutation; every constraint vanishes; with the round-constant additions
+    (BaseAlu's job in a real program) stood in for by MemoryVar rows, the bus balances."""
+    rng = np.random.default_rng(11)
+    chips = dict((a.name, (a, i)) for a, i in R.wrap_machine())
+    assert sorted(chips) == ["BaseAlu", "ExtAlu", "ExtFeltConvert", "MemoryConst", "MemoryVar", "Poseidon2LinearLayer", "Poseidon2SBox", "PublicValues", "Select"]
+    rc = R._round_constants()
+    lin_it, sbox_it, conv_it = chips["Poseidon2LinearLayer"][1], chips["Poseidon2SBox"][1], chips["ExtFeltConvert"][1]
+    lin_rows, sbox_rows, var_events, next_addr = [], [], [], [100]
+
+    def fresh(n):
+        next_addr[0] += n
+        return list(range(next_addr[0] - n, next_addr[0]))
+
+    def linear(state, addrs, external):
+        """One Poseidon2LinearLayer row reading `state` (16 values at 4 block addresses); returns the values its send carries."""
+        out_addrs = fresh(4)
+        prep = np.array(addrs + out_addrs + [int(external), int(not external)], dtype=np.uint64)
+        main = np.array(state, dtype=np.uint64)
+        lin_rows.append((prep, main))
+        sends = [s for s in lin_it.sends if s[2].apply(prep, main) == 1]
+        assert len(sends) == 4
+        vals = [v.apply(prep, main) for s in sends for v in s[1][1:]]
+        assert [s[1][0].apply(prep, main) for s in sends] == out_addrs
+        return vals, out_addrs
+
+    def sbox(block, addr, external):
+        out_addr = fresh(1)[0]
+        cubes = [pow(int(x), 3, MC.P) for x in block]
+        prep = np.array([addr, out_addr, int(external), int(not external)], dtype=np.uint64)
+        main = np.array(list(block) + cubes, dtype=np.uint64)
+        sbox_rows.append((prep, main))
+        (send,) = [s for s in sbox_it.sends if s[2].apply(prep, main) == 1]
+        return [v.apply(prep, main) for v in send[1][1:]], out_addr
+
+    def add_constants(state, addrs, consts):
+        """Stand-in for the BaseAlu rows that add round constants: the old blocks are consumed, new ones supplied (MemoryVar
+        multiplicities -1 / +1 keep the bus honest about what was read and written)."""
+        new = [(int(x) + int(c)) % MC.P for x, c in zip(state, consts)]
+        out = fresh(4)
+        for k in range(4):
+            var_events.append((addrs[k], state[4 * k:4 * k + 4], MC.P - 1))
+            var_events.append((out[k], new[4 * k:4 * k + 4], 1))
+        return new, out
+
+    x = [int(v) for v in rng.integers(0, MC.P, size=16)]
+    addrs = fresh(4)
+    for k in range(4):
+        var_events.append((addrs[k], x[4 * k:4 * k + 4], 1))             # the input appears in memory
+    state, addrs = linear(x, addrs, True)
+    for r in list(range(4)) + ["internal"] + list(range(4, 8)):
+        if r == "internal":
+            for j in range(20):
+                state, addrs = add_constants(state, addrs, [rc[4 + j][0]] + [0] * 15)
+                blk, a0 = sbox(state[:4], addrs[0], False)
+                state, addrs = linear(blk + state[4:], [a0] + addrs[1:], False)
+            continue
+        state, addrs = add_constants(state, addrs, rc[r] if r < 4 else rc[24 + (r - 4)])
+        blocks = [sbox(state[4 * k:4 * k + 4], addrs[k], True) for k in range(4)]
+        state, addrs = linear([v for b, _ in blocks for v in b], [a for _, a in blocks], True)
+    want = orc.from_monty(orc.permute(orc.to_monty(np.array(x, dtype=np.uint32))))
+    assert state == [int(v) for v in want]
+    # ExtFeltConvert: the first output block read as an extension element, its coordinates written as four base elements
+    felt_addrs = fresh(4)
+    conv_prep = np.array([addrs[0]] + felt_addrs + [1, 1, 1, 1, 1], dtype=np.uint64)
+    conv_main = np.array(state[:4], dtype=np.uint64)
+    for k in range(1, 4):
+        var_events.append((addrs[k], state[4 * k:4 * k + 4], MC.P - 1))   # the rest of the output is consumed
+    for k in range(4):
+        var_events.append((felt_addrs[k], [state[k], 0, 0, 0], MC.P - 1))
+    # tables: constraints vanish, the Memory bus balances
+    tables = []
+    for name, rows in (("Poseidon2LinearLayer", lin_rows), ("Poseidon2SBox", sbox_rows), ("ExtFeltConvert", [(conv_prep, conv_main)])):
+        air, it = chips[name]
+        prep, main = np.stack([p for p, _ in rows]), np.stack([m for _, m in rows])
+        assert not MC.constraint_values(air, prep, main, np.zeros(R.NUM_PUBLIC_VALUES, dtype=np.uint64)).any(), name
+        tables.append((it, prep, main))
+    if len(var_events) % 2:
+        var_events.append((0, [0, 0, 0, 0], 0))
+    ev = np.array([[a, m] + list(v) for a, v, m in var_events], dtype=np.uint64).reshape(-1, 2, 6)
+    var_prep = ev[:, :, :2].reshape(-1, 4)
+    var_main = ev[:, :, 2:].reshape(-1, 8)
+    tables.append((chips["MemoryVar"][1], var_prep, var_main))
+    assert MC.bus_imbalance(tables) == {}
+    sbox_main = tables[1][2].copy()
+    sbox_main[3, 5] = (sbox_main[3, 5] + 1) % MC.P                            # one cube off by one: its constraint and the bus both see it
+    assert MC.constraint_values(chips["Poseidon2SBox"][0], tables[1][1], sbox_main, np.zeros(R.NUM_PUBLIC_VALUES, dtype=np.uint64)).any()
+    assert MC.bus_imbalance([tables[0], (tables[1][0], tables[1][1], sbox_main)] + tables[2:]) != {}
