@@ -182,3 +182,31 @@ def test_a_flipped_field_limb_is_caught():
     tabs["Bn254FpOpAssign"][1][0, air.layout["output.result"] + 3] ^= 1
     bad, imb = check_shard(machine, tabs, publics)
     assert "Bn254FpOpAssign" in bad
+
+
+def test_the_oracle_proves_and_verifies_the_carry_shard():
+    """One of the new shard kinds through the whole (CPU) prover: LogUp-GKR over the chip's 301 interactions (its three register
+    reads among them), zerocheck over its 297 constraints, the jagged / BaseFold opening — and the pinned verifier accepts. (The
+    curve shards take 20 - 50 s each in the oracle: run by hand)"""
+    import numpy as np
+    import pyoracle as orc
+    from sp1_amd.machines import riscv_trace as RT
+    top = (1 << 256) - 1
+    data = words(top, 4) + words(top - 5, 4) + words(top, 4) + bytes(64)
+    prog = A.li(28, DATA) + [A.enc("addi", 12, 28, 64), A.enc("addi", 13, 28, 96), A.enc("addi", 14, 28, 128)] + call(0x00010131, 0, 32)
+    ex = X.Executor(A.elf(prog + A.halt(0), data=data + bytes(32)), stdin=[])
+    shards = {kind: (machine, tabs, publics) for kind, machine, tabs, publics, _, _ in X.program_shards(ex, 1 << 20)}
+    machine, tabs, publics = shards["uint256_ops"]
+    host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None) for a, i in machine]
+    shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None) for a, i in machine]
+    L, lsh, batch = 17, 12, 8
+    prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, 1)
+    orc.set_gkr_sparse(True)
+    try:
+        ch = orc.Challenger()
+        ch.observe(prep.commit)
+        v_ch = ch.clone()
+        blob = orc.shard_prove(host, RT.to_monty_np(publics), prep, L, lsh, batch, ch, 1, 5, 4)
+        assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4) == 0
+    finally:
+        orc.set_gkr_sparse(False)
