@@ -210,3 +210,55 @@ def test_the_oracle_proves_and_verifies_the_carry_shard():
         assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4) == 0
     finally:
         orc.set_gkr_sparse(False)
+
+
+@pytest.mark.parametrize("curve", ["Bls12381", "Ed25519"])
+def test_a_scalar_multiplication_by_the_precompiles(curve):
+    """k G by double-and-add, every step a precompile call (bls12-381: DOUBLE in place and ADD of the base point; ed25519: ED_ADD
+    for both, the law being complete), k a 40-bit scalar: ~60 calls with operands nobody chose by hand. The result equals Python's
+    own scalar multiplication and both precompile shards (up to 2,399 columns, 64 rows) check row by row."""
+    k = 0xB5C3A7910F
+    bits = bin(k)[3:]                                                           # below the leading one
+    if curve == "Ed25519":
+        n, G, add, dbl = 4, ED_B, ed_add, lambda p: ed_add(p, p)
+    else:
+        Pm, a, nl = M.CURVES[curve][:3]
+        n, G = nl // 8, BLS12381_G
+        add, dbl = (lambda p, q: w_add(p, q, Pm, a)), (lambda p: w_add(p, p, Pm, a))
+    size = 16 * n
+    pt = words(G[0], n) + words(G[1], n)
+    prog, want = A.li(28, DATA), G                                              # accumulator at +0, base point at +size, scratch copy at +2 size
+    for bit in bits:
+        if curve == "Ed25519":                                                  # acc <- acc + acc needs a second copy of acc: q is read, p rewritten
+            for i in range(2 * n):
+                prog += [A.enc("ld", 6, 28, 8 * i), A.enc("sd", 6, 28, 2 * size + 8 * i)]
+            prog += call(0x00010107, 0, 2 * size)
+        else:
+            prog += call(0x0000011F, 0, None)
+        want = dbl(want)
+        if bit == "1":
+            prog += call(0x00010107 if curve == "Ed25519" else 0x0001011E, 0, size)
+            want = add(want, G)
+    ex, kinds, _, last = run_program(A.elf(prog + A.halt(0), data=pt + pt + bytes(size) + bytes(32)), [], 1 << 20)
+    assert last.exit_code == 0 and kinds == (["core", "ed_add", "memory"] if curve == "Ed25519" else ["core", "bls12381_add", "bls12381_double", "memory"])
+    gm = memory_of(ex)
+    assert (value_at(gm, 0, n), value_at(gm, 8 * n, n)) == want
+    # the same point by an independent route: Python's pow-free ladder from the other end
+    acc, addend, kk = None, G, k
+    while kk:
+        if kk & 1:
+            acc = addend if acc is None else add(acc, addend)
+        addend, kk = dbl(addend), kk >> 1
+    assert acc == want
+
+
+def test_an_unknown_family_is_an_error_not_a_read():
+    import ctypes as C
+    ex = X.Executor(A.elf(A.halt(0)), stdin=[])
+    ex.run_shard(100)
+    n_ev, n_words, data = C.c_uint64(), C.c_uint64(), C.POINTER(C.c_uint64)()
+    with pytest.raises(_lib.Sp1HipError, match="family"):
+        _lib.check(ex.lib.sp1hip_rv64_precompile_events(ex.h, 15, C.byref(n_ev), C.byref(n_words), C.byref(data)))
+    for family in range(15):                                                     # every family answers, empty, with its event size
+        _lib.check(ex.lib.sp1hip_rv64_precompile_events(ex.h, family, C.byref(n_ev), C.byref(n_words), C.byref(data)))
+        assert n_ev.value == 0 and n_words.value in (24, 28, 34, 40, 44, 58, 64)
