@@ -1696,8 +1696,11 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         static const int forced_mode = [] { const char* e = getenv("SP1HIP_ZC_SCHEDULE"); return e ? atoi(e) : -1; }();
         SP1HIP_REQUIRE(forced_mode <= 3, "SP1HIP_ZC_SCHEDULE must be 0, 1, 2 or 3 (a debug knob; unset = try them)");
         // mode 3 (rematerialised loads: a ~3x longer program with a much smaller file) only where the file is the problem: when the
-        // best of the other orders needs at least this many registers (SP1HIP_ZC_LAZY_MIN_REGS; 128 = fewer than five waves' files per CU)
-        static const uint32_t lazy_min_regs = [] { const char* e = getenv("SP1HIP_ZC_LAZY_MIN_REGS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 128u; }();
+        // best of the other orders needs at least this many registers (SP1HIP_ZC_LAZY_MIN_REGS; 64 = two waves' files per CU). It was
+        // 128 while the secp256k1 / uint256 chips (195 - 225) were the only ones above 40; the tower / carry chips that came later
+        // (Bn254FpOpAssign 103, Uint256Ops 71, Bn254Fp2AddSubAssign 66: the same FieldOpCols programs) take the same form at 64;
+        // every chip with a measured schedule is below 40 and keeps it
+        static const uint32_t lazy_min_regs = [] { const char* e = getenv("SP1HIP_ZC_LAZY_MIN_REGS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 64u; }();
         uint32_t best_regs = 0xffffffffu;
         for (int mode = 0; mode < 4; mode++) {
             if (forced_mode >= 0 && mode != forced_mode) continue;

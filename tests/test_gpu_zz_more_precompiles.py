@@ -3,7 +3,8 @@ bytes == the oracle prover's and the oracle's verify_shard accepts, shard kind b
 programs differ most from the secp256k1 / UINT256_MUL chips that tests/test_gpu_riscv_exec.py already proves on the GPU:
 
     bls12381_fp     48-limb operands, witness offset 2^15, the operation-selected polynomial of FieldOpCols::eval_variable
-    bn254_fp        the same chip at 32 limbs: 103 extension registers in the zerocheck planner (the one-wave LDS tier)
+    bn254_fp        the same chip at 32 limbs (103 registers in the planner's kept-column orders: it takes the rematerialising
+                    schedule since the threshold moved to 64)
     ed_decompress   FieldSqrtCols (a FieldOpCols checked against another operation's result), one-coefficient operands
     uint256_ops     a + b + c / a * b + c with carry: five memory slices, three register reads, modulus 2^256
 
