@@ -36,3 +36,21 @@ def test_machine_rejects_malformed_documents(mutate):
     mutate(doc)
     with pytest.raises(ValueError):
         load_machine(json.dumps(doc))
+
+
+def test_the_whole_trusted_mode_machine_and_the_wrap_machine_round_trip():
+    """Every transcribed chip — the 62 supervisor-mode entries of the reference's cost table and the recursion wrap machine's nine —
+    through the JSON interchange document and back: same programs word for word (HINT pseudo-instructions included), same
+    interactions. This is the document a Rust exporter would write."""
+    from sp1_amd.machines import recursion as RC
+    from sp1_amd.machines import riscv as R
+    from sp1_amd.machines import riscv_more as M
+    names = sorted(set(R.CHIPS) | set(M.MORE_CHIPS))
+    assert len(names) == 62
+    for machine in ([R.chip(n) for n in names], RC.wrap_machine()):
+        loaded = load_machine(json.dumps(dump_machine(machine)))
+        assert [a.name for a, _ in loaded] == [a.name for a, _ in machine]
+        for (air, inter), (a0, i0) in zip(loaded, machine):
+            assert np.array_equal(air.to_array(), a0.to_array()) and air.num_constraints == a0.num_constraints, a0.name
+            assert np.array_equal(inter.to_array(), i0.to_array()), a0.name
+            assert (air.main_width, air.prep_width) == (a0.main_width, a0.prep_width)
