@@ -405,10 +405,10 @@ struct Vm {
     // fptower/*.rs): the second operand is read at clk, the first is read and rewritten at clk + 1; operands must be reduced
     // (the chips' carries only fit then) and the affine formulas have no special cases, as in the reference's.
     using BI = bigmod::Int;
-    // reads `n` words at `ptr` for a precompile: (previous timestamp, value) pairs appended to rec, the words returned; the cells'
-    // timestamps become `ts` when `stamp` (a read), stay for the caller to set otherwise (a slice that is rewritten)
     // what SyscallAddrOperation constrains (operations/syscall_addr.rs:L51-L93): 8-aligned, above the registers' 2^16, the slice below 2^48
     static bool slice_ok(uint64_t ptr, int n_words) { return !(ptr & 7) && ptr >= (1ull << 16) && ptr + 8 * (uint64_t)n_words <= (1ull << 48); }
+    // reads `n` words at `ptr` for a precompile: (previous timestamp, value) pairs appended to rec, the words returned; the cells'
+    // timestamps become `ts` when `stamp` (a read), stay for the caller to set otherwise (a slice that is rewritten)
     void read_words(uint64_t ptr, int n, uint64_t ts, bool stamp, std::vector<uint64_t>& rec, uint64_t* out) {
         for (int i = 0; i < n; ++i) { Cell& m = cell(ptr + 8 * i); touch_precompile(m, ptr + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); out[i] = m.val; if (stamp) m.ts = ts; }
     }
@@ -509,6 +509,7 @@ struct Vm {
         const BI y = bigmod::from_words(yw, 4);
         if (!F.reduced(y)) return fail("ED_DECOMPRESS: y is not a reduced field element (the sign bit travels in the second argument)");
         const BI yy = F.mul(y, y), u = F.sub(yy, bigmod::small(1)), v = F.add(F.mul(bigmod::from_words(ED25519_D_W, 4), yy), bigmod::small(1));
+        if (bigmod::is_zero(v)) return fail("ED_DECOMPRESS: d y^2 + 1 vanishes");
         const BI a = F.mul(u, F.inv(v));
         BI beta = F.pow(a, bigmod::from_words(ED25519_P_PLUS_3_OVER_8_W, 4));
         const BI bsq = F.mul(beta, beta);
