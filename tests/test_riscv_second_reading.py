@@ -1,6 +1,6 @@
 """A SECOND, independent reading of the rv64im trace layouts (VERDICT r4 #7a). riscv_trace.py fills the chips' columns with
 vectorised torch code written next to the transcription riscv.py; a reading error shared by the two (both made from the same
-reading of the reference) would pass every constraint test. Here the chip-specific columns of seven chips are filled AGAIN, row by
+reading of the reference) would pass every constraint test. Here the chip-specific columns of nine chips are filled AGAIN, row by
 row in plain Python integers, from the reference's own `populate` / `event_to_row` functions (cited per filler) given only each
 row's operands (opcode, b, c as the adapter's register reads show them) — and must equal what riscv_trace.py produced, cell for
 cell. The operands and the result `a` come from Python's own integer arithmetic, not from the executor."""
@@ -90,8 +90,50 @@ def fill_mul(op, b, c):                        # MulOperation::populate (operati
             "is_mul": [int(name == "MUL")], "is_mulh": [int(mulh)], "is_mulhu": [int(name == "MULHU")], "is_mulhsu": [int(mulhsu)], "is_mulw": [int(mulw)]}
 
 
-FILLERS = {"Add": fill_add, "Sub": fill_sub, "Addw": fill_addw, "Lt": fill_lt, "Bitwise": fill_bitwise, "Mul": fill_mul}
-COUNTS = {"Add": 12, "Sub": 12, "Addw": 12, "Lt": 24, "Bitwise": 24, "Mul": 30, "Addi": 4, "UType": 6, "LoadWord": 4, "StoreWord": 4, "Branch": 4}
+def fill_shift_left(op, b, c, imm):             # ShiftLeftChip::event_to_row (alu/sll/mod.rs:L224-L286)
+    sllw = op == R.OPC["SLLW"]
+    c0 = c & 0xFFFF
+    bit = c0 & 0xF
+    a = s32((b << (c0 & 0x1F)) & 0xFFFFFFFF) & M64 if sllw else (b << (c0 & 0x3F)) & M64
+    lower = [l & ((1 << (16 - bit)) - 1) for l in limbs(b)]
+    higher = [l >> (16 - bit) for l in limbs(b)]
+    amount = ((c0 >> 4) & 1) + 2 * ((c0 >> 5) & 1) * int(not sllw)
+    return {"a": limbs(a), "c_bits": [(c0 >> i) & 1 for i in range(6)], "v_01": [1 << (c0 & 3)], "v_012": [1 << (c0 & 7)], "v_0123": [1 << (c0 & 15)],
+            "shift_u16": [int(i == amount) for i in range(4)], "lower_limb": lower, "higher_limb": higher,
+            "limb_result": [(lower[i] << bit) + (higher[i - 1] if i else 0) for i in range(4)],
+            "sllw_msb": [((((b << (c0 & 0x1F)) & 0xFFFFFFFF) >> 31) & 1) if sllw else 0],
+            "is_sll": [int(not sllw)], "is_sllw": [int(sllw)], "is_sllw_imm": [int(sllw and imm)]}
+
+
+def fill_shift_right(op, b, c, imm):            # ShiftRightChip::event_to_row (alu/sr/mod.rs:L239-L312; is_w_imm: L185)
+    name = RT.OPC_NAME[op]
+    word, arith = name in ("SRLW", "SRAW"), name in ("SRA", "SRAW")
+    c0 = c & 0xFFFF
+    bit = c0 & 0xF
+    bl = limbs(b)
+    if word:
+        v = b & 0xFFFFFFFF
+        a = ((s32(v) >> (c0 & 0x1F)) if arith else s32(v >> (c0 & 0x1F))) & M64
+    else:
+        a = ((s64(b) >> (c0 & 0x3F)) if arith else (b >> (c0 & 0x3F))) & M64
+    b_msb = (bl[3] >> 15) if name == "SRA" else (bl[1] >> 15) if name == "SRAW" else 0
+    if word:
+        bl = bl[:2] + [0, 0]
+    lower = [l & ((1 << bit) - 1) for l in bl]
+    higher = [l >> bit for l in bl]
+    v0123 = 1 << (16 - (c0 & 15))
+    amount = ((c0 >> 4) & 1) + 2 * ((c0 >> 5) & 1) * int(not word)
+    return {"a": limbs(a), "b_msb": [b_msb], "srw_msb": [(limbs(a)[1] >> 15) if word else 0], "c_bits": [(c0 >> i) & 1 for i in range(6)],
+            "sra_msb_v0123": [b_msb * v0123], "v_0123": [v0123], "v_012": [1 << (8 - (c0 & 7))], "v_01": [1 << (4 - (c0 & 3))],
+            "lower_limb": lower, "higher_limb": higher,
+            "limb_result": [higher[i] + ((lower[i + 1] << (16 - bit)) if i < 3 else 0) for i in range(4)],
+            "shift_u16": [int(i == amount) for i in range(4)], "is_srl": [int(name == "SRL")], "is_sra": [int(name == "SRA")],
+            "is_srlw": [int(name == "SRLW")], "is_sraw": [int(name == "SRAW")], "is_w_imm": [int(word and imm)]}
+
+
+FILLERS = {"Add": fill_add, "Sub": fill_sub, "Addw": fill_addw, "Lt": fill_lt, "Bitwise": fill_bitwise, "Mul": fill_mul,
+           "ShiftLeft": fill_shift_left, "ShiftRight": fill_shift_right}
+COUNTS = {"Add": 12, "Sub": 12, "Addw": 12, "Lt": 24, "Bitwise": 24, "Mul": 30, "ShiftLeft": 24, "ShiftRight": 32, "Addi": 4, "UType": 6, "LoadWord": 4, "StoreWord": 4, "Branch": 4}
 
 
 def _word(main, row, col):
@@ -116,7 +158,7 @@ def test_second_reading_fills_the_same_rows(seed):
             op = opcode_of[tuple(int(x) for x in main[r, L["state.pc"]:L["state.pc"] + 3])]
             b = _word(main, r, L["adapter.op_b_memory.prev_value"])
             c = _word(main, r, L["adapter.op_c_memory.prev_value"])        # (ALU adapters keep an immediate's word here too)
-            want = fill(op, b, c)
+            want = fill(op, b, c, int(main[r, L["adapter.imm_c"]])) if name.startswith("Shift") else fill(op, b, c)
             for field, vals in want.items():
                 got = [int(v) for v in main[r, L[field]:L[field] + len(vals)]]
                 assert got == [v % P for v in vals], (name, r, field, RT.OPC_NAME[op], hex(b), hex(c))
@@ -146,3 +188,120 @@ def test_second_reading_of_divrem_agrees_with_python_arithmetic():
             q, rem = s32(q & 0xFFFFFFFF), s32(rem & 0xFFFFFFFF)
         want = (q if name.startswith("DIV") else rem) & M64
         assert _word(rows, r, L["a"]) == want, (name, b, c)
+
+
+def _pc(main, r, L):
+    return sum(int(main[r, L["state.pc"] + i]) << (16 * i) for i in range(3))
+
+
+def test_second_reading_of_the_control_flow_chips():
+    """Branch, UType, Jal, Jalr filled again from the reference's row builders — control_flow/branch/trace.rs:L134-L186 (flags,
+    `LtOperationSigned::populate_signed` on (a, b), next_pc, is_branching), utype/mod.rs:L262-L273 (addend = pc for AUIPC, the sum),
+    control_flow/jal/trace.rs:L57-L65 and jalr/trace.rs:L111-L128 (target, link value pc + 4 unless rd = x0, the target's low bit)
+    — from each row's pc, register values and immediates alone; the outcomes (taken or not, targets) are Python's."""
+    machine, tabs, _ = RT.generate({"Branch": 24, "UType": 8, "Jal": 6, "Jalr": 6, "Add": 4, "Addi": 4}, K=3, seed=41)
+    prog = tabs["Program"][0]
+    opcode_of = {tuple(int(x) for x in prog[r, 0:3]): int(prog[r, 3]) for r in range(prog.shape[0])}
+    checked = {}
+    for name in ("Branch", "UType", "Jal", "Jalr"):
+        air = R.chip(name)[0]
+        L = air.layout
+        main = tabs[name][1].numpy()
+        for r in range(main.shape[0]):
+            if name == "Branch":
+                if not any(main[r, L[k]] for k in ("is_beq", "is_bne", "is_blt", "is_bge", "is_bltu", "is_bgeu")):
+                    continue
+            elif main[r, L["is_real"]] == 0:
+                continue
+            pc = _pc(main, r, L)
+            op = RT.OPC_NAME[opcode_of[tuple(int(x) for x in main[r, L["state.pc"]:L["state.pc"] + 3])]]
+            if name == "Branch":
+                a, b = _word(main, r, L["adapter.op_a_memory.prev_value"]), _word(main, r, L["adapter.op_b_memory.prev_value"])
+                off = _word(main, r, L["adapter.op_c_imm"])
+                signed = op in ("BLT", "BGE")
+                lt = (s64(a) < s64(b)) if signed else a < b
+                taken = {"BEQ": a == b, "BNE": a != b, "BLT": lt, "BLTU": lt, "BGE": not lt, "BGEU": not lt}[op]
+                nxt = (pc + off) & M64 if taken else pc + 4
+                want = {"is_" + k.lower(): [int(op == k)] for k in ("BEQ", "BNE", "BLT", "BGE", "BLTU", "BGEU")}
+                want.update({"next_pc": limbs(nxt)[:3], "is_branching": [int(taken)], "cmp.b_msb": [a >> 63 if signed else 0], "cmp.c_msb": [b >> 63 if signed else 0]})
+                u = lt_unsigned(a ^ (1 << 63), b ^ (1 << 63)) if signed else lt_unsigned(a, b)
+                want.update({"cmp.result." + k: v for k, v in u.items()})
+            elif name == "UType":
+                imm = _word(main, r, L["adapter.op_b_imm"])
+                base = pc if op == "AUIPC" else 0
+                rd_is_x0 = int(main[r, L["adapter.op_a_0"]])
+                want = {"is_auipc": [int(op == "AUIPC")], "addend": limbs(base)[:3], "value": limbs(0 if rd_is_x0 else (base + imm) & M64)}
+            elif name == "Jal":
+                imm = _word(main, r, L["adapter.op_b_imm"])
+                rd_is_x0 = int(main[r, L["adapter.op_a_0"]])
+                want = {"next_pc": limbs((pc + imm) & M64), "op_a_value": limbs(0 if rd_is_x0 else pc + 4)}
+            else:
+                b, imm = _word(main, r, L["adapter.op_b_memory.prev_value"]), _word(main, r, L["adapter.op_c_imm"])
+                rd_is_x0 = int(main[r, L["adapter.op_a_0"]])
+                want = {"next_pc": limbs((b + imm) & M64), "op_a_value": limbs(0 if rd_is_x0 else pc + 4), "lsb": [(b + imm) & 1]}
+            for field, vals in want.items():
+                got = [int(v) for v in main[r, L[field]:L[field] + len(vals)]]
+                assert got == [v % P for v in vals], (name, r, field, op, hex(pc))
+            checked[name] = checked.get(name, 0) + 1
+    assert checked["Branch"] >= 72 and checked["UType"] >= 24 and checked["Jal"] >= 18 and checked["Jalr"] >= 18, checked
+
+
+def test_second_reading_of_the_load_and_store_chips():
+    """The eight memory-instruction chips filled again from memory/instructions/{load,store}/*.rs `event_to_row` (AddressOperation:
+    operations/address.rs:L38-L47; byte / half / word selection by the address's low bits; StoreByte's `increment`; the stored
+    word) from each row's base register, immediate, register value and the memory word BEFORE the access. The word after a store
+    is Python's own byte surgery."""
+    kinds = ("LoadByte", "LoadHalf", "LoadWord", "LoadDouble", "StoreByte", "StoreHalf", "StoreWord", "StoreDouble")
+    machine, tabs, _ = RT.generate({k: 12 for k in kinds} | {"Add": 4, "Addi": 4}, K=3, seed=43)
+    prog = tabs["Program"][0]
+    opcode_of = {tuple(int(x) for x in prog[r, 0:3]): int(prog[r, 3]) for r in range(prog.shape[0])}
+    checked = {}
+    for name in kinds:
+        air = R.chip(name)[0]
+        L = air.layout
+        main = tabs[name][1].numpy()
+        flags = [k for k in L if k.startswith("is_")]
+        for r in range(main.shape[0]):
+            if not any(main[r, L[k]] for k in flags):
+                continue
+            op = RT.OPC_NAME[opcode_of[tuple(int(x) for x in main[r, L["state.pc"]:L["state.pc"] + 3])]]
+            b, imm = _word(main, r, L["adapter.op_b_memory.prev_value"]), _word(main, r, L["adapter.op_c_imm"])
+            word = _word(main, r, L["memory_access.prev_value"])                  # the memory word before the access
+            addr = (b + imm) & M64
+            al = limbs(addr)
+            want = {"address.value": al[:3], "address.top_two_limb_inv": [inv(al[1] + al[2])]}
+            bit0, bit1, bit2 = addr & 1, (addr >> 1) & 1, (addr >> 2) & 1
+            wl = limbs(word)
+            if name == "LoadByte":
+                limb = wl[2 * bit2 + bit1]
+                byte = (limb >> (8 * bit0)) & 0xFF
+                want.update({"offset_bit": [bit0, bit1, bit2], "selected_limb": [limb], "selected_limb_low_byte": [limb & 0xFF], "selected_byte": [byte],
+                             "msb": [byte >> 7 if op == "LB" else 0], "is_lb": [int(op == "LB")], "is_lbu": [int(op == "LBU")]})
+            elif name == "LoadHalf":
+                limb = wl[2 * bit2 + bit1]
+                want.update({"offset_bit": [bit1, bit2], "selected_half": [limb], "msb": [limb >> 15 if op == "LH" else 0], "is_lh": [int(op == "LH")],
+                             "is_lhu": [int(op == "LHU")]})
+            elif name == "LoadWord":
+                want.update({"offset_bit": [bit2], "selected_word": wl[2 * bit2:2 * bit2 + 2], "msb": [wl[2 * bit2 + 1] >> 15 if op == "LW" else 0],
+                             "is_lw": [int(op == "LW")], "is_lwu": [int(op == "LWU")]})
+            elif name.startswith("Store"):
+                a = _word(main, r, L["adapter.op_a_memory.prev_value"])             # the register being stored
+                size = {"StoreByte": 1, "StoreHalf": 2, "StoreWord": 4, "StoreDouble": 8}[name]
+                shift = 8 * (addr & 7)
+                mask = ((1 << (8 * size)) - 1) << shift
+                new = (word & ~mask & M64) | ((a << shift) & mask)
+                if name == "StoreByte":
+                    limb, low = wl[2 * bit2 + bit1], a & 0xFF
+                    inc = (low - (limb & 0xFF)) * (1 - bit0) + (256 * low - limb + (limb & 0xFF)) * bit0
+                    want.update({"offset_bit": [bit0, bit1, bit2], "mem_limb": [limb], "mem_limb_low_byte": [limb & 0xFF], "register_low_byte": [low],
+                                 "increment": [inc], "store_value": limbs(new)})
+                elif name == "StoreHalf":
+                    want.update({"offset_bit": [bit1, bit2], "store_value": limbs(new)})
+                elif name == "StoreWord":
+                    want.update({"offset_bit": [bit2], "store_value": limbs(new)})
+                # StoreDouble keeps no copy of the stored word: the register value itself is what the access writes
+            for field, vals in want.items():
+                got = [int(v) for v in main[r, L[field]:L[field] + len(vals)]]
+                assert got == [v % P for v in vals], (name, r, field, op, hex(addr))
+            checked[name] = checked.get(name, 0) + 1
+    assert all(checked.get(k, 0) >= 36 for k in kinds), checked
