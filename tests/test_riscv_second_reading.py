@@ -305,3 +305,27 @@ def test_second_reading_of_the_load_and_store_chips():
                 assert got == [v % P for v in vals], (name, r, field, op, hex(addr))
             checked[name] = checked.get(name, 0) + 1
     assert all(checked.get(k, 0) >= 36 for k in kinds), checked
+
+
+def test_second_reading_of_addi_and_subw():
+    """The two remaining ALU chips: Addi is AddOperation on (register, immediate) (alu/add_sub/addi.rs; operations/add.rs:L33-L39),
+    Subw is SubwOperation (operations/subw.rs:L30-L38: the 32-bit difference's two limbs and its sign bit)."""
+    machine, tabs, _ = RT.generate({"Addi": 16, "Subw": 16, "Add": 4}, K=3, seed=47)
+    checked = {}
+    for name in ("Addi", "Subw"):
+        air = R.chip(name)[0]
+        L = air.layout
+        main = tabs[name][1].numpy()
+        for r in range(main.shape[0]):
+            if main[r, L["is_real"]] == 0:
+                continue
+            b = _word(main, r, L["adapter.op_b_memory.prev_value"])
+            if name == "Addi":
+                want = {"value": limbs((b + _word(main, r, L["adapter.op_c_imm"])) & M64)}
+            else:
+                v = (b - _word(main, r, L["adapter.op_c_memory.prev_value"])) & 0xFFFFFFFF
+                want = {"value": [v & 0xFFFF, v >> 16], "msb": [v >> 31]}
+            for field, vals in want.items():
+                assert [int(x) for x in main[r, L[field]:L[field] + len(vals)]] == vals, (name, r, field)
+            checked[name] = checked.get(name, 0) + 1
+    assert checked["Addi"] >= 48 and checked["Subw"] >= 48, checked
