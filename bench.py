@@ -96,11 +96,23 @@ def programs_of(kind, names):
 PROGRAMS = ("fibonacci", "loop", "keccak", "sha2", "poseidon2", "rsp")   # real guest programs: bench/program_shard.py
 
 
+RISCV_KINDS = ("real", "precompile") + PROGRAMS     # workloads of the rv64im machine: their shards carry PublicValues (meta["publics"])
+
+
 def publics_of(kind):
-    """The public values a workload's shard proofs carry: the real machines read PublicValues words (SyscallInstrs: commit /
-    exit-code words, all zero here: no COMMIT or HALT is executed), the synthetic shards have none."""
+    """The synthetic shards carry no public values; an rv64im shard's are its own (meta["publics"]: the record-level statement
+    `eval_public_values` closes the shard's buses with — sp1_amd/machines/public_values.py)."""
     import numpy as np
-    return np.zeros(160 if kind in ("real", "precompile") else 0, np.uint32)
+    assert kind not in RISCV_KINDS, "an rv64im shard is proved with ITS public values"
+    return np.zeros(0, np.uint32)
+
+
+def pv_program_of(kind):
+    """The machine's eval_public_values for the verifier: the RISC-V machine has one, the recursion machine and the synthetic shards none."""
+    if kind not in RISCV_KINDS:
+        return None
+    from sp1_amd.machines import public_values as PVM
+    return PVM.verifier_program()
 
 
 def build_workload(kind, k, L, seed):
@@ -213,7 +225,7 @@ def verify_child(path):
     ch = orc.Challenger()
     ch.observe(z["commit"])
     t0 = time.perf_counter()
-    rc = orc.shard_verify(shapes, z["commit"], z["proof"].tobytes(), L, lsh, ch, 2, 124, 16)
+    rc = orc.shard_verify(shapes, z["commit"], z["proof"].tobytes(), L, lsh, ch, 2, 124, 16, pv_program=pv_program_of(kind))
     print(json.dumps({"rc": int(rc), "seconds": time.perf_counter() - t0, "state_matches": bool(np.array_equal(ch.state(), z["state"]))}))
 
 
@@ -824,18 +836,19 @@ def main():
         traffic = d["hbm_bytes_pmc"] / dom_launches if d["hbm_bytes_pmc"] else None
         # (the essentials first: the driver's parse truncates long strings)
         if kind == "real":
-            workload_text = ("core shard, rv64im machine: %d real chips + %d closing chips, %d constraints, %d interactions, heights of "
-                             "the reference's recorded core shard 0, %d instructions executed"
-                             % (len(meta["real_chips"]), len(meta["synthetic_chips"]), meta["constraints"], meta["interactions"],
+            workload_text = ("core shard, rv64im machine: the %d chips of the core shape cluster (%d at height zero), %d constraints, %d interactions, "
+                             "heights of the reference's recorded core shard 0, %d instructions executed"
+                             % (len(meta["real_chips"]), len(meta["empty_chips"]), meta["constraints"], meta["interactions"],
                                 meta["instructions_executed"]))
         elif kind == "precompile":
-            workload_text = ("precompile shard: %d real chips (%s), %d constraints, %d interactions"
+            workload_text = ("precompile shard: the %d chips of the Keccak shape cluster (%s), %d constraints, %d interactions"
                              % (len(meta["real_chips"]), ", ".join(meta["real_chips"]), meta["constraints"], meta["interactions"]))
         elif kind in PROGRAMS:
             workload_text = ("core shard %d of the reference's `%s` guest ELF (%d cycles = executed rv64im instructions, %.1f cells per cycle): "
-                             "%d real chips + %d closing chips, %d constraints, %d interactions"
+                             "the %d chips of the reference's core shape cluster (%d without events, at height zero), %d constraints, %d interactions, "
+                             "the shard's own public values (eval_public_values closes its buses)"
                              % (meta["shard_index"], kind, meta["cycles"], meta["cells_per_cycle"], len(meta["real_chips"]),
-                                len(meta["synthetic_chips"]), meta["constraints"], meta["interactions"]))
+                                len(meta["empty_chips"]), meta["constraints"], meta["interactions"]))
         else:
             workload_text = ("core-shaped SYNTHETIC shard: %d chips, %d constraints, %d interactions"
                              % (meta["chips"], meta["constraints"], meta["interactions"]))
@@ -851,10 +864,10 @@ def main():
         out = {
             **headline, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": ("synthetic: traces of an rv64im test program executed by this repository's executor + 2 synthetic closing chips"
+            "dtype": "u32 (KoalaBear Montgomery words, exact integer arithmetic)", "data": ("synthetic: traces of an rv64im test program executed by this repository's executor"
                      if kind == "real" else "synthetic: seeded traces of real chips" if kind == "precompile"
                      else "the reference's guest binary (bench/programs/%s.elf.gz) on a synthetic input of sp1-gpu perf's form, executed by this "
-                          "repository's rv64im executor; 2 synthetic closing chips stand for eval_public_values" % kind if kind in PROGRAMS else "synthetic"),
+                          "repository's rv64im executor; the shard is the reference's machine (RiscvAir core cluster + eval_public_values)" % kind if kind in PROGRAMS else "synthetic"),
             "proofs_per_s": world * args.steps / dt, "cells_per_s": cells_per_s,
             "riscv_instructions_per_s": world * args.steps * cycles / dt if cycles else None,
             "config": {"workload": workload_text + "; %d cells%s, L %d, stack 2^%d, blowup 4, 124 queries, 16-bit PoW; one whole ShardProof "

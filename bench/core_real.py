@@ -6,10 +6,11 @@ recorded shard executes ~6.2e6 instructions of a 4.7e5-instruction program).
 What is real: EVERY chip of that shard (round 5 added DivRem, SyscallInstrs and SyscallCore: riscv_more.py) —
 the 25 instruction chips, MemoryLocal, MemoryBump, StateBump, Program, Byte, Range, SyscallCore and the septic-curve Global chip
 (a Poseidon2 permutation + curve arithmetic per row: a third of the shard's cells) — constraints, interactions, and traces
-with RISC-V semantics whose lookups balance. What is synthetic: two 2-row closing chips, `Boundary` and
-`GlobalAccBoundary`, standing in for the interactions of `eval_public_values` (initial / final CPU state, the two ends of
-the global digest chain). `real_global=False` swaps the Global chip for a sink + a filler of its recorded shape (the round-4
-intermediate workload; kept for A/B).
+with RISC-V semantics whose lookups balance against the shard's public values (`eval_public_values`,
+sp1_amd/machines/public_values.py: since round 6 the record's own messages close the State / GlobalAccumulation buses; the two
+synthetic closing chips of rounds 4-5 are gone and the shard is the reference's core shape cluster, chips without events at
+height zero). What is synthetic is the PROGRAM: a random rv64im loop, not a guest. `real_global=False` swaps the Global chip for
+a sink + a filler of its recorded shape (the round-4 intermediate workload; kept for A/B, not verifiable).
 """
 import os
 import sys
@@ -44,20 +45,20 @@ def to_col_major(t):
     return api.ColMajor(m.t().contiguous().view(-1), rows, width)
 
 
-SYNTHETIC = ("Boundary", "GlobalAccBoundary", "GlobalSink", "GlobalFiller")
+SYNTHETIC = ("GlobalSink", "GlobalFiller")
 
 
 def machine_only(scale=1.0, seed=1, K=K_ITER, device="cuda", real_global=True):
+    """(machine, tables, public values) of the executed loop at `scale` x the recorded heights."""
     counts = recorded_counts(scale, K)
     pages = max(4, int(600 * scale))
-    machine, tabs, _ = RT.generate(counts, K=K, seed=seed, mem_pages=(pages, pages), device=device, real_global=real_global)
-    return machine, tabs
+    return RT.generate(counts, K=K, seed=seed, mem_pages=(pages, pages), device=device, real_global=real_global)
 
 
 def build_real_shard(scale=1.0, seed=1, K=K_ITER, real_global=True):
     """[(AirProgram, InteractionProgram, main ColMajor, prep ColMajor | None)] in chip-name order + meta, on cuda."""
     from core_shard import chip_programs, chip_trace
-    machine, tabs = machine_only(scale, seed, K, "cuda", real_global)
+    machine, tabs, publics = machine_only(scale, seed, K, "cuda", real_global)
     chips = {a.name: (a, i, to_col_major(tabs[a.name][1]), to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
              for a, i in machine}
     real_area = sum(c[2].height * (c[2].width + (c[3].width if c[3] is not None else 0)) for n, c in chips.items()
@@ -79,6 +80,7 @@ def build_real_shard(scale=1.0, seed=1, K=K_ITER, real_global=True):
                          "instr_per_constraint": round(len(a.instrs) / a.num_constraints, 2) if a.num_constraints else None}
                 for a, i, m, _ in out}
     meta = {"chips": len(out), "real_chips": sorted(n for n in chips if n not in synthetic), "synthetic_chips": synthetic,
+            "empty_chips": sorted(c[0].name for c in out if c[2].height == 0), "publics": RT.to_monty_np(publics),
             "area_cells": area, "real_area_cells": real_area, "interactions": sum(c[1].num_interactions for c in out),
             "constraints": sum(c[0].num_constraints for c in out),
             "first_layer_entries": sum(c[2].height * c[1].num_interactions for c in out),
@@ -91,12 +93,8 @@ def programs_for(names):
     from core_shard import chip_programs
     out = []
     for n in names:
-        if n == "Boundary":
-            out.append(RT.boundary_chip())
-        elif n == "GlobalSink":
+        if n == "GlobalSink":
             out.append(RT.global_sink_chip())
-        elif n == "GlobalAccBoundary":
-            out.append(RT.global_acc_boundary_chip())
         elif n == "GlobalFiller":
             w, ncons, nint = R.RECORDED["Global"]
             out.append(chip_programs("GlobalFiller", w, 0, ncons, nint))

@@ -43,10 +43,13 @@ def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
     max_cycles = FULL_CYCLES_OF[program] >> (2 * k)
     elf = X.guest_file(program + ".elf")
     ex = X.Executor(elf, stdin=stdin_of(program, (shard_index + 1) * max_cycles + max_cycles // 8))
-    for i in range(shard_index + 1):                         # the shards before this rank's run without keeping their events
+    prev = None
+    for i in range(shard_index + 1):                         # the shards before this rank's run without keeping their events;
         shard = ex.run_shard(max_cycles, record=i == shard_index, copy=False)
+        if i < shard_index:                                  # their public values chain into this shard's prev_* words
+            prev = X.execution_public_values(shard, prev)
     assert shard.cycles == max_cycles and not shard.halted, "the run is too short for a full shard %d" % shard_index
-    machine, tabs, publics = X.shard_tables(ex, shard, device)
+    machine, tabs, publics = X.shard_tables(ex, shard, device, prev=prev)
     out = []
     for a, i in machine:
         prep, main = tabs[a.name]
@@ -57,6 +60,7 @@ def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
     per_chip = {a.name: {"rows": m.height, "columns": a.main_width + a.prep_width, "constraints": a.num_constraints,
                          "interactions": i.num_interactions, "instructions": len(a.instrs)} for a, i, m, _ in out}
     meta = {"chips": len(out), "real_chips": sorted(c[0].name for c in out if c[0].name not in synthetic), "synthetic_chips": synthetic,
+            "empty_chips": sorted(c[0].name for c in out if c[2].height == 0),
             "area_cells": area, "real_area_cells": area - sum(c[2].height * c[2].width for c in out if c[0].name in synthetic),
             "interactions": sum(c[1].num_interactions for c in out), "constraints": sum(c[0].num_constraints for c in out),
             "first_layer_entries": sum(c[2].height * c[1].num_interactions for c in out),

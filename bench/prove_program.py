@@ -44,7 +44,7 @@ def main():
     import numpy as np
     import torch
     from program_shard import FULL_CYCLES_OF, stdin_of
-    from sp1_amd.machines import riscv_exec as X, riscv_trace as RT
+    from sp1_amd.machines import public_values as PVM, riscv_exec as X, riscv_trace as RT
     device = "cpu" if args.dry_run else "cuda"
     if not args.dry_run:
         from core_real import to_col_major
@@ -58,7 +58,7 @@ def main():
     ex = X.Executor(X.guest_file(args.program + ".elf"), stdin=stdin_of(args.program, args.cycles or 3 * FULL_CYCLES_OF[args.program]))
     if not args.shard_cycles:
         ex.cut_by_area()
-    shards, gevs, kept, cycles, last, resident = [], [], {}, 0, None, []
+    shards, gevs, kept, cycles, last, resident, pvs, pk, pk_prep = [], [], {}, 0, None, [], [], None, None
     t_all = time.perf_counter()
     t_prev = t_all
     gen = X.program_shards(ex, shard_cycles, device=device, core_limit=args.core_shards or None)
@@ -77,15 +77,25 @@ def main():
             row["cycles"], row["estimated_cells"] = sh.cycles, sh.estimated_area
             cycles, last = cycles + sh.cycles, sh
         gevs.append(gev.cpu())
+        pvs.append([int(v) for v in publics])
         if not args.dry_run:
-            chips = [(a, i, to_col_major(tabs[a.name][1]), to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None) for a, i in machine]
+            # ONE proving key per program (sp1hip_setup: the preprocessed commitment of Program / Byte / Range + the verifying key):
+            # every shard of the run — core, precompile, memory — is a shape cluster that holds those three chips
+            row["setup_ms"] = 0.0
+            if pk is None:
+                t0 = time.perf_counter()
+                pk_prep = {a.name: to_col_major(tabs[a.name][0]) for a, _ in machine if tabs[a.name][0] is not None}
+                # the verifying key's words (Montgomery form, like everything the transcript absorbs): the entry pc, and the digest of
+                # the program's memory image — empty here: this executor initialises image words through MemoryGlobalInit rows
+                vk_words = RT.to_monty_np(torch.tensor(PVM.addr_limbs(sh.pc_start) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[0]) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[1])))
+                pk = api.ProvingKey([pk_prep[n] for n in sorted(pk_prep)], L, lsh, 32, pc_start=vk_words[:3], initial_global_cumulative_sum=vk_words[3:])
+                torch.cuda.synchronize()
+                row["setup_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+            assert sorted(a.name for a, _ in machine if tabs[a.name][0] is not None) == sorted(pk_prep), "a shard without the program's preprocessed chips"
+            chips = [(a, i, to_col_major(tabs[a.name][1]), pk_prep.get(a.name)) for a, i in machine]
             tabs.clear()
             pv = RT.to_monty_np(publics)
-            t0 = time.perf_counter()
-            pk = api.ProvingKey([c[3] for c in chips if c[3] is not None], L, lsh, 32)     # sp1hip_setup: the preprocessed commitment + vk
             commit = pk.preprocessed_commit
-            torch.cuda.synchronize()
-            row["setup_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
             api.check(lib.sp1hip_timers_reset())
             t0 = time.perf_counter()
             proof = pk.prove_shard(chips, pv)                                             # from the transcript head vk.observe_into leaves
@@ -103,7 +113,7 @@ def main():
                 resident.append((pk, chips, pv, proof))
                 torch.cuda.empty_cache()                                                  # the tracer's int64 intermediates go back to the driver
             else:
-                del chips, pk
+                del chips
         shards.append(row)
         print(json.dumps(row), file=sys.stderr, flush=True)
         if args.max_shards and len(shards) >= args.max_shards:
@@ -122,6 +132,12 @@ def main():
         out["note"] = out_note
     if whole:
         out["global_messages_cancel"] = not X.global_events_balance(gevs)
+        # what SP1Prover::verify checks across the shards before it verifies each: the public values chain from the entry point to
+        # HALT (timestamps, pcs, exit codes, digests, address chains) and the shards' septic digests add up to zero
+        kinds_seen = [s["kind"] for s in shards]
+        first_core = next(i for i, k_ in enumerate(kinds_seen) if k_ == "core")
+        entry = sum(v << (16 * j) for j, v in enumerate(PVM.get(pvs[first_core], "pc_start")))
+        out["public_values_chain"] = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds_seen)], entry) or "ok"
     if not args.dry_run:
         prove_s = sum(s["prove_ms"] for s in shards) / 1e3
         out.update({"prove_seconds": round(prove_s, 4), "setup_seconds": round(sum(s["setup_ms"] for s in shards) / 1e3, 4),
@@ -182,9 +198,12 @@ def main():
             for kind, (machine, commit, proof) in kept.items():
                 shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None) for a, i in machine]
                 v_ch = orc.Challenger()
-                v_ch.observe(np.concatenate([commit, np.zeros(3 + 14 + 7, np.uint32)]))   # vk.observe_into: commit, pc_start, septic x / y, flag, 6 zeros
+                v_ch.observe(np.concatenate([commit, vk_words, np.zeros(7, np.uint32)]))   # vk.observe_into: commit, pc_start, septic x / y, flag, 6 zeros
+                head = api.DuplexChallenger()
+                pk.observe_into(head)
+                assert np.array_equal(head.state(), v_ch.state()), "the verifier's transcript head differs from sp1hip_vk_observe_into's"
                 t0 = time.perf_counter()
-                rc = orc.shard_verify(shapes, commit, proof, L, lsh, v_ch, 2, 124, 16)
+                rc = orc.shard_verify(shapes, commit, proof, L, lsh, v_ch, 2, 124, 16, pv_program=PVM.verifier_program())
                 ver[kind] = {"rc": int(rc), "seconds": round(time.perf_counter() - t0, 2)}
             out["verified_first_of_kind"] = ver
     out["per_shard"] = shards

@@ -106,6 +106,34 @@ static inline int gkr_beta_seed_dim(const std::vector<GkrChip>& chips) {
     return log2_ceil(arity);
 }
 
+// `MachineRecord::eval_public_values` of a machine as data (sp1_amd/machines/public_values.py builds the RISC-V record's,
+// /root/reference/crates/core/executor/src/record.rs:L879-L906): constraints over the public words alone and the record's own
+// sends / receives, evaluated on the "row" of public values. A machine without one (the recursion machine: the trait's
+// default body is empty) has no constraints, no interactions and `interactions_in_public_values()` = [].
+struct PvProgram {
+    ZcAir air;                                   // main_width = prep_width = 0; loads are ZC_PUBLIC / ZC_CONST
+    std::vector<GkrInteraction> interactions;    // VCol "main" columns index the public values
+    int num_pv_elts = 0;                         // machine.num_pv_elts(): words beyond it must be zero (verifier/shard.rs:L455-L464)
+    int proof_max_num_pvs = 0;                   // PROOF_MAX_NUM_PVS, the length a ShardProof carries (0 = unchecked)
+    size_t max_kind_arity = 1;                   // max over interactions_in_public_values() of num_values + 1 (verifier.rs:L120-L124)
+};
+
+// LogUpGkrVerifier::verify_public_values (verifier.rs:L74-L96): the constraints folded with `challenge` must vanish; returns
+// the local interaction digest sum_sends m / (alpha + betas . (kind, values)) - sum_receives (folder.rs:L598-L620).
+static inline bool verify_public_values(const PvProgram& pvp, const E& challenge, const E& alpha, const std::vector<E>& betas,
+                                        const std::vector<F>& publics, E* digest) {
+    if (eval_constraints_horner(pvp.air, nullptr, nullptr, publics.data(), challenge) != E::zero()) return false;
+    E acc = E::zero();
+    for (auto& in : pvp.interactions) {
+        if (1 + in.values.size() > betas.size()) throw std::runtime_error("public-values interaction wider than the beta table");
+        F m; E d;
+        interaction_vals(in, nullptr, publics.data(), alpha, betas, &m, &d);     // m carries the sign: + send, - receive
+        acc += E::from_base(m) * einv(d);
+    }
+    *digest = acc;
+    return true;
+}
+
 // the rounds of a dense degree-3 sumcheck of sum_x eq[x] (lambda (n0 d1 + n1 d0) + d0 d1)[x] over 2^|pts| entries, binding the
 // LAST variable first; pts[r] = coordinate of the variable round r binds (the root of the eq factor needs it). eq carries
 // every factor already bound. Tables and claim are updated in place; messages / challenges are appended.
@@ -449,13 +477,28 @@ static inline GkrProof gkr_prove_sparse(const std::vector<GkrChip>& chips, int L
 
 // verify_logup_gkr. heights[k] = real rows of chip k. check_interactions = false skips the cumulative-sum
 // and the final interaction check (used on the reference's real proof, whose chips are not available).
+// `pvp` / `publics`: the machine's eval_public_values and the shard's public values; null = a machine without one (cumulative
+// sum zero). Codes: 4 = cumulative sum mismatch, 9 = the public values violate their constraints.
 static inline int gkr_verify(const std::vector<GkrChip>& chips, const std::vector<size_t>& heights, int L, const GkrProof& proof,
-                             bool check_interactions, int beta_seed_dim_override, Challenger& ch) {
-    const int beta_seed_dim = beta_seed_dim_override >= 0 ? beta_seed_dim_override : gkr_beta_seed_dim(chips);
+                             bool check_interactions, int beta_seed_dim_override, Challenger& ch, const PvProgram* pvp = nullptr,
+                             const std::vector<F>* publics = nullptr) {
+    int beta_seed_dim = beta_seed_dim_override >= 0 ? beta_seed_dim_override : gkr_beta_seed_dim(chips);
+    if (beta_seed_dim_override < 0 && pvp) {     // max(max_interaction_arity, max_interaction_kinds_values) (verifier.rs:L112-L126)
+        size_t arity = pvp->max_kind_arity;
+        for (auto& c : chips) for (auto& i : c.interactions) arity = std::max(arity, i.values.size() + 1);
+        beta_seed_dim = log2_ceil(arity);
+    }
     if (!ch.check_witness(GKR_GRINDING_BITS, proof.witness)) return 1;
     const E alpha = ch.sample_ext();
     const std::vector<E> beta_seed = sample_point(ch, beta_seed_dim);
-    (void)ch.sample_ext();
+    const E pv_challenge = ch.sample_ext();
+    E cumulative_sum = E::zero();
+    if (pvp && check_interactions) {
+        if (!publics) return 9;
+        E digest;
+        if (!verify_public_values(*pvp, pv_challenge, alpha, partial_lagrange(beta_seed), *publics, &digest)) return 9;
+        cumulative_sum = -digest;
+    }
     size_t num_interactions = 0;
     for (auto& c : chips) num_interactions += c.interactions.size();
     const int niv = check_interactions ? log2_ceil(num_interactions) : log2_ceil(proof.numerator.size()) - 1;
@@ -469,7 +512,7 @@ static inline int gkr_verify(const std::vector<GkrChip>& chips, const std::vecto
     if (check_interactions) {
         E sum = E::zero();
         for (size_t k = 0; k < expected; k++) sum += proof.numerator[k] * einv(proof.denominator[k]);
-        if (sum != E::zero()) return 4;              // cumulative sum of a shard without public-value interactions
+        if (sum != cumulative_sum) return 4;         // output_cumulative_sum != cumulative_sum (verifier.rs:L168-L181)
     }
     std::vector<E> eval_point = sample_point(ch, niv + 1);
     E num_eval = eval_ext_mle_at_point(proof.numerator, eval_point), den_eval = eval_ext_mle_at_point(proof.denominator, eval_point);

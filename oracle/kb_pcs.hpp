@@ -89,7 +89,7 @@ static inline MerkleTree merkle_commit(const std::vector<TensorRef>& ts) {
     while (((size_t)1 << mt.log_height) < h) mt.log_height++;
     std::vector<Digest> cur(h);
     const bool use_simd = simd::simd_available();
-    if (use_simd && h >= 16) {                               // sixteen rows per permutation (kb_simd.hpp)
+    if (use_simd && h >= 16 && h % 16 == 0) {                // sixteen rows per permutation (kb_simd.hpp); any other height: the scalar sponge
         std::vector<simd::RowSrc> src;
         for (auto& t : ts) src.push_back(simd::RowSrc{t.data, t.width});
 #pragma omp parallel for schedule(static)
@@ -107,7 +107,7 @@ static inline MerkleTree merkle_commit(const std::vector<TensorRef>& ts) {
     while (mt.layers.back().size() > 1) {
         const std::vector<Digest>& prev = mt.layers.back();
         std::vector<Digest> next(prev.size() / 2);
-        if (use_simd && next.size() >= 16) {
+        if (use_simd && next.size() >= 16 && next.size() % 16 == 0) {
 #pragma omp parallel for schedule(static)
             for (size_t i = 0; i < next.size(); i += 16) simd::compress16(prev.data(), i, next.data());
         } else {

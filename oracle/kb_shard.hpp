@@ -189,11 +189,17 @@ static inline ShardProof shard_prove(const std::vector<ShardChip>& chips, const 
 
 // verify_shard. with_chips = false: everything that does not need chip definitions (used on the reference's real
 // proof; `beta_seed_dim` must then be given). Returns 0 when accepted.
+// `pvp`: the machine's eval_public_values (kb_gkr.hpp PvProgram) or null for a machine without one. Code 4: public values of
+// the wrong length or non-zero beyond the machine's words.
 static inline int shard_verify(const std::vector<ShardChip>& chips, const Digest& preprocessed_commit, const ShardProof& proof,
-                               const ShardParams& sp, bool with_chips, int beta_seed_dim, Challenger& ch) {
+                               const ShardParams& sp, bool with_chips, int beta_seed_dim, Challenger& ch, const PvProgram* pvp = nullptr) {
     const int L = sp.max_log_row_count;
     const size_t n = proof.names.size();
     if (proof.degree_bits != (size_t)L + 1) return 1;
+    if (pvp && pvp->proof_max_num_pvs) {             // verifier/shard.rs:L455-L464
+        if (proof.public_values.size() != (size_t)pvp->proof_max_num_pvs || proof.public_values.size() < (size_t)pvp->num_pv_elts) return 4;
+        for (size_t i = pvp->num_pv_elts; i < proof.public_values.size(); i++) if (proof.public_values[i] != F::zero()) return 4;
+    }
     for (auto& x : proof.public_values) ch.observe(x);
     ch.observe_digest(proof.main_commitment);
     ch.observe(F::from_canonical((uint32_t)n));
@@ -212,7 +218,8 @@ static inline int shard_verify(const std::vector<ShardChip>& chips, const Digest
         }
     }
     if (proof.gkr.chip_names != proof.names) return 2;
-    if (int rc = gkr_verify(gkr_chips_of(chips), proof.heights, L, proof.gkr, with_chips, with_chips ? -1 : beta_seed_dim, ch))
+    if (int rc = gkr_verify(gkr_chips_of(chips), proof.heights, L, proof.gkr, with_chips, with_chips ? -1 : beta_seed_dim, ch, pvp,
+                            &proof.public_values))
         return 100 + rc;
     const E batching = ch.sample_ext(), gkr_batch = ch.sample_ext();
     if (with_chips) {

@@ -462,11 +462,39 @@ size_t orc_gkr_prove(int n_chips, const char** names, const uint32_t** progs, co
     return b.size();
 }
 
+// A machine's eval_public_values (kb_gkr.hpp PvProgram) from the two program encodings of sp1_amd/air.py: `zc_prog` [zc_len][3]
+// (PUBLIC / CONST loads only), `gkr_prog` = one InteractionProgram whose main columns are the public words. Null zc_prog = none.
+static bool make_pv_program(const uint32_t* zc_prog, int zc_len, int n_constraints, const uint32_t* gkr_prog, int num_pv_elts,
+                            int proof_max_num_pvs, int max_kind_arity, PvProgram* out) {
+    if (!zc_prog) return false;
+    const int zero = 0;
+    const uint32_t* zp[1] = {zc_prog};
+    out->air = make_airs(1, zp, &zc_len, &zero, &zero, &n_constraints)[0];
+    for (auto& in : out->air.prog) {
+        if (in.op == ZC_LOAD_MAIN || in.op == ZC_LOAD_PREP) throw std::runtime_error("public-values constraints read a trace column");
+        if (in.op == ZC_PUBLIC && in.a >= (uint32_t)num_pv_elts) throw std::runtime_error("public value index out of range");
+    }
+    const char* name = "PublicValues";
+    const uint32_t* gp[1] = {gkr_prog};
+    out->interactions = make_gkr_chips(1, &name, gp, &num_pv_elts, &zero, nullptr, nullptr, nullptr)[0].interactions;
+    for (auto& in : out->interactions) {
+        std::vector<const VCol*> cols{&in.multiplicity};
+        for (auto& v : in.values) cols.push_back(&v);
+        for (const VCol* v : cols)
+            for (auto& t : v->terms)
+                if (!std::get<0>(t) || std::get<1>(t) < 0 || std::get<1>(t) >= num_pv_elts) throw std::runtime_error("public-values interaction column out of range");
+    }
+    out->num_pv_elts = num_pv_elts; out->proof_max_num_pvs = proof_max_num_pvs; out->max_kind_arity = (size_t)max_kind_arity;
+    return true;
+}
+
 // 0 = accepted; > 0 = error code of the restated verifier; -1 = malformed blob. With check_interactions == 0 the
-// chips are ignored (n_chips may be 0) and beta_seed_dim must be given.
-int orc_gkr_verify(int n_chips, const char** names, const uint32_t** progs, const int* main_w, const int* prep_w,
-                   const uint64_t* heights, int L, const uint8_t* blob, size_t len, int check_interactions, int beta_seed_dim,
-                   void* challenger) {
+// chips are ignored (n_chips may be 0) and beta_seed_dim must be given. pv_*: the machine's eval_public_values and the shard's
+// public values (Montgomery words); pv_zc_prog == null = a machine without one.
+int orc_gkr_verify_pv(int n_chips, const char** names, const uint32_t** progs, const int* main_w, const int* prep_w,
+                      const uint64_t* heights, int L, const uint8_t* blob, size_t len, int check_interactions, int beta_seed_dim,
+                      void* challenger, const uint32_t* pv_zc_prog, int pv_zc_len, int pv_n_constraints, const uint32_t* pv_gkr_prog,
+                      int num_pv_elts, int max_kind_arity, const uint32_t* publics, int n_publics) {
     try {
         GkrProof p = deserialize_gkr_proof(blob, len);
         std::vector<GkrChip> chips;
@@ -475,11 +503,24 @@ int orc_gkr_verify(int n_chips, const char** names, const uint32_t** progs, cons
             chips = make_gkr_chips(n_chips, names, progs, main_w, prep_w, nullptr, nullptr, nullptr);
             hs.assign(heights, heights + n_chips);
         }
+        PvProgram pvp;
+        const bool has_pv = make_pv_program(pv_zc_prog, pv_zc_len, pv_n_constraints, pv_gkr_prog, num_pv_elts, 0, max_kind_arity, &pvp);
+        std::vector<F> pv(has_pv ? n_publics : 0);
+        if (has_pv) {
+            if (n_publics < num_pv_elts) return 9;
+            memcpy(pv.data(), publics, (size_t)n_publics * 4);
+        }
         return gkr_verify(chips, hs, L, p, check_interactions != 0, check_interactions ? -1 : beta_seed_dim,
-                          *static_cast<Challenger*>(challenger));
+                          *static_cast<Challenger*>(challenger), has_pv ? &pvp : nullptr, has_pv ? &pv : nullptr);
     } catch (const std::exception&) {
         return -1;
     }
+}
+int orc_gkr_verify(int n_chips, const char** names, const uint32_t** progs, const int* main_w, const int* prep_w,
+                   const uint64_t* heights, int L, const uint8_t* blob, size_t len, int check_interactions, int beta_seed_dim,
+                   void* challenger) {
+    return orc_gkr_verify_pv(n_chips, names, progs, main_w, prep_w, heights, L, blob, len, check_interactions, beta_seed_dim, challenger,
+                             nullptr, 0, 0, nullptr, 0, 1, nullptr, 0);
 }
 
 // ---- whole shard proof ------------------------------------------------------------------------------------
@@ -522,20 +563,33 @@ void orc_set_gkr_sparse(int on) { g_gkr_sparse = on; }
 void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void orc_stage_seconds(double* out4) { for (int k = 0; k < 4; k++) out4[k] = g_stage_seconds[k]; }
 
-// with_chips == 0: n may be 0; everything chip-independent is checked (the reference's real proof)
-int orc_shard_verify(int n, const char** names, const uint32_t** zc_progs, const int* zc_lens, const int* main_w, const int* prep_w,
-                     const int* n_constraints, const uint32_t** gkr_progs, const uint32_t* prep_commit8, const uint8_t* blob,
-                     size_t len, int L, int lsh, int log_blowup, int num_queries, int pow_bits, int with_chips, int beta_seed_dim,
-                     void* challenger) {
+// with_chips == 0: n may be 0; everything chip-independent is checked (the reference's real proof).
+// pv_*: the machine's eval_public_values (make_pv_program); pv_zc_prog == null = a machine without one.
+int orc_shard_verify_pv(int n, const char** names, const uint32_t** zc_progs, const int* zc_lens, const int* main_w, const int* prep_w,
+                        const int* n_constraints, const uint32_t** gkr_progs, const uint32_t* prep_commit8, const uint8_t* blob,
+                        size_t len, int L, int lsh, int log_blowup, int num_queries, int pow_bits, int with_chips, int beta_seed_dim,
+                        void* challenger, const uint32_t* pv_zc_prog, int pv_zc_len, int pv_n_constraints, const uint32_t* pv_gkr_prog,
+                        int num_pv_elts, int proof_max_num_pvs, int max_kind_arity) {
     try {
         ShardProof p = deserialize_shard_proof(blob, len);
         std::vector<ShardChip> chips;
         if (with_chips) chips = make_shard_chips(n, names, zc_progs, zc_lens, main_w, prep_w, n_constraints, gkr_progs, nullptr, nullptr, nullptr);
         ShardParams sp{L, lsh, 0, FriConfig{log_blowup, num_queries, pow_bits}};
-        return shard_verify(chips, load_d(prep_commit8), p, sp, with_chips != 0, beta_seed_dim, *static_cast<Challenger*>(challenger));
+        PvProgram pvp;
+        const bool has_pv = make_pv_program(pv_zc_prog, pv_zc_len, pv_n_constraints, pv_gkr_prog, num_pv_elts, proof_max_num_pvs, max_kind_arity, &pvp);
+        if (has_pv && p.public_values.size() < (size_t)num_pv_elts) return 4;
+        return shard_verify(chips, load_d(prep_commit8), p, sp, with_chips != 0, beta_seed_dim, *static_cast<Challenger*>(challenger),
+                            has_pv ? &pvp : nullptr);
     } catch (const std::exception&) {
         return -1;
     }
+}
+int orc_shard_verify(int n, const char** names, const uint32_t** zc_progs, const int* zc_lens, const int* main_w, const int* prep_w,
+                     const int* n_constraints, const uint32_t** gkr_progs, const uint32_t* prep_commit8, const uint8_t* blob,
+                     size_t len, int L, int lsh, int log_blowup, int num_queries, int pow_bits, int with_chips, int beta_seed_dim,
+                     void* challenger) {
+    return orc_shard_verify_pv(n, names, zc_progs, zc_lens, main_w, prep_w, n_constraints, gkr_progs, prep_commit8, blob, len, L, lsh,
+                               log_blowup, num_queries, pow_bits, with_chips, beta_seed_dim, challenger, nullptr, 0, 0, nullptr, 0, 0, 1);
 }
 
 // ---- BabyBear commit path (bb_commit.hpp): mles [n][w_k] row-major Montgomery words (R = 2^32 mod the BabyBear prime)

@@ -93,6 +93,8 @@ def lib():
                                       C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t]
         L.orc_shard_verify.argtypes = [C.c_int, cpp, C.POINTER(u32p), ip, ip, ip, ip, C.POINTER(u32p), u32p, C.POINTER(C.c_uint8),
                                        C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_gkr_verify_pv.argtypes = L.orc_gkr_verify.argtypes + [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, u32p, C.c_int]
+        L.orc_shard_verify_pv.argtypes = L.orc_shard_verify.argtypes + [u32p, C.c_int, C.c_int, u32p, C.c_int, C.c_int, C.c_int]
         L.orc_stage_seconds.argtypes = [C.POINTER(C.c_double)]
         L.orc_set_gkr_sparse.argtypes = [C.c_int]
         L.orc_set_threads.argtypes = [C.c_int]
@@ -602,12 +604,27 @@ def gkr_prove(chips, max_log_row_count, challenger):
     return bytes(buf)
 
 
-def gkr_verify(chips, heights, max_log_row_count, blob, challenger):
-    """LogUpGkrVerifier::verify_logup_gkr with the final interaction check; 0 = accepted."""
+def _pv_program_args(pv_program):
+    """pv_program: None, or the machine's eval_public_values as (AirProgram over PUBLIC words, InteractionProgram over the row of
+    public values, max interaction-kind arity, PROOF_MAX_NUM_PVS) — sp1_amd/machines/public_values.py."""
+    if pv_program is None:
+        return (None, 0, 0, None, 0), 0, 1, None
+    air, it, max_arity, max_pvs = pv_program
+    zc = np.ascontiguousarray(air.to_array(), dtype=np.uint32)
+    gk = np.ascontiguousarray(it.to_array(), dtype=np.uint32)
+    return (_p(zc), zc.shape[0], air.num_constraints, _p(gk), it.main_width), max_pvs, max_arity, (zc, gk)
+
+
+def gkr_verify(chips, heights, max_log_row_count, blob, challenger, pv_program=None, publics=None):
+    """LogUpGkrVerifier::verify_logup_gkr with the final interaction check; 0 = accepted. `pv_program` / `publics`: the
+    machine's eval_public_values and the shard's public values (the cumulative sum the circuit output must have)."""
     n, names, progs, mw, pw, _, _, _, keep = _gkr_chip_args(chips)
     hs = (C.c_uint64 * n)(*heights)
     buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
-    return lib().orc_gkr_verify(n, names, progs, mw, pw, hs, max_log_row_count, buf, C.c_size_t(len(blob)), 1, -1, challenger.h)
+    (zc, zl, nc, gk, npv), _, max_arity, keep2 = _pv_program_args(pv_program)
+    pv = _arr(publics).reshape(-1) if publics is not None else np.zeros(0, dtype=np.uint32)
+    return lib().orc_gkr_verify_pv(n, names, progs, mw, pw, hs, max_log_row_count, buf, C.c_size_t(len(blob)), 1, -1, challenger.h,
+                                   zc, zl, nc, gk, npv, max_arity, _p(pv) if pv.size else None, int(pv.size))
 
 
 def gkr_verify_transcript_only(max_log_row_count, blob, beta_seed_dim, challenger):
@@ -680,12 +697,14 @@ def stage_seconds():
     return dict(zip(("commit", "logup_gkr", "zerocheck", "evaluation_proof"), list(out)))
 
 
-def shard_verify(chips, prep_commit, blob, L, lsh, challenger, log_blowup=2, num_queries=124, pow_bits=16):
-    """ShardVerifier::verify_shard with every chip-dependent check; 0 = accepted."""
+def shard_verify(chips, prep_commit, blob, L, lsh, challenger, log_blowup=2, num_queries=124, pow_bits=16, pv_program=None):
+    """ShardVerifier::verify_shard with every chip-dependent check; 0 = accepted. `pv_program`: the machine's
+    eval_public_values (_pv_program_args) — the RISC-V machine has one, the recursion machine does not."""
     n, names, zc, zl, mw, pw, nc, gk, _, _, _, keep = _shard_chip_args(chips)
     buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
-    return lib().orc_shard_verify(n, names, zc, zl, mw, pw, nc, gk, _p(_arr(prep_commit)), buf, C.c_size_t(len(blob)), L, lsh,
-                                  log_blowup, num_queries, pow_bits, 1, -1, challenger.h)
+    (pzc, pzl, pnc, pgk, npv), max_pvs, max_arity, keep2 = _pv_program_args(pv_program)
+    return lib().orc_shard_verify_pv(n, names, zc, zl, mw, pw, nc, gk, _p(_arr(prep_commit)), buf, C.c_size_t(len(blob)), L, lsh,
+                                     log_blowup, num_queries, pow_bits, 1, -1, challenger.h, pzc, pzl, pnc, pgk, npv, max_pvs, max_arity)
 
 
 def shard_verify_transcript_only(prep_commit, blob, L, lsh, beta_seed_dim, challenger, log_blowup=2, num_queries=124, pow_bits=16):

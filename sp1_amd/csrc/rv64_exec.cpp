@@ -365,18 +365,28 @@ struct Vm {
         }
     }
 
-    // an unconstrained block: registers, pc, clock and memory are rolled back at EXIT_UNCONSTRAINED; only WRITE escapes
+    // what the memory instructions' AddressOperation constrains (operations/address.rs:L47-L98; the executor's InvalidMemoryAccess):
+    // 2^16 <= addr < 2^48. Below 2^16 an access would alias the register file (addresses < 32 ARE the registers in the memory argument)
+    static bool addr_ok(uint64_t addr) { return addr >= (1ull << 16) && addr < (1ull << 48); }
+
+    // an unconstrained block: registers, pc, clock and memory are rolled back at EXIT_UNCONSTRAINED; only WRITE escapes. Its
+    // instructions do not count as cycles, so a block that never exits is bounded separately (UNC_STEP_LIMIT)
+    static constexpr uint64_t UNC_STEP_LIMIT = 1ull << 32;
+    uint64_t unc_steps = 0;
     bool step_unconstrained(const Instr& in) {
+        if (++unc_steps > UNC_STEP_LIMIT) return fail("an unconstrained block ran %llu instructions without EXIT_UNCONSTRAINED", (unsigned long long)UNC_STEP_LIMIT);
         auto reg = [&](uint64_t r) { return r ? regs[r].val : 0ull; };
         auto setreg = [&](uint32_t r, uint64_t v) { if (r) regs[r].val = v; };
         uint64_t next_pc = pc + 4;
         if (in.op <= REMUW) setreg(in.a, alu(in.op, reg(in.b), in.imm_c ? in.c : reg(in.c)));
         else if (in.op <= LD) {
             const uint64_t addr = reg(in.b) + in.c; uint64_t v;
+            if (!addr_ok(addr)) return fail("invalid memory access in an unconstrained block: load at 0x%llx", (unsigned long long)addr);
             if (!load_value(in.op, addr, peek(addr & ~7ull), v)) return fail("misaligned load in an unconstrained block");
             setreg(in.a, v);
         } else if (in.op <= SD) {
             const uint64_t addr = reg(in.b) + in.c; uint64_t v;
+            if (!addr_ok(addr)) return fail("invalid memory access in an unconstrained block: store at 0x%llx", (unsigned long long)addr);
             if (!store_value(in.op, reg(in.a), addr, peek(addr & ~7ull), v)) return fail("misaligned store in an unconstrained block");
             unc_mem[addr & ~7ull] = v;
         } else if (in.op <= BGEU) {
@@ -393,7 +403,7 @@ struct Vm {
             if (code == SYS_WRITE) { if (!sys_write(reg(10), reg(11))) return false; }
             else if (code == SYS_EXIT_UNC) {
                 for (int r = 0; r < 32; ++r) regs[r].val = unc_regs[r];
-                unc = false; unc_mem.clear(); pc = unc_pc; clk = unc_clk;
+                unc = false; unc_steps = 0; unc_mem.clear(); pc = unc_pc; clk = unc_clk;
                 return true;                                           // back at the ENTER_UNCONSTRAINED ecall, now traced with a = 0
             } else return fail("system call 0x%llx inside an unconstrained block", (unsigned long long)code);
         } else return fail("unimplemented instruction in an unconstrained block");
@@ -406,7 +416,7 @@ struct Vm {
     // (the chips' carries only fit then) and the affine formulas have no special cases, as in the reference's.
     using BI = bigmod::Int;
     // what SyscallAddrOperation constrains (operations/syscall_addr.rs:L51-L93): 8-aligned, above the registers' 2^16, the slice below 2^48
-    static bool slice_ok(uint64_t ptr, int n_words) { return !(ptr & 7) && ptr >= (1ull << 16) && ptr + 8 * (uint64_t)n_words <= (1ull << 48); }
+    static bool slice_ok(uint64_t ptr, int n_words) { return !(ptr & 7) && ptr >= (1ull << 16) && ptr < (1ull << 48) && ptr + 8 * (uint64_t)n_words <= (1ull << 48); }
     // reads `n` words at `ptr` for a precompile: (previous timestamp, value) pairs appended to rec, the words returned; the cells'
     // timestamps become `ts` when `stamp` (a read), stay for the caller to set otherwise (a slice that is rewritten)
     void read_words(uint64_t ptr, int n, uint64_t ts, bool stamp, std::vector<uint64_t>& rec, uint64_t* out) {
@@ -631,6 +641,7 @@ struct Vm {
         } else if (in.op <= LD) {
             b = rr((uint32_t)in.b, 3, e[E_B_PTS]); c = in.c;
             const uint64_t addr = b + c, al = addr & ~7ull;
+            if (!addr_ok(addr)) return fail("invalid memory access: load at 0x%llx", (unsigned long long)addr);
             Cell& m = cell(al);
             touch(m, al);
             if (!load_value(in.op, addr, m.val, a)) return fail("misaligned load at 0x%llx", (unsigned long long)addr);
@@ -642,6 +653,7 @@ struct Vm {
             b = rr((uint32_t)in.b, 3, e[E_B_PTS]); c = in.c;
             a = rr(in.a, 4, e[E_A_PTS]); e[E_A_PREV] = a;
             const uint64_t addr = b + c, al = addr & ~7ull;
+            if (!addr_ok(addr)) return fail("invalid memory access: store at 0x%llx", (unsigned long long)addr);
             Cell& m = cell(al);
             touch(m, al);
             uint64_t nv;
@@ -691,7 +703,7 @@ struct Vm {
             case SYS_HINT_READ: {
                 if (input.empty()) return fail("hint input stream exhausted");
                 std::vector<uint8_t> v = std::move(input.front()); input.pop_front();
-                if (v.size() != c || (b & 7)) return fail("HINT_READ of %llu bytes at 0x%llx against an entry of %zu", (unsigned long long)c, (unsigned long long)b, v.size());
+                if (v.size() != c || !slice_ok(b, (int)std::min<uint64_t>(v.size() / 8 + 1, 1u << 30))) return fail("HINT_READ of %llu bytes at 0x%llx against an entry of %zu", (unsigned long long)c, (unsigned long long)b, v.size());
                 for (uint64_t i = 0; i <= v.size() / 8; ++i) {         // whole words, then the (possibly empty) tail word
                     uint64_t w = 0;
                     for (uint64_t j = 0; j < 8 && 8 * i + j < v.size(); ++j) w |= (uint64_t)v[8 * i + j] << (8 * j);
@@ -702,7 +714,7 @@ struct Vm {
                 break;
             }
             case SYS_KECCAK: {
-                if ((b & 7) || c != 0) return fail("KECCAK_PERMUTE arguments");
+                if (!slice_ok(b, 25) || c != 0) return fail("KECCAK_PERMUTE arguments");
                 uint64_t st[25];
                 std::vector<uint64_t> rec = {clk, b};
                 for (int i = 0; i < 25; ++i) {                        // reads at clk
@@ -715,7 +727,7 @@ struct Vm {
                 break;
             }
             case SYS_SHA_EXTEND: {                                     // vm/syscall/precompiles/sha256/extend.rs, minimal/.../sha256/extend.rs
-                if ((b & 7) || c != 0) return fail("SHA_EXTEND arguments");
+                if (!slice_ok(b, 64) || c != 0) return fail("SHA_EXTEND arguments");
                 std::vector<uint64_t> rec = {clk, b};
                 uint64_t first[64][2];                                 // the 64 words' state before the call
                 for (int i = 0; i < 64; ++i) { Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i); first[i][0] = m.ts; first[i][1] = m.val; }
@@ -740,7 +752,7 @@ struct Vm {
                 break;
             }
             case SYS_SHA_COMPRESS: {                                   // vm/syscall/precompiles/sha256/compress.rs: h read at clk, w at clk + 1, h written at clk + 2
-                if ((b & 7) || (c & 7)) return fail("SHA_COMPRESS arguments");
+                if (!slice_ok(b, 64) || !slice_ok(c, 8)) return fail("SHA_COMPRESS arguments");
                 static const uint32_t K[64] = {
                     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
                     0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
@@ -767,7 +779,7 @@ struct Vm {
                 break;
             }
             case SYS_UINT256_MUL: {                                    // y and the modulus (y_ptr + 32) read at clk, x rewritten at clk + 1
-                if ((b & 7) || (c & 7)) return fail("UINT256_MUL arguments");
+                if (!slice_ok(b, 4) || !slice_ok(c, 8)) return fail("UINT256_MUL arguments");
                 std::vector<uint64_t> rec = {clk, b, c};
                 uint64_t x[4], ym[8], r[4];
                 for (int i = 0; i < 4; ++i) { Cell& m = cell(b + 8 * i); touch_precompile(m, b + 8 * i); rec.push_back(m.ts); rec.push_back(m.val); x[i] = m.val; }
@@ -779,7 +791,7 @@ struct Vm {
             }
             case SYS_SECP256K1_ADD: case SYS_SECP256K1_DOUBLE: {       // vm/syscall/precompiles/weierstrass/{add,double}.rs: affine, no special cases
                 const bool is_add = code == SYS_SECP256K1_ADD;
-                if ((b & 7) || (is_add && (c & 7)) || (!is_add && c != 0)) return fail("SECP256K1 point arguments");
+                if (!slice_ok(b, 8) || (is_add && !slice_ok(c, 8)) || (!is_add && c != 0)) return fail("SECP256K1 point arguments");
                 std::vector<uint64_t> rec = {clk, b};
                 if (is_add) rec.push_back(c);
                 U256 px, py, qx = {}, qy = {};
@@ -815,7 +827,7 @@ struct Vm {
             case SYS_ED_DECOMPRESS: if (!sys_ed_decompress(b, c)) return false; break;
             case SYS_UINT256_ADD_CARRY: case SYS_UINT256_MUL_CARRY: if (!sys_uint256_ops(code, b, c)) return false; break;
             case SYS_POSEIDON2: {                                      // vm/syscall/poseidon2.rs, minimal/precompiles/poseidon2.rs
-                if ((b & 7) || c != 0) return fail("POSEIDON2 arguments");
+                if (!slice_ok(b, 8) || c != 0) return fail("POSEIDON2 arguments");
                 uint32_t st[16];
                 std::vector<uint64_t> rec = {clk, b};
                 for (int i = 0; i < 8; ++i) {                          // eight words = sixteen field elements, rewritten in place at clk
@@ -905,13 +917,16 @@ bool load_elf(Vm& vm, const uint8_t* p, size_t n) {
     if (rd(16, 2) != 2 || rd(18, 2) != 243) return vm.fail("not a RISC-V executable");
     const uint64_t entry = rd(24, 8), phoff = rd(32, 8), phentsize = rd(54, 2), phnum = rd(56, 2);
     if (entry & 3) return vm.fail("entry point is not aligned");
+    // header arithmetic without wrap-around: the table of 56-byte entries lies inside the file
+    if (phentsize != 56 || phoff > n || phnum > (n - phoff) / 56) return vm.fail("program header table outside the file");
+    constexpr uint64_t MAX_SEGMENT = 1ull << 32;                       // 4 GiB per segment: far above any guest, far below an allocation bomb
     bool have_base = false;
     for (uint64_t i = 0; i < phnum; ++i) {
         const size_t ph = phoff + i * phentsize;
-        if (ph + 56 > n) return vm.fail("program header outside the file");
         if (rd(ph, 4) != 1) continue;                                  // PT_LOAD
         const uint64_t flags = rd(ph + 4, 4), off = rd(ph + 8, 8), vaddr = rd(ph + 16, 8), filesz = rd(ph + 32, 8), memsz = rd(ph + 40, 8);
-        if ((vaddr & 3) || off + filesz > n) return vm.fail("segment is not aligned or outside the file");
+        if ((vaddr & 3) || filesz > n || off > n - filesz) return vm.fail("segment is not aligned or outside the file");
+        if (filesz > memsz || memsz > MAX_SEGMENT || vaddr >= (1ull << 48) || vaddr + memsz > (1ull << 48)) return vm.fail("segment size or address out of range");
         const bool exec = flags & 1;
         if (exec && !have_base) { vm.pc_base = vaddr; have_base = true; }
         else if (exec && vaddr != vm.pc_base + 4 * vm.program.size()) return vm.fail("executable segments are not contiguous");

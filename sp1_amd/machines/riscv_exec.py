@@ -7,8 +7,11 @@ riscv_trace.py, whose column fillers this module drives with executed events ins
     for shard in ex.shards(max_cycles=1 << 21):               # ExecutedShard: events, local memory, public values
         machine, tables, publics = shard_tables(ex, shard, device)   # every chip's (prep, main), ready for api.prove_shard
 
-The proof statement per shard is the reference's: the chips' constraints hold on every row, the Byte / Range / Program / Memory
-/ State buses balance inside the shard, and what crosses shards (memory states, syscalls) goes through the Global chip's digest.
+The proof statement per shard is the reference's: the chips of the shard's shape cluster (those without events at height zero),
+their constraints on every row, and the Byte / Range / Program / Memory / State buses balanced against the messages the shard's
+PUBLIC VALUES send and receive (`eval_public_values`, public_values.py: the initial and final CPU state, the ends of the Global
+accumulation and of the memory-initialisation chains); what crosses shards (memory states, syscalls) goes through the Global chip's
+digest, and the public values chain from shard to shard as `SP1Prover::verify` requires (public_values.verify_proof_public_values).
 """
 import ctypes as C
 import gzip
@@ -19,6 +22,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from . import public_values as PVM
 from . import riscv as R
 from . import riscv_trace as RT
 from .riscv_trace import I64, MASK16, OPC, P, POS_OFF, Table, limbs16
@@ -174,14 +178,7 @@ for _chip, _ops in RT.ALU_KINDS.items():
         _ALU_CHIP[OPC[_o]] = _chip
 _MEM_CHIP = {"LB": "LoadByte", "LBU": "LoadByte", "LH": "LoadHalf", "LHU": "LoadHalf", "LW": "LoadWord", "LWU": "LoadWord", "LD": "LoadDouble",
              "SB": "StoreByte", "SH": "StoreHalf", "SW": "StoreWord", "SD": "StoreDouble"}
-PV_WORDS = 160
-# PublicValues<[T; 4], [T; 3], [T; 4], T> word offsets (hypercube/src/air/public_values.rs:L33-L168, `mprotect` off)
-PV = dict(prev_committed_value_digest=0, committed_value_digest=32, prev_deferred_proofs_digest=64, deferred_proofs_digest=72, pc_start=80,
-          next_pc=83, prev_exit_code=86, exit_code=87, is_execution_shard=88, previous_init_addr=89, last_init_addr=92,
-          previous_finalize_addr=95, last_finalize_addr=98, initial_timestamp=113, last_timestamp=117, is_timestamp_high_eq=121,
-          inv_timestamp_high=122, is_timestamp_low_eq=123, inv_timestamp_low=124, global_init_count=125, global_finalize_count=126,
-          global_count=129, global_cumulative_sum=130, prev_commit_syscall=144, commit_syscall=145, prev_commit_deferred_syscall=146,
-          commit_deferred_syscall=147, initial_timestamp_inv=148, last_timestamp_inv=149, is_first_execution_shard=150)
+PV, PV_WORDS = PVM.PV, PVM.NUM_PV_ELTS                # PublicValues word offsets (public_values.py)
 
 
 def chip_of_events(ev):
@@ -245,9 +242,11 @@ class EventTracer(RT.Tracer):
     operations, load / store chips, SyscallInstrs, Global) are the base class's; what changes is where the timeline comes from:
     previous timestamps and memory states are the executor's records instead of the loop body's static analysis."""
 
-    def __init__(self, executor, shard, device="cpu"):
+    def __init__(self, executor, shard, device="cpu", prev=None):
+        """prev: the public values of the previous shard in execution order (a list of words) or None for the first — where
+        prev_committed_value_digest, prev_exit_code and the prev_commit_* flags come from (verify.rs:L262-L296, L445-L480)."""
         self.pc_base, self.program = executor.program()
-        self.shard = shard
+        self.shard, self.prev = shard, prev
         super().__init__(EventView(shard, self.pc_base, device))
         self.real_global = True
 
@@ -333,63 +332,15 @@ class EventTracer(RT.Tracer):
         self._bump_rows()
 
     def _program_table(self):
-        """Program: one row per instruction of the ELF's text (program/trusted.rs:L80-L131), multiplicity = executions in this shard."""
-        dev, prog = self.dev, torch.as_tensor(self.program, device=self.dev)
-        n = prog.shape[0]
-        air, it = R.chip("Program")
-        tb = Table(air, n, dev)
-        pc = self.pc_base + 4 * torch.arange(n, device=dev)
-        op, a, b_, c_, imm_b, imm_c = (prog[:, i] for i in range(6))
-        tb.prep[:n, 0:3] = limbs16(pc)[:, :3]
-        tb.prep[:n, 3], tb.prep[:n, 4] = op, a
-        regw = lambda r: torch.stack([r] + [torch.zeros_like(r)] * 3, dim=1)
-        tb.prep[:n, 5:9] = torch.where((imm_b == 1)[:, None], limbs16(b_), regw(b_))
-        tb.prep[:n, 9:13] = torch.where((imm_c == 1)[:, None], limbs16(c_), regw(c_))
-        tb.prep[:n, 13] = (a == 0).to(I64)
-        tb.prep[:n, 14], tb.prep[:n, 15] = imm_b, imm_c
-        idx = (self.ex.ev[:, E_PC] - self.pc_base) >> 2
-        tb.main[:n, 0] = torch.bincount(idx, minlength=n)
-        if tb.prep.shape[0] > n:
-            tb.prep[n:] = tb.prep[0]
-        return tb, (air, it)
+        return RT.program_table(self.program, self.pc_base, self.dev, executed_pc=self.ex.ev[:, E_PC])
 
-    def public_values(self, global_sum=None, n_global=0):
-        sh, pv = self.shard, [0] * PV_WORDS
-
-        def put(name, vals):
-            pv[PV[name]:PV[name] + len(vals)] = [int(v) for v in vals]
-        l16 = lambda v, n: [(v >> (16 * i)) & MASK16 for i in range(n)]
-        words = lambda ws: [(w >> (8 * i)) & 0xFF for w in ws for i in range(4)]
-        put("committed_value_digest", words(sh.committed_value_digest))
-        put("deferred_proofs_digest", sh.deferred_proofs_digest)
-        put("pc_start", l16(sh.pc_start, 3))
-        put("next_pc", l16(sh.next_pc, 3))
-        put("exit_code", [sh.exit_code])
-        put("is_execution_shard", [1])
-        put("initial_timestamp", l16(sh.clk_start, 4))
-        put("last_timestamp", l16(sh.clk_end, 4))
-        hi0, hi1, lo0, lo1 = sh.clk_start >> 24, sh.clk_end >> 24, sh.clk_start & 0xFFFFFF, sh.clk_end & 0xFFFFFF
-        put("is_timestamp_high_eq", [int(hi0 == hi1)])
-        put("inv_timestamp_high", [pow((hi1 - hi0) % P, P - 2, P)])
-        put("is_timestamp_low_eq", [int(lo0 == lo1)])
-        put("inv_timestamp_low", [pow((lo1 - lo0) % P, P - 2, P)])
-        put("global_count", [n_global])
-        if global_sum is not None:
-            put("global_cumulative_sum", global_sum)
-        put("commit_syscall", [sh.commit_syscall])
-        put("commit_deferred_syscall", [sh.commit_deferred_syscall])
-        put("is_first_execution_shard", [int(sh.index == 0)])
-        return torch.tensor(pv, dtype=I64)
+    def public_values(self):
+        return execution_public_values(self.shard, self.prev)
 
     def finish(self):
         ex, dev, sh = self.ex, self.dev, self.shard
         machine = {name: R.chip(name) for name in self.tables}
-        air, it = RT.boundary_chip()
-        tb = Table(air, 2, dev)
-        t0, t1 = sh.clk_start, sh.clk_end
-        tb.main[0] = torch.tensor([t0 >> 24, t0 & 0xFFFFFF] + [(sh.pc_start >> (16 * i)) & MASK16 for i in range(3)] + [1, 0], device=dev)
-        tb.main[1] = torch.tensor([t1 >> 24, t1 & 0xFFFFFF] + [(sh.next_pc >> (16 * i)) & MASK16 for i in range(3)] + [0, 1], device=dev)
-        self.tables["Boundary"], machine["Boundary"] = tb, (air, it)
+        pv = self.public_values()
         ml = self.tables["MemoryLocal"]
         (_, recv, _), (_, send, _) = RT.eval_interactions(R.chip("MemoryLocal")[1], ml.main[:ml.n], None, kinds=(R.GLOBAL,))
         events = [torch.stack([recv, send], dim=1).reshape(-1, 11)]
@@ -397,21 +348,43 @@ class EventTracer(RT.Tracer):
             t_ = self.tables["SyscallCore"]
             events += [v for _, v, _ in RT.eval_interactions(R.chip("SyscallCore")[1], t_.main[:t_.n], None, kinds=(R.GLOBAL,))]
         self.global_events = torch.cat(events)
-        self.global_chip(machine, self.global_events)
+        PVM.set_global(pv, *self.global_chip(machine, self.global_events))
         self.tables["Program"], machine["Program"] = self._program_table()
-        self.byte_range_tables(machine)
-        g = self.tables["Global"]
-        cx = g.main[g.n - 1, g.L["accumulation.cumulative_sum_x"]:g.L["accumulation.cumulative_sum_x"] + 7]
-        cy = g.main[g.n - 1, g.L["accumulation.cumulative_sum_y"]:g.L["accumulation.cumulative_sum_y"] + 7]
-        publics = self.public_values(cx.tolist() + cy.tolist(), g.n)
+        self.byte_range_tables(machine, pv)
+        self.fill_cluster(machine, RT.smallest_cluster(machine))
+        self.pv = pv
         names = sorted(machine)
-        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, publics
+        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, PVM.to_tensor(pv)
 
 
-def shard_tables(executor, shard, device="cpu"):
-    """(machine, tables, public values) of one executed shard: machine = [(AirProgram, InteractionProgram)] in chip-name order,
-    tables = {name: (prep, main)} canonical int64 tensors on `device`, public values = the shard's 160 words."""
-    return EventTracer(executor, shard, device).build()
+def execution_public_values(sh, prev=None):
+    """An execution shard's `PublicValues` as the tracing executor leaves them (tracing.rs postprocess L548-L562, executor.rs:L60
+    finalize_public_values(true)) with the previous shard's state threaded in (`prev`: its words, None for the first shard); the
+    Global chip's two fields are set once its table exists (EventTracer.finish)."""
+    pv = PVM.set_state(PVM.blank(), sh.pc_start, sh.next_pc, sh.clk_start, sh.clk_end, sh.exit_code, True)
+    PVM.put(pv, "committed_value_digest", PVM.digest_bytes(sh.committed_value_digest))
+    PVM.put(pv, "deferred_proofs_digest", sh.deferred_proofs_digest)
+    PVM.put(pv, "commit_syscall", sh.commit_syscall)
+    PVM.put(pv, "commit_deferred_syscall", sh.commit_deferred_syscall)
+    if prev is not None:
+        for name in ("committed_value_digest", "deferred_proofs_digest", "exit_code", "commit_syscall", "commit_deferred_syscall"):
+            PVM.put(pv, "prev_" + name, PVM.get(prev, name))
+    return PVM.no_memory_events(pv)
+
+
+def shard_tables(executor, shard, device="cpu", prev=None):
+    """(machine, tables, public values) of one executed shard: machine = [(AirProgram, InteractionProgram)] in chip-name order —
+    the shard's whole shape cluster —, tables = {name: (prep, main)} canonical int64 tensors on `device`, public values = the
+    PROOF_MAX_NUM_PVS words of its ShardProof (`prev`: the previous shard's words, see EventTracer)."""
+    return EventTracer(executor, shard, device, prev=prev).build()
+
+
+def proof_order(kinds):
+    """The order the shards of a run stand in inside a core proof, as indices into `kinds` (what `program_shards` yielded): the
+    precompile shards first — they are in the program's INITIAL state (timestamp 1, pc = entry) —, the core shards in execution
+    order, then the memory shards in the FINAL state (crates/prover/src/verify.rs:L160-L260 only accepts that chain)."""
+    idx = range(len(kinds))
+    return [i for i in idx if kinds[i] not in ("core", "memory")] + [i for i in idx if kinds[i] == "core"] + [i for i in idx if kinds[i] == "memory"]
 
 
 ELEMENT_THRESHOLD, HEIGHT_THRESHOLD = (1 << 28) + (1 << 27), 1 << 22        # core/executor/src/opts.rs:L12-L14
@@ -454,13 +427,20 @@ def program_shards(executor, max_cycles, device="cpu", core_limit=None):
     keccak, poseidon2, sha_extend, sha_compress, uint256, secp_add, secp_double = [], [], [], [], [], [], []
     families = {}
     n_core = 0
+    prev_pv, ctx, shard = None, None, None
     while not executor.halted:
         keep = core_limit is None or n_core < core_limit     # beyond the limit: executed (their precompile calls count), not traced
         shard = executor.run_shard(max_cycles, record=keep)
         n_core += 1
+        if ctx is None:                                      # what the shards without instructions take from the run (RunContext)
+            pc_base, program = executor.program()
+            ctx = RT.RunContext(program, pc_base, pc_start=shard.pc_start)
         if keep:
-            tr = EventTracer(executor, shard, device)
+            tr = EventTracer(executor, shard, device, prev=prev_pv)
             machine, tables, publics = tr.build()
+            prev_pv = tr.pv
+        else:
+            prev_pv = execution_public_values(shard, prev_pv)
         if shard.keccak.shape[0]:
             keccak.append(shard.keccak)
         if shard.poseidon2.shape[0]:
@@ -485,34 +465,36 @@ def program_shards(executor, max_cycles, device="cpu", core_limit=None):
     for kk in chunks("keccak", keccak):
         kk = torch.as_tensor(kk, device=device)
         rd = kk[:, 2:52].reshape(-1, 25, 2)
-        machine, tables, publics, gev = MT.precompile_shard_from(kk[:, 0], kk[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(), device)
+        machine, tables, publics, gev = MT.precompile_shard_from(kk[:, 0], kk[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(), device, ctx=ctx)
         yield "keccak", machine, tables, publics, gev, None
     for pp in chunks("poseidon2", poseidon2):
         pp = torch.as_tensor(pp, device=device)
         rd = pp[:, 2:18].reshape(-1, 8, 2)
         machine, tables, publics, gev = MT.poseidon2_shard_from(pp[:, 0], pp[:, 1], rd[:, :, 1].contiguous(), rd[:, :, 0].contiguous(),
-                                                               pp[:, 18:26].contiguous(), device)
+                                                               pp[:, 18:26].contiguous(), device, ctx=ctx)
         yield "poseidon2", machine, tables, publics, gev, None
     for name, evs, build in (("sha_extend", sha_extend, MT.sha_extend_shard_from), ("sha_compress", sha_compress, MT.sha_compress_shard_from),
                              ("uint256", uint256, MT.uint256_shard_from), ("secp256k1_add", secp_add, MT.secp256k1_add_shard_from),
                              ("secp256k1_double", secp_double, MT.secp256k1_double_shard_from)):
         for part in chunks(name, evs):
-            machine, tables, publics, gev = build(part, device)
+            machine, tables, publics, gev = build(part, device, ctx=ctx)
             yield name, machine, tables, publics, gev, None
     for kind in FAMILIES:                                    # one chip per kind; Fp / UINT256 kinds hold all their system calls' events
         for part in chunks(kind, families.get(kind)):
-            machine, tables, publics, gev = MT.family_shard_from(kind, part, device)
+            machine, tables, publics, gev = MT.family_shard_from(kind, part, device, ctx=ctx)
             yield kind, machine, tables, publics, gev, None
     gm = executor.global_memory()
     gm = gm[np.argsort(gm[:, 0].astype(np.uint64))]
     if gm.shape[0] == 0 or gm[0, 0] != 0:                  # register x0 opens the address chain whether or not the program read it
         gm = np.concatenate([np.zeros((1, 4), dtype=np.int64), gm])
     previous = 0
+    # the memory shards stand in the program's final state (update_finalized_state, worker/prover/core.rs:L370-L397)
+    ctx.final = (shard.clk_end, shard.next_pc, shard.exit_code, shard.committed_value_digest, shard.deferred_proofs_digest)
     for at in range(0, gm.shape[0], limit["memory"]):       # `split` (record.rs): init and finalise events chunked alike, zipped
         part = gm[at:at + limit["memory"]]
         addrs = part[:, 0].astype(np.uint64)
         machine, tables, publics, gev = MT.memory_shard_from(addrs, np.stack([part[:, 1], np.zeros_like(part[:, 1])], axis=1), part[:, 2:4],
-                                                             device, previous_addr=previous)
+                                                             device, previous_addr=previous, ctx=ctx)
         previous = int(addrs[-1])
         yield "memory", machine, tables, publics, gev, None
 

@@ -3,12 +3,12 @@
   * `precompile_shard` — a KECCAK_PERMUTE precompile shard as the reference builds it (crates/core/executor/src/record.rs splits
     precompile events into their own shards): KeccakPermuteControl (one row per syscall: syscall receive, 25 reads + 25 writes of
     the state words), KeccakPermute (24 rows per syscall: one Keccak-f round each), SyscallPrecompile (the Global receive of the
-    syscall), MemoryLocal (one row per touched word), Global (every global interaction, septic-curve digest), Byte, Range — all
-    REAL chips — plus the 2-row `GlobalAccBoundary` closing chip where the reference has `eval_public_values`.
+    syscall), MemoryLocal (one row per touched word), Global (every global interaction, septic-curve digest), Program, Byte,
+    Range: the reference's Keccak shape cluster, closed by the shard's public values (`eval_public_values`, public_values.py).
     The permutation is COMPUTED here (keccak_f_rows: theta / rho / pi / chi / iota on 64-bit lanes, every intermediate the AIR
     names) and checked against hashlib's SHA3-256 in the tests.
-  * `memory_shard` — global memory initialisation / finalisation (MemoryGlobalInit, MemoryGlobalFinalize, Global, Byte, Range +
-    closing chips for the two control chains and the accumulation chain).
+  * `memory_shard` — global memory initialisation / finalisation (MemoryGlobalInit, MemoryGlobalFinalize, Global, Program, Byte,
+    Range; the ends of the two control chains and of the accumulation chain are public values).
 
 As in riscv_trace.py nothing is fitted: tests/machine_check.py requires every constraint of every chip to vanish on every row and
 every bus to balance. References per function.
@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from ..air import AirProgram, InteractionProgram, P, VCol
+from . import public_values as PVM
 from . import riscv as R
 from . import riscv_more as M
 from . import riscv_trace as RT
@@ -188,7 +189,7 @@ def precompile_shard(n_events, seed=0, device="cpu", clk0=(5 << 24) + 1001):
     return precompile_shard_from(clk, addr, pre, t_prev, dev)[:3]
 
 
-def precompile_shard_from(clk, addr, pre, t_prev, device="cpu"):
+def precompile_shard_from(clk, addr, pre, t_prev, device="cpu", ctx=None):
     """The KECCAK_PERMUTE precompile shard of the syscalls (clk [n], state pointer addr [n], state read pre [n, 25], previous
     timestamps of its words t_prev [n, 25]): (machine, tables, publics, global events) — the first three like riscv_trace.generate
     (vectorised torch.int64: CPU in the tests, the GPU in the bench). Reads happen at clk, writes at clk + 1 (keccak256/permute.rs)."""
@@ -210,13 +211,16 @@ def precompile_shard_from(clk, addr, pre, t_prev, device="cpu"):
     tr.tables["KeccakPermuteControl"] = ct
     wa = (addr[:, None] + 8 * torch.arange(25, device=dev)[None, :]).reshape(-1)
     return _close_precompile_shard(tr, M.SYS_KECCAK_PERMUTE, clk, al, wa, t_prev.reshape(-1), (clk[:, None] + 1).expand(-1, 25).reshape(-1),
-                                   pre.reshape(-1), post.reshape(-1))
+                                   pre.reshape(-1), post.reshape(-1), ctx=ctx)
 
 
-def _close_precompile_shard(tr, syscall_id, clk, ptr_limbs, word_addr, t_initial, t_final, v_initial, v_final, arg2_limbs=None):
+def _close_precompile_shard(tr, syscall_id, clk, ptr_limbs, word_addr, t_initial, t_final, v_initial, v_final, arg2_limbs=None, ctx=None):
     """What every precompile shard has around its own chips: SyscallPrecompile (one row per call), MemoryLocal (one row per touched
-    word: state before the call's first and after its last access), the Global chip over their events, the byte tables."""
+    word: state before the call's first and after its last access), the Global chip over their events, the Program table of the
+    run (`ctx`: riscv_trace.RunContext; nothing executes here, its multiplicities are zero), the byte tables — the shard's shape
+    cluster (riscv/mod.rs:L560-L597) — and its public values: the program's initial state (`update_initialized_state`)."""
     dev = tr.dev
+    ctx = ctx if ctx is not None else RT.RunContext()
     # SyscallPrecompile (syscall/chip.rs:L196-L254)
     st = RT.Table(R.chip("SyscallPrecompile")[0], int(clk.shape[0]), dev)
     st.set("clk_high", clk >> 24); st.set("clk_low", clk & 0xFFFFFF); st.set("syscall_id", syscall_id)
@@ -242,12 +246,13 @@ def _close_precompile_shard(tr, syscall_id, clk, ptr_limbs, word_addr, t_initial
     ev = [torch.stack([recv, send], dim=1).reshape(-1, 11)]
     ev += [v for _, v, _ in RT.eval_interactions(R.chip("SyscallPrecompile")[1], st.main[:st.n], None, kinds=(R.GLOBAL,))]
     tr.global_events = torch.cat(ev)
-    tr.global_chip(machine, tr.global_events)
-    tr.byte_range_tables(machine)
+    pv = PVM.no_memory_events(PVM.initialized_state(ctx.pc_start))
+    PVM.set_global(pv, *tr.global_chip(machine, tr.global_events))
+    tr.tables["Program"], machine["Program"] = ctx.program_table(dev)
+    tr.byte_range_tables(machine, pv)
+    tr.fill_cluster(machine, RT.smallest_cluster(machine))
     names = sorted(machine)
-    publics = torch.zeros(M.PV_NUM_ELTS, dtype=I64)
-    _global_publics(publics, tr.tables["Global"])
-    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, publics, tr.global_events
+    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, PVM.to_tensor(pv), tr.global_events
 
 
 def _syscall_addr_t(tb, prefix, addr):
@@ -262,7 +267,7 @@ def _syscall_addr_t(tb, prefix, addr):
     return al
 
 
-def poseidon2_shard_from(clk, ptr, pre, t_prev, post, device="cpu"):
+def poseidon2_shard_from(clk, ptr, pre, t_prev, post, device="cpu", ctx=None):
     """The POSEIDON2 precompile shard of the syscalls (clk [n], pointer ptr [n], the eight words read pre [n, 8] with their previous
     timestamps t_prev [n, 8], the eight words written post [n, 8] — at clk, in place): the Poseidon2 chip's rows
     (`generate_trace_into`, syscall/precompiles/poseidon2/air.rs:L107-L290: the permutation's 179 columns are RECOMPUTED from the
@@ -294,27 +299,7 @@ def poseidon2_shard_from(clk, ptr, pre, t_prev, post, device="cpu"):
     tr.tables["Poseidon2"] = tb
     wa = (ptr[:, None] + 8 * torch.arange(8, device=dev)[None, :]).reshape(-1)
     return _close_precompile_shard(tr, M.SYS_POSEIDON2, clk, al, wa, t_prev.reshape(-1), clk[:, None].expand(-1, 8).reshape(-1),
-                                   pre.reshape(-1), post.reshape(-1))
-
-
-def _global_publics(publics, g):
-    """global_count and global_cumulative_sum (public_values.rs) from the Global table's last real row."""
-    publics[129] = g.n
-    for i, nm in enumerate(("accumulation.cumulative_sum_x", "accumulation.cumulative_sum_y")):
-        publics[130 + 7 * i:137 + 7 * i] = g.main[g.n - 1, g.L[nm]:g.L[nm] + 7].cpu()
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-def control_boundary_chip(name, kind):
-    """Closing chip for a MemoryGlobal{Init, Finalize}Control chain, where the reference has eval_public_values
-    (riscv/mod.rs: the chain starts at (0, previous_addr, 1) and ends at (count, last_addr, 1)): 2 rows of
-    [index, addr[3], flag, is_send, is_recv]."""
-    air = AirProgram(name, 7, 0)
-    it = InteractionProgram(name, 7, 0)
-    col = lambda i: VCol([("main", i, 1)], 0)
-    it.send(kind, [col(i) for i in range(5)], col(5))
-    it.receive(kind, [col(i) for i in range(5)], col(6))
-    return air, it
+                                   pre.reshape(-1), post.reshape(-1), ctx=ctx)
 
 
 def memory_shard(n_words, seed=0, device="cpu", with_zero=True):
@@ -331,26 +316,39 @@ def memory_shard(n_words, seed=0, device="cpu", with_zero=True):
     return memory_shard_from([int(a) for a in addrs], init, fin, device, previous_addr=0 if with_zero else 1 << 16)[:3]
 
 
-def memory_shard_from(addrs, init, fin, device="cpu", previous_addr=0):
-    """The memory shard of a run (memory/global.rs generate_trace_into): MemoryGlobalInit / MemoryGlobalFinalize rows for the
-    strictly increasing addresses `addrs` — init[i] / fin[i] = (value, timestamp) of address i (the Init chip's Global message
-    carries timestamp 0 whatever its clk columns hold) —, the chain of (index, prev_addr, validity) control messages closed by two
-    boundary rows, one Global event per row, the Global chip and the byte tables. Returns (machine, tables, publics, global events)."""
+def memory_shard_from(addrs, init, fin, device="cpu", previous_addr=0, ctx=None, fin_addrs=None, previous_fin_addr=None):
+    """A memory shard of a run (memory/global.rs generate_trace_into): MemoryGlobalInit rows for the strictly increasing addresses
+    `addrs` and MemoryGlobalFinalize rows for `fin_addrs` (default: the same addresses; the reference finalises every word of the
+    program image but initialises none of them, so the two lists differ there) — init[i] / fin[i] = (value, timestamp) of address i
+    (the Init chip's Global message carries timestamp 0 whatever its clk columns hold) —, the chains of (index, prev_addr, validity)
+    control messages whose two ends are the shard's public values (previous_*_addr / last_*_addr / global_*_count:
+    eval_global_memory_init / finalize; a chip without events is at height zero and its chain stands still), one Global event per
+    row, the Global chip, the run's Program table and the byte tables; the public values are the program's FINAL state
+    (`update_finalized_state`, ctx.final). Returns (machine, tables, publics, global events)."""
     dev = torch.device(device)
+    ctx = ctx if ctx is not None else RT.RunContext()
     tr = RT.Tracer.__new__(RT.Tracer)
     tr.dev, tr.tables = dev, {}
-    n_words = len(addrs)
-    addr_np = np.asarray(addrs, dtype=np.uint64)
+    fin_addrs = addrs if fin_addrs is None else fin_addrs
+    previous_fin_addr = previous_addr if previous_fin_addr is None else previous_fin_addr
+    pv = PVM.finalized_state(*ctx.final)
     machine, ev = {}, []
-    for name, kind, recs in (("MemoryGlobalInit", M.MEMORY_GLOBAL_INIT_CONTROL, init), ("MemoryGlobalFinalize", M.MEMORY_GLOBAL_FINALIZE_CONTROL, fin)):
+    for name, which, a_list, recs, previous in (("MemoryGlobalInit", "init", addrs, init, previous_addr),
+                                                ("MemoryGlobalFinalize", "finalize", fin_addrs, fin, previous_fin_addr)):
+        n = len(a_list)
+        PVM.put(pv, "previous_%s_addr" % which, PVM.addr_limbs(previous))
+        PVM.put(pv, "last_%s_addr" % which, PVM.addr_limbs(int(a_list[-1]) if n else previous))
+        PVM.put(pv, "global_%s_count" % which, n)
+        if n == 0:
+            continue
         air, it = R.chip(name)
         L = air.layout
-        tb = RT.Table(air, n_words, dev)
-        rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)
-        n = n_words                                                     # all rows at once: a large program touches millions of words
+        tb = RT.Table(air, n, dev)
+        rows = np.zeros((tb.main.shape[0], air.main_width), dtype=np.int64)   # all rows at once: a large program touches millions of words
+        addr_np = np.asarray(a_list, dtype=np.uint64)
         rec = recs.astype(np.uint64) if isinstance(recs, np.ndarray) else np.array([[int(x) & ((1 << 64) - 1) for x in r] for r in recs], dtype=np.uint64)
         v, t = rec[:, 0], rec[:, 1].astype(np.int64)
-        prev = np.concatenate([np.array([previous_addr], dtype=np.uint64), addr_np[:-1]])
+        prev = np.concatenate([np.array([previous], dtype=np.uint64), addr_np[:-1]])
         idx = np.arange(n, dtype=np.int64)
         xl, yl, vl = _limbs_np(prev), _limbs_np(addr_np), _limbs_np(v)
         rows[:n, L["clk_high"]], rows[:n, L["clk_low"]] = t >> 24, t & 0xFFFFFF
@@ -375,25 +373,18 @@ def memory_shard_from(addrs, init, fin, device="cpu", previous_addr=0):
         rows[:n, L["lt_cols.comparison_limbs"]], rows[:n, L["lt_cols.comparison_limbs"] + 1] = xj * comp, yj * comp
         rows[:n, L["lt_cols.not_eq_inv"]] = _inv_np((xj - yj) % P) * comp
         rows[:n, L["lt_cols.bit"]] = (xj < yj) & comp
+        # the public values receive (count, last_addr, 1): the chain cannot end on the uncompared row of address 0 alone
+        assert bool(comp[-1]), "a memory shard whose only %s event is address 0 does not close its chain" % which
         tb.main[:] = torch.as_tensor(rows % P, device=dev)
         tr.tables[name], machine[name] = tb, (air, it)
         ev += [v_ for _, v_, _ in RT.eval_interactions(it, tb.main[:tb.n], None, kinds=(R.GLOBAL,))]
-        # the two ends of the control chain: (0, previous_addr = 0, prev_valid = 1) is sent, (n, last_addr, is_comp of the last row) received
-        bair, bit = control_boundary_chip(name + "Boundary", kind)
-        bt = RT.Table(bair, 2, dev)
-        bt.main[0] = torch.tensor([0] + _limbs(previous_addr)[:3] + [1, 1, 0], device=dev)
-        bt.main[1] = torch.tensor([n_words] + _limbs(int(addrs[-1]))[:3] + [int(rows[n_words - 1, L["is_comp"]]), 0, 1], device=dev)
-        tr.tables[bair.name], machine[bair.name] = bt, (bair, bit)
     tr.global_events = torch.cat(ev)
-    tr.global_chip(machine, tr.global_events)
-    tr.byte_range_tables(machine)
+    PVM.set_global(pv, *tr.global_chip(machine, tr.global_events))
+    tr.tables["Program"], machine["Program"] = ctx.program_table(dev)
+    tr.byte_range_tables(machine, pv)
+    tr.fill_cluster(machine, RT.MEMORY_CLUSTER)
     names = sorted(machine)
-    publics = torch.zeros(M.PV_NUM_ELTS, dtype=I64)
-    for off, a in ((89, previous_addr), (92, int(addrs[-1])), (95, previous_addr), (98, int(addrs[-1]))):   # previous / last init, finalize addr
-        publics[off:off + 3] = torch.tensor(_limbs(a)[:3])
-    publics[125], publics[126] = n_words, n_words                                         # global_init_count, global_finalize_count
-    _global_publics(publics, tr.tables["Global"])
-    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, publics, tr.global_events
+    return [machine[n] for n in names], {n: (tr.tables[n].prep, tr.tables[n].main) for n in names}, PVM.to_tensor(pv), tr.global_events
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -434,7 +425,7 @@ def _set_sum(tb, prefix, *terms):
     return out
 
 
-def sha_extend_shard_from(events, device="cpu"):
+def sha_extend_shard_from(events, device="cpu", ctx=None):
     """The SHA_EXTEND precompile shard of the executor's events ([n, 786] int64: riscv_exec.SHA_EXTEND_WORDS): ShaExtend (48 rows per
     call, `event_to_rows`, extend/trace.rs:L82-L190), ShaExtendControl, SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
     dev = torch.device(device)
@@ -484,10 +475,10 @@ def sha_extend_shard_from(events, device="cpu"):
     tr.tables["ShaExtendControl"] = ct
     wa = (w_ptr[:, None] + 8 * torch.arange(64, device=dev)[None, :]).reshape(-1)
     ar = around.reshape(-1, 4)
-    return _close_precompile_shard(tr, M.SYS_SHA_EXTEND, clk, al, wa, ar[:, 0], ar[:, 2], ar[:, 1], ar[:, 3])
+    return _close_precompile_shard(tr, M.SYS_SHA_EXTEND, clk, al, wa, ar[:, 0], ar[:, 2], ar[:, 1], ar[:, 3], ctx=ctx)
 
 
-def sha_compress_shard_from(events, device="cpu"):
+def sha_compress_shard_from(events, device="cpu", ctx=None):
     """The SHA_COMPRESS precompile shard of the executor's events ([n, 155] int64): ShaCompress (80 rows per call: 8 initialise, 64
     compress, 8 finalise; padding rows keep cycling the octet flags, compress/trace.rs:L78-L104, L120-L360), ShaCompressControl, ..."""
     dev = torch.device(device)
@@ -600,7 +591,7 @@ def sha_compress_shard_from(events, device="cpu"):
     v_i = torch.cat([h_rd[:, :, 1].reshape(-1), w_rd[:, :, 1].reshape(-1)])
     t_f = torch.cat([(clk[:, None] + 2).expand(-1, 8).reshape(-1), (clk[:, None] + 1).expand(-1, 64).reshape(-1)])
     v_f = torch.cat([h_wr.reshape(-1), w_rd[:, :, 1].reshape(-1)])
-    return _close_precompile_shard(tr, M.SYS_SHA_COMPRESS, clk, wl, wa, t_i, t_f, v_i, v_f, arg2_limbs=hl)   # arg2 = h_ptr
+    return _close_precompile_shard(tr, M.SYS_SHA_COMPRESS, clk, wl, wa, t_i, t_f, v_i, v_f, arg2_limbs=hl, ctx=ctx)   # arg2 = h_ptr
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -651,7 +642,7 @@ def field_lt_columns(lhs, rhs, n_limbs):
     return flags, lb, rb
 
 
-def uint256_shard_from(events, device="cpu"):
+def uint256_shard_from(events, device="cpu", ctx=None):
     """The UINT256_MUL precompile shard of the executor's events ([n, 31] int64): Uint256MulMod rows (`generate_trace_into`,
     syscall/precompiles/uint256/air.rs:L118-L290), SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
     dev = torch.device(device)
@@ -708,7 +699,7 @@ def uint256_shard_from(events, device="cpu"):
     v_i = torch.cat([xs[:, :, 1].reshape(-1), ys[:, :, 1].reshape(-1)])
     t_f = torch.cat([(clk[:, None] + 1).expand(-1, 4).reshape(-1), clk[:, None].expand(-1, 8).reshape(-1)])
     v_f = torch.cat([t[:, 27:31].reshape(-1), ys[:, :, 1].reshape(-1)])
-    return _close_precompile_shard(tr, M.SYS_UINT256_MUL, clk, xl, wa, t_i, t_f, v_i, v_f, arg2_limbs=yl)
+    return _close_precompile_shard(tr, M.SYS_UINT256_MUL, clk, xl, wa, t_i, t_f, v_i, v_f, arg2_limbs=yl, ctx=ctx)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -838,7 +829,7 @@ _word256 = lambda ws: sum(int(x) << (64 * i) for i, x in enumerate(ws))
 _low_bytes = lambda v: torch.stack([(v >> (16 * k)) & 0xFF for k in range(4)], dim=1)
 
 
-def secp256k1_add_shard_from(events, device="cpu"):
+def secp256k1_add_shard_from(events, device="cpu", ctx=None):
     """The SECP256K1_ADD precompile shard of the executor's events ([n, 43] int64): Secp256k1AddAssign rows (`populate_row` and
     the dummy row of `generate_trace_into`, weierstrass_add.rs:L246-L330, L612-L680), SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
     dev = torch.device(device)
@@ -880,10 +871,10 @@ def secp256k1_add_shard_from(events, device="cpu"):
     v_i = torch.cat([ps[:, :, 1].reshape(-1), qs[:, :, 1].reshape(-1)])
     t_f = torch.cat([(clk[:, None] + 1).expand(-1, 8).reshape(-1), clk[:, None].expand(-1, 8).reshape(-1)])
     v_f = torch.cat([t[:, 35:43].reshape(-1), qs[:, :, 1].reshape(-1)])
-    return _close_precompile_shard(tr, M.SYS_SECP256K1_ADD, clk, pl, wa, t_i, t_f, v_i, v_f, arg2_limbs=ql)
+    return _close_precompile_shard(tr, M.SYS_SECP256K1_ADD, clk, pl, wa, t_i, t_f, v_i, v_f, arg2_limbs=ql, ctx=ctx)
 
 
-def secp256k1_double_shard_from(events, device="cpu"):
+def secp256k1_double_shard_from(events, device="cpu", ctx=None):
     """The SECP256K1_DOUBLE precompile shard of the executor's events ([n, 26] int64): Secp256k1DoubleAssign rows
     (weierstrass_double.rs:L262-L380: the point is rewritten in place at clk), SyscallPrecompile, MemoryLocal, Global, Byte, Range."""
     dev = torch.device(device)
@@ -917,7 +908,7 @@ def secp256k1_double_shard_from(events, device="cpu"):
     eight = torch.arange(8, device=dev)[None, :]
     wa = (pp[:, None] + 8 * eight).reshape(-1)
     return _close_precompile_shard(tr, M.SYS_SECP256K1_DOUBLE, clk, pl, wa, ps[:, :, 0].reshape(-1), clk[:, None].expand(-1, 8).reshape(-1),
-                                   ps[:, :, 1].reshape(-1), t[:, 18:26].reshape(-1))
+                                   ps[:, :, 1].reshape(-1), t[:, 18:26].reshape(-1), ctx=ctx)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1070,7 +1061,7 @@ def _ed_decompress_field_ops(rows, L, ys):                                # popu
     return xs, neg
 
 
-def family_shard_from(kind, events, device="cpu"):
+def family_shard_from(kind, events, device="cpu", ctx=None):
     """The precompile shard of one family's events ([n, words] int64, the layouts of include/sp1hip.h): the chip's rows (the
     reference's `populate_field_ops` / padding rows, cited at each filler), SyscallPrecompile, MemoryLocal, Global, Byte, Range.
     Every result the executor wrote is recomputed here from the operands it read and compared."""
@@ -1151,7 +1142,7 @@ def family_shard_from(kind, events, device="cpu"):
             wa = torch.cat([wa, (a2[:, None] + 8 * arange(nw)).reshape(-1)])
             t_i, v_i = torch.cat([t_i, yst[:, :, 0].reshape(-1)]), torch.cat([v_i, yst[:, :, 1].reshape(-1)])
             t_f, v_f = torch.cat([t_f, clk[:, None].expand(-1, nw).reshape(-1)]), torch.cat([v_f, yst[:, :, 1].reshape(-1)])
-        return _close_precompile_shard(tr, code, clk, xl, wa, t_i, t_f, v_i, v_f, arg2_limbs=yl if two else None)
+        return _close_precompile_shard(tr, code, clk, xl, wa, t_i, t_f, v_i, v_f, arg2_limbs=yl if two else None, ctx=ctx)
     if shape == "ed_decompress":
         xs, ys, out = ev[:, 4:12].reshape(n, 4, 2), ev[:, 12:20].reshape(n, 4, 2), ev[:, 20:24]
         if n:
@@ -1177,7 +1168,7 @@ def family_shard_from(kind, events, device="cpu"):
         t_i, v_i = torch.cat([xst[:, :, 0].reshape(-1), yst[:, :, 0].reshape(-1)]), torch.cat([xst[:, :, 1].reshape(-1), yst[:, :, 1].reshape(-1)])
         t_f = torch.cat([(clk[:, None] + 1).expand(-1, 4).reshape(-1), clk[:, None].expand(-1, 4).reshape(-1)])
         v_f = torch.cat([outs.reshape(-1), yst[:, :, 1].reshape(-1)])
-        return _close_precompile_shard(tr, code, clk, pl, wa, t_i, t_f, v_i, v_f, arg2_limbs=_limbs_t(a2))
+        return _close_precompile_shard(tr, code, clk, pl, wa, t_i, t_f, v_i, v_f, arg2_limbs=_limbs_t(a2), ctx=ctx)
     assert shape == "uint256_ops"
     blocks = ev[:, 10:50].reshape(n, 5, 4, 2)                             # a, b, c, d, e: (previous timestamp, word before)
     is_mul = (ev[:, 3] & np.uint64(0xFF)) == M.SYS_UINT256_MUL_CARRY
@@ -1236,4 +1227,4 @@ def family_shard_from(kind, events, device="cpu"):
     v_i = torch.cat([t[:, 4:7].reshape(-1)] + [bt[:, j, :, 1].reshape(-1) for j in range(5)])
     t_f = torch.cat([clk[:, None].expand(-1, 3).reshape(-1)] + [(clk[:, None] + j).expand(-1, 4).reshape(-1) for j in range(5)])
     v_f = torch.cat([t[:, 4:7].reshape(-1)] + [bt[:, j, :, 1].reshape(-1) for j in range(3)] + [outs["d"].reshape(-1), outs["e"].reshape(-1)])
-    return _close_precompile_shard(tr, code, clk, limbs["a"], wa, t_i, t_f, v_i, v_f, arg2_limbs=limbs["b"])
+    return _close_precompile_shard(tr, code, clk, limbs["a"], wa, t_i, t_f, v_i, v_f, arg2_limbs=limbs["b"], ctx=ctx)

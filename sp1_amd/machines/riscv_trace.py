@@ -28,9 +28,11 @@ Timestamps: instruction n runs at clk0 + 8 n (CLK_INC), its accesses at +1 memor
 Byte / Range / Program multiplicities are not re-derived chip by chip: they are COUNTED from the messages the chips' own
 interaction programs send on the generated rows (every message is checked to be a row of the table it addresses).
 
-Closing chips (synthetic, a few rows): `Boundary` stands in for `eval_public_values` (sends the initial CPU state, receives
-the final one: core/executor/src/record.rs:L1020-L1032); `GlobalSink` receives MemoryLocal's `Global` messages where the
-real Global chip (septic-curve digest) would.
+What closes a shard is the reference's own record-level statement, `eval_public_values` (public_values.py): the shard's public
+values send the initial CPU state and receive the final one, hold the two ends of the Global chip's accumulation chain, and
+range-check their own limbs on the Byte bus — so a shard's tables are the chips of its shape cluster (riscv/mod.rs:L560-L803,
+chips without events at height zero) and nothing else. (`real_global=False` swaps the Global chip for a synthetic `GlobalSink`
+that only receives MemoryLocal's messages: a trace-generator test aid, never proved.)
 """
 import numpy as np
 import torch
@@ -611,6 +613,89 @@ class Table:
             self.main[:self.n, c] = val
         else:
             self.main[:self.n, c:c + val.shape[1]] = val
+
+
+class EmptyTable(Table):
+    """A chip of the cluster without events: no rows at all (not even padding rows)."""
+
+    def __init__(self, air, dev):
+        self.air, self.n = air, 0
+        self.main = torch.zeros((0, air.main_width), dtype=I64, device=dev)
+        self.prep = None
+        self.L = getattr(air, "layout", {})
+
+
+# the shape clusters of RiscvAir::machine (core/machine/src/riscv/mod.rs:L547-L803, `mprotect` off), by chip name
+_PREPROCESSED = ["Program", "Byte", "Range"]
+CORE_CLUSTER = _PREPROCESSED + ["SyscallCore", "DivRem", "Add", "Addi", "Addw", "Sub", "Subw", "Bitwise", "Mul", "ShiftRight", "ShiftLeft", "Lt", "AluX0",
+                                "LoadByte", "LoadHalf", "LoadWord", "LoadDouble", "LoadX0", "StoreByte", "StoreHalf", "StoreWord", "StoreDouble",
+                                "UType", "Branch", "Jal", "Jalr", "SyscallInstrs", "MemoryBump", "StateBump", "MemoryLocal", "Global"]
+MEMORY_CLUSTER = _PREPROCESSED + ["MemoryGlobalInit", "MemoryGlobalFinalize", "Global"]
+_PRECOMPILE_BASE = _PREPROCESSED + ["SyscallPrecompile", "MemoryLocal", "Global"]
+PRECOMPILE_CLUSTERS = [_PRECOMPILE_BASE + c for c in (
+    ["ShaExtend", "ShaExtendControl"], ["ShaCompress", "ShaCompressControl"], ["EdAddAssign"], ["EdDecompress"], ["Secp256k1AddAssign"],
+    ["Secp256k1DoubleAssign"], ["Secp256r1AddAssign"], ["Secp256r1DoubleAssign"], ["KeccakPermute", "KeccakPermuteControl"], ["Bn254AddAssign"],
+    ["Bn254DoubleAssign"], ["Bls12381AddAssign"], ["Bls12381DoubleAssign"], ["Uint256MulMod"], ["Uint256Ops"], ["Bls12381FpOpAssign"],
+    ["Bls12381Fp2AddSubAssign"], ["Bls12381Fp2MulAssign"], ["Bn254FpOpAssign"], ["Bn254Fp2AddSubAssign"], ["Bn254Fp2MulAssign"], ["Poseidon2"])]
+_CORE_EXTENSIONS = [["MemoryGlobalInit", "MemoryGlobalFinalize"], ["Bls12381FpOpAssign"], ["Bn254FpOpAssign"],
+                    ["ShaExtend", "ShaExtendControl", "ShaCompress", "ShaCompressControl"], ["Uint256Ops"], ["Poseidon2"]]
+
+
+def chip_clusters():
+    """`machine.shape().chip_clusters` as frozensets of chip names: the core cluster alone, with one extension, with all six, the
+    special one, the memory cluster, the 22 precompile clusters (riscv/mod.rs:L717-L790). A shard's chip set must BE one of them
+    (`ShardVerifier::verify_shard`, verifier/shard.rs:L537)."""
+    core = [CORE_CLUSTER] + [CORE_CLUSTER + e for e in _CORE_EXTENSIONS] + [CORE_CLUSTER + [n for e in _CORE_EXTENSIONS for n in e]]
+    core.append(CORE_CLUSTER + ["MemoryGlobalInit", "MemoryGlobalFinalize", "ShaExtend", "ShaExtendControl", "ShaCompress", "ShaCompressControl", "Uint256Ops"])
+    return [frozenset(c) for c in core + [MEMORY_CLUSTER] + PRECOMPILE_CLUSTERS]
+
+
+def smallest_cluster(names):
+    """`MachineShape::smallest_cluster` (hypercube/src/machine.rs:L29-L35)."""
+    fits = [c for c in chip_clusters() if set(names) <= c]
+    assert fits, ("no shape cluster holds", sorted(names))
+    return min(fits, key=len)
+
+
+def program_table(program, pc_base, dev, executed_pc=None):
+    """Program: one row per instruction of the text — `program` [n, 6] = (opcode, op_a, op_b, op_c, imm_b, imm_c), the
+    transpiled instruction list — (program/trusted.rs:L80-L131); multiplicity = how often each pc of `executed_pc` occurs (none:
+    a shard that executes nothing — every cluster holds the Program chip, riscv/mod.rs:L547-L560)."""
+    prog = torch.as_tensor(program, device=dev)
+    n = prog.shape[0]
+    air, it = R.chip("Program")
+    tb = Table(air, n, dev)
+    pc = pc_base + 4 * torch.arange(n, device=dev)
+    op, a, b_, c_, imm_b, imm_c = (prog[:, i] for i in range(6))
+    tb.prep[:n, 0:3] = limbs16(pc)[:, :3]
+    tb.prep[:n, 3], tb.prep[:n, 4] = op, a
+    regw = lambda r: torch.stack([r] + [torch.zeros_like(r)] * 3, dim=1)
+    tb.prep[:n, 5:9] = torch.where((imm_b == 1)[:, None], limbs16(b_), regw(b_))
+    tb.prep[:n, 9:13] = torch.where((imm_c == 1)[:, None], limbs16(c_), regw(c_))
+    tb.prep[:n, 13] = (a == 0).to(I64)
+    tb.prep[:n, 14], tb.prep[:n, 15] = imm_b, imm_c
+    if executed_pc is not None:
+        tb.main[:n, 0] = torch.bincount((executed_pc - pc_base) >> 2, minlength=n)
+    if tb.prep.shape[0] > n:
+        tb.prep[n:] = tb.prep[0]
+    return tb, (air, it)
+
+
+class RunContext:
+    """What a shard that executes no instructions still takes from the run it belongs to: the program (its Program table, all
+    multiplicities zero, and the entry point a precompile shard's public values name: `update_initialized_state`,
+    public_values.rs:L272-L299) and, for the memory shards, the final state of the execution (`update_finalized_state`).
+    The default is a one-instruction program that has run to HALT without committing anything: what the stand-alone shard
+    builders of riscv_more_trace.py (tests, `bench.py --workload precompile`) are set in."""
+
+    def __init__(self, program=None, pc_base=0x200000, pc_start=None, final=None):
+        self.program = np.array([[OPC["ADD"], 0, 0, 0, 0, 0]], dtype=np.int64) if program is None else program
+        self.pc_base, self.pc_start = pc_base, pc_base if pc_start is None else pc_start
+        # (timestamp, pc, exit code, committed_value_digest[8 words], deferred_proofs_digest[8])
+        self.final = final if final is not None else (9, 1, 0, [0] * 8, [0] * 8)
+
+    def program_table(self, dev):
+        return program_table(self.program, self.pc_base, dev)
 
 
 def generate(counts, K=1, seed=0, clk0=1, pc_base=0x200000, mem_pages=(4, 4), device="cpu", real_global=True):
@@ -1232,23 +1317,20 @@ class Tracer:
             tb.set("addr", reg)
             tb.set("is_real", 1)
 
-    # -- closing chips + table multiplicities
+    # -- public values, the cluster's empty chips, table multiplicities
     def finish(self):
+        from . import public_values as PVM
         ex, b, dev = self.ex, self.b, self.dev
         machine = {}
         for name, tb in self.tables.items():
             machine[name] = R.chip(name)
-        # Boundary: sends the initial state, receives the final one (stands in for eval_public_values' eval_state)
-        air, it = boundary_chip()
-        tb = Table(air, 2, dev)
         t0, t1 = ex.clk0, self.final_state[0]
         pc1 = self.final_state[1]
         if (t1 >> 24) != ((t1 - 8) >> 24) and "StateBump" not in self.tables:
             raise AssertionError("unreachable: a clock carry always has its StateBump row")
-        tb.main[0] = torch.tensor([t0 >> 24, t0 & 0xFFFFFF] + [(b.pc_base >> (16 * i)) & MASK16 for i in range(3)] + [1, 0], device=dev)
-        tb.main[1] = torch.tensor([t1 >> 24, t1 & 0xFFFFFF] + [(pc1 >> (16 * i)) & MASK16 for i in range(3)] + [0, 1], device=dev)
-        self.tables["Boundary"], machine["Boundary"] = tb, (air, it)
-        # GlobalSink: receives what MemoryLocal sends to the Global chip
+        # the shard's public values (record.rs postprocess + finalize_public_values): one execution shard from clk0 to the loop's end
+        pv = PVM.no_memory_events(PVM.set_state(PVM.blank(), b.pc_base, pc1, t0, t1, 0, True))
+        # the global interactions: MemoryLocal's two per row (initial = receive, final = send), then SyscallCore's
         ml = self.tables["MemoryLocal"]
         msgs = eval_interactions(R.chip("MemoryLocal")[1], ml.main[:ml.n], None, kinds=(R.GLOBAL,))
         (_, recv, _), (_, send, _) = msgs                              # MemoryLocal's two Global sends, [rows, 11] each
@@ -1258,8 +1340,9 @@ class Tracer:
                 t_ = self.tables[name]
                 events += [v for _, v, _ in eval_interactions(R.chip(name)[1], t_.main[:t_.n], None, kinds=(R.GLOBAL,))]
         if getattr(self, "real_global", True):
-            self.global_chip(machine, torch.cat(events))
+            PVM.set_global(pv, *self.global_chip(machine, torch.cat(events)))
         else:
+            PVM.set_global(pv, 0, None)
             air, it = global_sink_chip()
             rows = torch.cat(events)
             tb = Table(air, rows.shape[0], dev)
@@ -1275,13 +1358,25 @@ class Tracer:
         if tb.prep.shape[0] > tb.n:                               # padding rows repeat instruction 0 with multiplicity 0
             tb.prep[tb.n:] = tb.prep[0]
         self.tables["Program"], machine["Program"] = tb, (air, it)
-        self.byte_range_tables(machine)
+        self.byte_range_tables(machine, pv)
+        self.fill_cluster(machine, CORE_CLUSTER)
         names = sorted(machine)
-        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, torch.zeros(0, dtype=I64)
+        return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, PVM.to_tensor(pv)
 
-    def byte_range_tables(self, machine):
+    def fill_cluster(self, machine, cluster):
+        """The chips of the shard's shape cluster that have no events: height zero (`PaddedMle::zeros`, hypercube/src/prover/
+        trace.rs:L157-L180) — they are in the proof (opened values, LogUp-GKR interactions) like every other chip."""
+        for name in cluster:
+            if name not in machine:
+                air, it = R.chip(name)
+                assert air.prep_width == 0, name
+                self.tables[name], machine[name] = EmptyTable(air, self.dev), (air, it)
+
+    def byte_range_tables(self, machine, publics):
         """Byte / Range tables (bytes/trace.rs, range/trace.rs) with multiplicities COUNTED from the byte messages every table of
-        `self.tables` sends on its rows; every message is checked to be a row of the table it addresses."""
+        `self.tables` sends on its rows and the ones `eval_public_values` sends for `publics` (the generate_dependencies of the
+        two tables: bytes/trace.rs:L50-L66, range/trace.rs:L54-L95); every message is checked to be a row of the table it addresses."""
+        from . import public_values as PVM
         dev = self.dev
         byte_air, byte_it = R.chip("Byte")
         range_air, range_it = R.chip("Range")
@@ -1293,9 +1388,10 @@ class Tracer:
         ri = torch.arange(1 << 17, device=dev)
         bits = torch.where(ri == 0, torch.zeros_like(ri), (torch.log2(ri.clamp(min=1).to(torch.float64)).floor()).to(I64))
         rt.prep[:, 0], rt.prep[:, 1] = torch.where(ri == 0, torch.zeros_like(ri), ri - (1 << bits)), bits
-        for name, tbl in self.tables.items():
-            _, it = machine[name]
-            for mult, vals, _ in eval_interactions(it, tbl.main[:tbl.n], tbl.prep[:tbl.n] if tbl.prep is not None else None, kinds=(R.BYTE,), sends_only=True):
+        senders = [(name, machine[name][1], tbl.main[:tbl.n], tbl.prep[:tbl.n] if tbl.prep is not None else None) for name, tbl in self.tables.items()]
+        senders.append(("PublicValues", PVM.program()[1], PVM.row(publics, dev), None))
+        for name, it, main_rows, prep_rows in senders:
+            for mult, vals, _ in eval_interactions(it, main_rows, prep_rows, kinds=(R.BYTE,), sends_only=True):
                 opc, a, x, y = vals[:, 0], vals[:, 1], vals[:, 2], vals[:, 3]
                 is_range = opc == R.B_RANGE
                 if bool(is_range.any()):
@@ -1318,7 +1414,7 @@ class Tracer:
     def global_chip(self, machine, ev):
         """GlobalChip::generate_trace_into (global/mod.rs:L131-L260): one row per global interaction event `ev` [n, 11] — the two
         events of every MemoryLocal row (memory/local.rs generate_dependencies: initial = receive, final = send), then the
-        syscall events of SyscallCore."""
+        syscall events of SyscallCore. Returns (number of events, the digest they accumulate to [x[7], y[7]])."""
         from . import septic as SE
         dev = self.dev
         n = ev.shape[0]
@@ -1359,14 +1455,8 @@ class Tracer:
                 c0 = tb.L["accumulation." + nm]
                 pad[:, c0:c0 + 7] = v
         self.tables["Global"], machine["Global"] = tb, (air, it)
-        # the two ends of the accumulation chain, where eval_public_values' eval_global_sum stands in the reference
-        air, it = global_acc_boundary_chip()
-        bt = Table(air, 2, dev)
-        bt.main[0, 0:15] = torch.cat([torch.zeros(1, dtype=I64, device=dev), start[0], start[1]])
-        bt.main[0, 15] = 1
-        bt.main[1, 0:15] = torch.cat([torch.full((1,), n, dtype=I64, device=dev), cx[-1], cy[-1]])
-        bt.main[1, 16] = 1
-        self.tables["GlobalAccBoundary"], machine["GlobalAccBoundary"] = bt, (air, it)
+        # the two ends of the accumulation chain are public values: global_count, global_cumulative_sum (eval_global_sum)
+        return n, [int(v) for v in cx[-1]] + [int(v) for v in cy[-1]]
 
     def _program_rows(self, tb, p):
         ex = self.ex
@@ -1427,18 +1517,6 @@ def eval_interactions(it, main, prep, kinds=None, sends_only=False):
     return out
 
 
-def boundary_chip():
-    """Synthetic: [clk_high, clk_low, pc0, pc1, pc2, is_send, is_receive]; sends / receives one State message per row."""
-    from .rv_builder import Builder
-    b = Builder("Boundary", 7)
-    c = [b.main(i) for i in range(7)]
-    b.assert_bool(c[5])
-    b.assert_bool(c[6])
-    b.send(R.STATE, c[:5], c[5])
-    b.receive(R.STATE, c[:5], c[6])
-    return b.air, b.it
-
-
 def global_sink_chip():
     """Synthetic: receives MemoryLocal's 11-word `Global` messages where the reference's Global chip would."""
     from .rv_builder import Builder
@@ -1446,19 +1524,6 @@ def global_sink_chip():
     c = [b.main(i) for i in range(12)]
     b.assert_bool(c[11])
     b.receive(R.GLOBAL, c[:11], c[11])
-    return b.air, b.it
-
-
-def global_acc_boundary_chip():
-    """Synthetic: [index, x[7], y[7], is_send, is_receive] — sends (0, zero digest), receives (count, final sum) like
-    eval_global_sum (core/executor/src/record.rs:L1331-L1363)."""
-    from .rv_builder import Builder
-    b = Builder("GlobalAccBoundary", 17)
-    c = [b.main(i) for i in range(17)]
-    b.assert_bool(c[15])
-    b.assert_bool(c[16])
-    b.send(R.GLOBAL_ACC, c[:15], c[15])
-    b.receive(R.GLOBAL_ACC, c[:15], c[16])
     return b.air, b.it
 
 

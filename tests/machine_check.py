@@ -102,3 +102,50 @@ def bus_imbalance_fast(chips, seed=1):
     ends = cs[last]
     sums = ends - np.r_[0, ends[:-1]]
     return int(np.count_nonzero(sums % P))
+
+
+def check_shard(machine, tabs, publics, pv_program=None):
+    """Every constraint of every chip on every row and every bus of one shard: returns (failing chips, unbalanced message keys).
+    `pv_program`: the machine's eval_public_values as (AirProgram, InteractionProgram) — its constraints must vanish on `publics`
+    and its sends / receives (the record's own: initial / final CPU state, the ends of the accumulation chains, range checks of
+    the public limbs) join the buses; without it a RISC-V shard does NOT balance."""
+    chips, bad = [], []
+    pv = (publics.numpy() if hasattr(publics, "numpy") else np.asarray(publics)).astype(np.uint64)
+    for air, it in machine:
+        prep, main = tabs[air.name]
+        m = main.cpu().numpy().astype(np.uint64)
+        pr = prep.cpu().numpy().astype(np.uint64) if prep is not None else None
+        assert (main >= 0).all() and (m < P).all(), air.name
+        if air.num_constraints and m.shape[0] and constraint_values(air, pr, m, pv).any():
+            bad.append(air.name)
+        chips.append((it, pr, m))
+    if pv_program is not None:
+        air, it = pv_program
+        row = pv[None, :it.main_width]
+        if constraint_values(air, None, row, pv).any():
+            bad.append(air.name)
+        chips.append((it, None, row))
+    return bad, bus_imbalance_fast(chips)
+
+
+def check_exact(machine, tabs, publics, pv_program=None):
+    """check_shard for small tables: ASSERTS that every constraint vanishes (naming the chip and the first failing constraint
+    indices) and returns the exact tally of unbalanced messages ({} = balanced)."""
+    chips = []
+    pv = (publics.numpy() if hasattr(publics, "numpy") else np.asarray(publics)).astype(np.uint64)
+    for air, it in machine:
+        prep, main = tabs[air.name]
+        m = main.cpu().numpy().astype(np.uint64)
+        pr = prep.cpu().numpy().astype(np.uint64) if prep is not None else None
+        assert (main >= 0).all() and (m < P).all(), air.name
+        if air.num_constraints and m.shape[0]:
+            cv = constraint_values(air, pr, m, pv)
+            assert not cv.any(), (air.name, sorted(set(np.argwhere(cv != 0)[:, 1]))[:8])
+        chips.append((it, pr, m))
+    if pv_program is not None:
+        air, it = pv_program
+        row = pv[None, :it.main_width]
+        cv = constraint_values(air, None, row, pv)
+        assert not cv.any(), (air.name, sorted(set(np.argwhere(cv != 0)[:, 1]))[:8])
+        chips.append((it, None, row))
+    return bus_imbalance(chips)

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 import pyoracle as orc  # noqa: E402
+from sp1_amd.machines import public_values as PVM  # noqa: E402
 from sp1_amd.machines import riscv_exec as X  # noqa: E402
 from sp1_amd.machines import riscv_trace as RT  # noqa: E402
 
@@ -58,8 +59,9 @@ def prove_both(api, machine, tabs, publics, L, lsh, batch, LB, NQ, PW, verify=Tr
     got = api.prove_shard(dev, pv, g_prep, L, lsh, batch, g_ch, LB, NQ, PW)
     assert got == want
     assert np.array_equal(g_ch.state(), o_ch.state())
-    if verify:
-        assert orc.shard_verify(_shapes_only(machine), g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
+    if verify:      # the reference's statement: the chip set is a shape cluster of the machine, the cumulative sum is the public values'
+        assert frozenset(a.name for a, _ in machine) in RT.chip_clusters()
+        assert orc.shard_verify(_shapes_only(machine), g_commit, got, L, lsh, v_ch, LB, NQ, PW, pv_program=PVM.verifier_program()) == 0
 
 
 @pytest.mark.parametrize("program,stdin,max_cycles,kinds", [
@@ -134,4 +136,30 @@ def test_a_corrupted_real_trace_is_rejected(api):
     proof = api.prove_shard(dev, pv, prep, L, lsh, batch, ch, 1, 5, 4)
     v_ch = orc.Challenger()
     v_ch.observe(commit)
-    assert orc.shard_verify(_shapes_only(machine), commit, proof, L, lsh, v_ch, 1, 5, 4) != 0
+    assert orc.shard_verify(_shapes_only(machine), commit, proof, L, lsh, v_ch, 1, 5, 4, pv_program=PVM.verifier_program()) != 0
+
+
+def test_a_proof_for_other_public_values_is_rejected(api):
+    """The GPU prover proves with the public values it is given (the reference's prover samples `pv_challenge` and drops it,
+    logup_gkr/prover.rs:L93); the VERIFIER derives the cumulative sum the LogUp-GKR output must have from them: a shard proved
+    for a different entry pc, digest or clock fails with the cumulative-sum code, a public word that breaks eval_public_values'
+    own constraints with the public-values code."""
+    import core_real
+    ex = X.Executor(_elf("fibonacci"), stdin=[struct.pack("<Q", 100)])
+    sh = ex.run_shard(1 << 20)
+    machine, tabs, publics = X.shard_tables(ex, sh, device="cuda")
+    dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
+           for a, i in machine]
+    L, lsh, batch = 17, 12, 8
+    commit, prep = api.JaggedProver(L, lsh, batch, 1).commit_multilinears([d[3] for d in dev if d[3] is not None])
+    for word, code in ((None, 0), (PVM.PV["pc_start"], 104), (PVM.PV["global_cumulative_sum"] + 2, 104), (PVM.PV["global_count"], 104),
+                       (PVM.PV["is_execution_shard"], 109), (PVM.PV["last_timestamp"] + 3, 109), (PVM.NUM_PV_ELTS + 3, 4)):
+        pv = publics.clone()
+        if word is not None:
+            pv[word] = (pv[word] + 1) % RT.P
+        ch = api.DuplexChallenger()
+        ch.observe(commit)
+        proof = api.prove_shard(dev, RT.to_monty_np(pv), prep, L, lsh, batch, ch, 1, 5, 4)
+        v_ch = orc.Challenger()
+        v_ch.observe(commit)
+        assert orc.shard_verify(_shapes_only(machine), commit, proof, L, lsh, v_ch, 1, 5, 4, pv_program=PVM.verifier_program()) == code, word

@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 import pyoracle as orc  # noqa: E402
+from sp1_amd.machines import public_values as PVM  # noqa: E402
 from sp1_amd.machines import riscv_more_trace as MT  # noqa: E402
 from sp1_amd.machines import riscv_trace as RT  # noqa: E402
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench"))
-PUBLICS = np.zeros(160, np.uint32)
 
 
 @pytest.fixture(scope="module")
@@ -28,8 +28,9 @@ def api():
     return a
 
 
-def _prove_both(api, machine, tabs, L=17, lsh=12, batch=8, LB=1, NQ=5, PW=4, check_verifier=True):
+def _prove_both(api, machine, tabs, publics, L=17, lsh=12, batch=8, LB=1, NQ=5, PW=4, check_verifier=True):
     import core_real
+    PUBLICS = RT.to_monty_np(publics.cpu())                 # the shard's own public values (they close its buses)
     host = [(a, i, RT.to_monty_np(tabs[a.name][1].cpu()), RT.to_monty_np(tabs[a.name][0].cpu()) if tabs[a.name][0] is not None else None)
             for a, i in machine]
     dev = [(a, i, core_real.to_col_major(tabs[a.name][1].cuda()), core_real.to_col_major(tabs[a.name][0].cuda()) if tabs[a.name][0] is not None else None)
@@ -52,16 +53,16 @@ def _prove_both(api, machine, tabs, L=17, lsh=12, batch=8, LB=1, NQ=5, PW=4, che
     if check_verifier:
         shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
                   for a, i in machine]
-        assert orc.shard_verify(shapes, g_commit, got, L, lsh, v_ch, LB, NQ, PW) == 0
+        assert orc.shard_verify(shapes, g_commit, got, L, lsh, v_ch, LB, NQ, PW, pv_program=PVM.verifier_program()) == 0
     return got
 
 
 def test_core_shard_with_divrem_and_ecalls_matches_oracle(api):
     counts = {"Add": 3, "Addi": 5, "Sub": 2, "Bitwise": 3, "Lt": 3, "Mul": 3, "DivRem": 24, "Ecall": 12, "UType": 8, "LoadWord": 3, "LoadByte": 3,
               "StoreWord": 3, "StoreByte": 3, "Branch": 5, "Jal": 2, "Jalr": 2}
-    machine, tabs, _ = RT.generate(counts, K=3, seed=5, device="cuda")
-    assert {"DivRem", "SyscallInstrs", "SyscallCore"} <= {a.name for a, _ in machine}
-    _prove_both(api, machine, tabs)
+    machine, tabs, publics = RT.generate(counts, K=3, seed=5, device="cuda")
+    assert all(tabs[n][1].shape[0] for n in ("DivRem", "SyscallInstrs", "SyscallCore"))
+    _prove_both(api, machine, tabs, publics)
 
 
 @pytest.mark.parametrize("n_events,env", [(2, {}), (12, {}), (12, {"SP1HIP_ZC_BIVARIATE": "0"}), (12, {"SP1HIP_ZC_MACRO": "0"}),
@@ -71,17 +72,17 @@ def test_keccak_precompile_shard_matches_oracle(api, monkeypatch, n_events, env)
     kernels), sequential rounds, hints ignored."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    machine, tabs, _ = MT.precompile_shard(n_events, seed=3, device="cuda")
+    machine, tabs, publics = MT.precompile_shard(n_events, seed=3, device="cuda")
     assert tabs["KeccakPermute"][1].shape[1] == 2640
-    _prove_both(api, machine, tabs, check_verifier=(n_events == 2))
+    _prove_both(api, machine, tabs, publics, check_verifier=(n_events == 2))
 
 
 def test_keccak_precompile_shard_at_production_parameters(api):
     """1/64 of the bench's precompile shard (80 permutations, 1,920 rows of the wide chip), blowup 4, 124 queries, 16-bit PoW."""
-    machine, tabs, _ = MT.precompile_shard(80, seed=7, device="cuda")
-    _prove_both(api, machine, tabs, L=17, lsh=15, batch=32, LB=2, NQ=124, PW=16, check_verifier=False)
+    machine, tabs, publics = MT.precompile_shard(80, seed=7, device="cuda")
+    _prove_both(api, machine, tabs, publics, L=17, lsh=15, batch=32, LB=2, NQ=124, PW=16, check_verifier=False)
 
 
 def test_memory_shard_matches_oracle(api):
-    machine, tabs, _ = MT.memory_shard(300, seed=2, device="cuda")
-    _prove_both(api, machine, tabs)
+    machine, tabs, publics = MT.memory_shard(300, seed=2, device="cuda")
+    _prove_both(api, machine, tabs, publics)

@@ -52,7 +52,7 @@ def test_device_global_trace_equals_the_host_trace(api, counts, K):
 def test_shard_proof_from_the_device_generated_global_table(api):
     import core_real
     counts = {"Add": 4, "Addi": 6, "LoadWord": 6, "StoreWord": 6, "UType": 8, "Branch": 4}
-    machine, tabs, _ = RT.generate(counts, K=2, seed=19, device="cuda")
+    machine, tabs, publics = RT.generate(counts, K=2, seed=19, device="cuda")
     dev = [(a, i, core_real.to_col_major(tabs[a.name][1]), core_real.to_col_major(tabs[a.name][0]) if tabs[a.name][0] is not None else None)
            for a, i in machine]
     L, lsh, batch = 17, 12, 8
@@ -61,7 +61,7 @@ def test_shard_proof_from_the_device_generated_global_table(api):
     def prove(chips):
         ch = api.DuplexChallenger()
         ch.observe(commit)
-        return api.prove_shard(chips, [], prep, L, lsh, batch, ch, 1, 5, 4)
+        return api.prove_shard(chips, RT.to_monty_np(publics), prep, L, lsh, batch, ch, 1, 5, 4)
     want = prove(dev)
     main = tabs["Global"][1]
     n = int((main[:, R.chip("Global")[0].layout["is_real"]] == 1).sum())

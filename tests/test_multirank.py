@@ -268,9 +268,12 @@ def _guest_shard_worker(rank, world, port, max_cycles, q):
     from sp1_amd.machines import riscv_exec as X, riscv_trace as RT
     orc.set_threads(1)
     ex = X.Executor(X.guest_file("fibonacci.elf"), stdin=[struct.pack("<Q", 10_000)])
-    for i in range(rank + 1):                       # the shards before this rank's run without keeping their events
+    prev = None
+    for i in range(rank + 1):                       # the shards before this rank's run without keeping their events ...
         sh = ex.run_shard(max_cycles, record=i == rank)
-    machine, tabs, publics = X.shard_tables(ex, sh)
+        if i < rank:                                # ... but their public values chain into this rank's (prev_* fields)
+            prev = X.execution_public_values(sh, prev)
+    machine, tabs, publics = X.shard_tables(ex, sh, prev=prev)
     host = [(a, i, RT.to_monty_np(tabs[a.name][1]), RT.to_monty_np(tabs[a.name][0]) if tabs[a.name][0] is not None else None) for a, i in machine]
     L, lsh, batch = 17, 12, 8
     prep = orc.JaggedRound([c[3] for c in host if c[3] is not None], L, lsh, batch, 1)
@@ -281,7 +284,8 @@ def _guest_shard_worker(rank, world, port, max_cycles, q):
     shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None) for a, i in machine]
     v_ch = orc.Challenger()
     v_ch.observe(prep.commit)
-    ok = orc.shard_verify(shapes, prep.commit, proof, L, lsh, v_ch, 1, 5, 4) == 0
+    from sp1_amd.machines import public_values as PVM
+    ok = orc.shard_verify(shapes, prep.commit, proof, L, lsh, v_ch, 1, 5, 4, pv_program=PVM.verifier_program()) == 0
     merged = shards.gather_blobs({rank: proof})
     q.put((rank, ok, sh.index, sh.clk_start, sh.clk_end, sh.pc_start, sh.next_pc, sorted((k, len(v)) for k, v in merged.items())))
     dist.barrier()

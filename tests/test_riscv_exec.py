@@ -22,7 +22,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import machine_check as MC
 import rv_asm as A
 
+from sp1_amd.machines import public_values as PVM
 from sp1_amd.machines import riscv_exec as X
+from sp1_amd.machines import riscv_trace as RT
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M64 = (1 << 64) - 1
@@ -33,30 +35,32 @@ def _elf(name):
 
 
 def check_shard(machine, tabs, publics):
-    """Every constraint on every row, every bus: returns (failing chips, unbalanced message keys)."""
-    chips, bad, pv = [], [], publics.numpy().astype(np.uint64)
-    for air, it in machine:
-        prep, main = tabs[air.name]
-        m = main.numpy().astype(np.uint64)
-        pr = prep.numpy().astype(np.uint64) if prep is not None else None
-        assert (main >= 0).all() and (m < MC.P).all(), air.name
-        if air.num_constraints and MC.constraint_values(air, pr, m, pv).any():
-            bad.append(air.name)
-        chips.append((it, pr, m))
-    return bad, MC.bus_imbalance_fast(chips)
+    """Every constraint on every row, every bus — the chips' and the public values' (eval_public_values): returns
+    (failing chips, unbalanced message keys). The shard must be one of the machine's shape clusters."""
+    assert frozenset(a.name for a, _ in machine) in RT.chip_clusters()
+    return MC.check_shard(machine, tabs, publics, PVM.program())
 
 
 def run_program(elf, stdin, max_cycles):
     ex = X.Executor(elf, stdin=stdin)
-    kinds, gevs, cycles, last = [], [], 0, None
+    kinds, gevs, pvs, cycles, last = [], [], [], 0, None
     for kind, machine, tabs, publics, gev, sh in X.program_shards(ex, max_cycles):
         bad, imb = check_shard(machine, tabs, publics)
         assert not bad and not imb, (kind, bad, imb)
         kinds.append(kind)
         gevs.append(gev)
+        pvs.append([int(v) for v in publics])
         if sh is not None:
             cycles, last = cycles + sh.cycles, sh
+            entry = sh.pc_start if len(kinds) == 1 else entry
     assert not X.global_events_balance(gevs)
+    # what `SP1Prover::verify` checks across the shards of a core proof before it verifies each of them: the public values chain
+    # (timestamps, pcs, exit codes, digests, address chains) from the entry point to HALT and the shards' septic digests add up to zero
+    err = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds)], entry)
+    if last.commit_syscall and last.commit_deferred_syscall:
+        assert err is None
+    else:       # a hand-assembled program that halts without COMMIT / COMMIT_DEFERRED_PROOFS: the reference refuses exactly that
+        assert err == "prev_commit_syscall doesn't equal the previous shard's commit_syscall"
     return ex, kinds, cycles, last
 
 
@@ -461,6 +465,6 @@ def test_the_oracle_proves_and_verifies_the_halting_shard_with_its_public_values
             ch.observe(prep.commit)
             v_ch = ch.clone()
             blob = orc.shard_prove(host, RT.to_monty_np(pv), prep, L, lsh, batch, ch, 1, 5, 4)
-            assert (orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4) == 0) == want_ok
+            assert (orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4, pv_program=PVM.verifier_program()) == 0) == want_ok
     finally:
         orc.set_gkr_sparse(False)

@@ -12,6 +12,7 @@ import pytest
 
 import machine_check as MC
 import pyoracle as orc
+from sp1_amd.machines import public_values as PVM
 from sp1_amd.machines import riscv as R
 from sp1_amd.machines import riscv_more as M
 from sp1_amd.machines import riscv_more_trace as MT
@@ -31,18 +32,9 @@ def test_counts_equal_the_reference_tables(name):
         assert R.RECORDED[name] == (cols, cons, inter)
 
 
-def _check(machine, tabs, publics=PUBLICS):
-    chips = []
-    for air, it in machine:
-        prep, main = tabs[air.name]
-        m = main.numpy().astype(np.uint64)
-        pr = prep.numpy().astype(np.uint64) if prep is not None else None
-        assert (main >= 0).all() and (m < MC.P).all(), air.name
-        if air.num_constraints:
-            cv = MC.constraint_values(air, pr, m, publics)
-            assert not cv.any(), (air.name, sorted(set(np.argwhere(cv != 0)[:, 1]))[:8])
-        chips.append((it, pr, m))
-    return MC.bus_imbalance(chips)
+def _check(machine, tabs, publics):
+    """Every constraint on every row (asserted) and the exact bus tally of the chips and of the record's eval_public_values."""
+    return MC.check_exact(machine, tabs, publics, PVM.program())
 
 
 CORE = {"Add": 3, "Addi": 5, "Sub": 2, "Bitwise": 3, "Lt": 3, "Mul": 3, "DivRem": 24, "Ecall": 12, "UType": 8, "LoadWord": 3, "LoadByte": 3,
@@ -53,10 +45,10 @@ CORE = {"Add": 3, "Addi": 5, "Sub": 2, "Bitwise": 3, "Lt": 3, "Mul": 3, "DivRem"
 def test_executed_core_traces_with_divrem_and_ecalls(K, seed, clk0):
     """DIV / DIVU / REM / REMU / DIVW / DIVUW / REMW / REMUW (x0 operands give divisions by zero) and ECALLs — with and without a
     table of their own (SyscallCore rows, Global sends), the clock advancing by 8 + 256 — next to the other instructions."""
-    machine, tabs, _ = RT.generate(CORE, K=K, seed=seed, clk0=clk0)
-    names = {a.name for a, _ in machine}
-    assert {"DivRem", "SyscallInstrs", "SyscallCore", "Global", "MemoryLocal"} <= names
-    assert not _check(machine, tabs)
+    machine, tabs, publics = RT.generate(CORE, K=K, seed=seed, clk0=clk0)
+    assert {a.name for a, _ in machine} == set(RT.CORE_CLUSTER)
+    assert all(tabs[n][1].shape[0] for n in ("DivRem", "SyscallInstrs", "SyscallCore", "Global", "MemoryLocal"))
+    assert not _check(machine, tabs, publics)
     ops = set(tabs["Program"][0][:, 3].tolist())
     assert {R.OPC[o] for o in ("DIV", "DIVU", "REM", "REMU", "DIVW", "DIVUW", "REMW", "REMUW", "ECALL")} <= ops
 
@@ -95,18 +87,23 @@ def test_keccak_rows_compute_the_permutation():
 
 
 def test_precompile_shard_satisfies_every_chip_and_balances():
-    machine, tabs, _ = MT.precompile_shard(3, seed=1)
+    machine, tabs, publics = MT.precompile_shard(3, seed=1)
     names = [a.name for a, _ in machine]
-    assert names == ["Byte", "Global", "GlobalAccBoundary", "KeccakPermute", "KeccakPermuteControl", "MemoryLocal", "Range", "SyscallPrecompile"]
-    assert tabs["KeccakPermute"][1].shape == (96, 2640)
-    assert not _check(machine, tabs)
+    # the reference's Keccak cluster (riscv/mod.rs:L560-L578): the three preprocessed chips, SyscallPrecompile, MemoryLocal, Global + the two
+    assert names == ["Byte", "Global", "KeccakPermute", "KeccakPermuteControl", "MemoryLocal", "Program", "Range", "SyscallPrecompile"]
+    assert frozenset(names) in RT.chip_clusters()
+    assert tabs["KeccakPermute"][1].shape == (96, 2640) and not tabs["Program"][1].any()
+    # a precompile shard stands in the program's initial state: timestamp 1, pc = entry, not an execution shard
+    assert PVM.get(publics, "initial_timestamp") == PVM.get(publics, "last_timestamp") == [0, 0, 0, 1]
+    assert PVM.get(publics, "pc_start") == PVM.get(publics, "next_pc") and PVM.get(publics, "is_execution_shard") == 0
+    assert not _check(machine, tabs, publics)
     # one flipped state bit in one round: the constraints (or the Keccak bus) notice
     air = R.chip("KeccakPermute")[0]
     for col in (air.layout["keccak.a_prime.2.3"] + 17, air.layout["keccak.a_prime_prime.1.1"], air.layout["keccak.c.4"] + 63):
         t = {k: (p, m.clone()) for k, (p, m) in tabs.items()}
         t["KeccakPermute"][1][30, col] = (t["KeccakPermute"][1][30, col] + 1) % MC.P
         try:
-            imbalance = _check(machine, t)
+            imbalance = _check(machine, t, publics)
         except AssertionError:
             continue
         assert imbalance, col
@@ -114,14 +111,21 @@ def test_precompile_shard_satisfies_every_chip_and_balances():
 
 @pytest.mark.parametrize("with_zero", [True, False])
 def test_memory_shard_satisfies_every_chip_and_balances(with_zero):
-    machine, tabs, _ = MT.memory_shard(40, seed=2, with_zero=with_zero)
-    assert {"MemoryGlobalInit", "MemoryGlobalFinalize", "Global"} <= {a.name for a, _ in machine}
-    assert not _check(machine, tabs)
+    machine, tabs, publics = MT.memory_shard(40, seed=2, with_zero=with_zero)
+    assert [a.name for a, _ in machine] == sorted(RT.MEMORY_CLUSTER)
+    assert PVM.get(publics, "global_init_count") == PVM.get(publics, "global_finalize_count") == 40
+    assert (PVM.get(publics, "previous_init_addr") == [0, 0, 0]) == with_zero
+    assert not _check(machine, tabs, publics)
+    # the ends of the two address chains are public values: another last address, count or first address does not balance
+    for word in (PVM.PV["last_init_addr"], PVM.PV["global_finalize_count"], PVM.PV["previous_finalize_addr"] + 1):
+        pv = publics.clone()
+        pv[word] = (pv[word] + 1) % (1 << 16)
+        assert _check(machine, tabs, pv), word
     t = {k: (p, m.clone()) for k, (p, m) in tabs.items()}
     lay = R.chip("MemoryGlobalInit")[0].layout
     t["MemoryGlobalInit"][1][5, lay["addr"]], t["MemoryGlobalInit"][1][6, lay["addr"]] = tabs["MemoryGlobalInit"][1][6, lay["addr"]], tabs["MemoryGlobalInit"][1][5, lay["addr"]]
     with pytest.raises(AssertionError):                      # addresses out of order: the comparison constraints fail
-        assert not _check(machine, t)
+        assert not _check(machine, t, publics)
 
 
 def test_oracle_proves_and_verifies_the_precompile_shard():
@@ -133,18 +137,19 @@ def test_oracle_proves_and_verifies_the_precompile_shard():
     ch = orc.Challenger()
     ch.observe(prep.commit)
     v = ch.clone()
-    publics = np.zeros(M.PV_NUM_ELTS, np.uint32)
     orc.set_gkr_sparse(True)
     try:
-        blob = orc.shard_prove(chips, publics, prep, L, lsh, batch, ch, LB, NQ, PW)
+        blob = orc.shard_prove(chips, RT.to_monty_np(pv), prep, L, lsh, batch, ch, LB, NQ, PW)
     finally:
         orc.set_gkr_sparse(False)
     shapes = [(a, i, np.zeros((0, a.main_width), np.uint32), np.zeros((0, a.prep_width), np.uint32) if a.prep_width else None)
               for a, i in machine]
-    assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v.clone(), LB, NQ, PW) == 0
+    pvp = PVM.verifier_program()
+    assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v.clone(), LB, NQ, PW, pv_program=pvp) == 0
+    assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v.clone(), LB, NQ, PW) == 104      # not a zero-sum shard
     bad = bytearray(blob)
     bad[len(bad) // 3] ^= 1
-    assert orc.shard_verify(shapes, prep.commit, bytes(bad), L, lsh, v.clone(), LB, NQ, PW) != 0
+    assert orc.shard_verify(shapes, prep.commit, bytes(bad), L, lsh, v.clone(), LB, NQ, PW, pv_program=pvp) != 0
 
 
 def test_vectorised_keccak_rounds_equal_the_scalar_ones():

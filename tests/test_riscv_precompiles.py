@@ -207,7 +207,8 @@ def test_the_oracle_proves_and_verifies_the_carry_shard():
         ch.observe(prep.commit)
         v_ch = ch.clone()
         blob = orc.shard_prove(host, RT.to_monty_np(publics), prep, L, lsh, batch, ch, 1, 5, 4)
-        assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4) == 0
+        from sp1_amd.machines import public_values as PVM
+        assert orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4, pv_program=PVM.verifier_program()) == 0
     finally:
         orc.set_gkr_sparse(False)
 
