@@ -125,8 +125,11 @@ __device__ __forceinline__ uint32_t level_pos(uint32_t e, uint32_t len) {
 }
 
 // ================================================================ first layer
-// Per (chip, interaction): program words in device memory (layout of sp1_amd/air.py InteractionProgram, one
-// interaction: is_send, kind, n_values, vcol(multiplicity), vcol(values..)), column-major traces.
+// Per (chip, interaction): program words in device memory, column-major traces. The words are the host's form of one
+// interaction of sp1_amd/air.py's InteractionProgram with everything that does not depend on the row folded in once the
+// challenges are known: [is_send, n, head[4], vcol(multiplicity), n x (beta index, vcol(value))] — head = alpha + beta_0 kind +
+// sum over the CONSTANT values c_j of beta_(1+j) c_j (a third of a core shard's message words are constants: byte opcodes, the
+// 16 of a range check, zero operands), the n remaining values name their beta.
 struct IntDesc {
     const uint32_t* prog;      // this interaction's words
     const uint32_t* main;      // column-major [main_w][rows]
@@ -150,17 +153,20 @@ __device__ __forceinline__ uint32_t vcol_apply(prog_words_t& p, const IntDesc& d
 }
 
 // betas: [n_betas] ext (partial Lagrange of beta_seed)
-__global__ __launch_bounds__(256) void first_layer_kernel(const IntDesc* __restrict__ descs, Ext alpha, const Ext* __restrict__ betas) {
+__global__ __launch_bounds__(256) void first_layer_kernel(const IntDesc* __restrict__ descs, const Ext* __restrict__ betas) {
     const IntDesc d = descs[blockIdx.y];
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < d.rows; r += gridDim.x * blockDim.x) {
         prog_words_t p = (prog_words_t)(uintptr_t)d.prog;
         const bool is_send = p[0] != 0;
-        const uint32_t kind = p[1], nv = p[2];            // kind: Montgomery form
-        p += 3;
+        const uint32_t nv = p[1];
+        Ext den{{p[2], p[3], p[4], p[5]}};                 // head (see above)
+        p += 6;
         uint32_t m = vcol_apply(p, d, r);
         if (!is_send) m = kb::sub(0u, m);
-        Ext den = kb::ext_add(alpha, kb::ext_mul_base(ld_ext(betas, 0), kind));
-        for (uint32_t j = 0; j < nv; j++) den = kb::ext_add(den, kb::ext_mul_base(ld_ext(betas, 1 + j), vcol_apply(p, d, r)));
+        for (uint32_t j = 0; j < nv; j++) {
+            const uint32_t bi = *p++;
+            den = kb::ext_add(den, kb::ext_mul_base(ld_ext(betas, bi), vcol_apply(p, d, r)));
+        }
         const uint32_t rp = level_pos(r, d.rows);
         gptr(d.n_out)[rp] = m;
         st_ext(d.d_out, rp, den);
@@ -204,6 +210,150 @@ __global__ __launch_bounds__(256) void transition_kernel(const TransDesc* __rest
             st_ext(d.n_out, io, load_n<NBASE>(d.n_in, ia));
             st_ext(d.d_out, io, da);
         }
+    }
+}
+
+// ---- the first layer and the two tree levels below it in ONE pass over the traces (round 6). A lane owns FOUR consecutive
+// rows of one interaction: it evaluates their fractions (level L), combines them in pairs (level L - 1) and the pairs again
+// (level L - 2) in registers and stores all three levels — level L is never read back to build the tree (20 B per entry) and
+// level L - 1 (32 B per entry pair) neither: 44 B per first-layer entry move where first_layer_kernel + two transition
+// launches moved 80. Column reads are one 16 B load per lane and term (rows % 4 == 0: every table this library's tracers
+// make), 1 KiB per wave instruction. Same field operations in the same order as the separate kernels: bit-identical levels.
+struct FirstDesc {
+    const uint32_t* prog;      // this interaction's words
+    const uint32_t* main;      // column-major [main_w][rows]
+    const uint32_t* prep;
+    uint32_t rows;
+    uint32_t* n0_out;          // level L: base numerators [rows]
+    Ext* d0_out;               //          ext denominators [rows]
+    Ext* n1_out; Ext* d1_out;  // level L - 1 [ceil(rows / 2)]
+    Ext* n2_out; Ext* d2_out;  // level L - 2 [ceil(rows / 4)]
+};
+
+// vcol over rows 4 q .. 4 q + 3 (rows >= 4 q + 1; lanes past the table's end hold zeros)
+__device__ __forceinline__ void vcol_apply4(prog_words_t& p, const FirstDesc& d, uint32_t q, bool vec, uint32_t (&out)[4]) {
+    const uint32_t nt = p[0], c0 = p[1];
+    p += 2;
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[j] = c0;
+    for (uint32_t t = 0; t < nt; t++, p += 3) {
+        const uint32_t* col = (p[0] ? d.main : d.prep) + (size_t)p[1] * d.rows;
+        const uint32_t wgt = p[2];
+        uint32_t v[4];
+        if (vec) {
+            const q4_t x = gptr(reinterpret_cast<const q4_t*>(col))[q];
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = 4 * q + j < d.rows ? gptr(col)[4 * q + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[j] = kb::add(out[j], wgt == kb::R1 ? v[j] : kb::mul(v[j], wgt));
+    }
+}
+
+__global__ __launch_bounds__(256) void first_layers_kernel(const FirstDesc* __restrict__ descs, const Ext* __restrict__ betas) {
+    const FirstDesc d = descs[blockIdx.y];
+    const uint32_t quads = (d.rows + 3) / 4, rows1 = (d.rows + 1) / 2, rows2 = (rows1 + 1) / 2;
+    const bool vec = (d.rows & 3u) == 0;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+        prog_words_t p = (prog_words_t)(uintptr_t)d.prog;
+        const bool is_send = p[0] != 0;
+        const uint32_t nv = p[1];
+        const Ext head{{p[2], p[3], p[4], p[5]}};
+        p += 6;
+        uint32_t m[4], val[4];
+        vcol_apply4(p, d, q, vec, m);
+        Ext den[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { if (!is_send) m[j] = kb::sub(0u, m[j]); den[j] = head; }
+        // den += sum_k beta_k value_k with delayed reduction: the four products of a coefficient ride one 64-bit accumulator
+        // (4 (p - 1)^2 < 2^64 - 2^58, kb::monty_reduce_wide) — 4 wide multiply-adds per value and row and one reduction per
+        // four values, where ext_mul_base + ext_add is four reductions and four modular additions per value
+        uint64_t acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[j][c] = 0;
+        uint32_t pending = 0;
+        for (uint32_t k = 0; k < nv; k++) {
+            const uint32_t bi = *p++;
+            vcol_apply4(p, d, q, vec, val);
+            const Ext b = ld_ext(betas, bi);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[j][c] += (uint64_t)b.c[c] * val[j];
+            if (++pending == 4 || k + 1 == nv) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { den[j].c[c] = kb::add(den[j].c[c], kb::monty_reduce_wide(acc[j][c])); acc[j][c] = 0; }
+                pending = 0;
+            }
+        }
+        const uint32_t live = min(4u, d.rows - 4 * q);     // rows of this quad that exist
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((uint32_t)j < live) {
+                const uint32_t rp = level_pos(4 * q + j, d.rows);
+                gptr(d.n0_out)[rp] = m[j];
+                st_ext(d.d0_out, rp, den[j]);
+            }
+        // level L - 1: rows 2 q, 2 q + 1 (transition_kernel<true>: a missing partner is the padding fraction (0, 1))
+        Ext n1[2], d1[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if ((uint32_t)(2 * h + 1) < live) {
+                n1[h] = kb::ext_add(kb::ext_mul_base(den[2 * h + 1], m[2 * h]), kb::ext_mul_base(den[2 * h], m[2 * h + 1]));
+                d1[h] = kb::ext_mul(den[2 * h], den[2 * h + 1]);
+            } else { n1[h] = kb::ext_from_base(m[2 * h]); d1[h] = den[2 * h]; }
+            if ((uint32_t)(2 * h) < live) {
+                const uint32_t io = level_pos(2 * q + h, rows1);
+                st_ext(d.n1_out, io, n1[h]); st_ext(d.d1_out, io, d1[h]);
+            }
+        }
+        // level L - 2: row q (transition_kernel<false>)
+        const uint32_t io = level_pos(q, rows2);
+        if (live > 2) {
+            st_ext(d.n2_out, io, kb::ext_add(kb::ext_mul(d1[1], n1[0]), kb::ext_mul(d1[0], n1[1])));
+            st_ext(d.d2_out, io, kb::ext_mul(d1[0], d1[1]));
+        } else { st_ext(d.n2_out, io, n1[0]); st_ext(d.d2_out, io, d1[0]); }
+    }
+}
+
+// Two tree levels per launch below that: a lane reads four entries of level l, stores two of level l - 1 and one of l - 2.
+struct Trans2Desc {
+    const Ext* n_in; const Ext* d_in;
+    Ext* n1_out; Ext* d1_out; Ext* n2_out; Ext* d2_out;
+    uint32_t rows_in;
+};
+__global__ __launch_bounds__(256) void transition2_kernel(const Trans2Desc* __restrict__ descs) {
+    const Trans2Desc d = descs[blockIdx.y];
+    const uint32_t quads = (d.rows_in + 3) / 4, rows1 = (d.rows_in + 1) / 2, rows2 = (rows1 + 1) / 2;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+        const uint32_t live = min(4u, d.rows_in - 4 * q);
+        Ext n[4], dd[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((uint32_t)j < live) { const uint32_t ip = level_pos(4 * q + j, d.rows_in); n[j] = ld_ext(d.n_in, ip); dd[j] = ld_ext(d.d_in, ip); }
+        Ext n1[2], d1[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if ((uint32_t)(2 * h + 1) < live) {
+                n1[h] = kb::ext_add(kb::ext_mul(dd[2 * h + 1], n[2 * h]), kb::ext_mul(dd[2 * h], n[2 * h + 1]));
+                d1[h] = kb::ext_mul(dd[2 * h], dd[2 * h + 1]);
+            } else if ((uint32_t)(2 * h) < live) { n1[h] = n[2 * h]; d1[h] = dd[2 * h]; }
+            if ((uint32_t)(2 * h) < live) {
+                const uint32_t io = level_pos(2 * q + h, rows1);
+                st_ext(d.n1_out, io, n1[h]); st_ext(d.d1_out, io, d1[h]);
+            }
+        }
+        const uint32_t io = level_pos(q, rows2);
+        if (live > 2) {
+            st_ext(d.n2_out, io, kb::ext_add(kb::ext_mul(d1[1], n1[0]), kb::ext_mul(d1[0], n1[1])));
+            st_ext(d.d2_out, io, kb::ext_mul(d1[0], d1[1]));
+        } else { st_ext(d.n2_out, io, n1[0]); st_ext(d.d2_out, io, d1[0]); }
     }
 }
 
@@ -668,7 +818,10 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
 
     // ---- parse the interaction programs (host words -> Montgomery device words), gather shapes
     std::vector<ChipInfo> info(n_chips);
-    std::vector<std::vector<uint32_t>> progs;               // per global interaction: device-form words
+    // per global interaction: is_send, kind (canonical), multiplicity and values as (constant flag, words) — words = the vcol in
+    // device form [n_terms, constant (Montgomery), n_terms x (is_main, column, weight (Montgomery))]
+    struct ParsedInt { uint32_t is_send, kind; std::vector<uint32_t> mult; std::vector<std::vector<uint32_t>> values; };
+    std::vector<ParsedInt> progs;
     size_t max_arity = 0, total_cols = 0;
     for (int c = 0; c < n_chips; c++) {
         const sp1hip_gkr_chip_t& ci = chips[c];
@@ -699,14 +852,14 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         };
         for (uint32_t i = 0; i < ni; i++) {
             SP1HIP_REQUIRE(p + 3 <= end, "truncated interaction program");
-            std::vector<uint32_t> w{p[0], kb::to_monty(p[1] % kb::P), p[2]};
             const uint32_t nv = p[2];
             SP1HIP_REQUIRE(p[0] <= 1 && p[1] < kb::P && nv < 4096, "bad interaction header");      // (the Keccak bus carries 106 values per message)
+            ParsedInt pi{p[0], p[1], {}, std::vector<std::vector<uint32_t>>(nv)};
             p += 3;
-            SP1HIP_REQUIRE(vcol(w), "bad multiplicity column");
-            for (uint32_t j = 0; j < nv; j++) SP1HIP_REQUIRE(vcol(w), "bad value column (index or weight out of range)");
+            SP1HIP_REQUIRE(vcol(pi.mult), "bad multiplicity column");
+            for (uint32_t j = 0; j < nv; j++) SP1HIP_REQUIRE(vcol(pi.values[j]), "bad value column (index or weight out of range)");
             max_arity = std::max<size_t>(max_arity, nv + 1);
-            progs.push_back(std::move(w));
+            progs.push_back(std::move(pi));
         }
         SP1HIP_REQUIRE(p == end, "trailing words in interaction program");
         total_cols += (size_t)ci.main_width + ci.prep_width;
@@ -787,11 +940,29 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     SP1HIP_TRY(stage.init(s));
     DeviceBuf d_progs, d_betas, d_descs;
     uint32_t max_rows = 0;
+    bool fused_tree = false;
     std::vector<uint32_t> flat;                              // upload sources live to the end of the call
     std::vector<IntDesc> descs(K);
     {
+        // device programs (see first_layer_kernel): the row-independent part of every denominator is folded into `head` here
         std::vector<size_t> poff(K);
-        for (uint32_t i = 0; i < K; i++) { poff[i] = flat.size(); flat.insert(flat.end(), progs[i].begin(), progs[i].end()); }
+        for (uint32_t i = 0; i < K; i++) {
+            poff[i] = flat.size();
+            const ParsedInt& pi = progs[i];
+            Ext head = alpha + kb::ext_mul_base(betas[0], kb::to_monty(pi.kind));
+            uint32_t live = 0;
+            for (size_t j = 0; j < pi.values.size(); j++) {
+                if (pi.values[j][0] == 0) head = head + kb::ext_mul_base(betas[1 + j], pi.values[j][1]);   // no terms: the constant
+                else live++;
+            }
+            flat.insert(flat.end(), {pi.is_send, live, head.c[0], head.c[1], head.c[2], head.c[3]});
+            flat.insert(flat.end(), pi.mult.begin(), pi.mult.end());
+            for (size_t j = 0; j < pi.values.size(); j++) {
+                if (pi.values[j][0] == 0) continue;
+                flat.push_back((uint32_t)(1 + j));
+                flat.insert(flat.end(), pi.values[j].begin(), pi.values[j].end());
+            }
+        }
         SP1HIP_TRY(upload(d_progs, flat.data(), flat.size() * 4, s, stage));
         SP1HIP_TRY(upload(d_betas, betas.data(), betas.size() * 16, s, stage));
         for (uint32_t i = 0; i < K; i++) {
@@ -799,35 +970,79 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
             descs[i] = IntDesc{d_progs.u32() + poff[i], c.d_main, c.d_prep, c.rows, (uint32_t*)n_ptr(L, i), d_ptr(L, i)};
             max_rows = std::max(max_rows, c.rows);
         }
-        SP1HIP_TRY(upload(d_descs, descs.data(), descs.size() * sizeof(IntDesc), s, stage));
-        if (max_rows) {
-            ScopedTimer t("gkr_first_layer", s);
-            hipLaunchKernelGGL(first_layer_kernel, dim3(tiles_for(max_rows), K), dim3(256), 0, s, (const IntDesc*)d_descs.p, alpha,
-                               (const Ext*)d_betas.p);
-            SP1HIP_LAUNCH_CHECK();
+        // L >= 3: the first layer and the two levels below it come out of ONE pass over the traces (first_layers_kernel), the
+        // rest of the tree two levels per launch (transition2_kernel; a last single level by transition_kernel). SP1HIP_GKR_FUSED=0:
+        // the separate kernels (first_layer_kernel, one transition launch per level) — same words in every level (tests)
+        fused_tree = L >= 3 && [] { const char* e = getenv("SP1HIP_GKR_FUSED"); return !e || atoi(e) != 0; }();
+        if (fused_tree) {
+            std::vector<FirstDesc> fdescs(K);
+            for (uint32_t i = 0; i < K; i++)
+                fdescs[i] = FirstDesc{descs[i].prog, descs[i].main, descs[i].prep, descs[i].rows, descs[i].n_out, descs[i].d_out,
+                                      (Ext*)n_ptr(L - 1, i), d_ptr(L - 1, i), (Ext*)n_ptr(L - 2, i), d_ptr(L - 2, i)};
+            SP1HIP_TRY(upload(d_descs, fdescs.data(), fdescs.size() * sizeof(FirstDesc), s, stage));
+            if (max_rows) {
+                ScopedTimer t("gkr_first_layer", s);
+                hipLaunchKernelGGL(first_layers_kernel, dim3(tiles_for((max_rows + 3) / 4), K), dim3(256), 0, s, (const FirstDesc*)d_descs.p,
+                                   (const Ext*)d_betas.p);
+                SP1HIP_LAUNCH_CHECK();
+            }
+        } else {
+            SP1HIP_TRY(upload(d_descs, descs.data(), descs.size() * sizeof(IntDesc), s, stage));
+            if (max_rows) {
+                ScopedTimer t("gkr_first_layer", s);
+                hipLaunchKernelGGL(first_layer_kernel, dim3(tiles_for(max_rows), K), dim3(256), 0, s, (const IntDesc*)d_descs.p,
+                                   (const Ext*)d_betas.p);
+                SP1HIP_LAUNCH_CHECK();
+            }
         }
     }
     mark("first layer enqueued");
     // ---- fraction tree
-    // every level's descriptors are planned and uploaded once: the tree is built by L - 1 back-to-back launches
-    DeviceBuf d_trans;
-    std::vector<TransDesc> tdesc((size_t)K * (L >= 2 ? L - 1 : 0));
-    std::vector<uint32_t> level_mr(L + 1, 0);
-    for (int l = L; l >= 2; l--)
-        for (uint32_t i = 0; i < K; i++) {
-            const uint32_t rin = rows_at(info[int_chip[i]].rows, l);
-            tdesc[(size_t)(L - l) * K + i] = TransDesc{n_ptr(l, i), d_ptr(l, i), (Ext*)n_ptr(l - 1, i), d_ptr(l - 1, i), rin};
-            level_mr[l] = std::max(level_mr[l], (rin + 1) / 2);
+    // every level's descriptors are planned and uploaded once: the tree is built by back-to-back launches
+    DeviceBuf d_trans, d_trans2;
+    {
+        const int top = fused_tree ? L - 2 : L;              // the highest level that still has to be combined downwards
+        std::vector<Trans2Desc> t2;                          // launches (top -> top - 2), (top - 2 -> top - 4), ...
+        std::vector<TransDesc> t1;                           // then at most one single level (or, unfused, every level)
+        std::vector<uint32_t> t2_mr, t1_mr;
+        std::vector<int> t1_level;
+        int l = top;
+        if (fused_tree)
+            for (; l >= 3; l -= 2) {
+                uint32_t mr = 0;
+                for (uint32_t i = 0; i < K; i++) {
+                    const uint32_t rin = rows_at(info[int_chip[i]].rows, l);
+                    t2.push_back(Trans2Desc{(const Ext*)n_ptr(l, i), d_ptr(l, i), (Ext*)n_ptr(l - 1, i), d_ptr(l - 1, i), (Ext*)n_ptr(l - 2, i), d_ptr(l - 2, i), rin});
+                    mr = std::max(mr, (rin + 3) / 4);
+                }
+                t2_mr.push_back(mr);
+            }
+        for (; l >= 2; l--) {
+            uint32_t mr = 0;
+            for (uint32_t i = 0; i < K; i++) {
+                const uint32_t rin = rows_at(info[int_chip[i]].rows, l);
+                t1.push_back(TransDesc{n_ptr(l, i), d_ptr(l, i), (Ext*)n_ptr(l - 1, i), d_ptr(l - 1, i), rin});
+                mr = std::max(mr, (rin + 1) / 2);
+            }
+            t1_mr.push_back(mr);
+            t1_level.push_back(l);
         }
-    SP1HIP_TRY(upload(d_trans, tdesc.data(), tdesc.size() * sizeof(TransDesc), s, stage));
-    for (int l = L; l >= 2; l--) {
-        const uint32_t mr = level_mr[l];
-        if (!mr) continue;
-        const TransDesc* d_t = (const TransDesc*)d_trans.p + (size_t)(L - l) * K;
-        ScopedTimer t("gkr_transition", s);
-        if (l == L) hipLaunchKernelGGL(transition_kernel<true>, dim3(tiles_for(mr), K), dim3(256), 0, s, d_t);
-        else hipLaunchKernelGGL(transition_kernel<false>, dim3(tiles_for(mr), K), dim3(256), 0, s, d_t);
-        SP1HIP_LAUNCH_CHECK();
+        if (!t2.empty()) SP1HIP_TRY(upload(d_trans2, t2.data(), t2.size() * sizeof(Trans2Desc), s, stage));
+        if (!t1.empty()) SP1HIP_TRY(upload(d_trans, t1.data(), t1.size() * sizeof(TransDesc), s, stage));
+        for (size_t k = 0; k < t2_mr.size(); k++) {
+            if (!t2_mr[k]) continue;
+            ScopedTimer t("gkr_transition", s);
+            hipLaunchKernelGGL(transition2_kernel, dim3(tiles_for(t2_mr[k]), K), dim3(256), 0, s, (const Trans2Desc*)d_trans2.p + k * K);
+            SP1HIP_LAUNCH_CHECK();
+        }
+        for (size_t k = 0; k < t1_mr.size(); k++) {
+            if (!t1_mr[k]) continue;
+            const TransDesc* d_t = (const TransDesc*)d_trans.p + k * K;
+            ScopedTimer t("gkr_transition", s);
+            if (t1_level[k] == L) hipLaunchKernelGGL(transition_kernel<true>, dim3(tiles_for(t1_mr[k]), K), dim3(256), 0, s, d_t);
+            else hipLaunchKernelGGL(transition_kernel<false>, dim3(tiles_for(t1_mr[k]), K), dim3(256), 0, s, d_t);
+            SP1HIP_LAUNCH_CHECK();
+        }
     }
     mark("tree enqueued");
     Mailbox mb;                                              // device -> host hand-overs outside the sumcheck rounds

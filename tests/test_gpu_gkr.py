@@ -88,6 +88,24 @@ def test_gkr_scalar_host_rounds_give_the_same_bytes(api, monkeypatch, n_tuples, 
     assert np.array_equal(g_ch.state(), o_ch.state())
 
 
+@pytest.mark.parametrize("n_tuples,L,with_empty,dup", [(4, 3, False, 2), (3, 5, False, 1), (9, 6, True, 2), (37, 7, True, 3), (300, 10, True, 3), (1300, 12, True, 3)])
+def test_gkr_separate_tree_kernels_give_the_same_bytes(api, monkeypatch, n_tuples, L, with_empty, dup):
+    """The first layer and the two levels below it come out of one pass over the traces, the rest of the fraction tree two levels
+    per launch (first_layers_kernel / transition2_kernel, round 6; every other test runs them: heights 8 .. 3900, multiples of four
+    and not, partial quads at every level). SP1HIP_GKR_FUSED=0 builds the same tree level by level (first_layer_kernel +
+    transition_kernel): not a byte may differ."""
+    monkeypatch.setenv("SP1HIP_GKR_FUSED", "0")
+    chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
+    o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+    seed = orc.random_felts((9,), L)
+    o_ch.observe(seed)
+    g_ch.observe(seed)
+    want = orc.gkr_prove(chips, L, o_ch)
+    got = api.logup_gkr(_dev(api, chips), L, g_ch)
+    assert got == want
+    assert np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_gkr_rejects_unsorted_chips_and_keeps_transcript(api):
     chips = make_gkr_chips(4, 3)
     dev = _dev(api, chips)
