@@ -300,12 +300,12 @@ def synthetic_core_shaped(api, k, repeat=3):
 
 
 def tree_mode(api, shards, dist, torch, args, rank, world, use_dist, chips, meta, prep_commit, prep_data, L, lsh, publics, kind, names):
-    """BASELINE config 5's shape (`CompressTree::reduce_proofs`, crates/prover/src/worker/controller/compress.rs:L234-L420) on the
-    backends this box has: K core shards striped over the ranks (each rank proves ITS shard's traces K / W times, with a different
-    transcript head per leaf so that the leaf proofs differ), then the proofs are reduced to one root — every parent a ShardProof
-    of the reference's recursion compress machine that commits to its children (shards.recursion_combine), proven on the parent's
-    rank with sp1hip_prove_shard; children travel point to point (RCCL send / recv under nccl, gloo otherwise). The WHOLE job is
-    inside the timed region; per-level times and bytes are collected on every rank."""
+    """BASELINE config 5's shape (`CompressTree::reduce_proofs`, crates/prover/src/worker/controller/compress.rs:L234-L470) on the
+    backends this box has: K core shards pulled from a work queue by the ranks (each rank proves ITS shard's traces, with a different
+    transcript head per leaf so that the leaf proofs differ), the proofs reduced to one root as they arrive — every parent a
+    ShardProof of the reference's recursion compress machine that commits to its children (shards.recursion_combine), proven by
+    whichever rank takes the reduce task with sp1hip_prove_shard; children travel point to point (RCCL send / recv under nccl, gloo
+    otherwise). The WHOLE job is inside the timed region; what every rank did is collected at the end."""
     import numpy as np
     from sp1_amd.machines import recursion as R
     from sp1_amd.machines import recursion_trace as RT
@@ -338,46 +338,47 @@ def tree_mode(api, shards, dist, torch, args, rank, world, use_dist, chips, meta
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    levels = []
+    # the reference's shape (sp1_amd/scheduler.py): ranks PULL leaves from a queue, a finished proof joins the adjacent range
+    # that is waiting for it, a full group becomes a reduce task on the same queue; no static assignment, no barrier per level
+    from sp1_amd import scheduler
+    wq = scheduler.WorkQueue(n_leaves, 2, name="bench-tree")
+    if use_dist:
+        dist.barrier()
     t0 = time.perf_counter()
-    mine = shards.stripe(n_leaves, world, rank)
-    leaves = {i: leaf(i) for i in mine}
-    torch.cuda.synchronize()
-    t_leaves = time.perf_counter() - t0
-    root = shards.reduce_tree(leaves, n_leaves, combine, 2, on_level=lambda li, st: levels.append(dict(st, level=li)))
+    root, st = wq.run(leaf, combine)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     dt = shards.max_over_ranks(time.perf_counter() - t0)
-    t_leaves = shards.max_over_ranks(t_leaves)
-    # per-level table: max over ranks of the times, sum over ranks of the bytes
-    table = []
-    for li in range(len(levels)):
-        st = levels[li]
-        row = {"level": li, "nodes": st["nodes"], "parents": st["parents"],
-               "exchange_ms": 1e3 * shards.max_over_ranks(st["exchange_s"]), "prove_ms": 1e3 * shards.max_over_ranks(st["prove_s"])}
-        if use_dist:
-            t = torch.tensor([st["sent_bytes"], st["proved"]], dtype=torch.int64, device=shards._device())
-            dist.all_reduce(t)
-            row["bytes_moved"], row["proved"] = int(t[0]), int(t[1])
-        else:
-            row["bytes_moved"], row["proved"] = st["sent_bytes"], st["proved"]
-        table.append(row)
+    per_rank = {"leaves": len(st["leaves"]), "joins": len(st["joins"]), "busy_ms": 1e3 * st["busy_s"], "wait_ms": 1e3 * st["wait_s"],
+                "sent_bytes": st["sent_bytes"], "recv_bytes": st["recv_bytes"], "store_ops": st["store_ops"]}
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank)
+    else:
+        gathered = [per_rank]
     if rank != 0:
         return None
+    scheduler.check_tree(n_leaves, st["nodes"], 2)
     # the root is a ShardProof of the recursion machine: full verification by the oracle (untimed)
     verified = None
     if not args.no_verify and root is not None:
         verified = verify_tree_root(root, rL, rlsh)
     area = meta["area_cells"]
+    depth = {i: 0 for i in range(n_leaves)}
+    for nd in st["nodes"]:
+        depth[nd["pid"]] = 1 + max(depth[c] for c in nd["children"])
     return {"metric": "core shards proved AND reduced to one root proof through the recursion compress tree: leaf trace cells / s (whole job)",
             "value": n_leaves * area / dt, "unit": "cells/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * dt,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery words)",
             "data": "synthetic", "mode": "tree",
-            "config": {"workload": "%d leaves (%s shard, scale 4^-%d, %d cells each) over %d ranks + binary compress tree of recursion-machine "
-                                   "ShardProofs (%d cells per node)" % (n_leaves, kind, k, area, world, sum(counts.values())),
-                       "backend": args.backend if use_dist else None, "leaves": n_leaves, "arity": 2},
-            "tree": {"leaves_ms": 1e3 * t_leaves, "levels": table, "root_bytes": len(root) if root else None, "root_verified": verified}}
+            "config": {"workload": "%d leaves (%s shard, scale 4^-%d, %d cells each) pulled from a work queue by %d ranks + compress tree joined as "
+                                   "proofs arrive (adjacent ranges, arity 2): every node a ShardProof of the recursion machine (%d cells) that commits to "
+                                   "its children's bytes — a STAND-IN program: the recursion verifier circuit is Rust and out of scope"
+                                   % (n_leaves, kind, k, area, world, sum(counts.values())),
+                       "backend": args.backend if use_dist else None, "leaves": n_leaves, "arity": 2, "scheduler": "work queue + event-driven tree (no level barrier)"},
+            "tree": {"nodes": len(st["nodes"]), "depth": max(depth.values()), "per_rank": gathered, "root_bytes": len(root) if root else None,
+                     "root_verified": verified}}
 
 
 def verify_tree_root(root, rL, rlsh):
