@@ -224,21 +224,26 @@ def verify_child(path):
               for a, i in progs]
     ch = orc.Challenger()
     ch.observe(z["commit"])
+    if "vk_words" in z.files and z["vk_words"].size:         # the whole verifying key (vk.observe_into): + pc_start, digest, flag, padding
+        ch.observe(np.concatenate([z["vk_words"], np.zeros(7, np.uint32)]))
     t0 = time.perf_counter()
     rc = orc.shard_verify(shapes, z["commit"], z["proof"].tobytes(), L, lsh, ch, 2, 124, 16, pv_program=pv_program_of(kind))
-    print(json.dumps({"rc": int(rc), "seconds": time.perf_counter() - t0, "state_matches": bool(np.array_equal(ch.state(), z["state"]))}))
+    print(json.dumps({"rc": int(rc), "seconds": time.perf_counter() - t0,
+                      "state_matches": bool(z["state"].size == 0 or np.array_equal(ch.state(), z["state"]))}))
 
 
-def verify_proof(kind, proof, commit, state, L, lsh, names=()):
-    """Runs verify_child on `proof`; returns True iff the verifier accepts AND ends in the prover's transcript state."""
+def verify_proof(kind, proof, commit, state, L, lsh, names=(), vk_words=None):
+    """Runs verify_child on `proof`; returns True iff the verifier accepts AND ends in the prover's transcript state. `vk_words`: the
+    rest of the verifying key the transcript absorbed behind the commitment (vk.observe_into: pc_start, the initial global
+    cumulative sum; the flag and the padding are zero) — None when only the commitment was observed; `state` may be None."""
     import subprocess
     import tempfile
 
     import numpy as np
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "proof.npz")
-        np.savez(path, proof=np.frombuffer(proof, np.uint8), commit=np.asarray(commit, np.uint32), state=np.asarray(state, np.uint32),
-                 L=L, lsh=lsh, kind=kind, names=np.array(list(names), dtype=str))
+        np.savez(path, proof=np.frombuffer(proof, np.uint8), commit=np.asarray(commit, np.uint32), state=np.asarray(state if state is not None else [], np.uint32),
+                 L=L, lsh=lsh, kind=kind, names=np.array(list(names), dtype=str), vk_words=np.asarray(vk_words if vk_words is not None else [], np.uint32))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--verify-child", path], capture_output=True, text=True)
     if r.returncode != 0:
         print("verifier child failed:\n" + r.stderr[-2000:], file=sys.stderr)
@@ -557,6 +562,8 @@ def main():
                     help="initialise torch.distributed even at --gpus 1 (the N = 1 line then runs the same barrier / "
                          "max-over-ranks collectives as N = 8; RCCL when --backend nccl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-program-run", action="store_true", help="skip the whole-run extra (every shard of a multi-shard execution, ~40 s)")
+    ap.add_argument("--program-run-cycles", type=int, default=26_000_000, help="cycles of the whole-run extra (3 core shards of fibonacci + the memory shard)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (2-in-flight, commit-only, CPU baseline)")
     ap.add_argument("--mode", default="shard", choices=["shard", "tree"],
                     help="shard (default): every rank proves its own shard, weak scaling. tree: BASELINE config 5's shape — "
@@ -729,6 +736,16 @@ def main():
                 "threads": len(th1)}
         except Exception as e:
             print("bench.py: untimed host CPU not measured: %r" % (e,), file=sys.stderr)
+        if kind in PROGRAMS and k == 0 and not args.no_program_run:
+            # a WHOLE run under the driver's clock: every shard of a multi-shard fibonacci execution, one proving key
+            try:
+                import prove_program
+                torch.cuda.empty_cache()
+                pr, last, pr_commit, _ = prove_program.program_run(api, kind if kind != "rsp" else "fibonacci", args.program_run_cycles, L, lsh)
+                pr["last_shard_verified"] = verify_proof(kind, last["proof"], pr_commit, None, L, lsh, last["names"], vk_words=last["vk_words"])
+                extras["program_run"] = pr
+            except Exception as e:
+                print("bench.py: program_run not measured: %r" % (e,), file=sys.stderr)
         extras["real_machine"] = real_machine(api)
         if kind == "real":
             extras["synthetic_core_shaped"] = synthetic_core_shaped(api, k)
@@ -761,16 +778,35 @@ def main():
         }
         # PMC table of THIS round (bench/pmc_traffic.sh -> profiles/r05_traffic.json, r05_traffic_precompile.json): HBM bytes and
         # SQ_INSTS_VALU per proof for every kernel group; the roofline fractions below are (table or live value) / (live time) / peak
-        pmc, pmc_note = {}, "no committed PMC table for this workload"
-        for fn in ("r05_traffic_%s.json" % kind, "r05_traffic.json", "r05_traffic_precompile.json", "r04_traffic.json"):
+        # The numerators cannot go stale silently: the table records the SHAPE of the proof its counters were taken on
+        # (trace cells, first-layer entries, launches per kernel group); a live run that differs is reported as `stale` with the reason.
+        pmc, pmc_note, pmc_stale = {}, "no committed PMC table for this workload", None
+        for fn in ("r06_traffic_%s.json" % kind, "r05_traffic_%s.json" % kind, "r05_traffic.json", "r05_traffic_precompile.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tt = json.load(f)
                 if k == 0 and tt.get("workload") == kind:
                     pmc, pmc_note = tt["kernels"], tt["source"] + " [profiles/%s]" % fn
+                    why = []
+                    shape = tt.get("shape")
+                    if not shape:
+                        why.append("the table carries no shape (made before round 6)")
+                    else:
+                        for key, live in (("area_cells", area), ("first_layer_entries", meta["first_layer_entries"])):
+                            if shape.get(key) != live:
+                                why.append("%s %s in the table, %s live" % (key, shape.get(key), live))
+                        for g_, (tn_, _) in groups.items():
+                            live_l = sum(launches.get(n_, 0) for n_ in tn_)
+                            if live_l and shape.get("launches", {}).get(g_) != live_l:
+                                why.append("%s: %s launches in the table, %d live" % (g_, shape.get("launches", {}).get(g_), live_l))
+                    pmc_stale = why
                     break
             except (OSError, ValueError, KeyError):
                 pass
+        if os.environ.get("SP1HIP_BENCH_PMC_META"):          # bench/pmc_traffic.sh: the shape this run's counters belong to
+            with open(os.environ["SP1HIP_BENCH_PMC_META"], "w") as f:
+                json.dump({"workload": kind, "area_cells": area, "first_layer_entries": meta["first_layer_entries"],
+                           "launches": {g_: sum(launches.get(n_, 0) for n_ in tn_) for g_, (tn_, _) in groups.items()}}, f)
         stages = {}
         for g, (tn, alg_bytes) in groups.items():
             g_ms = sum(ms.get(n, 0.0) for n in tn)
@@ -879,7 +915,8 @@ def main():
             "roofline": {"bound": d["bound"], "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / (alg_dom / dom_launches)) if traffic else None,
-                         "pmc_source": pmc_note, "hbm_frac": d["hbm_frac"], "valu_frac": d["valu_frac_vs_measured_int_rate"],
+                         "pmc_source": pmc_note, "stale": bool(pmc_stale) if pmc_stale is not None else None, "stale_because": pmc_stale or None,
+                         "hbm_frac": d["hbm_frac"], "valu_frac": d["valu_frac_vs_measured_int_rate"],
                          "avg_launch_ms": dom_ms / dom_launches, "launches_per_step": dom_launches, "overlapped_with": overlapped,
                          "algorithmic_bytes_per_launch": alg_dom // dom_launches,
                          "note": "dominant kernel group of the step by live launch time (HIP events on the launch stream, all timed "
@@ -898,6 +935,7 @@ def main():
             "host_threads": lib.sp1hip_host_threads(), "host_cpu_ms_per_proof": host_cpu_ms, "host_cpu_ms_by_thread": host_cpu_by_thread,
             "host_wait": os.environ.get("SP1HIP_WAIT", "predict"), "host_cpu_untimed": extras.get("host_cpu_untimed"),
             "dist": {"initialised": use_dist, "backend": args.backend if use_dist else None},
+            "program_run": extras.get("program_run"),
             "real_machine": extras.get("real_machine"),
             "synthetic_core_shaped": extras.get("synthetic_core_shaped"),
             "in_flight": extras.get("in_flight"),

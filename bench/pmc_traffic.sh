@@ -6,9 +6,12 @@
 # KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads (x 2), WRITE_SIZE is exact (x 1).
 # A third pass collects SQ_INSTS_VALU (wave-level VALU instructions; x 64 = lane-instructions) and SQ_INSTS_SALU per kernel: the
 # numerators of bench.py's VALU roofline fractions (from THIS round's counters, not a constant).
-# usage: bench/pmc_traffic.sh <out.json> [real|precompile]     (writes the table bench.py reads: profiles/r05_traffic[_precompile].json)
+# The shape of the proof the counters belong to (workload, trace cells, first-layer entries, launches per kernel group as the
+# library's own timers count them) is written into the table: bench.py holds its live run against it and says `stale` otherwise.
+# usage: bench/pmc_traffic.sh <out.json> [fibonacci|real|precompile]     (writes the table bench.py reads: profiles/r06_traffic_<workload>.json)
 out=$1
 export SP1HIP_PMC_WORKLOAD=${2:-real}
+export SP1HIP_BENCH_PMC_META=/tmp/pmc_bench_meta.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_v
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o f -- python $GRAFT_REPO_ROOT/bench/profile_bench_pmc.py > /dev/null 2>&1
@@ -45,8 +48,8 @@ groups = {   # bench.py's kernel names -> substrings of the HIP kernel names
     "zerocheck_fix": ["zc_fix_kernel", "zc_fix2_kernel"],
     "gkr_pass": ["gkr_pass"],
     "compress": ["compress_layer", "compress_top"],
-    "gkr_first_layer": ["first_layer_kernel"],
-    "gkr_transition": ["transition_kernel"],
+    "gkr_first_layer": ["first_layer_kernel", "first_layers_kernel"],
+    "gkr_transition": ["transition_kernel", "transition2_kernel"],
     "jagged_fold": ["jg_fold"],
 }
 kernels = {}
@@ -72,9 +75,13 @@ kernels["all_kernels"] = {"launches_per_proof": sum(fc[k] for k in own),
                           "salu_insts_per_proof": sum(salu.get(k, 0.0) for k in own)}
 kernels["all_kernels"]["hbm_bytes_per_launch"] = kernels["all_kernels"]["hbm_bytes_per_proof"] / max(1, kernels["all_kernels"]["launches_per_proof"])
 import os
-json.dump({"workload": os.environ.get("SP1HIP_PMC_WORKLOAD", "real"),
+try:
+    shape = json.load(open(os.environ["SP1HIP_BENCH_PMC_META"]))
+except (OSError, KeyError, ValueError):
+    shape = None
+json.dump({"workload": os.environ.get("SP1HIP_PMC_WORKLOAD", "real"), "shape": shape,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU SQ_INSTS_SALU, three separate passes over one proof of the "
-                     "bench workload named in `workload` (bench/pmc_traffic.sh -> profiles/r05_traffic*.json); KiB units, FETCH x 2 (gfx950: 64 B "
+                     "bench workload named in `workload` (bench/pmc_traffic.sh -> profiles/r06_traffic*.json); KiB units, FETCH x 2 (gfx950: 64 B "
                      "tallied per 128 B request), WRITE x 1; SQ_INSTS_VALU counts wave instructions (x 64 lanes)",
            "calibration": {"kernel": "monty_convert_kernel, 2^28 words each way", "fetch_scale_measured": fetch_scale,
                            "write_scale_measured": write_scale},
