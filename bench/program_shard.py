@@ -50,6 +50,10 @@ def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
             prev = X.execution_public_values(shard, prev)
     assert shard.cycles == max_cycles and not shard.halted, "the run is too short for a full shard %d" % shard_index
     machine, tabs, publics = X.shard_tables(ex, shard, device, prev=prev)
+    # the compact event records of the chips whose tables the device can generate itself (api.tracegen_riscv_alu): what a host
+    # hands over instead of their tables — 88 B per instruction where the row is 120-328 B
+    names_of = X.chip_of_events(shard.events)
+    alu_events = {n: X.pack_alu_events(shard.events[np.nonzero(names_of == n)[0]]) for n in X.ALU_TRACEGEN_CHIPS if (names_of == n).any()}
     out = []
     for a, i in machine:
         prep, main = tabs[a.name]
@@ -66,5 +70,6 @@ def build_program_shard(program="fibonacci", k=0, shard_index=0, device="cuda"):
             "first_layer_entries": sum(c[2].height * c[1].num_interactions for c in out),
             "program": program, "shard_index": shard_index, "cycles": shard.cycles, "clk": [shard.clk_start, shard.clk_end],
             "pc_start": shard.pc_start, "next_pc": shard.next_pc, "cells_per_cycle": area / shard.cycles,
-            "publics": RT.to_monty_np(publics), "per_chip": per_chip}       # Montgomery words, like the tables
+            "publics": RT.to_monty_np(publics), "per_chip": per_chip,       # Montgomery words, like the tables
+            "alu_events": alu_events}
     return out, meta

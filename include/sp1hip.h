@@ -469,6 +469,24 @@ int sp1hip_tracegen_recursion_poseidon2_wide(uint32_t* d_trace, uint64_t height,
 int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint32_t* d_events, uint64_t n_events,
                                  sp1hip_stream_t stream);
 
+/* Device trace generation for the RISC-V instruction chips of a core shard (round 6): Add, Addi, Sub, Addw, Subw, Mul, ShiftRight,
+ * Branch — `generate_trace_into` / `event_to_row` of /root/reference/crates/core/machine/src/alu/{add_sub,addw,subw,mul,sr}/ and
+ * control_flow/branch/, the R / I / ALU register adapters and CPUState they share (adapter/{state,register}, memory/consistency/trace.rs).
+ * The reference fills these tables on the host and copies them (sp1-gpu/crates/jagged_tracegen/src/lib.rs:L819-L835); here a row
+ * is made from an 88-byte event on the device. An event is the instruction's `AluEvent` / `BranchEvent` with its register access
+ * records (core/executor/src/events/{alu,branch,memory}.rs), flattened:
+ *   ops  = opcode | op_a << 8 | op_b << 16 | op_c << 24 | imm_b << 32 | imm_c << 33   (register numbers; Opcode as in opcode.rs)
+ *   a / b / c = the operand values (a: the value written; c: the immediate when imm_c), a_prev = the value op_a held before
+ *   (for a branch: the value of rs1), *_pts = the timestamp of the register's previous access, aux = next_pc (branches).
+ * Writes the column-major [width][height] table in Montgomery words, rows >= n_events as the chip's padding rows. Clock carries
+ * across 2^24 (MemoryBump / StateBump rows) stay with the caller: they are a handful of rows per shard. */
+typedef struct sp1hip_rv64_alu_event_s { uint64_t pc, clk, ops, a, b, c, a_prev, a_pts, b_pts, c_pts, aux; } sp1hip_rv64_alu_event_t;
+enum { SP1HIP_RV64_CHIP_ADD = 0, SP1HIP_RV64_CHIP_ADDI = 1, SP1HIP_RV64_CHIP_SUB = 2, SP1HIP_RV64_CHIP_ADDW = 3, SP1HIP_RV64_CHIP_SUBW = 4,
+       SP1HIP_RV64_CHIP_MUL = 5, SP1HIP_RV64_CHIP_SHIFT_RIGHT = 6, SP1HIP_RV64_CHIP_BRANCH = 7 };
+int sp1hip_tracegen_riscv_alu_width(int chip);       /* columns of the chip's table; -1 for an unknown chip */
+int sp1hip_tracegen_riscv_alu(int chip, uint32_t* d_table, uint32_t height, const sp1hip_rv64_alu_event_t* d_events, uint32_t n_events,
+                              sp1hip_stream_t stream);
+
 /* ---------------------------------------------------------------- guest execution (host code, no device work)
  * An rv64im executor for SP1 guest ELFs: what `MinimalExecutor` + `TracingVM` do for the core prover
  * (/root/reference/crates/core/executor/src/minimal.rs, tracing.rs:L57-L147, vm.rs:L139-L431; the controller's shard loop is

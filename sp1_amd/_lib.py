@@ -199,6 +199,8 @@ PROTOTYPES = [
     ("sp1hip_tracegen_recursion_prefix_sum_checks", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_tracegen_recursion_poseidon2_wide", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
     ("sp1hip_tracegen_riscv_global", None, [_vp, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("sp1hip_tracegen_riscv_alu_width", None, [C.c_int]),
+    ("sp1hip_tracegen_riscv_alu", None, [C.c_int, _vp, C.c_uint32, _vp, C.c_uint32, _vp]),
     ("sp1hip_rv64_create", None, [u8p, C.c_uint64, C.POINTER(_vp)]),
     ("sp1hip_rv64_destroy", "void", [_vp]),
     ("sp1hip_rv64_write_stdin", None, [_vp, u8p, C.c_uint64]),

@@ -554,6 +554,23 @@ def tracegen_riscv_global(events, height, stream=None):
     return ColMajor(out, int(height), 241)
 
 
+RISCV_ALU_CHIPS = {"Add": 0, "Addi": 1, "Sub": 2, "Addw": 3, "Subw": 4, "Mul": 5, "ShiftRight": 6, "Branch": 7}   # SP1HIP_RV64_CHIP_*
+ALU_EVENT_WORDS = 11                                                                 # sp1hip_rv64_alu_event_t: 11 u64
+
+
+def tracegen_riscv_alu(chip, events, height, stream=None):
+    """`generate_trace_device` for one of the RISC-V instruction chips of RISCV_ALU_CHIPS (sp1hip_tracegen_riscv_alu): events = a
+    device int64 tensor [n, 11] of sp1hip_rv64_alu_event_t records (riscv_exec.pack_alu_events); returns the column-major table
+    [width][height] as a ColMajor."""
+    kind = RISCV_ALU_CHIPS[chip]
+    width = _L().sp1hip_tracegen_riscv_alu_width(kind)
+    n = int(events.shape[0])
+    assert events.dtype == torch.int64 and (n == 0 or (events.shape[1] == ALU_EVENT_WORDS and events.is_contiguous()))
+    out = device_words(width * int(height))
+    check(_L().sp1hip_tracegen_riscv_alu(kind, _dptr(out), int(height), _dptr(events) if n else None, n, _stream_ptr(stream)))
+    return ColMajor(out, int(height), width)
+
+
 class ProvingKey:
     """`ProvingKey` of the AirProver slot: the preprocessed commitment round + the verifying key (sp1hip_setup).
     Keeps the preprocessed device tables alive."""

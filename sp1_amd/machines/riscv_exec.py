@@ -357,6 +357,24 @@ class EventTracer(RT.Tracer):
         return [machine[n] for n in names], {n: (self.tables[n].prep, self.tables[n].main) for n in names}, PVM.to_tensor(pv)
 
 
+ALU_TRACEGEN_CHIPS = ("Add", "Addi", "Sub", "Addw", "Subw", "Mul", "ShiftRight", "Branch")   # api.RISCV_ALU_CHIPS: tables made on the device
+
+
+def pack_alu_events(events, chip=None):
+    """The executor's 20-word instruction events -> `sp1hip_rv64_alu_event_t` records (include/sp1hip.h: 11 u64 words — pc, clk,
+    ops, a, b, c, a_prev, a_pts, b_pts, c_pts, aux) for the chips whose tables the device generates (api.tracegen_riscv_alu), in
+    the events' order = the tables' row order. `events`: [n, 20] int64 (numpy or torch; all of a shard's events when `chip` names
+    the chip to select, else already that chip's). An event is 88 bytes where the row it becomes is 120 (Addi) to 328 (Mul)."""
+    ev = events if chip is None else events[np.nonzero(chip_of_events(np.asarray(events.cpu() if torch.is_tensor(events) else events)) == chip)[0]]
+    xp = torch if torch.is_tensor(ev) else np
+    flags = ev[:, E_FLAGS]
+    imm_c = (flags & 2) >> 1
+    ops = ev[:, E_OP] | (ev[:, E_OPA] << 8) | ((ev[:, E_OPB] & 0xFF) << 16) | (((1 - imm_c) * (ev[:, E_OPC] & 0xFF)) << 24) | ((flags & 3) << 32)
+    c = xp.where(imm_c == 1, ev[:, E_OPC], ev[:, E_C])                   # an immediate operand travels as the value
+    cols = [ev[:, E_PC], ev[:, E_CLK], ops, ev[:, E_A], ev[:, E_B], c, ev[:, E_A_PREV], ev[:, E_A_PTS], ev[:, E_B_PTS], ev[:, E_C_PTS], ev[:, E_NEXT_PC]]
+    return xp.stack(cols, 1) if xp is np else torch.stack(cols, dim=1).contiguous()
+
+
 def execution_public_values(sh, prev=None):
     """An execution shard's `PublicValues` as the tracing executor leaves them (tracing.rs postprocess L548-L562, executor.rs:L60
     finalize_public_values(true)) with the previous shard's state threaded in (`prev`: its words, None for the first shard); the
