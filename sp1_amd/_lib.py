@@ -84,6 +84,11 @@ class Rv64ShardLimits(C.Structure):
                 ("memory_bump_cost", C.c_uint64), ("state_bump_cost", C.c_uint64)]
 
 
+class Rv64AluEvent(C.Structure):
+    """sp1hip_rv64_alu_event_t: what sp1hip_tracegen_riscv_alu makes a row of (riscv_exec.pack_alu_events builds arrays of them)."""
+    _fields_ = [(n, C.c_uint64) for n in ("pc", "clk", "ops", "a", "b", "c", "a_prev", "a_pts", "b_pts", "c_pts", "aux")]
+
+
 class Vk(C.Structure):
     _fields_ = [("pc_start", C.c_uint32 * 3), ("initial_global_cumulative_sum", C.c_uint32 * 14),
                 ("preprocessed_commit", C.c_uint32 * 8), ("enable_untrusted_programs", C.c_uint32)]

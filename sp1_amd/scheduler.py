@@ -60,7 +60,7 @@ def _device():
 class WorkQueue:
     """One run of the scheduler. Every rank builds it with the same arguments and calls `run`."""
 
-    def __init__(self, n_leaves, arity=2, name="sp1", store=None, poll_s=0.0005):
+    def __init__(self, n_leaves, arity=2, name="sp1", store=None, poll_s=0.001):
         assert arity >= 2
         self.n, self.arity, self.poll_s = int(n_leaves), int(arity), poll_s
         self.world = dist.get_world_size() if dist.is_initialized() else 1

@@ -157,7 +157,8 @@ def test_ffi_struct_layouts_match_the_header(tmp_path):
              "sp1hip_host_table_t": _lib.HostTable, "sp1hip_fri_config_t": _lib.FriConfig, "sp1hip_zc_chip_t": _lib.ZcChip,
              "sp1hip_gkr_chip_t": _lib.GkrChip, "sp1hip_shard_chip_t": _lib.ShardChip, "sp1hip_shard_params_t": _lib.ShardParams,
              "sp1hip_vk_t": _lib.Vk, "sp1hip_pool_chip_t": _lib.PoolChip, "sp1hip_pool_times_t": _lib.PoolTimes,
-             "sp1hip_rv64_shard_info_t": _lib.Rv64ShardInfo, "sp1hip_rv64_shard_limits_t": _lib.Rv64ShardLimits}
+             "sp1hip_rv64_shard_info_t": _lib.Rv64ShardInfo, "sp1hip_rv64_shard_limits_t": _lib.Rv64ShardLimits,
+             "sp1hip_rv64_alu_event_t": _lib.Rv64AluEvent}
     header = open(os.path.join(ROOT, "include", "sp1hip.h")).read()
     declared = set(re.findall(r"}\s*(sp1hip_\w+_t)\s*;", header))
     assert declared == set(pairs), "a struct of the header has no ctypes mirror (or the other way round): %s" % (declared ^ set(pairs))
