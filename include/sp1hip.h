@@ -480,9 +480,9 @@ int sp1hip_tracegen_riscv_global(uint32_t* d_trace, uint64_t height, const uint3
  *   (for a branch: the value of rs1), *_pts = the timestamp of the register's previous access, aux = next_pc (branches).
  * Writes the column-major [width][height] table in Montgomery words, rows >= n_events as the chip's padding rows. Clock carries
  * across 2^24 (MemoryBump / StateBump rows) stay with the caller: they are a handful of rows per shard. */
-typedef struct sp1hip_rv64_alu_event_s { uint64_t pc, clk, ops, a, b, c, a_prev, a_pts, b_pts, c_pts, aux; } sp1hip_rv64_alu_event_t;
-enum { SP1HIP_RV64_CHIP_ADD = 0, SP1HIP_RV64_CHIP_ADDI = 1, SP1HIP_RV64_CHIP_SUB = 2, SP1HIP_RV64_CHIP_ADDW = 3, SP1HIP_RV64_CHIP_SUBW = 4,
-       SP1HIP_RV64_CHIP_MUL = 5, SP1HIP_RV64_CHIP_SHIFT_RIGHT = 6, SP1HIP_RV64_CHIP_BRANCH = 7 };
+typedef struct { uint64_t pc, clk, ops, a, b, c, a_prev, a_pts, b_pts, c_pts, aux; } sp1hip_rv64_alu_event_t;
+typedef enum { SP1HIP_RV64_CHIP_ADD = 0, SP1HIP_RV64_CHIP_ADDI = 1, SP1HIP_RV64_CHIP_SUB = 2, SP1HIP_RV64_CHIP_ADDW = 3, SP1HIP_RV64_CHIP_SUBW = 4,
+               SP1HIP_RV64_CHIP_MUL = 5, SP1HIP_RV64_CHIP_SHIFT_RIGHT = 6, SP1HIP_RV64_CHIP_BRANCH = 7 } sp1hip_rv64_chip;
 int sp1hip_tracegen_riscv_alu_width(int chip);       /* columns of the chip's table; -1 for an unknown chip */
 int sp1hip_tracegen_riscv_alu(int chip, uint32_t* d_table, uint32_t height, const sp1hip_rv64_alu_event_t* d_events, uint32_t n_events,
                               sp1hip_stream_t stream);

@@ -27,7 +27,7 @@ namespace tg {
 
 constexpr uint32_t M16 = 0xffffu;
 // flags of sp1hip_rv64_alu_event_t.ops (bits 32..): operand b / c is an immediate
-constexpr uint64_t F_IMM_B = 1ull << 32, F_IMM_C = 1ull << 33;
+constexpr uint64_t F_IMM_C = 1ull << 33;                     // (bit 32: operand b is an immediate — none of these chips has one)
 constexpr uint32_t POS_C = 2, POS_B = 3, POS_A = 4;         // MemoryAccessPosition (core/executor/src/events/memory.rs:L63-L74)
 
 struct Ev { uint64_t pc, clk, ops, a, b, c, a_prev, a_pts, b_pts, c_pts, aux; };
