@@ -827,8 +827,11 @@ def main():
             "zerocheck_round": (["zerocheck_round"], (12 if zc_bivariate else 20) * area),
             "zerocheck_fix": (["zerocheck_fix"], (20 if zc_bivariate else 36) * area),
             "gkr_pass": (["gkr_pass_sum", "gkr_pass_fold_sum", "gkr_pass_fold"], 156 * meta["first_layer_entries"]),
-            "gkr_first_layer": (["gkr_first_layer"], 20 * meta["first_layer_entries"]),
-            "gkr_transition": (["gkr_transition"], 52 * meta["first_layer_entries"]),
+            # round 6: the first layer and the two tree levels below it are ONE kernel — it writes level L (4 + 16 B per entry), L - 1
+            # (32 B per pair) and L - 2 (32 B per quad) = 44 B per first-layer entry; the rest of the tree, two levels per launch, reads
+            # 8 E (1 + 1/4 + ...) and writes 6 E (1 + 1/4 + ...) = 18.7 B per entry (SP1HIP_GKR_FUSED=0: 20 and 52)
+            "gkr_first_layer": (["gkr_first_layer"], 44 * meta["first_layer_entries"]),
+            "gkr_transition": (["gkr_transition"], 56 * meta["first_layer_entries"] // 3),
             "jagged_fold": (["jagged_round0_sum", "jagged_fold0_sum", "jagged_fold_sum"], 28 * area),
         }
         # PMC table of THIS round (bench/pmc_traffic.sh -> profiles/r05_traffic.json, r05_traffic_precompile.json): HBM bytes and
