@@ -1,13 +1,16 @@
 #!/bin/bash
 # Every kernel launch of ONE proof between two marker kernels, in order: name, workgroups, duration, idle time before it (kernel
 # trace of `bench.py --steps 3 --warmup 1 --no-extras --no-verify`, last proof).
-# usage: bench/stage_trace.sh <out-file> <first-kernel-substring> <last-kernel-substring> [workload]
+# usage: bench/stage_trace.sh <out-file> <first-kernel-substring> <last-kernel-substring> [workload] [command]
+#   command: what to trace instead of bench.py, relative to the repository root (its LAST proof is the one listed), e.g.
+#   "bench/prove_program.py --program rsp --only-kinds secp256k1_add"
 #   LogUp-GKR: first_layer open_sum_kernel | zerocheck: (the launch after) open_sum_kernel .. zc_gather | whole proof: ntt_fast_pass fold_round
 out=$1; first=$2; last=$3
 wl=${4:-fibonacci}
+cmd=${5:-"bench.py --workload $wl --steps 3 --warmup 1 --no-extras --no-verify"}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_stage
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_stage -o g -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --no-extras --no-verify > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_stage -o g -- python $GRAFT_REPO_ROOT/$cmd > /dev/null 2>&1
 python - "$out" "$first" "$last" <<PY
 import csv, glob, sys, collections
 rows = list(csv.DictReader(open(glob.glob("/tmp/prof_stage/**/*kernel_trace.csv", recursive=True)[0])))

@@ -115,6 +115,25 @@ class AirProgram:
         assert 0 <= mul_col and mul_col + 50 <= self.main_width and 0 <= op_b_col and op_b_col + 11 <= self.main_width
         self.instrs.append((HINT, 6 | (op_b_col << 8), mul_col))
 
+    def hint_polynomial_identity(self, products, rest):
+        """The len(rest) asserts that follow are the coefficients of sum_t A_t(x) B_t(x) + R(x): assert k is sum over t and
+        i + j = k of A_t[i] B_t[j], plus rest[k] — `FieldOpCols`' vanishing polynomial (operations/field/util_air.rs:L6-L27), whose
+        63 coefficients are ~2,000 byte products. products: [(A, B)] lists of values (Expr), rest: values; every one of them affine
+        in the main columns (a prover checks that, and the identity on a pseudo-random row, before it believes the hint). With
+        consecutive alpha powers on consecutive coefficients the batched sum is w_0 (sum_t A_t(1/alpha) B_t(1/alpha) + R(1/alpha)):
+        three linear forms over the row instead of a convolution (sp1_amd/csrc/zerocheck.hip, zc_poly_kernel).
+        Pseudo-instructions: [16, 7 | terms << 8, len(rest)], then [16, 8 | code << 8, value] with code = 2 t for A_t's coefficients,
+        2 t + 1 for B_t's, 255 for the rest's, lowest coefficient first."""
+        assert len(products) < 120 and all(len(a) + len(bb) - 1 <= len(rest) for a, bb in products)
+        self.instrs.append((HINT, 7 | (len(products) << 8), len(rest)))
+        for t, (a, bb) in enumerate(products):
+            for e in a:
+                self.instrs.append((HINT, 8 | ((2 * t) << 8), e.idx))
+            for e in bb:
+                self.instrs.append((HINT, 8 | ((2 * t + 1) << 8), e.idx))
+        for e in rest:
+            self.instrs.append((HINT, 8 | (255 << 8), e.idx))
+
     def assert_zero(self, e):
         self._emit(ASSERT_ZERO, e.idx, 0)
         self.num_constraints += 1

@@ -37,6 +37,7 @@
 #include "zc_poseidon2.hpp"
 #include "zc_keccak.hpp"
 #include "zc_mul.hpp"
+#include "zc_poly.hpp"
 
 namespace sp1hip {
 
@@ -480,7 +481,7 @@ constexpr uint32_t ZC_DESC_MACRO = 2u;
 // KIND of a launch that carries the pieces of BOTH septic kinds (they are adjacent block ranges; the kind comes from the descriptor): in
 // the small rounds every launch is at its latency floor and the two septic launches would share a hardware queue (a process has four)
 constexpr uint32_t ZC_MACRO_BOTH_SEPTIC = 4u;
-constexpr uint32_t ZC_MACRO_KINDS = 7;        // kinds 1..3, the launch shape 4, Keccak = 5, MulOperation products = 6
+constexpr uint32_t ZC_MACRO_KINDS = 8;        // kinds 1..3, the launch shape 4, Keccak = 5, MulOperation products = 6, polynomial identities = 7
 template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
                                                        uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
@@ -670,6 +671,198 @@ __global__ __launch_bounds__(256) void zc_biv_macro_kernel(const ZcDesc* __restr
     if (threadIdx.x < 8) {
         const uint32_t k = threadIdx.x;
         partial[((size_t)bid * ZC_BIV_NODES + node) * 8 + k] = k < 4 ? kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k])) : 0u;
+    }
+}
+
+// ---- polynomial identities (zc_poly.hpp, hint kind 7): sum_t A_t B_t + R with affine forms A_t, B_t, R whose coefficients the host
+// collapsed for this proof's alpha (table at d.prog: header, then 8-word entries). An affine form's value at a node of a row pair is
+// the interpolation of its values on the two rows, so ONE workgroup (blockIdx.x = block) loads every column of its 256 row pairs once
+// and leaves the sums of all three nodes: partial slots as the per-node kernels write them. The columns the identity owns (carry and
+// witness limbs: nothing else reads them) carry their GKR batching term in the extension rounds.
+struct ZcPolyTable {
+    zc_const_words_t tb;
+    __device__ __forceinline__ uint32_t word(uint32_t off) const { return tb[off]; }
+    __device__ __forceinline__ kb::Ext coef(uint32_t off) const { return kb::Ext{{tb[off + 4], tb[off + 5], tb[off + 6], tb[off + 7]}}; }
+};
+__device__ __forceinline__ kb::Ext zc_ext_times_pow2(kb::Ext v, uint32_t k) {          // k in {0, 1, 2, 4, 8, 16}: compile-time after unrolling
+    if (k == 0) return kb::ext_zero();
+    for (uint32_t m = 1; m < k; m <<= 1) v = kb::ext_add(v, v);
+    return v;
+}
+template <bool FIRST>
+__global__ __launch_bounds__(256) void zc_poly_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                      uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base) {
+    using K = KT<FIRST>;
+    using T = typename K::T;
+    __shared__ uint32_t red[4 * 24];
+    const uint32_t bid = block_base + blockIdx.x;
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const ZcPolyTable tab{(zc_const_words_t)(uintptr_t)d.prog};
+    const uint32_t n_terms = tab.word(0), n_rest = tab.word(1), n_owned = tab.word(2);
+    const uint32_t terms = (d.rows + 1) / 2;
+    kb::Ext sa[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()}, sb[2] = {kb::ext_zero(), kb::ext_zero()};
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < terms; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, terms); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        const bool has1 = 2 * i + 1 < d.rows;
+        uint32_t off = ZC_POLY_HDR;
+        // the values of one affine form on the two rows of the pair (its constant entry first)
+        auto form = [&](uint32_t n, kb::Ext& f0, kb::Ext& f1) {
+            f0 = f1 = tab.coef(off);
+            off += ZC_POLY_ENTRY;
+#pragma unroll 4
+            for (uint32_t k = 0; k < n; k++, off += ZC_POLY_ENTRY) {
+                const uint32_t col = tab.word(off);
+                const kb::Ext c = tab.coef(off);
+                const T x0 = K::load(d.main, col, d.rows, 2 * i);
+                const T x1 = has1 ? K::load(d.main, col, d.rows, 2 * i + 1) : K::zero();
+                f0 = kb::ext_add(f0, K::scale(c, x0));
+                f1 = kb::ext_add(f1, K::scale(c, x1));
+            }
+        };
+        kb::Ext v0 = kb::ext_zero(), v2 = kb::ext_zero(), v4 = kb::ext_zero();      // eq * C at the three nodes
+        for (uint32_t t = 0; t < n_terms; t++) {
+            kb::Ext a0, a1, b0, b1;
+            form(tab.word(4 + 2 * t), a0, a1);
+            form(tab.word(5 + 2 * t), b0, b1);
+            a0 = kb::ext_mul(a0, e); a1 = kb::ext_mul(a1, e);
+            const kb::Ext da = kb::ext_sub(a1, a0), db = kb::ext_sub(b1, b0);
+            const kb::Ext da2 = kb::ext_add(da, da), db2 = kb::ext_add(db, db);
+            const kb::Ext a2 = kb::ext_add(a0, da2), b2 = kb::ext_add(b0, db2);
+            if (!FIRST) v0 = kb::ext_add(v0, kb::ext_mul(a0, b0));
+            v2 = kb::ext_add(v2, kb::ext_mul(a2, b2));
+            v4 = kb::ext_add(v4, kb::ext_mul(kb::ext_add(a2, da2), kb::ext_add(b2, db2)));
+        }
+        kb::Ext r0, r1, g0 = kb::ext_zero(), g1 = kb::ext_zero();
+        form(n_rest, r0, r1);
+#pragma unroll 2
+        for (uint32_t k = 0; k < n_owned; k++, off += ZC_POLY_ENTRY) {
+            const uint32_t col = tab.word(off);
+            const kb::Ext c = tab.coef(off);
+            const T x0 = K::load(d.main, col, d.rows, 2 * i);
+            const T x1 = has1 ? K::load(d.main, col, d.rows, 2 * i + 1) : K::zero();
+            r0 = kb::ext_add(r0, K::scale(c, x0));
+            r1 = kb::ext_add(r1, K::scale(c, x1));
+            if (!FIRST) {
+                const kb::Ext gp = load_ext_aos(d.gkr_pows, col);
+                g0 = kb::ext_add(g0, K::scale(gp, x0));
+                g1 = kb::ext_add(g1, K::scale(gp, x1));
+            }
+        }
+        r0 = kb::ext_mul(r0, e); r1 = kb::ext_mul(r1, e);
+        const kb::Ext dr = kb::ext_sub(r1, r0), dr2 = kb::ext_add(dr, dr), r2 = kb::ext_add(r0, dr2);
+        if (!FIRST) sa[0] = kb::ext_add(sa[0], kb::ext_add(v0, r0));
+        sa[1] = kb::ext_add(sa[1], kb::ext_add(v2, r2));
+        sa[2] = kb::ext_add(sa[2], kb::ext_add(v4, kb::ext_add(r2, dr2)));
+        if (!FIRST) {
+            g0 = kb::ext_mul(g0, e); g1 = kb::ext_mul(g1, e);
+            const kb::Ext dg = kb::ext_sub(g1, g0);
+            sb[0] = kb::ext_add(sb[0], g0);
+            sb[1] = kb::ext_add(sb[1], kb::ext_add(g0, kb::ext_add(dg, dg)));
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v[24];
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[pass * 8 + k] = zc_wave_sum(sa[pass].c[k]); v[pass * 8 + 4 + k] = pass < 2 ? zc_wave_sum(sb[pass].c[k]) : 0u; }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) red[wave * 24 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        const uint32_t k = threadIdx.x;
+        uint32_t acc = red[k];
+        for (uint32_t w = 1; w < blockDim.x / 64; w++) acc = kb::add(acc, red[w * 24 + k]);
+        partial[((size_t)bid * 3 + k / 8) * 8 + (k & 7u)] = acc;
+    }
+}
+
+// The bivariate rounds: row quads, the twelve nodes of the grid from the forms' values on the four rows (base-field words).
+__global__ __launch_bounds__(256) void zc_biv_poly_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                          uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base) {
+    __shared__ uint32_t red[4 * 48];
+    const uint32_t bid = block_base + blockIdx.x;
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const ZcPolyTable tab{(zc_const_words_t)(uintptr_t)d.prog};
+    const uint32_t n_terms = tab.word(0), n_rest = tab.word(1), n_owned = tab.word(2);
+    const uint32_t quads = (d.rows + 3) / 4;
+    kb::Ext sa[ZC_BIV_NODES];
+#pragma unroll
+    for (int n = 0; n < ZC_BIV_NODES; n++) sa[n] = kb::ext_zero();
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < quads; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, quads); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        const uint32_t r = 4 * i;
+        uint32_t off = ZC_POLY_HDR;
+        auto form = [&](uint32_t n, kb::Ext (&f)[4]) {              // f: the form on rows r .. r + 3 = (X, Y) = (0,0) (0,1) (1,0) (1,1)
+            f[0] = f[1] = f[2] = f[3] = tab.coef(off);
+            off += ZC_POLY_ENTRY;
+#pragma unroll 2
+            for (uint32_t k = 0; k < n; k++, off += ZC_POLY_ENTRY) {
+                const uint32_t col = tab.word(off);
+                const kb::Ext c = tab.coef(off);
+                const zc_global_words_t g = (zc_global_words_t)d.main + (size_t)col * d.rows;
+                const uint32_t x00 = g[r], x01 = r + 1 < d.rows ? g[r + 1] : 0u, x10 = r + 2 < d.rows ? g[r + 2] : 0u, x11 = r + 3 < d.rows ? g[r + 3] : 0u;
+                f[0] = kb::ext_add(f[0], kb::ext_mul_base(c, x00));
+                f[1] = kb::ext_add(f[1], kb::ext_mul_base(c, x01));
+                f[2] = kb::ext_add(f[2], kb::ext_mul_base(c, x10));
+                f[3] = kb::ext_add(f[3], kb::ext_mul_base(c, x11));
+            }
+        };
+        // f -> (f00, dX, dY, dXY): the form at node (X, Y) is f00 + X dX + Y dY + X Y dXY
+        auto slopes = [&](kb::Ext (&f)[4]) {
+            const kb::Ext dy = kb::ext_sub(f[1], f[0]), dx = kb::ext_sub(f[2], f[0]);
+            f[3] = kb::ext_sub(kb::ext_sub(f[3], f[2]), dy);
+            f[1] = dx; f[2] = dy;
+        };
+        auto at = [&](const kb::Ext (&f)[4], const ZcBivNode& nd) -> kb::Ext {
+            return kb::ext_add(kb::ext_add(f[0], zc_ext_times_pow2(f[1], nd.cx)), kb::ext_add(zc_ext_times_pow2(f[2], nd.cy), zc_ext_times_pow2(f[3], nd.cxy)));
+        };
+        for (uint32_t t = 0; t < n_terms; t++) {
+            kb::Ext a[4], b[4];
+            form(tab.word(4 + 2 * t), a);
+            form(tab.word(5 + 2 * t), b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) a[k] = kb::ext_mul(a[k], e);
+            slopes(a); slopes(b);
+#pragma unroll
+            for (int n = 0; n < ZC_BIV_NODES; n++) {
+                const ZcBivNode nd = zc_biv_node(n);
+                sa[n] = kb::ext_add(sa[n], kb::ext_mul(at(a, nd), at(b, nd)));
+            }
+        }
+        kb::Ext rr[4];
+        form(n_rest + n_owned, rr);                                 // (the owned columns follow the rest's: no GKR term in these rounds)
+#pragma unroll
+        for (int k = 0; k < 4; k++) rr[k] = kb::ext_mul(rr[k], e);
+        slopes(rr);
+#pragma unroll
+        for (int n = 0; n < ZC_BIV_NODES; n++) sa[n] = kb::ext_add(sa[n], at(rr, zc_biv_node(n)));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v[48];
+#pragma unroll
+    for (int n = 0; n < ZC_BIV_NODES; n++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[n * 4 + k] = zc_wave_sum(sa[n].c[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 48; k++) red[wave * 48 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const uint32_t k = threadIdx.x;
+        uint32_t acc = red[k];
+        for (uint32_t w = 1; w < blockDim.x / 64; w++) acc = kb::add(acc, red[w * 48 + k]);
+        partial[((size_t)bid * ZC_BIV_NODES + k / 4) * 8 + (k & 3u)] = acc;
+        partial[((size_t)bid * ZC_BIV_NODES + k / 4) * 8 + 4 + (k & 3u)] = 0u;
     }
 }
 
@@ -1027,13 +1220,15 @@ struct DevBuf {
 
 struct ZcMacro {                 // a hinted sub-AIR: its constraints are [first_constraint, first_constraint + n_constraints())
     uint32_t kind, base_col, first_constraint, aux0 = 0, aux1 = 0;
-    uint32_t n_constraints() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_KECCAK ? ZC_KK_CONSTRAINTS : kind == ZC_HINT_MUL ? ZC_MUL_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
+    uint32_t n_c = 0;            // kind 7 (a polynomial identity, zc_poly.hpp: ZcPlan::polys[aux0]): its number of constraints
+    uint32_t n_constraints() const { return kind == ZC_HINT_POLY ? n_c : kind == ZC_HINT_POSEIDON2 ? ZC_P2_CONSTRAINTS : kind == ZC_HINT_KECCAK ? ZC_KK_CONSTRAINTS : kind == ZC_HINT_MUL ? ZC_MUL_CONSTRAINTS : kind == ZC_HINT_SEPTIC_CURVE ? 7u : 14u; }
     // pieces the kernels run (the septic kinds: weighted forms, zc_septic_*_piece_w) / pieces of the host model (per-coefficient forms)
-    uint32_t n_pieces() const { return kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_KECCAK ? ZC_KK_PIECES : kind == ZC_HINT_MUL ? ZC_MUL_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 2u : 4u; }
+    uint32_t n_pieces() const { return kind == ZC_HINT_POLY ? 1u : kind == ZC_HINT_POSEIDON2 ? ZC_P2_PIECES : kind == ZC_HINT_KECCAK ? ZC_KK_PIECES : kind == ZC_HINT_MUL ? ZC_MUL_PIECES : kind == ZC_HINT_SEPTIC_CURVE ? 2u : 4u; }
     uint32_t n_host_pieces() const { return kind == ZC_HINT_SEPTIC_CURVE ? 1u : kind == ZC_HINT_SEPTIC_SUM ? 2u : n_pieces(); }
-    // the columns whose GKR-opening term the fused pieces carry: [lo, lo + n)
+    // the columns whose GKR-opening term the fused pieces carry: [lo, lo + n) (a polynomial identity: the list ZcPoly::owned instead)
     void owned(uint32_t* lo, uint32_t* n) const {
-        if (kind == ZC_HINT_POSEIDON2) { *lo = base_col; *n = ZC_P2_COLUMNS; }
+        if (kind == ZC_HINT_POLY) { *lo = 0; *n = 0; }
+        else if (kind == ZC_HINT_POSEIDON2) { *lo = base_col; *n = ZC_P2_COLUMNS; }
         else if (kind == ZC_HINT_KECCAK) { *lo = base_col; *n = ZC_KK_COLUMNS; }
         else if (kind == ZC_HINT_MUL) { *lo = base_col + MUL_CARRY; *n = ZC_MUL_OWNED; }
         else if (kind == ZC_HINT_SEPTIC_CURVE) { *lo = base_col; *n = 14; }
@@ -1056,11 +1251,16 @@ struct ZcPlan {                      // everything that depends on a chip's prog
     std::vector<Chunk> chunks, mono, fine;
     std::vector<uint32_t> sched;     // the scheduled SSA the forms above were cut from
     std::vector<ZcMacro> macros;     // hinted sub-AIRs evaluated by fused kernels (zc_poseidon2.hpp); their asserts are not in the forms above
+    std::vector<ZcPoly> polys;       // the polynomial identities among them (zc_poly.hpp), by ZcMacro::aux0
+    std::vector<std::vector<ZcPolySeg>> poly_segs;   // their device-table segments, ready for a proof's alpha
 };
 
 struct ChipState {
     const sp1hip_zc_chip_t* in;
     std::vector<ZcMacro> macros;
+    std::shared_ptr<const ZcPlan> plan;   // (the polynomial identities' forms live in the plan)
+    std::vector<size_t> poly_off;   // per macro: word offset of its device table in the call's constant blob (kind 7 only)
+    const uint32_t* p_blob = nullptr;
     std::vector<uint32_t> prog;     // allocated [n][4]
     uint32_t n_regs = 1;
     std::vector<Ext> alpha_pows, gkr_pows;
@@ -1423,7 +1623,8 @@ static int allocate_registers(const uint32_t* ssa, uint32_t n, std::vector<uint3
 // keeps the late, tiny sumcheck rounds from being one wave interpreting thousands of instructions
 // serially (cf. the reference's chunked bytecode, /root/reference/sp1-gpu/crates/air/src/ir/bytecode.rs:L27-L110).
 static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32_t prep_w, uint32_t limit,
-                        std::vector<Chunk>* out, uint32_t hard_max = ZC_CHUNK_HARD_MAX, const std::vector<ZcMacro>* macros = nullptr) {
+                        std::vector<Chunk>* out, uint32_t hard_max = ZC_CHUNK_HARD_MAX, const std::vector<ZcMacro>* macros = nullptr,
+                        const std::vector<ZcPoly>* polys = nullptr) {
     std::vector<uint32_t> stamp(n, 0xffffffffu);
     std::vector<uint8_t> cone_seen(n, 0);
     std::vector<uint32_t> members, asserts, stack;
@@ -1513,6 +1714,7 @@ static int build_chunks(const uint32_t* ssa, uint32_t n, uint32_t main_w, uint32
             uint32_t lo, cnt;
             m.owned(&lo, &cnt);
             for (uint32_t c = 0; c < cnt; c++) seen_m[lo + c] = true;
+            if (m.kind == ZC_HINT_POLY && polys) for (uint32_t c : (*polys)[m.aux0].owned) seen_m[c] = true;
         }
     for (auto& c : *out)
         for (size_t k = 0; k < c.prog.size() / 4; k++) {
@@ -1589,8 +1791,9 @@ static Ext eval_zero_row(const ChipState& c, const uint32_t* publics) {
 
 // host model of the fused pieces on ONE row of base-field words (the planner's check of a hint, sp1hip_zerocheck_plan_eval)
 template <class Sink>
-static void macro_eval_row(const ZcMacro& m, const uint32_t* main_row, Sink&& sink) {
+static void macro_eval_row(const ZcMacro& m, const std::vector<ZcPoly>& polys, const uint32_t* main_row, Sink&& sink) {
     static const p2::RoundConstants host_rc = p2::make_round_constants();
+    if (m.kind == ZC_HINT_POLY) { zc_poly_eval_row(polys[m.aux0], main_row, sink); return; }
     for (uint32_t q = 0; q < m.n_host_pieces(); q++) {
         if (m.kind == ZC_HINT_POSEIDON2)
             zc_p2_piece<P2Base>(q, &host_rc, [&](uint32_t c, bool) { return main_row[m.base_col + c]; }, sink);
@@ -1653,6 +1856,48 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                 if (clean[3 * k] == ZC_ASSERT_ZERO) asserts_before++;
                 if (clean[3 * k] != ZC_HINT) continue;
                 const uint32_t kind = clean[3 * k + 1] & 0xffu, w1 = clean[3 * k + 1] >> 8, w2 = clean[3 * k + 2];
+                if (kind == ZC_HINT_POLY) {
+                    // a polynomial identity (zc_poly.hpp): the values it names follow as ARG pseudo-instructions. Its forms are taken
+                    // from the SSA; values that are not affine in the main columns drop the hint (the interpreter keeps the constraints)
+                    const uint32_t n_terms = w1, n_c = w2;
+                    SP1HIP_REQUIRE(n_terms <= ZC_POLY_MAX_TERMS * 20 && n_c >= 1 && n_c < (1u << 16), "polynomial-identity hint: bad header");
+                    std::vector<std::vector<uint32_t>> ids(2 * (size_t)n_terms + 1);
+                    uint32_t j = k + 1;
+                    for (; j < n_instr && clean[3 * j] == ZC_HINT && (clean[3 * j + 1] & 0xffu) == ZC_HINT_POLY_ARG; j++) {
+                        const uint32_t code = clean[3 * j + 1] >> 8, id = clean[3 * j + 2];
+                        SP1HIP_REQUIRE((code == 255u || code < 2 * n_terms) && id < k, "polynomial-identity hint: bad argument");
+                        ids[code == 255u ? 2 * (size_t)n_terms : code].push_back(id);
+                    }
+                    bool shape = ids.back().size() == n_c;
+                    for (uint32_t t = 0; t < n_terms; t++) shape &= !ids[2 * t].empty() && !ids[2 * t + 1].empty() && ids[2 * t].size() + ids[2 * t + 1].size() - 1 <= n_c;
+                    SP1HIP_REQUIRE(shape, "polynomial-identity hint: operand counts do not match the number of constraints");
+                    for (uint32_t q = k; q < j; q++) { clean[3 * q] = ZC_CONST; clean[3 * q + 1] = 0; clean[3 * q + 2] = 0; }
+                    ZcPoly poly;
+                    poly.first_constraint = asserts_before; poly.n_c = n_c;
+                    bool affine = n_terms <= ZC_POLY_MAX_TERMS;
+                    std::vector<uint32_t> all;
+                    for (auto& v : ids) all.insert(all.end(), v.begin(), v.end());
+                    std::vector<ZcLinForm> forms;
+                    affine = affine && zc_poly_extract(clean.data(), n_instr, all, &forms);
+                    if (affine) {
+                        size_t at = 0;
+                        poly.terms.resize(n_terms);
+                        for (uint32_t t = 0; t < n_terms; t++) {
+                            poly.terms[t].a.assign(forms.begin() + at, forms.begin() + at + ids[2 * t].size()); at += ids[2 * t].size();
+                            poly.terms[t].b.assign(forms.begin() + at, forms.begin() + at + ids[2 * t + 1].size()); at += ids[2 * t + 1].size();
+                        }
+                        poly.rest.assign(forms.begin() + at, forms.end());
+                        ZcMacro m{kind, 0u, asserts_before};
+                        m.aux0 = (uint32_t)np->polys.size(); m.n_c = n_c;
+                        np->polys.push_back(std::move(poly));
+                        np->macros.push_back(m);
+                    } else if (getenv("SP1HIP_ZC_DEBUG")) {
+                        fprintf(stderr, "[sp1hip zc] chip %d: polynomial-identity hint at constraint %u dropped (a named value is not affine in the main columns)\n", chip_index, asserts_before);
+                    }
+                    k = j - 1;
+                    continue;
+                }
+                SP1HIP_REQUIRE(kind != ZC_HINT_POLY_ARG, "polynomial-identity argument without its hint");
                 SP1HIP_REQUIRE((kind >= ZC_HINT_POSEIDON2 && kind <= ZC_HINT_SEPTIC_SUM) || kind == ZC_HINT_KECCAK || kind == ZC_HINT_MUL, "unknown hint kind in constraint program");
                 ZcMacro m{kind, kind == ZC_HINT_SEPTIC_SUM ? (w2 & 0xffffu) : w2, asserts_before};
                 if (kind == ZC_HINT_SEPTIC_SUM) { m.aux0 = w2 >> 16; m.aux1 = w1; }
@@ -1685,6 +1930,41 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
             for (const ZcMacro& m : np->macros) if (idx >= m.first_constraint && idx < m.first_constraint + m.n_constraints()) return true;
             return false;
         };
+        // the columns a polynomial identity OWNS (its piece carries their GKR batching term, the interpreter never loads them): those
+        // of its rest form that neither its products, nor another identity, nor any constraint left to the interpreter reads
+        if (!np->polys.empty() && std::all_of(np->macros.begin(), np->macros.end(), [](const ZcMacro& m) { return m.kind == ZC_HINT_POLY; })) {
+            std::vector<uint8_t> interp(main_width, 0), visited(n_instr, 0);
+            std::vector<uint32_t> stack;
+            uint32_t idx = 0;
+            for (uint32_t k = 0; k < n_instr; k++) {
+                if (clean[3 * k] != ZC_ASSERT_ZERO) continue;
+                if (!hinted(idx) && clean[3 * k + 1] < n_instr) stack.push_back(clean[3 * k + 1]);
+                idx++;
+            }
+            while (!stack.empty()) {
+                const uint32_t v = stack.back();
+                stack.pop_back();
+                if (visited[v]) continue;
+                visited[v] = 1;
+                const uint32_t op = clean[3 * v], a = clean[3 * v + 1], b = clean[3 * v + 2];
+                if (op == ZC_LOAD_MAIN) { if (a < main_width) interp[a] = 1; }
+                else if (op == ZC_ADD || op == ZC_SUB || op == ZC_MUL) { if (a < v) stack.push_back(a); if (b < v) stack.push_back(b); }
+                else if (op == ZC_NEG) { if (a < v) stack.push_back(a); }
+            }
+            std::vector<uint32_t> users(main_width, 0);
+            std::vector<std::vector<uint8_t>> in_prod(np->polys.size(), std::vector<uint8_t>(main_width, 0)), in_any = in_prod;
+            for (size_t pi = 0; pi < np->polys.size(); pi++) {
+                const ZcPoly& pl = np->polys[pi];
+                auto mark = [&](const ZcLinForm& f, bool prod) { for (uint32_t c : f.cols) if (c < main_width) { in_any[pi][c] = 1; if (prod) in_prod[pi][c] = 1; } };
+                for (const ZcPolyTerm& t : pl.terms) { for (auto& f : t.a) mark(f, true); for (auto& f : t.b) mark(f, true); }
+                for (auto& f : pl.rest) mark(f, false);
+                for (uint32_t c = 0; c < main_width; c++) users[c] += in_any[pi][c];
+            }
+            for (size_t pi = 0; pi < np->polys.size(); pi++)
+                for (uint32_t c = 0; c < main_width; c++)
+                    if (in_any[pi][c] && !in_prod[pi][c] && !interp[c] && users[c] == 1) np->polys[pi].owned.push_back(c);
+        }
+        for (const ZcPoly& pl : np->polys) np->poly_segs.push_back(zc_poly_segments(pl));
         auto drop_hinted = [&](std::vector<uint32_t>& sch) {      // asserts carry their constraint index in operand b by now
             if (np->macros.empty()) return;
             for (size_t k = 0; k < sch.size() / 3; k++)
@@ -1710,7 +1990,7 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
             schedule_program(folded.data(), n_instr, main_width, mode, &cand);
             std::vector<uint32_t> cand_f = cand;
             drop_hinted(cand_f);
-            SP1HIP_TRY(build_chunks(cand_f.data(), (uint32_t)(cand_f.size() / 3), main_width, prep_width, 0xffffffffu, &mono, ZC_CHUNK_HARD_MAX, &np->macros));
+            SP1HIP_TRY(build_chunks(cand_f.data(), (uint32_t)(cand_f.size() / 3), main_width, prep_width, 0xffffffffu, &mono, ZC_CHUNK_HARD_MAX, &np->macros, &np->polys));
             uint32_t regs = 0;
             for (auto& ck : mono) regs = std::max(regs, ck.n_regs);
             if (regs < best_regs) { best_regs = regs; sched.swap(cand); np->mono.swap(mono); }
@@ -1728,8 +2008,8 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
         static const uint32_t chunk_hard = [] { const char* e = getenv("SP1HIP_ZC_CHUNK_HARD_MAX"); return e ? std::max<uint32_t>((uint32_t)atoi(e), 8u) : ZC_CHUNK_HARD_MAX; }();
         std::vector<uint32_t> sched_f = sched;
         drop_hinted(sched_f);
-        SP1HIP_TRY(build_chunks(sched_f.data(), n_sched, main_width, prep_width, chunk_limit, &np->chunks, chunk_hard, &np->macros));
-        SP1HIP_TRY(build_chunks(sched_f.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT, &np->macros));
+        SP1HIP_TRY(build_chunks(sched_f.data(), n_sched, main_width, prep_width, chunk_limit, &np->chunks, chunk_hard, &np->macros, &np->polys));
+        SP1HIP_TRY(build_chunks(sched_f.data(), n_sched, main_width, prep_width, ZC_FINE_LIMIT, &np->fine, ZC_FINE_LIMIT, &np->macros, &np->polys));
         np->sched = sched;
         // trust, but verify: on a pseudo-random row the fused pieces must give what the caller's SSA gives for the constraints
         // they replace (a hint on the wrong columns, or on constraints that are not the Poseidon2 sub-AIR, is an error here)
@@ -1747,7 +2027,7 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
             for (const ZcMacro& m : np->macros) {
                 bool ok = true;
                 uint32_t n_seen = 0;
-                macro_eval_row(m, row.data(), [&](uint32_t j, uint32_t v) {
+                macro_eval_row(m, np->polys, row.data(), [&](uint32_t j, uint32_t v) {
                     n_seen++;
                     const bool same = m.first_constraint + j < want.size() && want[m.first_constraint + j] == v;
                     if (!same && zc_debug)
@@ -1926,6 +2206,9 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     SP1HIP_TRY(stage.init(s));
     if (n_publics) SP1HIP_TRY(stage.upload(d_publics.p, publics.data(), (size_t)n_publics * 4));
     std::vector<uint32_t> blob;
+    Ext rho = kb::ext_zero();                     // 1 / alpha, once a chip needs it
+    bool have_rho = false;
+    std::vector<kb::Ext> poly_scratch[2];
     std::vector<std::unique_ptr<ChipState>> st;
     std::vector<Ext> claims;
     size_t oo = 0;
@@ -1947,6 +2230,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             SP1HIP_TRY(zc_get_plan(chips[i].program, chips[i].n_instr, chips[i].main_width, chips[i].prep_width, i, &plan, chips[i].real_rows));
             c->prog = plan->prog; c->n_regs = plan->n_regs; c->chunks = plan->chunks; c->mono = plan->mono; c->fine = plan->fine;
             c->macros = plan->macros;
+            c->plan = plan;
         }
         // [alpha^(n-1), ..., alpha, 1] so that the folder matches the verifier's Horner order
         c->alpha_pows.assign(pows.begin(), pows.begin() + chips[i].num_constraints);
@@ -1986,6 +2270,19 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         for (const Ext& e : c->alpha_pows) blob.insert(blob.end(), e.c, e.c + 4);
         c->off_gkr = blob.size();
         for (const Ext& e : c->gkr_pows) blob.insert(blob.end(), e.c, e.c + 4);
+        // the polynomial identities' affine forms, collapsed for this proof's alpha (zc_poly.hpp)
+        c->poly_off.assign(c->macros.size(), 0);
+        for (size_t mi = 0; mi < c->macros.size(); mi++) {
+            const ZcMacro& m = c->macros[mi];
+            if (m.kind != ZC_HINT_POLY) continue;
+            if (!have_rho) {
+                SP1HIP_REQUIRE(!kb::ext_eq(alpha, kb::ext_zero()), "the batching challenge is zero");
+                rho = kb::ext_inv(alpha); have_rho = true;
+            }
+            while (blob.size() & 7) blob.push_back(0);
+            c->poly_off[mi] = blob.size();
+            zc_poly_table(c->plan->polys[m.aux0], c->plan->poly_segs[m.aux0], c->alpha_pows.data() + m.first_constraint, rho, &blob, poly_scratch);
+        }
         st.push_back(std::move(c));
     }
     DevBuf d_blob;
@@ -1995,6 +2292,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         c->p_prog = d_blob.u32() + c->off_prog;
         c->p_alpha = d_blob.u32() + c->off_alpha;
         c->p_gkr = d_blob.u32() + c->off_gkr;
+        c->p_blob = d_blob.u32();
     }
 
     std::vector<Ext> zeta(L);
@@ -2233,10 +2531,12 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 const uint32_t terms = (uint32_t)((vrows[i] + unit - 1) / unit);
                 const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
                 ZcChipRange rg{total_blocks, 0, biv ? (uint32_t)(vrows[i] / 4) : terms - 1, 0};
-                for (const ZcMacro& m : c.macros) {
+                for (size_t mi = 0; mi < c.macros.size(); mi++) {
+                    const ZcMacro& m = c.macros[mi];
                     if (m.kind != kind) continue;
                     for (uint32_t q = 0; q < m.n_pieces(); q++) {
                         ZcDesc d{};
+                        if (kind == ZC_HINT_POLY) d.prog = c.p_blob + c.poly_off[mi];
                         d.main = vmain[i]; d.prep = vprep[i]; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
                         d.rows = (uint32_t)vrows[i]; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
                         d.block_start = total_blocks; d.n_blocks = blocks;
@@ -2348,7 +2648,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             {
                 ScopedTimer tm("zerocheck_round", s);
                 // the launches on fork streams, joined in front of the reduction (as in the later rounds)
-                const int n_launches = (int)rp.groups.size() + (rp.macro_n[1] ? 1 : 0) + (rp.macro_n[2] ? 1 : 0) + (rp.macro_n[3] ? 1 : 0) + (rp.macro_n[5] ? 1 : 0);
+                const int n_launches = (int)rp.groups.size() + (rp.macro_n[1] ? 1 : 0) + (rp.macro_n[2] ? 1 : 0) + (rp.macro_n[3] ? 1 : 0) + (rp.macro_n[5] ? 1 : 0) + (rp.macro_n[7] ? 1 : 0);
                 const bool forked = fork_enabled && n_launches > 1 && active_provers() <= 1;
                 constexpr int N_FORK = 3;
                 const int n_fork = zc_fork_streams();
@@ -2383,6 +2683,10 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 3)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 3)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(6u, 1)
+                if (rp.macro_n[ZC_HINT_POLY]) {            // all twelve nodes per workgroup
+                    hipLaunchKernelGGL(zc_biv_poly_kernel, dim3(rp.macro_n[ZC_HINT_POLY]), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_POLY]);
+                    SP1HIP_LAUNCH_CHECK();
+                }
                 if (rp.macro_n[ZC_HINT_KECCAK]) {          // four nodes per pass: three node-group workgroups per block
                     hipLaunchKernelGGL(zc_biv_keccak_kernel, dim3(rp.macro_n[ZC_HINT_KECCAK] * ZC_BIV_GROUPS), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_KECCAK]);
                     SP1HIP_LAUNCH_CHECK();
@@ -2535,7 +2839,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             // costs its LONGEST launch instead of their sum (five launches of 30-70 us each in the last fifteen rounds of a
             // core shard; in the large rounds one launch's tail overlaps the next one's head). SP1HIP_ZC_FORK=0: one stream.
             static const bool fuse_nodes = [] { const char* e = getenv("SP1HIP_ZC_FUSE_NODES"); return e && e[0] == '1'; }();
-            const int n_launches = (int)groups.size() + (macro_n[1] ? 1 : 0) + (macro_n[2] ? 1 : 0) + (macro_n[3] ? 1 : 0) + (macro_n[5] ? 1 : 0);
+            const int n_launches = (int)groups.size() + (macro_n[1] ? 1 : 0) + (macro_n[2] ? 1 : 0) + (macro_n[3] ? 1 : 0) + (macro_n[5] ? 1 : 0) + (macro_n[7] ? 1 : 0);
             static const uint32_t fork_max_blocks = [] { const char* e = getenv("SP1HIP_ZC_FORK_MAX_BLOCKS"); return e ? (uint32_t)strtoul(e, nullptr, 10) : ZC_FORK_MAX_BLOCKS; }();
             const bool forked = fork_enabled && n_launches > 1 && total_blocks <= fork_max_blocks && active_provers() <= 1;
             // the round's sums reach the host through the mailbox slot when they fit it (they do for any real machine)
@@ -2556,7 +2860,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             struct Launch { int kind; size_t group; double est; int slot; };           // kind 0: interpreter group, 1..3: fused pieces
             std::vector<Launch> order;
             {
-                static const double floor_us[ZC_MACRO_KINDS] = {45.0, 75.0, 45.0, 60.0, 60.0, 120.0, 45.0};
+                static const double floor_us[ZC_MACRO_KINDS] = {45.0, 75.0, 45.0, 60.0, 60.0, 120.0, 45.0, 90.0};
                 for (size_t g = 0; g < groups.size(); g++) order.push_back({0, g, floor_us[0] * (1.0 + groups[g].n_blocks * 3 / 1024.0), 0});
                 const bool both_septic = forked && r > 0 && macro_n[2] && macro_n[3] && (uint64_t)total_blocks * 3 <= ZC_SMALL_ROUND_WGS;
                 for (int kind = 1; kind <= 3; kind++) {
@@ -2566,6 +2870,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 }
                 if (macro_n[ZC_HINT_KECCAK]) order.push_back({(int)ZC_HINT_KECCAK, 0, floor_us[ZC_HINT_KECCAK] * (1.0 + macro_n[ZC_HINT_KECCAK] * 3 / 1024.0), 0});
                 if (macro_n[ZC_HINT_MUL]) order.push_back({(int)ZC_HINT_MUL, 0, floor_us[ZC_HINT_MUL] * (1.0 + macro_n[ZC_HINT_MUL] * 3 / 1024.0), 0});
+                if (macro_n[ZC_HINT_POLY]) order.push_back({(int)ZC_HINT_POLY, 0, floor_us[ZC_HINT_POLY] * (1.0 + macro_n[ZC_HINT_POLY] * 3 / 1024.0), 0});
                 if (forked) {
                     std::stable_sort(order.begin(), order.end(), [](const Launch& a, const Launch& b) { return a.est > b.est; });
                     double load[N_FORK + 1] = {0, 7, 14, 21};          // (the launches leave the host ~7 us apart)
@@ -2611,6 +2916,11 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_MACRO_LAUNCH(2u)
                 SP1HIP_ZC_MACRO_LAUNCH(3u)
                 SP1HIP_ZC_MACRO_LAUNCH(6u)
+                if (ln.kind == (int)ZC_HINT_POLY) {       // the three nodes per workgroup
+                    if (r == 0) hipLaunchKernelGGL(zc_poly_kernel<true>, dim3(macro_n[ZC_HINT_POLY]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[ZC_HINT_POLY]);
+                    else hipLaunchKernelGGL(zc_poly_kernel<false>, dim3(macro_n[ZC_HINT_POLY]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[ZC_HINT_POLY]);
+                    SP1HIP_LAUNCH_CHECK();
+                }
                 if (ln.kind == (int)ZC_HINT_KECCAK) {
                     const bool keccak3 = [] { const char* e = getenv("SP1HIP_ZC_KECCAK3"); return e && e[0] == '1'; }();   // (read per call: tests run both)
                     if (r == 0) hipLaunchKernelGGL((zc_macro_kernel<true, 5u>), dim3(macro_n[5] * 3), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[5], dctx->d_rc);
@@ -2823,7 +3133,7 @@ extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_in
     }
     if (form != 0) {                                  // the forms the GPU runs: hinted constraints come from the fused pieces
         for (const ZcMacro& m : plan->macros) {
-            macro_eval_row(m, main_row, [&](uint32_t j, uint32_t v) { on_assert(m.first_constraint + j, v); });
+            macro_eval_row(m, plan->polys, main_row, [&](uint32_t j, uint32_t v) { on_assert(m.first_constraint + j, v); });
             pieces += m.n_pieces();
         }
     }

@@ -26,6 +26,7 @@ permutes columns, not polynomials.
 import types
 
 from ..air import P
+from .rv_builder import Builder, Sym
 from .riscv import (ADDRESS_OP, ALU_TYPE, B_AND, B_LTU, B_RANGE, B_U8RANGE, B_XOR, BYTE, CLK_INC, CPU_STATE, GLOBAL, INV, LT_UNSIGNED, MEM_ACCESS, MEMORY, MUL_OP, OPC,
                     PC_INC, R_TYPE, S, SYSCALL, U16_TO_U8, _chip, _done, clk_low_of, eval_add, eval_addr_add, eval_alu_type, eval_compare_u16, eval_cpu_state,
                     eval_lt_unsigned, eval_memory_access, eval_msb, eval_mul, eval_r_type, next_pc_inc, send_byte, slice_range_check_u16,
@@ -757,12 +758,36 @@ def FIELD_LT(n_limbs):                                                          
 MEM_ACCESS_U8 = S(("memory_access", MEM_ACCESS), ("prev_value_u8", U16_TO_U8))            # memory/consistency/columns.rs:L38-L43
 
 
-def eval_field_op_polynomials(b, cols, p_op, p_modulus, p_result, is_real, witness_offset=WITNESS_OFFSET):   # field_op.rs eval_with_polynomials + util_air.rs
-    p_vanishing = _poly_sub(_poly_sub(p_op, p_result), _poly_mul(cols.carry, p_modulus))
+def eval_field_op_polynomials(b, cols, p_op, p_modulus, p_result, is_real, witness_offset=WITNESS_OFFSET, products=None):   # field_op.rs eval_with_polynomials + util_air.rs
+    """The coefficients of p_op - p_result - carry * modulus - (witness - offset) * (x - 2^8) are zero. `products`: p_op is
+    `p_op` + sum of A(x) B(x) over the (A, B) given — the same polynomial, with its products named so that the constraint program
+    can carry a hint for provers (AirProgram.hint_polynomial_identity) when everything else is affine in the row."""
     witness = [w - witness_offset for w in cols.witness]
     rhs = _poly_mul(witness, [-(1 << 8), 1])
-    for cst in _poly_sub(p_vanishing, rhs):
-        b.assert_zero(cst)
+    if products is None:
+        p_vanishing = _poly_sub(_poly_sub(p_op, p_result), _poly_mul(cols.carry, p_modulus))
+        for cst in _poly_sub(p_vanishing, rhs):
+            b.assert_zero(cst)
+    else:
+        products = list(products)
+        if all(isinstance(m, int) or m.is_const for m in p_modulus):
+            carry_mod = _poly_mul(cols.carry, p_modulus)
+        else:                                                                             # a modulus read from memory: one more product
+            carry_mod = []
+            products.append(([-c for c in cols.carry], list(p_modulus)))
+        rest = _poly_sub(_poly_sub(_poly_sub(p_op, p_result), carry_mod), rhs)
+        conv = []
+        for pa, pb in products:
+            conv = _poly_add(conv, _poly_mul(pa, pb))
+        rest = rest + [0] * (len(conv) - len(rest))
+        sym = lambda v: v if isinstance(v, Sym) else b.const(v)
+        rest = [sym(v) for v in rest]
+        products = [([sym(v) for v in pa], [sym(v) for v in pb]) for pa, pb in products]
+        main_affine = lambda v: v.lin is not None and all(kind == "main" for kind, _ in v.lin[0])
+        if isinstance(b, Builder) and all(main_affine(v) for pa, pb in products for v in pa + pb) and all(main_affine(v) for v in rest):
+            b.air.hint_polynomial_identity([([v.expr() for v in pa], [v.expr() for v in pb]) for pa, pb in products], [v.expr() for v in rest])
+        for k, v in enumerate(rest):
+            b.assert_zero(conv[k] + v if k < len(conv) else v)
     slice_range_check_u8(b, cols.result, is_real)
     slice_range_check_u8(b, cols.carry, is_real)
     slice_range_check_u16(b, cols.witness, is_real)
@@ -816,7 +841,7 @@ def uint256_mul_chip():                                                         
     eval_is_zero(b, byte_sum, L.modulus_is_zero, L.is_real)
     mz = L.modulus_is_zero.result
     p_modulus = _poly_add(_poly_scale(m_limbs, 1 - mz), [0] * 32 + [mz])                   # the modulus, or 2^256 when it is zero
-    eval_field_op_polynomials(b, L.output, _poly_mul(x_limbs, y_limbs), p_modulus, L.output.result, L.is_real)
+    eval_field_op_polynomials(b, L.output, [], p_modulus, L.output.result, L.is_real, products=[(x_limbs, y_limbs)])
     eval_field_lt(b, L.output_range_check, L.output.result, m_limbs, L.modulus_is_not_zero)
     b.assert_eq(L.modulus_is_not_zero, L.is_real * (1 - mz))
     result_words = limbs_to_words(L.output.result)
@@ -849,8 +874,10 @@ def eval_field_op(b, cols, a, bb, op, modulus, is_real, witness_offset=WITNESS_O
         p_a, p_res = a, cols.result
     else:
         p_a, p_res = cols.result, a
-    p_op = _poly_add(p_a, bb) if op in ("add", "sub") else _poly_mul(p_a, bb)
-    eval_field_op_polynomials(b, cols, p_op, p_mod, p_res, is_real, witness_offset)
+    if op in ("add", "sub"):
+        eval_field_op_polynomials(b, cols, _poly_add(p_a, bb), p_mod, p_res, is_real, witness_offset, products=[])
+    else:
+        eval_field_op_polynomials(b, cols, [], p_mod, p_res, is_real, witness_offset, products=[(p_a, bb)])
 
 
 # curve: (base-field modulus, a coefficient, byte limbs, witness limbs, witness offset) — curves/src/weierstrass/{secp256k1,secp256r1,bn254,bls12_381}.rs
@@ -1062,17 +1089,13 @@ SYS_ED_ADD, SYS_ED_DECOMPRESS = 0x07, 0x08
 
 
 def eval_field_inner_product(b, cols, a_list, b_list, modulus, is_real):                  # field_inner_product.rs:L106-L145
-    p_ip = []
-    for pa, pb in zip(a_list, b_list):
-        p_ip = _poly_add(p_ip, _poly_mul(pa, pb))
     p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(len(cols.result))]
-    eval_field_op_polynomials(b, cols, p_ip, p_mod, cols.result, is_real)
+    eval_field_op_polynomials(b, cols, [], p_mod, cols.result, is_real, products=list(zip(a_list, b_list)))
 
 
 def eval_field_den(b, cols, a, bb, sign, modulus, is_real):                               # field_den.rs:L113-L150: result = a / (1 + bb) or a / (1 - bb)
-    lhs = _poly_add(_poly_mul(bb, cols.result), cols.result if sign else a)
     p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(len(cols.result))]
-    eval_field_op_polynomials(b, cols, lhs, p_mod, a if sign else cols.result, is_real)
+    eval_field_op_polynomials(b, cols, cols.result if sign else a, p_mod, a if sign else cols.result, is_real, products=[(bb, cols.result)])
 
 
 def ed_add_chip():                                                                        # edwards/ed_add.rs:L330-L470
