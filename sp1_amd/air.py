@@ -116,21 +116,21 @@ class AirProgram:
         self.instrs.append((HINT, 6 | (op_b_col << 8), mul_col))
 
     def hint_polynomial_identity(self, products, rest):
-        """The len(rest) asserts that follow are the coefficients of sum_t A_t(x) B_t(x) + R(x): assert k is sum over t and
-        i + j = k of A_t[i] B_t[j], plus rest[k] — `FieldOpCols`' vanishing polynomial (operations/field/util_air.rs:L6-L27), whose
-        63 coefficients are ~2,000 byte products. products: [(A, B)] lists of values (Expr), rest: values; every one of them affine
-        in the main columns (a prover checks that, and the identity on a pseudo-random row, before it believes the hint). With
-        consecutive alpha powers on consecutive coefficients the batched sum is w_0 (sum_t A_t(1/alpha) B_t(1/alpha) + R(1/alpha)):
-        three linear forms over the row instead of a convolution (sp1_amd/csrc/zerocheck.hip, zc_poly_kernel).
-        Pseudo-instructions: [16, 7 | terms << 8, len(rest)], then [16, 8 | code << 8, value] with code = 2 t for A_t's coefficients,
-        2 t + 1 for B_t's, 255 for the rest's, lowest coefficient first."""
-        assert len(products) < 120 and all(len(a) + len(bb) - 1 <= len(rest) for a, bb in products)
+        """The len(rest) asserts that follow are the coefficients of sum_t F_t0(x) F_t1(x) [F_t2(x)] + R(x): assert k is the sum over
+        t of the k-th coefficient of the product of term t's two or three polynomials, plus rest[k] — `FieldOpCols`' vanishing
+        polynomial (operations/field/util_air.rs:L6-L27), whose 63 coefficients are ~2,000 byte products; a one-coefficient factor
+        is a selector (`eval_variable`'s is_add / is_sub / is_mul, field_op.rs:L367-L401). products: [(F0, F1) | (F0, F1, F2)] lists
+        of values (Expr), rest: values; every one of them affine in the main columns (a prover checks that, and the identity on a
+        pseudo-random row, before it believes the hint). With consecutive alpha powers on consecutive coefficients the batched sum is
+        w_0 (sum_t prod_f F_tf(1/alpha) + R(1/alpha)): affine forms over the row instead of convolutions (sp1_amd/csrc/zc_poly.hpp).
+        Pseudo-instructions: [16, 7 | terms << 8, len(rest)], then [16, 8 | code << 8, value] with code = 3 t + f for the
+        coefficients of factor f of term t, 255 for the rest's, lowest coefficient first."""
+        assert len(products) < 80 and all(2 <= len(fs) <= 3 and sum(len(f) - 1 for f in fs) + 1 <= len(rest) for fs in products)
         self.instrs.append((HINT, 7 | (len(products) << 8), len(rest)))
-        for t, (a, bb) in enumerate(products):
-            for e in a:
-                self.instrs.append((HINT, 8 | ((2 * t) << 8), e.idx))
-            for e in bb:
-                self.instrs.append((HINT, 8 | ((2 * t + 1) << 8), e.idx))
+        for t, fs in enumerate(products):
+            for f, poly in enumerate(fs):
+                for e in poly:
+                    self.instrs.append((HINT, 8 | ((3 * t + f) << 8), e.idx))
         for e in rest:
             self.instrs.append((HINT, 8 | (255 << 8), e.idx))
 

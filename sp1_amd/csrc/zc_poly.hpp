@@ -16,7 +16,8 @@
 // sum_t sum_{i + j = k} A_t[i] B_t[j] + R[k]". The planner extracts the affine form of every named value from the caller's SSA
 // (a value that is not affine in the main columns drops the hint: the interpreter keeps those constraints) and checks the
 // identity on a pseudo-random row like every other hint. Sums of several products (FieldInnerProductCols, a modulus read from
-// memory) are terms t = 0, 1, ...
+// memory) are terms t = 0, 1, ...; a term may have a third factor — `eval_variable`'s selectors (is_add, is_sub, is_mul) are
+// one-coefficient polynomials, and the product of three polynomials collapses to the product of three affine forms the same way.
 //
 // Because the three forms are affine, their values at the nodes t = 0, 2, 4 of a row pair (and at the twelve nodes of a row quad in
 // the bivariate rounds) follow from their values on the rows themselves: one workgroup loads every column of a row pair ONCE and
@@ -32,17 +33,17 @@
 namespace sp1hip {
 
 constexpr uint32_t ZC_HINT_POLY = 7, ZC_HINT_POLY_ARG = 8;
-constexpr uint32_t ZC_POLY_MAX_TERMS = 6;
-// device table of one identity (words): header [n_terms, n_rest, n_owned, 0, nA_0, nB_0, nA_1, nB_1, ...] (16 words), then segments of
-// 8-word entries [column, 0, 0, 0, coefficient (4 words)]: per term the A segment (its constant first, column = ZC_POLY_ONE), the B
-// segment (constant first), then the rest (constant first), then the rest's owned columns (their GKR batching term rides along)
-constexpr uint32_t ZC_POLY_HDR = 16, ZC_POLY_ENTRY = 8, ZC_POLY_ONE = 0xffffffffu;
+constexpr uint32_t ZC_POLY_MAX_TERMS = 4;
+// device table of one identity (words): header [n_terms, n_rest, n_owned, 0, then per term n_0, n_1, n_2 (ZC_POLY_NONE: two factors)]
+// (16 words), then segments of 8-word entries [column, 0, 0, 0, coefficient (4 words)]: per term one segment per factor (its constant
+// first, column = ZC_POLY_ONE), then the rest (constant first), then the rest's owned columns (their GKR batching term rides along)
+constexpr uint32_t ZC_POLY_HDR = 16, ZC_POLY_ENTRY = 8, ZC_POLY_ONE = 0xffffffffu, ZC_POLY_NONE = 0xffffffffu;
 
 struct ZcLinForm {                                       // sum coefs[k] * main[cols[k]] + c0 (Montgomery words)
     std::vector<uint32_t> cols, coefs;
     uint32_t c0 = 0;
 };
-struct ZcPolyTerm { std::vector<ZcLinForm> a, b; };
+struct ZcPolyTerm { std::vector<ZcLinForm> f[3]; };      // two or three factors (f[2] empty: two)
 struct ZcPoly {
     uint32_t first_constraint = 0, n_c = 0;
     std::vector<ZcPolyTerm> terms;
@@ -121,11 +122,13 @@ inline void zc_poly_eval_row(const ZcPoly& p, const uint32_t* main_row, Sink&& s
     std::vector<uint32_t> v(p.n_c, 0u);
     for (uint32_t k = 0; k < p.n_c; k++) v[k] = zc_lin_eval(p.rest[k], main_row);
     for (const ZcPolyTerm& t : p.terms) {
-        std::vector<uint32_t> av(t.a.size()), bv(t.b.size());
-        for (size_t i = 0; i < t.a.size(); i++) av[i] = zc_lin_eval(t.a[i], main_row);
-        for (size_t j = 0; j < t.b.size(); j++) bv[j] = zc_lin_eval(t.b[j], main_row);
-        for (size_t i = 0; i < av.size(); i++)
-            for (size_t j = 0; j < bv.size(); j++) v[i + j] = kb::add(v[i + j], kb::mul(av[i], bv[j]));
+        std::vector<uint32_t> fv[3];
+        for (int f = 0; f < 3; f++) for (const ZcLinForm& lf : t.f[f]) fv[f].push_back(zc_lin_eval(lf, main_row));
+        if (fv[2].empty()) fv[2].push_back(kb::to_monty(1u));
+        for (size_t i = 0; i < fv[0].size(); i++)
+            for (size_t j = 0; j < fv[1].size(); j++)
+                for (size_t l = 0; l < fv[2].size(); l++)
+                    v[i + j + l] = kb::add(v[i + j + l], kb::mul(kb::mul(fv[0][i], fv[1][j]), fv[2][l]));
     }
     for (uint32_t k = 0; k < p.n_c; k++) sink(k, v[k]);
 }
@@ -159,10 +162,11 @@ inline ZcPolySeg zc_poly_seg(const std::vector<ZcLinForm>& forms, const std::vec
     }
     return sg;
 }
-// (the segments of an identity, in table order: per term A then B, the rest, the rest's owned columns)
+// (the segments of an identity, in table order: per term its three factors — an absent third one is an empty segment —, the rest,
+// the rest's owned columns)
 inline std::vector<ZcPolySeg> zc_poly_segments(const ZcPoly& p) {
     std::vector<ZcPolySeg> out;
-    for (const ZcPolyTerm& t : p.terms) { out.push_back(zc_poly_seg(t.a, p.owned, false, false)); out.push_back(zc_poly_seg(t.b, p.owned, false, false)); }
+    for (const ZcPolyTerm& t : p.terms) for (int f = 0; f < 3; f++) out.push_back(zc_poly_seg(t.f[f], p.owned, false, false));
     out.push_back(zc_poly_seg(p.rest, p.owned, true, false));
     out.push_back(zc_poly_seg(p.rest, p.owned, false, true));
     return out;
@@ -181,16 +185,17 @@ inline void zc_poly_table(const ZcPoly& p, const std::vector<ZcPolySeg>& segs, c
     (*blob)[hdr + 0] = (uint32_t)p.terms.size();
     for (size_t si = 0; si < segs.size(); si++) {
         const ZcPolySeg& sg = segs[si];
-        const bool is_b = si < 2 * p.terms.size() && (si & 1u);
-        const kb::Ext* weight = is_b ? rp.data() : w;
+        const bool in_term = si < 3 * p.terms.size();
+        if (in_term && si % 3 == 2 && p.terms[si / 3].f[2].empty()) { (*blob)[hdr + 4 + si] = ZC_POLY_NONE; continue; }
+        const kb::Ext* weight = in_term && si % 3 != 0 ? rp.data() : w;               // (the first factor carries the batching powers)
         acc.assign(sg.cols.size() + 1, kb::ext_zero());
         for (const ZcPolySeg::E& e : sg.ent) acc[e.slot] = kb::ext_add(acc[e.slot], kb::ext_mul_base(weight[e.i], e.coef));
         auto push = [&](uint32_t col, const kb::Ext& c) { const uint32_t wds[8] = {col, 0u, 0u, 0u, c.c[0], c.c[1], c.c[2], c.c[3]}; blob->insert(blob->end(), wds, wds + 8); };
         if (sg.with_const) push(ZC_POLY_ONE, acc[0]);
         for (size_t k = 0; k < sg.cols.size(); k++) push(sg.cols[k], acc[k + 1]);
         const uint32_t n = (uint32_t)sg.cols.size();                                  // (counts exclude the constant entry)
-        if (si < 2 * p.terms.size()) (*blob)[hdr + 4 + si] = n;
-        else (*blob)[hdr + 1 + (si - 2 * p.terms.size())] = n;
+        if (in_term) (*blob)[hdr + 4 + si] = n;
+        else (*blob)[hdr + 1 + (si - 3 * p.terms.size())] = n;
     }
 }
 

@@ -725,15 +725,23 @@ __global__ __launch_bounds__(256) void zc_poly_kernel(const ZcDesc* __restrict__
         kb::Ext v0 = kb::ext_zero(), v2 = kb::ext_zero(), v4 = kb::ext_zero();      // eq * C at the three nodes
         for (uint32_t t = 0; t < n_terms; t++) {
             kb::Ext a0, a1, b0, b1;
-            form(tab.word(4 + 2 * t), a0, a1);
-            form(tab.word(5 + 2 * t), b0, b1);
+            form(tab.word(4 + 3 * t), a0, a1);
+            form(tab.word(5 + 3 * t), b0, b1);
             a0 = kb::ext_mul(a0, e); a1 = kb::ext_mul(a1, e);
             const kb::Ext da = kb::ext_sub(a1, a0), db = kb::ext_sub(b1, b0);
             const kb::Ext da2 = kb::ext_add(da, da), db2 = kb::ext_add(db, db);
             const kb::Ext a2 = kb::ext_add(a0, da2), b2 = kb::ext_add(b0, db2);
-            if (!FIRST) v0 = kb::ext_add(v0, kb::ext_mul(a0, b0));
-            v2 = kb::ext_add(v2, kb::ext_mul(a2, b2));
-            v4 = kb::ext_add(v4, kb::ext_mul(kb::ext_add(a2, da2), kb::ext_add(b2, db2)));
+            kb::Ext p0 = FIRST ? kb::ext_zero() : kb::ext_mul(a0, b0), p2 = kb::ext_mul(a2, b2), p4 = kb::ext_mul(kb::ext_add(a2, da2), kb::ext_add(b2, db2));
+            const uint32_t n2 = tab.word(6 + 3 * t);
+            if (n2 != ZC_POLY_NONE) {                                               // (wave-uniform)
+                kb::Ext c0, c1;
+                form(n2, c0, c1);
+                const kb::Ext dc = kb::ext_sub(c1, c0), dc2 = kb::ext_add(dc, dc), c2 = kb::ext_add(c0, dc2);
+                if (!FIRST) p0 = kb::ext_mul(p0, c0);
+                p2 = kb::ext_mul(p2, c2);
+                p4 = kb::ext_mul(p4, kb::ext_add(c2, dc2));
+            }
+            v0 = kb::ext_add(v0, p0); v2 = kb::ext_add(v2, p2); v4 = kb::ext_add(v4, p4);
         }
         kb::Ext r0, r1, g0 = kb::ext_zero(), g1 = kb::ext_zero();
         form(n_rest, r0, r1);
@@ -827,15 +835,27 @@ __global__ __launch_bounds__(256) void zc_biv_poly_kernel(const ZcDesc* __restri
         };
         for (uint32_t t = 0; t < n_terms; t++) {
             kb::Ext a[4], b[4];
-            form(tab.word(4 + 2 * t), a);
-            form(tab.word(5 + 2 * t), b);
+            form(tab.word(4 + 3 * t), a);
+            form(tab.word(5 + 3 * t), b);
 #pragma unroll
             for (int k = 0; k < 4; k++) a[k] = kb::ext_mul(a[k], e);
             slopes(a); slopes(b);
+            const uint32_t n2 = tab.word(6 + 3 * t);
+            if (n2 == ZC_POLY_NONE) {                                               // (wave-uniform)
 #pragma unroll
-            for (int n = 0; n < ZC_BIV_NODES; n++) {
-                const ZcBivNode nd = zc_biv_node(n);
-                sa[n] = kb::ext_add(sa[n], kb::ext_mul(at(a, nd), at(b, nd)));
+                for (int n = 0; n < ZC_BIV_NODES; n++) {
+                    const ZcBivNode nd = zc_biv_node(n);
+                    sa[n] = kb::ext_add(sa[n], kb::ext_mul(at(a, nd), at(b, nd)));
+                }
+            } else {
+                kb::Ext c[4];
+                form(n2, c);
+                slopes(c);
+#pragma unroll
+                for (int n = 0; n < ZC_BIV_NODES; n++) {
+                    const ZcBivNode nd = zc_biv_node(n);
+                    sa[n] = kb::ext_add(sa[n], kb::ext_mul(kb::ext_mul(at(a, nd), at(b, nd)), at(c, nd)));
+                }
             }
         }
         kb::Ext rr[4];
@@ -1860,16 +1880,17 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                     // a polynomial identity (zc_poly.hpp): the values it names follow as ARG pseudo-instructions. Its forms are taken
                     // from the SSA; values that are not affine in the main columns drop the hint (the interpreter keeps the constraints)
                     const uint32_t n_terms = w1, n_c = w2;
-                    SP1HIP_REQUIRE(n_terms <= ZC_POLY_MAX_TERMS * 20 && n_c >= 1 && n_c < (1u << 16), "polynomial-identity hint: bad header");
-                    std::vector<std::vector<uint32_t>> ids(2 * (size_t)n_terms + 1);
+                    SP1HIP_REQUIRE(n_terms <= 80 && n_c >= 1 && n_c < (1u << 16), "polynomial-identity hint: bad header");
+                    std::vector<std::vector<uint32_t>> ids(3 * (size_t)n_terms + 1);
                     uint32_t j = k + 1;
                     for (; j < n_instr && clean[3 * j] == ZC_HINT && (clean[3 * j + 1] & 0xffu) == ZC_HINT_POLY_ARG; j++) {
                         const uint32_t code = clean[3 * j + 1] >> 8, id = clean[3 * j + 2];
-                        SP1HIP_REQUIRE((code == 255u || code < 2 * n_terms) && id < k, "polynomial-identity hint: bad argument");
-                        ids[code == 255u ? 2 * (size_t)n_terms : code].push_back(id);
+                        SP1HIP_REQUIRE((code == 255u || code < 3 * n_terms) && id < k, "polynomial-identity hint: bad argument");
+                        ids[code == 255u ? 3 * (size_t)n_terms : code].push_back(id);
                     }
                     bool shape = ids.back().size() == n_c;
-                    for (uint32_t t = 0; t < n_terms; t++) shape &= !ids[2 * t].empty() && !ids[2 * t + 1].empty() && ids[2 * t].size() + ids[2 * t + 1].size() - 1 <= n_c;
+                    for (uint32_t t = 0; t < n_terms; t++)
+                        shape &= !ids[3 * t].empty() && !ids[3 * t + 1].empty() && ids[3 * t].size() + ids[3 * t + 1].size() + std::max<size_t>(ids[3 * t + 2].size(), 1) - 2 <= n_c;
                     SP1HIP_REQUIRE(shape, "polynomial-identity hint: operand counts do not match the number of constraints");
                     for (uint32_t q = k; q < j; q++) { clean[3 * q] = ZC_CONST; clean[3 * q + 1] = 0; clean[3 * q + 2] = 0; }
                     ZcPoly poly;
@@ -1882,10 +1903,11 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
                     if (affine) {
                         size_t at = 0;
                         poly.terms.resize(n_terms);
-                        for (uint32_t t = 0; t < n_terms; t++) {
-                            poly.terms[t].a.assign(forms.begin() + at, forms.begin() + at + ids[2 * t].size()); at += ids[2 * t].size();
-                            poly.terms[t].b.assign(forms.begin() + at, forms.begin() + at + ids[2 * t + 1].size()); at += ids[2 * t + 1].size();
-                        }
+                        for (uint32_t t = 0; t < n_terms; t++)
+                            for (int f = 0; f < 3; f++) {
+                                poly.terms[t].f[f].assign(forms.begin() + at, forms.begin() + at + ids[3 * t + f].size());
+                                at += ids[3 * t + f].size();
+                            }
                         poly.rest.assign(forms.begin() + at, forms.end());
                         ZcMacro m{kind, 0u, asserts_before};
                         m.aux0 = (uint32_t)np->polys.size(); m.n_c = n_c;
@@ -1956,7 +1978,7 @@ static int zc_get_plan(const uint32_t* program, uint32_t n_instr, uint32_t main_
             for (size_t pi = 0; pi < np->polys.size(); pi++) {
                 const ZcPoly& pl = np->polys[pi];
                 auto mark = [&](const ZcLinForm& f, bool prod) { for (uint32_t c : f.cols) if (c < main_width) { in_any[pi][c] = 1; if (prod) in_prod[pi][c] = 1; } };
-                for (const ZcPolyTerm& t : pl.terms) { for (auto& f : t.a) mark(f, true); for (auto& f : t.b) mark(f, true); }
+                for (const ZcPolyTerm& t : pl.terms) for (int f = 0; f < 3; f++) for (auto& lf : t.f[f]) mark(lf, true);
                 for (auto& f : pl.rest) mark(f, false);
                 for (uint32_t c = 0; c < main_width; c++) users[c] += in_any[pi][c];
             }

@@ -760,8 +760,9 @@ MEM_ACCESS_U8 = S(("memory_access", MEM_ACCESS), ("prev_value_u8", U16_TO_U8))  
 
 def eval_field_op_polynomials(b, cols, p_op, p_modulus, p_result, is_real, witness_offset=WITNESS_OFFSET, products=None):   # field_op.rs eval_with_polynomials + util_air.rs
     """The coefficients of p_op - p_result - carry * modulus - (witness - offset) * (x - 2^8) are zero. `products`: p_op is
-    `p_op` + sum of A(x) B(x) over the (A, B) given — the same polynomial, with its products named so that the constraint program
-    can carry a hint for provers (AirProgram.hint_polynomial_identity) when everything else is affine in the row."""
+    `p_op` + the sum over the terms given of the product of a term's two or three polynomials — the same polynomial, with its
+    products named so that the constraint program can carry a hint for provers (AirProgram.hint_polynomial_identity) when every
+    factor and everything else is affine in the row. p_modulus None: carry * modulus is among the terms (a modulus from memory)."""
     witness = [w - witness_offset for w in cols.witness]
     rhs = _poly_mul(witness, [-(1 << 8), 1])
     if products is None:
@@ -769,23 +770,21 @@ def eval_field_op_polynomials(b, cols, p_op, p_modulus, p_result, is_real, witne
         for cst in _poly_sub(p_vanishing, rhs):
             b.assert_zero(cst)
     else:
-        products = list(products)
-        if all(isinstance(m, int) or m.is_const for m in p_modulus):
-            carry_mod = _poly_mul(cols.carry, p_modulus)
-        else:                                                                             # a modulus read from memory: one more product
-            carry_mod = []
-            products.append(([-c for c in cols.carry], list(p_modulus)))
+        sym = lambda v: v if isinstance(v, Sym) else b.const(v)
+        products = [tuple([sym(v) for v in f] for f in fs) for fs in products]
+        products = [fs for fs in products if not any(all(v.is_const and v.const_value == 0 for v in f) for f in fs)]   # (a selector that is the constant 0)
+        carry_mod = _poly_mul(cols.carry, p_modulus) if p_modulus is not None else []
         rest = _poly_sub(_poly_sub(_poly_sub(p_op, p_result), carry_mod), rhs)
         conv = []
-        for pa, pb in products:
-            conv = _poly_add(conv, _poly_mul(pa, pb))
-        rest = rest + [0] * (len(conv) - len(rest))
-        sym = lambda v: v if isinstance(v, Sym) else b.const(v)
-        rest = [sym(v) for v in rest]
-        products = [([sym(v) for v in pa], [sym(v) for v in pb]) for pa, pb in products]
+        for fs in products:
+            term = fs[0]
+            for f in fs[1:]:
+                term = _poly_mul(term, f)
+            conv = _poly_add(conv, term)
+        rest = [sym(v) for v in rest + [0] * (len(conv) - len(rest))]
         main_affine = lambda v: v.lin is not None and all(kind == "main" for kind, _ in v.lin[0])
-        if isinstance(b, Builder) and all(main_affine(v) for pa, pb in products for v in pa + pb) and all(main_affine(v) for v in rest):
-            b.air.hint_polynomial_identity([([v.expr() for v in pa], [v.expr() for v in pb]) for pa, pb in products], [v.expr() for v in rest])
+        if isinstance(b, Builder) and len(products) <= 4 and all(main_affine(v) for fs in products for f in fs for v in f) and all(main_affine(v) for v in rest):
+            b.air.hint_polynomial_identity([tuple([v.expr() for v in f] for f in fs) for fs in products], [v.expr() for v in rest])
         for k, v in enumerate(rest):
             b.assert_zero(conv[k] + v if k < len(conv) else v)
     slice_range_check_u8(b, cols.result, is_real)
@@ -840,8 +839,10 @@ def uint256_mul_chip():                                                         
         byte_sum = byte_sum + v
     eval_is_zero(b, byte_sum, L.modulus_is_zero, L.is_real)
     mz = L.modulus_is_zero.result
-    p_modulus = _poly_add(_poly_scale(m_limbs, 1 - mz), [0] * 32 + [mz])                   # the modulus, or 2^256 when it is zero
-    eval_field_op_polynomials(b, L.output, [], p_modulus, L.output.result, L.is_real, products=[(x_limbs, y_limbs)])
+    # carry * (the modulus, or 2^256 when it is zero) = carry * (1 - mz) * m(x) + carry * mz x^32
+    neg_carry = [-v for v in L.output.carry]
+    eval_field_op_polynomials(b, L.output, [], None, L.output.result, L.is_real,
+                              products=[(x_limbs, y_limbs), (neg_carry, [1 - mz], m_limbs), (neg_carry, [0] * 32 + [mz])])
     eval_field_lt(b, L.output_range_check, L.output.result, m_limbs, L.modulus_is_not_zero)
     b.assert_eq(L.modulus_is_not_zero, L.is_real * (1 - mz))
     result_words = limbs_to_words(L.output.result)
@@ -1003,10 +1004,12 @@ def _binary_memory(b, L, words, length):
 
 
 def eval_field_op_variable(b, cols, a, bb, modulus, is_add, is_sub, is_mul, is_real, witness_offset):   # FieldOpCols::eval_variable (field_op.rs:L367-L401, is_div = 0)
+    """p_op - p_result with p_op = is_add (a + b) + is_sub (result + b) + is_mul (a b) and p_result = (is_add + is_mul) result +
+    is_sub a, selector by selector: is_add (a + b - result) + is_sub (result + b - a) + is_mul (a b) - is_mul result."""
     p_mod = [(modulus >> (8 * i)) & 0xFF for i in range(len(cols.result))]
-    p_result = _poly_add(_poly_scale(cols.result, is_add + is_mul), _poly_scale(a, is_sub))
-    p_op = _poly_add(_poly_add(_poly_scale(_poly_add(a, bb), is_add), _poly_scale(_poly_add(cols.result, bb), is_sub)), _poly_scale(_poly_mul(a, bb), is_mul))
-    eval_field_op_polynomials(b, cols, p_op, p_mod, p_result, is_real, witness_offset)
+    res = cols.result
+    terms = [([is_add], _poly_sub(_poly_add(a, bb), res)), ([is_sub], _poly_sub(_poly_add(res, bb), a)), ([is_mul], a, bb), ([is_mul], [-v for v in res])]
+    eval_field_op_polynomials(b, cols, [], p_mod, [], is_real, witness_offset, products=terms)
 
 
 def fp_op_chip(field):                                                                    # fptower/fp.rs:L292-L461
@@ -1221,8 +1224,8 @@ def uint256_ops_chip():                                                         
             acc = getattr(L, k + "_memory")[i].memory_access
             eval_memory_access(b, L.clk_high, L.clk_low + at, getattr(L, k + "_addrs")[i].value, acc, acc.prev_value, r)
     a_l, b_l, c_l = (generate_limbs(b, getattr(L, k + "_memory"), r) for k in "abc")
-    p_op = _poly_add(_poly_add(_poly_scale(_poly_add(a_l, b_l), L.is_add), _poly_scale(_poly_mul(a_l, b_l), L.is_mul)), c_l)   # eval_add_mul_and_carry
-    eval_field_op_polynomials(b, L.field_op, p_op, [0] * 32 + [1], L.field_op.result, r)
+    # eval_add_mul_and_carry: p_op = is_add (a + b) + is_mul (a b) + c
+    eval_field_op_polynomials(b, L.field_op, c_l, [0] * 32 + [1], L.field_op.result, r, products=[([L.is_add], _poly_add(a_l, b_l)), ([L.is_mul], a_l, b_l)])
     for at, k, limbs in ((3, "d", L.field_op.result), (4, "e", L.field_op.carry)):
         words = limbs_to_words(limbs)
         for i in range(4):
