@@ -176,6 +176,7 @@ def main():
                 row["first_proof_of_kind_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
                 warmed[kind] = first
             api.check(lib.sp1hip_timers_reset())
+            torch.cuda.synchronize()                                                      # (the tracer's layout kernels are not the prover's time)
             t0 = time.perf_counter()
             proof = pk.prove_shard(chips, pv)                                             # from the transcript head vk.observe_into leaves
             torch.cuda.synchronize()

@@ -66,6 +66,7 @@ inline hipStream_t S(sp1hip_stream_t s) { return static_cast<hipStream_t>(s); }
 int arena_alloc(void** ptr, size_t bytes, hipStream_t stream);
 void arena_free(void* ptr, size_t bytes, hipStream_t stream);
 size_t arena_trim();
+void arena_miss_stats(uint64_t* n, uint64_t* bytes);   // requests that went to hipMalloc since the process started
 size_t arena_release_stream(hipStream_t stream);      // blocks cached for a stream that is going away
 
 // Optional event bracketing of a kernel launch (see sp1hip_timers_* in include/sp1hip.h).

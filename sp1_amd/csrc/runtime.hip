@@ -330,6 +330,9 @@ static size_t arena_cap_bytes(int dev) {
 }
 
 size_t arena_trim_device(int dev);
+// requests no cached block served (each one is a hipMalloc: a driver call that may synchronise the device) — SP1HIP_SHARD_TIMING prints them
+static std::atomic<uint64_t> g_arena_misses{0}, g_arena_miss_bytes{0};
+void arena_miss_stats(uint64_t* n, uint64_t* bytes) { *n = g_arena_misses.load(); *bytes = g_arena_miss_bytes.load(); }
 int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
     int dev = 0;
     SP1HIP_HIP(hipGetDevice(&dev));
@@ -356,6 +359,8 @@ int arena_alloc(void** ptr, size_t bytes, hipStream_t stream) {
                     return SP1HIP_SUCCESS;
                 }
     }
+    g_arena_misses.fetch_add(1, std::memory_order_relaxed);
+    g_arena_miss_bytes.fetch_add(sz, std::memory_order_relaxed);
     hipError_t e = hipMalloc(ptr, sz);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();

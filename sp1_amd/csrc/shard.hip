@@ -52,6 +52,9 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     SP1HIP_REQUIRE(chips && n_chips > 0 && preprocessed && challenger && proof_len, "bad argument");
     SP1HIP_REQUIRE(h_publics || n_publics == 0, "null public values");
     ActiveProver active;                                     // (counted for the zerocheck's fork-stream decision: common.hpp)
+    const auto sh_entry = std::chrono::steady_clock::now();
+    uint64_t miss_n0 = 0, miss_b0 = 0;
+    arena_miss_stats(&miss_n0, &miss_b0);
     const int L = params.max_log_row_count, lsh = params.log_stacking_height;
     SP1HIP_REQUIRE(preprocessed->jagged && preprocessed->max_log_row_count == L && preprocessed->log_stacking_height == lsh,
                    "the preprocessed round was committed with different parameters");
@@ -272,8 +275,11 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
     if (sh_timing) {
         sh_t[5] = std::chrono::steady_clock::now();
         const auto ms = [&](int a, int b) { return std::chrono::duration<double, std::milli>(sh_t[b] - sh_t[a]).count(); };
-        fprintf(stderr, "[sp1hip shard] commit %.3f ms | LogUp-GKR %.3f | zerocheck %.3f | evaluation proof %.3f | proof bytes %.3f\n", ms(0, 1), ms(1, 2),
-                ms(2, 3), ms(3, 4), ms(4, 5));
+        uint64_t miss_n1 = 0, miss_b1 = 0;
+        arena_miss_stats(&miss_n1, &miss_b1);
+        fprintf(stderr, "[sp1hip shard] prologue %.3f ms | commit %.3f | LogUp-GKR %.3f | zerocheck %.3f | evaluation proof %.3f | proof bytes %.3f | %llu arena misses (%.1f MB)\n",
+                std::chrono::duration<double, std::milli>(sh_t[0] - sh_entry).count(), ms(0, 1), ms(1, 2), ms(2, 3), ms(3, 4), ms(4, 5),
+                (unsigned long long)(miss_n1 - miss_n0), (double)(miss_b1 - miss_b0) / 1e6);
     }
     wait_plan.ok = true;
     return SP1HIP_SUCCESS;
