@@ -119,7 +119,7 @@ def main():
                 continue
             if pk is None:                                       # the program's proving key from the first shard's preprocessed tables
                 pk_prep = {a.name: to_col_major(tabs[a.name][0]) for a, _ in machine if tabs[a.name][0] is not None}
-                vk_words = RT.to_monty_np(torch.tensor(PVM.addr_limbs(sh.pc_start) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[0]) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[1])))
+                vk_words = RT.to_monty_np(torch.tensor(X.verifying_key_words(ex, sh.pc_start, "cuda")))
                 pk = api.ProvingKey([pk_prep[nm] for nm in sorted(pk_prep)], L, lsh, 32, pc_start=vk_words[:3], initial_global_cumulative_sum=vk_words[3:])
             if k != kind:
                 continue

@@ -51,9 +51,11 @@ def program_run(api, program="fibonacci", cycles=26_000_000, L=22, lsh=21):
         area = sum(int(tabs[a.name][1].shape[0]) * (a.main_width + a.prep_width) for a, _ in machine)
         setup_s = 0.0
         if pk is None:
+            vk_ints = X.verifying_key_words(ex, sh.pc_start, "cuda")     # entry point + the digest of the memory image's initialisation
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             pk_prep = {a.name: to_col_major(tabs[a.name][0]) for a, _ in machine if tabs[a.name][0] is not None}
-            vk_words = RT.to_monty_np(torch.tensor(PVM.addr_limbs(sh.pc_start) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[0]) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[1])))
+            vk_words = RT.to_monty_np(torch.tensor(vk_ints))
             pk = api.ProvingKey([pk_prep[n] for n in sorted(pk_prep)], L, lsh, 32, pc_start=vk_words[:3], initial_global_cumulative_sum=vk_words[3:])
             torch.cuda.synchronize()
             setup_s = time.perf_counter() - t0
@@ -79,7 +81,7 @@ def program_run(api, program="fibonacci", cycles=26_000_000, L=22, lsh=21):
     prove_s = sum(r["prove_ms"] for r in rows) / 1e3
     setup_s = sum(r["setup_ms"] for r in rows) / 1e3
     build_s = sum(r["build_s"] for r in rows)
-    chain = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds)], entry)
+    chain = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds)], entry, vk_ints[3:])
     head = api.DuplexChallenger()
     pk.observe_into(head)
     out = {"program": program, "cycles": n_cycles, "shards": len(rows), "kinds": {k: kinds.count(k) for k in dict.fromkeys(kinds)},
@@ -154,11 +156,13 @@ def main():
             # every shard of the run — core, precompile, memory — is a shape cluster that holds those three chips
             row["setup_ms"] = 0.0
             if pk is None:
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 pk_prep = {a.name: to_col_major(tabs[a.name][0]) for a, _ in machine if tabs[a.name][0] is not None}
+                vk_ints = X.verifying_key_words(ex, sh.pc_start, "cuda")
                 # the verifying key's words (Montgomery form, like everything the transcript absorbs): the entry pc, and the digest of
-                # the program's memory image — empty here: this executor initialises image words through MemoryGlobalInit rows
-                vk_words = RT.to_monty_np(torch.tensor(PVM.addr_limbs(sh.pc_start) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[0]) + list(PVM.R.CURVE_CUMULATIVE_SUM_START[1])))
+                # the memory image's initialisation (one septic point per image word: program.rs:L170-L199)
+                vk_words = RT.to_monty_np(torch.tensor(vk_ints))
                 pk = api.ProvingKey([pk_prep[n] for n in sorted(pk_prep)], L, lsh, 32, pc_start=vk_words[:3], initial_global_cumulative_sum=vk_words[3:])
                 torch.cuda.synchronize()
                 row["setup_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
@@ -214,13 +218,14 @@ def main():
     if args.core_shards:
         out["note"] = out_note
     if whole:
-        out["global_messages_cancel"] = not X.global_events_balance(gevs)
+        out["global_messages_cancel"] = not X.global_events_balance(gevs + [X.image_events(ex)])   # (the image's initialisation: the verifying key's digest)
         # what SP1Prover::verify checks across the shards before it verifies each: the public values chain from the entry point to
         # HALT (timestamps, pcs, exit codes, digests, address chains) and the shards' septic digests add up to zero
         kinds_seen = [s["kind"] for s in shards]
         first_core = next(i for i, k_ in enumerate(kinds_seen) if k_ == "core")
         entry = sum(v << (16 * j) for j, v in enumerate(PVM.get(pvs[first_core], "pc_start")))
-        out["public_values_chain"] = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds_seen)], entry) or "ok"
+        vk_digest = vk_ints[3:] if not args.dry_run else X.verifying_key_words(ex, entry)[3:]
+        out["public_values_chain"] = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds_seen)], entry, vk_digest) or "ok"
     if not args.dry_run:
         prove_s = sum(s["prove_ms"] for s in shards) / 1e3
         out.update({"prove_seconds": round(prove_s, 4), "setup_seconds": round(sum(s["setup_ms"] for s in shards) / 1e3, 4),

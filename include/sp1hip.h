@@ -605,6 +605,12 @@ int sp1hip_rv64_precompile_events(sp1hip_rv64_vm_t vm, uint32_t family, uint64_t
  * pc_base + 4 i. */
 int sp1hip_rv64_program(sp1hip_rv64_vm_t vm, uint64_t* pc_base, uint64_t* n_instructions, const uint64_t** table);
 int sp1hip_rv64_global_memory(sp1hip_rv64_vm_t vm, uint64_t* n, const uint64_t** table);
+/* The program's memory image (`Program::memory_image`, /root/reference/crates/core/executor/src/disassembler/elf.rs:L320-L353):
+ * [n][2] u64 = (address, value) of every 8-byte word of the ELF's PT_LOAD segments, file bytes and zero fill alike, by ascending
+ * address. The reference initialises these words through the verifying key (`initial_global_cumulative_sum`,
+ * core/executor/src/program.rs:L170-L199: no MemoryGlobalInit row) and finalises every one of them, touched or not
+ * (prover/src/worker/controller/global.rs:L145-L300). */
+int sp1hip_rv64_memory_image(sp1hip_rv64_vm_t vm, uint64_t* n, const uint64_t** table);
 /* which = 0: the bytes written to the public-values descriptor; 1: stdout / stderr. */
 int sp1hip_rv64_output(sp1hip_rv64_vm_t vm, int which, const uint8_t** data, uint64_t* len);
 

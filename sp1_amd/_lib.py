@@ -224,6 +224,7 @@ PROTOTYPES = [
     ("sp1hip_rv64_precompile_events", None, [_vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_program", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_global_memory", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
+    ("sp1hip_rv64_memory_image", None, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64))]),
     ("sp1hip_rv64_output", None, [_vp, _int, C.POINTER(u8p), C.POINTER(C.c_uint64)]),
     ("sp1hip_setup", None, [C.POINTER(Table), _int, u32p, u32p, C.c_uint32, ShardParams, C.POINTER(_vp), _vp]),
     ("sp1hip_pk_free", "void", [_vp]),

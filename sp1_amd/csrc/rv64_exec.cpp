@@ -257,6 +257,7 @@ struct Vm {
     // the whole run
     std::vector<uint64_t> touched;                                     // [t][2]: addr, initial value (then final value, final ts)
     std::vector<uint64_t> global_out;
+    std::vector<uint64_t> image;                                       // [m][2]: addr, value of every word of the ELF's segments, ascending
     std::string error;
 
     ~Vm() { for (auto& kv : pages) delete kv.second; }
@@ -704,12 +705,15 @@ struct Vm {
                 if (input.empty()) return fail("hint input stream exhausted");
                 std::vector<uint8_t> v = std::move(input.front()); input.pop_front();
                 if (v.size() != c || !slice_ok(b, (int)std::min<uint64_t>(v.size() / 8 + 1, 1u << 30))) return fail("HINT_READ of %llu bytes at 0x%llx against an entry of %zu", (unsigned long long)c, (unsigned long long)b, v.size());
-                for (uint64_t i = 0; i <= v.size() / 8; ++i) {         // whole words, then the (possibly empty) tail word
+                for (uint64_t i = 0; i < (v.size() + 7) / 8; ++i) {    // whole words, then the tail word if there is one (minimal/postprocess.rs:L10-L36)
                     uint64_t w = 0;
                     for (uint64_t j = 0; j < 8 && 8 * i + j < v.size(); ++j) w |= (uint64_t)v[8 * i + j] << (8 * j);
                     Cell& m = cell(b + 8 * i);
                     if (m.ever || m.ts) return fail("hint written over touched memory at 0x%llx", (unsigned long long)(b + 8 * i));
                     m.val = w;
+                    // a hinted word is initialised (with the hinted value) and finalised whether or not the program reads it
+                    // (prover/src/worker/controller/global.rs:L133-L142: hint addresses join the touched set)
+                    m.ever = true; touched.insert(touched.end(), {b + 8 * i, w});
                 }
                 break;
             }
@@ -921,6 +925,7 @@ bool load_elf(Vm& vm, const uint8_t* p, size_t n) {
     if (phentsize != 56 || phoff > n || phnum > (n - phoff) / 56) return vm.fail("program header table outside the file");
     constexpr uint64_t MAX_SEGMENT = 1ull << 32;                       // 4 GiB per segment: far above any guest, far below an allocation bomb
     bool have_base = false;
+    std::vector<uint64_t> image_words;
     for (uint64_t i = 0; i < phnum; ++i) {
         const size_t ph = phoff + i * phentsize;
         if (rd(ph, 4) != 1) continue;                                  // PT_LOAD
@@ -932,12 +937,17 @@ bool load_elf(Vm& vm, const uint8_t* p, size_t n) {
         else if (exec && vaddr != vm.pc_base + 4 * vm.program.size()) return vm.fail("executable segments are not contiguous");
         for (uint64_t addr = vaddr; addr < vaddr + memsz; addr += 4) {
             uint64_t w = 0;
-            if (addr < vaddr + filesz) { const uint64_t m = filesz - (addr - vaddr); for (uint64_t j = 0; j < 4 && j < m; ++j) w |= (uint64_t)p[off + (addr - vaddr) + j] << (8 * j); }
             Cell& c = vm.cell(addr & ~7ull);
+            if (image_words.empty() || image_words.back() != (addr & ~7ull)) image_words.push_back(addr & ~7ull);
+            if (addr < vaddr + filesz) { const uint64_t m = filesz - (addr - vaddr); for (uint64_t j = 0; j < 4 && j < m; ++j) w |= (uint64_t)p[off + (addr - vaddr) + j] << (8 * j); }
+            else { c.val = 0; continue; }                              // zero fill REPLACES the word (elf.rs:L321-L324: `image.insert(addr - addr % 8, 0)`)
             c.val += w << (8 * (addr & 4));
             if (exec) { vm.words.push_back((uint32_t)w); vm.program.push_back(decode((uint32_t)w)); }
         }
     }
+    std::sort(image_words.begin(), image_words.end());
+    image_words.erase(std::unique(image_words.begin(), image_words.end()), image_words.end());
+    for (uint64_t a : image_words) { vm.image.push_back(a); vm.image.push_back(vm.cell(a).val); }
     if (!have_base || vm.program.empty()) return vm.fail("no executable segment");
     vm.pc_start = vm.pc = entry;
     return true;
@@ -1047,6 +1057,13 @@ int sp1hip_rv64_global_memory(sp1hip_rv64_vm_t h, uint64_t* n, const uint64_t** 
         vm.global_out.insert(vm.global_out.end(), {addr, vm.touched[i + 1], c.val, c.ts});
     }
     *n = vm.touched.size() / 2; *table = vm.global_out.data();
+    return SP1HIP_SUCCESS;
+}
+
+int sp1hip_rv64_memory_image(sp1hip_rv64_vm_t h, uint64_t* n, const uint64_t** table) {
+    if (!h || !n || !table) return SP1HIP_ERROR_INVALID_ARGUMENT;
+    const Vm& vm = *(Vm*)h;
+    *n = vm.image.size() / 2; *table = vm.image.data();
     return SP1HIP_SUCCESS;
 }
 

@@ -163,6 +163,12 @@ class Executor:
         _lib.check(self.lib.sp1hip_rv64_global_memory(self.h, C.byref(n), C.byref(tab)))
         return self._matrix(tab, n.value, 4)
 
+    def memory_image(self):
+        """[m, 2] int64: (address, value) of every 8-byte word of the ELF's segments, ascending (`Program::memory_image`)."""
+        n, tab = C.c_uint64(), C.POINTER(C.c_uint64)()
+        _lib.check(self.lib.sp1hip_rv64_memory_image(self.h, C.byref(n), C.byref(tab)))
+        return self._matrix(tab, n.value, 2)
+
     def output(self, which=0):
         p, n = _lib.u8p(), C.c_uint64()
         _lib.check(self.lib.sp1hip_rv64_output(self.h, which, C.byref(p), C.byref(n)))
@@ -501,20 +507,65 @@ def program_shards(executor, max_cycles, device="cpu", core_limit=None):
         for part in chunks(kind, families.get(kind)):
             machine, tables, publics, gev = MT.family_shard_from(kind, part, device, ctx=ctx)
             yield kind, machine, tables, publics, gev, None
+    # ---- the memory shards (prover/src/worker/controller/global.rs:L145-L300). Every touched address — registers with a timestamp,
+    # memory words, hinted words — is finalised, and so is every word of the program's memory image, touched or not; every touched
+    # address OUTSIDE the image is initialised (registers and fresh memory with 0, hinted words with their hint). The image's own
+    # initialisation is the verifying key's `initial_global_cumulative_sum` (image_events / verifying_key_words below). The two
+    # streams are merged by address and a shard is flushed when either buffer reaches the threshold: the finalise buffer, which
+    # grows at every step, fills first — chunks of `memory` finalise events with the initialise events of their address range.
     gm = executor.global_memory()
     gm = gm[np.argsort(gm[:, 0].astype(np.uint64))]
     if gm.shape[0] == 0 or gm[0, 0] != 0:                  # register x0 opens the address chain whether or not the program read it
         gm = np.concatenate([np.zeros((1, 4), dtype=np.int64), gm])
-    previous = 0
+    img = executor.memory_image()
+    t_addr, i_addr = gm[:, 0].astype(np.uint64), img[:, 0].astype(np.uint64)
+    outside = ~np.isin(t_addr, i_addr)
+    init_addr, init_rec = t_addr[outside], np.stack([gm[outside, 1], np.zeros(int(outside.sum()), dtype=np.int64)], axis=1)
+    untouched = ~np.isin(i_addr, t_addr)
+    fin_addr = np.concatenate([t_addr, i_addr[untouched]])
+    fin_rec = np.concatenate([gm[:, 2:4], np.stack([img[untouched, 1], np.zeros(int(untouched.sum()), dtype=np.int64)], axis=1)])
+    order = np.argsort(fin_addr, kind="stable")
+    fin_addr, fin_rec = fin_addr[order], fin_rec[order]
+    previous_init = previous_fin = 0
     # the memory shards stand in the program's final state (update_finalized_state, worker/prover/core.rs:L370-L397)
     ctx.final = (shard.clk_end, shard.next_pc, shard.exit_code, shard.committed_value_digest, shard.deferred_proofs_digest)
-    for at in range(0, gm.shape[0], limit["memory"]):       # `split` (record.rs): init and finalise events chunked alike, zipped
-        part = gm[at:at + limit["memory"]]
-        addrs = part[:, 0].astype(np.uint64)
-        machine, tables, publics, gev = MT.memory_shard_from(addrs, np.stack([part[:, 1], np.zeros_like(part[:, 1])], axis=1), part[:, 2:4],
-                                                             device, previous_addr=previous, ctx=ctx)
-        previous = int(addrs[-1])
+    for at in range(0, fin_addr.shape[0], limit["memory"]):
+        fa, fr = fin_addr[at:at + limit["memory"]], fin_rec[at:at + limit["memory"]]
+        lo, hi = np.searchsorted(init_addr, fa[0], side="left"), np.searchsorted(init_addr, fa[-1], side="right")
+        machine, tables, publics, gev = MT.memory_shard_from(init_addr[lo:hi], init_rec[lo:hi], fr, device, previous_addr=previous_init, ctx=ctx,
+                                                             fin_addrs=fa, previous_fin_addr=previous_fin)
+        previous_init = int(init_addr[hi - 1]) if hi > lo else previous_init
+        previous_fin = int(fa[-1])
         yield "memory", machine, tables, publics, gev, None
+
+
+def image_events(executor, device="cpu"):
+    """The Global events the verifying key stands for: one SEND per word of the program's memory image, in the form MemoryGlobalInit
+    would have sent it — [0, 0, address limbs, value limbs 0 / 1 with bytes 4 / 5 on top, value limb 3] at timestamp 0
+    (`initial_global_cumulative_sum`, core/executor/src/program.rs:L170-L199). [m, 11] like every shard's events: with them
+    appended, the events of a whole run cancel."""
+    img = executor.memory_image()
+    a, v = torch.as_tensor(img[:, 0], device=device), torch.as_tensor(img[:, 1], device=device)
+    lim = lambda x, k: (x >> (16 * k)) & 0xFFFF
+    cols = [torch.zeros_like(a), torch.zeros_like(a), lim(a, 0), lim(a, 1), lim(a, 2), lim(v, 0) + (((v >> 32) & 0xFF) << 16), lim(v, 1) + (((v >> 40) & 0xFF) << 16),
+            lim(v, 3), torch.ones_like(a), torch.zeros_like(a), torch.full_like(a, R.MEMORY)]
+    return torch.stack(cols, dim=1)
+
+
+def verifying_key_words(executor, pc_start, device="cpu"):
+    """What the transcript absorbs of the program besides the preprocessed commitment (`MachineVerifyingKey`: pc_start,
+    initial_global_cumulative_sum): the entry point's three 16-bit limbs, then the septic digest x[7], y[7] of the memory image's
+    initialisation — canonical integers. pc_start: the first shard's (the ELF's entry point)."""
+    from . import septic as SE
+    ev = image_events(executor, device)
+    start = tuple(torch.tensor(v, dtype=torch.int64, device=device) for v in R.CURVE_CUMULATIVE_SUM_START)
+    if ev.shape[0]:
+        x, y, _, _ = SE.lift_x(ev[:, :8], ev[:, 10], ev[:, 9] == 1)
+        cx, cy = SE.prefix_sums(start, x, y)
+        digest = [int(t) for t in cx[-1]] + [int(t) for t in cy[-1]]
+    else:
+        digest = [int(t) for t in start[0]] + [int(t) for t in start[1]]
+    return PVM.addr_limbs(pc_start) + digest
 
 
 def global_events_balance(event_lists):

@@ -52,4 +52,4 @@ def test_the_tower_edwards_and_carry_precompile_shards_match_the_oracle(api):
         if kind not in ("core", "memory"):                                   # those two kinds are test_gpu_riscv_exec.py's
             prove_both(api, machine, tabs, publics, 17, 12, 8, 1, 5, 4)
     assert seen == ["core", "bn254_fp", "bls12381_fp", "ed_decompress", "uint256_ops", "memory"]
-    assert not X.global_events_balance(gevs)
+    assert not X.global_events_balance(gevs + [X.image_events(ex)])

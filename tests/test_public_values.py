@@ -70,9 +70,11 @@ def test_program_counts_follow_the_reference_body():
     assert not any(op in (LOAD_MAIN, LOAD_PREP) for op, _, _ in air.instrs)
 
 
-def _fibonacci_shards(n=300, cycles=3000):
+def _fibonacci_shards(n=300, cycles=3000, with_key=False):
     ex = X.Executor(X.guest_file("fibonacci.elf"), stdin=[struct.pack("<Q", n)])
     out = list(X.program_shards(ex, cycles))
+    if with_key:                                               # + the verifying key's digest: the memory image's initialisation
+        return out, out[0][5].pc_start, X.verifying_key_words(ex, out[0][5].pc_start)[3:]
     return out, out[0][5].pc_start
 
 
@@ -152,25 +154,26 @@ def test_state_constraints_case_by_case():
 
 
 def test_the_chain_across_shards_is_the_reference_verify():
-    shards, entry = _fibonacci_shards()
+    shards, entry, vk_digest = _fibonacci_shards(with_key=True)
     kinds = [s[0] for s in shards]
     pvs = [[int(v) for v in s[3]] for s in shards]
     order = X.proof_order(kinds)
-    assert PVM.verify_proof_public_values([pvs[i] for i in order], entry) is None
-    assert "vk.pc_start" in PVM.verify_proof_public_values([pvs[i] for i in order], entry + 4)
-    assert "first execution shard is not set" == PVM.verify_proof_public_values([pvs[i] for i in order[1:]], entry)       # first shard missing
-    assert "invalid initial timestamp" == PVM.verify_proof_public_values([pvs[i] for i in [order[0]] + order[2:]], entry) # a middle shard missing
-    assert "execution should have halted" in PVM.verify_proof_public_values([pvs[i] for i in order[:-2]], entry)           # stops before HALT
-    assert "never initialized" in PVM.verify_proof_public_values([pvs[i] for i in order[:-1]], entry)                      # no memory shard
+    assert PVM.verify_proof_public_values([pvs[i] for i in order], entry, vk_digest) is None
+    assert PVM.verify_proof_public_values([pvs[i] for i in order], entry) == "global cumulative sum is not zero"     # without the key's digest
+    assert "vk.pc_start" in PVM.verify_proof_public_values([pvs[i] for i in order], entry + 4, vk_digest)
+    assert "first execution shard is not set" == PVM.verify_proof_public_values([pvs[i] for i in order[1:]], entry, vk_digest)       # first shard missing
+    assert "invalid initial timestamp" == PVM.verify_proof_public_values([pvs[i] for i in [order[0]] + order[2:]], entry, vk_digest) # a middle shard missing
+    assert "execution should have halted" in PVM.verify_proof_public_values([pvs[i] for i in order[:-2]], entry, vk_digest)           # stops before HALT
+    assert "never initialized" in PVM.verify_proof_public_values([pvs[i] for i in order[:-1]], entry, vk_digest)                      # no memory shard
     swapped = [pvs[i] for i in order]
     swapped[0], swapped[1] = swapped[1], swapped[0]
-    assert PVM.verify_proof_public_values(swapped, entry) is not None
+    assert PVM.verify_proof_public_values(swapped, entry, vk_digest) is not None
     for name, msg in (("global_cumulative_sum", "global cumulative sum is not zero"), ("prev_exit_code", "prev_exit_code"),
                       ("previous_finalize_addr", "previous_finalize_addr"), ("proof_nonce", "proof_nonce")):
         bad = [list(pvs[i]) for i in order]
         bad[1][PVM.PV[name]] = (bad[1][PVM.PV[name]] + 1) % MC.P
-        assert msg in PVM.verify_proof_public_values(bad, entry), name
-    assert "length" in PVM.verify_proof_public_values([pvs[i][:160] for i in order], entry)
+        assert msg in PVM.verify_proof_public_values(bad, entry, vk_digest), name
+    assert "length" in PVM.verify_proof_public_values([pvs[i][:160] for i in order], entry, vk_digest)
 
 
 def test_oracle_logup_gkr_verifier_public_values_leg():

@@ -53,12 +53,17 @@ def run_program(elf, stdin, max_cycles):
         if sh is not None:
             cycles, last = cycles + sh.cycles, sh
             entry = sh.pc_start if len(kinds) == 1 else entry
-    assert not X.global_events_balance(gevs)
+    # the Global events of all shards cancel against the initialisation of the program's memory image: the part of the bus the
+    # verifying key stands for (vk.initial_global_cumulative_sum), not a shard
+    assert not X.global_events_balance(gevs + [X.image_events(ex)])
+    assert X.global_events_balance(gevs)
     # what `SP1Prover::verify` checks across the shards of a core proof before it verifies each of them: the public values chain
     # (timestamps, pcs, exit codes, digests, address chains) from the entry point to HALT and the shards' septic digests add up to zero
-    err = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds)], entry)
+    vk = X.verifying_key_words(ex, entry)
+    err = PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds)], entry, vk[3:])
     if last.commit_syscall and last.commit_deferred_syscall:
         assert err is None
+        assert PVM.verify_proof_public_values([pvs[i] for i in X.proof_order(kinds)], entry) == "global cumulative sum is not zero"   # (without the key's digest)
     else:       # a hand-assembled program that halts without COMMIT / COMMIT_DEFERRED_PROOFS: the reference refuses exactly that
         assert err == "prev_commit_syscall doesn't equal the previous shard's commit_syscall"
     return ex, kinds, cycles, last
@@ -288,7 +293,7 @@ def test_core_shards_are_cut_by_the_trace_area_estimator():
         if kind == "core":
             real = sum(int(tabs[a.name][1].shape[0]) * (a.main_width + a.prep_width) for a, _ in machine)
             sizes.append((sh.cycles, sh.estimated_area, real, sh.halted))
-    assert not X.global_events_balance(gevs)
+    assert not X.global_events_balance(gevs + [X.image_events(ex)])
     assert kinds.count("core") >= 3
     for cycles, est, real, halted in sizes:
         assert real <= threshold and abs(est - real) < 0.25 * (threshold - fixed) + (1 << 19)
