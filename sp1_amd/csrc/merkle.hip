@@ -32,7 +32,7 @@ __global__ void expand_columns_kernel(TensorTable tab, uint32_t total_width, uin
 
 int make_tensor_table(const sp1hip_tensor_t* tensors, int n_tensors, TensorTable* tab, uint32_t* total_width) {
     SP1HIP_REQUIRE(tensors && n_tensors > 0, "empty tensor message");
-    SP1HIP_REQUIRE(n_tensors <= MAX_TENSORS, "too many tensors in one message (max 128)");
+    SP1HIP_REQUIRE(n_tensors <= MAX_TENSORS, "too many tensors in one message (max 256)");
     uint32_t w = 0;
     for (int i = 0; i < n_tensors; i++) {
         SP1HIP_REQUIRE(tensors[i].d_data != nullptr || tensors[i].width == 0, "null tensor data");

@@ -8,7 +8,7 @@
 
 namespace sp1hip {
 
-constexpr int MAX_TENSORS = 128;
+constexpr int MAX_TENSORS = 256;      // (the table travels as a kernel argument: 12 bytes per tensor of the 4 KB a launch may pass)
 
 struct TensorTable {
     const uint32_t* base[MAX_TENSORS];
