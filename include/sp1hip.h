@@ -399,6 +399,15 @@ int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_instr, uint32
                                const uint32_t* main_row, const uint32_t* prep_row, const uint32_t* publics,
                                uint32_t n_publics, int form, uint32_t* out_values, uint32_t n_constraints,
                                uint32_t* out_stats);
+/* Host-only check of the polynomial-identity pieces (hint kind 7, sp1_amd/csrc/zc_poly.hpp) without a GPU: plans `program`, builds
+ * every identity's device table for the batching challenge `alpha` exactly as sp1hip_zerocheck_prove does, and evaluates the
+ * tables on ONE main row the way the kernels do (affine forms, then products). out_collapsed = the sum over the identities of
+ * their batched value; out_direct = the same sum taken constraint by constraint, sum_k alpha^(n - 1 - k) C_k(row) over the
+ * constraints the identities cover (n = num constraints of the program); *n_identities = how many hints the planner accepted.
+ * Equal for every row and alpha, or the pieces are wrong. */
+int sp1hip_zerocheck_poly_check(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width,
+                                const uint32_t* main_row, sp1hip_ext_t alpha, sp1hip_ext_t* out_collapsed, sp1hip_ext_t* out_direct,
+                                uint32_t* n_identities);
 /* Host-only: the bilinear extension of a column's row quad (r00, r01, r10, r11 = rows 4q .. 4q + 3, Montgomery words) at node
  * `node` (0 .. 11) of the bivariate grid the fused first two zerocheck rounds evaluate — the same function the kernels call
  * (zc_biv_interp: one 36-bit accumulation and its reduction); for tests of its edge cases without a GPU. */

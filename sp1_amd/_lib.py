@@ -241,6 +241,7 @@ PROTOTYPES = [
     ("sp1hip_zerocheck_biv_interp_host", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p]),
     ("sp1hip_zerocheck_plan_eval", None, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.c_uint32, _int, u32p,
                                           C.c_uint32, u32p]),
+    ("sp1hip_zerocheck_poly_check", None, [u32p, C.c_uint32, C.c_uint32, C.c_uint32, u32p, Ext, C.POINTER(Ext), C.POINTER(Ext), u32p]),
 ]
 
 _lib = None

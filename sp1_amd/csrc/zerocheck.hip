@@ -3164,6 +3164,52 @@ extern "C" int sp1hip_zerocheck_plan_eval(const uint32_t* program, uint32_t n_in
     return SP1HIP_SUCCESS;
 }
 
+extern "C" int sp1hip_zerocheck_poly_check(const uint32_t* program, uint32_t n_instr, uint32_t main_width, uint32_t prep_width,
+                                           const uint32_t* main_row, sp1hip_ext_t alpha_c, sp1hip_ext_t* out_collapsed,
+                                           sp1hip_ext_t* out_direct, uint32_t* n_identities) {
+    SP1HIP_REQUIRE(program && main_row && out_collapsed && out_direct && n_identities, "null argument");
+    for (uint32_t k = 0; k < n_instr; k++) SP1HIP_REQUIRE(program[3 * k] <= ZC_ASSERT_ZERO || program[3 * k] == ZC_HINT, "bad opcode in constraint program");
+    std::shared_ptr<const ZcPlan> plan;
+    SP1HIP_TRY(zc_get_plan(program, n_instr, main_width, prep_width, -1, &plan));
+    const Ext alpha{{alpha_c.c[0], alpha_c.c[1], alpha_c.c[2], alpha_c.c[3]}};
+    SP1HIP_REQUIRE(!kb::ext_eq(alpha, kb::ext_zero()), "the batching challenge is zero");
+    const uint32_t n_c = asserts_total(program, n_instr);
+    std::vector<Ext> pows(n_c);                                   // [alpha^(n-1), ..., alpha, 1] as in zerocheck_prove_impl
+    { Ext cur = kb::ext_one(); for (uint32_t k = n_c; k-- > 0;) { pows[k] = cur; cur = cur * alpha; } }
+    const Ext rho = kb::ext_inv(alpha);
+    Ext collapsed = kb::ext_zero(), direct = kb::ext_zero();
+    std::vector<kb::Ext> scratch[2];
+    uint32_t count = 0;
+    for (const ZcMacro& m : plan->macros) {
+        if (m.kind != ZC_HINT_POLY) continue;
+        count++;
+        const ZcPoly& pl = plan->polys[m.aux0];
+        std::vector<uint32_t> tb;
+        zc_poly_table(pl, plan->poly_segs[m.aux0], pows.data() + m.first_constraint, rho, &tb, scratch);
+        // the kernels' evaluation of the table on one row: every segment is an affine form (constant first)
+        size_t off = ZC_POLY_HDR;
+        auto form = [&](uint32_t n, bool with_const) -> Ext {
+            Ext f = kb::ext_zero();
+            if (with_const) { f = Ext{{tb[off + 4], tb[off + 5], tb[off + 6], tb[off + 7]}}; off += ZC_POLY_ENTRY; }
+            for (uint32_t k = 0; k < n; k++, off += ZC_POLY_ENTRY) f = f + kb::ext_mul_base(Ext{{tb[off + 4], tb[off + 5], tb[off + 6], tb[off + 7]}}, main_row[tb[off]]);
+            return f;
+        };
+        Ext v = kb::ext_zero();
+        for (uint32_t t = 0; t < tb[0]; t++) {
+            Ext p = form(tb[4 + 3 * t], true) * form(tb[5 + 3 * t], true);
+            if (tb[6 + 3 * t] != ZC_POLY_NONE) p = p * form(tb[6 + 3 * t], true);
+            v = v + p;
+        }
+        v = v + form(tb[1], true) + form(tb[2], false);
+        collapsed = collapsed + v;
+        zc_poly_eval_row(pl, main_row, [&](uint32_t k, uint32_t c) { direct = direct + kb::ext_mul_base(pows[m.first_constraint + k], c); });
+    }
+    memcpy(out_collapsed->c, collapsed.c, 16);
+    memcpy(out_direct->c, direct.c, 16);
+    *n_identities = count;
+    return SP1HIP_SUCCESS;
+}
+
 extern "C" int sp1hip_fix_last_variable(const uint32_t* d_in, uint64_t rows, uint32_t width, int in_is_ext, sp1hip_ext_t alpha,
                                         const uint32_t* d_padding, uint32_t* d_out, sp1hip_stream_t stream) {
     SP1HIP_REQUIRE(rows < ((uint64_t)1 << 32), "too many rows");

@@ -193,3 +193,37 @@ def test_planner_rejects_overlapping_hints(lib):
     st = lib.sp1hip_zerocheck_plan_eval(_u32p(prog), len(dup.instrs), air.main_width, air.prep_width, _u32p(u(row)), _u32p(u(prow)),
                                         _u32p(u(pub)), 4, 1, _u32p(out), air.num_constraints, _u32p(stats))
     assert st != 0 and b"same constraints" in lib.sp1hip_last_error()
+
+
+def test_polynomial_identity_tables_collapse_to_the_batched_constraints(lib):
+    """Hint kind 7 (zc_poly.hpp): FieldOpCols' coefficient constraints carry consecutive alpha powers, so the kernels evaluate
+    w_0 (sum of products of affine forms at 1 / alpha + the rest) instead of the convolution. sp1hip_zerocheck_poly_check builds
+    the device tables for a given alpha as the prover does and evaluates them on one row like the kernels: the result must equal
+    the sum of alpha^(n - 1 - k) C_k(row) over the covered constraints — for every chip that carries the hint (two- and
+    three-factor terms, selectors, a modulus from memory, 32- and 48-limb fields), random rows, the zero row, several alphas."""
+    from sp1_amd._lib import Ext
+    names = ("Secp256k1AddAssign", "Secp256k1DoubleAssign", "Uint256MulMod", "Bn254FpOpAssign", "Bls12381FpOpAssign", "Bn254Fp2AddSubAssign",
+             "Bls12381Fp2MulAssign", "EdAddAssign", "EdDecompress", "Uint256Ops", "Bls12381AddAssign")
+    rng = np.random.default_rng(77)
+    for name in names:
+        air = riscv.chip(name)[0]
+        prog = np.ascontiguousarray(air.to_array().reshape(-1), dtype=np.uint32)
+        for trial in range(3):
+            row = rng.integers(0, P, size=air.main_width, dtype=np.uint64) if trial < 2 else np.zeros(air.main_width, dtype=np.uint64)
+            m = np.ascontiguousarray((row * np.uint64(R)) % np.uint64(P), dtype=np.uint32)
+            alpha = Ext()
+            for k in range(4):
+                alpha.c[k] = int(rng.integers(1, P))
+            a, b, n = Ext(), Ext(), C.c_uint32()
+            st = lib.sp1hip_zerocheck_poly_check(_u32p(prog), len(air.instrs), air.main_width, air.prep_width, _u32p(m), alpha, C.byref(a), C.byref(b), C.byref(n))
+            assert st == 0, lib.sp1hip_last_error().decode()
+            assert n.value >= 1, name
+            assert list(a.c) == list(b.c), (name, trial)
+    # a chip without the hint: nothing to check, both sums empty
+    air = riscv.chip("Add")[0]
+    prog = np.ascontiguousarray(air.to_array().reshape(-1), dtype=np.uint32)
+    a, b, n = Ext(), Ext(), C.c_uint32()
+    alpha = Ext()
+    alpha.c[0] = 5
+    assert lib.sp1hip_zerocheck_poly_check(_u32p(prog), len(air.instrs), air.main_width, air.prep_width, _u32p(np.zeros(air.main_width, dtype=np.uint32)), alpha,
+                                           C.byref(a), C.byref(b), C.byref(n)) == 0 and n.value == 0
