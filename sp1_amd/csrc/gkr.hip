@@ -586,8 +586,14 @@ template <int FV, int SV, bool FIRST, bool NBASE, bool FLAT>
 __global__ __launch_bounds__(256) void gkr_pass(const PassDesc* __restrict__ descs, const Ext* __restrict__ eq_int,
                                                 const Ext* __restrict__ T, const Ext* __restrict__ TL, Ext a0, Ext a1,
                                                 uint32_t* __restrict__ partials, RoundSync rs, uint32_t seq, uint32_t K,
-                                                uint32_t tile_size, FlatArgs fa) {
+                                                uint32_t tile_size, FlatArgs fa, GateArg gate) {
     static_assert(FV + SV > 0 && FV <= 2 && SV <= 2, "a pass folds and / or sums");
+    if (FV > 0 && gate.block != nullptr) {                   // enqueued one hand-over early: the challenges arrive through the gate
+        __shared__ uint32_t gate_words[8];
+        gate_wait_load(gate, gate_words, 8);
+        a0 = Ext{{gate_words[0], gate_words[1], gate_words[2], gate_words[3]}};
+        a1 = Ext{{gate_words[4], gate_words[5], gate_words[6], gate_words[7]}};
+    }
     constexpr int SVS = SV == 0 ? 1 : SV;                    // (types only; SV = 0 never touches the grid)
     GridAcc<SVS> g;
     grid_init<SVS>(g);
@@ -1160,6 +1166,15 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
     size_t launch_idx = 0;                                   // next pass: shapes[launch_idx], K descriptors of d_all
     RoundSyncHost rsync;
     SP1HIP_TRY(rsync.init(s));
+    // SP1HIP_GATE=1 (off by default): small passes are enqueued one hand-over early and wait for their challenges at a HostGate
+    // (round_sync.hpp), so that the dispatch of a pass overlaps the host's half of the round trip. Measured on the fibonacci shard
+    // (eight alternating runs): 25.3-25.6 ms with the gate against 24.5-25.1 without — the two reads of mapped host memory a gated
+    // workgroup starts with (ticket, then challenges: ~2 us each across PCIe) cost what the overlapped dispatch saves. Kept as an
+    // A/B knob; the proof bytes are the same either way (tests/test_gpu_gkr.py). SP1HIP_GATE_MAX_TILES: what "small" means.
+    const bool gate_on = [] { const char* e = getenv("SP1HIP_GATE"); return e && e[0] == '1'; }();
+    const uint32_t gate_max_tiles = [] { const char* e = getenv("SP1HIP_GATE_MAX_TILES"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 256u; }();
+    HostGate gate;                                           // (declared after rsync / mb: destroyed first, so an early exit opens it before they drain)
+    if (gate_on) SP1HIP_TRY(gate.init(s));
     const Ext one = kb::ext_one(), zero = kb::ext_zero(), inv8 = kb::ext_inv(ext_c(8)), inv2 = kb::ext_inv(ext_c(2)), four = ext_c(4);
     uint32_t h_sums[40];
     // the cubic  scale (1 - pt + (2 pt - 1) X) (q0 + q1 X + q2 X^2)
@@ -1231,45 +1246,64 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
         Ext a0 = zero, a1 = zero;                            // the challenges the next pass folds with
         int t = v;                                           // row variables not yet bound by a FOLD
         size_t final_rows_total = 0;
-        for (;;) {                                           // the passes of the layer (two rounds each)
-            const PassShape shape = shapes[launch_idx];
-            const PassDesc* d_descs = (const PassDesc*)d_all.p + (launch_idx++) * K;
+        // one pass of the layer: shapes[idx], t_after = row variables left once it has folded. gate_slot: the pass is enqueued behind
+        // a HostGate and reads its challenges there; else they are the arguments. *seq_out = the number of its hand-over (sv > 0).
+        auto launch_pass = [&](size_t idx, int t_after, GateArg gate_arg, const Ext& c0, const Ext& c1, uint32_t* seq_out) -> int {
+            const PassShape shape = shapes[idx];
+            const PassDesc* d_descs = (const PassDesc*)d_all.p + idx * K;
             const int fv = shape.fv, sv = shape.sv;
-            t -= fv;                                         // variables left once this pass has folded
             const FlatArgs fa{(const uint16_t*)d_flat.p + shape.flat_off, shape.total_slots};
             const bool nbase = shape.first && v + 1 == L;
-            if (!simd && t == sv) par.wake();                // the helpers' wake-up hides behind the layer's last two passes
             const bool publish_rows = sv == 0 && direct_final;
             if (publish_rows) { rsync.pending = true; mb.pending = true; }       // (an early error return must drain the stream first)
             const RoundSync rs = sv > 0 ? rsync.next() : publish_rows ? RoundSync{rsync.d_counter, (volatile uint32_t*)mb.h_slot} : RoundSync{};
-            const Ext* Tp = sv > 0 ? T_of(t - sv) : (const Ext*)nullptr;
-            const Ext* TLp = sv > 0 ? TL_of(t - sv) : (const Ext*)nullptr;
-            const auto dbg_l0 = std::chrono::steady_clock::now();
-            if (gkr_debug && dbg_pass_pending) dbg_host += std::chrono::duration<double, std::milli>(dbg_l0 - dbg_pass_t).count();
-            dbg_pass_pending = false;
-            {
-                ScopedTimer tm(fv == 0 ? "gkr_pass_sum" : sv == 0 ? "gkr_pass_fold" : "gkr_pass_fold_sum", s);
-#define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, TLp, a0, a1, d_partials.u32(), rs, publish_rows ? mb.seq + 1 : rsync.seq, K, shape.tile_size, fa)
+            *seq_out = rsync.seq;
+            const Ext* Tp = sv > 0 ? T_of(t_after - sv) : (const Ext*)nullptr;
+            const Ext* TLp = sv > 0 ? TL_of(t_after - sv) : (const Ext*)nullptr;
+            ScopedTimer tm(fv == 0 ? "gkr_pass_sum" : sv == 0 ? "gkr_pass_fold" : "gkr_pass_fold_sum", s);
+#define SP1HIP_GKR_PASS(FV, SV, F, NB, FL) hipLaunchKernelGGL((gkr_pass<FV, SV, F, NB, FL>), dim3(shape.tiles), dim3(256), 0, s, d_descs, (const Ext*)d_eq_int.p, Tp, TLp, c0, c1, d_partials.u32(), rs, publish_rows ? mb.seq + 1 : rsync.seq, K, shape.tile_size, fa, gate_arg)
 #define SP1HIP_GKR_PASS_FL(FV, SV, F, NB) do { if (shape.flat) SP1HIP_GKR_PASS(FV, SV, F, NB, true); else SP1HIP_GKR_PASS(FV, SV, F, NB, false); } while (0)
 #define SP1HIP_GKR_PASS_SRC(FV, SV) do { if (nbase) SP1HIP_GKR_PASS_FL(FV, SV, true, true); else if (shape.first) SP1HIP_GKR_PASS_FL(FV, SV, true, false); else SP1HIP_GKR_PASS_FL(FV, SV, false, false); } while (0)
-                if (fv == 0 && sv == 2) { if (nbase) SP1HIP_GKR_PASS_FL(0, 2, true, true); else SP1HIP_GKR_PASS_FL(0, 2, true, false); }
-                else if (fv == 0 && sv == 1) { if (nbase) SP1HIP_GKR_PASS_FL(0, 1, true, true); else SP1HIP_GKR_PASS_FL(0, 1, true, false); }
-                else if (fv == 2 && sv == 2) SP1HIP_GKR_PASS_SRC(2, 2);
-                else if (fv == 2 && sv == 1) SP1HIP_GKR_PASS_SRC(2, 1);
-                else if (fv == 2 && sv == 0) SP1HIP_GKR_PASS_SRC(2, 0);
-                else if (fv == 1 && sv == 0) SP1HIP_GKR_PASS_SRC(1, 0);
-                else { set_error("internal error: GKR pass shape (%d, %d)", fv, sv); return SP1HIP_ERROR_RUNTIME; }
+            if (fv == 0 && sv == 2) { if (nbase) SP1HIP_GKR_PASS_FL(0, 2, true, true); else SP1HIP_GKR_PASS_FL(0, 2, true, false); }
+            else if (fv == 0 && sv == 1) { if (nbase) SP1HIP_GKR_PASS_FL(0, 1, true, true); else SP1HIP_GKR_PASS_FL(0, 1, true, false); }
+            else if (fv == 2 && sv == 2) SP1HIP_GKR_PASS_SRC(2, 2);
+            else if (fv == 2 && sv == 1) SP1HIP_GKR_PASS_SRC(2, 1);
+            else if (fv == 2 && sv == 0) SP1HIP_GKR_PASS_SRC(2, 0);
+            else if (fv == 1 && sv == 0) SP1HIP_GKR_PASS_SRC(1, 0);
+            else { set_error("internal error: GKR pass shape (%d, %d)", fv, sv); return SP1HIP_ERROR_RUNTIME; }
 #undef SP1HIP_GKR_PASS_SRC
 #undef SP1HIP_GKR_PASS_FL
 #undef SP1HIP_GKR_PASS
-                SP1HIP_LAUNCH_CHECK();
-            }
+            SP1HIP_LAUNCH_CHECK();
+            return SP1HIP_SUCCESS;
+        };
+        bool pre = false;                                    // the pass about to be handled is already enqueued (behind the gate, opened)
+        uint32_t pre_ticket = 0, pre_seq = 0;
+        for (;;) {                                           // the passes of the layer (two rounds each)
+            const PassShape shape = shapes[launch_idx];
+            const size_t idx = launch_idx++;
+            const int fv = shape.fv, sv = shape.sv;
+            t -= fv;                                         // variables left once this pass has folded
+            if (!simd && t == sv) par.wake();                // the helpers' wake-up hides behind the layer's last two passes
+            const auto dbg_l0 = std::chrono::steady_clock::now();
+            if (gkr_debug && dbg_pass_pending) dbg_host += std::chrono::duration<double, std::milli>(dbg_l0 - dbg_pass_t).count();
+            dbg_pass_pending = false;
+            uint32_t my_seq = pre_seq;
+            if (!pre) SP1HIP_TRY(launch_pass(idx, t, GateArg{nullptr, 0u}, a0, a1, &my_seq));
+            pre = false;
             if (gkr_debug) dbg_launch += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_l0).count();
             build_eq_tabs();                                 // (first pass of the layer only) host work behind a running kernel
             if (sv == 0) break;
+            // the NEXT pass, one hand-over early when it is small (its duration is latency: the launch would be on the critical path)
+            if (gate_on && shapes[launch_idx].tiles <= gate_max_tiles) {
+                const GateArg ga = gate.arm();
+                pre_ticket = ga.ticket;
+                pre = true;                                  // (armed: from here on the ticket must be opened, whatever happens)
+                SP1HIP_TRY(launch_pass(launch_idx, t - shapes[launch_idx].fv, ga, zero, zero, &pre_seq));
+            }
             const int ns = sv == 2 ? 10 : 4;
             const auto dbg_w0 = std::chrono::steady_clock::now();
-            SP1HIP_TRY(rsync.wait(h_sums, 4 * ns));
+            SP1HIP_TRY(rsync.wait_for(my_seq, h_sums, 4 * ns));
             if (gkr_debug) { const auto now = std::chrono::steady_clock::now(); dbg_wait += std::chrono::duration<double, std::milli>(now - dbg_w0).count(); dbg_pass_t = now; dbg_passes++; dbg_pass_pending = true; }
             Ext S[10];
             memcpy(S, h_sums, 16 * (size_t)ns);
@@ -1315,6 +1349,11 @@ int sp1hip_logup_gkr_prove(const sp1hip_gkr_chip_t* chips, int n_chips, int max_
                 alphas.push_back(a0);
                 claim = poly_eval(poly, a0);
                 PA = PA * (pt_a * a0 + (one - pt_a) * (one - a0));
+            }
+            if (pre) {                                       // the armed pass starts now
+                uint32_t words[8];
+                memcpy(words, a0.c, 16); memcpy(words + 4, a1.c, 16);
+                gate.open(pre_ticket, words, 8);
             }
         }
         // the layer's last fold left one row per interaction: dense over 2^niv on the host

@@ -178,15 +178,84 @@ struct RoundSyncHost {
     RoundSync chained() { pending = true; return RoundSync{d_counter, nullptr}; }
     void settled() { pending = false; }
     // copies n_words sums (from slot[1..]) into out
-    int wait(uint32_t* out, int n_words) {
+    int wait(uint32_t* out, int n_words) { return wait_for(seq, out, n_words); }
+    // the same for the hand-over numbered `which` (a launch armed behind a HostGate may already have taken the next number)
+    int wait_for(uint32_t which, uint32_t* out, int n_words) {
         volatile uint32_t* slot = h_slot;
-        SP1HIP_TRY(wait_for_seq(slot, seq, s, "a sumcheck round result"));
+        SP1HIP_TRY(wait_for_seq(slot, which, s, "a sumcheck round result"));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         pending = false;
         for (int k = 0; k < n_words; k++) out[k] = slot[1 + k];
         return SP1HIP_SUCCESS;
     }
 };
+
+// ---- HostGate: hand a few words from the HOST to a launch that is already enqueued.
+// Every sumcheck round ends with the host sampling a challenge the next launch needs. Launching at that moment puts the launch
+// on the critical path: ~12 us from the host's store to the completion of a one-wave kernel, of which ~6 us are the dispatch of a
+// kernel behind another one. So a small pass is enqueued one hand-over EARLY — its dispatch overlaps the host's half of the round
+// trip — and lane 0 of every workgroup polls a ticket word in mapped pinned memory until the host has written the challenges
+// into the ticket's slot (`open()`: the slot first, then the ticket with release order). hipStreamWaitValue32 was tried for the
+// wait: ROCm 7.2 implements it as a one-workgroup polling KERNEL between the two launches, i.e. two dependent dispatches instead
+// of one, and nothing is gained (bench/ubench/ubench_wait_value.hip; profiles/r06_gkr_launch_trace_stream_wait_value.txt).
+// Tickets only grow; the poll is bounded by the wall clock (GATE_TIMEOUT_TICKS) and a gate that goes out of scope with armed
+// tickets opens them all, so neither an error return nor a dead host thread leaves a kernel spinning for ever.
+constexpr uint32_t GATE_RING = 64;                     // slots of 8 extension elements each; at most a few tickets are armed at a time
+constexpr uint32_t GATE_SLOT_WORDS = 32, GATE_SLOT0 = 64;
+constexpr uint64_t GATE_TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz wall clock
+struct HostGateBlock { uint32_t* h; };                 // [0] = the ticket word (its own cache line), slots from word GATE_SLOT0
+int host_gate_acquire(HostGateBlock* out);             // runtime.hip (process-wide free list per device, like the mailbox slots)
+void host_gate_release(HostGateBlock b);
+
+struct GateArg { const uint32_t* block; uint32_t ticket; };   // kernel argument: block == nullptr: not gated
+
+struct HostGate {
+    uint32_t* h = nullptr;
+    uint32_t issued = 0, opened = 0;                   // tickets armed / opened so far (both continue the block's sequence)
+    hipStream_t s = nullptr;
+    int init(hipStream_t stream) {
+        s = stream;
+        HostGateBlock b;
+        SP1HIP_TRY(host_gate_acquire(&b));
+        h = b.h;
+        issued = opened = h[0];
+        return SP1HIP_SUCCESS;
+    }
+    ~HostGate() {
+        if (!h) return;
+        if (opened != issued) {                        // an early exit: let the armed launches run (on whatever the slots hold) and drain
+            __atomic_store_n(h, issued, __ATOMIC_RELEASE);
+            (void)hipStreamSynchronize(s);
+        }
+        host_gate_release(HostGateBlock{h});
+    }
+    HostGate() = default;
+    HostGate(const HostGate&) = delete;
+    HostGate& operator=(const HostGate&) = delete;
+    GateArg arm() { issued++; return GateArg{h, issued}; }      // the launch that takes this argument waits for open(ticket)
+    void open(uint32_t ticket, const uint32_t* words, int n_words) {
+        uint32_t* slot = h + GATE_SLOT0 + (size_t)(ticket % GATE_RING) * GATE_SLOT_WORDS;
+        for (int k = 0; k < n_words; k++) slot[k] = words[k];
+        __atomic_store_n(h, ticket, __ATOMIC_RELEASE);
+        opened = ticket;
+    }
+};
+// device side, all threads of the workgroup: wait for the ticket, then the first n_words (<= 32) of its slot through LDS — ONE
+// polling lane and one read of the slot per workgroup (every lane reading mapped host memory itself is thousands of uncached reads
+// across PCIe per workgroup: measured +85 us per small pass)
+__device__ __forceinline__ void gate_wait_load(const GateArg& g, uint32_t* lds_words, int n_words) {
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(g.block, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - g.ticket) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > GATE_TIMEOUT_TICKS) break;
+        }
+    }
+    __syncthreads();
+    const uint32_t* slot = g.block + GATE_SLOT0 + (size_t)(g.ticket % GATE_RING) * GATE_SLOT_WORDS;
+    if ((int)threadIdx.x < n_words) lds_words[threadIdx.x] = __hip_atomic_load(slot + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+}
 
 // ---- Mailbox: "copy these few device words to the host and wait for them" without hipMemcpyAsync + hipStreamSynchronize.
 // A one-workgroup kernel, ordered on the stream behind the producer, stores the words into mapped pinned memory and

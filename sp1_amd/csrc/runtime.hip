@@ -620,6 +620,31 @@ void mailbox_release(MailboxSlot slot) {
     g_mb_free[dev].push_back(slot);
 }
 
+static std::vector<HostGateBlock> g_gate_free[64];
+
+int host_gate_acquire(HostGateBlock* out) {
+    int dev = 0;
+    SP1HIP_HIP(hipGetDevice(&dev));
+    SP1HIP_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    {
+        std::lock_guard<std::mutex> lock(g_rs_mutex);
+        if (!g_gate_free[dev].empty()) { *out = g_gate_free[dev].back(); g_gate_free[dev].pop_back(); return SP1HIP_SUCCESS; }
+    }
+    HostGateBlock b{nullptr};
+    const size_t words = 64 + (size_t)GATE_RING * GATE_SLOT_WORDS;
+    SP1HIP_HIP(hipHostMalloc((void**)&b.h, words * 4, hipHostMallocMapped));
+    memset(b.h, 0, words * 4);
+    *out = b;
+    return SP1HIP_SUCCESS;
+}
+
+void host_gate_release(HostGateBlock b) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lock(g_rs_mutex);
+    g_gate_free[dev].push_back(b);
+}
+
 static std::vector<PinnedBlock> g_pin_free[64];
 
 int pinned_stage_acquire(PinnedBlock* out) {

@@ -106,6 +106,25 @@ def test_gkr_separate_tree_kernels_give_the_same_bytes(api, monkeypatch, n_tuple
     assert np.array_equal(g_ch.state(), o_ch.state())
 
 
+@pytest.mark.parametrize("n_tuples,L,with_empty,dup", [(9, 6, True, 2), (300, 10, True, 3), (1300, 12, True, 3)])
+def test_gkr_passes_behind_the_host_gate_give_the_same_bytes(api, monkeypatch, n_tuples, L, with_empty, dup):
+    """SP1HIP_GATE=1: the small passes are enqueued one hand-over early and take their challenges from mapped host memory once the
+    host has written them (HostGate, round_sync.hpp: one polling lane per workgroup, bounded by the wall clock) instead of from
+    their kernel arguments — an A/B knob that measured no faster (gkr.hip). The bytes and the transcript must not change, and
+    the gate must leave no launch waiting (the second proof on the same stream runs)."""
+    monkeypatch.setenv("SP1HIP_GATE", "1")
+    chips = make_gkr_chips(n_tuples, 10 + L, with_empty, dup)
+    for _ in range(2):
+        o_ch, g_ch = orc.Challenger(), api.DuplexChallenger()
+        seed = orc.random_felts((9,), L)
+        o_ch.observe(seed)
+        g_ch.observe(seed)
+        want = orc.gkr_prove(chips, L, o_ch)
+        got = api.logup_gkr(_dev(api, chips), L, g_ch)
+        assert got == want
+        assert np.array_equal(g_ch.state(), o_ch.state())
+
+
 def test_gkr_rejects_unsorted_chips_and_keeps_transcript(api):
     chips = make_gkr_chips(4, 3)
     dev = _dev(api, chips)
