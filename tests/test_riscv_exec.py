@@ -473,3 +473,46 @@ def test_the_oracle_proves_and_verifies_the_halting_shard_with_its_public_values
             assert (orc.shard_verify(shapes, prep.commit, blob, L, lsh, v_ch, 1, 5, 4, pv_program=PVM.verifier_program()) == 0) == want_ok
     finally:
         orc.set_gkr_sparse(False)
+
+
+def test_memory_image_follows_the_reference_elf_rules():
+    """`Program::memory_image` (disassembler/elf.rs:L320-L353): every 8-byte word of every PT_LOAD segment, file bytes and zero
+    fill alike, by address — and the reference's zero-fill rule as it is written: `image.insert(addr - addr % 8, 0)` REPLACES the
+    word, so a segment whose file part ends in the middle of a word loses that word's file half. The executor's memory starts as
+    the image says (the verifying key's digest is computed from it: a loader with other rules would prove another statement)."""
+    import struct as st
+    import rv_asm as A
+    data = bytes(range(1, 13))                                            # 12 file bytes: one whole word and a half
+    elf = bytearray(A.elf(A.li(5, 0) + A.halt(0), data=data))
+    ph = 64 + 56                                                          # the second program header: p_filesz at +32, p_memsz at +40
+    assert st.unpack_from("<Q", elf, ph + 32)[0] == 12
+    st.pack_into("<Q", elf, ph + 40, 28)                                  # memsz: zero fill up to byte 28
+    ex = X.Executor(bytes(elf), stdin=[])
+    img = {int(a): int(v) & ((1 << 64) - 1) for a, v in ex.memory_image()}
+    base = 0x78100000
+    assert img[base] == int.from_bytes(data[:8], "little")
+    assert img[base + 8] == 0 and img[base + 16] == 0 and img[base + 24] == 0   # the half word 9..12 is gone with the first zero fill
+    assert base + 32 not in img
+    text = [a for a in img if a < base]
+    assert text == sorted(text) and len(text) == (len(A.li(5, 0) + A.halt(0)) + 1) // 2
+    ev = X.image_events(ex)
+    assert ev.shape == (len(img), 11) and int(ev[:, 8].sum()) == len(img) and int(ev[:, 9].sum()) == 0      # one SEND per word
+
+
+def test_hinted_words_are_initialised_whether_or_not_they_are_read():
+    """HINT_READ writes whole words and a tail word only if there is one (minimal/postprocess.rs:L10-L36); every hinted word is
+    initialised with its hint and finalised (controller/global.rs:L133-L142), read or not."""
+    import rv_asm as A
+    buf = 0x78200000
+    prog = A.li(10, buf) + A.li(11, 16) + A.li(5, 0xF1) + [A.enc("ecall")]           # HINT_READ(buf, 16): two words, no tail
+    prog += A.li(10, buf + 64) + A.li(11, 5) + A.li(5, 0xF1) + [A.enc("ecall")]      # HINT_READ(buf + 64, 5): a tail word only
+    prog += [A.enc("ld", 6, 10, 0)]                                                 # the program reads only the tail word
+    ex = X.Executor(A.elf(prog + A.halt(0)), stdin=[bytes(range(16)), b"\x01\x02\x03\x04\x05"])
+    while not ex.halted:
+        ex.run_shard(1 << 20)
+    gm = {int(r[0]): (int(r[1]) & ((1 << 64) - 1), int(r[2]) & ((1 << 64) - 1), int(r[3])) for r in ex.global_memory()}
+    w0, w1 = int.from_bytes(bytes(range(8)), "little"), int.from_bytes(bytes(range(8, 16)), "little")
+    assert gm[buf] == (w0, w0, 0) and gm[buf + 8] == (w1, w1, 0)            # never read: initial = final = the hint, timestamp 0
+    assert buf + 16 not in gm                                               # no empty tail word
+    tail = int.from_bytes(b"\x01\x02\x03\x04\x05", "little")
+    assert gm[buf + 64][:2] == (tail, tail) and gm[buf + 64][2] > 0          # read: it carries the load's timestamp
