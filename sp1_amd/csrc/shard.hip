@@ -13,6 +13,8 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "device_ctx.hpp"
@@ -88,15 +90,33 @@ int sp1hip_prove_shard(const sp1hip_shard_chip_t* chips, int n_chips, const uint
         for (int c = 0; c < n_chips; c++) { mix(chips[c].real_rows); mix((uint64_t)chips[c].main_width << 32 | (uint32_t)chips[c].n_instr); }
     }
 
-    // ---- exact proof size from the shapes
+    // ---- exact proof size from the shapes (remembered per shape signature + interaction / program sizes: the two dry calls walk
+    // every interaction and every constraint program, ~0.3 ms of host time in front of a proof's first launch)
     size_t gkr_size = 0, zc_size = 0;
+    uint64_t size_sig = shape_sig;
+    for (int c = 0; c < n_chips; c++) {
+        size_sig = (size_sig ^ ((uint64_t)chips[c].n_words << 32 | chips[c].num_constraints)) * 0x100000001b3ull;
+        size_sig = (size_sig ^ ((uint64_t)strlen(chips[c].name) << 32 | chips[c].prep_width)) * 0x100000001b3ull;
+    }
+    size_sig = (size_sig ^ (uint64_t)n_publics) * 0x100000001b3ull;
+    static std::mutex size_mutex;
+    static std::unordered_map<uint64_t, std::pair<size_t, size_t>> size_cache;
+    bool have_sizes = false;
     {
+        std::lock_guard<std::mutex> lk(size_mutex);
+        auto it = size_cache.find(size_sig);
+        if (it != size_cache.end()) { gkr_size = it->second.first; zc_size = it->second.second; have_sizes = true; }
+    }
+    if (!have_sizes) {
         int st = sp1hip_logup_gkr_prove(gk.data(), n_chips, L, challenger, nullptr, &gkr_size, stream);
         if (st != SP1HIP_ERROR_BUFFER_TOO_SMALL) return st == SP1HIP_SUCCESS ? SP1HIP_ERROR_RUNTIME : st;
         std::vector<sp1hip_ext_t> dummy(std::max<size_t>({total_w, (size_t)L, 1}));
         st = sp1hip_zerocheck_prove(zc.data(), n_chips, L, dummy.data(), dummy.data(), dummy[0], dummy[0], h_publics, n_publics,
                                     challenger, nullptr, &zc_size, stream);
         if (st != SP1HIP_ERROR_BUFFER_TOO_SMALL) return st == SP1HIP_SUCCESS ? SP1HIP_ERROR_RUNTIME : st;
+        std::lock_guard<std::mutex> lk(size_mutex);
+        if (size_cache.size() > 4096) size_cache.clear();
+        size_cache[size_sig] = {gkr_size, zc_size};
     }
     const uint64_t H = (uint64_t)1 << lsh;
     const uint64_t main_padded = std::max<uint64_t>((main_area + H - 1) / H, 1) * H;
