@@ -53,3 +53,30 @@ def test_the_tower_edwards_and_carry_precompile_shards_match_the_oracle(api):
             prove_both(api, machine, tabs, publics, 17, 12, 8, 1, 5, 4)
     assert seen == ["core", "bn254_fp", "bls12381_fp", "ed_decompress", "uint256_ops", "memory"]
     assert not X.global_events_balance(gevs + [X.image_events(ex)])
+
+
+def test_field_operation_pieces_over_several_workgroups_match_the_oracle(api):
+    """The polynomial-identity pieces of FieldOpCols (zc_poly.hpp) at a height where a round has several workgroups per identity
+    and the last one is partial: 700 SECP256K1_DOUBLE calls and 700 bn254 Fp multiplications in a loop (the bivariate rounds see
+    175 row quads, round 2 88 row pairs, ... down to one; three-factor terms with selectors in the Fp chip). Proof bytes == the
+    oracle's, the verifier accepts with the shards' public values."""
+    import struct
+    G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+    M64 = (1 << 64) - 1
+    w4 = lambda v: b"".join(struct.pack("<Q", (v >> (64 * i)) & M64) for i in range(4))
+    bn = M.BN254_P
+    data = w4(G[0]) + w4(G[1]) + w4(7 ** 90 % bn) + w4(bn - 11)              # 0: the point, 64: the Fp operands
+    body = [A.enc("addi", 10, 28, 0), A.enc("addi", 11, 0, 0)] + A.li(5, 0x0000010B) + [A.enc("ecall")]        # p <- 2 p
+    body += call(0x00010128, 64, 96)                                                                           # x <- x * y over bn254's Fp
+    n = 700
+    prog = A.li(28, DATA) + A.li(29, n) + body + [A.enc("addi", 29, 29, -1), A.enc("bne", 29, 0, -4 * (len(body) + 1))]
+    ex = X.Executor(A.elf(prog + A.halt(0), data=data + bytes(32)), stdin=[])
+    seen, gevs = [], []
+    for kind, machine, tabs, publics, gev, sh in X.program_shards(ex, 1 << 22, device="cuda"):
+        seen.append(kind)
+        gevs.append(gev)
+        if kind in ("secp256k1_double", "bn254_fp"):
+            assert int(tabs[{"secp256k1_double": "Secp256k1DoubleAssign", "bn254_fp": "Bn254FpOpAssign"}[kind]][1].shape[0]) == -(-n // 32) * 32      # (heights are multiples of 32)
+            prove_both(api, machine, tabs, publics, 17, 13, 8, 1, 5, 4)
+    assert seen == ["core", "secp256k1_double", "bn254_fp", "memory"]
+    assert not X.global_events_balance(gevs + [X.image_events(ex)])
