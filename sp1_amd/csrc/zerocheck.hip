@@ -2456,7 +2456,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
     // update that ends the round. It depends on the tables' heights and addresses only — not on anything the transcript
     // produces — so round r + 1 is planned and its descriptors uploaded while round r's kernels run (the host used to do
     // this between the fix launch and the round's first launch, ~35 us per round with the device idle).
-    struct Group { bool staged; uint32_t wg, max_regs, max_instr, block_lo, n_blocks; std::vector<int> chips; };
+    struct Group { bool staged; uint32_t wg, resident, max_regs, max_instr, block_lo, n_blocks; std::vector<int> chips; };
     struct RoundPlan {
         std::vector<ZcDesc> descs;
         std::vector<ZcChipRange> ranges;
@@ -2523,9 +2523,21 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 wg = (r == 0 && !biv) ? zc_wg_for<true>(regs, staged ? 128 + (size_t)instr * 16 : 128) : zc_wg_for<false>(regs, staged ? 128 + (size_t)instr * 16 : 128);
             }
             SP1HIP_REQUIRE(wg != 0, "constraint program too large: one constraint keeps more than 160 extension values live (the LDS register file of one wave)");
+            // A launch allocates its LDS register file for the LARGEST file among its chips, so a group is made of chips that keep
+            // the same number of workgroups resident per CU on their own: until round 6 every chip of one workgroup width shared a
+            // launch, and SyscallInstrs (32 rows, 23 registers) held the Add / Addi / Sub / Addw chips (7 registers, 4.5 million
+            // rows of a fibonacci shard) to 3 workgroups of 128 lanes per CU where their own files allow 11. Chips too short for
+            // occupancy to matter (the rounds that run the fine cut) share one group per width whatever their files.
+            // SP1HIP_ZC_GROUPS=legacy: one group per width (A/B runs; the proof bytes are the same).
+            static const bool by_residency = [] { const char* e = getenv("SP1HIP_ZC_GROUPS"); return !(e && e[0] == 'l'); }();
+            uint32_t resident = 0;
+            if (by_residency && terms > ZC_FINE_MAX_TERMS) {
+                const size_t per_wg = (staged ? 128 + (size_t)instr * 16 : 128) + ((r == 0 && !biv) ? zc_rf_lane_bytes<true>(regs) : zc_rf_lane_bytes<false>(regs)) * wg;
+                resident = (uint32_t)std::min<size_t>(ZC_LDS_CU / per_wg, 2048 / wg);
+            }
             size_t g = 0;
-            for (; g < groups.size(); g++) if (groups[g].staged == staged && groups[g].wg == wg) break;
-            if (g == groups.size()) groups.push_back(Group{staged, wg, 1, 1, 0, 0, {}});
+            for (; g < groups.size(); g++) if (groups[g].staged == staged && groups[g].wg == wg && groups[g].resident == resident) break;
+            if (g == groups.size()) groups.push_back(Group{staged, wg, resident, 1, 1, 0, 0, {}});
             groups[g].max_regs = std::max(groups[g].max_regs, regs);
             groups[g].max_instr = std::max(groups[g].max_instr, instr);
             groups[g].chips.push_back(i);
@@ -2712,11 +2724,21 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 // these launches fill the device together (the round is throughput-bound: 5.1 ms on the core shard however they are
                 // placed): the largest interpreter group on the caller's stream, the Poseidon2 pieces on the second, the other
                 // interpreter groups on the third, the septic pieces on the fourth
-                size_t big = 0;
-                for (size_t g = 1; g < rp.groups.size(); g++) if (rp.groups[g].n_blocks > rp.groups[big].n_blocks) big = g;
-                for (size_t gi = 0; gi < rp.groups.size(); gi++) {
-                    const auto& g = rp.groups[gi];
-                    SP1HIP_TRY(launch_biv_round(g.max_regs, g.staged, dd, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq, eq_len, d_publics.u32(), d_partial.u32(), stream_of(gi == big ? 0 : 2)));
+                // (the interpreter groups, longest first — workgroups x instructions —, each on the less loaded of the caller's stream and
+                // the third: since the groups are cut by residency there are up to ten of them, and one stream for all but the largest
+                // serialised 6 ms of launches)
+                {
+                    std::vector<size_t> by_work(rp.groups.size());
+                    for (size_t g = 0; g < by_work.size(); g++) by_work[g] = g;
+                    auto work = [&](size_t g) { return (double)rp.groups[g].n_blocks * (double)rp.groups[g].max_instr; };
+                    std::stable_sort(by_work.begin(), by_work.end(), [&](size_t a, size_t b) { return work(a) > work(b); });
+                    double load0 = 0, load2 = 0;
+                    for (size_t gi : by_work) {
+                        const auto& g = rp.groups[gi];
+                        const int slot = load0 <= load2 ? 0 : 2;
+                        (slot == 0 ? load0 : load2) += work(gi);
+                        SP1HIP_TRY(launch_biv_round(g.max_regs, g.staged, dd, n_descs, g.block_lo, g.n_blocks, g.max_instr, d_eq, eq_len, d_publics.u32(), d_partial.u32(), stream_of(slot)));
+                    }
                 }
 #define SP1HIP_ZC_BIV_MACRO_LAUNCH(KIND, SLOT)                                                                                           \
                 if (rp.macro_n[KIND]) {                                                                                                \
@@ -2907,7 +2929,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             std::vector<Launch> order;
             {
                 static const double floor_us[ZC_MACRO_KINDS] = {45.0, 75.0, 45.0, 60.0, 60.0, 120.0, 45.0, 90.0};
-                for (size_t g = 0; g < groups.size(); g++) order.push_back({0, g, floor_us[0] * (1.0 + groups[g].n_blocks * 3 / 1024.0), 0});
+                // (an interpreter group's length grows with its longest program too: 100 instructions are the unit the floor was measured at)
+                for (size_t g = 0; g < groups.size(); g++) order.push_back({0, g, floor_us[0] * (1.0 + groups[g].n_blocks * 3 / 1024.0 * std::max(groups[g].max_instr, 25u) / 100.0), 0});
                 const bool both_septic = forked && r > 0 && macro_n[2] && macro_n[3] && (uint64_t)total_blocks * 3 <= ZC_SMALL_ROUND_WGS;
                 for (int kind = 1; kind <= 3; kind++) {
                     if (!macro_n[kind] || (both_septic && kind == 2)) continue;
