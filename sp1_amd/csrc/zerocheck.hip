@@ -482,6 +482,7 @@ constexpr uint32_t ZC_DESC_MACRO = 2u;
 // the small rounds every launch is at its latency floor and the two septic launches would share a hardware queue (a process has four)
 constexpr uint32_t ZC_MACRO_BOTH_SEPTIC = 4u;
 constexpr uint32_t ZC_MACRO_KINDS = 8;        // kinds 1..3, the launch shape 4, Keccak = 5, MulOperation products = 6, polynomial identities = 7
+constexpr uint32_t ZC_RANGE_CORNERS = ZC_MACRO_KINDS;   // (not a hint kind: the block range of zc_biv_corner_kernel in a bivariate plan)
 template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
                                                        uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base,
@@ -619,6 +620,60 @@ __global__ __launch_bounds__(256) void zc_biv_round_kernel(const ZcDesc* __restr
             const uint32_t k = threadIdx.x;
             partial[((size_t)bid * ZC_BIV_NODES + 4 * grp + n) * 8 + k] = kb::add(kb::add(red[k], red[8 + k]), kb::add(red[16 + k], red[24 + k]));
         }
+    }
+}
+
+// The GKR batching term's corner sums of the bivariate rounds: B_n = sum_q eq(q) sum_c gkr_pow[c] * column c at row 4 q + n.
+// Until round 6 the first chunk's node-group-0 workgroups of a chip walked ALL its columns for them, one after the other per lane:
+// for the 2,640-column Keccak chip 400,000 dependent instructions on 477 waves — 6.2 ms, the longest launch of a Keccak shard's
+// zerocheck by a factor of two, with the device idle around it. Here a workgroup takes 256 quads x ZC_CORNER_COLS columns:
+// blockIdx.x = block of the launch's range; d.aux0 / d.aux1 = the slice [c0, c1) of the chip's main-then-preprocessed columns.
+// Writes the B half of nodes 0..3 (what the interpreter's first chunk used to leave) and zeros everywhere else of its slots.
+constexpr uint32_t ZC_CORNER_COLS = 32;
+__global__ __launch_bounds__(256) void zc_biv_corner_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                            uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base) {
+    using K = KT<true>;
+    __shared__ uint32_t red[4 * 16];
+    const uint32_t bid = block_base + blockIdx.x;
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const uint32_t c0 = d.aux0, c1 = d.aux1;
+    const uint32_t quads = (d.rows + 3) / 4;
+    kb::Ext sb[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+    for (uint32_t base = (bid - d.block_start) * d.block_pairs; base < quads; base += d.n_blocks * d.block_pairs)
+    for (uint32_t i = base + threadIdx.x; i < min(base + d.block_pairs, quads); i += blockDim.x) {
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        kb::Ext vb[4] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero(), kb::ext_zero()};
+#pragma unroll 4
+        for (uint32_t c = c0; c < c1; c++) {
+            const kb::Ext pw = load_ext_aos(d.gkr_pows, c);
+            const uint32_t* tbl = c < d.main_w ? d.main : d.prep;
+            const uint32_t col = c < d.main_w ? c : c - d.main_w;
+#pragma unroll
+            for (uint32_t n = 0; n < 4; n++)
+                if (4 * i + n < d.rows) vb[n] = kb::ext_add(vb[n], K::scale(pw, K::load(tbl, col, d.rows, 4 * i + n)));
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) sb[n] = kb::ext_add(sb[n], kb::ext_mul(vb[n], e));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t w = zc_wave_sum(sb[n].c[k]);
+            if (lane == 0) red[wave * 16 + 4 * n + k] = w;
+        }
+    __syncthreads();
+    if (threadIdx.x < ZC_BIV_NODES * 8) {
+        const uint32_t node = threadIdx.x / 8, k = threadIdx.x % 8;
+        uint32_t v = 0;
+        if (node < 4 && k >= 4) {
+            const uint32_t j = 4 * node + (k - 4);
+            v = kb::add(kb::add(red[j], red[16 + j]), kb::add(red[32 + j], red[48 + j]));
+        }
+        partial[((size_t)bid * ZC_BIV_NODES + node) * 8 + k] = v;
     }
 }
 
@@ -2462,7 +2517,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<ZcChipRange> ranges;
         std::vector<int> desc_chip;
         std::vector<Group> groups;
-        uint32_t total_blocks = 0, macro_lo[ZC_MACRO_KINDS] = {}, macro_n[ZC_MACRO_KINDS] = {};
+        uint32_t total_blocks = 0, macro_lo[ZC_MACRO_KINDS + 1] = {}, macro_n[ZC_MACRO_KINDS + 1] = {};
         std::vector<ZcFixDesc> fds;
         std::vector<uint32_t*> fresh;
         std::vector<std::pair<int, bool>> owner;
@@ -2485,6 +2540,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<int>& desc_chip = rp.desc_chip;
         std::vector<Group>& groups = rp.groups;
         static const bool mono_enabled = [] { const char* e = getenv("SP1HIP_ZC_MONO"); return !(e && e[0] == '0'); }();
+        // SP1HIP_ZC_BIV_CORNERS=inline: the corner sums inside the interpreter's first chunk, as in rounds 4-5 (A/B runs; same bytes)
+        static const bool corner_kernel = [] { const char* e = getenv("SP1HIP_ZC_BIV_CORNERS"); return !(e && e[0] == 'i'); }();
         std::vector<char> use_mono(n_chips, 0);
         for (int i = 0; i < n_chips; i++) {
             ChipState& c = *st[i];
@@ -2563,7 +2620,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     d.main = vmain[i]; d.prep = vprep[i]; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
                     d.rows = (uint32_t)vrows[i]; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
                     d.block_start = total_blocks; d.n_blocks = blocks;
-                    d.alpha_off = cks[q].alpha_off; d.flags = q == 0 ? 1u : 0u;
+                    d.alpha_off = cks[q].alpha_off; d.flags = (q == 0 && !(biv && corner_kernel)) ? 1u : 0u;
                     d.block_pairs = bp;
                     total_blocks += blocks;
                     descs.push_back(d);
@@ -2576,8 +2633,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         }
         // the fused pieces of hinted sub-AIRs: one launch per kind (each kind is its own kernel with its own register budget),
         // one block range — and one reduction range — per (kind, chip)
-        uint32_t (&macro_lo)[ZC_MACRO_KINDS] = rp.macro_lo;
-        uint32_t (&macro_n)[ZC_MACRO_KINDS] = rp.macro_n;
+        uint32_t (&macro_lo)[ZC_MACRO_KINDS + 1] = rp.macro_lo;
+        uint32_t (&macro_n)[ZC_MACRO_KINDS + 1] = rp.macro_n;
         for (uint32_t kind = ZC_HINT_POSEIDON2; kind < ZC_MACRO_KINDS; kind++) {
             if (kind == ZC_MACRO_BOTH_SEPTIC) continue;                   // (a launch shape, not a hint kind)
             macro_lo[kind] = total_blocks;
@@ -2607,6 +2664,30 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
             }
             macro_n[kind] = total_blocks - macro_lo[kind];
         }
+        // the bivariate rounds' GKR corner sums (zc_biv_corner_kernel): per chip, slices of ZC_CORNER_COLS columns x blocks of 256 quads,
+        // one reduction range per chip
+        macro_lo[ZC_RANGE_CORNERS] = total_blocks;
+        if (biv && corner_kernel)
+            for (int i = 0; i < n_chips; i++) {
+                ChipState& c = *st[i];
+                if (vrows[i] == 0) continue;
+                const uint32_t quads = (uint32_t)((vrows[i] + 3) / 4), width = c.in->main_width + c.in->prep_width;
+                const uint32_t blocks = std::min<uint32_t>((quads + 255) / 256, 512u);
+                ZcChipRange rg{total_blocks, 0, (uint32_t)(vrows[i] / 4), 0};
+                for (uint32_t c0 = 0; c0 < width; c0 += ZC_CORNER_COLS) {
+                    ZcDesc d{};
+                    d.main = vmain[i]; d.prep = vprep[i]; d.main_w = c.in->main_width; d.prep_w = c.in->prep_width;
+                    d.rows = (uint32_t)vrows[i]; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
+                    d.block_start = total_blocks; d.n_blocks = blocks;
+                    d.flags = ZC_DESC_MACRO | (ZC_RANGE_CORNERS << 12);
+                    d.block_pairs = 256; d.aux0 = c0; d.aux1 = std::min(width, c0 + ZC_CORNER_COLS);
+                    total_blocks += blocks;
+                    descs.push_back(d);
+                }
+                rg.n_blocks = total_blocks - rg.block_start;
+                if (rg.n_blocks) { ranges.push_back(rg); desc_chip.push_back(i); }
+            }
+        macro_n[ZC_RANGE_CORNERS] = total_blocks - macro_lo[ZC_RANGE_CORNERS];
         // the table update that ends this round needs nothing from the transcript but alpha (a kernel argument): plan
         // it now, so that every descriptor of the round goes up in ONE copy
         std::vector<ZcFixDesc>& fds = rp.fds;
@@ -2745,16 +2826,23 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     hipLaunchKernelGGL((zc_biv_macro_kernel<KIND>), dim3(rp.macro_n[KIND] * (uint32_t)ZC_BIV_NODES), dim3(256), 0, stream_of(SLOT), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[KIND], dctx->d_rc); \
                     SP1HIP_LAUNCH_CHECK();                                                                                             \
                 }
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 3)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 3)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(6u, 1)
-                if (rp.macro_n[ZC_HINT_POLY]) {            // all twelve nodes per workgroup
-                    hipLaunchKernelGGL(zc_biv_poly_kernel, dim3(rp.macro_n[ZC_HINT_POLY]), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_POLY]);
-                    SP1HIP_LAUNCH_CHECK();
-                }
+                // the second stream: the long fused launches, longest first (a Keccak shard's pieces 3.0 ms, the MulOperation pieces of a
+                // fibonacci shard 2.7 ms, Poseidon2 1.0 ms where the Global chip is tall); the short ones — septic pieces, the GKR corner
+                // sums, the polynomial identities — go behind the interpreter groups of the third
                 if (rp.macro_n[ZC_HINT_KECCAK]) {          // four nodes per pass: three node-group workgroups per block
                     hipLaunchKernelGGL(zc_biv_keccak_kernel, dim3(rp.macro_n[ZC_HINT_KECCAK] * ZC_BIV_GROUPS), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_KECCAK]);
+                    SP1HIP_LAUNCH_CHECK();
+                }
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(6u, 1)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 2)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 2)
+                if (rp.macro_n[ZC_RANGE_CORNERS]) {         // the GKR corner sums: columns in slices
+                    hipLaunchKernelGGL(zc_biv_corner_kernel, dim3(rp.macro_n[ZC_RANGE_CORNERS]), dim3(256), 0, stream_of(2), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_RANGE_CORNERS]);
+                    SP1HIP_LAUNCH_CHECK();
+                }
+                if (rp.macro_n[ZC_HINT_POLY]) {            // all twelve nodes per workgroup
+                    hipLaunchKernelGGL(zc_biv_poly_kernel, dim3(rp.macro_n[ZC_HINT_POLY]), dim3(256), 0, stream_of(2), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_POLY]);
                     SP1HIP_LAUNCH_CHECK();
                 }
 #undef SP1HIP_ZC_BIV_MACRO_LAUNCH
@@ -2884,8 +2972,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<int>& desc_chip = rp.desc_chip;
         std::vector<Group>& groups = rp.groups;
         const uint32_t total_blocks = rp.total_blocks;
-        uint32_t (&macro_lo)[ZC_MACRO_KINDS] = rp.macro_lo;
-        uint32_t (&macro_n)[ZC_MACRO_KINDS] = rp.macro_n;
+        uint32_t (&macro_lo)[ZC_MACRO_KINDS + 1] = rp.macro_lo;
+        uint32_t (&macro_n)[ZC_MACRO_KINDS + 1] = rp.macro_n;
         std::vector<ZcFixDesc>& fds = rp.fds;
         std::vector<uint32_t*>& fresh = rp.fresh;
         std::vector<std::pair<int, bool>>& owner = rp.owner;
