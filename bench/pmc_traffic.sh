@@ -44,7 +44,7 @@ write_scale = cal_bytes / (w[cal] * 1024.0)          # expected 1.0
 groups = {   # bench.py's kernel names -> substrings of the HIP kernel names
     "leaf_hash": ["leaf_hash_part_kernel", "leaf_hash_kernel"],
     "rs_encode": ["ntt_fast_pass"],
-    "zerocheck_round": ["zc_round_kernel", "zc_macro_kernel", "zc_biv_round_kernel", "zc_biv_macro_kernel", "zc_biv_keccak_kernel"],
+    "zerocheck_round": ["zc_round_kernel", "zc_macro_kernel", "zc_biv_round_kernel", "zc_biv_macro_kernel", "zc_biv_keccak_kernel", "zc_biv_corner_kernel", "zc_poly_kernel", "zc_biv_poly_kernel", "zc_keccak3_kernel"],
     "zerocheck_fix": ["zc_fix_kernel", "zc_fix2_kernel"],
     "gkr_pass": ["gkr_pass"],
     "compress": ["compress_layer", "compress_top"],
