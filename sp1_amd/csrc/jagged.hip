@@ -1124,10 +1124,21 @@ int sp1hip_jagged_prove(const sp1hip_ext_t* h_z_row, int max_log_row_count, sp1h
                 for (size_t t = 0; t < d->row_counts.size(); t++) {
                     const uint32_t h = (uint32_t)d->row_counts[t], w = (uint32_t)d->column_counts[t];
                     if (t < n_real && h && w) {
-                        tabs0.push_back(JgTab{(const uint32_t*)d->d_dense + off, h, col, w, n_tiles0, (uint32_t)(seg_start + off), n_tiles1, n_tiles2});
-                        n_tiles0 += (h / 2 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
-                        n_tiles1 += ((h + 3) / 4 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
-                        n_tiles2 += ((h + 7) / 8 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
+                        // a lane of the table-major kernels owns a few rows of a table and walks its columns one after the other, so a
+                        // wide, short table is a few waves with a long dependent loop: the 2,640 columns x 122k rows of a Keccak shard
+                        // made jg_fold_tables<2> one 3.3 ms launch on 60 workgroups (0.7 ms on a core shard of the same area). Every
+                        // quantity is a sum over columns, so a table enters as slices of at most `col_slice` columns — descriptors of
+                        // their own, the kernels see narrower tables. SP1HIP_JAGGED_COL_SLICE=0: whole tables (A/B; same bytes).
+                        static const uint32_t col_slice = [] { const char* e2 = getenv("SP1HIP_JAGGED_COL_SLICE"); return e2 ? (uint32_t)strtoul(e2, nullptr, 10) : 64u; }();
+                        const uint32_t step = col_slice ? col_slice : w;
+                        for (uint32_t c_lo = 0; c_lo < w; c_lo += step) {
+                            const uint32_t wc = std::min(step, w - c_lo);
+                            const uint64_t o = off + (uint64_t)c_lo * h;
+                            tabs0.push_back(JgTab{(const uint32_t*)d->d_dense + o, h, col + c_lo, wc, n_tiles0, (uint32_t)(seg_start + o), n_tiles1, n_tiles2});
+                            n_tiles0 += (h / 2 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
+                            n_tiles1 += ((h + 3) / 4 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
+                            n_tiles2 += ((h + 7) / 8 + JG_TAB_PAIRS - 1) / JG_TAB_PAIRS;
+                        }
                     }
                     if (t == n_real) zero_tails.push_back({seg_start + off, seg_start + d->padded});
                     off += (uint64_t)h * w;
