@@ -482,6 +482,7 @@ constexpr uint32_t ZC_DESC_MACRO = 2u;
 // the small rounds every launch is at its latency floor and the two septic launches would share a hardware queue (a process has four)
 constexpr uint32_t ZC_MACRO_BOTH_SEPTIC = 4u;
 constexpr uint32_t ZC_MACRO_KINDS = 8;        // kinds 1..3, the launch shape 4, Keccak = 5, MulOperation products = 6, polynomial identities = 7
+constexpr uint32_t ZC_POLY_WAVE_MAX_TERMS = 16384;   // row pairs of the tallest chip with polynomial identities below which a round runs them one wave per pair
 constexpr uint32_t ZC_RANGE_CORNERS = ZC_MACRO_KINDS;   // (not a hint kind: the block range of zc_biv_corner_kernel in a bivariate plan)
 template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
@@ -841,6 +842,103 @@ __global__ __launch_bounds__(256) void zc_poly_kernel(const ZcDesc* __restrict__
         const uint32_t k = threadIdx.x;
         uint32_t acc = red[k];
         for (uint32_t w = 1; w < blockDim.x / 64; w++) acc = kb::add(acc, red[w * 24 + k]);
+        partial[((size_t)bid * 3 + k / 8) * 8 + (k & 7u)] = acc;
+    }
+}
+
+// The same in the SMALL extension rounds, one WAVE per row pair: a lane of zc_poly_kernel walks every entry of every form of its
+// pair — ~350 dependent load-multiply steps for a 48-limb field operation —, and once a round has only a few thousand pairs that
+// walk is the round: 400 us per round whatever its size, 6.5 ms of a bls12-381 Fp shard's 23.8 ms of zerocheck. Here the 64 lanes
+// of a wave take the entries of a form 64 at a time and the form is a wave sum; workgroup = 4 pairs (d.block_pairs = 4).
+__global__ __launch_bounds__(256) void zc_poly_wave_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
+                                                           uint32_t eq_len, uint32_t* __restrict__ partial, uint32_t block_base) {
+    using K = KT<false>;
+    __shared__ uint32_t red[4 * 24];
+    const uint32_t bid = block_base + blockIdx.x;
+    const ZcDesc d = zc_find_desc(descs, n_descs, bid);
+    const ZcPolyTable tab{(zc_const_words_t)(uintptr_t)d.prog};
+    const zc_global_words_t tg = (zc_global_words_t)d.prog;           // (entries are read per lane)
+    const zc_global_words_t gp = (zc_global_words_t)d.gkr_pows;
+    const uint32_t n_terms = tab.word(0), n_rest = tab.word(1), n_owned = tab.word(2);
+    const uint32_t terms = (d.rows + 1) / 2;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    kb::Ext sa[3] = {kb::ext_zero(), kb::ext_zero(), kb::ext_zero()}, sb[2] = {kb::ext_zero(), kb::ext_zero()};
+    auto wsum = [&](kb::Ext& v) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v.c[k] = zc_wave_sum(v.c[k]);
+    };
+    for (uint32_t i = (bid - d.block_start) * 4 + wave; i < terms; i += d.n_blocks * 4) {     // (wave-uniform)
+        kb::Ext e;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e.c[k] = eq[(size_t)k * eq_len + i];
+        const bool has1 = 2 * i + 1 < d.rows;
+        uint32_t off = ZC_POLY_HDR;
+        // one affine form on the two rows: `n` entries behind an optional constant entry; with_gkr: the owned columns' batching term too
+        auto form = [&](uint32_t n, bool with_const, kb::Ext& f0, kb::Ext& f1, kb::Ext* g0, kb::Ext* g1) {
+            const uint32_t first = off + (with_const ? ZC_POLY_ENTRY : 0u);
+            kb::Ext p0 = kb::ext_zero(), p1 = kb::ext_zero(), q0 = kb::ext_zero(), q1 = kb::ext_zero();
+            for (uint32_t k = lane; k < n; k += 64) {
+                const uint32_t o = first + ZC_POLY_ENTRY * k;
+                const uint32_t col = tg[o];
+                const kb::Ext c{{tg[o + 4], tg[o + 5], tg[o + 6], tg[o + 7]}};
+                const kb::Ext x0 = K::load(d.main, col, d.rows, 2 * i);
+                const kb::Ext x1 = has1 ? K::load(d.main, col, d.rows, 2 * i + 1) : kb::ext_zero();
+                p0 = kb::ext_add(p0, kb::ext_mul(x0, c));
+                p1 = kb::ext_add(p1, kb::ext_mul(x1, c));
+                if (g0) {
+                    const kb::Ext w{{gp[4 * col], gp[4 * col + 1], gp[4 * col + 2], gp[4 * col + 3]}};
+                    q0 = kb::ext_add(q0, kb::ext_mul(x0, w));
+                    q1 = kb::ext_add(q1, kb::ext_mul(x1, w));
+                }
+            }
+            wsum(p0); wsum(p1);
+            if (with_const) { const kb::Ext c0 = tab.coef(off); p0 = kb::ext_add(p0, c0); p1 = kb::ext_add(p1, c0); }
+            f0 = p0; f1 = p1;
+            if (g0) { wsum(q0); wsum(q1); *g0 = q0; *g1 = q1; }
+            off = first + ZC_POLY_ENTRY * n;
+        };
+        kb::Ext v0 = kb::ext_zero(), v2 = kb::ext_zero(), v4 = kb::ext_zero();
+        for (uint32_t t = 0; t < n_terms; t++) {
+            kb::Ext a0, a1, b0, b1;
+            form(tab.word(4 + 3 * t), true, a0, a1, nullptr, nullptr);
+            form(tab.word(5 + 3 * t), true, b0, b1, nullptr, nullptr);
+            a0 = kb::ext_mul(a0, e); a1 = kb::ext_mul(a1, e);
+            const kb::Ext da = kb::ext_sub(a1, a0), db = kb::ext_sub(b1, b0);
+            const kb::Ext da2 = kb::ext_add(da, da), db2 = kb::ext_add(db, db);
+            const kb::Ext a2 = kb::ext_add(a0, da2), b2 = kb::ext_add(b0, db2);
+            kb::Ext p0 = kb::ext_mul(a0, b0), p2 = kb::ext_mul(a2, b2), p4 = kb::ext_mul(kb::ext_add(a2, da2), kb::ext_add(b2, db2));
+            const uint32_t n2 = tab.word(6 + 3 * t);
+            if (n2 != ZC_POLY_NONE) {
+                kb::Ext c0, c1;
+                form(n2, true, c0, c1, nullptr, nullptr);
+                const kb::Ext dc = kb::ext_sub(c1, c0), dc2 = kb::ext_add(dc, dc), c2 = kb::ext_add(c0, dc2);
+                p0 = kb::ext_mul(p0, c0); p2 = kb::ext_mul(p2, c2); p4 = kb::ext_mul(p4, kb::ext_add(c2, dc2));
+            }
+            v0 = kb::ext_add(v0, p0); v2 = kb::ext_add(v2, p2); v4 = kb::ext_add(v4, p4);
+        }
+        kb::Ext r0, r1, o0, o1, g0, g1;
+        form(n_rest, true, r0, r1, nullptr, nullptr);
+        form(n_owned, false, o0, o1, &g0, &g1);
+        r0 = kb::ext_mul(kb::ext_add(r0, o0), e); r1 = kb::ext_mul(kb::ext_add(r1, o1), e);
+        const kb::Ext dr = kb::ext_sub(r1, r0), dr2 = kb::ext_add(dr, dr), r2 = kb::ext_add(r0, dr2);
+        sa[0] = kb::ext_add(sa[0], kb::ext_add(v0, r0));
+        sa[1] = kb::ext_add(sa[1], kb::ext_add(v2, r2));
+        sa[2] = kb::ext_add(sa[2], kb::ext_add(v4, kb::ext_add(r2, dr2)));
+        g0 = kb::ext_mul(g0, e); g1 = kb::ext_mul(g1, e);
+        const kb::Ext dg = kb::ext_sub(g1, g0);
+        sb[0] = kb::ext_add(sb[0], g0);
+        sb[1] = kb::ext_add(sb[1], kb::ext_add(g0, kb::ext_add(dg, dg)));
+    }
+    if (lane == 0) {                                                   // (every lane of a wave holds the same sums)
+#pragma unroll
+        for (int pass = 0; pass < 3; pass++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { red[wave * 24 + pass * 8 + k] = sa[pass].c[k]; red[wave * 24 + pass * 8 + 4 + k] = pass < 2 ? sb[pass].c[k] : 0u; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        const uint32_t k = threadIdx.x;
+        const uint32_t acc = kb::add(kb::add(red[k], red[24 + k]), kb::add(red[48 + k], red[72 + k]));
         partial[((size_t)bid * 3 + k / 8) * 8 + (k & 7u)] = acc;
     }
 }
@@ -2518,6 +2616,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         std::vector<int> desc_chip;
         std::vector<Group> groups;
         uint32_t total_blocks = 0, macro_lo[ZC_MACRO_KINDS + 1] = {}, macro_n[ZC_MACRO_KINDS + 1] = {};
+        bool poly_wave = false;                             // the polynomial identities run one wave per row pair this round (zc_poly_wave_kernel)
         std::vector<ZcFixDesc> fds;
         std::vector<uint32_t*> fresh;
         std::vector<std::pair<int, bool>> owner;
@@ -2635,6 +2734,15 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
         // one block range — and one reduction range — per (kind, chip)
         uint32_t (&macro_lo)[ZC_MACRO_KINDS + 1] = rp.macro_lo;
         uint32_t (&macro_n)[ZC_MACRO_KINDS + 1] = rp.macro_n;
+        // the polynomial identities: one lane per row pair while the round is large, one wave per pair once the tallest chip that has
+        // them is down to ZC_POLY_WAVE_MAX_TERMS pairs (SP1HIP_ZC_POLY_WAVE=0: always the former; same bytes)
+        {
+            static const bool wave_on = [] { const char* e = getenv("SP1HIP_ZC_POLY_WAVE"); return !(e && e[0] == '0'); }();
+            uint64_t max_terms = 0;
+            for (int i = 0; i < n_chips; i++)
+                for (const ZcMacro& m : st[i]->macros) if (m.kind == ZC_HINT_POLY && vrows[i]) max_terms = std::max<uint64_t>(max_terms, (vrows[i] + unit - 1) / unit);
+            rp.poly_wave = wave_on && !biv && r > 0 && max_terms > 0 && max_terms <= ZC_POLY_WAVE_MAX_TERMS;
+        }
         for (uint32_t kind = ZC_HINT_POSEIDON2; kind < ZC_MACRO_KINDS; kind++) {
             if (kind == ZC_MACRO_BOTH_SEPTIC) continue;                   // (a launch shape, not a hint kind)
             macro_lo[kind] = total_blocks;
@@ -2642,7 +2750,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 ChipState& c = *st[i];
                 if (vrows[i] == 0) continue;
                 const uint32_t terms = (uint32_t)((vrows[i] + unit - 1) / unit);
-                const uint32_t blocks = std::min<uint32_t>((terms + 255) / 256, 512u);
+                const bool wave_form = kind == ZC_HINT_POLY && rp.poly_wave;
+                const uint32_t blocks = wave_form ? std::min<uint32_t>((terms + 3) / 4, 1024u) : std::min<uint32_t>((terms + 255) / 256, 512u);
                 ZcChipRange rg{total_blocks, 0, biv ? (uint32_t)(vrows[i] / 4) : terms - 1, 0};
                 for (size_t mi = 0; mi < c.macros.size(); mi++) {
                     const ZcMacro& m = c.macros[mi];
@@ -2654,7 +2763,7 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                         d.rows = (uint32_t)vrows[i]; d.alpha_pows = c.p_alpha; d.gkr_pows = c.p_gkr;
                         d.block_start = total_blocks; d.n_blocks = blocks;
                         d.alpha_off = m.first_constraint; d.flags = ZC_DESC_MACRO | (q << 8) | (m.kind << 12);
-                        d.block_pairs = 256; d.pad = m.base_col; d.aux0 = m.aux0; d.aux1 = m.aux1;
+                        d.block_pairs = wave_form ? 4 : 256; d.pad = m.base_col; d.aux0 = m.aux0; d.aux1 = m.aux1;
                             total_blocks += blocks;
                         descs.push_back(d);
                     }
@@ -2827,24 +2936,26 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     SP1HIP_LAUNCH_CHECK();                                                                                             \
                 }
                 // the second stream: the long fused launches, longest first (a Keccak shard's pieces 3.0 ms, the MulOperation pieces of a
-                // fibonacci shard 2.7 ms, Poseidon2 1.0 ms where the Global chip is tall); the short ones — septic pieces, the GKR corner
-                // sums, the polynomial identities — go behind the interpreter groups of the third
+                // fibonacci shard 2.7 ms, Poseidon2 1.0-6.0 ms where the Global chip is tall). The third: the SHORT launches FIRST — the
+                // GKR corner sums, the polynomial identities (59 workgroups of long loops on a bls12-381 shard), the septic curve pieces —
+                // so that they run under the long ones, and the septic sum pieces (6.6 ms on a shard with 1.7 million Global rows) last:
+                // behind them the short launches were a 1.4 ms tail with the device nearly idle
                 if (rp.macro_n[ZC_HINT_KECCAK]) {          // four nodes per pass: three node-group workgroups per block
                     hipLaunchKernelGGL(zc_biv_keccak_kernel, dim3(rp.macro_n[ZC_HINT_KECCAK] * ZC_BIV_GROUPS), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_KECCAK]);
                     SP1HIP_LAUNCH_CHECK();
                 }
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(6u, 1)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 2)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 2)
-                if (rp.macro_n[ZC_RANGE_CORNERS]) {         // the GKR corner sums: columns in slices
-                    hipLaunchKernelGGL(zc_biv_corner_kernel, dim3(rp.macro_n[ZC_RANGE_CORNERS]), dim3(256), 0, stream_of(2), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_RANGE_CORNERS]);
-                    SP1HIP_LAUNCH_CHECK();
-                }
                 if (rp.macro_n[ZC_HINT_POLY]) {            // all twelve nodes per workgroup
                     hipLaunchKernelGGL(zc_biv_poly_kernel, dim3(rp.macro_n[ZC_HINT_POLY]), dim3(256), 0, stream_of(2), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_POLY]);
                     SP1HIP_LAUNCH_CHECK();
                 }
+                if (rp.macro_n[ZC_RANGE_CORNERS]) {         // the GKR corner sums: columns in slices
+                    hipLaunchKernelGGL(zc_biv_corner_kernel, dim3(rp.macro_n[ZC_RANGE_CORNERS]), dim3(256), 0, stream_of(2), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_RANGE_CORNERS]);
+                    SP1HIP_LAUNCH_CHECK();
+                }
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 2)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 2)
 #undef SP1HIP_ZC_BIV_MACRO_LAUNCH
                 if (forked)
                     for (int k = 0; k < N_FORK; k++)
@@ -3074,7 +3185,8 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                 SP1HIP_ZC_MACRO_LAUNCH(3u)
                 SP1HIP_ZC_MACRO_LAUNCH(6u)
                 if (ln.kind == (int)ZC_HINT_POLY) {       // the three nodes per workgroup
-                    if (r == 0) hipLaunchKernelGGL(zc_poly_kernel<true>, dim3(macro_n[ZC_HINT_POLY]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[ZC_HINT_POLY]);
+                    if (rp.poly_wave) hipLaunchKernelGGL(zc_poly_wave_kernel, dim3(macro_n[ZC_HINT_POLY]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[ZC_HINT_POLY]);
+                    else if (r == 0) hipLaunchKernelGGL(zc_poly_kernel<true>, dim3(macro_n[ZC_HINT_POLY]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[ZC_HINT_POLY]);
                     else hipLaunchKernelGGL(zc_poly_kernel<false>, dim3(macro_n[ZC_HINT_POLY]), dim3(256), 0, ls, dd, n_descs, d_eq.u32(), eq_len, d_partial.u32(), macro_lo[ZC_HINT_POLY]);
                     SP1HIP_LAUNCH_CHECK();
                 }
