@@ -482,7 +482,7 @@ constexpr uint32_t ZC_DESC_MACRO = 2u;
 // the small rounds every launch is at its latency floor and the two septic launches would share a hardware queue (a process has four)
 constexpr uint32_t ZC_MACRO_BOTH_SEPTIC = 4u;
 constexpr uint32_t ZC_MACRO_KINDS = 8;        // kinds 1..3, the launch shape 4, Keccak = 5, MulOperation products = 6, polynomial identities = 7
-constexpr uint32_t ZC_POLY_WAVE_MAX_TERMS = 16384;   // row pairs of the tallest chip with polynomial identities below which a round runs them one wave per pair
+constexpr uint32_t ZC_POLY_WAVE_MAX_TERMS = 4096;    // row pairs of the tallest chip with polynomial identities below which a round runs them one wave per pair
 constexpr uint32_t ZC_RANGE_CORNERS = ZC_MACRO_KINDS;   // (not a hint kind: the block range of zc_biv_corner_kernel in a bivariate plan)
 template <bool FIRST, uint32_t KIND>
 __global__ __launch_bounds__(256) void zc_macro_kernel(const ZcDesc* __restrict__ descs, int n_descs, const uint32_t* __restrict__ eq,
@@ -2936,26 +2936,26 @@ static int zerocheck_prove_impl(const sp1hip_zc_chip_t* chips, int n_chips, int 
                     SP1HIP_LAUNCH_CHECK();                                                                                             \
                 }
                 // the second stream: the long fused launches, longest first (a Keccak shard's pieces 3.0 ms, the MulOperation pieces of a
-                // fibonacci shard 2.7 ms, Poseidon2 1.0-6.0 ms where the Global chip is tall). The third: the SHORT launches FIRST — the
-                // GKR corner sums, the polynomial identities (59 workgroups of long loops on a bls12-381 shard), the septic curve pieces —
-                // so that they run under the long ones, and the septic sum pieces (6.6 ms on a shard with 1.7 million Global rows) last:
-                // behind them the short launches were a 1.4 ms tail with the device nearly idle
+                // fibonacci shard 2.7 ms, Poseidon2 1.0-6.0 ms where the Global chip is tall), then the short ones (the polynomial
+                // identities, the GKR corner sums, the septic curve pieces); the third stream: behind its interpreter groups the septic
+                // sum pieces (6.6 ms on a shard with 1.7 million Global rows). On such a shard the short launches behind the septic sum
+                // were a 1.4 ms tail with the device nearly idle, and in front of it they delay the longest launch by as much.
                 if (rp.macro_n[ZC_HINT_KECCAK]) {          // four nodes per pass: three node-group workgroups per block
                     hipLaunchKernelGGL(zc_biv_keccak_kernel, dim3(rp.macro_n[ZC_HINT_KECCAK] * ZC_BIV_GROUPS), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_KECCAK]);
                     SP1HIP_LAUNCH_CHECK();
                 }
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 2)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(6u, 1)
                 SP1HIP_ZC_BIV_MACRO_LAUNCH(1u, 1)
                 if (rp.macro_n[ZC_HINT_POLY]) {            // all twelve nodes per workgroup
-                    hipLaunchKernelGGL(zc_biv_poly_kernel, dim3(rp.macro_n[ZC_HINT_POLY]), dim3(256), 0, stream_of(2), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_POLY]);
+                    hipLaunchKernelGGL(zc_biv_poly_kernel, dim3(rp.macro_n[ZC_HINT_POLY]), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_HINT_POLY]);
                     SP1HIP_LAUNCH_CHECK();
                 }
                 if (rp.macro_n[ZC_RANGE_CORNERS]) {         // the GKR corner sums: columns in slices
-                    hipLaunchKernelGGL(zc_biv_corner_kernel, dim3(rp.macro_n[ZC_RANGE_CORNERS]), dim3(256), 0, stream_of(2), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_RANGE_CORNERS]);
+                    hipLaunchKernelGGL(zc_biv_corner_kernel, dim3(rp.macro_n[ZC_RANGE_CORNERS]), dim3(256), 0, stream_of(1), dd, n_descs, d_eq, eq_len, d_partial.u32(), rp.macro_lo[ZC_RANGE_CORNERS]);
                     SP1HIP_LAUNCH_CHECK();
                 }
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 2)
-                SP1HIP_ZC_BIV_MACRO_LAUNCH(3u, 2)
+                SP1HIP_ZC_BIV_MACRO_LAUNCH(2u, 1)
 #undef SP1HIP_ZC_BIV_MACRO_LAUNCH
                 if (forked)
                     for (int k = 0; k < N_FORK; k++)
